@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json headline: RK4 trajectory-steps/s on 1e7 float64 IVPs per GPU, with the achieved
+HBM bandwidth of the step-streaming kernel against the 8 TB/s roofline.
+
+One bench "step" = one pass of the hot path over the batch: the fixed-step ODESolver loop
+(ode.nim:511-532) for config C2 — dy/dt = -y, N = 1e7 scalar float64 IVPs per GPU, dt = 2^-10,
+tspan = [0, 1000*dt] -> exactly 1000 RK4_step (ode.nim:180-189) launches of the step-streaming kernel,
+state resident in HBM between launches (16 algorithmic bytes per trajectory-step).
+Multi-GPU (weak scaling, config C5): every rank owns a contiguous shard of the global IVP index
+range; the only collective is one all-gather of the final states per solve (RCCL over xGMI).
+
+Usage: python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n-ivp", type=float, default=1e7, help="IVPs per GPU (config C2: 1e7)")
+    ap.add_argument("--rk4-steps", type=int, default=1000, help="RK4 time steps per solve (C2: 1000)")
+    ap.add_argument("--pingpong", type=int, default=0, help="1: ping-pong between two state buffers instead of in-place")
+    ap.add_argument("--no-gather", action="store_true", help="skip the final-state all-gather (N>1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=float, default=2e5, help="IVPs in the CPU-baseline sample")
+    ap.add_argument("--no-fused", action="store_true", help="skip the informational fused-solve measurement")
+    ap.add_argument("--no-check", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import numericalnim_amd as nn
+    from numericalnim_amd import distributed as nd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = int(args.n_ivp)
+    nsteps = int(args.rk4_steps)
+    dt = 2.0 ** -10
+    t_end = nsteps * dt  # exact in binary: t accumulates without rounding -> exactly nsteps launches
+    opt = nn.newODEoptions(dt=dt)
+    f = nn.Rhs.neg_y()
+    lo, hi = nd.shard_range(n * world, rank, world)
+    y0 = nd.c2_y0_torch(lo, hi, dev)
+    y = torch.empty_like(y0)
+    scratch = torch.empty_like(y0) if args.pingpong else None
+    gathered = torch.empty(n * world, dtype=torch.float64, device=dev) if (world > 1 and not args.no_gather) else None
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    gev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def one_solve(k=None):
+        y.copy_(y0)  # solveODE starts from y0 (y0.clone(), ode.nim:482)
+        if k is not None:
+            ev[k][0].record()
+        yf, ns = nn.fixedStream(f, y, 0.0, t_end, opt, integrator="rk4", scratch=scratch)
+        if k is not None:
+            ev[k][1].record()
+        assert ns == nsteps, (ns, nsteps)
+        if gathered is not None:
+            if k is not None:
+                gev[k][0].record()
+            dist.all_gather_into_tensor(gathered, yf)
+            if k is not None:
+                gev[k][1].record()
+        return yf
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_solve()
+    sync_all()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        yf = one_solve(k)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    total_traj_steps = float(n) * world * nsteps * args.steps
+    value = total_traj_steps / elapsed
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev)  # device time of the 1000*K step launches on this rank
+    launch_s = kern_ms * 1e-3 / (args.steps * nsteps)
+    algo_bytes = 16.0 * n  # 8 B read + 8 B written per trajectory-step, n trajectory-steps per launch
+    achieved = algo_bytes / launch_s / 1e9
+    gather_ms = (sum(a.elapsed_time(b) for a, b in gev) / args.steps) if gathered is not None else None
+
+    # ---- parity spot-check of the timed result against the oracle (fixed 4096-index subsample) -----------
+    check = None
+    if not args.no_check and rank == 0:
+        from oracle import oracle as O
+        idx = (np.arange(4096, dtype=np.int64) * 2441) % n
+        got = yf[torch.from_numpy(idx).to(dev)].cpu().numpy()
+        y0s = nd.c2_y0_numpy(lo, hi)[idx] if n <= 50_000_000 else (1.0 + ((idx + lo) % (1 << 20)) * 2.0 ** -20)
+        ref = O.solve_ode_batch(O.RHS_NEG_Y, [], y0s, len(idx), 0, [0.0, t_end], O.new_options(dt=dt), "rk4")
+        check = float(np.abs(got - ref["y"][-1, 0]).max())
+        assert check <= 1e-10, f"parity failure vs oracle: max abs err {check}"
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- PMC traffic from the committed profile of this same command, if present ------------------------
+    traffic = None
+    pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pj):
+        try:
+            traffic = json.load(open(pj)).get("rk4_stream", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "RK4 trajectory-steps/sec on 1e7 float64 IVPs",
+        "value": value,
+        "unit": "trajectory-steps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed * 1e3 / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "C2: RK4 fixed-step step-streaming, dy/dt=-y, %d scalar float64 IVPs per GPU x %d steps (dt=2^-10), "
+                        "one RK4_step kernel launch per time step, state in HBM between launches" % (n, nsteps),
+            "ivps_per_gpu": n, "rk4_steps": nsteps, "state_update": "pingpong" if args.pingpong else "in-place",
+            "final_state_allgather": bool(gathered is not None),
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+            "kernel": "rk4_stream_vec_kernel", "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": launch_s * 1e6,
+        },
+        "parity_max_abs_err_vs_oracle": check,
+    }
+    if gather_ms is not None:
+        out["allgather_ms_per_solve"] = gather_ms
+
+    # ---- informational: the fused whole-solve kernel (FP64-VALU bound; the HBM roofline does not apply) ----
+    if not args.no_fused:
+        for _ in range(2):
+            nn.solveODE(f, y0, [0.0, t_end], opt, integrator="rk4")
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        reps = 3
+        for _ in range(reps):
+            _, yfu = nn.solveODE(f, y0, [0.0, t_end], opt, integrator="rk4")
+        e1.record()
+        torch.cuda.synchronize()
+        fs = e0.elapsed_time(e1) * 1e-3 / reps
+        out["fused_solve"] = {"value": float(n) * nsteps / fs, "unit": "trajectory-steps/s", "ms_per_solve": fs * 1e3,
+                              "bound": "fp64-valu", "fp64_ops_per_s": 27.0 * n * nsteps / fs,
+                              "bitwise_equal_to_stream": bool(torch.equal(yfu[-1], yf))}
+
+    # ---- CPU baseline: the oracle (C++ restatement of the reference) on this box's host cores -------------
+    if not args.no_cpu_baseline and world == 1:
+        from oracle import oracle as O
+        ns = int(args.cpu_sample)
+        y0s = nd.c2_y0_numpy(0, ns)
+        oo = O.new_options(dt=dt)
+        O.solve_ode_batch(O.RHS_NEG_Y, [], y0s[:1000], 1000, 0, [0.0, t_end], oo, "rk4")  # warm
+        c0 = time.perf_counter()
+        O.solve_ode_batch(O.RHS_NEG_Y, [], y0s, ns, 0, [0.0, t_end], oo, "rk4", n_threads=1)
+        c1 = time.perf_counter()
+        ncores = os.cpu_count() or 1
+        O.solve_ode_batch(O.RHS_NEG_Y, [], y0s, ns, 0, [0.0, t_end], oo, "rk4", n_threads=ncores)
+        c2 = time.perf_counter()
+        out["cpu_baseline"] = {
+            "value": ns * nsteps / (c1 - c0), "unit": "trajectory-steps/s", "cores": 1, "kind": "port",
+            "sample": "first %d IVPs of the C2 batch x %d RK4 steps through the oracle's solveODE (closure-style RHS call), "
+                      "1 thread = the single-threaded reference; IVPs are independent so the rate extrapolates linearly" % (ns, nsteps),
+            "all_cores": {"value": ns * nsteps / (c2 - c1), "cores": ncores},
+        }
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

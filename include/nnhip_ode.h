@@ -1,0 +1,174 @@
+/*
+ * nnhip_ode.h — C ABI of the MI355X-native batched ODE backend for numericalnim.
+ *
+ * This is the drop-in boundary for the reference's ODE hot path.  The reference (Nim, CPU, one IVP per
+ * call) has no FFI today; these are the entry points its Nim side would bind with {.importc, cdecl.}
+ * (see INTEGRATION.md for the Nim stub).  Each entry cites the reference interface it replaces,
+ * relative to /root/reference/src/numericalnim/.
+ *
+ * Conventions
+ *   - A *batch* is N independent IVPs that share (f, tspan, options, integrator); IVP i has its own y0.
+ *   - State arrays are float64.  dim = components per IVP; the scalar `float` state path of the
+ *     reference is dim = 1 (bit-identical arithmetic: ode.nim:45-55 makes size=1, sum=id).
+ *   - layout NNHIP_LAYOUT_SOA: y[c*N + i]              trajectories y_out[(j*dim + c)*N + i]
+ *     layout NNHIP_LAYOUT_AOS: y[i*dim + c]            trajectories y_out[(j*N + i)*dim + c]
+ *   - The user RHS closure f(t, y, ctx) (ODEProc[T], ode.nim:36) becomes (rhs_kind, rhs_params[]):
+ *     a compiled-in __device__ RHS selected by enum, parameters = ctx.fValues flattened.
+ *   - Every function returns NNHIP_OK (0) or a negative nnhip_status; nnhip_last_error() gives the
+ *     thread-local message.  Nim exceptions map as: ValueError -> NNHIP_EVALUE / NNHIP_EINTEGRATOR.
+ *   - "_dev" entry points take DEVICE pointers and a hipStream_t (as void*; NULL = default stream)
+ *     and are asynchronous.  The others take HOST pointers and return when the result is in them.
+ *   - The library owns no pointer after a call returns (plans excepted, until destroyed).
+ *   - There is NO CPU fallback: without a usable HIP device every compute entry fails with NNHIP_EHIP.
+ */
+#ifndef NNHIP_ODE_H
+#define NNHIP_ODE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NNHIP_ABI_VERSION 1
+
+typedef enum nnhip_status {
+  NNHIP_OK = 0,
+  NNHIP_EVALUE = -1,       /* ValueError: bad option / size / argument (ode.nim:95-100, utils.nim:26)        */
+  NNHIP_EINTEGRATOR = -2,  /* ValueError: "... is not a valid integrator" (ode.nim:651)                      */
+  NNHIP_EHIP = -3,         /* HIP runtime / device failure (incl. no device)                                 */
+  NNHIP_EUNSUPPORTED = -4, /* (integrator, rhs_kind, dim, layout) combination has no compiled kernel         */
+  NNHIP_ENOMEM = -5,
+} nnhip_status;
+
+/* ODEoptions, field for field (ode.nim:26-34). Build with nnhip_ode_new_options to get the reference's
+ * abs() normalisation and validation (ode.nim:78-102). scaleMax/scaleMin are stored but, as in the
+ * reference, never read by the controller (it hard-codes min(4, max(0.125, ...)), ode.nim:71,537). */
+typedef struct nnhip_ode_options {
+  double dt, dtMax, dtMin, tStart, absTol, relTol, scaleMax, scaleMin;
+} nnhip_ode_options;
+
+/* Integrator ids; names are the reference's strings (ode.nim:40-42, 607-649). */
+typedef enum nnhip_integrator {
+  NNHIP_RK4 = 0, NNHIP_DOPRI54 = 1, NNHIP_TSIT54 = 2, NNHIP_VERN65 = 3, NNHIP_BS32 = 4, NNHIP_RK21 = 5,
+  NNHIP_HEUN2 = 6, NNHIP_RALSTON2 = 7, NNHIP_KUTTA3 = 8, NNHIP_HEUN3 = 9, NNHIP_RALSTON3 = 10,
+  NNHIP_SSPRK3 = 11, NNHIP_RALSTON4 = 12, NNHIP_KUTTA4 = 13, NNHIP_N_INTEGRATORS = 14
+} nnhip_integrator;
+
+/* Compiled-in right-hand sides.  p[] = rhs_params.  Expressions are evaluated in exactly this order
+ * (no FMA contraction in the default build), so they are part of the numerical contract. */
+typedef enum nnhip_rhs_kind {
+  NNHIP_RHS_NEG_Y = 0,     /* any dim : dy_c = -y_c                                    (ode.nim:16-17)      */
+  NNHIP_RHS_LINEAR = 1,    /* any dim : dy_c = y_c * p0      (p0 = -0.1: tests/test_ode.nim:5-7)            */
+  NNHIP_RHS_LORENZ = 2,    /* dim 3   : dx = p0*(y-x); dy = x*(p1-z) - y; dz = x*y - p2*z                   */
+  NNHIP_RHS_RING = 3,      /* dim d   : dy_c = -((c+1)/d)*y_c + p0*y_{(c+1) mod d}                          */
+  NNHIP_RHS_AFFINE_T = 4,  /* any dim : dy_c = p0*y_c + p1*t                                                */
+  NNHIP_RHS_VANDERPOL = 5, /* dim 2   : dx = v; dv = p0*((1 - x*x)*v) - x                                   */
+  NNHIP_N_RHS = 6
+} nnhip_rhs_kind;
+
+typedef enum nnhip_layout { NNHIP_LAYOUT_SOA = 0, NNHIP_LAYOUT_AOS = 1 } nnhip_layout;
+
+/* Aggregate statistics of one batch solve (all optional outputs). */
+typedef struct nnhip_ode_stats {
+  int64_t steps_total;    /* accepted integrator calls summed over the batch (both directions)              */
+  int64_t rejected_total; /* in-step retries (ode.nim:58-76) summed over the batch                          */
+  int64_t steps_max;      /* max accepted steps of any single IVP                                           */
+  int32_t n_t_out;        /* entries written to t_out (= n_t unless tStart is duplicated in tspan)          */
+  int32_t ny_min;         /* min over IVPs of the number of y rows the reference would return               */
+  int32_t nan_aborts;     /* IVPs aborted because the error norm became NaN (reference would hang)          */
+  int32_t truncated;      /* IVPs stopped by max_steps                                                      */
+  double kernel_ms;       /* device time of the compute kernels (hipEvent), host-pointer entry points only  */
+} nnhip_ode_stats;
+
+/* ---- library / device ------------------------------------------------------------------------ */
+int nnhip_abi_version(void);
+int nnhip_device_count(void);            /* >=0, or NNHIP_EHIP                                              */
+const char* nnhip_last_error(void);      /* thread-local, never NULL                                        */
+const char* nnhip_build_info(void);      /* arch, fp-contract mode, compiler                                */
+
+/* ---- options / dispatch (host only, no device needed) ---------------------------------------- */
+/* newODEoptions (ode.nim:78-102): abs() of everything but tStart; NNHIP_EVALUE if |dtMax| < |dtMin|,
+ * |scaleMax| < 1 or 1 < |scaleMin|.  Argument order = the Nim proc's. */
+int nnhip_ode_new_options(nnhip_ode_options* out, double dt, double absTol, double relTol, double dtMax, double dtMin,
+                          double scaleMax, double scaleMin, double tStart);
+/* DEFAULT_ODEoptions (ode.nim:104): dt=1e-4 absTol=relTol=1e-4 dtMax=1e-2 dtMin=1e-4 scale 4/0.1 tStart=0 */
+int nnhip_ode_default_options(nnhip_ode_options* out);
+/* `case integrator.toLower()` (ode.nim:607-651): id, or NNHIP_EINTEGRATOR. */
+int nnhip_ode_integrator_id(const char* name);
+const char* nnhip_ode_integrator_name(int integrator);
+/* (useFSAL, order, adaptive) triple the dispatch passes to ODESolver (ode.nim:608-649). */
+int nnhip_ode_integrator_traits(int integrator, int* use_fsal, double* order, int* adaptive);
+/* Output time grid exactly as ODESolver assembles it (ode.nim:476-480, 585): tspan.sorted(), split
+ * around tStart, tNegative.reversed ++ tZero ++ tPositive.  t_out has room for n_t doubles. */
+int nnhip_ode_time_grid(const nnhip_ode_options* opt, const double* tspan, int n_t, double* t_out, int* n_t_out);
+/* Is there a compiled kernel for this combination?  1 / 0.  mode: 0 fused solve, 1 step-streaming. */
+int nnhip_ode_supported(int integrator, int rhs_kind, int dim, int layout, int mode);
+
+/* ---- fused batch solve: replaces solveODE -> ODESolver (ode.nim:589-651, 471-586) -------------
+ * One launch integrates every IVP from tStart across the whole (sorted) tspan, forward and backward
+ * branches, dense Hermite output included; state, stage vectors and (t, dt) stay on chip.
+ *   y0      [dim*N]        in `layout`
+ *   tspan   [n_t]          any order (sorted internally, like tspan.sorted())
+ *   t_out   [n_t]          (host) output grid; nullable
+ *   y_out   [n_t*dim*N]    row j = state at t_out[j]; rows >= ny_out[i] are NaN for IVP i
+ *   ny_out  [N] nullable   rows the reference would return for IVP i (it can drop requested times that
+ *                          fall strictly inside the final step)
+ *   steps_out / rejected_out [N] nullable per-IVP counters
+ *   max_steps              safety cap on integrator calls per IVP and direction; <= 0 = unlimited
+ * Host-pointer form; device = HIP device ordinal. */
+int nnhip_ode_solve_batch_f64(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
+                              int n_params, const double* y0, int64_t N, int dim, int layout, const double* tspan,
+                              int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
+                              int64_t* rejected_out, int64_t max_steps, nnhip_ode_stats* stats, int device);
+
+/* Device-pointer form (asynchronous on `stream`).  y0/y_out/ny_out/steps_out/rejected_out are device
+ * pointers on the current device; tspan/t_out stay host pointers (tiny, shared by the batch).
+ * `ws` is a device workspace of at least nnhip_ode_solve_workspace_bytes(n_t) bytes. */
+int64_t nnhip_ode_solve_workspace_bytes(int n_t);
+int nnhip_ode_solve_batch_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
+                                  int n_params, const double* y0, int64_t N, int dim, int layout, const double* tspan,
+                                  int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
+                                  int64_t* rejected_out, int64_t max_steps, void* ws, int64_t ws_bytes, void* stream);
+
+/* ---- step-streaming: replaces one IntegratorProc call (ode.nim:38, call sites :531,:573) ------
+ * (yNew, FSAL', dtUsed, error) = integrator(f, t, y, FSAL, dt, options, ctx) for every IVP of the batch,
+ * state resident in HBM between calls.  t/dt are per-IVP device arrays [N], or — when t_dev / dt_dev is
+ * NULL — the uniform host scalars t_uniform / dt_uniform (fixed-step methods: every IVP shares them).
+ * fsal_in/fsal_out may be NULL for non-FSAL methods; dt_used/error may be NULL for fixed-step methods
+ * (they return their input dt and 0.0).  In-place (y_out == y_in, fsal_out == fsal_in) is allowed.
+ * negate_time != 0 integrates g(t,y) = -f(-t,y) (backward branch, ode.nim:545). */
+int nnhip_ode_step_batch_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
+                                 int n_params, int64_t N, int dim, int layout, const double* t_dev, double t_uniform,
+                                 const double* dt_dev, double dt_uniform, const double* y_in, const double* fsal_in,
+                                 double* y_out, double* fsal_out, double* dt_used, double* error, int negate_time,
+                                 void* stream);
+
+/* Fixed-step time loop of ODESolver (ode.nim:511-542 with adaptive=false, tspan.len == 2) driven from
+ * the host over the step-streaming kernel: while t < tEnd: dt = min(dt, tEnd - t); step; t += dt.
+ * y (device, in `layout`) is advanced in place from t0 to tEnd; `scratch` (device, dim*N doubles,
+ * nullable) enables ping-pong instead of in-place.  Returns the number of steps via n_steps_out.
+ * Works for every fixed-step integrator; asynchronous on `stream`. */
+int nnhip_ode_fixed_stream_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
+                                   int n_params, int64_t N, int dim, int layout, double t0, double tEnd, double* y,
+                                   double* scratch, int64_t* n_steps_out, double** y_final, void* stream);
+
+/* ---- multi-GPU (one process, n_gpus devices): contiguous shards of the IVP index range, no exchange
+ * during integration, final trajectory tensor reassembled on every device's host view.  Host pointers. */
+int nnhip_ode_solve_batch_multi_gpu_f64(const nnhip_ode_options* opt, int integrator, int rhs_kind,
+                                        const double* rhs_params, int n_params, const double* y0, int64_t N, int dim,
+                                        int layout, const double* tspan, int n_t, double* t_out, double* y_out,
+                                        int32_t* ny_out, int64_t max_steps, nnhip_ode_stats* stats, int n_gpus);
+
+/* ---- consumers either side of the path ------------------------------------------------------- */
+/* hermiteSpline (utils.nim:273-279), batched on device: out[i] = H(x; x1, x2, y1[i], y2[i], dy1[i], dy2[i]) */
+int nnhip_hermite_spline_f64_dev(double x, double x1, double x2, const double* y1, const double* y2, const double* dy1,
+                                 const double* dy2, double* out, int64_t n, void* stream);
+/* RHS evaluation alone over a batch: dy = f(t, y) (pins the compiled-in RHS library). */
+int nnhip_ode_rhs_batch_f64_dev(int rhs_kind, const double* rhs_params, int n_params, int64_t N, int dim, int layout,
+                                double t, const double* y, double* dy, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NNHIP_ODE_H */

@@ -1,0 +1,75 @@
+"""ctypes binding of include/nnhip_ode.h.  Loading fails loudly if the HIP library is not built."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libnnhip_ode.so")
+
+NNHIP_OK, NNHIP_EVALUE, NNHIP_EINTEGRATOR, NNHIP_EHIP, NNHIP_EUNSUPPORTED, NNHIP_ENOMEM = 0, -1, -2, -3, -4, -5
+
+
+class Options(C.Structure):  # nnhip_ode_options == ODEoptions (ode.nim:26-34)
+    _fields_ = [(n, C.c_double) for n in ("dt", "dtMax", "dtMin", "tStart", "absTol", "relTol", "scaleMax", "scaleMin")]
+
+    def __repr__(self):
+        return "ODEoptions(" + ", ".join(f"{n}={getattr(self, n)!r}" for n, _ in self._fields_) + ")"
+
+
+class Stats(C.Structure):  # nnhip_ode_stats
+    _fields_ = [("steps_total", C.c_int64), ("rejected_total", C.c_int64), ("steps_max", C.c_int64), ("n_t_out", C.c_int32),
+                ("ny_min", C.c_int32), ("nan_aborts", C.c_int32), ("truncated", C.c_int32), ("kernel_ms", C.c_double)]
+
+
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); every function include/nnhip_ode.h declares
+SIGNATURES = {
+    "nnhip_abi_version": (C.c_int, []),
+    "nnhip_device_count": (C.c_int, []),
+    "nnhip_last_error": (C.c_char_p, []),
+    "nnhip_build_info": (C.c_char_p, []),
+    "nnhip_ode_new_options": (C.c_int, [C.POINTER(Options)] + [C.c_double] * 8),
+    "nnhip_ode_default_options": (C.c_int, [C.POINTER(Options)]),
+    "nnhip_ode_integrator_id": (C.c_int, [C.c_char_p]),
+    "nnhip_ode_integrator_name": (C.c_char_p, [C.c_int]),
+    "nnhip_ode_integrator_traits": (C.c_int, [C.c_int, C.POINTER(C.c_int), _dp, C.POINTER(C.c_int)]),
+    "nnhip_ode_time_grid": (C.c_int, [C.POINTER(Options), _dp, C.c_int, _dp, C.POINTER(C.c_int)]),
+    "nnhip_ode_supported": (C.c_int, [C.c_int] * 5),
+    "nnhip_ode_solve_batch_f64": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, _vp, C.c_int64, C.c_int, C.c_int,
+                                            _dp, C.c_int, _dp, _vp, _vp, _vp, _vp, C.c_int64, C.POINTER(Stats), C.c_int]),
+    "nnhip_ode_solve_workspace_bytes": (C.c_int64, [C.c_int]),
+    "nnhip_ode_solve_batch_f64_dev": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, _vp, C.c_int64, C.c_int,
+                                                C.c_int, _dp, C.c_int, _dp, _vp, _vp, _vp, _vp, C.c_int64, _vp, C.c_int64, _vp]),
+    "nnhip_ode_step_batch_f64_dev": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                               _vp, C.c_double, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    "nnhip_ode_fixed_stream_f64_dev": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                                 C.c_double, C.c_double, _vp, _vp, C.POINTER(C.c_int64), C.POINTER(_vp), _vp]),
+    "nnhip_ode_solve_batch_multi_gpu_f64": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, _vp, C.c_int64, C.c_int,
+                                                      C.c_int, _dp, C.c_int, _dp, _vp, _vp, C.c_int64, C.POINTER(Stats), C.c_int]),
+    "nnhip_hermite_spline_f64_dev": (C.c_int, [C.c_double] * 3 + [_vp] * 5 + [C.c_int64, _vp]),
+    "nnhip_ode_rhs_batch_f64_dev": (C.c_int, [C.c_int, _dp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_double, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library.  Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise ImportError(
+                f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C numericalnim_amd/csrc`). numericalnim_amd has no CPU fallback.")
+        h = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def last_error():
+    return lib().nnhip_last_error().decode()

@@ -1,0 +1,414 @@
+// ode_capi.hip — the extern "C" boundary (include/nnhip_ode.h): option handling, time-grid assembly,
+// dispatch and the host-side loops of the ODE backend.  No CPU compute fallback exists here: every
+// compute entry needs a HIP device and fails with NNHIP_EHIP otherwise.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "ode_kernels.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t _e = (expr);                                                                             \
+    if (_e != hipSuccess) return fail(NNHIP_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                      __FILE__, __LINE__);                                              \
+  } while (0)
+
+struct MethodInfo {
+  const char* name;
+  int useFSAL;
+  double order;
+  int adaptive;
+  int implemented;
+};
+// solveODE's dispatch (ode.nim:607-649), indexed by nnhip_integrator
+const MethodInfo kMethods[NNHIP_N_INTEGRATORS] = {
+    {"rk4", 0, 4.0, 0, 1},      {"dopri54", 1, 5.0, 1, 1},  {"tsit54", 1, 5.0, 1, 1},   {"vern65", 1, 6.0, 1, 0},
+    {"bs32", 1, 3.0, 1, 0},     {"rk21", 0, 2.0, 1, 0},     {"heun2", 0, 2.0, 0, 0},    {"ralston2", 0, 2.0, 0, 0},
+    {"kutta3", 0, 3.0, 0, 0},   {"heun3", 0, 3.0, 0, 0},    {"ralston3", 0, 3.0, 0, 0}, {"ssprk3", 0, 3.0, 0, 0},
+    {"ralston4", 0, 4.0, 0, 0}, {"kutta4", 0, 4.0, 0, 0},
+};
+
+nnhip::SolveLaunchFn find_solve(int integrator, int rhs_kind, int dim) {
+  switch (integrator) {
+    case NNHIP_RK4: return nnhip::find_solve_rk4(rhs_kind, dim);
+    case NNHIP_DOPRI54: return nnhip::find_solve_dopri54(rhs_kind, dim);
+    case NNHIP_TSIT54: return nnhip::find_solve_tsit54(rhs_kind, dim);
+  }
+  return nullptr;
+}
+nnhip::StepLaunchFn find_step(int integrator, int rhs_kind, int dim) {
+  switch (integrator) {
+    case NNHIP_RK4: return nnhip::find_step_rk4(rhs_kind, dim);
+    case NNHIP_DOPRI54: return nnhip::find_step_dopri54(rhs_kind, dim);
+    case NNHIP_TSIT54: return nnhip::find_step_tsit54(rhs_kind, dim);
+  }
+  return nullptr;
+}
+
+bool elementwise_rhs(int k) { return k == NNHIP_RHS_NEG_Y || k == NNHIP_RHS_LINEAR || k == NNHIP_RHS_AFFINE_T; }
+
+int check_common(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
+                 int64_t N, int dim, int layout, nnhip::Params& P) {
+  if (!opt) return fail(NNHIP_EVALUE, "options is NULL");
+  if (integrator < 0 || integrator >= NNHIP_N_INTEGRATORS) return fail(NNHIP_EINTEGRATOR, "%d is not a valid integrator", integrator);
+  if (rhs_kind < 0 || rhs_kind >= NNHIP_N_RHS) return fail(NNHIP_EVALUE, "unknown rhs_kind %d", rhs_kind);
+  if (N < 0) return fail(NNHIP_EVALUE, "N must be >= 0");
+  if (dim < 1) return fail(NNHIP_EVALUE, "dim must be >= 1 (scalar state = dim 1)");
+  if (layout != NNHIP_LAYOUT_SOA && layout != NNHIP_LAYOUT_AOS) return fail(NNHIP_EVALUE, "unknown layout %d", layout);
+  if (n_params < 0 || n_params > nnhip::kMaxParams) return fail(NNHIP_EVALUE, "n_params must be in [0, %d]", nnhip::kMaxParams);
+  if (n_params > 0 && !rhs_params) return fail(NNHIP_EVALUE, "rhs_params is NULL");
+  static const int need[NNHIP_N_RHS] = {0, 1, 3, 1, 2, 1};
+  if (n_params < need[rhs_kind]) return fail(NNHIP_EVALUE, "rhs_kind %d needs %d parameters, got %d", rhs_kind, need[rhs_kind], n_params);
+  for (int k = 0; k < nnhip::kMaxParams; ++k) P.p[k] = k < n_params ? rhs_params[k] : 0.0;
+  return NNHIP_OK;
+}
+
+nnhip::StepCtl ctl_of(const nnhip_ode_options* o) { return nnhip::StepCtl{o->absTol, o->relTol, o->dtMax, o->dtMin}; }
+
+// Nim system.min/max (`if x <= y: x else: y`), host copy for the time loop
+inline double nmin_h(double x, double y) { return (x <= y) ? x : y; }
+inline double nmax_h(double x, double y) { return (y <= x) ? x : y; }
+
+struct TimeGrid {
+  std::vector<double> sorted, tPos, tNeg /*descending*/, tOut;
+  int nZero = 0;
+  double tEndPos = 0, tEndNeg = 0;
+};
+// ODESolver's bookkeeping before the loops (ode.nim:476-487, 510, 549, 585)
+void make_grid(const nnhip_ode_options* opt, const double* tspan, int n_t, TimeGrid& g) {
+  g.sorted.assign(tspan, tspan + n_t);
+  std::sort(g.sorted.begin(), g.sorted.end());  // tspan.sorted() (ode.nim:609)
+  const double t0 = opt->tStart;
+  for (double x : g.sorted) if (x > t0) g.tPos.push_back(x);  // :479
+  for (double x : g.sorted) if (x < t0) g.tNeg.push_back(x);  // :480
+  std::reverse(g.tNeg.begin(), g.tNeg.end());
+  g.nZero = std::find(g.sorted.begin(), g.sorted.end(), t0) != g.sorted.end() ? 1 : 0;  // `t0 in tspan` (:485)
+  if (!g.tPos.empty()) { g.tEndPos = g.tPos[0]; for (double x : g.tPos) g.tEndPos = nmax_h(g.tEndPos, x); }
+  if (!g.tNeg.empty()) { double mn = g.tNeg[0]; for (double x : g.tNeg) mn = nmin_h(mn, x); g.tEndNeg = -mn; }
+  for (auto it = g.tNeg.rbegin(); it != g.tNeg.rend(); ++it) g.tOut.push_back(*it);  // :585
+  if (g.nZero) g.tOut.push_back(t0);
+  for (double x : g.tPos) g.tOut.push_back(x);
+}
+
+// pinned staging for the (tiny) requested-time arrays of the device-pointer solve
+struct Staging {
+  double* host = nullptr;
+  size_t cap = 0;
+  hipEvent_t ev = nullptr;
+  bool pending = false;
+};
+thread_local Staging g_stage;
+
+int stage_reserve(size_t n) {
+  Staging& s = g_stage;
+  if (s.pending) { HIP_TRY(hipEventSynchronize(s.ev)); s.pending = false; }
+  if (!s.ev) HIP_TRY(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+  if (n > s.cap) {
+    if (s.host) HIP_TRY(hipHostFree(s.host));
+    s.host = nullptr; s.cap = 0;
+    HIP_TRY(hipHostMalloc((void**)&s.host, n * sizeof(double), hipHostMallocDefault));
+    s.cap = n;
+  }
+  return NNHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nnhip_abi_version(void) { return NNHIP_ABI_VERSION; }
+
+int nnhip_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(NNHIP_EHIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+  return n;
+}
+
+const char* nnhip_last_error(void) { return g_err; }
+
+const char* nnhip_build_info(void) {
+  return "numericalnim-hip ODE backend; target gfx950 (CDNA4); device math -ffp-contract=off (bit-parity build); "
+         "compiler " __VERSION__;
+}
+
+int nnhip_ode_new_options(nnhip_ode_options* out, double dt, double absTol, double relTol, double dtMax, double dtMin,
+                          double scaleMax, double scaleMin, double tStart) {
+  if (!out) return fail(NNHIP_EVALUE, "out is NULL");
+  if (std::fabs(dtMax) < std::fabs(dtMin)) return fail(NNHIP_EVALUE, "dtMin must be less than dtMax");  // ode.nim:95-96
+  if (std::fabs(scaleMax) < 1) return fail(NNHIP_EVALUE, "scaleMax must be bigger than 1");             // :97-98
+  if (1 < std::fabs(scaleMin)) return fail(NNHIP_EVALUE, "scaleMin must be smaller than 1");            // :99-100
+  out->dt = std::fabs(dt); out->absTol = std::fabs(absTol); out->relTol = std::fabs(relTol);             // :101-102
+  out->dtMax = std::fabs(dtMax); out->dtMin = std::fabs(dtMin); out->scaleMax = std::fabs(scaleMax);
+  out->scaleMin = std::fabs(scaleMin); out->tStart = tStart;
+  return NNHIP_OK;
+}
+
+int nnhip_ode_default_options(nnhip_ode_options* out) {  // ode.nim:78-79,104
+  return nnhip_ode_new_options(out, 1e-4, 1e-4, 1e-4, 1e-2, 1e-4, 4.0, 0.1, 0.0);
+}
+
+int nnhip_ode_integrator_id(const char* name) {
+  if (!name) return fail(NNHIP_EINTEGRATOR, "(null) is not a valid integrator");
+  std::string s(name);
+  for (auto& ch : s) ch = (char)std::tolower((unsigned char)ch);  // integrator.toLower() (ode.nim:607)
+  for (int i = 0; i < NNHIP_N_INTEGRATORS; ++i) if (s == kMethods[i].name) return i;
+  return fail(NNHIP_EINTEGRATOR, "%s is not a valid integrator", name);  // ode.nim:651
+}
+
+const char* nnhip_ode_integrator_name(int integrator) {
+  if (integrator < 0 || integrator >= NNHIP_N_INTEGRATORS) return "";
+  return kMethods[integrator].name;
+}
+
+int nnhip_ode_integrator_traits(int integrator, int* use_fsal, double* order, int* adaptive) {
+  if (integrator < 0 || integrator >= NNHIP_N_INTEGRATORS) return fail(NNHIP_EINTEGRATOR, "%d is not a valid integrator", integrator);
+  if (use_fsal) *use_fsal = kMethods[integrator].useFSAL;
+  if (order) *order = kMethods[integrator].order;
+  if (adaptive) *adaptive = kMethods[integrator].adaptive;
+  return NNHIP_OK;
+}
+
+int nnhip_ode_time_grid(const nnhip_ode_options* opt, const double* tspan, int n_t, double* t_out, int* n_t_out) {
+  if (!opt || (!tspan && n_t > 0) || n_t < 0) return fail(NNHIP_EVALUE, "bad arguments");
+  TimeGrid g;
+  make_grid(opt, tspan, n_t, g);
+  if (t_out) std::copy(g.tOut.begin(), g.tOut.end(), t_out);
+  if (n_t_out) *n_t_out = (int)g.tOut.size();
+  return NNHIP_OK;
+}
+
+int nnhip_ode_supported(int integrator, int rhs_kind, int dim, int layout, int mode) {
+  if (integrator < 0 || integrator >= NNHIP_N_INTEGRATORS || rhs_kind < 0 || rhs_kind >= NNHIP_N_RHS) return 0;
+  if (layout != NNHIP_LAYOUT_SOA && layout != NNHIP_LAYOUT_AOS) return 0;
+  if (mode == 0) return find_solve(integrator, rhs_kind, dim) != nullptr;
+  if (mode == 1) {
+    if (find_step(integrator, rhs_kind, dim)) return 1;
+    return (!kMethods[integrator].adaptive && integrator == NNHIP_RK4 && elementwise_rhs(rhs_kind)) ? 1 : 0;
+  }
+  return 0;
+}
+
+int64_t nnhip_ode_solve_workspace_bytes(int n_t) {
+  const int64_t n = n_t < 0 ? 0 : n_t;
+  return (n + 8) * (int64_t)sizeof(double) + 8 * (int64_t)sizeof(unsigned long long);
+}
+
+// ---- fused solve ---------------------------------------------------------------------------------
+static int solve_dev_impl(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
+                          const double* y0, int64_t N, int dim, int layout, const double* tspan, int n_t, double* t_out,
+                          double* y_out, int32_t* ny_out, int64_t* steps_out, int64_t* rejected_out, int64_t max_steps,
+                          void* ws, int64_t ws_bytes, unsigned long long* agg, int* n_t_out, hipStream_t stream) {
+  nnhip::Params P;
+  int rc = check_common(opt, integrator, rhs_kind, rhs_params, n_params, N, dim, layout, P);
+  if (rc) return rc;
+  if (n_t < 0 || (n_t > 0 && !tspan)) return fail(NNHIP_EVALUE, "bad tspan");
+  if (N > 0 && (!y0 || !y_out)) return fail(NNHIP_EVALUE, "y0 / y_out is NULL");
+  if (!kMethods[integrator].implemented) return fail(NNHIP_EUNSUPPORTED, "integrator %s has no HIP kernel yet", kMethods[integrator].name);
+  nnhip::SolveLaunchFn fn = find_solve(integrator, rhs_kind, dim);
+  if (!fn) return fail(NNHIP_EUNSUPPORTED, "no fused-solve kernel for integrator=%s rhs_kind=%d dim=%d", kMethods[integrator].name, rhs_kind, dim);
+  const bool adaptive = kMethods[integrator].adaptive;
+  // Deviations from the reference that keep the device from spinning forever (documented in DESIGN.md):
+  if (!adaptive && !(opt->dt > 0.0)) return fail(NNHIP_EVALUE, "fixed-step integrators need options.dt > 0 (the reference would loop forever)");
+  if (adaptive && !(opt->dtMin > 0.0) && max_steps <= 0) return fail(NNHIP_EVALUE, "adaptive integrators need options.dtMin > 0 or max_steps > 0");
+
+  TimeGrid g;
+  make_grid(opt, tspan, n_t, g);
+  if (t_out) std::copy(g.tOut.begin(), g.tOut.end(), t_out);
+  if (n_t_out) *n_t_out = (int)g.tOut.size();
+  if (N == 0) return NNHIP_OK;
+
+  nnhip::SolveArgs a{};
+  a.y0 = y0; a.y_out = y_out; a.ny_out = ny_out; a.steps_out = steps_out; a.rejected_out = rejected_out; a.agg = agg;
+  a.N = N;
+  if (layout == NNHIP_LAYOUT_SOA) { a.ivpStride = 1; a.compStride = N; } else { a.ivpStride = dim; a.compStride = 1; }
+  a.rowStride = (int64_t)dim * N;
+  a.n_t = n_t;
+  a.nPos = (int)g.tPos.size(); a.nNeg = (int)g.tNeg.size(); a.nZero = g.nZero;
+  a.t0 = opt->tStart; a.tEndPos = g.tEndPos; a.tEndNeg = g.tEndNeg;
+  a.dtInit = adaptive ? std::sqrt(opt->dtMax * opt->dtMin) : opt->dt;  // ode.nim:491-496
+  a.useDense = (n_t != 2) ? 1 : 0;                                      // ode.nim:499-502
+  a.maxSteps = max_steps;
+  a.ctl = ctl_of(opt);
+  a.P = P;
+  a.tPos = nullptr; a.tNeg = nullptr;
+  if (a.useDense && (a.nPos + a.nNeg) > 0) {
+    const size_t n = (size_t)a.nPos + (size_t)a.nNeg;
+    if (!ws || ws_bytes < (int64_t)(n * sizeof(double))) return fail(NNHIP_EVALUE, "workspace too small: need %zu bytes", n * sizeof(double));
+    rc = stage_reserve(n);
+    if (rc) return rc;
+    std::copy(g.tPos.begin(), g.tPos.end(), g_stage.host);
+    std::copy(g.tNeg.begin(), g.tNeg.end(), g_stage.host + a.nPos);
+    HIP_TRY(hipMemcpyAsync(ws, g_stage.host, n * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(g_stage.ev, stream));
+    g_stage.pending = true;
+    a.tPos = (const double*)ws;
+    a.tNeg = (const double*)ws + a.nPos;
+  }
+  HIP_TRY(fn(a, stream));
+  return NNHIP_OK;
+}
+
+int nnhip_ode_solve_batch_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
+                                  int n_params, const double* y0, int64_t N, int dim, int layout, const double* tspan,
+                                  int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
+                                  int64_t* rejected_out, int64_t max_steps, void* ws, int64_t ws_bytes, void* stream) {
+  return solve_dev_impl(opt, integrator, rhs_kind, rhs_params, n_params, y0, N, dim, layout, tspan, n_t, t_out, y_out, ny_out,
+                        steps_out, rejected_out, max_steps, ws, ws_bytes, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int nnhip_ode_solve_batch_f64(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
+                              int n_params, const double* y0, int64_t N, int dim, int layout, const double* tspan,
+                              int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
+                              int64_t* rejected_out, int64_t max_steps, nnhip_ode_stats* stats, int device) {
+  if (N < 0 || dim < 1 || n_t < 0) return fail(NNHIP_EVALUE, "bad sizes");
+  int ndev = nnhip_device_count();
+  if (ndev < 0) return ndev;
+  if (ndev == 0) return fail(NNHIP_EHIP, "no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(NNHIP_EVALUE, "device %d out of range [0,%d)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  const size_t nState = (size_t)N * dim, nOut = nState * (size_t)n_t;
+  double *d_y0 = nullptr, *d_out = nullptr;
+  int32_t* d_ny = nullptr;
+  int64_t *d_steps = nullptr, *d_rej = nullptr;
+  void* d_ws = nullptr;
+  unsigned long long* d_agg = nullptr;
+  hipStream_t s = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = NNHIP_OK;
+  int nTOut = 0;
+  const int64_t wsBytes = nnhip_ode_solve_workspace_bytes(n_t);
+  auto cleanup = [&]() {
+    void* bufs[] = {d_y0, d_out, d_ny, d_steps, d_rej, d_ws, d_agg};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (s) (void)hipStreamDestroy(s);
+  };
+#define HIP_TRY_C(expr)                                                                                                   \
+  do {                                                                                                                    \
+    hipError_t _e = (expr);                                                                                               \
+    if (_e != hipSuccess) { rc = fail(_e == hipErrorOutOfMemory ? NNHIP_ENOMEM : NNHIP_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e)); cleanup(); return rc; } \
+  } while (0)
+  HIP_TRY_C(hipStreamCreate(&s));
+  HIP_TRY_C(hipEventCreate(&e0));
+  HIP_TRY_C(hipEventCreate(&e1));
+  if (nState) HIP_TRY_C(hipMalloc((void**)&d_y0, nState * sizeof(double)));
+  if (nOut) HIP_TRY_C(hipMalloc((void**)&d_out, nOut * sizeof(double)));
+  if (ny_out && N) HIP_TRY_C(hipMalloc((void**)&d_ny, (size_t)N * sizeof(int32_t)));
+  if (steps_out && N) HIP_TRY_C(hipMalloc((void**)&d_steps, (size_t)N * sizeof(int64_t)));
+  if (rejected_out && N) HIP_TRY_C(hipMalloc((void**)&d_rej, (size_t)N * sizeof(int64_t)));
+  HIP_TRY_C(hipMalloc(&d_ws, (size_t)wsBytes));
+  HIP_TRY_C(hipMalloc((void**)&d_agg, 8 * sizeof(unsigned long long)));
+  {
+    unsigned long long init[8] = {0, 0, 0, ~0ull, 0, 0, 0, 0};
+    HIP_TRY_C(hipMemcpyAsync(d_agg, init, sizeof(init), hipMemcpyHostToDevice, s));
+  }
+  if (nState) HIP_TRY_C(hipMemcpyAsync(d_y0, y0, nState * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY_C(hipEventRecord(e0, s));
+  rc = solve_dev_impl(opt, integrator, rhs_kind, rhs_params, n_params, d_y0, N, dim, layout, tspan, n_t, t_out, d_out, d_ny,
+                      d_steps, d_rej, max_steps, d_ws, wsBytes, d_agg, &nTOut, s);
+  if (rc) { cleanup(); return rc; }
+  HIP_TRY_C(hipEventRecord(e1, s));
+  if (nOut) HIP_TRY_C(hipMemcpyAsync(y_out, d_out, nOut * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (d_ny) HIP_TRY_C(hipMemcpyAsync(ny_out, d_ny, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  if (d_steps) HIP_TRY_C(hipMemcpyAsync(steps_out, d_steps, (size_t)N * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  if (d_rej) HIP_TRY_C(hipMemcpyAsync(rejected_out, d_rej, (size_t)N * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  unsigned long long agg[8] = {0};
+  HIP_TRY_C(hipMemcpyAsync(agg, d_agg, sizeof(agg), hipMemcpyDeviceToHost, s));
+  HIP_TRY_C(hipStreamSynchronize(s));
+  if (stats) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    stats->steps_total = (int64_t)agg[0]; stats->rejected_total = (int64_t)agg[1]; stats->steps_max = (int64_t)agg[2];
+    stats->n_t_out = nTOut; stats->ny_min = N ? (int32_t)agg[3] : 0; stats->nan_aborts = (int32_t)agg[4];
+    stats->truncated = (int32_t)agg[5]; stats->kernel_ms = ms;
+  }
+  cleanup();
+  return NNHIP_OK;
+#undef HIP_TRY_C
+}
+
+// ---- step-streaming ---------------------------------------------------------------------------------
+int nnhip_ode_step_batch_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
+                                 int n_params, int64_t N, int dim, int layout, const double* t_dev, double t_uniform,
+                                 const double* dt_dev, double dt_uniform, const double* y_in, const double* fsal_in,
+                                 double* y_out, double* fsal_out, double* dt_used, double* error, int negate_time,
+                                 void* stream) {
+  nnhip::Params P;
+  int rc = check_common(opt, integrator, rhs_kind, rhs_params, n_params, N, dim, layout, P);
+  if (rc) return rc;
+  if (!kMethods[integrator].implemented) return fail(NNHIP_EUNSUPPORTED, "integrator %s has no HIP kernel yet", kMethods[integrator].name);
+  if (N == 0) return NNHIP_OK;
+  if (!y_in || !y_out) return fail(NNHIP_EVALUE, "y_in / y_out is NULL");
+  if (kMethods[integrator].useFSAL && (!fsal_in || !fsal_out)) return fail(NNHIP_EVALUE, "FSAL methods need fsal_in and fsal_out");
+  // scalar elementwise RK4 with uniform (t, dt): the vectorised streaming kernel over N*dim flat states
+  if (integrator == NNHIP_RK4 && elementwise_rhs(rhs_kind) && !t_dev && !dt_dev && !fsal_out && !dt_used && !error &&
+      (((uintptr_t)y_in | (uintptr_t)y_out) & 15) == 0) {
+    HIP_TRY(nnhip::launch_rk4_stream(rhs_kind, y_in, y_out, N * dim, t_uniform, dt_uniform, P, negate_time, 0, (hipStream_t)stream));
+    return NNHIP_OK;
+  }
+  nnhip::StepLaunchFn fn = find_step(integrator, rhs_kind, dim);
+  if (!fn) return fail(NNHIP_EUNSUPPORTED, "no step kernel for integrator=%s rhs_kind=%d dim=%d", kMethods[integrator].name, rhs_kind, dim);
+  nnhip::StepArgs a{};
+  a.N = N;
+  if (layout == NNHIP_LAYOUT_SOA) { a.ivpStride = 1; a.compStride = N; } else { a.ivpStride = dim; a.compStride = 1; }
+  a.t_dev = t_dev; a.t_uniform = t_uniform; a.dt_dev = dt_dev; a.dt_uniform = dt_uniform;
+  a.y_in = y_in; a.fsal_in = fsal_in; a.y_out = y_out; a.fsal_out = fsal_out; a.dt_used = dt_used; a.error = error;
+  a.ctl = ctl_of(opt); a.P = P;
+  HIP_TRY(fn(a, negate_time, (hipStream_t)stream));
+  return NNHIP_OK;
+}
+
+int nnhip_ode_fixed_stream_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
+                                   int n_params, int64_t N, int dim, int layout, double t0, double tEnd, double* y,
+                                   double* scratch, int64_t* n_steps_out, double** y_final, void* stream) {
+  nnhip::Params P;
+  int rc = check_common(opt, integrator, rhs_kind, rhs_params, n_params, N, dim, layout, P);
+  if (rc) return rc;
+  if (kMethods[integrator].adaptive) return fail(NNHIP_EVALUE, "nnhip_ode_fixed_stream_f64_dev needs a fixed-step integrator");
+  if (!kMethods[integrator].implemented) return fail(NNHIP_EUNSUPPORTED, "integrator %s has no HIP kernel yet", kMethods[integrator].name);
+  if (!(opt->dt > 0.0)) return fail(NNHIP_EVALUE, "fixed-step integrators need options.dt > 0 (the reference would loop forever)");
+  if (N > 0 && !y) return fail(NNHIP_EVALUE, "y is NULL");
+  // ODESolver forward loop, adaptive = false, no dense output (ode.nim:509-532)
+  double t = t0;
+  double dt = opt->dt;
+  int64_t n = 0;
+  double* cur = y;
+  double* nxt = scratch ? scratch : y;
+  while (t < tEnd) {             // :511
+    dt = nmin_h(dt, tEnd - t);   // :525
+    rc = nnhip_ode_step_batch_f64_dev(opt, integrator, rhs_kind, rhs_params, n_params, N, dim, layout, nullptr, t, nullptr, dt,
+                                      cur, nullptr, nxt, nullptr, nullptr, nullptr, 0, stream);  // :531
+    if (rc) return rc;
+    if (scratch) std::swap(cur, nxt);
+    t += dt;                     // :532
+    ++n;
+  }
+  if (n_steps_out) *n_steps_out = n;
+  if (y_final) *y_final = cur;
+  return NNHIP_OK;
+}
+
+}  // extern "C"

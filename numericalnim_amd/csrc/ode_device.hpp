@@ -1,0 +1,405 @@
+// ode_device.hpp — device-side building blocks of the batched ODE backend (gfx950 / CDNA4).
+//
+// What lives here: the compiled-in RHS library, the Butcher tableaux, the per-IVP steppers and the
+// per-IVP time-loop driver, all as __device__ templates over (RHS, DIM) so that the state vector, the
+// stage vectors k1..kS and (t, dt) of one IVP are VGPR-resident for a whole solve.  No MFMA anywhere:
+// this is AXPY-shaped FP64 VALU work (the kernels built from these pieces are bounded by HBM when the
+// state streams through memory once per step, and by the FP64 VALU when a whole solve is fused).
+//
+// Numerical contract: every floating-point expression below is written in the evaluation order of the
+// reference (src/numericalnim/ode.nim; citations inline) and this translation unit is compiled with
+// -ffp-contract=off, so +,-,*,/ and sqrt round exactly as the reference's C backend does on x86-64.
+// The only operation that may differ in the last ulp is pow() in the step-size controller.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nnhip_ode.h"
+
+namespace nnhip {
+
+#define NNHIP_DEV __device__ __forceinline__
+
+// Nim's system.min/max on floats: `if x <= y: x else: y` / `if y <= x: x else: y` (NaN falls through
+// to the second operand exactly as in the reference).
+NNHIP_DEV double nmin(double x, double y) { return (x <= y) ? x : y; }
+NNHIP_DEV double nmax(double x, double y) { return (y <= x) ? x : y; }
+
+constexpr int kMaxParams = 8;
+
+struct Params {
+  double p[kMaxParams];
+};
+
+// ------------------------------------------------------------------------------------------------
+// RHS library (enum nnhip_rhs_kind).  eval(): thread-per-IVP form, whole state in registers.
+// comp(): lanes-per-system form, lane c computes component c reading the stage argument vector from
+// LDS (`ys`, DIM doubles).  Both must produce bit-identical values.
+// ------------------------------------------------------------------------------------------------
+template <int DIM>
+struct RhsNegY {  // dy = -y   (ode.nim:16-17)
+  static constexpr int dim = DIM;
+  NNHIP_DEV static void eval(double, const double (&y)[DIM], double (&dy)[DIM], const Params&) {
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) dy[c] = -y[c];
+  }
+  NNHIP_DEV static double comp(double, int c, const double* ys, const Params&) { return -ys[c]; }
+};
+
+template <int DIM>
+struct RhsLinear {  // dy = p0 * y   (tests/test_ode.nim:5-7: -0.1 * y)
+  static constexpr int dim = DIM;
+  NNHIP_DEV static void eval(double, const double (&y)[DIM], double (&dy)[DIM], const Params& P) {
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) dy[c] = y[c] * P.p[0];
+  }
+  NNHIP_DEV static double comp(double, int c, const double* ys, const Params& P) { return ys[c] * P.p[0]; }
+};
+
+template <int DIM>
+struct RhsAffineT {  // dy = p0*y + p1*t
+  static constexpr int dim = DIM;
+  NNHIP_DEV static void eval(double t, const double (&y)[DIM], double (&dy)[DIM], const Params& P) {
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) dy[c] = P.p[0] * y[c] + P.p[1] * t;
+  }
+  NNHIP_DEV static double comp(double t, int c, const double* ys, const Params& P) { return P.p[0] * ys[c] + P.p[1] * t; }
+};
+
+struct RhsLorenz {  // sigma=p0, rho=p1, beta=p2
+  static constexpr int dim = 3;
+  NNHIP_DEV static void eval(double, const double (&y)[3], double (&dy)[3], const Params& P) {
+    dy[0] = P.p[0] * (y[1] - y[0]);
+    dy[1] = y[0] * (P.p[1] - y[2]) - y[1];
+    dy[2] = y[0] * y[1] - P.p[2] * y[2];
+  }
+  NNHIP_DEV static double comp(double, int c, const double* ys, const Params& P) {
+    if (c == 0) return P.p[0] * (ys[1] - ys[0]);
+    if (c == 1) return ys[0] * (P.p[1] - ys[2]) - ys[1];
+    return ys[0] * ys[1] - P.p[2] * ys[2];
+  }
+};
+
+struct RhsVanDerPol {  // mu = p0
+  static constexpr int dim = 2;
+  NNHIP_DEV static void eval(double, const double (&y)[2], double (&dy)[2], const Params& P) {
+    dy[0] = y[1];
+    dy[1] = P.p[0] * ((1.0 - y[0] * y[0]) * y[1]) - y[0];
+  }
+  NNHIP_DEV static double comp(double, int c, const double* ys, const Params& P) {
+    if (c == 0) return ys[1];
+    return P.p[0] * ((1.0 - ys[0] * ys[0]) * ys[1]) - ys[0];
+  }
+};
+
+template <int DIM>
+struct RhsRing {  // dy_c = -((c+1)/d)*y_c + p0*y_{(c+1) mod d}
+  static constexpr int dim = DIM;
+  NNHIP_DEV static void eval(double, const double (&y)[DIM], double (&dy)[DIM], const Params& P) {
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) dy[c] = -((double)(c + 1) / (double)DIM) * y[c] + P.p[0] * y[(c + 1) % DIM];
+  }
+  NNHIP_DEV static double comp(double, int c, const double* ys, const Params& P) {
+    return -((double)(c + 1) / (double)DIM) * ys[c] + P.p[0] * ys[(c + 1) % DIM];
+  }
+};
+
+// f or g(t,y) = -f(-t,y) (ode.nim:545)
+template <class RHS, bool NEG>
+NNHIP_DEV void rhs_eval(double t, const double (&y)[RHS::dim], double (&dy)[RHS::dim], const Params& P) {
+  if constexpr (NEG) {
+    RHS::eval(-t, y, dy, P);
+#pragma unroll
+    for (int c = 0; c < RHS::dim; ++c) dy[c] = -dy[c];
+  } else {
+    RHS::eval(t, y, dy, P);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Butcher tableaux of the embedded FSAL pairs.  A[s][j] = a_{s+2, j+1} (row of stage s+2).
+// Zero entries are kept: the reference multiplies by them (ode.nim:263,277,299,302).
+// ------------------------------------------------------------------------------------------------
+template <int METHOD>
+struct Tableau;
+
+template <>
+struct Tableau<NNHIP_DOPRI54> {  // ode.nim:240-282
+  static constexpr int S = 7;
+  static constexpr int ORDER = 5;
+  static constexpr bool DIRECT_ERR = false;  // error_y = yNew - yLow (:303)
+  static constexpr int NB = 6;               // terms in yNew
+  NNHIP_DEV static double c(int s) {
+    constexpr double C[7] = {0.0, 1.0 / 5.0, 3.0 / 10.0, 4.0 / 5.0, 8.0 / 9.0, 1.0, 1.0};
+    return C[s];
+  }
+  NNHIP_DEV static double a(int s, int j) {
+    constexpr double A[7][6] = {
+        {0, 0, 0, 0, 0, 0},
+        {1.0 / 5.0, 0, 0, 0, 0, 0},
+        {3.0 / 40.0, 9.0 / 40.0, 0, 0, 0, 0},
+        {44.0 / 45.0, -56.0 / 15.0, 32.0 / 9.0, 0, 0, 0},
+        {19372.0 / 6561.0, -25360.0 / 2187.0, 64448.0 / 6561.0, -212.0 / 729.0, 0, 0},
+        {9017.0 / 3168.0, -355.0 / 33.0, 46732.0 / 5247.0, 49.0 / 176.0, -5103.0 / 18656.0, 0},
+        {35.0 / 384.0, 0.0, 500.0 / 1113.0, 125.0 / 192.0, -2187.0 / 6784.0, 11.0 / 84.0}};
+    return A[s][j];
+  }
+  NNHIP_DEV static double b(int j) { return a(6, j); }  // b_i = a_7i (:269-274)
+  NNHIP_DEV static double bhat(int j) {
+    constexpr double B[7] = {5179.0 / 57600.0, 0.0, 7571.0 / 16695.0, 393.0 / 640.0, -92097.0 / 339200.0, 187.0 / 2100.0, 1.0 / 40.0};
+    return B[j];
+  }
+};
+
+template <>
+struct Tableau<NNHIP_TSIT54> {  // ode.nim:310-352
+  static constexpr int S = 7;
+  static constexpr int ORDER = 5;
+  static constexpr bool DIRECT_ERR = true;  // error_y = dt * (sum bHat_i k_i) (:372)
+  static constexpr int NB = 6;
+  NNHIP_DEV static double c(int s) {
+    constexpr double C[7] = {0.0, 0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0};
+    return C[s];
+  }
+  NNHIP_DEV static double a(int s, int j) {
+    constexpr double A[7][6] = {
+        {0, 0, 0, 0, 0, 0},
+        {0.161, 0, 0, 0, 0, 0},
+        {-0.008480655492356989, 0.335480655492357, 0, 0, 0, 0},
+        {2.8971530571054935, -6.359448489975075, 4.3622954328695815, 0, 0, 0},
+        {5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525, 0, 0},
+        {5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383, 0},
+        {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774}};
+    return A[s][j];
+  }
+  NNHIP_DEV static double b(int j) { return a(6, j); }
+  NNHIP_DEV static double bhat(int j) {
+    constexpr double B[7] = {-0.001780011052226, -0.000816434459657, 0.007880878010262, -0.144711007173263,
+                             0.582357165452555,  -0.458082105929187, 1.0 / 66.0};
+    return B[j];
+  }
+};
+
+// Which methods are adaptive / FSAL / their `order` float — the triple solveODE passes (ode.nim:608-649)
+template <int METHOD> struct MethodTraits;
+template <> struct MethodTraits<NNHIP_RK4>     { static constexpr bool fsal = false, adaptive = false; static constexpr double order = 4.0; };
+template <> struct MethodTraits<NNHIP_DOPRI54> { static constexpr bool fsal = true,  adaptive = true;  static constexpr double order = 5.0; };
+template <> struct MethodTraits<NNHIP_TSIT54>  { static constexpr bool fsal = true,  adaptive = true;  static constexpr double order = 5.0; };
+
+struct StepCtl {  // the option fields the steppers read (ode.nim:283-286)
+  double absTol, relTol, dtMax, dtMin;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Steppers, thread-per-IVP.  Signature mirrors IntegratorProc (ode.nim:38):
+//   in  (t, y, FSAL, dt)   out (yNew, FSAL', dt used, error);  returns status bits.
+// ------------------------------------------------------------------------------------------------
+constexpr int kStatusNaN = 1;
+
+template <class RHS, bool NEG>
+NNHIP_DEV void rk4_step(double t, double dt, const double (&y)[RHS::dim], double (&yNew)[RHS::dim], const Params& P) {
+  constexpr int D = RHS::dim;  // ode.nim:180-189
+  double k1[D], k2[D], k3[D], k4[D], ya[D];
+  rhs_eval<RHS, NEG>(t, y, k1, P);
+  const double hdt = 0.5 * dt;
+#pragma unroll
+  for (int c = 0; c < D; ++c) ya[c] = y[c] + hdt * k1[c];          // y + 0.5 * dt * k1
+  rhs_eval<RHS, NEG>(t + 0.5 * dt, ya, k2, P);
+#pragma unroll
+  for (int c = 0; c < D; ++c) ya[c] = y[c] + hdt * k2[c];
+  rhs_eval<RHS, NEG>(t + 0.5 * dt, ya, k3, P);
+#pragma unroll
+  for (int c = 0; c < D; ++c) ya[c] = y[c] + dt * k3[c];
+  rhs_eval<RHS, NEG>(t + dt, ya, k4, P);
+  const double dt6 = dt / 6.0;
+#pragma unroll
+  for (int c = 0; c < D; ++c) yNew[c] = y[c] + dt6 * (k1[c] + 2.0 * (k2[c] + k3[c]) + k4[c]);  // :188
+}
+
+// Scaled RMS error norm + accept test + in-step dt shrink: commonAdaptiveMethodCode (ode.nim:57-76).
+// Returns true when the retry loop must stop.
+template <int D>
+NNHIP_DEV double error_norm(const double (&yNew)[D], const double (&err_y)[D], const StepCtl& o) {
+  double sum = 0.0;  // std/math sum: left to right from 0.0 (utils.nim:233-235)
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    const double totalTol = fabs(yNew[c]) * o.relTol + o.absTol;  // absTol +. relTol * abs(yNew)  (:61)
+    const double e = err_y[c] / totalTol;                        // :62
+    sum = sum + e * e;                                           // :63, :65
+  }
+  return sqrt(1.0 / (double)D * sum);  // :65
+}
+
+NNHIP_DEV double shrink_factor(double error, double inv_order) {  // min(4, max(0.125, 0.9 * pow(1/error, 1/order)))  (:71,:537)
+  return nmin(4.0, nmax(0.125, 0.9 * pow(1.0 / error, inv_order)));
+}
+
+template <int METHOD, class RHS, bool NEG>
+NNHIP_DEV int embedded_step(double t, double& dt, const double (&y)[RHS::dim], double (&fsal)[RHS::dim],
+                            double (&yNew)[RHS::dim], double& error, const StepCtl& o, const Params& P, int64_t& rejected) {
+  using T = Tableau<METHOD>;
+  constexpr int D = RHS::dim;
+  constexpr int S = T::S;
+  double k[S][D];
+  double ya[D], err_y[D];
+  int limitCounter = 0;
+  int status = 0;
+#pragma unroll
+  for (int c = 0; c < D; ++c) k[0][c] = fsal[c];  // k1 = FSAL (:293,:363)
+  while (limitCounter < 2) {                      // :58
+#pragma unroll
+    for (int s = 1; s < S; ++s) {
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        double acc = T::a(s, 0) * k[0][c];
+#pragma unroll
+        for (int j = 1; j < s; ++j) acc = acc + T::a(s, j) * k[j][c];
+        ya[c] = y[c] + dt * acc;  // y + dt * (a_s1*k1 + ... )
+      }
+      rhs_eval<RHS, NEG>(t + dt * T::c(s), ya, k[s], P);
+    }
+    // yNew = y + dt*(b1*k1+...+b6*k6): identical expression to k7's argument (:299-301) -> ya holds it
+#pragma unroll
+    for (int c = 0; c < D; ++c) yNew[c] = ya[c];
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      double acc = T::bhat(0) * k[0][c];
+#pragma unroll
+      for (int j = 1; j < S; ++j) acc = acc + T::bhat(j) * k[j][c];
+      if constexpr (T::DIRECT_ERR) {
+        err_y[c] = dt * acc;  // :372
+      } else {
+        const double yLow = y[c] + dt * acc;  // :302
+        err_y[c] = yNew[c] - yLow;            // :303
+      }
+    }
+    error = error_norm<D>(yNew, err_y, o);
+    if (error <= 1.0) break;                                   // :69-70
+    if (error != error) { status |= kStatusNaN; break; }       // deviation: the reference would spin forever
+    dt = dt * shrink_factor(error, 1.0 / (double)T::ORDER);    // :71
+    if (fabs(dt) < o.dtMin) { dt = o.dtMin; limitCounter += 1; }  // :72-74
+    else if (o.dtMax < fabs(dt)) { dt = o.dtMax; }             // :75-76
+    rejected += 1;
+  }
+#pragma unroll
+  for (int c = 0; c < D; ++c) fsal[c] = k[S - 1][c];  // return k7 (:305,:374)
+  return status;
+}
+
+// hermiteSpline per component (utils.nim:273-279)
+struct HermiteW {
+  double h00, h10w, h01, h11w;  // h10*(x2-x1), h11*(x2-x1) pre-multiplied exactly as the expression does
+};
+NNHIP_DEV HermiteW hermite_weights(double x, double x1, double x2) {
+  const double t = (x - x1) / (x2 - x1);
+  const double omt = 1.0 - t;
+  HermiteW w;
+  w.h00 = (1.0 + 2.0 * t) * (omt * omt);
+  const double h10 = t * (omt * omt);
+  w.h01 = (t * t) * (3.0 - 2.0 * t);
+  const double h11 = (t * t * t) - (t * t);
+  w.h10w = h10 * (x2 - x1);
+  w.h11w = h11 * (x2 - x1);
+  return w;
+}
+NNHIP_DEV double hermite_apply(const HermiteW& w, double y1, double y2, double dy1, double dy2) {
+  return w.h00 * y1 + w.h10w * dy1 + w.h01 * y2 + w.h11w * dy2;  // left-assoc sum (:279)
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-IVP driver = one direction of ODESolver's time loop (ode.nim:508-542 forward, :544-584 backward).
+// `emit(k, yv)` stores the k-th emitted state of this direction.
+// ------------------------------------------------------------------------------------------------
+struct DriveIn {
+  double tStartEff;  // t0 (forward) or -t0 (backward)
+  double tEnd;       // max(tPositive) or -min(tNegative)
+  double dtInit;
+  const double* tReq;  // tPositive, or tNegative (reversed order as the reference stores it; negated on read when NEG)
+  int nReq;
+  int useDense;
+  int64_t maxSteps;
+  StepCtl ctl;
+};
+struct DriveOut {
+  int emitted;
+  int status;
+  int64_t steps, rejected;
+};
+
+template <int METHOD, class RHS, bool NEG, class Emit>
+NNHIP_DEV void drive(const DriveIn& in, const double (&y0)[RHS::dim], const Params& P, Emit&& emit, DriveOut& out) {
+  constexpr int D = RHS::dim;
+  using MT = MethodTraits<METHOD>;
+  double t = in.tStartEff;
+  double y[D], fsal[D], lastY[D], lastDy[D], yNew[D], dyNow[D];
+  double lastT = in.tStartEff;
+#pragma unroll
+  for (int c = 0; c < D; ++c) y[c] = y0[c];
+  rhs_eval<RHS, NEG>(t, y, fsal, P);  // FSAL = f(t0, y) (:506) / g(-t0, y0) (:546)
+#pragma unroll
+  for (int c = 0; c < D; ++c) { lastY[c] = y[c]; lastDy[c] = fsal[c]; }  // lastIter (:498,:548)
+  double dt = in.dtInit;
+  double error = 0.0;
+  int denseIndex = 0;
+  const int high = in.nReq - 1;
+  int status = 0;
+  int64_t steps = 0, rejected = 0;
+  while (t < in.tEnd) {  // :511
+    if (in.useDense) {
+      if (high < denseIndex) break;  // :513-514
+      double treq = NEG ? -in.tReq[denseIndex] : in.tReq[denseIndex];
+      if (treq <= t) {
+        if constexpr (!MT::fsal) rhs_eval<RHS, NEG>(t, y, dyNow, P);  // f(t, y, ctx) per emitted point (:521); same value each time
+        while (treq <= t) {  // :515
+          const HermiteW w = hermite_weights(treq, lastT, t);
+          double yv[D];
+#pragma unroll
+          for (int c = 0; c < D; ++c) yv[c] = hermite_apply(w, lastY[c], y[c], lastDy[c], MT::fsal ? fsal[c] : dyNow[c]);
+          emit(denseIndex, yv);
+          denseIndex += 1;
+          if (high < denseIndex) break;  // :523-524
+          treq = NEG ? -in.tReq[denseIndex] : in.tReq[denseIndex];
+        }
+      }
+    }
+    dt = nmin(dt, in.tEnd - t);  // :525
+    if (in.useDense) {           // :526-530
+      lastT = t;
+#pragma unroll
+      for (int c = 0; c < D; ++c) lastY[c] = y[c];
+      if constexpr (MT::fsal) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) lastDy[c] = fsal[c];
+      } else {
+        rhs_eval<RHS, NEG>(t, y, lastDy, P);
+      }
+    }
+    if constexpr (METHOD == NNHIP_RK4) {
+      rk4_step<RHS, NEG>(t, dt, y, yNew, P);  // :531
+      error = 0.0;
+    } else {
+      status |= embedded_step<METHOD, RHS, NEG>(t, dt, y, fsal, yNew, error, in.ctl, P, rejected);
+    }
+#pragma unroll
+    for (int c = 0; c < D; ++c) y[c] = yNew[c];
+    t += dt;  // :532
+    steps += 1;
+    if constexpr (MT::adaptive) {  // :533-541
+      if (error == 0.0) dt *= 5.0;
+      else dt = dt * shrink_factor(error, 1.0 / MT::order);
+      if (dt < in.ctl.dtMin) dt = in.ctl.dtMin;
+      else if (in.ctl.dtMax < dt) dt = in.ctl.dtMax;
+    }
+    if (status) break;
+    if (in.maxSteps > 0 && steps >= in.maxSteps) { status |= 2; break; }
+  }
+  // yPositive.add(y) / yNegative.add(y) (:542,:584): appended after whatever was emitted so far
+  // (denseIndex stays 0 when tspan.len == 2, so a non-dense solve returns exactly this one row).
+  emit(denseIndex, y);
+  out.emitted = denseIndex + 1;
+  out.status = status;
+  out.steps = steps;
+  out.rejected = rejected;
+}
+
+}  // namespace nnhip

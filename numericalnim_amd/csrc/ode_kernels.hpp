@@ -1,0 +1,314 @@
+// ode_kernels.hpp — __global__ kernels built from ode_device.hpp, and their launch records.
+//
+// Kernel families (all FP64 VALU, no MFMA):
+//   solve_tpi_kernel   thread-per-IVP fused solve: a whole ODESolver run (ode.nim:471-586) per thread,
+//                      HBM touched only for y0 in and the requested rows out        -> FP64-VALU bound
+//   step_tpi_kernel    thread-per-IVP single IntegratorProc call (ode.nim:38,531), state streams
+//                      HBM -> VGPR -> HBM once per step                              -> HBM bound
+//   rk4_stream_vec_kernel  the scalar RK4 instance of the above with 16-byte lane accesses and several
+//                      independent loads in flight per lane (the BASELINE.json headline kernel;
+//                      algorithmic traffic 16 B per trajectory-step)                 -> HBM bound
+#pragma once
+#include "ode_device.hpp"
+
+namespace nnhip {
+
+struct SolveArgs {
+  const double* y0;
+  double* y_out;
+  int32_t* ny_out;        // nullable
+  int64_t* steps_out;     // nullable
+  int64_t* rejected_out;  // nullable
+  unsigned long long* agg;  // nullable: [0] steps_total [1] rejected_total [2] steps_max [3] ny_min [4] nan_aborts [5] truncated
+  int64_t N;
+  int64_t ivpStride, compStride;  // element (i, c) of a state array lives at i*ivpStride + c*compStride
+  int64_t rowStride;              // distance between consecutive output rows (= dim*N)
+  int n_t;
+  const double* tPos;  // device, ascending requested times > t0
+  const double* tNeg;  // device, requested times < t0 in DESCENDING order (tNegative as the reference holds it)
+  int nPos, nNeg, nZero;
+  double t0, tEndPos, tEndNeg, dtInit;
+  int useDense;
+  int64_t maxSteps;
+  StepCtl ctl;
+  Params P;
+};
+
+struct StepArgs {
+  int64_t N;
+  int64_t ivpStride, compStride;
+  const double* t_dev;  // nullable -> t_uniform
+  double t_uniform;
+  const double* dt_dev;  // nullable -> dt_uniform
+  double dt_uniform;
+  const double* y_in;
+  const double* fsal_in;
+  double* y_out;
+  double* fsal_out;
+  double* dt_used;  // nullable
+  double* error;    // nullable
+  StepCtl ctl;
+  Params P;
+};
+
+using SolveLaunchFn = hipError_t (*)(const SolveArgs&, hipStream_t);
+using StepLaunchFn = hipError_t (*)(const StepArgs&, int negate, hipStream_t);
+
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------------------------------------
+// fused solve, thread per IVP
+// ------------------------------------------------------------------------------------------------
+template <int METHOD, class RHS>
+__global__ __launch_bounds__(kBlock) void solve_tpi_kernel(const SolveArgs a) {
+  constexpr int D = RHS::dim;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  unsigned long long steps = 0, rejected = 0;
+  int ny = 0x7fffffff, nanAb = 0, trunc = 0;
+  if (i < a.N) {
+    double y0[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) y0[c] = a.y0[i * a.ivpStride + c * a.compStride];
+    double* const out = a.y_out + i * a.ivpStride;
+    int rowBase = 0;
+    int status = 0;
+    DriveIn in;
+    in.useDense = a.useDense;
+    in.maxSteps = a.maxSteps;
+    in.ctl = a.ctl;
+    in.dtInit = a.dtInit;
+    // Backward branch first (ode.nim:544-584; the two branches are independent, both restart from y0).
+    // Emission k of this branch is element k of yNegative; the result holds yNegative.reversed(), so it
+    // lands in row nNeg-1-k.
+    if (a.nNeg > 0) {
+      in.tStartEff = -a.t0;
+      in.tEnd = a.tEndNeg;
+      in.tReq = a.tNeg;
+      in.nReq = a.nNeg;
+      DriveOut o;
+      const int nNeg = a.nNeg;
+      const int64_t rs = a.rowStride, cs = a.compStride;
+      drive<METHOD, RHS, true>(in, y0, a.P,
+                               [=](int k, const double(&yv)[D]) {
+                                 if (k < nNeg) {
+#pragma unroll
+                                   for (int c = 0; c < D; ++c) out[(int64_t)(nNeg - 1 - k) * rs + c * cs] = yv[c];
+                                 }
+                               },
+                               o);
+      int m = o.emitted < nNeg ? o.emitted : nNeg;
+      if (m < nNeg) {  // reference quirk: fewer rows than requested -> they close up
+        const int shift = nNeg - m;
+        for (int j = 0; j < m; ++j)
+#pragma unroll
+          for (int c = 0; c < D; ++c) out[(int64_t)j * rs + c * cs] = out[(int64_t)(j + shift) * rs + c * cs];
+      }
+      rowBase = m;
+      status |= o.status;
+      steps += o.steps;
+      rejected += o.rejected;
+    }
+    if (a.nZero > 0) {  // `if t0 in tspan` (ode.nim:485-487)
+#pragma unroll
+      for (int c = 0; c < D; ++c) out[(int64_t)rowBase * a.rowStride + c * a.compStride] = y0[c];
+      rowBase += 1;
+    }
+    if (a.nPos > 0) {  // ode.nim:508-542
+      in.tStartEff = a.t0;
+      in.tEnd = a.tEndPos;
+      in.tReq = a.tPos;
+      in.nReq = a.nPos;
+      DriveOut o;
+      const int nPos = a.nPos;
+      const int64_t rs = a.rowStride, cs = a.compStride;
+      const int rb = rowBase;
+      drive<METHOD, RHS, false>(in, y0, a.P,
+                                [=](int k, const double(&yv)[D]) {
+                                  if (k < nPos) {
+#pragma unroll
+                                    for (int c = 0; c < D; ++c) out[(int64_t)(rb + k) * rs + c * cs] = yv[c];
+                                  }
+                                },
+                                o);
+      rowBase += o.emitted < nPos ? o.emitted : nPos;
+      status |= o.status;
+      steps += o.steps;
+      rejected += o.rejected;
+    }
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+    for (int j = rowBase; j < a.n_t; ++j)
+#pragma unroll
+      for (int c = 0; c < D; ++c) out[(int64_t)j * a.rowStride + c * a.compStride] = qnan;
+    if (a.ny_out) a.ny_out[i] = rowBase;
+    if (a.steps_out) a.steps_out[i] = (int64_t)steps;
+    if (a.rejected_out) a.rejected_out[i] = (int64_t)rejected;
+    ny = rowBase;
+    nanAb = (status & kStatusNaN) ? 1 : 0;
+    trunc = (status & 2) ? 1 : 0;
+  }
+  if (a.agg) {  // wave-level reduction, one atomic per wave and field
+    unsigned long long smax = steps;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      steps += __shfl_down(steps, off, 64);
+      rejected += __shfl_down(rejected, off, 64);
+      const unsigned long long om = __shfl_down(smax, off, 64);
+      smax = om > smax ? om : smax;
+      const int on = __shfl_down(ny, off, 64);
+      ny = on < ny ? on : ny;
+      nanAb += __shfl_down(nanAb, off, 64);
+      trunc += __shfl_down(trunc, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&a.agg[0], steps);
+      atomicAdd(&a.agg[1], rejected);
+      atomicMax(&a.agg[2], smax);
+      atomicMin(&a.agg[3], (unsigned long long)(unsigned)ny);
+      if (nanAb) atomicAdd(&a.agg[4], (unsigned long long)nanAb);
+      if (trunc) atomicAdd(&a.agg[5], (unsigned long long)trunc);
+    }
+  }
+}
+
+template <int METHOD, class RHS>
+hipError_t launch_solve_tpi(const SolveArgs& a, hipStream_t s) {
+  const int64_t grid = (a.N + kBlock - 1) / kBlock;
+  if (grid <= 0) return hipSuccess;
+  hipLaunchKernelGGL((solve_tpi_kernel<METHOD, RHS>), dim3((unsigned)grid), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// one IntegratorProc call, thread per IVP (step-streaming; state in HBM between calls)
+// ------------------------------------------------------------------------------------------------
+template <int METHOD, class RHS, bool NEG>
+__global__ __launch_bounds__(kBlock) void step_tpi_kernel(const StepArgs a) {
+  constexpr int D = RHS::dim;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= a.N) return;
+  double y[D], yNew[D];
+  const int64_t base = i * a.ivpStride;
+#pragma unroll
+  for (int c = 0; c < D; ++c) y[c] = a.y_in[base + c * a.compStride];
+  const double t = a.t_dev ? a.t_dev[i] : a.t_uniform;
+  double dt = a.dt_dev ? a.dt_dev[i] : a.dt_uniform;
+  double error = 0.0;
+  if constexpr (METHOD == NNHIP_RK4) {
+    rk4_step<RHS, NEG>(t, dt, y, yNew, a.P);
+    if (a.fsal_out) {  // fixed-step methods return yNew in the FSAL slot (ode.nim:189)
+#pragma unroll
+      for (int c = 0; c < D; ++c) a.fsal_out[base + c * a.compStride] = yNew[c];
+    }
+  } else {
+    double fsal[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) fsal[c] = a.fsal_in[base + c * a.compStride];
+    int64_t rej = 0;
+    embedded_step<METHOD, RHS, NEG>(t, dt, y, fsal, yNew, error, a.ctl, a.P, rej);
+#pragma unroll
+    for (int c = 0; c < D; ++c) a.fsal_out[base + c * a.compStride] = fsal[c];
+  }
+#pragma unroll
+  for (int c = 0; c < D; ++c) a.y_out[base + c * a.compStride] = yNew[c];
+  if (a.dt_used) a.dt_used[i] = dt;
+  if (a.error) a.error[i] = error;
+}
+
+template <int METHOD, class RHS>
+hipError_t launch_step_tpi(const StepArgs& a, int negate, hipStream_t s) {
+  const int64_t grid = (a.N + kBlock - 1) / kBlock;
+  if (grid <= 0) return hipSuccess;
+  if (negate) hipLaunchKernelGGL((step_tpi_kernel<METHOD, RHS, true>), dim3((unsigned)grid), dim3(kBlock), 0, s, a);
+  else        hipLaunchKernelGGL((step_tpi_kernel<METHOD, RHS, false>), dim3((unsigned)grid), dim3(kBlock), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Headline kernel: scalar RK4 step over a flat array of n independent float64 states, uniform (t, dt).
+// Each lane moves VEC*16 bytes per direction with VEC independent 16-byte loads in flight; one
+// workgroup covers a contiguous kBlock*2*VEC-element tile so every wave-level access is a full
+// 1 KiB coalesced segment.  Algorithmic HBM traffic: 8 B read + 8 B written per trajectory-step.
+// ------------------------------------------------------------------------------------------------
+template <class RHS1, bool NEG, int VEC>
+__global__ __launch_bounds__(kBlock) void rk4_stream_vec_kernel(const double* __restrict__ yin, double* __restrict__ yout,
+                                                                int64_t n, double t, double dt, const Params P) {
+  static_assert(RHS1::dim == 1, "scalar RHS only");
+  const int64_t tile = (int64_t)blockIdx.x * (kBlock * 2 * VEC);
+  double2 v[VEC];
+  if (tile + kBlock * 2 * VEC <= n) {  // full tile: unguarded vector accesses
+    const double2* src = reinterpret_cast<const double2*>(yin + tile) + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) v[u] = src[u * kBlock];
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) {
+      double a0[1] = {v[u].x}, a1[1] = {v[u].y}, r0[1], r1[1];
+      rk4_step<RHS1, NEG>(t, dt, a0, r0, P);
+      rk4_step<RHS1, NEG>(t, dt, a1, r1, P);
+      v[u].x = r0[0];
+      v[u].y = r1[0];
+    }
+    double2* dst = reinterpret_cast<double2*>(yout + tile) + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) dst[u * kBlock] = v[u];
+  } else {  // ragged tail tile: scalar, bounds-checked
+    for (int64_t j = tile + threadIdx.x; j < n; j += kBlock) {
+      double a0[1] = {yin[j]}, r0[1];
+      rk4_step<RHS1, NEG>(t, dt, a0, r0, P);
+      yout[j] = r0[0];
+    }
+  }
+}
+
+template <class RHS1, int VEC>
+hipError_t launch_rk4_stream_vec(const double* yin, double* yout, int64_t n, double t, double dt, const Params& P,
+                                 int negate, hipStream_t s) {
+  const int64_t per = (int64_t)kBlock * 2 * VEC;
+  const int64_t grid = (n + per - 1) / per;
+  if (grid <= 0) return hipSuccess;
+  if (negate) hipLaunchKernelGGL((rk4_stream_vec_kernel<RHS1, true, VEC>), dim3((unsigned)grid), dim3(kBlock), 0, s, yin, yout, n, t, dt, P);
+  else        hipLaunchKernelGGL((rk4_stream_vec_kernel<RHS1, false, VEC>), dim3((unsigned)grid), dim3(kBlock), 0, s, yin, yout, n, t, dt, P);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dispatch tables: (rhs_kind, dim) -> launcher, one table per integrator (one translation unit each,
+// so the method x RHS instantiations compile in parallel).
+// ------------------------------------------------------------------------------------------------
+#define NNHIP_FOR_EACH_TPI_RHS(X)                                                                                  \
+  X(NNHIP_RHS_NEG_Y, 1, RhsNegY<1>) X(NNHIP_RHS_NEG_Y, 2, RhsNegY<2>) X(NNHIP_RHS_NEG_Y, 3, RhsNegY<3>)            \
+  X(NNHIP_RHS_NEG_Y, 4, RhsNegY<4>) X(NNHIP_RHS_LINEAR, 1, RhsLinear<1>) X(NNHIP_RHS_LINEAR, 2, RhsLinear<2>)      \
+  X(NNHIP_RHS_LINEAR, 3, RhsLinear<3>) X(NNHIP_RHS_LINEAR, 4, RhsLinear<4>) X(NNHIP_RHS_AFFINE_T, 1, RhsAffineT<1>) \
+  X(NNHIP_RHS_AFFINE_T, 2, RhsAffineT<2>) X(NNHIP_RHS_AFFINE_T, 3, RhsAffineT<3>)                                  \
+  X(NNHIP_RHS_AFFINE_T, 4, RhsAffineT<4>) X(NNHIP_RHS_LORENZ, 3, RhsLorenz) X(NNHIP_RHS_VANDERPOL, 2, RhsVanDerPol) \
+  X(NNHIP_RHS_RING, 4, RhsRing<4>)
+
+template <int METHOD>
+SolveLaunchFn find_solve_tpi(int rhs_kind, int dim) {
+#define X(kind, d, T) \
+  if (rhs_kind == kind && dim == d) return &launch_solve_tpi<METHOD, T>;
+  NNHIP_FOR_EACH_TPI_RHS(X)
+#undef X
+  return nullptr;
+}
+template <int METHOD>
+StepLaunchFn find_step_tpi(int rhs_kind, int dim) {
+#define X(kind, d, T) \
+  if (rhs_kind == kind && dim == d) return &launch_step_tpi<METHOD, T>;
+  NNHIP_FOR_EACH_TPI_RHS(X)
+#undef X
+  return nullptr;
+}
+
+// defined in ode_tu_<method>.hip
+SolveLaunchFn find_solve_rk4(int rhs_kind, int dim);
+SolveLaunchFn find_solve_dopri54(int rhs_kind, int dim);
+SolveLaunchFn find_solve_tsit54(int rhs_kind, int dim);
+StepLaunchFn find_step_rk4(int rhs_kind, int dim);
+StepLaunchFn find_step_dopri54(int rhs_kind, int dim);
+StepLaunchFn find_step_tsit54(int rhs_kind, int dim);
+// scalar RK4 streaming (vectorised); rhs_kind must be an elementwise kind. Defined in ode_tu_rk4.hip
+hipError_t launch_rk4_stream(int rhs_kind, const double* yin, double* yout, int64_t n, double t, double dt, const Params& P,
+                             int negate, int variant, hipStream_t s);
+bool rk4_stream_supported(int rhs_kind);
+
+}  // namespace nnhip

@@ -1,0 +1,276 @@
+"""Host-side mirror of the reference's ODE interface over the C ABI.
+
+Reference (Nim)                                        here
+  newODEoptions(dt, absTol, ...)  ode.nim:78-102        newODEoptions(...)        -> ValueError on bad input
+  DEFAULT_ODEoptions              ode.nim:104           DEFAULT_ODEoptions
+  NumContext[T, float]            commonTypes.nim:4-39  NumContext (fValues / tValues, [] / setF / getF)
+  solveODE(f, y0, tspan, options, ctx, integrator)      solveODE(f, y0, tspan, options, ctx, integrator)
+                                  ode.nim:589-651          f: Rhs (compiled-in device RHS + names of its ctx.fValues)
+                                                           y0: batch of initial states (torch CUDA tensor or numpy)
+  IntegratorProc call             ode.nim:38,531        integratorStep(...)       one step over a device batch
+  fixedODE / adaptiveODE / allODE ode.nim:40-42         same names
+
+A batch y0 is [N] (scalar `float` states), [dim, N] (layout SoA) or [N, dim] (layout AoS).
+torch CUDA tensors stay on the device (device-pointer entry points, torch's current stream);
+numpy arrays go through the host-pointer entry point.  Nothing here computes on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Options as ODEoptions, Stats
+
+LAYOUT_SOA, LAYOUT_AOS = 0, 1
+
+fixedODE = ["heun2", "ralston2", "kutta3", "heun3", "ralston3", "ssprk3", "ralston4", "kutta4", "rk4"]  # ode.nim:40
+adaptiveODE = ["rk21", "bs32", "dopri54", "tsit54", "vern65"]  # ode.nim:41
+allODE = fixedODE + adaptiveODE  # ode.nim:42
+implementedODE = ["rk4", "dopri54", "tsit54"]  # integrators with HIP kernels in this round
+
+
+class NnhipError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc == _lib.NNHIP_OK:
+        return
+    msg = _lib.last_error()
+    if rc in (_lib.NNHIP_EVALUE, _lib.NNHIP_EINTEGRATOR):
+        raise ValueError(msg)  # the reference raises ValueError (ode.nim:95-100,651; utils.nim:26)
+    if rc == _lib.NNHIP_EUNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == _lib.NNHIP_ENOMEM:
+        raise MemoryError(msg)
+    raise NnhipError(f"nnhip error {rc}: {msg}")
+
+
+def newODEoptions(dt=1e-4, absTol=1e-4, relTol=1e-4, dtMax=1e-2, dtMin=1e-4, scaleMax=4.0, scaleMin=0.1, tStart=0.0):
+    """ode.nim:78-102 (same argument order and defaults)."""
+    o = ODEoptions()
+    _check(_lib.lib().nnhip_ode_new_options(C.byref(o), dt, absTol, relTol, dtMax, dtMin, scaleMax, scaleMin, tStart))
+    return o
+
+
+DEFAULT_ODEoptions = None  # filled lazily by _default_options(); ode.nim:104
+
+
+def _default_options():
+    global DEFAULT_ODEoptions
+    if DEFAULT_ODEoptions is None:
+        DEFAULT_ODEoptions = newODEoptions()
+    return DEFAULT_ODEoptions
+
+
+class NumContext:
+    """commonTypes.nim:4-39: two string-keyed tables; enum keys are stringified."""
+
+    def __init__(self, fValues=None, tValues=None):
+        self.fValues = dict(fValues or {})
+        self.tValues = dict(tValues or {})
+
+    def __getitem__(self, key):
+        return self.tValues[str(getattr(key, "name", key))]
+
+    def __setitem__(self, key, val):
+        self.tValues[str(getattr(key, "name", key))] = val
+
+    def getF(self, key):
+        return self.fValues[str(getattr(key, "name", key))]
+
+    def setF(self, key, val):
+        self.fValues[str(getattr(key, "name", key))] = val
+
+
+def newNumContext(fValues=None, tValues=None):
+    return NumContext(fValues, tValues)
+
+
+class Rhs:
+    """A compiled-in device RHS standing in for the user closure `f(t, y, ctx)` (ODEProc[T], ode.nim:36).
+
+    kind: nnhip_rhs_kind; keys: names looked up in ctx.fValues (in this order) to build rhs_params;
+    defaults: values used for keys absent from ctx."""
+    NEG_Y, LINEAR, LORENZ, RING, AFFINE_T, VANDERPOL = range(6)
+
+    def __init__(self, kind, keys=(), defaults=None):
+        self.kind = kind
+        self.keys = tuple(keys)
+        self.defaults = dict(defaults or {})
+
+    def params(self, ctx):
+        out = []
+        for k in self.keys:
+            if ctx is not None and k in ctx.fValues:
+                out.append(float(ctx.fValues[k]))
+            elif k in self.defaults:
+                out.append(float(self.defaults[k]))
+            else:
+                raise KeyError(f"ctx.fValues has no '{k}' for this RHS")  # Nim: KeyError from Table lookup
+        return out
+
+    @staticmethod
+    def neg_y():  # dy = -y (ode.nim:16-17)
+        return Rhs(Rhs.NEG_Y)
+
+    @staticmethod
+    def linear(a=None):  # dy = a*y (tests/test_ode.nim:5-7 uses a = -0.1)
+        return Rhs(Rhs.LINEAR, ("a",), {} if a is None else {"a": a})
+
+    @staticmethod
+    def lorenz(sigma=10.0, rho=28.0, beta=8.0 / 3.0):
+        return Rhs(Rhs.LORENZ, ("sigma", "rho", "beta"), {"sigma": sigma, "rho": rho, "beta": beta})
+
+    @staticmethod
+    def ring(c=0.1):
+        return Rhs(Rhs.RING, ("c",), {"c": c})
+
+    @staticmethod
+    def affine_t(a, b):
+        return Rhs(Rhs.AFFINE_T, ("a", "b"), {"a": a, "b": b})
+
+    @staticmethod
+    def vanderpol(mu=1.0):
+        return Rhs(Rhs.VANDERPOL, ("mu",), {"mu": mu})
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _shape_info(y0, layout):
+    shp = tuple(y0.shape)
+    if len(shp) == 1:
+        return shp[0], 1, True
+    if len(shp) != 2:
+        raise ValueError("y0 must be [N], [dim, N] (SoA) or [N, dim] (AoS)")
+    if layout == LAYOUT_SOA:
+        return shp[1], shp[0], False
+    return shp[0], shp[1], False
+
+
+def _params_array(f, ctx):
+    p = np.asarray(f.params(ctx), dtype=np.float64)
+    return p, (p.ctypes.data_as(C.POINTER(C.c_double)) if p.size else None)
+
+
+def integrator_id(integrator):
+    rc = _lib.lib().nnhip_ode_integrator_id(str(integrator).encode())
+    if rc < 0:
+        raise ValueError(f"{integrator} is not a valid integrator")  # ode.nim:651
+    return rc
+
+
+def solveODE(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=LAYOUT_SOA, max_steps=0, stats=None,
+             return_counts=False):
+    """Batched solveODE (ode.nim:589-651): returns (t, y) with t = the sorted output grid (ndarray) and
+    y = [n_t, *y0.shape] holding the state of every IVP at every t (rows the reference would not
+    return for an IVP are NaN; see include/nnhip_ode.h).
+
+    return_counts=True appends a dict(ny, steps, rejected) of per-IVP int arrays/tensors."""
+    L = _lib.lib()
+    options = options if options is not None else _default_options()
+    ctx = ctx if ctx is not None else NumContext()  # ode.nim:604-606
+    integ = integrator_id(integrator)
+    tspan = np.ascontiguousarray(np.asarray(tspan, dtype=np.float64))
+    n_t = int(tspan.size)
+    p, pp = _params_array(f, ctx)
+    t_out = np.empty(max(n_t, 1), dtype=np.float64)
+    tp = t_out.ctypes.data_as(C.POINTER(C.c_double))
+    tsp = tspan.ctypes.data_as(C.POINTER(C.c_double))
+    N, dim, scalar = _shape_info(y0, layout)
+    ntout = C.c_int(0)
+    _check(L.nnhip_ode_time_grid(C.byref(options), tsp, n_t, tp, C.byref(ntout)))
+    if _is_torch(y0):
+        import torch
+        if not y0.is_cuda:
+            raise ValueError("torch y0 must live on a CUDA/HIP device (numericalnim_amd has no CPU path)")
+        if y0.dtype != torch.float64:
+            raise ValueError("y0 must be float64")
+        y0c = y0.contiguous()
+        with torch.cuda.device(y0c.device):
+            y = torch.empty((n_t,) + tuple(y0c.shape), dtype=torch.float64, device=y0c.device)
+            ny = torch.empty(N, dtype=torch.int32, device=y0c.device) if return_counts else None
+            st = torch.empty(N, dtype=torch.int64, device=y0c.device) if return_counts else None
+            rj = torch.empty(N, dtype=torch.int64, device=y0c.device) if return_counts else None
+            wsb = int(L.nnhip_ode_solve_workspace_bytes(n_t))
+            ws = torch.empty(wsb, dtype=torch.uint8, device=y0c.device)
+            stream = torch.cuda.current_stream().cuda_stream
+            _check(L.nnhip_ode_solve_batch_f64_dev(C.byref(options), integ, f.kind, pp, int(p.size), y0c.data_ptr(), N, dim, layout,
+                                                   tsp, n_t, tp, y.data_ptr(), ny.data_ptr() if return_counts else None,
+                                                   st.data_ptr() if return_counts else None,
+                                                   rj.data_ptr() if return_counts else None, int(max_steps), ws.data_ptr(), wsb,
+                                                   stream))
+    else:
+        y0c = np.ascontiguousarray(np.asarray(y0, dtype=np.float64))
+        y = np.empty((n_t,) + y0c.shape, dtype=np.float64)
+        ny = np.empty(N, dtype=np.int32) if return_counts else None
+        st = np.empty(N, dtype=np.int64) if return_counts else None
+        rj = np.empty(N, dtype=np.int64) if return_counts else None
+        s = stats if stats is not None else Stats()
+        _check(L.nnhip_ode_solve_batch_f64(C.byref(options), integ, f.kind, pp, int(p.size), y0c.ctypes.data, N, dim, layout, tsp,
+                                           n_t, tp, y.ctypes.data, ny.ctypes.data if return_counts else None,
+                                           st.ctypes.data if return_counts else None, rj.ctypes.data if return_counts else None,
+                                           int(max_steps), C.byref(s), 0))
+    t = t_out[:ntout.value].copy()
+    if return_counts:
+        return t, y, dict(ny=ny, steps=st, rejected=rj)
+    return t, y
+
+
+def integratorStep(f, t, y, FSAL, dt, options=None, ctx=None, integrator="dopri54", layout=LAYOUT_SOA, negate_time=False,
+                   out=None):
+    """One IntegratorProc call (ode.nim:38) over a device batch: returns (yNew, FSAL', dtUsed, error).
+
+    y / FSAL: torch CUDA float64 batches; t / dt: Python floats (uniform) or [N] CUDA tensors."""
+    import torch
+    L = _lib.lib()
+    options = options if options is not None else _default_options()
+    integ = integrator_id(integrator)
+    p, pp = _params_array(f, ctx)
+    N, dim, scalar = _shape_info(y, layout)
+    yc = y.contiguous()
+    use_fsal = C.c_int()
+    adaptive = C.c_int()
+    _check(L.nnhip_ode_integrator_traits(integ, C.byref(use_fsal), None, C.byref(adaptive)))
+    with torch.cuda.device(yc.device):
+        y_new = out if out is not None else torch.empty_like(yc)
+        fs_in = FSAL.contiguous() if FSAL is not None else None
+        fs_new = torch.empty_like(yc) if (use_fsal.value or FSAL is not None) else None
+        t_dev = t.contiguous() if _is_torch(t) else None
+        dt_dev = dt.contiguous() if _is_torch(dt) else None
+        dt_used = torch.empty(N, dtype=torch.float64, device=yc.device) if adaptive.value else None
+        err = torch.empty(N, dtype=torch.float64, device=yc.device) if adaptive.value else None
+        stream = torch.cuda.current_stream().cuda_stream
+        _check(L.nnhip_ode_step_batch_f64_dev(C.byref(options), integ, f.kind, pp, int(p.size), N, dim, layout,
+                                              t_dev.data_ptr() if t_dev is not None else None, 0.0 if t_dev is not None else float(t),
+                                              dt_dev.data_ptr() if dt_dev is not None else None,
+                                              0.0 if dt_dev is not None else float(dt), yc.data_ptr(),
+                                              fs_in.data_ptr() if fs_in is not None else None, y_new.data_ptr(),
+                                              fs_new.data_ptr() if fs_new is not None else None,
+                                              dt_used.data_ptr() if dt_used is not None else None,
+                                              err.data_ptr() if err is not None else None, 1 if negate_time else 0, stream))
+    return y_new, fs_new, dt_used, err
+
+
+def fixedStream(f, y, t0, tEnd, options=None, ctx=None, integrator="rk4", layout=LAYOUT_SOA, scratch=None):
+    """ODESolver's fixed-step loop (ode.nim:511-532) over the step-streaming kernel; y (CUDA tensor) is
+    advanced from t0 to tEnd.  Returns (y_final_tensor, n_steps); y_final is `y` or `scratch`."""
+    import torch
+    L = _lib.lib()
+    options = options if options is not None else _default_options()
+    integ = integrator_id(integrator)
+    p, pp = _params_array(f, ctx)
+    N, dim, scalar = _shape_info(y, layout)
+    if not y.is_contiguous():
+        raise ValueError("y must be contiguous (it is updated in place)")
+    nsteps = C.c_int64(0)
+    yfin = C.c_void_p(0)
+    with torch.cuda.device(y.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        _check(L.nnhip_ode_fixed_stream_f64_dev(C.byref(options), integ, f.kind, pp, int(p.size), N, dim, layout, float(t0),
+                                                float(tEnd), y.data_ptr(), scratch.data_ptr() if scratch is not None else None,
+                                                C.byref(nsteps), C.byref(yfin), stream))
+    final = scratch if (scratch is not None and yfin.value == scratch.data_ptr()) else y
+    return final, nsteps.value

@@ -1,0 +1,758 @@
+// =============================================================================
+// ode_oracle.cpp — CPU ORACLE for the numericalnim ODE path.  TEST INFRASTRUCTURE ONLY.
+//
+// This file is a CPU restatement, operation for operation, of the reference's ODE solver
+//   /root/reference/src/numericalnim/ode.nim      (steppers, controller, driver, dispatch)
+//   /root/reference/src/numericalnim/utils.nim    (Vector[T] arithmetic, hermiteSpline, linspace)
+// It exists only so that tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg can
+// check / time the HIP product path against it.  NOTHING in the product path (numericalnim_amd/,
+// include/) may include, link or call anything in oracle/.
+//
+// Parity pin status: the reference is Nim and no Nim compiler exists in the build image, so the
+// reference itself cannot be run here, and it stores no bit-level golden vectors.  The oracle is
+// pinned against every known-answer test the reference holds for this path
+// (tests/test_ode.nim:24-257: all 14 integrators vs exp(-0.1 t) on linspace(-10,10,100) incl.
+// `t == tspan`, at the reference's own tolerances; tests/test_vector.nim operator semantics;
+// tests/test_utils.nim:15-23 linspace) — see tests/test_oracle_reference_kats.py — and against the
+// survey's independent scratch known-answer values.  Bit-level identity with
+// a Nim build is by construction (same IEEE-754 double operations in the same order, compiled
+// -ffp-contract=off, no fast-math), not by execution.
+//
+// Build: see oracle/Makefile  (g++ -O2 -ffp-contract=off -fno-fast-math)
+// =============================================================================
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace oracle {
+
+// ---------------------------------------------------------------------------------------------
+// Vector[T] — utils.nim:15-17.  Every binary operator allocates a fresh seq (utils.nim:61,115,...)
+// exactly like the reference; that allocation cost is part of the CPU baseline for vector states.
+// ---------------------------------------------------------------------------------------------
+struct Vec {
+  std::vector<double> components;  // utils.nim:16
+};
+
+static inline void checkVectorSizes(const Vec& a, const Vec& b) {  // utils.nim:22-26
+  if (a.components.size() == b.components.size()) return;
+  throw std::invalid_argument("Vectors must have the same size.");
+}
+static inline Vec operator+(const Vec& v1, const Vec& v2) {  // utils.nim:59-64
+  checkVectorSizes(v1, v2);
+  Vec r; r.components.resize(v1.components.size());
+  for (size_t i = 0; i < v1.components.size(); ++i) r.components[i] = v1.components[i] + v2.components[i];
+  return r;
+}
+static inline Vec operator-(const Vec& v1, const Vec& v2) {  // utils.nim:113-118
+  checkVectorSizes(v1, v2);
+  Vec r; r.components.resize(v1.components.size());
+  for (size_t i = 0; i < v1.components.size(); ++i) r.components[i] = v1.components[i] - v2.components[i];
+  return r;
+}
+static inline Vec operator*(double d, const Vec& v1) {  // utils.nim:176-180  (v1[i] * d)
+  Vec r; r.components.resize(v1.components.size());
+  for (size_t i = 0; i < v1.components.size(); ++i) r.components[i] = v1.components[i] * d;
+  return r;
+}
+static inline Vec operator-(const Vec& v1) {  // utils.nim:214-218
+  Vec r; r.components.resize(v1.components.size());
+  for (size_t i = 0; i < v1.components.size(); ++i) r.components[i] = -v1.components[i];
+  return r;
+}
+static inline Vec nabs(const Vec& v1) {  // utils.nim:219-223
+  Vec r; r.components.resize(v1.components.size());
+  for (size_t i = 0; i < v1.components.size(); ++i) r.components[i] = std::fabs(v1.components[i]);
+  return r;
+}
+static inline Vec dotAdd(double d, const Vec& v1) {  // `+.` utils.nim:78-79 -> `+`(d, v1) :72-76 (v1[i] + d)
+  Vec r; r.components.resize(v1.components.size());
+  for (size_t i = 0; i < v1.components.size(); ++i) r.components[i] = v1.components[i] + d;
+  return r;
+}
+static inline Vec dotMul(const Vec& v1, const Vec& v2) {  // `*.` utils.nim:186-191
+  checkVectorSizes(v1, v2);
+  Vec r; r.components.resize(v1.components.size());
+  for (size_t i = 0; i < v1.components.size(); ++i) r.components[i] = v1.components[i] * v2.components[i];
+  return r;
+}
+static inline Vec dotDiv(const Vec& v1, const Vec& v2) {  // `/.` utils.nim:192-197
+  checkVectorSizes(v1, v2);
+  Vec r; r.components.resize(v1.components.size());
+  for (size_t i = 0; i < v1.components.size(); ++i) r.components[i] = v1.components[i] / v2.components[i];
+  return r;
+}
+static inline int nsize(const Vec& v) { return (int)v.components.size(); }  // utils.nim:57
+static inline double nsum(const Vec& v) {  // utils.nim:243-250 -> norm(v,1) :233-235 -> std/math sum: left-to-right from 0.0
+  double result = 0.0;
+  for (double x : v.components) result = result + x;
+  return result;
+}
+
+// scalar shims — ode.nim:45-55
+static inline double nabs(double d) { return std::fabs(d); }
+static inline double dotAdd(double d1, double d2) { return d1 + d2; }  // ode.nim:45-46
+static inline double dotDiv(double d1, double d2) { return d1 / d2; }  // ode.nim:48-49
+static inline double dotMul(double d1, double d2) { return d1 * d2; }  // ode.nim:51-52
+static inline int nsize(double) { return 1; }                          // ode.nim:54
+static inline double nsum(double d) { return d; }                      // ode.nim:55
+
+// Nim system min/max for floats: `if x <= y: x else: y` / `if y <= x: x else: y`
+static inline double nmin(double x, double y) { return (x <= y) ? x : y; }
+static inline double nmax(double x, double y) { return (y <= x) ? x : y; }
+
+// std/math `^` with Natural exponent (cases 2 and 3 are plain products)
+static inline double sq(double x) { return x * x; }
+static inline double cube(double x) { return x * x * x; }
+
+// hermiteSpline — utils.nim:273-279
+template <class T>
+static inline T hermiteSpline(double x, double x1, double x2, const T& y1, const T& y2, const T& dy1, const T& dy2) {
+  const double t = (x - x1) / (x2 - x1);
+  const double h00 = (1.0 + 2.0 * t) * sq(1.0 - t);
+  const double h10 = t * sq(1.0 - t);
+  const double h01 = sq(t) * (3.0 - 2.0 * t);
+  const double h11 = cube(t) - sq(t);
+  return h00 * y1 + h10 * (x2 - x1) * dy1 + h01 * y2 + h11 * (x2 - x1) * dy2;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ODEoptions — ode.nim:26-34, newODEoptions ode.nim:78-102
+// ---------------------------------------------------------------------------------------------
+struct ODEoptions {
+  double dt, dtMax, dtMin, tStart, absTol, relTol, scaleMax, scaleMin;
+};
+
+static ODEoptions newODEoptions(double dt = 1e-4, double absTol = 1e-4, double relTol = 1e-4, double dtMax = 1e-2,
+                                double dtMin = 1e-4, double scaleMax = 4.0, double scaleMin = 0.1, double tStart = 0.0) {
+  if (std::fabs(dtMax) < std::fabs(dtMin)) throw std::invalid_argument("dtMin must be less than dtMax");   // :95-96
+  if (std::fabs(scaleMax) < 1) throw std::invalid_argument("scaleMax must be bigger than 1");             // :97-98
+  if (1 < std::fabs(scaleMin)) throw std::invalid_argument("scaleMin must be smaller than 1");            // :99-100
+  ODEoptions o;                                                                                             // :101-102
+  o.dt = std::fabs(dt); o.absTol = std::fabs(absTol); o.relTol = std::fabs(relTol); o.dtMax = std::fabs(dtMax);
+  o.dtMin = std::fabs(dtMin); o.scaleMax = std::fabs(scaleMax); o.scaleMin = std::fabs(scaleMin); o.tStart = tStart;
+  return o;
+}
+
+// ODEProc[T] — ode.nim:36.  A Nim closure is (fn pointer, environment); model it the same way so the
+// CPU baseline pays the same indirect call.  `ctx` (NumContext) is the env: a flat double array here.
+struct Counters {
+  int64_t rhsEvals = 0, steps = 0, rejected = 0;
+  int nanAbort = 0;
+};
+template <class T>
+struct ODEProc {
+  T (*fn)(double t, const T& y, const void* env);
+  const void* env;
+  Counters* counters;
+  bool countEvals = true;  // false for the wrapper g(t,y) = -f(-t,y): the inner f call is the one counted
+  inline T operator()(double t, const T& y) const {
+    if (counters && countEvals) counters->rhsEvals++;
+    return fn(t, y, env);
+  }
+};
+
+template <class T>
+struct StepResult {  // (T, T, float, float) — ode.nim:38
+  T yNew, fsal;
+  double dt, error;
+};
+
+// commonAdaptiveMethodCode tail — ode.nim:61-76.  Returns true when the retry loop must `break`.
+// DEVIATION (documented in DESIGN.md): with error = NaN the reference loops forever
+// (`error <= 1` is false, dt becomes NaN, neither clamp fires, limitCounter never moves).
+// The oracle and the HIP path both abort the trajectory instead and flag it.
+template <class T>
+static inline bool adaptiveTail(const T& yNew, const T& error_y, int order, double absTol, double relTol, double dtMin,
+                                double dtMax, double& dt, double& error, int& limitCounter, Counters* cnt) {
+  const T totalTol = dotAdd(absTol, relTol * nabs(yNew));              // :61
+  const T err1 = dotDiv(error_y, totalTol);                            // :62
+  const T err1_square = dotMul(err1, err1);                            // :63
+  const double size = (double)nsize(err1);                             // :64
+  error = std::sqrt(1 / size * nsum(err1_square));                     // :65
+  if (error <= 1) return true;                                         // :69-70
+  if (error != error) { if (cnt) cnt->nanAbort = 1; return true; }     // deviation: see above
+  dt = dt * nmin(4, nmax(0.125, 0.9 * std::pow(1 / error, 1.0 / order)));  // :71
+  if (std::fabs(dt) < dtMin) { dt = dtMin; limitCounter += 1; }        // :72-74
+  else if (dtMax < std::fabs(dt)) { dt = dtMax; }                      // :75-76
+  if (cnt) cnt->rejected++;
+  return false;
+}
+
+// ---- fixed-step steppers ---------------------------------------------------------------------
+template <class T> static StepResult<T> HEUN2_step(const ODEProc<T>& f, double t, const T& y, const T&, double dt, const ODEoptions&) {  // ode.nim:107-113
+  const T k1 = f(t, y);
+  const T k2 = f(t + dt, y + dt * k1);
+  const T yNew = y + 0.5 * dt * (k1 + k2);
+  return {yNew, yNew, dt, 0.0};
+}
+template <class T> static StepResult<T> RALSTON2_step(const ODEProc<T>& f, double t, const T& y, const T&, double dt, const ODEoptions&) {  // :115-121
+  const T k1 = f(t, y);
+  const T k2 = f(t + 2.0 / 3.0 * dt, y + 2.0 / 3.0 * dt * k1);
+  const T yNew = y + dt * (0.25 * k1 + 0.75 * k2);
+  return {yNew, yNew, dt, 0.0};
+}
+template <class T> static StepResult<T> KUTTA3_step(const ODEProc<T>& f, double t, const T& y, const T&, double dt, const ODEoptions&) {  // :123-130
+  const T k1 = f(t, y);
+  const T k2 = f(t + 0.5 * dt, y + 0.5 * dt * k1);
+  const T k3 = f(t + dt, y - dt * k1 + 2.0 * dt * k2);
+  const T yNew = y + dt * (1.0 / 6.0 * k1 + 2.0 / 3.0 * k2 + 1.0 / 6.0 * k3);
+  return {yNew, yNew, dt, 0.0};
+}
+template <class T> static StepResult<T> HEUN3_step(const ODEProc<T>& f, double t, const T& y, const T&, double dt, const ODEoptions&) {  // :132-139
+  const T k1 = f(t, y);
+  const T k2 = f(t + 1.0 / 3.0 * dt, y + 1.0 / 3.0 * dt * k1);
+  const T k3 = f(t + 2.0 / 3.0 * dt, y + 2.0 / 3.0 * dt * k2);
+  const T yNew = y + dt * (0.25 * k1 + 0.75 * k3);
+  return {yNew, yNew, dt, 0.0};
+}
+template <class T> static StepResult<T> RALSTON3_step(const ODEProc<T>& f, double t, const T& y, const T&, double dt, const ODEoptions&) {  // :141-148
+  const T k1 = f(t, y);
+  const T k2 = f(t + 1.0 / 2.0 * dt, y + 1.0 / 2.0 * dt * k1);
+  const T k3 = f(t + 3.0 / 4.0 * dt, y + 3.0 / 4.0 * dt * k2);
+  const T yNew = y + dt * (2.0 / 9.0 * k1 + 1.0 / 3.0 * k2 + 4.0 / 9.0 * k3);
+  return {yNew, yNew, dt, 0.0};
+}
+template <class T> static StepResult<T> SSPRK3_step(const ODEProc<T>& f, double t, const T& y, const T&, double dt, const ODEoptions&) {  // :150-157
+  const T k1 = f(t, y);
+  const T k2 = f(t + dt, y + dt * k1);
+  const T k3 = f(t + 0.5 * dt, y + 0.25 * dt * (k1 + k2));
+  const T yNew = y + dt * (1.0 / 6.0 * k1 + 1.0 / 6.0 * k2 + 2.0 / 3.0 * k3);
+  return {yNew, yNew, dt, 0.0};
+}
+template <class T> static StepResult<T> RALSTON4_step(const ODEProc<T>& f, double t, const T& y, const T&, double dt, const ODEoptions&) {  // :160-168
+  const T k1 = f(t, y);
+  const T k2 = f(t + 0.4 * dt, y + 0.4 * dt * k1);
+  const T k3 = f(t + 0.45573725 * dt, y + dt * (0.29697761 * k1 + 0.15875964 * k2));
+  const T k4 = f(t + dt, y + dt * (0.21810040 * k1 - 3.05096516 * k2 + 3.83286476 * k3));
+  const T yNew = y + dt * (0.17476028 * k1 - 0.55148066 * k2 + 1.20553560 * k3 + 0.17118478 * k4);
+  return {yNew, yNew, dt, 0.0};
+}
+template <class T> static StepResult<T> KUTTA4_step(const ODEProc<T>& f, double t, const T& y, const T&, double dt, const ODEoptions&) {  // :170-178
+  const T k1 = f(t, y);
+  const T k2 = f(t + 1.0 / 3.0 * dt, y + 1.0 / 3.0 * dt * k1);
+  const T k3 = f(t + 2.0 / 3.0 * dt, y + dt * (-1.0 / 3.0 * k1 + k2));
+  const T k4 = f(t + dt, y + dt * (k1 - k2 + k3));
+  const T yNew = y + dt * (1.0 / 8.0 * k1 + 3.0 / 8.0 * k2 + 3.0 / 8.0 * k3 + 1.0 / 8.0 * k4);
+  return {yNew, yNew, dt, 0.0};
+}
+template <class T> static StepResult<T> RK4_step(const ODEProc<T>& f, double t, const T& y, const T&, double dt, const ODEoptions&) {  // :180-189
+  const T k1 = f(t, y);
+  const T k2 = f(t + 0.5 * dt, y + 0.5 * dt * k1);
+  const T k3 = f(t + 0.5 * dt, y + 0.5 * dt * k2);
+  const T k4 = f(t + dt, y + dt * k3);
+  const T yNew = y + dt / 6.0 * (k1 + 2.0 * (k2 + k3) + k4);
+  return {yNew, yNew, dt, 0.0};
+}
+
+// ---- adaptive steppers -----------------------------------------------------------------------
+template <class T> static StepResult<T> RK21_step(const ODEProc<T>& f, double t, const T& y, const T&, double dt_in, const ODEoptions& options) {  // :191-210
+  const double absTol = options.absTol, relTol = options.relTol, dtMax = options.dtMax, dtMin = options.dtMin;
+  T k1, k2, yNew, yLow;
+  double error = 0.0; int limitCounter = 0; double dt = dt_in;
+  while (limitCounter < 2) {
+    k1 = f(t, y);
+    k2 = f(t + dt, y + dt * k1);
+    yNew = y + dt * 0.5 * (k1 + k2);
+    yLow = y + dt * k1;
+    const T error_y = yNew - yLow;
+    if (adaptiveTail(yNew, error_y, 2, absTol, relTol, dtMin, dtMax, dt, error, limitCounter, f.counters)) break;
+  }
+  return {yNew, yNew, dt, error};
+}
+template <class T> static StepResult<T> BS32_step(const ODEProc<T>& f, double t, const T& y, const T&, double dt_in, const ODEoptions& options) {  // :212-234
+  const double absTol = options.absTol, relTol = options.relTol, dtMax = options.dtMax, dtMin = options.dtMin;
+  T k1, k2, k3, k4, yNew, yLow;
+  double error = 0.0; int limitCounter = 0; double dt = dt_in;
+  while (limitCounter < 2) {
+    k1 = f(t, y);
+    k2 = f(t + 0.5 * dt, y + 0.5 * dt * k1);
+    k3 = f(t + 0.75 * dt, y + 0.75 * dt * k2);
+    yNew = y + dt * (2.0 / 9.0 * k1 + 1.0 / 3.0 * k2 + 4.0 / 9.0 * k3);
+    k4 = f(t + dt, yNew);
+    yLow = y + dt * (7.0 / 24.0 * k1 + 1.0 / 4.0 * k2 + 1.0 / 3.0 * k3 + 1.0 / 8.0 * k4);
+    const T error_y = yNew - yLow;
+    if (adaptiveTail(yNew, error_y, 3, absTol, relTol, dtMin, dtMax, dt, error, limitCounter, f.counters)) break;
+  }
+  return {yNew, k4, dt, error};
+}
+
+template <class T> static StepResult<T> DOPRI54_step(const ODEProc<T>& f, double t, const T& y, const T& FSAL, double dt_in, const ODEoptions& options) {  // :237-305
+  constexpr double c2 = 1.0 / 5.0, c3 = 3.0 / 10.0, c4 = 4.0 / 5.0, c5 = 8.0 / 9.0, c6 = 1.0, c7 = 1.0;
+  constexpr double a21 = 1.0 / 5.0;
+  constexpr double a31 = 3.0 / 40.0, a32 = 9.0 / 40.0;
+  constexpr double a41 = 44.0 / 45.0, a42 = -56.0 / 15.0, a43 = 32.0 / 9.0;
+  constexpr double a51 = 19372.0 / 6561.0, a52 = -25360.0 / 2187.0, a53 = 64448.0 / 6561.0, a54 = -212.0 / 729.0;
+  constexpr double a61 = 9017.0 / 3168.0, a62 = -355.0 / 33.0, a63 = 46732.0 / 5247.0, a64 = 49.0 / 176.0, a65 = -5103.0 / 18656.0;
+  constexpr double a71 = 35.0 / 384.0, a72 = 0.0, a73 = 500.0 / 1113.0, a74 = 125.0 / 192.0, a75 = -2187.0 / 6784.0, a76 = 11.0 / 84.0;
+  constexpr double b1 = a71, b2 = a72, b3 = a73, b4 = a74, b5 = a75, b6 = a76;
+  constexpr double bHat1 = 5179.0 / 57600.0, bHat2 = 0.0, bHat3 = 7571.0 / 16695.0, bHat4 = 393.0 / 640.0,
+                   bHat5 = -92097.0 / 339200.0, bHat6 = 187.0 / 2100.0, bHat7 = 1.0 / 40.0;
+  const double absTol = options.absTol, relTol = options.relTol, dtMax = options.dtMax, dtMin = options.dtMin;
+  T k1, k2, k3, k4, k5, k6, k7, yNew, yLow;
+  double error = 0.0; int limitCounter = 0; double dt = dt_in;
+  while (limitCounter < 2) {
+    k1 = FSAL;
+    k2 = f(t + dt * c2, y + dt * (a21 * k1));
+    k3 = f(t + dt * c3, y + dt * (a31 * k1 + a32 * k2));
+    k4 = f(t + dt * c4, y + dt * (a41 * k1 + a42 * k2 + a43 * k3));
+    k5 = f(t + dt * c5, y + dt * (a51 * k1 + a52 * k2 + a53 * k3 + a54 * k4));
+    k6 = f(t + dt * c6, y + dt * (a61 * k1 + a62 * k2 + a63 * k3 + a64 * k4 + a65 * k5));
+    k7 = f(t + dt * c7, y + dt * (a71 * k1 + a72 * k2 + a73 * k3 + a74 * k4 + a75 * k5 + a76 * k6));
+    yNew = y + dt * (b1 * k1 + b2 * k2 + b3 * k3 + b4 * k4 + b5 * k5 + b6 * k6);
+    yLow = y + dt * (bHat1 * k1 + bHat2 * k2 + bHat3 * k3 + bHat4 * k4 + bHat5 * k5 + bHat6 * k6 + bHat7 * k7);
+    const T error_y = yNew - yLow;
+    if (adaptiveTail(yNew, error_y, 5, absTol, relTol, dtMin, dtMax, dt, error, limitCounter, f.counters)) break;
+  }
+  return {yNew, k7, dt, error};
+}
+
+template <class T> static StepResult<T> TSIT54_step(const ODEProc<T>& f, double t, const T& y, const T& FSAL, double dt_in, const ODEoptions& options) {  // :307-374
+  constexpr double c2 = 0.161, c3 = 0.327, c4 = 0.9, c5 = 0.9800255409045097, c6 = 1.0, c7 = 1.0;
+  constexpr double a21 = 0.161;
+  constexpr double a31 = -0.008480655492356989, a32 = 0.335480655492357;
+  constexpr double a41 = 2.8971530571054935, a42 = -6.359448489975075, a43 = 4.3622954328695815;
+  constexpr double a51 = 5.325864828439257, a52 = -11.748883564062828, a53 = 7.4955393428898365, a54 = -0.09249506636175525;
+  constexpr double a61 = 5.86145544294642, a62 = -12.92096931784711, a63 = 8.159367898576159, a64 = -0.071584973281401, a65 = -0.028269050394068383;
+  constexpr double a71 = 0.09646076681806523, a72 = 0.01, a73 = 0.4798896504144996, a74 = 1.379008574103742, a75 = -3.290069515436081, a76 = 2.324710524099774;
+  constexpr double b1 = a71, b2 = a72, b3 = a73, b4 = a74, b5 = a75, b6 = a76;
+  constexpr double bHat1 = -0.001780011052226, bHat2 = -0.000816434459657, bHat3 = 0.007880878010262, bHat4 = -0.144711007173263,
+                   bHat5 = 0.582357165452555, bHat6 = -0.458082105929187, bHat7 = 1.0 / 66.0;
+  const double absTol = options.absTol, relTol = options.relTol, dtMax = options.dtMax, dtMin = options.dtMin;
+  T k1, k2, k3, k4, k5, k6, k7, yNew;
+  double error = 0.0; int limitCounter = 0; double dt = dt_in;
+  while (limitCounter < 2) {
+    k1 = FSAL;
+    k2 = f(t + dt * c2, y + dt * (a21 * k1));
+    k3 = f(t + dt * c3, y + dt * (a31 * k1 + a32 * k2));
+    k4 = f(t + dt * c4, y + dt * (a41 * k1 + a42 * k2 + a43 * k3));
+    k5 = f(t + dt * c5, y + dt * (a51 * k1 + a52 * k2 + a53 * k3 + a54 * k4));
+    k6 = f(t + dt * c6, y + dt * (a61 * k1 + a62 * k2 + a63 * k3 + a64 * k4 + a65 * k5));
+    k7 = f(t + dt * c7, y + dt * (a71 * k1 + a72 * k2 + a73 * k3 + a74 * k4 + a75 * k5 + a76 * k6));
+    yNew = y + dt * (b1 * k1 + b2 * k2 + b3 * k3 + b4 * k4 + b5 * k5 + b6 * k6);
+    const T error_y = dt * (bHat1 * k1 + bHat2 * k2 + bHat3 * k3 + bHat4 * k4 + bHat5 * k5 + bHat6 * k6 + bHat7 * k7);
+    if (adaptiveTail(yNew, error_y, 5, absTol, relTol, dtMin, dtMax, dt, error, limitCounter, f.counters)) break;
+  }
+  return {yNew, k7, dt, error};
+}
+
+template <class T> static StepResult<T> VERN65_step(const ODEProc<T>& f, double t, const T& y, const T& FSAL, double dt_in, const ODEoptions& options) {  // :377-468
+  constexpr double c2 = 0.06, c3 = 0.09593333333333333, c4 = 0.1439, c5 = 0.4973, c6 = 0.9725, c7 = 0.9995, c8 = 1.0, c9 = 1.0;
+  constexpr double a21 = 0.06;
+  constexpr double a31 = 0.019239962962962962, a32 = 0.07669337037037037;
+  constexpr double a41 = 0.035975, a42 = 0.0, a43 = 0.107925;
+  constexpr double a51 = 1.3186834152331484, a52 = 0.0, a53 = -5.042058063628562, a54 = 4.220674648395414;
+  constexpr double a61 = -41.87259166432751, a62 = 0.0, a63 = 159.43256216313748, a64 = -122.11921356501004, a65 = 5.531743066200053;
+  constexpr double a71 = -54.430156935316504, a72 = 0.0, a73 = 207.06725136501848, a74 = -158.61081378459, a75 = 6.991816585950242, a76 = -0.01859723106220323;
+  constexpr double a81 = -54.66374178728198, a82 = 0.0, a83 = 207.95280625538936, a84 = -159.2889574744995, a85 = 7.018743740796944, a86 = -0.018338785905045722, a87 = -0.0005119484997882099;
+  constexpr double a91 = 0.03438957868357036, a92 = 0.0, a93 = 0.0, a94 = 0.25826245556335037, a95 = 0.4209371189673537, a96 = 4.405396469669310, a97 = -176.48311902429865, a98 = 172.36413340141507;
+  constexpr double b1 = 0.03438957868357036, b2 = 0.0, b3 = 0.0, b4 = 0.25826245556335034, b5 = 0.42093711896735372, b6 = 4.4053964696693102, b7 = -176.48311902429866, b8 = 172.36413340141507;
+  constexpr double bHat1 = 0.04909967648382, bHat2 = 0.0, bHat3 = 0.0, bHat4 = 0.22511122295165, bHat5 = 0.46946822530296, bHat6 = 0.80657922499889, bHat7 = 0.0, bHat8 = -0.60711948917780, bHat9 = 0.05686113944048;
+  const double absTol = options.absTol, relTol = options.relTol, dtMax = options.dtMax, dtMin = options.dtMin;
+  T k1, k2, k3, k4, k5, k6, k7, k8, k9, yNew, yLow;
+  double error = 0.0; int limitCounter = 0; double dt = dt_in;
+  while (limitCounter < 2) {
+    k1 = FSAL;
+    k2 = f(t + dt * c2, y + dt * (a21 * k1));
+    k3 = f(t + dt * c3, y + dt * (a31 * k1 + a32 * k2));
+    k4 = f(t + dt * c4, y + dt * (a41 * k1 + a42 * k2 + a43 * k3));
+    k5 = f(t + dt * c5, y + dt * (a51 * k1 + a52 * k2 + a53 * k3 + a54 * k4));
+    k6 = f(t + dt * c6, y + dt * (a61 * k1 + a62 * k2 + a63 * k3 + a64 * k4 + a65 * k5));
+    k7 = f(t + dt * c7, y + dt * (a71 * k1 + a72 * k2 + a73 * k3 + a74 * k4 + a75 * k5 + a76 * k6));
+    k8 = f(t + dt * c8, y + dt * (a81 * k1 + a82 * k2 + a83 * k3 + a84 * k4 + a85 * k5 + a86 * k6 + a87 * k7));
+    k9 = f(t + dt * c9, y + dt * (a91 * k1 + a92 * k2 + a93 * k3 + a94 * k4 + a95 * k5 + a96 * k6 + a97 * k7 + a98 * k8));
+    yNew = y + dt * (b1 * k1 + b2 * k2 + b3 * k3 + b4 * k4 + b5 * k5 + b6 * k6 + b7 * k7 + b8 * k8);
+    yLow = y + dt * (bHat1 * k1 + bHat2 * k2 + bHat3 * k3 + bHat4 * k4 + bHat5 * k5 + bHat6 * k6 + bHat7 * k7 + bHat8 * k8 + bHat9 * k9);
+    const T error_y = yNew - yLow;
+    if (adaptiveTail(yNew, error_y, 6, absTol, relTol, dtMin, dtMax, dt, error, limitCounter, f.counters)) break;
+  }
+  return {yNew, k9, dt, error};
+}
+
+template <class T>
+using IntegratorProc = StepResult<T> (*)(const ODEProc<T>&, double, const T&, const T&, double, const ODEoptions&);  // ode.nim:38
+
+struct Method { int id; const char* name; bool useFSAL; double order; bool adaptive; };
+// solveODE dispatch table — ode.nim:607-649
+static const Method kMethods[] = {
+    {0, "rk4", false, 4.0, false},      {1, "dopri54", true, 5.0, true},   {2, "tsit54", true, 5.0, true},
+    {3, "vern65", true, 6.0, true},     {4, "bs32", true, 3.0, true},      {5, "rk21", false, 2.0, true},
+    {6, "heun2", false, 2.0, false},    {7, "ralston2", false, 2.0, false}, {8, "kutta3", false, 3.0, false},
+    {9, "heun3", false, 3.0, false},    {10, "ralston3", false, 3.0, false}, {11, "ssprk3", false, 3.0, false},
+    {12, "ralston4", false, 4.0, false}, {13, "kutta4", false, 4.0, false},
+};
+template <class T> static IntegratorProc<T> stepperFor(int id) {
+  switch (id) {
+    case 0: return RK4_step<T>;      case 1: return DOPRI54_step<T>;  case 2: return TSIT54_step<T>;
+    case 3: return VERN65_step<T>;   case 4: return BS32_step<T>;     case 5: return RK21_step<T>;
+    case 6: return HEUN2_step<T>;    case 7: return RALSTON2_step<T>; case 8: return KUTTA3_step<T>;
+    case 9: return HEUN3_step<T>;    case 10: return RALSTON3_step<T>; case 11: return SSPRK3_step<T>;
+    case 12: return RALSTON4_step<T>; case 13: return KUTTA4_step<T>;
+  }
+  return nullptr;
+}
+static const Method* methodByName(const char* name) {  // integrator.toLower() — ode.nim:607
+  std::string s(name);
+  for (auto& ch : s) ch = (char)std::tolower((unsigned char)ch);
+  for (const Method& m : kMethods) if (s == m.name) return &m;
+  return nullptr;  // ode.nim:651 ValueError
+}
+
+// ---------------------------------------------------------------------------------------------
+// ODESolver — ode.nim:471-586.  Returns (t, y) with y possibly SHORTER than t (reference quirk:
+// requested times strictly inside the last step are never emitted).
+// ---------------------------------------------------------------------------------------------
+template <class T>
+static void ODESolver(const ODEProc<T>& f, const T& y0, const std::vector<double>& tspan /*sorted*/, const ODEoptions& options,
+                      IntegratorProc<T> integrator, bool useFSAL, double order, bool adaptive,
+                      std::vector<double>& tOut, std::vector<T>& yOut, int64_t maxSteps = -1) {
+  const double t0 = options.tStart;                                                    // :476
+  double t = t0;
+  std::vector<double> tPositive, tNegative;
+  for (double x : tspan) if (x > t0) tPositive.push_back(x);                           // :479
+  for (double x : tspan) if (x < t0) tNegative.push_back(x);                           // :480
+  std::reverse(tNegative.begin(), tNegative.end());
+  std::vector<T> yPositive, yNegative;
+  T y = y0;                                                                            // :482 clone
+  std::vector<T> yZero; std::vector<double> tZero;
+  if (std::find(tspan.begin(), tspan.end(), t0) != tspan.end()) { yZero.push_back(y); tZero.push_back(t0); }  // :485-487
+  const double dtMax = options.dtMax, dtMin = options.dtMin;
+  double dt, dtInit;
+  if (adaptive) { dtInit = std::sqrt(dtMax * dtMin); dt = dtInit; }                    // :491-493
+  else { dtInit = options.dt; dt = dtInit; }                                           // :494-496
+  struct Iter { double t; T y; T dy; };
+  Iter lastIter{t0, y, f(t0, y)};                                                      // :498
+  const bool useDense = (tspan.size() != 2);                                           // :499-502
+  long denseIndex = 0;
+  double error = 0.0;
+  T FSAL = f(t0, y);                                                                   // :506
+  double tEnd;
+  Counters* cnt = f.counters;
+  if (0 < tPositive.size()) {                                                          // :508
+    dt = dtInit;
+    tEnd = tPositive[0]; for (size_t i = 1; i < tPositive.size(); ++i) tEnd = nmax(tEnd, tPositive[i]);  // :510
+    const long high = (long)tPositive.size() - 1;
+    while (t < tEnd) {                                                                 // :511
+      if (useDense) {
+        if (high < denseIndex) break;                                                  // :513-514
+        while (tPositive[denseIndex] <= t) {                                           // :515
+          if (useFSAL) yPositive.push_back(hermiteSpline(tPositive[denseIndex], lastIter.t, t, lastIter.y, y, lastIter.dy, FSAL));
+          else         yPositive.push_back(hermiteSpline(tPositive[denseIndex], lastIter.t, t, lastIter.y, y, lastIter.dy, f(t, y)));
+          denseIndex += 1;
+          if (high < denseIndex) break;                                                // :523-524
+        }
+      }
+      dt = nmin(dt, tEnd - t);                                                         // :525
+      if (useDense) {
+        if (useFSAL) lastIter = Iter{t, y, FSAL};                                      // :528
+        else         lastIter = Iter{t, y, f(t, y)};                                   // :530
+      }
+      StepResult<T> r = integrator(f, t, y, FSAL, dt, options);                        // :531
+      y = r.yNew; FSAL = r.fsal; dt = r.dt; error = r.error;
+      t += dt;                                                                         // :532
+      if (cnt) cnt->steps++;
+      if (adaptive) {
+        if (error == 0.0) dt *= 5;                                                     // :534-535
+        else dt = dt * nmin(4, nmax(0.125, 0.9 * std::pow(1 / error, 1 / order)));     // :537
+        if (dt < dtMin) dt = dtMin;                                                    // :538-539
+        else if (dtMax < dt) dt = dtMax;                                               // :540-541
+      }
+      if (cnt && cnt->nanAbort) break;                        // deviation: NaN abort (see adaptiveTail)
+      if (maxSteps >= 0 && cnt && cnt->steps >= maxSteps) break;
+    }
+    yPositive.push_back(y);                                                            // :542
+  }
+  if (0 < tNegative.size()) {                                                          // :544
+    // g(t, y) = -f(-t, y) — a closure over f, exactly as the reference builds it              // :545
+    struct GEnv { ODEProc<T> f; } genv{f};
+    struct Shim { static T call(double tt, const T& yy, const void* env) { const GEnv* e = (const GEnv*)env; return -(e->f)(-tt, yy); } };
+    const ODEProc<T> g{Shim::call, &genv, cnt, false};
+    FSAL = g(-t0, y0);                                                                 // :546
+    dt = dtInit;                                                                       // :547
+    lastIter = Iter{-t0, y0, FSAL};                                                    // :548
+    double mn = tNegative[0]; for (size_t i = 1; i < tNegative.size(); ++i) mn = nmin(mn, tNegative[i]);
+    tEnd = -mn;                                                                        // :549
+    t = -t0;                                                                           // :550
+    y = y0;                                                                            // :551
+    denseIndex = 0;                                                                    // :552
+    const long high = (long)tNegative.size() - 1;
+    while (t < tEnd) {                                                                 // :553
+      if (useDense) {
+        if (high < denseIndex) break;                                                  // :555-556
+        while (-tNegative[denseIndex] <= t) {                                          // :557
+          if (useFSAL) yNegative.push_back(hermiteSpline(-tNegative[denseIndex], lastIter.t, t, lastIter.y, y, lastIter.dy, FSAL));
+          else         yNegative.push_back(hermiteSpline(-tNegative[denseIndex], lastIter.t, t, lastIter.y, y, lastIter.dy, g(t, y)));
+          denseIndex += 1;
+          if (high < denseIndex) break;                                                // :565-566
+        }
+      }
+      dt = nmin(dt, tEnd - t);                                                         // :567
+      if (useDense) {
+        if (useFSAL) lastIter = Iter{t, y, FSAL};                                      // :570
+        else         lastIter = Iter{t, y, g(t, y)};                                   // :572
+      }
+      StepResult<T> r = integrator(g, t, y, FSAL, dt, options);                        // :573
+      y = r.yNew; FSAL = r.fsal; dt = r.dt; error = r.error;
+      t += dt;                                                                         // :574
+      if (cnt) cnt->steps++;
+      if (adaptive) {
+        if (error == 0.0) dt *= 5;                                                     // :576-577
+        else dt = dt * nmin(4, nmax(0.125, 0.9 * std::pow(1 / error, 1 / order)));     // :579
+        if (dt < dtMin) dt = dtMin;                                                    // :580-581
+        else if (dtMax < dt) dt = dtMax;                                               // :582-583
+      }
+      if (cnt && cnt->nanAbort) break;
+      if (maxSteps >= 0 && cnt && cnt->steps >= maxSteps) break;
+    }
+    yNegative.push_back(y);                                                            // :584
+  }
+  // :585-586
+  tOut.clear(); yOut.clear();
+  for (auto it = tNegative.rbegin(); it != tNegative.rend(); ++it) tOut.push_back(*it);
+  for (double x : tZero) tOut.push_back(x);
+  for (double x : tPositive) tOut.push_back(x);
+  for (auto it = yNegative.rbegin(); it != yNegative.rend(); ++it) yOut.push_back(*it);
+  for (auto& v : yZero) yOut.push_back(v);
+  for (auto& v : yPositive) yOut.push_back(v);
+}
+
+// solveODE — ode.nim:589-651
+template <class T>
+static int solveODE(const ODEProc<T>& f, const T& y0, const double* tspan, int nT, const ODEoptions& options,
+                    const char* integrator, std::vector<double>& tOut, std::vector<T>& yOut) {
+  const Method* m = methodByName(integrator);
+  if (!m) return -2;  // ValueError "... is not a valid integrator" :651
+  std::vector<double> ts(tspan, tspan + nT);
+  std::sort(ts.begin(), ts.end());  // tspan.sorted()
+  ODESolver<T>(f, y0, ts, options, stepperFor<T>(m->id), m->useFSAL, m->order, m->adaptive, tOut, yOut);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// RHS library restated on the CPU (definitions: include/nnhip_ode.h, enum nnhip_rhs_kind).
+// The reference takes an arbitrary user closure; these are the closures the tests/bench supply.
+// ---------------------------------------------------------------------------------------------
+enum RhsKind { RHS_NEG_Y = 0, RHS_LINEAR = 1, RHS_LORENZ = 2, RHS_RING = 3, RHS_AFFINE_T = 4, RHS_VANDERPOL = 5 };
+
+static double rhsScalar(double t, const double& y, const void* env) {
+  const double* p = (const double*)env;  // p[0] = kind, p[1..] = params
+  switch ((int)p[0]) {
+    case RHS_NEG_Y: return -y;                      // ode.nim:16-17
+    case RHS_LINEAR: return p[1] * y;               // tests/test_ode.nim:5   (-0.1 * y)
+    case RHS_AFFINE_T: return p[1] * y + p[2] * t;  // time-dependent probe
+  }
+  return NAN;
+}
+static Vec rhsVector(double t, const Vec& y, const void* env) {
+  const double* p = (const double*)env;
+  const size_t d = y.components.size();
+  Vec r; r.components.resize(d);
+  switch ((int)p[0]) {
+    case RHS_NEG_Y: for (size_t i = 0; i < d; ++i) r.components[i] = -y.components[i]; break;
+    case RHS_LINEAR: for (size_t i = 0; i < d; ++i) r.components[i] = y.components[i] * p[1]; break;  // tests/test_ode.nim:6 (-0.1 * y -> y[i]*d)
+    case RHS_AFFINE_T: for (size_t i = 0; i < d; ++i) r.components[i] = p[1] * y.components[i] + p[2] * t; break;
+    case RHS_LORENZ: {  // sigma, rho, beta = p[1..3]
+      const double x = y.components[0], yy = y.components[1], z = y.components[2];
+      r.components[0] = p[1] * (yy - x);
+      r.components[1] = x * (p[2] - z) - yy;
+      r.components[2] = x * yy - p[3] * z;
+      break;
+    }
+    case RHS_RING: {  // y_i' = -((i+1)/d) * y_i + c * y_{(i+1) mod d}, c = p[1]
+      for (size_t i = 0; i < d; ++i)
+        r.components[i] = -((double)(i + 1) / (double)d) * y.components[i] + p[1] * y.components[(i + 1) % d];
+      break;
+    }
+    case RHS_VANDERPOL: {  // mu = p[1]
+      const double x = y.components[0], v = y.components[1];
+      r.components[0] = v;
+      r.components[1] = p[1] * ((1.0 - x * x) * v) - x;
+      break;
+    }
+    default: for (size_t i = 0; i < d; ++i) r.components[i] = NAN;
+  }
+  return r;
+}
+
+}  // namespace oracle
+
+// =============================================================================================
+// C entry points for ctypes (tests / smoke / bench cpu_baseline only)
+// =============================================================================================
+extern "C" {
+
+struct oracle_options { double dt, dtMax, dtMin, tStart, absTol, relTol, scaleMax, scaleMin; };
+struct oracle_stats { int64_t rhs_evals, steps, rejected; int32_t n_t, n_y, nan_abort, _pad; };
+
+// newODEoptions (ode.nim:78-102). Returns 0, or -1 (ValueError) with nothing written.
+int oracle_new_options(oracle_options* out, double dt, double absTol, double relTol, double dtMax, double dtMin,
+                       double scaleMax, double scaleMin, double tStart) {
+  try {
+    oracle::ODEoptions o = oracle::newODEoptions(dt, absTol, relTol, dtMax, dtMin, scaleMax, scaleMin, tStart);
+    std::memcpy(out, &o, sizeof(o));
+    return 0;
+  } catch (const std::invalid_argument&) { return -1; }
+}
+
+// Is `name` a valid integrator (case-insensitive)? returns method id or -2.
+int oracle_integrator_id(const char* name) {
+  const oracle::Method* m = oracle::methodByName(name);
+  return m ? m->id : -2;
+}
+
+// One IVP. dim == 0 → scalar `float` state path (T = float); dim >= 1 → Vector[float] path of that length.
+// y_out is [n_t][max(dim,1)] row-major; only the first stats->n_y rows are written (reference quirk A.8).
+int oracle_solve_ode(int rhs_kind, const double* rhs_params, int n_params, int dim, const double* y0, const double* tspan,
+                     int n_t, const oracle_options* opt, const char* integrator, double* t_out, double* y_out,
+                     oracle_stats* stats) {
+  using namespace oracle;
+  std::vector<double> env(1 + (size_t)n_params);
+  env[0] = rhs_kind;
+  for (int i = 0; i < n_params; ++i) env[1 + i] = rhs_params[i];
+  ODEoptions o; std::memcpy(&o, opt, sizeof(o));
+  Counters cnt;
+  std::vector<double> tO;
+  int rc;
+  int ny = 0;
+  try {
+    if (dim == 0) {
+      ODEProc<double> f{rhsScalar, env.data(), &cnt};
+      std::vector<double> yO;
+      rc = solveODE<double>(f, y0[0], tspan, n_t, o, integrator, tO, yO);
+      if (rc) return rc;
+      ny = (int)yO.size();
+      for (int j = 0; j < ny; ++j) y_out[j] = yO[j];
+    } else {
+      ODEProc<Vec> f{rhsVector, env.data(), &cnt};
+      Vec v0; v0.components.assign(y0, y0 + dim);
+      std::vector<Vec> yO;
+      rc = solveODE<Vec>(f, v0, tspan, n_t, o, integrator, tO, yO);
+      if (rc) return rc;
+      ny = (int)yO.size();
+      for (int j = 0; j < ny; ++j)
+        for (int c = 0; c < dim; ++c) y_out[(size_t)j * dim + c] = yO[j].components[c];
+    }
+  } catch (const std::invalid_argument&) { return -1; }
+  for (size_t j = 0; j < tO.size(); ++j) t_out[j] = tO[j];
+  if (stats) {
+    stats->rhs_evals = cnt.rhsEvals; stats->steps = cnt.steps; stats->rejected = cnt.rejected;
+    stats->n_t = (int)tO.size(); stats->n_y = ny; stats->nan_abort = cnt.nanAbort; stats->_pad = 0;
+  }
+  return 0;
+}
+
+// Batch of independent IVPs = the reference called once per IVP (ode.nim:589). Layout of y0 / y_out:
+//   layout 0 (SoA): y0[c*N + i], y_out[(j*dimv + c)*N + i];  layout 1 (AoS): y0[i*dimv + c], y_out[(j*N + i)*dimv + c]
+// with dimv = max(dim,1). ny_out[i] (nullable) = number of y rows the reference returns for IVP i;
+// rows >= ny_out[i] are filled with NaN. steps_out / rejected_out nullable per-IVP counters.
+// n_threads > 1 uses OpenMP over IVPs (all-cores CPU baseline); 1 = the single-threaded reference.
+int oracle_solve_ode_batch(int rhs_kind, const double* rhs_params, int n_params, int dim, int layout, const double* y0,
+                           int64_t N, const double* tspan, int n_t, const oracle_options* opt, const char* integrator,
+                           double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out, int64_t* rejected_out,
+                           int n_threads) {
+  if (oracle_integrator_id(integrator) < 0) return -2;
+  const int dimv = dim > 0 ? dim : 1;
+  int rc_all = 0;
+#pragma omp parallel for schedule(static) num_threads(n_threads) if (n_threads > 1)
+  for (int64_t i = 0; i < N; ++i) {
+    std::vector<double> y0i(dimv), tO(n_t), yO((size_t)n_t * dimv);
+    for (int c = 0; c < dimv; ++c) y0i[c] = layout == 0 ? y0[(size_t)c * N + i] : y0[(size_t)i * dimv + c];
+    oracle_stats st{};
+    int rc = oracle_solve_ode(rhs_kind, rhs_params, n_params, dim, y0i.data(), tspan, n_t, opt, integrator, tO.data(),
+                              yO.data(), &st);
+    if (rc) { rc_all = rc; continue; }
+    if (i == 0 && t_out) for (int j = 0; j < st.n_t; ++j) t_out[j] = tO[j];
+    for (int j = 0; j < n_t; ++j)
+      for (int c = 0; c < dimv; ++c) {
+        const double v = j < st.n_y ? yO[(size_t)j * dimv + c] : NAN;
+        if (layout == 0) y_out[((size_t)j * dimv + c) * N + i] = v;
+        else y_out[((size_t)j * N + i) * dimv + c] = v;
+      }
+    if (ny_out) ny_out[i] = st.n_y;
+    if (steps_out) steps_out[i] = st.steps;
+    if (rejected_out) rejected_out[i] = st.rejected;
+  }
+  return rc_all;
+}
+
+// One IntegratorProc call (ode.nim:38) on one IVP — for checking the step-streaming kernels.
+// in: t, y[dimv], fsal[dimv], dt;  out: y_new[dimv], fsal_new[dimv], *dt_used, *error
+int oracle_step(int rhs_kind, const double* rhs_params, int n_params, int dim, const char* integrator, const oracle_options* opt,
+                double t, const double* y, const double* fsal, double dt, double* y_new, double* fsal_new, double* dt_used,
+                double* error) {
+  using namespace oracle;
+  const Method* m = methodByName(integrator);
+  if (!m) return -2;
+  std::vector<double> env(1 + (size_t)n_params);
+  env[0] = rhs_kind;
+  for (int i = 0; i < n_params; ++i) env[1 + i] = rhs_params[i];
+  ODEoptions o; std::memcpy(&o, opt, sizeof(o));
+  if (dim == 0) {
+    ODEProc<double> f{rhsScalar, env.data(), nullptr};
+    StepResult<double> r = stepperFor<double>(m->id)(f, t, y[0], fsal[0], dt, o);
+    y_new[0] = r.yNew; fsal_new[0] = r.fsal; *dt_used = r.dt; *error = r.error;
+  } else {
+    ODEProc<Vec> f{rhsVector, env.data(), nullptr};
+    Vec vy, vf; vy.components.assign(y, y + dim); vf.components.assign(fsal, fsal + dim);
+    StepResult<Vec> r = stepperFor<Vec>(m->id)(f, t, vy, vf, dt, o);
+    for (int c = 0; c < dim; ++c) { y_new[c] = r.yNew.components[c]; fsal_new[c] = r.fsal.components[c]; }
+    *dt_used = r.dt; *error = r.error;
+  }
+  return 0;
+}
+
+// RHS evaluation alone (to pin the RHS library definitions).
+int oracle_rhs(int rhs_kind, const double* rhs_params, int n_params, int dim, double t, const double* y, double* dy) {
+  using namespace oracle;
+  std::vector<double> env(1 + (size_t)n_params);
+  env[0] = rhs_kind;
+  for (int i = 0; i < n_params; ++i) env[1 + i] = rhs_params[i];
+  if (dim == 0) { dy[0] = rhsScalar(t, y[0], env.data()); return 0; }
+  Vec vy; vy.components.assign(y, y + dim);
+  Vec r = rhsVector(t, vy, env.data());
+  for (int c = 0; c < dim; ++c) dy[c] = r.components[c];
+  return 0;
+}
+
+// hermiteSpline (utils.nim:273-279) on scalars, and linspace (utils.nim:498-507)
+double oracle_hermite_spline(double x, double x1, double x2, double y1, double y2, double dy1, double dy2) {
+  return oracle::hermiteSpline<double>(x, x1, x2, y1, y2, dy1, dy2);
+}
+int oracle_linspace(double x1, double x2, int N, double* out) {
+  if (N <= 0) return -1;  // ValueError utils.nim:500-501
+  const double dx = (x2 - x1) / (double)(N - 1);
+  int k = 0;
+  out[k++] = x1;
+  for (int i = 1; i <= N - 2; ++i) out[k++] = x1 + dx * (double)i;
+  out[k++] = x2;  // N == 1 yields two points in the reference as well (x1, x2); caller must size N+1
+  return k;
+}
+
+// Vector operator probes (tests/test_vector.nim semantics). op: 0 '+', 1 '-', 2 scalar*V, 3 abs, 4 *. 5 /. 6 d +. V
+int oracle_vector_op(int op, const double* a, int na, const double* b, int nb, double d, double* out) {
+  using namespace oracle;
+  Vec va, vb; va.components.assign(a, a + na); if (b) vb.components.assign(b, b + nb);
+  try {
+    Vec r;
+    switch (op) {
+      case 0: r = va + vb; break;
+      case 1: r = va - vb; break;
+      case 2: r = d * va; break;
+      case 3: r = nabs(va); break;
+      case 4: r = dotMul(va, vb); break;
+      case 5: r = dotDiv(va, vb); break;
+      case 6: r = dotAdd(d, va); break;
+      case 7: out[0] = nsum(va); return 1;
+      default: return -2;
+    }
+    for (size_t i = 0; i < r.components.size(); ++i) out[i] = r.components[i];
+    return (int)r.components.size();
+  } catch (const std::invalid_argument&) { return -1; }  // ValueError utils.nim:26
+}
+
+}  // extern "C"

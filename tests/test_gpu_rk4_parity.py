@@ -1,0 +1,116 @@
+"""GPU parity of the RK4 hot path (ode.nim:180-189 + ODESolver loop :511-542) against the CPU oracle.
+
+Tolerance stated by BASELINE.json's north_star: 1e-10 abs for fixed-step RK4.  Because the device code is
+built -ffp-contract=off with the reference's operation order we additionally assert BIT equality.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_FIXED = 1e-10
+
+
+def _c1(n=1024):
+    return 1.0 + np.arange(n, dtype=np.float64) * 2.0 ** -10
+
+
+def test_c1_fused_solve_matches_oracle(nn, oracle, dev):
+    """BASELINE config C1: dy/dt=-y, 1024 scalar IVPs, dt=2^-10, 1000 steps."""
+    import torch
+    O = oracle
+    y0 = _c1()
+    dt = 2.0 ** -10
+    tspan = [0.0, 1000 * dt]
+    t, y, cnt = nn.solveODE(nn.Rhs.neg_y(), torch.from_numpy(y0).to(dev), tspan, nn.newODEoptions(dt=dt), integrator="rk4",
+                            return_counts=True)
+    ref = O.solve_ode_batch(O.RHS_NEG_Y, [], y0, len(y0), 0, tspan, O.new_options(dt=dt), "rk4")
+    got = y.cpu().numpy()
+    assert np.array_equal(t, ref["t"])
+    assert np.abs(got[-1] - ref["y"][-1, 0]).max() <= TOL_FIXED
+    assert np.array_equal(got, ref["y"][:, 0, :]), "expected bit-exact agreement"
+    assert np.array_equal(cnt["steps"].cpu().numpy(), ref["steps"])
+    assert (cnt["steps"].cpu().numpy() == 1000).all()
+    assert np.array_equal(cnt["ny"].cpu().numpy(), ref["ny"])
+    # SURVEY Appendix B known-answer (independent restatement): y0=1.0 -> 0x1.81a455c174b97p-2
+    assert float(got[-1][0]).hex() == "0x1.81a455c174b97p-2"
+
+
+@pytest.mark.parametrize("pingpong", [False, True])
+def test_c1_step_streaming_matches_oracle(nn, oracle, dev, pingpong):
+    import torch
+    O = oracle
+    y0 = _c1()
+    dt = 2.0 ** -10
+    y = torch.from_numpy(y0).to(dev)
+    scratch = torch.empty_like(y) if pingpong else None
+    yf, nsteps = nn.fixedStream(nn.Rhs.neg_y(), y, 0.0, 1000 * dt, nn.newODEoptions(dt=dt), integrator="rk4", scratch=scratch)
+    ref = O.solve_ode_batch(O.RHS_NEG_Y, [], y0, len(y0), 0, [0.0, 1000 * dt], O.new_options(dt=dt), "rk4")
+    assert nsteps == 1000
+    assert np.array_equal(yf.cpu().numpy(), ref["y"][-1, 0])
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 255, 256, 2047, 2048, 2049, 4097, 100_003])
+def test_stream_ragged_sizes(nn, oracle, dev, n):
+    """Ragged batch sizes exercise the vector kernel's scalar tail tile."""
+    import torch
+    O = oracle
+    rng = np.random.default_rng(n)
+    y0 = rng.uniform(-2.0, 2.0, n)
+    dt = 1e-3  # non-dyadic: exercises the drifting t += dt loop count as well
+    opt, oo = nn.newODEoptions(dt=dt), O.new_options(dt=dt)
+    yf, nsteps = nn.fixedStream(nn.Rhs.linear(-0.7), torch.from_numpy(y0).to(dev), 0.0, 0.05, opt, integrator="rk4")
+    ref = O.solve_ode_batch(O.RHS_LINEAR, [-0.7], y0, n, 0, [0.0, 0.05], oo, "rk4")
+    assert nsteps == ref["steps"][0]
+    assert np.array_equal(yf.cpu().numpy(), ref["y"][-1, 0])
+
+
+def test_empty_batch(nn, dev):
+    import torch
+    y0 = torch.empty(0, dtype=torch.float64, device=dev)
+    t, y = nn.solveODE(nn.Rhs.neg_y(), y0, [0.0, 1.0], nn.newODEoptions(dt=0.25), integrator="rk4")
+    assert y.shape == (2, 0) and list(t) == [0.0, 1.0]
+
+
+def test_reference_harness_dense_forward_backward(nn, oracle, dev):
+    """tests/test_ode.nim:5-46 harness: f=-0.1*y, tspan=linspace(-10,10,100), tStart=0 not in tspan ->
+    backward AND forward branches with dense Hermite output; `t == tspan` and |y-exp(-0.1t)| <= 1e-4."""
+    import torch
+    O = oracle
+    ts = O.linspace(-10.0, 10.0, 100)
+    y0 = np.array([1.0, 0.5, 2.0, -1.25])
+    opt, oo = nn.newODEoptions(dt=1e-2), O.new_options(dt=1e-2)
+    t, y = nn.solveODE(nn.Rhs.linear(-0.1), torch.from_numpy(y0).to(dev), ts, opt, integrator="rk4")
+    assert np.array_equal(t, ts)  # check t == tspan
+    got = y.cpu().numpy()
+    assert np.abs(got[:, 0] - np.exp(-0.1 * ts)).max() <= 1e-4
+    ref = O.solve_ode_batch(O.RHS_LINEAR, [-0.1], y0, len(y0), 0, ts, oo, "rk4")
+    assert np.abs(got - ref["y"][:, 0, :]).max() <= TOL_FIXED
+    assert np.array_equal(got, ref["y"][:, 0, :])
+
+
+def test_c2_full_size_properties(nn, oracle, dev):
+    """BASELINE config C2 at full size (1e7 IVPs) through size-independent properties:
+    (1) oracle parity on a fixed 4096-index subsample, (2) exact linearity in y0 under power-of-two
+    scaling (RK4 on a linear RHS commutes with exact scalings), (3) fused == streamed bitwise,
+    (4) monotone in y0 (the RK4 amplification factor is a positive constant)."""
+    import torch
+    from numericalnim_amd import distributed as nd
+    O = oracle
+    n, dt, nsteps = 10_000_000, 2.0 ** -10, 100
+    y0 = nd.c2_y0_torch(0, n, dev)
+    opt = nn.newODEoptions(dt=dt)
+    y = y0.clone()
+    yf, k = nn.fixedStream(nn.Rhs.neg_y(), y, 0.0, nsteps * dt, opt, integrator="rk4")
+    assert k == nsteps
+    idx = (np.arange(4096, dtype=np.int64) * 2441) % n
+    ref = O.solve_ode_batch(O.RHS_NEG_Y, [], nd.c2_y0_numpy(0, n)[idx], len(idx), 0, [0.0, nsteps * dt], O.new_options(dt=dt), "rk4")
+    assert np.array_equal(yf[torch.from_numpy(idx).to(dev)].cpu().numpy(), ref["y"][-1, 0])
+    y2 = (y0 * 4.0).clone()
+    y2f, _ = nn.fixedStream(nn.Rhs.neg_y(), y2, 0.0, nsteps * dt, opt, integrator="rk4")
+    assert torch.equal(y2f, yf * 4.0)
+    _, yfused = nn.solveODE(nn.Rhs.neg_y(), y0, [0.0, nsteps * dt], opt, integrator="rk4")
+    assert torch.equal(yfused[-1], yf)
+    assert torch.equal(yfused[0], y0)
+    order = torch.argsort(y0[:1 << 20])
+    assert bool((torch.diff(yf[:1 << 20][order]) >= 0).all())
