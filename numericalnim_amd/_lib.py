@@ -54,6 +54,31 @@ SIGNATURES = {
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7, the same as /opt/rocm's).
+    A process must use ONE HIP runtime: device pointers and streams handed over from torch are only valid in
+    the runtime that created them.  If our library were loaded first it would bind to /opt/rocm's copy and
+    torch would then load a second runtime next to it (symptom: hipErrorNoDevice from our launches).  So when
+    torch is installed, load ITS runtime first; our NEEDED libamdhip64.so.7 then resolves to it by SONAME.
+    Non-Python consumers (the Nim shim, C++) simply use the system runtime the library is linked against."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """The loaded C-ABI library.  Raises (never falls back) when it is missing."""
     global _lib
@@ -62,6 +87,7 @@ def lib():
             raise ImportError(
                 f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C numericalnim_amd/csrc`). numericalnim_amd has no CPU fallback.")
+        _preload_torch_hip_runtime()
         h = C.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)  # AttributeError if the .so lacks a declared symbol

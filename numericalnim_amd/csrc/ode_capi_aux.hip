@@ -29,8 +29,7 @@ template <class RHS>
 hipError_t launch_rhs_batch(int64_t N, int64_t is, int64_t cs, double t, const double* y, double* dy, const Params& P, hipStream_t s) {
   const int64_t grid = (N + kBlock - 1) / kBlock;
   if (grid <= 0) return hipSuccess;
-  hipLaunchKernelGGL((rhs_batch_kernel<RHS>), dim3((unsigned)grid), dim3(kBlock), 0, s, N, is, cs, t, y, dy, P);
-  return hipGetLastError();
+  return launch_kernel(rhs_batch_kernel<RHS>, dim3((unsigned)grid), dim3(kBlock), s, N, is, cs, t, y, dy, P);
 }
 
 // hermiteSpline (utils.nim:273-279) over a flat batch
@@ -52,9 +51,8 @@ int nnhip_hermite_spline_f64_dev(double x, double x1, double x2, const double* y
   if (n < 0 || (n > 0 && (!y1 || !y2 || !dy1 || !dy2 || !out))) return NNHIP_EVALUE;
   if (n == 0) return NNHIP_OK;
   const int64_t grid = (n + nnhip::kBlock - 1) / nnhip::kBlock;
-  hipLaunchKernelGGL(nnhip::hermite_kernel, dim3((unsigned)grid), dim3(nnhip::kBlock), 0, (hipStream_t)stream, x, x1, x2, y1, y2,
-                     dy1, dy2, out, n);
-  return hipGetLastError() == hipSuccess ? NNHIP_OK : NNHIP_EHIP;
+  return nnhip::launch_kernel(nnhip::hermite_kernel, dim3((unsigned)grid), dim3(nnhip::kBlock), (hipStream_t)stream, x, x1, x2, y1,
+                              y2, dy1, dy2, out, n) == hipSuccess ? NNHIP_OK : NNHIP_EHIP;
 }
 
 int nnhip_ode_rhs_batch_f64_dev(int rhs_kind, const double* rhs_params, int n_params, int64_t N, int dim, int layout, double t,

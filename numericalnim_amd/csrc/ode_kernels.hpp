@@ -9,6 +9,10 @@
 //                      independent loads in flight per lane (the BASELINE.json headline kernel;
 //                      algorithmic traffic 16 B per trajectory-step)                 -> HBM bound
 #pragma once
+#include <tuple>
+#include <type_traits>
+#include <utility>
+
 #include "ode_device.hpp"
 
 namespace nnhip {
@@ -55,6 +59,17 @@ using SolveLaunchFn = hipError_t (*)(const SolveArgs&, hipStream_t);
 using StepLaunchFn = hipError_t (*)(const StepArgs&, int negate, hipStream_t);
 
 constexpr int kBlock = 256;
+
+// Launch through hipLaunchKernel so the returned status belongs to THIS launch (hipGetLastError() can hand
+// back a stale error left by an unrelated runtime call of the host process).
+template <class... KArgs, class... Args>
+inline hipError_t launch_kernel(void (*kernel)(KArgs...), dim3 grid, dim3 block, hipStream_t s, Args&&... args) {
+  std::tuple<std::decay_t<KArgs>...> pack(std::forward<Args>(args)...);
+  void* ptrs[sizeof...(KArgs)];
+  int k = 0;
+  std::apply([&](auto&... a) { ((ptrs[k++] = (void*)&a), ...); }, pack);
+  return hipLaunchKernel((const void*)kernel, grid, block, ptrs, 0, s);
+}
 
 // ------------------------------------------------------------------------------------------------
 // fused solve, thread per IVP
@@ -174,8 +189,7 @@ template <int METHOD, class RHS>
 hipError_t launch_solve_tpi(const SolveArgs& a, hipStream_t s) {
   const int64_t grid = (a.N + kBlock - 1) / kBlock;
   if (grid <= 0) return hipSuccess;
-  hipLaunchKernelGGL((solve_tpi_kernel<METHOD, RHS>), dim3((unsigned)grid), dim3(kBlock), 0, s, a);
-  return hipGetLastError();
+  return launch_kernel(solve_tpi_kernel<METHOD, RHS>, dim3((unsigned)grid), dim3(kBlock), s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -218,9 +232,8 @@ template <int METHOD, class RHS>
 hipError_t launch_step_tpi(const StepArgs& a, int negate, hipStream_t s) {
   const int64_t grid = (a.N + kBlock - 1) / kBlock;
   if (grid <= 0) return hipSuccess;
-  if (negate) hipLaunchKernelGGL((step_tpi_kernel<METHOD, RHS, true>), dim3((unsigned)grid), dim3(kBlock), 0, s, a);
-  else        hipLaunchKernelGGL((step_tpi_kernel<METHOD, RHS, false>), dim3((unsigned)grid), dim3(kBlock), 0, s, a);
-  return hipGetLastError();
+  if (negate) return launch_kernel(step_tpi_kernel<METHOD, RHS, true>, dim3((unsigned)grid), dim3(kBlock), s, a);
+  return launch_kernel(step_tpi_kernel<METHOD, RHS, false>, dim3((unsigned)grid), dim3(kBlock), s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -265,9 +278,8 @@ hipError_t launch_rk4_stream_vec(const double* yin, double* yout, int64_t n, dou
   const int64_t per = (int64_t)kBlock * 2 * VEC;
   const int64_t grid = (n + per - 1) / per;
   if (grid <= 0) return hipSuccess;
-  if (negate) hipLaunchKernelGGL((rk4_stream_vec_kernel<RHS1, true, VEC>), dim3((unsigned)grid), dim3(kBlock), 0, s, yin, yout, n, t, dt, P);
-  else        hipLaunchKernelGGL((rk4_stream_vec_kernel<RHS1, false, VEC>), dim3((unsigned)grid), dim3(kBlock), 0, s, yin, yout, n, t, dt, P);
-  return hipGetLastError();
+  if (negate) return launch_kernel(rk4_stream_vec_kernel<RHS1, true, VEC>, dim3((unsigned)grid), dim3(kBlock), s, yin, yout, n, t, dt, P);
+  return launch_kernel(rk4_stream_vec_kernel<RHS1, false, VEC>, dim3((unsigned)grid), dim3(kBlock), s, yin, yout, n, t, dt, P);
 }
 
 // ------------------------------------------------------------------------------------------------
