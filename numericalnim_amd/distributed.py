@@ -27,11 +27,10 @@ def all_gather_states(local, group=None):
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    if local.dim() == 1:
-        out = torch.empty(world * local.shape[0], dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
-        return out
-    # [..., n_local] -> gather along a new leading axis, then move it next to the IVP axis
-    parts = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(parts, local.contiguous(), group=group)
+    loc = local.contiguous()
+    flat = torch.empty(world * loc.numel(), dtype=loc.dtype, device=loc.device)
+    dist.all_gather_into_tensor(flat, loc.view(-1), group=group)  # one collective: RCCL over xGMI on GPUs, gloo on CPU
+    if loc.dim() == 1:
+        return flat
+    parts = flat.view((world,) + tuple(loc.shape))  # [world, ..., n_local] -> concatenate along the IVP axis
     return torch.cat(list(parts.unbind(0)), dim=-1)

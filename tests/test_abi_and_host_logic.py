@@ -1,0 +1,128 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/*.h
+declares, and its host-only logic (option normalisation, integrator dispatch, output time grid) matches the
+reference semantics (cross-checked with the oracle).  No compute entry is called without a GPU — except to
+assert that it FAILS loudly (there is no CPU fallback)."""
+import ctypes as C
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    names = set()
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        src = open(h).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        for m in re.finditer(r"\b(nnhip_[a-z0-9_]+)\s*\(", src):
+            names.add(m.group(1))
+    return names
+
+
+def test_library_exports_every_declared_symbol(nn):
+    from numericalnim_amd import _lib
+    lib = C.CDLL(_lib.SO_PATH)
+    declared = _declared_functions()
+    assert len(declared) >= 18
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/nnhip_ode.h but not exported"
+    assert declared == set(_lib.SIGNATURES), "python binding table out of sync with the header"
+    assert _lib.lib().nnhip_abi_version() == 1
+
+
+def test_no_oracle_or_cpu_fallback_in_product():
+    """The product tree must not reference the oracle (parity would be void)."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "numericalnim_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.lower() or f in (), f"{f} mentions the oracle"
+    for f in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        assert "oracle" not in open(f).read().lower()
+
+
+def test_new_options_semantics(nn):
+    o = nn.newODEoptions()  # DEFAULT_ODEoptions (ode.nim:78-79,104)
+    assert (o.dt, o.absTol, o.relTol, o.dtMax, o.dtMin, o.scaleMax, o.scaleMin, o.tStart) == (1e-4, 1e-4, 1e-4, 1e-2, 1e-4, 4.0, 0.1, 0.0)
+    o = nn.newODEoptions(dt=-1e-3, absTol=-2e-5, relTol=-3e-5, dtMax=-1.0, dtMin=-1e-3, scaleMax=-5.0, scaleMin=-0.5, tStart=-2.0)
+    assert (o.dt, o.absTol, o.relTol, o.dtMax, o.dtMin, o.scaleMax, o.scaleMin, o.tStart) == (1e-3, 2e-5, 3e-5, 1.0, 1e-3, 5.0, 0.5, -2.0)
+    for kw in (dict(dtMax=1e-5, dtMin=1e-4), dict(scaleMax=0.5), dict(scaleMin=2.0)):
+        with pytest.raises(ValueError):
+            nn.newODEoptions(**kw)
+
+
+def test_options_match_oracle(nn, oracle):
+    a = nn.newODEoptions(dt=-0.5, relTol=1e-9, tStart=3.0)
+    b = oracle.new_options(dt=-0.5, relTol=1e-9, tStart=3.0)
+    assert bytes(a) == bytes(b)
+
+
+def test_integrator_dispatch(nn):
+    L = nn._lib.lib()
+    # names / (useFSAL, order, adaptive) as solveODE passes them (ode.nim:607-649)
+    want = {"dopri54": (1, 5.0, 1), "rk21": (0, 2.0, 1), "bs32": (1, 3.0, 1), "rk4": (0, 4.0, 0), "heun2": (0, 2.0, 0),
+            "ralston2": (0, 2.0, 0), "kutta3": (0, 3.0, 0), "heun3": (0, 3.0, 0), "ralston3": (0, 3.0, 0), "ssprk3": (0, 3.0, 0),
+            "ralston4": (0, 4.0, 0), "kutta4": (0, 4.0, 0), "vern65": (1, 6.0, 1), "tsit54": (1, 5.0, 1)}
+    assert sorted(want) == sorted(nn.allODE)
+    for name, (fs, order, ad) in want.items():
+        i = L.nnhip_ode_integrator_id(name.upper().encode())  # toLower (ode.nim:607)
+        assert i >= 0 and L.nnhip_ode_integrator_name(i).decode() == name
+        f, o, a = C.c_int(), C.c_double(), C.c_int()
+        assert L.nnhip_ode_integrator_traits(i, C.byref(f), C.byref(o), C.byref(a)) == 0
+        assert (f.value, o.value, a.value) == (fs, order, ad)
+    assert L.nnhip_ode_integrator_id(b"rk5") == -2
+    with pytest.raises(ValueError, match="not a valid integrator"):
+        nn.solveODE(nn.Rhs.neg_y(), np.ones(3), [0.0, 1.0], integrator="rk5")
+
+
+@pytest.mark.parametrize("tspan,tstart", [([0.0, 1.0], 0.0), ([1.0, -1.0, 0.0], 0.0), ([3.0, 1.0, 2.0], 0.0), ([-3.0, -1.0], 0.0),
+                                          ([0.5, 1.0, 1.5, 2.5], 1.5), ([0.0, 0.0, 1.0], 0.0), (list(np.linspace(-10, 10, 100)), 0.0),
+                                          ([2.0], 0.0), ([], 0.0)])
+def test_time_grid_matches_oracle(nn, oracle, tspan, tstart):
+    L = nn._lib.lib()
+    o = nn.newODEoptions(dt=0.25, tStart=tstart)
+    ts = np.asarray(tspan, dtype=np.float64)
+    out = np.empty(max(len(ts), 1))
+    n = C.c_int()
+    assert L.nnhip_ode_time_grid(C.byref(o), ts.ctypes.data_as(C.POINTER(C.c_double)), len(ts), out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(n)) == 0
+    if len(ts):
+        t_ref, _, _ = oracle.solve_ode(oracle.RHS_NEG_Y, [], 1.0, ts, oracle.new_options(dt=0.25, tStart=tstart), "rk4")
+        assert np.array_equal(out[:n.value], t_ref)
+    else:
+        assert n.value == 0
+
+
+def test_supported_matrix(nn):
+    L = nn._lib.lib()
+    R = nn.Rhs
+    for integ in (0, 1, 2):
+        assert L.nnhip_ode_supported(integ, R.NEG_Y, 1, 0, 0) == 1
+        assert L.nnhip_ode_supported(integ, R.LINEAR, 3, 1, 0) == 1
+        assert L.nnhip_ode_supported(integ, R.LORENZ, 3, 0, 0) == 1
+        assert L.nnhip_ode_supported(integ, R.LORENZ, 2, 0, 0) == 0
+        assert L.nnhip_ode_supported(integ, R.LORENZ, 3, 0, 1) == 1
+    assert L.nnhip_ode_supported(99, 0, 1, 0, 0) == 0
+
+
+def test_compute_fails_loudly_without_gpu(nn):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(nn.NnhipError, match="(no CPU fallback|hipGetDeviceCount)"):
+        nn.solveODE(nn.Rhs.neg_y(), np.ones(4), [0.0, 1.0], nn.newODEoptions(dt=0.25), integrator="rk4")
+    with pytest.raises(ValueError):
+        nn.solveODE(nn.Rhs.neg_y(), torch.ones(4, dtype=torch.float64), [0.0, 1.0], integrator="rk4")  # CPU tensor refused
+
+
+def test_argument_validation(nn):
+    with pytest.raises(KeyError):
+        nn.solveODE(nn.Rhs.linear(), np.ones(3), [0.0, 1.0], integrator="rk4")      # ctx.fValues lacks "a"
+    ctx = nn.newNumContext()
+    ctx.setF("a", -0.1)
+    assert ctx.getF("a") == -0.1 and nn.Rhs.linear().params(ctx) == [-0.1]
+    ctx["k"] = 3
+    assert ctx["k"] == 3

@@ -1,0 +1,184 @@
+"""DOPRI54 / Tsit54 (ode.nim:237-374, controller :57-76, driver :471-586) on the GPU vs the live oracle at
+batch sizes the oracle finishes in seconds, plus full-size properties for BASELINE configs C3."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL_ADAPTIVE = 1e-6
+LOR = [10.0, 28.0, 8.0 / 3.0]
+
+
+def _lorenz_y0(n):
+    return np.stack([1.0 + (np.arange(n) % 1024) * 2.0 ** -20, np.ones(n), np.ones(n)])  # BASELINE C3
+
+
+@pytest.mark.parametrize("integrator", ["dopri54", "tsit54"])
+@pytest.mark.parametrize("okey", ["default", "tight"])
+def test_c3_lorenz_small_batch(nn, oracle, dev, integrator, okey):
+    import torch
+    O = oracle
+    kw = {} if okey == "default" else dict(absTol=1e-10, relTol=1e-10, dtMin=1e-6, dtMax=1e-1)
+    n = 2048
+    y0 = _lorenz_y0(n)
+    t, y, cnt = nn.solveODE(nn.Rhs.lorenz(), torch.from_numpy(y0).to(dev), [0.0, 1.0], nn.newODEoptions(**kw), integrator=integrator,
+                            return_counts=True)
+    ref = O.solve_ode_batch(O.RHS_LORENZ, LOR, y0, n, 3, [0.0, 1.0], O.new_options(**kw), integrator, n_threads=8)
+    got = y.cpu().numpy()
+    assert np.abs(got - ref["y"]).max() <= TOL_ADAPTIVE
+    assert np.array_equal(cnt["steps"].cpu().numpy(), ref["steps"])
+    assert np.array_equal(cnt["rejected"].cpu().numpy(), ref["rejected"])
+    frac_exact = float((got == ref["y"]).mean())
+    assert frac_exact > 0.5  # pow() is the only non-bit-reproducible op; most trajectories still agree bitwise
+
+
+@pytest.mark.parametrize("integrator", ["rk4", "dopri54", "tsit54"])
+def test_vector3_reference_harness(nn, oracle, dev, integrator):
+    """tests/test_ode.nim:139-185 shape: Vector[float] of 3 equal components, f = -0.1*y, dense output both ways."""
+    import torch
+    O = oracle
+    ts = O.linspace(-10.0, 10.0, 100)
+    y0 = np.ones((3, 5)) * np.array([1.0, 0.5, 2.0, -1.0, 1.5])
+    t, y = nn.solveODE(nn.Rhs.linear(-0.1), torch.from_numpy(y0).to(dev), ts, nn.newODEoptions(relTol=1e-8, dt=1e-2), integrator=integrator)
+    assert np.array_equal(t, ts)
+    got = y.cpu().numpy()
+    ref = O.solve_ode_batch(O.RHS_LINEAR, [-0.1], y0, 5, 3, ts, O.new_options(relTol=1e-8, dt=1e-2), integrator)
+    assert np.abs(got - ref["y"]).max() <= (1e-10 if integrator == "rk4" else TOL_ADAPTIVE)
+    err = np.sqrt(((got[:, :, 0] - np.exp(-0.1 * ts)[:, None]) ** 2).sum(axis=1)) / 3.0   # isClose on Vector (utils.nim:252)
+    assert np.all(err <= 1e-8)
+
+
+@pytest.mark.parametrize("integrator", ["dopri54", "tsit54"])
+def test_step_api_matches_oracle_step(nn, oracle, dev, integrator):
+    """nnhip_ode_step_batch_f64_dev == one IntegratorProc call (ode.nim:38) per IVP, per-IVP t and dt."""
+    import torch
+    O = oracle
+    n = 257
+    rng = np.random.default_rng(5)
+    y = rng.uniform(-5, 5, (3, n)) + np.array([[0.0], [0.0], [20.0]])
+    t = rng.uniform(0, 2, n)
+    dt = 10 ** rng.uniform(-4, -1.3, n)   # some large enough to be rejected and shrunk
+    opt_kw = dict(absTol=1e-8, relTol=1e-8, dtMin=1e-7, dtMax=1e-1)
+    fs = np.stack([O.rhs(O.RHS_LORENZ, LOR, t[i], list(y[:, i])) for i in range(n)], axis=1)
+    yn, fn, dtu, err = nn.integratorStep(nn.Rhs.lorenz(), torch.from_numpy(t).to(dev), torch.from_numpy(y).to(dev),
+                                         torch.from_numpy(fs).to(dev), torch.from_numpy(dt).to(dev), nn.newODEoptions(**opt_kw),
+                                         integrator=integrator)
+    yn, fn, dtu, err = (x.cpu().numpy() for x in (yn, fn, dtu, err))
+    oo = O.new_options(**opt_kw)
+    shrunk = 0
+    for i in range(n):
+        ryn, rfn, rdt, rerr = O.step(O.RHS_LORENZ, LOR, integrator, oo, t[i], list(y[:, i]), list(fs[:, i]), dt[i])
+        assert np.abs(yn[:, i] - ryn).max() <= TOL_ADAPTIVE and np.abs(fn[:, i] - rfn).max() <= 1e-4
+        assert abs(dtu[i] - rdt) <= 1e-12 * abs(rdt) and abs(err[i] - rerr) <= 1e-9 * max(1.0, abs(rerr))
+        shrunk += rdt < dt[i]
+    assert shrunk > 10  # the in-step retry path (ode.nim:58-76) was exercised
+
+
+def test_rhs_library_matches_oracle(nn, oracle, dev):
+    """Pins the compiled-in RHS definitions (include/nnhip_ode.h) bitwise."""
+    import ctypes as C
+    import torch
+    O = oracle
+    L = nn._lib.lib()
+    rng = np.random.default_rng(11)
+    cases = [(O.RHS_NEG_Y, [], 1), (O.RHS_NEG_Y, [], 4), (O.RHS_LINEAR, [-0.1], 3), (O.RHS_AFFINE_T, [-0.5, 0.25], 2),
+             (O.RHS_LORENZ, LOR, 3), (O.RHS_VANDERPOL, [1.5], 2), (O.RHS_RING, [0.1], 4)]
+    for kind, params, dim in cases:
+        n = 100
+        y = rng.normal(size=(dim, n))
+        yt = torch.from_numpy(y).to(dev)
+        out = torch.empty_like(yt)
+        p = np.asarray(params, dtype=np.float64)
+        rc = L.nnhip_ode_rhs_batch_f64_dev(kind, p.ctypes.data_as(C.POINTER(C.c_double)) if len(p) else None, len(p), n, dim, 0, 0.75,
+                                           yt.data_ptr(), out.data_ptr(), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        ref = np.stack([np.atleast_1d(O.rhs(kind, params, 0.75, list(y[:, i]))) for i in range(n)], axis=1)
+        assert np.array_equal(out.cpu().numpy(), ref), (kind, dim)
+
+
+def test_hermite_kernel_matches_oracle(nn, oracle, dev):
+    import torch
+    O = oracle
+    L = nn._lib.lib()
+    rng = np.random.default_rng(3)
+    n = 1000
+    a = [torch.from_numpy(rng.normal(size=n)).to(dev) for _ in range(4)]
+    out = torch.empty(n, dtype=torch.float64, device=dev)
+    assert L.nnhip_hermite_spline_f64_dev(0.3, 0.1, 0.9, a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), a[3].data_ptr(), out.data_ptr(), n, None) == 0
+    torch.cuda.synchronize()
+    an = [x.cpu().numpy() for x in a]
+    ref = np.array([O.hermite_spline(0.3, 0.1, 0.9, an[0][i], an[1][i], an[2][i], an[3][i]) for i in range(n)])
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("integrator", ["dopri54", "tsit54"])
+def test_c3_full_size_properties(nn, oracle, dev, integrator):
+    """BASELINE C3 at full size (1e6 Lorenz IVPs): y0 repeats with period 1024, so (1) the result must be
+    exactly periodic in the IVP index (trajectories are independent: idempotence under batch position),
+    (2) the first period equals the oracle, (3) every IVP ends at tEnd with ny == 2."""
+    import torch
+    O = oracle
+    n = 1_000_000
+    y0 = torch.from_numpy(_lorenz_y0(n)).to(dev)
+    t, y, cnt = nn.solveODE(nn.Rhs.lorenz(), y0, [0.0, 1.0], integrator=integrator, return_counts=True)
+    yf = y[-1]
+    assert torch.equal(y[0], y0)
+    m = (n // 1024) * 1024
+    assert torch.equal(yf[:, :m].reshape(3, -1, 1024), yf[:, :1024].reshape(3, 1, 1024).expand(3, m // 1024, 1024))
+    ref = O.solve_ode_batch(O.RHS_LORENZ, LOR, _lorenz_y0(1024), 1024, 3, [0.0, 1.0], O.new_options(), integrator, n_threads=8)
+    assert np.abs(yf[:, :1024].cpu().numpy() - ref["y"][-1]).max() <= TOL_ADAPTIVE
+    assert bool((cnt["ny"] == 2).all())
+    assert np.array_equal(cnt["steps"][:1024].cpu().numpy(), ref["steps"])
+
+
+def test_host_pointer_entry_and_stats(nn, oracle, dev):
+    """nnhip_ode_solve_batch_f64 (host buffers in, host buffers out) + aggregate stats."""
+    O = oracle
+    n = 1000
+    y0 = _lorenz_y0(n)
+    st = nn.ode.Stats()
+    kw = dict(absTol=1e-6, relTol=1e-6, dtMin=1e-9, dtMax=1.0)
+    t, y, cnt = nn.solveODE(nn.Rhs.lorenz(), y0, [0.0, 2.0, 5.0], nn.newODEoptions(**kw), integrator="dopri54", stats=st, return_counts=True)
+    ref = O.solve_ode_batch(O.RHS_LORENZ, LOR, y0, n, 3, [0.0, 2.0, 5.0], O.new_options(**kw), "dopri54", n_threads=8)
+    # Lorenz amplifies ulp-level pow() differences by ~e^{0.9 T}: compare at T=2 tightly, at T=5 loosely
+    assert np.abs(y[1] - ref["y"][1]).max() <= 1e-6
+    assert np.abs(y[2] - ref["y"][2]).max() <= 1e-3
+    assert st.steps_total == int(cnt["steps"].sum()) and st.rejected_total == int(cnt["rejected"].sum())
+    assert st.steps_max == int(cnt["steps"].max()) and st.ny_min == 3 and st.n_t_out == 3 and st.nan_aborts == 0
+    assert st.rejected_total > 0 and st.kernel_ms > 0
+    assert abs(st.steps_total - int(ref["steps"].sum())) <= 0.001 * ref["steps"].sum()
+
+
+def test_edge_cases(nn, oracle, dev):
+    import torch
+    O = oracle
+    f = nn.Rhs.neg_y()
+    # N = 1; tspan unsorted with tStart inside; duplicate tStart
+    for tspan in ([1.0, -1.0, 0.0], [0.0, 0.0, 1.0], [-2.0, -1.0], [2.0], [0.5, 0.25, 0.75, 1.0]):
+        for integ in ("rk4", "dopri54", "tsit54"):
+            t, y, cnt = nn.solveODE(f, torch.tensor([1.5], dtype=torch.float64, device=dev), tspan, nn.newODEoptions(dt=1e-2),
+                                    integrator=integ, return_counts=True)
+            rt, ry, st = O.solve_ode(O.RHS_NEG_Y, [], 1.5, tspan, O.new_options(dt=1e-2), integ)
+            assert np.array_equal(t, rt)
+            g = y[:, 0].cpu().numpy()
+            assert int(cnt["ny"][0]) == st.n_y
+            assert np.abs(g[:st.n_y] - ry).max() <= 1e-9
+            assert np.isnan(g[st.n_y:]).all()
+    # NaN initial state: adaptive trajectory is aborted and flagged instead of spinning forever
+    y0 = torch.tensor([1.0, float("nan"), 2.0], dtype=torch.float64, device=dev)
+    t, y = nn.solveODE(f, y0, [0.0, 1.0], integrator="dopri54")
+    g = y[-1].cpu().numpy()
+    assert np.isnan(g[1]) and not np.isnan(g[0]) and not np.isnan(g[2])
+    # options that would make the reference loop forever are refused
+    with pytest.raises(ValueError):
+        nn.solveODE(f, y0, [0.0, 1.0], nn.newODEoptions(dt=0.0), integrator="rk4")
+    with pytest.raises(ValueError):
+        nn.solveODE(f, y0, [0.0, 1.0], nn.newODEoptions(dtMin=0.0), integrator="dopri54")
+    # max_steps truncation
+    t, y, cnt = nn.solveODE(f, y0[:1], [0.0, 1.0], nn.newODEoptions(dt=1e-3), integrator="rk4", max_steps=10, return_counts=True)
+    assert int(cnt["steps"][0]) == 10
+    # unsupported combination is reported, not silently emulated
+    with pytest.raises(NotImplementedError):
+        nn.solveODE(nn.Rhs.lorenz(), torch.ones(2, 4, dtype=torch.float64, device=dev), [0.0, 1.0], integrator="rk4")
+    with pytest.raises(NotImplementedError):
+        nn.solveODE(f, y0, [0.0, 1.0], integrator="vern65")

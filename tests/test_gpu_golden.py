@@ -1,0 +1,60 @@
+"""HIP path vs the committed golden fixtures (tests/golden/ode_golden.json) and vs a live oracle run.
+Tolerances (BASELINE.json north_star): fixed-step 1e-10 abs, adaptive 1e-6 abs.  We additionally require
+bit equality for fixed-step and identical accepted/rejected step counts for adaptive runs."""
+import numpy as np
+import pytest
+
+from golden_util import fh, load_cases
+
+pytestmark = pytest.mark.gpu
+TOL_FIXED, TOL_ADAPTIVE = 1e-10, 1e-6
+KEYS = {1: ("a",), 2: ("sigma", "rho", "beta"), 3: ("c",), 4: ("a", "b"), 5: ("mu",)}
+
+
+def _rhs(nn, kind, params):
+    return nn.Rhs(kind, KEYS.get(kind, ()), dict(zip(KEYS.get(kind, ()), params)))
+
+
+@pytest.mark.parametrize("layout", [0, 1], ids=["soa", "aos"])
+@pytest.mark.parametrize("case", load_cases(), ids=lambda c: c["name"])
+def test_hip_matches_golden(nn, dev, case, layout):
+    import torch
+    dim = max(case["dim"], 1)
+    integ = nn._lib.lib().nnhip_ode_integrator_id(case["integrator"].encode())
+    if not nn._lib.lib().nnhip_ode_supported(integ, case["rhs_kind"], dim, layout, 0):
+        pytest.skip("no kernel for this (integrator, rhs, dim) yet")
+    if case["dim"] == 0 and layout == 1:
+        pytest.skip("scalar states have one layout")
+    n = len(case["y0"])
+    y0 = np.stack([fh(y) for y in case["y0"]])  # [n, dim]
+    if case["dim"] == 0:
+        y0t = torch.from_numpy(y0[:, 0].copy()).to(dev)
+    elif layout == 0:
+        y0t = torch.from_numpy(np.ascontiguousarray(y0.T)).to(dev)  # [dim, n]
+    else:
+        y0t = torch.from_numpy(y0.copy()).to(dev)                   # [n, dim]
+    opt = nn.newODEoptions(**case["options"])
+    t, y, cnt = nn.solveODE(_rhs(nn, case["rhs_kind"], fh(case["params"])), y0t, fh(case["tspan"]), opt,
+                            integrator=case["integrator"], layout=layout, return_counts=True)
+    assert np.array_equal(t, fh(case["t"]))
+    got = y.cpu().numpy()
+    ny, steps, rej = (cnt[k].cpu().numpy() for k in ("ny", "steps", "rejected"))
+    for i, exp in enumerate(case["ivps"]):
+        if case["dim"] == 0:
+            g = got[:, i]
+        elif layout == 0:
+            g = got[:, :, i]
+        else:
+            g = got[:, i, :]
+        want = fh(exp["y"]).reshape(exp["n_y"], -1)
+        assert ny[i] == exp["n_y"]
+        gi = g.reshape(len(t), -1)
+        assert np.isnan(gi[exp["n_y"]:]).all()
+        gi = gi[:exp["n_y"]]
+        if case["integrator"] == "rk4":
+            assert np.abs(gi - want).max() <= TOL_FIXED
+            assert np.array_equal(gi, want), "fixed-step results must be bit-exact"
+            assert steps[i] == exp["steps"]
+        else:
+            assert np.abs(gi - want).max() <= TOL_ADAPTIVE
+            assert (steps[i], rej[i]) == (exp["steps"], exp["rejected"])
