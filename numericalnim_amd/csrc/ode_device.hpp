@@ -104,17 +104,81 @@ struct RhsRing {  // dy_c = -((c+1)/d)*y_c + p0*y_{(c+1) mod d}
   }
 };
 
-// f or g(t,y) = -f(-t,y) (ode.nim:545)
+struct StepCtl {  // the option fields the steppers read (ode.nim:283-286)
+  double absTol, relTol, dtMax, dtMin;
+};
+
+// ------------------------------------------------------------------------------------------------
+// "Ops" policies: how one lane sees its IVP.  The steppers and the driver below are written once over
+//   Ops::D          number of state components THIS LANE owns
+//   ops.rhs(t,y,dy) dy = f(t,y), or g(t,y) = -f(-t,y) when NEG (backward branch, ode.nim:545)
+//   ops.norm(...)   scaled RMS error norm of commonAdaptiveMethodCode (ode.nim:61-65)
+// TpiOps: thread-per-IVP — the lane owns the whole state (D = dim), everything in VGPRs.
+// LpsOps: lanes-per-system — DIM lanes of ONE wavefront own one component each (D = 1).  The stage
+//         argument vector is staged in LDS so any component's RHS can read any other component, and the
+//         error norm is reduced across the DIM lanes through LDS in the reference's left-to-right order
+//         (every lane of a system gets the bit-identical `error`, so the group stays in lock-step).
+// ------------------------------------------------------------------------------------------------
 template <class RHS, bool NEG>
-NNHIP_DEV void rhs_eval(double t, const double (&y)[RHS::dim], double (&dy)[RHS::dim], const Params& P) {
-  if constexpr (NEG) {
-    RHS::eval(-t, y, dy, P);
+struct TpiOps {
+  static constexpr int D = RHS::dim;
+  const Params& P;
+  NNHIP_DEV void rhs(double t, const double (&y)[D], double (&dy)[D]) const {
+    if constexpr (NEG) {
+      RHS::eval(-t, y, dy, P);
 #pragma unroll
-    for (int c = 0; c < RHS::dim; ++c) dy[c] = -dy[c];
-  } else {
-    RHS::eval(t, y, dy, P);
+      for (int c = 0; c < D; ++c) dy[c] = -dy[c];
+    } else {
+      RHS::eval(t, y, dy, P);
+    }
   }
+  NNHIP_DEV double norm(const double (&yNew)[D], const double (&err_y)[D], const StepCtl& o) const {
+    double sum = 0.0;  // std/math sum: left to right from 0.0 (utils.nim:233-235)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      const double totalTol = fabs(yNew[c]) * o.relTol + o.absTol;  // absTol +. relTol * abs(yNew)  (:61)
+      const double e = err_y[c] / totalTol;                        // :62
+      sum = sum + e * e;                                           // :63, :65
+    }
+    return sqrt(1.0 / (double)D * sum);  // :65
+  }
+};
+
+// Orders this wavefront's LDS traffic: DS operations of one wave execute in issue order, so all that is
+// needed between a lane's ds_write and another lane's ds_read is that the compiler keeps program order.
+NNHIP_DEV void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+template <class RHS, bool NEG>
+struct LpsOps {
+  static constexpr int D = 1;
+  static constexpr int DIM = RHS::dim;
+  const Params& P;
+  double* ys;  // LDS, DIM doubles: stage argument vector of this lane's system
+  double* es;  // LDS, DIM doubles: squared scaled error components
+  int c;       // component owned by this lane
+  NNHIP_DEV void rhs(double t, const double (&y)[1], double (&dy)[1]) const {
+    ys[c] = y[0];
+    wave_lds_sync();
+    const double v = RHS::comp(NEG ? -t : t, c, ys, P);
+    dy[0] = NEG ? -v : v;
+    wave_lds_sync();  // the next stage overwrites ys
+  }
+  NNHIP_DEV double norm(const double (&yNew)[1], const double (&err_y)[1], const StepCtl& o) const {
+    const double totalTol = fabs(yNew[0]) * o.relTol + o.absTol;
+    const double e = err_y[0] / totalTol;
+    es[c] = e * e;
+    wave_lds_sync();
+    double sum = 0.0;
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) sum = sum + es[j];  // same left-to-right order as utils.nim:233-235
+    wave_lds_sync();
+    return sqrt(1.0 / (double)DIM * sum);
+  }
+};
 
 // ------------------------------------------------------------------------------------------------
 // Butcher tableaux of the embedded FSAL pairs.  A[s][j] = a_{s+2, j+1} (row of stage s+2).
@@ -186,59 +250,41 @@ template <> struct MethodTraits<NNHIP_RK4>     { static constexpr bool fsal = fa
 template <> struct MethodTraits<NNHIP_DOPRI54> { static constexpr bool fsal = true,  adaptive = true;  static constexpr double order = 5.0; };
 template <> struct MethodTraits<NNHIP_TSIT54>  { static constexpr bool fsal = true,  adaptive = true;  static constexpr double order = 5.0; };
 
-struct StepCtl {  // the option fields the steppers read (ode.nim:283-286)
-  double absTol, relTol, dtMax, dtMin;
-};
-
 // ------------------------------------------------------------------------------------------------
-// Steppers, thread-per-IVP.  Signature mirrors IntegratorProc (ode.nim:38):
+// Steppers.  Signature mirrors IntegratorProc (ode.nim:38):
 //   in  (t, y, FSAL, dt)   out (yNew, FSAL', dt used, error);  returns status bits.
 // ------------------------------------------------------------------------------------------------
 constexpr int kStatusNaN = 1;
 
-template <class RHS, bool NEG>
-NNHIP_DEV void rk4_step(double t, double dt, const double (&y)[RHS::dim], double (&yNew)[RHS::dim], const Params& P) {
-  constexpr int D = RHS::dim;  // ode.nim:180-189
+template <class Ops>
+NNHIP_DEV void rk4_step(const Ops& ops, double t, double dt, const double (&y)[Ops::D], double (&yNew)[Ops::D]) {
+  constexpr int D = Ops::D;  // ode.nim:180-189
   double k1[D], k2[D], k3[D], k4[D], ya[D];
-  rhs_eval<RHS, NEG>(t, y, k1, P);
+  ops.rhs(t, y, k1);
   const double hdt = 0.5 * dt;
 #pragma unroll
   for (int c = 0; c < D; ++c) ya[c] = y[c] + hdt * k1[c];          // y + 0.5 * dt * k1
-  rhs_eval<RHS, NEG>(t + 0.5 * dt, ya, k2, P);
+  ops.rhs(t + 0.5 * dt, ya, k2);
 #pragma unroll
   for (int c = 0; c < D; ++c) ya[c] = y[c] + hdt * k2[c];
-  rhs_eval<RHS, NEG>(t + 0.5 * dt, ya, k3, P);
+  ops.rhs(t + 0.5 * dt, ya, k3);
 #pragma unroll
   for (int c = 0; c < D; ++c) ya[c] = y[c] + dt * k3[c];
-  rhs_eval<RHS, NEG>(t + dt, ya, k4, P);
+  ops.rhs(t + dt, ya, k4);
   const double dt6 = dt / 6.0;
 #pragma unroll
   for (int c = 0; c < D; ++c) yNew[c] = y[c] + dt6 * (k1[c] + 2.0 * (k2[c] + k3[c]) + k4[c]);  // :188
-}
-
-// Scaled RMS error norm + accept test + in-step dt shrink: commonAdaptiveMethodCode (ode.nim:57-76).
-// Returns true when the retry loop must stop.
-template <int D>
-NNHIP_DEV double error_norm(const double (&yNew)[D], const double (&err_y)[D], const StepCtl& o) {
-  double sum = 0.0;  // std/math sum: left to right from 0.0 (utils.nim:233-235)
-#pragma unroll
-  for (int c = 0; c < D; ++c) {
-    const double totalTol = fabs(yNew[c]) * o.relTol + o.absTol;  // absTol +. relTol * abs(yNew)  (:61)
-    const double e = err_y[c] / totalTol;                        // :62
-    sum = sum + e * e;                                           // :63, :65
-  }
-  return sqrt(1.0 / (double)D * sum);  // :65
 }
 
 NNHIP_DEV double shrink_factor(double error, double inv_order) {  // min(4, max(0.125, 0.9 * pow(1/error, 1/order)))  (:71,:537)
   return nmin(4.0, nmax(0.125, 0.9 * pow(1.0 / error, inv_order)));
 }
 
-template <int METHOD, class RHS, bool NEG>
-NNHIP_DEV int embedded_step(double t, double& dt, const double (&y)[RHS::dim], double (&fsal)[RHS::dim],
-                            double (&yNew)[RHS::dim], double& error, const StepCtl& o, const Params& P, int64_t& rejected) {
+template <int METHOD, class Ops>
+NNHIP_DEV int embedded_step(const Ops& ops, double t, double& dt, const double (&y)[Ops::D], double (&fsal)[Ops::D],
+                            double (&yNew)[Ops::D], double& error, const StepCtl& o, int64_t& rejected) {
   using T = Tableau<METHOD>;
-  constexpr int D = RHS::dim;
+  constexpr int D = Ops::D;
   constexpr int S = T::S;
   double k[S][D];
   double ya[D], err_y[D];
@@ -256,7 +302,7 @@ NNHIP_DEV int embedded_step(double t, double& dt, const double (&y)[RHS::dim], d
         for (int j = 1; j < s; ++j) acc = acc + T::a(s, j) * k[j][c];
         ya[c] = y[c] + dt * acc;  // y + dt * (a_s1*k1 + ... )
       }
-      rhs_eval<RHS, NEG>(t + dt * T::c(s), ya, k[s], P);
+      ops.rhs(t + dt * T::c(s), ya, k[s]);
     }
     // yNew = y + dt*(b1*k1+...+b6*k6): identical expression to k7's argument (:299-301) -> ya holds it
 #pragma unroll
@@ -273,7 +319,7 @@ NNHIP_DEV int embedded_step(double t, double& dt, const double (&y)[RHS::dim], d
         err_y[c] = yNew[c] - yLow;            // :303
       }
     }
-    error = error_norm<D>(yNew, err_y, o);
+    error = ops.norm(yNew, err_y, o);  // scaled RMS norm (:61-65)
     if (error <= 1.0) break;                                   // :69-70
     if (error != error) { status |= kStatusNaN; break; }       // deviation: the reference would spin forever
     dt = dt * shrink_factor(error, 1.0 / (double)T::ORDER);    // :71
@@ -326,16 +372,16 @@ struct DriveOut {
   int64_t steps, rejected;
 };
 
-template <int METHOD, class RHS, bool NEG, class Emit>
-NNHIP_DEV void drive(const DriveIn& in, const double (&y0)[RHS::dim], const Params& P, Emit&& emit, DriveOut& out) {
-  constexpr int D = RHS::dim;
+template <int METHOD, bool NEG, class Ops, class Emit>
+NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::D], Emit&& emit, DriveOut& out) {
+  constexpr int D = Ops::D;
   using MT = MethodTraits<METHOD>;
   double t = in.tStartEff;
   double y[D], fsal[D], lastY[D], lastDy[D], yNew[D], dyNow[D];
   double lastT = in.tStartEff;
 #pragma unroll
   for (int c = 0; c < D; ++c) y[c] = y0[c];
-  rhs_eval<RHS, NEG>(t, y, fsal, P);  // FSAL = f(t0, y) (:506) / g(-t0, y0) (:546)
+  ops.rhs(t, y, fsal);  // FSAL = f(t0, y) (:506) / g(-t0, y0) (:546)
 #pragma unroll
   for (int c = 0; c < D; ++c) { lastY[c] = y[c]; lastDy[c] = fsal[c]; }  // lastIter (:498,:548)
   double dt = in.dtInit;
@@ -349,7 +395,7 @@ NNHIP_DEV void drive(const DriveIn& in, const double (&y0)[RHS::dim], const Para
       if (high < denseIndex) break;  // :513-514
       double treq = NEG ? -in.tReq[denseIndex] : in.tReq[denseIndex];
       if (treq <= t) {
-        if constexpr (!MT::fsal) rhs_eval<RHS, NEG>(t, y, dyNow, P);  // f(t, y, ctx) per emitted point (:521); same value each time
+        if constexpr (!MT::fsal) ops.rhs(t, y, dyNow);  // f(t, y, ctx) per emitted point (:521); same value each time
         while (treq <= t) {  // :515
           const HermiteW w = hermite_weights(treq, lastT, t);
           double yv[D];
@@ -371,14 +417,14 @@ NNHIP_DEV void drive(const DriveIn& in, const double (&y0)[RHS::dim], const Para
 #pragma unroll
         for (int c = 0; c < D; ++c) lastDy[c] = fsal[c];
       } else {
-        rhs_eval<RHS, NEG>(t, y, lastDy, P);
+        ops.rhs(t, y, lastDy);
       }
     }
     if constexpr (METHOD == NNHIP_RK4) {
-      rk4_step<RHS, NEG>(t, dt, y, yNew, P);  // :531
+      rk4_step(ops, t, dt, y, yNew);  // :531
       error = 0.0;
     } else {
-      status |= embedded_step<METHOD, RHS, NEG>(t, dt, y, fsal, yNew, error, in.ctl, P, rejected);
+      status |= embedded_step<METHOD>(ops, t, dt, y, fsal, yNew, error, in.ctl, rejected);
     }
 #pragma unroll
     for (int c = 0; c < D; ++c) y[c] = yNew[c];

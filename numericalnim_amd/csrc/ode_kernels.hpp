@@ -5,6 +5,8 @@
 //                      HBM touched only for y0 in and the requested rows out        -> FP64-VALU bound
 //   step_tpi_kernel    thread-per-IVP single IntegratorProc call (ode.nim:38,531), state streams
 //                      HBM -> VGPR -> HBM once per step                              -> HBM bound
+//   solve_lps_kernel / step_lps_kernel  the same two for larger systems: DIM lanes of one wavefront per
+//                      system, stage argument vector + error components staged in LDS
 //   rk4_stream_vec_kernel  the scalar RK4 instance of the above with 16-byte lane accesses and several
 //                      independent loads in flight per lane (the BASELINE.json headline kernel;
 //                      algorithmic traffic 16 B per trajectory-step)                 -> HBM bound
@@ -72,117 +74,133 @@ inline hipError_t launch_kernel(void (*kernel)(KArgs...), dim3 grid, dim3 block,
 }
 
 // ------------------------------------------------------------------------------------------------
-// fused solve, thread per IVP
+// fused solve: the body shared by the thread-per-IVP and lanes-per-system kernels.  `out`/`y0p` already
+// point at this lane's first owned component of IVP i; D = components owned by the lane.
+// Result rows follow ODESolver's assembly: yNegative.reversed ++ yZero ++ yPositive (ode.nim:585-586).
 // ------------------------------------------------------------------------------------------------
-template <int METHOD, class RHS>
-__global__ __launch_bounds__(kBlock) void solve_tpi_kernel(const SolveArgs a) {
-  constexpr int D = RHS::dim;
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+struct LaneStats {
   unsigned long long steps = 0, rejected = 0;
   int ny = 0x7fffffff, nanAb = 0, trunc = 0;
+};
+
+template <int METHOD, class OpsF, class OpsB>
+NNHIP_DEV void solve_body(const SolveArgs& a, const OpsF& opsF, const OpsB& opsB, const double* y0p, double* out, LaneStats& ls) {
+  constexpr int D = OpsF::D;
+  double y0[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) y0[c] = y0p[c * a.compStride];
+  int rowBase = 0;
+  int status = 0;
+  DriveIn in;
+  in.useDense = a.useDense;
+  in.maxSteps = a.maxSteps;
+  in.ctl = a.ctl;
+  in.dtInit = a.dtInit;
+  const int64_t rs = a.rowStride, cs = a.compStride;
+  // Backward branch first (ode.nim:544-584; the two branches are independent, both restart from y0).
+  // Emission k of this branch is element k of yNegative; the result holds yNegative.reversed(), so it
+  // lands in row nNeg-1-k.
+  if (a.nNeg > 0) {
+    in.tStartEff = -a.t0;
+    in.tEnd = a.tEndNeg;
+    in.tReq = a.tNeg;
+    in.nReq = a.nNeg;
+    DriveOut o;
+    const int nNeg = a.nNeg;
+    drive<METHOD, true>(opsB, in, y0,
+                        [=](int k, const double(&yv)[D]) {
+                          if (k < nNeg) {
+#pragma unroll
+                            for (int c = 0; c < D; ++c) out[(int64_t)(nNeg - 1 - k) * rs + c * cs] = yv[c];
+                          }
+                        },
+                        o);
+    const int m = o.emitted < nNeg ? o.emitted : nNeg;
+    if (m < nNeg) {  // reference quirk: fewer rows than requested -> they close up
+      const int shift = nNeg - m;
+      for (int j = 0; j < m; ++j)
+#pragma unroll
+        for (int c = 0; c < D; ++c) out[(int64_t)j * rs + c * cs] = out[(int64_t)(j + shift) * rs + c * cs];
+    }
+    rowBase = m;
+    status |= o.status;
+    ls.steps += o.steps;
+    ls.rejected += o.rejected;
+  }
+  if (a.nZero > 0) {  // `if t0 in tspan` (ode.nim:485-487)
+#pragma unroll
+    for (int c = 0; c < D; ++c) out[(int64_t)rowBase * rs + c * cs] = y0[c];
+    rowBase += 1;
+  }
+  if (a.nPos > 0) {  // ode.nim:508-542
+    in.tStartEff = a.t0;
+    in.tEnd = a.tEndPos;
+    in.tReq = a.tPos;
+    in.nReq = a.nPos;
+    DriveOut o;
+    const int nPos = a.nPos;
+    const int rb = rowBase;
+    drive<METHOD, false>(opsF, in, y0,
+                         [=](int k, const double(&yv)[D]) {
+                           if (k < nPos) {
+#pragma unroll
+                             for (int c = 0; c < D; ++c) out[(int64_t)(rb + k) * rs + c * cs] = yv[c];
+                           }
+                         },
+                         o);
+    rowBase += o.emitted < nPos ? o.emitted : nPos;
+    status |= o.status;
+    ls.steps += o.steps;
+    ls.rejected += o.rejected;
+  }
+  const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+  for (int j = rowBase; j < a.n_t; ++j)
+#pragma unroll
+    for (int c = 0; c < D; ++c) out[(int64_t)j * rs + c * cs] = qnan;
+  ls.ny = rowBase;
+  ls.nanAb = (status & kStatusNaN) ? 1 : 0;
+  ls.trunc = (status & 2) ? 1 : 0;
+}
+
+// wave-level reduction of the per-IVP statistics, one atomic per wave and field
+NNHIP_DEV void aggregate_stats(unsigned long long* agg, LaneStats ls) {
+  unsigned long long steps = ls.steps, rejected = ls.rejected, smax = ls.steps;
+  int ny = ls.ny, nanAb = ls.nanAb, trunc = ls.trunc;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    steps += __shfl_down(steps, off, 64);
+    rejected += __shfl_down(rejected, off, 64);
+    const unsigned long long om = __shfl_down(smax, off, 64);
+    smax = om > smax ? om : smax;
+    const int on = __shfl_down(ny, off, 64);
+    ny = on < ny ? on : ny;
+    nanAb += __shfl_down(nanAb, off, 64);
+    trunc += __shfl_down(trunc, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&agg[0], steps);
+    atomicAdd(&agg[1], rejected);
+    atomicMax(&agg[2], smax);
+    atomicMin(&agg[3], (unsigned long long)(unsigned)ny);
+    if (nanAb) atomicAdd(&agg[4], (unsigned long long)nanAb);
+    if (trunc) atomicAdd(&agg[5], (unsigned long long)trunc);
+  }
+}
+
+// ---- thread per IVP: state, k1..kS, (t, dt) all in VGPRs -----------------------------------------
+template <int METHOD, class RHS>
+__global__ __launch_bounds__(kBlock) void solve_tpi_kernel(const SolveArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  LaneStats ls;
   if (i < a.N) {
-    double y0[D];
-#pragma unroll
-    for (int c = 0; c < D; ++c) y0[c] = a.y0[i * a.ivpStride + c * a.compStride];
-    double* const out = a.y_out + i * a.ivpStride;
-    int rowBase = 0;
-    int status = 0;
-    DriveIn in;
-    in.useDense = a.useDense;
-    in.maxSteps = a.maxSteps;
-    in.ctl = a.ctl;
-    in.dtInit = a.dtInit;
-    // Backward branch first (ode.nim:544-584; the two branches are independent, both restart from y0).
-    // Emission k of this branch is element k of yNegative; the result holds yNegative.reversed(), so it
-    // lands in row nNeg-1-k.
-    if (a.nNeg > 0) {
-      in.tStartEff = -a.t0;
-      in.tEnd = a.tEndNeg;
-      in.tReq = a.tNeg;
-      in.nReq = a.nNeg;
-      DriveOut o;
-      const int nNeg = a.nNeg;
-      const int64_t rs = a.rowStride, cs = a.compStride;
-      drive<METHOD, RHS, true>(in, y0, a.P,
-                               [=](int k, const double(&yv)[D]) {
-                                 if (k < nNeg) {
-#pragma unroll
-                                   for (int c = 0; c < D; ++c) out[(int64_t)(nNeg - 1 - k) * rs + c * cs] = yv[c];
-                                 }
-                               },
-                               o);
-      int m = o.emitted < nNeg ? o.emitted : nNeg;
-      if (m < nNeg) {  // reference quirk: fewer rows than requested -> they close up
-        const int shift = nNeg - m;
-        for (int j = 0; j < m; ++j)
-#pragma unroll
-          for (int c = 0; c < D; ++c) out[(int64_t)j * rs + c * cs] = out[(int64_t)(j + shift) * rs + c * cs];
-      }
-      rowBase = m;
-      status |= o.status;
-      steps += o.steps;
-      rejected += o.rejected;
-    }
-    if (a.nZero > 0) {  // `if t0 in tspan` (ode.nim:485-487)
-#pragma unroll
-      for (int c = 0; c < D; ++c) out[(int64_t)rowBase * a.rowStride + c * a.compStride] = y0[c];
-      rowBase += 1;
-    }
-    if (a.nPos > 0) {  // ode.nim:508-542
-      in.tStartEff = a.t0;
-      in.tEnd = a.tEndPos;
-      in.tReq = a.tPos;
-      in.nReq = a.nPos;
-      DriveOut o;
-      const int nPos = a.nPos;
-      const int64_t rs = a.rowStride, cs = a.compStride;
-      const int rb = rowBase;
-      drive<METHOD, RHS, false>(in, y0, a.P,
-                                [=](int k, const double(&yv)[D]) {
-                                  if (k < nPos) {
-#pragma unroll
-                                    for (int c = 0; c < D; ++c) out[(int64_t)(rb + k) * rs + c * cs] = yv[c];
-                                  }
-                                },
-                                o);
-      rowBase += o.emitted < nPos ? o.emitted : nPos;
-      status |= o.status;
-      steps += o.steps;
-      rejected += o.rejected;
-    }
-    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-    for (int j = rowBase; j < a.n_t; ++j)
-#pragma unroll
-      for (int c = 0; c < D; ++c) out[(int64_t)j * a.rowStride + c * a.compStride] = qnan;
-    if (a.ny_out) a.ny_out[i] = rowBase;
-    if (a.steps_out) a.steps_out[i] = (int64_t)steps;
-    if (a.rejected_out) a.rejected_out[i] = (int64_t)rejected;
-    ny = rowBase;
-    nanAb = (status & kStatusNaN) ? 1 : 0;
-    trunc = (status & 2) ? 1 : 0;
+    const TpiOps<RHS, false> opsF{a.P};
+    const TpiOps<RHS, true> opsB{a.P};
+    solve_body<METHOD>(a, opsF, opsB, a.y0 + i * a.ivpStride, a.y_out + i * a.ivpStride, ls);
+    if (a.ny_out) a.ny_out[i] = ls.ny;
+    if (a.steps_out) a.steps_out[i] = (int64_t)ls.steps;
+    if (a.rejected_out) a.rejected_out[i] = (int64_t)ls.rejected;
   }
-  if (a.agg) {  // wave-level reduction, one atomic per wave and field
-    unsigned long long smax = steps;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      steps += __shfl_down(steps, off, 64);
-      rejected += __shfl_down(rejected, off, 64);
-      const unsigned long long om = __shfl_down(smax, off, 64);
-      smax = om > smax ? om : smax;
-      const int on = __shfl_down(ny, off, 64);
-      ny = on < ny ? on : ny;
-      nanAb += __shfl_down(nanAb, off, 64);
-      trunc += __shfl_down(trunc, off, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
-      atomicAdd(&a.agg[0], steps);
-      atomicAdd(&a.agg[1], rejected);
-      atomicMax(&a.agg[2], smax);
-      atomicMin(&a.agg[3], (unsigned long long)(unsigned)ny);
-      if (nanAb) atomicAdd(&a.agg[4], (unsigned long long)nanAb);
-      if (trunc) atomicAdd(&a.agg[5], (unsigned long long)trunc);
-    }
-  }
+  if (a.agg) aggregate_stats(a.agg, ls);
 }
 
 template <int METHOD, class RHS>
@@ -192,23 +210,57 @@ hipError_t launch_solve_tpi(const SolveArgs& a, hipStream_t s) {
   return launch_kernel(solve_tpi_kernel<METHOD, RHS>, dim3((unsigned)grid), dim3(kBlock), s, a);
 }
 
+// ---- lanes per system: DIM lanes of one wavefront integrate one DIM-component system -------------
+// Lane (s, c) owns component c of system s: its y, k1..kS, yNew are single VGPR doubles; the stage
+// argument vector and the squared error components of each system live in LDS (2*DIM doubles per system,
+// 4 KiB per 256-thread workgroup).  With the AoS layout a wave's 64 lanes read 512 contiguous bytes.
+template <int METHOD, class RHS>
+__global__ __launch_bounds__(kBlock) void solve_lps_kernel(const SolveArgs a) {
+  constexpr int DIM = RHS::dim;
+  static_assert(64 % DIM == 0, "a system must not straddle wavefronts");
+  __shared__ double lds[2 * kBlock];
+  const int sysInBlock = threadIdx.x / DIM, c = threadIdx.x % DIM;
+  const int64_t i = (int64_t)blockIdx.x * (kBlock / DIM) + sysInBlock;
+  LaneStats ls;
+  if (i < a.N) {
+    double* ys = lds + sysInBlock * DIM;
+    double* es = lds + kBlock + sysInBlock * DIM;
+    const LpsOps<RHS, false> opsF{a.P, ys, es, c};
+    const LpsOps<RHS, true> opsB{a.P, ys, es, c};
+    solve_body<METHOD>(a, opsF, opsB, a.y0 + i * a.ivpStride + c * a.compStride, a.y_out + i * a.ivpStride + c * a.compStride, ls);
+    if (c == 0) {
+      if (a.ny_out) a.ny_out[i] = ls.ny;
+      if (a.steps_out) a.steps_out[i] = (int64_t)ls.steps;
+      if (a.rejected_out) a.rejected_out[i] = (int64_t)ls.rejected;
+    } else {  // count each system once in the aggregate sums
+      ls.steps = 0; ls.rejected = 0; ls.nanAb = 0; ls.trunc = 0;
+    }
+  }
+  if (a.agg) aggregate_stats(a.agg, ls);
+}
+
+template <int METHOD, class RHS>
+hipError_t launch_solve_lps(const SolveArgs& a, hipStream_t s) {
+  constexpr int perBlock = kBlock / RHS::dim;
+  const int64_t grid = (a.N + perBlock - 1) / perBlock;
+  if (grid <= 0) return hipSuccess;
+  return launch_kernel(solve_lps_kernel<METHOD, RHS>, dim3((unsigned)grid), dim3(kBlock), s, a);
+}
+
 // ------------------------------------------------------------------------------------------------
-// one IntegratorProc call, thread per IVP (step-streaming; state in HBM between calls)
+// one IntegratorProc call (step-streaming; state in HBM between calls)
 // ------------------------------------------------------------------------------------------------
-template <int METHOD, class RHS, bool NEG>
-__global__ __launch_bounds__(kBlock) void step_tpi_kernel(const StepArgs a) {
-  constexpr int D = RHS::dim;
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= a.N) return;
+template <int METHOD, class Ops>
+NNHIP_DEV void step_body(const StepArgs& a, const Ops& ops, int64_t i, int64_t base, bool writeScalars) {
+  constexpr int D = Ops::D;
   double y[D], yNew[D];
-  const int64_t base = i * a.ivpStride;
 #pragma unroll
   for (int c = 0; c < D; ++c) y[c] = a.y_in[base + c * a.compStride];
   const double t = a.t_dev ? a.t_dev[i] : a.t_uniform;
   double dt = a.dt_dev ? a.dt_dev[i] : a.dt_uniform;
   double error = 0.0;
   if constexpr (METHOD == NNHIP_RK4) {
-    rk4_step<RHS, NEG>(t, dt, y, yNew, a.P);
+    rk4_step(ops, t, dt, y, yNew);
     if (a.fsal_out) {  // fixed-step methods return yNew in the FSAL slot (ode.nim:189)
 #pragma unroll
       for (int c = 0; c < D; ++c) a.fsal_out[base + c * a.compStride] = yNew[c];
@@ -218,14 +270,24 @@ __global__ __launch_bounds__(kBlock) void step_tpi_kernel(const StepArgs a) {
 #pragma unroll
     for (int c = 0; c < D; ++c) fsal[c] = a.fsal_in[base + c * a.compStride];
     int64_t rej = 0;
-    embedded_step<METHOD, RHS, NEG>(t, dt, y, fsal, yNew, error, a.ctl, a.P, rej);
+    embedded_step<METHOD>(ops, t, dt, y, fsal, yNew, error, a.ctl, rej);
 #pragma unroll
     for (int c = 0; c < D; ++c) a.fsal_out[base + c * a.compStride] = fsal[c];
   }
 #pragma unroll
   for (int c = 0; c < D; ++c) a.y_out[base + c * a.compStride] = yNew[c];
-  if (a.dt_used) a.dt_used[i] = dt;
-  if (a.error) a.error[i] = error;
+  if (writeScalars) {
+    if (a.dt_used) a.dt_used[i] = dt;
+    if (a.error) a.error[i] = error;
+  }
+}
+
+template <int METHOD, class RHS, bool NEG>
+__global__ __launch_bounds__(kBlock) void step_tpi_kernel(const StepArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= a.N) return;
+  const TpiOps<RHS, NEG> ops{a.P};
+  step_body<METHOD>(a, ops, i, i * a.ivpStride, true);
 }
 
 template <int METHOD, class RHS>
@@ -234,6 +296,26 @@ hipError_t launch_step_tpi(const StepArgs& a, int negate, hipStream_t s) {
   if (grid <= 0) return hipSuccess;
   if (negate) return launch_kernel(step_tpi_kernel<METHOD, RHS, true>, dim3((unsigned)grid), dim3(kBlock), s, a);
   return launch_kernel(step_tpi_kernel<METHOD, RHS, false>, dim3((unsigned)grid), dim3(kBlock), s, a);
+}
+
+template <int METHOD, class RHS, bool NEG>
+__global__ __launch_bounds__(kBlock) void step_lps_kernel(const StepArgs a) {
+  constexpr int DIM = RHS::dim;
+  __shared__ double lds[2 * kBlock];
+  const int sysInBlock = threadIdx.x / DIM, c = threadIdx.x % DIM;
+  const int64_t i = (int64_t)blockIdx.x * (kBlock / DIM) + sysInBlock;
+  if (i >= a.N) return;
+  const LpsOps<RHS, NEG> ops{a.P, lds + sysInBlock * DIM, lds + kBlock + sysInBlock * DIM, c};
+  step_body<METHOD>(a, ops, i, i * a.ivpStride + c * a.compStride, c == 0);
+}
+
+template <int METHOD, class RHS>
+hipError_t launch_step_lps(const StepArgs& a, int negate, hipStream_t s) {
+  constexpr int perBlock = kBlock / RHS::dim;
+  const int64_t grid = (a.N + perBlock - 1) / perBlock;
+  if (grid <= 0) return hipSuccess;
+  if (negate) return launch_kernel(step_lps_kernel<METHOD, RHS, true>, dim3((unsigned)grid), dim3(kBlock), s, a);
+  return launch_kernel(step_lps_kernel<METHOD, RHS, false>, dim3((unsigned)grid), dim3(kBlock), s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -247,6 +329,7 @@ __global__ __launch_bounds__(kBlock) void rk4_stream_vec_kernel(const double* __
                                                                 int64_t n, double t, double dt, const Params P) {
   static_assert(RHS1::dim == 1, "scalar RHS only");
   const int64_t tile = (int64_t)blockIdx.x * (kBlock * 2 * VEC);
+  const TpiOps<RHS1, NEG> ops{P};
   double2 v[VEC];
   if (tile + kBlock * 2 * VEC <= n) {  // full tile: unguarded vector accesses
     const double2* src = reinterpret_cast<const double2*>(yin + tile) + threadIdx.x;
@@ -255,8 +338,8 @@ __global__ __launch_bounds__(kBlock) void rk4_stream_vec_kernel(const double* __
 #pragma unroll
     for (int u = 0; u < VEC; ++u) {
       double a0[1] = {v[u].x}, a1[1] = {v[u].y}, r0[1], r1[1];
-      rk4_step<RHS1, NEG>(t, dt, a0, r0, P);
-      rk4_step<RHS1, NEG>(t, dt, a1, r1, P);
+      rk4_step(ops, t, dt, a0, r0);
+      rk4_step(ops, t, dt, a1, r1);
       v[u].x = r0[0];
       v[u].y = r1[0];
     }
@@ -266,7 +349,7 @@ __global__ __launch_bounds__(kBlock) void rk4_stream_vec_kernel(const double* __
   } else {  // ragged tail tile: scalar, bounds-checked
     for (int64_t j = tile + threadIdx.x; j < n; j += kBlock) {
       double a0[1] = {yin[j]}, r0[1];
-      rk4_step<RHS1, NEG>(t, dt, a0, r0, P);
+      rk4_step(ops, t, dt, a0, r0);
       yout[j] = r0[0];
     }
   }
@@ -294,11 +377,20 @@ hipError_t launch_rk4_stream_vec(const double* yin, double* yout, int64_t n, dou
   X(NNHIP_RHS_AFFINE_T, 4, RhsAffineT<4>) X(NNHIP_RHS_LORENZ, 3, RhsLorenz) X(NNHIP_RHS_VANDERPOL, 2, RhsVanDerPol) \
   X(NNHIP_RHS_RING, 4, RhsRing<4>)
 
+// systems integrated by DIM lanes of one wavefront (DIM must divide 64)
+#define NNHIP_FOR_EACH_LPS_RHS(X)                                                                              \
+  X(NNHIP_RHS_RING, 8, RhsRing<8>) X(NNHIP_RHS_RING, 16, RhsRing<16>) X(NNHIP_RHS_RING, 32, RhsRing<32>)       \
+  X(NNHIP_RHS_NEG_Y, 16, RhsNegY<16>) X(NNHIP_RHS_LINEAR, 16, RhsLinear<16>) X(NNHIP_RHS_AFFINE_T, 16, RhsAffineT<16>)
+
 template <int METHOD>
 SolveLaunchFn find_solve_tpi(int rhs_kind, int dim) {
 #define X(kind, d, T) \
   if (rhs_kind == kind && dim == d) return &launch_solve_tpi<METHOD, T>;
   NNHIP_FOR_EACH_TPI_RHS(X)
+#undef X
+#define X(kind, d, T) \
+  if (rhs_kind == kind && dim == d) return &launch_solve_lps<METHOD, T>;
+  NNHIP_FOR_EACH_LPS_RHS(X)
 #undef X
   return nullptr;
 }
@@ -307,6 +399,10 @@ StepLaunchFn find_step_tpi(int rhs_kind, int dim) {
 #define X(kind, d, T) \
   if (rhs_kind == kind && dim == d) return &launch_step_tpi<METHOD, T>;
   NNHIP_FOR_EACH_TPI_RHS(X)
+#undef X
+#define X(kind, d, T) \
+  if (rhs_kind == kind && dim == d) return &launch_step_lps<METHOD, T>;
+  NNHIP_FOR_EACH_LPS_RHS(X)
 #undef X
   return nullptr;
 }
