@@ -29,7 +29,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n-ivp", type=float, default=1e7, help="IVPs per GPU (config C2: 1e7)")
     ap.add_argument("--rk4-steps", type=int, default=1000, help="RK4 time steps per solve (C2: 1000)")
-    ap.add_argument("--pingpong", type=int, default=0, help="1: ping-pong between two state buffers instead of in-place")
+    ap.add_argument("--pingpong", type=int, default=1, help="1: ping-pong between two state buffers (default), 0: update in place")
     ap.add_argument("--no-gather", action="store_true", help="skip the final-state all-gather (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=float, default=2e5, help="IVPs in the CPU-baseline sample")

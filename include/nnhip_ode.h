@@ -87,6 +87,11 @@ int nnhip_device_count(void);            /* >=0, or NNHIP_EHIP                  
 const char* nnhip_last_error(void);      /* thread-local, never NULL                                        */
 const char* nnhip_build_info(void);      /* arch, fp-contract mode, compiler                                */
 
+/* Performance tuning knobs (process-wide; results are bit-identical for every setting):
+ *   "rk4_stream_auto" 0|1 (default 1: choose vec/mode from the working-set size), "rk4_stream_vec" 1|2|4|8,
+ *   "rk4_stream_mode" 0..3 (0 plain, 1 non-temporal, 2 persistent, 3 both), "rk4_stream_blocks_per_cu" 1..64 */
+int nnhip_tune_set(const char* key, int value);
+
 /* ---- options / dispatch (host only, no device needed) ---------------------------------------- */
 /* newODEoptions (ode.nim:78-102): abs() of everything but tStart; NNHIP_EVALUE if |dtMax| < |dtMin|,
  * |scaleMax| < 1 or 1 < |scaleMin|.  Argument order = the Nim proc's. */

@@ -1,0 +1,141 @@
+// numericalnim_hip.hpp — C++17 host-side mirror of the reference's ODE interface over the C ABI (nnhip_ode.h).
+//
+// The reference's host language is Nim; no Nim toolchain exists in the build image, so the host side above the
+// C ABI is provided (a) as the Nim shim a maintainer would add (nim/numericalnim_hip.nim) and
+// (b) as this header for compiled hosts.  Names, argument order, defaults and error behaviour follow
+// /root/reference/src/numericalnim/ode.nim:
+//   ODEoptions / newODEoptions / DEFAULT_ODEoptions   ode.nim:26-34, 78-104     (ValueError -> std::invalid_argument)
+//   NumContext[T, float]                              common/commonTypes.nim:4-39
+//   solveODE(f, y0, tspan, options, ctx, integrator)  ode.nim:589-651
+// What changes is only what must: y0 is a *batch* of initial states and f is an RhsSpec naming a compiled-in
+// device RHS whose parameters are pulled from ctx.fValues (the reference's parameter channel).
+#pragma once
+#include <cstdint>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "nnhip_ode.h"
+
+namespace numericalnim {
+
+using ODEoptions = nnhip_ode_options;
+
+inline void throwOn(int rc) {
+  if (rc == NNHIP_OK) return;
+  const std::string msg = nnhip_last_error();
+  if (rc == NNHIP_EVALUE || rc == NNHIP_EINTEGRATOR) throw std::invalid_argument(msg);  // Nim: ValueError
+  if (rc == NNHIP_ENOMEM) throw std::bad_alloc();
+  throw std::runtime_error("nnhip error " + std::to_string(rc) + ": " + msg);
+}
+
+// ode.nim:78-102 — same parameter order and defaults as the Nim proc
+inline ODEoptions newODEoptions(double dt = 1e-4, double absTol = 1e-4, double relTol = 1e-4, double dtMax = 1e-2,
+                                double dtMin = 1e-4, double scaleMax = 4.0, double scaleMin = 0.1, double tStart = 0.0) {
+  ODEoptions o;
+  throwOn(nnhip_ode_new_options(&o, dt, absTol, relTol, dtMax, dtMin, scaleMax, scaleMin, tStart));
+  return o;
+}
+inline const ODEoptions& DEFAULT_ODEoptions() {  // ode.nim:104
+  static const ODEoptions o = newODEoptions();
+  return o;
+}
+
+// commonTypes.nim:4-39 — the context handed to the RHS; fValues is the float-parameter table
+template <class T>
+struct NumContext {
+  std::map<std::string, double> fValues;
+  std::map<std::string, T> tValues;
+  double getF(const std::string& key) const { return fValues.at(key); }
+  void setF(const std::string& key, double v) { fValues[key] = v; }
+  T& operator[](const std::string& key) { return tValues[key]; }
+};
+
+// Stand-in for the closure ODEProc[T] (ode.nim:36): a compiled-in device RHS + the ctx.fValues keys it reads
+struct RhsSpec {
+  nnhip_rhs_kind kind;
+  std::vector<std::string> keys;
+  std::map<std::string, double> defaults;
+  template <class T>
+  std::vector<double> params(const NumContext<T>* ctx) const {
+    std::vector<double> p;
+    for (const auto& k : keys) {
+      if (ctx) {
+        auto it = ctx->fValues.find(k);
+        if (it != ctx->fValues.end()) { p.push_back(it->second); continue; }
+      }
+      auto d = defaults.find(k);
+      if (d == defaults.end()) throw std::out_of_range("ctx.fValues has no '" + k + "'");  // Nim: KeyError
+      p.push_back(d->second);
+    }
+    return p;
+  }
+};
+inline RhsSpec rhsNegY() { return {NNHIP_RHS_NEG_Y, {}, {}}; }                                  // ode.nim:16-17
+inline RhsSpec rhsLinear() { return {NNHIP_RHS_LINEAR, {"a"}, {}}; }                            // tests/test_ode.nim:5
+inline RhsSpec rhsLinear(double a) { return {NNHIP_RHS_LINEAR, {"a"}, {{"a", a}}}; }
+inline RhsSpec rhsLorenz(double sigma = 10.0, double rho = 28.0, double beta = 8.0 / 3.0) {
+  return {NNHIP_RHS_LORENZ, {"sigma", "rho", "beta"}, {{"sigma", sigma}, {"rho", rho}, {"beta", beta}}};
+}
+inline RhsSpec rhsRing(double c = 0.1) { return {NNHIP_RHS_RING, {"c"}, {{"c", c}}}; }
+inline RhsSpec rhsAffineT(double a, double b) { return {NNHIP_RHS_AFFINE_T, {"a", "b"}, {{"a", a}, {"b", b}}}; }
+inline RhsSpec rhsVanDerPol(double mu = 1.0) { return {NNHIP_RHS_VANDERPOL, {"mu"}, {{"mu", mu}}}; }
+
+// A batch of N initial states of `dim` float64 components (host memory).  dim == 1 is the reference's
+// scalar `float` state; dim > 1 its Vector[float] / seq[float] state.
+struct OdeBatch {
+  int64_t N = 0;
+  int dim = 1;
+  nnhip_layout layout = NNHIP_LAYOUT_SOA;
+  std::vector<double> data;  // [dim][N] (SoA) or [N][dim] (AoS)
+  double& at(int64_t i, int c) { return layout == NNHIP_LAYOUT_SOA ? data[(size_t)c * N + i] : data[(size_t)i * dim + c]; }
+  double at(int64_t i, int c) const { return layout == NNHIP_LAYOUT_SOA ? data[(size_t)c * N + i] : data[(size_t)i * dim + c]; }
+  static OdeBatch zeros(int64_t N, int dim = 1, nnhip_layout layout = NNHIP_LAYOUT_SOA) {
+    OdeBatch b; b.N = N; b.dim = dim; b.layout = layout; b.data.assign((size_t)N * dim, 0.0); return b;
+  }
+};
+
+// Result of a batched solveODE: y[j] is the batch state at t[j] (same layout as y0).  ny[i] = number of rows the
+// reference returns for IVP i (rows beyond are NaN; see nnhip_ode.h).
+struct OdeSolution {
+  std::vector<double> t;
+  std::vector<OdeBatch> y;
+  std::vector<int32_t> ny;
+  nnhip_ode_stats stats{};
+};
+
+// solveODE — ode.nim:589-651.  integrator is the reference's case-insensitive string; unknown -> invalid_argument.
+template <class T = double>
+inline OdeSolution solveODE(const RhsSpec& f, const OdeBatch& y0, const std::vector<double>& tspan,
+                            const ODEoptions& options = DEFAULT_ODEoptions(), const NumContext<T>* ctx = nullptr,
+                            const std::string& integrator = "dopri54", int device = 0, int n_gpus = 1) {
+  const int integ = nnhip_ode_integrator_id(integrator.c_str());
+  if (integ < 0) throw std::invalid_argument(integrator + " is not a valid integrator");  // ode.nim:651
+  const std::vector<double> p = f.params(ctx);
+  const int n_t = (int)tspan.size();
+  OdeSolution sol;
+  sol.t.assign((size_t)std::max(n_t, 1), 0.0);
+  std::vector<double> yout((size_t)n_t * y0.N * y0.dim);
+  sol.ny.assign((size_t)y0.N, 0);
+  int rc;
+  if (n_gpus > 1) {
+    rc = nnhip_ode_solve_batch_multi_gpu_f64(&options, integ, f.kind, p.data(), (int)p.size(), y0.data.data(), y0.N, y0.dim, y0.layout,
+                                             tspan.data(), n_t, sol.t.data(), yout.data(), sol.ny.data(), 0, &sol.stats, n_gpus);
+  } else {
+    rc = nnhip_ode_solve_batch_f64(&options, integ, f.kind, p.data(), (int)p.size(), y0.data.data(), y0.N, y0.dim, y0.layout,
+                                   tspan.data(), n_t, sol.t.data(), yout.data(), sol.ny.data(), nullptr, nullptr, 0, &sol.stats, device);
+  }
+  throwOn(rc);
+  sol.t.resize((size_t)sol.stats.n_t_out);
+  sol.y.resize((size_t)n_t);
+  const size_t row = (size_t)y0.N * y0.dim;
+  for (int j = 0; j < n_t; ++j) {
+    sol.y[j].N = y0.N; sol.y[j].dim = y0.dim; sol.y[j].layout = y0.layout;
+    sol.y[j].data.assign(yout.begin() + (size_t)j * row, yout.begin() + (size_t)(j + 1) * row);
+  }
+  return sol;
+}
+
+}  // namespace numericalnim

@@ -1,0 +1,84 @@
+## numericalnim_hip.nim — the reference-side binding a numericalnim maintainer would add to route batches of
+## independent IVPs to the MI355X backend.  It keeps the `solveODE` / `ODEoptions` / `NumContext` signatures
+## (src/numericalnim/ode.nim:589-591, :26-34, common/commonTypes.nim:4-39) so it drops in behind the existing
+## generic-T dispatch: `T` becomes `OdeBatch` (a batch of float / Vector[float] states) and `f` an `RhsKind`
+## whose parameters are read from `ctx.fValues`.
+##
+## NOT compiled in this repository's build image (no Nim toolchain there); it is the binding shown in
+## INTEGRATION.md.  Build:  nim c -d:release --passL:"-L<repo>/numericalnim_amd/csrc -lnnhip_ode" yourprog.nim
+## (Nim's {.compile.} only drives the configured C compiler, so the hipcc-built library is linked, not compiled.)
+import std/[strformat, tables, algorithm]
+import numericalnim            # ODEoptions, newODEoptions, NumContext, newNumContext stay the reference's own
+
+type
+  NnhipOptions {.bycopy.} = object          ## == ODEoptions field for field (ode.nim:26-34)
+    dt, dtMax, dtMin, tStart, absTol, relTol, scaleMax, scaleMin: cdouble
+  NnhipStats {.bycopy.} = object
+    stepsTotal, rejectedTotal, stepsMax: int64
+    nTOut, nyMin, nanAborts, truncated: int32
+    kernelMs: cdouble
+
+  RhsKind* = enum                           ## include/nnhip_ode.h: enum nnhip_rhs_kind
+    rhsNegY = 0, rhsLinear = 1, rhsLorenz = 2, rhsRing = 3, rhsAffineT = 4, rhsVanDerPol = 5
+  RhsSpec* = object                         ## stands in for ODEProc[T] (ode.nim:36)
+    kind*: RhsKind
+    keys*: seq[string]                      ## ctx.fValues keys, in rhs_params order
+  BatchLayout* = enum layoutSoA = 0, layoutAoS = 1
+  OdeBatch* = object                        ## N states of `dim` float64 components
+    n*: int
+    dim*: int
+    layout*: BatchLayout
+    data*: seq[float]                       ## [dim][N] (SoA) or [N][dim] (AoS)
+
+proc nnhip_last_error(): cstring {.importc, cdecl.}
+proc nnhip_ode_integrator_id(name: cstring): cint {.importc, cdecl.}
+proc nnhip_ode_solve_batch_f64(opt: ptr NnhipOptions, integrator, rhsKind: cint, rhsParams: ptr cdouble, nParams: cint,
+                               y0: ptr cdouble, N: int64, dim, layout: cint, tspan: ptr cdouble, nT: cint,
+                               tOut, yOut: ptr cdouble, nyOut: ptr int32, stepsOut, rejectedOut: ptr int64,
+                               maxSteps: int64, stats: ptr NnhipStats, device: cint): cint {.importc, cdecl.}
+proc nnhip_ode_solve_batch_multi_gpu_f64(opt: ptr NnhipOptions, integrator, rhsKind: cint, rhsParams: ptr cdouble,
+                                         nParams: cint, y0: ptr cdouble, N: int64, dim, layout: cint,
+                                         tspan: ptr cdouble, nT: cint, tOut, yOut: ptr cdouble, nyOut: ptr int32,
+                                         maxSteps: int64, stats: ptr NnhipStats, nGpus: cint): cint {.importc, cdecl.}
+
+proc toC(o: ODEoptions): NnhipOptions =
+  NnhipOptions(dt: o.dt, dtMax: o.dtMax, dtMin: o.dtMin, tStart: o.tStart, absTol: o.absTol, relTol: o.relTol,
+               scaleMax: o.scaleMax, scaleMin: o.scaleMin)
+
+proc check(rc: cint) =
+  if rc == 0: return
+  let msg = $nnhip_last_error()
+  if rc == -1 or rc == -2: raise newException(ValueError, msg)      # as ode.nim:95-100, :651
+  raise newException(IOError, &"nnhip error {rc}: {msg}")
+
+proc solveODE*(f: RhsSpec, y0: OdeBatch, tspan: openArray[float],
+               options: ODEoptions = newODEoptions(), ctx: NumContext[OdeBatch, float] = nil,
+               integrator = "dopri54", nGpus = 1): (seq[float], seq[OdeBatch]) =
+  ## Batched drop-in for ode.nim:589-651: same parameter names, order and defaults; returns (t, y) where
+  ## y[j] is the whole batch at t[j].
+  var ctx = ctx
+  if ctx.isNil: ctx = newNumContext[OdeBatch, float]()               # ode.nim:604-606
+  let integ = nnhip_ode_integrator_id(integrator.cstring)           # toLower + dispatch, ode.nim:607-651
+  if integ < 0: raise newException(ValueError, &"{integrator} is not a valid integrator")
+  var params: seq[cdouble]
+  for k in f.keys: params.add(ctx.fValues[k].cdouble)               # ctx is the parameter channel (ode.nim:599)
+  var opt = options.toC
+  var ts = @tspan
+  var tOut = newSeq[cdouble](max(ts.len, 1))
+  var yOut = newSeq[cdouble](ts.len * y0.n * y0.dim)
+  var ny = newSeq[int32](y0.n)
+  var stats: NnhipStats
+  var y0d = y0.data
+  let pp = if params.len > 0: addr params[0] else: nil
+  if nGpus > 1:
+    check nnhip_ode_solve_batch_multi_gpu_f64(addr opt, integ, f.kind.cint, pp, params.len.cint, addr y0d[0], y0.n.int64,
+                                              y0.dim.cint, y0.layout.cint, addr ts[0], ts.len.cint, addr tOut[0],
+                                              addr yOut[0], addr ny[0], 0, addr stats, nGpus.cint)
+  else:
+    check nnhip_ode_solve_batch_f64(addr opt, integ, f.kind.cint, pp, params.len.cint, addr y0d[0], y0.n.int64,
+                                    y0.dim.cint, y0.layout.cint, addr ts[0], ts.len.cint, addr tOut[0], addr yOut[0],
+                                    addr ny[0], nil, nil, 0, addr stats, 0)
+  result[0] = tOut[0 ..< stats.nTOut.int]
+  let row = y0.n * y0.dim
+  for j in 0 ..< ts.len:
+    result[1].add OdeBatch(n: y0.n, dim: y0.dim, layout: y0.layout, data: yOut[j*row ..< (j+1)*row])

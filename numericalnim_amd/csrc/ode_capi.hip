@@ -111,6 +111,10 @@ void make_grid(const nnhip_ode_options* opt, const double* tspan, int n_t, TimeG
   for (double x : g.tPos) g.tOut.push_back(x);
 }
 
+// tuning knobs of the headline streaming kernel (nnhip_tune_set); defaults = the measured best
+nnhip::StreamTune g_tune;
+bool g_tune_auto = true;  // pick (vec, mode) from the working-set size; any explicit nnhip_tune_set pins them
+
 // pinned staging for the (tiny) requested-time arrays of the device-pointer solve
 struct Staging {
   double* host = nullptr;
@@ -151,6 +155,17 @@ const char* nnhip_last_error(void) { return g_err; }
 const char* nnhip_build_info(void) {
   return "numericalnim-hip ODE backend; target gfx950 (CDNA4); device math -ffp-contract=off (bit-parity build); "
          "compiler " __VERSION__;
+}
+
+int nnhip_tune_set(const char* key, int value) {
+  if (!key) return fail(NNHIP_EVALUE, "key is NULL");
+  const std::string k(key);
+  if (k == "rk4_stream_auto") { g_tune_auto = value != 0; return NNHIP_OK; }
+  if (k == "rk4_stream_vec" || k == "rk4_stream_mode") g_tune_auto = false;
+  if (k == "rk4_stream_vec") { if (value != 1 && value != 2 && value != 4 && value != 8) return fail(NNHIP_EVALUE, "rk4_stream_vec must be 1, 2, 4 or 8"); g_tune.vec = value; return NNHIP_OK; }
+  if (k == "rk4_stream_mode") { if (value < 0 || value > 3) return fail(NNHIP_EVALUE, "rk4_stream_mode must be 0..3"); g_tune.mode = value; return NNHIP_OK; }
+  if (k == "rk4_stream_blocks_per_cu") { if (value < 1 || value > 64) return fail(NNHIP_EVALUE, "rk4_stream_blocks_per_cu must be 1..64"); g_tune.blocksPerCU = value; return NNHIP_OK; }
+  return fail(NNHIP_EVALUE, "unknown tuning key %s", key);
 }
 
 int nnhip_ode_new_options(nnhip_ode_options* out, double dt, double absTol, double relTol, double dtMax, double dtMin,
@@ -366,7 +381,15 @@ int nnhip_ode_step_batch_f64_dev(const nnhip_ode_options* opt, int integrator, i
   // scalar elementwise RK4 with uniform (t, dt): the vectorised streaming kernel over N*dim flat states
   if (integrator == NNHIP_RK4 && elementwise_rhs(rhs_kind) && !t_dev && !dt_dev && !fsal_out && !dt_used && !error &&
       (((uintptr_t)y_in | (uintptr_t)y_out) & 15) == 0) {
-    HIP_TRY(nnhip::launch_rk4_stream(rhs_kind, y_in, y_out, N * dim, t_uniform, dt_uniform, P, negate_time, 0, (hipStream_t)stream));
+    nnhip::StreamTune tune = g_tune;
+    if (g_tune_auto) {
+      // Measured on MI355X (profiles/r01_stream_tuning.txt): while the streamed working set fits the 256 MiB
+      // Infinity Cache plain accesses with one 16-B load per lane win (6.9 TB/s); beyond it, non-temporal
+      // accesses with 4 loads in flight per lane do (6.4 TB/s vs 5.9).
+      const int64_t workingSet = 8 * N * dim * (y_in == y_out ? 1 : 2);
+      if (workingSet <= (192LL << 20)) { tune.vec = 1; tune.mode = 0; } else { tune.vec = 4; tune.mode = 1; }
+    }
+    HIP_TRY(nnhip::launch_rk4_stream(rhs_kind, y_in, y_out, N * dim, t_uniform, dt_uniform, P, negate_time, tune, (hipStream_t)stream));
     return NNHIP_OK;
   }
   nnhip::StepLaunchFn fn = find_step(integrator, rhs_kind, dim);

@@ -324,45 +324,74 @@ hipError_t launch_step_lps(const StepArgs& a, int negate, hipStream_t s) {
 // workgroup covers a contiguous kBlock*2*VEC-element tile so every wave-level access is a full
 // 1 KiB coalesced segment.  Algorithmic HBM traffic: 8 B read + 8 B written per trajectory-step.
 // ------------------------------------------------------------------------------------------------
-template <class RHS1, bool NEG, int VEC>
+// MODE 0: plain loads/stores, one tile per workgroup.   MODE 1: non-temporal loads+stores (streaming hint).
+// MODE 2: persistent grid-stride over tiles (grid = a few workgroups per CU).  MODE 3: MODE 2 + non-temporal.
+template <class RHS1, bool NEG, int VEC, int MODE>
 __global__ __launch_bounds__(kBlock) void rk4_stream_vec_kernel(const double* __restrict__ yin, double* __restrict__ yout,
                                                                 int64_t n, double t, double dt, const Params P) {
   static_assert(RHS1::dim == 1, "scalar RHS only");
-  const int64_t tile = (int64_t)blockIdx.x * (kBlock * 2 * VEC);
+  constexpr bool NT = (MODE & 1) != 0;
+  constexpr bool PERSIST = (MODE & 2) != 0;
+  constexpr int64_t TILE = (int64_t)kBlock * 2 * VEC;
   const TpiOps<RHS1, NEG> ops{P};
-  double2 v[VEC];
-  if (tile + kBlock * 2 * VEC <= n) {  // full tile: unguarded vector accesses
-    const double2* src = reinterpret_cast<const double2*>(yin + tile) + threadIdx.x;
+  const int64_t nTiles = (n + TILE - 1) / TILE;
+  for (int64_t tileIdx = blockIdx.x; tileIdx < nTiles; tileIdx += PERSIST ? (int64_t)gridDim.x : nTiles) {
+    const int64_t tile = tileIdx * TILE;
+    if (tile + TILE <= n) {  // full tile: unguarded 16-byte lane accesses, VEC independent loads in flight
+      double2 v[VEC];
+      const double2* src = reinterpret_cast<const double2*>(yin + tile) + threadIdx.x;
 #pragma unroll
-    for (int u = 0; u < VEC; ++u) v[u] = src[u * kBlock];
+      for (int u = 0; u < VEC; ++u) {
+        if constexpr (NT) {
+          v[u].x = __builtin_nontemporal_load(&src[u * kBlock].x);
+          v[u].y = __builtin_nontemporal_load(&src[u * kBlock].y);
+        } else {
+          v[u] = src[u * kBlock];
+        }
+      }
 #pragma unroll
-    for (int u = 0; u < VEC; ++u) {
-      double a0[1] = {v[u].x}, a1[1] = {v[u].y}, r0[1], r1[1];
-      rk4_step(ops, t, dt, a0, r0);
-      rk4_step(ops, t, dt, a1, r1);
-      v[u].x = r0[0];
-      v[u].y = r1[0];
-    }
-    double2* dst = reinterpret_cast<double2*>(yout + tile) + threadIdx.x;
+      for (int u = 0; u < VEC; ++u) {
+        double a0[1] = {v[u].x}, a1[1] = {v[u].y}, r0[1], r1[1];
+        rk4_step(ops, t, dt, a0, r0);
+        rk4_step(ops, t, dt, a1, r1);
+        v[u].x = r0[0];
+        v[u].y = r1[0];
+      }
+      double2* dst = reinterpret_cast<double2*>(yout + tile) + threadIdx.x;
 #pragma unroll
-    for (int u = 0; u < VEC; ++u) dst[u * kBlock] = v[u];
-  } else {  // ragged tail tile: scalar, bounds-checked
-    for (int64_t j = tile + threadIdx.x; j < n; j += kBlock) {
-      double a0[1] = {yin[j]}, r0[1];
-      rk4_step(ops, t, dt, a0, r0);
-      yout[j] = r0[0];
+      for (int u = 0; u < VEC; ++u) {
+        if constexpr (NT) {
+          __builtin_nontemporal_store(v[u].x, &dst[u * kBlock].x);
+          __builtin_nontemporal_store(v[u].y, &dst[u * kBlock].y);
+        } else {
+          dst[u * kBlock] = v[u];
+        }
+      }
+    } else {  // ragged tail tile: scalar, bounds-checked
+      for (int64_t j = tile + threadIdx.x; j < n; j += kBlock) {
+        double a0[1] = {yin[j]}, r0[1];
+        rk4_step(ops, t, dt, a0, r0);
+        yout[j] = r0[0];
+      }
     }
   }
 }
 
-template <class RHS1, int VEC>
-hipError_t launch_rk4_stream_vec(const double* yin, double* yout, int64_t n, double t, double dt, const Params& P,
-                                 int negate, hipStream_t s) {
+struct StreamTune {
+  int vec = 4;           // 16-byte accesses in flight per lane and direction: 1, 2, 4, 8
+  int mode = 0;          // see rk4_stream_vec_kernel
+  int blocksPerCU = 8;   // persistent modes: grid = 256 CUs * blocksPerCU
+};
+
+template <class RHS1, int VEC, int MODE>
+hipError_t launch_rk4_stream_vec(const double* yin, double* yout, int64_t n, double t, double dt, const Params& P, int negate,
+                                 const StreamTune& tune, hipStream_t s) {
   const int64_t per = (int64_t)kBlock * 2 * VEC;
-  const int64_t grid = (n + per - 1) / per;
+  int64_t grid = (n + per - 1) / per;
   if (grid <= 0) return hipSuccess;
-  if (negate) return launch_kernel(rk4_stream_vec_kernel<RHS1, true, VEC>, dim3((unsigned)grid), dim3(kBlock), s, yin, yout, n, t, dt, P);
-  return launch_kernel(rk4_stream_vec_kernel<RHS1, false, VEC>, dim3((unsigned)grid), dim3(kBlock), s, yin, yout, n, t, dt, P);
+  if (MODE & 2) { const int64_t cap = 256LL * tune.blocksPerCU; if (grid > cap) grid = cap; }
+  if (negate) return launch_kernel(rk4_stream_vec_kernel<RHS1, true, VEC, MODE>, dim3((unsigned)grid), dim3(kBlock), s, yin, yout, n, t, dt, P);
+  return launch_kernel(rk4_stream_vec_kernel<RHS1, false, VEC, MODE>, dim3((unsigned)grid), dim3(kBlock), s, yin, yout, n, t, dt, P);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -416,7 +445,7 @@ StepLaunchFn find_step_dopri54(int rhs_kind, int dim);
 StepLaunchFn find_step_tsit54(int rhs_kind, int dim);
 // scalar RK4 streaming (vectorised); rhs_kind must be an elementwise kind. Defined in ode_tu_rk4.hip
 hipError_t launch_rk4_stream(int rhs_kind, const double* yin, double* yout, int64_t n, double t, double dt, const Params& P,
-                             int negate, int variant, hipStream_t s);
+                             int negate, const StreamTune& tune, hipStream_t s);
 bool rk4_stream_supported(int rhs_kind);
 
 }  // namespace nnhip

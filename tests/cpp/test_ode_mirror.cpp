@@ -1,0 +1,74 @@
+// C++ host-side parity harness: reads like /root/reference/tests/test_ode.nim (same RHS, y0, tspan, option sets,
+// tolerances and checks), driving the HIP backend through include/numericalnim_hip.hpp.  Built and run by
+// tests/test_gpu_cpp_host.py on the GPU box (g++ + libnnhip_ode.so).
+#include <cmath>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "numericalnim_hip.hpp"
+
+using namespace numericalnim;
+
+static int failures = 0;
+#define CHECK(cond)                                                        \
+  do {                                                                     \
+    if (!(cond)) { ++failures; std::printf("  CHECK failed: %s (line %d)\n", #cond, __LINE__); } \
+  } while (0)
+
+static std::vector<double> linspace(double x1, double x2, int N) {  // utils.nim:498-507
+  std::vector<double> r;
+  const double dx = (x2 - x1) / (double)(N - 1);
+  r.push_back(x1);
+  for (int i = 1; i <= N - 2; ++i) r.push_back(x1 + dx * (double)i);
+  r.push_back(x2);
+  return r;
+}
+static bool isClose(double a, double b, double tol) { return std::fabs(a - b) <= tol; }  // utils.nim:270,474-479
+
+int main() {
+  // test_ode.nim:5-16
+  NumContext<double> ctx;
+  ctx.setF("a", -0.1);                       // proc f(x, y, ctx) = -0.1 * y
+  const RhsSpec f = rhsLinear();
+  const ODEoptions oo = newODEoptions(/*dt=*/1e-6, /*absTol=*/1e-4, /*relTol=*/1e-8);   // newODEoptions(relTol=1e-8, dt=1e-6)
+  const ODEoptions ooVector = newODEoptions(/*dt=*/1e-2, 1e-4, /*relTol=*/1e-8);
+  const std::vector<double> tspan = linspace(-10.0, 10.0, 100);
+  OdeBatch y0 = OdeBatch::zeros(1, 1);
+  y0.at(0, 0) = 1.0;
+  OdeBatch y0Vector = OdeBatch::zeros(1, 3, NNHIP_LAYOUT_AOS);
+  for (int c = 0; c < 3; ++c) y0Vector.at(0, c) = 1.0;
+
+  struct Case { const char* name; const char* integ; const ODEoptions* opt; double tol; };
+  const Case scalar[] = {{"DOPRI54, default", "dopri54", nullptr, 1e-4}, {"DOPRI54, tol = 1e-8", "dopri54", &oo, 1e-8},
+                         {"RK4, default", "rk4", nullptr, 1e-4},         {"RK4, dt = 1e-6", "rk4", &oo, 1e-8},
+                         {"Tsit54, default", "tsit54", nullptr, 1e-4},   {"Tsit54, tol = 1e-8", "tsit54", &oo, 1e-8}};
+  for (const Case& c : scalar) {
+    std::printf("test \"%s\"\n", c.name);
+    OdeSolution s = solveODE(f, y0, tspan, c.opt ? *c.opt : DEFAULT_ODEoptions(), &ctx, c.integ);
+    CHECK(s.t == tspan);                                      // check t == tspan
+    for (size_t i = 0; i < s.y.size(); ++i) CHECK(isClose(s.y[i].at(0, 0), std::exp(-0.1 * tspan[i]), c.tol));
+  }
+  const Case vec[] = {{"DOPRI54 Vector, default", "dopri54", nullptr, 1e-4}, {"DOPRI54 Vector, tol = 1e-8", "dopri54", &ooVector, 1e-8},
+                      {"RK4 Vector, default", "rk4", nullptr, 1e-4},         {"RK4 Vector, dt = 1e-2", "rk4", &ooVector, 1e-8},
+                      {"Tsit54 Vector, default", "tsit54", nullptr, 1e-4},   {"Tsit54 Vector, dt = 1e-2", "tsit54", &ooVector, 1e-8}};
+  for (const Case& c : vec) {
+    std::printf("test \"%s\"\n", c.name);
+    OdeSolution s = solveODE(f, y0Vector, tspan, c.opt ? *c.opt : DEFAULT_ODEoptions(), &ctx, c.integ);
+    CHECK(s.t == tspan);
+    for (size_t i = 0; i < s.y.size(); ++i) {  // isClose on Vector: norm2(a-b)/len <= tol (utils.nim:252)
+      double n2 = 0.0;
+      for (int k = 0; k < 3; ++k) { const double d = s.y[i].at(0, k) - std::exp(-0.1 * tspan[i]); n2 += d * d; }
+      CHECK(std::sqrt(n2) / 3.0 <= c.tol);
+    }
+  }
+  // error behaviour: ValueError analogues
+  bool threw = false;
+  try { solveODE(f, y0, tspan, DEFAULT_ODEoptions(), &ctx, "rk5"); } catch (const std::invalid_argument&) { threw = true; }
+  CHECK(threw);
+  threw = false;
+  try { newODEoptions(1e-4, 1e-4, 1e-4, /*dtMax=*/1e-5, /*dtMin=*/1e-4); } catch (const std::invalid_argument&) { threw = true; }
+  CHECK(threw);
+  std::printf(failures ? "FAILED (%d)\n" : "OK\n", failures);
+  return failures ? 1 : 0;
+}

@@ -1,0 +1,19 @@
+"""Builds and runs the C++ host-side mirror harness (tests/cpp/test_ode_mirror.cpp over include/numericalnim_hip.hpp),
+which restates the scalar and Vector RK4/DOPRI54/Tsit54 cases of the reference's tests/test_ode.nim."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cpp_host_mirror(nn, tmp_path):
+    exe = str(tmp_path / "test_ode_mirror")
+    libdir = os.path.join(ROOT, "numericalnim_amd", "csrc")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_ode_mirror.cpp"),
+                           "-L", libdir, "-lnnhip_ode", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK")
