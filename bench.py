@@ -31,6 +31,7 @@ def parse():
     ap.add_argument("--rk4-steps", type=int, default=1000, help="RK4 time steps per solve (C2: 1000)")
     ap.add_argument("--pingpong", type=int, default=1, help="1: ping-pong between two state buffers (default), 0: update in place")
     ap.add_argument("--no-gather", action="store_true", help="skip the final-state all-gather (N>1)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl=RCCL) and run the all-gather even at world size 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=float, default=2e5, help="IVPs in the CPU-baseline sample")
     ap.add_argument("--no-fused", action="store_true", help="skip the informational fused-solve measurement")
@@ -55,9 +56,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     n = int(args.n_ivp)
     nsteps = int(args.rk4_steps)
@@ -69,7 +72,7 @@ def main():
     y0 = nd.c2_y0_torch(lo, hi, dev)
     y = torch.empty_like(y0)
     scratch = torch.empty_like(y0) if args.pingpong else None
-    gathered = torch.empty(n * world, dtype=torch.float64, device=dev) if (world > 1 and not args.no_gather) else None
+    gathered = torch.empty(n * world, dtype=torch.float64, device=dev) if (use_dist and not args.no_gather) else None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     gev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
@@ -91,7 +94,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -103,7 +106,7 @@ def main():
         yf = one_solve(k)
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -127,8 +130,11 @@ def main():
         check = float(np.abs(got - ref["y"][-1, 0]).max())
         assert check <= 1e-10, f"parity failure vs oracle: max abs err {check}"
 
+    if gathered is not None and not args.no_check:
+        # the gathered tensor must hold every rank's final states in rank order
+        assert torch.equal(gathered[lo:hi], yf), "all-gather misplaced this rank's shard"
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -207,7 +213,7 @@ def main():
             "all_cores": {"value": ns * nsteps / (c2 - c1), "cores": ncores},
         }
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -256,22 +256,31 @@ template <> struct MethodTraits<NNHIP_TSIT54>  { static constexpr bool fsal = tr
 // ------------------------------------------------------------------------------------------------
 constexpr int kStatusNaN = 1;
 
+// dt-derived constants of one RK4 step.  `dt / 6.0` is an IEEE division (~11 VALU instructions on gfx950):
+// it is computed once per distinct dt (on the host for the uniform-dt streaming kernel, cached in the fused
+// driver) instead of once per step — the value is bit-identical wherever it is computed.
+struct Rk4Dt {
+  double dt, hdt, dt6;
+};
+NNHIP_DEV Rk4Dt rk4_dt(double dt) { return Rk4Dt{dt, 0.5 * dt, dt / 6.0}; }
+
 template <class Ops>
-NNHIP_DEV void rk4_step(const Ops& ops, double t, double dt, const double (&y)[Ops::D], double (&yNew)[Ops::D]) {
+NNHIP_DEV void rk4_step(const Ops& ops, double t, const Rk4Dt& h, const double (&y)[Ops::D], double (&yNew)[Ops::D]) {
   constexpr int D = Ops::D;  // ode.nim:180-189
   double k1[D], k2[D], k3[D], k4[D], ya[D];
+  const double dt = h.dt;
   ops.rhs(t, y, k1);
-  const double hdt = 0.5 * dt;
+  const double hdt = h.hdt;  // 0.5 * dt
 #pragma unroll
   for (int c = 0; c < D; ++c) ya[c] = y[c] + hdt * k1[c];          // y + 0.5 * dt * k1
-  ops.rhs(t + 0.5 * dt, ya, k2);
+  ops.rhs(t + hdt, ya, k2);  // t + 0.5*dt
 #pragma unroll
   for (int c = 0; c < D; ++c) ya[c] = y[c] + hdt * k2[c];
-  ops.rhs(t + 0.5 * dt, ya, k3);
+  ops.rhs(t + hdt, ya, k3);
 #pragma unroll
   for (int c = 0; c < D; ++c) ya[c] = y[c] + dt * k3[c];
   ops.rhs(t + dt, ya, k4);
-  const double dt6 = dt / 6.0;
+  const double dt6 = h.dt6;  // dt / 6.0
 #pragma unroll
   for (int c = 0; c < D; ++c) yNew[c] = y[c] + dt6 * (k1[c] + 2.0 * (k2[c] + k3[c]) + k4[c]);  // :188
 }
@@ -385,6 +394,7 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
 #pragma unroll
   for (int c = 0; c < D; ++c) { lastY[c] = y[c]; lastDy[c] = fsal[c]; }  // lastIter (:498,:548)
   double dt = in.dtInit;
+  [[maybe_unused]] Rk4Dt h4 = rk4_dt(dt);
   double error = 0.0;
   int denseIndex = 0;
   const int high = in.nReq - 1;
@@ -421,7 +431,8 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
       }
     }
     if constexpr (METHOD == NNHIP_RK4) {
-      rk4_step(ops, t, dt, y, yNew);  // :531
+      if (dt != h4.dt) h4 = rk4_dt(dt);  // only the clipped last step changes dt
+      rk4_step(ops, t, h4, y, yNew);     // :531
       error = 0.0;
     } else {
       status |= embedded_step<METHOD>(ops, t, dt, y, fsal, yNew, error, in.ctl, rejected);

@@ -260,7 +260,7 @@ NNHIP_DEV void step_body(const StepArgs& a, const Ops& ops, int64_t i, int64_t b
   double dt = a.dt_dev ? a.dt_dev[i] : a.dt_uniform;
   double error = 0.0;
   if constexpr (METHOD == NNHIP_RK4) {
-    rk4_step(ops, t, dt, y, yNew);
+    rk4_step(ops, t, rk4_dt(dt), y, yNew);
     if (a.fsal_out) {  // fixed-step methods return yNew in the FSAL slot (ode.nim:189)
 #pragma unroll
       for (int c = 0; c < D; ++c) a.fsal_out[base + c * a.compStride] = yNew[c];
@@ -328,7 +328,7 @@ hipError_t launch_step_lps(const StepArgs& a, int negate, hipStream_t s) {
 // MODE 2: persistent grid-stride over tiles (grid = a few workgroups per CU).  MODE 3: MODE 2 + non-temporal.
 template <class RHS1, bool NEG, int VEC, int MODE>
 __global__ __launch_bounds__(kBlock) void rk4_stream_vec_kernel(const double* __restrict__ yin, double* __restrict__ yout,
-                                                                int64_t n, double t, double dt, const Params P) {
+                                                                int64_t n, double t, const Rk4Dt h, const Params P) {
   static_assert(RHS1::dim == 1, "scalar RHS only");
   constexpr bool NT = (MODE & 1) != 0;
   constexpr bool PERSIST = (MODE & 2) != 0;
@@ -352,8 +352,8 @@ __global__ __launch_bounds__(kBlock) void rk4_stream_vec_kernel(const double* __
 #pragma unroll
       for (int u = 0; u < VEC; ++u) {
         double a0[1] = {v[u].x}, a1[1] = {v[u].y}, r0[1], r1[1];
-        rk4_step(ops, t, dt, a0, r0);
-        rk4_step(ops, t, dt, a1, r1);
+        rk4_step(ops, t, h, a0, r0);
+        rk4_step(ops, t, h, a1, r1);
         v[u].x = r0[0];
         v[u].y = r1[0];
       }
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(kBlock) void rk4_stream_vec_kernel(const double* __
     } else {  // ragged tail tile: scalar, bounds-checked
       for (int64_t j = tile + threadIdx.x; j < n; j += kBlock) {
         double a0[1] = {yin[j]}, r0[1];
-        rk4_step(ops, t, dt, a0, r0);
+        rk4_step(ops, t, h, a0, r0);
         yout[j] = r0[0];
       }
     }
@@ -390,8 +390,9 @@ hipError_t launch_rk4_stream_vec(const double* yin, double* yout, int64_t n, dou
   int64_t grid = (n + per - 1) / per;
   if (grid <= 0) return hipSuccess;
   if (MODE & 2) { const int64_t cap = 256LL * tune.blocksPerCU; if (grid > cap) grid = cap; }
-  if (negate) return launch_kernel(rk4_stream_vec_kernel<RHS1, true, VEC, MODE>, dim3((unsigned)grid), dim3(kBlock), s, yin, yout, n, t, dt, P);
-  return launch_kernel(rk4_stream_vec_kernel<RHS1, false, VEC, MODE>, dim3((unsigned)grid), dim3(kBlock), s, yin, yout, n, t, dt, P);
+  const Rk4Dt h{dt, 0.5 * dt, dt / 6.0};  // host IEEE double ops == the device's (this TU is built -ffp-contract=off)
+  if (negate) return launch_kernel(rk4_stream_vec_kernel<RHS1, true, VEC, MODE>, dim3((unsigned)grid), dim3(kBlock), s, yin, yout, n, t, h, P);
+  return launch_kernel(rk4_stream_vec_kernel<RHS1, false, VEC, MODE>, dim3((unsigned)grid), dim3(kBlock), s, yin, yout, n, t, h, P);
 }
 
 // ------------------------------------------------------------------------------------------------
