@@ -43,25 +43,27 @@ struct MethodInfo {
 };
 // solveODE's dispatch (ode.nim:607-649), indexed by nnhip_integrator
 const MethodInfo kMethods[NNHIP_N_INTEGRATORS] = {
-    {"rk4", 0, 4.0, 0, 1},      {"dopri54", 1, 5.0, 1, 1},  {"tsit54", 1, 5.0, 1, 1},   {"vern65", 1, 6.0, 1, 0},
-    {"bs32", 1, 3.0, 1, 0},     {"rk21", 0, 2.0, 1, 0},     {"heun2", 0, 2.0, 0, 0},    {"ralston2", 0, 2.0, 0, 0},
-    {"kutta3", 0, 3.0, 0, 0},   {"heun3", 0, 3.0, 0, 0},    {"ralston3", 0, 3.0, 0, 0}, {"ssprk3", 0, 3.0, 0, 0},
-    {"ralston4", 0, 4.0, 0, 0}, {"kutta4", 0, 4.0, 0, 0},
+    {"rk4", 0, 4.0, 0, 1},      {"dopri54", 1, 5.0, 1, 1},  {"tsit54", 1, 5.0, 1, 1},   {"vern65", 1, 6.0, 1, 1},
+    {"bs32", 1, 3.0, 1, 1},     {"rk21", 0, 2.0, 1, 1},     {"heun2", 0, 2.0, 0, 1},    {"ralston2", 0, 2.0, 0, 1},
+    {"kutta3", 0, 3.0, 0, 1},   {"heun3", 0, 3.0, 0, 1},    {"ralston3", 0, 3.0, 0, 1}, {"ssprk3", 0, 3.0, 0, 1},
+    {"ralston4", 0, 4.0, 0, 1}, {"kutta4", 0, 4.0, 0, 1},
 };
 
 nnhip::SolveLaunchFn find_solve(int integrator, int rhs_kind, int dim) {
   switch (integrator) {
-    case NNHIP_RK4: return nnhip::find_solve_rk4(rhs_kind, dim);
-    case NNHIP_DOPRI54: return nnhip::find_solve_dopri54(rhs_kind, dim);
-    case NNHIP_TSIT54: return nnhip::find_solve_tsit54(rhs_kind, dim);
+#define X(id, name) \
+  case id: return nnhip::find_solve_##name(rhs_kind, dim);
+    NNHIP_FOR_EACH_METHOD(X)
+#undef X
   }
   return nullptr;
 }
 nnhip::StepLaunchFn find_step(int integrator, int rhs_kind, int dim) {
   switch (integrator) {
-    case NNHIP_RK4: return nnhip::find_step_rk4(rhs_kind, dim);
-    case NNHIP_DOPRI54: return nnhip::find_step_dopri54(rhs_kind, dim);
-    case NNHIP_TSIT54: return nnhip::find_step_tsit54(rhs_kind, dim);
+#define X(id, name) \
+  case id: return nnhip::find_step_##name(rhs_kind, dim);
+    NNHIP_FOR_EACH_METHOD(X)
+#undef X
   }
   return nullptr;
 }
@@ -378,6 +380,7 @@ int nnhip_ode_step_batch_f64_dev(const nnhip_ode_options* opt, int integrator, i
   if (N == 0) return NNHIP_OK;
   if (!y_in || !y_out) return fail(NNHIP_EVALUE, "y_in / y_out is NULL");
   if (kMethods[integrator].useFSAL && (!fsal_in || !fsal_out)) return fail(NNHIP_EVALUE, "FSAL methods need fsal_in and fsal_out");
+  if (kMethods[integrator].adaptive && !fsal_out) return fail(NNHIP_EVALUE, "adaptive methods need fsal_out");
   // scalar elementwise RK4 with uniform (t, dt): the vectorised streaming kernel over N*dim flat states
   if (integrator == NNHIP_RK4 && elementwise_rhs(rhs_kind) && !t_dev && !dt_dev && !fsal_out && !dt_used && !error &&
       (((uintptr_t)y_in | (uintptr_t)y_out) & 15) == 0) {

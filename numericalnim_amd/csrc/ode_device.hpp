@@ -193,6 +193,7 @@ struct Tableau<NNHIP_DOPRI54> {  // ode.nim:240-282
   static constexpr int ORDER = 5;
   static constexpr bool DIRECT_ERR = false;  // error_y = yNew - yLow (:303)
   static constexpr int NB = 6;               // terms in yNew
+  static constexpr bool B_IS_LAST_ROW = true;  // b_i = a_7i literally (:269-274): yNew == the last stage argument
   NNHIP_DEV static double c(int s) {
     constexpr double C[7] = {0.0, 1.0 / 5.0, 3.0 / 10.0, 4.0 / 5.0, 8.0 / 9.0, 1.0, 1.0};
     return C[s];
@@ -221,6 +222,7 @@ struct Tableau<NNHIP_TSIT54> {  // ode.nim:310-352
   static constexpr int ORDER = 5;
   static constexpr bool DIRECT_ERR = true;  // error_y = dt * (sum bHat_i k_i) (:372)
   static constexpr int NB = 6;
+  static constexpr bool B_IS_LAST_ROW = true;  // :339-344
   NNHIP_DEV static double c(int s) {
     constexpr double C[7] = {0.0, 0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0};
     return C[s];
@@ -244,11 +246,53 @@ struct Tableau<NNHIP_TSIT54> {  // ode.nim:310-352
   }
 };
 
+template <>
+struct Tableau<NNHIP_VERN65> {  // ode.nim:380-443
+  static constexpr int S = 9;
+  static constexpr int ORDER = 6;
+  static constexpr bool DIRECT_ERR = false;     // error_y = yNew - yLow (:466)
+  static constexpr int NB = 8;
+  static constexpr bool B_IS_LAST_ROW = false;  // b4..b7 are separate literals (:426-433), not a9j
+  NNHIP_DEV static double c(int s) {
+    constexpr double C[9] = {0.0, 0.06, 0.09593333333333333, 0.1439, 0.4973, 0.9725, 0.9995, 1.0, 1.0};
+    return C[s];
+  }
+  NNHIP_DEV static double a(int s, int j) {
+    constexpr double A[9][8] = {
+        {0, 0, 0, 0, 0, 0, 0, 0},
+        {0.06, 0, 0, 0, 0, 0, 0, 0},
+        {0.019239962962962962, 0.07669337037037037, 0, 0, 0, 0, 0, 0},
+        {0.035975, 0.0, 0.107925, 0, 0, 0, 0, 0},
+        {1.3186834152331484, 0.0, -5.042058063628562, 4.220674648395414, 0, 0, 0, 0},
+        {-41.87259166432751, 0.0, 159.43256216313748, -122.11921356501004, 5.531743066200053, 0, 0, 0},
+        {-54.430156935316504, 0.0, 207.06725136501848, -158.61081378459, 6.991816585950242, -0.01859723106220323, 0, 0},
+        {-54.66374178728198, 0.0, 207.95280625538936, -159.2889574744995, 7.018743740796944, -0.018338785905045722, -0.0005119484997882099, 0},
+        {0.03438957868357036, 0.0, 0.0, 0.25826245556335037, 0.4209371189673537, 4.405396469669310, -176.48311902429865, 172.36413340141507}};
+    return A[s][j];
+  }
+  NNHIP_DEV static double b(int j) {
+    constexpr double B[8] = {0.03438957868357036, 0.0, 0.0, 0.25826245556335034, 0.42093711896735372, 4.4053964696693102,
+                             -176.48311902429866, 172.36413340141507};
+    return B[j];
+  }
+  NNHIP_DEV static double bhat(int j) {
+    constexpr double B[9] = {0.04909967648382, 0.0, 0.0, 0.22511122295165, 0.46946822530296, 0.80657922499889, 0.0,
+                             -0.60711948917780, 0.05686113944048};
+    return B[j];
+  }
+};
+
 // Which methods are adaptive / FSAL / their `order` float — the triple solveODE passes (ode.nim:608-649)
 template <int METHOD> struct MethodTraits;
-template <> struct MethodTraits<NNHIP_RK4>     { static constexpr bool fsal = false, adaptive = false; static constexpr double order = 4.0; };
-template <> struct MethodTraits<NNHIP_DOPRI54> { static constexpr bool fsal = true,  adaptive = true;  static constexpr double order = 5.0; };
-template <> struct MethodTraits<NNHIP_TSIT54>  { static constexpr bool fsal = true,  adaptive = true;  static constexpr double order = 5.0; };
+#define NNHIP_TRAITS(M, FSAL, ORDER, ADAPTIVE) \
+  template <> struct MethodTraits<M> { static constexpr bool fsal = FSAL, adaptive = ADAPTIVE; static constexpr double order = ORDER; };
+NNHIP_TRAITS(NNHIP_RK4, false, 4.0, false)      NNHIP_TRAITS(NNHIP_DOPRI54, true, 5.0, true)   NNHIP_TRAITS(NNHIP_TSIT54, true, 5.0, true)
+NNHIP_TRAITS(NNHIP_VERN65, true, 6.0, true)     NNHIP_TRAITS(NNHIP_BS32, true, 3.0, true)      NNHIP_TRAITS(NNHIP_RK21, false, 2.0, true)
+NNHIP_TRAITS(NNHIP_HEUN2, false, 2.0, false)    NNHIP_TRAITS(NNHIP_RALSTON2, false, 2.0, false) NNHIP_TRAITS(NNHIP_KUTTA3, false, 3.0, false)
+NNHIP_TRAITS(NNHIP_HEUN3, false, 3.0, false)    NNHIP_TRAITS(NNHIP_RALSTON3, false, 3.0, false) NNHIP_TRAITS(NNHIP_SSPRK3, false, 3.0, false)
+NNHIP_TRAITS(NNHIP_RALSTON4, false, 4.0, false) NNHIP_TRAITS(NNHIP_KUTTA4, false, 4.0, false)
+#undef NNHIP_TRAITS
+constexpr bool has_tableau(int m) { return m == NNHIP_DOPRI54 || m == NNHIP_TSIT54 || m == NNHIP_VERN65; }
 
 // ------------------------------------------------------------------------------------------------
 // Steppers.  Signature mirrors IntegratorProc (ode.nim:38):
@@ -285,59 +329,201 @@ NNHIP_DEV void rk4_step(const Ops& ops, double t, const Rk4Dt& h, const double (
   for (int c = 0; c < D; ++c) yNew[c] = y[c] + dt6 * (k1[c] + 2.0 * (k2[c] + k3[c]) + k4[c]);  // :188
 }
 
+// The other eight fixed-step steppers (ode.nim:107-178), each in the reference's own expression order
+// (Nim: `a * b * c` = (a*b)*c, `2/3` is the float 0.666.., `-1/3` is (-1)/3).
+template <int METHOD, class Ops>
+NNHIP_DEV void fixed_step(const Ops& ops, double t, double dt, const double (&y)[Ops::D], double (&yNew)[Ops::D]) {
+  constexpr int D = Ops::D;
+  double k1[D], k2[D], k3[D], k4[D], ya[D];
+  ops.rhs(t, y, k1);
+  if constexpr (METHOD == NNHIP_HEUN2) {  // :107-113
+#pragma unroll
+    for (int c = 0; c < D; ++c) ya[c] = y[c] + dt * k1[c];
+    ops.rhs(t + dt, ya, k2);
+    const double h = 0.5 * dt;
+#pragma unroll
+    for (int c = 0; c < D; ++c) yNew[c] = y[c] + h * (k1[c] + k2[c]);
+  } else if constexpr (METHOD == NNHIP_RALSTON2) {  // :115-121
+    const double h = 2.0 / 3.0 * dt;
+#pragma unroll
+    for (int c = 0; c < D; ++c) ya[c] = y[c] + h * k1[c];
+    ops.rhs(t + h, ya, k2);
+#pragma unroll
+    for (int c = 0; c < D; ++c) yNew[c] = y[c] + dt * (0.25 * k1[c] + 0.75 * k2[c]);
+  } else if constexpr (METHOD == NNHIP_KUTTA3) {  // :123-130
+    const double h = 0.5 * dt, h2 = 2.0 * dt;
+#pragma unroll
+    for (int c = 0; c < D; ++c) ya[c] = y[c] + h * k1[c];
+    ops.rhs(t + h, ya, k2);
+#pragma unroll
+    for (int c = 0; c < D; ++c) ya[c] = y[c] - dt * k1[c] + h2 * k2[c];
+    ops.rhs(t + dt, ya, k3);
+#pragma unroll
+    for (int c = 0; c < D; ++c) yNew[c] = y[c] + dt * (1.0 / 6.0 * k1[c] + 2.0 / 3.0 * k2[c] + 1.0 / 6.0 * k3[c]);
+  } else if constexpr (METHOD == NNHIP_HEUN3) {  // :132-139
+    const double h1 = 1.0 / 3.0 * dt, h2 = 2.0 / 3.0 * dt;
+#pragma unroll
+    for (int c = 0; c < D; ++c) ya[c] = y[c] + h1 * k1[c];
+    ops.rhs(t + h1, ya, k2);
+#pragma unroll
+    for (int c = 0; c < D; ++c) ya[c] = y[c] + h2 * k2[c];
+    ops.rhs(t + h2, ya, k3);
+#pragma unroll
+    for (int c = 0; c < D; ++c) yNew[c] = y[c] + dt * (0.25 * k1[c] + 0.75 * k3[c]);
+  } else if constexpr (METHOD == NNHIP_RALSTON3) {  // :141-148
+    const double h1 = 1.0 / 2.0 * dt, h2 = 3.0 / 4.0 * dt;
+#pragma unroll
+    for (int c = 0; c < D; ++c) ya[c] = y[c] + h1 * k1[c];
+    ops.rhs(t + h1, ya, k2);
+#pragma unroll
+    for (int c = 0; c < D; ++c) ya[c] = y[c] + h2 * k2[c];
+    ops.rhs(t + h2, ya, k3);
+#pragma unroll
+    for (int c = 0; c < D; ++c) yNew[c] = y[c] + dt * (2.0 / 9.0 * k1[c] + 1.0 / 3.0 * k2[c] + 4.0 / 9.0 * k3[c]);
+  } else if constexpr (METHOD == NNHIP_SSPRK3) {  // :150-157
+#pragma unroll
+    for (int c = 0; c < D; ++c) ya[c] = y[c] + dt * k1[c];
+    ops.rhs(t + dt, ya, k2);
+    const double q = 0.25 * dt;
+#pragma unroll
+    for (int c = 0; c < D; ++c) ya[c] = y[c] + q * (k1[c] + k2[c]);
+    ops.rhs(t + 0.5 * dt, ya, k3);
+#pragma unroll
+    for (int c = 0; c < D; ++c) yNew[c] = y[c] + dt * (1.0 / 6.0 * k1[c] + 1.0 / 6.0 * k2[c] + 2.0 / 3.0 * k3[c]);
+  } else if constexpr (METHOD == NNHIP_RALSTON4) {  // :160-168
+    const double h = 0.4 * dt;
+#pragma unroll
+    for (int c = 0; c < D; ++c) ya[c] = y[c] + h * k1[c];
+    ops.rhs(t + h, ya, k2);
+#pragma unroll
+    for (int c = 0; c < D; ++c) ya[c] = y[c] + dt * (0.29697761 * k1[c] + 0.15875964 * k2[c]);
+    ops.rhs(t + 0.45573725 * dt, ya, k3);
+#pragma unroll
+    for (int c = 0; c < D; ++c) ya[c] = y[c] + dt * (0.21810040 * k1[c] - 3.05096516 * k2[c] + 3.83286476 * k3[c]);
+    ops.rhs(t + dt, ya, k4);
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+      yNew[c] = y[c] + dt * (0.17476028 * k1[c] - 0.55148066 * k2[c] + 1.20553560 * k3[c] + 0.17118478 * k4[c]);
+  } else {  // NNHIP_KUTTA4 :170-178
+    static_assert(METHOD == NNHIP_KUTTA4, "unknown fixed-step method");
+    const double h1 = 1.0 / 3.0 * dt;
+#pragma unroll
+    for (int c = 0; c < D; ++c) ya[c] = y[c] + h1 * k1[c];
+    ops.rhs(t + h1, ya, k2);
+#pragma unroll
+    for (int c = 0; c < D; ++c) ya[c] = y[c] + dt * (-1.0 / 3.0 * k1[c] + k2[c]);
+    ops.rhs(t + 2.0 / 3.0 * dt, ya, k3);
+#pragma unroll
+    for (int c = 0; c < D; ++c) ya[c] = y[c] + dt * (k1[c] - k2[c] + k3[c]);
+    ops.rhs(t + dt, ya, k4);
+#pragma unroll
+    for (int c = 0; c < D; ++c) yNew[c] = y[c] + dt * (1.0 / 8.0 * k1[c] + 3.0 / 8.0 * k2[c] + 3.0 / 8.0 * k3[c] + 1.0 / 8.0 * k4[c]);
+  }
+}
+
 NNHIP_DEV double shrink_factor(double error, double inv_order) {  // min(4, max(0.125, 0.9 * pow(1/error, 1/order)))  (:71,:537)
   return nmin(4.0, nmax(0.125, 0.9 * pow(1.0 / error, inv_order)));
 }
 
+// One adaptive IntegratorProc call = the method's stage block inside commonAdaptiveMethodCode's retry loop
+// (ode.nim:57-76).  `fsal` is k1 on entry for the tableau methods and the returned FSAL slot on exit.
 template <int METHOD, class Ops>
 NNHIP_DEV int embedded_step(const Ops& ops, double t, double& dt, const double (&y)[Ops::D], double (&fsal)[Ops::D],
                             double (&yNew)[Ops::D], double& error, const StepCtl& o, int64_t& rejected) {
-  using T = Tableau<METHOD>;
   constexpr int D = Ops::D;
-  constexpr int S = T::S;
-  double k[S][D];
-  double ya[D], err_y[D];
+  double ya[D], err_y[D], fsalNew[D];
   int limitCounter = 0;
   int status = 0;
+  constexpr int ORDER = METHOD == NNHIP_RK21 ? 2 : METHOD == NNHIP_BS32 ? 3 : METHOD == NNHIP_VERN65 ? 6 : 5;
+  while (limitCounter < 2) {  // :58
+    if constexpr (has_tableau(METHOD)) {
+      using T = Tableau<METHOD>;
+      constexpr int S = T::S;
+      double k[S][D];
 #pragma unroll
-  for (int c = 0; c < D; ++c) k[0][c] = fsal[c];  // k1 = FSAL (:293,:363)
-  while (limitCounter < 2) {                      // :58
+      for (int c = 0; c < D; ++c) k[0][c] = fsal[c];  // k1 = FSAL (:293,:363,:454)
 #pragma unroll
-    for (int s = 1; s < S; ++s) {
+      for (int s = 1; s < S; ++s) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+          double acc = T::a(s, 0) * k[0][c];
+#pragma unroll
+          for (int j = 1; j < s; ++j) acc = acc + T::a(s, j) * k[j][c];
+          ya[c] = y[c] + dt * acc;  // y + dt * (a_s1*k1 + ... )
+        }
+        ops.rhs(t + dt * T::c(s), ya, k[s]);
+      }
+      if constexpr (T::B_IS_LAST_ROW) {
+        // yNew = y + dt*(b1*k1+...): identical expression to the last stage's argument (:299-301) -> ya holds it
+#pragma unroll
+        for (int c = 0; c < D; ++c) yNew[c] = ya[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+          double acc = T::b(0) * k[0][c];
+#pragma unroll
+          for (int j = 1; j < T::NB; ++j) acc = acc + T::b(j) * k[j][c];
+          yNew[c] = y[c] + dt * acc;  // :464
+        }
+      }
 #pragma unroll
       for (int c = 0; c < D; ++c) {
-        double acc = T::a(s, 0) * k[0][c];
+        double acc = T::bhat(0) * k[0][c];
 #pragma unroll
-        for (int j = 1; j < s; ++j) acc = acc + T::a(s, j) * k[j][c];
-        ya[c] = y[c] + dt * acc;  // y + dt * (a_s1*k1 + ... )
+        for (int j = 1; j < S; ++j) acc = acc + T::bhat(j) * k[j][c];
+        if constexpr (T::DIRECT_ERR) {
+          err_y[c] = dt * acc;  // :372
+        } else {
+          const double yLow = y[c] + dt * acc;  // :302,:465
+          err_y[c] = yNew[c] - yLow;            // :303,:466
+        }
+        fsalNew[c] = k[S - 1][c];  // returns the last stage (:305,:374,:468)
       }
-      ops.rhs(t + dt * T::c(s), ya, k[s]);
-    }
-    // yNew = y + dt*(b1*k1+...+b6*k6): identical expression to k7's argument (:299-301) -> ya holds it
+    } else if constexpr (METHOD == NNHIP_RK21) {  // :203-210
+      double k1[D], k2[D];
+      ops.rhs(t, y, k1);
 #pragma unroll
-    for (int c = 0; c < D; ++c) yNew[c] = ya[c];
+      for (int c = 0; c < D; ++c) ya[c] = y[c] + dt * k1[c];
+      ops.rhs(t + dt, ya, k2);
+      const double h = dt * 0.5;
 #pragma unroll
-    for (int c = 0; c < D; ++c) {
-      double acc = T::bhat(0) * k[0][c];
+      for (int c = 0; c < D; ++c) {
+        yNew[c] = y[c] + h * (k1[c] + k2[c]);   // y + dt * 0.5 * (k1 + k2)
+        const double yLow = y[c] + dt * k1[c];
+        err_y[c] = yNew[c] - yLow;
+        fsalNew[c] = yNew[c];                   // result = (yNew, yNew, dt, error)
+      }
+    } else {  // NNHIP_BS32 :224-234
+      static_assert(METHOD == NNHIP_BS32, "unknown adaptive method");
+      double k1[D], k2[D], k3[D], k4[D];
+      ops.rhs(t, y, k1);
+      const double h1 = 0.5 * dt, h2 = 0.75 * dt;
 #pragma unroll
-      for (int j = 1; j < S; ++j) acc = acc + T::bhat(j) * k[j][c];
-      if constexpr (T::DIRECT_ERR) {
-        err_y[c] = dt * acc;  // :372
-      } else {
-        const double yLow = y[c] + dt * acc;  // :302
-        err_y[c] = yNew[c] - yLow;            // :303
+      for (int c = 0; c < D; ++c) ya[c] = y[c] + h1 * k1[c];
+      ops.rhs(t + h1, ya, k2);
+#pragma unroll
+      for (int c = 0; c < D; ++c) ya[c] = y[c] + h2 * k2[c];
+      ops.rhs(t + h2, ya, k3);
+#pragma unroll
+      for (int c = 0; c < D; ++c) yNew[c] = y[c] + dt * (2.0 / 9.0 * k1[c] + 1.0 / 3.0 * k2[c] + 4.0 / 9.0 * k3[c]);
+      ops.rhs(t + dt, yNew, k4);
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        const double yLow = y[c] + dt * (7.0 / 24.0 * k1[c] + 1.0 / 4.0 * k2[c] + 1.0 / 3.0 * k3[c] + 1.0 / 8.0 * k4[c]);
+        err_y[c] = yNew[c] - yLow;
+        fsalNew[c] = k4[c];
       }
     }
     error = ops.norm(yNew, err_y, o);  // scaled RMS norm (:61-65)
     if (error <= 1.0) break;                                   // :69-70
     if (error != error) { status |= kStatusNaN; break; }       // deviation: the reference would spin forever
-    dt = dt * shrink_factor(error, 1.0 / (double)T::ORDER);    // :71
+    dt = dt * shrink_factor(error, 1.0 / (double)ORDER);       // :71
     if (fabs(dt) < o.dtMin) { dt = o.dtMin; limitCounter += 1; }  // :72-74
     else if (o.dtMax < fabs(dt)) { dt = o.dtMax; }             // :75-76
     rejected += 1;
   }
 #pragma unroll
-  for (int c = 0; c < D; ++c) fsal[c] = k[S - 1][c];  // return k7 (:305,:374)
+  for (int c = 0; c < D; ++c) fsal[c] = fsalNew[c];
   return status;
 }
 
@@ -433,6 +619,9 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
     if constexpr (METHOD == NNHIP_RK4) {
       if (dt != h4.dt) h4 = rk4_dt(dt);  // only the clipped last step changes dt
       rk4_step(ops, t, h4, y, yNew);     // :531
+      error = 0.0;
+    } else if constexpr (!MT::adaptive) {
+      fixed_step<METHOD>(ops, t, dt, y, yNew);
       error = 0.0;
     } else {
       status |= embedded_step<METHOD>(ops, t, dt, y, fsal, yNew, error, in.ctl, rejected);

@@ -265,14 +265,24 @@ NNHIP_DEV void step_body(const StepArgs& a, const Ops& ops, int64_t i, int64_t b
 #pragma unroll
       for (int c = 0; c < D; ++c) a.fsal_out[base + c * a.compStride] = yNew[c];
     }
+  } else if constexpr (!MethodTraits<METHOD>::adaptive) {
+    fixed_step<METHOD>(ops, t, dt, y, yNew);
+    if (a.fsal_out) {
+#pragma unroll
+      for (int c = 0; c < D; ++c) a.fsal_out[base + c * a.compStride] = yNew[c];
+    }
   } else {
     double fsal[D];
+    if constexpr (has_tableau(METHOD)) {  // only the tableau methods read FSAL (k1 = FSAL); RK21 / BS32 ignore it
 #pragma unroll
-    for (int c = 0; c < D; ++c) fsal[c] = a.fsal_in[base + c * a.compStride];
+      for (int c = 0; c < D; ++c) fsal[c] = a.fsal_in[base + c * a.compStride];
+    }
     int64_t rej = 0;
     embedded_step<METHOD>(ops, t, dt, y, fsal, yNew, error, a.ctl, rej);
+    if (a.fsal_out) {
 #pragma unroll
-    for (int c = 0; c < D; ++c) a.fsal_out[base + c * a.compStride] = fsal[c];
+      for (int c = 0; c < D; ++c) a.fsal_out[base + c * a.compStride] = fsal[c];
+    }
   }
 #pragma unroll
   for (int c = 0; c < D; ++c) a.y_out[base + c * a.compStride] = yNew[c];
@@ -437,14 +447,17 @@ StepLaunchFn find_step_tpi(int rhs_kind, int dim) {
   return nullptr;
 }
 
-// defined in ode_tu_<method>.hip
-SolveLaunchFn find_solve_rk4(int rhs_kind, int dim);
-SolveLaunchFn find_solve_dopri54(int rhs_kind, int dim);
-SolveLaunchFn find_solve_tsit54(int rhs_kind, int dim);
-StepLaunchFn find_step_rk4(int rhs_kind, int dim);
-StepLaunchFn find_step_dopri54(int rhs_kind, int dim);
-StepLaunchFn find_step_tsit54(int rhs_kind, int dim);
-// scalar RK4 streaming (vectorised); rhs_kind must be an elementwise kind. Defined in ode_tu_rk4.hip
+// one translation unit per integrator (ode_tu_method.hip compiled with -DNNHIP_TU_METHOD=<id>)
+#define NNHIP_FOR_EACH_METHOD(X)                                                                                       \
+  X(NNHIP_RK4, rk4) X(NNHIP_DOPRI54, dopri54) X(NNHIP_TSIT54, tsit54) X(NNHIP_VERN65, vern65) X(NNHIP_BS32, bs32)        \
+  X(NNHIP_RK21, rk21) X(NNHIP_HEUN2, heun2) X(NNHIP_RALSTON2, ralston2) X(NNHIP_KUTTA3, kutta3) X(NNHIP_HEUN3, heun3)    \
+  X(NNHIP_RALSTON3, ralston3) X(NNHIP_SSPRK3, ssprk3) X(NNHIP_RALSTON4, ralston4) X(NNHIP_KUTTA4, kutta4)
+#define X(id, name)                                        \
+  SolveLaunchFn find_solve_##name(int rhs_kind, int dim);  \
+  StepLaunchFn find_step_##name(int rhs_kind, int dim);
+NNHIP_FOR_EACH_METHOD(X)
+#undef X
+// scalar RK4 streaming (vectorised); rhs_kind must be an elementwise kind. Defined in ode_tu_rk4_stream.hip
 hipError_t launch_rk4_stream(int rhs_kind, const double* yin, double* yout, int64_t n, double t, double dt, const Params& P,
                              int negate, const StreamTune& tune, hipStream_t s);
 bool rk4_stream_supported(int rhs_kind);

@@ -1,0 +1,11 @@
+// ode_tu_method.hip — all (RHS, dim) instantiations of ONE integrator; compiled once per integrator with
+// -DNNHIP_TU_METHOD=<nnhip_integrator id> -DNNHIP_TU_NAME=<its reference name> (see Makefile).
+#include "ode_kernels.hpp"
+
+#define NNHIP_CAT2(a, b) a##b
+#define NNHIP_CAT(a, b) NNHIP_CAT2(a, b)
+
+namespace nnhip {
+SolveLaunchFn NNHIP_CAT(find_solve_, NNHIP_TU_NAME)(int rhs_kind, int dim) { return find_solve_tpi<NNHIP_TU_METHOD>(rhs_kind, dim); }
+StepLaunchFn NNHIP_CAT(find_step_, NNHIP_TU_NAME)(int rhs_kind, int dim) { return find_step_tpi<NNHIP_TU_METHOD>(rhs_kind, dim); }
+}  // namespace nnhip

@@ -1,10 +1,7 @@
-// ode_tu_rk4.hip — RK4 instantiations (ode.nim:180-189): fused solve, step-streaming, vectorised scalar stream.
+// ode_tu_rk4_stream.hip — the headline kernel's instantiations: vectorised scalar RK4 step-streaming (ode.nim:180-189).
 #include "ode_kernels.hpp"
 
 namespace nnhip {
-
-SolveLaunchFn find_solve_rk4(int rhs_kind, int dim) { return find_solve_tpi<NNHIP_RK4>(rhs_kind, dim); }
-StepLaunchFn find_step_rk4(int rhs_kind, int dim) { return find_step_tpi<NNHIP_RK4>(rhs_kind, dim); }
 
 bool rk4_stream_supported(int rhs_kind) {
   return rhs_kind == NNHIP_RHS_NEG_Y || rhs_kind == NNHIP_RHS_LINEAR || rhs_kind == NNHIP_RHS_AFFINE_T;

@@ -26,7 +26,7 @@ LAYOUT_SOA, LAYOUT_AOS = 0, 1
 fixedODE = ["heun2", "ralston2", "kutta3", "heun3", "ralston3", "ssprk3", "ralston4", "kutta4", "rk4"]  # ode.nim:40
 adaptiveODE = ["rk21", "bs32", "dopri54", "tsit54", "vern65"]  # ode.nim:41
 allODE = fixedODE + adaptiveODE  # ode.nim:42
-implementedODE = ["rk4", "dopri54", "tsit54"]  # integrators with HIP kernels in this round
+implementedODE = list(allODE)  # every integrator of the reference has HIP kernels
 
 
 class NnhipError(RuntimeError):

@@ -54,6 +54,19 @@ def main():
                           [0.0, 1.0], dict(dt=1e-3), m))
         cases.append(case(f"tstart_shift_{m}", O.RHS_LINEAR, [0.3], [1.0, 2.0], [0.5, 1.0, 1.5, 2.5, 3.0],
                           dict(dt=1e-2, tStart=1.5), m))
+    # the other 11 integrators (ode.nim:107-178, 191-234, 377-468): a smaller set each
+    for m in [x for x in O.ALL_ODE if x not in ("rk4", "dopri54", "tsit54")]:
+        cases.append(case(f"harness_scalar_{m}", O.RHS_LINEAR, [-0.1], [1.0, -1.25], lin, dict(dt=1e-2), m))
+        cases.append(case(f"harness_vec3_{m}", O.RHS_LINEAR, [-0.1], [[1.0, 2.0, -0.5]], lin, dict(dt=1e-2), m))
+        cases.append(case(f"affine_t_{m}", O.RHS_AFFINE_T, [-0.5, 0.25], [1.0, -2.0], [-1.0, -0.25, 0.0, 0.5, 2.0], dict(dt=1e-3), m))
+        cases.append(case(f"lorenz_default_{m}", O.RHS_LORENZ, [10.0, 28.0, 8.0 / 3.0], [[1.0, 1.0, 1.0], [1.0 + 2.0 ** -10, 1.0, 1.0]],
+                          [0.0, 1.0], dict(dt=1e-3), m))
+        cases.append(case(f"ring16_{m}", O.RHS_RING, [0.1], [[1 + i / 16 for i in range(16)]], [0.0, 0.5, 1.0], dict(dt=1e-3), m))
+    for m in ["vern65", "bs32", "rk21"]:
+        cases.append(case(f"rejecting_vdp_{m}", O.RHS_VANDERPOL, [5.0], [[2.0, 0.0]], [0.0, 20.0],
+                          dict(absTol=1e-6, relTol=1e-6, dtMin=1e-9, dtMax=2.0), m))
+        cases.append(case(f"dtmin_escape_{m}", O.RHS_LINEAR, [-200.0], [1.0], [0.0, 0.2],
+                          dict(absTol=1e-12, relTol=1e-12, dtMin=1e-2, dtMax=1e-1), m))
     for m in ["dopri54", "tsit54"]:
         cases.append(case(f"lorenz_tight_{m}", O.RHS_LORENZ, [10.0, 28.0, 8.0 / 3.0],
                           [[1.0 + k * 2.0 ** -20, 1.0, 1.0] for k in (0, 1023)], [0.0, 1.0], tight, m))

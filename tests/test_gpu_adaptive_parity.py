@@ -181,8 +181,6 @@ def test_edge_cases(nn, oracle, dev):
     # unsupported combination is reported, not silently emulated
     with pytest.raises(NotImplementedError):
         nn.solveODE(nn.Rhs.lorenz(), torch.ones(2, 4, dtype=torch.float64, device=dev), [0.0, 1.0], integrator="rk4")
-    with pytest.raises(NotImplementedError):
-        nn.solveODE(f, y0, [0.0, 1.0], integrator="vern65")
 
 
 # ---- BASELINE config C4: Tsit54, 16-dim vector state, lanes-per-system kernel (LDS-staged stage vector) -------

@@ -114,3 +114,29 @@ def test_c2_full_size_properties(nn, oracle, dev):
     assert torch.equal(yfused[0], y0)
     order = torch.argsort(y0[:1 << 20])
     assert bool((torch.diff(yf[:1 << 20][order]) >= 0).all())
+
+
+def test_all_integrators_reference_harness(nn, oracle, dev):
+    """Every integrator name of the reference (allODE, ode.nim:40-42) on the tests/test_ode.nim harness, scalar and
+    Vector states, against the oracle and against the reference's own analytic tolerance for that integrator."""
+    import torch
+    O = oracle
+    ts = O.linspace(-10.0, 10.0, 100)
+    tol_ref = {"dopri54": 1e-4, "rk4": 1e-4, "heun2": 1e-10, "ralston2": 1e-10, "kutta3": 1e-10, "heun3": 1e-10, "ralston3": 1e-10,
+               "ssprk3": 1e-10, "ralston4": 1e-10, "kutta4": 1e-10, "rk21": 1e-6, "bs32": 1e-6, "tsit54": 1e-4, "vern65": 1e-4}
+    assert sorted(tol_ref) == sorted(nn.allODE)
+    y0s = torch.tensor([1.0], dtype=torch.float64, device=dev)
+    y0v = torch.ones(3, 1, dtype=torch.float64, device=dev)
+    for m in nn.allODE:
+        t, y = nn.solveODE(nn.Rhs.linear(-0.1), y0s, ts, integrator=m)           # default options, as test_ode.nim
+        assert np.array_equal(t, ts)
+        got = y[:, 0].cpu().numpy()
+        assert np.abs(got - np.exp(-0.1 * ts)).max() <= tol_ref[m], m
+        rt, ry, st = O.solve_ode(O.RHS_LINEAR, [-0.1], 1.0, ts, O.new_options(), m)
+        if m in nn.fixedODE:
+            assert np.array_equal(got, ry), m
+        else:
+            assert np.abs(got - ry).max() <= 1e-6, m
+        tv, yv = nn.solveODE(nn.Rhs.linear(-0.1), y0v, ts, integrator=m)
+        gv = yv[:, :, 0].cpu().numpy()
+        assert np.array_equal(gv[:, 0], got) and np.array_equal(gv[:, 1], got) and np.array_equal(gv[:, 2], got), m
