@@ -169,6 +169,9 @@ int nnhip_ode_solve_batch_multi_gpu_f64(const nnhip_ode_options* opt, int integr
 /* hermiteSpline (utils.nim:273-279), batched on device: out[i] = H(x; x1, x2, y1[i], y2[i], dy1[i], dy2[i]) */
 int nnhip_hermite_spline_f64_dev(double x, double x1, double x2, const double* y1, const double* y2, const double* dy1,
                                  const double* dy2, double* out, int64_t n, void* stream);
+/* The adaptive controller's step-size factor min(4, max(0.125, 0.9 * pow(1/error, 1/order))) (ode.nim:71, 537) over an
+ * array of error norms; order in {2, 3, 5, 6} (rk21, bs32, dopri54/tsit54, vern65). */
+int nnhip_ode_controller_factor_f64_dev(int order, const double* error, double* out, int64_t n, void* stream);
 /* RHS evaluation alone over a batch: dy = f(t, y) (pins the compiled-in RHS library). */
 int nnhip_ode_rhs_batch_f64_dev(int rhs_kind, const double* rhs_params, int n_params, int64_t N, int dim, int layout,
                                 double t, const double* y, double* dy, void* stream);

@@ -42,6 +42,13 @@ __global__ __launch_bounds__(kBlock) void hermite_kernel(double x, double x1, do
   out[i] = hermite_apply(w, y1[i], y2[i], dy1[i], dy2[i]);
 }
 
+// the controller's step-size factor (ode.nim:71,537) over an array of error norms
+template <int ORDER>
+__global__ __launch_bounds__(kBlock) void controller_factor_kernel(const double* __restrict__ error, double* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) out[i] = shrink_factor<ORDER>(error[i]);
+}
+
 }  // namespace nnhip
 
 extern "C" {
@@ -53,6 +60,21 @@ int nnhip_hermite_spline_f64_dev(double x, double x1, double x2, const double* y
   const int64_t grid = (n + nnhip::kBlock - 1) / nnhip::kBlock;
   return nnhip::launch_kernel(nnhip::hermite_kernel, dim3((unsigned)grid), dim3(nnhip::kBlock), (hipStream_t)stream, x, x1, x2, y1,
                               y2, dy1, dy2, out, n) == hipSuccess ? NNHIP_OK : NNHIP_EHIP;
+}
+
+int nnhip_ode_controller_factor_f64_dev(int order, const double* error, double* out, int64_t n, void* stream) {
+  if (n < 0 || (n > 0 && (!error || !out))) return NNHIP_EVALUE;
+  if (n == 0) return NNHIP_OK;
+  const dim3 grid((unsigned)((n + nnhip::kBlock - 1) / nnhip::kBlock)), block(nnhip::kBlock);
+  hipError_t e;
+  switch (order) {
+    case 2: e = nnhip::launch_kernel(nnhip::controller_factor_kernel<2>, grid, block, (hipStream_t)stream, error, out, n); break;
+    case 3: e = nnhip::launch_kernel(nnhip::controller_factor_kernel<3>, grid, block, (hipStream_t)stream, error, out, n); break;
+    case 5: e = nnhip::launch_kernel(nnhip::controller_factor_kernel<5>, grid, block, (hipStream_t)stream, error, out, n); break;
+    case 6: e = nnhip::launch_kernel(nnhip::controller_factor_kernel<6>, grid, block, (hipStream_t)stream, error, out, n); break;
+    default: return NNHIP_EVALUE;
+  }
+  return e == hipSuccess ? NNHIP_OK : NNHIP_EHIP;
 }
 
 int nnhip_ode_rhs_batch_f64_dev(int rhs_kind, const double* rhs_params, int n_params, int64_t N, int dim, int layout, double t,

@@ -261,3 +261,35 @@ def test_c4_full_size_properties(nn, oracle, dev):
     assert np.abs(yf[:1024].cpu().numpy() - ref["y"][-1]).max() <= TOL_ADAPTIVE
     assert np.array_equal(cnt["steps"][:1024].cpu().numpy(), ref["steps"])
     assert bool((cnt["ny"] == 2).all())
+
+
+@pytest.mark.parametrize("order", [2, 3, 5, 6])
+def test_controller_factor_accuracy(nn, dev, order):
+    """The controller factor min(4, max(0.125, 0.9*pow(1/error, 1/order))) (ode.nim:71,537) computed on the device
+    (nth_root: fp32 estimate + 2 Newton steps) vs a long-double evaluation: within 2 ulp everywhere, exact where
+    the clamp decides, and the reference's special values."""
+    import torch
+    L = nn._lib.lib()
+    rng = np.random.default_rng(order)
+    err = np.concatenate([10 ** rng.uniform(-8, 8, 200_000), 10 ** rng.uniform(-0.5, 0.5, 200_000),
+                          [1.0, 1.0 + 2 ** -52, 1e-300, 1e300, 5e-324, np.inf, 3.0, 0.5]])
+    e = torch.from_numpy(err).to(dev)
+    out = torch.empty_like(e)
+    assert L.nnhip_ode_controller_factor_f64_dev(order, e.data_ptr(), out.data_ptr(), e.numel(), None) == 0
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    with np.errstate(over="ignore", divide="ignore"):
+        x = (1.0 / err).astype(np.longdouble)          # 1/error is an IEEE double division in the reference
+        root = np.exp(np.log(x) / np.longdouble(order))
+        ref = np.minimum(4.0, np.maximum(0.125, (np.longdouble(0.9) * root))).astype(np.float64)
+        ref[np.isinf(err)] = 0.125                     # pow(0, p) = 0 -> max(0.125, 0)
+    ulp = np.spacing(np.abs(ref))
+    assert np.all(np.abs(got - ref) <= 2 * ulp), float(np.max(np.abs(got - ref) / ulp))
+    clamped = (ref == 4.0) | (ref == 0.125)
+    assert clamped.sum() > 1000 and np.array_equal(got[clamped], ref[clamped])
+    # NaN error propagates as NaN (the reference's min/max let NaN through, ode.nim:71)
+    en = torch.tensor([float("nan")], dtype=torch.float64, device=dev)
+    on = torch.empty_like(en)
+    L.nnhip_ode_controller_factor_f64_dev(order, en.data_ptr(), on.data_ptr(), 1, None)
+    torch.cuda.synchronize()
+    assert np.isnan(on.cpu().numpy()[0])
