@@ -49,10 +49,12 @@ const MethodInfo kMethods[NNHIP_N_INTEGRATORS] = {
     {"ralston4", 0, 4.0, 0, 1}, {"kutta4", 0, 4.0, 0, 1},
 };
 
+int g_wide_tpi = 0;  // tuning: prefer the register-resident thread-per-IVP fused kernel for dim-16 systems
+
 nnhip::SolveLaunchFn find_solve(int integrator, int rhs_kind, int dim) {
   switch (integrator) {
 #define X(id, name) \
-  case id: return nnhip::find_solve_##name(rhs_kind, dim);
+  case id: return nnhip::find_solve_##name(rhs_kind, dim, g_wide_tpi);
     NNHIP_FOR_EACH_METHOD(X)
 #undef X
   }
@@ -162,6 +164,7 @@ const char* nnhip_build_info(void) {
 int nnhip_tune_set(const char* key, int value) {
   if (!key) return fail(NNHIP_EVALUE, "key is NULL");
   const std::string k(key);
+  if (k == "wide_tpi") { g_wide_tpi = value; return NNHIP_OK; }
   if (k == "rk4_stream_auto") { g_tune_auto = value != 0; return NNHIP_OK; }
   if (k == "rk4_stream_vec" || k == "rk4_stream_mode") g_tune_auto = false;
   if (k == "rk4_stream_vec") { if (value != 1 && value != 2 && value != 4 && value != 8) return fail(NNHIP_EVALUE, "rk4_stream_vec must be 1, 2, 4 or 8"); g_tune.vec = value; return NNHIP_OK; }

@@ -115,7 +115,7 @@ struct StepCtl {  // the option fields the steppers read (ode.nim:283-286)
 //   ops.rhs(t,y,dy) dy = f(t,y), or g(t,y) = -f(-t,y) when NEG (backward branch, ode.nim:545)
 //   ops.norm(...)   scaled RMS error norm of commonAdaptiveMethodCode (ode.nim:61-65)
 // TpiOps: thread-per-IVP — the lane owns the whole state (D = dim), everything in VGPRs.
-// LpsOps: lanes-per-system — DIM lanes of ONE wavefront own one component each (D = 1).  The stage
+// LpsOps: lanes-per-system — DIM/CPL lanes of ONE wavefront own CPL components each (D = CPL).  The stage
 //         argument vector is staged in LDS so any component's RHS can read any other component, and the
 //         error norm is reduced across the DIM lanes through LDS in the reference's left-to-right order
 //         (every lane of a system gets the bit-identical `error`, so the group stays in lock-step).
@@ -153,25 +153,32 @@ NNHIP_DEV void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <class RHS, bool NEG>
+template <class RHS, bool NEG, int CPL = 1>
 struct LpsOps {
-  static constexpr int D = 1;
-  static constexpr int DIM = RHS::dim;
+  static constexpr int D = CPL;            // components per lane
+  static constexpr int DIM = RHS::dim;     // components per system; DIM / CPL lanes of one wavefront share a system
   const Params& P;
   double* ys;  // LDS, DIM doubles: stage argument vector of this lane's system
   double* es;  // LDS, DIM doubles: squared scaled error components
-  int c;       // component owned by this lane
-  NNHIP_DEV void rhs(double t, const double (&y)[1], double (&dy)[1]) const {
-    ys[c] = y[0];
+  int c0;      // first component owned by this lane (owns c0 .. c0+CPL-1)
+  NNHIP_DEV void rhs(double t, const double (&y)[CPL], double (&dy)[CPL]) const {
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) ys[c0 + j] = y[j];
     wave_lds_sync();
-    const double v = RHS::comp(NEG ? -t : t, c, ys, P);
-    dy[0] = NEG ? -v : v;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const double v = RHS::comp(NEG ? -t : t, c0 + j, ys, P);
+      dy[j] = NEG ? -v : v;
+    }
     wave_lds_sync();  // the next stage overwrites ys
   }
-  NNHIP_DEV double norm(const double (&yNew)[1], const double (&err_y)[1], const StepCtl& o) const {
-    const double totalTol = fabs(yNew[0]) * o.relTol + o.absTol;
-    const double e = err_y[0] / totalTol;
-    es[c] = e * e;
+  NNHIP_DEV double norm(const double (&yNew)[CPL], const double (&err_y)[CPL], const StepCtl& o) const {
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const double totalTol = fabs(yNew[j]) * o.relTol + o.absTol;
+      const double e = err_y[j] / totalTol;
+      es[c0 + j] = e * e;
+    }
     wave_lds_sync();
     double sum = 0.0;
 #pragma unroll

@@ -214,19 +214,20 @@ hipError_t launch_solve_tpi(const SolveArgs& a, hipStream_t s) {
 // Lane (s, c) owns component c of system s: its y, k1..kS, yNew are single VGPR doubles; the stage
 // argument vector and the squared error components of each system live in LDS (2*DIM doubles per system,
 // 4 KiB per 256-thread workgroup).  With the AoS layout a wave's 64 lanes read 512 contiguous bytes.
-template <int METHOD, class RHS>
+template <int METHOD, class RHS, int CPL>
 __global__ __launch_bounds__(kBlock) void solve_lps_kernel(const SolveArgs a) {
   constexpr int DIM = RHS::dim;
-  static_assert(64 % DIM == 0, "a system must not straddle wavefronts");
-  __shared__ double lds[2 * kBlock];
-  const int sysInBlock = threadIdx.x / DIM, c = threadIdx.x % DIM;
-  const int64_t i = (int64_t)blockIdx.x * (kBlock / DIM) + sysInBlock;
+  constexpr int LPSYS = DIM / CPL;  // lanes per system
+  static_assert(DIM % CPL == 0 && 64 % LPSYS == 0, "a system must not straddle wavefronts");
+  __shared__ double lds[2 * kBlock * CPL];
+  const int sysInBlock = threadIdx.x / LPSYS, c = (threadIdx.x % LPSYS) * CPL;
+  const int64_t i = (int64_t)blockIdx.x * (kBlock / LPSYS) + sysInBlock;
   LaneStats ls;
   if (i < a.N) {
     double* ys = lds + sysInBlock * DIM;
-    double* es = lds + kBlock + sysInBlock * DIM;
-    const LpsOps<RHS, false> opsF{a.P, ys, es, c};
-    const LpsOps<RHS, true> opsB{a.P, ys, es, c};
+    double* es = lds + kBlock * CPL + sysInBlock * DIM;
+    const LpsOps<RHS, false, CPL> opsF{a.P, ys, es, c};
+    const LpsOps<RHS, true, CPL> opsB{a.P, ys, es, c};
     solve_body<METHOD>(a, opsF, opsB, a.y0 + i * a.ivpStride + c * a.compStride, a.y_out + i * a.ivpStride + c * a.compStride, ls);
     if (c == 0) {
       if (a.ny_out) a.ny_out[i] = ls.ny;
@@ -239,12 +240,12 @@ __global__ __launch_bounds__(kBlock) void solve_lps_kernel(const SolveArgs a) {
   if (a.agg) aggregate_stats(a.agg, ls);
 }
 
-template <int METHOD, class RHS>
+template <int METHOD, class RHS, int CPL = 1>
 hipError_t launch_solve_lps(const SolveArgs& a, hipStream_t s) {
-  constexpr int perBlock = kBlock / RHS::dim;
+  constexpr int perBlock = kBlock / (RHS::dim / CPL);
   const int64_t grid = (a.N + perBlock - 1) / perBlock;
   if (grid <= 0) return hipSuccess;
-  return launch_kernel(solve_lps_kernel<METHOD, RHS>, dim3((unsigned)grid), dim3(kBlock), s, a);
+  return launch_kernel(solve_lps_kernel<METHOD, RHS, CPL>, dim3((unsigned)grid), dim3(kBlock), s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -417,19 +418,30 @@ hipError_t launch_rk4_stream_vec(const double* yin, double* yout, int64_t n, dou
   X(NNHIP_RHS_AFFINE_T, 4, RhsAffineT<4>) X(NNHIP_RHS_LORENZ, 3, RhsLorenz) X(NNHIP_RHS_VANDERPOL, 2, RhsVanDerPol) \
   X(NNHIP_RHS_RING, 4, RhsRing<4>)
 
-// systems integrated by DIM lanes of one wavefront (DIM must divide 64)
-#define NNHIP_FOR_EACH_LPS_RHS(X)                                                                              \
-  X(NNHIP_RHS_RING, 8, RhsRing<8>) X(NNHIP_RHS_RING, 16, RhsRing<16>) X(NNHIP_RHS_RING, 32, RhsRing<32>)       \
-  X(NNHIP_RHS_NEG_Y, 16, RhsNegY<16>) X(NNHIP_RHS_LINEAR, 16, RhsLinear<16>) X(NNHIP_RHS_AFFINE_T, 16, RhsAffineT<16>)
+// Systems integrated by several lanes of one wavefront.  X(kind, dim, RHS type, CPL adaptive, CPL fixed-step):
+// components per lane of the FUSED kernels, from the A/B on MI355X (profiles/r01_dim16_variants.txt; 1e6 16-dim
+// systems, Tsit54: 1 comp/lane 10.9 ms, 2: 7.9, 4: 7.6, 8: 13.1, all-in-one-lane 7.4; Vern65: 4/lane 9.8 vs 13.9).
+// Fewer lanes per system = less redundant controller work (norm, sqrt, root run once per LANE); more
+// components per lane = more VGPRs (85 / 115 / 193 / 256) and less latency hiding.  The step-streaming kernels
+// are HBM-bound and keep 1 component per lane (best coalescing, fewest registers).
+#define NNHIP_FOR_EACH_LPS_RHS(X)                                                                  \
+  X(NNHIP_RHS_RING, 8, RhsRing<8>, 2, 2) X(NNHIP_RHS_RING, 16, RhsRing<16>, 4, 2) X(NNHIP_RHS_RING, 32, RhsRing<32>, 4, 2) \
+  X(NNHIP_RHS_NEG_Y, 16, RhsNegY<16>, 4, 2) X(NNHIP_RHS_LINEAR, 16, RhsLinear<16>, 4, 2) X(NNHIP_RHS_AFFINE_T, 16, RhsAffineT<16>, 4, 2)
+
+// dim-16 systems also have a register-resident thread-per-IVP fused kernel (all 512 VGPR+AGPR of a lane, one
+// wave per SIMD; tuning knob "wide_tpi" = 1) and the 1-component-per-lane form ("wide_tpi" = -1) for A/B runs.
+#define NNHIP_FOR_EACH_WIDE_TPI_RHS(X) X(NNHIP_RHS_RING, 16, RhsRing<16>)
 
 template <int METHOD>
-SolveLaunchFn find_solve_tpi(int rhs_kind, int dim) {
+SolveLaunchFn find_solve_tpi(int rhs_kind, int dim, int wide_tpi) {
 #define X(kind, d, T) \
   if (rhs_kind == kind && dim == d) return &launch_solve_tpi<METHOD, T>;
   NNHIP_FOR_EACH_TPI_RHS(X)
+  if (wide_tpi == 1) { NNHIP_FOR_EACH_WIDE_TPI_RHS(X) }
 #undef X
-#define X(kind, d, T) \
-  if (rhs_kind == kind && dim == d) return &launch_solve_lps<METHOD, T>;
+  if (wide_tpi == -1 && rhs_kind == NNHIP_RHS_RING && dim == 16) return &launch_solve_lps<METHOD, RhsRing<16>, 1>;
+#define X(kind, d, T, CA, CF) \
+  if (rhs_kind == kind && dim == d) return &launch_solve_lps<METHOD, T, (MethodTraits<METHOD>::adaptive ? CA : CF)>;
   NNHIP_FOR_EACH_LPS_RHS(X)
 #undef X
   return nullptr;
@@ -440,7 +452,7 @@ StepLaunchFn find_step_tpi(int rhs_kind, int dim) {
   if (rhs_kind == kind && dim == d) return &launch_step_tpi<METHOD, T>;
   NNHIP_FOR_EACH_TPI_RHS(X)
 #undef X
-#define X(kind, d, T) \
+#define X(kind, d, T, CA, CF) \
   if (rhs_kind == kind && dim == d) return &launch_step_lps<METHOD, T>;
   NNHIP_FOR_EACH_LPS_RHS(X)
 #undef X
@@ -452,8 +464,8 @@ StepLaunchFn find_step_tpi(int rhs_kind, int dim) {
   X(NNHIP_RK4, rk4) X(NNHIP_DOPRI54, dopri54) X(NNHIP_TSIT54, tsit54) X(NNHIP_VERN65, vern65) X(NNHIP_BS32, bs32)        \
   X(NNHIP_RK21, rk21) X(NNHIP_HEUN2, heun2) X(NNHIP_RALSTON2, ralston2) X(NNHIP_KUTTA3, kutta3) X(NNHIP_HEUN3, heun3)    \
   X(NNHIP_RALSTON3, ralston3) X(NNHIP_SSPRK3, ssprk3) X(NNHIP_RALSTON4, ralston4) X(NNHIP_KUTTA4, kutta4)
-#define X(id, name)                                        \
-  SolveLaunchFn find_solve_##name(int rhs_kind, int dim);  \
+#define X(id, name)                                                      \
+  SolveLaunchFn find_solve_##name(int rhs_kind, int dim, int wide_tpi);  \
   StepLaunchFn find_step_##name(int rhs_kind, int dim);
 NNHIP_FOR_EACH_METHOD(X)
 #undef X
