@@ -1,0 +1,66 @@
+"""Randomised parity sweep: random (integrator, RHS, dim, layout, tspan incl. negatives / duplicates / tStart inside or
+outside, options) -> HIP path vs live oracle.  Seeds are fixed, so failures are reproducible."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+KEYS = {1: ("a",), 2: ("sigma", "rho", "beta"), 3: ("c",), 4: ("a", "b"), 5: ("mu",)}
+
+
+def _draw(rng, nn):
+    kind = int(rng.choice([0, 1, 2, 3, 4, 5]))
+    if kind in (0, 1, 4):
+        dim = int(rng.choice([1, 2, 3, 4, 16]))
+        params = {0: [], 1: [float(rng.uniform(-2, 0.5))], 4: [float(rng.uniform(-2, 0.5)), float(rng.uniform(-1, 1))]}[kind]
+    elif kind == 2:
+        dim, params = 3, [10.0, float(rng.uniform(20, 30)), 8.0 / 3.0]
+    elif kind == 3:
+        dim, params = int(rng.choice([4, 8, 16, 32])), [float(rng.uniform(-0.3, 0.3))]
+    else:
+        dim, params = 2, [float(rng.uniform(0.2, 3.0))]
+    integ = str(rng.choice(nn.allODE))
+    n_t = int(rng.choice([1, 2, 2, 3, 5, 17]))
+    tstart = float(rng.choice([0.0, 0.0, 0.5, -0.25]))
+    span = float(rng.uniform(0.05, 0.6))
+    ts = np.round(rng.uniform(tstart - span, tstart + span, n_t), 3)
+    if rng.random() < 0.3:
+        ts[0] = tstart                      # tStart inside tspan
+    if rng.random() < 0.15 and n_t > 2:
+        ts[1] = ts[2]                       # duplicate request
+    if rng.random() < 0.2:
+        ts = np.abs(ts - tstart) + tstart   # all on the forward side
+    opt = dict(dt=float(rng.choice([1e-2, 3e-3, 2.0 ** -7])), absTol=float(10 ** rng.uniform(-9, -4)), relTol=float(10 ** rng.uniform(-9, -4)),
+               dtMin=float(10 ** rng.uniform(-6, -4)), dtMax=float(10 ** rng.uniform(-2.5, -1)), tStart=tstart)
+    n = int(rng.choice([1, 5, 70, 300]))
+    layout = int(rng.choice([0, 1]))
+    return kind, dim, params, integ, ts, opt, n, layout
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_case(nn, oracle, dev, seed):
+    import torch
+    O = oracle
+    rng = np.random.default_rng(1000 + seed)
+    kind, dim, params, integ, ts, opt, n, layout = _draw(rng, nn)
+    y0 = rng.uniform(-1.5, 1.5, (n, dim)) + (np.array([0.0, 0.0, 15.0]) if kind == 2 else 0.0)
+    y0l = np.ascontiguousarray(y0 if layout == 1 else y0.T)
+    if dim == 1:
+        y0l, layout = y0[:, 0].copy(), 0
+    f = nn.Rhs(kind, KEYS.get(kind, ()), dict(zip(KEYS.get(kind, ()), params)))
+    t, y, cnt = nn.solveODE(f, torch.from_numpy(y0l).to(dev), ts, nn.newODEoptions(**opt), integrator=integ, layout=layout, return_counts=True)
+    ref = O.solve_ode_batch(kind, params, y0l, n, 0 if dim == 1 else dim, ts, O.new_options(**opt), integ, layout=layout, n_threads=8)
+    nt_ref = len(O.solve_ode(kind, params, float(y0[0, 0]) if dim == 1 else list(y0[0]), ts, O.new_options(**opt), integ)[0])
+    assert len(t) == nt_ref and np.array_equal(t, ref["t"][:nt_ref])
+    got = y.cpu().numpy().reshape(ref["y"].shape)
+    assert np.array_equal(cnt["ny"].cpu().numpy(), ref["ny"])
+    assert np.array_equal(np.isnan(got), np.isnan(ref["y"]))
+    fixed = integ in nn.fixedODE
+    m = ~np.isnan(ref["y"])
+    if fixed:
+        assert np.array_equal(got[m], ref["y"][m]), (integ, kind, dim)
+        assert np.array_equal(cnt["steps"].cpu().numpy(), ref["steps"])
+    else:
+        assert np.abs(got[m] - ref["y"][m]).max() <= 1e-6 if m.any() else True
+        # step counts: identical unless a last-ulp root difference flips an accept decision (allow a tiny fraction)
+        ds = np.abs(cnt["steps"].cpu().numpy() - ref["steps"]) + np.abs(cnt["rejected"].cpu().numpy() - ref["rejected"])
+        assert (ds > 0).mean() <= 0.02, (integ, kind, dim, int((ds > 0).sum()))
