@@ -64,7 +64,8 @@ typedef enum nnhip_rhs_kind {
   NNHIP_RHS_RING = 3,      /* dim d   : dy_c = -((c+1)/d)*y_c + p0*y_{(c+1) mod d}                          */
   NNHIP_RHS_AFFINE_T = 4,  /* any dim : dy_c = p0*y_c + p1*t                                                */
   NNHIP_RHS_VANDERPOL = 5, /* dim 2   : dx = v; dv = p0*((1 - x*x)*v) - x                                   */
-  NNHIP_N_RHS = 6
+  NNHIP_N_RHS = 6,
+  NNHIP_RHS_USER_BASE = 1000 /* rhs_kind values >= this are user right-hand sides from nnhip_ode_rhs_compile */
 } nnhip_rhs_kind;
 
 typedef enum nnhip_layout { NNHIP_LAYOUT_SOA = 0, NNHIP_LAYOUT_AOS = 1 } nnhip_layout;
@@ -164,6 +165,18 @@ int nnhip_ode_solve_batch_multi_gpu_f64(const nnhip_ode_options* opt, int integr
                                         const double* rhs_params, int n_params, const double* y0, int64_t N, int dim,
                                         int layout, const double* tspan, int n_t, double* t_out, double* y_out,
                                         int32_t* ny_out, int64_t max_steps, nnhip_ode_stats* stats, int n_gpus);
+
+/* ---- user-supplied right-hand side (run-time compiled) ------------------------------------------
+ * The reference accepts any closure f(t, y, ctx) (ODEProc[T], ode.nim:36).  A host closure cannot run on the
+ * device, its source can: `body` is the HIP C++ body of
+ *     __device__ void rhs(double t, const double* y, double* dy, const double* p)   // y, dy: dim components; p: rhs_params
+ * e.g. "dy[0] = y[1]; dy[1] = -p[0]*y[0];".  It is compiled with hiprtc into the SAME stepper / driver kernel
+ * templates the built-in RHS use (same -ffp-contract=off numerics), once per (rhs, integrator), cached in-process.
+ * *rhs_kind_out receives a handle (>= NNHIP_RHS_USER_BASE) accepted by every entry that takes rhs_kind
+ * (thread-per-IVP kernels; dim 1..16).  The body is syntax-checked at registration; NNHIP_EVALUE + the compiler
+ * log in nnhip_last_error() on failure. */
+int nnhip_ode_rhs_compile(const char* name, int dim, int n_params, const char* body, int* rhs_kind_out);
+int nnhip_ode_rhs_release(int rhs_kind);
 
 /* ---- consumers either side of the path ------------------------------------------------------- */
 /* hermiteSpline (utils.nim:273-279), batched on device: out[i] = H(x; x1, x2, y1[i], y2[i], dy1[i], dy2[i]) */

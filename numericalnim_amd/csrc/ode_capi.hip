@@ -14,10 +14,11 @@
 #include <vector>
 
 #include "ode_kernels.hpp"
+#include "ode_rtc.hpp"
 
 namespace {
 
-thread_local char g_err[512] = "";
+thread_local char g_err[8192] = "";
 
 int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -76,14 +77,22 @@ int check_common(const nnhip_ode_options* opt, int integrator, int rhs_kind, con
                  int64_t N, int dim, int layout, nnhip::Params& P) {
   if (!opt) return fail(NNHIP_EVALUE, "options is NULL");
   if (integrator < 0 || integrator >= NNHIP_N_INTEGRATORS) return fail(NNHIP_EINTEGRATOR, "%d is not a valid integrator", integrator);
-  if (rhs_kind < 0 || rhs_kind >= NNHIP_N_RHS) return fail(NNHIP_EVALUE, "unknown rhs_kind %d", rhs_kind);
+  int userDim = 0, userParams = 0;
+  const bool user = rhs_kind >= NNHIP_RHS_USER_BASE;
+  if (user) {
+    if (!nnhip::rtc_info(rhs_kind, &userDim, &userParams)) return fail(NNHIP_EVALUE, "unknown user rhs_kind %d", rhs_kind);
+    if (dim != userDim) return fail(NNHIP_EVALUE, "user rhs_kind %d was compiled for dim %d, got %d", rhs_kind, userDim, dim);
+  } else if (rhs_kind < 0 || rhs_kind >= NNHIP_N_RHS) {
+    return fail(NNHIP_EVALUE, "unknown rhs_kind %d", rhs_kind);
+  }
   if (N < 0) return fail(NNHIP_EVALUE, "N must be >= 0");
   if (dim < 1) return fail(NNHIP_EVALUE, "dim must be >= 1 (scalar state = dim 1)");
   if (layout != NNHIP_LAYOUT_SOA && layout != NNHIP_LAYOUT_AOS) return fail(NNHIP_EVALUE, "unknown layout %d", layout);
   if (n_params < 0 || n_params > nnhip::kMaxParams) return fail(NNHIP_EVALUE, "n_params must be in [0, %d]", nnhip::kMaxParams);
   if (n_params > 0 && !rhs_params) return fail(NNHIP_EVALUE, "rhs_params is NULL");
   static const int need[NNHIP_N_RHS] = {0, 1, 3, 1, 2, 1};
-  if (n_params < need[rhs_kind]) return fail(NNHIP_EVALUE, "rhs_kind %d needs %d parameters, got %d", rhs_kind, need[rhs_kind], n_params);
+  const int needed = user ? userParams : need[rhs_kind];
+  if (n_params < needed) return fail(NNHIP_EVALUE, "rhs_kind %d needs %d parameters, got %d", rhs_kind, needed, n_params);
   for (int k = 0; k < nnhip::kMaxParams; ++k) P.p[k] = k < n_params ? rhs_params[k] : 0.0;
   return NNHIP_OK;
 }
@@ -219,7 +228,25 @@ int nnhip_ode_time_grid(const nnhip_ode_options* opt, const double* tspan, int n
   return NNHIP_OK;
 }
 
+int nnhip_ode_rhs_compile(const char* name, int dim, int n_params, const char* body, int* rhs_kind_out) {
+  if (!body || !rhs_kind_out) return fail(NNHIP_EVALUE, "body / rhs_kind_out is NULL");
+  if (dim < 1 || dim > 16) return fail(NNHIP_EVALUE, "user RHS dim must be in [1, 16]");
+  if (n_params < 0 || n_params > nnhip::kMaxParams) return fail(NNHIP_EVALUE, "n_params must be in [0, %d]", nnhip::kMaxParams);
+  const int k = nnhip::rtc_register(name, dim, n_params, body, true);
+  if (k < 0) return fail(NNHIP_EVALUE, "%s", nnhip::rtc_last_error());
+  *rhs_kind_out = k;
+  return NNHIP_OK;
+}
+
+int nnhip_ode_rhs_release(int rhs_kind) {
+  return nnhip::rtc_release(rhs_kind) == 0 ? NNHIP_OK : fail(NNHIP_EVALUE, "unknown user rhs_kind %d", rhs_kind);
+}
+
 int nnhip_ode_supported(int integrator, int rhs_kind, int dim, int layout, int mode) {
+  if (integrator >= 0 && integrator < NNHIP_N_INTEGRATORS && rhs_kind >= NNHIP_RHS_USER_BASE) {
+    int d = 0;
+    return nnhip::rtc_info(rhs_kind, &d, nullptr) && d == dim;
+  }
   if (integrator < 0 || integrator >= NNHIP_N_INTEGRATORS || rhs_kind < 0 || rhs_kind >= NNHIP_N_RHS) return 0;
   if (layout != NNHIP_LAYOUT_SOA && layout != NNHIP_LAYOUT_AOS) return 0;
   if (mode == 0) return find_solve(integrator, rhs_kind, dim) != nullptr;
@@ -246,8 +273,9 @@ static int solve_dev_impl(const nnhip_ode_options* opt, int integrator, int rhs_
   if (n_t < 0 || (n_t > 0 && !tspan)) return fail(NNHIP_EVALUE, "bad tspan");
   if (N > 0 && (!y0 || !y_out)) return fail(NNHIP_EVALUE, "y0 / y_out is NULL");
   if (!kMethods[integrator].implemented) return fail(NNHIP_EUNSUPPORTED, "integrator %s has no HIP kernel yet", kMethods[integrator].name);
-  nnhip::SolveLaunchFn fn = find_solve(integrator, rhs_kind, dim);
-  if (!fn) return fail(NNHIP_EUNSUPPORTED, "no fused-solve kernel for integrator=%s rhs_kind=%d dim=%d", kMethods[integrator].name, rhs_kind, dim);
+  const bool user = rhs_kind >= NNHIP_RHS_USER_BASE;
+  nnhip::SolveLaunchFn fn = user ? nullptr : find_solve(integrator, rhs_kind, dim);
+  if (!fn && !user) return fail(NNHIP_EUNSUPPORTED, "no fused-solve kernel for integrator=%s rhs_kind=%d dim=%d", kMethods[integrator].name, rhs_kind, dim);
   const bool adaptive = kMethods[integrator].adaptive;
   // Deviations from the reference that keep the device from spinning forever (documented in DESIGN.md):
   if (!adaptive && !(opt->dt > 0.0)) return fail(NNHIP_EVALUE, "fixed-step integrators need options.dt > 0 (the reference would loop forever)");
@@ -285,6 +313,11 @@ static int solve_dev_impl(const nnhip_ode_options* opt, int integrator, int rhs_
     g_stage.pending = true;
     a.tPos = (const double*)ws;
     a.tNeg = (const double*)ws + a.nPos;
+  }
+  if (user) {
+    if (nnhip::rtc_launch_solve(rhs_kind, integrator, a, stream) != hipSuccess)
+      return fail(NNHIP_EHIP, "user RHS launch failed: %s", nnhip::rtc_last_error());
+    return NNHIP_OK;
   }
   HIP_TRY(fn(a, stream));
   return NNHIP_OK;
@@ -398,14 +431,20 @@ int nnhip_ode_step_batch_f64_dev(const nnhip_ode_options* opt, int integrator, i
     HIP_TRY(nnhip::launch_rk4_stream(rhs_kind, y_in, y_out, N * dim, t_uniform, dt_uniform, P, negate_time, tune, (hipStream_t)stream));
     return NNHIP_OK;
   }
-  nnhip::StepLaunchFn fn = find_step(integrator, rhs_kind, dim);
-  if (!fn) return fail(NNHIP_EUNSUPPORTED, "no step kernel for integrator=%s rhs_kind=%d dim=%d", kMethods[integrator].name, rhs_kind, dim);
+  const bool user = rhs_kind >= NNHIP_RHS_USER_BASE;
+  nnhip::StepLaunchFn fn = user ? nullptr : find_step(integrator, rhs_kind, dim);
+  if (!fn && !user) return fail(NNHIP_EUNSUPPORTED, "no step kernel for integrator=%s rhs_kind=%d dim=%d", kMethods[integrator].name, rhs_kind, dim);
   nnhip::StepArgs a{};
   a.N = N;
   if (layout == NNHIP_LAYOUT_SOA) { a.ivpStride = 1; a.compStride = N; } else { a.ivpStride = dim; a.compStride = 1; }
   a.t_dev = t_dev; a.t_uniform = t_uniform; a.dt_dev = dt_dev; a.dt_uniform = dt_uniform;
   a.y_in = y_in; a.fsal_in = fsal_in; a.y_out = y_out; a.fsal_out = fsal_out; a.dt_used = dt_used; a.error = error;
   a.ctl = ctl_of(opt); a.P = P;
+  if (user) {
+    if (nnhip::rtc_launch_step(rhs_kind, integrator, a, negate_time, (hipStream_t)stream) != hipSuccess)
+      return fail(NNHIP_EHIP, "user RHS launch failed: %s", nnhip::rtc_last_error());
+    return NNHIP_OK;
+  }
   HIP_TRY(fn(a, negate_time, (hipStream_t)stream));
   return NNHIP_OK;
 }

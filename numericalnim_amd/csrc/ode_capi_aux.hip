@@ -8,22 +8,9 @@
 #include <vector>
 
 #include "ode_kernels.hpp"
+#include "ode_rtc.hpp"
 
 namespace nnhip {
-
-template <class RHS>
-__global__ __launch_bounds__(kBlock) void rhs_batch_kernel(int64_t N, int64_t ivpStride, int64_t compStride, double t,
-                                                           const double* __restrict__ y, double* __restrict__ dy, const Params P) {
-  constexpr int D = RHS::dim;
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= N) return;
-  double yv[D], d[D];
-#pragma unroll
-  for (int c = 0; c < D; ++c) yv[c] = y[i * ivpStride + c * compStride];
-  RHS::eval(t, yv, d, P);
-#pragma unroll
-  for (int c = 0; c < D; ++c) dy[i * ivpStride + c * compStride] = d[c];
-}
 
 template <class RHS>
 hipError_t launch_rhs_batch(int64_t N, int64_t is, int64_t cs, double t, const double* y, double* dy, const Params& P, hipStream_t s) {
@@ -84,6 +71,11 @@ int nnhip_ode_rhs_batch_f64_dev(int rhs_kind, const double* rhs_params, int n_pa
   nnhip::Params P;
   for (int k = 0; k < nnhip::kMaxParams; ++k) P.p[k] = k < n_params ? rhs_params[k] : 0.0;
   const int64_t is = layout == NNHIP_LAYOUT_SOA ? 1 : dim, cs = layout == NNHIP_LAYOUT_SOA ? N : 1;
+  if (rhs_kind >= NNHIP_RHS_USER_BASE) {
+    int d = 0;
+    if (!nnhip::rtc_info(rhs_kind, &d, nullptr) || d != dim) return NNHIP_EVALUE;
+    return nnhip::rtc_launch_rhs(rhs_kind, N, is, cs, t, y, dy, P, (hipStream_t)stream) == hipSuccess ? NNHIP_OK : NNHIP_EHIP;
+  }
   hipError_t e = hipErrorInvalidValue;
   bool found = false;
 #define X(kind, d, T)                                                                    \

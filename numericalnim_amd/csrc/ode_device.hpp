@@ -13,9 +13,13 @@
 // (nth_root below; glibc's pow is not correctly rounded either).
 #pragma once
 #include <hip/hip_runtime.h>
+#ifdef __HIPCC_RTC__
+#include "nnhip_ode.h"  // virtual header handed to hiprtc
+#else
 #include <stdint.h>
 
 #include "../../include/nnhip_ode.h"
+#endif
 
 namespace nnhip {
 

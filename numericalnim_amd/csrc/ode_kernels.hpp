@@ -11,9 +11,14 @@
 //                      independent loads in flight per lane (the BASELINE.json headline kernel;
 //                      algorithmic traffic 16 B per trajectory-step)                 -> HBM bound
 #pragma once
+#ifdef __HIPCC_RTC__  // compiled at run time by hiprtc for a user-supplied RHS (ode_rtc.hip): device code only
+#define NNHIP_RTC 1
+#else
+#define NNHIP_RTC 0
 #include <tuple>
 #include <type_traits>
 #include <utility>
+#endif
 
 #include "ode_device.hpp"
 
@@ -57,10 +62,11 @@ struct StepArgs {
   Params P;
 };
 
+constexpr int kBlock = 256;
+
+#if !NNHIP_RTC
 using SolveLaunchFn = hipError_t (*)(const SolveArgs&, hipStream_t);
 using StepLaunchFn = hipError_t (*)(const StepArgs&, int negate, hipStream_t);
-
-constexpr int kBlock = 256;
 
 // Launch through hipLaunchKernel so the returned status belongs to THIS launch (hipGetLastError() can hand
 // back a stale error left by an unrelated runtime call of the host process).
@@ -72,6 +78,7 @@ inline hipError_t launch_kernel(void (*kernel)(KArgs...), dim3 grid, dim3 block,
   std::apply([&](auto&... a) { ((ptrs[k++] = (void*)&a), ...); }, pack);
   return hipLaunchKernel((const void*)kernel, grid, block, ptrs, 0, s);
 }
+#endif  // !NNHIP_RTC
 
 // ------------------------------------------------------------------------------------------------
 // fused solve: the body shared by the thread-per-IVP and lanes-per-system kernels.  `out`/`y0p` already
@@ -203,12 +210,14 @@ __global__ __launch_bounds__(kBlock) void solve_tpi_kernel(const SolveArgs a) {
   if (a.agg) aggregate_stats(a.agg, ls);
 }
 
+#if !NNHIP_RTC
 template <int METHOD, class RHS>
 hipError_t launch_solve_tpi(const SolveArgs& a, hipStream_t s) {
   const int64_t grid = (a.N + kBlock - 1) / kBlock;
   if (grid <= 0) return hipSuccess;
   return launch_kernel(solve_tpi_kernel<METHOD, RHS>, dim3((unsigned)grid), dim3(kBlock), s, a);
 }
+#endif
 
 // ---- lanes per system: DIM lanes of one wavefront integrate one DIM-component system -------------
 // Lane (s, c) owns component c of system s: its y, k1..kS, yNew are single VGPR doubles; the stage
@@ -240,6 +249,7 @@ __global__ __launch_bounds__(kBlock) void solve_lps_kernel(const SolveArgs a) {
   if (a.agg) aggregate_stats(a.agg, ls);
 }
 
+#if !NNHIP_RTC
 template <int METHOD, class RHS, int CPL = 1>
 hipError_t launch_solve_lps(const SolveArgs& a, hipStream_t s) {
   constexpr int perBlock = kBlock / (RHS::dim / CPL);
@@ -247,6 +257,7 @@ hipError_t launch_solve_lps(const SolveArgs& a, hipStream_t s) {
   if (grid <= 0) return hipSuccess;
   return launch_kernel(solve_lps_kernel<METHOD, RHS, CPL>, dim3((unsigned)grid), dim3(kBlock), s, a);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // one IntegratorProc call (step-streaming; state in HBM between calls)
@@ -301,6 +312,7 @@ __global__ __launch_bounds__(kBlock) void step_tpi_kernel(const StepArgs a) {
   step_body<METHOD>(a, ops, i, i * a.ivpStride, true);
 }
 
+#if !NNHIP_RTC
 template <int METHOD, class RHS>
 hipError_t launch_step_tpi(const StepArgs& a, int negate, hipStream_t s) {
   const int64_t grid = (a.N + kBlock - 1) / kBlock;
@@ -308,6 +320,7 @@ hipError_t launch_step_tpi(const StepArgs& a, int negate, hipStream_t s) {
   if (negate) return launch_kernel(step_tpi_kernel<METHOD, RHS, true>, dim3((unsigned)grid), dim3(kBlock), s, a);
   return launch_kernel(step_tpi_kernel<METHOD, RHS, false>, dim3((unsigned)grid), dim3(kBlock), s, a);
 }
+#endif
 
 template <int METHOD, class RHS, bool NEG>
 __global__ __launch_bounds__(kBlock) void step_lps_kernel(const StepArgs a) {
@@ -320,6 +333,7 @@ __global__ __launch_bounds__(kBlock) void step_lps_kernel(const StepArgs a) {
   step_body<METHOD>(a, ops, i, i * a.ivpStride + c * a.compStride, c == 0);
 }
 
+#if !NNHIP_RTC
 template <int METHOD, class RHS>
 hipError_t launch_step_lps(const StepArgs& a, int negate, hipStream_t s) {
   constexpr int perBlock = kBlock / RHS::dim;
@@ -328,6 +342,7 @@ hipError_t launch_step_lps(const StepArgs& a, int negate, hipStream_t s) {
   if (negate) return launch_kernel(step_lps_kernel<METHOD, RHS, true>, dim3((unsigned)grid), dim3(kBlock), s, a);
   return launch_kernel(step_lps_kernel<METHOD, RHS, false>, dim3((unsigned)grid), dim3(kBlock), s, a);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Headline kernel: scalar RK4 step over a flat array of n independent float64 states, uniform (t, dt).
@@ -388,6 +403,22 @@ __global__ __launch_bounds__(kBlock) void rk4_stream_vec_kernel(const double* __
   }
 }
 
+// dy = f(t, y) alone over a batch (pins the RHS library; also used for user-compiled RHS)
+template <class RHS>
+__global__ __launch_bounds__(kBlock) void rhs_batch_kernel(int64_t N, int64_t ivpStride, int64_t compStride, double t,
+                                                           const double* __restrict__ y, double* __restrict__ dy, const Params P) {
+  constexpr int D = RHS::dim;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N) return;
+  double yv[D], d[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) yv[c] = y[i * ivpStride + c * compStride];
+  RHS::eval(t, yv, d, P);
+#pragma unroll
+  for (int c = 0; c < D; ++c) dy[i * ivpStride + c * compStride] = d[c];
+}
+
+#if !NNHIP_RTC
 struct StreamTune {
   int vec = 4;           // 16-byte accesses in flight per lane and direction: 1, 2, 4, 8
   int mode = 0;          // see rk4_stream_vec_kernel
@@ -473,5 +504,7 @@ NNHIP_FOR_EACH_METHOD(X)
 hipError_t launch_rk4_stream(int rhs_kind, const double* yin, double* yout, int64_t n, double t, double dt, const Params& P,
                              int negate, const StreamTune& tune, hipStream_t s);
 bool rk4_stream_supported(int rhs_kind);
+
+#endif  // !NNHIP_RTC
 
 }  // namespace nnhip

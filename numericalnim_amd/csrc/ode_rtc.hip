@@ -1,0 +1,216 @@
+// ode_rtc.hip — user-supplied right-hand sides, compiled at run time with hiprtc.
+//
+// The reference takes an arbitrary closure f(t, y, ctx) (ODEProc[T], ode.nim:36).  A host closure cannot run on the
+// device, but its *source* can: the caller hands over the body of
+//     __device__ void rhs(double t, const double* y, double* dy, const double* p)      // y, dy: dim components
+// and this module instantiates the SAME kernel templates the built-in RHS use (ode_kernels.hpp, embedded in the library
+// as text) for it — same steppers, same driver, same -ffp-contract=off numerics — one hiprtc program per
+// (rhs, integrator), cached for the life of the process.
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "ode_kernels.hpp"
+#include "ode_rtc.hpp"
+
+namespace nnhip {
+namespace {
+
+struct Header { const char* name; const char* text; };
+const Header kHeaders[] = {
+#include "embedded_headers.inc"
+};
+
+struct Program {
+  hipModule_t module = nullptr;
+  hipFunction_t solve = nullptr, stepPos = nullptr, stepNeg = nullptr, rhs = nullptr;
+};
+struct UserRhsEntry {
+  std::string name, body;
+  int dim = 0, n_params = 0;
+  bool alive = false;
+  std::map<int, Program> programs;  // by integrator; key -1 = the rhs_batch kernel only
+};
+
+std::mutex g_mu;
+std::vector<UserRhsEntry> g_user;
+thread_local std::string g_rtc_err;
+
+std::string make_source(const UserRhsEntry& e) {
+  std::string s;
+  s += "#include \"ode_kernels.hpp\"\n";
+  s += "namespace nnhip {\nstruct UserRhs {\n  static constexpr int dim = " + std::to_string(e.dim) + ";\n";
+  s += "  NNHIP_DEV static void eval(double t, const double (&y)[dim], double (&dy)[dim], const Params& P_) {\n";
+  s += "    const double* p = P_.p; (void)p; (void)t;\n";
+  s += "    {\n" + e.body + "\n    }\n  }\n";
+  s += "  NNHIP_DEV static double comp(double t, int c, const double* ys, const Params& P_) {\n";
+  s += "    double y[dim], dy[dim];\n    for (int k = 0; k < dim; ++k) y[k] = ys[k];\n    eval(t, y, dy, P_);\n";
+  s += "    double r = dy[0];\n    for (int k = 1; k < dim; ++k) if (c == k) r = dy[k];\n    return r;\n  }\n};\n}\n";
+  return s;
+}
+
+bool compile(const UserRhsEntry& e, int integrator, Program& out) {
+  const std::string src = make_source(e);
+  hiprtcProgram prog;
+  std::vector<const char*> hsrc, hname;
+  for (const Header& h : kHeaders) { hsrc.push_back(h.text); hname.push_back(h.name); }
+  if (hiprtcCreateProgram(&prog, src.c_str(), "nnhip_user_rhs.hip", (int)hsrc.size(), hsrc.data(), hname.data()) != HIPRTC_SUCCESS) {
+    g_rtc_err = "hiprtcCreateProgram failed";
+    return false;
+  }
+  std::vector<std::string> names;
+  if (integrator >= 0) {
+    const std::string m = std::to_string(integrator);
+    names.push_back("nnhip::solve_tpi_kernel<" + m + ", nnhip::UserRhs>");
+    names.push_back("nnhip::step_tpi_kernel<" + m + ", nnhip::UserRhs, false>");
+    names.push_back("nnhip::step_tpi_kernel<" + m + ", nnhip::UserRhs, true>");
+  } else {
+    names.push_back("nnhip::rhs_batch_kernel<nnhip::UserRhs>");
+  }
+  for (auto& n : names) hiprtcAddNameExpression(prog, n.c_str());
+  // same numerical contract as the ahead-of-time kernels
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+  const hiprtcResult rc = hiprtcCompileProgram(prog, 4, opts);
+  if (rc != HIPRTC_SUCCESS) {
+    size_t n = 0;
+    hiprtcGetProgramLogSize(prog, &n);
+    std::string log(n, '\0');
+    if (n) hiprtcGetProgramLog(prog, log.data());
+    g_rtc_err = "hiprtc compilation of user RHS '" + e.name + "' failed:\n" + log;
+    hiprtcDestroyProgram(&prog);
+    return false;
+  }
+  size_t codeSize = 0;
+  hiprtcGetCodeSize(prog, &codeSize);
+  std::vector<char> code(codeSize);
+  hiprtcGetCode(prog, code.data());
+  std::vector<std::string> lowered;
+  for (auto& n : names) {
+    const char* ln = nullptr;
+    if (hiprtcGetLoweredName(prog, n.c_str(), &ln) != HIPRTC_SUCCESS || !ln) {
+      g_rtc_err = "hiprtcGetLoweredName failed for " + n;
+      hiprtcDestroyProgram(&prog);
+      return false;
+    }
+    lowered.push_back(ln);
+  }
+  hiprtcDestroyProgram(&prog);
+  if (hipModuleLoadData(&out.module, code.data()) != hipSuccess) {
+    g_rtc_err = "hipModuleLoadData failed (no HIP device?)";
+    return false;
+  }
+  hipFunction_t* slots[3] = {&out.solve, &out.stepPos, &out.stepNeg};
+  if (integrator < 0) slots[0] = &out.rhs;
+  for (size_t i = 0; i < lowered.size(); ++i)
+    if (hipModuleGetFunction(slots[i], out.module, lowered[i].c_str()) != hipSuccess) {
+      g_rtc_err = "hipModuleGetFunction failed for " + lowered[i];
+      return false;
+    }
+  return true;
+}
+
+Program* get_program(int rhs_kind, int integrator) {
+  const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (idx < 0 || idx >= (int)g_user.size() || !g_user[idx].alive) { g_rtc_err = "unknown user rhs_kind"; return nullptr; }
+  auto it = g_user[idx].programs.find(integrator);
+  if (it != g_user[idx].programs.end()) return &it->second;
+  Program p;
+  if (!compile(g_user[idx], integrator, p)) return nullptr;
+  return &(g_user[idx].programs[integrator] = p);
+}
+
+}  // namespace
+
+const char* rtc_last_error() { return g_rtc_err.c_str(); }
+
+int rtc_register(const char* name, int dim, int n_params, const char* body, bool check_compiles) {
+  UserRhsEntry e;
+  e.name = name ? name : "user";
+  e.body = body;
+  e.dim = dim;
+  e.n_params = n_params;
+  e.alive = true;
+  if (check_compiles) {  // syntax check now (device-independent), so errors surface at registration
+    const std::string src = make_source(e) + "\n";
+    hiprtcProgram prog;
+    std::vector<const char*> hsrc, hname;
+    for (const Header& h : kHeaders) { hsrc.push_back(h.text); hname.push_back(h.name); }
+    if (hiprtcCreateProgram(&prog, src.c_str(), "nnhip_user_rhs.hip", (int)hsrc.size(), hsrc.data(), hname.data()) != HIPRTC_SUCCESS) {
+      g_rtc_err = "hiprtcCreateProgram failed";
+      return -1;
+    }
+    hiprtcAddNameExpression(prog, "nnhip::rhs_batch_kernel<nnhip::UserRhs>");
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+    if (hiprtcCompileProgram(prog, 4, opts) != HIPRTC_SUCCESS) {
+      size_t n = 0;
+      hiprtcGetProgramLogSize(prog, &n);
+      std::string log(n, '\0');
+      if (n) hiprtcGetProgramLog(prog, log.data());
+      g_rtc_err = "hiprtc compilation of user RHS '" + e.name + "' failed:\n" + log;
+      hiprtcDestroyProgram(&prog);
+      return -1;
+    }
+    hiprtcDestroyProgram(&prog);
+  }
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_user.push_back(std::move(e));
+  return NNHIP_RHS_USER_BASE + (int)g_user.size() - 1;
+}
+
+int rtc_release(int rhs_kind) {
+  const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (idx < 0 || idx >= (int)g_user.size() || !g_user[idx].alive) return -1;
+  for (auto& kv : g_user[idx].programs) if (kv.second.module) (void)hipModuleUnload(kv.second.module);
+  g_user[idx].programs.clear();
+  g_user[idx].alive = false;
+  return 0;
+}
+
+bool rtc_info(int rhs_kind, int* dim, int* n_params) {
+  const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (idx < 0 || idx >= (int)g_user.size() || !g_user[idx].alive) return false;
+  if (dim) *dim = g_user[idx].dim;
+  if (n_params) *n_params = g_user[idx].n_params;
+  return true;
+}
+
+static hipError_t launch(hipFunction_t f, int64_t n, void* arg, hipStream_t s) {
+  const int64_t grid = (n + kBlock - 1) / kBlock;
+  if (grid <= 0) return hipSuccess;
+  void* params[] = {arg};
+  return hipModuleLaunchKernel(f, (unsigned)grid, 1, 1, kBlock, 1, 1, 0, s, params, nullptr);
+}
+
+hipError_t rtc_launch_solve(int rhs_kind, int integrator, const SolveArgs& a, hipStream_t s) {
+  Program* p = get_program(rhs_kind, integrator);
+  if (!p) return hipErrorInvalidValue;
+  SolveArgs copy = a;
+  return launch(p->solve, a.N, &copy, s);
+}
+hipError_t rtc_launch_step(int rhs_kind, int integrator, const StepArgs& a, int negate, hipStream_t s) {
+  Program* p = get_program(rhs_kind, integrator);
+  if (!p) return hipErrorInvalidValue;
+  StepArgs copy = a;
+  return launch(negate ? p->stepNeg : p->stepPos, a.N, &copy, s);
+}
+hipError_t rtc_launch_rhs(int rhs_kind, int64_t N, int64_t is, int64_t cs, double t, const double* y, double* dy, const Params& P,
+                          hipStream_t s) {
+  Program* p = get_program(rhs_kind, -1);
+  if (!p) return hipErrorInvalidValue;
+  const int64_t grid = (N + kBlock - 1) / kBlock;
+  if (grid <= 0) return hipSuccess;
+  Params Pc = P;
+  void* params[] = {&N, &is, &cs, &t, &y, &dy, &Pc};
+  return hipModuleLaunchKernel(p->rhs, (unsigned)grid, 1, 1, kBlock, 1, 1, 0, s, params, nullptr);
+}
+
+}  // namespace nnhip

@@ -1,0 +1,14 @@
+// ode_rtc.hpp — internal interface of the hiprtc user-RHS module (ode_rtc.hip).
+#pragma once
+#include "ode_kernels.hpp"
+
+namespace nnhip {
+const char* rtc_last_error();
+int rtc_register(const char* name, int dim, int n_params, const char* body, bool check_compiles);  // -> rhs_kind or -1
+int rtc_release(int rhs_kind);
+bool rtc_info(int rhs_kind, int* dim, int* n_params);
+hipError_t rtc_launch_solve(int rhs_kind, int integrator, const SolveArgs& a, hipStream_t s);
+hipError_t rtc_launch_step(int rhs_kind, int integrator, const StepArgs& a, int negate, hipStream_t s);
+hipError_t rtc_launch_rhs(int rhs_kind, int64_t N, int64_t is, int64_t cs, double t, const double* y, double* dy, const Params& P,
+                          hipStream_t s);
+}  // namespace nnhip

@@ -111,6 +111,17 @@ class Rhs:
         return out
 
     @staticmethod
+    def custom(dim, body, keys=(), defaults=None, name="user"):
+        """A user right-hand side from HIP C++ source (compiled at run time with hiprtc; include/nnhip_ode.h,
+        nnhip_ode_rhs_compile).  `body` sees t, y[dim], dy[dim] and p[len(keys)] — e.g. for a damped oscillator
+        Rhs.custom(2, "dy[0] = y[1]; dy[1] = -p[0]*y[0] - p[1]*y[1];", keys=("k", "c"))."""
+        kind = C.c_int(0)
+        _check(_lib.lib().nnhip_ode_rhs_compile(str(name).encode(), int(dim), len(keys), body.encode(), C.byref(kind)))
+        r = Rhs(kind.value, keys, defaults)
+        r.dim = int(dim)
+        return r
+
+    @staticmethod
     def neg_y():  # dy = -y (ode.nim:16-17)
         return Rhs(Rhs.NEG_Y)
 

@@ -537,7 +537,8 @@ static int solveODE(const ODEProc<T>& f, const T& y0, const double* tspan, int n
 // RHS library restated on the CPU (definitions: include/nnhip_ode.h, enum nnhip_rhs_kind).
 // The reference takes an arbitrary user closure; these are the closures the tests/bench supply.
 // ---------------------------------------------------------------------------------------------
-enum RhsKind { RHS_NEG_Y = 0, RHS_LINEAR = 1, RHS_LORENZ = 2, RHS_RING = 3, RHS_AFFINE_T = 4, RHS_VANDERPOL = 5 };
+enum RhsKind { RHS_NEG_Y = 0, RHS_LINEAR = 1, RHS_LORENZ = 2, RHS_RING = 3, RHS_AFFINE_T = 4, RHS_VANDERPOL = 5,
+               RHS_DUFFING = 6 /* oracle-only: checks run-time compiled user RHS */ };
 
 static double rhsScalar(double t, const double& y, const void* env) {
   const double* p = (const double*)env;  // p[0] = kind, p[1..] = params
@@ -572,6 +573,12 @@ static Vec rhsVector(double t, const Vec& y, const void* env) {
       const double x = y.components[0], v = y.components[1];
       r.components[0] = v;
       r.components[1] = p[1] * ((1.0 - x * x) * v) - x;
+      break;
+    }
+    case RHS_DUFFING: {  // delta, alpha, beta, gamma = p[1..4]: x' = v; v' = -delta v - alpha x - beta x^3 + gamma t
+      const double x = y.components[0], v = y.components[1];
+      r.components[0] = v;
+      r.components[1] = ((-p[1] * v - p[2] * x) - p[3] * (x * x * x)) + p[4] * t;
       break;
     }
     default: for (size_t i = 0; i < d; ++i) r.components[i] = NAN;
