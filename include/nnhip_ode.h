@@ -182,6 +182,16 @@ int nnhip_ode_rhs_release(int rhs_kind);
 /* hermiteSpline (utils.nim:273-279), batched on device: out[i] = H(x; x1, x2, y1[i], y2[i], dy1[i], dy2[i]) */
 int nnhip_hermite_spline_f64_dev(double x, double x1, double x2, const double* y1, const double* y2, const double* dy1,
                                  const double* dy2, double* out, int64_t n, void* stream);
+/* Output consumer: newHermiteSpline(X, Y, dY) + eval / derivEval (src/numericalnim/interpolate.nim:114-115,
+ * 186-240, 299-390) over M independent series — e.g. M = dim*N for a trajectory tensor returned by the solver, with
+ * dY = f(t_j, y_j) from nnhip_ode_rhs_batch_f64_dev (the README's (t, y, dy) recipe).
+ *   X [n_knots] host, strictly ascending (what sortAndTrimDataset yields; else NNHIP_EVALUE)
+ *   Y, dY [n_knots][M] device;  xq [n_q] host;  out [n_q][M] device
+ *   deriv 0 = eval, 1 = derivEval;  extrap: 0 Constant(extrap_value) 1 Edge 2 Linear 3 Native 4 Error (ExtrapolateKind :89-90;
+ *   Error out of range -> NNHIP_EVALUE, as the reference raises ValueError) */
+int nnhip_hermite_spline_eval_batch_f64_dev(const double* X, int n_knots, const double* Y, const double* dY, int64_t M,
+                                            const double* xq, int n_q, int deriv, int extrap, double extrap_value, double* out,
+                                            void* stream);
 /* The adaptive controller's step-size factor min(4, max(0.125, 0.9 * pow(1/error, 1/order))) (ode.nim:71, 537) over an
  * array of error norms; order in {2, 3, 5, 6} (rk21, bs32, dopri54/tsit54, vern65). */
 int nnhip_ode_controller_factor_f64_dev(int order, const double* error, double* out, int64_t n, void* stream);

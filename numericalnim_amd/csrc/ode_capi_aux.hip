@@ -2,6 +2,7 @@
 // and the one-process multi-GPU solve (contiguous shards of the IVP index range, no exchange).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <thread>
@@ -29,6 +30,49 @@ __global__ __launch_bounds__(kBlock) void hermite_kernel(double x, double x1, do
   out[i] = hermite_apply(w, y1[i], y2[i], dy1[i], dy2[i]);
 }
 
+// newHermiteSpline(X, Y, dY).eval / .derivEval over M independent series (interpolate.nim:186-217, 299-390).
+// Everything that depends only on the query point (interval, basis weights, extrapolation branch) is computed on
+// the host in the reference's expression order and shipped as a descriptor; the kernel does the per-series part.
+struct HermSet {
+  int row;           // knots (row, row+1)
+  double w[4];       // h00, h10*xDiff, h01, h11*xDiff
+  double xDiff;
+};
+struct HermQuery {
+  int mode;          // 0 eval, 1 derivEval, 2 constant, 3 copy row A, 4 linear between rows A/B, 5 linear between derivEval sets A/B
+  HermSet a, b;
+  double k, value;
+};
+constexpr int kHermChunk = 24;
+struct HermChunk {
+  HermQuery q[kHermChunk];
+};
+
+NNHIP_DEV double herm_apply(const HermSet& s, const double* __restrict__ Y, const double* __restrict__ dY, int64_t M, int64_t m, bool deriv) {
+  const double p1 = Y[(int64_t)s.row * M + m], p2 = Y[(int64_t)(s.row + 1) * M + m];
+  const double m1 = dY[(int64_t)s.row * M + m], m2 = dY[(int64_t)(s.row + 1) * M + m];
+  const double v = s.w[0] * p1 + s.w[1] * m1 + s.w[2] * p2 + s.w[3] * m2;  // h00*p1 + h10*xDiff*m1 + h01*p2 + h11*xDiff*m2
+  return deriv ? v / s.xDiff : v;
+}
+
+__global__ __launch_bounds__(kBlock) void hermite_interp_kernel(const HermChunk c, int nq, const double* __restrict__ Y,
+                                                                const double* __restrict__ dY, int64_t M, double* __restrict__ out) {
+  const int64_t m = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int qi = blockIdx.y;
+  if (m >= M || qi >= nq) return;
+  const HermQuery& q = c.q[qi];
+  double r;
+  switch (q.mode) {
+    case 0: r = herm_apply(q.a, Y, dY, M, m, false); break;
+    case 1: r = herm_apply(q.a, Y, dY, M, m, true); break;
+    case 2: r = q.value; break;
+    case 3: r = Y[(int64_t)q.a.row * M + m]; break;
+    case 4: { const double y0 = Y[(int64_t)q.a.row * M + m], y1 = Y[(int64_t)q.b.row * M + m]; r = y0 + q.k * (y1 - y0); break; }
+    default: { const double y0 = herm_apply(q.a, Y, dY, M, m, true), y1 = herm_apply(q.b, Y, dY, M, m, true); r = y0 + q.k * (y1 - y0); break; }
+  }
+  out[(int64_t)qi * M + m] = r;
+}
+
 // the controller's step-size factor (ode.nim:71,537) over an array of error norms
 template <int ORDER>
 __global__ __launch_bounds__(kBlock) void controller_factor_kernel(const double* __restrict__ error, double* __restrict__ out, int64_t n) {
@@ -47,6 +91,66 @@ int nnhip_hermite_spline_f64_dev(double x, double x1, double x2, const double* y
   const int64_t grid = (n + nnhip::kBlock - 1) / nnhip::kBlock;
   return nnhip::launch_kernel(nnhip::hermite_kernel, dim3((unsigned)grid), dim3(nnhip::kBlock), (hipStream_t)stream, x, x1, x2, y1,
                               y2, dy1, dy2, out, n) == hipSuccess ? NNHIP_OK : NNHIP_EHIP;
+}
+
+static nnhip::HermSet herm_set(const double* X, int n, double x, bool deriv) {
+  // findInterval (interpolate.nim:114-115): clamp(lowerbound(X, x) - 1, 0, high - 1)
+  int k = (int)(std::lower_bound(X, X + n, x) - X) - 1;
+  if (k < 0) k = 0;
+  if (k > n - 2) k = n - 2;
+  nnhip::HermSet s;
+  s.row = k;
+  const double xDiff = X[k + 1] - X[k];
+  const double t = (x - X[k]) / xDiff;
+  const double t2 = t * t;
+  s.xDiff = xDiff;
+  if (!deriv) {  // interpolate.nim:190-195
+    const double t3 = t2 * t;
+    const double h00 = 2 * t3 - 3 * t2 + 1, h10 = t3 - 2 * t2 + t, h01 = -2 * t3 + 3 * t2, h11 = t3 - t2;
+    s.w[0] = h00; s.w[1] = h10 * xDiff; s.w[2] = h01; s.w[3] = h11 * xDiff;
+  } else {  // :207-211
+    const double h00 = 6 * t2 - 6 * t, h10 = 3 * t2 - 4 * t + 1, h01 = -6 * t2 + 6 * t, h11 = 3 * t2 - 2 * t;
+    s.w[0] = h00; s.w[1] = h10 * xDiff; s.w[2] = h01; s.w[3] = h11 * xDiff;
+  }
+  return s;
+}
+
+int nnhip_hermite_spline_eval_batch_f64_dev(const double* X, int n_knots, const double* Y, const double* dY, int64_t M,
+                                            const double* xq, int n_q, int deriv, int extrap, double extrap_value, double* out,
+                                            void* stream) {
+  if (n_knots < 2 || M < 0 || n_q < 0 || !X || (n_q > 0 && !xq) || extrap < 0 || extrap > 4) return NNHIP_EVALUE;
+  for (int i = 1; i < n_knots; ++i) if (!(X[i - 1] < X[i])) return NNHIP_EVALUE;  // sortAndTrimDataset's postcondition (:231)
+  if (M == 0 || n_q == 0) return NNHIP_OK;
+  if (!Y || !dY || !out) return NNHIP_EVALUE;
+  if (extrap == 4) for (int q = 0; q < n_q; ++q) if (xq[q] < X[0] || xq[q] > X[n_knots - 1]) return NNHIP_EVALUE;  // ValueError :340-341
+  for (int q0 = 0; q0 < n_q; q0 += nnhip::kHermChunk) {
+    nnhip::HermChunk c;
+    std::memset(&c, 0, sizeof(c));
+    const int nq = std::min(nnhip::kHermChunk, n_q - q0);
+    for (int j = 0; j < nq; ++j) {
+      const double x = xq[q0 + j];
+      nnhip::HermQuery& hq = c.q[j];
+      const bool xLeft = x < X[0], xRight = x > X[n_knots - 1];
+      hq.mode = deriv ? 1 : 0;
+      hq.a = herm_set(X, n_knots, x, deriv != 0);
+      if (xLeft || xRight) {  // interpolate.nim:317-341 / 364-388
+        if (extrap == 0) { hq.mode = 2; hq.value = extrap_value; }
+        else if (extrap == 1) {
+          if (!deriv) { hq.mode = 3; hq.a.row = xLeft ? 0 : n_knots - 1; }
+          else hq.a = herm_set(X, n_knots, xLeft ? X[0] : X[n_knots - 1], true);
+        } else if (extrap == 2) {
+          const int r0 = xLeft ? 0 : n_knots - 2, r1 = r0 + 1;
+          hq.k = (x - X[r0]) / (X[r1] - X[r0]);
+          if (!deriv) { hq.mode = 4; hq.a.row = r0; hq.b.row = r1; }
+          else { hq.mode = 5; hq.a = herm_set(X, n_knots, X[r0], true); hq.b = herm_set(X, n_knots, X[r1], true); }
+        }
+      }
+    }
+    const dim3 grid((unsigned)((M + nnhip::kBlock - 1) / nnhip::kBlock), (unsigned)nq), block(nnhip::kBlock);
+    if (nnhip::launch_kernel(nnhip::hermite_interp_kernel, grid, block, (hipStream_t)stream, c, nq, Y, dY, M, out + (int64_t)q0 * M) != hipSuccess)
+      return NNHIP_EHIP;
+  }
+  return NNHIP_OK;
 }
 
 int nnhip_ode_controller_factor_f64_dev(int order, const double* error, double* out, int64_t n, void* stream) {

@@ -1,0 +1,59 @@
+"""Output consumer of the ODE path: the batched form of the reference's
+`newHermiteSpline(t, y, dy)` + `eval` / `derivEval` (src/numericalnim/interpolate.nim:186-240, 299-390),
+the consumer the reference's README advertises for `(t, y, dy)` from `solveODE` (README.md:147)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .ode import _check, _params_array, _shape_info, LAYOUT_SOA
+
+ExtrapolateKind = {"Constant": 0, "Edge": 1, "Linear": 2, "Native": 3, "Error": 4}  # interpolate.nim:89-90
+
+
+def rhsBatch(f, t, y, ctx=None, layout=LAYOUT_SOA):
+    """dy = f(t, y) over a device batch (one RHS evaluation per IVP)."""
+    import torch
+    p, pp = _params_array(f, ctx)
+    N, dim, _ = _shape_info(y, layout)
+    yc = y.contiguous()
+    out = torch.empty_like(yc)
+    with torch.cuda.device(yc.device):
+        rc = _lib.lib().nnhip_ode_rhs_batch_f64_dev(f.kind, pp, int(p.size), N, dim, layout, float(t), yc.data_ptr(), out.data_ptr(),
+                                                    torch.cuda.current_stream().cuda_stream)
+    if rc:
+        raise ValueError("rhs batch evaluation failed (rc=%d)" % rc)
+    return out
+
+
+class HermiteSpline:
+    """newHermiteSpline(X, Y, dY) for a whole batch: Y, dY are [n_knots, ...] CUDA tensors (every trailing element its
+    own series).  X must be strictly ascending (the solver's output grid is, unless tStart is duplicated)."""
+
+    def __init__(self, X, Y, dY):
+        self.X = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
+        if len(self.X) != Y.shape[0] or len(self.X) != dY.shape[0]:
+            raise ValueError("X and Y and dY must have the same length.")  # interpolate.nim:229-230
+        self.Y, self.dY = Y.contiguous(), dY.contiguous()
+        self.M = int(self.Y[0].numel())
+
+    def _run(self, x, deriv, extrap, extrapValue):
+        import torch
+        xq = np.ascontiguousarray(np.atleast_1d(np.asarray(x, dtype=np.float64)))
+        out = torch.empty((len(xq),) + tuple(self.Y.shape[1:]), dtype=torch.float64, device=self.Y.device)
+        with torch.cuda.device(self.Y.device):
+            _check(_lib.lib().nnhip_hermite_spline_eval_batch_f64_dev(
+                self.X.ctypes.data_as(C.POINTER(C.c_double)), len(self.X), self.Y.data_ptr(), self.dY.data_ptr(), self.M,
+                xq.ctypes.data_as(C.POINTER(C.c_double)), len(xq), int(deriv), ExtrapolateKind[extrap], float(extrapValue or 0.0),
+                out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        return out if np.ndim(x) else out[0]
+
+    def eval(self, x, extrap="Native", extrapValue=None):       # interpolate.nim:299-345, 392-404
+        return self._run(x, 0, extrap, extrapValue)
+
+    def derivEval(self, x, extrap="Native", extrapValue=None):  # interpolate.nim:346-390, 406-418
+        return self._run(x, 1, extrap, extrapValue)
+
+
+def newHermiteSpline(X, Y, dY):
+    return HermiteSpline(X, Y, dY)

@@ -740,6 +740,59 @@ int oracle_linspace(double x1, double x2, int N, double* out) {
   return k;
 }
 
+// newHermiteSpline(X, Y, dY) + eval / derivEval (src/numericalnim/interpolate.nim:114-115 findInterval, :186-217 handlers,
+// :299-345 / :346-390 extrapolation) for one scalar series.  X must already be sorted and duplicate-free (what
+// sortAndTrimDataset, :231, produces).  extrap: 0 Constant 1 Edge 2 Linear 3 Native 4 Error.  Returns -1 for Error out of range.
+int oracle_hermite_interp(const double* X, int n, const double* Y, const double* dY, const double* xq, int nq, int deriv, int extrap,
+                          double extrapValue, double* out) {
+  auto handler = [&](double x, bool d) -> double {  // eval_hermitespline :186-201 / derivEval_hermitespline :203-217
+    // findInterval (:114-115): clamp(lowerbound(X, x) - 1, 0, high - 1)
+    int k = (int)(std::lower_bound(X, X + n, x) - X) - 1;
+    if (k < 0) k = 0;
+    if (k > n - 2) k = n - 2;
+    const double xDiff = X[k + 1] - X[k];
+    const double t = (x - X[k]) / xDiff;
+    const double t2 = t * t;
+    const double p1 = Y[k], p2 = Y[k + 1], m1 = dY[k], m2 = dY[k + 1];
+    if (!d) {
+      const double t3 = t2 * t;
+      const double h00 = 2 * t3 - 3 * t2 + 1;
+      const double h10 = t3 - 2 * t2 + t;
+      const double h01 = -2 * t3 + 3 * t2;
+      const double h11 = t3 - t2;
+      return h00 * p1 + h10 * xDiff * m1 + h01 * p2 + h11 * xDiff * m2;
+    }
+    const double h00 = 6 * t2 - 6 * t;
+    const double h10 = 3 * t2 - 4 * t + 1;
+    const double h01 = -6 * t2 + 6 * t;
+    const double h11 = 3 * t2 - 2 * t;
+    return (h00 * p1 + h10 * xDiff * m1 + h01 * p2 + h11 * xDiff * m2) / xDiff;
+  };
+  for (int q = 0; q < nq; ++q) {
+    const double x = xq[q];
+    const bool xLeft = x < X[0], xRight = x > X[n - 1];
+    if (xLeft || xRight) {  // :317-341 / :364-388
+      if (extrap == 0) { out[q] = extrapValue; continue; }
+      if (extrap == 1) {
+        if (!deriv) out[q] = xLeft ? Y[0] : Y[n - 1];
+        else out[q] = xLeft ? handler(X[0], true) : handler(X[n - 1], true);
+        continue;
+      }
+      if (extrap == 2) {
+        const double x0 = xLeft ? X[0] : X[n - 2], x1 = xLeft ? X[1] : X[n - 1];
+        const double y0 = !deriv ? (xLeft ? Y[0] : Y[n - 2]) : handler(x0, true);
+        const double y1 = !deriv ? (xLeft ? Y[1] : Y[n - 1]) : handler(x1, true);
+        const double k = (x - x0) / (x1 - x0);
+        out[q] = y0 + k * (y1 - y0);
+        continue;
+      }
+      if (extrap == 4) return -1;
+    }
+    out[q] = handler(x, deriv != 0);
+  }
+  return 0;
+}
+
 // Vector operator probes (tests/test_vector.nim semantics). op: 0 '+', 1 '-', 2 scalar*V, 3 abs, 4 *. 5 /. 6 d +. V
 int oracle_vector_op(int op, const double* a, int na, const double* b, int nb, double d, double* out) {
   using namespace oracle;

@@ -59,6 +59,7 @@ def lib():
         _lib.oracle_hermite_spline.argtypes = [C.c_double] * 7
         _lib.oracle_hermite_spline.restype = C.c_double
         _lib.oracle_linspace.argtypes = [C.c_double, C.c_double, C.c_int, dp]
+        _lib.oracle_hermite_interp.argtypes = [dp, C.c_int, dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_double, dp]
         _lib.oracle_vector_op.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int, C.c_double, dp]
     return _lib
 
@@ -166,6 +167,19 @@ def rhs(rhs_kind, params, t, y):
 
 def hermite_spline(x, x1, x2, y1, y2, dy1, dy2):
     return lib().oracle_hermite_spline(x, x1, x2, y1, y2, dy1, dy2)
+
+
+EXTRAP = {"Constant": 0, "Edge": 1, "Linear": 2, "Native": 3, "Error": 4}  # interpolate.nim:89-90
+
+
+def hermite_interp(X, Y, dY, xq, deriv=False, extrap="Native", extrap_value=0.0):
+    """newHermiteSpline(X, Y, dY).eval / .derivEval (interpolate.nim:186-240, 299-390) for one scalar series."""
+    X, Y, dY, xq = (np.ascontiguousarray(np.asarray(a, dtype=np.float64)) for a in (X, Y, dY, xq))
+    out = np.empty(len(xq), dtype=np.float64)
+    rc = lib().oracle_hermite_interp(_dp(X), len(X), _dp(Y), _dp(dY), _dp(xq), len(xq), int(deriv), EXTRAP[extrap], extrap_value, _dp(out))
+    if rc:
+        raise ValueError("x isn't in the interval")
+    return out
 
 
 def vector_op(op, a, b=None, d=0.0):

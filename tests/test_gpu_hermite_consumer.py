@@ -1,0 +1,36 @@
+"""§8 f4 consumer: batched newHermiteSpline(t, y, dy).eval / .derivEval (interpolate.nim:186-240, 299-390) on the
+solver's trajectory tensor vs the oracle's restatement, bit-exact, every ExtrapolateKind."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hermite_spline_on_trajectories(nn, oracle, dev):
+    import torch
+    O = oracle
+    n = 200
+    rng = np.random.default_rng(9)
+    y0 = np.stack([1.0 + rng.uniform(0, 1, n), np.ones(n), np.ones(n)])
+    ts = O.linspace(0.0, 1.0, 21)
+    f = nn.Rhs.lorenz()
+    t, y = nn.solveODE(f, torch.from_numpy(y0).to(dev), ts, nn.newODEoptions(dt=1e-3), integrator="rk4")
+    dy = torch.stack([nn.rhsBatch(f, t[j], y[j]) for j in range(len(t))])          # the README's (t, y, dy) recipe
+    spl = nn.newHermiteSpline(t, y, dy)
+    xq = np.concatenate([rng.uniform(-0.2, 1.2, 40), [0.0, 1.0, 0.5, t[3], -0.5, 1.5]])
+    Yh, dYh = y.cpu().numpy().reshape(len(t), -1), dy.cpu().numpy().reshape(len(t), -1)
+    for deriv in (False, True):
+        for extrap, val in (("Native", None), ("Edge", None), ("Linear", None), ("Constant", 7.25)):
+            got = (spl.derivEval if deriv else spl.eval)(xq, extrap=extrap, extrapValue=val).cpu().numpy().reshape(len(xq), -1)
+            for m in range(0, Yh.shape[1], 37):
+                ref = O.hermite_interp(t, Yh[:, m], dYh[:, m], xq, deriv=deriv, extrap=extrap, extrap_value=val or 0.0)
+                assert np.array_equal(got[:, m], ref), (deriv, extrap, m)
+    # knots are reproduced exactly; Error raises like the reference's ValueError
+    assert torch.equal(spl.eval(t), y)
+    with pytest.raises(ValueError):
+        spl.eval([1.5], extrap="Error")
+    with pytest.raises(ValueError):
+        nn.newHermiteSpline(t[::-1].copy(), y, dy).eval([0.5])
+    # interpolation error of the cubic Hermite spline against a fine-grid solve is small
+    tf, yf = nn.solveODE(f, torch.from_numpy(y0).to(dev), [0.0, 0.525], nn.newODEoptions(dt=1e-3), integrator="rk4")
+    assert float((spl.eval(0.525) - yf[-1]).abs().max()) < 5e-3
