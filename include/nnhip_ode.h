@@ -192,6 +192,10 @@ int nnhip_hermite_spline_f64_dev(double x, double x1, double x2, const double* y
 int nnhip_hermite_spline_eval_batch_f64_dev(const double* X, int n_knots, const double* Y, const double* dY, int64_t M,
                                             const double* xq, int n_q, int deriv, int extrap, double extrap_value, double* out,
                                             void* stream);
+/* Output consumer: cumtrapz(Y, X) for discrete points (src/numericalnim/integrate.nim:120-135) over M series (a trajectory
+ * tensor's columns).  X [n] host, strictly ascending; Y, out [n][M] device; out[0] = Y[0]-Y[0].  trapz(Y, X) (:104-117) is the
+ * last row for finite data. */
+int nnhip_cumtrapz_batch_f64_dev(const double* X, int n, const double* Y, int64_t M, double* out, void* stream);
 /* The adaptive controller's step-size factor min(4, max(0.125, 0.9 * pow(1/error, 1/order))) (ode.nim:71, 537) over an
  * array of error norms; order in {2, 3, 5, 6} (rk21, bs32, dopri54/tsit54, vern65). */
 int nnhip_ode_controller_factor_f64_dev(int order, const double* error, double* out, int64_t n, void* stream);

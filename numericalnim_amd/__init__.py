@@ -10,5 +10,5 @@ from .ode import (  # noqa: F401
     ODEoptions, newODEoptions, DEFAULT_ODEoptions, NumContext, newNumContext, Rhs, solveODE, integratorStep, fixedStream,
     fixedODE, adaptiveODE, allODE, implementedODE, LAYOUT_SOA, LAYOUT_AOS, NnhipError,
 )
-from .interpolate import newHermiteSpline, HermiteSpline, rhsBatch  # noqa: F401
+from .interpolate import newHermiteSpline, HermiteSpline, rhsBatch, cumtrapz, trapz  # noqa: F401
 from . import _lib  # noqa: F401

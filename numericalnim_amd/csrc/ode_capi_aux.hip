@@ -73,6 +73,33 @@ __global__ __launch_bounds__(kBlock) void hermite_interp_kernel(const HermChunk 
   out[(int64_t)qi * M + m] = r;
 }
 
+// cumtrapz(Y, X) over M series (integrate.nim:120-135): thread per series marches down the time axis;
+// the interval weights 0.5*(x_{i+1}-x_i) are computed on the host (same IEEE ops) and arrive as arguments.
+constexpr int kTrapzChunk = 384;
+struct TrapzWeights {
+  double w[kTrapzChunk];
+};
+__global__ __launch_bounds__(kBlock) void cumtrapz_kernel(const TrapzWeights W, int nw, int first, const double* __restrict__ Y,
+                                                          double* __restrict__ out, int64_t M) {
+  const int64_t m = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (m >= M) return;
+  // rows [first, first + nw] of Y / out; out[first] is already final unless first == 0
+  double yPrev = Y[(int64_t)first * M + m];
+  double integral;
+  if (first == 0) {
+    integral = yPrev - yPrev;  // "the right kind of zero" (:131-132): NaN/Inf states stay NaN
+    out[m] = integral;
+  } else {
+    integral = out[(int64_t)first * M + m];
+  }
+  for (int i = 0; i < nw; ++i) {
+    const double yNext = Y[(int64_t)(first + i + 1) * M + m];
+    integral += W.w[i] * (yNext + yPrev);  // 0.5 * (x[i+1] - x[i]) * (y[i+1] + y[i])  (:134)
+    out[(int64_t)(first + i + 1) * M + m] = integral;
+    yPrev = yNext;
+  }
+}
+
 // the controller's step-size factor (ode.nim:71,537) over an array of error norms
 template <int ORDER>
 __global__ __launch_bounds__(kBlock) void controller_factor_kernel(const double* __restrict__ error, double* __restrict__ out, int64_t n) {
@@ -150,6 +177,23 @@ int nnhip_hermite_spline_eval_batch_f64_dev(const double* X, int n_knots, const 
     if (nnhip::launch_kernel(nnhip::hermite_interp_kernel, grid, block, (hipStream_t)stream, c, nq, Y, dY, M, out + (int64_t)q0 * M) != hipSuccess)
       return NNHIP_EHIP;
   }
+  return NNHIP_OK;
+}
+
+int nnhip_cumtrapz_batch_f64_dev(const double* X, int n, const double* Y, int64_t M, double* out, void* stream) {
+  if (n < 1 || M < 0 || !X) return NNHIP_EVALUE;
+  for (int i = 1; i < n; ++i) if (!(X[i - 1] < X[i])) return NNHIP_EVALUE;  // sortAndTrimDataset's postcondition (:130)
+  if (M == 0) return NNHIP_OK;
+  if (!Y || !out) return NNHIP_EVALUE;
+  const dim3 grid((unsigned)((M + nnhip::kBlock - 1) / nnhip::kBlock)), block(nnhip::kBlock);
+  int first = 0;
+  do {
+    nnhip::TrapzWeights W;
+    const int nw = std::min(nnhip::kTrapzChunk, n - 1 - first);
+    for (int i = 0; i < nw; ++i) W.w[i] = 0.5 * (X[first + i + 1] - X[first + i]);
+    if (nnhip::launch_kernel(nnhip::cumtrapz_kernel, grid, block, (hipStream_t)stream, W, nw, first, Y, out, M) != hipSuccess) return NNHIP_EHIP;
+    first += nw;
+  } while (first < n - 1);
   return NNHIP_OK;
 }
 

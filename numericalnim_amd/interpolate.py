@@ -57,3 +57,23 @@ class HermiteSpline:
 
 def newHermiteSpline(X, Y, dY):
     return HermiteSpline(X, Y, dY)
+
+
+def cumtrapz(Y, X):
+    """cumtrapz(Y, X) for discrete points (integrate.nim:120-135), batched: Y is an [n, ...] CUDA tensor, every trailing
+    element its own series; X strictly ascending.  Returns the cumulative integrals, same shape as Y."""
+    import torch
+    Xa = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
+    if len(Xa) != Y.shape[0]:
+        raise ValueError("X and Y must have the same length")  # utils.nim:423-424
+    Yc = Y.contiguous()
+    out = torch.empty_like(Yc)
+    with torch.cuda.device(Yc.device):
+        _check(_lib.lib().nnhip_cumtrapz_batch_f64_dev(Xa.ctypes.data_as(C.POINTER(C.c_double)), len(Xa), Yc.data_ptr(), int(Yc[0].numel()),
+                                                       out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    return out
+
+
+def trapz(Y, X):
+    """trapz(Y, X) (integrate.nim:104-117): the last cumulative value."""
+    return cumtrapz(Y, X)[-1]

@@ -793,6 +793,18 @@ int oracle_hermite_interp(const double* X, int n, const double* Y, const double*
   return 0;
 }
 
+// cumtrapz(Y, X) for discrete points (src/numericalnim/integrate.nim:120-135) on one scalar series; X sorted and
+// duplicate-free (sortAndTrimDataset's postcondition).  trapz(Y, X) (:104-117) equals the last entry for finite data.
+int oracle_cumtrapz(const double* X, int n, const double* Y, double* out) {
+  out[0] = Y[0] - Y[0];            // "get the right kind of zero" (:131)
+  double integral = Y[0] - Y[0];   // :132
+  for (int i = 0; i <= n - 2; ++i) {
+    integral += 0.5 * (X[i + 1] - X[i]) * (Y[i + 1] + Y[i]);  // :134
+    out[i + 1] = integral;
+  }
+  return 0;
+}
+
 // Vector operator probes (tests/test_vector.nim semantics). op: 0 '+', 1 '-', 2 scalar*V, 3 abs, 4 *. 5 /. 6 d +. V
 int oracle_vector_op(int op, const double* a, int na, const double* b, int nb, double d, double* out) {
   using namespace oracle;

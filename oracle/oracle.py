@@ -60,6 +60,7 @@ def lib():
         _lib.oracle_hermite_spline.restype = C.c_double
         _lib.oracle_linspace.argtypes = [C.c_double, C.c_double, C.c_int, dp]
         _lib.oracle_hermite_interp.argtypes = [dp, C.c_int, dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_double, dp]
+        _lib.oracle_cumtrapz.argtypes = [dp, C.c_int, dp, dp]
         _lib.oracle_vector_op.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int, C.c_double, dp]
     return _lib
 
@@ -179,6 +180,14 @@ def hermite_interp(X, Y, dY, xq, deriv=False, extrap="Native", extrap_value=0.0)
     rc = lib().oracle_hermite_interp(_dp(X), len(X), _dp(Y), _dp(dY), _dp(xq), len(xq), int(deriv), EXTRAP[extrap], extrap_value, _dp(out))
     if rc:
         raise ValueError("x isn't in the interval")
+    return out
+
+
+def cumtrapz(Y, X):
+    """cumtrapz(Y, X) (integrate.nim:120-135) for one scalar series with sorted, unique X."""
+    X, Y = (np.ascontiguousarray(np.asarray(a, dtype=np.float64)) for a in (X, Y))
+    out = np.empty(len(X), dtype=np.float64)
+    lib().oracle_cumtrapz(_dp(X), len(X), _dp(Y), _dp(out))
     return out
 
 

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Extra single-GPU measurements: step-streaming adaptive kernels at N = 1e7 (steady state), dense-output fused solves
+(HBM-write bound), Hermite-spline consumer bandwidth."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import numericalnim_amd as nn
+from numericalnim_amd import distributed as nd
+dev = torch.device("cuda:0")
+
+
+def timed(fn, reps=5, warm=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); r = fn(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e-3)
+    return sorted(ts)[len(ts) // 2], r
+
+
+out = {}
+tight = dict(absTol=1e-10, relTol=1e-10, dtMin=1e-6, dtMax=1e-1)
+for n in (1_000_000, 10_000_000):
+    y0 = torch.from_numpy(np.stack([1.0 + (np.arange(n) % 1024) * 2.0 ** -20, np.ones(n), np.ones(n)])).to(dev)
+    fs = nn.rhsBatch(nn.Rhs.lorenz(), 0.0, y0)
+    tdev = torch.zeros(n, dtype=torch.float64, device=dev)
+    dtdev = torch.full((n,), 1e-3, dtype=torch.float64, device=dev)
+    opt = nn.newODEoptions(**tight)
+    for integ in ("rk4", "dopri54", "tsit54", "vern65"):
+        s, _ = timed(lambda: nn.integratorStep(nn.Rhs.lorenz(), tdev, y0, fs, dtdev, opt, integrator=integ))
+        b = 8 * (4 * 3 + 5) * n if integ != "rk4" else 8 * (2 * 3 + 2) * n
+        out[f"step_stream_lorenz_{integ}_N{n:.0e}"] = dict(us=s * 1e6, GBps=b / s / 1e9)
+# dense output: C2-like, RK4 fused, 1e7 IVPs, 33 requested times -> 33 x 80 MB written
+n = 10_000_000
+y2 = nd.c2_y0_torch(0, n, dev)
+o2 = nn.newODEoptions(dt=2.0 ** -10)
+for nt in (2, 9, 33):
+    ts = np.linspace(0.0, 0.25, nt)
+    s, _ = timed(lambda: nn.solveODE(nn.Rhs.neg_y(), y2, ts, o2, integrator="rk4"), reps=3)
+    out[f"fused_rk4_dense_nt{nt}"] = dict(ms=s * 1e3, out_GB=8.0 * n * nt / 1e9, write_GBps=8.0 * n * nt / s / 1e9, steps=256)
+# hermite consumer bandwidth: 40 B per output element
+t, y = nn.solveODE(nn.Rhs.neg_y(), y2, np.linspace(0.0, 0.25, 9), o2, integrator="rk4")
+dy = -y
+spl = nn.newHermiteSpline(t, y, dy)
+xq = np.linspace(0.01, 0.24, 16)
+s, _ = timed(lambda: spl.eval(xq), reps=3)
+out["hermite_eval_16q_1e7"] = dict(ms=s * 1e3, GBps=40.0 * n * 16 / s / 1e9)
+print(json.dumps(out, indent=1))

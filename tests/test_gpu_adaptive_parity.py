@@ -293,3 +293,33 @@ def test_controller_factor_accuracy(nn, dev, order):
     L.nnhip_ode_controller_factor_f64_dev(order, en.data_ptr(), on.data_ptr(), 1, None)
     torch.cuda.synchronize()
     assert np.isnan(on.cpu().numpy()[0])
+
+
+@pytest.mark.parametrize("layout", [0, 1], ids=["soa", "aos"])
+def test_multi_gpu_c_entry_single_device(nn, oracle, dev, layout):
+    """nnhip_ode_solve_batch_multi_gpu_f64 (one process, G devices, host buffers) with the one device this box has:
+    exercises the shard pack / unpack for both layouts, dense output included."""
+    import ctypes as C
+    O = oracle
+    L = nn._lib.lib()
+    n, dim = 777, 3
+    y0 = np.stack([1.0 + (np.arange(n) % 1024) * 2.0 ** -20, np.ones(n), np.ones(n)])
+    y0l = np.ascontiguousarray(y0 if layout == 0 else y0.T)
+    ts = np.array([-0.1, 0.0, 0.2, 0.3])
+    opt = nn.newODEoptions()
+    out = np.empty((len(ts),) + y0l.shape)
+    t_out = np.empty(len(ts))
+    ny = np.empty(n, dtype=np.int32)
+    st = nn.ode.Stats()
+    p = np.array([10.0, 28.0, 8.0 / 3.0])
+    dp = C.POINTER(C.c_double)
+    rc = L.nnhip_ode_solve_batch_multi_gpu_f64(C.byref(opt), 1, 2, p.ctypes.data_as(dp), 3, y0l.ctypes.data, n, dim, layout,
+                                               ts.ctypes.data_as(dp), len(ts), t_out.ctypes.data_as(dp), out.ctypes.data, ny.ctypes.data, 0,
+                                               C.byref(st), 1)
+    assert rc == 0, nn._lib.last_error()
+    ref = O.solve_ode_batch(O.RHS_LORENZ, list(p), y0l, n, dim, ts, O.new_options(), "dopri54", layout=layout, n_threads=8)
+    assert np.array_equal(t_out, ref["t"]) and np.abs(out - ref["y"]).max() <= TOL_ADAPTIVE
+    assert np.array_equal(ny, ref["ny"]) and st.steps_total == int(ref["steps"].sum())
+    assert L.nnhip_ode_solve_batch_multi_gpu_f64(C.byref(opt), 1, 2, p.ctypes.data_as(dp), 3, y0l.ctypes.data, n, dim, layout,
+                                                 ts.ctypes.data_as(dp), len(ts), t_out.ctypes.data_as(dp), out.ctypes.data, ny.ctypes.data, 0,
+                                                 C.byref(st), 9) != 0  # more GPUs than the box has -> refused

@@ -34,3 +34,25 @@ def test_hermite_spline_on_trajectories(nn, oracle, dev):
     # interpolation error of the cubic Hermite spline against a fine-grid solve is small
     tf, yf = nn.solveODE(f, torch.from_numpy(y0).to(dev), [0.0, 0.525], nn.newODEoptions(dt=1e-3), integrator="rk4")
     assert float((spl.eval(0.525) - yf[-1]).abs().max()) < 2e-2  # h^4 error of a cubic Hermite with knot spacing 0.05 on Lorenz
+
+
+def test_cumtrapz_on_trajectories(nn, oracle, dev):
+    """cumtrapz(Y, X) / trapz (integrate.nim:104-135) over a trajectory tensor, bit-exact vs the oracle; > one weight chunk."""
+    import torch
+    O = oracle
+    n = 150
+    rng = np.random.default_rng(10)
+    y0 = rng.uniform(0.5, 2.0, n)
+    ts = np.sort(np.unique(np.round(rng.uniform(0.0, 2.0, 500), 4)))
+    ts[0] = 0.0
+    t, y = nn.solveODE(nn.Rhs.linear(-0.8), torch.from_numpy(y0).to(dev), ts, nn.newODEoptions(dt=1e-3), integrator="rk4")
+    assert len(t) > 400
+    c = nn.cumtrapz(y, t).cpu().numpy()
+    yh = y.cpu().numpy()
+    for m in range(0, n, 13):
+        assert np.array_equal(c[:, m], O.cumtrapz(yh[:, m], t))
+    assert np.array_equal(nn.trapz(y, t).cpu().numpy(), c[-1])
+    exact = y0 * (1 - np.exp(-0.8 * t[-1])) / 0.8
+    assert np.abs(c[-1] - exact).max() < 1e-4
+    with pytest.raises(ValueError):
+        nn.cumtrapz(y, t[::-1].copy())
