@@ -7,8 +7,15 @@ it, used by the tests and bench.py.  There is no CPU fallback: without the built
 call raises.
 """
 from .ode import (  # noqa: F401
-    ODEoptions, newODEoptions, DEFAULT_ODEoptions, NumContext, newNumContext, Rhs, solveODE, integratorStep, fixedStream,
+    ODEoptions, newODEoptions, NumContext, newNumContext, Rhs, solveODE, integratorStep, fixedStream,
     fixedODE, adaptiveODE, allODE, implementedODE, LAYOUT_SOA, LAYOUT_AOS, NnhipError,
 )
 from .interpolate import newHermiteSpline, HermiteSpline, rhsBatch, cumtrapz, trapz  # noqa: F401
 from . import _lib  # noqa: F401
+
+
+def __getattr__(name):
+    if name == "DEFAULT_ODEoptions":
+        from . import ode
+        return ode._default_options()
+    raise AttributeError(name)

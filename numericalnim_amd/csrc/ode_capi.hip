@@ -50,6 +50,7 @@ const MethodInfo kMethods[NNHIP_N_INTEGRATORS] = {
     {"ralston4", 0, 4.0, 0, 1}, {"kutta4", 0, 4.0, 0, 1},
 };
 
+int g_stream_graph = 0;  // tuning knob "stream_graph": 0 eager launches, 1 hipGraph capture + replay of the streaming loop
 int g_wide_tpi = 0;  // tuning: prefer the register-resident thread-per-IVP fused kernel for dim-16 systems
 
 nnhip::SolveLaunchFn find_solve(int integrator, int rhs_kind, int dim) {
@@ -173,6 +174,7 @@ const char* nnhip_build_info(void) {
 int nnhip_tune_set(const char* key, int value) {
   if (!key) return fail(NNHIP_EVALUE, "key is NULL");
   const std::string k(key);
+  if (k == "stream_graph") { g_stream_graph = value != 0; return NNHIP_OK; }
   if (k == "wide_tpi") { g_wide_tpi = value; return NNHIP_OK; }
   if (k == "rk4_stream_auto") { g_tune_auto = value != 0; return NNHIP_OK; }
   if (k == "rk4_stream_vec" || k == "rk4_stream_mode") g_tune_auto = false;
@@ -449,12 +451,68 @@ int nnhip_ode_step_batch_f64_dev(const nnhip_ode_options* opt, int integrator, i
   return NNHIP_OK;
 }
 
+namespace {
+// hipGraph cache for the fixed-step streaming loop: for small / mid-size batches the loop is launch-bound
+// (a 1e5-IVP RK4 step runs ~2 us, a launch costs ~4 us of host time), so the whole sequence of step launches is
+// captured once per (buffers, sizes, times, options, RHS) and replayed with one hipGraphLaunch.
+struct StreamGraphKey {
+  int integrator, rhs_kind, dim, layout, n_params;
+  int64_t N;
+  double t0, tEnd, dt, p[nnhip::kMaxParams];
+  const void *y, *scratch;
+  hipStream_t stream;
+  bool operator==(const StreamGraphKey& o) const { return std::memcmp(this, &o, sizeof(*this)) == 0; }
+};
+struct StreamGraphEntry {
+  StreamGraphKey key;
+  hipGraphExec_t exec = nullptr;
+  int64_t nSteps = 0;
+  double* yFinal = nullptr;
+};
+thread_local std::vector<StreamGraphEntry> g_graphs;
+thread_local bool g_capturing = false;
+}  // namespace
+
 int nnhip_ode_fixed_stream_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
                                    int n_params, int64_t N, int dim, int layout, double t0, double tEnd, double* y,
                                    double* scratch, int64_t* n_steps_out, double** y_final, void* stream) {
   nnhip::Params P;
   int rc = check_common(opt, integrator, rhs_kind, rhs_params, n_params, N, dim, layout, P);
   if (rc) return rc;
+  if (g_stream_graph && !g_capturing && N > 0 && stream != nullptr) {  // the legacy default stream cannot be captured
+    StreamGraphKey key;
+    std::memset(&key, 0, sizeof(key));
+    key.integrator = integrator; key.rhs_kind = rhs_kind; key.dim = dim; key.layout = layout; key.n_params = n_params; key.N = N;
+    key.t0 = t0; key.tEnd = tEnd; key.dt = opt->dt;
+    for (int k = 0; k < nnhip::kMaxParams; ++k) key.p[k] = P.p[k];
+    key.y = y; key.scratch = scratch; key.stream = (hipStream_t)stream;
+    for (auto& e : g_graphs)
+      if (e.key == key) {
+        HIP_TRY(hipGraphLaunch(e.exec, (hipStream_t)stream));
+        if (n_steps_out) *n_steps_out = e.nSteps;
+        if (y_final) *y_final = e.yFinal;
+        return NNHIP_OK;
+      }
+    StreamGraphEntry e;
+    e.key = key;
+    hipGraph_t graph = nullptr;
+    HIP_TRY(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+    g_capturing = true;
+    rc = nnhip_ode_fixed_stream_f64_dev(opt, integrator, rhs_kind, rhs_params, n_params, N, dim, layout, t0, tEnd, y, scratch, &e.nSteps,
+                                        &e.yFinal, stream);
+    g_capturing = false;
+    hipError_t ce = hipStreamEndCapture((hipStream_t)stream, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (ce != hipSuccess) return fail(NNHIP_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+    HIP_TRY(hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    if (g_graphs.size() >= 8) { (void)hipGraphExecDestroy(g_graphs.front().exec); g_graphs.erase(g_graphs.begin()); }
+    g_graphs.push_back(e);
+    HIP_TRY(hipGraphLaunch(e.exec, (hipStream_t)stream));
+    if (n_steps_out) *n_steps_out = e.nSteps;
+    if (y_final) *y_final = e.yFinal;
+    return NNHIP_OK;
+  }
   if (kMethods[integrator].adaptive) return fail(NNHIP_EVALUE, "nnhip_ode_fixed_stream_f64_dev needs a fixed-step integrator");
   if (!kMethods[integrator].implemented) return fail(NNHIP_EUNSUPPORTED, "integrator %s has no HIP kernel yet", kMethods[integrator].name);
   if (!(opt->dt > 0.0)) return fail(NNHIP_EVALUE, "fixed-step integrators need options.dt > 0 (the reference would loop forever)");

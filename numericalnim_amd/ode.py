@@ -53,14 +53,21 @@ def newODEoptions(dt=1e-4, absTol=1e-4, relTol=1e-4, dtMax=1e-2, dtMin=1e-4, sca
     return o
 
 
-DEFAULT_ODEoptions = None  # filled lazily by _default_options(); ode.nim:104
+_DEFAULT = None
 
 
 def _default_options():
-    global DEFAULT_ODEoptions
-    if DEFAULT_ODEoptions is None:
-        DEFAULT_ODEoptions = newODEoptions()
-    return DEFAULT_ODEoptions
+    """DEFAULT_ODEoptions (ode.nim:104), built on first use (needs the C library)."""
+    global _DEFAULT
+    if _DEFAULT is None:
+        _DEFAULT = newODEoptions()
+    return _DEFAULT
+
+
+def __getattr__(name):  # module attribute DEFAULT_ODEoptions, evaluated lazily
+    if name == "DEFAULT_ODEoptions":
+        return _default_options()
+    raise AttributeError(name)
 
 
 class NumContext:
