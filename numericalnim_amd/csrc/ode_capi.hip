@@ -16,6 +16,13 @@
 #include "ode_kernels.hpp"
 #include "ode_rtc.hpp"
 
+namespace nnhip_fast {  // ode_tu_method.hip compiled with -ffp-contract=fast -DNNHIP_NS=nnhip_fast (Makefile)
+nnhip_abi::SolveLaunchFn find_solve_rk4(int rhs_kind, int dim, int wide_tpi);
+nnhip_abi::SolveLaunchFn find_solve_dopri54(int rhs_kind, int dim, int wide_tpi);
+nnhip_abi::SolveLaunchFn find_solve_tsit54(int rhs_kind, int dim, int wide_tpi);
+nnhip_abi::SolveLaunchFn find_solve_vern65(int rhs_kind, int dim, int wide_tpi);
+}  // namespace nnhip_fast
+
 namespace {
 
 thread_local char g_err[8192] = "";
@@ -50,10 +57,19 @@ const MethodInfo kMethods[NNHIP_N_INTEGRATORS] = {
     {"ralston4", 0, 4.0, 0, 1}, {"kutta4", 0, 4.0, 0, 1},
 };
 
+int g_fast_math = 0;     // tuning knob "fp_contract": 1 = FMA-contracted instantiations of the fused kernels (not bit-exact)
 int g_stream_graph = 0;  // tuning knob "stream_graph": 0 eager launches, 1 hipGraph capture + replay of the streaming loop
 int g_wide_tpi = 0;  // tuning: prefer the register-resident thread-per-IVP fused kernel for dim-16 systems
 
 nnhip::SolveLaunchFn find_solve(int integrator, int rhs_kind, int dim) {
+  if (g_fast_math) {  // opt-in FMA-contracted build of the compute-bound fused kernels
+    switch (integrator) {
+      case NNHIP_RK4: return nnhip_fast::find_solve_rk4(rhs_kind, dim, g_wide_tpi);
+      case NNHIP_DOPRI54: return nnhip_fast::find_solve_dopri54(rhs_kind, dim, g_wide_tpi);
+      case NNHIP_TSIT54: return nnhip_fast::find_solve_tsit54(rhs_kind, dim, g_wide_tpi);
+      case NNHIP_VERN65: return nnhip_fast::find_solve_vern65(rhs_kind, dim, g_wide_tpi);
+    }
+  }
   switch (integrator) {
 #define X(id, name) \
   case id: return nnhip::find_solve_##name(rhs_kind, dim, g_wide_tpi);
@@ -174,6 +190,7 @@ const char* nnhip_build_info(void) {
 int nnhip_tune_set(const char* key, int value) {
   if (!key) return fail(NNHIP_EVALUE, "key is NULL");
   const std::string k(key);
+  if (k == "fp_contract") { g_fast_math = value != 0; return NNHIP_OK; }
   if (k == "stream_graph") { g_stream_graph = value != 0; return NNHIP_OK; }
   if (k == "wide_tpi") { g_wide_tpi = value; return NNHIP_OK; }
   if (k == "rk4_stream_auto") { g_tune_auto = value != 0; return NNHIP_OK; }
@@ -273,6 +290,10 @@ static int solve_dev_impl(const nnhip_ode_options* opt, int integrator, int rhs_
   int rc = check_common(opt, integrator, rhs_kind, rhs_params, n_params, N, dim, layout, P);
   if (rc) return rc;
   if (n_t < 0 || (n_t > 0 && !tspan)) return fail(NNHIP_EVALUE, "bad tspan");
+  // Non-finite times make the reference's `while t < tEnd` loop spin forever (t += dt never reaches +inf; NaN breaks
+  // tspan.sorted()).  On a GPU that is a hung device, so they are refused (deviation).
+  for (int j = 0; j < n_t; ++j) if (!std::isfinite(tspan[j])) return fail(NNHIP_EVALUE, "tspan[%d] is not finite", j);
+  if (!std::isfinite(opt->tStart)) return fail(NNHIP_EVALUE, "options.tStart is not finite");
   if (N > 0 && (!y0 || !y_out)) return fail(NNHIP_EVALUE, "y0 / y_out is NULL");
   if (!kMethods[integrator].implemented) return fail(NNHIP_EUNSUPPORTED, "integrator %s has no HIP kernel yet", kMethods[integrator].name);
   const bool user = rhs_kind >= NNHIP_RHS_USER_BASE;
@@ -338,6 +359,9 @@ int nnhip_ode_solve_batch_f64(const nnhip_ode_options* opt, int integrator, int 
                               int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
                               int64_t* rejected_out, int64_t max_steps, nnhip_ode_stats* stats, int device) {
   if (N < 0 || dim < 1 || n_t < 0) return fail(NNHIP_EVALUE, "bad sizes");
+  if (!opt || (n_t > 0 && !tspan)) return fail(NNHIP_EVALUE, "options / tspan is NULL");
+  for (int j = 0; j < n_t; ++j) if (!std::isfinite(tspan[j])) return fail(NNHIP_EVALUE, "tspan[%d] is not finite", j);
+  if (!std::isfinite(opt->tStart)) return fail(NNHIP_EVALUE, "options.tStart is not finite");
   int ndev = nnhip_device_count();
   if (ndev < 0) return ndev;
   if (ndev == 0) return fail(NNHIP_EHIP, "no HIP device available (this library has no CPU fallback)");
@@ -517,6 +541,7 @@ int nnhip_ode_fixed_stream_f64_dev(const nnhip_ode_options* opt, int integrator,
   if (!kMethods[integrator].implemented) return fail(NNHIP_EUNSUPPORTED, "integrator %s has no HIP kernel yet", kMethods[integrator].name);
   if (!(opt->dt > 0.0)) return fail(NNHIP_EVALUE, "fixed-step integrators need options.dt > 0 (the reference would loop forever)");
   if (N > 0 && !y) return fail(NNHIP_EVALUE, "y is NULL");
+  if (!std::isfinite(t0) || !std::isfinite(tEnd)) return fail(NNHIP_EVALUE, "t0 / tEnd must be finite");
   // ODESolver forward loop, adaptive = false, no dense output (ode.nim:509-532)
   double t = t0;
   double dt = opt->dt;

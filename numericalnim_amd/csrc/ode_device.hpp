@@ -21,7 +21,25 @@
 #include "../../include/nnhip_ode.h"
 #endif
 
-namespace nnhip {
+// The kernels live in a build-variant namespace: `nnhip` for the default bit-parity build (-ffp-contract=off) and
+// `nnhip_fast` for the opt-in FMA-contracted instantiations of the compute-bound fused kernels (Makefile: the same
+// sources compiled with -ffp-contract=fast -DNNHIP_NS=nnhip_fast).  Plain argument structs shared by both live in nnhip_abi.
+#ifndef NNHIP_NS
+#define NNHIP_NS nnhip
+#endif
+
+namespace nnhip_abi {
+constexpr int kMaxParams = 8;
+struct Params {
+  double p[kMaxParams];
+};
+struct StepCtl {  // the option fields the steppers read (ode.nim:283-286)
+  double absTol, relTol, dtMax, dtMin;
+};
+}  // namespace nnhip_abi
+
+namespace NNHIP_NS {
+using namespace nnhip_abi;
 
 #define NNHIP_DEV __device__ __forceinline__
 
@@ -29,12 +47,6 @@ namespace nnhip {
 // to the second operand exactly as in the reference).
 NNHIP_DEV double nmin(double x, double y) { return (x <= y) ? x : y; }
 NNHIP_DEV double nmax(double x, double y) { return (y <= x) ? x : y; }
-
-constexpr int kMaxParams = 8;
-
-struct Params {
-  double p[kMaxParams];
-};
 
 // ------------------------------------------------------------------------------------------------
 // RHS library (enum nnhip_rhs_kind).  eval(): thread-per-IVP form, whole state in registers.
@@ -107,10 +119,6 @@ struct RhsRing {  // dy_c = -((c+1)/d)*y_c + p0*y_{(c+1) mod d}
   NNHIP_DEV static double comp(double, int c, const double* ys, const Params& P) {
     return -((double)(c + 1) / (double)DIM) * ys[c] + P.p[0] * ys[(c + 1) % DIM];
   }
-};
-
-struct StepCtl {  // the option fields the steppers read (ode.nim:283-286)
-  double absTol, relTol, dtMax, dtMin;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -689,4 +697,4 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
   out.rejected = rejected;
 }
 
-}  // namespace nnhip
+}  // namespace NNHIP_NS

@@ -22,7 +22,7 @@
 
 #include "ode_device.hpp"
 
-namespace nnhip {
+namespace nnhip_abi {
 
 struct SolveArgs {
   const double* y0;
@@ -67,6 +67,19 @@ constexpr int kBlock = 256;
 #if !NNHIP_RTC
 using SolveLaunchFn = hipError_t (*)(const SolveArgs&, hipStream_t);
 using StepLaunchFn = hipError_t (*)(const StepArgs&, int negate, hipStream_t);
+
+struct StreamTune {
+  int vec = 4;           // 16-byte accesses in flight per lane and direction: 1, 2, 4, 8
+  int mode = 0;          // see rk4_stream_vec_kernel
+  int blocksPerCU = 8;   // persistent modes: grid = 256 CUs * blocksPerCU
+};
+#endif
+}  // namespace nnhip_abi
+
+namespace NNHIP_NS {
+using namespace nnhip_abi;
+
+#if !NNHIP_RTC
 
 // Launch through hipLaunchKernel so the returned status belongs to THIS launch (hipGetLastError() can hand
 // back a stale error left by an unrelated runtime call of the host process).
@@ -419,11 +432,6 @@ __global__ __launch_bounds__(kBlock) void rhs_batch_kernel(int64_t N, int64_t iv
 }
 
 #if !NNHIP_RTC
-struct StreamTune {
-  int vec = 4;           // 16-byte accesses in flight per lane and direction: 1, 2, 4, 8
-  int mode = 0;          // see rk4_stream_vec_kernel
-  int blocksPerCU = 8;   // persistent modes: grid = 256 CUs * blocksPerCU
-};
 
 template <class RHS1, int VEC, int MODE>
 hipError_t launch_rk4_stream_vec(const double* yin, double* yout, int64_t n, double t, double dt, const Params& P, int negate,
@@ -507,4 +515,4 @@ bool rk4_stream_supported(int rhs_kind);
 
 #endif  // !NNHIP_RTC
 
-}  // namespace nnhip
+}  // namespace NNHIP_NS

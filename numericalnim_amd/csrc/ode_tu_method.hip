@@ -5,9 +5,9 @@
 #define NNHIP_CAT2(a, b) a##b
 #define NNHIP_CAT(a, b) NNHIP_CAT2(a, b)
 
-namespace nnhip {
+namespace NNHIP_NS {
 SolveLaunchFn NNHIP_CAT(find_solve_, NNHIP_TU_NAME)(int rhs_kind, int dim, int wide_tpi) {
   return find_solve_tpi<NNHIP_TU_METHOD>(rhs_kind, dim, wide_tpi);
 }
 StepLaunchFn NNHIP_CAT(find_step_, NNHIP_TU_NAME)(int rhs_kind, int dim) { return find_step_tpi<NNHIP_TU_METHOD>(rhs_kind, dim); }
-}  // namespace nnhip
+}  // namespace NNHIP_NS

@@ -82,6 +82,15 @@ def main():
     nn.solveODE(nn.Rhs.neg_y(), y2h, [0.0, 1000 * 2.0 ** -10], o2, integrator="rk4", stats=st)
     c1 = time.perf_counter()
     out["C2_fused_rk4_host_pointers"] = dict(wall_ms=(c1 - c0) * 1e3, kernel_ms=st.kernel_ms, traj_steps_per_s_pcie_inclusive=n2 * 1000 / (c1 - c0))
+    # ---- opt-in FMA-contracted instantiations (tuning knob fp_contract; not bit-exact, inside the 1e-10 / 1e-6 tolerances) ----
+    L.nnhip_tune_set(b"fp_contract", 1)
+    s, _ = timed(lambda: nn.solveODE(nn.Rhs.neg_y(), y2, [0.0, 1000 * 2.0 ** -10], o2, integrator="rk4"))
+    out["fp_contract_C2_fused_rk4"] = dict(ms=s * 1e3, traj_steps_per_s=n2 * 1000 / s)
+    s, _ = timed(lambda: nn.solveODE(nn.Rhs.lorenz(), y0, [0.0, 1.0], nn.newODEoptions(), integrator="dopri54"))
+    out["fp_contract_C3_lorenz_dopri54_default"] = dict(ms=s * 1e3)
+    s, _ = timed(lambda: nn.solveODE(nn.Rhs.ring(0.1), y16, [0.0, 1.0], nn.newODEoptions(), integrator="tsit54", layout=1))
+    out["fp_contract_C4_ring16_tsit54_default"] = dict(ms=s * 1e3)
+    L.nnhip_tune_set(b"fp_contract", 0)
     print(json.dumps(out, indent=1))
 
 

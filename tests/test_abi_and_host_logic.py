@@ -126,3 +126,12 @@ def test_argument_validation(nn):
     assert ctx.getF("a") == -0.1 and nn.Rhs.linear().params(ctx) == [-0.1]
     ctx["k"] = 3
     assert ctx["k"] == 3
+
+
+def test_non_finite_times_are_refused(nn):
+    """inf / NaN in tspan or tStart would make the reference loop forever; the ABI refuses them before touching the device."""
+    for ts in ([0.0, float("inf")], [float("nan"), 1.0]):
+        with pytest.raises(ValueError, match="not finite"):
+            nn.solveODE(nn.Rhs.neg_y(), np.ones(3), ts, nn.newODEoptions(dt=0.1), integrator="rk4")
+    with pytest.raises(ValueError, match="not finite"):
+        nn.solveODE(nn.Rhs.neg_y(), np.ones(3), [0.0, 1.0], nn.newODEoptions(dt=0.1, tStart=float("inf")), integrator="rk4")

@@ -323,3 +323,29 @@ def test_multi_gpu_c_entry_single_device(nn, oracle, dev, layout):
     assert L.nnhip_ode_solve_batch_multi_gpu_f64(C.byref(opt), 1, 2, p.ctypes.data_as(dp), 3, y0l.ctypes.data, n, dim, layout,
                                                  ts.ctypes.data_as(dp), len(ts), t_out.ctypes.data_as(dp), out.ctypes.data, ny.ctypes.data, 0,
                                                  C.byref(st), 9) != 0  # more GPUs than the box has -> refused
+
+
+def test_fp_contract_opt_in_stays_within_north_star_tolerance(nn, oracle, dev):
+    """Tuning knob "fp_contract" = 1 selects FMA-contracted instantiations of the fused RK4 / DOPRI54 / Tsit54 / Vern65
+    kernels (opt-in: not bit-exact).  They must still meet BASELINE.json's tolerances: 1e-10 fixed-step, 1e-6 adaptive."""
+    import torch
+    O = oracle
+    L = nn._lib.lib()
+    n = 2048
+    y0 = 1.0 + np.arange(n) * 2.0 ** -11
+    y0l = np.stack([1.0 + (np.arange(n) % 1024) * 2.0 ** -20, np.ones(n), np.ones(n)])
+    dt = 2.0 ** -10
+    try:
+        L.nnhip_tune_set(b"fp_contract", 1)
+        t, y = nn.solveODE(nn.Rhs.neg_y(), torch.from_numpy(y0).to(dev), [0.0, 1000 * dt], nn.newODEoptions(dt=dt), integrator="rk4")
+        ref = O.solve_ode_batch(O.RHS_NEG_Y, [], y0, n, 0, [0.0, 1000 * dt], O.new_options(dt=dt), "rk4")
+        err = np.abs(y[-1].cpu().numpy() - ref["y"][-1, 0]).max()
+        assert 0 < err <= 1e-10, err   # contracted: differs in the last bits, far inside the tolerance
+        for integ in ("dopri54", "tsit54", "vern65"):
+            t, yl = nn.solveODE(nn.Rhs.lorenz(), torch.from_numpy(y0l).to(dev), [0.0, 1.0], integrator=integ)
+            refl = O.solve_ode_batch(O.RHS_LORENZ, LOR, y0l, n, 3, [0.0, 1.0], O.new_options(), integ, n_threads=8)
+            assert np.abs(yl.cpu().numpy() - refl["y"]).max() <= TOL_ADAPTIVE
+    finally:
+        L.nnhip_tune_set(b"fp_contract", 0)
+    t, y2 = nn.solveODE(nn.Rhs.neg_y(), torch.from_numpy(y0).to(dev), [0.0, 1000 * dt], nn.newODEoptions(dt=dt), integrator="rk4")
+    assert np.array_equal(y2[-1].cpu().numpy(), ref["y"][-1, 0])  # default build is bit-exact again
