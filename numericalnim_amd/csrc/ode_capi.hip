@@ -57,6 +57,8 @@ const MethodInfo kMethods[NNHIP_N_INTEGRATORS] = {
     {"ralston4", 0, 4.0, 0, 1}, {"kutta4", 0, 4.0, 0, 1},
 };
 
+int g_host_chunks = 0;    // tuning knob "host_chunks": 0 = auto (= 1, see nnhip_ode_solve_batch_f64)
+int g_host_register = 0;  // tuning knob "host_register": page-lock the caller's buffers for the duration of a host-pointer solve
 int g_fast_math = 0;     // tuning knob "fp_contract": 1 = FMA-contracted instantiations of the fused kernels (not bit-exact)
 int g_stream_graph = 0;  // tuning knob "stream_graph": 0 eager launches, 1 hipGraph capture + replay of the streaming loop
 int g_wide_tpi = 0;  // tuning: prefer the register-resident thread-per-IVP fused kernel for dim-16 systems
@@ -190,6 +192,8 @@ const char* nnhip_build_info(void) {
 int nnhip_tune_set(const char* key, int value) {
   if (!key) return fail(NNHIP_EVALUE, "key is NULL");
   const std::string k(key);
+  if (k == "host_chunks") { if (value < 0 || value > 64) return fail(NNHIP_EVALUE, "host_chunks must be 0..64"); g_host_chunks = value; return NNHIP_OK; }
+  if (k == "host_register") { g_host_register = value != 0; return NNHIP_OK; }
   if (k == "fp_contract") { g_fast_math = value != 0; return NNHIP_OK; }
   if (k == "stream_graph") { g_stream_graph = value != 0; return NNHIP_OK; }
   if (k == "wide_tpi") { g_wide_tpi = value; return NNHIP_OK; }
@@ -282,10 +286,18 @@ int64_t nnhip_ode_solve_workspace_bytes(int n_t) {
 }
 
 // ---- fused solve ---------------------------------------------------------------------------------
-static int solve_dev_impl(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
-                          const double* y0, int64_t N, int dim, int layout, const double* tspan, int n_t, double* t_out,
-                          double* y_out, int32_t* ny_out, int64_t* steps_out, int64_t* rejected_out, int64_t max_steps,
-                          void* ws, int64_t ws_bytes, unsigned long long* agg, int* n_t_out, hipStream_t stream) {
+struct PreparedSolve {
+  nnhip::SolveArgs a{};       // arguments for the FULL batch
+  nnhip::SolveLaunchFn fn = nullptr;
+  bool user = false;
+  int integrator = 0, rhs_kind = 0;
+};
+
+// Everything of solveODE / ODESolver that precedes the per-IVP loops: validation, time grid, dispatch (ode.nim:589-651, 476-510).
+static int prepare_solve(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
+                         const double* y0, int64_t N, int dim, int layout, const double* tspan, int n_t, double* t_out,
+                         double* y_out, int32_t* ny_out, int64_t* steps_out, int64_t* rejected_out, int64_t max_steps, void* ws,
+                         int64_t ws_bytes, unsigned long long* agg, int* n_t_out, hipStream_t stream, PreparedSolve& ps) {
   nnhip::Params P;
   int rc = check_common(opt, integrator, rhs_kind, rhs_params, n_params, N, dim, layout, P);
   if (rc) return rc;
@@ -296,9 +308,11 @@ static int solve_dev_impl(const nnhip_ode_options* opt, int integrator, int rhs_
   if (!std::isfinite(opt->tStart)) return fail(NNHIP_EVALUE, "options.tStart is not finite");
   if (N > 0 && (!y0 || !y_out)) return fail(NNHIP_EVALUE, "y0 / y_out is NULL");
   if (!kMethods[integrator].implemented) return fail(NNHIP_EUNSUPPORTED, "integrator %s has no HIP kernel yet", kMethods[integrator].name);
-  const bool user = rhs_kind >= NNHIP_RHS_USER_BASE;
-  nnhip::SolveLaunchFn fn = user ? nullptr : find_solve(integrator, rhs_kind, dim);
-  if (!fn && !user) return fail(NNHIP_EUNSUPPORTED, "no fused-solve kernel for integrator=%s rhs_kind=%d dim=%d", kMethods[integrator].name, rhs_kind, dim);
+  ps.user = rhs_kind >= NNHIP_RHS_USER_BASE;
+  ps.integrator = integrator;
+  ps.rhs_kind = rhs_kind;
+  ps.fn = ps.user ? nullptr : find_solve(integrator, rhs_kind, dim);
+  if (!ps.fn && !ps.user) return fail(NNHIP_EUNSUPPORTED, "no fused-solve kernel for integrator=%s rhs_kind=%d dim=%d", kMethods[integrator].name, rhs_kind, dim);
   const bool adaptive = kMethods[integrator].adaptive;
   // Deviations from the reference that keep the device from spinning forever (documented in DESIGN.md):
   if (!adaptive && !(opt->dt > 0.0)) return fail(NNHIP_EVALUE, "fixed-step integrators need options.dt > 0 (the reference would loop forever)");
@@ -308,9 +322,8 @@ static int solve_dev_impl(const nnhip_ode_options* opt, int integrator, int rhs_
   make_grid(opt, tspan, n_t, g);
   if (t_out) std::copy(g.tOut.begin(), g.tOut.end(), t_out);
   if (n_t_out) *n_t_out = (int)g.tOut.size();
-  if (N == 0) return NNHIP_OK;
 
-  nnhip::SolveArgs a{};
+  nnhip::SolveArgs& a = ps.a;
   a.y0 = y0; a.y_out = y_out; a.ny_out = ny_out; a.steps_out = steps_out; a.rejected_out = rejected_out; a.agg = agg;
   a.N = N;
   if (layout == NNHIP_LAYOUT_SOA) { a.ivpStride = 1; a.compStride = N; } else { a.ivpStride = dim; a.compStride = 1; }
@@ -324,7 +337,7 @@ static int solve_dev_impl(const nnhip_ode_options* opt, int integrator, int rhs_
   a.ctl = ctl_of(opt);
   a.P = P;
   a.tPos = nullptr; a.tNeg = nullptr;
-  if (a.useDense && (a.nPos + a.nNeg) > 0) {
+  if (N > 0 && a.useDense && (a.nPos + a.nNeg) > 0) {
     const size_t n = (size_t)a.nPos + (size_t)a.nNeg;
     if (!ws || ws_bytes < (int64_t)(n * sizeof(double))) return fail(NNHIP_EVALUE, "workspace too small: need %zu bytes", n * sizeof(double));
     rc = stage_reserve(n);
@@ -337,12 +350,25 @@ static int solve_dev_impl(const nnhip_ode_options* opt, int integrator, int rhs_
     a.tPos = (const double*)ws;
     a.tNeg = (const double*)ws + a.nPos;
   }
-  if (user) {
-    if (nnhip::rtc_launch_solve(rhs_kind, integrator, a, stream) != hipSuccess)
+  return NNHIP_OK;
+}
+
+// Launch the fused kernel over the IVP index range [lo, lo + n) of a prepared batch (strides keep addressing the full arrays).
+static int launch_solve_range(const PreparedSolve& ps, int64_t lo, int64_t n, hipStream_t stream) {
+  if (n <= 0) return NNHIP_OK;
+  nnhip::SolveArgs a = ps.a;
+  a.y0 += lo * a.ivpStride;
+  a.y_out += lo * a.ivpStride;
+  if (a.ny_out) a.ny_out += lo;
+  if (a.steps_out) a.steps_out += lo;
+  if (a.rejected_out) a.rejected_out += lo;
+  a.N = n;
+  if (ps.user) {
+    if (nnhip::rtc_launch_solve(ps.rhs_kind, ps.integrator, a, stream) != hipSuccess)
       return fail(NNHIP_EHIP, "user RHS launch failed: %s", nnhip::rtc_last_error());
     return NNHIP_OK;
   }
-  HIP_TRY(fn(a, stream));
+  HIP_TRY(ps.fn(a, stream));
   return NNHIP_OK;
 }
 
@@ -350,8 +376,11 @@ int nnhip_ode_solve_batch_f64_dev(const nnhip_ode_options* opt, int integrator, 
                                   int n_params, const double* y0, int64_t N, int dim, int layout, const double* tspan,
                                   int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
                                   int64_t* rejected_out, int64_t max_steps, void* ws, int64_t ws_bytes, void* stream) {
-  return solve_dev_impl(opt, integrator, rhs_kind, rhs_params, n_params, y0, N, dim, layout, tspan, n_t, t_out, y_out, ny_out,
-                        steps_out, rejected_out, max_steps, ws, ws_bytes, nullptr, nullptr, (hipStream_t)stream);
+  PreparedSolve ps;
+  int rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, y0, N, dim, layout, tspan, n_t, t_out, y_out, ny_out, steps_out,
+                         rejected_out, max_steps, ws, ws_bytes, nullptr, nullptr, (hipStream_t)stream, ps);
+  if (rc) return rc;
+  return launch_solve_range(ps, 0, N, (hipStream_t)stream);
 }
 
 int nnhip_ode_solve_batch_f64(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
@@ -367,62 +396,113 @@ int nnhip_ode_solve_batch_f64(const nnhip_ode_options* opt, int integrator, int 
   if (ndev == 0) return fail(NNHIP_EHIP, "no HIP device available (this library has no CPU fallback)");
   if (device < 0 || device >= ndev) return fail(NNHIP_EVALUE, "device %d out of range [0,%d)", device, ndev);
   HIP_TRY(hipSetDevice(device));
+  // Host buffers in, host buffers out.  The batch can be cut into chunks of the IVP index range that flow through two
+  // streams (H2D of chunk c+1 overlaps the kernel and D2H of chunk c) and the user buffers can be page-locked for the
+  // duration of the call (tuning knobs "host_chunks", "host_register"); see the measurement below for the defaults.
   const size_t nState = (size_t)N * dim, nOut = nState * (size_t)n_t;
   double *d_y0 = nullptr, *d_out = nullptr;
   int32_t* d_ny = nullptr;
   int64_t *d_steps = nullptr, *d_rej = nullptr;
   void* d_ws = nullptr;
   unsigned long long* d_agg = nullptr;
-  hipStream_t s = nullptr;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipStream_t s[2] = {nullptr, nullptr};
+  std::vector<hipEvent_t> evs;
+  hipEvent_t evPrep = nullptr;
+  bool regIn = false, regOut = false;
   int rc = NNHIP_OK;
   int nTOut = 0;
   const int64_t wsBytes = nnhip_ode_solve_workspace_bytes(n_t);
   auto cleanup = [&]() {
+    if (regIn) (void)hipHostUnregister((void*)y0);
+    if (regOut) (void)hipHostUnregister((void*)y_out);
     void* bufs[] = {d_y0, d_out, d_ny, d_steps, d_rej, d_ws, d_agg};
     for (void* b : bufs) if (b) (void)hipFree(b);
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    if (s) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+    if (evPrep) (void)hipEventDestroy(evPrep);
+    for (hipStream_t st : s) if (st) (void)hipStreamDestroy(st);
   };
 #define HIP_TRY_C(expr)                                                                                                   \
   do {                                                                                                                    \
     hipError_t _e = (expr);                                                                                               \
     if (_e != hipSuccess) { rc = fail(_e == hipErrorOutOfMemory ? NNHIP_ENOMEM : NNHIP_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e)); cleanup(); return rc; } \
   } while (0)
-  HIP_TRY_C(hipStreamCreate(&s));
-  HIP_TRY_C(hipEventCreate(&e0));
-  HIP_TRY_C(hipEventCreate(&e1));
+  // Measured on MI355X / EPYC 9575F (scripts/ab_host_path.py, C2 fused RK4, 80 MB in + 160 MB out): 1 chunk 19.0 ms, 2 chunks 20.5,
+  // 4 chunks 22.1; page-locking the user buffers first 25.5 / 23.7 / 22.9.  Staged pageable copies already run near the
+  // host's memcpy rate, so the default is one chunk, no registration; the knobs remain for hosts where that differs.
+  int nChunks = g_host_chunks > 0 ? g_host_chunks : 1;
+  if ((int64_t)nChunks > N) nChunks = (int)std::max<int64_t>(1, N);
+  HIP_TRY_C(hipStreamCreateWithFlags(&s[0], hipStreamNonBlocking));
+  HIP_TRY_C(hipStreamCreateWithFlags(&s[1], hipStreamNonBlocking));
+  HIP_TRY_C(hipEventCreateWithFlags(&evPrep, hipEventDisableTiming));
   if (nState) HIP_TRY_C(hipMalloc((void**)&d_y0, nState * sizeof(double)));
   if (nOut) HIP_TRY_C(hipMalloc((void**)&d_out, nOut * sizeof(double)));
   if (ny_out && N) HIP_TRY_C(hipMalloc((void**)&d_ny, (size_t)N * sizeof(int32_t)));
   if (steps_out && N) HIP_TRY_C(hipMalloc((void**)&d_steps, (size_t)N * sizeof(int64_t)));
   if (rejected_out && N) HIP_TRY_C(hipMalloc((void**)&d_rej, (size_t)N * sizeof(int64_t)));
   HIP_TRY_C(hipMalloc(&d_ws, (size_t)wsBytes));
-  HIP_TRY_C(hipMalloc((void**)&d_agg, 8 * sizeof(unsigned long long)));
+  HIP_TRY_C(hipMalloc((void**)&d_agg, nnhip::kAggSlots * 8 * sizeof(unsigned long long)));
   {
-    unsigned long long init[8] = {0, 0, 0, ~0ull, 0, 0, 0, 0};
-    HIP_TRY_C(hipMemcpyAsync(d_agg, init, sizeof(init), hipMemcpyHostToDevice, s));
+    std::vector<unsigned long long> init((size_t)nnhip::kAggSlots * 8, 0ull);
+    for (int k = 0; k < nnhip::kAggSlots; ++k) init[(size_t)k * 8 + 3] = ~0ull;
+    HIP_TRY_C(hipMemcpy(d_agg, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
   }
-  if (nState) HIP_TRY_C(hipMemcpyAsync(d_y0, y0, nState * sizeof(double), hipMemcpyHostToDevice, s));
-  HIP_TRY_C(hipEventRecord(e0, s));
-  rc = solve_dev_impl(opt, integrator, rhs_kind, rhs_params, n_params, d_y0, N, dim, layout, tspan, n_t, t_out, d_out, d_ny,
-                      d_steps, d_rej, max_steps, d_ws, wsBytes, d_agg, &nTOut, s);
+  if (g_host_register) {  // best effort: a failed registration just leaves the copies staged
+    regIn = nState && hipHostRegister((void*)y0, nState * sizeof(double), hipHostRegisterDefault) == hipSuccess;
+    regOut = nOut && hipHostRegister((void*)y_out, nOut * sizeof(double), hipHostRegisterDefault) == hipSuccess;
+    (void)hipGetLastError();
+  }
+  PreparedSolve ps;
+  rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, d_y0, N, dim, layout, tspan, n_t, t_out, d_out, d_ny, d_steps, d_rej,
+                     max_steps, d_ws, wsBytes, d_agg, &nTOut, s[0], ps);
   if (rc) { cleanup(); return rc; }
-  HIP_TRY_C(hipEventRecord(e1, s));
-  if (nOut) HIP_TRY_C(hipMemcpyAsync(y_out, d_out, nOut * sizeof(double), hipMemcpyDeviceToHost, s));
-  if (d_ny) HIP_TRY_C(hipMemcpyAsync(ny_out, d_ny, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-  if (d_steps) HIP_TRY_C(hipMemcpyAsync(steps_out, d_steps, (size_t)N * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-  if (d_rej) HIP_TRY_C(hipMemcpyAsync(rejected_out, d_rej, (size_t)N * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-  unsigned long long agg[8] = {0};
-  HIP_TRY_C(hipMemcpyAsync(agg, d_agg, sizeof(agg), hipMemcpyDeviceToHost, s));
-  HIP_TRY_C(hipStreamSynchronize(s));
+  HIP_TRY_C(hipEventRecord(evPrep, s[0]));
+  HIP_TRY_C(hipStreamWaitEvent(s[1], evPrep, 0));
+  evs.resize((size_t)nChunks * 2, nullptr);
+  for (auto& e : evs) HIP_TRY_C(hipEventCreate(&e));
+  const bool soa = layout == NNHIP_LAYOUT_SOA;
+  for (int cI = 0; cI < nChunks && N > 0; ++cI) {
+    const int64_t lo = N * cI / nChunks, hi = N * (cI + 1) / nChunks, n = hi - lo;
+    if (n <= 0) continue;
+    hipStream_t st = s[cI & 1];
+    if (soa) {  // component planes: `dim` rows of n doubles, pitch N
+      HIP_TRY_C(hipMemcpy2DAsync(d_y0 + lo, (size_t)N * 8, y0 + lo, (size_t)N * 8, (size_t)n * 8, (size_t)dim, hipMemcpyHostToDevice, st));
+    } else {
+      HIP_TRY_C(hipMemcpyAsync(d_y0 + lo * dim, y0 + lo * dim, (size_t)n * dim * 8, hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY_C(hipEventRecord(evs[(size_t)cI * 2], st));
+    rc = launch_solve_range(ps, lo, n, st);
+    if (rc) { cleanup(); return rc; }
+    HIP_TRY_C(hipEventRecord(evs[(size_t)cI * 2 + 1], st));
+    if (n_t > 0) {
+      if (soa) {
+        HIP_TRY_C(hipMemcpy2DAsync(y_out + lo, (size_t)N * 8, d_out + lo, (size_t)N * 8, (size_t)n * 8, (size_t)n_t * dim, hipMemcpyDeviceToHost, st));
+      } else {
+        HIP_TRY_C(hipMemcpy2DAsync(y_out + lo * dim, (size_t)N * dim * 8, d_out + lo * dim, (size_t)N * dim * 8, (size_t)n * dim * 8, (size_t)n_t,
+                                   hipMemcpyDeviceToHost, st));
+      }
+    }
+    if (d_ny) HIP_TRY_C(hipMemcpyAsync(ny_out + lo, d_ny + lo, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (d_steps) HIP_TRY_C(hipMemcpyAsync(steps_out + lo, d_steps + lo, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    if (d_rej) HIP_TRY_C(hipMemcpyAsync(rejected_out + lo, d_rej + lo, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY_C(hipStreamSynchronize(s[0]));
+  HIP_TRY_C(hipStreamSynchronize(s[1]));
   if (stats) {
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    stats->steps_total = (int64_t)agg[0]; stats->rejected_total = (int64_t)agg[1]; stats->steps_max = (int64_t)agg[2];
-    stats->n_t_out = nTOut; stats->ny_min = N ? (int32_t)agg[3] : 0; stats->nan_aborts = (int32_t)agg[4];
-    stats->truncated = (int32_t)agg[5]; stats->kernel_ms = ms;
+    std::vector<unsigned long long> agg((size_t)nnhip::kAggSlots * 8, 0ull);
+    HIP_TRY_C(hipMemcpy(agg.data(), d_agg, agg.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long tot[8] = {0, 0, 0, ~0ull, 0, 0, 0, 0};
+    for (int k = 0; k < nnhip::kAggSlots; ++k) {
+      const unsigned long long* a8 = &agg[(size_t)k * 8];
+      tot[0] += a8[0]; tot[1] += a8[1]; tot[2] = std::max(tot[2], a8[2]); tot[3] = std::min(tot[3], a8[3]); tot[4] += a8[4]; tot[5] += a8[5];
+    }
+    double ms = 0.0;
+    for (int cI = 0; cI < nChunks && N > 0; ++cI) {
+      float m1 = 0.f;
+      if (hipEventElapsedTime(&m1, evs[(size_t)cI * 2], evs[(size_t)cI * 2 + 1]) == hipSuccess) ms += m1;
+    }
+    stats->steps_total = (int64_t)tot[0]; stats->rejected_total = (int64_t)tot[1]; stats->steps_max = (int64_t)tot[2];
+    stats->n_t_out = nTOut; stats->ny_min = N ? (int32_t)tot[3] : 0; stats->nan_aborts = (int32_t)tot[4];
+    stats->truncated = (int32_t)tot[5]; stats->kernel_ms = ms;
   }
   cleanup();
   return NNHIP_OK;

@@ -30,7 +30,7 @@ struct SolveArgs {
   int32_t* ny_out;        // nullable
   int64_t* steps_out;     // nullable
   int64_t* rejected_out;  // nullable
-  unsigned long long* agg;  // nullable: [0] steps_total [1] rejected_total [2] steps_max [3] ny_min [4] nan_aborts [5] truncated
+  unsigned long long* agg;  // nullable: kAggSlots x {[0] steps_total [1] rejected_total [2] steps_max [3] ny_min [4] nan_aborts [5] truncated, 2 pad}
   int64_t N;
   int64_t ivpStride, compStride;  // element (i, c) of a state array lives at i*ivpStride + c*compStride
   int64_t rowStride;              // distance between consecutive output rows (= dim*N)
@@ -63,6 +63,7 @@ struct StepArgs {
 };
 
 constexpr int kBlock = 256;
+constexpr int kAggSlots = 64;  // replicated statistics accumulators (see aggregate_stats)
 
 #if !NNHIP_RTC
 using SolveLaunchFn = hipError_t (*)(const SolveArgs&, hipStream_t);
@@ -182,8 +183,10 @@ NNHIP_DEV void solve_body(const SolveArgs& a, const OpsF& opsF, const OpsB& opsB
   ls.trunc = (status & 2) ? 1 : 0;
 }
 
-// wave-level reduction of the per-IVP statistics, one atomic per wave and field
-NNHIP_DEV void aggregate_stats(unsigned long long* agg, LaneStats ls) {
+// wave-level reduction of the per-IVP statistics, one atomic per wave and field; the accumulators are replicated
+// kAggSlots times (slot = workgroup index mod kAggSlots) so 1e5 waves do not serialise on four addresses
+NNHIP_DEV void aggregate_stats(unsigned long long* aggBase, LaneStats ls) {
+  unsigned long long* agg = aggBase + (size_t)(blockIdx.x % kAggSlots) * 8;
   unsigned long long steps = ls.steps, rejected = ls.rejected, smax = ls.steps;
   int ny = ls.ny, nanAb = ls.nanAb, trunc = ls.trunc;
 #pragma unroll

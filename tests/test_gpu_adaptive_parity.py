@@ -349,3 +349,28 @@ def test_fp_contract_opt_in_stays_within_north_star_tolerance(nn, oracle, dev):
         L.nnhip_tune_set(b"fp_contract", 0)
     t, y2 = nn.solveODE(nn.Rhs.neg_y(), torch.from_numpy(y0).to(dev), [0.0, 1000 * dt], nn.newODEoptions(dt=dt), integrator="rk4")
     assert np.array_equal(y2[-1].cpu().numpy(), ref["y"][-1, 0])  # default build is bit-exact again
+
+
+def test_host_entry_chunked_pipeline_is_bitwise_identical(nn, dev):
+    """Tuning knobs host_chunks / host_register of the host-pointer solve only change how the batch flows over PCIe."""
+    L = nn._lib.lib()
+    n = 10_007
+    y0 = _lorenz_y0(n)
+    ts = [-0.1, 0.0, 0.15, 0.3]
+    ref = None
+    try:
+        for chunks, reg in ((1, 0), (3, 0), (7, 1), (64, 1)):
+            L.nnhip_tune_set(b"host_chunks", chunks)
+            L.nnhip_tune_set(b"host_register", reg)
+            for layout in (0, 1):
+                st = nn.ode.Stats()
+                y0l = y0 if layout == 0 else np.ascontiguousarray(y0.T)
+                t, y, cnt = nn.solveODE(nn.Rhs.lorenz(), y0l, ts, integrator="tsit54", layout=layout, stats=st, return_counts=True)
+                yy = y if layout == 0 else np.ascontiguousarray(np.transpose(y, (0, 2, 1)))
+                if ref is None:
+                    ref = (yy.copy(), cnt["steps"].copy(), st.steps_total)
+                assert np.array_equal(yy, ref[0]) and np.array_equal(cnt["steps"], ref[1]) and st.steps_total == ref[2]
+                assert st.steps_total == int(cnt["steps"].sum()) and st.ny_min == 4
+    finally:
+        L.nnhip_tune_set(b"host_chunks", 0)
+        L.nnhip_tune_set(b"host_register", 0)
