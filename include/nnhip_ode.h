@@ -163,6 +163,17 @@ int nnhip_ode_fixed_stream_f64_dev(const nnhip_ode_options* opt, int integrator,
                                    int n_params, int64_t N, int dim, int layout, double t0, double tEnd, double* y,
                                    double* scratch, int64_t* n_steps_out, double** y_final, void* stream);
 
+/* Adaptive time loop of ODESolver (ode.nim:506-542 with adaptive=true, tspan.len == 2) driven from the host over an
+ * `advance` kernel: per launch, every unfinished IVP does dt = min(dt, tEnd-t); step; t += dt; controller — with y, FSAL,
+ * t, dt resident in HBM between launches (8*(4*dim+5) algorithmic bytes per attempted step).  y (device, in `layout`) is
+ * advanced in place from t0 to tEnd; `ws` is device scratch of nnhip_ode_adaptive_stream_workspace_bytes(N, dim).  The host
+ * polls the count of unfinished IVPs every `check_every` launches (<= 0: 8).  Results are bitwise those of the fused solve.
+ * Thread-per-IVP kernels (dim <= 4 built-in RHS). */
+int64_t nnhip_ode_adaptive_stream_workspace_bytes(int64_t N, int dim);
+int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
+                                      int n_params, int64_t N, int dim, int layout, double t0, double tEnd, double* y, void* ws,
+                                      int64_t ws_bytes, int check_every, int64_t max_launches, int64_t* launches_out, void* stream);
+
 /* ---- multi-GPU (one process, n_gpus devices): contiguous shards of the IVP index range, no exchange
  * during integration, final trajectory tensor reassembled on every device's host view.  Host pointers. */
 int nnhip_ode_solve_batch_multi_gpu_f64(const nnhip_ode_options* opt, int integrator, int rhs_kind,

@@ -46,6 +46,9 @@ SIGNATURES = {
                                                _vp, C.c_double, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "nnhip_ode_fixed_stream_f64_dev": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, C.c_int64, C.c_int, C.c_int,
                                                  C.c_double, C.c_double, _vp, _vp, C.POINTER(C.c_int64), C.POINTER(_vp), _vp]),
+    "nnhip_ode_adaptive_stream_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int]),
+    "nnhip_ode_adaptive_stream_f64_dev": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, C.c_int64, C.c_int, C.c_int,
+                                                    C.c_double, C.c_double, _vp, _vp, C.c_int64, C.c_int, C.c_int64, C.POINTER(C.c_int64), _vp]),
     "nnhip_ode_solve_batch_multi_gpu_f64": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, _vp, C.c_int64, C.c_int,
                                                       C.c_int, _dp, C.c_int, _dp, _vp, _vp, C.c_int64, C.POINTER(Stats), C.c_int]),
     "nnhip_hermite_spline_f64_dev": (C.c_int, [C.c_double] * 3 + [_vp] * 5 + [C.c_int64, _vp]),

@@ -89,6 +89,16 @@ nnhip::StepLaunchFn find_step(int integrator, int rhs_kind, int dim) {
   return nullptr;
 }
 
+nnhip::StepLaunchFn find_advance(int integrator, int rhs_kind, int dim) {
+  switch (integrator) {
+#define X(id, name) \
+  case id: return nnhip::find_advance_##name(rhs_kind, dim);
+    NNHIP_FOR_EACH_METHOD(X)
+#undef X
+  }
+  return nullptr;
+}
+
 bool elementwise_rhs(int k) { return k == NNHIP_RHS_NEG_Y || k == NNHIP_RHS_LINEAR || k == NNHIP_RHS_AFFINE_T; }
 
 int check_common(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
@@ -638,6 +648,70 @@ int nnhip_ode_fixed_stream_f64_dev(const nnhip_ode_options* opt, int integrator,
   }
   if (n_steps_out) *n_steps_out = n;
   if (y_final) *y_final = cur;
+  return NNHIP_OK;
+}
+
+int64_t nnhip_ode_adaptive_stream_workspace_bytes(int64_t N, int dim) {
+  if (N < 0 || dim < 1) return 0;
+  return (int64_t)sizeof(double) * (N * dim /*FSAL*/ + 3 * N /*t, dt, error*/) + 256;
+}
+
+// ODESolver's adaptive forward loop (ode.nim:506-542, tspan.len == 2) over the `advance` kernel: per-IVP (t, dt, FSAL)
+// live in `ws`; every launch performs one loop iteration of every unfinished IVP; the host polls the number of
+// unfinished IVPs every `check_every` launches.
+int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
+                                      int n_params, int64_t N, int dim, int layout, double t0, double tEnd, double* y, void* ws,
+                                      int64_t ws_bytes, int check_every, int64_t max_launches, int64_t* launches_out, void* stream) {
+  nnhip::Params P;
+  int rc = check_common(opt, integrator, rhs_kind, rhs_params, n_params, N, dim, layout, P);
+  if (rc) return rc;
+  if (!kMethods[integrator].adaptive) return fail(NNHIP_EVALUE, "nnhip_ode_adaptive_stream_f64_dev needs an adaptive integrator");
+  if (rhs_kind >= NNHIP_RHS_USER_BASE) return fail(NNHIP_EUNSUPPORTED, "user RHS: use the fused solve or the step entry");
+  if (!std::isfinite(t0) || !std::isfinite(tEnd)) return fail(NNHIP_EVALUE, "t0 / tEnd must be finite");
+  if (!(opt->dtMin > 0.0) && max_launches <= 0) return fail(NNHIP_EVALUE, "adaptive integrators need options.dtMin > 0 or max_launches > 0");
+  if (launches_out) *launches_out = 0;
+  if (N == 0 || !(t0 < tEnd)) return NNHIP_OK;
+  if (!y || !ws || ws_bytes < nnhip_ode_adaptive_stream_workspace_bytes(N, dim)) return fail(NNHIP_EVALUE, "y / workspace missing or too small");
+  nnhip::StepLaunchFn fn = find_advance(integrator, rhs_kind, dim);
+  if (!fn) return fail(NNHIP_EUNSUPPORTED, "no advance kernel for integrator=%s rhs_kind=%d dim=%d", kMethods[integrator].name, rhs_kind, dim);
+  hipStream_t s = (hipStream_t)stream;
+  double* fsal = (double*)ws;
+  double* tArr = fsal + N * dim;
+  double* dtArr = tArr + N;
+  double* errArr = dtArr + N;
+  unsigned int* active = (unsigned int*)(errArr + N);
+  // FSAL = f(t0, y) (:506); t = t0; dt = sqrt(dtMax*dtMin) (:491-493)
+  rc = nnhip_ode_rhs_batch_f64_dev(rhs_kind, rhs_params, n_params, N, dim, layout, t0, y, fsal, stream);
+  if (rc) return fail(rc, "initial RHS evaluation failed");
+  {
+    std::vector<double> init((size_t)2 * N);
+    const double dtInit = std::sqrt(opt->dtMax * opt->dtMin);
+    std::fill(init.begin(), init.begin() + N, t0);
+    std::fill(init.begin() + N, init.end(), dtInit);
+    HIP_TRY(hipMemcpyAsync(tArr, init.data(), init.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));  // `init` goes out of scope
+  }
+  nnhip::StepArgs a{};
+  a.N = N;
+  if (layout == NNHIP_LAYOUT_SOA) { a.ivpStride = 1; a.compStride = N; } else { a.ivpStride = dim; a.compStride = 1; }
+  a.y_in = y; a.y_out = y; a.fsal_in = fsal; a.fsal_out = fsal; a.error = errArr;
+  a.ctl = ctl_of(opt); a.P = P;
+  a.tEnd = tEnd; a.t_io = tArr; a.dt_io = dtArr; a.active = active; a.steps_io = nullptr;
+  if (check_every <= 0) check_every = 8;
+  int64_t launches = 0;
+  for (;;) {
+    unsigned int h = 0;
+    for (int k = 0; k < check_every; ++k) {
+      if (k == check_every - 1) HIP_TRY(hipMemsetAsync(active, 0, sizeof(unsigned int), s));  // only the last launch's count is read
+      HIP_TRY(fn(a, 0, s));
+      ++launches;
+    }
+    HIP_TRY(hipMemcpyAsync(&h, active, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (h == 0) break;
+    if (max_launches > 0 && launches >= max_launches) break;
+  }
+  if (launches_out) *launches_out = launches;
   return NNHIP_OK;
 }
 

@@ -60,6 +60,12 @@ struct StepArgs {
   double* error;    // nullable
   StepCtl ctl;
   Params P;
+  // advance mode (adaptive streaming driver): one iteration of ODESolver's loop body per launch (ode.nim:525-541)
+  double tEnd;           // IVPs with t >= tEnd are finished and touch no memory
+  double* t_io;          // per-IVP time, read and updated in place
+  double* dt_io;         // per-IVP step size, read and updated in place
+  unsigned int* active;  // += number of IVPs still short of tEnd after this launch
+  int64_t* steps_io;     // nullable: per-IVP accepted-step counter
 };
 
 constexpr int kBlock = 256;
@@ -338,6 +344,62 @@ hipError_t launch_step_tpi(const StepArgs& a, int negate, hipStream_t s) {
 }
 #endif
 
+// ------------------------------------------------------------------------------------------------
+// advance: ONE iteration of ODESolver's adaptive loop body per IVP and launch (ode.nim:525-541), everything resident
+// in HBM between launches:  dt = min(dt, tEnd - t); (y, FSAL, dt, error) = integrator(...); t += dt; controller.
+// Algorithmic traffic per attempted step: read y(d)+FSAL(d)+t+dt, write y(d)+FSAL(d)+t+dt+error = 8*(4d+5) B.
+// ------------------------------------------------------------------------------------------------
+template <int METHOD, class RHS>
+__global__ __launch_bounds__(kBlock) void advance_tpi_kernel(const StepArgs a) {
+  constexpr int D = RHS::dim;
+  using MT = MethodTraits<METHOD>;
+  static_assert(MT::adaptive, "fixed-step methods share (t, dt): use the uniform streaming loop");
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  unsigned int stillActive = 0;
+  if (i < a.N) {
+    double t = a.t_io[i];
+    if (t < a.tEnd) {  // :511
+      const TpiOps<RHS, false> ops{a.P};
+      const int64_t base = i * a.ivpStride;
+      double y[D], yNew[D], fsal[D];
+#pragma unroll
+      for (int c = 0; c < D; ++c) { y[c] = a.y_in[base + c * a.compStride]; fsal[c] = a.fsal_in[base + c * a.compStride]; }
+      double dt = nmin(a.dt_io[i], a.tEnd - t);  // :525
+      double error = 0.0;
+      int64_t rej = 0;
+      embedded_step<METHOD>(ops, t, dt, y, fsal, yNew, error, a.ctl, rej);  // :531
+      t += dt;                                                              // :532
+      if (error == 0.0) dt *= 5.0;                                          // :534-535
+      else dt = dt * shrink_factor<(int)MT::order>(error);                  // :537
+      if (dt < a.ctl.dtMin) dt = a.ctl.dtMin;                               // :538-539
+      else if (a.ctl.dtMax < dt) dt = a.ctl.dtMax;                          // :540-541
+      if (error != error) t = a.tEnd;  // NaN abort (same deviation as the fused driver): retire the IVP
+#pragma unroll
+      for (int c = 0; c < D; ++c) { a.y_out[base + c * a.compStride] = yNew[c]; a.fsal_out[base + c * a.compStride] = fsal[c]; }
+      a.t_io[i] = t;
+      a.dt_io[i] = dt;
+      if (a.error) a.error[i] = error;
+      if (a.steps_io) a.steps_io[i] += 1;
+      stillActive = t < a.tEnd ? 1u : 0u;
+    }
+  }
+  const unsigned long long m = __ballot(stillActive != 0);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(a.active, (unsigned int)__popcll(m));
+}
+
+#if !NNHIP_RTC
+template <int METHOD, class RHS>
+hipError_t launch_advance_tpi(const StepArgs& a, int, hipStream_t s) {
+  if constexpr (MethodTraits<METHOD>::adaptive) {
+    const int64_t grid = (a.N + kBlock - 1) / kBlock;
+    if (grid <= 0) return hipSuccess;
+    return launch_kernel(advance_tpi_kernel<METHOD, RHS>, dim3((unsigned)grid), dim3(kBlock), s, a);
+  } else {
+    return hipErrorInvalidValue;
+  }
+}
+#endif
+
 template <int METHOD, class RHS, bool NEG>
 __global__ __launch_bounds__(kBlock) void step_lps_kernel(const StepArgs a) {
   constexpr int DIM = RHS::dim;
@@ -501,6 +563,15 @@ StepLaunchFn find_step_tpi(int rhs_kind, int dim) {
   return nullptr;
 }
 
+template <int METHOD>
+StepLaunchFn find_advance_tpi(int rhs_kind, int dim) {
+#define X(kind, d, T) \
+  if (rhs_kind == kind && dim == d) return &launch_advance_tpi<METHOD, T>;
+  NNHIP_FOR_EACH_TPI_RHS(X)
+#undef X
+  return nullptr;
+}
+
 // one translation unit per integrator (ode_tu_method.hip compiled with -DNNHIP_TU_METHOD=<id>)
 #define NNHIP_FOR_EACH_METHOD(X)                                                                                       \
   X(NNHIP_RK4, rk4) X(NNHIP_DOPRI54, dopri54) X(NNHIP_TSIT54, tsit54) X(NNHIP_VERN65, vern65) X(NNHIP_BS32, bs32)        \
@@ -508,7 +579,8 @@ StepLaunchFn find_step_tpi(int rhs_kind, int dim) {
   X(NNHIP_RALSTON3, ralston3) X(NNHIP_SSPRK3, ssprk3) X(NNHIP_RALSTON4, ralston4) X(NNHIP_KUTTA4, kutta4)
 #define X(id, name)                                                      \
   SolveLaunchFn find_solve_##name(int rhs_kind, int dim, int wide_tpi);  \
-  StepLaunchFn find_step_##name(int rhs_kind, int dim);
+  StepLaunchFn find_step_##name(int rhs_kind, int dim);                  \
+  StepLaunchFn find_advance_##name(int rhs_kind, int dim);
 NNHIP_FOR_EACH_METHOD(X)
 #undef X
 // scalar RK4 streaming (vectorised); rhs_kind must be an elementwise kind. Defined in ode_tu_rk4_stream.hip

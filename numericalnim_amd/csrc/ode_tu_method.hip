@@ -10,4 +10,8 @@ SolveLaunchFn NNHIP_CAT(find_solve_, NNHIP_TU_NAME)(int rhs_kind, int dim, int w
   return find_solve_tpi<NNHIP_TU_METHOD>(rhs_kind, dim, wide_tpi);
 }
 StepLaunchFn NNHIP_CAT(find_step_, NNHIP_TU_NAME)(int rhs_kind, int dim) { return find_step_tpi<NNHIP_TU_METHOD>(rhs_kind, dim); }
+StepLaunchFn NNHIP_CAT(find_advance_, NNHIP_TU_NAME)(int rhs_kind, int dim) {
+  if constexpr (MethodTraits<NNHIP_TU_METHOD>::adaptive) return find_advance_tpi<NNHIP_TU_METHOD>(rhs_kind, dim);
+  else return nullptr;
+}
 }  // namespace NNHIP_NS

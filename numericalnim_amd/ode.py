@@ -292,3 +292,24 @@ def fixedStream(f, y, t0, tEnd, options=None, ctx=None, integrator="rk4", layout
                                                 C.byref(nsteps), C.byref(yfin), stream))
     final = scratch if (scratch is not None and yfin.value == scratch.data_ptr()) else y
     return final, nsteps.value
+
+
+def adaptiveStream(f, y, t0, tEnd, options=None, ctx=None, integrator="dopri54", layout=LAYOUT_SOA, check_every=8):
+    """ODESolver's adaptive loop (ode.nim:506-542) over the HBM-resident `advance` kernel; y (CUDA tensor) is advanced
+    in place from t0 to tEnd.  Returns (y, number of launches).  Bitwise equal to solveODE(f, y0, [t0, tEnd])[1][-1]."""
+    import torch
+    L = _lib.lib()
+    options = options if options is not None else _default_options()
+    integ = integrator_id(integrator)
+    p, pp = _params_array(f, ctx)
+    N, dim, scalar = _shape_info(y, layout)
+    if not y.is_contiguous():
+        raise ValueError("y must be contiguous (it is updated in place)")
+    nl = C.c_int64(0)
+    with torch.cuda.device(y.device):
+        wsb = int(L.nnhip_ode_adaptive_stream_workspace_bytes(N, dim))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=y.device)
+        _check(L.nnhip_ode_adaptive_stream_f64_dev(C.byref(options), integ, f.kind, pp, int(p.size), N, dim, layout, float(t0), float(tEnd),
+                                                   y.data_ptr(), ws.data_ptr(), wsb, int(check_every), 0, C.byref(nl),
+                                                   torch.cuda.current_stream().cuda_stream))
+    return y, nl.value

@@ -374,3 +374,21 @@ def test_host_entry_chunked_pipeline_is_bitwise_identical(nn, dev):
     finally:
         L.nnhip_tune_set(b"host_chunks", 0)
         L.nnhip_tune_set(b"host_register", 0)
+
+
+@pytest.mark.parametrize("integrator", ["dopri54", "tsit54", "vern65", "bs32", "rk21"])
+def test_adaptive_stream_driver_equals_fused(nn, oracle, dev, integrator):
+    """nnhip_ode_adaptive_stream_f64_dev: ODESolver's adaptive loop with (y, FSAL, t, dt) resident in HBM between launches
+    must give the bits of the fused solve (and so match the oracle) — rejections included."""
+    import torch
+    O = oracle
+    n = 3000
+    y0 = _lorenz_y0(n)
+    kw = dict(absTol=1e-6, relTol=1e-6, dtMin=1e-9, dtMax=1.0)
+    yt = torch.from_numpy(y0).to(dev)
+    t, yf = nn.solveODE(nn.Rhs.lorenz(), yt, [0.0, 1.5], nn.newODEoptions(**kw), integrator=integrator)
+    ys, launches = nn.adaptiveStream(nn.Rhs.lorenz(), yt.clone(), 0.0, 1.5, nn.newODEoptions(**kw), integrator=integrator, check_every=5)
+    assert torch.equal(ys, yf[-1])
+    ref = O.solve_ode_batch(O.RHS_LORENZ, LOR, y0, n, 3, [0.0, 1.5], O.new_options(**kw), integrator, n_threads=8)
+    assert np.abs(ys.cpu().numpy() - ref["y"][-1]).max() <= TOL_ADAPTIVE
+    assert int(ref["steps"].max()) <= launches < int(ref["steps"].max()) + 5   # one loop iteration per launch, polled every 5
