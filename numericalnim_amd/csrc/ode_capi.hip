@@ -653,7 +653,7 @@ int nnhip_ode_fixed_stream_f64_dev(const nnhip_ode_options* opt, int integrator,
 
 int64_t nnhip_ode_adaptive_stream_workspace_bytes(int64_t N, int dim) {
   if (N < 0 || dim < 1) return 0;
-  return (int64_t)sizeof(double) * (N * dim /*FSAL*/ + 3 * N /*t, dt, error*/) + 256;
+  return (int64_t)sizeof(double) * (N * dim /*FSAL*/ + 3 * N /*t, dt, error*/) + (int64_t)sizeof(unsigned int) * nnhip::kAggSlots;
 }
 
 // ODESolver's adaptive forward loop (ode.nim:506-542, tspan.len == 2) over the `advance` kernel: per-IVP (t, dt, FSAL)
@@ -683,32 +683,30 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
   // FSAL = f(t0, y) (:506); t = t0; dt = sqrt(dtMax*dtMin) (:491-493)
   rc = nnhip_ode_rhs_batch_f64_dev(rhs_kind, rhs_params, n_params, N, dim, layout, t0, y, fsal, stream);
   if (rc) return fail(rc, "initial RHS evaluation failed");
-  {
-    std::vector<double> init((size_t)2 * N);
-    const double dtInit = std::sqrt(opt->dtMax * opt->dtMin);
-    std::fill(init.begin(), init.begin() + N, t0);
-    std::fill(init.begin() + N, init.end(), dtInit);
-    HIP_TRY(hipMemcpyAsync(tArr, init.data(), init.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));  // `init` goes out of scope
-  }
+  HIP_TRY(nnhip::launch_kernel(nnhip::fill_t_dt_kernel<0>, dim3((unsigned)((N + nnhip::kBlock - 1) / nnhip::kBlock)), dim3(nnhip::kBlock), s, tArr,
+                               dtArr, N, t0, std::sqrt(opt->dtMax * opt->dtMin)));
   nnhip::StepArgs a{};
   a.N = N;
   if (layout == NNHIP_LAYOUT_SOA) { a.ivpStride = 1; a.compStride = N; } else { a.ivpStride = dim; a.compStride = 1; }
   a.y_in = y; a.y_out = y; a.fsal_in = fsal; a.fsal_out = fsal; a.error = errArr;
   a.ctl = ctl_of(opt); a.P = P;
-  a.tEnd = tEnd; a.t_io = tArr; a.dt_io = dtArr; a.active = active; a.steps_io = nullptr;
+  a.tEnd = tEnd; a.t_io = tArr; a.dt_io = dtArr; a.active = nullptr; a.steps_io = nullptr;
   if (check_every <= 0) check_every = 8;
   int64_t launches = 0;
   for (;;) {
-    unsigned int h = 0;
+    unsigned int h[nnhip::kAggSlots];
     for (int k = 0; k < check_every; ++k) {
-      if (k == check_every - 1) HIP_TRY(hipMemsetAsync(active, 0, sizeof(unsigned int), s));  // only the last launch's count is read
+      const bool last = k == check_every - 1;  // only the last launch of a group reports whether work is left
+      if (last) HIP_TRY(hipMemsetAsync(active, 0, sizeof(h), s));
+      a.active = last ? active : nullptr;
       HIP_TRY(fn(a, 0, s));
       ++launches;
     }
-    HIP_TRY(hipMemcpyAsync(&h, active, sizeof(h), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h, active, sizeof(h), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    if (h == 0) break;
+    unsigned int any = 0;
+    for (unsigned int v : h) any |= v;
+    if (!any) break;
     if (max_launches > 0 && launches >= max_launches) break;
   }
   if (launches_out) *launches_out = launches;

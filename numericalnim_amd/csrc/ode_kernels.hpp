@@ -64,7 +64,7 @@ struct StepArgs {
   double tEnd;           // IVPs with t >= tEnd are finished and touch no memory
   double* t_io;          // per-IVP time, read and updated in place
   double* dt_io;         // per-IVP step size, read and updated in place
-  unsigned int* active;  // += number of IVPs still short of tEnd after this launch
+  unsigned int* active;  // nullable; kAggSlots flags, set when a workgroup still has IVPs short of tEnd after this launch
   int64_t* steps_io;     // nullable: per-IVP accepted-step counter
 };
 
@@ -383,8 +383,18 @@ __global__ __launch_bounds__(kBlock) void advance_tpi_kernel(const StepArgs a) {
       stillActive = t < a.tEnd ? 1u : 0u;
     }
   }
-  const unsigned long long m = __ballot(stillActive != 0);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(a.active, (unsigned int)__popcll(m));
+  // "is anyone still integrating?" — a plain flag store per workgroup into one of kAggSlots words (no atomics: 1e5 waves
+  // hitting one address cost ~170 us per launch), and only in the launches whose answer the host will read
+  if (a.active) {
+    if (__syncthreads_or((int)stillActive) && threadIdx.x == 0) a.active[blockIdx.x % kAggSlots] = 1u;
+  }
+}
+
+// t[i] = t0, dt[i] = dt0: the per-IVP loop variables before the first iteration (ode.nim:477, 491-493)
+template <int UNUSED = 0>  // a template only so that the header can be included by every translation unit
+__global__ __launch_bounds__(kBlock) void fill_t_dt_kernel(double* __restrict__ t, double* __restrict__ dt, int64_t n, double t0, double dt0) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) { t[i] = t0; dt[i] = dt0; }
 }
 
 #if !NNHIP_RTC
