@@ -246,6 +246,14 @@ def main():
                       "1 thread = the single-threaded reference; IVPs are independent so the rate extrapolates linearly" % (ns, nsteps),
             "all_cores": {"value": ns * nsteps / (c2 - c1), "cores": ncores},
         }
+    # RCCL prints a banner ("Librccl path : ...") through C stdio, which would otherwise be flushed AFTER this line at
+    # exit; flush C stdio first so that the JSON line is the last thing on stdout.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
     print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
