@@ -165,7 +165,7 @@ NNHIP_DEV void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <class RHS, bool NEG, int CPL = 1>
+template <class RHS, bool NEG, int CPL = 1, bool SHUFFLE_NORM = false>
 struct LpsOps {
   static constexpr int D = CPL;            // components per lane
   static constexpr int DIM = RHS::dim;     // components per system; DIM / CPL lanes of one wavefront share a system
@@ -191,12 +191,24 @@ struct LpsOps {
       const double e = err_y[j] / totalTol;
       es[c0 + j] = e * e;
     }
-    wave_lds_sync();
-    double sum = 0.0;
+    if constexpr (SHUFFLE_NORM) {
+      // A/B variant (tuning knob "lps_shuffle_norm"): butterfly all-reduce across the system's lanes with wavefront
+      // shuffles (ds_bpermute / DPP), no LDS round trip.  The association order differs from the reference's
+      // left-to-right sum, so `error` can differ in the last ulp (all lanes of a system still get identical bits).
+      double part = 0.0;
 #pragma unroll
-    for (int j = 0; j < DIM; ++j) sum = sum + es[j];  // same left-to-right order as utils.nim:233-235
-    wave_lds_sync();
-    return sqrt(1.0 / (double)DIM * sum);
+      for (int j = 0; j < CPL; ++j) part = part + es[c0 + j];
+#pragma unroll
+      for (int off = 1; off < DIM / CPL; off <<= 1) part = part + __shfl_xor(part, off, 64);
+      return sqrt(1.0 / (double)DIM * part);
+    } else {
+      wave_lds_sync();
+      double sum = 0.0;
+#pragma unroll
+      for (int j = 0; j < DIM; ++j) sum = sum + es[j];  // same left-to-right order as utils.nim:233-235
+      wave_lds_sync();
+      return sqrt(1.0 / (double)DIM * sum);
+    }
   }
 };
 

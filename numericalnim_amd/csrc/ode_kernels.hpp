@@ -245,7 +245,7 @@ hipError_t launch_solve_tpi(const SolveArgs& a, hipStream_t s) {
 // Lane (s, c) owns component c of system s: its y, k1..kS, yNew are single VGPR doubles; the stage
 // argument vector and the squared error components of each system live in LDS (2*DIM doubles per system,
 // 4 KiB per 256-thread workgroup).  With the AoS layout a wave's 64 lanes read 512 contiguous bytes.
-template <int METHOD, class RHS, int CPL>
+template <int METHOD, class RHS, int CPL, bool SHUFFLE_NORM = false>
 __global__ __launch_bounds__(kBlock) void solve_lps_kernel(const SolveArgs a) {
   constexpr int DIM = RHS::dim;
   constexpr int LPSYS = DIM / CPL;  // lanes per system
@@ -257,8 +257,8 @@ __global__ __launch_bounds__(kBlock) void solve_lps_kernel(const SolveArgs a) {
   if (i < a.N) {
     double* ys = lds + sysInBlock * DIM;
     double* es = lds + kBlock * CPL + sysInBlock * DIM;
-    const LpsOps<RHS, false, CPL> opsF{a.P, ys, es, c};
-    const LpsOps<RHS, true, CPL> opsB{a.P, ys, es, c};
+    const LpsOps<RHS, false, CPL, SHUFFLE_NORM> opsF{a.P, ys, es, c};
+    const LpsOps<RHS, true, CPL, SHUFFLE_NORM> opsB{a.P, ys, es, c};
     solve_body<METHOD>(a, opsF, opsB, a.y0 + i * a.ivpStride + c * a.compStride, a.y_out + i * a.ivpStride + c * a.compStride, ls);
     if (c == 0) {
       if (a.ny_out) a.ny_out[i] = ls.ny;
@@ -272,12 +272,12 @@ __global__ __launch_bounds__(kBlock) void solve_lps_kernel(const SolveArgs a) {
 }
 
 #if !NNHIP_RTC
-template <int METHOD, class RHS, int CPL = 1>
+template <int METHOD, class RHS, int CPL = 1, bool SHUFFLE_NORM = false>
 hipError_t launch_solve_lps(const SolveArgs& a, hipStream_t s) {
   constexpr int perBlock = kBlock / (RHS::dim / CPL);
   const int64_t grid = (a.N + perBlock - 1) / perBlock;
   if (grid <= 0) return hipSuccess;
-  return launch_kernel(solve_lps_kernel<METHOD, RHS, CPL>, dim3((unsigned)grid), dim3(kBlock), s, a);
+  return launch_kernel(solve_lps_kernel<METHOD, RHS, CPL, SHUFFLE_NORM>, dim3((unsigned)grid), dim3(kBlock), s, a);
 }
 #endif
 
@@ -554,6 +554,10 @@ SolveLaunchFn find_solve_tpi(int rhs_kind, int dim, int wide_tpi) {
   if (wide_tpi == 1) { NNHIP_FOR_EACH_WIDE_TPI_RHS(X) }
 #undef X
   if (wide_tpi == -1 && rhs_kind == NNHIP_RHS_RING && dim == 16) return &launch_solve_lps<METHOD, RhsRing<16>, 1>;
+  if constexpr (MethodTraits<METHOD>::adaptive) {  // A/B: wavefront-shuffle error norm instead of the ordered LDS sum
+    if (wide_tpi == -2 && rhs_kind == NNHIP_RHS_RING && dim == 16) return &launch_solve_lps<METHOD, RhsRing<16>, 4, true>;
+    if (wide_tpi == -3 && rhs_kind == NNHIP_RHS_RING && dim == 16) return &launch_solve_lps<METHOD, RhsRing<16>, 1, true>;
+  }
 #define X(kind, d, T, CA, CF) \
   if (rhs_kind == kind && dim == d) return &launch_solve_lps<METHOD, T, (MethodTraits<METHOD>::adaptive ? CA : CF)>;
   NNHIP_FOR_EACH_LPS_RHS(X)
