@@ -191,6 +191,12 @@ int nnhip_ode_solve_batch_multi_gpu_f64(const nnhip_ode_options* opt, int integr
  * (thread-per-IVP kernels; dim 1..16).  The body is syntax-checked at registration; NNHIP_EVALUE + the compiler
  * log in nnhip_last_error() on failure. */
 int nnhip_ode_rhs_compile(const char* name, int dim, int n_params, const char* body, int* rhs_kind_out);
+/* Per-component form: `comp_body` is the body of
+ *     __device__ double rhs_comp(double t, int c, const double* y, const double* p)   // returns dy_c
+ * e.g. "return -((c+1)/16.0)*y[c] + p[0]*y[(c+1)%16];".  Systems of 8, 16 or 32 components given this way run on the
+ * lanes-per-system kernels (stage vector in LDS, several lanes of one wavefront per system); dim 1..16 otherwise
+ * thread-per-IVP. */
+int nnhip_ode_rhs_compile_comp(const char* name, int dim, int n_params, const char* comp_body, int* rhs_kind_out);
 int nnhip_ode_rhs_release(int rhs_kind);
 
 /* ---- consumers either side of the path ------------------------------------------------------- */

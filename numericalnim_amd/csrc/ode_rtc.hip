@@ -30,10 +30,12 @@ const Header kHeaders[] = {
 struct Program {
   hipModule_t module = nullptr;
   hipFunction_t solve = nullptr, stepPos = nullptr, stepNeg = nullptr, rhs = nullptr;
+  int ivpsPerBlockSolve = kBlock, ivpsPerBlockStep = kBlock;  // thread-per-IVP: 256; lanes-per-system: 256 / lanes per system
 };
 struct UserRhsEntry {
   std::string name, body;
   int dim = 0, n_params = 0;
+  bool perComponent = false;  // body computes ONE component (usable by the lanes-per-system kernels) instead of the whole vector
   bool alive = false;
   std::map<int, Program> programs;  // by integrator; key -1 = the rhs_batch kernel only
 };
@@ -46,14 +48,27 @@ std::string make_source(const UserRhsEntry& e) {
   std::string s;
   s += "#include \"ode_kernels.hpp\"\n";
   s += "namespace nnhip {\nstruct UserRhs {\n  static constexpr int dim = " + std::to_string(e.dim) + ";\n";
-  s += "  NNHIP_DEV static void eval(double t, const double (&y)[dim], double (&dy)[dim], const Params& P_) {\n";
-  s += "    const double* p = P_.p; (void)p; (void)t;\n";
-  s += "    {\n" + e.body + "\n    }\n  }\n";
-  s += "  NNHIP_DEV static double comp(double t, int c, const double* ys, const Params& P_) {\n";
-  s += "    double y[dim], dy[dim];\n    for (int k = 0; k < dim; ++k) y[k] = ys[k];\n    eval(t, y, dy, P_);\n";
-  s += "    double r = dy[0];\n    for (int k = 1; k < dim; ++k) if (c == k) r = dy[k];\n    return r;\n  }\n};\n}\n";
+  if (!e.perComponent) {
+    s += "  NNHIP_DEV static void eval(double t, const double (&y)[dim], double (&dy)[dim], const Params& P_) {\n";
+    s += "    const double* p = P_.p; (void)p; (void)t;\n";
+    s += "    {\n" + e.body + "\n    }\n  }\n";
+    s += "  NNHIP_DEV static double comp(double t, int c, const double* ys, const Params& P_) {\n";
+    s += "    double y[dim], dy[dim];\n    for (int k = 0; k < dim; ++k) y[k] = ys[k];\n    eval(t, y, dy, P_);\n";
+    s += "    double r = dy[0];\n    for (int k = 1; k < dim; ++k) if (c == k) r = dy[k];\n    return r;\n  }\n};\n}\n";
+  } else {
+    s += "  NNHIP_DEV static double comp(double t, int c, const double* y, const Params& P_) {\n";
+    s += "    const double* p = P_.p; (void)p; (void)t; (void)c;\n";
+    s += "    {\n" + e.body + "\n    }\n  }\n";
+    s += "  NNHIP_DEV static void eval(double t, const double (&y)[dim], double (&dy)[dim], const Params& P_) {\n";
+    s += "#pragma unroll\n    for (int c = 0; c < dim; ++c) dy[c] = comp(t, c, &y[0], P_);\n  }\n};\n}\n";
+  }
   return s;
 }
+
+// Systems of 8 / 16 / 32 components given per component run on the lanes-per-system kernels (same components-per-lane
+// choice as the built-in RHS: ode_kernels.hpp NNHIP_FOR_EACH_LPS_RHS); everything else is thread-per-IVP.
+bool uses_lps(const UserRhsEntry& e) { return e.perComponent && (e.dim == 8 || e.dim == 16 || e.dim == 32); }
+int lps_cpl(const UserRhsEntry& e, bool adaptive) { return e.dim == 8 ? 2 : (adaptive ? 4 : 2); }
 
 bool compile(const UserRhsEntry& e, int integrator, Program& out) {
   const std::string src = make_source(e);
@@ -67,9 +82,20 @@ bool compile(const UserRhsEntry& e, int integrator, Program& out) {
   std::vector<std::string> names;
   if (integrator >= 0) {
     const std::string m = std::to_string(integrator);
-    names.push_back("nnhip::solve_tpi_kernel<" + m + ", nnhip::UserRhs>");
-    names.push_back("nnhip::step_tpi_kernel<" + m + ", nnhip::UserRhs, false>");
-    names.push_back("nnhip::step_tpi_kernel<" + m + ", nnhip::UserRhs, true>");
+    if (uses_lps(e)) {
+      int adaptive = 0;
+      nnhip_ode_integrator_traits(integrator, nullptr, nullptr, &adaptive);
+      const int cpl = lps_cpl(e, adaptive != 0);
+      names.push_back("nnhip::solve_lps_kernel<" + m + ", nnhip::UserRhs, " + std::to_string(cpl) + ", false>");
+      names.push_back("nnhip::step_lps_kernel<" + m + ", nnhip::UserRhs, false>");
+      names.push_back("nnhip::step_lps_kernel<" + m + ", nnhip::UserRhs, true>");
+      out.ivpsPerBlockSolve = kBlock / (e.dim / cpl);
+      out.ivpsPerBlockStep = kBlock / e.dim;
+    } else {
+      names.push_back("nnhip::solve_tpi_kernel<" + m + ", nnhip::UserRhs>");
+      names.push_back("nnhip::step_tpi_kernel<" + m + ", nnhip::UserRhs, false>");
+      names.push_back("nnhip::step_tpi_kernel<" + m + ", nnhip::UserRhs, true>");
+    }
   } else {
     names.push_back("nnhip::rhs_batch_kernel<nnhip::UserRhs>");
   }
@@ -130,12 +156,13 @@ Program* get_program(int rhs_kind, int integrator) {
 
 const char* rtc_last_error() { return g_rtc_err.c_str(); }
 
-int rtc_register(const char* name, int dim, int n_params, const char* body, bool check_compiles) {
+int rtc_register(const char* name, int dim, int n_params, const char* body, bool per_component, bool check_compiles) {
   UserRhsEntry e;
   e.name = name ? name : "user";
   e.body = body;
   e.dim = dim;
   e.n_params = n_params;
+  e.perComponent = per_component;
   e.alive = true;
   if (check_compiles) {  // syntax check now (device-independent), so errors surface at registration
     const std::string src = make_source(e) + "\n";
@@ -183,8 +210,8 @@ bool rtc_info(int rhs_kind, int* dim, int* n_params) {
   return true;
 }
 
-static hipError_t launch(hipFunction_t f, int64_t n, void* arg, hipStream_t s) {
-  const int64_t grid = (n + kBlock - 1) / kBlock;
+static hipError_t launch(hipFunction_t f, int64_t n, int perBlock, void* arg, hipStream_t s) {
+  const int64_t grid = (n + perBlock - 1) / perBlock;
   if (grid <= 0) return hipSuccess;
   void* params[] = {arg};
   return hipModuleLaunchKernel(f, (unsigned)grid, 1, 1, kBlock, 1, 1, 0, s, params, nullptr);
@@ -194,13 +221,13 @@ hipError_t rtc_launch_solve(int rhs_kind, int integrator, const SolveArgs& a, hi
   Program* p = get_program(rhs_kind, integrator);
   if (!p) return hipErrorInvalidValue;
   SolveArgs copy = a;
-  return launch(p->solve, a.N, &copy, s);
+  return launch(p->solve, a.N, p->ivpsPerBlockSolve, &copy, s);
 }
 hipError_t rtc_launch_step(int rhs_kind, int integrator, const StepArgs& a, int negate, hipStream_t s) {
   Program* p = get_program(rhs_kind, integrator);
   if (!p) return hipErrorInvalidValue;
   StepArgs copy = a;
-  return launch(negate ? p->stepNeg : p->stepPos, a.N, &copy, s);
+  return launch(negate ? p->stepNeg : p->stepPos, a.N, p->ivpsPerBlockStep, &copy, s);
 }
 hipError_t rtc_launch_rhs(int rhs_kind, int64_t N, int64_t is, int64_t cs, double t, const double* y, double* dy, const Params& P,
                           hipStream_t s) {

@@ -4,7 +4,7 @@
 
 namespace nnhip {
 const char* rtc_last_error();
-int rtc_register(const char* name, int dim, int n_params, const char* body, bool check_compiles);  // -> rhs_kind or -1
+int rtc_register(const char* name, int dim, int n_params, const char* body, bool per_component, bool check_compiles);  // -> rhs_kind or -1
 int rtc_release(int rhs_kind);
 bool rtc_info(int rhs_kind, int* dim, int* n_params);
 hipError_t rtc_launch_solve(int rhs_kind, int integrator, const SolveArgs& a, hipStream_t s);

@@ -118,12 +118,15 @@ class Rhs:
         return out
 
     @staticmethod
-    def custom(dim, body, keys=(), defaults=None, name="user"):
+    def custom(dim, body, keys=(), defaults=None, name="user", per_component=False):
         """A user right-hand side from HIP C++ source (compiled at run time with hiprtc; include/nnhip_ode.h,
         nnhip_ode_rhs_compile).  `body` sees t, y[dim], dy[dim] and p[len(keys)] — e.g. for a damped oscillator
-        Rhs.custom(2, "dy[0] = y[1]; dy[1] = -p[0]*y[0] - p[1]*y[1];", keys=("k", "c"))."""
+        Rhs.custom(2, "dy[0] = y[1]; dy[1] = -p[0]*y[0] - p[1]*y[1];", keys=("k", "c")).
+        per_component=True: `body` returns dy_c for the component index `c` (nnhip_ode_rhs_compile_comp); systems of
+        8 / 16 / 32 components then run on the lanes-per-system (LDS-staged) kernels."""
         kind = C.c_int(0)
-        _check(_lib.lib().nnhip_ode_rhs_compile(str(name).encode(), int(dim), len(keys), body.encode(), C.byref(kind)))
+        fn = _lib.lib().nnhip_ode_rhs_compile_comp if per_component else _lib.lib().nnhip_ode_rhs_compile
+        _check(fn(str(name).encode(), int(dim), len(keys), body.encode(), C.byref(kind)))
         r = Rhs(kind.value, keys, defaults)
         r.dim = int(dim)
         return r
