@@ -233,6 +233,13 @@ int nnhip_ode_rhs_batch_f64_dev(int rhs_kind, const double* rhs_params, int n_pa
   }
   NNHIP_FOR_EACH_TPI_RHS(X)
 #undef X
+#define X(kind, d, T, CA, CF)                                                            \
+  if (!found && rhs_kind == kind && dim == d) {                                          \
+    found = true;                                                                        \
+    e = nnhip::launch_rhs_batch<nnhip::T>(N, is, cs, t, y, dy, P, (hipStream_t)stream);  \
+  }
+  NNHIP_FOR_EACH_LPS_RHS(X)
+#undef X
   if (!found) return NNHIP_EUNSUPPORTED;
   return e == hipSuccess ? NNHIP_OK : NNHIP_EHIP;
 }
