@@ -454,11 +454,14 @@ NNHIP_DEV void fixed_step(const Ops& ops, double t, double dt, const double (&y)
 }
 
 // x^(1/N) for the step-size controller's pow(1/error, 1/order) (ode.nim:71,537), N = order in {2,3,5,6}.
-// ocml's general pow() costs 215 VALU instructions — a third of a whole DOPRI54 Lorenz step — so the root is
-// taken directly: an fp32 v_log_f32/v_exp_f32 estimate (rel. error ~1e-6) refined by two Newton steps in fp64
-// (quadratic: 1e-6 -> 1e-12 -> rounding level; measured <= 1 ulp from the correctly rounded root, the same
-// class as glibc's / ocml's pow).  52 instructions.  Outside [1e-30, 1e30] the value only has to land on the
-// right side of the controller's clamp min(4, max(0.125, 0.9*root)): 0 / 1e30 do; NaN propagates.
+// ocml's general pow() costs 215 VALU instructions — a third of a whole DOPRI54 Lorenz step — so the root is taken
+// directly: an fp32 v_log_f32/v_exp_f32 estimate (rel. error ~1e-6), one plain Newton step in fp64 (-> ~1e-11), then a
+// final Newton correction whose residual x - r^N is evaluated in double-double arithmetic (explicit FMAs give the exact
+// low parts of the products), so r + delta rounds to the correctly rounded root except in astronomically rare
+// half-way cases — of x^fl(1/N), the function the reference actually evaluates.  glibc's pow (what the reference calls)
+// is itself within 0.52 ulp, so the two agree bit for bit in all but a few percent of calls — which is what keeps accept/reject decisions and the loop's last-ulp end
+// condition (`t < tEnd`) aligned with the reference.  ~65 VALU instructions.  Outside [1e-30, 1e30] the value only
+// has to land on the right side of the controller's clamp min(4, max(0.125, 0.9*root)): 0 / 1e30 do; NaN propagates.
 template <int N>
 NNHIP_DEV double nth_root(double x) {
 #ifdef NNHIP_USE_OCML_POW
@@ -469,13 +472,29 @@ NNHIP_DEV double nth_root(double x) {
   if (x > 1e30) return 1e30;
   const float lf = __builtin_amdgcn_logf((float)x);  // log2
   double r = (double)__builtin_amdgcn_exp2f(lf * (1.0f / (float)N));
-#pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  {  // Newton step 1, plain fp64
     double rn = r;
 #pragma unroll
     for (int k = 1; k < N; ++k) rn = rn * r;
     const double d = x / rn - 1.0;
     r = r + r * (d * (1.0 / (double)N));
+  }
+  {  // Newton step 2 with a double-double residual: r^N = p + e to ~2^-100 relative
+    double p = r, e = 0.0, pm1 = 1.0;  // pm1 = r^(N-1) (plain precision is enough for the slope)
+#pragma unroll
+    for (int k = 1; k < N; ++k) {
+      pm1 = p;
+      const double np_ = p * r;
+      e = __builtin_fma(p, r, -np_) + e * r;
+      p = np_;
+    }
+    const double resid = (x - p) - e;              // x - r^N; (x - p) is exact (Sterbenz: p is within a few ulp of x)
+    // The reference raises to the DOUBLE 1/order, which is not 1/N: pow(x, fl(1/N)) = x^(1/N) * x^(fl(1/N) - 1/N)
+    // = root * (1 + dN*ln x), dN = fl(1/N) - 1/N (3: -1.85e-17, 5: +1.11e-17, 6: -9.25e-18, 2: 0) — a shift of up to
+    // 0.4 ulp that decides the rounding in a quarter of all calls.  ln x from the fp32 estimate is ample here.
+    constexpr double dN = N == 3 ? -1.850371707708594e-17 : N == 5 ? 1.1102230246251566e-17 : N == 6 ? -9.25185853854297e-18 : 0.0;
+    const double lnx = (double)lf * 0.6931471805599453;
+    r = r + (resid / ((double)N * pm1) + r * (dN * lnx));  // both corrections are far below 1 ulp of r: one final rounding
   }
   return r;
 #endif

@@ -280,11 +280,14 @@ def test_controller_factor_accuracy(nn, dev, order):
     got = out.cpu().numpy()
     with np.errstate(over="ignore", divide="ignore"):
         x = (1.0 / err).astype(np.longdouble)          # 1/error is an IEEE double division in the reference
-        root = np.exp(np.log(x) / np.longdouble(order))
-        ref = np.minimum(4.0, np.maximum(0.125, (np.longdouble(0.9) * root))).astype(np.float64)
+        root = np.exp(np.log(x) * np.longdouble(np.float64(1.0) / np.float64(order)))  # pow(x, fl(1/order)), as the reference calls it
+        root64 = root.astype(np.float64)                       # the correctly rounded pow(x, fl(1/order)) ...
+        ref = np.minimum(4.0, np.maximum(0.125, 0.9 * root64))   # ... then the reference's own double operations
         ref[np.isinf(err)] = 0.125                     # pow(0, p) = 0 -> max(0.125, 0)
     ulp = np.spacing(np.abs(ref))
-    assert np.all(np.abs(got - ref) <= 2 * ulp), float(np.max(np.abs(got - ref) / ulp))
+    assert np.all(np.abs(got - ref) <= 2 * ulp), float(np.max(np.abs(got - ref) / ulp))  # 1 ulp of the root = 2 ulp after `0.9 *` crosses a binade
+    # the device root is correctly rounded (double-double residual) except in rare near-half-way cases
+    assert (got != ref).mean() < 0.01
     clamped = (ref == 4.0) | (ref == 0.125)
     assert clamped.sum() > 1000 and np.array_equal(got[clamped], ref[clamped])
     # NaN error propagates as NaN (the reference's min/max let NaN through, ode.nim:71)
