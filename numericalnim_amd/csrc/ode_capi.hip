@@ -16,10 +16,10 @@
 #include "ode_rtc.hpp"
 
 namespace nnhip_fast {  // ode_tu_method.hip compiled with -ffp-contract=fast -DNNHIP_NS=nnhip_fast (Makefile)
-nnhip_abi::SolveLaunchFn find_solve_rk4(int rhs_kind, int dim, int wide_tpi);
-nnhip_abi::SolveLaunchFn find_solve_dopri54(int rhs_kind, int dim, int wide_tpi);
-nnhip_abi::SolveLaunchFn find_solve_tsit54(int rhs_kind, int dim, int wide_tpi);
-nnhip_abi::SolveLaunchFn find_solve_vern65(int rhs_kind, int dim, int wide_tpi);
+nnhip_abi::SolveLaunchFn find_solve_rk4(int rhs_kind, int dim, int dim16_variant);
+nnhip_abi::SolveLaunchFn find_solve_dopri54(int rhs_kind, int dim, int dim16_variant);
+nnhip_abi::SolveLaunchFn find_solve_tsit54(int rhs_kind, int dim, int dim16_variant);
+nnhip_abi::SolveLaunchFn find_solve_vern65(int rhs_kind, int dim, int dim16_variant);
 }  // namespace nnhip_fast
 
 namespace {
@@ -60,20 +60,20 @@ int g_host_chunks = 0;    // tuning knob "host_chunks": 0 = auto (= 1, see nnhip
 int g_host_register = 0;  // tuning knob "host_register": page-lock the caller's buffers for the duration of a host-pointer solve
 int g_fast_math = 0;     // tuning knob "fp_contract": 1 = FMA-contracted instantiations of the fused kernels (not bit-exact)
 int g_stream_graph = 0;  // tuning knob "stream_graph": 0 eager launches, 1 hipGraph capture + replay of the streaming loop
-int g_wide_tpi = 0;  // tuning: prefer the register-resident thread-per-IVP fused kernel for dim-16 systems
+int g_dim16_variant = 0;  // tuning knob "dim16_variant": A/B mappings of the fused 16-component kernels (see ode_kernels.hpp)
 
 nnhip::SolveLaunchFn find_solve(int integrator, int rhs_kind, int dim) {
   if (g_fast_math) {  // opt-in FMA-contracted build of the compute-bound fused kernels
     switch (integrator) {
-      case NNHIP_RK4: return nnhip_fast::find_solve_rk4(rhs_kind, dim, g_wide_tpi);
-      case NNHIP_DOPRI54: return nnhip_fast::find_solve_dopri54(rhs_kind, dim, g_wide_tpi);
-      case NNHIP_TSIT54: return nnhip_fast::find_solve_tsit54(rhs_kind, dim, g_wide_tpi);
-      case NNHIP_VERN65: return nnhip_fast::find_solve_vern65(rhs_kind, dim, g_wide_tpi);
+      case NNHIP_RK4: return nnhip_fast::find_solve_rk4(rhs_kind, dim, g_dim16_variant);
+      case NNHIP_DOPRI54: return nnhip_fast::find_solve_dopri54(rhs_kind, dim, g_dim16_variant);
+      case NNHIP_TSIT54: return nnhip_fast::find_solve_tsit54(rhs_kind, dim, g_dim16_variant);
+      case NNHIP_VERN65: return nnhip_fast::find_solve_vern65(rhs_kind, dim, g_dim16_variant);
     }
   }
   switch (integrator) {
 #define X(id, name) \
-  case id: return nnhip::find_solve_##name(rhs_kind, dim, g_wide_tpi);
+  case id: return nnhip::find_solve_##name(rhs_kind, dim, g_dim16_variant);
     NNHIP_FOR_EACH_METHOD(X)
 #undef X
   }
@@ -205,7 +205,7 @@ int nnhip_tune_set(const char* key, int value) {
   if (k == "host_register") { g_host_register = value != 0; return NNHIP_OK; }
   if (k == "fp_contract") { g_fast_math = value != 0; return NNHIP_OK; }
   if (k == "stream_graph") { g_stream_graph = value != 0; return NNHIP_OK; }
-  if (k == "wide_tpi") { g_wide_tpi = value; return NNHIP_OK; }
+  if (k == "dim16_variant") { if (value < 0 || value > 4) return fail(NNHIP_EVALUE, "dim16_variant must be 0..4"); g_dim16_variant = value; return NNHIP_OK; }
   if (k == "rk4_stream_auto") { g_tune_auto = value != 0; return NNHIP_OK; }
   if (k == "rk4_stream_vec" || k == "rk4_stream_mode") g_tune_auto = false;
   if (k == "rk4_stream_vec") { if (value != 1 && value != 2 && value != 4 && value != 8) return fail(NNHIP_EVALUE, "rk4_stream_vec must be 1, 2, 4 or 8"); g_tune.vec = value; return NNHIP_OK; }

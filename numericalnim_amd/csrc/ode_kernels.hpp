@@ -543,20 +543,22 @@ hipError_t launch_rk4_stream_vec(const double* yin, double* yout, int64_t n, dou
   X(NNHIP_RHS_NEG_Y, 16, RhsNegY<16>, 4, 2) X(NNHIP_RHS_LINEAR, 16, RhsLinear<16>, 4, 2) X(NNHIP_RHS_AFFINE_T, 16, RhsAffineT<16>, 4, 2)
 
 // dim-16 systems also have a register-resident thread-per-IVP fused kernel (all 512 VGPR+AGPR of a lane, one
-// wave per SIMD; tuning knob "wide_tpi" = 1) and the 1-component-per-lane form ("wide_tpi" = -1) for A/B runs.
+// wave per SIMD) and other mappings kept for A/B runs; tuning knob "dim16_variant": 0 default (components per lane
+// from the table above), 1 whole system in one lane, 2 lanes-per-system 16x1, 3 / 4 = 4x4 / 16x1 with the
+// wavefront-shuffle error norm (adaptive methods only).
 #define NNHIP_FOR_EACH_WIDE_TPI_RHS(X) X(NNHIP_RHS_RING, 16, RhsRing<16>)
 
 template <int METHOD>
-SolveLaunchFn find_solve_tpi(int rhs_kind, int dim, int wide_tpi) {
+SolveLaunchFn find_solve_tpi(int rhs_kind, int dim, int dim16_variant) {
 #define X(kind, d, T) \
   if (rhs_kind == kind && dim == d) return &launch_solve_tpi<METHOD, T>;
   NNHIP_FOR_EACH_TPI_RHS(X)
-  if (wide_tpi == 1) { NNHIP_FOR_EACH_WIDE_TPI_RHS(X) }
+  if (dim16_variant == 1) { NNHIP_FOR_EACH_WIDE_TPI_RHS(X) }
 #undef X
-  if (wide_tpi == -1 && rhs_kind == NNHIP_RHS_RING && dim == 16) return &launch_solve_lps<METHOD, RhsRing<16>, 1>;
+  if (dim16_variant == 2 && rhs_kind == NNHIP_RHS_RING && dim == 16) return &launch_solve_lps<METHOD, RhsRing<16>, 1>;
   if constexpr (MethodTraits<METHOD>::adaptive) {  // A/B: wavefront-shuffle error norm instead of the ordered LDS sum
-    if (wide_tpi == -2 && rhs_kind == NNHIP_RHS_RING && dim == 16) return &launch_solve_lps<METHOD, RhsRing<16>, 4, true>;
-    if (wide_tpi == -3 && rhs_kind == NNHIP_RHS_RING && dim == 16) return &launch_solve_lps<METHOD, RhsRing<16>, 1, true>;
+    if (dim16_variant == 3 && rhs_kind == NNHIP_RHS_RING && dim == 16) return &launch_solve_lps<METHOD, RhsRing<16>, 4, true>;
+    if (dim16_variant == 4 && rhs_kind == NNHIP_RHS_RING && dim == 16) return &launch_solve_lps<METHOD, RhsRing<16>, 1, true>;
   }
 #define X(kind, d, T, CA, CF) \
   if (rhs_kind == kind && dim == d) return &launch_solve_lps<METHOD, T, (MethodTraits<METHOD>::adaptive ? CA : CF)>;
@@ -592,7 +594,7 @@ StepLaunchFn find_advance_tpi(int rhs_kind, int dim) {
   X(NNHIP_RK21, rk21) X(NNHIP_HEUN2, heun2) X(NNHIP_RALSTON2, ralston2) X(NNHIP_KUTTA3, kutta3) X(NNHIP_HEUN3, heun3)    \
   X(NNHIP_RALSTON3, ralston3) X(NNHIP_SSPRK3, ssprk3) X(NNHIP_RALSTON4, ralston4) X(NNHIP_KUTTA4, kutta4)
 #define X(id, name)                                                      \
-  SolveLaunchFn find_solve_##name(int rhs_kind, int dim, int wide_tpi);  \
+  SolveLaunchFn find_solve_##name(int rhs_kind, int dim, int dim16_variant);  \
   StepLaunchFn find_step_##name(int rhs_kind, int dim);                  \
   StepLaunchFn find_advance_##name(int rhs_kind, int dim);
 NNHIP_FOR_EACH_METHOD(X)

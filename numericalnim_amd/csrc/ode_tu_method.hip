@@ -6,8 +6,8 @@
 #define NNHIP_CAT(a, b) NNHIP_CAT2(a, b)
 
 namespace NNHIP_NS {
-SolveLaunchFn NNHIP_CAT(find_solve_, NNHIP_TU_NAME)(int rhs_kind, int dim, int wide_tpi) {
-  return find_solve_tpi<NNHIP_TU_METHOD>(rhs_kind, dim, wide_tpi);
+SolveLaunchFn NNHIP_CAT(find_solve_, NNHIP_TU_NAME)(int rhs_kind, int dim, int dim16_variant) {
+  return find_solve_tpi<NNHIP_TU_METHOD>(rhs_kind, dim, dim16_variant);
 }
 StepLaunchFn NNHIP_CAT(find_step_, NNHIP_TU_NAME)(int rhs_kind, int dim) { return find_step_tpi<NNHIP_TU_METHOD>(rhs_kind, dim); }
 StepLaunchFn NNHIP_CAT(find_advance_, NNHIP_TU_NAME)(int rhs_kind, int dim) {

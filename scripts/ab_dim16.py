@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B: dim-16 fused solve, lanes-per-system (LDS) vs register-resident thread-per-IVP ("wide_tpi"), both layouts."""
+"""A/B: dim-16 fused solve, lanes-per-system (LDS) vs register-resident thread-per-IVP ("dim16_variant"), both layouts."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,9 +17,9 @@ outs = {}
 for integ in ("tsit54", "dopri54", "rk4", "vern65"):
     for oname, kw in (("default", dict(dt=1e-2)), ("tight", dict(dt=1e-2, **tight))):
         opt = nn.newODEoptions(**kw)
-        for wide in (-1, 0, 1):
+        for wide in (2, 0, 1):
             for lname, lay, y0 in (("aos", 1, yaos), ("soa", 0, ysoa)):
-                L.nnhip_tune_set(b"wide_tpi", wide)
+                L.nnhip_tune_set(b"dim16_variant", wide)
                 ts = []
                 for r in range(4):
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -27,7 +27,7 @@ for integ in ("tsit54", "dopri54", "rk4", "vern65"):
                     t, y = nn.solveODE(nn.Rhs.ring(0.1), y0, [0.0, 1.0], opt, integrator=integ, layout=lay)
                     e1.record(); torch.cuda.synchronize()
                     ts.append(e0.elapsed_time(e1))
-                key = f"{integ}_{oname}_{ {-1: 'lps1', 0: 'default', 1: 'tpi16'}[wide]}_{lname}"
+                key = f"{integ}_{oname}_{ {2: 'lps1', 0: 'default', 1: 'tpi16'}[wide]}_{lname}"
                 res[key] = sorted(ts[1:])[1]
                 yy = y[-1] if lay == 1 else y[-1].t()
                 outs.setdefault((integ, oname), []).append(yy.contiguous())

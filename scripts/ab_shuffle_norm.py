@@ -15,8 +15,8 @@ res = {}
 for integ in ("tsit54", "dopri54"):
     for oname, kw in (("default", {}), ("tight", tight)):
         outs = {}
-        for name, knob in (("lds_ordered_4x4", 0), ("shuffle_4x4", -2), ("lds_ordered_16x1", -1), ("shuffle_16x1", -3)):
-            L.nnhip_tune_set(b"wide_tpi", knob)
+        for name, knob in (("lds_ordered_4x4", 0), ("shuffle_4x4", 3), ("lds_ordered_16x1", 2), ("shuffle_16x1", 4)):
+            L.nnhip_tune_set(b"dim16_variant", knob)
             ts = []
             for r in range(4):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -25,5 +25,5 @@ for integ in ("tsit54", "dopri54"):
             outs[name] = y[-1].clone()
             res[f"{integ}_{oname}_{name}_ms"] = sorted(ts[1:])[1]
         res[f"{integ}_{oname}_shuffle_max_abs_diff_vs_ordered"] = float((outs["shuffle_4x4"] - outs["lds_ordered_4x4"]).abs().max())
-L.nnhip_tune_set(b"wide_tpi", 0)
+L.nnhip_tune_set(b"dim16_variant", 0)
 print(json.dumps(res, indent=1))
