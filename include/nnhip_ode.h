@@ -217,6 +217,10 @@ int nnhip_hermite_spline_eval_batch_f64_dev(const double* X, int n_knots, const 
  * tensor's columns).  X [n] host, strictly ascending; Y, out [n][M] device; out[0] = Y[0]-Y[0].  trapz(Y, X) (:104-117) is the
  * last row for finite data. */
 int nnhip_cumtrapz_batch_f64_dev(const double* X, int n, const double* Y, int64_t M, double* out, void* stream);
+/* cumsimpson(Y, X) for discrete points (integrate.nim:329-375: composite Simpson with non-uniform weights on interval pairs,
+ * three-point closure for an odd number of intervals, then hermiteInterpolate (utils.nim:282-312) with dy = Y); same layout as
+ * cumtrapz; n >= 3 (else NNHIP_EVALUE, as the reference raises ValueError).  Synchronises `stream` before returning. */
+int nnhip_cumsimpson_batch_f64_dev(const double* X, int n, const double* Y, int64_t M, double* out, void* stream);
 /* The adaptive controller's step-size factor min(4, max(0.125, 0.9 * pow(1/error, 1/order))) (ode.nim:71, 537) over an
  * array of error norms; order in {2, 3, 5, 6} (rk21, bs32, dopri54/tsit54, vern65). */
 int nnhip_ode_controller_factor_f64_dev(int order, const double* error, double* out, int64_t n, void* stream);

@@ -10,7 +10,7 @@ from .ode import (  # noqa: F401
     ODEoptions, newODEoptions, NumContext, newNumContext, Rhs, solveODE, integratorStep, fixedStream, adaptiveStream,
     fixedODE, adaptiveODE, allODE, implementedODE, LAYOUT_SOA, LAYOUT_AOS, NnhipError,
 )
-from .interpolate import newHermiteSpline, HermiteSpline, rhsBatch, cumtrapz, trapz  # noqa: F401
+from .interpolate import newHermiteSpline, HermiteSpline, rhsBatch, cumtrapz, cumsimpson, trapz  # noqa: F401
 from . import _lib  # noqa: F401
 
 

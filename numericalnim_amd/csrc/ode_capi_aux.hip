@@ -100,6 +100,44 @@ __global__ __launch_bounds__(kBlock) void cumtrapz_kernel(const TrapzWeights W, 
   }
 }
 
+// cumsimpson(Y, X) over M series (integrate.nim:329-375): composite Simpson on interval pairs + hermiteInterpolate
+// (utils.nim:282-312) with dy = Y.  Per-point weights depend only on X: computed on the host in reference order.
+struct SimpsonPoint {
+  double w[4];  // hermiteSpline weights of this output point inside its pair interval (utils.nim:273-279)
+};
+struct SimpsonPair {
+  double alpha, beta, eta;  // integral += alpha*y2 + beta*y1 + eta*y0  (:355-359; tail pair :366-370)
+};
+__global__ __launch_bounds__(kBlock) void cumsimpson_kernel(const SimpsonPair* __restrict__ pairs, int nPairs, int evenN,
+                                                            const SimpsonPoint* __restrict__ pts, const double* __restrict__ Y,
+                                                            double* __restrict__ out, int64_t M, int n) {
+  const int64_t m = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (m >= M) return;
+  auto herm = [](const SimpsonPoint& p, double y1, double y2, double dy1, double dy2) {
+    return p.w[0] * y1 + p.w[1] * dy1 + p.w[2] * y2 + p.w[3] * dy2;  // h00*y1 + h10*(x2-x1)*dy1 + h01*y2 + h11*(x2-x1)*dy2
+  };
+  double y0 = Y[m];
+  double integral = y0 - y0;  // the right kind of zero (:350)
+  for (int i = 0; i < nPairs; ++i) {
+    const double y1 = Y[(int64_t)(2 * i + 1) * M + m], y2 = Y[(int64_t)(2 * i + 2) * M + m];
+    const SimpsonPair w = pairs[i];
+    const double next = integral + (w.alpha * y2 + w.beta * y1 + w.eta * y0);
+    out[(int64_t)(2 * i) * M + m] = herm(pts[2 * i], integral, next, y0, y2);
+    out[(int64_t)(2 * i + 1) * M + m] = herm(pts[2 * i + 1], integral, next, y0, y2);
+    integral = next;
+    y0 = y2;
+  }
+  if (evenN) {  // odd number of intervals: the last one is closed with the three-point rule of :363-373
+    const int l = n - 1;
+    const double ym2 = Y[(int64_t)(l - 2) * M + m], ym1 = y0, yl = Y[(int64_t)l * M + m];
+    const SimpsonPair w = pairs[nPairs];
+    const double next = integral + (w.eta * ym2 + w.beta * ym1 + w.alpha * yl);
+    out[(int64_t)(l - 1) * M + m] = herm(pts[l - 1], integral, next, ym1, yl);
+    integral = next;
+  }
+  out[(int64_t)(n - 1) * M + m] = integral;  // `if x[x.high] == t[t.high]: result.add(y[y.high])` (utils.nim:300-301)
+}
+
 // the controller's step-size factor (ode.nim:71,537) over an array of error norms
 template <int ORDER>
 __global__ __launch_bounds__(kBlock) void controller_factor_kernel(const double* __restrict__ error, double* __restrict__ out, int64_t n) {
@@ -195,6 +233,65 @@ int nnhip_cumtrapz_batch_f64_dev(const double* X, int n, const double* Y, int64_
     first += nw;
   } while (first < n - 1);
   return NNHIP_OK;
+}
+
+static nnhip::SimpsonPoint simpson_point(double x, double x1, double x2) {  // hermiteSpline weights, utils.nim:273-279
+  const double t = (x - x1) / (x2 - x1);
+  const double omt = 1.0 - t;
+  nnhip::SimpsonPoint p;
+  p.w[0] = (1.0 + 2.0 * t) * (omt * omt);
+  p.w[1] = (t * (omt * omt)) * (x2 - x1);
+  p.w[2] = (t * t) * (3.0 - 2.0 * t);
+  p.w[3] = ((t * t * t) - (t * t)) * (x2 - x1);
+  return p;
+}
+
+int nnhip_cumsimpson_batch_f64_dev(const double* X, int n, const double* Y, int64_t M, double* out, void* stream) {
+  if (M < 0 || !X) return NNHIP_EVALUE;
+  if (n < 3) return NNHIP_EVALUE;  // ValueError "at least 3 elements" (integrate.nim:345-346)
+  for (int i = 1; i < n; ++i) if (!(X[i - 1] < X[i])) return NNHIP_EVALUE;
+  if (M == 0) return NNHIP_OK;
+  if (!Y || !out) return NNHIP_EVALUE;
+  const bool evenN = (n % 2) == 0;
+  const int N = evenN ? n - 1 : n;
+  const int nPairs = (N - 1) / 2;
+  auto cube = [](double v) { return v * v * v; };
+  auto sq = [](double v) { return v * v; };
+  std::vector<nnhip::SimpsonPair> pairs((size_t)nPairs + 1);
+  std::vector<nnhip::SimpsonPoint> pts((size_t)n);
+  for (int i = 0; i < nPairs; ++i) {  // integrate.nim:354-358
+    const double h1 = X[2 * i + 1] - X[2 * i], h2 = X[2 * i + 2] - X[2 * i + 1];
+    pairs[i].alpha = (2.0 * cube(h2) - cube(h1) + 3.0 * h1 * sq(h2)) / (6.0 * h2 * (h2 + h1));
+    pairs[i].beta = (cube(h2) + cube(h1) + 3.0 * h1 * h2 * (h2 + h1)) / (6.0 * h2 * h1);
+    pairs[i].eta = (2.0 * cube(h1) - cube(h2) + 3.0 * h2 * sq(h1)) / (6.0 * h1 * (h2 + h1));
+    pts[2 * i] = simpson_point(X[2 * i], X[2 * i], X[2 * i + 2]);
+    pts[2 * i + 1] = simpson_point(X[2 * i + 1], X[2 * i], X[2 * i + 2]);
+  }
+  if (evenN) {  // :363-370
+    const int l = n - 1;
+    const double h1 = X[l - 1] - X[l - 2], h2 = X[l] - X[l - 1];
+    pairs[nPairs].alpha = (2.0 * sq(h2) + 3.0 * h1 * h2) / (6.0 * (h1 + h2));
+    pairs[nPairs].beta = (sq(h2) + 3.0 * h1 * h2) / (6.0 * h1);
+    pairs[nPairs].eta = -(cube(h2)) / (6.0 * h1 * (h1 + h2));
+    pts[l - 1] = simpson_point(X[l - 1], X[l - 1], X[l]);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  nnhip::SimpsonPair* dPairs = nullptr;
+  nnhip::SimpsonPoint* dPts = nullptr;
+  if (hipMalloc((void**)&dPairs, pairs.size() * sizeof(pairs[0])) != hipSuccess) return NNHIP_ENOMEM;
+  if (hipMalloc((void**)&dPts, pts.size() * sizeof(pts[0])) != hipSuccess) { (void)hipFree(dPairs); return NNHIP_ENOMEM; }
+  int rc = NNHIP_OK;
+  if (hipMemcpyAsync(dPairs, pairs.data(), pairs.size() * sizeof(pairs[0]), hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(dPts, pts.data(), pts.size() * sizeof(pts[0]), hipMemcpyHostToDevice, s) != hipSuccess)
+    rc = NNHIP_EHIP;
+  const dim3 grid((unsigned)((M + nnhip::kBlock - 1) / nnhip::kBlock)), block(nnhip::kBlock);
+  if (!rc && nnhip::launch_kernel(nnhip::cumsimpson_kernel, grid, block, s, (const nnhip::SimpsonPair*)dPairs, nPairs, evenN ? 1 : 0,
+                                  (const nnhip::SimpsonPoint*)dPts, Y, out, M, n) != hipSuccess)
+    rc = NNHIP_EHIP;
+  (void)hipStreamSynchronize(s);  // the weight tables are freed below
+  (void)hipFree(dPairs);
+  (void)hipFree(dPts);
+  return rc;
 }
 
 int nnhip_ode_controller_factor_f64_dev(int order, const double* error, double* out, int64_t n, void* stream) {

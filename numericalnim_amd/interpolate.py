@@ -74,6 +74,22 @@ def cumtrapz(Y, X):
     return out
 
 
+def cumsimpson(Y, X):
+    """cumsimpson(Y, X) for discrete points (integrate.nim:329-375), batched like cumtrapz; needs len(X) >= 3."""
+    import torch
+    Xa = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
+    if len(Xa) != Y.shape[0]:
+        raise ValueError("X and Y must have the same length")
+    if len(Xa) < 3:
+        raise ValueError("X and Y must have at least 3 elements to perform Simpson, use cumtrapz instead")  # integrate.nim:345-346
+    Yc = Y.contiguous()
+    out = torch.empty_like(Yc)
+    with torch.cuda.device(Yc.device):
+        _check(_lib.lib().nnhip_cumsimpson_batch_f64_dev(Xa.ctypes.data_as(C.POINTER(C.c_double)), len(Xa), Yc.data_ptr(), int(Yc[0].numel()),
+                                                         out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    return out
+
+
 def trapz(Y, X):
     """trapz(Y, X) (integrate.nim:104-117): the last cumulative value."""
     return cumtrapz(Y, X)[-1]

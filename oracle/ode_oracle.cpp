@@ -805,6 +805,52 @@ int oracle_cumtrapz(const double* X, int n, const double* Y, double* out) {
   return 0;
 }
 
+// cumsimpson(Y, X) for discrete points (src/numericalnim/integrate.nim:329-375) on one scalar series: composite Simpson on
+// pairs of intervals (non-uniform weights :354-359, odd-tail correction :364-373) gives the integral at every second
+// point; hermiteInterpolate (utils.nim:282-312, sorted branch) with dy = Y fills in all points of X.
+// X sorted and duplicate-free; n >= 3 (else ValueError -> -1).
+int oracle_cumsimpson(const double* X, int n, const double* Y, double* out) {
+  if (n < 3) return -1;  // :345-346
+  int N = n;
+  bool evenN = false;
+  if (N % 2 == 0) { evenN = true; N -= 1; }  // :347-349
+  std::vector<double> xs, y, dy;
+  double integral = Y[0] - Y[0];  // :350
+  y.push_back(integral); dy.push_back(Y[0]); xs.push_back(X[0]);
+  for (int i = 0; i < (N - 1) / 2; ++i) {  // :354
+    const double h1 = X[2 * i + 1] - X[2 * i];
+    const double h2 = X[2 * i + 2] - X[2 * i + 1];
+    const double alpha = (2.0 * oracle::cube(h2) - oracle::cube(h1) + 3.0 * h1 * oracle::sq(h2)) / (6.0 * h2 * (h2 + h1));
+    const double beta = (oracle::cube(h2) + oracle::cube(h1) + 3.0 * h1 * h2 * (h2 + h1)) / (6.0 * h2 * h1);
+    const double eta = (2.0 * oracle::cube(h1) - oracle::cube(h2) + 3.0 * h2 * oracle::sq(h1)) / (6.0 * h1 * (h2 + h1));
+    integral += alpha * Y[2 * i + 2] + beta * Y[2 * i + 1] + eta * Y[2 * i];  // :359
+    y.push_back(integral); dy.push_back(Y[2 * i + 2]); xs.push_back(X[2 * i + 2]);
+  }
+  if (evenN) {  // :363-373
+    const int last = n - 1;
+    const double h1 = X[last - 1] - X[last - 2];
+    const double h2 = X[last] - X[last - 1];
+    const double alpha = (2.0 * oracle::sq(h2) + 3.0 * h1 * h2) / (6.0 * (h1 + h2));
+    const double beta = (oracle::sq(h2) + 3.0 * h1 * h2) / (6.0 * h1);
+    const double eta = -(oracle::cube(h2)) / (6.0 * h1 * (h1 + h2));
+    integral += eta * Y[last - 2] + beta * Y[last - 1] + alpha * Y[last];
+    y.push_back(integral); dy.push_back(Y[last]); xs.push_back(X[last]);
+  }
+  // hermiteInterpolate(X, xs, y, dy), X sorted (utils.nim:290-301)
+  int k = 0, xIndex = 0;
+  const int th = (int)xs.size() - 1;
+  bool done = false;
+  for (int i = 0; i <= th - 1 && !done; ++i) {
+    while (xs[i] <= X[xIndex] && X[xIndex] < xs[i + 1]) {
+      out[k++] = oracle::hermiteSpline<double>(X[xIndex], xs[i], xs[i + 1], y[i], y[i + 1], dy[i], dy[i + 1]);
+      xIndex += 1;
+      if (n - 1 < xIndex) { done = true; break; }
+    }
+  }
+  if (X[n - 1] == xs[th]) out[k++] = y[th];
+  return k;
+}
+
 // Vector operator probes (tests/test_vector.nim semantics). op: 0 '+', 1 '-', 2 scalar*V, 3 abs, 4 *. 5 /. 6 d +. V
 int oracle_vector_op(int op, const double* a, int na, const double* b, int nb, double d, double* out) {
   using namespace oracle;

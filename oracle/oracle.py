@@ -61,6 +61,7 @@ def lib():
         _lib.oracle_linspace.argtypes = [C.c_double, C.c_double, C.c_int, dp]
         _lib.oracle_hermite_interp.argtypes = [dp, C.c_int, dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_double, dp]
         _lib.oracle_cumtrapz.argtypes = [dp, C.c_int, dp, dp]
+        _lib.oracle_cumsimpson.argtypes = [dp, C.c_int, dp, dp]
         _lib.oracle_vector_op.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int, C.c_double, dp]
     return _lib
 
@@ -189,6 +190,16 @@ def cumtrapz(Y, X):
     out = np.empty(len(X), dtype=np.float64)
     lib().oracle_cumtrapz(_dp(X), len(X), _dp(Y), _dp(out))
     return out
+
+
+def cumsimpson(Y, X):
+    """cumsimpson(Y, X) (integrate.nim:329-375) for one scalar series with sorted, unique X (len >= 3)."""
+    X, Y = (np.ascontiguousarray(np.asarray(a, dtype=np.float64)) for a in (X, Y))
+    out = np.empty(len(X), dtype=np.float64)
+    k = lib().oracle_cumsimpson(_dp(X), len(X), _dp(Y), _dp(out))
+    if k < 0:
+        raise ValueError("X and Y must have at least 3 elements to perform Simpson, use cumtrapz instead")
+    return out[:k].copy()
 
 
 def vector_op(op, a, b=None, d=0.0):

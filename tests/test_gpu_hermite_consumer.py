@@ -56,3 +56,26 @@ def test_cumtrapz_on_trajectories(nn, oracle, dev):
     assert np.abs(c[-1] - exact).max() < 1e-4
     with pytest.raises(ValueError):
         nn.cumtrapz(y, t[::-1].copy())
+
+
+@pytest.mark.parametrize("n_t", [3, 4, 5, 10, 11, 200, 201])
+def test_cumsimpson_on_trajectories(nn, oracle, dev, n_t):
+    """cumsimpson(Y, X) (integrate.nim:329-375) over a trajectory tensor, odd and even point counts, non-uniform grid,
+    bit-exact vs the oracle."""
+    import torch
+    O = oracle
+    n = 90
+    rng = np.random.default_rng(n_t)
+    y0 = rng.uniform(0.5, 2.0, n)
+    ts = np.sort(np.unique(np.round(rng.uniform(0.0, 2.0, 3 * n_t), 5)))[:n_t]
+    ts[0] = 0.0
+    assert len(ts) == n_t
+    t, y = nn.solveODE(nn.Rhs.linear(-0.8), torch.from_numpy(y0).to(dev), ts, nn.newODEoptions(dt=1e-3), integrator="rk4")
+    c = nn.cumsimpson(y, t).cpu().numpy()
+    yh = y.cpu().numpy()
+    for m in range(0, n, 7):
+        assert np.array_equal(c[:, m], O.cumsimpson(yh[:, m], t)), (n_t, m)
+    if n_t >= 200:
+        assert np.abs(c[-1] - y0 * (1 - np.exp(-0.8 * t[-1])) / 0.8).max() < 1e-6
+    with pytest.raises(ValueError):
+        nn.cumsimpson(y[:2], t[:2])
