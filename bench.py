@@ -75,9 +75,15 @@ def main():
     # Two buffer sets: with the all-gather of solve k overlapped with solve k+1 (second HIP stream), solve k+1 must not
     # overwrite the states that are still being gathered.
     overlap = use_dist and not args.no_gather and not args.no_overlap
-    nset = 2 if overlap else 1
+    # Overlapped gather + ping-pong: three state buffers rotate (solve k uses B[k%3] and B[(k+1)%3]; its result lands back in
+    # B[k%3] after an even number of steps, so solve k+1 can start in B[(k+1)%3] / B[(k+2)%3] while B[k%3] is being gathered).
+    rotate3 = overlap and bool(args.pingpong) and nsteps % 2 == 0
+    nset = 3 if rotate3 else (2 if overlap else 1)
     ys = [torch.empty_like(y0) for _ in range(nset)]
-    scratches = [torch.empty_like(y0) if args.pingpong else None for _ in range(nset)]
+    if rotate3:
+        scratches = [ys[(s + 1) % 3] for s in range(3)]
+    else:
+        scratches = [torch.empty_like(y0) if args.pingpong else None for _ in range(nset)]
     gathered = torch.empty(n * world, dtype=torch.float64, device=dev) if (use_dist and not args.no_gather) else None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     comm_stream = torch.cuda.Stream() if overlap else None
@@ -87,9 +93,10 @@ def main():
     def one_solve(k=None):
         s = state["i"] % nset
         state["i"] += 1
-        if pending[s] is not None:  # the gather issued two solves ago must have consumed this buffer set
-            pending[s].wait()
-            pending[s] = None
+        for q in ((s, (s + 1) % 3) if rotate3 else (s,)):  # buffers about to be overwritten must have been gathered
+            if pending[q] is not None:
+                pending[q].wait()
+                pending[q] = None
         y = ys[s]
         y.copy_(y0)  # solveODE starts from y0 (y0.clone(), ode.nim:482)
         if k is not None:
