@@ -11,6 +11,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -41,7 +42,7 @@ struct UserRhsEntry {
 };
 
 std::mutex g_mu;
-std::vector<UserRhsEntry> g_user;
+std::deque<UserRhsEntry> g_user;  // deque: registering a new RHS never moves existing entries (programs are handed out by pointer)
 thread_local std::string g_rtc_err;
 
 std::string make_source(const UserRhsEntry& e) {
