@@ -199,6 +199,15 @@ int nnhip_ode_rhs_compile(const char* name, int dim, int n_params, const char* b
 int nnhip_ode_rhs_compile_comp(const char* name, int dim, int n_params, const char* comp_body, int* rhs_kind_out);
 int nnhip_ode_rhs_release(int rhs_kind);
 
+/* Device-resident reassembly (BASELINE.json config C5): one process, n_gpus devices, RCCL over xGMI.  shard[r] lives on
+ * device r and holds that device's contiguous IVP range (counts[r] IVPs) of a state tensor in `layout`; full[r] on device r
+ * receives the whole tensor ([dim][N] / [N][dim], N = sum counts).  Equal shards use one ncclAllGather per component
+ * plane (SoA) or one in total (AoS); ragged shards one ncclBroadcast per shard.  Enqueued on streams[r] (nullable).
+ * RCCL is loaded lazily (dlopen); failure text: nnhip_multigpu_last_error(). */
+int nnhip_allgather_states_f64_dev(int n_gpus, const double* const* shard, const int64_t* counts, int dim, int layout,
+                                   double* const* full, void* const* streams);
+const char* nnhip_multigpu_last_error(void);
+
 /* ---- consumers either side of the path ------------------------------------------------------- */
 /* hermiteSpline (utils.nim:273-279), batched on device: out[i] = H(x; x1, x2, y1[i], y2[i], dy1[i], dy2[i]) */
 int nnhip_hermite_spline_f64_dev(double x, double x1, double x2, const double* y1, const double* y2, const double* dy1,

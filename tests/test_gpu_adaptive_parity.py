@@ -395,3 +395,26 @@ def test_adaptive_stream_driver_equals_fused(nn, oracle, dev, integrator):
     ref = O.solve_ode_batch(O.RHS_LORENZ, LOR, y0, n, 3, [0.0, 1.5], O.new_options(**kw), integrator, n_threads=8)
     assert np.abs(ys.cpu().numpy() - ref["y"][-1]).max() <= TOL_ADAPTIVE
     assert int(ref["steps"].max()) <= launches < int(ref["steps"].max()) + 5   # one loop iteration per launch, polled every 5
+
+
+@pytest.mark.parametrize("layout,dim", [(0, 1), (0, 3), (1, 3)])
+def test_rccl_allgather_states_single_device(nn, dev, layout, dim):
+    """nnhip_allgather_states_f64_dev (one process, G devices, RCCL): with the one device of this box the gather must
+    reproduce the shard as the full tensor (plane-by-plane for SoA)."""
+    import ctypes as C
+    import torch
+    L = nn._lib.lib()
+    n = 12345
+    shard = torch.randn((dim, n) if layout == 0 else (n, dim), dtype=torch.float64, device=dev)
+    if dim == 1 and layout == 0:
+        shard = shard.reshape(n)
+    full = torch.zeros_like(shard)
+    sp = (C.c_void_p * 1)(shard.data_ptr())
+    fp = (C.c_void_p * 1)(full.data_ptr())
+    cnt = (C.c_int64 * 1)(n)
+    torch.cuda.synchronize()
+    rc = L.nnhip_allgather_states_f64_dev(1, sp, cnt, dim, layout, fp, None)
+    assert rc == 0, L.nnhip_multigpu_last_error().decode()
+    torch.cuda.synchronize()
+    assert torch.equal(full, shard)
+    assert L.nnhip_allgather_states_f64_dev(5, sp, cnt, dim, layout, fp, None) != 0  # more devices than the box has
