@@ -3,7 +3,7 @@
 buffer) through the fused and the step-streaming RK4 paths; verifies 64-bit indexing end to end against the oracle on
 samples from the head, the 2^31 boundary and the tail."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import numericalnim_amd as nn

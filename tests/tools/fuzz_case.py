@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Inspect individual seeds of the randomised parity sweep."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import numericalnim_amd as nn

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off soak: the randomised parity sweep of tests/test_gpu_fuzz_parity.py over many more seeds (not part of the suite)."""
 import os, sys, traceback
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import numericalnim_amd as nn
