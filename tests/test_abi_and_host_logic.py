@@ -41,8 +41,13 @@ def test_no_oracle_or_cpu_fallback_in_product():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.lower() or f in (), f"{f} mentions the oracle"
-    for f in glob.glob(os.path.join(ROOT, "include", "*.h")):
+    for f in glob.glob(os.path.join(ROOT, "include", "*.h*")) + glob.glob(os.path.join(ROOT, "nim", "*.nim")):
         assert "oracle" not in open(f).read().lower()
+    # dev tooling and examples outside tests/ must not use it either; bench.py only in its cpu_baseline leg
+    for f in glob.glob(os.path.join(ROOT, "scripts", "*")) + glob.glob(os.path.join(ROOT, "examples", "*")):
+        assert "import oracle" not in open(f).read() and "from oracle" not in open(f).read(), f
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert bench.count("from oracle import") == 1 and bench.index("from oracle import") > bench.index("CPU baseline: the oracle")
 
 
 def test_new_options_semantics(nn):
