@@ -140,3 +140,16 @@ def test_non_finite_times_are_refused(nn):
             nn.solveODE(nn.Rhs.neg_y(), np.ones(3), ts, nn.newODEoptions(dt=0.1), integrator="rk4")
     with pytest.raises(ValueError, match="not finite"):
         nn.solveODE(nn.Rhs.neg_y(), np.ones(3), [0.0, 1.0], nn.newODEoptions(dt=0.1, tStart=float("inf")), integrator="rk4")
+
+
+def test_header_is_plain_c_and_host_entries_work_from_c(nn, tmp_path):
+    """include/nnhip_ode.h compiles as C99 (-pedantic) and the host-only entries behave from a C caller."""
+    import subprocess
+    from numericalnim_amd import _lib
+    exe = str(tmp_path / "abi_is_c")
+    libdir = os.path.dirname(_lib.SO_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "abi_is_c.c"), "-L", libdir, "-lnnhip_ode", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "abi 1 ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
