@@ -355,6 +355,33 @@ static int prepare_solve(const nnhip_ode_options* opt, int integrator, int rhs_k
   a.maxSteps = max_steps;
   a.ctl = ctl_of(opt);
   a.P = P;
+  a.uniformFull[0] = a.uniformFull[1] = -1;
+  a.nTail[0] = a.nTail[1] = 0;
+  if (!adaptive && !a.useDense) {
+    // Replay ODESolver's fixed-step time loop on the host (same IEEE double operations, ode.nim:511,525,532): it does not
+    // depend on the state, so the device loop needs no `tEnd - t` / compare / select per step.
+    const double tS[2] = {opt->tStart, -opt->tStart}, tE[2] = {g.tEndPos, g.tEndNeg};
+    const bool have[2] = {a.nPos > 0, a.nNeg > 0};
+    for (int dir = 0; dir < 2; ++dir) {
+      if (!have[dir]) { a.uniformFull[dir] = 0; continue; }
+      if (!((tE[dir] - tS[dir]) / opt->dt < 5e7)) continue;  // keep the replay itself negligible; generic path otherwise
+      double t = tS[dir], dt = opt->dt;
+      int64_t full = 0, total = 0;
+      int nTail = 0;
+      bool ok = true;
+      while (t < tE[dir]) {
+        if (max_steps > 0 && total >= max_steps) break;
+        const double dtc = nmin_h(dt, tE[dir] - t);
+        if (nTail == 0 && dtc == opt->dt) ++full;
+        else if (nTail < 4) a.tailDt[dir][nTail++] = dtc;
+        else { ok = false; break; }
+        dt = dtc;  // fixed-step steppers hand their input dt back (ode.nim:189): a clipped dt persists
+        t += dtc;
+        ++total;
+      }
+      if (ok) { a.uniformFull[dir] = full; a.nTail[dir] = nTail; }
+    }
+  }
   a.tPos = nullptr; a.tNeg = nullptr;
   if (N > 0 && a.useDense && (a.nPos + a.nNeg) > 0) {
     const size_t n = (size_t)a.nPos + (size_t)a.nNeg;

@@ -640,6 +640,12 @@ struct DriveIn {
   int useDense;
   int64_t maxSteps;
   StepCtl ctl;
+  // Fixed-step, no dense output: (t, dt) do not depend on the state, so the host replays the reference's time loop
+  // (dt = min(dt, tEnd - t); t += dt, ode.nim:525,532) once and hands over the resulting step schedule:
+  // `uniformFull` steps of dtInit, then `nTail` clipped / ulp-sized closing steps.  uniformFull < 0: not available.
+  int64_t uniformFull;
+  int nTail;
+  double tailDt[4];
 };
 struct DriveOut {
   int emitted;
@@ -666,6 +672,31 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
   const int high = in.nReq - 1;
   int status = 0;
   int64_t steps = 0, rejected = 0;
+  if constexpr (!MT::adaptive) {
+    if (in.uniformFull >= 0) {  // pre-computed schedule: the loop carries no FP64 bookkeeping besides t itself
+      for (int64_t n = 0; n < in.uniformFull; ++n) {
+        if constexpr (METHOD == NNHIP_RK4) rk4_step(ops, t, h4, y, yNew);
+        else fixed_step<METHOD>(ops, t, dt, y, yNew);
+#pragma unroll
+        for (int c = 0; c < D; ++c) y[c] = yNew[c];
+        t += dt;
+      }
+      for (int k = 0; k < in.nTail; ++k) {
+        const double dk = in.tailDt[k];
+        if constexpr (METHOD == NNHIP_RK4) rk4_step(ops, t, rk4_dt(dk), y, yNew);
+        else fixed_step<METHOD>(ops, t, dk, y, yNew);
+#pragma unroll
+        for (int c = 0; c < D; ++c) y[c] = yNew[c];
+        t += dk;
+      }
+      emit(0, y);  // yPositive.add(y) / yNegative.add(y) (:542,:584)
+      out.emitted = 1;
+      out.status = (in.maxSteps > 0 && in.uniformFull + in.nTail >= in.maxSteps && t < in.tEnd) ? 2 : 0;
+      out.steps = in.uniformFull + in.nTail;
+      out.rejected = 0;
+      return;
+    }
+  }
   while (t < in.tEnd) {  // :511
     if (in.useDense) {
       if (high < denseIndex) break;  // :513-514

@@ -43,6 +43,10 @@ struct SolveArgs {
   int64_t maxSteps;
   StepCtl ctl;
   Params P;
+  // host-replayed step schedule of the two directions ([0] forward, [1] backward); see DriveIn
+  int64_t uniformFull[2];
+  int nTail[2];
+  double tailDt[2][4];
 };
 
 struct StepArgs {
@@ -132,6 +136,10 @@ NNHIP_DEV void solve_body(const SolveArgs& a, const OpsF& opsF, const OpsB& opsB
     in.tEnd = a.tEndNeg;
     in.tReq = a.tNeg;
     in.nReq = a.nNeg;
+    in.uniformFull = a.uniformFull[1];
+    in.nTail = a.nTail[1];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) in.tailDt[q] = a.tailDt[1][q];
     DriveOut o;
     const int nNeg = a.nNeg;
     drive<METHOD, true>(opsB, in, y0,
@@ -164,6 +172,10 @@ NNHIP_DEV void solve_body(const SolveArgs& a, const OpsF& opsF, const OpsB& opsB
     in.tEnd = a.tEndPos;
     in.tReq = a.tPos;
     in.nReq = a.nPos;
+    in.uniformFull = a.uniformFull[0];
+    in.nTail = a.nTail[0];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) in.tailDt[q] = a.tailDt[0][q];
     DriveOut o;
     const int nPos = a.nPos;
     const int rb = rowBase;
