@@ -222,7 +222,7 @@ def main():
         torch.cuda.synchronize()
         fs = e0.elapsed_time(e1) * 1e-3 / reps
         out["fused_solve"] = {"value": float(n) * nsteps / fs, "unit": "trajectory-steps/s", "ms_per_solve": fs * 1e3,
-                              "bound": "fp64-valu", "useful_fp64_flop_per_s": 16.0 * n * nsteps / fs,  # 16 irreducible flop/step
+                              "bound": "fp64-valu", "model_fp64_flop_per_s": 16.0 * n * nsteps / fs,  # SURVEY.md §8d model: 16 flop per step (≈12 VALU instructions after sign folding)
                               "bitwise_equal_to_stream": bool(torch.equal(yfu[-1], yf))}
 
     # ---- CPU baseline: the oracle (C++ restatement of the reference) on this box's host cores -------------
