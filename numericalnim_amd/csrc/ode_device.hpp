@@ -665,6 +665,7 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
   ops.rhs(t, y, fsal);  // FSAL = f(t0, y) (:506) / g(-t0, y0) (:546)
 #pragma unroll
   for (int c = 0; c < D; ++c) { lastY[c] = y[c]; lastDy[c] = fsal[c]; }  // lastIter (:498,:548)
+  [[maybe_unused]] bool lastDyValid = true;
   double dt = in.dtInit;
   [[maybe_unused]] Rk4Dt h4 = rk4_dt(dt);
   double error = 0.0;
@@ -702,7 +703,10 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
       if (high < denseIndex) break;  // :513-514
       double treq = NEG ? -in.tReq[denseIndex] : in.tReq[denseIndex];
       if (treq <= t) {
-        if constexpr (!MT::fsal) ops.rhs(t, y, dyNow);  // f(t, y, ctx) per emitted point (:521); same value each time
+        if constexpr (!MT::fsal) {
+          ops.rhs(t, y, dyNow);  // f(t, y, ctx) per emitted point (:521); same value each time
+          if (!lastDyValid) { ops.rhs(lastT, lastY, lastDy); lastDyValid = true; }  // deferred lastIter.dy (see below)
+        }
         while (treq <= t) {  // :515
           const HermiteW w = hermite_weights(treq, lastT, t);
           double yv[D];
@@ -724,7 +728,9 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
 #pragma unroll
         for (int c = 0; c < D; ++c) lastDy[c] = fsal[c];
       } else {
-        ops.rhs(t, y, lastDy);
+        // lastIter.dy = f(t, y, ctx) (:530) is only ever read when a requested time falls into the coming step, so it is
+        // evaluated lazily at emission time from (lastT, lastY) — the same call, hence the same bits — instead of once per step.
+        lastDyValid = false;
       }
     }
     if constexpr (METHOD == NNHIP_RK4) {
