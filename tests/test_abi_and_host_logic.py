@@ -153,3 +153,16 @@ def test_header_is_plain_c_and_host_entries_work_from_c(nn, tmp_path):
                            "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "abi 1 ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+def test_tune_set_validation(nn):
+    L = nn._lib.lib()
+    assert L.nnhip_tune_set(b"no_such_knob", 1) == -1
+    for key, bad in ((b"rk4_stream_vec", 3), (b"rk4_stream_mode", 7), (b"rk4_stream_blocks_per_cu", 0), (b"dim16_variant", 9), (b"host_chunks", 100)):
+        assert L.nnhip_tune_set(key, bad) == -1, key
+    for key, good, reset in ((b"rk4_stream_vec", 2, None), (b"rk4_stream_mode", 1, None), (b"rk4_stream_auto", 1, 1), (b"stream_graph", 1, 0),
+                             (b"dim16_variant", 1, 0), (b"fp_contract", 1, 0), (b"host_chunks", 4, 0), (b"host_register", 1, 0)):
+        assert L.nnhip_tune_set(key, good) == 0, key
+        if reset is not None:
+            assert L.nnhip_tune_set(key, reset) == 0
+    assert L.nnhip_tune_set(b"rk4_stream_auto", 1) == 0  # back to automatic variant selection
