@@ -698,10 +698,11 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
       return;
     }
   }
+  // next requested time, kept in a register and re-read only after an emission (a per-step global load otherwise)
+  double treq = (in.useDense && in.nReq > 0) ? (NEG ? -in.tReq[0] : in.tReq[0]) : 0.0;
   while (t < in.tEnd) {  // :511
     if (in.useDense) {
       if (high < denseIndex) break;  // :513-514
-      double treq = NEG ? -in.tReq[denseIndex] : in.tReq[denseIndex];
       if (treq <= t) {
         if constexpr (!MT::fsal) {
           ops.rhs(t, y, dyNow);  // f(t, y, ctx) per emitted point (:521); same value each time
