@@ -141,6 +141,16 @@ int nnhip_ode_solve_batch_f64_dev(const nnhip_ode_options* opt, int integrator, 
                                   int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
                                   int64_t* rejected_out, int64_t max_steps, void* ws, int64_t ws_bytes, void* stream);
 
+/* Parameter sweeps: the same fused solve with PER-IVP right-hand-side parameters.  In the reference every IVP is its own
+ * solveODE call and may carry its own ctx (ode.nim:589-591, 599); here `per_ivp_params` is a device table [n_per_ivp][N]
+ * whose column i overrides rhs_params[0 .. n_per_ivp) for IVP i (n_per_ivp <= n_params; remaining parameters stay
+ * batch-wide).  Everything else as nnhip_ode_solve_batch_f64_dev. */
+int nnhip_ode_solve_batch_sweep_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
+                                        int n_params, const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t N,
+                                        int dim, int layout, const double* tspan, int n_t, double* t_out, double* y_out,
+                                        int32_t* ny_out, int64_t* steps_out, int64_t* rejected_out, int64_t max_steps, void* ws,
+                                        int64_t ws_bytes, void* stream);
+
 /* ---- step-streaming: replaces one IntegratorProc call (ode.nim:38, call sites :531,:573) ------
  * (yNew, FSAL', dtUsed, error) = integrator(f, t, y, FSAL, dt, options, ctx) for every IVP of the batch,
  * state resident in HBM between calls.  t/dt are per-IVP device arrays [N], or — when t_dev / dt_dev is

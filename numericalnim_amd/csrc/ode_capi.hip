@@ -314,7 +314,7 @@ struct PreparedSolve {
 
 // Everything of solveODE / ODESolver that precedes the per-IVP loops: validation, time grid, dispatch (ode.nim:589-651, 476-510).
 static int prepare_solve(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
-                         const double* y0, int64_t N, int dim, int layout, const double* tspan, int n_t, double* t_out,
+                         const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t N, int dim, int layout, const double* tspan, int n_t, double* t_out,
                          double* y_out, int32_t* ny_out, int64_t* steps_out, int64_t* rejected_out, int64_t max_steps, void* ws,
                          int64_t ws_bytes, unsigned long long* agg, int* n_t_out, hipStream_t stream, PreparedSolve& ps) {
   nnhip::Params P;
@@ -355,6 +355,10 @@ static int prepare_solve(const nnhip_ode_options* opt, int integrator, int rhs_k
   a.maxSteps = max_steps;
   a.ctl = ctl_of(opt);
   a.P = P;
+  if (n_per_ivp < 0 || n_per_ivp > nnhip::kMaxParams || (n_per_ivp > 0 && !per_ivp_params)) return fail(NNHIP_EVALUE, "bad per-IVP parameter table");
+  a.perIvpParams = n_per_ivp > 0 ? per_ivp_params : nullptr;
+  a.nPerIvp = n_per_ivp;
+  a.perIvpStride = N;
   a.uniformFull[0] = a.uniformFull[1] = -1;
   a.nTail[0] = a.nTail[1] = 0;
   if (!adaptive && !a.useDense) {
@@ -408,6 +412,7 @@ static int launch_solve_range(const PreparedSolve& ps, int64_t lo, int64_t n, hi
   if (a.ny_out) a.ny_out += lo;
   if (a.steps_out) a.steps_out += lo;
   if (a.rejected_out) a.rejected_out += lo;
+  if (a.perIvpParams) a.perIvpParams += lo;
   a.N = n;
   if (ps.user) {
     if (nnhip::rtc_launch_solve(ps.rhs_kind, ps.integrator, a, stream) != hipSuccess)
@@ -423,8 +428,20 @@ int nnhip_ode_solve_batch_f64_dev(const nnhip_ode_options* opt, int integrator, 
                                   int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
                                   int64_t* rejected_out, int64_t max_steps, void* ws, int64_t ws_bytes, void* stream) {
   PreparedSolve ps;
-  int rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, y0, N, dim, layout, tspan, n_t, t_out, y_out, ny_out, steps_out,
-                         rejected_out, max_steps, ws, ws_bytes, nullptr, nullptr, (hipStream_t)stream, ps);
+  int rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, nullptr, 0, y0, N, dim, layout, tspan, n_t, t_out, y_out, ny_out,
+                         steps_out, rejected_out, max_steps, ws, ws_bytes, nullptr, nullptr, (hipStream_t)stream, ps);
+  if (rc) return rc;
+  return launch_solve_range(ps, 0, N, (hipStream_t)stream);
+}
+
+int nnhip_ode_solve_batch_sweep_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
+                                        int n_params, const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t N,
+                                        int dim, int layout, const double* tspan, int n_t, double* t_out, double* y_out,
+                                        int32_t* ny_out, int64_t* steps_out, int64_t* rejected_out, int64_t max_steps, void* ws,
+                                        int64_t ws_bytes, void* stream) {
+  PreparedSolve ps;
+  int rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y0, N, dim, layout, tspan, n_t, t_out,
+                         y_out, ny_out, steps_out, rejected_out, max_steps, ws, ws_bytes, nullptr, nullptr, (hipStream_t)stream, ps);
   if (rc) return rc;
   return launch_solve_range(ps, 0, N, (hipStream_t)stream);
 }
@@ -498,8 +515,8 @@ int nnhip_ode_solve_batch_f64(const nnhip_ode_options* opt, int integrator, int 
     (void)hipGetLastError();
   }
   PreparedSolve ps;
-  rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, d_y0, N, dim, layout, tspan, n_t, t_out, d_out, d_ny, d_steps, d_rej,
-                     max_steps, d_ws, wsBytes, d_agg, &nTOut, s[0], ps);
+  rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, nullptr, 0, d_y0, N, dim, layout, tspan, n_t, t_out, d_out, d_ny, d_steps,
+                     d_rej, max_steps, d_ws, wsBytes, d_agg, &nTOut, s[0], ps);
   if (rc) { cleanup(); return rc; }
   HIP_TRY_C(hipEventRecord(evPrep, s[0]));
   HIP_TRY_C(hipStreamWaitEvent(s[1], evPrep, 0));

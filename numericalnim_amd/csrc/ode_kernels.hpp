@@ -43,6 +43,11 @@ struct SolveArgs {
   int64_t maxSteps;
   StepCtl ctl;
   Params P;
+  // per-IVP RHS parameters (parameter sweeps: every IVP of the batch is its own solveODE call with its own ctx.fValues):
+  // nullable device array [nPerIvp][N]; parameter k of IVP i = perIvpParams[k*N + i] and overrides P.p[k]
+  const double* perIvpParams;
+  int nPerIvp;
+  int64_t perIvpStride;  // = N of the full batch (a sub-range launch shrinks N but keeps addressing the full table)
   // host-replayed step schedule of the two directions ([0] forward, [1] backward); see DriveIn
   int64_t uniformFull[2];
   int nTail[2];
@@ -70,6 +75,9 @@ struct StepArgs {
   double* dt_io;         // per-IVP step size, read and updated in place
   unsigned int* active;  // nullable; kAggSlots flags, set when a workgroup still has IVPs short of tEnd after this launch
   int64_t* steps_io;     // nullable: per-IVP accepted-step counter
+  const double* perIvpParams;  // nullable [nPerIvp][N], as in SolveArgs
+  int nPerIvp;
+  int64_t perIvpStride;
 };
 
 constexpr int kBlock = 256;
@@ -103,6 +111,18 @@ inline hipError_t launch_kernel(void (*kernel)(KArgs...), dim3 grid, dim3 block,
   return hipLaunchKernel((const void*)kernel, grid, block, ptrs, 0, s);
 }
 #endif  // !NNHIP_RTC
+
+// RHS parameters of IVP i: the batch-wide ones, overridden by this IVP's column of the per-IVP table when there is one
+template <class Args>
+NNHIP_DEV Params params_of(const Args& a, int64_t i) {
+  Params P = a.P;
+  if (a.perIvpParams) {
+#pragma unroll
+    for (int k = 0; k < kMaxParams; ++k)
+      if (k < a.nPerIvp) P.p[k] = a.perIvpParams[(int64_t)k * a.perIvpStride + i];
+  }
+  return P;
+}
 
 // ------------------------------------------------------------------------------------------------
 // fused solve: the body shared by the thread-per-IVP and lanes-per-system kernels.  `out`/`y0p` already
@@ -234,8 +254,9 @@ __global__ __launch_bounds__(kBlock) void solve_tpi_kernel(const SolveArgs a) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   LaneStats ls;
   if (i < a.N) {
-    const TpiOps<RHS, false> opsF{a.P};
-    const TpiOps<RHS, true> opsB{a.P};
+    const Params P = params_of(a, i);
+    const TpiOps<RHS, false> opsF{P};
+    const TpiOps<RHS, true> opsB{P};
     solve_body<METHOD>(a, opsF, opsB, a.y0 + i * a.ivpStride, a.y_out + i * a.ivpStride, ls);
     if (a.ny_out) a.ny_out[i] = ls.ny;
     if (a.steps_out) a.steps_out[i] = (int64_t)ls.steps;
@@ -269,8 +290,9 @@ __global__ __launch_bounds__(kBlock) void solve_lps_kernel(const SolveArgs a) {
   if (i < a.N) {
     double* ys = lds + sysInBlock * DIM;
     double* es = lds + kBlock * CPL + sysInBlock * DIM;
-    const LpsOps<RHS, false, CPL, SHUFFLE_NORM> opsF{a.P, ys, es, c};
-    const LpsOps<RHS, true, CPL, SHUFFLE_NORM> opsB{a.P, ys, es, c};
+    const Params P = params_of(a, i);
+    const LpsOps<RHS, false, CPL, SHUFFLE_NORM> opsF{P, ys, es, c};
+    const LpsOps<RHS, true, CPL, SHUFFLE_NORM> opsB{P, ys, es, c};
     solve_body<METHOD>(a, opsF, opsB, a.y0 + i * a.ivpStride + c * a.compStride, a.y_out + i * a.ivpStride + c * a.compStride, ls);
     if (c == 0) {
       if (a.ny_out) a.ny_out[i] = ls.ny;
@@ -342,7 +364,8 @@ template <int METHOD, class RHS, bool NEG>
 __global__ __launch_bounds__(kBlock) void step_tpi_kernel(const StepArgs a) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= a.N) return;
-  const TpiOps<RHS, NEG> ops{a.P};
+  const Params P = params_of(a, i);
+  const TpiOps<RHS, NEG> ops{P};
   step_body<METHOD>(a, ops, i, i * a.ivpStride, true);
 }
 
@@ -371,7 +394,8 @@ __global__ __launch_bounds__(kBlock) void advance_tpi_kernel(const StepArgs a) {
   if (i < a.N) {
     double t = a.t_io[i];
     if (t < a.tEnd) {  // :511
-      const TpiOps<RHS, false> ops{a.P};
+      const Params P = params_of(a, i);
+      const TpiOps<RHS, false> ops{P};
       const int64_t base = i * a.ivpStride;
       double y[D], yNew[D], fsal[D];
 #pragma unroll
@@ -429,7 +453,8 @@ __global__ __launch_bounds__(kBlock) void step_lps_kernel(const StepArgs a) {
   const int sysInBlock = threadIdx.x / DIM, c = threadIdx.x % DIM;
   const int64_t i = (int64_t)blockIdx.x * (kBlock / DIM) + sysInBlock;
   if (i >= a.N) return;
-  const LpsOps<RHS, NEG> ops{a.P, lds + sysInBlock * DIM, lds + kBlock + sysInBlock * DIM, c};
+  const Params P = params_of(a, i);
+  const LpsOps<RHS, NEG> ops{P, lds + sysInBlock * DIM, lds + kBlock + sysInBlock * DIM, c};
   step_body<METHOD>(a, ops, i, i * a.ivpStride + c * a.compStride, c == 0);
 }
 

@@ -184,12 +184,14 @@ def integrator_id(integrator):
 
 
 def solveODE(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=LAYOUT_SOA, max_steps=0, stats=None,
-             return_counts=False):
+             return_counts=False, sweep=None):
     """Batched solveODE (ode.nim:589-651): returns (t, y) with t = the sorted output grid (ndarray) and
     y = [n_t, *y0.shape] holding the state of every IVP at every t (rows the reference would not
     return for an IVP are NaN; see include/nnhip_ode.h).
 
-    return_counts=True appends a dict(ny, steps, rejected) of per-IVP int arrays/tensors."""
+    return_counts=True appends a dict(ny, steps, rejected) of per-IVP int arrays/tensors.
+    sweep: optional CUDA tensor [k, N] of PER-IVP values for the first k RHS parameters (a parameter sweep: IVP i is
+    integrated with parameters sweep[:, i], exactly as if it were its own solveODE call with its own ctx)."""
     L = _lib.lib()
     options = options if options is not None else _default_options()
     ctx = ctx if ctx is not None else NumContext()  # ode.nim:604-606
@@ -218,11 +220,20 @@ def solveODE(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=
             wsb = int(L.nnhip_ode_solve_workspace_bytes(n_t))
             ws = torch.empty(wsb, dtype=torch.uint8, device=y0c.device)
             stream = torch.cuda.current_stream().cuda_stream
-            _check(L.nnhip_ode_solve_batch_f64_dev(C.byref(options), integ, f.kind, pp, int(p.size), y0c.data_ptr(), N, dim, layout,
-                                                   tsp, n_t, tp, y.data_ptr(), ny.data_ptr() if return_counts else None,
-                                                   st.data_ptr() if return_counts else None,
-                                                   rj.data_ptr() if return_counts else None, int(max_steps), ws.data_ptr(), wsb,
-                                                   stream))
+            if sweep is not None:
+                sw = sweep.contiguous()
+                if sw.dim() != 2 or sw.shape[1] != N or sw.dtype != torch.float64 or not sw.is_cuda:
+                    raise ValueError("sweep must be a CUDA float64 tensor of shape [k, N]")
+                _check(L.nnhip_ode_solve_batch_sweep_f64_dev(C.byref(options), integ, f.kind, pp, int(p.size), sw.data_ptr(), int(sw.shape[0]),
+                                                             y0c.data_ptr(), N, dim, layout, tsp, n_t, tp, y.data_ptr(),
+                                                             ny.data_ptr() if return_counts else None, st.data_ptr() if return_counts else None,
+                                                             rj.data_ptr() if return_counts else None, int(max_steps), ws.data_ptr(), wsb, stream))
+            else:
+                _check(L.nnhip_ode_solve_batch_f64_dev(C.byref(options), integ, f.kind, pp, int(p.size), y0c.data_ptr(), N, dim, layout,
+                                                       tsp, n_t, tp, y.data_ptr(), ny.data_ptr() if return_counts else None,
+                                                       st.data_ptr() if return_counts else None,
+                                                       rj.data_ptr() if return_counts else None, int(max_steps), ws.data_ptr(), wsb,
+                                                       stream))
     else:
         y0c = np.ascontiguousarray(np.asarray(y0, dtype=np.float64))
         y = np.empty((n_t,) + y0c.shape, dtype=np.float64)

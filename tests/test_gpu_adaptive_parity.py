@@ -418,3 +418,38 @@ def test_rccl_allgather_states_single_device(nn, dev, layout, dim):
     torch.cuda.synchronize()
     assert torch.equal(full, shard)
     assert L.nnhip_allgather_states_f64_dev(5, sp, cnt, dim, layout, fp, None) != 0  # more devices than the box has
+
+
+@pytest.mark.parametrize("integrator", ["rk4", "dopri54", "tsit54"])
+def test_parameter_sweep_per_ivp_params(nn, oracle, dev, integrator):
+    """nnhip_ode_solve_batch_sweep_f64_dev: every IVP carries its own RHS parameters (its own ctx in the reference's terms).
+    Thread-per-IVP (Lorenz: per-IVP rho and sigma) and lanes-per-system (16-dim ring: per-IVP coupling) kernels vs one
+    oracle solve per IVP with that IVP's parameters."""
+    import torch
+    O = oracle
+    n = 257
+    rng = np.random.default_rng(21)
+    y0 = _lorenz_y0(n)
+    sigma, rho = rng.uniform(8, 12, n), rng.uniform(20, 35, n)
+    sweep = torch.from_numpy(np.stack([sigma, rho])).to(dev)           # first two parameters per IVP; beta stays batch-wide
+    ts = [-0.1, 0.0, 0.2, 0.4]
+    kw = dict(dt=1e-3, absTol=1e-8, relTol=1e-8, dtMin=1e-7, dtMax=5e-2)
+    t, y, cnt = nn.solveODE(nn.Rhs.lorenz(), torch.from_numpy(y0).to(dev), ts, nn.newODEoptions(**kw), integrator=integrator, sweep=sweep,
+                            return_counts=True)
+    got = y.cpu().numpy()
+    for i in range(0, n, 9):
+        rt, ry, st = O.solve_ode(O.RHS_LORENZ, [sigma[i], rho[i], 8.0 / 3.0], list(y0[:, i]), ts, O.new_options(**kw), integrator)
+        if integrator == "rk4":
+            assert np.array_equal(got[:, :, i], ry)
+        else:
+            assert np.abs(got[:, :, i] - ry).max() <= TOL_ADAPTIVE
+        assert int(cnt["steps"][i]) == st.steps
+    # lanes-per-system kernel
+    y16 = _ring_y0(n)
+    csw = rng.uniform(-0.3, 0.3, n)
+    t, y = nn.solveODE(nn.Rhs.ring(0.1), torch.from_numpy(y16).to(dev), [0.0, 0.5], nn.newODEoptions(**kw), integrator=integrator, layout=1,
+                       sweep=torch.from_numpy(csw[None, :].copy()).to(dev))
+    got = y.cpu().numpy()
+    for i in range(0, n, 31):
+        rt, ry, st = O.solve_ode(O.RHS_RING, [csw[i]], list(y16[i]), [0.0, 0.5], O.new_options(**kw), integrator)
+        assert np.abs(got[:, i, :] - ry).max() <= (0 if integrator == "rk4" else TOL_ADAPTIVE)
