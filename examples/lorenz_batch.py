@@ -32,3 +32,9 @@ duffing = nn.Rhs.custom(2, "dy[0] = y[1]; dy[1] = -p[0]*y[1] + y[0] - y[0]*y[0]*
                         defaults=dict(delta=0.3, gamma=0.1))
 t2, y2 = nn.solveODE(duffing, torch.rand(2, 100_000, dtype=torch.float64, device=dev), [0.0, 5.0], integrator="tsit54")
 print("Duffing end state of IVP 0:", y2[-1][:, 0].tolist())
+
+# a parameter sweep: every trajectory gets its own rho (the other parameters stay batch-wide)
+rho = torch.linspace(20.0, 35.0, n, dtype=torch.float64, device=dev)
+sigma = torch.full_like(rho, 10.0)
+t3, y3 = nn.solveODE(nn.Rhs.lorenz(), y0, [0.0, 1.0], opt, integrator="tsit54", sweep=torch.stack([sigma, rho]))
+print("z(1) across the rho sweep (first / last IVP):", float(y3[-1][2, 0]), float(y3[-1][2, -1]))
