@@ -87,3 +87,26 @@ def test_user_per_component_rhs_equals_builtin_ring(nn, dev, dim):
     a = nn.integratorStep(f, 0.0, y0, fs, 5e-2, integrator="dopri54", layout=1)
     b = nn.integratorStep(nn.Rhs.ring(0.1), 0.0, y0, fs, 5e-2, integrator="dopri54", layout=1)
     assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.gpu
+def test_user_rhs_reads_a_device_table_through_a_parameter_slot(nn, dev):
+    """ctx "can be used ... to pass in big Tensors" (ode.nim:599).  On the device the idiom is: hand the table's device
+    address to the RHS through a parameter slot (bit pattern of the pointer in a double) and index it in the RHS source."""
+    import struct
+    import torch
+    table = torch.linspace(0.0, 2.0, 4097, dtype=torch.float64, device=dev) ** 2        # forcing samples on t in [0, 1]: g(t) = (2t)^2
+    addr_as_double = struct.unpack("d", struct.pack("q", table.data_ptr()))[0]
+    body = ("const double* tab = (const double*)__double_as_longlong(p[1]);\n"
+            "const double s = t * 4096.0; int j = (int)s; j = j < 0 ? 0 : (j > 4095 ? 4095 : j);\n"
+            "const double g = tab[j] + (s - (double)j) * (tab[j + 1] - tab[j]);\n"   # linear interpolation in the table
+            "dy[0] = p[0] * y[0] + g;")
+    f_tab = nn.Rhs.custom(1, body, keys=("a", "table"), defaults=dict(a=-1.5, table=addr_as_double), name="forced_table")
+    f_ref = nn.Rhs.custom(1, "dy[0] = p[0] * y[0] + 4.0 * t * t;", keys=("a",), defaults=dict(a=-1.5), name="forced_exact")
+    y0 = torch.linspace(0.5, 1.5, 1000, dtype=torch.float64, device=dev)
+    ts = [0.0, 0.25, 0.5, 1.0]
+    for m in ("rk4", "tsit54"):
+        _, ya = nn.solveODE(f_tab, y0, ts, nn.newODEoptions(dt=1e-3), integrator=m)
+        _, yb = nn.solveODE(f_ref, y0, ts, nn.newODEoptions(dt=1e-3), integrator=m)
+        assert float((ya - yb).abs().max()) < 1e-6      # table interpolation error of a quadratic on a 4096-cell grid ~ 6e-8
+        assert torch.isfinite(ya).all()
