@@ -453,3 +453,20 @@ def test_parameter_sweep_per_ivp_params(nn, oracle, dev, integrator):
     for i in range(0, n, 31):
         rt, ry, st = O.solve_ode(O.RHS_RING, [csw[i]], list(y16[i]), [0.0, 0.5], O.new_options(**kw), integrator)
         assert np.abs(got[:, i, :] - ry).max() <= (0 if integrator == "rk4" else TOL_ADAPTIVE)
+
+
+def test_sort_by_returns_identical_results_in_caller_order(nn, dev):
+    """solveODE(sort_by=...) integrates in sorted order (less wavefront divergence) and un-permutes: bit-identical output."""
+    import torch
+    n = 5000
+    rng = np.random.default_rng(8)
+    mu = torch.from_numpy(rng.uniform(0.1, 10.0, n)).to(dev)
+    y0 = torch.from_numpy(np.stack([rng.uniform(1.5, 2.5, n), np.zeros(n)])).to(dev)
+    opt = nn.newODEoptions(absTol=1e-6, relTol=1e-6, dtMin=1e-9, dtMax=1.0)
+    ts = [0.0, 1.0, 3.0]
+    a = nn.solveODE(nn.Rhs.vanderpol(), y0, ts, opt, integrator="tsit54", sweep=mu[None, :], return_counts=True)
+    b = nn.solveODE(nn.Rhs.vanderpol(), y0, ts, opt, integrator="tsit54", sweep=mu[None, :], return_counts=True, sort_by=mu)
+    assert torch.equal(a[1], b[1]) and all(torch.equal(a[2][k], b[2][k]) for k in a[2])
+    y0a = y0.t().contiguous()
+    c = nn.solveODE(nn.Rhs.vanderpol(), y0a, ts, opt, integrator="tsit54", sweep=mu[None, :], layout=1, sort_by=mu)
+    assert torch.equal(c[1].permute(0, 2, 1), a[1])
