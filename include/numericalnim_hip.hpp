@@ -82,6 +82,14 @@ inline RhsSpec rhsLorenz(double sigma = 10.0, double rho = 28.0, double beta = 8
 inline RhsSpec rhsRing(double c = 0.1) { return {NNHIP_RHS_RING, {"c"}, {{"c", c}}}; }
 inline RhsSpec rhsAffineT(double a, double b) { return {NNHIP_RHS_AFFINE_T, {"a", "b"}, {{"a", a}, {"b", b}}}; }
 inline RhsSpec rhsVanDerPol(double mu = 1.0) { return {NNHIP_RHS_VANDERPOL, {"mu"}, {{"mu", mu}}}; }
+// An arbitrary right-hand side from HIP C++ source (compiled at run time, nnhip_ode_rhs_compile): `body` is the body of
+// rhs(double t, const double* y, double* dy, const double* p) with p = the values of `keys` in ctx.fValues order.
+inline RhsSpec rhsFromSource(int dim, const std::string& body, std::vector<std::string> keys = {},
+                             std::map<std::string, double> defaults = {}, const std::string& name = "user") {
+  int kind = 0;
+  throwOn(nnhip_ode_rhs_compile(name.c_str(), dim, (int)keys.size(), body.c_str(), &kind));
+  return {static_cast<nnhip_rhs_kind>(kind), std::move(keys), std::move(defaults)};
+}
 
 // A batch of N initial states of `dim` float64 components (host memory).  dim == 1 is the reference's
 // scalar `float` state; dim > 1 its Vector[float] / seq[float] state.

@@ -23,6 +23,7 @@ type
   RhsSpec* = object                         ## stands in for ODEProc[T] (ode.nim:36)
     kind*: RhsKind
     keys*: seq[string]                      ## ctx.fValues keys, in rhs_params order
+    userKind*: int                          ## > 0: handle of a run-time compiled RHS (rhsFromSource); overrides `kind`
   BatchLayout* = enum layoutSoA = 0, layoutAoS = 1
   OdeBatch* = object                        ## N states of `dim` float64 components
     n*: int
@@ -40,6 +41,16 @@ proc nnhip_ode_solve_batch_multi_gpu_f64(opt: ptr NnhipOptions, integrator, rhsK
                                          nParams: cint, y0: ptr cdouble, N: int64, dim, layout: cint,
                                          tspan: ptr cdouble, nT: cint, tOut, yOut: ptr cdouble, nyOut: ptr int32,
                                          maxSteps: int64, stats: ptr NnhipStats, nGpus: cint): cint {.importc, cdecl.}
+
+proc nnhip_ode_rhs_compile(name: cstring, dim, nParams: cint, body: cstring, rhsKindOut: ptr cint): cint {.importc, cdecl.}
+
+proc rhsFromSource*(dim: int, body: string, keys: seq[string] = @[], name = "user"): RhsSpec =
+  ## An arbitrary right-hand side given as HIP C++ source (compiled on the fly by the backend): `body` is the body of
+  ## `rhs(double t, const double* y, double* dy, const double* p)`, p = ctx.fValues[keys[i]].
+  var kind: cint
+  let rc = nnhip_ode_rhs_compile(name.cstring, dim.cint, keys.len.cint, body.cstring, addr kind)
+  if rc != 0: raise newException(ValueError, $nnhip_last_error())
+  RhsSpec(kind: RhsKind(0), keys: keys, userKind: kind.int)
 
 proc toC(o: ODEoptions): NnhipOptions =
   NnhipOptions(dt: o.dt, dtMax: o.dtMax, dtMin: o.dtMin, tStart: o.tStart, absTol: o.absTol, relTol: o.relTol,
@@ -70,12 +81,13 @@ proc solveODE*(f: RhsSpec, y0: OdeBatch, tspan: openArray[float],
   var stats: NnhipStats
   var y0d = y0.data
   let pp = if params.len > 0: addr params[0] else: nil
+  let rhsKind = (if f.userKind > 0: f.userKind else: f.kind.int).cint
   if nGpus > 1:
-    check nnhip_ode_solve_batch_multi_gpu_f64(addr opt, integ, f.kind.cint, pp, params.len.cint, addr y0d[0], y0.n.int64,
+    check nnhip_ode_solve_batch_multi_gpu_f64(addr opt, integ, rhsKind, pp, params.len.cint, addr y0d[0], y0.n.int64,
                                               y0.dim.cint, y0.layout.cint, addr ts[0], ts.len.cint, addr tOut[0],
                                               addr yOut[0], addr ny[0], 0, addr stats, nGpus.cint)
   else:
-    check nnhip_ode_solve_batch_f64(addr opt, integ, f.kind.cint, pp, params.len.cint, addr y0d[0], y0.n.int64,
+    check nnhip_ode_solve_batch_f64(addr opt, integ, rhsKind, pp, params.len.cint, addr y0d[0], y0.n.int64,
                                     y0.dim.cint, y0.layout.cint, addr ts[0], ts.len.cint, addr tOut[0], addr yOut[0],
                                     addr ny[0], nil, nil, 0, addr stats, 0)
   result[0] = tOut[0 ..< stats.nTOut.int]

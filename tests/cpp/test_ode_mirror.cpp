@@ -62,6 +62,17 @@ int main() {
       CHECK(std::sqrt(n2) / 3.0 <= c.tol);
     }
   }
+  // an arbitrary RHS handed over as source must reproduce the compiled-in one bit for bit
+  {
+    std::printf("test \"user RHS from source\"\n");
+    const RhsSpec fsrc = rhsFromSource(1, "dy[0] = y[0] * p[0];", {"a"});
+    OdeSolution a = solveODE(fsrc, y0, tspan, DEFAULT_ODEoptions(), &ctx, "tsit54");
+    OdeSolution b = solveODE(f, y0, tspan, DEFAULT_ODEoptions(), &ctx, "tsit54");
+    for (size_t i = 0; i < a.y.size(); ++i) CHECK(a.y[i].at(0, 0) == b.y[i].at(0, 0));
+    bool threwSrc = false;
+    try { rhsFromSource(1, "dy[0] = undefined_symbol;"); } catch (const std::invalid_argument&) { threwSrc = true; }
+    CHECK(threwSrc);
+  }
   // error behaviour: ValueError analogues
   bool threw = false;
   try { solveODE(f, y0, tspan, DEFAULT_ODEoptions(), &ctx, "rk5"); } catch (const std::invalid_argument&) { threw = true; }
