@@ -12,10 +12,12 @@
 // The only operation that may differ in the last ulp is pow(1/error, 1/order) in the step-size controller
 // (nth_root below; glibc's pow is not correctly rounded either).
 #pragma once
-#include <hip/hip_runtime.h>
 #ifdef __HIPCC_RTC__
+// hiprtc pre-includes its built-in HIP runtime header; an explicit <hip/hip_runtime.h> is not found by a stand-alone
+// (non-PyTorch) process using /opt/rocm's hiprtc
 #include "nnhip_ode.h"  // virtual header handed to hiprtc
 #else
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/nnhip_ode.h"
