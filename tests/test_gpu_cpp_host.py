@@ -17,3 +17,16 @@ def test_cpp_host_mirror(nn, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0 and r.stdout.strip().endswith("OK")
+
+
+def test_cpp_device_entries_standalone(nn, tmp_path):
+    """Device-pointer entries, hipGraph replay, adaptive streaming, RCCL reassembly and hiprtc from a process WITHOUT PyTorch
+    (system ROCm runtime / hiprtc / librccl only) — what a compiled or Nim host sees."""
+    exe = str(tmp_path / "test_device_entries")
+    libdir = os.path.join(ROOT, "numericalnim_amd", "csrc")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "test_device_entries.cpp"), "-L", libdir, "-lnnhip_ode", "-L", "/opt/rocm/lib",
+                           "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK")
