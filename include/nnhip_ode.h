@@ -240,6 +240,21 @@ int nnhip_cumtrapz_batch_f64_dev(const double* X, int n, const double* Y, int64_
  * three-point closure for an odd number of intervals, then hermiteInterpolate (utils.nim:282-312) with dy = Y); same layout as
  * cumtrapz; n >= 3 (else NNHIP_EVALUE, as the reference raises ValueError).  Synchronises `stream` before returning. */
 int nnhip_cumsimpson_batch_f64_dev(const double* X, int n, const double* Y, int64_t M, double* out, void* stream);
+/* The function-argument forms: cumtrapz(f, X, ctx, dx) (src/numericalnim/integrate.nim:138-175) and cumsimpson(f, X, ctx, dx)
+ * (:377-400) — sample f on a grid of spacing dx over [min X, max X (+1)], accumulate the rule left to right, resample the running
+ * integral at X with hermiteInterpolate (utils.nim:282-312).  The integrand is a function of x alone (NumContextProc,
+ * integrate.nim:9): f(x) := rhs(x, y = 0, params) for any thread-per-IVP rhs_kind, compiled-in or registered from source
+ * (nnhip_ode_rhs_compile) with dim components.  The batch axis is a parameter sweep: item i uses rhs_params overridden by
+ * per_item_params[k*N + i] (device, nullable) for k < n_per_item — N calls of the reference, each with its own ctx.
+ *   X [n_x] host, any order (the reference's sorted / unsorted branches are both reproduced, including rows it drops);
+ *   out [n_x][dim][N] (SoA) / [n_x][N][dim] (AoS) device; *n_rows_out (nullable) = rows the reference returns (<= n_x);
+ *   NNHIP_EVALUE where the reference raises ValueError or would never terminate (dx <= 0).  Synchronises `stream`. */
+int nnhip_cumtrapz_fn_batch_f64_dev(int rhs_kind, const double* rhs_params, int n_params, const double* per_item_params,
+                                    int n_per_item, int64_t N, int dim, int layout, const double* X, int n_x, double dx,
+                                    double* out, int* n_rows_out, void* stream);
+int nnhip_cumsimpson_fn_batch_f64_dev(int rhs_kind, const double* rhs_params, int n_params, const double* per_item_params,
+                                      int n_per_item, int64_t N, int dim, int layout, const double* X, int n_x, double dx,
+                                      double* out, int* n_rows_out, void* stream);
 /* The adaptive controller's step-size factor min(4, max(0.125, 0.9 * pow(1/error, 1/order))) (ode.nim:71, 537) over an
  * array of error norms; order in {2, 3, 5, 6} (rk21, bs32, dopri54/tsit54, vern65). */
 int nnhip_ode_controller_factor_f64_dev(int order, const double* error, double* out, int64_t n, void* stream);

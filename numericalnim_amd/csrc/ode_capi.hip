@@ -180,6 +180,17 @@ int stage_reserve(size_t n) {
 
 }  // namespace
 
+namespace nnhip {
+// error reporting for the other translation units of the C ABI (ode_capi_quad.hip): same thread-local message buffer
+int fail_msg(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+}  // namespace nnhip
+
 extern "C" {
 
 int nnhip_abi_version(void) { return NNHIP_ABI_VERSION; }

@@ -10,6 +10,7 @@
 
 #include "ode_kernels.hpp"
 #include "ode_rtc.hpp"
+#include "quad_kernels.hpp"
 
 namespace nnhip {
 
@@ -102,12 +103,6 @@ __global__ __launch_bounds__(kBlock) void cumtrapz_kernel(const TrapzWeights W, 
 
 // cumsimpson(Y, X) over M series (integrate.nim:329-375): composite Simpson on interval pairs + hermiteInterpolate
 // (utils.nim:282-312) with dy = Y.  Per-point weights depend only on X: computed on the host in reference order.
-struct SimpsonPoint {
-  double w[4];  // hermiteSpline weights of this output point inside its pair interval (utils.nim:273-279)
-};
-struct SimpsonPair {
-  double alpha, beta, eta;  // integral += alpha*y2 + beta*y1 + eta*y0  (:355-359; tail pair :366-370)
-};
 __global__ __launch_bounds__(kBlock) void cumsimpson_kernel(const SimpsonPair* __restrict__ pairs, int nPairs, int evenN,
                                                             const SimpsonPoint* __restrict__ pts, const double* __restrict__ Y,
                                                             double* __restrict__ out, int64_t M, int n) {
@@ -235,46 +230,18 @@ int nnhip_cumtrapz_batch_f64_dev(const double* X, int n, const double* Y, int64_
   return NNHIP_OK;
 }
 
-static nnhip::SimpsonPoint simpson_point(double x, double x1, double x2) {  // hermiteSpline weights, utils.nim:273-279
-  const double t = (x - x1) / (x2 - x1);
-  const double omt = 1.0 - t;
-  nnhip::SimpsonPoint p;
-  p.w[0] = (1.0 + 2.0 * t) * (omt * omt);
-  p.w[1] = (t * (omt * omt)) * (x2 - x1);
-  p.w[2] = (t * t) * (3.0 - 2.0 * t);
-  p.w[3] = ((t * t * t) - (t * t)) * (x2 - x1);
-  return p;
-}
-
 int nnhip_cumsimpson_batch_f64_dev(const double* X, int n, const double* Y, int64_t M, double* out, void* stream) {
   if (M < 0 || !X) return NNHIP_EVALUE;
   if (n < 3) return NNHIP_EVALUE;  // ValueError "at least 3 elements" (integrate.nim:345-346)
   for (int i = 1; i < n; ++i) if (!(X[i - 1] < X[i])) return NNHIP_EVALUE;
   if (M == 0) return NNHIP_OK;
   if (!Y || !out) return NNHIP_EVALUE;
-  const bool evenN = (n % 2) == 0;
-  const int N = evenN ? n - 1 : n;
-  const int nPairs = (N - 1) / 2;
-  auto cube = [](double v) { return v * v * v; };
-  auto sq = [](double v) { return v * v; };
-  std::vector<nnhip::SimpsonPair> pairs((size_t)nPairs + 1);
-  std::vector<nnhip::SimpsonPoint> pts((size_t)n);
-  for (int i = 0; i < nPairs; ++i) {  // integrate.nim:354-358
-    const double h1 = X[2 * i + 1] - X[2 * i], h2 = X[2 * i + 2] - X[2 * i + 1];
-    pairs[i].alpha = (2.0 * cube(h2) - cube(h1) + 3.0 * h1 * sq(h2)) / (6.0 * h2 * (h2 + h1));
-    pairs[i].beta = (cube(h2) + cube(h1) + 3.0 * h1 * h2 * (h2 + h1)) / (6.0 * h2 * h1);
-    pairs[i].eta = (2.0 * cube(h1) - cube(h2) + 3.0 * h2 * sq(h1)) / (6.0 * h1 * (h2 + h1));
-    pts[2 * i] = simpson_point(X[2 * i], X[2 * i], X[2 * i + 2]);
-    pts[2 * i + 1] = simpson_point(X[2 * i + 1], X[2 * i], X[2 * i + 2]);
-  }
-  if (evenN) {  // :363-370
-    const int l = n - 1;
-    const double h1 = X[l - 1] - X[l - 2], h2 = X[l] - X[l - 1];
-    pairs[nPairs].alpha = (2.0 * sq(h2) + 3.0 * h1 * h2) / (6.0 * (h1 + h2));
-    pairs[nPairs].beta = (sq(h2) + 3.0 * h1 * h2) / (6.0 * h1);
-    pairs[nPairs].eta = -(cube(h2)) / (6.0 * h1 * (h1 + h2));
-    pts[l - 1] = simpson_point(X[l - 1], X[l - 1], X[l]);
-  }
+  std::vector<nnhip::SimpsonPair> pairs;
+  std::vector<nnhip::SimpsonPoint> pts;
+  int64_t nPairs64 = 0;
+  bool evenN = false;
+  nnhip::simpson_tables(X, n, pairs, pts, nPairs64, evenN);
+  const int nPairs = (int)nPairs64;
   hipStream_t s = (hipStream_t)stream;
   nnhip::SimpsonPair* dPairs = nullptr;
   nnhip::SimpsonPoint* dPts = nullptr;

@@ -30,7 +30,7 @@ const Header kHeaders[] = {
 
 struct Program {
   hipModule_t module = nullptr;
-  hipFunction_t solve = nullptr, stepPos = nullptr, stepNeg = nullptr, rhs = nullptr;
+  hipFunction_t solve = nullptr, stepPos = nullptr, stepNeg = nullptr, rhs = nullptr, quad[2] = {nullptr, nullptr};
   int ivpsPerBlockSolve = kBlock, ivpsPerBlockStep = kBlock;  // thread-per-IVP: 256; lanes-per-system: 256 / lanes per system
 };
 struct UserRhsEntry {
@@ -38,7 +38,7 @@ struct UserRhsEntry {
   int dim = 0, n_params = 0;
   bool perComponent = false;  // body computes ONE component (usable by the lanes-per-system kernels) instead of the whole vector
   bool alive = false;
-  std::map<int, Program> programs;  // by integrator; key -1 = the rhs_batch kernel only
+  std::map<int, Program> programs;  // by integrator; key -1 = the rhs_batch kernel only, key -2 = the cumulative-quadrature kernels
 };
 
 std::mutex g_mu;
@@ -47,7 +47,7 @@ thread_local std::string g_rtc_err;
 
 std::string make_source(const UserRhsEntry& e) {
   std::string s;
-  s += "#include \"ode_kernels.hpp\"\n";
+  s += "#include \"ode_kernels.hpp\"\n#include \"quad_kernels.hpp\"\n";
   s += "namespace nnhip {\nstruct UserRhs {\n  static constexpr int dim = " + std::to_string(e.dim) + ";\n";
   if (!e.perComponent) {
     s += "  NNHIP_DEV static void eval(double t, const double (&y)[dim], double (&dy)[dim], const Params& P_) {\n";
@@ -97,6 +97,9 @@ bool compile(const UserRhsEntry& e, int integrator, Program& out) {
       names.push_back("nnhip::step_tpi_kernel<" + m + ", nnhip::UserRhs, false>");
       names.push_back("nnhip::step_tpi_kernel<" + m + ", nnhip::UserRhs, true>");
     }
+  } else if (integrator == -2) {
+    names.push_back("nnhip::cumtrapz_fn_kernel<nnhip::UserRhs>");
+    names.push_back("nnhip::cumsimpson_fn_kernel<nnhip::UserRhs>");
   } else {
     names.push_back("nnhip::rhs_batch_kernel<nnhip::UserRhs>");
   }
@@ -133,7 +136,8 @@ bool compile(const UserRhsEntry& e, int integrator, Program& out) {
     return false;
   }
   hipFunction_t* slots[3] = {&out.solve, &out.stepPos, &out.stepNeg};
-  if (integrator < 0) slots[0] = &out.rhs;
+  if (integrator == -1) slots[0] = &out.rhs;
+  if (integrator == -2) { slots[0] = &out.quad[0]; slots[1] = &out.quad[1]; }
   for (size_t i = 0; i < lowered.size(); ++i)
     if (hipModuleGetFunction(slots[i], out.module, lowered[i].c_str()) != hipSuccess) {
       g_rtc_err = "hipModuleGetFunction failed for " + lowered[i];
@@ -239,6 +243,13 @@ hipError_t rtc_launch_rhs(int rhs_kind, int64_t N, int64_t is, int64_t cs, doubl
   Params Pc = P;
   void* params[] = {&N, &is, &cs, &t, &y, &dy, &Pc};
   return hipModuleLaunchKernel(p->rhs, (unsigned)grid, 1, 1, kBlock, 1, 1, 0, s, params, nullptr);
+}
+
+hipError_t rtc_launch_quad(int rhs_kind, int rule, const QuadArgs& a, hipStream_t s) {
+  Program* p = get_program(rhs_kind, -2);
+  if (!p) return hipErrorInvalidValue;
+  QuadArgs copy = a;
+  return launch(p->quad[rule ? 1 : 0], a.N, kBlock, &copy, s);
 }
 
 }  // namespace nnhip

@@ -1,6 +1,7 @@
 // ode_rtc.hpp — internal interface of the hiprtc user-RHS module (ode_rtc.hip).
 #pragma once
 #include "ode_kernels.hpp"
+#include "quad_kernels.hpp"
 
 namespace nnhip {
 const char* rtc_last_error();
@@ -11,4 +12,6 @@ hipError_t rtc_launch_solve(int rhs_kind, int integrator, const SolveArgs& a, hi
 hipError_t rtc_launch_step(int rhs_kind, int integrator, const StepArgs& a, int negate, hipStream_t s);
 hipError_t rtc_launch_rhs(int rhs_kind, int64_t N, int64_t is, int64_t cs, double t, const double* y, double* dy, const Params& P,
                           hipStream_t s);
+// cumtrapz (rule 0) / cumsimpson (rule 1) of a user integrand f(x) := rhs(x, 0, params)
+hipError_t rtc_launch_quad(int rhs_kind, int rule, const QuadArgs& a, hipStream_t s);
 }  // namespace nnhip

@@ -59,10 +59,45 @@ def newHermiteSpline(X, Y, dY):
     return HermiteSpline(X, Y, dY)
 
 
-def cumtrapz(Y, X):
-    """cumtrapz(Y, X) for discrete points (integrate.nim:120-135), batched: Y is an [n, ...] CUDA tensor, every trailing
-    element its own series; X strictly ascending.  Returns the cumulative integrals, same shape as Y."""
+def _cumquad_fn(entry, f, X, ctx, dx, sweep, n, dim, device, layout):
+    """The function-argument forms cumtrapz(f, X, ctx, dx) / cumsimpson(f, X, ctx, dx) (integrate.nim:138-175, 377-400):
+    f is an Rhs whose value at (x, y=0) is the integrand; the batch axis is a parameter sweep (`sweep` [k, N] CUDA tensor of per-item
+    values for the first k parameters) or N identical items.  Returns [rows, dim, N] (SoA) / [rows, N, dim] (AoS) with
+    rows <= len(X) exactly as the reference's hermiteInterpolate produces them; dim == 1 results are squeezed to [rows, N]."""
     import torch
+    Xa = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
+    if Xa.ndim != 1 or len(Xa) < 1:
+        raise ValueError("X must be a non-empty 1-d sequence")
+    p, pp = _params_array(f, ctx)
+    dim = int(getattr(f, "dim", dim))  # run-time compiled integrands know their own size
+    if sweep is not None:
+        sw = sweep.contiguous()
+        if not sw.is_cuda or sw.dtype != torch.float64 or sw.ndim != 2:
+            raise ValueError("sweep must be a CUDA float64 tensor of shape [k, N]")
+        N, k, swp, device = int(sw.shape[1]), int(sw.shape[0]), sw.data_ptr(), sw.device
+    else:
+        N, k, swp = int(n), 0, None
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    shape = (len(Xa), dim, N) if layout == LAYOUT_SOA else (len(Xa), N, dim)
+    out = torch.full(shape, float("nan"), dtype=torch.float64, device=device)
+    rows = C.c_int(0)
+    with torch.cuda.device(device):
+        _check(entry(f.kind, pp, int(p.size), swp, k, N, dim, layout, Xa.ctypes.data_as(C.POINTER(C.c_double)), len(Xa), float(dx),
+                     out.data_ptr(), C.byref(rows), torch.cuda.current_stream().cuda_stream))
+    out = out[:rows.value]
+    if dim == 1:
+        out = out.reshape(rows.value, N)
+    return out
+
+
+def cumtrapz(Y, X, ctx=None, dx=1e-5, sweep=None, n=1, dim=1, device=None, layout=LAYOUT_SOA):
+    """cumtrapz(Y, X) for discrete points (integrate.nim:120-135), batched: Y is an [n, ...] CUDA tensor, every trailing
+    element its own series; X strictly ascending.  Returns the cumulative integrals, same shape as Y.
+    With an Rhs as first argument: cumtrapz(f, X, ctx, dx) (integrate.nim:138-175), see _cumquad_fn."""
+    import torch
+    from .ode import Rhs
+    if isinstance(Y, Rhs):
+        return _cumquad_fn(_lib.lib().nnhip_cumtrapz_fn_batch_f64_dev, Y, X, ctx, dx, sweep, n, dim, device, layout)
     Xa = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
     if len(Xa) != Y.shape[0]:
         raise ValueError("X and Y must have the same length")  # utils.nim:423-424
@@ -74,9 +109,13 @@ def cumtrapz(Y, X):
     return out
 
 
-def cumsimpson(Y, X):
-    """cumsimpson(Y, X) for discrete points (integrate.nim:329-375), batched like cumtrapz; needs len(X) >= 3."""
+def cumsimpson(Y, X, ctx=None, dx=1e-5, sweep=None, n=1, dim=1, device=None, layout=LAYOUT_SOA):
+    """cumsimpson(Y, X) for discrete points (integrate.nim:329-375), batched like cumtrapz; needs len(X) >= 3.
+    With an Rhs as first argument: cumsimpson(f, X, ctx, dx) (integrate.nim:377-400), see _cumquad_fn."""
     import torch
+    from .ode import Rhs
+    if isinstance(Y, Rhs):
+        return _cumquad_fn(_lib.lib().nnhip_cumsimpson_fn_batch_f64_dev, Y, X, ctx, dx, sweep, n, dim, device, layout)
     Xa = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
     if len(Xa) != Y.shape[0]:
         raise ValueError("X and Y must have the same length")

@@ -538,7 +538,9 @@ static int solveODE(const ODEProc<T>& f, const T& y0, const double* tspan, int n
 // The reference takes an arbitrary user closure; these are the closures the tests/bench supply.
 // ---------------------------------------------------------------------------------------------
 enum RhsKind { RHS_NEG_Y = 0, RHS_LINEAR = 1, RHS_LORENZ = 2, RHS_RING = 3, RHS_AFFINE_T = 4, RHS_VANDERPOL = 5,
-               RHS_DUFFING = 6 /* oracle-only: checks run-time compiled user RHS */ };
+               RHS_DUFFING = 6 /* oracle-only: checks run-time compiled user RHS */,
+               RHS_COS_T = 7 /* oracle-only integrand a*cos(t): tests/test_integrate.nim:5-6 */,
+               RHS_POLY_T = 8 /* oracle-only integrand ((a t + b) t)(1 + c) + d for component c */ };
 
 static double rhsScalar(double t, const double& y, const void* env) {
   const double* p = (const double*)env;  // p[0] = kind, p[1..] = params
@@ -546,6 +548,8 @@ static double rhsScalar(double t, const double& y, const void* env) {
     case RHS_NEG_Y: return -y;                      // ode.nim:16-17
     case RHS_LINEAR: return p[1] * y;               // tests/test_ode.nim:5   (-0.1 * y)
     case RHS_AFFINE_T: return p[1] * y + p[2] * t;  // time-dependent probe
+    case RHS_COS_T: return p[1] * std::cos(t);      // tests/test_integrate.nim:5
+    case RHS_POLY_T: return ((p[1] * t + p[2]) * t) * 1.0 + p[3];
   }
   return NAN;
 }
@@ -581,9 +585,123 @@ static Vec rhsVector(double t, const Vec& y, const void* env) {
       r.components[1] = ((-p[1] * v - p[2] * x) - p[3] * (x * x * x)) + p[4] * t;
       break;
     }
+    case RHS_COS_T: for (size_t i = 0; i < d; ++i) r.components[i] = p[1] * std::cos(t); break;  // tests/test_integrate.nim:6 (cos(x) * ctx["a"])
+    case RHS_POLY_T: for (size_t i = 0; i < d; ++i) r.components[i] = ((p[1] * t + p[2]) * t) * (1.0 + (double)i) + p[3]; break;
     default: for (size_t i = 0; i < d; ++i) r.components[i] = NAN;
   }
   return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cumulative quadrature of a function of x ("march + Hermite resample"):
+//   hermiteInterpolate     utils.nim:282-312
+//   cumsimpson(Y, X)       integrate.nim:329-375     (generic T restatement of oracle_cumsimpson below)
+//   cumtrapz(f, X, ctx, dx)    integrate.nim:138-175
+//   cumsimpson(f, X, ctx, dx)  integrate.nim:377-400
+// ---------------------------------------------------------------------------------------------
+template <class T>
+static std::vector<T> hermiteInterpolate(const std::vector<double>& x, const std::vector<double>& t, const std::vector<T>& y,
+                                         const std::vector<T>& dy) {
+  std::vector<T> result;
+  const long xHigh = (long)x.size() - 1, tHigh = (long)t.size() - 1;
+  long xIndex = 0;
+  if (std::is_sorted(x.begin(), x.end())) {  // isSorted(x): non-decreasing (:290)
+    bool done = false;
+    for (long i = 0; i <= tHigh - 1 && !done; ++i) {  // :291
+      while (t[i] <= x[xIndex] && x[xIndex] < t[i + 1]) {  // :292
+        result.push_back(hermiteSpline<T>(x[xIndex], t[i], t[i + 1], y[i], y[i + 1], dy[i], dy[i + 1]));
+        xIndex += 1;
+        if (xHigh < xIndex) { done = true; break; }  // :295-298
+      }
+    }
+    if (x[xHigh] == t[tHigh]) result.push_back(y[tHigh]);  // :299-300
+  } else {  // :302-311
+    for (double a : x) {
+      bool found = false;
+      for (long i = 0; i <= tHigh - 1; ++i)
+        if (t[i] <= a && a < t[i + 1]) {
+          result.push_back(hermiteSpline<T>(a, t[i], t[i + 1], y[i], y[i + 1], dy[i], dy[i + 1]));
+          found = true;
+          break;  // break forblock
+        }
+      if (found) continue;
+      if (a == t[tHigh]) result.push_back(y[tHigh]);
+      else throw std::invalid_argument("x not in interval");  // ValueError :311
+    }
+  }
+  return result;
+}
+
+template <class T>
+static std::vector<T> cumsimpsonDiscrete(const std::vector<T>& Y, const std::vector<double>& X) {  // X sorted, duplicate-free
+  int N = (int)X.size();
+  const int n = N;
+  bool evenN = false;
+  if (N < 3) throw std::invalid_argument("X and Y must have at least 3 elements to perform Simpson, use cumtrapz instead");
+  if (N % 2 == 0) { evenN = true; N -= 1; }
+  std::vector<T> y, dy;
+  std::vector<double> xs;
+  T integral = Y[0] - Y[0];
+  y.push_back(integral); dy.push_back(Y[0]); xs.push_back(X[0]);
+  for (int i = 0; i < (N - 1) / 2; ++i) {
+    const double h1 = X[2 * i + 1] - X[2 * i];
+    const double h2 = X[2 * i + 2] - X[2 * i + 1];
+    const double alpha = (2.0 * cube(h2) - cube(h1) + 3.0 * h1 * sq(h2)) / (6.0 * h2 * (h2 + h1));
+    const double beta = (cube(h2) + cube(h1) + 3.0 * h1 * h2 * (h2 + h1)) / (6.0 * h2 * h1);
+    const double eta = (2.0 * cube(h1) - cube(h2) + 3.0 * h2 * sq(h1)) / (6.0 * h1 * (h2 + h1));
+    integral = integral + (alpha * Y[2 * i + 2] + beta * Y[2 * i + 1] + eta * Y[2 * i]);  // `+=` :359
+    y.push_back(integral); dy.push_back(Y[2 * i + 2]); xs.push_back(X[2 * i + 2]);
+  }
+  if (evenN) {
+    const int last = n - 1;
+    const double h1 = X[last - 1] - X[last - 2];
+    const double h2 = X[last] - X[last - 1];
+    const double alpha = (2.0 * sq(h2) + 3.0 * h1 * h2) / (6.0 * (h1 + h2));
+    const double beta = (sq(h2) + 3.0 * h1 * h2) / (6.0 * h1);
+    const double eta = -(cube(h2)) / (6.0 * h1 * (h1 + h2));
+    integral = integral + (eta * Y[last - 2] + beta * Y[last - 1] + alpha * Y[last]);
+    y.push_back(integral); dy.push_back(Y[last]); xs.push_back(X[last]);
+  }
+  return hermiteInterpolate<T>(X, xs, y, dy);  // :375
+}
+
+template <class T, class F>
+static std::vector<T> cumtrapzFn(F f, const std::vector<double>& X, double dx) {  // integrate.nim:138-175
+  std::vector<double> times;
+  std::vector<T> dy, y;
+  double t = *std::min_element(X.begin(), X.end());
+  const double tEnd = *std::max_element(X.begin(), X.end()) + 1.0;  // "make sure to get the endpoint as well"
+  T dyTemp = f(t), dyPrev = dyTemp;
+  T integral = dyTemp - dyTemp;
+  times.push_back(t); dy.push_back(dyTemp); y.push_back(integral);
+  t += dx;
+  while (t <= tEnd) {
+    dyPrev = dyTemp;
+    dyTemp = f(t);
+    integral = integral + (0.5 * dx) * (dyPrev + dyTemp);  // integral += 0.5 * dx * (dyPrev + dyTemp)
+    times.push_back(t); dy.push_back(dyTemp); y.push_back(integral);
+    t += dx;
+  }
+  return hermiteInterpolate<T>(X, times, y, dy);
+}
+
+static long nimToInt(double v) { return (long)std::round(v); }  // system.toInt: rounds half away from zero
+
+template <class T, class F>
+static std::vector<T> cumsimpsonFn(F f, const std::vector<double>& X, double dx) {  // integrate.nim:377-400
+  const double lo = *std::min_element(X.begin(), X.end()), hi = *std::max_element(X.begin(), X.end());
+  const long N = nimToInt((hi - lo) / dx) + 2;
+  std::vector<double> t;  // linspace(lo, hi, N), utils.nim:498-507
+  const double step = (hi - lo) / (double)(N - 1);
+  t.push_back(lo);
+  for (long i = 1; i <= N - 2; ++i) t.push_back(lo + step * (double)i);
+  t.push_back(hi);
+  std::vector<T> dy;
+  for (double x : t) dy.push_back(f(x));
+  // cumsimpson(dy, t) sorts and trims (sortAndTrimDataset); a linspace with step > 0 is already sorted and duplicate-free,
+  // anything else is refused by the entry point before we get here.
+  const std::vector<T> ys = cumsimpsonDiscrete<T>(dy, t);
+  return hermiteInterpolate<T>(X, t, ys, dy);
 }
 
 }  // namespace oracle
@@ -849,6 +967,32 @@ int oracle_cumsimpson(const double* X, int n, const double* Y, double* out) {
   }
   if (X[n - 1] == xs[th]) out[k++] = y[th];
   return k;
+}
+
+// cumtrapz(f, X, ctx, dx) (rule 0) / cumsimpson(f, X, ctx, dx) (rule 1) with f(x) := rhs(x, y = 0, params) — the integrand is a
+// function of x alone (NumContextProc, integrate.nim:9).  dim == 0: T = float; dim >= 1: T = Vector[float].
+// out is [n_x][max(dim,1)]; returns the number of rows produced (the reference can return fewer than n_x), -1 for a ValueError.
+int oracle_cumquad_fn(int rule, int rhs_kind, const double* rhs_params, int n_params, int dim, const double* X, int n_x, double dx,
+                      double* out) {
+  using namespace oracle;
+  std::vector<double> env(1 + (size_t)n_params);
+  env[0] = rhs_kind;
+  for (int i = 0; i < n_params; ++i) env[1 + i] = rhs_params[i];
+  const std::vector<double> x(X, X + n_x);
+  try {
+    if (dim == 0) {
+      auto f = [&](double t) { return rhsScalar(t, 0.0, env.data()); };
+      const std::vector<double> r = rule == 0 ? cumtrapzFn<double>(f, x, dx) : cumsimpsonFn<double>(f, x, dx);
+      for (size_t j = 0; j < r.size(); ++j) out[j] = r[j];
+      return (int)r.size();
+    }
+    Vec zero; zero.components.assign((size_t)dim, 0.0);
+    auto f = [&](double t) { return rhsVector(t, zero, env.data()); };
+    const std::vector<Vec> r = rule == 0 ? cumtrapzFn<Vec>(f, x, dx) : cumsimpsonFn<Vec>(f, x, dx);
+    for (size_t j = 0; j < r.size(); ++j)
+      for (int c = 0; c < dim; ++c) out[j * (size_t)dim + c] = r[j].components[c];
+    return (int)r.size();
+  } catch (const std::invalid_argument&) { return -1; }
 }
 
 // Vector operator probes (tests/test_vector.nim semantics). op: 0 '+', 1 '-', 2 scalar*V, 3 abs, 4 *. 5 /. 6 d +. V

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liboracle_ode.so")
 
 # RHS kinds — must match include/nnhip_ode.h (enum nnhip_rhs_kind)
-RHS_NEG_Y, RHS_LINEAR, RHS_LORENZ, RHS_RING, RHS_AFFINE_T, RHS_VANDERPOL, RHS_DUFFING = range(7)  # DUFFING: oracle-only
+RHS_NEG_Y, RHS_LINEAR, RHS_LORENZ, RHS_RING, RHS_AFFINE_T, RHS_VANDERPOL, RHS_DUFFING, RHS_COS_T, RHS_POLY_T = range(9)  # DUFFING.. : oracle-only
 LAYOUT_SOA, LAYOUT_AOS = 0, 1
 
 ALL_ODE = ["heun2", "ralston2", "kutta3", "heun3", "ralston3", "ssprk3", "ralston4", "kutta4", "rk4",
@@ -200,6 +200,23 @@ def cumsimpson(Y, X):
     if k < 0:
         raise ValueError("X and Y must have at least 3 elements to perform Simpson, use cumtrapz instead")
     return out[:k].copy()
+
+
+def cumquad_fn(rule, rhs_kind, params, dim, X, dx=1e-5):
+    """cumtrapz(f, X, ctx, dx) (rule "trapz", integrate.nim:138-175) / cumsimpson(f, X, ctx, dx) (rule "simpson", :377-400) with
+    f(x) := rhs(x, y=0, params).  dim == 0: T = float -> [rows]; dim >= 1: T = Vector[float] -> [rows][dim].  The reference can
+    return fewer rows than len(X) (hermiteInterpolate quirks); ValueError as the reference raises it."""
+    X = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
+    p = np.ascontiguousarray(np.asarray(params, dtype=np.float64))
+    out = np.empty((len(X) + 1, max(dim, 1)), dtype=np.float64)
+    lib().oracle_cumquad_fn.restype = C.c_int
+    lib().oracle_cumquad_fn.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_int, C.c_double, C.c_void_p]
+    k = lib().oracle_cumquad_fn({"trapz": 0, "simpson": 1}[rule], rhs_kind, p.ctypes.data, len(p), dim, X.ctypes.data, len(X), float(dx),
+                                out.ctypes.data)
+    if k < 0:
+        raise ValueError("cumulative quadrature: ValueError in the reference")
+    return out[:k, 0].copy() if dim == 0 else out[:k].copy()
 
 
 def vector_op(op, a, b=None, d=0.0):

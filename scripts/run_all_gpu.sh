@@ -11,4 +11,5 @@ bash scripts/profile_configs.sh > gpurun_out/profile_cfg.log 2>&1
 timeout 300 python scripts/bench_configs.py > gpurun_out/bench_configs.log 2>&1
 timeout 300 python scripts/bench_extra.py > gpurun_out/bench_extra.log 2>&1
 timeout 300 python scripts/bench_adaptive_stream.py > gpurun_out/bench_adaptive_stream.log 2>&1
-echo "then, in the build container: python scripts/summarize_profiles.py --round N and copy the logs into profiles/"
+timeout 300 python scripts/bench_cumquad.py > gpurun_out/bench_cumquad.log 2>&1
+echo "then, in the build container: python scripts/summarize_profiles.py --round N   (copies the summaries into profiles/)"

@@ -62,6 +62,26 @@ def main():
                     "write_size_raw_kib_median": statistics.median(vals["WRITE_SIZE"]),
                     "dispatches_sampled": len(vals["FETCH_SIZE"]),
                     "correction": "FETCH_SIZE KiB*1024*2 (gfx950 wide-read half-count), WRITE_SIZE KiB*1024; separate --pmc passes"})
+    # the benchmark logs of the same gpurun call: keep the JSON each script printed (its last '{'-line)
+    for name in ("bench_default", "bench_configs", "bench_extra", "bench_adaptive_stream", "bench_cumquad"):
+        lp = os.path.join(a.src, name + ".log")
+        if not os.path.exists(lp):
+            continue
+        text = open(lp, errors="replace").read()
+        start = None
+        for line in text.splitlines():
+            if line.startswith("{"):
+                start = line
+        if start is None:
+            continue
+        try:
+            obj = json.loads(start)            # single-line JSON
+        except ValueError:
+            try:
+                obj = json.loads(text[text.index("{"):])  # pretty-printed JSON to the end of the log
+            except ValueError:
+                continue
+        json.dump(obj, open(os.path.join(ROOT, "profiles", f"{tag}_{name}.json"), "w"), indent=1)
     pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     allj = json.load(open(pj)) if os.path.exists(pj) else {}
     allj["rk4_stream"] = out

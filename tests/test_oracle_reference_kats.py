@@ -173,3 +173,41 @@ def test_reference_quirks(oracle):
     # tspan is sorted (ode.nim:609) and tStart inside tspan is emitted verbatim
     t, y, st = O.solve_ode(O.RHS_NEG_Y, [], 3.0, [1.0, -1.0, 0.0], O.new_options(dt=1e-2), "rk4")
     assert list(t) == [-1.0, 0.0, 1.0] and y[1] == 3.0
+
+
+# ---- tests/test_integrate.nim:72-95: the function-argument forms of cumtrapz / cumsimpson -----------------------------------
+@pytest.mark.parametrize("rule,tol", [("trapz", 1e-1), ("simpson", 1e-3)])
+@pytest.mark.parametrize("dx", [1e-5, 0.1])
+@pytest.mark.parametrize("dim", [0, 3])
+def test_cumquad_fn_reference_tests(oracle, rule, tol, dx, dim):
+    """"cumtrapz func, discrete points" / "... dx = 0.1" / "cumsimpson func ..." (f = a cos x, a = 2, X = linspace(0, 3pi/2, 17),
+    checked against 2 sin x at the reference's tolerances); dim 3 = the Vector flavour of the same integrand."""
+    import math
+    O = oracle
+    X = np.array(O.linspace(0.0, 1.5 * math.pi, 17))
+    r = O.cumquad_fn(rule, O.RHS_COS_T, [2.0], dim, X, dx)
+    assert r.shape[0] == 17
+    exact = 2.0 * np.sin(X)
+    if dim == 0:
+        assert np.abs(r - exact).max() < tol
+    else:
+        for c in range(dim):
+            assert np.abs(r[:, c] - exact).max() < tol
+
+
+def test_cumquad_fn_matches_its_discrete_building_blocks(oracle):
+    """cumsimpson(f, X, dx) == hermiteInterpolate(X, t, cumsimpson(f(t), t), f(t)) with t the linspace the reference builds
+    (integrate.nim:395-400): ties the function form to the already pinned discrete cumsimpson."""
+    O = oracle
+    X = np.array([0.0, 0.3, 0.55, 1.0])
+    dx = 0.05
+    n = int(round((X.max() - X.min()) / dx)) + 2
+    t = np.array(O.linspace(X.min(), X.max(), n))
+    dy = np.array([((0.5 * x + 2.0) * x) * 1.0 - 1.0 for x in t])
+    ys = O.cumsimpson(dy, t)
+    r = O.cumquad_fn("simpson", O.RHS_POLY_T, [0.5, 2.0, -1.0], 0, X, dx)
+    assert len(r) == 4 and r[0] == ys[0] and r[-1] == ys[-1]
+    # a query sitting on a grid point reproduces that grid value (h00 = 1, every other weight 0)
+    k = int(np.argmin(np.abs(t - 0.55)))
+    if t[k] == 0.55:
+        assert r[2] == ys[k]
