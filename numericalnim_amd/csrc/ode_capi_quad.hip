@@ -105,7 +105,11 @@ struct DeviceTables {  // freed on scope exit (after the stream has been drained
   const T* upload(const std::vector<T>& v, hipStream_t s, int& rc) {
     if (v.empty() || rc != NNHIP_OK) return nullptr;
     void* d = nullptr;
-    if (hipMalloc(&d, v.size() * sizeof(T)) != hipSuccess) { rc = fail_msg(NNHIP_ENOMEM, "hipMalloc of a %zu-byte quadrature table failed", v.size() * sizeof(T)); return nullptr; }
+    const hipError_t me = hipMalloc(&d, v.size() * sizeof(T));
+    if (me != hipSuccess) {  // no device / no driver is a HIP failure, not an allocation failure
+      rc = fail_msg(me == hipErrorOutOfMemory ? NNHIP_ENOMEM : NNHIP_EHIP, "hipMalloc of a %zu-byte quadrature table failed: %s", v.size() * sizeof(T), hipGetErrorString(me));
+      return nullptr;
+    }
     ptrs.push_back(d);
     if (hipMemcpyAsync(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s) != hipSuccess) { rc = fail_msg(NNHIP_EHIP, "hipMemcpyAsync of a quadrature table failed"); return nullptr; }
     return (const T*)d;

@@ -121,6 +121,16 @@ def test_compute_fails_loudly_without_gpu(nn):
         nn.solveODE(nn.Rhs.neg_y(), np.ones(4), [0.0, 1.0], nn.newODEoptions(dt=0.25), integrator="rk4")
     with pytest.raises(ValueError):
         nn.solveODE(nn.Rhs.neg_y(), torch.ones(4, dtype=torch.float64), [0.0, 1.0], integrator="rk4")  # CPU tensor refused
+    # the quadrature entries do their host-side planning first (row count is known without a device), then fail on the device part
+    import ctypes as C
+    from numericalnim_amd import _lib
+    X = np.array([0.0, 0.5, 1.0])
+    p = np.array([0.0, 1.0])
+    rows = C.c_int(-1)
+    dp = C.POINTER(C.c_double)
+    for entry in (_lib.lib().nnhip_cumtrapz_fn_batch_f64_dev, _lib.lib().nnhip_cumsimpson_fn_batch_f64_dev):
+        rc = entry(nn.Rhs.AFFINE_T, p.ctypes.data_as(dp), 2, None, 0, 4, 1, 0, X.ctypes.data_as(dp), 3, 0.01, C.c_void_p(16), C.byref(rows), None)
+        assert rc == _lib.NNHIP_EHIP and rows.value == 3, (rc, rows.value, _lib.last_error())
 
 
 def test_argument_validation(nn):

@@ -43,3 +43,39 @@ def test_new_options_property(nn, oracle, dt, absTol, relTol, dtMax, dtMin, scal
     assert (ref is None) == (got is None)
     if ref is not None:
         assert bytes(ref) == bytes(got)
+
+
+# cumtrapz(f, X, ctx, dx) / cumsimpson(f, X, ctx, dx): the host replays the reference's sampling grid and hermiteInterpolate's
+# control flow (utils.nim:282-312) to decide how many rows come back and whether a ValueError is raised.  That part runs
+# before any device work, so it can be checked against the oracle without a GPU (with one, the call simply goes on to succeed).
+xq = st.one_of(st.floats(min_value=-2.0, max_value=2.0, allow_nan=False), st.sampled_from([0.0, 0.25, 0.5, 1.0, -1.0]))
+
+
+@settings(max_examples=300, deadline=None)
+@given(X=st.lists(xq, min_size=1, max_size=8), dx=st.sampled_from([0.01, 0.1, 0.25, 0.3, 1.0, 1.5, 7.0]), rule=st.sampled_from(["trapz", "simpson"]),
+       sort=st.booleans())
+def test_cumquad_fn_row_plan_property(nn, oracle, X, dx, rule, sort):
+    import torch
+    L = nn._lib.lib()
+    Xa = np.asarray(sorted(X) if sort else X, dtype=np.float64)
+    p = np.array([0.0, 1.0])
+    dp = C.POINTER(C.c_double)
+    rows = C.c_int(-1)
+    entry = L.nnhip_cumtrapz_fn_batch_f64_dev if rule == "trapz" else L.nnhip_cumsimpson_fn_batch_f64_dev
+    gpu = torch.cuda.is_available()
+    out = torch.empty((len(Xa) + 1) * 4, dtype=torch.float64, device="cuda") if gpu else None
+    rc = entry(nn.Rhs.AFFINE_T, p.ctypes.data_as(dp), 2, None, 0, 4, 1, 0, Xa.ctypes.data_as(dp), len(Xa), dx,
+               C.c_void_p(out.data_ptr() if gpu else 16), C.byref(rows), None)
+    try:
+        ref = oracle.cumquad_fn(rule, oracle.RHS_AFFINE_T, p, 0, Xa, dx)
+    except ValueError:
+        ref = None
+    if rule == "simpson" and rc == nn._lib.NNHIP_EUNSUPPORTED:
+        # max(X) == min(X) with a grid of >= 3 coincident points: the reference would deduplicate the grid; refused here
+        assert Xa.max() == Xa.min()
+        return
+    if ref is None:
+        assert rc == nn._lib.NNHIP_EVALUE, (rc, nn._lib.last_error())
+    else:
+        assert rows.value == len(ref), (Xa, dx, rule, rows.value, len(ref))
+        assert rc == (nn._lib.NNHIP_OK if (gpu or len(ref) == 0) else nn._lib.NNHIP_EHIP), (rc, nn._lib.last_error())
