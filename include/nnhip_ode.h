@@ -112,7 +112,10 @@ int nnhip_ode_integrator_traits(int integrator, int* use_fsal, double* order, in
 /* Output time grid exactly as ODESolver assembles it (ode.nim:476-480, 585): tspan.sorted(), split
  * around tStart, tNegative.reversed ++ tZero ++ tPositive.  t_out has room for n_t doubles. */
 int nnhip_ode_time_grid(const nnhip_ode_options* opt, const double* tspan, int n_t, double* t_out, int* n_t_out);
-/* Is there a compiled kernel for this combination?  1 / 0.  mode: 0 fused solve, 1 step-streaming. */
+/* Is there a kernel for this combination?  1 / 0.  mode: 0 fused solve, 1 step-streaming.  Ahead-of-time kernels cover the
+ * sizes of the reference's tests and of the BASELINE configs (dims 1-4, Lorenz, Van der Pol, 8/16/32-component systems); the
+ * size-generic kinds NEG_Y, LINEAR, AFFINE_T and RING also run at every other dim in 1..16 and at 32 (the reference's
+ * Vector[float] has any length): those sizes are instantiated at run time from the same expressions on first use (hiprtc). */
 int nnhip_ode_supported(int integrator, int rhs_kind, int dim, int layout, int mode);
 
 /* ---- fused batch solve: replaces solveODE -> ODESolver (ode.nim:589-651, 471-586) -------------

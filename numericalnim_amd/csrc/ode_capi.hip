@@ -302,9 +302,9 @@ int nnhip_ode_supported(int integrator, int rhs_kind, int dim, int layout, int m
   }
   if (integrator < 0 || integrator >= NNHIP_N_INTEGRATORS || rhs_kind < 0 || rhs_kind >= NNHIP_N_RHS) return 0;
   if (layout != NNHIP_LAYOUT_SOA && layout != NNHIP_LAYOUT_AOS) return 0;
-  if (mode == 0) return find_solve(integrator, rhs_kind, dim) != nullptr;
+  if (mode == 0) return find_solve(integrator, rhs_kind, dim) != nullptr || nnhip::rtc_builtin_available(rhs_kind, dim);
   if (mode == 1) {
-    if (find_step(integrator, rhs_kind, dim)) return 1;
+    if (find_step(integrator, rhs_kind, dim) || nnhip::rtc_builtin_available(rhs_kind, dim)) return 1;
     return (!kMethods[integrator].adaptive && integrator == NNHIP_RK4 && elementwise_rhs(rhs_kind)) ? 1 : 0;
   }
   return 0;
@@ -342,6 +342,10 @@ static int prepare_solve(const nnhip_ode_options* opt, int integrator, int rhs_k
   ps.integrator = integrator;
   ps.rhs_kind = rhs_kind;
   ps.fn = ps.user ? nullptr : find_solve(integrator, rhs_kind, dim);
+  if (!ps.fn && !ps.user) {  // a built-in right-hand side at a size without an ahead-of-time kernel
+    const int k = nnhip::rtc_builtin_kind(rhs_kind, dim);
+    if (k >= 0) { ps.user = true; ps.rhs_kind = k; }
+  }
   if (!ps.fn && !ps.user) return fail(NNHIP_EUNSUPPORTED, "no fused-solve kernel for integrator=%s rhs_kind=%d dim=%d", kMethods[integrator].name, rhs_kind, dim);
   const bool adaptive = kMethods[integrator].adaptive;
   // Deviations from the reference that keep the device from spinning forever (documented in DESIGN.md):
@@ -611,8 +615,12 @@ int nnhip_ode_step_batch_f64_dev(const nnhip_ode_options* opt, int integrator, i
     HIP_TRY(nnhip::launch_rk4_stream(rhs_kind, y_in, y_out, N * dim, t_uniform, dt_uniform, P, negate_time, tune, (hipStream_t)stream));
     return NNHIP_OK;
   }
-  const bool user = rhs_kind >= NNHIP_RHS_USER_BASE;
+  bool user = rhs_kind >= NNHIP_RHS_USER_BASE;
   nnhip::StepLaunchFn fn = user ? nullptr : find_step(integrator, rhs_kind, dim);
+  if (!fn && !user) {
+    const int k = nnhip::rtc_builtin_kind(rhs_kind, dim);
+    if (k >= 0) { user = true; rhs_kind = k; }
+  }
   if (!fn && !user) return fail(NNHIP_EUNSUPPORTED, "no step kernel for integrator=%s rhs_kind=%d dim=%d", kMethods[integrator].name, rhs_kind, dim);
   nnhip::StepArgs a{};
   a.N = N;

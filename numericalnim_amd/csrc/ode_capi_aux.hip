@@ -304,7 +304,11 @@ int nnhip_ode_rhs_batch_f64_dev(int rhs_kind, const double* rhs_params, int n_pa
   }
   NNHIP_FOR_EACH_LPS_RHS(X)
 #undef X
-  if (!found) return NNHIP_EUNSUPPORTED;
+  if (!found) {  // size-generic built-in kind at a size without an ahead-of-time kernel: run-time instantiation
+    const int k = nnhip::rtc_builtin_kind(rhs_kind, dim);
+    if (k < 0) return NNHIP_EUNSUPPORTED;
+    return nnhip::rtc_launch_rhs(k, N, is, cs, t, y, dy, P, (hipStream_t)stream) == hipSuccess ? NNHIP_OK : NNHIP_EHIP;
+  }
   return e == hipSuccess ? NNHIP_OK : NNHIP_EHIP;
 }
 

@@ -245,6 +245,36 @@ hipError_t rtc_launch_rhs(int rhs_kind, int64_t N, int64_t is, int64_t cs, doubl
   return hipModuleLaunchKernel(p->rhs, (unsigned)grid, 1, 1, kBlock, 1, 1, 0, s, params, nullptr);
 }
 
+// The reference's Vector[float] state has any length; the ahead-of-time kernels cover the sizes of the BASELINE configs and the
+// reference's tests (NNHIP_FOR_EACH_TPI_RHS / _LPS_RHS).  Every other size of the size-generic built-in right-hand sides is
+// instantiated at run time from the same per-component expressions (hiprtc, ode_rtc.hip; one entry per (kind, dim), compiled on
+// first use, cached for the life of the process): dims 1..16 thread-per-IVP, 8 / 16 / 32 lanes-per-system.
+bool rtc_builtin_available(int rhs_kind, int dim) {
+  if (!(rhs_kind == NNHIP_RHS_NEG_Y || rhs_kind == NNHIP_RHS_LINEAR || rhs_kind == NNHIP_RHS_AFFINE_T || rhs_kind == NNHIP_RHS_RING)) return false;
+  return (dim >= 1 && dim <= 16) || dim == 32;
+}
+static std::mutex g_synth_mu;
+static std::map<std::pair<int, int>, int> g_synth;  // (built-in kind, dim) -> user rhs_kind
+int rtc_builtin_kind(int rhs_kind, int dim) {
+  if (!rtc_builtin_available(rhs_kind, dim)) return -1;
+  std::lock_guard<std::mutex> lk(g_synth_mu);
+  auto it = g_synth.find({rhs_kind, dim});
+  if (it != g_synth.end()) return it->second;
+  const char* body = nullptr;  // the comp() bodies of RhsNegY / RhsLinear / RhsAffineT / RhsRing (ode_device.hpp), verbatim
+  int np = 0;
+  switch (rhs_kind) {
+    case NNHIP_RHS_NEG_Y: body = "return -y[c];"; np = 0; break;
+    case NNHIP_RHS_LINEAR: body = "return y[c] * p[0];"; np = 1; break;
+    case NNHIP_RHS_AFFINE_T: body = "return p[0] * y[c] + p[1] * t;"; np = 2; break;
+    default: body = "return -((double)(c + 1) / (double)dim) * y[c] + p[0] * y[(c + 1) % dim];"; np = 1; break;
+  }
+  const std::string name = "builtin" + std::to_string(rhs_kind) + "_dim" + std::to_string(dim);
+  const int k = rtc_register(name.c_str(), dim, np, body, true, false);
+  if (k >= 0) g_synth[{rhs_kind, dim}] = k;
+  return k;
+}
+
+
 hipError_t rtc_launch_quad(int rhs_kind, int rule, const QuadArgs& a, hipStream_t s) {
   Program* p = get_program(rhs_kind, -2);
   if (!p) return hipErrorInvalidValue;

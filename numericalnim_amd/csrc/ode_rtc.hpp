@@ -12,6 +12,10 @@ hipError_t rtc_launch_solve(int rhs_kind, int integrator, const SolveArgs& a, hi
 hipError_t rtc_launch_step(int rhs_kind, int integrator, const StepArgs& a, int negate, hipStream_t s);
 hipError_t rtc_launch_rhs(int rhs_kind, int64_t N, int64_t is, int64_t cs, double t, const double* y, double* dy, const Params& P,
                           hipStream_t s);
+// size-generic built-in right-hand sides (NEG_Y, LINEAR, AFFINE_T, RING) at a size without an ahead-of-time kernel: the user
+// rhs_kind of their run-time instantiation (registered on first request), or -1
+bool rtc_builtin_available(int rhs_kind, int dim);
+int rtc_builtin_kind(int rhs_kind, int dim);
 // cumtrapz (rule 0) / cumsimpson (rule 1) of a user integrand f(x) := rhs(x, 0, params)
 hipError_t rtc_launch_quad(int rhs_kind, int rule, const QuadArgs& a, hipStream_t s);
 }  // namespace nnhip
