@@ -278,8 +278,13 @@ hipError_t launch_solve_tpi(const SolveArgs& a, hipStream_t s) {
 // Lane (s, c) owns component c of system s: its y, k1..kS, yNew are single VGPR doubles; the stage
 // argument vector and the squared error components of each system live in LDS (2*DIM doubles per system,
 // 4 KiB per 256-thread workgroup).  With the AoS layout a wave's 64 lanes read 512 contiguous bytes.
+#ifndef NNHIP_LPS_WPE  // A/B hook: -DNNHIP_LPS_WPE=n caps the fused lanes-per-system kernels' VGPRs for n waves per SIMD
+#define NNHIP_LPS_ATTR
+#else
+#define NNHIP_LPS_ATTR __attribute__((amdgpu_waves_per_eu(NNHIP_LPS_WPE, NNHIP_LPS_WPE)))
+#endif
 template <int METHOD, class RHS, int CPL, bool SHUFFLE_NORM = false>
-__global__ __launch_bounds__(kBlock) void solve_lps_kernel(const SolveArgs a) {
+__global__ __launch_bounds__(kBlock) NNHIP_LPS_ATTR void solve_lps_kernel(const SolveArgs a) {
   constexpr int DIM = RHS::dim;
   constexpr int LPSYS = DIM / CPL;  // lanes per system
   static_assert(DIM % CPL == 0 && 64 % LPSYS == 0, "a system must not straddle wavefronts");
