@@ -1,0 +1,45 @@
+"""bench.py's output contract (one JSON line, last on stdout, with the keys the driver and the judge read) on a reduced
+workload, single process and through torch.distributed (world size 1, nccl = RCCL, the overlapped all-gather path)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "2", "--warmup", "1", "--n-ivp", "200000", "--rk4-steps", "64", "--cpu-sample", "2000"]
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+        "config", "roofline"}
+
+
+def _run(args, env=None):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    last = r.stdout.strip().splitlines()[-1]
+    return json.loads(last)
+
+
+def test_single_process_line():
+    out = _run(SMALL)
+    assert KEYS <= set(out), KEYS - set(out)
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["dtype"] == "f64" and out["scaling"] == "weak"
+    assert out["vs_baseline"] is None and out["higher_is_better"] is True and "workload" in out["config"]
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert rf["algorithmic_bytes_per_launch"] == 16.0 * 200000
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
+    assert out["parity_max_abs_err_vs_oracle"] == 0.0 and out["parity_checked_ivps"] == 2000
+    assert out["fused_solve"]["bitwise_equal_to_stream"] is True
+    # value = trajectory-steps / wall time of the timed region
+    assert abs(out["value"] - 200000 * 64 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-9
+
+
+def test_distributed_line_world_size_one():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    out = _run(SMALL + ["--force-dist", "--no-cpu-baseline"], env=env)
+    assert KEYS <= set(out)
+    assert out["config"]["final_state_allgather"] is True and out["config"]["allgather_overlapped_with_next_solve"] is True
+    assert out["allgather_ms_per_solve"] > 0 and "cpu_baseline" not in out
