@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=float, default=1e6, help="IVPs in the CPU-baseline sample (1e6 x 1000 steps = ~16 s on one core)")
     ap.add_argument("--no-fused", action="store_true", help="skip the informational fused-solve measurement")
+    ap.add_argument("--verify-gathers", action="store_true",
+                    help="debug: after every overlapped all-gather completes, compare this rank's slice of the gathered tensor with the "
+                         "solve result it was issued for (checks the buffer rotation; adds a device comparison per solve)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity comparison inside the cpu_baseline leg and the all-gather placement check")
     return ap.parse_args()
 
@@ -88,15 +91,21 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     comm_stream = torch.cuda.Stream() if overlap else None
     pending = [None] * nset  # outstanding all-gather reading buffer set s
-    state = {"i": 0}
+    state = {"i": 0, "expected": None, "verified": 0}
+
+    def finish(q):  # wait for the all-gather that reads buffer set q
+        pending[q].wait()
+        pending[q] = None
+        if args.verify_gathers and state["expected"] is not None:
+            assert torch.equal(gathered[lo:hi], state["expected"]), "an overlapped all-gather read a buffer that was being overwritten"
+            state["verified"] += 1
 
     def one_solve(k=None):
         s = state["i"] % nset
         state["i"] += 1
         for q in ((s, (s + 1) % 3) if rotate3 else (s,)):  # buffers about to be overwritten must have been gathered
             if pending[q] is not None:
-                pending[q].wait()
-                pending[q] = None
+                finish(q)
         y = ys[s]
         y.copy_(y0)  # solveODE starts from y0 (y0.clone(), ode.nim:482)
         if k is not None:
@@ -105,6 +114,8 @@ def main():
         if k is not None:
             ev[k][1].record()
         assert ns == nsteps, (ns, nsteps)
+        if args.verify_gathers and state["expected"] is None:
+            state["expected"] = yf.clone()  # every solve starts from the same y0, so every result equals the first one
         if gathered is not None:
             if overlap:
                 done = torch.cuda.Event()
@@ -119,8 +130,7 @@ def main():
     def drain():
         for s in range(nset):
             if pending[s] is not None:
-                pending[s].wait()
-                pending[s] = None
+                finish(s)
 
     def sync_all():
         drain()
@@ -207,6 +217,8 @@ def main():
     }
     if gather_ms is not None:
         out["allgather_ms_per_solve"] = gather_ms
+    if args.verify_gathers:
+        out["gathers_verified"] = state["verified"]
 
     # ---- informational: the fused whole-solve kernel (FP64-VALU bound; the HBM roofline does not apply) ----
     if not args.no_fused:

@@ -39,7 +39,8 @@ def test_single_process_line():
 
 def test_distributed_line_world_size_one():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
-    out = _run(SMALL + ["--force-dist", "--no-cpu-baseline"], env=env)
+    out = _run(SMALL + ["--force-dist", "--no-cpu-baseline", "--verify-gathers"], env=env)
     assert KEYS <= set(out)
+    assert out["gathers_verified"] == 3  # warmup + 2 timed solves, each gather checked against the solve it belongs to
     assert out["config"]["final_state_allgather"] is True and out["config"]["allgather_overlapped_with_next_solve"] is True
     assert out["allgather_ms_per_solve"] > 0 and "cpu_baseline" not in out
