@@ -114,7 +114,7 @@ int nnhip_ode_integrator_traits(int integrator, int* use_fsal, double* order, in
 int nnhip_ode_time_grid(const nnhip_ode_options* opt, const double* tspan, int n_t, double* t_out, int* n_t_out);
 /* Is there a kernel for this combination?  1 / 0.  mode: 0 fused solve, 1 step-streaming.  Ahead-of-time kernels cover the
  * sizes of the reference's tests and of the BASELINE configs (dims 1-4, Lorenz, Van der Pol, 8/16/32-component systems); the
- * size-generic kinds NEG_Y, LINEAR, AFFINE_T and RING also run at every other dim in 1..16 and at 32 (the reference's
+ * size-generic kinds NEG_Y, LINEAR, AFFINE_T and RING also run at every other dim in 1..256 (the reference's
  * Vector[float] has any length): those sizes are instantiated at run time from the same expressions on first use (hiprtc). */
 int nnhip_ode_supported(int integrator, int rhs_kind, int dim, int layout, int mode);
 
@@ -206,9 +206,10 @@ int nnhip_ode_solve_batch_multi_gpu_f64(const nnhip_ode_options* opt, int integr
 int nnhip_ode_rhs_compile(const char* name, int dim, int n_params, const char* body, int* rhs_kind_out);
 /* Per-component form: `comp_body` is the body of
  *     __device__ double rhs_comp(double t, int c, const double* y, const double* p)   // returns dy_c
- * e.g. "return -((c+1)/16.0)*y[c] + p[0]*y[(c+1)%16];".  Systems of 8, 16 or 32 components given this way run on the
- * lanes-per-system kernels (stage vector in LDS, several lanes of one wavefront per system); dim 1..16 otherwise
- * thread-per-IVP. */
+ * e.g. "return -((c+1)/16.0)*y[c] + p[0]*y[(c+1)%16];" (`dim` is visible in the body).  dim 1..256: systems of 8 or 16
+ * components and every system wider than 16 run on the lanes-per-system kernels (stage vector in LDS, up to a whole
+ * wavefront of lanes x 4 components per system; sizes that are not a power of two use the next one with the tail slots
+ * switched off); the other sizes up to 16 run thread-per-IVP. */
 int nnhip_ode_rhs_compile_comp(const char* name, int dim, int n_params, const char* comp_body, int* rhs_kind_out);
 int nnhip_ode_rhs_release(int rhs_kind);
 

@@ -283,7 +283,7 @@ int nnhip_ode_rhs_compile(const char* name, int dim, int n_params, const char* b
 
 int nnhip_ode_rhs_compile_comp(const char* name, int dim, int n_params, const char* comp_body, int* rhs_kind_out) {
   if (!comp_body || !rhs_kind_out) return fail(NNHIP_EVALUE, "comp_body / rhs_kind_out is NULL");
-  if (!((dim >= 1 && dim <= 16) || dim == 32)) return fail(NNHIP_EVALUE, "per-component user RHS: dim must be in [1, 16] or 32");
+  if (dim < 1 || dim > 256) return fail(NNHIP_EVALUE, "per-component user RHS: dim must be in [1, 256]");
   if (n_params < 0 || n_params > nnhip::kMaxParams) return fail(NNHIP_EVALUE, "n_params must be in [0, %d]", nnhip::kMaxParams);
   const int k = nnhip::rtc_register(name, dim, n_params, comp_body, true, true);
   if (k < 0) return fail(NNHIP_EVALUE, "%s", nnhip::rtc_last_error());

@@ -124,6 +124,7 @@ int cumquad_fn(int rule, int rhs_kind, const double* rhs_params, int n_params, c
     return fail_msg(NNHIP_EVALUE, "%s(f, X): bad argument", what);
   for (int j = 0; j < n_x; ++j)
     if (!std::isfinite(X[j])) return fail_msg(NNHIP_EVALUE, "%s(f, X): X[%d] is not finite", what, j);
+  if (dim > 16) return fail_msg(NNHIP_EUNSUPPORTED, "%s(f, X): integrands of more than 16 components are not supported (thread-per-item kernels)", what);
   if (!(dx > 0.0) || !std::isfinite(dx)) return fail_msg(NNHIP_EVALUE, "%s(f, X): dx must be a positive finite number (the reference's march would not end)", what);
   const double lo = *std::min_element(X, X + n_x), hi = *std::max_element(X, X + n_x);
   hipStream_t s = (hipStream_t)stream;

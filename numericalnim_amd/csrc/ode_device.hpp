@@ -134,10 +134,18 @@ struct RhsRing {  // dy_c = -((c+1)/d)*y_c + p0*y_{(c+1) mod d}
 //         error norm is reduced across the DIM lanes through LDS in the reference's left-to-right order
 //         (every lane of a system gets the bit-identical `error`, so the group stays in lock-step).
 // ------------------------------------------------------------------------------------------------
+// A right-hand side may declare fewer real components (`size`) than lanes are laid out for (`dim`, a power of two): systems
+// of any length then run on the lanes-per-system kernels with the tail components switched off.
+template <class R, class = void>
+struct RhsSize { static constexpr int value = R::dim; };
+template <class R>
+struct RhsSize<R, decltype((void)R::size)> { static constexpr int value = R::size; };
+
 template <class RHS, bool NEG>
 struct TpiOps {
   static constexpr int D = RHS::dim;
   const Params& P;
+  NNHIP_DEV static constexpr bool owns(int) { return true; }  // every component slot of the lane is a real component
   NNHIP_DEV void rhs(double t, const double (&y)[D], double (&dy)[D]) const {
     if constexpr (NEG) {
       RHS::eval(-t, y, dy, P);
@@ -170,18 +178,23 @@ NNHIP_DEV void wave_lds_sync() {
 template <class RHS, bool NEG, int CPL = 1, bool SHUFFLE_NORM = false>
 struct LpsOps {
   static constexpr int D = CPL;            // components per lane
-  static constexpr int DIM = RHS::dim;     // components per system; DIM / CPL lanes of one wavefront share a system
+  static constexpr int DIM = RHS::dim;     // component slots per system; DIM / CPL lanes of one wavefront share a system
+  static constexpr int SIZE = RhsSize<RHS>::value;  // real components (<= DIM); slots SIZE..DIM-1 stay 0 and touch no memory
   const Params& P;
   double* ys;  // LDS, DIM doubles: stage argument vector of this lane's system
   double* es;  // LDS, DIM doubles: squared scaled error components
   int c0;      // first component owned by this lane (owns c0 .. c0+CPL-1)
+  NNHIP_DEV bool owns(int j) const {
+    if constexpr (SIZE == DIM) return true;
+    else return c0 + j < SIZE;
+  }
   NNHIP_DEV void rhs(double t, const double (&y)[CPL], double (&dy)[CPL]) const {
 #pragma unroll
     for (int j = 0; j < CPL; ++j) ys[c0 + j] = y[j];
     wave_lds_sync();
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
-      const double v = RHS::comp(NEG ? -t : t, c0 + j, ys, P);
+      const double v = owns(j) ? RHS::comp(NEG ? -t : t, c0 + j, ys, P) : 0.0;
       dy[j] = NEG ? -v : v;
     }
     wave_lds_sync();  // the next stage overwrites ys
@@ -199,17 +212,17 @@ struct LpsOps {
       // left-to-right sum, so `error` can differ in the last ulp (all lanes of a system still get identical bits).
       double part = 0.0;
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) part = part + es[c0 + j];
+      for (int j = 0; j < CPL; ++j) part = part + (owns(j) ? es[c0 + j] : 0.0);
 #pragma unroll
       for (int off = 1; off < DIM / CPL; off <<= 1) part = part + __shfl_xor(part, off, 64);
-      return sqrt(1.0 / (double)DIM * part);
+      return sqrt(1.0 / (double)SIZE * part);
     } else {
       wave_lds_sync();
       double sum = 0.0;
 #pragma unroll
-      for (int j = 0; j < DIM; ++j) sum = sum + es[j];  // same left-to-right order as utils.nim:233-235
+      for (int j = 0; j < SIZE; ++j) sum = sum + es[j];  // same left-to-right order as utils.nim:233-235
       wave_lds_sync();
-      return sqrt(1.0 / (double)DIM * sum);
+      return sqrt(1.0 / (double)SIZE * sum);
     }
   }
 };

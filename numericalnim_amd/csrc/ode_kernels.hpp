@@ -139,7 +139,7 @@ NNHIP_DEV void solve_body(const SolveArgs& a, const OpsF& opsF, const OpsB& opsB
   constexpr int D = OpsF::D;
   double y0[D];
 #pragma unroll
-  for (int c = 0; c < D; ++c) y0[c] = y0p[c * a.compStride];
+  for (int c = 0; c < D; ++c) y0[c] = opsF.owns(c) ? y0p[c * a.compStride] : 0.0;
   int rowBase = 0;
   int status = 0;
   DriveIn in;
@@ -166,7 +166,8 @@ NNHIP_DEV void solve_body(const SolveArgs& a, const OpsF& opsF, const OpsB& opsB
                         [=](int k, const double(&yv)[D]) {
                           if (k < nNeg) {
 #pragma unroll
-                            for (int c = 0; c < D; ++c) out[(int64_t)(nNeg - 1 - k) * rs + c * cs] = yv[c];
+                            for (int c = 0; c < D; ++c)
+                              if (opsF.owns(c)) out[(int64_t)(nNeg - 1 - k) * rs + c * cs] = yv[c];
                           }
                         },
                         o);
@@ -175,7 +176,8 @@ NNHIP_DEV void solve_body(const SolveArgs& a, const OpsF& opsF, const OpsB& opsB
       const int shift = nNeg - m;
       for (int j = 0; j < m; ++j)
 #pragma unroll
-        for (int c = 0; c < D; ++c) out[(int64_t)j * rs + c * cs] = out[(int64_t)(j + shift) * rs + c * cs];
+        for (int c = 0; c < D; ++c)
+          if (opsF.owns(c)) out[(int64_t)j * rs + c * cs] = out[(int64_t)(j + shift) * rs + c * cs];
     }
     rowBase = m;
     status |= o.status;
@@ -184,7 +186,8 @@ NNHIP_DEV void solve_body(const SolveArgs& a, const OpsF& opsF, const OpsB& opsB
   }
   if (a.nZero > 0) {  // `if t0 in tspan` (ode.nim:485-487)
 #pragma unroll
-    for (int c = 0; c < D; ++c) out[(int64_t)rowBase * rs + c * cs] = y0[c];
+    for (int c = 0; c < D; ++c)
+      if (opsF.owns(c)) out[(int64_t)rowBase * rs + c * cs] = y0[c];
     rowBase += 1;
   }
   if (a.nPos > 0) {  // ode.nim:508-542
@@ -203,7 +206,8 @@ NNHIP_DEV void solve_body(const SolveArgs& a, const OpsF& opsF, const OpsB& opsB
                          [=](int k, const double(&yv)[D]) {
                            if (k < nPos) {
 #pragma unroll
-                             for (int c = 0; c < D; ++c) out[(int64_t)(rb + k) * rs + c * cs] = yv[c];
+                             for (int c = 0; c < D; ++c)
+                               if (opsF.owns(c)) out[(int64_t)(rb + k) * rs + c * cs] = yv[c];
                            }
                          },
                          o);
@@ -215,7 +219,8 @@ NNHIP_DEV void solve_body(const SolveArgs& a, const OpsF& opsF, const OpsB& opsB
   const double qnan = __longlong_as_double(0x7ff8000000000000LL);
   for (int j = rowBase; j < a.n_t; ++j)
 #pragma unroll
-    for (int c = 0; c < D; ++c) out[(int64_t)j * rs + c * cs] = qnan;
+    for (int c = 0; c < D; ++c)
+      if (opsF.owns(c)) out[(int64_t)j * rs + c * cs] = qnan;
   ls.ny = rowBase;
   ls.nanAb = (status & kStatusNaN) ? 1 : 0;
   ls.trunc = (status & 2) ? 1 : 0;
@@ -328,7 +333,7 @@ NNHIP_DEV void step_body(const StepArgs& a, const Ops& ops, int64_t i, int64_t b
   constexpr int D = Ops::D;
   double y[D], yNew[D];
 #pragma unroll
-  for (int c = 0; c < D; ++c) y[c] = a.y_in[base + c * a.compStride];
+  for (int c = 0; c < D; ++c) y[c] = ops.owns(c) ? a.y_in[base + c * a.compStride] : 0.0;
   const double t = a.t_dev ? a.t_dev[i] : a.t_uniform;
   double dt = a.dt_dev ? a.dt_dev[i] : a.dt_uniform;
   double error = 0.0;
@@ -336,29 +341,33 @@ NNHIP_DEV void step_body(const StepArgs& a, const Ops& ops, int64_t i, int64_t b
     rk4_step(ops, t, rk4_dt(dt), y, yNew);
     if (a.fsal_out) {  // fixed-step methods return yNew in the FSAL slot (ode.nim:189)
 #pragma unroll
-      for (int c = 0; c < D; ++c) a.fsal_out[base + c * a.compStride] = yNew[c];
+      for (int c = 0; c < D; ++c)
+        if (ops.owns(c)) a.fsal_out[base + c * a.compStride] = yNew[c];
     }
   } else if constexpr (!MethodTraits<METHOD>::adaptive) {
     fixed_step<METHOD>(ops, t, dt, y, yNew);
     if (a.fsal_out) {
 #pragma unroll
-      for (int c = 0; c < D; ++c) a.fsal_out[base + c * a.compStride] = yNew[c];
+      for (int c = 0; c < D; ++c)
+        if (ops.owns(c)) a.fsal_out[base + c * a.compStride] = yNew[c];
     }
   } else {
     double fsal[D];
     if constexpr (has_tableau(METHOD)) {  // only the tableau methods read FSAL (k1 = FSAL); RK21 / BS32 ignore it
 #pragma unroll
-      for (int c = 0; c < D; ++c) fsal[c] = a.fsal_in[base + c * a.compStride];
+      for (int c = 0; c < D; ++c) fsal[c] = ops.owns(c) ? a.fsal_in[base + c * a.compStride] : 0.0;
     }
     int64_t rej = 0;
     embedded_step<METHOD>(ops, t, dt, y, fsal, yNew, error, a.ctl, rej);
     if (a.fsal_out) {
 #pragma unroll
-      for (int c = 0; c < D; ++c) a.fsal_out[base + c * a.compStride] = fsal[c];
+      for (int c = 0; c < D; ++c)
+        if (ops.owns(c)) a.fsal_out[base + c * a.compStride] = fsal[c];
     }
   }
 #pragma unroll
-  for (int c = 0; c < D; ++c) a.y_out[base + c * a.compStride] = yNew[c];
+  for (int c = 0; c < D; ++c)
+    if (ops.owns(c)) a.y_out[base + c * a.compStride] = yNew[c];
   if (writeScalars) {
     if (a.dt_used) a.dt_used[i] = dt;
     if (a.error) a.error[i] = error;
@@ -451,15 +460,17 @@ hipError_t launch_advance_tpi(const StepArgs& a, int, hipStream_t s) {
 }
 #endif
 
-template <int METHOD, class RHS, bool NEG>
+template <int METHOD, class RHS, bool NEG, int CPL = 1>
 __global__ __launch_bounds__(kBlock) void step_lps_kernel(const StepArgs a) {
   constexpr int DIM = RHS::dim;
-  __shared__ double lds[2 * kBlock];
-  const int sysInBlock = threadIdx.x / DIM, c = threadIdx.x % DIM;
-  const int64_t i = (int64_t)blockIdx.x * (kBlock / DIM) + sysInBlock;
+  constexpr int LPSYS = DIM / CPL;  // lanes per system (CPL > 1 only for systems wider than a wavefront)
+  static_assert(DIM % CPL == 0 && 64 % LPSYS == 0, "a system must not straddle wavefronts");
+  __shared__ double lds[2 * kBlock * CPL];
+  const int sysInBlock = threadIdx.x / LPSYS, c = (threadIdx.x % LPSYS) * CPL;
+  const int64_t i = (int64_t)blockIdx.x * (kBlock / LPSYS) + sysInBlock;
   if (i >= a.N) return;
   const Params P = params_of(a, i);
-  const LpsOps<RHS, NEG> ops{P, lds + sysInBlock * DIM, lds + kBlock + sysInBlock * DIM, c};
+  const LpsOps<RHS, NEG, CPL> ops{P, lds + sysInBlock * DIM, lds + kBlock * CPL + sysInBlock * DIM, c};
   step_body<METHOD>(a, ops, i, i * a.ivpStride + c * a.compStride, c == 0);
 }
 
@@ -537,15 +548,15 @@ __global__ __launch_bounds__(kBlock) void rk4_stream_vec_kernel(const double* __
 template <class RHS>
 __global__ __launch_bounds__(kBlock) void rhs_batch_kernel(int64_t N, int64_t ivpStride, int64_t compStride, double t,
                                                            const double* __restrict__ y, double* __restrict__ dy, const Params P) {
-  constexpr int D = RHS::dim;
+  constexpr int D = RHS::dim, SIZE = RhsSize<RHS>::value;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= N) return;
   double yv[D], d[D];
 #pragma unroll
-  for (int c = 0; c < D; ++c) yv[c] = y[i * ivpStride + c * compStride];
+  for (int c = 0; c < D; ++c) yv[c] = c < SIZE ? y[i * ivpStride + c * compStride] : 0.0;
   RHS::eval(t, yv, d, P);
 #pragma unroll
-  for (int c = 0; c < D; ++c) dy[i * ivpStride + c * compStride] = d[c];
+  for (int c = 0; c < SIZE; ++c) dy[i * ivpStride + c * compStride] = d[c];
 }
 
 #if !NNHIP_RTC

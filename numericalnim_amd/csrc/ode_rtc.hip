@@ -45,10 +45,26 @@ std::mutex g_mu;
 std::deque<UserRhsEntry> g_user;  // deque: registering a new RHS never moves existing entries (programs are handed out by pointer)
 thread_local std::string g_rtc_err;
 
+// Systems of 8 or 16 components, and every system wider than 16, given per component run on the lanes-per-system kernels:
+// component slots are laid out for the next power of two (32 / 64 / 128 / 256), the slots beyond the real size stay zero and
+// touch no memory (RhsSize, LpsOps::owns).  Everything else is thread-per-IVP.
+bool uses_lps(const UserRhsEntry& e) { return e.perComponent && (e.dim == 8 || e.dim == 16 || e.dim > 16); }
+int padded_dim(const UserRhsEntry& e) {
+  if (!uses_lps(e)) return e.dim;
+  int p = 8;
+  while (p < e.dim) p *= 2;
+  return p;
+}
+// components per lane: fused kernels from the A/B of the built-in systems (ode_kernels.hpp NNHIP_FOR_EACH_LPS_RHS); the
+// step-streaming kernels keep one component per lane until a system would no longer fit one wavefront
+int lps_cpl(const UserRhsEntry& e, bool adaptive) { return padded_dim(e) == 8 ? 2 : (padded_dim(e) >= 64 ? 4 : (adaptive ? 4 : 2)); }
+int lps_step_cpl(const UserRhsEntry& e) { return padded_dim(e) <= 64 ? 1 : padded_dim(e) / 64; }
+
 std::string make_source(const UserRhsEntry& e) {
   std::string s;
   s += "#include \"ode_kernels.hpp\"\n#include \"quad_kernels.hpp\"\n";
-  s += "namespace nnhip {\nstruct UserRhs {\n  static constexpr int dim = " + std::to_string(e.dim) + ";\n";
+  s += "namespace nnhip {\nstruct UserRhs {\n  static constexpr int dim = " + std::to_string(padded_dim(e)) + ";\n";
+  s += "  static constexpr int size = " + std::to_string(e.dim) + ";\n";
   if (!e.perComponent) {
     s += "  NNHIP_DEV static void eval(double t, const double (&y)[dim], double (&dy)[dim], const Params& P_) {\n";
     s += "    const double* p = P_.p; (void)p; (void)t;\n";
@@ -59,17 +75,14 @@ std::string make_source(const UserRhsEntry& e) {
   } else {
     s += "  NNHIP_DEV static double comp(double t, int c, const double* y, const Params& P_) {\n";
     s += "    const double* p = P_.p; (void)p; (void)t; (void)c;\n";
+    s += "    if (c >= size) return 0.0;\n";
+    s += "    constexpr int dim = size; (void)dim;  // inside the body `dim` is the real number of components\n";
     s += "    {\n" + e.body + "\n    }\n  }\n";
     s += "  NNHIP_DEV static void eval(double t, const double (&y)[dim], double (&dy)[dim], const Params& P_) {\n";
     s += "#pragma unroll\n    for (int c = 0; c < dim; ++c) dy[c] = comp(t, c, &y[0], P_);\n  }\n};\n}\n";
   }
   return s;
 }
-
-// Systems of 8 / 16 / 32 components given per component run on the lanes-per-system kernels (same components-per-lane
-// choice as the built-in RHS: ode_kernels.hpp NNHIP_FOR_EACH_LPS_RHS); everything else is thread-per-IVP.
-bool uses_lps(const UserRhsEntry& e) { return e.perComponent && (e.dim == 8 || e.dim == 16 || e.dim == 32); }
-int lps_cpl(const UserRhsEntry& e, bool adaptive) { return e.dim == 8 ? 2 : (adaptive ? 4 : 2); }
 
 bool compile(const UserRhsEntry& e, int integrator, Program& out) {
   const std::string src = make_source(e);
@@ -88,10 +101,11 @@ bool compile(const UserRhsEntry& e, int integrator, Program& out) {
       nnhip_ode_integrator_traits(integrator, nullptr, nullptr, &adaptive);
       const int cpl = lps_cpl(e, adaptive != 0);
       names.push_back("nnhip::solve_lps_kernel<" + m + ", nnhip::UserRhs, " + std::to_string(cpl) + ", false>");
-      names.push_back("nnhip::step_lps_kernel<" + m + ", nnhip::UserRhs, false>");
-      names.push_back("nnhip::step_lps_kernel<" + m + ", nnhip::UserRhs, true>");
-      out.ivpsPerBlockSolve = kBlock / (e.dim / cpl);
-      out.ivpsPerBlockStep = kBlock / e.dim;
+      const int scpl = lps_step_cpl(e);
+      names.push_back("nnhip::step_lps_kernel<" + m + ", nnhip::UserRhs, false, " + std::to_string(scpl) + ">");
+      names.push_back("nnhip::step_lps_kernel<" + m + ", nnhip::UserRhs, true, " + std::to_string(scpl) + ">");
+      out.ivpsPerBlockSolve = kBlock / (padded_dim(e) / cpl);
+      out.ivpsPerBlockStep = kBlock / (padded_dim(e) / scpl);
     } else {
       names.push_back("nnhip::solve_tpi_kernel<" + m + ", nnhip::UserRhs>");
       names.push_back("nnhip::step_tpi_kernel<" + m + ", nnhip::UserRhs, false>");
@@ -251,7 +265,7 @@ hipError_t rtc_launch_rhs(int rhs_kind, int64_t N, int64_t is, int64_t cs, doubl
 // first use, cached for the life of the process): dims 1..16 thread-per-IVP, 8 / 16 / 32 lanes-per-system.
 bool rtc_builtin_available(int rhs_kind, int dim) {
   if (!(rhs_kind == NNHIP_RHS_NEG_Y || rhs_kind == NNHIP_RHS_LINEAR || rhs_kind == NNHIP_RHS_AFFINE_T || rhs_kind == NNHIP_RHS_RING)) return false;
-  return (dim >= 1 && dim <= 16) || dim == 32;
+  return dim >= 1 && dim <= 256;
 }
 static std::mutex g_synth_mu;
 static std::map<std::pair<int, int>, int> g_synth;  // (built-in kind, dim) -> user rhs_kind

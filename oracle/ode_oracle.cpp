@@ -540,7 +540,8 @@ static int solveODE(const ODEProc<T>& f, const T& y0, const double* tspan, int n
 enum RhsKind { RHS_NEG_Y = 0, RHS_LINEAR = 1, RHS_LORENZ = 2, RHS_RING = 3, RHS_AFFINE_T = 4, RHS_VANDERPOL = 5,
                RHS_DUFFING = 6 /* oracle-only: checks run-time compiled user RHS */,
                RHS_COS_T = 7 /* oracle-only integrand a*cos(t): tests/test_integrate.nim:5-6 */,
-               RHS_POLY_T = 8 /* oracle-only integrand ((a t + b) t)(1 + c) + d for component c */ };
+               RHS_POLY_T = 8 /* oracle-only integrand ((a t + b) t)(1 + c) + d for component c */,
+               RHS_HEAT = 9 /* oracle-only: method-of-lines heat equation, checks wide run-time compiled systems */ };
 
 static double rhsScalar(double t, const double& y, const void* env) {
   const double* p = (const double*)env;  // p[0] = kind, p[1..] = params
@@ -587,6 +588,13 @@ static Vec rhsVector(double t, const Vec& y, const void* env) {
     }
     case RHS_COS_T: for (size_t i = 0; i < d; ++i) r.components[i] = p[1] * std::cos(t); break;  // tests/test_integrate.nim:6 (cos(x) * ctx["a"])
     case RHS_POLY_T: for (size_t i = 0; i < d; ++i) r.components[i] = ((p[1] * t + p[2]) * t) * (1.0 + (double)i) + p[3]; break;
+    case RHS_HEAT: {  // y_i' = kappa * ((y_{i-1} - 2 y_i) + y_{i+1}), zero boundary values; kappa = p[1]
+      for (size_t i = 0; i < d; ++i) {
+        const double left = i > 0 ? y.components[i - 1] : 0.0, right = i + 1 < d ? y.components[i + 1] : 0.0;
+        r.components[i] = p[1] * ((left - 2.0 * y.components[i]) + right);
+      }
+      break;
+    }
     default: for (size_t i = 0; i < d; ++i) r.components[i] = NAN;
   }
   return r;

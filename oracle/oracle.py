@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liboracle_ode.so")
 
 # RHS kinds — must match include/nnhip_ode.h (enum nnhip_rhs_kind)
-RHS_NEG_Y, RHS_LINEAR, RHS_LORENZ, RHS_RING, RHS_AFFINE_T, RHS_VANDERPOL, RHS_DUFFING, RHS_COS_T, RHS_POLY_T = range(9)  # DUFFING.. : oracle-only
+RHS_NEG_Y, RHS_LINEAR, RHS_LORENZ, RHS_RING, RHS_AFFINE_T, RHS_VANDERPOL, RHS_DUFFING, RHS_COS_T, RHS_POLY_T, RHS_HEAT = range(10)  # DUFFING.. : oracle-only
 LAYOUT_SOA, LAYOUT_AOS = 0, 1
 
 ALL_ODE = ["heun2", "ralston2", "kutta3", "heun3", "ralston3", "ssprk3", "ralston4", "kutta4", "rk4",

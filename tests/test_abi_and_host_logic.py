@@ -111,9 +111,9 @@ def test_supported_matrix(nn):
         assert L.nnhip_ode_supported(integ, R.LORENZ, 2, 0, 0) == 0
         assert L.nnhip_ode_supported(integ, R.LORENZ, 3, 0, 1) == 1
     assert L.nnhip_ode_supported(99, 0, 1, 0, 0) == 0
-    # size-generic kinds run at any dim in 1..16 and at 32 (run-time instantiation); beyond that, and for fixed-size systems, no
+    # size-generic kinds run at any dim in 1..256 (run-time instantiation); beyond that, and for fixed-size systems, no
     for kind, dim, ok in ((R.NEG_Y, 5, 1), (R.LINEAR, 13, 1), (R.AFFINE_T, 9, 1), (R.RING, 6, 1), (R.RING, 32, 1), (R.NEG_Y, 32, 1),
-                          (R.NEG_Y, 17, 0), (R.RING, 64, 0), (R.LORENZ, 5, 0), (R.VANDERPOL, 3, 0)):
+                          (R.NEG_Y, 17, 1), (R.RING, 64, 1), (R.LINEAR, 256, 1), (R.RING, 257, 0), (R.LORENZ, 5, 0), (R.VANDERPOL, 3, 0)):
         assert L.nnhip_ode_supported(1, kind, dim, 0, 0) == ok and L.nnhip_ode_supported(1, kind, dim, 0, 1) == ok, (kind, dim)
 
 
