@@ -12,4 +12,5 @@ timeout 300 python scripts/bench_configs.py > gpurun_out/bench_configs.log 2>&1
 timeout 300 python scripts/bench_extra.py > gpurun_out/bench_extra.log 2>&1
 timeout 300 python scripts/bench_adaptive_stream.py > gpurun_out/bench_adaptive_stream.log 2>&1
 timeout 300 python scripts/bench_cumquad.py > gpurun_out/bench_cumquad.log 2>&1
+timeout 300 python scripts/bench_wide.py > gpurun_out/bench_wide.log 2>&1
 echo "then, in the build container: python scripts/summarize_profiles.py --round N; python scripts/summarize_configs_pmc.py --round N   (summaries into profiles/)"

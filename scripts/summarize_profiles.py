@@ -63,7 +63,7 @@ def main():
                     "dispatches_sampled": len(vals["FETCH_SIZE"]),
                     "correction": "FETCH_SIZE KiB*1024*2 (gfx950 wide-read half-count), WRITE_SIZE KiB*1024; separate --pmc passes"})
     # the benchmark logs of the same gpurun call: keep the JSON each script printed (its last '{'-line)
-    for name in ("bench_default", "bench_configs", "bench_extra", "bench_adaptive_stream", "bench_cumquad"):
+    for name in ("bench_default", "bench_configs", "bench_extra", "bench_adaptive_stream", "bench_cumquad", "bench_wide"):
         lp = os.path.join(a.src, name + ".log")
         if not os.path.exists(lp):
             continue
