@@ -28,17 +28,23 @@ const Header kHeaders[] = {
 #include "embedded_headers.inc"
 };
 
-struct Program {
+struct Program {  // the kernels of one (rhs, integrator) code object as loaded on ONE device
   hipModule_t module = nullptr;
   hipFunction_t solve = nullptr, stepPos = nullptr, stepNeg = nullptr, rhs = nullptr, quad[2] = {nullptr, nullptr};
   int ivpsPerBlockSolve = kBlock, ivpsPerBlockStep = kBlock;  // thread-per-IVP: 256; lanes-per-system: 256 / lanes per system
+};
+struct CodeObject {  // compiled once per (rhs, integrator); hipModuleLoadData binds it to the device that is current at the time
+  std::vector<char> code;
+  std::vector<std::string> lowered;
+  int ivpsPerBlockSolve = kBlock, ivpsPerBlockStep = kBlock;
+  std::map<int, Program> loaded;  // by device ordinal
 };
 struct UserRhsEntry {
   std::string name, body;
   int dim = 0, n_params = 0;
   bool perComponent = false;  // body computes ONE component (usable by the lanes-per-system kernels) instead of the whole vector
   bool alive = false;
-  std::map<int, Program> programs;  // by integrator; key -1 = the rhs_batch kernel only, key -2 = the cumulative-quadrature kernels
+  std::map<int, CodeObject> programs;  // by integrator; key -1 = the rhs_batch kernel only, key -2 = the cumulative-quadrature kernels
 };
 
 std::mutex g_mu;
@@ -84,7 +90,7 @@ std::string make_source(const UserRhsEntry& e) {
   return s;
 }
 
-bool compile(const UserRhsEntry& e, int integrator, Program& out) {
+bool compile(const UserRhsEntry& e, int integrator, CodeObject& out) {
   const std::string src = make_source(e);
   hiprtcProgram prog;
   std::vector<const char*> hsrc, hname;
@@ -132,9 +138,9 @@ bool compile(const UserRhsEntry& e, int integrator, Program& out) {
   }
   size_t codeSize = 0;
   hiprtcGetCodeSize(prog, &codeSize);
-  std::vector<char> code(codeSize);
-  hiprtcGetCode(prog, code.data());
-  std::vector<std::string> lowered;
+  out.code.resize(codeSize);
+  hiprtcGetCode(prog, out.code.data());
+  out.lowered.clear();
   for (auto& n : names) {
     const char* ln = nullptr;
     if (hiprtcGetLoweredName(prog, n.c_str(), &ln) != HIPRTC_SUCCESS || !ln) {
@@ -142,19 +148,27 @@ bool compile(const UserRhsEntry& e, int integrator, Program& out) {
       hiprtcDestroyProgram(&prog);
       return false;
     }
-    lowered.push_back(ln);
+    out.lowered.push_back(ln);
   }
   hiprtcDestroyProgram(&prog);
-  if (hipModuleLoadData(&out.module, code.data()) != hipSuccess) {
+  return true;
+}
+
+bool load(const CodeObject& co, int integrator, Program& out) {
+  out.ivpsPerBlockSolve = co.ivpsPerBlockSolve;
+  out.ivpsPerBlockStep = co.ivpsPerBlockStep;
+  if (hipModuleLoadData(&out.module, co.code.data()) != hipSuccess) {
     g_rtc_err = "hipModuleLoadData failed (no HIP device?)";
     return false;
   }
   hipFunction_t* slots[3] = {&out.solve, &out.stepPos, &out.stepNeg};
   if (integrator == -1) slots[0] = &out.rhs;
   if (integrator == -2) { slots[0] = &out.quad[0]; slots[1] = &out.quad[1]; }
-  for (size_t i = 0; i < lowered.size(); ++i)
-    if (hipModuleGetFunction(slots[i], out.module, lowered[i].c_str()) != hipSuccess) {
-      g_rtc_err = "hipModuleGetFunction failed for " + lowered[i];
+  for (size_t i = 0; i < co.lowered.size(); ++i)
+    if (hipModuleGetFunction(slots[i], out.module, co.lowered[i].c_str()) != hipSuccess) {
+      g_rtc_err = "hipModuleGetFunction failed for " + co.lowered[i];
+      (void)hipModuleUnload(out.module);
+      out.module = nullptr;
       return false;
     }
   return true;
@@ -162,13 +176,21 @@ bool compile(const UserRhsEntry& e, int integrator, Program& out) {
 
 Program* get_program(int rhs_kind, int integrator) {
   const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) { g_rtc_err = "hipGetDevice failed (no HIP device?)"; return nullptr; }
   std::lock_guard<std::mutex> lk(g_mu);
   if (idx < 0 || idx >= (int)g_user.size() || !g_user[idx].alive) { g_rtc_err = "unknown user rhs_kind"; return nullptr; }
   auto it = g_user[idx].programs.find(integrator);
-  if (it != g_user[idx].programs.end()) return &it->second;
+  if (it == g_user[idx].programs.end()) {
+    CodeObject co;
+    if (!compile(g_user[idx], integrator, co)) return nullptr;
+    it = g_user[idx].programs.emplace(integrator, std::move(co)).first;
+  }
+  auto ld = it->second.loaded.find(device);
+  if (ld != it->second.loaded.end()) return &ld->second;
   Program p;
-  if (!compile(g_user[idx], integrator, p)) return nullptr;
-  return &(g_user[idx].programs[integrator] = p);
+  if (!load(it->second, integrator, p)) return nullptr;
+  return &(it->second.loaded[device] = p);
 }
 
 }  // namespace
@@ -214,7 +236,9 @@ int rtc_release(int rhs_kind) {
   const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
   std::lock_guard<std::mutex> lk(g_mu);
   if (idx < 0 || idx >= (int)g_user.size() || !g_user[idx].alive) return -1;
-  for (auto& kv : g_user[idx].programs) if (kv.second.module) (void)hipModuleUnload(kv.second.module);
+  for (auto& kv : g_user[idx].programs)
+    for (auto& ld : kv.second.loaded)
+      if (ld.second.module) (void)hipModuleUnload(ld.second.module);
   g_user[idx].programs.clear();
   g_user[idx].alive = false;
   return 0;

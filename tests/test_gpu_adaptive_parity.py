@@ -336,6 +336,15 @@ def test_multi_gpu_c_entry_single_device(nn, oracle, dev, layout):
     assert L.nnhip_ode_solve_batch_multi_gpu_f64(C.byref(opt), 1, 2, p.ctypes.data_as(dp), 3, y0l.ctypes.data, n, dim, layout,
                                                  ts.ctypes.data_as(dp), len(ts), t_out.ctypes.data_as(dp), out.ctypes.data, ny.ctypes.data, 0,
                                                  C.byref(st), 9) != 0  # more GPUs than the box has -> refused
+    # a run-time compiled right-hand side through the same entry (its code object is loaded per device by the worker threads)
+    f = nn.Rhs.custom(3, "dy[0] = p[0] * (y[1] - y[0]); dy[1] = y[0] * (p[1] - y[2]) - y[1]; dy[2] = y[0] * y[1] - p[2] * y[2];",
+                      keys=("sigma", "rho", "beta"), name="lorenz_mg")
+    out2 = np.empty_like(out)
+    rc = L.nnhip_ode_solve_batch_multi_gpu_f64(C.byref(opt), 1, f.kind, p.ctypes.data_as(dp), 3, y0l.ctypes.data, n, dim, layout,
+                                               ts.ctypes.data_as(dp), len(ts), t_out.ctypes.data_as(dp), out2.ctypes.data, ny.ctypes.data, 0,
+                                               C.byref(st), 1)
+    assert rc == 0, nn._lib.last_error()
+    assert np.array_equal(out2, out, equal_nan=True)  # same expressions as the compiled-in Lorenz system: same bits
 
 
 def test_fp_contract_opt_in_stays_within_north_star_tolerance(nn, oracle, dev):
