@@ -739,14 +739,16 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
   int rc = check_common(opt, integrator, rhs_kind, rhs_params, n_params, N, dim, layout, P);
   if (rc) return rc;
   if (!kMethods[integrator].adaptive) return fail(NNHIP_EVALUE, "nnhip_ode_adaptive_stream_f64_dev needs an adaptive integrator");
-  if (rhs_kind >= NNHIP_RHS_USER_BASE) return fail(NNHIP_EUNSUPPORTED, "user RHS: use the fused solve or the step entry");
   if (!std::isfinite(t0) || !std::isfinite(tEnd)) return fail(NNHIP_EVALUE, "t0 / tEnd must be finite");
   if (!(opt->dtMin > 0.0) && max_launches <= 0) return fail(NNHIP_EVALUE, "adaptive integrators need options.dtMin > 0 or max_launches > 0");
   if (launches_out) *launches_out = 0;
   if (N == 0 || !(t0 < tEnd)) return NNHIP_OK;
   if (!y || !ws || ws_bytes < nnhip_ode_adaptive_stream_workspace_bytes(N, dim)) return fail(NNHIP_EVALUE, "y / workspace missing or too small");
-  nnhip::StepLaunchFn fn = find_advance(integrator, rhs_kind, dim);
-  if (!fn) return fail(NNHIP_EUNSUPPORTED, "no advance kernel for integrator=%s rhs_kind=%d dim=%d", kMethods[integrator].name, rhs_kind, dim);
+  int userKind = rhs_kind >= NNHIP_RHS_USER_BASE ? rhs_kind : -1;
+  nnhip::StepLaunchFn fn = userKind >= 0 ? nullptr : find_advance(integrator, rhs_kind, dim);
+  if (!fn && userKind < 0) userKind = nnhip::rtc_builtin_kind(rhs_kind, dim);  // built-in kind at a size without an ahead-of-time kernel
+  if (!fn && (userKind < 0 || !nnhip::rtc_is_thread_per_ivp(userKind)))
+    return fail(NNHIP_EUNSUPPORTED, "no advance kernel for integrator=%s rhs_kind=%d dim=%d (thread-per-IVP right-hand sides only)", kMethods[integrator].name, rhs_kind, dim);
   hipStream_t s = (hipStream_t)stream;
   double* fsal = (double*)ws;
   double* tArr = fsal + N * dim;
@@ -772,7 +774,8 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
       const bool last = k == check_every - 1;  // only the last launch of a group reports whether work is left
       if (last) HIP_TRY(hipMemsetAsync(active, 0, sizeof(h), s));
       a.active = last ? active : nullptr;
-      HIP_TRY(fn(a, 0, s));
+      if (fn) HIP_TRY(fn(a, 0, s));
+      else if (nnhip::rtc_launch_advance(userKind, integrator, a, s) != hipSuccess) return fail(NNHIP_EHIP, "user RHS launch failed: %s", nnhip::rtc_last_error());
       ++launches;
     }
     HIP_TRY(hipMemcpyAsync(h, active, sizeof(h), hipMemcpyDeviceToHost, s));

@@ -30,7 +30,7 @@ const Header kHeaders[] = {
 
 struct Program {  // the kernels of one (rhs, integrator) code object as loaded on ONE device
   hipModule_t module = nullptr;
-  hipFunction_t solve = nullptr, stepPos = nullptr, stepNeg = nullptr, rhs = nullptr, quad[2] = {nullptr, nullptr};
+  hipFunction_t solve = nullptr, stepPos = nullptr, stepNeg = nullptr, advance = nullptr, rhs = nullptr, quad[2] = {nullptr, nullptr};
   int ivpsPerBlockSolve = kBlock, ivpsPerBlockStep = kBlock;  // thread-per-IVP: 256; lanes-per-system: 256 / lanes per system
 };
 struct CodeObject {  // compiled once per (rhs, integrator); hipModuleLoadData binds it to the device that is current at the time
@@ -116,6 +116,9 @@ bool compile(const UserRhsEntry& e, int integrator, CodeObject& out) {
       names.push_back("nnhip::solve_tpi_kernel<" + m + ", nnhip::UserRhs>");
       names.push_back("nnhip::step_tpi_kernel<" + m + ", nnhip::UserRhs, false>");
       names.push_back("nnhip::step_tpi_kernel<" + m + ", nnhip::UserRhs, true>");
+      int adaptive = 0;
+      nnhip_ode_integrator_traits(integrator, nullptr, nullptr, &adaptive);
+      if (adaptive) names.push_back("nnhip::advance_tpi_kernel<" + m + ", nnhip::UserRhs>");  // 4th kernel: adaptive streaming
     }
   } else if (integrator == -2) {
     names.push_back("nnhip::cumtrapz_fn_kernel<nnhip::UserRhs>");
@@ -161,7 +164,7 @@ bool load(const CodeObject& co, int integrator, Program& out) {
     g_rtc_err = "hipModuleLoadData failed (no HIP device?)";
     return false;
   }
-  hipFunction_t* slots[3] = {&out.solve, &out.stepPos, &out.stepNeg};
+  hipFunction_t* slots[4] = {&out.solve, &out.stepPos, &out.stepNeg, &out.advance};
   if (integrator == -1) slots[0] = &out.rhs;
   if (integrator == -2) { slots[0] = &out.quad[0]; slots[1] = &out.quad[1]; }
   for (size_t i = 0; i < co.lowered.size(); ++i)
@@ -244,6 +247,12 @@ int rtc_release(int rhs_kind) {
   return 0;
 }
 
+bool rtc_is_thread_per_ivp(int rhs_kind) {
+  const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
+  std::lock_guard<std::mutex> lk(g_mu);
+  return idx >= 0 && idx < (int)g_user.size() && g_user[idx].alive && !uses_lps(g_user[idx]);
+}
+
 bool rtc_info(int rhs_kind, int* dim, int* n_params) {
   const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
   std::lock_guard<std::mutex> lk(g_mu);
@@ -271,6 +280,13 @@ hipError_t rtc_launch_step(int rhs_kind, int integrator, const StepArgs& a, int 
   if (!p) return hipErrorInvalidValue;
   StepArgs copy = a;
   return launch(negate ? p->stepNeg : p->stepPos, a.N, p->ivpsPerBlockStep, &copy, s);
+}
+hipError_t rtc_launch_advance(int rhs_kind, int integrator, const StepArgs& a, hipStream_t s) {
+  Program* p = get_program(rhs_kind, integrator);
+  if (!p) return hipErrorInvalidValue;
+  if (!p->advance) { g_rtc_err = "no advance kernel: fixed-step integrator or a lanes-per-system right-hand side"; return hipErrorInvalidValue; }
+  StepArgs copy = a;
+  return launch(p->advance, a.N, kBlock, &copy, s);
 }
 hipError_t rtc_launch_rhs(int rhs_kind, int64_t N, int64_t is, int64_t cs, double t, const double* y, double* dy, const Params& P,
                           hipStream_t s) {

@@ -416,6 +416,25 @@ def test_adaptive_stream_driver_equals_fused(nn, oracle, dev, integrator):
     assert int(ref["steps"].max()) <= launches < int(ref["steps"].max()) + 5   # one loop iteration per launch, polled every 5
 
 
+def test_adaptive_stream_with_runtime_compiled_right_hand_sides(nn, dev):
+    """The HBM-resident adaptive loop also runs right-hand sides instantiated at run time: a user system from source and a
+    built-in kind at a size without an ahead-of-time kernel; bitwise equal to the fused solve.  Lanes-per-system kinds are refused."""
+    import torch
+    n = 2000
+    rng = np.random.default_rng(9)
+    kw = dict(absTol=1e-7, relTol=1e-7, dtMin=1e-9, dtMax=0.5)
+    duff = nn.Rhs.custom(2, "dy[0] = y[1]; dy[1] = ((-p[0] * y[1] - p[1] * y[0]) - p[2] * (y[0] * y[0] * y[0])) + p[3] * t;",
+                         keys=("delta", "alpha", "beta", "gamma"), defaults=dict(delta=0.2, alpha=1.0, beta=0.5, gamma=0.3), name="duffing_stream")
+    for f, dim in ((duff, 2), (nn.Rhs.linear(-0.7), 5), (nn.Rhs.ring(0.1), 6)):
+        y0 = torch.from_numpy(0.5 + rng.random((dim, n))).to(dev)
+        for integ in ("dopri54", "bs32"):
+            t, yf = nn.solveODE(f, y0, [0.0, 2.0], nn.newODEoptions(**kw), integrator=integ)
+            ys, launches = nn.adaptiveStream(f, y0.clone(), 0.0, 2.0, nn.newODEoptions(**kw), integrator=integ)
+            assert torch.equal(ys, yf[-1]) and launches > 0, (dim, integ)
+    with pytest.raises(NotImplementedError):
+        nn.adaptiveStream(nn.Rhs.ring(0.1), torch.ones(16, 8, dtype=torch.float64, device=dev), 0.0, 1.0, nn.newODEoptions(**kw))
+
+
 @pytest.mark.parametrize("layout,dim", [(0, 1), (0, 3), (1, 3)])
 def test_rccl_allgather_states_single_device(nn, dev, layout, dim):
     """nnhip_allgather_states_f64_dev (one process, G devices, RCCL): with the one device of this box the gather must
