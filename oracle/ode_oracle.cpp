@@ -3,7 +3,10 @@
 //
 // This file is a CPU restatement, operation for operation, of the reference's ODE solver
 //   /root/reference/src/numericalnim/ode.nim      (steppers, controller, driver, dispatch)
-//   /root/reference/src/numericalnim/utils.nim    (Vector[T] arithmetic, hermiteSpline, linspace)
+//   /root/reference/src/numericalnim/utils.nim    (Vector[T] arithmetic, hermiteSpline, hermiteInterpolate, linspace)
+// and of the consumers on either side of it
+//   /root/reference/src/numericalnim/interpolate.nim  (newHermiteSpline eval / derivEval + extrapolation)
+//   /root/reference/src/numericalnim/integrate.nim    (cumtrapz / cumsimpson for discrete points and for functions)
 // It exists only so that tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg can
 // check / time the HIP product path against it.  NOTHING in the product path (numericalnim_amd/,
 // include/) may include, link or call anything in oracle/.
@@ -13,7 +16,8 @@
 // pinned against every known-answer test the reference holds for this path
 // (tests/test_ode.nim:24-257: all 14 integrators vs exp(-0.1 t) on linspace(-10,10,100) incl.
 // `t == tspan`, at the reference's own tolerances; tests/test_vector.nim operator semantics;
-// tests/test_utils.nim:15-23 linspace) — see tests/test_oracle_reference_kats.py — and against the
+// tests/test_utils.nim:15-23 linspace; tests/test_integrate.nim:67-95 cumtrapz / cumsimpson, discrete and
+// function forms) — see tests/test_oracle_reference_kats.py — and against the
 // survey's independent scratch known-answer values.  Bit-level identity with
 // a Nim build is by construction (same IEEE-754 double operations in the same order, compiled
 // -ffp-contract=off, no fast-math), not by execution.
