@@ -211,3 +211,38 @@ def test_cumquad_fn_matches_its_discrete_building_blocks(oracle):
     k = int(np.argmin(np.abs(t - 0.55)))
     if t[k] == 0.55:
         assert r[2] == ys[k]
+
+
+# ---- tests/test_interpolate.nim:5-18, 104-145: newHermiteSpline(t, y, dy) eval / derivEval -----------------------------------
+def _arange(x1, x2, dx):
+    """utils.nim:480-493 with includeStart = true, includeEnd = false."""
+    n = abs(int(np.floor((x2 - x1) / dx)))
+    return np.array([x1] + [x1 + float(i) * dx for i in range(1, n + 1)])
+
+
+def test_hermite_spline_reference_tests(oracle):
+    O = oracle
+    t = np.array(O.linspace(0.0, 10.0, 100))
+    y, dy = np.sin(t), np.cos(t)
+    t_test = _arange(0.0, 10.0, 0.2345)
+    # "HermiteSpline Eval in input points, direct" / "... for loop" / ".toProc, single value": isClose(val, y[i], 1e-15)
+    assert np.all(np.abs(O.hermite_interp(t, y, dy, t) - y) <= 1e-15)
+    for x, yy in zip(t, y):
+        assert abs(O.hermite_interp(t, y, dy, [x])[0] - yy) <= 1e-15
+    # "HermiteSpline Eval between input points": isClose(val, yTest[i], 1e-4)
+    assert np.all(np.abs(O.hermite_interp(t, y, dy, t_test) - np.sin(t_test)) <= 1e-4)
+    # "HermiteSpline derivEval, single value": abs(res - cos(t[20])) < 1e-9 ; "... seq input": < 1e-5
+    assert abs(O.hermite_interp(t, y, dy, [t[20]], deriv=True)[0] - np.cos(t[20])) < 1e-9
+    assert np.all(np.abs(O.hermite_interp(t, y, dy, t_test, deriv=True) - np.cos(t_test)) < 1e-5)
+
+
+# ---- tests/test_integrate.nim:67-70, 82-85: cumtrapz / cumsimpson for discrete points -----------------------------------------
+def test_cumulative_quadrature_discrete_reference_tests(oracle):
+    import math
+    O = oracle
+    X = np.array(O.linspace(0.0, 1.5 * math.pi, 17))
+    Y = 2.0 * np.cos(X)
+    cum = 2.0 * np.sin(X)
+    assert np.all(np.abs(O.cumtrapz(Y, X) - cum) <= 1e-1)      # "cumtrapz discrete points"
+    assert np.all(np.abs(O.cumsimpson(Y, X) - cum) <= 1e-3)    # "cumsimpson discrete points"
+    assert abs(O.cumtrapz(Y, X)[-1] - 2.0 * math.sin(1.5 * math.pi)) <= 1e-1   # "trapz discrete points" (:55-57) = last cumulative value
