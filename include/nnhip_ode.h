@@ -236,6 +236,11 @@ int nnhip_hermite_spline_f64_dev(double x, double x1, double x2, const double* y
 int nnhip_hermite_spline_eval_batch_f64_dev(const double* X, int n_knots, const double* Y, const double* dY, int64_t M,
                                             const double* xq, int n_q, int deriv, int extrap, double extrap_value, double* out,
                                             void* stream);
+/* newHermiteSpline(X, Y) WITHOUT derivatives (interpolate.nim:241-253): the three-point difference slopes the reference
+ * estimates — (Y1-Y0)/(X1-X0) at the ends, 0.5*((Y[i+1]-Y[i])/(X[i+1]-X[i]) + (Y[i]-Y[i-1])/(X[i]-X[i-1])) inside — over M series.
+ * X [n_knots] host, strictly ascending, 2 <= n_knots <= 65535; Y, dY [n_knots][M] device.  Feed dY to the eval entry above.
+ * Synchronises `stream`. */
+int nnhip_hermite_spline_slopes_f64_dev(const double* X, int n_knots, const double* Y, int64_t M, double* dY, void* stream);
 /* Output consumer: cumtrapz(Y, X) for discrete points (src/numericalnim/integrate.nim:120-135) over M series (a trajectory
  * tensor's columns).  X [n] host, strictly ascending; Y, out [n][M] device; out[0] = Y[0]-Y[0].  trapz(Y, X) (:104-117) is the
  * last row for finite data. */

@@ -74,6 +74,19 @@ __global__ __launch_bounds__(kBlock) void hermite_interp_kernel(const HermChunk 
   out[(int64_t)qi * M + m] = r;
 }
 
+// The slopes newHermiteSpline(X, Y) estimates when no derivatives are given (interpolate.nim:241-253): one-sided differences at
+// the ends, the mean of the two adjacent difference quotients inside.  Thread per (knot, series); invDx-free: the reference divides.
+__global__ __launch_bounds__(kBlock) void hermite_slopes_kernel(const double* __restrict__ X, int n, const double* __restrict__ Y,
+                                                                int64_t M, double* __restrict__ dY) {
+  const int64_t m = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int i = blockIdx.y;
+  if (m >= M || i >= n) return;
+  const int64_t r = (int64_t)i * M + m;
+  if (i == 0) dY[r] = (Y[r + M] - Y[r]) / (X[1] - X[0]);
+  else if (i == n - 1) dY[r] = (Y[r] - Y[r - M]) / (X[n - 1] - X[n - 2]);
+  else dY[r] = 0.5 * ((Y[r + M] - Y[r]) / (X[i + 1] - X[i]) + (Y[r] - Y[r - M]) / (X[i] - X[i - 1]));
+}
+
 // cumtrapz(Y, X) over M series (integrate.nim:120-135): thread per series marches down the time axis;
 // the interval weights 0.5*(x_{i+1}-x_i) are computed on the host (same IEEE ops) and arrive as arguments.
 constexpr int kTrapzChunk = 384;
@@ -211,6 +224,23 @@ int nnhip_hermite_spline_eval_batch_f64_dev(const double* X, int n_knots, const 
       return NNHIP_EHIP;
   }
   return NNHIP_OK;
+}
+
+int nnhip_hermite_spline_slopes_f64_dev(const double* X, int n_knots, const double* Y, int64_t M, double* dY, void* stream) {
+  if (n_knots < 2 || n_knots > 65535 || M < 0 || !X) return NNHIP_EVALUE;
+  for (int i = 1; i < n_knots; ++i) if (!(X[i - 1] < X[i])) return NNHIP_EVALUE;  // sortAndTrimDataset's postcondition (:244)
+  if (M == 0) return NNHIP_OK;
+  if (!Y || !dY) return NNHIP_EVALUE;
+  hipStream_t s = (hipStream_t)stream;
+  double* dX = nullptr;
+  if (hipMalloc((void**)&dX, (size_t)n_knots * sizeof(double)) != hipSuccess) return NNHIP_EHIP;
+  int rc = NNHIP_OK;
+  if (hipMemcpyAsync(dX, X, (size_t)n_knots * sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess) rc = NNHIP_EHIP;
+  const dim3 grid((unsigned)((M + nnhip::kBlock - 1) / nnhip::kBlock), (unsigned)n_knots), block(nnhip::kBlock);
+  if (!rc && nnhip::launch_kernel(nnhip::hermite_slopes_kernel, grid, block, s, (const double*)dX, n_knots, Y, M, dY) != hipSuccess) rc = NNHIP_EHIP;
+  (void)hipStreamSynchronize(s);  // X was staged from pageable memory and is freed below
+  (void)hipFree(dX);
+  return rc;
 }
 
 int nnhip_cumtrapz_batch_f64_dev(const double* X, int n, const double* Y, int64_t M, double* out, void* stream) {

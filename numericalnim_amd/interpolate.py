@@ -30,12 +30,20 @@ class HermiteSpline:
     """newHermiteSpline(X, Y, dY) for a whole batch: Y, dY are [n_knots, ...] CUDA tensors (every trailing element its
     own series).  X must be strictly ascending (the solver's output grid is, unless tStart is duplicated)."""
 
-    def __init__(self, X, Y, dY):
+    def __init__(self, X, Y, dY=None):
+        import torch
         self.X = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
-        if len(self.X) != Y.shape[0] or len(self.X) != dY.shape[0]:
+        if len(self.X) != Y.shape[0] or (dY is not None and len(self.X) != dY.shape[0]):
             raise ValueError("X and Y and dY must have the same length.")  # interpolate.nim:229-230
-        self.Y, self.dY = Y.contiguous(), dY.contiguous()
+        self.Y = Y.contiguous()
         self.M = int(self.Y[0].numel())
+        if dY is None:  # newHermiteSpline(X, Y): three-point difference slopes (interpolate.nim:241-253)
+            self.dY = torch.empty_like(self.Y)
+            with torch.cuda.device(self.Y.device):
+                _check(_lib.lib().nnhip_hermite_spline_slopes_f64_dev(self.X.ctypes.data_as(C.POINTER(C.c_double)), len(self.X), self.Y.data_ptr(),
+                                                                      self.M, self.dY.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        else:
+            self.dY = dY.contiguous()
 
     def _run(self, x, deriv, extrap, extrapValue):
         import torch
@@ -55,7 +63,8 @@ class HermiteSpline:
         return self._run(x, 1, extrap, extrapValue)
 
 
-def newHermiteSpline(X, Y, dY):
+def newHermiteSpline(X, Y, dY=None):
+    """newHermiteSpline(X, Y, dY) (interpolate.nim:216-239) or, without dY, newHermiteSpline(X, Y) (:241-257)."""
     return HermiteSpline(X, Y, dY)
 
 

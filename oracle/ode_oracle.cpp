@@ -923,6 +923,18 @@ int oracle_hermite_interp(const double* X, int n, const double* Y, const double*
   return 0;
 }
 
+// newHermiteSpline(X, Y) without derivatives (src/numericalnim/interpolate.nim:241-253): three-point difference slopes for one
+// scalar series; X sorted and duplicate-free, n >= 2.
+int oracle_hermite_slopes(const double* X, int n, const double* Y, double* dY) {
+  if (n < 2) return -1;
+  const int highest = n - 1;
+  dY[0] = (Y[1] - Y[0]) / (X[1] - X[0]);                                               // :247
+  dY[highest] = (Y[highest] - Y[highest - 1]) / (X[highest] - X[highest - 1]);         // :248-249
+  for (int i = 1; i <= highest - 1; ++i)                                               // :250-252
+    dY[i] = 0.5 * ((Y[i + 1] - Y[i]) / (X[i + 1] - X[i]) + (Y[i] - Y[i - 1]) / (X[i] - X[i - 1]));
+  return 0;
+}
+
 // cumtrapz(Y, X) for discrete points (src/numericalnim/integrate.nim:120-135) on one scalar series; X sorted and
 // duplicate-free (sortAndTrimDataset's postcondition).  trapz(Y, X) (:104-117) equals the last entry for finite data.
 int oracle_cumtrapz(const double* X, int n, const double* Y, double* out) {

@@ -184,6 +184,15 @@ def hermite_interp(X, Y, dY, xq, deriv=False, extrap="Native", extrap_value=0.0)
     return out
 
 
+def hermite_slopes(X, Y):
+    """The derivative estimates of newHermiteSpline(X, Y) (interpolate.nim:241-253) for one scalar series."""
+    X, Y = (np.ascontiguousarray(np.asarray(a, dtype=np.float64)) for a in (X, Y))
+    out = np.empty(len(X), dtype=np.float64)
+    if lib().oracle_hermite_slopes(_dp(X), len(X), _dp(Y), _dp(out)):
+        raise ValueError("need at least 2 points")
+    return out
+
+
 def cumtrapz(Y, X):
     """cumtrapz(Y, X) (integrate.nim:120-135) for one scalar series with sorted, unique X."""
     X, Y = (np.ascontiguousarray(np.asarray(a, dtype=np.float64)) for a in (X, Y))

@@ -80,3 +80,24 @@ def test_cumsimpson_on_trajectories(nn, oracle, dev, n_t):
         assert np.abs(c[-1] - y0 * (1 - np.exp(-0.8 * t[-1])) / 0.8).max() < 1e-3  # random non-uniform grid: loose sanity bound only
     with pytest.raises(ValueError):
         nn.cumsimpson(y[:2], t[:2])
+
+
+def test_hermite_spline_without_dy(nn, oracle, dev):
+    """newHermiteSpline(X, Y) (interpolate.nim:241-257): the slope estimates and everything evaluated from them are bit-identical to
+    the oracle's; non-uniform knots, several series."""
+    import torch
+    O = oracle
+    rng = np.random.default_rng(4)
+    X = np.cumsum(0.05 + rng.random(60))
+    Yh = np.stack([np.sin(X) * (1 + k) + 0.1 * k * X for k in range(5)], axis=1)  # [knots, series]
+    Y = torch.from_numpy(Yh).to(dev)
+    sp = nn.newHermiteSpline(X, Y)
+    xq = np.concatenate([X[[0, 7, -1]], X[0] + (X[-1] - X[0]) * rng.random(40)])
+    ev, dv = sp.eval(xq).cpu().numpy(), sp.derivEval(xq).cpu().numpy()
+    for m in range(5):
+        slopes = O.hermite_slopes(X, Yh[:, m])
+        assert np.array_equal(sp.dY.cpu().numpy()[:, m], slopes)
+        assert np.array_equal(ev[:, m], O.hermite_interp(X, Yh[:, m], slopes, xq))
+        assert np.array_equal(dv[:, m], O.hermite_interp(X, Yh[:, m], slopes, xq, deriv=True))
+    with pytest.raises(ValueError):
+        nn.newHermiteSpline(X[:1], Y[:1])

@@ -246,3 +246,16 @@ def test_cumulative_quadrature_discrete_reference_tests(oracle):
     assert np.all(np.abs(O.cumtrapz(Y, X) - cum) <= 1e-1)      # "cumtrapz discrete points"
     assert np.all(np.abs(O.cumsimpson(Y, X) - cum) <= 1e-3)    # "cumsimpson discrete points"
     assert abs(O.cumtrapz(Y, X)[-1] - 2.0 * math.sin(1.5 * math.pi)) <= 1e-1   # "trapz discrete points" (:55-57) = last cumulative value
+
+
+def test_hermite_spline_without_dy_reference_tests(oracle):
+    """tests/test_interpolate.nim:11, 59-103: newHermiteSpline(t, y) estimates the slopes by three-point differences."""
+    O = oracle
+    t = np.array(O.linspace(0.0, 10.0, 100))
+    y = np.sin(t)
+    dy = O.hermite_slopes(t, y)
+    t_test = _arange(0.0, 10.0, 0.2345)
+    assert np.all(np.abs(O.hermite_interp(t, y, dy, t) - y) <= 1e-15)                       # "... Eval in input points"
+    assert np.all(np.abs(O.hermite_interp(t, y, dy, t_test) - np.sin(t_test)) <= 1e-4)        # "... Eval between input points"
+    assert abs(O.hermite_interp(t, y, dy, [t[20]], deriv=True)[0] - np.cos(t[20])) < 1e-3     # "... derivEval, single value"
+    assert np.all(np.abs(O.hermite_interp(t, y, dy, t_test, deriv=True) - np.cos(t_test)) < 2e-3)  # "... derivEval, seq input"
