@@ -10,14 +10,9 @@
 import std/[strformat, tables, algorithm]
 import numericalnim            # ODEoptions, newODEoptions, NumContext, newNumContext stay the reference's own
 
-type
-  NnhipOptions {.bycopy.} = object          ## == ODEoptions field for field (ode.nim:26-34)
-    dt, dtMax, dtMin, tStart, absTol, relTol, scaleMax, scaleMin: cdouble
-  NnhipStats {.bycopy.} = object
-    stepsTotal, rejectedTotal, stepsMax: int64
-    nTOut, nyMin, nanAborts, truncated: int32
-    kernelMs: cdouble
+import ./nnhip_ode_bindings   # raw {.importc.} procs + NnhipOptions / NnhipStats, generated from include/nnhip_ode.h
 
+type
   RhsKind* = enum                           ## include/nnhip_ode.h: enum nnhip_rhs_kind
     rhsNegY = 0, rhsLinear = 1, rhsLorenz = 2, rhsRing = 3, rhsAffineT = 4, rhsVanDerPol = 5
   RhsSpec* = object                         ## stands in for ODEProc[T] (ode.nim:36)
@@ -30,19 +25,6 @@ type
     dim*: int
     layout*: BatchLayout
     data*: seq[float]                       ## [dim][N] (SoA) or [N][dim] (AoS)
-
-proc nnhip_last_error(): cstring {.importc, cdecl.}
-proc nnhip_ode_integrator_id(name: cstring): cint {.importc, cdecl.}
-proc nnhip_ode_solve_batch_f64(opt: ptr NnhipOptions, integrator, rhsKind: cint, rhsParams: ptr cdouble, nParams: cint,
-                               y0: ptr cdouble, N: int64, dim, layout: cint, tspan: ptr cdouble, nT: cint,
-                               tOut, yOut: ptr cdouble, nyOut: ptr int32, stepsOut, rejectedOut: ptr int64,
-                               maxSteps: int64, stats: ptr NnhipStats, device: cint): cint {.importc, cdecl.}
-proc nnhip_ode_solve_batch_multi_gpu_f64(opt: ptr NnhipOptions, integrator, rhsKind: cint, rhsParams: ptr cdouble,
-                                         nParams: cint, y0: ptr cdouble, N: int64, dim, layout: cint,
-                                         tspan: ptr cdouble, nT: cint, tOut, yOut: ptr cdouble, nyOut: ptr int32,
-                                         maxSteps: int64, stats: ptr NnhipStats, nGpus: cint): cint {.importc, cdecl.}
-
-proc nnhip_ode_rhs_compile(name: cstring, dim, nParams: cint, body: cstring, rhsKindOut: ptr cint): cint {.importc, cdecl.}
 
 proc rhsFromSource*(dim: int, body: string, keys: seq[string] = @[], name = "user"): RhsSpec =
   ## An arbitrary right-hand side given as HIP C++ source (compiled on the fly by the backend): `body` is the body of

@@ -34,6 +34,28 @@ def test_library_exports_every_declared_symbol(nn):
     assert _lib.lib().nnhip_abi_version() == 1
 
 
+def test_nim_bindings_are_generated_from_the_header():
+    """nim/nnhip_ode_bindings.nim (the raw importc procs a numericalnim maintainer links against) is regenerated from
+    include/nnhip_ode.h and must be up to date: one proc per declared entry, same argument order."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("gen_nim_bindings", os.path.join(ROOT, "scripts", "gen_nim_bindings.py"))
+    g = importlib.util.module_from_spec(spec)
+    dont = sys.dont_write_bytecode
+    sys.dont_write_bytecode = True  # keep scripts/ free of __pycache__
+    try:
+        spec.loader.exec_module(g)
+    finally:
+        sys.dont_write_bytecode = dont
+    header = open(os.path.join(ROOT, "include", "nnhip_ode.h")).read()
+    text = g.generate(header)
+    assert open(os.path.join(ROOT, "nim", "nnhip_ode_bindings.nim")).read() == text, "run python scripts/gen_nim_bindings.py"
+    from numericalnim_amd import _lib
+    assert {name for _, name, _ in g.prototypes(header)} == set(_lib.SIGNATURES)
+    shim = open(os.path.join(ROOT, "nim", "numericalnim_hip.nim")).read()
+    assert "import ./nnhip_ode_bindings" in shim and "{.importc, cdecl.}" not in shim  # no hand-written duplicates of the raw procs
+
+
 def test_no_oracle_or_cpu_fallback_in_product():
     """The product tree must not reference the oracle (parity would be void)."""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "numericalnim_amd")):
@@ -45,6 +67,8 @@ def test_no_oracle_or_cpu_fallback_in_product():
         assert "oracle" not in open(f).read().lower()
     # dev tooling and examples outside tests/ must not use it either; bench.py only in its cpu_baseline leg
     for f in glob.glob(os.path.join(ROOT, "scripts", "*")) + glob.glob(os.path.join(ROOT, "examples", "*")):
+        if os.path.isdir(f):
+            continue
         assert "import oracle" not in open(f).read() and "from oracle" not in open(f).read(), f
     bench = open(os.path.join(ROOT, "bench.py")).read()
     assert bench.count("from oracle import") == 1 and bench.index("from oracle import") > bench.index("CPU baseline: the oracle")
