@@ -93,8 +93,8 @@ const char* nnhip_build_info(void);      /* arch, fp-contract mode, compiler    
  *   "rk4_stream_mode" 0..3 (0 plain, 1 non-temporal, 2 persistent, 3 both), "rk4_stream_blocks_per_cu" 1..64,
  *   "stream_graph" 0|1 (capture nnhip_ode_fixed_stream_f64_dev's launch sequence in a hipGraph and replay it; pays for
  *   launch-bound batch sizes), "dim16_variant" 0..4 (A/B mappings of the fused 16-component kernels), "fp_contract" 0|1 (opt-in FMA-contracted fused
- *   kernels: NOT bit-exact, within 1e-10 / 1e-6), "host_chunks" 0..64 and "host_register" 0|1 (pipelining of the
- *   host-pointer solve) */
+ *   kernels: NOT bit-exact, within 1e-10 / 1e-6), "host_chunks" 0..64 (0 = automatic: 8 when the caller's buffers are page-locked, else 1) and
+ *   "host_register" 0|1 (pipelining of the host-pointer solve) */
 int nnhip_tune_set(const char* key, int value);
 
 /* ---- options / dispatch (host only, no device needed) ---------------------------------------- */

@@ -7,6 +7,8 @@
 #include <cctype>
 #include <cmath>
 #include <cstdarg>
+#include <deque>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -56,7 +58,7 @@ const MethodInfo kMethods[NNHIP_N_INTEGRATORS] = {
     {"ralston4", 0, 4.0, 0, 1}, {"kutta4", 0, 4.0, 0, 1},
 };
 
-int g_host_chunks = 0;    // tuning knob "host_chunks": 0 = auto (= 1, see nnhip_ode_solve_batch_f64)
+int g_host_chunks = 0;    // tuning knob "host_chunks": 0 = auto (8 when the caller's buffers are page-locked, else 1; see nnhip_ode_solve_batch_f64)
 int g_host_register = 0;  // tuning knob "host_register": page-lock the caller's buffers for the duration of a host-pointer solve
 int g_fast_math = 0;     // tuning knob "fp_contract": 1 = FMA-contracted instantiations of the fused kernels (not bit-exact)
 int g_stream_graph = 0;  // tuning knob "stream_graph": 0 eager launches, 1 hipGraph capture + replay of the streaming loop
@@ -164,6 +166,65 @@ struct Staging {
   bool pending = false;
 };
 thread_local Staging g_stage;
+
+bool is_page_locked(const void* p) {
+  hipPointerAttribute_t a;
+  const hipError_t e = hipPointerGetAttributes(&a, p);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }  // ordinary pageable memory is unknown to the runtime
+  return a.type == hipMemoryTypeHost;
+}
+
+// `rows` segments of `width` bytes, `pitch` bytes apart in both buffers.  A few long rows go as plain 1-D copies (DMA engines, which
+// overlap with kernels); hipMemcpy2DAsync is kept for many short rows.
+hipError_t copy_rows(void* dst, const void* src, size_t pitch, size_t width, size_t rows, hipMemcpyKind kind, hipStream_t st) {
+  if (rows == 0 || width == 0) return hipSuccess;
+  if (pitch == width) return hipMemcpyAsync(dst, src, width * rows, kind, st);
+  if (rows <= 64) {
+    for (size_t r = 0; r < rows; ++r) {
+      const hipError_t e = hipMemcpyAsync((char*)dst + r * pitch, (const char*)src + r * pitch, width, kind, st);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }
+  return hipMemcpy2DAsync(dst, pitch, src, pitch, width, rows, kind, st);
+}
+
+// Streams and events of the host-pointer solve come from a process-wide pool keyed by device: creating and destroying two streams
+// and a handful of events costs ~7 ms on this platform — as much as moving C2's 240 MB over PCIe.  A call borrows a context and
+// hands it back; the pool grows to the number of concurrent calls per device and is never torn down (process exit may come after
+// the runtime's own teardown).
+struct HostSolveCtx {
+  int device = -1;
+  bool busy = false;
+  hipStream_t s[2] = {nullptr, nullptr};
+  hipEvent_t evPrep = nullptr;
+  std::vector<hipEvent_t> evs;  // timing events, grown on demand
+};
+std::mutex g_host_ctx_mu;
+std::deque<HostSolveCtx> g_host_ctx;  // deque: growing never moves a borrowed context
+int host_ctx_acquire(int device, int nEvents, HostSolveCtx** out) {
+  HostSolveCtx* c = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_host_ctx_mu);
+    for (auto& x : g_host_ctx) if (x.device == device && !x.busy) { c = &x; break; }
+    if (!c) { g_host_ctx.emplace_back(); c = &g_host_ctx.back(); c->device = device; }
+    c->busy = true;
+  }
+  *out = c;  // from here on the context belongs to this call (released by the caller even when the creations below fail)
+  for (hipStream_t& st : c->s) if (!st) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  if (!c->evPrep) HIP_TRY(hipEventCreateWithFlags(&c->evPrep, hipEventDisableTiming));
+  while ((int)c->evs.size() < nEvents) {
+    hipEvent_t e = nullptr;
+    HIP_TRY(hipEventCreate(&e));
+    c->evs.push_back(e);
+  }
+  return NNHIP_OK;
+}
+void host_ctx_release(HostSolveCtx* c) {
+  if (!c) return;
+  std::lock_guard<std::mutex> lk(g_host_ctx_mu);
+  c->busy = false;
+}
 
 int stage_reserve(size_t n) {
   Staging& s = g_stage;
@@ -483,35 +544,40 @@ int nnhip_ode_solve_batch_f64(const nnhip_ode_options* opt, int integrator, int 
   int64_t *d_steps = nullptr, *d_rej = nullptr;
   void* d_ws = nullptr;
   unsigned long long* d_agg = nullptr;
-  hipStream_t s[2] = {nullptr, nullptr};
-  std::vector<hipEvent_t> evs;
+  hipStream_t s[2] = {nullptr, nullptr};  // borrowed from the per-thread context (host_ctx_for), not owned
+  hipEvent_t* evs = nullptr;
   hipEvent_t evPrep = nullptr;
+  HostSolveCtx* hc = nullptr;
   bool regIn = false, regOut = false;
   int rc = NNHIP_OK;
   int nTOut = 0;
   const int64_t wsBytes = nnhip_ode_solve_workspace_bytes(n_t);
   auto cleanup = [&]() {
+    for (hipStream_t st : s) if (st) (void)hipStreamSynchronize(st);  // nothing may still be reading the buffers freed below
     if (regIn) (void)hipHostUnregister((void*)y0);
     if (regOut) (void)hipHostUnregister((void*)y_out);
     void* bufs[] = {d_y0, d_out, d_ny, d_steps, d_rej, d_ws, d_agg};
     for (void* b : bufs) if (b) (void)hipFree(b);
-    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
-    if (evPrep) (void)hipEventDestroy(evPrep);
-    for (hipStream_t st : s) if (st) (void)hipStreamDestroy(st);
+    host_ctx_release(hc);
+    hc = nullptr;
   };
 #define HIP_TRY_C(expr)                                                                                                   \
   do {                                                                                                                    \
     hipError_t _e = (expr);                                                                                               \
     if (_e != hipSuccess) { rc = fail(_e == hipErrorOutOfMemory ? NNHIP_ENOMEM : NNHIP_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e)); cleanup(); return rc; } \
   } while (0)
-  // Measured on MI355X / EPYC 9575F (scripts/ab_host_path.py, C2 fused RK4, 80 MB in + 160 MB out): 1 chunk 19.0 ms, 2 chunks 20.5,
-  // 4 chunks 22.1; page-locking the user buffers first 25.5 / 23.7 / 22.9.  Staged pageable copies already run near the
-  // host's memcpy rate, so the default is one chunk, no registration; the knobs remain for hosts where that differs.
+  // Measured on MI355X / EPYC 9575F (scripts/ab_host_pinned.py, C2 fused RK4, 80 MB in + 160 MB out, caller's buffers reused):
+  // pageable buffers 8.9 ms whatever the chunk count (their copies block the host thread, nothing overlaps); page-locked buffers
+  // 8.9 ms in one chunk, 6.6 ms in 4 and 5.5 ms in 8 chunks (copy engines overlap the kernel).  Page-locking pageable buffers for the
+  // duration of the call costs more than it gains ("host_register", off).  Hence: automatic = 8 chunks when both buffers are
+  // already page-locked (hipHostMalloc / hipHostRegister by the caller), else 1.  A wrapper that allocates a fresh result array
+  // per call pays ~8-13 ms of first-touch page faults inside the copy on top of this.
   int nChunks = g_host_chunks > 0 ? g_host_chunks : 1;
+  if (g_host_chunks == 0 && (nState + nOut) * sizeof(double) >= ((size_t)32 << 20) && is_page_locked(y0) && is_page_locked(y_out)) nChunks = 8;
   if ((int64_t)nChunks > N) nChunks = (int)std::max<int64_t>(1, N);
-  HIP_TRY_C(hipStreamCreateWithFlags(&s[0], hipStreamNonBlocking));
-  HIP_TRY_C(hipStreamCreateWithFlags(&s[1], hipStreamNonBlocking));
-  HIP_TRY_C(hipEventCreateWithFlags(&evPrep, hipEventDisableTiming));
+  rc = host_ctx_acquire(device, nChunks * 2, &hc);
+  if (rc) { host_ctx_release(hc); return rc; }
+  s[0] = hc->s[0]; s[1] = hc->s[1]; evPrep = hc->evPrep; evs = hc->evs.data();
   if (nState) HIP_TRY_C(hipMalloc((void**)&d_y0, nState * sizeof(double)));
   if (nOut) HIP_TRY_C(hipMalloc((void**)&d_out, nOut * sizeof(double)));
   if (ny_out && N) HIP_TRY_C(hipMalloc((void**)&d_ny, (size_t)N * sizeof(int32_t)));
@@ -535,15 +601,13 @@ int nnhip_ode_solve_batch_f64(const nnhip_ode_options* opt, int integrator, int 
   if (rc) { cleanup(); return rc; }
   HIP_TRY_C(hipEventRecord(evPrep, s[0]));
   HIP_TRY_C(hipStreamWaitEvent(s[1], evPrep, 0));
-  evs.resize((size_t)nChunks * 2, nullptr);
-  for (auto& e : evs) HIP_TRY_C(hipEventCreate(&e));
   const bool soa = layout == NNHIP_LAYOUT_SOA;
   for (int cI = 0; cI < nChunks && N > 0; ++cI) {
     const int64_t lo = N * cI / nChunks, hi = N * (cI + 1) / nChunks, n = hi - lo;
     if (n <= 0) continue;
     hipStream_t st = s[cI & 1];
     if (soa) {  // component planes: `dim` rows of n doubles, pitch N
-      HIP_TRY_C(hipMemcpy2DAsync(d_y0 + lo, (size_t)N * 8, y0 + lo, (size_t)N * 8, (size_t)n * 8, (size_t)dim, hipMemcpyHostToDevice, st));
+      HIP_TRY_C(copy_rows(d_y0 + lo, y0 + lo, (size_t)N * 8, (size_t)n * 8, (size_t)dim, hipMemcpyHostToDevice, st));
     } else {
       HIP_TRY_C(hipMemcpyAsync(d_y0 + lo * dim, y0 + lo * dim, (size_t)n * dim * 8, hipMemcpyHostToDevice, st));
     }
@@ -553,10 +617,9 @@ int nnhip_ode_solve_batch_f64(const nnhip_ode_options* opt, int integrator, int 
     HIP_TRY_C(hipEventRecord(evs[(size_t)cI * 2 + 1], st));
     if (n_t > 0) {
       if (soa) {
-        HIP_TRY_C(hipMemcpy2DAsync(y_out + lo, (size_t)N * 8, d_out + lo, (size_t)N * 8, (size_t)n * 8, (size_t)n_t * dim, hipMemcpyDeviceToHost, st));
+        HIP_TRY_C(copy_rows(y_out + lo, d_out + lo, (size_t)N * 8, (size_t)n * 8, (size_t)n_t * dim, hipMemcpyDeviceToHost, st));
       } else {
-        HIP_TRY_C(hipMemcpy2DAsync(y_out + lo * dim, (size_t)N * dim * 8, d_out + lo * dim, (size_t)N * dim * 8, (size_t)n * dim * 8, (size_t)n_t,
-                                   hipMemcpyDeviceToHost, st));
+        HIP_TRY_C(copy_rows(y_out + lo * dim, d_out + lo * dim, (size_t)N * dim * 8, (size_t)n * dim * 8, (size_t)n_t, hipMemcpyDeviceToHost, st));
       }
     }
     if (d_ny) HIP_TRY_C(hipMemcpyAsync(ny_out + lo, d_ny + lo, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
