@@ -184,7 +184,7 @@ def integrator_id(integrator):
 
 
 def solveODE(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=LAYOUT_SOA, max_steps=0, stats=None,
-             return_counts=False, sweep=None, sort_by=None):
+             return_counts=False, sweep=None, sort_by=None, out=None):
     """Batched solveODE (ode.nim:589-651): returns (t, y) with t = the sorted output grid (ndarray) and
     y = [n_t, *y0.shape] holding the state of every IVP at every t (rows the reference would not
     return for an IVP are NaN; see include/nnhip_ode.h).
@@ -195,7 +195,10 @@ def solveODE(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=
     sort_by: optional CUDA tensor [N]; the batch is integrated in argsort(sort_by) order and the results are returned in
     the caller's order.  Results are bit-identical; neighbouring lanes of a wavefront then take similar step sequences,
     which removes most of the divergence of adaptive methods on heterogeneous batches (1.7x on a Van der Pol mu-sweep,
-    scripts/bench_divergence.py)."""
+    scripts/bench_divergence.py).
+    out: optional result array for numpy batches, float64 C-contiguous of shape [len(tspan), *y0.shape], returned as y.  Reusing
+    it across calls avoids the first-touch page faults of a fresh 100+ MB array inside the device-to-host copy (2x on C2), and if
+    both y0 and out are page-locked the transfers are overlapped with the kernel (another 1.6x)."""
     if sort_by is not None:
         import torch
         if not _is_torch(y0):
@@ -204,6 +207,8 @@ def solveODE(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=
         inv = torch.empty_like(order)
         inv[order] = torch.arange(order.numel(), device=order.device)
         ax = 0 if (y0.dim() == 1 or layout == LAYOUT_AOS) else 1
+        if out is not None:
+            raise ValueError("out is for numpy batches")
         res = solveODE(f, y0.index_select(ax, order), tspan, options, ctx, integrator, layout, max_steps, stats, return_counts,
                        None if sweep is None else sweep.index_select(1, order), None)
         t, y = res[0], res[1].index_select(ax + 1, inv)
@@ -229,6 +234,8 @@ def solveODE(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=
             raise ValueError("torch y0 must live on a CUDA/HIP device (numericalnim_amd has no CPU path)")
         if y0.dtype != torch.float64:
             raise ValueError("y0 must be float64")
+        if out is not None:
+            raise ValueError("out is for numpy batches (torch results already live on the device)")
         y0c = y0.contiguous()
         with torch.cuda.device(y0c.device):
             y = torch.empty((n_t,) + tuple(y0c.shape), dtype=torch.float64, device=y0c.device)
@@ -254,7 +261,12 @@ def solveODE(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=
                                                        stream))
     else:
         y0c = np.ascontiguousarray(np.asarray(y0, dtype=np.float64))
-        y = np.empty((n_t,) + y0c.shape, dtype=np.float64)
+        if out is not None:
+            if not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.flags.c_contiguous and out.shape == (n_t,) + y0c.shape):
+                raise ValueError(f"out must be a C-contiguous float64 ndarray of shape {(n_t,) + y0c.shape}")
+            y = out
+        else:
+            y = np.empty((n_t,) + y0c.shape, dtype=np.float64)
         ny = np.empty(N, dtype=np.int32) if return_counts else None
         st = np.empty(N, dtype=np.int64) if return_counts else None
         rj = np.empty(N, dtype=np.int64) if return_counts else None

@@ -164,3 +164,32 @@ def test_stream_loop_hipgraph_replay(nn, oracle, dev):
                 assert k == nsteps and np.array_equal(yf.cpu().numpy(), ref)
     finally:
         L.nnhip_tune_set(b"stream_graph", 0)
+
+
+def test_host_path_result_array_reuse_and_page_locked_buffers(nn, oracle):
+    """solveODE(numpy, out=...) writes into the caller's array; page-locked y0 / out take the chunked, overlapped transfer path
+    (automatic) — same bits as the plain call."""
+    import torch
+    n = 300000
+    y0 = 1.0 + (np.arange(n) % 4096) * 2.0 ** -12
+    opt = nn.newODEoptions(dt=2.0 ** -7)
+    ts = [0.0, 0.5, 1.0]
+    t, ref = nn.solveODE(nn.Rhs.neg_y(), y0, ts, opt, integrator="rk4")
+    out = np.zeros((3, n))
+    t2, y2 = nn.solveODE(nn.Rhs.neg_y(), y0, ts, opt, integrator="rk4", out=out)
+    assert y2 is out and np.array_equal(out, ref)
+    y0p = torch.empty(n, dtype=torch.float64).pin_memory()
+    y0p.numpy()[:] = y0
+    outp = torch.zeros(3, n, dtype=torch.float64).pin_memory()
+    nn.solveODE(nn.Rhs.neg_y(), y0p.numpy(), ts, opt, integrator="rk4", out=outp.numpy())
+    assert np.array_equal(outp.numpy(), ref)
+    # large enough for the automatic chunked pipeline (>= 32 MB moved)
+    big = 3_000_000
+    yb = torch.empty(big, dtype=torch.float64).pin_memory()
+    yb.numpy()[:] = 1.0 + (np.arange(big) % 4096) * 2.0 ** -12
+    ob = torch.zeros(2, big, dtype=torch.float64).pin_memory()
+    nn.solveODE(nn.Rhs.neg_y(), yb.numpy(), [0.0, 1.0], opt, integrator="rk4", out=ob.numpy())
+    tb, refb = nn.solveODE(nn.Rhs.neg_y(), yb.numpy().copy(), [0.0, 1.0], opt, integrator="rk4")
+    assert np.array_equal(ob.numpy(), refb)
+    with pytest.raises(ValueError):
+        nn.solveODE(nn.Rhs.neg_y(), y0, ts, opt, integrator="rk4", out=np.zeros((2, n)))
