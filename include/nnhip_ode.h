@@ -88,6 +88,12 @@ int nnhip_device_count(void);            /* >=0, or NNHIP_EHIP                  
 const char* nnhip_last_error(void);      /* thread-local, never NULL                                        */
 const char* nnhip_build_info(void);      /* arch, fp-contract mode, compiler                                */
 
+/* Page-locked host memory for the buffers handed to nnhip_ode_solve_batch_f64: with page-locked y0 and y_out the transfers
+ * are overlapped with the kernel (automatic; 1.6x on config C2).  Plain hipHostMalloc / hipHostFree underneath — memory from
+ * any other page-locking allocator (or hipHostRegister) is recognised just the same. */
+int nnhip_host_alloc(void** out, int64_t bytes);
+int nnhip_host_free(void* p);
+
 /* Performance tuning knobs (process-wide; results are bit-identical for every setting):
  *   "rk4_stream_auto" 0|1 (default 1: choose vec/mode from the working-set size), "rk4_stream_vec" 1|2|4|8,
  *   "rk4_stream_mode" 0..3 (0 plain, 1 non-temporal, 2 persistent, 3 both), "rk4_stream_blocks_per_cu" 1..64,

@@ -270,6 +270,21 @@ const char* nnhip_build_info(void) {
          "compiler " __VERSION__;
 }
 
+int nnhip_host_alloc(void** out, int64_t bytes) {
+  if (!out || bytes < 0) return fail(NNHIP_EVALUE, "out is NULL or bytes < 0");
+  *out = nullptr;
+  if (bytes == 0) return NNHIP_OK;
+  const hipError_t e = hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault);
+  if (e != hipSuccess) { *out = nullptr; return fail(e == hipErrorOutOfMemory ? NNHIP_ENOMEM : NNHIP_EHIP, "hipHostMalloc(%lld) failed: %s", (long long)bytes, hipGetErrorString(e)); }
+  return NNHIP_OK;
+}
+
+int nnhip_host_free(void* p) {
+  if (!p) return NNHIP_OK;
+  HIP_TRY(hipHostFree(p));
+  return NNHIP_OK;
+}
+
 int nnhip_tune_set(const char* key, int value) {
   if (!key) return fail(NNHIP_EVALUE, "key is NULL");
   const std::string k(key);

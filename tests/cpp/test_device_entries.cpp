@@ -69,6 +69,23 @@ int main() {
   std::vector<double> g(N);
   CHECK(hipStreamSynchronize(s) == hipSuccess && hipMemcpy(g.data(), dFull, N * 8, hipMemcpyDeviceToHost) == hipSuccess);
   for (int64_t i = 0; i < N; i += 997) CHECK(g[i] == fin[i]);
+  // host-pointer entry with page-locked buffers from the library's own allocator (chunked, overlapped transfers) == pageable buffers
+  {
+    const int64_t NB = 3000000;
+    double *py0 = nullptr, *pout = nullptr;
+    CHECK(nnhip_host_alloc((void**)&py0, NB * 8) == NNHIP_OK && nnhip_host_alloc((void**)&pout, 2 * NB * 8) == NNHIP_OK);
+    std::vector<double> hy0(NB), hout(2 * NB);
+    for (int64_t i = 0; i < NB; ++i) hy0[i] = py0[i] = 1.0 + 1e-7 * (double)i;
+    nnhip_ode_stats st;
+    CHECK(nnhip_ode_solve_batch_f64(&opt, NNHIP_RK4, NNHIP_RHS_NEG_Y, nullptr, 0, py0, NB, 1, NNHIP_LAYOUT_SOA, tspan, 2, tOut, pout, nullptr, nullptr, nullptr,
+                                    0, &st, 0) == NNHIP_OK);
+    CHECK(nnhip_ode_solve_batch_f64(&opt, NNHIP_RK4, NNHIP_RHS_NEG_Y, nullptr, 0, hy0.data(), NB, 1, NNHIP_LAYOUT_SOA, tspan, 2, tOut, hout.data(), nullptr,
+                                    nullptr, nullptr, 0, &st, 0) == NNHIP_OK);
+    int bad = 0;
+    for (int64_t i = 0; i < 2 * NB; ++i) bad += pout[i] != hout[i];
+    CHECK(bad == 0 && st.steps_total == NB * 256);
+    CHECK(nnhip_host_free(py0) == NNHIP_OK && nnhip_host_free(pout) == NNHIP_OK && nnhip_host_free(nullptr) == NNHIP_OK);
+  }
   // run-time compiled RHS on the device entry
   int kind = 0;
   CHECK(nnhip_ode_rhs_compile("negy_user", 1, 0, "dy[0] = -y[0];", &kind) == NNHIP_OK);
