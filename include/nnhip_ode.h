@@ -88,6 +88,12 @@ int nnhip_device_count(void);            /* >=0, or NNHIP_EHIP                  
 const char* nnhip_last_error(void);      /* thread-local, never NULL                                        */
 const char* nnhip_build_info(void);      /* arch, fp-contract mode, compiler                                */
 
+/* Frees what the library caches between calls: the calling thread's pinned staging buffer and hipGraph cache, the idle
+ * stream / event contexts of the host-pointer solve, the RCCL communicators.  Everything is rebuilt on demand; compiled user
+ * right-hand sides are released one by one with nnhip_ode_rhs_release.  Call it from each thread that used the library if a
+ * clean shutdown matters; not calling it is harmless. */
+int nnhip_release(void);
+
 /* Page-locked host memory for the buffers handed to nnhip_ode_solve_batch_f64: with page-locked y0 and y_out the transfers
  * are overlapped with the kernel (automatic; 1.6x on config C2).  Plain hipHostMalloc / hipHostFree underneath — memory from
  * any other page-locking allocator (or hipHostRegister) is recognised just the same. */

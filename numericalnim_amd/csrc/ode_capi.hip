@@ -242,6 +242,12 @@ int stage_reserve(size_t n) {
 }  // namespace
 
 namespace nnhip {
+void multigpu_release();  // ode_multigpu.hip
+}
+namespace {
+void release_stream_graphs();  // defined next to the graph cache below
+}
+namespace nnhip {
 // error reporting for the other translation units of the C ABI (ode_capi_quad.hip): same thread-local message buffer
 int fail_msg(int code, const char* fmt, ...) {
   va_list ap;
@@ -268,6 +274,33 @@ const char* nnhip_last_error(void) { return g_err; }
 const char* nnhip_build_info(void) {
   return "numericalnim-hip ODE backend; target gfx950 (CDNA4); device math -ffp-contract=off (bit-parity build); "
          "compiler " __VERSION__;
+}
+
+int nnhip_release(void) {
+  // calling thread: pinned staging buffer of the requested-time arrays and the hipGraph cache of the streaming loop
+  Staging& st = g_stage;
+  if (st.pending && st.ev) (void)hipEventSynchronize(st.ev);
+  if (st.host) (void)hipHostFree(st.host);
+  if (st.ev) (void)hipEventDestroy(st.ev);
+  st = Staging();
+  release_stream_graphs();
+  // process: idle stream / event contexts of the host-pointer solve, RCCL communicators
+  {
+    std::lock_guard<std::mutex> lk(g_host_ctx_mu);
+    int prev = 0;
+    const bool havePrev = hipGetDevice(&prev) == hipSuccess;
+    for (auto& c : g_host_ctx) {
+      if (c.busy) continue;
+      if (c.device >= 0) (void)hipSetDevice(c.device);
+      for (hipStream_t& x : c.s) if (x) { (void)hipStreamDestroy(x); x = nullptr; }
+      if (c.evPrep) { (void)hipEventDestroy(c.evPrep); c.evPrep = nullptr; }
+      for (hipEvent_t e : c.evs) (void)hipEventDestroy(e);
+      c.evs.clear();
+    }
+    if (havePrev) (void)hipSetDevice(prev);
+  }
+  nnhip::multigpu_release();
+  return NNHIP_OK;
 }
 
 int nnhip_host_alloc(void** out, int64_t bytes) {
@@ -735,6 +768,10 @@ struct StreamGraphEntry {
 };
 thread_local std::vector<StreamGraphEntry> g_graphs;
 thread_local bool g_capturing = false;
+void release_stream_graphs() {
+  for (auto& e : g_graphs) if (e.exec) (void)hipGraphExecDestroy(e.exec);
+  g_graphs.clear();
+}
 }  // namespace
 
 int nnhip_ode_fixed_stream_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,

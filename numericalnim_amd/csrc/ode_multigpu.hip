@@ -49,6 +49,15 @@ bool load_rccl() {
 
 }  // namespace
 
+namespace nnhip {
+void multigpu_release() {  // nnhip_release(): destroy the cached RCCL communicators (rebuilt on the next collective)
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_rccl.ok) for (ncclComm_t c : g_comms) if (c) g_rccl.CommDestroy(c);
+  g_comms.clear();
+  g_comm_gpus = 0;
+}
+}  // namespace nnhip
+
 extern "C" const char* nnhip_multigpu_last_error(void) { return g_mg_err; }
 
 // shard[r] (on device r): this device's IVP index range [lo_r, lo_r + counts[r]) of a state tensor in `layout`;

@@ -110,3 +110,33 @@ def test_errors_are_per_thread():
     a, b = threading.Thread(target=bad), threading.Thread(target=good)
     a.start(); b.start(); a.join(); b.join()
     assert "no_such_knob_from_thread" in msgs["bad"][1] and "another_missing_knob" in msgs["good"][1], msgs
+
+
+def test_release_frees_caches_and_everything_is_rebuilt_on_demand():
+    """nnhip_release(): staging buffer, graph cache, pooled stream contexts and RCCL communicators go away; the next calls rebuild
+    them and give the same bits.  Also callable from a thread that never used the library, and twice in a row."""
+    import torch
+    import numericalnim_amd as nn
+    L = nn._lib.lib()
+    dev = torch.device("cuda", 0)
+    jobs = _jobs(nn)[:3]
+    before = [nn.solveODE(f, y0, ts, opt, integrator=integ)[1] for f, y0, ts, opt, integ in jobs]              # host-pointer path
+    yd = torch.from_numpy(np.ascontiguousarray(jobs[1][1])).to(dev)
+    dense = nn.solveODE(jobs[1][0], yd, [0.0, 0.2, 0.4, 1.0], jobs[1][3], integrator=jobs[1][4])[1].clone()     # staging buffer
+    s = torch.cuda.Stream(device=dev)
+    L.nnhip_tune_set(b"stream_graph", 1)
+    with torch.cuda.stream(s):
+        ys1 = nn.fixedStream(nn.Rhs.neg_y(), torch.ones(5000, dtype=torch.float64, device=dev), 0.0, 1.0, nn.newODEoptions(dt=1e-2), integrator="rk4")[0].clone()
+    s.synchronize()
+    assert L.nnhip_release() == 0 and L.nnhip_release() == 0
+    t = threading.Thread(target=lambda: L.nnhip_release())
+    t.start(); t.join()
+    after = [nn.solveODE(f, y0, ts, opt, integrator=integ)[1] for f, y0, ts, opt, integ in jobs]
+    for a, b in zip(before, after):
+        assert np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+    assert torch.equal(nn.solveODE(jobs[1][0], yd, [0.0, 0.2, 0.4, 1.0], jobs[1][3], integrator=jobs[1][4])[1], dense)
+    with torch.cuda.stream(s):
+        ys2 = nn.fixedStream(nn.Rhs.neg_y(), torch.ones(5000, dtype=torch.float64, device=dev), 0.0, 1.0, nn.newODEoptions(dt=1e-2), integrator="rk4")[0].clone()
+    s.synchronize()
+    L.nnhip_tune_set(b"stream_graph", 0)
+    assert torch.equal(ys1, ys2)
