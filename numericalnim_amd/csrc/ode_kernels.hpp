@@ -226,10 +226,11 @@ NNHIP_DEV void solve_body(const SolveArgs& a, const OpsF& opsF, const OpsB& opsB
   ls.trunc = (status & 2) ? 1 : 0;
 }
 
-// wave-level reduction of the per-IVP statistics, one atomic per wave and field; the accumulators are replicated
-// kAggSlots times (slot = workgroup index mod kAggSlots) so 1e5 waves do not serialise on four addresses
+// Reduction of the per-IVP statistics: wavefront shuffles, then the four waves of the workgroup through LDS, then one atomic per
+// workgroup and field; the accumulators are replicated kAggSlots times (slot = workgroup index mod kAggSlots) so 4e4 workgroups do
+// not serialise on four addresses.  Must be reached by every thread of the workgroup (it contains a barrier).
 NNHIP_DEV void aggregate_stats(unsigned long long* aggBase, LaneStats ls) {
-  unsigned long long* agg = aggBase + (size_t)(blockIdx.x % kAggSlots) * 8;
+  __shared__ unsigned long long part[kBlock / 64][6];
   unsigned long long steps = ls.steps, rejected = ls.rejected, smax = ls.steps;
   int ny = ls.ny, nanAb = ls.nanAb, trunc = ls.trunc;
 #pragma unroll
@@ -243,17 +244,30 @@ NNHIP_DEV void aggregate_stats(unsigned long long* aggBase, LaneStats ls) {
     nanAb += __shfl_down(nanAb, off, 64);
     trunc += __shfl_down(trunc, off, 64);
   }
+  const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&agg[0], steps);
-    atomicAdd(&agg[1], rejected);
-    atomicMax(&agg[2], smax);
-    atomicMin(&agg[3], (unsigned long long)(unsigned)ny);
-    if (nanAb) atomicAdd(&agg[4], (unsigned long long)nanAb);
-    if (trunc) atomicAdd(&agg[5], (unsigned long long)trunc);
+    part[wave][0] = steps; part[wave][1] = rejected; part[wave][2] = smax; part[wave][3] = (unsigned long long)(unsigned)ny;
+    part[wave][4] = (unsigned long long)nanAb; part[wave][5] = (unsigned long long)trunc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 1; w < kBlock / 64; ++w) {
+      part[0][0] += part[w][0]; part[0][1] += part[w][1];
+      part[0][2] = part[w][2] > part[0][2] ? part[w][2] : part[0][2];
+      part[0][3] = part[w][3] < part[0][3] ? part[w][3] : part[0][3];
+      part[0][4] += part[w][4]; part[0][5] += part[w][5];
+    }
+    unsigned long long* agg = aggBase + (size_t)(blockIdx.x % kAggSlots) * 8;
+    atomicAdd(&agg[0], part[0][0]);
+    atomicAdd(&agg[1], part[0][1]);
+    atomicMax(&agg[2], part[0][2]);
+    atomicMin(&agg[3], part[0][3]);
+    if (part[0][4]) atomicAdd(&agg[4], part[0][4]);
+    if (part[0][5]) atomicAdd(&agg[5], part[0][5]);
   }
 }
 
-// ---- thread per IVP: state, k1..kS, (t, dt) all in VGPRs -----------------------------------------
 template <int METHOD, class RHS>
 __global__ __launch_bounds__(kBlock) void solve_tpi_kernel(const SolveArgs a) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
