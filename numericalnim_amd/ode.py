@@ -100,6 +100,7 @@ class Rhs:
     kind: nnhip_rhs_kind; keys: names looked up in ctx.fValues (in this order) to build rhs_params;
     defaults: values used for keys absent from ctx."""
     NEG_Y, LINEAR, LORENZ, RING, AFFINE_T, VANDERPOL = range(6)
+    _compiled = {}  # (dim, body, n_params, per_component) -> rhs_kind of Rhs.custom
 
     def __init__(self, kind, keys=(), defaults=None):
         self.kind = kind
@@ -124,10 +125,16 @@ class Rhs:
         Rhs.custom(2, "dy[0] = y[1]; dy[1] = -p[0]*y[0] - p[1]*y[1];", keys=("k", "c")).
         per_component=True: `body` returns dy_c for the component index `c` (nnhip_ode_rhs_compile_comp); systems of
         8 / 16 / 32 components then run on the lanes-per-system (LDS-staged) kernels."""
-        kind = C.c_int(0)
-        fn = _lib.lib().nnhip_ode_rhs_compile_comp if per_component else _lib.lib().nnhip_ode_rhs_compile
-        _check(fn(str(name).encode(), int(dim), len(keys), body.encode(), C.byref(kind)))
-        r = Rhs(kind.value, keys, defaults)
+        key = (int(dim), body, len(keys), bool(per_component))
+        k = Rhs._compiled.get(key)  # the same source is registered (and compiled) once per process
+        if k is not None and not _lib.lib().nnhip_ode_supported(0, k, int(dim), LAYOUT_SOA, 0):
+            k = None  # released in the meantime (nnhip_ode_rhs_release)
+        if k is None:
+            kind = C.c_int(0)
+            fn = _lib.lib().nnhip_ode_rhs_compile_comp if per_component else _lib.lib().nnhip_ode_rhs_compile
+            _check(fn(str(name).encode(), int(dim), len(keys), body.encode(), C.byref(kind)))
+            k = Rhs._compiled[key] = kind.value
+        r = Rhs(k, keys, defaults)
         r.dim = int(dim)
         return r
 
