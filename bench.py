@@ -33,6 +33,9 @@ def parse():
     ap.add_argument("--no-gather", action="store_true", help="skip the final-state all-gather (N>1)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="issue the final-state all-gather on the compute stream instead of overlapping it with the next solve")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend (nccl = RCCL, the default and the only one measured; gloo lets several ranks share "
+                         "one GPU to exercise the multi-rank code path on a single-GPU box)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl=RCCL) and run the all-gather even at world size 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=float, default=1e6, help="IVPs in the CPU-baseline sample (1e6 x 1000 steps = ~16 s on one core)")
@@ -59,13 +62,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     n = int(args.n_ivp)
     nsteps = int(args.rk4_steps)
@@ -208,6 +215,7 @@ def main():
                         "one RK4_step kernel launch per time step, state in HBM between launches" % (n, nsteps),
             "ivps_per_gpu": n, "rk4_steps": nsteps, "state_update": "pingpong" if args.pingpong else "in-place",
             "final_state_allgather": bool(gathered is not None), "allgather_overlapped_with_next_solve": bool(overlap),
+            **({"backend": args.backend} if args.backend != "nccl" else {}),
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,

@@ -44,3 +44,20 @@ def test_distributed_line_world_size_one():
     assert out["gathers_verified"] == 3  # warmup + 2 timed solves, each gather checked against the solve it belongs to
     assert out["config"]["final_state_allgather"] is True and out["config"]["allgather_overlapped_with_next_solve"] is True
     assert out["allgather_ms_per_solve"] > 0 and "cpu_baseline" not in out
+
+
+def test_two_ranks_share_the_gpu_over_gloo():
+    """The driver's multi-GPU launch line (torch.distributed.run, one rank per GPU) with two ranks on this box's single GPU: gloo
+    instead of RCCL (RCCL refuses two ranks on one device), everything else identical — contiguous shards of the global index range,
+    the overlapped all-gather with its three rotating buffers (every gather verified), max-over-ranks timing, one JSON line from rank 0."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29581",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--verify-gathers", "--steps", "3", "--warmup", "1", "--n-ivp", "300000",
+           "--rk4-steps", "64"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines  # only rank 0 prints
+    out = json.loads(lines[0])
+    assert KEYS <= set(out) and out["n_gpus"] == 2 and out["config"]["backend"] == "gloo"
+    assert out["gathers_verified"] == 4 and "cpu_baseline" not in out  # cpu_baseline is reported at N = 1 only
+    assert abs(out["value"] - 2 * 300000 * 64 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 1e-9  # whole-job aggregate
