@@ -276,6 +276,19 @@ int nnhip_cumtrapz_fn_batch_f64_dev(int rhs_kind, const double* rhs_params, int 
 int nnhip_cumsimpson_fn_batch_f64_dev(int rhs_kind, const double* rhs_params, int n_params, const double* per_item_params,
                                       int n_per_item, int64_t N, int dim, int layout, const double* X, int n_x, double dx,
                                       double* out, int* n_rows_out, void* stream);
+/* Host-pointer forms of the consumers above, for hosts without device-memory management (the Nim shim): every array lives in
+ * host memory, the call stages it, runs the device-pointer entry on a private stream and copies the result back; same bits.
+ * dY == NULL in the spline entry means newHermiteSpline(X, Y): the slopes are estimated (interpolate.nim:241-253). */
+int nnhip_cumtrapz_batch_f64(const double* X, int n, const double* Y, int64_t M, double* out, int device);
+int nnhip_cumsimpson_batch_f64(const double* X, int n, const double* Y, int64_t M, double* out, int device);
+int nnhip_hermite_spline_eval_batch_f64(const double* X, int n_knots, const double* Y, const double* dY, int64_t M, const double* xq,
+                                        int n_q, int deriv, int extrap, double extrap_value, double* out, int device);
+int nnhip_cumtrapz_fn_batch_f64(int rhs_kind, const double* rhs_params, int n_params, const double* per_item_params, int n_per_item,
+                                int64_t N, int dim, int layout, const double* X, int n_x, double dx, double* out, int* n_rows_out,
+                                int device);
+int nnhip_cumsimpson_fn_batch_f64(int rhs_kind, const double* rhs_params, int n_params, const double* per_item_params,
+                                  int n_per_item, int64_t N, int dim, int layout, const double* X, int n_x, double dx, double* out,
+                                  int* n_rows_out, int device);
 /* The adaptive controller's step-size factor min(4, max(0.125, 0.9 * pow(1/error, 1/order))) (ode.nim:71, 537) over an
  * array of error norms; order in {2, 3, 5, 6} (rk21, bs32, dopri54/tsit54, vern65). */
 int nnhip_ode_controller_factor_f64_dev(int order, const double* error, double* out, int64_t n, void* stream);

@@ -146,4 +146,100 @@ inline OdeSolution solveODE(const RhsSpec& f, const OdeBatch& y0, const std::vec
   return sol;
 }
 
+// ---- the consumers on either side of the solver: same names as the reference's procs, batched, over the
+// host-pointer entries (arrays are staged through the device per call) ---------------------------------------------------------
+namespace detail {
+inline std::vector<double> flatten(const std::vector<OdeBatch>& Y) {
+  std::vector<double> f;
+  for (const auto& b : Y) f.insert(f.end(), b.data.begin(), b.data.end());
+  return f;
+}
+inline std::vector<OdeBatch> rows(const std::vector<double>& flat, size_t nRows, const OdeBatch& proto) {
+  std::vector<OdeBatch> out(nRows);
+  const size_t m = proto.data.size();
+  for (size_t j = 0; j < nRows; ++j) {
+    out[j].N = proto.N; out[j].dim = proto.dim; out[j].layout = proto.layout;
+    out[j].data.assign(flat.begin() + j * m, flat.begin() + (j + 1) * m);
+  }
+  return out;
+}
+}  // namespace detail
+
+// cumtrapz(Y, X) / cumsimpson(Y, X) for discrete points (integrate.nim:120-135, 329-375): Y[j] = the batch at X[j]
+inline std::vector<OdeBatch> cumtrapz(const std::vector<OdeBatch>& Y, const std::vector<double>& X, int device = 0) {
+  if (Y.size() != X.size()) throw std::invalid_argument("X and Y must have the same length");
+  const std::vector<double> in = detail::flatten(Y);
+  std::vector<double> out(in.size());
+  throwOn(nnhip_cumtrapz_batch_f64(X.data(), (int)X.size(), in.data(), (int64_t)Y.at(0).data.size(), out.data(), device));
+  return detail::rows(out, X.size(), Y[0]);
+}
+inline std::vector<OdeBatch> cumsimpson(const std::vector<OdeBatch>& Y, const std::vector<double>& X, int device = 0) {
+  if (Y.size() != X.size()) throw std::invalid_argument("X and Y must have the same length");
+  const std::vector<double> in = detail::flatten(Y);
+  std::vector<double> out(in.size());
+  throwOn(nnhip_cumsimpson_batch_f64(X.data(), (int)X.size(), in.data(), (int64_t)Y.at(0).data.size(), out.data(), device));
+  return detail::rows(out, X.size(), Y[0]);
+}
+
+// cumtrapz(f, X, ctx, dx) / cumsimpson(f, X, ctx, dx) (integrate.nim:138-175, 377-400) for N parameter sets at once:
+// sweep[k][i] overrides parameter k for item i (empty: one item with ctx's parameters).  result[j] = the batch at X[j];
+// the reference can return fewer rows than X.size() and so does this.
+template <class T = double>
+inline std::vector<OdeBatch> cumQuadFn(bool simpson, const RhsSpec& f, const std::vector<double>& X, const NumContext<T>* ctx, double dx,
+                                       const std::vector<std::vector<double>>& sweep, int dim, int device) {
+  const std::vector<double> p = f.params(ctx);
+  const int64_t N = sweep.empty() ? 1 : (int64_t)sweep[0].size();
+  std::vector<double> flat;
+  for (const auto& row : sweep) {
+    if ((int64_t)row.size() != N) throw std::invalid_argument("sweep rows must have the same length");
+    flat.insert(flat.end(), row.begin(), row.end());
+  }
+  OdeBatch proto = OdeBatch::zeros(N, dim);
+  std::vector<double> out(X.size() * proto.data.size());
+  int rows = 0;
+  const auto fn = simpson ? nnhip_cumsimpson_fn_batch_f64 : nnhip_cumtrapz_fn_batch_f64;
+  throwOn(fn(f.kind, p.data(), (int)p.size(), flat.empty() ? nullptr : flat.data(), (int)sweep.size(), N, dim, NNHIP_LAYOUT_SOA, X.data(), (int)X.size(),
+             dx, out.data(), &rows, device));
+  return detail::rows(out, (size_t)rows, proto);
+}
+template <class T = double>
+inline std::vector<OdeBatch> cumtrapz(const RhsSpec& f, const std::vector<double>& X, const NumContext<T>* ctx = nullptr, double dx = 1e-5,
+                                      const std::vector<std::vector<double>>& sweep = {}, int dim = 1, int device = 0) {
+  return cumQuadFn<T>(false, f, X, ctx, dx, sweep, dim, device);
+}
+template <class T = double>
+inline std::vector<OdeBatch> cumsimpson(const RhsSpec& f, const std::vector<double>& X, const NumContext<T>* ctx = nullptr, double dx = 1e-5,
+                                        const std::vector<std::vector<double>>& sweep = {}, int dim = 1, int device = 0) {
+  return cumQuadFn<T>(true, f, X, ctx, dx, sweep, dim, device);
+}
+
+// newHermiteSpline(X, Y[, dY]) + eval / derivEval (interpolate.nim:216-257, 299-390) for a whole batch
+enum class ExtrapolateKind { Constant = 0, Edge = 1, Linear = 2, Native = 3, Error = 4 };  // interpolate.nim:89-90
+class HermiteSpline {
+ public:
+  HermiteSpline(const std::vector<double>& X, const std::vector<OdeBatch>& Y, const std::vector<OdeBatch>& dY = {})
+      : X_(X), Y_(detail::flatten(Y)), dY_(detail::flatten(dY)), proto_(Y.at(0)) {
+    if (X.size() != Y.size() || (!dY.empty() && dY.size() != X.size())) throw std::invalid_argument("X and Y and dY must have the same length.");
+  }
+  std::vector<OdeBatch> eval(const std::vector<double>& x, ExtrapolateKind extrap = ExtrapolateKind::Native, double extrapValue = 0.0, int device = 0) const {
+    return run(x, 0, extrap, extrapValue, device);
+  }
+  std::vector<OdeBatch> derivEval(const std::vector<double>& x, ExtrapolateKind extrap = ExtrapolateKind::Native, double extrapValue = 0.0, int device = 0) const {
+    return run(x, 1, extrap, extrapValue, device);
+  }
+
+ private:
+  std::vector<OdeBatch> run(const std::vector<double>& x, int deriv, ExtrapolateKind extrap, double extrapValue, int device) const {
+    std::vector<double> out(x.size() * proto_.data.size());
+    throwOn(nnhip_hermite_spline_eval_batch_f64(X_.data(), (int)X_.size(), Y_.data(), dY_.empty() ? nullptr : dY_.data(), (int64_t)proto_.data.size(),
+                                                x.data(), (int)x.size(), deriv, (int)extrap, extrapValue, out.data(), device));
+    return detail::rows(out, x.size(), proto_);
+  }
+  std::vector<double> X_, Y_, dY_;
+  OdeBatch proto_;
+};
+inline HermiteSpline newHermiteSpline(const std::vector<double>& X, const std::vector<OdeBatch>& Y, const std::vector<OdeBatch>& dY = {}) {
+  return HermiteSpline(X, Y, dY);
+}
+
 }  // namespace numericalnim

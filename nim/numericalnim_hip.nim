@@ -76,3 +76,92 @@ proc solveODE*(f: RhsSpec, y0: OdeBatch, tspan: openArray[float],
   let row = y0.n * y0.dim
   for j in 0 ..< ts.len:
     result[1].add OdeBatch(n: y0.n, dim: y0.dim, layout: y0.layout, data: yOut[j*row ..< (j+1)*row])
+
+# ---- the consumers on either side of the solver (SURVEY §8 f4), same names as the reference's procs -------------------------
+proc paramsOf(f: RhsSpec, ctx: NumContext[OdeBatch, float]): seq[cdouble] =
+  for k in f.keys: result.add(ctx.fValues[k].cdouble)
+
+proc cumQuadFn(simpson: bool, f: RhsSpec, X: openArray[float], ctx: NumContext[OdeBatch, float], dx: float,
+               sweep: seq[seq[float]], dim: int): seq[OdeBatch] =
+  ## cumtrapz(f, X, ctx, dx) / cumsimpson(f, X, ctx, dx) (integrate.nim:138-175, 377-400) for N parameter sets at once:
+  ## sweep[k][i] overrides parameter k for item i (empty sweep: one item with ctx's parameters).  result[j] = the batch at X[j].
+  var ctx = ctx
+  if ctx.isNil: ctx = newNumContext[OdeBatch, float]()
+  var params = paramsOf(f, ctx)
+  let n = (if sweep.len > 0: sweep[0].len else: 1)
+  var flat: seq[cdouble]
+  for row in sweep:
+    for v in row: flat.add(v.cdouble)
+  var xs = @X
+  var outBuf = newSeq[cdouble](xs.len * dim * n)
+  var rows: cint
+  let rhsKind = (if f.userKind > 0: f.userKind else: f.kind.int).cint
+  let pp = if params.len > 0: addr params[0] else: nil
+  let sp = if flat.len > 0: addr flat[0] else: nil
+  if simpson:
+    check nnhip_cumsimpson_fn_batch_f64(rhsKind, pp, params.len.cint, sp, sweep.len.cint, n.int64, dim.cint, 0, addr xs[0], xs.len.cint,
+                                        dx.cdouble, addr outBuf[0], addr rows, 0)
+  else:
+    check nnhip_cumtrapz_fn_batch_f64(rhsKind, pp, params.len.cint, sp, sweep.len.cint, n.int64, dim.cint, 0, addr xs[0], xs.len.cint,
+                                      dx.cdouble, addr outBuf[0], addr rows, 0)
+  let row = dim * n
+  for j in 0 ..< rows.int:
+    result.add OdeBatch(n: n, dim: dim, layout: layoutSoA, data: outBuf[j*row ..< (j+1)*row])
+
+proc cumtrapz*(f: RhsSpec, X: openArray[float], ctx: NumContext[OdeBatch, float] = nil, dx = 1e-5,
+               sweep: seq[seq[float]] = @[], dim = 1): seq[OdeBatch] = cumQuadFn(false, f, X, ctx, dx, sweep, dim)
+proc cumsimpson*(f: RhsSpec, X: openArray[float], ctx: NumContext[OdeBatch, float] = nil, dx = 1e-5,
+                 sweep: seq[seq[float]] = @[], dim = 1): seq[OdeBatch] = cumQuadFn(true, f, X, ctx, dx, sweep, dim)
+
+proc flatten(Y: openArray[OdeBatch]): seq[cdouble] =
+  for b in Y:
+    for v in b.data: result.add(v.cdouble)
+
+proc cumtrapz*(Y: openArray[OdeBatch], X: openArray[float]): seq[OdeBatch] =
+  ## cumtrapz(Y, X) for discrete points (integrate.nim:120-135) over every series of a trajectory (Y[j] = the batch at X[j]).
+  var xs = @X
+  var yin = flatten(Y)
+  var outBuf = newSeq[cdouble](yin.len)
+  let m = Y[0].data.len
+  check nnhip_cumtrapz_batch_f64(addr xs[0], xs.len.cint, addr yin[0], m.int64, addr outBuf[0], 0)
+  for j in 0 ..< xs.len:
+    result.add OdeBatch(n: Y[0].n, dim: Y[0].dim, layout: Y[0].layout, data: outBuf[j*m ..< (j+1)*m])
+
+proc cumsimpson*(Y: openArray[OdeBatch], X: openArray[float]): seq[OdeBatch] =
+  ## cumsimpson(Y, X) for discrete points (integrate.nim:329-375).
+  var xs = @X
+  var yin = flatten(Y)
+  var outBuf = newSeq[cdouble](yin.len)
+  let m = Y[0].data.len
+  check nnhip_cumsimpson_batch_f64(addr xs[0], xs.len.cint, addr yin[0], m.int64, addr outBuf[0], 0)
+  for j in 0 ..< xs.len:
+    result.add OdeBatch(n: Y[0].n, dim: Y[0].dim, layout: Y[0].layout, data: outBuf[j*m ..< (j+1)*m])
+
+type BatchHermiteSpline* = object            ## newHermiteSpline(X, Y[, dY]) for a whole batch (interpolate.nim:216-257)
+  X*: seq[float]
+  Y*, dY*: seq[cdouble]                      ## [knots][series]; dY empty -> slopes estimated by the backend
+  proto*: OdeBatch
+
+proc newHermiteSpline*(X: openArray[float], Y: openArray[OdeBatch], dY: openArray[OdeBatch] = []): BatchHermiteSpline =
+  if X.len != Y.len or (dY.len != 0 and dY.len != X.len):
+    raise newException(ValueError, "X and Y and dY must have the same length.")
+  BatchHermiteSpline(X: @X, Y: flatten(Y), dY: flatten(dY), proto: Y[0])
+
+proc evalImpl(s: BatchHermiteSpline, x: openArray[float], deriv: bool, extrap: int, extrapValue: float): seq[OdeBatch] =
+  var xs = s.X
+  var xq = @x
+  var yv = s.Y
+  var dv = s.dY
+  let m = s.proto.data.len
+  var outBuf = newSeq[cdouble](xq.len * m)
+  let dp = if dv.len > 0: addr dv[0] else: nil
+  check nnhip_hermite_spline_eval_batch_f64(addr xs[0], xs.len.cint, addr yv[0], dp, m.int64, addr xq[0], xq.len.cint,
+                                            (if deriv: 1 else: 0).cint, extrap.cint, extrapValue.cdouble, addr outBuf[0], 0)
+  for j in 0 ..< xq.len:
+    result.add OdeBatch(n: s.proto.n, dim: s.proto.dim, layout: s.proto.layout, data: outBuf[j*m ..< (j+1)*m])
+
+proc eval*(s: BatchHermiteSpline, x: openArray[float], extrap = 3, extrapValue = 0.0): seq[OdeBatch] =
+  ## extrap: 0 Constant, 1 Edge, 2 Linear, 3 Native, 4 Error (ExtrapolateKind, interpolate.nim:89-90)
+  evalImpl(s, x, false, extrap, extrapValue)
+proc derivEval*(s: BatchHermiteSpline, x: openArray[float], extrap = 3, extrapValue = 0.0): seq[OdeBatch] =
+  evalImpl(s, x, true, extrap, extrapValue)

@@ -70,6 +70,13 @@ SIGNATURES = {
                                                   C.POINTER(C.c_int), _vp]),
     "nnhip_cumsimpson_fn_batch_f64_dev": (C.c_int, [C.c_int, _dp, C.c_int, _vp, C.c_int, C.c_int64, C.c_int, C.c_int, _dp, C.c_int, C.c_double, _vp,
                                                     C.POINTER(C.c_int), _vp]),
+    "nnhip_cumtrapz_batch_f64": (C.c_int, [_dp, C.c_int, _dp, C.c_int64, _dp, C.c_int]),
+    "nnhip_cumsimpson_batch_f64": (C.c_int, [_dp, C.c_int, _dp, C.c_int64, _dp, C.c_int]),
+    "nnhip_hermite_spline_eval_batch_f64": (C.c_int, [_dp, C.c_int, _dp, _dp, C.c_int64, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _dp, C.c_int]),
+    "nnhip_cumtrapz_fn_batch_f64": (C.c_int, [C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int64, C.c_int, C.c_int, _dp, C.c_int, C.c_double, _dp,
+                                              C.POINTER(C.c_int), C.c_int]),
+    "nnhip_cumsimpson_fn_batch_f64": (C.c_int, [C.c_int, _dp, C.c_int, _dp, C.c_int, C.c_int64, C.c_int, C.c_int, _dp, C.c_int, C.c_double, _dp,
+                                                C.POINTER(C.c_int), C.c_int]),
     "nnhip_ode_controller_factor_f64_dev": (C.c_int, [C.c_int, _vp, _vp, C.c_int64, _vp]),
     "nnhip_ode_rhs_batch_f64_dev": (C.c_int, [C.c_int, _dp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_double, _vp, _vp, _vp]),
 }

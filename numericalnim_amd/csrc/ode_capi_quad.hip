@@ -238,3 +238,117 @@ int nnhip_cumsimpson_fn_batch_f64_dev(int rhs_kind, const double* rhs_params, in
 }
 
 }  // extern "C"
+
+// ---- host-pointer forms of the consumers (what a host language without device-memory management calls): stage, run the
+// device-pointer entry on a private stream, copy back.  Same results bit for bit. ------------------------------------------------
+namespace {
+
+struct HostStage {
+  std::vector<void*> bufs;
+  hipStream_t s = nullptr;
+  ~HostStage() {
+    if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    for (void* b : bufs) (void)hipFree(b);
+  }
+  int begin(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return nnhip::fail_msg(NNHIP_EHIP, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return nnhip::fail_msg(NNHIP_EVALUE, "device %d out of range [0,%d)", device, ndev);
+    if (hipSetDevice(device) != hipSuccess) return nnhip::fail_msg(NNHIP_EHIP, "hipSetDevice(%d) failed", device);
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nnhip::fail_msg(NNHIP_EHIP, "hipStreamCreate failed");
+    return NNHIP_OK;
+  }
+  int upload(const void* host, size_t bytes, void** dev) {  // host may be null: allocate only
+    *dev = nullptr;
+    if (bytes == 0) return NNHIP_OK;
+    const hipError_t e = hipMalloc(dev, bytes);
+    if (e != hipSuccess) return nnhip::fail_msg(e == hipErrorOutOfMemory ? NNHIP_ENOMEM : NNHIP_EHIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    bufs.push_back(*dev);
+    if (host && hipMemcpyAsync(*dev, host, bytes, hipMemcpyHostToDevice, s) != hipSuccess) return nnhip::fail_msg(NNHIP_EHIP, "host-to-device copy failed");
+    return NNHIP_OK;
+  }
+  int download(void* host, const void* dev, size_t bytes) {
+    if (bytes == 0) return NNHIP_OK;
+    if (hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+      return nnhip::fail_msg(NNHIP_EHIP, "device-to-host copy failed");
+    return NNHIP_OK;
+  }
+};
+
+int cumquad_fn_host(int rule, int rhs_kind, const double* rhs_params, int n_params, const double* per_item_params, int n_per_item, int64_t N, int dim,
+                    int layout, const double* X, int n_x, double dx, double* out, int* n_rows_out, int device) {
+  if (N < 0 || dim < 1 || n_x < 1 || n_per_item < 0) return nnhip::fail_msg(NNHIP_EVALUE, "bad sizes");
+  HostStage st;
+  int rc = st.begin(device);
+  if (rc) return rc;
+  void *dPer = nullptr, *dOut = nullptr;
+  const size_t outBytes = (size_t)n_x * (size_t)dim * (size_t)N * sizeof(double);
+  if ((rc = st.upload(n_per_item > 0 ? per_item_params : nullptr, (size_t)n_per_item * (size_t)N * sizeof(double), &dPer))) return rc;
+  if ((rc = st.upload(nullptr, outBytes, &dOut))) return rc;
+  int rows = 0;
+  rc = nnhip::cumquad_fn(rule, rhs_kind, rhs_params, n_params, (const double*)dPer, n_per_item, N, dim, layout, X, n_x, dx, (double*)dOut, &rows, st.s);
+  if (n_rows_out) *n_rows_out = rows;
+  if (rc) return rc;
+  if (N > 0 && rows > 0 && !out) return nnhip::fail_msg(NNHIP_EVALUE, "out is NULL");
+  return st.download(out, dOut, (size_t)rows * (size_t)dim * (size_t)N * sizeof(double));
+}
+
+}  // namespace
+
+extern "C" {
+
+int nnhip_cumtrapz_fn_batch_f64(int rhs_kind, const double* rhs_params, int n_params, const double* per_item_params, int n_per_item, int64_t N,
+                                int dim, int layout, const double* X, int n_x, double dx, double* out, int* n_rows_out, int device) {
+  return cumquad_fn_host(0, rhs_kind, rhs_params, n_params, per_item_params, n_per_item, N, dim, layout, X, n_x, dx, out, n_rows_out, device);
+}
+
+int nnhip_cumsimpson_fn_batch_f64(int rhs_kind, const double* rhs_params, int n_params, const double* per_item_params, int n_per_item, int64_t N,
+                                  int dim, int layout, const double* X, int n_x, double dx, double* out, int* n_rows_out, int device) {
+  return cumquad_fn_host(1, rhs_kind, rhs_params, n_params, per_item_params, n_per_item, N, dim, layout, X, n_x, dx, out, n_rows_out, device);
+}
+
+int nnhip_cumtrapz_batch_f64(const double* X, int n, const double* Y, int64_t M, double* out, int device) {
+  if (n < 1 || M < 0) return nnhip::fail_msg(NNHIP_EVALUE, "bad sizes");
+  HostStage st;
+  int rc = st.begin(device);
+  if (rc) return rc;
+  void *dY = nullptr, *dOut = nullptr;
+  const size_t bytes = (size_t)n * (size_t)M * sizeof(double);
+  if ((rc = st.upload(Y, bytes, &dY)) || (rc = st.upload(nullptr, bytes, &dOut))) return rc;
+  rc = nnhip_cumtrapz_batch_f64_dev(X, n, (const double*)dY, M, (double*)dOut, st.s);
+  if (rc) return nnhip::fail_msg(rc, "cumtrapz(Y, X): bad arguments (X must be strictly ascending) or launch failure");
+  return st.download(out, dOut, bytes);
+}
+
+int nnhip_cumsimpson_batch_f64(const double* X, int n, const double* Y, int64_t M, double* out, int device) {
+  if (n < 1 || M < 0) return nnhip::fail_msg(NNHIP_EVALUE, "bad sizes");
+  HostStage st;
+  int rc = st.begin(device);
+  if (rc) return rc;
+  void *dY = nullptr, *dOut = nullptr;
+  const size_t bytes = (size_t)n * (size_t)M * sizeof(double);
+  if ((rc = st.upload(Y, bytes, &dY)) || (rc = st.upload(nullptr, bytes, &dOut))) return rc;
+  rc = nnhip_cumsimpson_batch_f64_dev(X, n, (const double*)dY, M, (double*)dOut, st.s);
+  if (rc) return nnhip::fail_msg(rc, "cumsimpson(Y, X): needs >= 3 strictly ascending points (ValueError, integrate.nim:345-346) or launch failure");
+  return st.download(out, dOut, bytes);
+}
+
+int nnhip_hermite_spline_eval_batch_f64(const double* X, int n_knots, const double* Y, const double* dY, int64_t M, const double* xq, int n_q,
+                                        int deriv, int extrap, double extrap_value, double* out, int device) {
+  if (n_knots < 2 || M < 0 || n_q < 0) return nnhip::fail_msg(NNHIP_EVALUE, "bad sizes");
+  HostStage st;
+  int rc = st.begin(device);
+  if (rc) return rc;
+  void *dYd = nullptr, *ddY = nullptr, *dOut = nullptr;
+  const size_t bytes = (size_t)n_knots * (size_t)M * sizeof(double);
+  if ((rc = st.upload(Y, bytes, &dYd)) || (rc = st.upload(dY, bytes, &ddY)) || (rc = st.upload(nullptr, (size_t)n_q * (size_t)M * sizeof(double), &dOut))) return rc;
+  if (!dY && M > 0) {  // newHermiteSpline(X, Y): estimate the slopes (interpolate.nim:241-253)
+    rc = nnhip_hermite_spline_slopes_f64_dev(X, n_knots, (const double*)dYd, M, (double*)ddY, st.s);
+    if (rc) return nnhip::fail_msg(rc, "newHermiteSpline(X, Y): X must be strictly ascending");
+  }
+  rc = nnhip_hermite_spline_eval_batch_f64_dev(X, n_knots, (const double*)dYd, (const double*)ddY, M, xq, n_q, deriv, extrap, extrap_value, (double*)dOut, st.s);
+  if (rc) return nnhip::fail_msg(rc, "HermiteSpline eval: bad arguments (X strictly ascending, extrap in 0..4; Error extrapolation raises outside the knots)");
+  return st.download(out, dOut, (size_t)n_q * (size_t)M * sizeof(double));
+}
+
+}  // extern "C"

@@ -31,10 +31,16 @@ class HermiteSpline:
     own series).  X must be strictly ascending (the solver's output grid is, unless tStart is duplicated)."""
 
     def __init__(self, X, Y, dY=None):
-        import torch
         self.X = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
+        self.host = isinstance(Y, np.ndarray)  # numpy series: host-pointer entry (staged through the device per call)
         if len(self.X) != Y.shape[0] or (dY is not None and len(self.X) != dY.shape[0]):
             raise ValueError("X and Y and dY must have the same length.")  # interpolate.nim:229-230
+        if self.host:
+            self.Y = np.ascontiguousarray(Y, dtype=np.float64)
+            self.dY = None if dY is None else np.ascontiguousarray(dY, dtype=np.float64)
+            self.M = int(self.Y[0].size)
+            return
+        import torch
         self.Y = Y.contiguous()
         self.M = int(self.Y[0].numel())
         if dY is None:  # newHermiteSpline(X, Y): three-point difference slopes (interpolate.nim:241-253)
@@ -46,8 +52,15 @@ class HermiteSpline:
             self.dY = dY.contiguous()
 
     def _run(self, x, deriv, extrap, extrapValue):
-        import torch
         xq = np.ascontiguousarray(np.atleast_1d(np.asarray(x, dtype=np.float64)))
+        dp = C.POINTER(C.c_double)
+        if self.host:
+            out = np.empty((len(xq),) + self.Y.shape[1:], dtype=np.float64)
+            _check(_lib.lib().nnhip_hermite_spline_eval_batch_f64(
+                self.X.ctypes.data_as(dp), len(self.X), self.Y.ctypes.data_as(dp), None if self.dY is None else self.dY.ctypes.data_as(dp), self.M,
+                xq.ctypes.data_as(dp), len(xq), int(deriv), ExtrapolateKind[extrap], float(extrapValue or 0.0), out.ctypes.data_as(dp), 0))
+            return out if np.ndim(x) else out[0]
+        import torch
         out = torch.empty((len(xq),) + tuple(self.Y.shape[1:]), dtype=torch.float64, device=self.Y.device)
         with torch.cuda.device(self.Y.device):
             _check(_lib.lib().nnhip_hermite_spline_eval_batch_f64_dev(
@@ -68,17 +81,30 @@ def newHermiteSpline(X, Y, dY=None):
     return HermiteSpline(X, Y, dY)
 
 
-def _cumquad_fn(entry, f, X, ctx, dx, sweep, n, dim, device, layout):
+def _cumquad_fn(rule, f, X, ctx, dx, sweep, n, dim, device, layout):
     """The function-argument forms cumtrapz(f, X, ctx, dx) / cumsimpson(f, X, ctx, dx) (integrate.nim:138-175, 377-400):
     f is an Rhs whose value at (x, y=0) is the integrand; the batch axis is a parameter sweep (`sweep` [k, N] CUDA tensor of per-item
     values for the first k parameters) or N identical items.  Returns [rows, dim, N] (SoA) / [rows, N, dim] (AoS) with
     rows <= len(X) exactly as the reference's hermiteInterpolate produces them; dim == 1 results are squeezed to [rows, N]."""
-    import torch
     Xa = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
     if Xa.ndim != 1 or len(Xa) < 1:
         raise ValueError("X must be a non-empty 1-d sequence")
     p, pp = _params_array(f, ctx)
     dim = int(getattr(f, "dim", dim))  # run-time compiled integrands know their own size
+    if isinstance(sweep, np.ndarray) or (sweep is None and device == "host"):  # host arrays in, host array out
+        dp = C.POINTER(C.c_double)
+        sw = None if sweep is None else np.ascontiguousarray(sweep, dtype=np.float64)
+        if sw is not None and sw.ndim != 2:
+            raise ValueError("sweep must have shape [k, N]")
+        N, k = (int(n), 0) if sw is None else (int(sw.shape[1]), int(sw.shape[0]))
+        shape = (len(Xa), dim, N) if layout == LAYOUT_SOA else (len(Xa), N, dim)
+        out = np.full(shape, np.nan)
+        rows = C.c_int(0)
+        _check(getattr(_lib.lib(), f"nnhip_{rule}_fn_batch_f64")(f.kind, pp, int(p.size), None if sw is None else sw.ctypes.data_as(dp), k, N, dim, layout, Xa.ctypes.data_as(dp), len(Xa),
+                          float(dx), out.ctypes.data_as(dp), C.byref(rows), 0))
+        out = out[:rows.value]
+        return out.reshape(rows.value, N) if dim == 1 else out
+    import torch
     if sweep is not None:
         sw = sweep.contiguous()
         if not sw.is_cuda or sw.dtype != torch.float64 or sw.ndim != 2:
@@ -91,7 +117,7 @@ def _cumquad_fn(entry, f, X, ctx, dx, sweep, n, dim, device, layout):
     out = torch.full(shape, float("nan"), dtype=torch.float64, device=device)
     rows = C.c_int(0)
     with torch.cuda.device(device):
-        _check(entry(f.kind, pp, int(p.size), swp, k, N, dim, layout, Xa.ctypes.data_as(C.POINTER(C.c_double)), len(Xa), float(dx),
+        _check(getattr(_lib.lib(), f"nnhip_{rule}_fn_batch_f64_dev")(f.kind, pp, int(p.size), swp, k, N, dim, layout, Xa.ctypes.data_as(C.POINTER(C.c_double)), len(Xa), float(dx),
                      out.data_ptr(), C.byref(rows), torch.cuda.current_stream().cuda_stream))
     out = out[:rows.value]
     if dim == 1:
@@ -106,10 +132,16 @@ def cumtrapz(Y, X, ctx=None, dx=1e-5, sweep=None, n=1, dim=1, device=None, layou
     import torch
     from .ode import Rhs
     if isinstance(Y, Rhs):
-        return _cumquad_fn(_lib.lib().nnhip_cumtrapz_fn_batch_f64_dev, Y, X, ctx, dx, sweep, n, dim, device, layout)
+        return _cumquad_fn("cumtrapz", Y, X, ctx, dx, sweep, n, dim, device, layout)
     Xa = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
     if len(Xa) != Y.shape[0]:
         raise ValueError("X and Y must have the same length")  # utils.nim:423-424
+    if isinstance(Y, np.ndarray):  # host series: host-pointer entry
+        Yh = np.ascontiguousarray(Y, dtype=np.float64)
+        outh = np.empty_like(Yh)
+        dp = C.POINTER(C.c_double)
+        _check(_lib.lib().nnhip_cumtrapz_batch_f64(Xa.ctypes.data_as(dp), len(Xa), Yh.ctypes.data_as(dp), int(Yh[0].size), outh.ctypes.data_as(dp), 0))
+        return outh
     Yc = Y.contiguous()
     out = torch.empty_like(Yc)
     with torch.cuda.device(Yc.device):
@@ -124,12 +156,18 @@ def cumsimpson(Y, X, ctx=None, dx=1e-5, sweep=None, n=1, dim=1, device=None, lay
     import torch
     from .ode import Rhs
     if isinstance(Y, Rhs):
-        return _cumquad_fn(_lib.lib().nnhip_cumsimpson_fn_batch_f64_dev, Y, X, ctx, dx, sweep, n, dim, device, layout)
+        return _cumquad_fn("cumsimpson", Y, X, ctx, dx, sweep, n, dim, device, layout)
     Xa = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
     if len(Xa) != Y.shape[0]:
         raise ValueError("X and Y must have the same length")
     if len(Xa) < 3:
         raise ValueError("X and Y must have at least 3 elements to perform Simpson, use cumtrapz instead")  # integrate.nim:345-346
+    if isinstance(Y, np.ndarray):
+        Yh = np.ascontiguousarray(Y, dtype=np.float64)
+        outh = np.empty_like(Yh)
+        dp = C.POINTER(C.c_double)
+        _check(_lib.lib().nnhip_cumsimpson_batch_f64(Xa.ctypes.data_as(dp), len(Xa), Yh.ctypes.data_as(dp), int(Yh[0].size), outh.ctypes.data_as(dp), 0))
+        return outh
     Yc = Y.contiguous()
     out = torch.empty_like(Yc)
     with torch.cuda.device(Yc.device):

@@ -73,6 +73,42 @@ int main() {
     try { rhsFromSource(1, "dy[0] = undefined_symbol;"); } catch (const std::invalid_argument&) { threwSrc = true; }
     CHECK(threwSrc);
   }
+  // the consumers, as tests/test_integrate.nim:19-21, 67-95 and tests/test_interpolate.nim:5-18, 104-145 use them
+  {
+    std::printf("test \"cumtrapz / cumsimpson / HermiteSpline\"\n");
+    const double pi = 3.14159265358979323846;
+    const std::vector<double> X = linspace(0.0, 1.5 * pi, 17);
+    std::vector<OdeBatch> Y(X.size(), OdeBatch::zeros(2, 1));  // two series: 2 cos x and 4 cos x
+    for (size_t j = 0; j < X.size(); ++j) { Y[j].at(0, 0) = 2.0 * std::cos(X[j]); Y[j].at(1, 0) = 4.0 * std::cos(X[j]); }
+    const auto ct = cumtrapz(Y, X), cs = cumsimpson(Y, X);
+    for (size_t j = 0; j < X.size(); ++j) {
+      CHECK(isClose(ct[j].at(0, 0), 2.0 * std::sin(X[j]), 1e-1) && isClose(cs[j].at(0, 0), 2.0 * std::sin(X[j]), 1e-3));  // :67-70, :82-85
+      CHECK(isClose(cs[j].at(1, 0), 4.0 * std::sin(X[j]), 2e-3));
+    }
+    const RhsSpec acos = rhsFromSource(1, "dy[0] = p[0] * cos(t);", {"a"}, {{"a", 2.0}}, "acos_cpp");
+    for (double dx : {1e-5, 0.1}) {  // "cumtrapz func ..." / "cumsimpson func ..." (:72-95)
+      const auto ft = cumtrapz<double>(acos, X, nullptr, dx), fs = cumsimpson<double>(acos, X, nullptr, dx);
+      CHECK(ft.size() == X.size() && fs.size() == X.size());
+      for (size_t j = 0; j < X.size(); ++j) CHECK(isClose(ft[j].at(0, 0), 2.0 * std::sin(X[j]), 1e-1) && isClose(fs[j].at(0, 0), 2.0 * std::sin(X[j]), 1e-3));
+    }
+    const auto sw = cumsimpson<double>(acos, X, nullptr, 1e-2, {{1.0, 2.0, 3.0}});  // a parameter sweep: three amplitudes at once
+    for (size_t j = 0; j < X.size(); ++j) for (int i = 0; i < 3; ++i) CHECK(isClose(sw[j].at(i, 0), (i + 1.0) * std::sin(X[j]), 1e-3));
+    const std::vector<double> t = linspace(0.0, 10.0, 100);
+    std::vector<OdeBatch> ys(t.size(), OdeBatch::zeros(1, 1)), dys(t.size(), OdeBatch::zeros(1, 1));
+    for (size_t j = 0; j < t.size(); ++j) { ys[j].at(0, 0) = std::sin(t[j]); dys[j].at(0, 0) = std::cos(t[j]); }
+    std::vector<double> tTest;  // arange(0.0, 10.0, 0.2345)
+    for (int i = 0; i <= (int)std::floor(10.0 / 0.2345); ++i) tTest.push_back(0.0 + (double)i * 0.2345);
+    const HermiteSpline h2 = newHermiteSpline(t, ys, dys), h1 = newHermiteSpline(t, ys);
+    const auto e2 = h2.eval(t), e1 = h1.eval(t), b2 = h2.eval(tTest), d2 = h2.derivEval(tTest), d1 = h1.derivEval(tTest);
+    for (size_t j = 0; j < t.size(); ++j) CHECK(isClose(e2[j].at(0, 0), ys[j].at(0, 0), 1e-15) && isClose(e1[j].at(0, 0), ys[j].at(0, 0), 1e-15));
+    for (size_t j = 0; j < tTest.size(); ++j) {
+      CHECK(isClose(b2[j].at(0, 0), std::sin(tTest[j]), 1e-4));
+      CHECK(std::fabs(d2[j].at(0, 0) - std::cos(tTest[j])) < 1e-5 && std::fabs(d1[j].at(0, 0) - std::cos(tTest[j])) < 2e-3);
+    }
+    bool threwX = false;
+    try { h2.eval({11.0}, ExtrapolateKind::Error); } catch (const std::invalid_argument&) { threwX = true; }
+    CHECK(threwX);
+  }
   // error behaviour: ValueError analogues
   bool threw = false;
   try { solveODE(f, y0, tspan, DEFAULT_ODEoptions(), &ctx, "rk5"); } catch (const std::invalid_argument&) { threw = true; }

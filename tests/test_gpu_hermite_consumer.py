@@ -101,3 +101,35 @@ def test_hermite_spline_without_dy(nn, oracle, dev):
         assert np.array_equal(dv[:, m], O.hermite_interp(X, Yh[:, m], slopes, xq, deriv=True))
     with pytest.raises(ValueError):
         nn.newHermiteSpline(X[:1], Y[:1])
+
+
+def test_host_pointer_forms_equal_the_device_forms(nn, dev):
+    """The consumers called with host arrays (what the Nim shim would do) stage through the device and return the same bits:
+    HermiteSpline with and without dY, cumtrapz, cumsimpson, and the function forms with a host parameter sweep."""
+    import torch
+    rng = np.random.default_rng(12)
+    X = np.cumsum(0.05 + rng.random(41))
+    Yh = np.stack([np.cos(X) * (1 + k) for k in range(6)], axis=1)
+    dYh = np.stack([-np.sin(X) * (1 + k) for k in range(6)], axis=1)
+    Y, dY = torch.from_numpy(Yh).to(dev), torch.from_numpy(dYh).to(dev)
+    xq = X[0] + (X[-1] - X[0]) * rng.random(30)
+    for args_h, args_d in (((Yh, dYh), (Y, dY)), ((Yh,), (Y,))):
+        sh, sd = nn.newHermiteSpline(X, *args_h), nn.newHermiteSpline(X, *args_d)
+        assert isinstance(sh.eval(xq), np.ndarray)
+        assert np.array_equal(sh.eval(xq), sd.eval(xq).cpu().numpy()) and np.array_equal(sh.derivEval(xq), sd.derivEval(xq).cpu().numpy())
+        assert np.array_equal(sh.eval(X[-1] + 1.0, extrap="Linear"), sd.eval(X[-1] + 1.0, extrap="Linear").cpu().numpy())
+    assert np.array_equal(nn.cumtrapz(Yh, X), nn.cumtrapz(Y, X).cpu().numpy())
+    assert np.array_equal(nn.cumsimpson(Yh, X), nn.cumsimpson(Y, X).cpu().numpy())
+    f = nn.Rhs.custom(2, "dy[0] = p[0] * t * t; dy[1] = p[1] * (1.0 - t);", keys=("a", "b"), defaults={"a": 0.0, "b": 0.0}, name="host_forms")
+    sw = rng.uniform(-1, 1, (2, 500))
+    Xq = np.array([0.0, 0.4, 0.1, 1.0])
+    for fn in (nn.cumtrapz, nn.cumsimpson):
+        h = fn(f, Xq, dx=1e-2, sweep=sw)
+        d = fn(f, Xq, dx=1e-2, sweep=torch.from_numpy(sw).to(dev))
+        assert isinstance(h, np.ndarray) and np.array_equal(h, d.cpu().numpy())
+        assert np.array_equal(fn(f, Xq, dx=1e-2, n=3, device="host", ctx=nn.newNumContext({"a": 0.5, "b": 2.0})),
+                              fn(f, Xq, dx=1e-2, n=3, ctx=nn.newNumContext({"a": 0.5, "b": 2.0})).cpu().numpy())
+    with pytest.raises(ValueError):
+        nn.cumsimpson(Yh[:2], X[:2])
+    with pytest.raises(ValueError):
+        nn.cumtrapz(Yh, X[::-1].copy())
