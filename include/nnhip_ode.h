@@ -146,6 +146,13 @@ int nnhip_ode_solve_batch_f64(const nnhip_ode_options* opt, int integrator, int 
                               int n_params, const double* y0, int64_t N, int dim, int layout, const double* tspan,
                               int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
                               int64_t* rejected_out, int64_t max_steps, nnhip_ode_stats* stats, int device);
+/* The same with PER-IVP right-hand-side parameters in host memory (see nnhip_ode_solve_batch_sweep_f64_dev): parameter k of IVP i
+ * = per_ivp_params[k*N + i] for k < n_per_ivp, overriding rhs_params[k]. */
+int nnhip_ode_solve_batch_sweep_f64(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
+                                    int n_params, const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t N,
+                                    int dim, int layout, const double* tspan, int n_t, double* t_out, double* y_out,
+                                    int32_t* ny_out, int64_t* steps_out, int64_t* rejected_out, int64_t max_steps,
+                                    nnhip_ode_stats* stats, int device);
 
 /* Device-pointer form (asynchronous on `stream`).  y0/y_out/ny_out/steps_out/rejected_out are device
  * pointers on the current device; tspan/t_out stay host pointers (tiny, shared by the batch).

@@ -118,7 +118,9 @@ struct OdeSolution {
 template <class T = double>
 inline OdeSolution solveODE(const RhsSpec& f, const OdeBatch& y0, const std::vector<double>& tspan,
                             const ODEoptions& options = DEFAULT_ODEoptions(), const NumContext<T>* ctx = nullptr,
-                            const std::string& integrator = "dopri54", int device = 0, int n_gpus = 1) {
+                            const std::string& integrator = "dopri54", int device = 0, int n_gpus = 1,
+                            const std::vector<std::vector<double>>& sweep = {}) {
+  // sweep[k][i]: value of RHS parameter k for IVP i (a parameter sweep: every IVP its own ctx); empty = one ctx for the batch
   const int integ = nnhip_ode_integrator_id(integrator.c_str());
   if (integ < 0) throw std::invalid_argument(integrator + " is not a valid integrator");  // ode.nim:651
   const std::vector<double> p = f.params(ctx);
@@ -129,11 +131,18 @@ inline OdeSolution solveODE(const RhsSpec& f, const OdeBatch& y0, const std::vec
   sol.ny.assign((size_t)y0.N, 0);
   int rc;
   if (n_gpus > 1) {
+    if (!sweep.empty()) throw std::invalid_argument("parameter sweeps are single-device");
     rc = nnhip_ode_solve_batch_multi_gpu_f64(&options, integ, f.kind, p.data(), (int)p.size(), y0.data.data(), y0.N, y0.dim, y0.layout,
                                              tspan.data(), n_t, sol.t.data(), yout.data(), sol.ny.data(), 0, &sol.stats, n_gpus);
   } else {
-    rc = nnhip_ode_solve_batch_f64(&options, integ, f.kind, p.data(), (int)p.size(), y0.data.data(), y0.N, y0.dim, y0.layout,
-                                   tspan.data(), n_t, sol.t.data(), yout.data(), sol.ny.data(), nullptr, nullptr, 0, &sol.stats, device);
+    std::vector<double> flat;
+    for (const auto& row : sweep) {
+      if ((int64_t)row.size() != y0.N) throw std::invalid_argument("sweep rows must have one value per IVP");
+      flat.insert(flat.end(), row.begin(), row.end());
+    }
+    rc = nnhip_ode_solve_batch_sweep_f64(&options, integ, f.kind, p.data(), (int)p.size(), flat.empty() ? nullptr : flat.data(), (int)sweep.size(),
+                                         y0.data.data(), y0.N, y0.dim, y0.layout, tspan.data(), n_t, sol.t.data(), yout.data(), sol.ny.data(), nullptr,
+                                         nullptr, 0, &sol.stats, device);
   }
   throwOn(rc);
   sol.t.resize((size_t)sol.stats.n_t_out);

@@ -46,9 +46,9 @@ proc check(rc: cint) =
 
 proc solveODE*(f: RhsSpec, y0: OdeBatch, tspan: openArray[float],
                options: ODEoptions = newODEoptions(), ctx: NumContext[OdeBatch, float] = nil,
-               integrator = "dopri54", nGpus = 1): (seq[float], seq[OdeBatch]) =
+               integrator = "dopri54", nGpus = 1, sweep: seq[seq[float]] = @[]): (seq[float], seq[OdeBatch]) =
   ## Batched drop-in for ode.nim:589-651: same parameter names, order and defaults; returns (t, y) where
-  ## y[j] is the whole batch at t[j].
+  ## y[j] is the whole batch at t[j].  sweep[k][i] = value of RHS parameter k for IVP i (every IVP its own ctx); single device.
   var ctx = ctx
   if ctx.isNil: ctx = newNumContext[OdeBatch, float]()               # ode.nim:604-606
   let integ = nnhip_ode_integrator_id(integrator.cstring)           # toLower + dispatch, ode.nim:607-651
@@ -69,9 +69,13 @@ proc solveODE*(f: RhsSpec, y0: OdeBatch, tspan: openArray[float],
                                               y0.dim.cint, y0.layout.cint, addr ts[0], ts.len.cint, addr tOut[0],
                                               addr yOut[0], addr ny[0], 0, addr stats, nGpus.cint)
   else:
-    check nnhip_ode_solve_batch_f64(addr opt, integ, rhsKind, pp, params.len.cint, addr y0d[0], y0.n.int64,
-                                    y0.dim.cint, y0.layout.cint, addr ts[0], ts.len.cint, addr tOut[0], addr yOut[0],
-                                    addr ny[0], nil, nil, 0, addr stats, 0)
+    var flat: seq[cdouble]
+    for row in sweep:
+      for v in row: flat.add(v.cdouble)
+    let sp = if flat.len > 0: addr flat[0] else: nil
+    check nnhip_ode_solve_batch_sweep_f64(addr opt, integ, rhsKind, pp, params.len.cint, sp, sweep.len.cint, addr y0d[0], y0.n.int64,
+                                          y0.dim.cint, y0.layout.cint, addr ts[0], ts.len.cint, addr tOut[0], addr yOut[0],
+                                          addr ny[0], nil, nil, 0, addr stats, 0)
   result[0] = tOut[0 ..< stats.nTOut.int]
   let row = y0.n * y0.dim
   for j in 0 ..< ts.len:

@@ -42,6 +42,8 @@ SIGNATURES = {
     "nnhip_ode_supported": (C.c_int, [C.c_int] * 5),
     "nnhip_ode_solve_batch_f64": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, _vp, C.c_int64, C.c_int, C.c_int,
                                             _dp, C.c_int, _dp, _vp, _vp, _vp, _vp, C.c_int64, C.POINTER(Stats), C.c_int]),
+    "nnhip_ode_solve_batch_sweep_f64": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, _vp, C.c_int, _vp, C.c_int64, C.c_int, C.c_int,
+                                                  _dp, C.c_int, _dp, _vp, _vp, _vp, _vp, C.c_int64, C.POINTER(Stats), C.c_int]),
     "nnhip_ode_solve_workspace_bytes": (C.c_int64, [C.c_int]),
     "nnhip_ode_solve_batch_f64_dev": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, _vp, C.c_int64, C.c_int,
                                                 C.c_int, _dp, C.c_int, _dp, _vp, _vp, _vp, _vp, C.c_int64, _vp, C.c_int64, _vp]),

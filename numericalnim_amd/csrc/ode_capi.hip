@@ -574,7 +574,16 @@ int nnhip_ode_solve_batch_f64(const nnhip_ode_options* opt, int integrator, int 
                               int n_params, const double* y0, int64_t N, int dim, int layout, const double* tspan,
                               int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
                               int64_t* rejected_out, int64_t max_steps, nnhip_ode_stats* stats, int device) {
+  return nnhip_ode_solve_batch_sweep_f64(opt, integrator, rhs_kind, rhs_params, n_params, nullptr, 0, y0, N, dim, layout, tspan, n_t, t_out, y_out,
+                                         ny_out, steps_out, rejected_out, max_steps, stats, device);
+}
+
+int nnhip_ode_solve_batch_sweep_f64(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
+                                    int n_params, const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t N, int dim,
+                                    int layout, const double* tspan, int n_t, double* t_out, double* y_out, int32_t* ny_out,
+                                    int64_t* steps_out, int64_t* rejected_out, int64_t max_steps, nnhip_ode_stats* stats, int device) {
   if (N < 0 || dim < 1 || n_t < 0) return fail(NNHIP_EVALUE, "bad sizes");
+  if (n_per_ivp < 0 || n_per_ivp > nnhip::kMaxParams || (n_per_ivp > 0 && !per_ivp_params)) return fail(NNHIP_EVALUE, "bad per-IVP parameter table");
   if (!opt || (n_t > 0 && !tspan)) return fail(NNHIP_EVALUE, "options / tspan is NULL");
   for (int j = 0; j < n_t; ++j) if (!std::isfinite(tspan[j])) return fail(NNHIP_EVALUE, "tspan[%d] is not finite", j);
   if (!std::isfinite(opt->tStart)) return fail(NNHIP_EVALUE, "options.tStart is not finite");
@@ -591,8 +600,9 @@ int nnhip_ode_solve_batch_f64(const nnhip_ode_options* opt, int integrator, int 
   int32_t* d_ny = nullptr;
   int64_t *d_steps = nullptr, *d_rej = nullptr;
   void* d_ws = nullptr;
+  double* d_per = nullptr;  // per-IVP parameter table [n_per_ivp][N]
   unsigned long long* d_agg = nullptr;
-  hipStream_t s[2] = {nullptr, nullptr};  // borrowed from the per-thread context (host_ctx_for), not owned
+  hipStream_t s[2] = {nullptr, nullptr};  // borrowed from the pool (host_ctx_acquire), not owned
   hipEvent_t* evs = nullptr;
   hipEvent_t evPrep = nullptr;
   HostSolveCtx* hc = nullptr;
@@ -604,7 +614,7 @@ int nnhip_ode_solve_batch_f64(const nnhip_ode_options* opt, int integrator, int 
     for (hipStream_t st : s) if (st) (void)hipStreamSynchronize(st);  // nothing may still be reading the buffers freed below
     if (regIn) (void)hipHostUnregister((void*)y0);
     if (regOut) (void)hipHostUnregister((void*)y_out);
-    void* bufs[] = {d_y0, d_out, d_ny, d_steps, d_rej, d_ws, d_agg};
+    void* bufs[] = {d_y0, d_out, d_ny, d_steps, d_rej, d_ws, d_agg, d_per};
     for (void* b : bufs) if (b) (void)hipFree(b);
     host_ctx_release(hc);
     hc = nullptr;
@@ -632,6 +642,10 @@ int nnhip_ode_solve_batch_f64(const nnhip_ode_options* opt, int integrator, int 
   if (steps_out && N) HIP_TRY_C(hipMalloc((void**)&d_steps, (size_t)N * sizeof(int64_t)));
   if (rejected_out && N) HIP_TRY_C(hipMalloc((void**)&d_rej, (size_t)N * sizeof(int64_t)));
   HIP_TRY_C(hipMalloc(&d_ws, (size_t)wsBytes));
+  if (n_per_ivp > 0 && N > 0) {  // the whole table goes up front: a chunk addresses its columns of the full [k][N] table
+    HIP_TRY_C(hipMalloc((void**)&d_per, (size_t)n_per_ivp * (size_t)N * sizeof(double)));
+    HIP_TRY_C(hipMemcpy(d_per, per_ivp_params, (size_t)n_per_ivp * (size_t)N * sizeof(double), hipMemcpyHostToDevice));
+  }
   HIP_TRY_C(hipMalloc((void**)&d_agg, nnhip::kAggSlots * 8 * sizeof(unsigned long long)));
   {
     std::vector<unsigned long long> init((size_t)nnhip::kAggSlots * 8, 0ull);
@@ -644,7 +658,7 @@ int nnhip_ode_solve_batch_f64(const nnhip_ode_options* opt, int integrator, int 
     (void)hipGetLastError();
   }
   PreparedSolve ps;
-  rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, nullptr, 0, d_y0, N, dim, layout, tspan, n_t, t_out, d_out, d_ny, d_steps,
+  rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, d_per, d_per ? n_per_ivp : 0, d_y0, N, dim, layout, tspan, n_t, t_out, d_out, d_ny, d_steps,
                      d_rej, max_steps, d_ws, wsBytes, d_agg, &nTOut, s[0], ps);
   if (rc) { cleanup(); return rc; }
   HIP_TRY_C(hipEventRecord(evPrep, s[0]));

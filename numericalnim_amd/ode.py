@@ -278,10 +278,16 @@ def solveODE(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=
         st = np.empty(N, dtype=np.int64) if return_counts else None
         rj = np.empty(N, dtype=np.int64) if return_counts else None
         s = stats if stats is not None else Stats()
-        _check(L.nnhip_ode_solve_batch_f64(C.byref(options), integ, f.kind, pp, int(p.size), y0c.ctypes.data, N, dim, layout, tsp,
-                                           n_t, tp, y.ctypes.data, ny.ctypes.data if return_counts else None,
-                                           st.ctypes.data if return_counts else None, rj.ctypes.data if return_counts else None,
-                                           int(max_steps), C.byref(s), 0))
+        swh, kh = None, 0
+        if sweep is not None:  # per-IVP parameters in host memory
+            swa = np.ascontiguousarray(np.asarray(sweep, dtype=np.float64))
+            if swa.ndim != 2 or swa.shape[1] != N:
+                raise ValueError("sweep must have shape [k, N]")
+            swh, kh = swa.ctypes.data, int(swa.shape[0])
+        _check(L.nnhip_ode_solve_batch_sweep_f64(C.byref(options), integ, f.kind, pp, int(p.size), swh, kh, y0c.ctypes.data, N, dim, layout, tsp,
+                                                 n_t, tp, y.ctypes.data, ny.ctypes.data if return_counts else None,
+                                                 st.ctypes.data if return_counts else None, rj.ctypes.data if return_counts else None,
+                                                 int(max_steps), C.byref(s), 0))
     t = t_out[:ntout.value].copy()
     if return_counts:
         return t, y, dict(ny=ny, steps=st, rejected=rj)

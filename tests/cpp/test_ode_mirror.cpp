@@ -73,6 +73,22 @@ int main() {
     try { rhsFromSource(1, "dy[0] = undefined_symbol;"); } catch (const std::invalid_argument&) { threwSrc = true; }
     CHECK(threwSrc);
   }
+  // a parameter sweep: every IVP with its own `a` must equal separate solves with that `a`
+  {
+    std::printf("test \"parameter sweep\"\n");
+    OdeBatch yb = OdeBatch::zeros(3, 1);
+    for (int i = 0; i < 3; ++i) yb.at(i, 0) = 1.0;
+    const std::vector<double> as = {-0.1, -0.5, 0.25};
+    OdeSolution all = solveODE(f, yb, tspan, DEFAULT_ODEoptions(), &ctx, "dopri54", 0, 1, {as});
+    for (int i = 0; i < 3; ++i) {
+      NumContext<double> ci;
+      ci.setF("a", as[i]);
+      OdeBatch y1 = OdeBatch::zeros(1, 1);
+      y1.at(0, 0) = 1.0;
+      OdeSolution one = solveODE(f, y1, tspan, DEFAULT_ODEoptions(), &ci, "dopri54");
+      for (size_t j = 0; j < one.y.size(); ++j) CHECK(all.y[j].at(i, 0) == one.y[j].at(0, 0));
+    }
+  }
   // the consumers, as tests/test_integrate.nim:19-21, 67-95 and tests/test_interpolate.nim:5-18, 104-145 use them
   {
     std::printf("test \"cumtrapz / cumsimpson / HermiteSpline\"\n");

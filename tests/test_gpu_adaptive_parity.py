@@ -508,3 +508,19 @@ def test_sort_by_returns_identical_results_in_caller_order(nn, dev):
     y0a = y0.t().contiguous()
     c = nn.solveODE(nn.Rhs.vanderpol(), y0a, ts, opt, integrator="tsit54", sweep=mu[None, :], layout=1, sort_by=mu)
     assert torch.equal(c[1].permute(0, 2, 1), a[1])
+
+
+def test_parameter_sweep_through_the_host_pointer_entry(nn, dev):
+    """solveODE(numpy y0, sweep=numpy [k, N]) (nnhip_ode_solve_batch_sweep_f64) == the device-pointer sweep bit for bit."""
+    import torch
+    n = 5000
+    rng = np.random.default_rng(21)
+    y0 = np.stack([1.0 + rng.random(n), np.ones(n), np.ones(n)])
+    sw = np.stack([np.full(n, 10.0), rng.uniform(20, 30, n)])  # per-IVP sigma, rho; beta from the Rhs defaults
+    ts = [0.0, 0.3, 0.6]
+    th, yh, ch = nn.solveODE(nn.Rhs.lorenz(), y0, ts, nn.newODEoptions(), integrator="tsit54", sweep=sw, return_counts=True)
+    td, yd, cd = nn.solveODE(nn.Rhs.lorenz(), torch.from_numpy(y0).to(dev), ts, nn.newODEoptions(), integrator="tsit54", sweep=torch.from_numpy(sw).to(dev),
+                             return_counts=True)
+    assert np.array_equal(yh, yd.cpu().numpy()) and np.array_equal(ch["steps"], cd["steps"].cpu().numpy())
+    plain = nn.solveODE(nn.Rhs.lorenz(), y0, ts, nn.newODEoptions(), integrator="tsit54")[1]
+    assert not np.array_equal(plain, yh)  # the sweep really changes the trajectories
