@@ -245,6 +245,25 @@ def main():
                               "bound": "fp64-valu", "model_fp64_flop_per_s": 16.0 * n * nsteps / fs,  # SURVEY.md §8d model: 16 flop per step (≈12 VALU instructions after sign folding)
                               "bitwise_equal_to_stream": bool(torch.equal(yfu[-1], yf))}
 
+    # ---- informational: the same kernel on a batch that cannot live in the 256 MiB Infinity Cache (1 GB of ping-pong state) ----
+    if not args.no_fused and world == 1 and n <= 20_000_000:
+        nb = 64_000_000
+        yb = nd.c2_y0_torch(0, nb, dev)
+        sb = torch.empty_like(yb)
+        tb_end = 100 * dt
+        nn.fixedStream(f, yb, 0.0, tb_end, opt, integrator="rk4", scratch=sb)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _, nsb = nn.fixedStream(f, yb, 0.0, tb_end, opt, integrator="rk4", scratch=sb)
+        e1.record()
+        torch.cuda.synchronize()
+        lb = e0.elapsed_time(e1) * 1e-3 / nsb
+        out["beyond_infinity_cache"] = {"ivps": nb, "launches": int(nsb), "avg_launch_us": lb * 1e6, "achieved": 16.0 * nb / lb / 1e9, "unit": "GB/s",
+                                        "frac": 16.0 * nb / lb / 1e9 / 8000.0,
+                                        "note": "same kernel family, 1 GB working set: the unambiguous HBM figure (the headline batch's 160 MB fit the Infinity Cache)"}
+        del yb, sb
+
     # ---- CPU baseline: the oracle (C++ restatement of the reference) on this box's host cores -------------
     if not args.no_cpu_baseline and world == 1:
         from oracle import oracle as O
