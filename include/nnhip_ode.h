@@ -103,8 +103,9 @@ int nnhip_host_free(void* p);
 /* Performance tuning knobs (process-wide; results are bit-identical for every setting):
  *   "rk4_stream_auto" 0|1 (default 1: choose vec/mode from the working-set size), "rk4_stream_vec" 1|2|4|8,
  *   "rk4_stream_mode" 0..3 (0 plain, 1 non-temporal, 2 persistent, 3 both), "rk4_stream_blocks_per_cu" 1..64,
- *   "stream_graph" 0|1 (capture nnhip_ode_fixed_stream_f64_dev's launch sequence in a hipGraph and replay it; pays for
- *   launch-bound batch sizes), "dim16_variant" 0..4 (A/B mappings of the fused 16-component kernels), "fp_contract" 0|1 (opt-in FMA-contracted fused
+ *   "stream_graph" 0|1|2 (0 eager launches; 1 capture nnhip_ode_fixed_stream_f64_dev's launch sequence in a hipGraph
+ *   and replay it; default 2 = do so for launch-bound batches — up to 2e6 states, 16..1e5 steps, a non-default stream — from the
+ *   second identical call on), "dim16_variant" 0..4 (A/B mappings of the fused 16-component kernels), "fp_contract" 0|1 (opt-in FMA-contracted fused
  *   kernels: NOT bit-exact, within 1e-10 / 1e-6), "host_chunks" 0..64 (0 = automatic: 8 when the caller's buffers are page-locked, else 1) and
  *   "host_register" 0|1 (pipelining of the host-pointer solve) */
 int nnhip_tune_set(const char* key, int value);

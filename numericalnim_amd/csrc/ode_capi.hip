@@ -61,7 +61,8 @@ const MethodInfo kMethods[NNHIP_N_INTEGRATORS] = {
 int g_host_chunks = 0;    // tuning knob "host_chunks": 0 = auto (8 when the caller's buffers are page-locked, else 1; see nnhip_ode_solve_batch_f64)
 int g_host_register = 0;  // tuning knob "host_register": page-lock the caller's buffers for the duration of a host-pointer solve
 int g_fast_math = 0;     // tuning knob "fp_contract": 1 = FMA-contracted instantiations of the fused kernels (not bit-exact)
-int g_stream_graph = 0;  // tuning knob "stream_graph": 0 eager launches, 1 hipGraph capture + replay of the streaming loop
+int g_stream_graph = 2;  // tuning knob "stream_graph": 0 eager launches; 1 hipGraph capture + replay of the streaming loop;
+                         // 2 (default) = replay only launch-bound batches, from the second identical call on
 int g_dim16_variant = 0;  // tuning knob "dim16_variant": A/B mappings of the fused 16-component kernels (see ode_kernels.hpp)
 
 nnhip::SolveLaunchFn find_solve(int integrator, int rhs_kind, int dim) {
@@ -324,7 +325,7 @@ int nnhip_tune_set(const char* key, int value) {
   if (k == "host_chunks") { if (value < 0 || value > 64) return fail(NNHIP_EVALUE, "host_chunks must be 0..64"); g_host_chunks = value; return NNHIP_OK; }
   if (k == "host_register") { g_host_register = value != 0; return NNHIP_OK; }
   if (k == "fp_contract") { g_fast_math = value != 0; return NNHIP_OK; }
-  if (k == "stream_graph") { g_stream_graph = value != 0; return NNHIP_OK; }
+  if (k == "stream_graph") { if (value < 0 || value > 2) return fail(NNHIP_EVALUE, "stream_graph must be 0, 1 or 2"); g_stream_graph = value; return NNHIP_OK; }
   if (k == "dim16_variant") { if (value < 0 || value > 4) return fail(NNHIP_EVALUE, "dim16_variant must be 0..4"); g_dim16_variant = value; return NNHIP_OK; }
   if (k == "rk4_stream_auto") { g_tune_auto = value != 0; return NNHIP_OK; }
   if (k == "rk4_stream_vec" || k == "rk4_stream_mode") g_tune_auto = false;
@@ -781,10 +782,12 @@ struct StreamGraphEntry {
   double* yFinal = nullptr;
 };
 thread_local std::vector<StreamGraphEntry> g_graphs;
+thread_local std::vector<StreamGraphKey> g_graph_seen;  // automatic mode: keys that ran eagerly once (a repeat is worth capturing)
 thread_local bool g_capturing = false;
 void release_stream_graphs() {
   for (auto& e : g_graphs) if (e.exec) (void)hipGraphExecDestroy(e.exec);
   g_graphs.clear();
+  g_graph_seen.clear();
 }
 }  // namespace
 
@@ -794,7 +797,12 @@ int nnhip_ode_fixed_stream_f64_dev(const nnhip_ode_options* opt, int integrator,
   nnhip::Params P;
   int rc = check_common(opt, integrator, rhs_kind, rhs_params, n_params, N, dim, layout, P);
   if (rc) return rc;
-  if (g_stream_graph && !g_capturing && N > 0 && stream != nullptr) {  // the legacy default stream cannot be captured
+  // Graph replay pays when the loop is launch-bound: a dependent launch costs >= 3.2 us, the step kernel less than that below
+  // ~2e6 states.  Automatic mode replays such batches from the second identical call on (the first runs eagerly and
+  // is remembered), so one-off calls never pay for a capture.
+  const bool graphAuto = g_stream_graph == 2 && !kMethods[integrator].adaptive && opt->dt > 0.0 && N * (int64_t)dim <= 2000000 &&
+                         (tEnd - t0) / opt->dt >= 16.0 && (tEnd - t0) / opt->dt <= 100000.0;
+  if ((g_stream_graph == 1 || graphAuto) && !g_capturing && N > 0 && stream != nullptr) {  // the legacy default stream cannot be captured
     StreamGraphKey key;
     std::memset(&key, 0, sizeof(key));
     key.integrator = integrator; key.rhs_kind = rhs_kind; key.dim = dim; key.layout = layout; key.n_params = n_params; key.N = N;
@@ -808,10 +816,25 @@ int nnhip_ode_fixed_stream_f64_dev(const nnhip_ode_options* opt, int integrator,
         if (y_final) *y_final = e.yFinal;
         return NNHIP_OK;
       }
+    bool eager = false;
+    if (g_stream_graph == 2) {
+      bool seen = false;
+      for (auto& k2 : g_graph_seen) seen = seen || k2 == key;
+      if (!seen) {
+        if (g_graph_seen.size() >= 32) g_graph_seen.erase(g_graph_seen.begin());
+        g_graph_seen.push_back(key);
+        eager = true;  // first sight of this call: run it eagerly below
+      }
+    }
+    hipGraph_t graph = nullptr;
+    if (!eager && hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+      (void)hipGetLastError();
+      if (g_stream_graph == 1) return fail(NNHIP_EHIP, "hipStreamBeginCapture failed (stream already capturing?)");
+      eager = true;  // automatic mode: e.g. the caller is capturing this stream itself — just enqueue the launches
+    }
+    if (!eager) {
     StreamGraphEntry e;
     e.key = key;
-    hipGraph_t graph = nullptr;
-    HIP_TRY(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
     g_capturing = true;
     rc = nnhip_ode_fixed_stream_f64_dev(opt, integrator, rhs_kind, rhs_params, n_params, N, dim, layout, t0, tEnd, y, scratch, &e.nSteps,
                                         &e.yFinal, stream);
@@ -827,6 +850,7 @@ int nnhip_ode_fixed_stream_f64_dev(const nnhip_ode_options* opt, int integrator,
     if (n_steps_out) *n_steps_out = e.nSteps;
     if (y_final) *y_final = e.yFinal;
     return NNHIP_OK;
+    }  // !eager
   }
   if (kMethods[integrator].adaptive) return fail(NNHIP_EVALUE, "nnhip_ode_fixed_stream_f64_dev needs a fixed-step integrator");
   if (!kMethods[integrator].implemented) return fail(NNHIP_EUNSUPPORTED, "integrator %s has no HIP kernel yet", kMethods[integrator].name);

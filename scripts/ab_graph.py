@@ -17,7 +17,7 @@ for n in (1024, 10_000, 100_000, 1_000_000, 10_000_000):
     y0 = nd.c2_y0_torch(0, n, dev)
     y, sc = y0.clone(), torch.empty_like(y0)
     outs = []
-    for g in (0, 1):
+    for g in (0, 1, 2):
         L.nnhip_tune_set(b"stream_graph", g)
         ts = []
         for r in range(6):
@@ -27,7 +27,7 @@ for n in (1024, 10_000, 100_000, 1_000_000, 10_000_000):
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - c0)
         outs.append(yf.clone())
-        res[f"N{n}_{'graph' if g else 'eager'}_ms"] = sorted(ts[2:])[1] * 1e3
-    res[f"N{n}_equal"] = bool(torch.equal(outs[0], outs[1]))
-L.nnhip_tune_set(b"stream_graph", 0)
+        res[f"N{n}_{('eager', 'graph', 'auto')[g]}_ms"] = sorted(ts[2:])[1] * 1e3
+    res[f"N{n}_equal"] = bool(torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]))
+L.nnhip_tune_set(b"stream_graph", 2)
 print(json.dumps(res, indent=1))

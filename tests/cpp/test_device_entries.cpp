@@ -46,7 +46,7 @@ int main() {
       for (int64_t i = 0; i < N; i += 997) CHECK(fin[i] == out[N + i]);
     }
   }
-  CHECK(nnhip_tune_set("stream_graph", 0) == NNHIP_OK);
+  CHECK(nnhip_tune_set("stream_graph", 2) == NNHIP_OK);
   // adaptive solve streamed through HBM == fused adaptive solve
   CHECK(nnhip_ode_solve_batch_f64_dev(&opt, NNHIP_TSIT54, NNHIP_RHS_NEG_Y, nullptr, 0, dY0, N, 1, NNHIP_LAYOUT_SOA, tspan, 2, tOut, dOut, nullptr, nullptr,
                                       nullptr, 0, dWs, nnhip_ode_solve_workspace_bytes(2), s) == NNHIP_OK);

@@ -163,7 +163,26 @@ def test_stream_loop_hipgraph_replay(nn, oracle, dev):
                 side.synchronize()
                 assert k == nsteps and np.array_equal(yf.cpu().numpy(), ref)
     finally:
-        L.nnhip_tune_set(b"stream_graph", 0)
+        L.nnhip_tune_set(b"stream_graph", 2)
+    # default (automatic) mode: the first identical call runs eagerly, later ones replay a graph; other methods and a
+    # run-time compiled right-hand side included; always the same bits as the eager loop
+    L.nnhip_tune_set(b"stream_graph", 0)
+    eager = {}
+    cases = [("rk4", nn.Rhs.linear(-0.5), 1), ("heun3", nn.Rhs.lorenz(), 3), ("kutta4", nn.Rhs.linear(-0.3), 5)]
+    with torch.cuda.stream(side):
+        for integ, f, dim in cases:
+            yy = torch.from_numpy(np.tile(y0[:1000], (dim, 1)) if dim > 1 else y0[:1000].copy()).to(dev)
+            eager[integ] = nn.fixedStream(f, yy, 0.0, 64 * dt, nn.newODEoptions(dt=dt), integrator=integ, scratch=torch.empty_like(yy))[0].clone()
+        side.synchronize()
+        L.nnhip_tune_set(b"stream_graph", 2)
+        for integ, f, dim in cases:
+            base = torch.from_numpy(np.tile(y0[:1000], (dim, 1)) if dim > 1 else y0[:1000].copy()).to(dev)
+            yy, sc2 = base.clone(), torch.empty_like(base)
+            for rep in range(4):
+                yy.copy_(base)
+                got = nn.fixedStream(f, yy, 0.0, 64 * dt, nn.newODEoptions(dt=dt), integrator=integ, scratch=sc2)[0]
+                side.synchronize()
+                assert torch.equal(got, eager[integ]), (integ, rep)
 
 
 def test_host_path_result_array_reuse_and_page_locked_buffers(nn, oracle):

@@ -138,5 +138,5 @@ def test_release_frees_caches_and_everything_is_rebuilt_on_demand():
     with torch.cuda.stream(s):
         ys2 = nn.fixedStream(nn.Rhs.neg_y(), torch.ones(5000, dtype=torch.float64, device=dev), 0.0, 1.0, nn.newODEoptions(dt=1e-2), integrator="rk4")[0].clone()
     s.synchronize()
-    L.nnhip_tune_set(b"stream_graph", 0)
+    L.nnhip_tune_set(b"stream_graph", 2)
     assert torch.equal(ys1, ys2)
