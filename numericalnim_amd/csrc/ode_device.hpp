@@ -9,8 +9,9 @@
 // Numerical contract: every floating-point expression below is written in the evaluation order of the
 // reference (src/numericalnim/ode.nim; citations inline) and this translation unit is compiled with
 // -ffp-contract=off, so +,-,*,/ and sqrt round exactly as the reference's C backend does on x86-64.
-// The only operation that may differ in the last ulp is pow(1/error, 1/order) in the step-size controller
-// (nth_root below; glibc's pow is not correctly rounded either).
+// pow(1/error, 1/order) in the step-size controller is the one libm call on the path: it is evaluated by
+// glibc_pow.hpp, an operation-for-operation restatement of glibc's table-driven pow (bit-identical to the libm the
+// reference links against), so adaptive solves follow the reference's step sequence exactly.
 #pragma once
 #ifdef __HIPCC_RTC__
 // hiprtc pre-includes its built-in HIP runtime header; an explicit <hip/hip_runtime.h> is not found by a stand-alone
@@ -22,6 +23,7 @@
 
 #include "../../include/nnhip_ode.h"
 #endif
+#include "glibc_pow.hpp"  // pow(1/error, 1/order) with the C library's bits (the reference's libm)
 
 // The kernels live in a build-variant namespace: `nnhip` for the default bit-parity build (-ffp-contract=off) and
 // `nnhip_fast` for the opt-in FMA-contracted instantiations of the compute-bound fused kernels (Makefile: the same
@@ -515,9 +517,16 @@ NNHIP_DEV double nth_root(double x) {
 #endif
 }
 
+// min(4, max(0.125, 0.9 * pow(1/error, 1/order)))  (:71,:537).  Default (bit-parity) build: glibc's pow, bit for bit
+// (glibc_pow.hpp).  The opt-in FMA-contracted build (namespace nnhip_fast, -DNNHIP_FAST_ROOT) keeps the correctly
+// rounded nth_root above: it is not bit-exact anyway and the root is ~20 VALU instructions shorter.
 template <int ORDER>
-NNHIP_DEV double shrink_factor(double error) {  // min(4, max(0.125, 0.9 * pow(1/error, 1/order)))  (:71,:537)
+NNHIP_DEV double shrink_factor(double error) {
+#ifdef NNHIP_FAST_ROOT
   return nmin(4.0, nmax(0.125, 0.9 * nth_root<ORDER>(1.0 / error)));
+#else
+  return nmin(4.0, nmax(0.125, 0.9 * nnhip_gpow::pow_pos(1.0 / error, 1.0 / (double)ORDER)));
+#endif
 }
 
 // One adaptive IntegratorProc call = the method's stage block inside commonAdaptiveMethodCode's retry loop

@@ -860,6 +860,12 @@ int oracle_rhs(int rhs_kind, const double* rhs_params, int n_params, int dim, do
 double oracle_hermite_spline(double x, double x1, double x2, double y1, double y2, double dy1, double dy2) {
   return oracle::hermiteSpline<double>(x, x1, x2, y1, y2, dy1, dy2);
 }
+// The step-size controller's factor alone (ode.nim:71 / :537): min(4, max(0.125, 0.9 * pow(1/error, 1/order))) with the C
+// library's pow, as Nim's std/math pow resolves to.  Lets the tests compare the device factor with the reference's libm directly.
+void oracle_controller_factor(const double* error, int64_t n, int order_i, double* out) {
+  const double order = (double)order_i;
+  for (int64_t i = 0; i < n; ++i) out[i] = oracle::nmin(4, oracle::nmax(0.125, 0.9 * std::pow(1 / error[i], 1 / order)));
+}
 int oracle_linspace(double x1, double x2, int N, double* out) {
   if (N <= 0) return -1;  // ValueError utils.nim:500-501
   const double dx = (x2 - x1) / (double)(N - 1);

@@ -79,6 +79,16 @@ def new_options(dt=1e-4, absTol=1e-4, relTol=1e-4, dtMax=1e-2, dtMin=1e-4, scale
     return o
 
 
+def controller_factor(error, order):
+    """min(4, max(0.125, 0.9*pow(1/error, 1/order))) (ode.nim:71,537) with libm's pow, element-wise."""
+    e = np.ascontiguousarray(error, dtype=np.float64)
+    out = np.empty_like(e)
+    lib().oracle_controller_factor.argtypes = [C.POINTER(C.c_double), C.c_int64, C.c_int, C.POINTER(C.c_double)]
+    lib().oracle_controller_factor.restype = None
+    lib().oracle_controller_factor(_dp(e), e.size, int(order), _dp(out))
+    return out
+
+
 def linspace(x1, x2, n):
     """utils.nim:498-507 (NOT numpy.linspace: x1 + dx*i with the endpoint appended verbatim)."""
     if n <= 0:
