@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "libnnhip_ode.so")
+# NNHIP_LIB: developer override used by the A/B scripts (scripts/build_variant.sh builds the same sources with other flags)
+SO_PATH = os.environ.get("NNHIP_LIB") or os.path.join(_HERE, "csrc", "libnnhip_ode.so")
 
 NNHIP_OK, NNHIP_EVALUE, NNHIP_EINTEGRATOR, NNHIP_EHIP, NNHIP_EUNSUPPORTED, NNHIP_ENOMEM = 0, -1, -2, -3, -4, -5
 

@@ -21,48 +21,66 @@
 #endif
 #include "glibc_pow_tables.inc"
 
-#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__) || defined(__HIPCC_RTC__)
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
 #define NNHIP_GPOW_FN __host__ __device__ __forceinline__
-#define NNHIP_GPOW_TAB static __device__ const
 #else
-#define NNHIP_GPOW_FN static inline
-#define NNHIP_GPOW_TAB static const
+#define NNHIP_GPOW_FN inline
 #endif
 
 namespace nnhip_gpow {
 
-// {invc, logc, logctail} x 128 and {tail, sbits} x 128, as bit patterns.  On the device they live in global memory
-// (5 KiB, resident in every CU's vector L1 / the scalar-cache-backed L2 after the first touch); a lane's lookup index
-// depends on its own x, so these are per-lane gathers.
+// One packed table of 768 eight-byte words: rows 0..127 {invc, logc, logctail, 0} (32 B each), then rows 0..127
+// {tail, sbits} (16 B each).  A lane's row index depends on its own x, so lookups are per-lane gathers.  Three homes:
+//   host    plain array (tests/cpp/test_glibc_pow.cpp, exactness check against the live libm)
+//   global  (default on the device) __device__ array, L1/L2-resident: one 16-byte + one 8-byte gather for the log row, one
+//           16-byte gather for the exp row
+//   LDS     a per-workgroup copy filled by the kernel prologue (lds_fill) and read with ds_read_b128 — A/B only
+//           (-DNNHIP_GPOW_LDS): measured slower, see ode_device.hpp
+constexpr int kTabWords = 4 * NNHIP_GPOW_N + 2 * NNHIP_GPOW_N;
 #if defined(__HIPCC__) || defined(__HIPCC_RTC__)
-static __device__ const uint64_t d_log_tab[3 * NNHIP_GPOW_N] = {NNHIP_GPOW_LOG_TABLE};
-static __device__ const uint64_t d_exp_tab[2 * NNHIP_GPOW_N] = {NNHIP_GPOW_EXP_TABLE};
+static __device__ const uint64_t d_tab[kTabWords] __attribute__((aligned(16))) = {NNHIP_GPOW_LOG_TABLE, NNHIP_GPOW_EXP_TABLE};
+static __shared__ uint64_t s_tab[kTabWords] __attribute__((aligned(16)));
 #endif
 #if !defined(__HIP_DEVICE_COMPILE__) && !defined(__HIPCC_RTC__)
-static const uint64_t h_log_tab[3 * NNHIP_GPOW_N] = {NNHIP_GPOW_LOG_TABLE};
-static const uint64_t h_exp_tab[2 * NNHIP_GPOW_N] = {NNHIP_GPOW_EXP_TABLE};
+static const uint64_t h_tab[kTabWords] __attribute__((aligned(16))) = {NNHIP_GPOW_LOG_TABLE, NNHIP_GPOW_EXP_TABLE};
 #endif
 
 NNHIP_GPOW_FN double as_f64(uint64_t u) { return __builtin_bit_cast(double, u); }
 NNHIP_GPOW_FN uint64_t as_u64(double d) { return __builtin_bit_cast(uint64_t, d); }
 
-NNHIP_GPOW_FN uint64_t log_tab(int i) {
+struct U64x2 { uint64_t a, b; } __attribute__((aligned(16)));
+
+struct TabHostOrGlobal {  // host: plain array; device: the __device__ array
+  NNHIP_GPOW_FN static U64x2 pair(int word) {
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC_RTC__)
-  return d_log_tab[i];
+    return *reinterpret_cast<const U64x2*>(&d_tab[word]);
 #else
-  return h_log_tab[i];
+    return *reinterpret_cast<const U64x2*>(&h_tab[word]);
 #endif
-}
-NNHIP_GPOW_FN uint64_t exp_tab(int i) {
+  }
+  NNHIP_GPOW_FN static uint64_t word(int word) {
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC_RTC__)
-  return d_exp_tab[i];
+    return d_tab[word];
 #else
-  return h_exp_tab[i];
+    return h_tab[word];
 #endif
+  }
+};
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
+struct TabLds {  // the workgroup's LDS copy; the kernel must have called lds_fill()
+  __device__ __forceinline__ static U64x2 pair(int word) { return *reinterpret_cast<const U64x2*>(&s_tab[word]); }
+  __device__ __forceinline__ static uint64_t word(int word) { return s_tab[word]; }
+};
+// Kernel prologue of every kernel that may evaluate the controller: all threads of the workgroup, before any early exit.
+__device__ __forceinline__ void lds_fill() {
+  for (int k = threadIdx.x; k < kTabWords; k += blockDim.x) s_tab[k] = d_tab[k];
+  __syncthreads();
 }
+#endif
 
 // pow(x, y) on the domain stated above.
-NNHIP_GPOW_FN double pow_pos(double x, double y) {
+template <class Tab>
+NNHIP_GPOW_FN double pow_pos_t(double x, double y) {
   uint64_t ix = as_u64(x);
   if (!(x == x)) return x + y;                        // NaN propagates
   if (ix == 0) return 0.0;                            // pow(+0, y>0) = +0
@@ -81,7 +99,8 @@ NNHIP_GPOW_FN double pow_pos(double x, double y) {
   const uint64_t iz = ix - (tmp & (0xfffULL << 52));
   const double z = as_f64(iz);
   const double kd = (double)k;
-  const double invc = as_f64(log_tab(3 * i)), logc = as_f64(log_tab(3 * i + 1)), logctail = as_f64(log_tab(3 * i + 2));
+  const U64x2 row = Tab::pair(4 * i);
+  const double invc = as_f64(row.a), logc = as_f64(row.b), logctail = as_f64(Tab::word(4 * i + 2));
   const double A0 = as_f64(NNHIP_GPOW_A0), A1 = as_f64(NNHIP_GPOW_A1), A2 = as_f64(NNHIP_GPOW_A2), A3 = as_f64(NNHIP_GPOW_A3),
                A4 = as_f64(NNHIP_GPOW_A4), A5 = as_f64(NNHIP_GPOW_A5), A6 = as_f64(NNHIP_GPOW_A6);
   const double t1 = __builtin_fma(kd, as_f64(NNHIP_GPOW_LN2HI), logc);      // fused in the FMA build
@@ -124,8 +143,9 @@ NNHIP_GPOW_FN double pow_pos(double x, double y) {
   rr = elo + rr;
   const int idx = 2 * (int)(ki % NNHIP_GPOW_N);
   const uint64_t top = ki << (52 - 7);
-  const double tail = as_f64(exp_tab(idx));
-  const uint64_t sbits = exp_tab(idx + 1) + top;
+  const U64x2 erow = Tab::pair(4 * NNHIP_GPOW_N + idx);
+  const double tail = as_f64(erow.a);
+  const uint64_t sbits = erow.b + top;
   const double c23 = __builtin_fma(rr, as_f64(NNHIP_GPOW_C3), as_f64(NNHIP_GPOW_C2));
   const double tr = rr + tail;
   const double r2 = rr * rr;
@@ -136,5 +156,8 @@ NNHIP_GPOW_FN double pow_pos(double x, double y) {
   const double scale = as_f64(sbits);
   return __builtin_fma(tm, scale, scale);
 }
+
+// host + device entry reading the plain / global-memory table
+NNHIP_GPOW_FN double pow_pos(double x, double y) { return pow_pos_t<TabHostOrGlobal>(x, y); }
 
 }  // namespace nnhip_gpow

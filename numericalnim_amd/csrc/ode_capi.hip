@@ -63,6 +63,10 @@ int g_host_register = 0;  // tuning knob "host_register": page-lock the caller's
 int g_fast_math = 0;     // tuning knob "fp_contract": 1 = FMA-contracted instantiations of the fused kernels (not bit-exact)
 int g_stream_graph = 2;  // tuning knob "stream_graph": 0 eager launches; 1 hipGraph capture + replay of the streaming loop;
                          // 2 (default) = replay only launch-bound batches, from the second identical call on
+int g_fixed_vec_ipl = 2;  // tuning knob "fixed_vec_ipl": IVPs per lane of the vectorised fixed-step streaming kernel (0 = off, 2, 4)
+int g_adv_speculate = 0;  // tuning knob "adv_speculate": advance kernels issue all loads before the `t < tEnd` test (see StepArgs::speculate);
+                          // measured: no gain (1e7 Lorenz IVPs 274.9 vs 273.6 us per iteration), so finished IVPs keep touching no memory
+int g_adv_split = 0;      // tuning knob "adv_split": index ranges the adaptive streaming loop interleaves on separate streams (0 = auto, 1, 2, 4)
 int g_dim16_variant = 0;  // tuning knob "dim16_variant": A/B mappings of the fused 16-component kernels (see ode_kernels.hpp)
 
 nnhip::SolveLaunchFn find_solve(int integrator, int rhs_kind, int dim) {
@@ -96,6 +100,16 @@ nnhip::StepLaunchFn find_advance(int integrator, int rhs_kind, int dim) {
   switch (integrator) {
 #define X(id, name) \
   case id: return nnhip::find_advance_##name(rhs_kind, dim);
+    NNHIP_FOR_EACH_METHOD(X)
+#undef X
+  }
+  return nullptr;
+}
+
+nnhip::FixedVecLaunchFn find_fixed_vec(int integrator, int rhs_kind, int dim) {
+  switch (integrator) {
+#define X(id, name) \
+  case id: return nnhip::find_fixed_vec_##name(rhs_kind, dim);
     NNHIP_FOR_EACH_METHOD(X)
 #undef X
   }
@@ -246,7 +260,8 @@ namespace nnhip {
 void multigpu_release();  // ode_multigpu.hip
 }
 namespace {
-void release_stream_graphs();  // defined next to the graph cache below
+void release_stream_graphs();  // defined next to the graph caches below
+void release_adv_graphs();
 }
 namespace nnhip {
 // error reporting for the other translation units of the C ABI (ode_capi_quad.hip): same thread-local message buffer
@@ -285,6 +300,7 @@ int nnhip_release(void) {
   if (st.ev) (void)hipEventDestroy(st.ev);
   st = Staging();
   release_stream_graphs();
+  release_adv_graphs();
   // process: idle stream / event contexts of the host-pointer solve, RCCL communicators
   {
     std::lock_guard<std::mutex> lk(g_host_ctx_mu);
@@ -322,10 +338,17 @@ int nnhip_host_free(void* p) {
 int nnhip_tune_set(const char* key, int value) {
   if (!key) return fail(NNHIP_EVALUE, "key is NULL");
   const std::string k(key);
+  // Captured graphs bake in the kernel variants the knobs select: drop this thread's caches so the new setting takes effect
+  // on the next call (the caches are per thread; other threads keep theirs until they change a knob or call nnhip_release).
+  release_stream_graphs();
+  release_adv_graphs();
   if (k == "host_chunks") { if (value < 0 || value > 64) return fail(NNHIP_EVALUE, "host_chunks must be 0..64"); g_host_chunks = value; return NNHIP_OK; }
   if (k == "host_register") { g_host_register = value != 0; return NNHIP_OK; }
   if (k == "fp_contract") { g_fast_math = value != 0; return NNHIP_OK; }
   if (k == "stream_graph") { if (value < 0 || value > 2) return fail(NNHIP_EVALUE, "stream_graph must be 0, 1 or 2"); g_stream_graph = value; return NNHIP_OK; }
+  if (k == "fixed_vec_ipl") { if (value != 0 && value != 2 && value != 4) return fail(NNHIP_EVALUE, "fixed_vec_ipl must be 0, 2 or 4"); g_fixed_vec_ipl = value; return NNHIP_OK; }
+  if (k == "adv_speculate") { g_adv_speculate = value != 0; return NNHIP_OK; }
+  if (k == "adv_split") { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(NNHIP_EVALUE, "adv_split must be 0, 1, 2 or 4"); g_adv_split = value; return NNHIP_OK; }
   if (k == "dim16_variant") { if (value < 0 || value > 4) return fail(NNHIP_EVALUE, "dim16_variant must be 0..4"); g_dim16_variant = value; return NNHIP_OK; }
   if (k == "rk4_stream_auto") { g_tune_auto = value != 0; return NNHIP_OK; }
   if (k == "rk4_stream_vec" || k == "rk4_stream_mode") g_tune_auto = false;
@@ -741,6 +764,19 @@ int nnhip_ode_step_batch_f64_dev(const nnhip_ode_options* opt, int integrator, i
     HIP_TRY(nnhip::launch_rk4_stream(rhs_kind, y_in, y_out, N * dim, t_uniform, dt_uniform, P, negate_time, tune, (hipStream_t)stream));
     return NNHIP_OK;
   }
+  // any fixed-step method over a thread-per-IVP system: 16-byte lane accesses, several IVPs per lane (uniform or per-IVP t, dt)
+  if (!kMethods[integrator].adaptive && g_fixed_vec_ipl && rhs_kind < NNHIP_RHS_USER_BASE && !dt_used && !error &&
+      (((uintptr_t)y_in | (uintptr_t)y_out | (uintptr_t)fsal_out | (uintptr_t)t_dev | (uintptr_t)dt_dev) & 15) == 0 &&
+      (layout == NNHIP_LAYOUT_AOS || dim == 1 || (N & 1) == 0)) {
+    if (nnhip::FixedVecLaunchFn vf = find_fixed_vec(integrator, rhs_kind, dim)) {
+      nnhip::FixedVecArgs va{};
+      va.yin = y_in; va.yout = y_out; va.fsalOut = fsal_out; va.tDev = t_dev; va.dtDev = dt_dev; va.N = N;
+      va.aos = layout == NNHIP_LAYOUT_AOS && dim > 1 ? 1 : 0;
+      va.t = t_uniform; va.dt = dt_uniform; va.P = P;
+      HIP_TRY(vf(va, negate_time, g_fixed_vec_ipl, (hipStream_t)stream));
+      return NNHIP_OK;
+    }
+  }
   bool user = rhs_kind >= NNHIP_RHS_USER_BASE;
   nnhip::StepLaunchFn fn = user ? nullptr : find_step(integrator, rhs_kind, dim);
   if (!fn && !user) {
@@ -785,7 +821,7 @@ thread_local std::vector<StreamGraphEntry> g_graphs;
 thread_local std::vector<StreamGraphKey> g_graph_seen;  // automatic mode: keys that ran eagerly once (a repeat is worth capturing)
 thread_local bool g_capturing = false;
 void release_stream_graphs() {
-  for (auto& e : g_graphs) if (e.exec) (void)hipGraphExecDestroy(e.exec);
+  for (auto& e : g_graphs) if (e.exec) { (void)hipStreamSynchronize(e.key.stream); (void)hipGraphExecDestroy(e.exec); }
   g_graphs.clear();
   g_graph_seen.clear();
 }
@@ -801,7 +837,7 @@ int nnhip_ode_fixed_stream_f64_dev(const nnhip_ode_options* opt, int integrator,
   // ~2e6 states.  Automatic mode replays such batches from the second identical call on (the first runs eagerly and
   // is remembered), so one-off calls never pay for a capture.
   const bool graphAuto = g_stream_graph == 2 && !kMethods[integrator].adaptive && opt->dt > 0.0 && N * (int64_t)dim <= 2000000 &&
-                         (tEnd - t0) / opt->dt >= 16.0 && (tEnd - t0) / opt->dt <= 100000.0;
+                         (tEnd - t0) / opt->dt >= 16.0 && (tEnd - t0) / opt->dt <= 10000.0;  // <= 1e4 kernel nodes per graph
   if ((g_stream_graph == 1 || graphAuto) && !g_capturing && N > 0 && stream != nullptr) {  // the legacy default stream cannot be captured
     StreamGraphKey key;
     std::memset(&key, 0, sizeof(key));
@@ -842,9 +878,14 @@ int nnhip_ode_fixed_stream_f64_dev(const nnhip_ode_options* opt, int integrator,
     hipError_t ce = hipStreamEndCapture((hipStream_t)stream, &graph);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (ce != hipSuccess) return fail(NNHIP_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
-    HIP_TRY(hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0));
+    const hipError_t ie = hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
-    if (g_graphs.size() >= 8) { (void)hipGraphExecDestroy(g_graphs.front().exec); g_graphs.erase(g_graphs.begin()); }
+    if (ie != hipSuccess) return fail(NNHIP_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+    if (g_graphs.size() >= 8) {  // evict the oldest; it may still be executing on its stream
+      (void)hipStreamSynchronize(g_graphs.front().key.stream);
+      (void)hipGraphExecDestroy(g_graphs.front().exec);
+      g_graphs.erase(g_graphs.begin());
+    }
     g_graphs.push_back(e);
     HIP_TRY(hipGraphLaunch(e.exec, (hipStream_t)stream));
     if (n_steps_out) *n_steps_out = e.nSteps;
@@ -882,9 +923,111 @@ int64_t nnhip_ode_adaptive_stream_workspace_bytes(int64_t N, int dim) {
   return (int64_t)sizeof(double) * (N * dim /*FSAL*/ + 3 * N /*t, dt, error*/) + (int64_t)sizeof(unsigned int) * nnhip::kAggSlots;
 }
 
-// ODESolver's adaptive forward loop (ode.nim:506-542, tspan.len == 2) over the `advance` kernel: per-IVP (t, dt, FSAL)
-// live in `ws`; every launch performs one loop iteration of every unfinished IVP; the host polls the number of
-// unfinished IVPs every `check_every` launches.
+}  // extern "C"
+
+namespace {
+// hipGraph cache of the adaptive streaming loop: one graph = one polling group (flag reset + `check_every` advance launches).
+// Every group of a solve is the same graph (the state is advanced in place), so it is replayed until the batch is done, and kept
+// for the next identical call.  Why: at C3's own size (1e6 Lorenz IVPs) an eagerly launched advance kernel runs 20 us but costs
+// 27 us per loop iteration — the rest is the dispatch gap between dependent launches, which a graph replay removes.
+struct AdvGraphKey {
+  nnhip::StepArgs a;
+  const void* fn;
+  int userKind, integrator, checkEvery, device, split;
+  hipStream_t stream;
+};
+struct AdvGraphEntry {
+  AdvGraphKey key;
+  hipGraphExec_t exec = nullptr;
+};
+struct AdvPoll {  // pinned landing zone of the "anyone still integrating?" flags: two groups in flight
+  unsigned int* h = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  // side streams + fork/join events for interleaving index ranges of the batch (see adv_issue_group)
+  hipStream_t side[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
+  int device = -1;
+};
+thread_local std::vector<AdvGraphEntry> g_adv_graphs;
+thread_local AdvPoll g_adv_poll;
+
+void release_adv_graphs();
+int adv_poll_reserve() {
+  int device = 0;
+  HIP_TRY(hipGetDevice(&device));
+  if (g_adv_poll.device != device) release_adv_graphs();  // streams and events belong to one device
+  AdvPoll& p = g_adv_poll;
+  p.device = device;
+  if (!p.h) HIP_TRY(hipHostMalloc((void**)&p.h, 2 * nnhip::kAggSlots * sizeof(unsigned int), hipHostMallocDefault));
+  for (hipEvent_t& e : p.ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (hipStream_t& st : p.side) if (!st) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  if (!p.fork) HIP_TRY(hipEventCreateWithFlags(&p.fork, hipEventDisableTiming));
+  for (hipEvent_t& e : p.join) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return NNHIP_OK;
+}
+void release_adv_graphs() {
+  for (auto& e : g_adv_graphs) if (e.exec) { (void)hipStreamSynchronize(e.key.stream); (void)hipGraphExecDestroy(e.exec); }
+  g_adv_graphs.clear();
+  AdvPoll& p = g_adv_poll;
+  if (p.h) (void)hipHostFree(p.h);
+  for (hipEvent_t e : p.ev) if (e) (void)hipEventDestroy(e);
+  for (hipStream_t st : p.side) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+  if (p.fork) (void)hipEventDestroy(p.fork);
+  for (hipEvent_t e : p.join) if (e) (void)hipEventDestroy(e);
+  p = AdvPoll();
+}
+
+// The arguments of the sub-batch [lo, lo + n) of a prepared advance launch (strides keep addressing the full arrays).
+nnhip::StepArgs adv_range(const nnhip::StepArgs& full, int64_t lo, int64_t n) {
+  nnhip::StepArgs a = full;
+  a.N = n;
+  a.y_in += lo * a.ivpStride; a.y_out += lo * a.ivpStride; a.fsal_in += lo * a.ivpStride; a.fsal_out += lo * a.ivpStride;
+  a.t_io += lo; a.dt_io += lo;
+  if (a.error) a.error += lo;
+  if (a.steps_io) a.steps_io += lo;
+  if (a.perIvpParams) a.perIvpParams += lo;
+  return a;
+}
+
+// One polling group: reset the flags, then `checkEvery` loop iterations, the last one reporting whether work is left.
+// With split > 1 the batch is cut into `split` index ranges whose launch chains run on separate streams (fork / join by
+// events; under stream capture they become parallel branches of the graph): while one range's kernel drains its last
+// waves, the other range's next kernel is already filling the freed CUs, which hides the ramp-down / ramp-up gap between
+// DEPENDENT launches (6 of 27 us per iteration at C3's own size).  The ranges are independent IVPs: same bits.
+int adv_issue_group(nnhip::StepLaunchFn fn, int userKind, int integrator, const nnhip::StepArgs& full, unsigned int* active, int checkEvery,
+                    int split, hipStream_t s) {
+  AdvPoll& p = g_adv_poll;
+  HIP_TRY(hipMemsetAsync(active, 0, nnhip::kAggSlots * sizeof(unsigned int), s));
+  if (split > 1) {
+    HIP_TRY(hipEventRecord(p.fork, s));
+    for (int r = 1; r < split; ++r) HIP_TRY(hipStreamWaitEvent(p.side[r - 1], p.fork, 0));
+  }
+  for (int k = 0; k < checkEvery; ++k) {
+    for (int r = 0; r < split; ++r) {
+      const int64_t lo = full.N * r / split, hi = full.N * (r + 1) / split;
+      nnhip::StepArgs a = split > 1 ? adv_range(full, lo, hi - lo) : full;
+      a.active = k == checkEvery - 1 ? active : nullptr;
+      hipStream_t st = r == 0 ? s : p.side[r - 1];
+      if (fn) HIP_TRY(fn(a, 0, st));
+      else if (nnhip::rtc_launch_advance(userKind, integrator, a, st) != hipSuccess) return fail(NNHIP_EHIP, "user RHS launch failed: %s", nnhip::rtc_last_error());
+    }
+  }
+  for (int r = 1; r < split; ++r) {
+    HIP_TRY(hipEventRecord(p.join[r - 1], p.side[r - 1]));
+    HIP_TRY(hipStreamWaitEvent(s, p.join[r - 1], 0));
+  }
+  return NNHIP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+// ODESolver's adaptive forward loop (ode.nim:506-542, tspan.len == 2) over the `advance` kernels: per-IVP (t, dt, FSAL)
+// live in `ws`; every launch performs one loop iteration of every unfinished IVP (thread-per-IVP for small systems,
+// lanes-per-system for Vector[float] states of 8 / 16 / 32 ... components).  The host learns whether anyone is still
+// integrating once per group of `check_every` launches, and always has the NEXT group enqueued before it waits for the
+// answer of the current one (a launch over finished IVPs only reads their t: 8 B per IVP), so the device never idles on
+// the host.  Groups are replayed from a hipGraph unless tuning knob "stream_graph" is 0 or `stream` is the legacy default stream.
 int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
                                       int n_params, int64_t N, int dim, int layout, double t0, double tEnd, double* y, void* ws,
                                       int64_t ws_bytes, int check_every, int64_t max_launches, int64_t* launches_out, void* stream) {
@@ -900,8 +1043,8 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
   int userKind = rhs_kind >= NNHIP_RHS_USER_BASE ? rhs_kind : -1;
   nnhip::StepLaunchFn fn = userKind >= 0 ? nullptr : find_advance(integrator, rhs_kind, dim);
   if (!fn && userKind < 0) userKind = nnhip::rtc_builtin_kind(rhs_kind, dim);  // built-in kind at a size without an ahead-of-time kernel
-  if (!fn && (userKind < 0 || !nnhip::rtc_is_thread_per_ivp(userKind)))
-    return fail(NNHIP_EUNSUPPORTED, "no advance kernel for integrator=%s rhs_kind=%d dim=%d (thread-per-IVP right-hand sides only)", kMethods[integrator].name, rhs_kind, dim);
+  if (!fn && userKind < 0)
+    return fail(NNHIP_EUNSUPPORTED, "no advance kernel for integrator=%s rhs_kind=%d dim=%d", kMethods[integrator].name, rhs_kind, dim);
   hipStream_t s = (hipStream_t)stream;
   double* fsal = (double*)ws;
   double* tArr = fsal + N * dim;
@@ -919,24 +1062,87 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
   a.y_in = y; a.y_out = y; a.fsal_in = fsal; a.fsal_out = fsal; a.error = errArr;
   a.ctl = ctl_of(opt); a.P = P;
   a.tEnd = tEnd; a.t_io = tArr; a.dt_io = dtArr; a.active = nullptr; a.steps_io = nullptr;
+  a.speculate = g_adv_speculate;
   if (check_every <= 0) check_every = 8;
-  int64_t launches = 0;
-  for (;;) {
-    unsigned int h[nnhip::kAggSlots];
-    for (int k = 0; k < check_every; ++k) {
-      const bool last = k == check_every - 1;  // only the last launch of a group reports whether work is left
-      if (last) HIP_TRY(hipMemsetAsync(active, 0, sizeof(h), s));
-      a.active = last ? active : nullptr;
-      if (fn) HIP_TRY(fn(a, 0, s));
-      else if (nnhip::rtc_launch_advance(userKind, integrator, a, s) != hipSuccess) return fail(NNHIP_EHIP, "user RHS launch failed: %s", nnhip::rtc_last_error());
-      ++launches;
+  rc = adv_poll_reserve();
+  if (rc) return rc;
+  AdvPoll& poll = g_adv_poll;
+  // Interleaved index ranges pay while a launch is short enough for its ramp-down to matter and long enough to fill the chip twice
+  int split = g_adv_split;
+  if (split == 0) split = 1;  // measured and rejected as a default: 1e6 Lorenz IVPs 29 us per iteration unsplit, 35 us in 2 ranges, 44 us in 4
+                              // (profiles/r02_pow_tables_ab.txt) — the launches were never gap-bound: the kernel itself takes 27 us
+  if ((int64_t)split > N) split = 1;
+
+  // ---- the polling group as a graph (cached per thread; key = everything the launches depend on) ----
+  hipGraphExec_t exec = nullptr;
+  if (g_stream_graph != 0 && s != nullptr) {
+    int device = 0;
+    HIP_TRY(hipGetDevice(&device));
+    AdvGraphKey key;
+    std::memset(&key, 0, sizeof(key));
+    std::memcpy(&key.a, &a, sizeof(a));
+    key.fn = (const void*)fn; key.userKind = userKind; key.integrator = integrator; key.checkEvery = check_every; key.device = device; key.split = split; key.stream = s;
+    for (auto& e : g_adv_graphs)
+      if (std::memcmp(&e.key, &key, sizeof(key)) == 0) { exec = e.exec; break; }
+    if (!exec) {
+      if (fn == nullptr) {  // run-time compiled kernels: make sure the module is loaded before the stream goes into capture mode
+        nnhip::StepArgs warm = a;
+        warm.N = 0;
+        (void)nnhip::rtc_launch_advance(userKind, integrator, warm, s);
+      }
+      hipGraph_t graph = nullptr;
+      if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        rc = adv_issue_group(fn, userKind, integrator, a, active, check_every, split, s);
+        const hipError_t ce = hipStreamEndCapture(s, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (ce == hipSuccess && graph) {
+          const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+          (void)hipGraphDestroy(graph);
+          if (ie != hipSuccess) { exec = nullptr; (void)hipGetLastError(); }
+        } else {
+          (void)hipGetLastError();
+        }
+      } else {
+        (void)hipGetLastError();  // e.g. the caller is capturing this stream itself: plain launches below
+      }
+      if (exec) {
+        if (g_adv_graphs.size() >= 8) {  // evict the oldest; it may still be executing on its stream
+          (void)hipStreamSynchronize(g_adv_graphs.front().key.stream);
+          (void)hipGraphExecDestroy(g_adv_graphs.front().exec);
+          g_adv_graphs.erase(g_adv_graphs.begin());
+        }
+        AdvGraphEntry e;
+        e.key = key; e.exec = exec;
+        g_adv_graphs.push_back(e);
+      }
     }
-    HIP_TRY(hipMemcpyAsync(h, active, sizeof(h), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+  }
+  auto issue = [&](int64_t g) -> int {
+    if (exec) HIP_TRY(hipGraphLaunch(exec, s));
+    else { const int r = adv_issue_group(fn, userKind, integrator, a, active, check_every, split, s); if (r) return r; }
+    HIP_TRY(hipMemcpyAsync(poll.h + (g & 1) * nnhip::kAggSlots, active, nnhip::kAggSlots * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(poll.ev[g & 1], s));
+    return NNHIP_OK;
+  };
+  int64_t launches = 0, g = 0;
+  rc = issue(0);
+  if (rc) return rc;
+  launches += check_every;
+  for (;;) {
+    const bool more = !(max_launches > 0 && launches >= max_launches);
+    if (more) {  // keep the device busy while the host waits for group g's answer
+      rc = issue(g + 1);
+      if (rc) return rc;
+      launches += check_every;
+    }
+    HIP_TRY(hipEventSynchronize(poll.ev[g & 1]));
     unsigned int any = 0;
-    for (unsigned int v : h) any |= v;
-    if (!any) break;
-    if (max_launches > 0 && launches >= max_launches) break;
+    for (int k = 0; k < nnhip::kAggSlots; ++k) any |= poll.h[(g & 1) * nnhip::kAggSlots + k];
+    if (!any || !more) {
+      if (more) HIP_TRY(hipEventSynchronize(poll.ev[(g + 1) & 1]));  // the speculative group (it found nothing left to do)
+      break;
+    }
+    ++g;
   }
   if (launches_out) *launches_out = launches;
   return NNHIP_OK;

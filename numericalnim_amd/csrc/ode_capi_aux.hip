@@ -149,6 +149,7 @@ __global__ __launch_bounds__(kBlock) void cumsimpson_kernel(const SimpsonPair* _
 // the controller's step-size factor (ode.nim:71,537) over an array of error norms
 template <int ORDER>
 __global__ __launch_bounds__(kBlock) void controller_factor_kernel(const double* __restrict__ error, double* __restrict__ out, int64_t n) {
+  controller_prologue();
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < n) out[i] = shrink_factor<ORDER>(error[i]);
 }

@@ -520,20 +520,37 @@ NNHIP_DEV double nth_root(double x) {
 // min(4, max(0.125, 0.9 * pow(1/error, 1/order)))  (:71,:537).  Default (bit-parity) build: glibc's pow, bit for bit
 // (glibc_pow.hpp).  The opt-in FMA-contracted build (namespace nnhip_fast, -DNNHIP_FAST_ROOT) keeps the correctly
 // rounded nth_root above: it is not bit-exact anyway and the root is ~20 VALU instructions shorter.
+// pow's two table lookups are per-lane gathers from a 6 KiB __device__ array (L1/L2-resident).  A per-workgroup LDS copy
+// (-DNNHIP_GPOW_LDS, filled by controller_prologue) was measured and rejected: the fill + barrier put one more dependent
+// memory round trip in front of every workgroup (advance kernel, 1e7 Lorenz IVPs: 342 us vs 302 us per loop iteration;
+// fused kernels unchanged; profiles/r02_pow_tables_ab.txt).
 template <int ORDER>
 NNHIP_DEV double shrink_factor(double error) {
-#ifdef NNHIP_FAST_ROOT
+#if defined(NNHIP_FAST_ROOT)
   return nmin(4.0, nmax(0.125, 0.9 * nth_root<ORDER>(1.0 / error)));
+#elif defined(NNHIP_GPOW_LDS)
+  return nmin(4.0, nmax(0.125, 0.9 * nnhip_gpow::pow_pos_t<nnhip_gpow::TabLds>(1.0 / error, 1.0 / (double)ORDER)));
 #else
-  return nmin(4.0, nmax(0.125, 0.9 * nnhip_gpow::pow_pos(1.0 / error, 1.0 / (double)ORDER)));
+  return nmin(4.0, nmax(0.125, 0.9 * nnhip_gpow::pow_pos_t<nnhip_gpow::TabHostOrGlobal>(1.0 / error, 1.0 / (double)ORDER)));
+#endif
+}
+// Prologue of every kernel whose method has a step-size controller; a no-op unless the A/B build -DNNHIP_GPOW_LDS stages pow's
+// tables in LDS.  All threads of the workgroup must reach it (it may contain a barrier) — before any `if (i >= N) return`.
+template <bool ADAPTIVE = true>
+NNHIP_DEV void controller_prologue() {
+#if !defined(NNHIP_FAST_ROOT) && defined(NNHIP_GPOW_LDS)
+  if constexpr (ADAPTIVE) nnhip_gpow::lds_fill();
 #endif
 }
 
 // One adaptive IntegratorProc call = the method's stage block inside commonAdaptiveMethodCode's retry loop
 // (ode.nim:57-76).  `fsal` is k1 on entry for the tableau methods and the returned FSAL slot on exit.
+// `factor` returns min(4, max(0.125, 0.9*pow(1/error, 1/order))) of the ACCEPTED attempt's error: the post-step controller
+// (ode.nim:537) evaluates exactly that expression on the error this call returns, so the one pow per attempt is evaluated at
+// one place — here — for both the in-step shrink (:71) and the caller's post-step update (same operands, same bits).
 template <int METHOD, class Ops>
 NNHIP_DEV int embedded_step(const Ops& ops, double t, double& dt, const double (&y)[Ops::D], double (&fsal)[Ops::D],
-                            double (&yNew)[Ops::D], double& error, const StepCtl& o, int64_t& rejected) {
+                            double (&yNew)[Ops::D], double& error, const StepCtl& o, int64_t& rejected, double& factor) {
   constexpr int D = Ops::D;
   double ya[D], err_y[D], fsalNew[D];
   int limitCounter = 0;
@@ -619,9 +636,10 @@ NNHIP_DEV int embedded_step(const Ops& ops, double t, double& dt, const double (
       }
     }
     error = ops.norm(yNew, err_y, o);  // scaled RMS norm (:61-65)
+    factor = shrink_factor<ORDER>(error);                      // the attempt's one pow (:71 if rejected, :537 if accepted)
     if (error <= 1.0) break;                                   // :69-70
     if (error != error) { status |= kStatusNaN; break; }       // deviation: the reference would spin forever
-    dt = dt * shrink_factor<ORDER>(error);                     // :71
+    dt = dt * factor;                                          // :71
     if (fabs(dt) < o.dtMin) { dt = o.dtMin; limitCounter += 1; }  // :72-74
     else if (o.dtMax < fabs(dt)) { dt = o.dtMax; }             // :75-76
     rejected += 1;
@@ -693,6 +711,7 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
   double dt = in.dtInit;
   [[maybe_unused]] Rk4Dt h4 = rk4_dt(dt);
   double error = 0.0;
+  [[maybe_unused]] double factor = 1.0;
   int denseIndex = 0;
   const int high = in.nReq - 1;
   int status = 0;
@@ -766,7 +785,7 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
       fixed_step<METHOD>(ops, t, dt, y, yNew);
       error = 0.0;
     } else {
-      status |= embedded_step<METHOD>(ops, t, dt, y, fsal, yNew, error, in.ctl, rejected);
+      status |= embedded_step<METHOD>(ops, t, dt, y, fsal, yNew, error, in.ctl, rejected, factor);
     }
 #pragma unroll
     for (int c = 0; c < D; ++c) y[c] = yNew[c];
@@ -774,7 +793,7 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
     steps += 1;
     if constexpr (MT::adaptive) {  // :533-541
       if (error == 0.0) dt *= 5.0;
-      else dt = dt * shrink_factor<(int)MT::order>(error);
+      else dt = dt * factor;  // = shrink_factor<order>(error), evaluated inside embedded_step
       if (dt < in.ctl.dtMin) dt = in.ctl.dtMin;
       else if (in.ctl.dtMax < dt) dt = in.ctl.dtMax;
     }

@@ -78,6 +78,9 @@ struct StepArgs {
   const double* perIvpParams;  // nullable [nPerIvp][N], as in SolveArgs
   int nPerIvp;
   int64_t perIvpStride;
+  // advance mode: issue the loads of (y, FSAL, dt) together with the load of t instead of after the `t < tEnd` test: one memory
+  // round trip per launch less; IVPs that are already finished then still READ their state (they never write)
+  int speculate;
 };
 
 constexpr int kBlock = 256;
@@ -270,6 +273,7 @@ NNHIP_DEV void aggregate_stats(unsigned long long* aggBase, LaneStats ls) {
 
 template <int METHOD, class RHS>
 __global__ __launch_bounds__(kBlock) void solve_tpi_kernel(const SolveArgs a) {
+  controller_prologue<MethodTraits<METHOD>::adaptive>();
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   LaneStats ls;
   if (i < a.N) {
@@ -308,6 +312,7 @@ __global__ __launch_bounds__(kBlock) NNHIP_LPS_ATTR void solve_lps_kernel(const 
   constexpr int LPSYS = DIM / CPL;  // lanes per system
   static_assert(DIM % CPL == 0 && 64 % LPSYS == 0, "a system must not straddle wavefronts");
   __shared__ double lds[2 * kBlock * CPL];
+  controller_prologue<MethodTraits<METHOD>::adaptive>();
   const int sysInBlock = threadIdx.x / LPSYS, c = (threadIdx.x % LPSYS) * CPL;
   const int64_t i = (int64_t)blockIdx.x * (kBlock / LPSYS) + sysInBlock;
   LaneStats ls;
@@ -372,7 +377,8 @@ NNHIP_DEV void step_body(const StepArgs& a, const Ops& ops, int64_t i, int64_t b
       for (int c = 0; c < D; ++c) fsal[c] = ops.owns(c) ? a.fsal_in[base + c * a.compStride] : 0.0;
     }
     int64_t rej = 0;
-    embedded_step<METHOD>(ops, t, dt, y, fsal, yNew, error, a.ctl, rej);
+    double factor;
+    embedded_step<METHOD>(ops, t, dt, y, fsal, yNew, error, a.ctl, rej, factor);
     if (a.fsal_out) {
 #pragma unroll
       for (int c = 0; c < D; ++c)
@@ -390,6 +396,7 @@ NNHIP_DEV void step_body(const StepArgs& a, const Ops& ops, int64_t i, int64_t b
 
 template <int METHOD, class RHS, bool NEG>
 __global__ __launch_bounds__(kBlock) void step_tpi_kernel(const StepArgs a) {
+  controller_prologue<MethodTraits<METHOD>::adaptive>();
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= a.N) return;
   const Params P = params_of(a, i);
@@ -412,43 +419,112 @@ hipError_t launch_step_tpi(const StepArgs& a, int negate, hipStream_t s) {
 // in HBM between launches:  dt = min(dt, tEnd - t); (y, FSAL, dt, error) = integrator(...); t += dt; controller.
 // Algorithmic traffic per attempted step: read y(d)+FSAL(d)+t+dt, write y(d)+FSAL(d)+t+dt+error = 8*(4d+5) B.
 // ------------------------------------------------------------------------------------------------
-template <int METHOD, class RHS>
-__global__ __launch_bounds__(kBlock) void advance_tpi_kernel(const StepArgs a) {
-  constexpr int D = RHS::dim;
+// Shared by the thread-per-IVP and the lanes-per-system form.  `base` addresses this lane's first owned component of IVP i; all
+// lanes of a system read the same (t, dt) and compute bit-identical values for them; lane `writeScalars` stores them.
+template <int METHOD, class Ops>
+NNHIP_DEV unsigned int advance_body(const StepArgs& a, const Ops& ops, int64_t i, int64_t base, bool writeScalars) {
+  constexpr int D = Ops::D;
   using MT = MethodTraits<METHOD>;
-  static_assert(MT::adaptive, "fixed-step methods share (t, dt): use the uniform streaming loop");
+  double t = a.t_io[i];
+  double y[D], yNew[D], fsal[D];
+  double dt;
+  if (a.speculate) {  // all loads in flight at once; the exit test comes after them
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      y[c] = ops.owns(c) ? a.y_in[base + c * a.compStride] : 0.0;
+      fsal[c] = ops.owns(c) ? a.fsal_in[base + c * a.compStride] : 0.0;
+    }
+    dt = a.dt_io[i];
+    if (!(t < a.tEnd)) return 0u;  // :511
+  } else {
+    if (!(t < a.tEnd)) return 0u;  // :511 — finished IVPs touch no other memory
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      y[c] = ops.owns(c) ? a.y_in[base + c * a.compStride] : 0.0;
+      fsal[c] = ops.owns(c) ? a.fsal_in[base + c * a.compStride] : 0.0;
+    }
+    dt = a.dt_io[i];
+  }
+  dt = nmin(dt, a.tEnd - t);  // :525
+  double error = 0.0;
+  int64_t rej = 0;
+  double factor;
+  embedded_step<METHOD>(ops, t, dt, y, fsal, yNew, error, a.ctl, rej, factor);  // :531
+  t += dt;                                                              // :532
+  if (error == 0.0) dt *= 5.0;                                          // :534-535
+  else dt = dt * factor;                                                // :537 (the factor of the accepted attempt's error)
+  if (dt < a.ctl.dtMin) dt = a.ctl.dtMin;                               // :538-539
+  else if (a.ctl.dtMax < dt) dt = a.ctl.dtMax;                          // :540-541
+  if (error != error) t = a.tEnd;  // NaN abort (same deviation as the fused driver): retire the IVP
+#pragma unroll
+  for (int c = 0; c < D; ++c)
+    if (ops.owns(c)) { a.y_out[base + c * a.compStride] = yNew[c]; a.fsal_out[base + c * a.compStride] = fsal[c]; }
+  if (writeScalars) {
+    a.t_io[i] = t;
+    a.dt_io[i] = dt;
+    if (a.error) a.error[i] = error;
+    if (a.steps_io) a.steps_io[i] += 1;
+  }
+  return t < a.tEnd ? 1u : 0u;
+}
+
+// Occupancy of the thread-per-IVP advance kernel.  glibc's pow keeps six 64-bit polynomial constants in VGPRs (an FMA takes
+// at most one scalar operand on gfx9), which puts the 7-stage methods on 3-component systems at 131-135 VGPRs = 3 waves per SIMD;
+// asked for 4 waves the allocator rematerialises them instead (128 VGPRs, 0-12 B of scratch) and the HBM-bound loop gains 4-12 %
+// (1e7 Lorenz IVPs, DOPRI54 298 -> 264 us, Tsit54 286 -> 274 us per iteration; profiles/r02_pow_tables_ab.txt).  Larger systems
+// and the 9-stage Vern65 would spill 50-260 B per lane — more traffic than they save — and keep the default allocation.
+// -DNNHIP_ADV_TPI_WPE=n overrides (A/B).
+#ifdef NNHIP_ADV_TPI_WPE
+#define NNHIP_ADV_TPI_ATTR __attribute__((amdgpu_waves_per_eu(NNHIP_ADV_TPI_WPE)))
+#else
+template <int METHOD, class RHS>
+constexpr int adv_tpi_waves() { return (RHS::dim <= 3 && METHOD != NNHIP_VERN65) || RHS::dim <= 2 ? 4 : 1; }
+#define NNHIP_ADV_TPI_ATTR __attribute__((amdgpu_waves_per_eu(adv_tpi_waves<METHOD, RHS>())))
+#endif
+#ifdef NNHIP_ADV_LPS_WPE
+#define NNHIP_ADV_LPS_ATTR __attribute__((amdgpu_waves_per_eu(NNHIP_ADV_LPS_WPE)))
+#else
+#define NNHIP_ADV_LPS_ATTR
+#endif
+template <int METHOD, class RHS>
+__global__ __launch_bounds__(kBlock) NNHIP_ADV_TPI_ATTR void advance_tpi_kernel(const StepArgs a) {
+  static_assert(MethodTraits<METHOD>::adaptive, "fixed-step methods share (t, dt): use the uniform streaming loop");
+  controller_prologue();
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   unsigned int stillActive = 0;
   if (i < a.N) {
-    double t = a.t_io[i];
-    if (t < a.tEnd) {  // :511
-      const Params P = params_of(a, i);
-      const TpiOps<RHS, false> ops{P};
-      const int64_t base = i * a.ivpStride;
-      double y[D], yNew[D], fsal[D];
-#pragma unroll
-      for (int c = 0; c < D; ++c) { y[c] = a.y_in[base + c * a.compStride]; fsal[c] = a.fsal_in[base + c * a.compStride]; }
-      double dt = nmin(a.dt_io[i], a.tEnd - t);  // :525
-      double error = 0.0;
-      int64_t rej = 0;
-      embedded_step<METHOD>(ops, t, dt, y, fsal, yNew, error, a.ctl, rej);  // :531
-      t += dt;                                                              // :532
-      if (error == 0.0) dt *= 5.0;                                          // :534-535
-      else dt = dt * shrink_factor<(int)MT::order>(error);                  // :537
-      if (dt < a.ctl.dtMin) dt = a.ctl.dtMin;                               // :538-539
-      else if (a.ctl.dtMax < dt) dt = a.ctl.dtMax;                          // :540-541
-      if (error != error) t = a.tEnd;  // NaN abort (same deviation as the fused driver): retire the IVP
-#pragma unroll
-      for (int c = 0; c < D; ++c) { a.y_out[base + c * a.compStride] = yNew[c]; a.fsal_out[base + c * a.compStride] = fsal[c]; }
-      a.t_io[i] = t;
-      a.dt_io[i] = dt;
-      if (a.error) a.error[i] = error;
-      if (a.steps_io) a.steps_io[i] += 1;
-      stillActive = t < a.tEnd ? 1u : 0u;
-    }
+    const Params P = params_of(a, i);
+    const TpiOps<RHS, false> ops{P};
+    stillActive = advance_body<METHOD>(a, ops, i, i * a.ivpStride, true);
   }
   // "is anyone still integrating?" — a plain flag store per workgroup into one of kAggSlots words (no atomics: 1e5 waves
   // hitting one address cost ~170 us per launch), and only in the launches whose answer the host will read
+  if (a.active) {
+    if (__syncthreads_or((int)stillActive) && threadIdx.x == 0) a.active[blockIdx.x % kAggSlots] = 1u;
+  }
+}
+
+// The same loop iteration for Vector[float] states of 8 / 16 / 32 ... components (C4's streamed form; ode.nim:525-541 over
+// Vector[float]): DIM / CPL lanes of one wavefront per system, one component per lane by default (best coalescing: with the AoS
+// layout a wave moves 512 contiguous bytes per array), stage argument vector and error components through LDS (LpsOps).
+// Algorithmic traffic 8*(4d+5) B per attempted step: 552 B at d = 16, so 1e6 systems stream 552 MB per launch — far
+// beyond the 256 MiB Infinity Cache.
+template <int METHOD, class RHS, int CPL = 1>
+__global__ __launch_bounds__(kBlock) NNHIP_ADV_LPS_ATTR void advance_lps_kernel(const StepArgs a) {
+  static_assert(MethodTraits<METHOD>::adaptive, "fixed-step methods share (t, dt): use the uniform streaming loop");
+  constexpr int DIM = RHS::dim;
+  constexpr int LPSYS = DIM / CPL;
+  static_assert(DIM % CPL == 0 && 64 % LPSYS == 0, "a system must not straddle wavefronts");
+  __shared__ double lds[2 * kBlock * CPL];
+  controller_prologue();
+  const int sysInBlock = threadIdx.x / LPSYS, c = (threadIdx.x % LPSYS) * CPL;
+  const int64_t i = (int64_t)blockIdx.x * (kBlock / LPSYS) + sysInBlock;
+  unsigned int stillActive = 0;
+  if (i < a.N) {
+    const Params P = params_of(a, i);
+    const LpsOps<RHS, false, CPL> ops{P, lds + sysInBlock * DIM, lds + kBlock * CPL + sysInBlock * DIM, c};
+    stillActive = advance_body<METHOD>(a, ops, i, i * a.ivpStride + c * a.compStride, c == 0);
+  }
   if (a.active) {
     if (__syncthreads_or((int)stillActive) && threadIdx.x == 0) a.active[blockIdx.x % kAggSlots] = 1u;
   }
@@ -474,12 +550,33 @@ hipError_t launch_advance_tpi(const StepArgs& a, int, hipStream_t s) {
 }
 #endif
 
+#if !NNHIP_RTC
+// components per lane of the lanes-per-system advance kernel, from the fused kernels' value `ca`
+// (A/B hook: -DNNHIP_ADV_CPL_MAX=1|2|4 caps it)
+#ifndef NNHIP_ADV_CPL_MAX  // measured, 1e6 16-component systems (profiles/r02_pow_tables_ab.txt): 1 -> 200 us, 2 -> 152 us, 4 -> 170 us per iteration:
+#define NNHIP_ADV_CPL_MAX 2  // with one component per lane the controller (norm, division, sqrt, pow: ~200 VALU) runs 16x per system and the
+#endif                       // kernel is VALU-bound; two per lane halve that and still move 16 B per lane access (AoS)
+#define NNHIP_ADV_CPL(ca) ((ca) < NNHIP_ADV_CPL_MAX ? (ca) : NNHIP_ADV_CPL_MAX)
+template <int METHOD, class RHS, int CPL>
+hipError_t launch_advance_lps(const StepArgs& a, int, hipStream_t s) {
+  if constexpr (MethodTraits<METHOD>::adaptive) {
+    constexpr int perBlock = kBlock / (RHS::dim / CPL);
+    const int64_t grid = (a.N + perBlock - 1) / perBlock;
+    if (grid <= 0) return hipSuccess;
+    return launch_kernel(advance_lps_kernel<METHOD, RHS, CPL>, dim3((unsigned)grid), dim3(kBlock), s, a);
+  } else {
+    return hipErrorInvalidValue;
+  }
+}
+#endif
+
 template <int METHOD, class RHS, bool NEG, int CPL = 1>
 __global__ __launch_bounds__(kBlock) void step_lps_kernel(const StepArgs a) {
   constexpr int DIM = RHS::dim;
   constexpr int LPSYS = DIM / CPL;  // lanes per system (CPL > 1 only for systems wider than a wavefront)
   static_assert(DIM % CPL == 0 && 64 % LPSYS == 0, "a system must not straddle wavefronts");
   __shared__ double lds[2 * kBlock * CPL];
+  controller_prologue<MethodTraits<METHOD>::adaptive>();
   const int sysInBlock = threadIdx.x / LPSYS, c = (threadIdx.x % LPSYS) * CPL;
   const int64_t i = (int64_t)blockIdx.x * (kBlock / LPSYS) + sysInBlock;
   if (i >= a.N) return;
@@ -508,7 +605,7 @@ hipError_t launch_step_lps(const StepArgs& a, int negate, hipStream_t s) {
 // MODE 0: plain loads/stores, one tile per workgroup.   MODE 1: non-temporal loads+stores (streaming hint).
 // MODE 2: persistent grid-stride over tiles (grid = a few workgroups per CU).  MODE 3: MODE 2 + non-temporal.
 template <class RHS1, bool NEG, int VEC, int MODE>
-__global__ __launch_bounds__(kBlock) void rk4_stream_vec_kernel(const double* __restrict__ yin, double* __restrict__ yout,
+__global__ __launch_bounds__(kBlock) void rk4_stream_vec_kernel(const double* yin, double* yout,  // may alias (in-place stepping): no __restrict__
                                                                 int64_t n, double t, const Rk4Dt h, const Params P) {
   static_assert(RHS1::dim == 1, "scalar RHS only");
   constexpr bool NT = (MODE & 1) != 0;
@@ -558,6 +655,123 @@ __global__ __launch_bounds__(kBlock) void rk4_stream_vec_kernel(const double* __
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same treatment for ANY fixed-step method and any thread-per-IVP system (RK4_step[Vector] etc., ode.nim:107-189) with
+// uniform (t, dt): a lane advances IPL IVPs, moving them with 16-byte accesses (SoA: two neighbouring IVPs per component
+// plane; AoS: the 2*dim contiguous doubles of two neighbouring IVPs), all loads issued before the arithmetic, one workgroup
+// per contiguous tile of kBlock*IPL IVPs.  Half (a quarter) as many waves as step_tpi_kernel and twice as wide accesses:
+// RK4 Lorenz at 1e7 IVPs went from 4.06 TB/s to the figure in DESIGN.md §6.  Algorithmic traffic 16*dim B per IVP-step.
+// `yin` may alias `yout` (in-place stepping): a lane reads its own IVPs before it writes them; no __restrict__.
+// ------------------------------------------------------------------------------------------------
+struct FixedVecArgs {
+  const double* yin;
+  double* yout;
+  double* fsalOut;      // nullable: fixed-step IntegratorProcs hand yNew back in the FSAL slot too (ode.nim:189)
+  const double* tDev;   // nullable -> t   (per-IVP times: every IVP of the reference is its own solveODE call)
+  const double* dtDev;  // nullable -> dt
+  int64_t N;
+  int aos;
+  double t, dt;
+  Params P;
+};
+
+template <int METHOD, class RHS, bool NEG, int IPL>
+__global__ __launch_bounds__(kBlock) void fixed_stream_vec_kernel(const FixedVecArgs a) {
+  static_assert(!MethodTraits<METHOD>::adaptive && IPL % 2 == 0, "fixed-step methods, an even number of IVPs per lane");
+  constexpr int D = RHS::dim;
+  constexpr int PAIRS = IPL / 2;
+  const TpiOps<RHS, NEG> ops{a.P};
+  const int64_t N = a.N;
+  const int aos = a.aos;
+  const double* yin = a.yin;
+  double* yout = a.yout;
+  const int64_t tile = (int64_t)blockIdx.x * kBlock * IPL;
+  const bool uniform = !a.tDev && !a.dtDev;
+  [[maybe_unused]] const Rk4Dt h4u = rk4_dt(a.dt);
+  auto one = [&](double t, double dt, const double (&y)[D], double (&r)[D]) {
+    if constexpr (METHOD == NNHIP_RK4) rk4_step(ops, t, uniform ? h4u : rk4_dt(dt), y, r);
+    else fixed_step<METHOD>(ops, t, dt, y, r);
+  };
+  if (tile + (int64_t)kBlock * IPL <= N) {
+    double2 v[PAIRS][D];
+    double2 tt[PAIRS], dd[PAIRS];
+#pragma unroll
+    for (int u = 0; u < PAIRS; ++u) {
+      const int64_t i = tile + (int64_t)u * 2 * kBlock + 2 * threadIdx.x;
+      if (aos) {
+        const double2* src = reinterpret_cast<const double2*>(yin + i * D);
+#pragma unroll
+        for (int c = 0; c < D; ++c) v[u][c] = src[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < D; ++c) v[u][c] = *reinterpret_cast<const double2*>(yin + (int64_t)c * N + i);
+      }
+      tt[u] = a.tDev ? *reinterpret_cast<const double2*>(a.tDev + i) : double2{a.t, a.t};
+      dd[u] = a.dtDev ? *reinterpret_cast<const double2*>(a.dtDev + i) : double2{a.dt, a.dt};
+    }
+#pragma unroll
+    for (int u = 0; u < PAIRS; ++u) {
+      double ya[D], yb[D], ra[D], rb[D];
+      if (aos) {  // v[u] holds [a_0 .. a_{D-1}, b_0 .. b_{D-1}] as D double2
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+          ya[c] = (c % 2 == 0) ? v[u][c / 2].x : v[u][c / 2].y;
+          yb[c] = ((c + D) % 2 == 0) ? v[u][(c + D) / 2].x : v[u][(c + D) / 2].y;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < D; ++c) { ya[c] = v[u][c].x; yb[c] = v[u][c].y; }
+      }
+      one(tt[u].x, dd[u].x, ya, ra);
+      one(tt[u].y, dd[u].y, yb, rb);
+      if (aos) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+          if (c % 2 == 0) v[u][c / 2].x = ra[c]; else v[u][c / 2].y = ra[c];
+          if ((c + D) % 2 == 0) v[u][(c + D) / 2].x = rb[c]; else v[u][(c + D) / 2].y = rb[c];
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < D; ++c) { v[u][c].x = ra[c]; v[u][c].y = rb[c]; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PAIRS; ++u) {
+      const int64_t i = tile + (int64_t)u * 2 * kBlock + 2 * threadIdx.x;
+      if (aos) {
+        double2* dst = reinterpret_cast<double2*>(yout + i * D);
+#pragma unroll
+        for (int c = 0; c < D; ++c) dst[c] = v[u][c];
+        if (a.fsalOut) {
+          double2* fd = reinterpret_cast<double2*>(a.fsalOut + i * D);
+#pragma unroll
+          for (int c = 0; c < D; ++c) fd[c] = v[u][c];
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < D; ++c) *reinterpret_cast<double2*>(yout + (int64_t)c * N + i) = v[u][c];
+        if (a.fsalOut) {
+#pragma unroll
+          for (int c = 0; c < D; ++c) *reinterpret_cast<double2*>(a.fsalOut + (int64_t)c * N + i) = v[u][c];
+        }
+      }
+    }
+  } else {  // ragged last tile: one IVP at a time, bounds-checked
+    const int64_t is = aos ? D : 1, cs = aos ? 1 : N;
+    for (int64_t i = tile + threadIdx.x; i < N; i += kBlock) {
+      double y1[D], r[D];
+#pragma unroll
+      for (int c = 0; c < D; ++c) y1[c] = yin[i * is + c * cs];
+      one(a.tDev ? a.tDev[i] : a.t, a.dtDev ? a.dtDev[i] : a.dt, y1, r);
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        yout[i * is + c * cs] = r[c];
+        if (a.fsalOut) a.fsalOut[i * is + c * cs] = r[c];
+      }
+    }
+  }
+}
+
 // dy = f(t, y) alone over a batch (pins the RHS library; also used for user-compiled RHS)
 template <class RHS>
 __global__ __launch_bounds__(kBlock) void rhs_batch_kernel(int64_t N, int64_t ivpStride, int64_t compStride, double t,
@@ -585,6 +799,24 @@ hipError_t launch_rk4_stream_vec(const double* yin, double* yout, int64_t n, dou
   const Rk4Dt h{dt, 0.5 * dt, dt / 6.0};  // host IEEE double ops == the device's (this TU is built -ffp-contract=off)
   if (negate) return launch_kernel(rk4_stream_vec_kernel<RHS1, true, VEC, MODE>, dim3((unsigned)grid), dim3(kBlock), s, yin, yout, n, t, h, P);
   return launch_kernel(rk4_stream_vec_kernel<RHS1, false, VEC, MODE>, dim3((unsigned)grid), dim3(kBlock), s, yin, yout, n, t, h, P);
+}
+
+using FixedVecLaunchFn = hipError_t (*)(const FixedVecArgs& a, int negate, int ipl, hipStream_t s);
+template <int METHOD, class RHS>
+hipError_t launch_fixed_stream_vec(const FixedVecArgs& a, int negate, int ipl, hipStream_t s) {
+  if constexpr (!MethodTraits<METHOD>::adaptive) {
+    if (a.N <= 0) return hipSuccess;
+    const int64_t per = (int64_t)kBlock * (ipl == 4 ? 4 : 2);
+    const dim3 grid((unsigned)((a.N + per - 1) / per)), block(kBlock);
+    if (ipl == 4) {
+      if (negate) return launch_kernel(fixed_stream_vec_kernel<METHOD, RHS, true, 4>, grid, block, s, a);
+      return launch_kernel(fixed_stream_vec_kernel<METHOD, RHS, false, 4>, grid, block, s, a);
+    }
+    if (negate) return launch_kernel(fixed_stream_vec_kernel<METHOD, RHS, true, 2>, grid, block, s, a);
+    return launch_kernel(fixed_stream_vec_kernel<METHOD, RHS, false, 2>, grid, block, s, a);
+  } else {
+    return hipErrorInvalidValue;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -647,10 +879,23 @@ StepLaunchFn find_step_tpi(int rhs_kind, int dim) {
 }
 
 template <int METHOD>
+FixedVecLaunchFn find_fixed_vec_tpi(int rhs_kind, int dim) {
+#define X(kind, d, T) \
+  if (rhs_kind == kind && dim == d) return &launch_fixed_stream_vec<METHOD, T>;
+  NNHIP_FOR_EACH_TPI_RHS(X)
+#undef X
+  return nullptr;
+}
+
+template <int METHOD>
 StepLaunchFn find_advance_tpi(int rhs_kind, int dim) {
 #define X(kind, d, T) \
   if (rhs_kind == kind && dim == d) return &launch_advance_tpi<METHOD, T>;
   NNHIP_FOR_EACH_TPI_RHS(X)
+#undef X
+#define X(kind, d, T, CA, CF) \
+  if (rhs_kind == kind && dim == d) return &launch_advance_lps<METHOD, T, NNHIP_ADV_CPL(CA)>;
+  NNHIP_FOR_EACH_LPS_RHS(X)
 #undef X
   return nullptr;
 }
@@ -663,7 +908,8 @@ StepLaunchFn find_advance_tpi(int rhs_kind, int dim) {
 #define X(id, name)                                                      \
   SolveLaunchFn find_solve_##name(int rhs_kind, int dim, int dim16_variant);  \
   StepLaunchFn find_step_##name(int rhs_kind, int dim);                  \
-  StepLaunchFn find_advance_##name(int rhs_kind, int dim);
+  StepLaunchFn find_advance_##name(int rhs_kind, int dim);               \
+  FixedVecLaunchFn find_fixed_vec_##name(int rhs_kind, int dim);
 NNHIP_FOR_EACH_METHOD(X)
 #undef X
 // scalar RK4 streaming (vectorised); rhs_kind must be an elementwise kind. Defined in ode_tu_rk4_stream.hip

@@ -110,6 +110,7 @@ bool compile(const UserRhsEntry& e, int integrator, CodeObject& out) {
       const int scpl = lps_step_cpl(e);
       names.push_back("nnhip::step_lps_kernel<" + m + ", nnhip::UserRhs, false, " + std::to_string(scpl) + ">");
       names.push_back("nnhip::step_lps_kernel<" + m + ", nnhip::UserRhs, true, " + std::to_string(scpl) + ">");
+      if (adaptive) names.push_back("nnhip::advance_lps_kernel<" + m + ", nnhip::UserRhs, " + std::to_string(scpl) + ">");  // adaptive streaming
       out.ivpsPerBlockSolve = kBlock / (padded_dim(e) / cpl);
       out.ivpsPerBlockStep = kBlock / (padded_dim(e) / scpl);
     } else {
@@ -284,9 +285,9 @@ hipError_t rtc_launch_step(int rhs_kind, int integrator, const StepArgs& a, int 
 hipError_t rtc_launch_advance(int rhs_kind, int integrator, const StepArgs& a, hipStream_t s) {
   Program* p = get_program(rhs_kind, integrator);
   if (!p) return hipErrorInvalidValue;
-  if (!p->advance) { g_rtc_err = "no advance kernel: fixed-step integrator or a lanes-per-system right-hand side"; return hipErrorInvalidValue; }
+  if (!p->advance) { g_rtc_err = "no advance kernel: fixed-step integrator"; return hipErrorInvalidValue; }
   StepArgs copy = a;
-  return launch(p->advance, a.N, kBlock, &copy, s);
+  return launch(p->advance, a.N, p->ivpsPerBlockStep, &copy, s);
 }
 hipError_t rtc_launch_rhs(int rhs_kind, int64_t N, int64_t is, int64_t cs, double t, const double* y, double* dy, const Params& P,
                           hipStream_t s) {

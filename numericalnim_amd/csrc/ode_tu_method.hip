@@ -14,4 +14,8 @@ StepLaunchFn NNHIP_CAT(find_advance_, NNHIP_TU_NAME)(int rhs_kind, int dim) {
   if constexpr (MethodTraits<NNHIP_TU_METHOD>::adaptive) return find_advance_tpi<NNHIP_TU_METHOD>(rhs_kind, dim);
   else return nullptr;
 }
+FixedVecLaunchFn NNHIP_CAT(find_fixed_vec_, NNHIP_TU_NAME)(int rhs_kind, int dim) {
+  if constexpr (!MethodTraits<NNHIP_TU_METHOD>::adaptive) return find_fixed_vec_tpi<NNHIP_TU_METHOD>(rhs_kind, dim);
+  else return nullptr;
+}
 }  // namespace NNHIP_NS

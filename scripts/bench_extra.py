@@ -30,10 +30,20 @@ for n in (1_000_000, 10_000_000):
     tdev = torch.zeros(n, dtype=torch.float64, device=dev)
     dtdev = torch.full((n,), 1e-3, dtype=torch.float64, device=dev)
     opt = nn.newODEoptions(**tight)
+    ynew = torch.empty_like(y0)
     for integ in ("rk4", "dopri54", "tsit54", "vern65"):
-        s, _ = timed(lambda: nn.integratorStep(nn.Rhs.lorenz(), tdev, y0, fs, dtdev, opt, integrator=integ))
-        b = 8 * (4 * 3 + 5) * n if integ != "rk4" else 8 * (2 * 3 + 2) * n
-        out[f"step_stream_lorenz_{integ}_N{n:.0e}"] = dict(us=s * 1e6, GBps=b / s / 1e9)
+        if integ == "rk4":
+            # RK4_step[Vector] (ode.nim:180-189) with per-IVP (t, dt): reads y(3)+t+dt, writes yNew(3) = 8*(2d+2) B per IVP-step
+            # (r01 measured this with the FSAL slot written as well — 24 B per IVP more than it counted)
+            s, _ = timed(lambda: nn.integratorStep(nn.Rhs.lorenz(), tdev, y0, None, dtdev, opt, integrator=integ, out=ynew))
+            out[f"step_stream_lorenz_rk4_N{n:.0e}"] = dict(us=s * 1e6, GBps=8 * (2 * 3 + 2) * n / s / 1e9, algorithmic_bytes=8 * (2 * 3 + 2) * n)
+            s, _ = timed(lambda: nn.integratorStep(nn.Rhs.lorenz(), tdev, y0, fs, dtdev, opt, integrator=integ, out=ynew))
+            out[f"step_stream_lorenz_rk4_fsalslot_N{n:.0e}"] = dict(us=s * 1e6, GBps=8 * (3 * 3 + 2) * n / s / 1e9, algorithmic_bytes=8 * (3 * 3 + 2) * n)
+            s, _ = timed(lambda: nn.integratorStep(nn.Rhs.lorenz(), 0.0, y0, None, 1e-3, opt, integrator=integ, out=ynew))
+            out[f"step_stream_lorenz_rk4_uniform_N{n:.0e}"] = dict(us=s * 1e6, GBps=8 * (2 * 3) * n / s / 1e9, algorithmic_bytes=8 * (2 * 3) * n)
+            continue
+        s, _ = timed(lambda: nn.integratorStep(nn.Rhs.lorenz(), tdev, y0, fs, dtdev, opt, integrator=integ, out=ynew))
+        out[f"step_stream_lorenz_{integ}_N{n:.0e}"] = dict(us=s * 1e6, GBps=8 * (4 * 3 + 5) * n / s / 1e9)
 # dense output: C2-like, RK4 fused, 1e7 IVPs, 33 requested times -> 33 x 80 MB written
 n = 10_000_000
 y2 = nd.c2_y0_torch(0, n, dev)

@@ -1,6 +1,6 @@
 """The reference's Vector[float] state has any length.  Sizes without an ahead-of-time kernel run through run-time instantiation
 of the same per-component expressions (ode_rtc.hip: rtc_builtin_kind); results must equal the oracle's exactly as for the
-ahead-of-time sizes: bit-exact for fixed-step methods, <= 1e-10 with identical step counts for the adaptive ones."""
+ahead-of-time sizes: bit-exact with identical step counts for fixed-step and adaptive methods."""
 import numpy as np
 import pytest
 
@@ -44,11 +44,8 @@ def test_any_dim_solve_matches_oracle(env, name, dim, integrator):
     t, y, cnt = nn.solveODE(f, torch.from_numpy(y0).cuda(), ts, nn.newODEoptions(**kw), integrator=integrator, return_counts=True)
     ref = O.solve_ode_batch(kind, params, y0, n, dim, ts, O.new_options(**kw), integrator, n_threads=8)
     got = y.cpu().numpy()
-    if integrator == "rk4":
-        assert np.array_equal(got, ref["y"]), float(np.abs(got - ref["y"]).max())
-    else:
-        assert np.abs(got - ref["y"]).max() <= 1e-10
-        assert np.array_equal(cnt["steps"].cpu().numpy(), ref["steps"])
+    assert np.array_equal(got, ref["y"]), float(np.abs(got - ref["y"]).max())
+    assert np.array_equal(cnt["steps"].cpu().numpy(), ref["steps"])
 
 
 def test_any_dim_aos_layout_and_step_entry(env):
@@ -93,11 +90,8 @@ def test_wide_user_system_method_of_lines(env, dim, integrator, layout):
     t, y, cnt = nn.solveODE(f, torch.from_numpy(y0l).cuda(), ts, nn.newODEoptions(**kw), integrator=integrator, layout=layout, return_counts=True)
     ref = O.solve_ode_batch(O.RHS_HEAT, [0.4], y0l, n, dim, ts, O.new_options(**kw), integrator, layout=layout, n_threads=8)
     got = y.cpu().numpy()
-    if integrator == "rk4":
-        assert np.array_equal(got, ref["y"]), float(np.abs(got - ref["y"]).max())
-    else:
-        assert np.abs(got - ref["y"]).max() <= 1e-10
-        assert np.array_equal(cnt["steps"].cpu().numpy(), ref["steps"])
+    assert np.array_equal(got, ref["y"]), float(np.abs(got - ref["y"]).max())
+    assert np.array_equal(cnt["steps"].cpu().numpy(), ref["steps"])
     if layout == 0:
         ys = torch.from_numpy(y0).cuda()
         fsal = nn.rhsBatch(f, 0.0, ys)

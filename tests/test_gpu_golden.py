@@ -1,6 +1,7 @@
 """HIP path vs the committed golden fixtures (tests/golden/ode_golden.json) and vs a live oracle run.
-Tolerances (BASELINE.json north_star): fixed-step 1e-10 abs, adaptive 1e-6 abs.  We additionally require
-bit equality for fixed-step and identical accepted/rejected step counts for adaptive runs."""
+Tolerances (BASELINE.json north_star): fixed-step 1e-10 abs, adaptive 1e-6 abs.  We require more: bit equality for
+fixed-step AND adaptive runs (the controller's pow is glibc's, bit for bit: glibc_pow.hpp) and identical accepted/rejected
+step counts."""
 import numpy as np
 import pytest
 
@@ -58,4 +59,5 @@ def test_hip_matches_golden(nn, dev, case, layout):
             assert steps[i] == exp["steps"]
         else:
             assert np.abs(gi - want).max() <= TOL_ADAPTIVE
+            assert np.array_equal(gi, want), "adaptive results must be bit-exact too"
             assert (steps[i], rej[i]) == (exp["steps"], exp["rejected"])

@@ -133,10 +133,7 @@ def test_all_integrators_reference_harness(nn, oracle, dev):
         got = y[:, 0].cpu().numpy()
         assert np.abs(got - np.exp(-0.1 * ts)).max() <= tol_ref[m], m
         rt, ry, st = O.solve_ode(O.RHS_LINEAR, [-0.1], 1.0, ts, O.new_options(), m)
-        if m in nn.fixedODE:
-            assert np.array_equal(got, ry), m
-        else:
-            assert np.abs(got - ry).max() <= 1e-6, m
+        assert np.array_equal(got, ry), m   # all 14 integrators bit-exact, adaptive ones included
         tv, yv = nn.solveODE(nn.Rhs.linear(-0.1), y0v, ts, integrator=m)
         gv = yv[:, :, 0].cpu().numpy()
         assert np.array_equal(gv[:, 0], got) and np.array_equal(gv[:, 1], got) and np.array_equal(gv[:, 2], got), m
@@ -212,3 +209,48 @@ def test_host_path_result_array_reuse_and_page_locked_buffers(nn, oracle):
     assert np.array_equal(ob.numpy(), refb)
     with pytest.raises(ValueError):
         nn.solveODE(nn.Rhs.neg_y(), y0, ts, opt, integrator="rk4", out=np.zeros((2, n)))
+
+
+@pytest.mark.parametrize("ipl", [2, 4])
+@pytest.mark.parametrize("integrator", ["rk4", "heun2", "ralston2", "kutta3", "heun3", "ralston3", "ssprk3", "ralston4", "kutta4"])
+def test_fixed_step_vectorised_streaming_kernel(nn, oracle, dev, integrator, ipl):
+    """fixed_stream_vec_kernel (any fixed-step IntegratorProc over a thread-per-IVP system, 16-byte lane accesses, 2 or 4
+    IVPs per lane; ode.nim:107-189) vs the one-IVP-per-lane step kernel (tuning knob fixed_vec_ipl = 0) and vs the oracle's
+    stepper: same bits for both layouts, uniform and per-IVP (t, dt), with and without the FSAL slot, full tiles + ragged
+    tail, negated time, and in-place (y_out == y_in)."""
+    import torch
+    O = oracle
+    L = nn._lib.lib()
+    rng = np.random.default_rng(17)
+    opt = nn.newODEoptions(dt=2.0 ** -6)
+    cases = [(nn.Rhs.lorenz(), O.RHS_LORENZ, [10.0, 28.0, 8.0 / 3.0], 3), (nn.Rhs.vanderpol(1.5), O.RHS_VANDERPOL, [1.5], 2),
+             (nn.Rhs.linear(-0.4), O.RHS_LINEAR, [-0.4], 1), (nn.Rhs.ring(0.1), O.RHS_RING, [0.1], 4)]
+    try:
+        for f, okind, params, dim in cases:
+            for n in (5000, 4097 if dim == 1 else 4098):   # several full tiles + a ragged tail
+                for layout in ((0, 1) if dim > 1 else (0,)):
+                    y = rng.uniform(-2, 2, (n, dim)) + (np.array([0.0, 0.0, 20.0]) if dim == 3 else 0.0)
+                    yl = np.ascontiguousarray(y if layout == 1 else y.T) if dim > 1 else y[:, 0].copy()
+                    yt = torch.from_numpy(yl).to(dev)
+                    tarr = torch.from_numpy(rng.uniform(0, 1, n)).to(dev)
+                    dtarr = torch.from_numpy(10 ** rng.uniform(-3, -1.5, n)).to(dev)
+                    for tt, dd, fsal, neg in ((0.25, 2.0 ** -6, None, False), (tarr, dtarr, yt, False), (0.25, dtarr, None, True), (tarr, 2.0 ** -6, yt, True)):
+                        L.nnhip_tune_set(b"fixed_vec_ipl", 0)
+                        r0 = nn.integratorStep(f, tt, yt, fsal, dd, opt, integrator=integrator, layout=layout, negate_time=neg)
+                        L.nnhip_tune_set(b"fixed_vec_ipl", ipl)
+                        r1 = nn.integratorStep(f, tt, yt, fsal, dd, opt, integrator=integrator, layout=layout, negate_time=neg)
+                        assert torch.equal(r0[0], r1[0]), (integrator, dim, n, layout)
+                        if fsal is not None:
+                            assert torch.equal(r1[1], r1[0])          # yNew in the FSAL slot (ode.nim:189)
+                        inplace = yt.clone()
+                        nn.integratorStep(f, tt, inplace, None, dd, opt, integrator=integrator, layout=layout, negate_time=neg, out=inplace)
+                        assert torch.equal(inplace, r1[0])
+                    # against the oracle's stepper on a sample (uniform t, dt)
+                    got = nn.integratorStep(f, 0.25, yt, None, 2.0 ** -6, opt, integrator=integrator, layout=layout)[0].cpu().numpy()
+                    got = got.reshape(n, dim) if (layout == 1 or dim == 1) else got.T
+                    for i in (0, 1, 511, 512, 1023, 1024, n - 2, n - 1):
+                        yi = list(y[i]) if dim > 1 else float(y[i, 0])
+                        ryn = O.step(okind, params, integrator, O.new_options(dt=2.0 ** -6), 0.25, yi, yi, 2.0 ** -6)[0]
+                        assert np.array_equal(got[i], np.atleast_1d(ryn)), (integrator, dim, i)
+    finally:
+        L.nnhip_tune_set(b"fixed_vec_ipl", 2)
