@@ -123,6 +123,11 @@ struct RhsRing {  // dy_c = -((c+1)/d)*y_c + p0*y_{(c+1) mod d}
   NNHIP_DEV static double comp(double, int c, const double* ys, const Params& P) {
     return -((double)(c + 1) / (double)DIM) * ys[c] + P.p[0] * ys[(c + 1) % DIM];
   }
+  // Banded form (see LpsOps::rhs): component c reads components c .. c+1 (cyclic) only.  w[0] = y_c, w[1] = y_{(c+1) mod DIM}.
+  static constexpr int halo_lo = 0, halo_hi = 1;
+  NNHIP_DEV static double comp_window(double, int c, const double* w, const Params& P) {
+    return -((double)(c + 1) / (double)DIM) * w[0] + P.p[0] * w[1];
+  }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -177,6 +182,41 @@ NNHIP_DEV void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// A right-hand side is "banded" when component c only reads components c-halo_lo .. c+halo_hi (cyclically; ring couplings,
+// stencils of a method-of-lines discretisation).  A lane of the lanes-per-system kernels then needs, besides its own CPL
+// components, only the first halo_hi components of the next lane and the last halo_lo of the previous one: they are exchanged
+// with DPP / lane permutes between registers instead of staging the whole stage argument vector in LDS (one exposed LDS round
+// trip per stage otherwise: 7 per Tsit54 attempt).  Same per-component expression (comp_window), hence the same bits.
+template <class R, class = void>
+struct RhsBanded { static constexpr bool value = false; };
+template <class R>
+struct RhsBanded<R, decltype((void)R::halo_hi)> { static constexpr bool value = true; };
+
+// value of `v` in the next (DIR = +1) / previous (DIR = -1) lane of this lane's group of L consecutive lanes, cyclically
+template <int L, int DIR>
+NNHIP_DEV double lane_rotate(double v) {
+  static_assert(L >= 2 && L <= 64 && (L & (L - 1)) == 0, "group size must be a power of two");
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  if constexpr (L == 2) {         // quad_perm [1,0,3,2]
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, false);
+  } else if constexpr (L == 4) {  // quad_perm [1,2,3,0] / [3,0,1,2]
+    constexpr int ctrl = DIR > 0 ? 0x39 : 0x93;
+    lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, false);
+  } else if constexpr (L == 16) {  // row_ror: lane i <- lane (i - n) mod 16
+    constexpr int ctrl = DIR > 0 ? 0x12F : 0x121;
+    lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, false);
+  } else {                         // any other group size: ds_bpermute (no LDS memory involved)
+    const int lane = (int)(threadIdx.x & 63);
+    const int src = (lane & ~(L - 1)) | ((lane + (DIR > 0 ? 1 : L - 1)) & (L - 1));
+    lo = __builtin_amdgcn_ds_bpermute(src << 2, lo);
+    hi = __builtin_amdgcn_ds_bpermute(src << 2, hi);
+  }
+  return __hiloint2double(hi, lo);
+}
+
 template <class RHS, bool NEG, int CPL = 1, bool SHUFFLE_NORM = false>
 struct LpsOps {
   static constexpr int D = CPL;            // components per lane
@@ -191,6 +231,25 @@ struct LpsOps {
     else return c0 + j < SIZE;
   }
   NNHIP_DEV void rhs(double t, const double (&y)[CPL], double (&dy)[CPL]) const {
+#ifndef NNHIP_NO_BANDED_RHS
+    if constexpr (RhsBanded<RHS>::value && SIZE == DIM && DIM / CPL >= 2) {
+      constexpr int LO = RHS::halo_lo, HI = RHS::halo_hi, L = DIM / CPL;
+      static_assert(LO <= CPL && HI <= CPL, "halo wider than a lane's share");
+      double w[LO + CPL + HI];
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) w[LO + j] = y[j];
+#pragma unroll
+      for (int h = 0; h < HI; ++h) w[LO + CPL + h] = lane_rotate<L, +1>(y[h]);            // next lane's first components
+#pragma unroll
+      for (int h = 0; h < LO; ++h) w[LO - 1 - h] = lane_rotate<L, -1>(y[CPL - 1 - h]);    // previous lane's last components
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        const double v = RHS::comp_window(NEG ? -t : t, c0 + j, &w[j], P);  // window of component c0+j starts at w[j] (= y_{c-LO})
+        dy[j] = NEG ? -v : v;
+      }
+      return;
+    }
+#endif
 #pragma unroll
     for (int j = 0; j < CPL; ++j) ys[c0 + j] = y[j];
     wave_lds_sync();
@@ -524,14 +583,32 @@ NNHIP_DEV double nth_root(double x) {
 // (-DNNHIP_GPOW_LDS, filled by controller_prologue) was measured and rejected: the fill + barrier put one more dependent
 // memory round trip in front of every workgroup (advance kernel, 1e7 Lorenz IVPs: 342 us vs 302 us per loop iteration;
 // fused kernels unchanged; profiles/r02_pow_tables_ab.txt).
+// Early-out on the clamp: min(4, max(0.125, 0.9*p)) with p = pow(1/error, 1/order) is exactly 4 once 0.9*p >= 4 and exactly 0.125
+// once 0.9*p <= 0.125.  pow is within 1 ulp of the true value, so thresholds that leave a relative margin of 1e-4 (twelve orders
+// of magnitude more than an ulp) decide the clamp without evaluating pow: error < kClampHi<ORDER> -> 4, error > kClampLo<ORDER> -> 0.125
+// (also covers error = inf: pow(0, y) = 0).  With loose tolerances (the BASELINE configs' default options) almost every step
+// lands on the upper clamp, so whole wavefronts skip the ~90-instruction pow and its two table gathers; NaN takes the pow path
+// and propagates as before.  Bit-identical by construction; tests/test_gpu_adaptive_parity.py::test_controller_factor_is_libm_exact
+// sweeps both thresholds densely.
+template <int ORDER> struct ClampThresholds;
+// (0.9/4)^ORDER * (1 - 1e-3)   and   (0.9/0.125)^ORDER * (1 + 1e-3)
+template <> struct ClampThresholds<2> { static constexpr double hi = 0.050574375, lo = 51.89184; };
+template <> struct ClampThresholds<3> { static constexpr double hi = 0.011379234375, lo = 373.621248; };
+template <> struct ClampThresholds<5> { static constexpr double hi = 5.7607374023437e-4, lo = 19368.52; };
+template <> struct ClampThresholds<6> { static constexpr double hi = 1.2961659155273e-4, lo = 139453.4; };
+
 template <int ORDER>
 NNHIP_DEV double shrink_factor(double error) {
 #if defined(NNHIP_FAST_ROOT)
   return nmin(4.0, nmax(0.125, 0.9 * nth_root<ORDER>(1.0 / error)));
-#elif defined(NNHIP_GPOW_LDS)
+#else
+  if (error < ClampThresholds<ORDER>::hi) return 4.0;
+  if (error > ClampThresholds<ORDER>::lo) return 0.125;
+#if defined(NNHIP_GPOW_LDS)
   return nmin(4.0, nmax(0.125, 0.9 * nnhip_gpow::pow_pos_t<nnhip_gpow::TabLds>(1.0 / error, 1.0 / (double)ORDER)));
 #else
   return nmin(4.0, nmax(0.125, 0.9 * nnhip_gpow::pow_pos_t<nnhip_gpow::TabHostOrGlobal>(1.0 / error, 1.0 / (double)ORDER)));
+#endif
 #endif
 }
 // Prologue of every kernel whose method has a step-size controller; a no-op unless the A/B build -DNNHIP_GPOW_LDS stages pow's
@@ -695,18 +772,25 @@ struct DriveOut {
   int64_t steps, rejected;
 };
 
-template <int METHOD, bool NEG, class Ops, class Emit>
+// DENSE = false is the lean instantiation for tspan.len == 2 (in.useDense must be 0): the Hermite history lastIter = (t, y, dy)
+// (ode.nim:498,526-530) is never read then, and not carrying it frees 2-3 state vectors of registers — the difference between two
+// and three waves per SIMD for the 16-component lanes-per-system kernels.  DENSE = true handles both cases.
+template <int METHOD, bool NEG, bool DENSE = true, class Ops, class Emit>
 NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::D], Emit&& emit, DriveOut& out) {
   constexpr int D = Ops::D;
+  constexpr int DH = DENSE ? D : 1;  // size of the history vectors (1 = unused placeholder)
   using MT = MethodTraits<METHOD>;
   double t = in.tStartEff;
-  double y[D], fsal[D], lastY[D], lastDy[D], yNew[D], dyNow[D];
-  double lastT = in.tStartEff;
+  double y[D], fsal[D], yNew[D];
+  [[maybe_unused]] double lastY[DH], lastDy[DH], dyNow[DH];
+  [[maybe_unused]] double lastT = in.tStartEff;
 #pragma unroll
   for (int c = 0; c < D; ++c) y[c] = y0[c];
   ops.rhs(t, y, fsal);  // FSAL = f(t0, y) (:506) / g(-t0, y0) (:546)
+  if constexpr (DENSE) {
 #pragma unroll
-  for (int c = 0; c < D; ++c) { lastY[c] = y[c]; lastDy[c] = fsal[c]; }  // lastIter (:498,:548)
+    for (int c = 0; c < D; ++c) { lastY[c] = y[c]; lastDy[c] = fsal[c]; }  // lastIter (:498,:548)
+  }
   [[maybe_unused]] bool lastDyValid = true;
   double dt = in.dtInit;
   [[maybe_unused]] Rk4Dt h4 = rk4_dt(dt);
@@ -742,9 +826,9 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
     }
   }
   // next requested time, kept in a register and re-read only after an emission (a per-step global load otherwise)
-  double treq = (in.useDense && in.nReq > 0) ? (NEG ? -in.tReq[0] : in.tReq[0]) : 0.0;
+  [[maybe_unused]] double treq = (DENSE && in.useDense && in.nReq > 0) ? (NEG ? -in.tReq[0] : in.tReq[0]) : 0.0;
   while (t < in.tEnd) {  // :511
-    if (in.useDense) {
+    if constexpr (DENSE) if (in.useDense) {
       if (high < denseIndex) break;  // :513-514
       if (treq <= t) {
         if constexpr (!MT::fsal) {
@@ -764,7 +848,7 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
       }
     }
     dt = nmin(dt, in.tEnd - t);  // :525
-    if (in.useDense) {           // :526-530
+    if constexpr (DENSE) if (in.useDense) {           // :526-530
       lastT = t;
 #pragma unroll
       for (int c = 0; c < D; ++c) lastY[c] = y[c];

@@ -137,7 +137,7 @@ struct LaneStats {
   int ny = 0x7fffffff, nanAb = 0, trunc = 0;
 };
 
-template <int METHOD, class OpsF, class OpsB>
+template <int METHOD, bool DENSE = true, class OpsF, class OpsB>
 NNHIP_DEV void solve_body(const SolveArgs& a, const OpsF& opsF, const OpsB& opsB, const double* y0p, double* out, LaneStats& ls) {
   constexpr int D = OpsF::D;
   double y0[D];
@@ -165,7 +165,7 @@ NNHIP_DEV void solve_body(const SolveArgs& a, const OpsF& opsF, const OpsB& opsB
     for (int q = 0; q < 4; ++q) in.tailDt[q] = a.tailDt[1][q];
     DriveOut o;
     const int nNeg = a.nNeg;
-    drive<METHOD, true>(opsB, in, y0,
+    drive<METHOD, true, DENSE>(opsB, in, y0,
                         [=](int k, const double(&yv)[D]) {
                           if (k < nNeg) {
 #pragma unroll
@@ -205,7 +205,7 @@ NNHIP_DEV void solve_body(const SolveArgs& a, const OpsF& opsF, const OpsB& opsB
     DriveOut o;
     const int nPos = a.nPos;
     const int rb = rowBase;
-    drive<METHOD, false>(opsF, in, y0,
+    drive<METHOD, false, DENSE>(opsF, in, y0,
                          [=](int k, const double(&yv)[D]) {
                            if (k < nPos) {
 #pragma unroll
@@ -271,7 +271,7 @@ NNHIP_DEV void aggregate_stats(unsigned long long* aggBase, LaneStats ls) {
   }
 }
 
-template <int METHOD, class RHS>
+template <int METHOD, class RHS, bool DENSE = true>
 __global__ __launch_bounds__(kBlock) void solve_tpi_kernel(const SolveArgs a) {
   controller_prologue<MethodTraits<METHOD>::adaptive>();
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(kBlock) void solve_tpi_kernel(const SolveArgs a) {
     const Params P = params_of(a, i);
     const TpiOps<RHS, false> opsF{P};
     const TpiOps<RHS, true> opsB{P};
-    solve_body<METHOD>(a, opsF, opsB, a.y0 + i * a.ivpStride, a.y_out + i * a.ivpStride, ls);
+    solve_body<METHOD, DENSE>(a, opsF, opsB, a.y0 + i * a.ivpStride, a.y_out + i * a.ivpStride, ls);
     if (a.ny_out) a.ny_out[i] = ls.ny;
     if (a.steps_out) a.steps_out[i] = (int64_t)ls.steps;
     if (a.rejected_out) a.rejected_out[i] = (int64_t)ls.rejected;
@@ -293,7 +293,8 @@ template <int METHOD, class RHS>
 hipError_t launch_solve_tpi(const SolveArgs& a, hipStream_t s) {
   const int64_t grid = (a.N + kBlock - 1) / kBlock;
   if (grid <= 0) return hipSuccess;
-  return launch_kernel(solve_tpi_kernel<METHOD, RHS>, dim3((unsigned)grid), dim3(kBlock), s, a);
+  if (!a.useDense) return launch_kernel(solve_tpi_kernel<METHOD, RHS, false>, dim3((unsigned)grid), dim3(kBlock), s, a);  // lean: no Hermite history
+  return launch_kernel(solve_tpi_kernel<METHOD, RHS, true>, dim3((unsigned)grid), dim3(kBlock), s, a);
 }
 #endif
 
@@ -301,12 +302,18 @@ hipError_t launch_solve_tpi(const SolveArgs& a, hipStream_t s) {
 // Lane (s, c) owns component c of system s: its y, k1..kS, yNew are single VGPR doubles; the stage
 // argument vector and the squared error components of each system live in LDS (2*DIM doubles per system,
 // 4 KiB per 256-thread workgroup).  With the AoS layout a wave's 64 lanes read 512 contiguous bytes.
-#ifndef NNHIP_LPS_WPE  // A/B hook: -DNNHIP_LPS_WPE=n caps the fused lanes-per-system kernels' VGPRs for n waves per SIMD
-#define NNHIP_LPS_ATTR
+// Occupancy of the fused lanes-per-system kernels.  With 4 components per lane a 7-stage method holds ~190 VGPRs (2 waves per
+// SIMD) even without the dense-output history; asked for 3 waves the allocator fits 168 with 28-56 B of scratch per lane, and the
+// VALU-bound solve gains ~9 % (C4 Tsit54 default 7.45 -> 6.75 ms, DOPRI54 6.71 -> 6.17 ms; profiles/r02_c4_fused_ab.txt).  The
+// dense instantiations (215+ VGPRs) would spill 140-170 B and keep 2 waves.  A/B hook: -DNNHIP_LPS_WPE=n forces n for all of them.
+#ifndef NNHIP_LPS_WPE
+template <int CPL, bool DENSE>
+constexpr int lps_solve_waves() { return (CPL >= 4 && !DENSE) ? 3 : 1; }
+#define NNHIP_LPS_ATTR __attribute__((amdgpu_waves_per_eu(lps_solve_waves<CPL, DENSE>())))
 #else
 #define NNHIP_LPS_ATTR __attribute__((amdgpu_waves_per_eu(NNHIP_LPS_WPE, NNHIP_LPS_WPE)))
 #endif
-template <int METHOD, class RHS, int CPL, bool SHUFFLE_NORM = false>
+template <int METHOD, class RHS, int CPL, bool SHUFFLE_NORM = false, bool DENSE = true>
 __global__ __launch_bounds__(kBlock) NNHIP_LPS_ATTR void solve_lps_kernel(const SolveArgs a) {
   constexpr int DIM = RHS::dim;
   constexpr int LPSYS = DIM / CPL;  // lanes per system
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(kBlock) NNHIP_LPS_ATTR void solve_lps_kernel(const 
     const Params P = params_of(a, i);
     const LpsOps<RHS, false, CPL, SHUFFLE_NORM> opsF{P, ys, es, c};
     const LpsOps<RHS, true, CPL, SHUFFLE_NORM> opsB{P, ys, es, c};
-    solve_body<METHOD>(a, opsF, opsB, a.y0 + i * a.ivpStride + c * a.compStride, a.y_out + i * a.ivpStride + c * a.compStride, ls);
+    solve_body<METHOD, DENSE>(a, opsF, opsB, a.y0 + i * a.ivpStride + c * a.compStride, a.y_out + i * a.ivpStride + c * a.compStride, ls);
     if (c == 0) {
       if (a.ny_out) a.ny_out[i] = ls.ny;
       if (a.steps_out) a.steps_out[i] = (int64_t)ls.steps;
@@ -340,7 +347,8 @@ hipError_t launch_solve_lps(const SolveArgs& a, hipStream_t s) {
   constexpr int perBlock = kBlock / (RHS::dim / CPL);
   const int64_t grid = (a.N + perBlock - 1) / perBlock;
   if (grid <= 0) return hipSuccess;
-  return launch_kernel(solve_lps_kernel<METHOD, RHS, CPL, SHUFFLE_NORM>, dim3((unsigned)grid), dim3(kBlock), s, a);
+  if (!a.useDense) return launch_kernel(solve_lps_kernel<METHOD, RHS, CPL, SHUFFLE_NORM, false>, dim3((unsigned)grid), dim3(kBlock), s, a);
+  return launch_kernel(solve_lps_kernel<METHOD, RHS, CPL, SHUFFLE_NORM, true>, dim3((unsigned)grid), dim3(kBlock), s, a);
 }
 #endif
 

@@ -47,3 +47,21 @@ def test_oracle_controller_uses_libm_pow(oracle):
         got = oracle.controller_factor(err, order)
         ref = np.array([min(4.0, max(0.125, 0.9 * libm.pow(1.0 / e, 1.0 / order))) for e in err])
         assert np.array_equal(got, ref)
+
+
+def test_clamp_early_out_thresholds_are_safe(oracle):
+    """shrink_factor (ode_device.hpp) skips pow when error < ClampThresholds<order>::hi (-> 4.0) or > ::lo (-> 0.125).  With the
+    C library's pow (oracle.controller_factor) the full expression gives exactly those values on and beyond the thresholds."""
+    import re
+    src = open(os.path.join(ROOT, "numericalnim_amd", "csrc", "ode_device.hpp")).read()
+    thr = {int(o): (float(h), float(l)) for o, h, l in re.findall(r"ClampThresholds<(\d)> \{ static constexpr double hi = ([0-9.e+-]+), lo = ([0-9.e+-]+);", src)}
+    assert set(thr) == {2, 3, 5, 6}
+    rng = np.random.default_rng(0)
+    for order, (hi, lo) in thr.items():
+        assert hi <= (0.9 / 4) ** order * (1 - 0.9e-3) and lo >= (0.9 / 0.125) ** order * (1 + 0.9e-3)
+        below = np.concatenate([hi * (1 - 10 ** rng.uniform(-16, 0, 200_000)), 10 ** rng.uniform(-300, np.log10(hi), 200_000), [hi, np.nextafter(hi, 0), 5e-324]])
+        below = below[(below > 0) & (below <= hi)]
+        assert np.all(oracle.controller_factor(below, order) == 4.0)
+        above = np.concatenate([lo * (1 + 10 ** rng.uniform(-16, 0, 200_000)), 10 ** rng.uniform(np.log10(lo), 308, 200_000), [lo, np.nextafter(lo, np.inf), np.inf]])
+        with np.errstate(divide="ignore"):
+            assert np.all(oracle.controller_factor(above[above >= lo], order) == 0.125)

@@ -281,6 +281,8 @@ def test_controller_factor_is_libm_exact(nn, oracle, dev, order):
     err = np.concatenate([10 ** rng.uniform(-8, 8, 1_000_000), 10 ** rng.uniform(-0.5, 0.5, 1_000_000),
                           1.0 + (rng.uniform(-1, 1, 500_000)) * 2.0 ** -rng.integers(1, 52, 500_000),   # the accept/reject knife edge
                           10 ** rng.uniform(-300, 308, 200_000),                                        # incl. subnormal 1/error
+                          (0.9 / 4) ** order * (1 + rng.uniform(-3e-3, 3e-3, 300_000)),        # around the clamp early-out thresholds
+                          (0.9 / 0.125) ** order * (1 + rng.uniform(-3e-3, 3e-3, 300_000)),
                           [1.0, 1.0 + 2 ** -52, 1.0 - 2 ** -53, 1e-300, 1e300, 1.7e308, 5e-324, np.inf, 3.0, 0.5, 0.0]])
     e = torch.from_numpy(err).to(dev)
     out = torch.empty_like(e)
