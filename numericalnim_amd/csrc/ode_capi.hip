@@ -64,6 +64,8 @@ int g_fast_math = 0;     // tuning knob "fp_contract": 1 = FMA-contracted instan
 int g_stream_graph = 2;  // tuning knob "stream_graph": 0 eager launches; 1 hipGraph capture + replay of the streaming loop;
                          // 2 (default) = replay only launch-bound batches, from the second identical call on
 int g_fixed_vec_ipl = 2;  // tuning knob "fixed_vec_ipl": IVPs per lane of the vectorised fixed-step streaming kernel (0 = off, 2, 4)
+int g_mg_oversubscribe = 0;  // tuning knob "multi_gpu_oversubscribe": the multi-GPU host entry accepts more shards than devices (shard r on device
+                             // r mod #devices) — lets a one-GPU box exercise the sharded code path (index ranges, strided copies, empty shards)
 int g_adv_speculate = 0;  // tuning knob "adv_speculate": advance kernels issue all loads before the `t < tEnd` test (see StepArgs::speculate);
                           // measured: no gain (1e7 Lorenz IVPs 274.9 vs 273.6 us per iteration), so finished IVPs keep touching no memory
 int g_adv_split = 0;      // tuning knob "adv_split": index ranges the adaptive streaming loop interleaves on separate streams (0 = auto, 1, 2, 4)
@@ -191,17 +193,17 @@ bool is_page_locked(const void* p) {
 
 // `rows` segments of `width` bytes, `pitch` bytes apart in both buffers.  A few long rows go as plain 1-D copies (DMA engines, which
 // overlap with kernels); hipMemcpy2DAsync is kept for many short rows.
-hipError_t copy_rows(void* dst, const void* src, size_t pitch, size_t width, size_t rows, hipMemcpyKind kind, hipStream_t st) {
+hipError_t copy_rows(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows, hipMemcpyKind kind, hipStream_t st) {
   if (rows == 0 || width == 0) return hipSuccess;
-  if (pitch == width) return hipMemcpyAsync(dst, src, width * rows, kind, st);
+  if (dpitch == width && spitch == width) return hipMemcpyAsync(dst, src, width * rows, kind, st);
   if (rows <= 64) {
     for (size_t r = 0; r < rows; ++r) {
-      const hipError_t e = hipMemcpyAsync((char*)dst + r * pitch, (const char*)src + r * pitch, width, kind, st);
+      const hipError_t e = hipMemcpyAsync((char*)dst + r * dpitch, (const char*)src + r * spitch, width, kind, st);
       if (e != hipSuccess) return e;
     }
     return hipSuccess;
   }
-  return hipMemcpy2DAsync(dst, pitch, src, pitch, width, rows, kind, st);
+  return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, kind, st);
 }
 
 // Streams and events of the host-pointer solve come from a process-wide pool keyed by device: creating and destroying two streams
@@ -258,6 +260,10 @@ int stage_reserve(size_t n) {
 
 namespace nnhip {
 void multigpu_release();  // ode_multigpu.hip
+int solve_host_range(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
+                     const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t NFull, int64_t lo0, int64_t N, int dim,
+                     int layout, const double* tspan, int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
+                     int64_t* rejected_out, int64_t max_steps, nnhip_ode_stats* stats, int device);
 }
 namespace {
 void release_stream_graphs();  // defined next to the graph caches below
@@ -347,6 +353,7 @@ int nnhip_tune_set(const char* key, int value) {
   if (k == "fp_contract") { g_fast_math = value != 0; return NNHIP_OK; }
   if (k == "stream_graph") { if (value < 0 || value > 2) return fail(NNHIP_EVALUE, "stream_graph must be 0, 1 or 2"); g_stream_graph = value; return NNHIP_OK; }
   if (k == "fixed_vec_ipl") { if (value != 0 && value != 2 && value != 4) return fail(NNHIP_EVALUE, "fixed_vec_ipl must be 0, 2 or 4"); g_fixed_vec_ipl = value; return NNHIP_OK; }
+  if (k == "multi_gpu_oversubscribe") { g_mg_oversubscribe = value != 0; return NNHIP_OK; }
   if (k == "adv_speculate") { g_adv_speculate = value != 0; return NNHIP_OK; }
   if (k == "adv_split") { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(NNHIP_EVALUE, "adv_split must be 0, 1, 2 or 4"); g_adv_split = value; return NNHIP_OK; }
   if (k == "dim16_variant") { if (value < 0 || value > 4) return fail(NNHIP_EVALUE, "dim16_variant must be 0..4"); g_dim16_variant = value; return NNHIP_OK; }
@@ -606,7 +613,31 @@ int nnhip_ode_solve_batch_sweep_f64(const nnhip_ode_options* opt, int integrator
                                     int n_params, const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t N, int dim,
                                     int layout, const double* tspan, int n_t, double* t_out, double* y_out, int32_t* ny_out,
                                     int64_t* steps_out, int64_t* rejected_out, int64_t max_steps, nnhip_ode_stats* stats, int device) {
-  if (N < 0 || dim < 1 || n_t < 0) return fail(NNHIP_EVALUE, "bad sizes");
+  return nnhip::solve_host_range(opt, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y0, N, 0, N, dim, layout, tspan, n_t,
+                                 t_out, y_out, ny_out, steps_out, rejected_out, max_steps, stats, device);
+}
+
+}  // extern "C"
+
+namespace nnhip {
+void release_thread_staging() {  // worker threads of the multi-GPU entry call this before they exit
+  Staging& st = g_stage;
+  if (st.pending && st.ev) (void)hipEventSynchronize(st.ev);
+  if (st.host) (void)hipHostFree(st.host);
+  if (st.ev) (void)hipEventDestroy(st.ev);
+  st = Staging();
+}
+const char* thread_error() { return g_err; }
+bool multi_gpu_oversubscribe() { return g_mg_oversubscribe != 0; }
+
+// The host-pointer solve over the IVP index range [lo, lo + N) of the caller's arrays, which hold NFull IVPs (SoA planes and
+// per-IVP tables have pitch NFull): host buffers in, host buffers out, on `device`.  The single-GPU entry passes (NFull, 0, NFull);
+// the multi-GPU entry hands every device its shard of the SAME arrays — no staging copies in between.
+int solve_host_range(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
+                     const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t NFull, int64_t lo0, int64_t N, int dim,
+                     int layout, const double* tspan, int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
+                     int64_t* rejected_out, int64_t max_steps, nnhip_ode_stats* stats, int device) {
+  if (N < 0 || NFull < N || lo0 < 0 || lo0 + N > NFull || dim < 1 || n_t < 0) return fail(NNHIP_EVALUE, "bad sizes");
   if (n_per_ivp < 0 || n_per_ivp > nnhip::kMaxParams || (n_per_ivp > 0 && !per_ivp_params)) return fail(NNHIP_EVALUE, "bad per-IVP parameter table");
   if (!opt || (n_t > 0 && !tspan)) return fail(NNHIP_EVALUE, "options / tspan is NULL");
   for (int j = 0; j < n_t; ++j) if (!std::isfinite(tspan[j])) return fail(NNHIP_EVALUE, "tspan[%d] is not finite", j);
@@ -666,9 +697,9 @@ int nnhip_ode_solve_batch_sweep_f64(const nnhip_ode_options* opt, int integrator
   if (steps_out && N) HIP_TRY_C(hipMalloc((void**)&d_steps, (size_t)N * sizeof(int64_t)));
   if (rejected_out && N) HIP_TRY_C(hipMalloc((void**)&d_rej, (size_t)N * sizeof(int64_t)));
   HIP_TRY_C(hipMalloc(&d_ws, (size_t)wsBytes));
-  if (n_per_ivp > 0 && N > 0) {  // the whole table goes up front: a chunk addresses its columns of the full [k][N] table
+  if (n_per_ivp > 0 && N > 0) {  // this range's columns of the [k][NFull] table go up front as a dense [k][N] table
     HIP_TRY_C(hipMalloc((void**)&d_per, (size_t)n_per_ivp * (size_t)N * sizeof(double)));
-    HIP_TRY_C(hipMemcpy(d_per, per_ivp_params, (size_t)n_per_ivp * (size_t)N * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY_C(hipMemcpy2D(d_per, (size_t)N * 8, per_ivp_params + lo0, (size_t)NFull * 8, (size_t)N * 8, (size_t)n_per_ivp, hipMemcpyHostToDevice));
   }
   HIP_TRY_C(hipMalloc((void**)&d_agg, nnhip::kAggSlots * 8 * sizeof(unsigned long long)));
   {
@@ -676,7 +707,7 @@ int nnhip_ode_solve_batch_sweep_f64(const nnhip_ode_options* opt, int integrator
     for (int k = 0; k < nnhip::kAggSlots; ++k) init[(size_t)k * 8 + 3] = ~0ull;
     HIP_TRY_C(hipMemcpy(d_agg, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
   }
-  if (g_host_register) {  // best effort: a failed registration just leaves the copies staged
+  if (g_host_register && N == NFull) {  // best effort: a failed registration just leaves the copies staged
     regIn = nState && hipHostRegister((void*)y0, nState * sizeof(double), hipHostRegisterDefault) == hipSuccess;
     regOut = nOut && hipHostRegister((void*)y_out, nOut * sizeof(double), hipHostRegisterDefault) == hipSuccess;
     (void)hipGetLastError();
@@ -692,10 +723,11 @@ int nnhip_ode_solve_batch_sweep_f64(const nnhip_ode_options* opt, int integrator
     const int64_t lo = N * cI / nChunks, hi = N * (cI + 1) / nChunks, n = hi - lo;
     if (n <= 0) continue;
     hipStream_t st = s[cI & 1];
-    if (soa) {  // component planes: `dim` rows of n doubles, pitch N
-      HIP_TRY_C(copy_rows(d_y0 + lo, y0 + lo, (size_t)N * 8, (size_t)n * 8, (size_t)dim, hipMemcpyHostToDevice, st));
+    const int64_t hlo = lo0 + lo;  // the chunk's first IVP in the caller's arrays
+    if (soa) {  // component planes: `dim` rows of n doubles; device pitch N, host pitch NFull
+      HIP_TRY_C(copy_rows(d_y0 + lo, (size_t)N * 8, y0 + hlo, (size_t)NFull * 8, (size_t)n * 8, (size_t)dim, hipMemcpyHostToDevice, st));
     } else {
-      HIP_TRY_C(hipMemcpyAsync(d_y0 + lo * dim, y0 + lo * dim, (size_t)n * dim * 8, hipMemcpyHostToDevice, st));
+      HIP_TRY_C(hipMemcpyAsync(d_y0 + lo * dim, y0 + hlo * dim, (size_t)n * dim * 8, hipMemcpyHostToDevice, st));
     }
     HIP_TRY_C(hipEventRecord(evs[(size_t)cI * 2], st));
     rc = launch_solve_range(ps, lo, n, st);
@@ -703,14 +735,14 @@ int nnhip_ode_solve_batch_sweep_f64(const nnhip_ode_options* opt, int integrator
     HIP_TRY_C(hipEventRecord(evs[(size_t)cI * 2 + 1], st));
     if (n_t > 0) {
       if (soa) {
-        HIP_TRY_C(copy_rows(y_out + lo, d_out + lo, (size_t)N * 8, (size_t)n * 8, (size_t)n_t * dim, hipMemcpyDeviceToHost, st));
+        HIP_TRY_C(copy_rows(y_out + hlo, (size_t)NFull * 8, d_out + lo, (size_t)N * 8, (size_t)n * 8, (size_t)n_t * dim, hipMemcpyDeviceToHost, st));
       } else {
-        HIP_TRY_C(copy_rows(y_out + lo * dim, d_out + lo * dim, (size_t)N * dim * 8, (size_t)n * dim * 8, (size_t)n_t, hipMemcpyDeviceToHost, st));
+        HIP_TRY_C(copy_rows(y_out + hlo * dim, (size_t)NFull * dim * 8, d_out + lo * dim, (size_t)N * dim * 8, (size_t)n * dim * 8, (size_t)n_t, hipMemcpyDeviceToHost, st));
       }
     }
-    if (d_ny) HIP_TRY_C(hipMemcpyAsync(ny_out + lo, d_ny + lo, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    if (d_steps) HIP_TRY_C(hipMemcpyAsync(steps_out + lo, d_steps + lo, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    if (d_rej) HIP_TRY_C(hipMemcpyAsync(rejected_out + lo, d_rej + lo, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    if (d_ny) HIP_TRY_C(hipMemcpyAsync(ny_out + hlo, d_ny + lo, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (d_steps) HIP_TRY_C(hipMemcpyAsync(steps_out + hlo, d_steps + lo, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    if (d_rej) HIP_TRY_C(hipMemcpyAsync(rejected_out + hlo, d_rej + lo, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, st));
   }
   HIP_TRY_C(hipStreamSynchronize(s[0]));
   HIP_TRY_C(hipStreamSynchronize(s[1]));
@@ -735,6 +767,9 @@ int nnhip_ode_solve_batch_sweep_f64(const nnhip_ode_options* opt, int integrator
   return NNHIP_OK;
 #undef HIP_TRY_C
 }
+}  // namespace nnhip
+
+extern "C" {
 
 // ---- step-streaming ---------------------------------------------------------------------------------
 int nnhip_ode_step_batch_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,

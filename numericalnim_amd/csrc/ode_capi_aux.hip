@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -13,6 +14,15 @@
 #include "quad_kernels.hpp"
 
 namespace nnhip {
+// ode_capi.hip
+int fail_msg(int code, const char* fmt, ...);
+const char* thread_error();
+bool multi_gpu_oversubscribe();
+void release_thread_staging();
+int solve_host_range(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
+                     const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t NFull, int64_t lo0, int64_t N, int dim,
+                     int layout, const double* tspan, int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
+                     int64_t* rejected_out, int64_t max_steps, nnhip_ode_stats* stats, int device);
 
 template <class RHS>
 hipError_t launch_rhs_batch(int64_t N, int64_t is, int64_t cs, double t, const double* y, double* dy, const Params& P, hipStream_t s) {
@@ -160,11 +170,11 @@ extern "C" {
 
 int nnhip_hermite_spline_f64_dev(double x, double x1, double x2, const double* y1, const double* y2, const double* dy1,
                                  const double* dy2, double* out, int64_t n, void* stream) {
-  if (n < 0 || (n > 0 && (!y1 || !y2 || !dy1 || !dy2 || !out))) return NNHIP_EVALUE;
+  if (n < 0 || (n > 0 && (!y1 || !y2 || !dy1 || !dy2 || !out))) return nnhip::fail_msg(NNHIP_EVALUE, "hermite_spline: n < 0 or a NULL array");
   if (n == 0) return NNHIP_OK;
   const int64_t grid = (n + nnhip::kBlock - 1) / nnhip::kBlock;
   return nnhip::launch_kernel(nnhip::hermite_kernel, dim3((unsigned)grid), dim3(nnhip::kBlock), (hipStream_t)stream, x, x1, x2, y1,
-                              y2, dy1, dy2, out, n) == hipSuccess ? NNHIP_OK : NNHIP_EHIP;
+                              y2, dy1, dy2, out, n) == hipSuccess ? NNHIP_OK : nnhip::fail_msg(NNHIP_EHIP, "hermite_spline: kernel launch failed");
 }
 
 static nnhip::HermSet herm_set(const double* X, int n, double x, bool deriv) {
@@ -192,11 +202,11 @@ static nnhip::HermSet herm_set(const double* X, int n, double x, bool deriv) {
 int nnhip_hermite_spline_eval_batch_f64_dev(const double* X, int n_knots, const double* Y, const double* dY, int64_t M,
                                             const double* xq, int n_q, int deriv, int extrap, double extrap_value, double* out,
                                             void* stream) {
-  if (n_knots < 2 || M < 0 || n_q < 0 || !X || (n_q > 0 && !xq) || extrap < 0 || extrap > 4) return NNHIP_EVALUE;
-  for (int i = 1; i < n_knots; ++i) if (!(X[i - 1] < X[i])) return NNHIP_EVALUE;  // sortAndTrimDataset's postcondition (:231)
+  if (n_knots < 2 || M < 0 || n_q < 0 || !X || (n_q > 0 && !xq) || extrap < 0 || extrap > 4) return nnhip::fail_msg(NNHIP_EVALUE, "hermite spline eval: need >= 2 knots, M >= 0, n_q >= 0, non-NULL X / xq and an ExtrapolateKind in 0..4");
+  for (int i = 1; i < n_knots; ++i) if (!(X[i - 1] < X[i])) return nnhip::fail_msg(NNHIP_EVALUE, "hermite spline eval: X must be strictly ascending (X[%d] = %g, X[%d] = %g)", i - 1, X[i - 1], i, X[i]);  // sortAndTrimDataset's postcondition (:231)
   if (M == 0 || n_q == 0) return NNHIP_OK;
-  if (!Y || !dY || !out) return NNHIP_EVALUE;
-  if (extrap == 4) for (int q = 0; q < n_q; ++q) if (xq[q] < X[0] || xq[q] > X[n_knots - 1]) return NNHIP_EVALUE;  // ValueError :340-341
+  if (!Y || !dY || !out) return nnhip::fail_msg(NNHIP_EVALUE, "hermite spline eval: Y / dY / out is NULL");
+  if (extrap == 4) for (int q = 0; q < n_q; ++q) if (xq[q] < X[0] || xq[q] > X[n_knots - 1]) return nnhip::fail_msg(NNHIP_EVALUE, "x = %g is outside the interpolation range [%g, %g] (ExtrapolateKind.Error)", xq[q], X[0], X[n_knots - 1]);  // ValueError :340-341
   for (int q0 = 0; q0 < n_q; q0 += nnhip::kHermChunk) {
     nnhip::HermChunk c;
     std::memset(&c, 0, sizeof(c));
@@ -222,19 +232,20 @@ int nnhip_hermite_spline_eval_batch_f64_dev(const double* X, int n_knots, const 
     }
     const dim3 grid((unsigned)((M + nnhip::kBlock - 1) / nnhip::kBlock), (unsigned)nq), block(nnhip::kBlock);
     if (nnhip::launch_kernel(nnhip::hermite_interp_kernel, grid, block, (hipStream_t)stream, c, nq, Y, dY, M, out + (int64_t)q0 * M) != hipSuccess)
-      return NNHIP_EHIP;
+      return nnhip::fail_msg(NNHIP_EHIP, "hermite spline eval: kernel launch failed");
   }
   return NNHIP_OK;
 }
 
 int nnhip_hermite_spline_slopes_f64_dev(const double* X, int n_knots, const double* Y, int64_t M, double* dY, void* stream) {
-  if (n_knots < 2 || n_knots > 65535 || M < 0 || !X) return NNHIP_EVALUE;
-  for (int i = 1; i < n_knots; ++i) if (!(X[i - 1] < X[i])) return NNHIP_EVALUE;  // sortAndTrimDataset's postcondition (:244)
+  if (n_knots < 2 || M < 0 || !X) return nnhip::fail_msg(NNHIP_EVALUE, "hermite slopes: need >= 2 knots, M >= 0 and a non-NULL X");
+  if (n_knots > 65535) return nnhip::fail_msg(NNHIP_EUNSUPPORTED, "hermite slopes: at most 65535 knots (got %d)", n_knots);
+  for (int i = 1; i < n_knots; ++i) if (!(X[i - 1] < X[i])) return nnhip::fail_msg(NNHIP_EVALUE, "hermite slopes: X must be strictly ascending (X[%d] = %g, X[%d] = %g)", i - 1, X[i - 1], i, X[i]);  // sortAndTrimDataset's postcondition (:244)
   if (M == 0) return NNHIP_OK;
-  if (!Y || !dY) return NNHIP_EVALUE;
+  if (!Y || !dY) return nnhip::fail_msg(NNHIP_EVALUE, "hermite slopes: Y / dY is NULL");
   hipStream_t s = (hipStream_t)stream;
   double* dX = nullptr;
-  if (hipMalloc((void**)&dX, (size_t)n_knots * sizeof(double)) != hipSuccess) return NNHIP_EHIP;
+  if (hipMalloc((void**)&dX, (size_t)n_knots * sizeof(double)) != hipSuccess) return nnhip::fail_msg(NNHIP_ENOMEM, "hermite slopes: hipMalloc failed");
   int rc = NNHIP_OK;
   if (hipMemcpyAsync(dX, X, (size_t)n_knots * sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess) rc = NNHIP_EHIP;
   const dim3 grid((unsigned)((M + nnhip::kBlock - 1) / nnhip::kBlock), (unsigned)n_knots), block(nnhip::kBlock);
@@ -245,28 +256,28 @@ int nnhip_hermite_spline_slopes_f64_dev(const double* X, int n_knots, const doub
 }
 
 int nnhip_cumtrapz_batch_f64_dev(const double* X, int n, const double* Y, int64_t M, double* out, void* stream) {
-  if (n < 1 || M < 0 || !X) return NNHIP_EVALUE;
-  for (int i = 1; i < n; ++i) if (!(X[i - 1] < X[i])) return NNHIP_EVALUE;  // sortAndTrimDataset's postcondition (:130)
+  if (n < 1 || M < 0 || !X) return nnhip::fail_msg(NNHIP_EVALUE, "cumtrapz: need n >= 1, M >= 0 and a non-NULL X");
+  for (int i = 1; i < n; ++i) if (!(X[i - 1] < X[i])) return nnhip::fail_msg(NNHIP_EVALUE, "cumtrapz: X must be strictly ascending (X[%d] = %g, X[%d] = %g)", i - 1, X[i - 1], i, X[i]);  // sortAndTrimDataset's postcondition (:130)
   if (M == 0) return NNHIP_OK;
-  if (!Y || !out) return NNHIP_EVALUE;
+  if (!Y || !out) return nnhip::fail_msg(NNHIP_EVALUE, "cumulative quadrature: Y / out is NULL");
   const dim3 grid((unsigned)((M + nnhip::kBlock - 1) / nnhip::kBlock)), block(nnhip::kBlock);
   int first = 0;
   do {
     nnhip::TrapzWeights W;
     const int nw = std::min(nnhip::kTrapzChunk, n - 1 - first);
     for (int i = 0; i < nw; ++i) W.w[i] = 0.5 * (X[first + i + 1] - X[first + i]);
-    if (nnhip::launch_kernel(nnhip::cumtrapz_kernel, grid, block, (hipStream_t)stream, W, nw, first, Y, out, M) != hipSuccess) return NNHIP_EHIP;
+    if (nnhip::launch_kernel(nnhip::cumtrapz_kernel, grid, block, (hipStream_t)stream, W, nw, first, Y, out, M) != hipSuccess) return nnhip::fail_msg(NNHIP_EHIP, "cumtrapz: kernel launch failed");
     first += nw;
   } while (first < n - 1);
   return NNHIP_OK;
 }
 
 int nnhip_cumsimpson_batch_f64_dev(const double* X, int n, const double* Y, int64_t M, double* out, void* stream) {
-  if (M < 0 || !X) return NNHIP_EVALUE;
-  if (n < 3) return NNHIP_EVALUE;  // ValueError "at least 3 elements" (integrate.nim:345-346)
-  for (int i = 1; i < n; ++i) if (!(X[i - 1] < X[i])) return NNHIP_EVALUE;
+  if (M < 0 || !X) return nnhip::fail_msg(NNHIP_EVALUE, "cumsimpson: need M >= 0 and a non-NULL X");
+  if (n < 3) return nnhip::fail_msg(NNHIP_EVALUE, "cumsimpson: X and Y must have at least 3 elements (got %d)", n);  // ValueError (integrate.nim:345-346)
+  for (int i = 1; i < n; ++i) if (!(X[i - 1] < X[i])) return nnhip::fail_msg(NNHIP_EVALUE, "cumsimpson: X must be strictly ascending (X[%d] = %g, X[%d] = %g)", i - 1, X[i - 1], i, X[i]);
   if (M == 0) return NNHIP_OK;
-  if (!Y || !out) return NNHIP_EVALUE;
+  if (!Y || !out) return nnhip::fail_msg(NNHIP_EVALUE, "cumulative quadrature: Y / out is NULL");
   std::vector<nnhip::SimpsonPair> pairs;
   std::vector<nnhip::SimpsonPoint> pts;
   int64_t nPairs64 = 0;
@@ -276,8 +287,8 @@ int nnhip_cumsimpson_batch_f64_dev(const double* X, int n, const double* Y, int6
   hipStream_t s = (hipStream_t)stream;
   nnhip::SimpsonPair* dPairs = nullptr;
   nnhip::SimpsonPoint* dPts = nullptr;
-  if (hipMalloc((void**)&dPairs, pairs.size() * sizeof(pairs[0])) != hipSuccess) return NNHIP_ENOMEM;
-  if (hipMalloc((void**)&dPts, pts.size() * sizeof(pts[0])) != hipSuccess) { (void)hipFree(dPairs); return NNHIP_ENOMEM; }
+  if (hipMalloc((void**)&dPairs, pairs.size() * sizeof(pairs[0])) != hipSuccess) return nnhip::fail_msg(NNHIP_ENOMEM, "cumsimpson: hipMalloc failed");
+  if (hipMalloc((void**)&dPts, pts.size() * sizeof(pts[0])) != hipSuccess) { (void)hipFree(dPairs); return nnhip::fail_msg(NNHIP_ENOMEM, "cumsimpson: hipMalloc failed"); }
   int rc = NNHIP_OK;
   if (hipMemcpyAsync(dPairs, pairs.data(), pairs.size() * sizeof(pairs[0]), hipMemcpyHostToDevice, s) != hipSuccess ||
       hipMemcpyAsync(dPts, pts.data(), pts.size() * sizeof(pts[0]), hipMemcpyHostToDevice, s) != hipSuccess)
@@ -293,7 +304,7 @@ int nnhip_cumsimpson_batch_f64_dev(const double* X, int n, const double* Y, int6
 }
 
 int nnhip_ode_controller_factor_f64_dev(int order, const double* error, double* out, int64_t n, void* stream) {
-  if (n < 0 || (n > 0 && (!error || !out))) return NNHIP_EVALUE;
+  if (n < 0 || (n > 0 && (!error || !out))) return nnhip::fail_msg(NNHIP_EVALUE, "controller_factor: n < 0 or a NULL array");
   if (n == 0) return NNHIP_OK;
   const dim3 grid((unsigned)((n + nnhip::kBlock - 1) / nnhip::kBlock)), block(nnhip::kBlock);
   hipError_t e;
@@ -302,22 +313,22 @@ int nnhip_ode_controller_factor_f64_dev(int order, const double* error, double* 
     case 3: e = nnhip::launch_kernel(nnhip::controller_factor_kernel<3>, grid, block, (hipStream_t)stream, error, out, n); break;
     case 5: e = nnhip::launch_kernel(nnhip::controller_factor_kernel<5>, grid, block, (hipStream_t)stream, error, out, n); break;
     case 6: e = nnhip::launch_kernel(nnhip::controller_factor_kernel<6>, grid, block, (hipStream_t)stream, error, out, n); break;
-    default: return NNHIP_EVALUE;
+    default: return nnhip::fail_msg(NNHIP_EVALUE, "controller_factor: order must be 2, 3, 5 or 6 (got %d)", order);
   }
-  return e == hipSuccess ? NNHIP_OK : NNHIP_EHIP;
+  return e == hipSuccess ? NNHIP_OK : nnhip::fail_msg(NNHIP_EHIP, "controller_factor: kernel launch failed: %s", hipGetErrorString(e));
 }
 
 int nnhip_ode_rhs_batch_f64_dev(int rhs_kind, const double* rhs_params, int n_params, int64_t N, int dim, int layout, double t,
                                 const double* y, double* dy, void* stream) {
-  if (N < 0 || dim < 1 || n_params < 0 || n_params > nnhip::kMaxParams) return NNHIP_EVALUE;
+  if (N < 0 || dim < 1 || n_params < 0 || n_params > nnhip::kMaxParams) return nnhip::fail_msg(NNHIP_EVALUE, "rhs_batch: bad N / dim / n_params");
   if (N == 0) return NNHIP_OK;
   nnhip::Params P;
   for (int k = 0; k < nnhip::kMaxParams; ++k) P.p[k] = k < n_params ? rhs_params[k] : 0.0;
   const int64_t is = layout == NNHIP_LAYOUT_SOA ? 1 : dim, cs = layout == NNHIP_LAYOUT_SOA ? N : 1;
   if (rhs_kind >= NNHIP_RHS_USER_BASE) {
     int d = 0;
-    if (!nnhip::rtc_info(rhs_kind, &d, nullptr) || d != dim) return NNHIP_EVALUE;
-    return nnhip::rtc_launch_rhs(rhs_kind, N, is, cs, t, y, dy, P, (hipStream_t)stream) == hipSuccess ? NNHIP_OK : NNHIP_EHIP;
+    if (!nnhip::rtc_info(rhs_kind, &d, nullptr) || d != dim) return nnhip::fail_msg(NNHIP_EVALUE, "rhs_batch: unknown user rhs_kind %d or dim mismatch", rhs_kind);
+    return nnhip::rtc_launch_rhs(rhs_kind, N, is, cs, t, y, dy, P, (hipStream_t)stream) == hipSuccess ? NNHIP_OK : nnhip::fail_msg(NNHIP_EHIP, "rhs_batch: %s", nnhip::rtc_last_error());
   }
   hipError_t e = hipErrorInvalidValue;
   bool found = false;
@@ -337,10 +348,10 @@ int nnhip_ode_rhs_batch_f64_dev(int rhs_kind, const double* rhs_params, int n_pa
 #undef X
   if (!found) {  // size-generic built-in kind at a size without an ahead-of-time kernel: run-time instantiation
     const int k = nnhip::rtc_builtin_kind(rhs_kind, dim);
-    if (k < 0) return NNHIP_EUNSUPPORTED;
-    return nnhip::rtc_launch_rhs(k, N, is, cs, t, y, dy, P, (hipStream_t)stream) == hipSuccess ? NNHIP_OK : NNHIP_EHIP;
+    if (k < 0) return nnhip::fail_msg(NNHIP_EUNSUPPORTED, "rhs_batch: no kernel for rhs_kind=%d dim=%d", rhs_kind, dim);
+    return nnhip::rtc_launch_rhs(k, N, is, cs, t, y, dy, P, (hipStream_t)stream) == hipSuccess ? NNHIP_OK : nnhip::fail_msg(NNHIP_EHIP, "rhs_batch: %s", nnhip::rtc_last_error());
   }
-  return e == hipSuccess ? NNHIP_OK : NNHIP_EHIP;
+  return e == hipSuccess ? NNHIP_OK : nnhip::fail_msg(NNHIP_EHIP, "rhs_batch: kernel launch failed: %s", hipGetErrorString(e));
 }
 
 int nnhip_ode_solve_batch_multi_gpu_f64(const nnhip_ode_options* opt, int integrator, int rhs_kind,
@@ -348,39 +359,37 @@ int nnhip_ode_solve_batch_multi_gpu_f64(const nnhip_ode_options* opt, int integr
                                         int layout, const double* tspan, int n_t, double* t_out, double* y_out,
                                         int32_t* ny_out, int64_t max_steps, nnhip_ode_stats* stats, int n_gpus) {
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return NNHIP_EHIP;
-  if (n_gpus <= 0 || n_gpus > ndev || N < 0 || dim < 1 || n_t < 0) return NNHIP_EVALUE;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return nnhip::fail_msg(NNHIP_EHIP, "no HIP device available (this library has no CPU fallback)");
+  if (n_gpus <= 0 || (n_gpus > ndev && !nnhip::multi_gpu_oversubscribe()) || n_gpus > 64)
+    return nnhip::fail_msg(NNHIP_EVALUE, "n_gpus = %d, but this node has %d HIP device(s)", n_gpus, ndev);
+  if (N < 0 || dim < 1 || n_t < 0 || !opt || (n_t > 0 && !tspan)) return nnhip::fail_msg(NNHIP_EVALUE, "bad sizes / NULL options or tspan");
+  // The output time grid depends on (options, tspan) only: assembled once, on the calling thread (ode.nim:476-487, 585) — also
+  // when some (or all) shards are empty.
+  int nTOut = 0;
+  int rc = nnhip_ode_time_grid(opt, tspan, n_t, t_out, &nTOut);
+  if (rc) return rc;
   std::vector<int> rcs(n_gpus, NNHIP_OK);
+  std::vector<std::string> errs(n_gpus);
   std::vector<nnhip_ode_stats> sts(n_gpus);
   std::vector<std::thread> th;
-  // contiguous index ranges [r*N/G, (r+1)*N/G): nothing couples trajectories (ode.nim:589: one solveODE call per IVP)
+  // Contiguous index ranges [r*N/G, (r+1)*N/G): nothing couples trajectories (ode.nim:589: one solveODE call per IVP).  Every
+  // device works on its range of the caller's own arrays (nnhip::solve_host_range: strided copies straight between the caller's
+  // buffers and the device, chunked and overlapped with the kernel when the buffers are page-locked) — no intermediate copies.
   for (int r = 0; r < n_gpus; ++r) {
     th.emplace_back([&, r]() {
       const int64_t lo = N * r / n_gpus, hi = N * (r + 1) / n_gpus, n = hi - lo;
       std::memset(&sts[r], 0, sizeof(nnhip_ode_stats));
-      if (n == 0) { sts[r].ny_min = 0x7fffffff; return; }
-      if (layout == NNHIP_LAYOUT_AOS && n_t <= 1) {  // shard is contiguous in both arrays
-        rcs[r] = nnhip_ode_solve_batch_f64(opt, integrator, rhs_kind, rhs_params, n_params, y0 + lo * dim, n, dim, layout, tspan,
-                                           n_t, r == 0 ? t_out : nullptr, y_out + lo * dim, ny_out ? ny_out + lo : nullptr,
-                                           nullptr, nullptr, max_steps, &sts[r], r);
-        return;
-      }
-      std::vector<double> y0s((size_t)n * dim), outs((size_t)n * dim * n_t);
-      if (layout == NNHIP_LAYOUT_SOA) for (int c = 0; c < dim; ++c) std::memcpy(&y0s[(size_t)c * n], y0 + (size_t)c * N + lo, (size_t)n * sizeof(double));
-      else std::memcpy(y0s.data(), y0 + (size_t)lo * dim, (size_t)n * dim * sizeof(double));
-      rcs[r] = nnhip_ode_solve_batch_f64(opt, integrator, rhs_kind, rhs_params, n_params, y0s.data(), n, dim, layout, tspan, n_t,
-                                         r == 0 ? t_out : nullptr, outs.data(), ny_out ? ny_out + lo : nullptr, nullptr, nullptr,
-                                         max_steps, &sts[r], r);
-      if (rcs[r]) return;
-      if (layout == NNHIP_LAYOUT_SOA) {
-        for (int64_t p = 0; p < (int64_t)n_t * dim; ++p) std::memcpy(y_out + (size_t)p * N + lo, &outs[(size_t)p * n], (size_t)n * sizeof(double));
-      } else {
-        for (int j = 0; j < n_t; ++j) std::memcpy(y_out + ((size_t)j * N + lo) * dim, &outs[(size_t)j * n * dim], (size_t)n * dim * sizeof(double));
-      }
+      sts[r].ny_min = 0x7fffffff;
+      if (n == 0) return;
+      rcs[r] = nnhip::solve_host_range(opt, integrator, rhs_kind, rhs_params, n_params, nullptr, 0, y0, N, lo, n, dim, layout, tspan, n_t,
+                                       nullptr, y_out, ny_out, nullptr, nullptr, max_steps, &sts[r], r % ndev);
+      if (rcs[r]) errs[r] = nnhip::thread_error();  // the message lives in THIS thread's buffer: hand it to the caller
+      nnhip::release_thread_staging();              // pinned staging + event of this (short-lived) thread
     });
   }
   for (auto& t : th) t.join();
-  for (int r = 0; r < n_gpus; ++r) if (rcs[r]) return rcs[r];
+  for (int r = 0; r < n_gpus; ++r)
+    if (rcs[r]) return nnhip::fail_msg(rcs[r], "device %d (IVPs %lld..%lld): %s", r, (long long)(N * r / n_gpus), (long long)(N * (r + 1) / n_gpus), errs[r].c_str());
   if (stats) {
     std::memset(stats, 0, sizeof(*stats));
     stats->ny_min = 0x7fffffff;
@@ -390,8 +399,9 @@ int nnhip_ode_solve_batch_multi_gpu_f64(const nnhip_ode_options* opt, int integr
       if (sts[r].ny_min < stats->ny_min) stats->ny_min = sts[r].ny_min;
       stats->nan_aborts += sts[r].nan_aborts; stats->truncated += sts[r].truncated;
       if (sts[r].kernel_ms > stats->kernel_ms) stats->kernel_ms = sts[r].kernel_ms;
-      if (r == 0) stats->n_t_out = sts[r].n_t_out;
     }
+    if (N == 0) stats->ny_min = 0;
+    stats->n_t_out = nTOut;
   }
   return NNHIP_OK;
 }

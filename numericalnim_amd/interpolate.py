@@ -52,6 +52,9 @@ class HermiteSpline:
             self.dY = dY.contiguous()
 
     def _run(self, x, deriv, extrap, extrapValue):
+        if extrap == "Constant" and extrapValue is None:
+            # the reference asserts (AssertionDefect) when extrapValue is missing
+            raise AssertionError("When using `extrap = Constant`, a value `extrapValue` must be supplied!")  # interpolate.nim:312,359
         xq = np.ascontiguousarray(np.atleast_1d(np.asarray(x, dtype=np.float64)))
         dp = C.POINTER(C.c_double)
         if self.host:
