@@ -189,11 +189,16 @@ def main():
         return
 
     # ---- PMC traffic from the committed profile of this same command, if present ------------------------
+    # (PMC counters cannot be read from inside the process being timed: `traffic` is the STATIC figure of the committed profile,
+    # collected by scripts/profile_gpu.sh on an earlier run of this same command; roofline.traffic_source says so.)
     traffic = None
+    traffic_src = None
     pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pj):
+    if os.path.exists(pj) and n == 10_000_000:
         try:
-            traffic = json.load(open(pj)).get("rk4_stream", {}).get("hbm_bytes_per_launch")
+            pm = json.load(open(pj))
+            traffic = pm.get("rk4_stream", {}).get("hbm_bytes_per_launch")
+            traffic_src = "profiles/pmc_traffic.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round %s, scripts/profile_gpu.sh; not measured in this run)" % pm.get("round")
         except Exception:
             traffic = None
 
@@ -219,7 +224,12 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+            "traffic_source": traffic_src,
             "kernel": "rk4_stream_vec_kernel", "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_us": launch_s * 1e6,
+            # the headline batch (2 x 80 MB of ping-pong state) lives in the 256 MiB Infinity Cache, and gfx950's FETCH_SIZE counts
+            # Infinity-Cache hits: `frac` is the kernel's streaming rate, `frac_hbm_only` (filled from the 6.4e7-IVP leg below,
+            # 1 GB working set) is the part that is certainly HBM
+            "frac_hbm_only": None, "achieved_hbm_only": None,
         },
         "parity_max_abs_err_vs_oracle": check,  # set by the cpu_baseline leg
     }
@@ -246,6 +256,8 @@ def main():
                               "bitwise_equal_to_stream": bool(torch.equal(yfu[-1], yf))}
 
     # ---- informational: the same kernel on a batch that cannot live in the 256 MiB Infinity Cache (1 GB of ping-pong state) ----
+    if n > 20_000_000:  # the batch itself is beyond the Infinity Cache
+        out["roofline"]["achieved_hbm_only"], out["roofline"]["frac_hbm_only"] = achieved, achieved / 8000.0
     if not args.no_fused and world == 1 and n <= 20_000_000:
         nb = 64_000_000
         yb = nd.c2_y0_torch(0, nb, dev)
@@ -259,6 +271,8 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         lb = e0.elapsed_time(e1) * 1e-3 / nsb
+        out["roofline"]["achieved_hbm_only"] = 16.0 * nb / lb / 1e9
+        out["roofline"]["frac_hbm_only"] = 16.0 * nb / lb / 1e9 / 8000.0
         out["beyond_infinity_cache"] = {"ivps": nb, "launches": int(nsb), "avg_launch_us": lb * 1e6, "achieved": 16.0 * nb / lb / 1e9, "unit": "GB/s",
                                         "frac": 16.0 * nb / lb / 1e9 / 8000.0,
                                         "note": "same kernel family, 1 GB working set: the unambiguous HBM figure (the headline batch's 160 MB fit the Infinity Cache)"}

@@ -29,6 +29,11 @@ def test_single_process_line():
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["algorithmic_bytes_per_launch"] == 16.0 * 200000
+    # the Infinity-Cache caveat is part of the line: the HBM-only figure comes from the 6.4e7-IVP leg of the same run, and the PMC
+    # traffic (a static figure from profiles/) is only attached to the configuration it was collected on (1e7 IVPs) — with its source
+    assert {"frac_hbm_only", "achieved_hbm_only", "traffic", "traffic_source"} <= set(rf)
+    assert rf["traffic"] is None and rf["traffic_source"] is None
+    assert 0 < rf["frac_hbm_only"] < 1 and abs(rf["frac_hbm_only"] - out["beyond_infinity_cache"]["frac"]) < 1e-12
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
     assert out["parity_max_abs_err_vs_oracle"] == 0.0 and out["parity_checked_ivps"] == 2000
@@ -61,3 +66,19 @@ def test_two_ranks_share_the_gpu_over_gloo():
     assert KEYS <= set(out) and out["n_gpus"] == 2 and out["config"]["backend"] == "gloo"
     assert out["gathers_verified"] == 4 and "cpu_baseline" not in out  # cpu_baseline is reported at N = 1 only
     assert abs(out["value"] - 2 * 300000 * 64 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 1e-9  # whole-job aggregate
+
+
+def test_eight_ranks_share_the_gpu_over_gloo():
+    """BASELINE config C5's launch shape — the driver's exact line at --gpus 8 — on this box's single GPU: eight ranks over gloo, a
+    reduced batch per rank, every overlapped all-gather verified against the solve it belongs to, whole-job aggregate from rank 0."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29583",
+           os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--verify-gathers", "--n-ivp", "100000",
+           "--rk4-steps", "32"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert KEYS <= set(out) and out["n_gpus"] == 8 and out["scaling"] == "weak" and out["config"]["ivps_per_gpu"] == 100000
+    assert out["gathers_verified"] == 4 and out["config"]["allgather_overlapped_with_next_solve"] is True
+    assert abs(out["value"] - 8 * 100000 * 32 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 1e-9
