@@ -174,6 +174,20 @@ int nnhip_ode_solve_batch_sweep_f64_dev(const nnhip_ode_options* opt, int integr
                                         int32_t* ny_out, int64_t* steps_out, int64_t* rejected_out, int64_t max_steps, void* ws,
                                         int64_t ws_bytes, void* stream);
 
+/* Divergence binning: the same fused solve for batches whose members take very different step sequences (the reference runs
+ * them one after the other, ode.nim:589-591; on a wavefront they share an instruction stream).  The IVPs are INTEGRATED in
+ * ascending order of `sort_key` (device array [N]) and every result is WRITTEN at the IVP's own index, so outputs are in the
+ * caller's order and bit-identical to nnhip_ode_solve_batch_sweep_f64_dev.  sort_key == NULL: automatic two-pass mode — a probe
+ * solve of `probe_steps` accepted steps per IVP (<= 0: 12) ranks the IVPs by the progress they make, then the batch is
+ * integrated in that order.  Fixed-step integrators run unsorted (no divergence).  per_ivp_params may be NULL (n_per_ivp = 0).
+ * `ws`: device workspace of nnhip_ode_solve_sorted_workspace_bytes(N, n_t) bytes.  N < 2^31. */
+int64_t nnhip_ode_solve_sorted_workspace_bytes(int64_t N, int n_t);
+int nnhip_ode_solve_batch_sorted_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
+                                         int n_params, const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t N,
+                                         int dim, int layout, const double* tspan, int n_t, double* t_out, double* y_out,
+                                         int32_t* ny_out, int64_t* steps_out, int64_t* rejected_out, int64_t max_steps,
+                                         const double* sort_key, int probe_steps, void* ws, int64_t ws_bytes, void* stream);
+
 /* ---- step-streaming: replaces one IntegratorProc call (ode.nim:38, call sites :531,:573) ------
  * (yNew, FSAL', dtUsed, error) = integrator(f, t, y, FSAL, dt, options, ctx) for every IVP of the batch,
  * state resident in HBM between calls.  t/dt are per-IVP device arrays [N], or — when t_dev / dt_dev is
@@ -200,8 +214,10 @@ int nnhip_ode_fixed_stream_f64_dev(const nnhip_ode_options* opt, int integrator,
  * `advance` kernel: per launch, every unfinished IVP does dt = min(dt, tEnd-t); step; t += dt; controller — with y, FSAL,
  * t, dt resident in HBM between launches (8*(4*dim+5) algorithmic bytes per attempted step).  y (device, in `layout`) is
  * advanced in place from t0 to tEnd; `ws` is device scratch of nnhip_ode_adaptive_stream_workspace_bytes(N, dim).  The host
- * polls the count of unfinished IVPs every `check_every` launches (<= 0: 8).  Results are bitwise those of the fused solve.
- * Thread-per-IVP kernels (dim <= 4 built-in RHS). */
+ * learns whether anyone is still integrating every `check_every` launches (<= 0: 8) and always has the next group enqueued
+ * before it waits (groups are replayed from a hipGraph on a non-default stream), so up to 2*check_every trailing launches
+ * find nothing to do (they read t only).  Results are bitwise those of the fused solve.  Thread-per-IVP kernels for small
+ * systems, lanes-per-system kernels for Vector[float] states of 8 / 16 / 32 ... components (ahead of time or run-time compiled). */
 int64_t nnhip_ode_adaptive_stream_workspace_bytes(int64_t N, int dim);
 int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
                                       int n_params, int64_t N, int dim, int layout, double t0, double tEnd, double* y, void* ws,

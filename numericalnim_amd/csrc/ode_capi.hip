@@ -259,6 +259,10 @@ int stage_reserve(size_t n) {
 }  // namespace
 
 namespace nnhip {
+// ode_sort.hip
+int64_t argsort_workspace_bytes(int64_t N);
+hipError_t argsort_f64(const double* keys, int64_t N, uint32_t* perm_out, void* ws, int64_t ws_bytes, hipStream_t s);
+hipError_t negate_f64(const double* in, double* out, int64_t N, hipStream_t s);
 void multigpu_release();  // ode_multigpu.hip
 int solve_host_range(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
                      const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t NFull, int64_t lo0, int64_t N, int dim,
@@ -510,7 +514,7 @@ static int prepare_solve(const nnhip_ode_options* opt, int integrator, int rhs_k
   a.maxSteps = max_steps;
   a.ctl = ctl_of(opt);
   a.P = P;
-  if (n_per_ivp < 0 || n_per_ivp > nnhip::kMaxParams || (n_per_ivp > 0 && !per_ivp_params)) return fail(NNHIP_EVALUE, "bad per-IVP parameter table");
+  if (n_per_ivp < 0 || n_per_ivp > nnhip::kMaxParams || (n_per_ivp > 0 && !per_ivp_params && N > 0)) return fail(NNHIP_EVALUE, "bad per-IVP parameter table");
   a.perIvpParams = n_per_ivp > 0 ? per_ivp_params : nullptr;
   a.nPerIvp = n_per_ivp;
   a.perIvpStride = N;
@@ -562,12 +566,17 @@ static int prepare_solve(const nnhip_ode_options* opt, int integrator, int rhs_k
 static int launch_solve_range(const PreparedSolve& ps, int64_t lo, int64_t n, hipStream_t stream) {
   if (n <= 0) return NNHIP_OK;
   nnhip::SolveArgs a = ps.a;
-  a.y0 += lo * a.ivpStride;
-  a.y_out += lo * a.ivpStride;
-  if (a.ny_out) a.ny_out += lo;
-  if (a.steps_out) a.steps_out += lo;
-  if (a.rejected_out) a.rejected_out += lo;
-  if (a.perIvpParams) a.perIvpParams += lo;
+  if (a.perm) {  // work items [lo, lo + n) of the integration order; every array keeps its full-batch addressing
+    a.perm += lo;
+  } else {
+    a.y0 += lo * a.ivpStride;
+    a.y_out += lo * a.ivpStride;
+    if (a.ny_out) a.ny_out += lo;
+    if (a.steps_out) a.steps_out += lo;
+    if (a.rejected_out) a.rejected_out += lo;
+    if (a.progress_out) a.progress_out += lo;
+    if (a.perIvpParams) a.perIvpParams += lo;
+  }
   a.N = n;
   if (ps.user) {
     if (nnhip::rtc_launch_solve(ps.rhs_kind, ps.integrator, a, stream) != hipSuccess)
@@ -599,6 +608,60 @@ int nnhip_ode_solve_batch_sweep_f64_dev(const nnhip_ode_options* opt, int integr
                          y_out, ny_out, steps_out, rejected_out, max_steps, ws, ws_bytes, nullptr, nullptr, (hipStream_t)stream, ps);
   if (rc) return rc;
   return launch_solve_range(ps, 0, N, (hipStream_t)stream);
+}
+
+// ---- divergence binning below the boundary -----------------------------------------------------------------------
+// Workspace of nnhip_ode_solve_batch_sorted_f64_dev: requested times + order of integration (4N) + probe progress / key (8N)
+// + the device sort's scratch.
+int64_t nnhip_ode_solve_sorted_workspace_bytes(int64_t N, int n_t) {
+  if (N < 0) return 0;
+  return ((nnhip_ode_solve_workspace_bytes(n_t) + 255) & ~(int64_t)255) + (((int64_t)N * 4 + 255) & ~(int64_t)255) + (((int64_t)N * 8 + 255) & ~(int64_t)255) +
+         nnhip::argsort_workspace_bytes(N) + 256;
+}
+
+// solveODE over a batch whose members take very different step sequences (heterogeneous parameters / initial states): the
+// IVPs are integrated in ascending order of `sort_key` — neighbouring lanes of a wavefront then agree on accept / reject and
+// finish together — and every result is written at the IVP's own index (SolveArgs::perm), so the output is in the caller's
+// order and bit-identical to the unsorted solve.  sort_key == NULL selects the automatic two-pass mode: a probe solve of
+// `probe_steps` accepted steps per IVP (default 12) measures how far each IVP gets, which ranks the step sizes the controller
+// settles on; the batch is then integrated in that order.  Fixed-step methods have no divergence: they run unsorted.
+int nnhip_ode_solve_batch_sorted_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
+                                         const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t N, int dim, int layout,
+                                         const double* tspan, int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
+                                         int64_t* rejected_out, int64_t max_steps, const double* sort_key, int probe_steps, void* ws,
+                                         int64_t ws_bytes, void* stream) {
+  if (N < 0 || N >= ((int64_t)1 << 31)) return fail(NNHIP_EVALUE, "N must be in [0, 2^31)");
+  if (integrator < 0 || integrator >= NNHIP_N_INTEGRATORS) return fail(NNHIP_EINTEGRATOR, "%d is not a valid integrator", integrator);
+  if (N > 0 && (!ws || ws_bytes < nnhip_ode_solve_sorted_workspace_bytes(N, n_t))) return fail(NNHIP_EVALUE, "workspace missing or too small: need %lld bytes", (long long)nnhip_ode_solve_sorted_workspace_bytes(N, n_t));
+  hipStream_t s = (hipStream_t)stream;
+  char* base = (char*)ws;
+  const int64_t wsTimes = (nnhip_ode_solve_workspace_bytes(n_t) + 255) & ~(int64_t)255;
+  uint32_t* perm = (uint32_t*)(base + wsTimes);
+  double* key = (double*)(base + wsTimes + (((int64_t)N * 4 + 255) & ~(int64_t)255));
+  void* sortWs = (char*)key + (((int64_t)N * 8 + 255) & ~(int64_t)255);
+  const int64_t sortWsBytes = ws_bytes - (int64_t)((char*)sortWs - base);
+  const bool adaptive = kMethods[integrator].adaptive != 0;
+  PreparedSolve ps;
+  if (adaptive && N > 1) {
+    if (!sort_key) {  // pass 1: the probe.  Same solve, cut off after probe_steps accepted steps; only the progress is kept.
+      if (probe_steps <= 0) probe_steps = 12;
+      if (max_steps > 0 && probe_steps > max_steps) probe_steps = (int)max_steps;
+      int rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y0, N, dim, layout, tspan, n_t, nullptr, y_out,
+                             nullptr, nullptr, nullptr, probe_steps, ws, wsTimes, nullptr, nullptr, s, ps);
+      if (rc) return rc;
+      ps.a.progress_out = key;
+      rc = launch_solve_range(ps, 0, N, s);
+      if (rc) return rc;
+      HIP_TRY(nnhip::negate_f64(key, key, N, s));  // furthest first; the order among equal keys is the caller's (stable sort)
+      sort_key = key;
+    }
+    HIP_TRY(nnhip::argsort_f64(sort_key, N, perm, sortWs, sortWsBytes, s));
+  }
+  int rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y0, N, dim, layout, tspan, n_t, t_out, y_out, ny_out,
+                         steps_out, rejected_out, max_steps, ws, wsTimes, nullptr, nullptr, s, ps);
+  if (rc) return rc;
+  if (adaptive && N > 1) ps.a.perm = perm;
+  return launch_solve_range(ps, 0, N, s);
 }
 
 int nnhip_ode_solve_batch_f64(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
@@ -638,7 +701,7 @@ int solve_host_range(const nnhip_ode_options* opt, int integrator, int rhs_kind,
                      int layout, const double* tspan, int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
                      int64_t* rejected_out, int64_t max_steps, nnhip_ode_stats* stats, int device) {
   if (N < 0 || NFull < N || lo0 < 0 || lo0 + N > NFull || dim < 1 || n_t < 0) return fail(NNHIP_EVALUE, "bad sizes");
-  if (n_per_ivp < 0 || n_per_ivp > nnhip::kMaxParams || (n_per_ivp > 0 && !per_ivp_params)) return fail(NNHIP_EVALUE, "bad per-IVP parameter table");
+  if (n_per_ivp < 0 || n_per_ivp > nnhip::kMaxParams || (n_per_ivp > 0 && !per_ivp_params && N > 0)) return fail(NNHIP_EVALUE, "bad per-IVP parameter table");
   if (!opt || (n_t > 0 && !tspan)) return fail(NNHIP_EVALUE, "options / tspan is NULL");
   for (int j = 0; j < n_t; ++j) if (!std::isfinite(tspan[j])) return fail(NNHIP_EVALUE, "tspan[%d] is not finite", j);
   if (!std::isfinite(opt->tStart)) return fail(NNHIP_EVALUE, "options.tStart is not finite");

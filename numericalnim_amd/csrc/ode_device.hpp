@@ -770,6 +770,7 @@ struct DriveOut {
   int emitted;
   int status;
   int64_t steps, rejected;
+  double tFinal;  // loop variable t when the direction ended (= tEnd unless truncated by maxSteps / aborted)
 };
 
 // DENSE = false is the lean instantiation for tspan.len == 2 (in.useDense must be 0): the Hermite history lastIter = (t, y, dy)
@@ -822,6 +823,7 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
       out.status = (in.maxSteps > 0 && in.uniformFull + in.nTail >= in.maxSteps && t < in.tEnd) ? 2 : 0;
       out.steps = in.uniformFull + in.nTail;
       out.rejected = 0;
+      out.tFinal = t;
       return;
     }
   }
@@ -891,6 +893,7 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
   out.status = status;
   out.steps = steps;
   out.rejected = rejected;
+  out.tFinal = t;
 }
 
 }  // namespace NNHIP_NS

@@ -52,6 +52,12 @@ struct SolveArgs {
   int64_t uniformFull[2];
   int nTail[2];
   double tailDt[2][4];
+  // Order of integration (divergence binning): nullable device array [N]; work item k integrates IVP perm[k].  Every per-IVP
+  // array (y0, y_out, counters, per-IVP parameters) is still addressed by the IVP's own index, so results land in the caller's
+  // order without an un-permute pass; neighbouring lanes then hold IVPs with similar step sequences.
+  const uint32_t* perm;
+  // nullable [N]: how far the IVP got, |t - t0| summed over the directions integrated (= the full span unless max_steps cut it short)
+  double* progress_out;
 };
 
 struct StepArgs {
@@ -135,6 +141,7 @@ NNHIP_DEV Params params_of(const Args& a, int64_t i) {
 struct LaneStats {
   unsigned long long steps = 0, rejected = 0;
   int ny = 0x7fffffff, nanAb = 0, trunc = 0;
+  double progress = 0.0;
 };
 
 template <int METHOD, bool DENSE = true, class OpsF, class OpsB>
@@ -186,6 +193,7 @@ NNHIP_DEV void solve_body(const SolveArgs& a, const OpsF& opsF, const OpsB& opsB
     status |= o.status;
     ls.steps += o.steps;
     ls.rejected += o.rejected;
+    ls.progress += o.tFinal - in.tStartEff;
   }
   if (a.nZero > 0) {  // `if t0 in tspan` (ode.nim:485-487)
 #pragma unroll
@@ -218,6 +226,7 @@ NNHIP_DEV void solve_body(const SolveArgs& a, const OpsF& opsF, const OpsB& opsB
     status |= o.status;
     ls.steps += o.steps;
     ls.rejected += o.rejected;
+    ls.progress += o.tFinal - in.tStartEff;
   }
   const double qnan = __longlong_as_double(0x7ff8000000000000LL);
   for (int j = rowBase; j < a.n_t; ++j)
@@ -274,9 +283,10 @@ NNHIP_DEV void aggregate_stats(unsigned long long* aggBase, LaneStats ls) {
 template <int METHOD, class RHS, bool DENSE = true>
 __global__ __launch_bounds__(kBlock) void solve_tpi_kernel(const SolveArgs a) {
   controller_prologue<MethodTraits<METHOD>::adaptive>();
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   LaneStats ls;
-  if (i < a.N) {
+  if (k < a.N) {
+    const int64_t i = a.perm ? (int64_t)a.perm[k] : k;  // the IVP this work item integrates
     const Params P = params_of(a, i);
     const TpiOps<RHS, false> opsF{P};
     const TpiOps<RHS, true> opsB{P};
@@ -284,6 +294,7 @@ __global__ __launch_bounds__(kBlock) void solve_tpi_kernel(const SolveArgs a) {
     if (a.ny_out) a.ny_out[i] = ls.ny;
     if (a.steps_out) a.steps_out[i] = (int64_t)ls.steps;
     if (a.rejected_out) a.rejected_out[i] = (int64_t)ls.rejected;
+    if (a.progress_out) a.progress_out[i] = ls.progress;
   }
   if (a.agg) aggregate_stats(a.agg, ls);
 }
@@ -321,9 +332,10 @@ __global__ __launch_bounds__(kBlock) NNHIP_LPS_ATTR void solve_lps_kernel(const 
   __shared__ double lds[2 * kBlock * CPL];
   controller_prologue<MethodTraits<METHOD>::adaptive>();
   const int sysInBlock = threadIdx.x / LPSYS, c = (threadIdx.x % LPSYS) * CPL;
-  const int64_t i = (int64_t)blockIdx.x * (kBlock / LPSYS) + sysInBlock;
+  const int64_t k = (int64_t)blockIdx.x * (kBlock / LPSYS) + sysInBlock;
   LaneStats ls;
-  if (i < a.N) {
+  if (k < a.N) {
+    const int64_t i = a.perm ? (int64_t)a.perm[k] : k;  // the system this group of lanes integrates
     double* ys = lds + sysInBlock * DIM;
     double* es = lds + kBlock * CPL + sysInBlock * DIM;
     const Params P = params_of(a, i);
@@ -334,6 +346,7 @@ __global__ __launch_bounds__(kBlock) NNHIP_LPS_ATTR void solve_lps_kernel(const 
       if (a.ny_out) a.ny_out[i] = ls.ny;
       if (a.steps_out) a.steps_out[i] = (int64_t)ls.steps;
       if (a.rejected_out) a.rejected_out[i] = (int64_t)ls.rejected;
+      if (a.progress_out) a.progress_out[i] = ls.progress;
     } else {  // count each system once in the aggregate sums
       ls.steps = 0; ls.rejected = 0; ls.nanAb = 0; ls.trunc = 0;
     }

@@ -199,29 +199,14 @@ def solveODE(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=
     return_counts=True appends a dict(ny, steps, rejected) of per-IVP int arrays/tensors.
     sweep: optional CUDA tensor [k, N] of PER-IVP values for the first k RHS parameters (a parameter sweep: IVP i is
     integrated with parameters sweep[:, i], exactly as if it were its own solveODE call with its own ctx).
-    sort_by: optional CUDA tensor [N]; the batch is integrated in argsort(sort_by) order and the results are returned in
-    the caller's order.  Results are bit-identical; neighbouring lanes of a wavefront then take similar step sequences,
-    which removes most of the divergence of adaptive methods on heterogeneous batches (1.7x on a Van der Pol mu-sweep,
-    scripts/bench_divergence.py).
+    sort_by: optional CUDA float64 tensor [N], or the string "auto"; the batch is integrated in argsort(sort_by) order and
+    every result is written at the IVP's own index (nnhip_ode_solve_batch_sorted_f64_dev: the ordering lives below the C ABI).
+    Results are bit-identical; neighbouring lanes of a wavefront then take similar step sequences, which removes most of the
+    divergence of adaptive methods on heterogeneous batches (1.7x on a Van der Pol mu-sweep, scripts/bench_divergence.py).
+    "auto" ranks the IVPs with a short probe solve instead of a user key.
     out: optional result array for numpy batches, float64 C-contiguous of shape [len(tspan), *y0.shape], returned as y.  Reusing
     it across calls avoids the first-touch page faults of a fresh 100+ MB array inside the device-to-host copy (2x on C2), and if
     both y0 and out are page-locked the transfers are overlapped with the kernel (another 1.6x)."""
-    if sort_by is not None:
-        import torch
-        if not _is_torch(y0):
-            raise ValueError("sort_by needs a torch CUDA batch")
-        order = torch.argsort(sort_by)
-        inv = torch.empty_like(order)
-        inv[order] = torch.arange(order.numel(), device=order.device)
-        ax = 0 if (y0.dim() == 1 or layout == LAYOUT_AOS) else 1
-        if out is not None:
-            raise ValueError("out is for numpy batches")
-        res = solveODE(f, y0.index_select(ax, order), tspan, options, ctx, integrator, layout, max_steps, stats, return_counts,
-                       None if sweep is None else sweep.index_select(1, order), None)
-        t, y = res[0], res[1].index_select(ax + 1, inv)
-        if return_counts:
-            return t, y, {k: v.index_select(0, inv) for k, v in res[2].items()}
-        return t, y
     L = _lib.lib()
     options = options if options is not None else _default_options()
     ctx = ctx if ctx is not None else NumContext()  # ode.nim:604-606
@@ -252,10 +237,28 @@ def solveODE(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=
             wsb = int(L.nnhip_ode_solve_workspace_bytes(n_t))
             ws = torch.empty(wsb, dtype=torch.uint8, device=y0c.device)
             stream = torch.cuda.current_stream().cuda_stream
+            sw = None
             if sweep is not None:
                 sw = sweep.contiguous()
                 if sw.dim() != 2 or sw.shape[1] != N or sw.dtype != torch.float64 or not sw.is_cuda:
                     raise ValueError("sweep must be a CUDA float64 tensor of shape [k, N]")
+            if sort_by is not None:
+                auto = isinstance(sort_by, str)
+                if auto and sort_by != "auto":
+                    raise ValueError('sort_by must be a CUDA float64 tensor of shape [N] or "auto"')
+                key = None
+                if not auto:
+                    key = sort_by.contiguous()
+                    if key.dim() != 1 or key.shape[0] != N or key.dtype != torch.float64 or not key.is_cuda:
+                        raise ValueError("sort_by must be a CUDA float64 tensor of shape [N]")
+                wsb = int(L.nnhip_ode_solve_sorted_workspace_bytes(N, n_t))
+                ws = torch.empty(wsb, dtype=torch.uint8, device=y0c.device)
+                _check(L.nnhip_ode_solve_batch_sorted_f64_dev(C.byref(options), integ, f.kind, pp, int(p.size), sw.data_ptr() if sw is not None else None,
+                                                              int(sw.shape[0]) if sw is not None else 0, y0c.data_ptr(), N, dim, layout, tsp, n_t, tp,
+                                                              y.data_ptr(), ny.data_ptr() if return_counts else None,
+                                                              st.data_ptr() if return_counts else None, rj.data_ptr() if return_counts else None,
+                                                              int(max_steps), key.data_ptr() if key is not None else None, 0, ws.data_ptr(), wsb, stream))
+            elif sweep is not None:
                 _check(L.nnhip_ode_solve_batch_sweep_f64_dev(C.byref(options), integ, f.kind, pp, int(p.size), sw.data_ptr(), int(sw.shape[0]),
                                                              y0c.data_ptr(), N, dim, layout, tsp, n_t, tp, y.data_ptr(),
                                                              ny.data_ptr() if return_counts else None, st.data_ptr() if return_counts else None,
@@ -267,6 +270,8 @@ def solveODE(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=
                                                        rj.data_ptr() if return_counts else None, int(max_steps), ws.data_ptr(), wsb,
                                                        stream))
     else:
+        if sort_by is not None:
+            raise ValueError("sort_by needs a torch CUDA batch")
         y0c = np.ascontiguousarray(np.asarray(y0, dtype=np.float64))
         if out is not None:
             if not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.flags.c_contiguous and out.shape == (n_t,) + y0c.shape):

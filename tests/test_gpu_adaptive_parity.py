@@ -547,6 +547,34 @@ def test_sort_by_returns_identical_results_in_caller_order(nn, dev):
     y0a = y0.t().contiguous()
     c = nn.solveODE(nn.Rhs.vanderpol(), y0a, ts, opt, integrator="tsit54", sweep=mu[None, :], layout=1, sort_by=mu)
     assert torch.equal(c[1].permute(0, 2, 1), a[1])
+    # automatic two-pass mode (probe solve -> device argsort -> solve in that order), every adaptive integrator, with counters
+    for integ in ("dopri54", "vern65", "bs32", "rk21"):
+        a = nn.solveODE(nn.Rhs.vanderpol(), y0, ts, opt, integrator=integ, sweep=mu[None, :], return_counts=True)
+        d = nn.solveODE(nn.Rhs.vanderpol(), y0, ts, opt, integrator=integ, sweep=mu[None, :], return_counts=True, sort_by="auto")
+        assert torch.equal(a[1], d[1]) and all(torch.equal(a[2][k], d[2][k]) for k in a[2]), integ
+    # max_steps smaller than the probe, a fixed-step method (runs unsorted), N = 1 and N = 0
+    e0 = nn.solveODE(nn.Rhs.vanderpol(), y0, ts, opt, integrator="tsit54", sweep=mu[None, :], max_steps=5, return_counts=True)
+    e1 = nn.solveODE(nn.Rhs.vanderpol(), y0, ts, opt, integrator="tsit54", sweep=mu[None, :], max_steps=5, return_counts=True, sort_by="auto")
+    assert torch.equal(e0[2]["steps"], e1[2]["steps"]) and bool((e1[2]["steps"] == 5).all())
+    assert torch.equal(torch.nan_to_num(e0[1], nan=-1.0), torch.nan_to_num(e1[1], nan=-1.0))
+    f0 = nn.solveODE(nn.Rhs.vanderpol(), y0, ts, nn.newODEoptions(dt=1e-2), integrator="rk4", sweep=mu[None, :])
+    f1 = nn.solveODE(nn.Rhs.vanderpol(), y0, ts, nn.newODEoptions(dt=1e-2), integrator="rk4", sweep=mu[None, :], sort_by=mu)
+    assert torch.equal(f0[1], f1[1])
+    for m in (1, 0):
+        g0 = nn.solveODE(nn.Rhs.vanderpol(), y0[:, :m].contiguous(), ts, opt, integrator="tsit54", sweep=mu[None, :m].contiguous())
+        g1 = nn.solveODE(nn.Rhs.vanderpol(), y0[:, :m].contiguous(), ts, opt, integrator="tsit54", sweep=mu[None, :m].contiguous(), sort_by="auto")
+        assert torch.equal(g0[1], g1[1])
+    # lanes-per-system kernels: 16-component ring systems with per-system coupling, sorted by the coupling and automatically
+    rngc = np.random.default_rng(4)
+    y16 = torch.from_numpy(_ring_y0(700)).to(dev)
+    csw = torch.from_numpy(rngc.uniform(-3.0, 3.0, 700)).to(dev)
+    kw = dict(absTol=1e-8, relTol=1e-8, dtMin=1e-8, dtMax=0.5)
+    h0 = nn.solveODE(nn.Rhs.ring(0.1), y16, [0.0, 0.4, 1.0], nn.newODEoptions(**kw), integrator="tsit54", layout=1, sweep=csw[None, :], return_counts=True)
+    for key in (csw.abs(), "auto"):
+        h1 = nn.solveODE(nn.Rhs.ring(0.1), y16, [0.0, 0.4, 1.0], nn.newODEoptions(**kw), integrator="tsit54", layout=1, sweep=csw[None, :], return_counts=True,
+                         sort_by=key)
+        assert torch.equal(h0[1], h1[1]) and all(torch.equal(h0[2][k], h1[2][k]) for k in h0[2])
+    assert int(h0[2]["steps"].max()) > 2 * int(h0[2]["steps"].min())   # the batch really is heterogeneous
 
 
 def test_parameter_sweep_through_the_host_pointer_entry(nn, dev):
