@@ -210,6 +210,20 @@ int nnhip_ode_fixed_stream_f64_dev(const nnhip_ode_options* opt, int integrator,
                                    int n_params, int64_t N, int dim, int layout, double t0, double tEnd, double* y,
                                    double* scratch, int64_t* n_steps_out, double** y_final, void* stream);
 
+/* The WHOLE of ODESolver (ode.nim:471-586) for fixed-step integrators through the IntegratorProc seam: both directions around
+ * options.tStart, any tspan, requested-time rows by Hermite interpolation between consecutive steps (ode.nim:512-524), output
+ * assembly yNegative.reversed ++ yZero ++ yPositive (:585).  The state stays in HBM between IntegratorProc calls (one
+ * step-streaming launch per time step); when requested times fall into the step just taken, f(lastT, lastY), f(t, y) and one
+ * Hermite kernel per requested time are launched — the two ping-pong buffers are (lastIter.y, y).  y0 / y_out [n_t][dim][N] (SoA)
+ * or [n_t][N][dim] (AoS) are device pointers, tspan / t_out host.  (t, dt) are shared by the batch, so the number of rows the
+ * reference would return is the same for every IVP: *ny_out (host, nullable); rows beyond it are NaN.  `ws`: device scratch of
+ * nnhip_ode_fixed_stream_dense_workspace_bytes(N, dim).  Bitwise equal to nnhip_ode_solve_batch_f64_dev. */
+int64_t nnhip_ode_fixed_stream_dense_workspace_bytes(int64_t N, int dim);
+int nnhip_ode_fixed_stream_dense_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
+                                         int n_params, const double* y0, int64_t N, int dim, int layout, const double* tspan, int n_t,
+                                         double* t_out, double* y_out, int* ny_out, int64_t max_steps, void* ws, int64_t ws_bytes,
+                                         int64_t* n_steps_out, void* stream);
+
 /* Adaptive time loop of ODESolver (ode.nim:506-542 with adaptive=true, tspan.len == 2) driven from the host over an
  * `advance` kernel: per launch, every unfinished IVP does dt = min(dt, tEnd-t); step; t += dt; controller — with y, FSAL,
  * t, dt resident in HBM between launches (8*(4*dim+5) algorithmic bytes per attempted step).  y (device, in `layout`) is

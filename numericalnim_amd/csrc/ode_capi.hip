@@ -259,6 +259,10 @@ int stage_reserve(size_t n) {
 }  // namespace
 
 namespace nnhip {
+// ode_capi_aux.hip
+hipError_t launch_hermite(double x, double x1, double x2, const double* y1, const double* y2, const double* dy1, const double* dy2, double* out, int64_t n,
+                          int negate_dy, hipStream_t s);
+hipError_t launch_fill_f64(double* p, int64_t n, double v, hipStream_t s);
 // ode_sort.hip
 int64_t argsort_workspace_bytes(int64_t N);
 hipError_t argsort_f64(const double* keys, int64_t N, uint32_t* perm_out, void* ws, int64_t ws_bytes, hipStream_t s);
@@ -480,7 +484,7 @@ static int prepare_solve(const nnhip_ode_options* opt, int integrator, int rhs_k
   // tspan.sorted()).  On a GPU that is a hung device, so they are refused (deviation).
   for (int j = 0; j < n_t; ++j) if (!std::isfinite(tspan[j])) return fail(NNHIP_EVALUE, "tspan[%d] is not finite", j);
   if (!std::isfinite(opt->tStart)) return fail(NNHIP_EVALUE, "options.tStart is not finite");
-  if (N > 0 && (!y0 || !y_out)) return fail(NNHIP_EVALUE, "y0 / y_out is NULL");
+  if (N > 0 && (!y0 || (!y_out && n_t > 0))) return fail(NNHIP_EVALUE, "y0 / y_out is NULL");
   if (!kMethods[integrator].implemented) return fail(NNHIP_EUNSUPPORTED, "integrator %s has no HIP kernel yet", kMethods[integrator].name);
   ps.user = rhs_kind >= NNHIP_RHS_USER_BASE;
   ps.integrator = integrator;
@@ -1013,6 +1017,118 @@ int nnhip_ode_fixed_stream_f64_dev(const nnhip_ode_options* opt, int integrator,
   }
   if (n_steps_out) *n_steps_out = n;
   if (y_final) *y_final = cur;
+  return NNHIP_OK;
+}
+
+// ---- ODESolver through the IntegratorProc seam, fixed-step methods, WITH dense output -----------------------------------------
+// The reference's whole driver (ode.nim:471-586: both directions, requested-time rows by Hermite interpolation :512-524, output
+// assembly :585) over the step-streaming kernels: the state lives in HBM between IntegratorProc calls, (t, dt) are shared by the
+// batch — so the host replays the time loop and, whenever requested times fall into the step just taken, launches f(lastT, lastY),
+// f(t, y) and one Hermite kernel per requested time.  The two state buffers of the ping-pong ARE (lastIter.y, y).  Bitwise equal
+// to the fused solve, rows, NaN fill and the reference's dropped-rows quirk included (they are uniform over the batch here).
+int64_t nnhip_ode_fixed_stream_dense_workspace_bytes(int64_t N, int dim) {
+  if (N < 0 || dim < 1) return 0;
+  return 4 * N * dim * (int64_t)sizeof(double);  // ping, pong, f(lastT, lastY), f(t, y)
+}
+
+int nnhip_ode_fixed_stream_dense_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
+                                         const double* y0, int64_t N, int dim, int layout, const double* tspan, int n_t, double* t_out,
+                                         double* y_out, int* ny_out, int64_t max_steps, void* ws, int64_t ws_bytes, int64_t* n_steps_out,
+                                         void* stream) {
+  nnhip::Params P;
+  int rc = check_common(opt, integrator, rhs_kind, rhs_params, n_params, N, dim, layout, P);
+  if (rc) return rc;
+  if (kMethods[integrator].adaptive) return fail(NNHIP_EVALUE, "nnhip_ode_fixed_stream_dense_f64_dev needs a fixed-step integrator");
+  if (!(opt->dt > 0.0)) return fail(NNHIP_EVALUE, "fixed-step integrators need options.dt > 0 (the reference would loop forever)");
+  if (n_t < 0 || (n_t > 0 && !tspan)) return fail(NNHIP_EVALUE, "bad tspan");
+  for (int j = 0; j < n_t; ++j) if (!std::isfinite(tspan[j])) return fail(NNHIP_EVALUE, "tspan[%d] is not finite", j);
+  if (!std::isfinite(opt->tStart)) return fail(NNHIP_EVALUE, "options.tStart is not finite");
+  if (N > 0 && (!y0 || (!y_out && n_t > 0) || !ws || ws_bytes < nnhip_ode_fixed_stream_dense_workspace_bytes(N, dim))) return fail(NNHIP_EVALUE, "y0 / y_out / workspace missing or too small");
+  TimeGrid g;
+  make_grid(opt, tspan, n_t, g);
+  if (t_out) std::copy(g.tOut.begin(), g.tOut.end(), t_out);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t nState = N * dim;
+  double* bufA = (double*)ws;
+  double* bufB = bufA + nState;
+  double* d1 = bufB + nState;
+  double* d2 = d1 + nState;
+  const bool useDense = n_t != 2;  // ode.nim:499-502
+  int64_t stepsTotal = 0;
+  bool truncated = false;
+  auto row = [&](int j) { return y_out + (int64_t)j * nState; };
+  // one direction of ODESolver's loop; returns the number of rows it produced (<= nReq), rows go to row(rowOf(k))
+  auto run_dir = [&](bool neg, double tStartEff, double tEnd, const std::vector<double>& req, auto rowOf, int& produced) -> int {
+    const int nReq = (int)req.size(), high = nReq - 1;
+    double* cur = bufA;
+    double* nxt = bufB;
+    const double* lastBuf = nullptr;
+    if (nState) HIP_TRY(hipMemcpyAsync(cur, y0, (size_t)nState * 8, hipMemcpyDeviceToDevice, s));  // y = y0.clone() (:482)
+    double t = tStartEff, dt = opt->dt, lastT = tStartEff;
+    int denseIndex = 0;
+    int64_t steps = 0;
+    while (t < tEnd) {  // :511
+      if (useDense) {
+        if (high < denseIndex) break;  // :513-514
+        double treq = neg ? -req[denseIndex] : req[denseIndex];
+        if (treq <= t) {
+          const double* lb = lastBuf ? lastBuf : cur;
+          // lastIter.dy = f(lastT, lastY) (:530) and f(t, y) (:521); for the backward branch the kernels negate them (g = -f(-t, y))
+          int r2 = nnhip_ode_rhs_batch_f64_dev(rhs_kind, rhs_params, n_params, N, dim, layout, neg ? -lastT : lastT, lb, d1, stream);
+          if (!r2) r2 = nnhip_ode_rhs_batch_f64_dev(rhs_kind, rhs_params, n_params, N, dim, layout, neg ? -t : t, cur, d2, stream);
+          if (r2) return r2;
+          while (treq <= t) {  // :515
+            HIP_TRY(nnhip::launch_hermite(treq, lastT, t, lb, cur, d1, d2, row(rowOf(denseIndex)), nState, neg ? 1 : 0, s));
+            denseIndex += 1;
+            if (high < denseIndex) break;  // :523-524
+            treq = neg ? -req[denseIndex] : req[denseIndex];
+          }
+        }
+      }
+      dt = nmin_h(dt, tEnd - t);  // :525
+      const int r3 = nnhip_ode_step_batch_f64_dev(opt, integrator, rhs_kind, rhs_params, n_params, N, dim, layout, nullptr, t, nullptr, dt, cur, nullptr,
+                                                  nxt, nullptr, nullptr, nullptr, neg ? 1 : 0, stream);  // :531
+      if (r3) return r3;
+      lastT = t;       // lastIter = (t, y, ...) (:526-530)
+      lastBuf = cur;
+      std::swap(cur, nxt);
+      t += dt;  // :532
+      ++steps;
+      if (max_steps > 0 && steps >= max_steps) { truncated = truncated || t < tEnd; break; }
+    }
+    // yPositive.add(y) / yNegative.add(y) (:542, :584): appended after whatever was emitted
+    if (denseIndex < nReq && nState) HIP_TRY(hipMemcpyAsync(row(rowOf(denseIndex)), cur, (size_t)nState * 8, hipMemcpyDeviceToDevice, s));
+    produced = denseIndex + 1 < nReq ? denseIndex + 1 : nReq;
+    stepsTotal += steps;
+    return NNHIP_OK;
+  };
+  int rowBase = 0;
+  if (!g.tNeg.empty()) {  // backward branch (:544-584): element k of yNegative lands in row nNeg-1-k (yNegative.reversed, :585)
+    const int nNeg = (int)g.tNeg.size();
+    int m = 0;
+    rc = run_dir(true, -opt->tStart, g.tEndNeg, g.tNeg, [&](int k) { return nNeg - 1 - k; }, m);
+    if (rc) return rc;
+    if (m < nNeg && nState) {  // reference quirk: fewer rows than requested -> they close up
+      const int shift = nNeg - m;
+      for (int j = 0; j < m; ++j) HIP_TRY(hipMemcpyAsync(row(j), row(j + shift), (size_t)nState * 8, hipMemcpyDeviceToDevice, s));
+    }
+    rowBase = m;
+  }
+  if (g.nZero) {  // `if t0 in tspan` (:485-487)
+    if (nState) HIP_TRY(hipMemcpyAsync(row(rowBase), y0, (size_t)nState * 8, hipMemcpyDeviceToDevice, s));
+    rowBase += 1;
+  }
+  if (!g.tPos.empty()) {
+    int m = 0;
+    const int rb = rowBase;
+    rc = run_dir(false, opt->tStart, g.tEndPos, g.tPos, [&](int k) { return rb + k; }, m);
+    if (rc) return rc;
+    rowBase += m;
+  }
+  if (rowBase < n_t) HIP_TRY(nnhip::launch_fill_f64(row(rowBase), (int64_t)(n_t - rowBase) * nState, std::nan(""), s));
+  if (ny_out) *ny_out = rowBase;
+  if (n_steps_out) *n_steps_out = stepsTotal;
+  (void)truncated;
   return NNHIP_OK;
 }
 

@@ -32,13 +32,28 @@ hipError_t launch_rhs_batch(int64_t N, int64_t is, int64_t cs, double t, const d
 }
 
 // hermiteSpline (utils.nim:273-279) over a flat batch
+// negate_dy: the slopes are those of g(t, y) = -f(-t, y) (backward branch, ode.nim:545) while dy1 / dy2 hold f: use their negatives
 __global__ __launch_bounds__(kBlock) void hermite_kernel(double x, double x1, double x2, const double* __restrict__ y1,
                                                          const double* __restrict__ y2, const double* __restrict__ dy1,
-                                                         const double* __restrict__ dy2, double* __restrict__ out, int64_t n) {
+                                                         const double* __restrict__ dy2, double* __restrict__ out, int64_t n, int negate_dy) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const HermiteW w = hermite_weights(x, x1, x2);
-  out[i] = hermite_apply(w, y1[i], y2[i], dy1[i], dy2[i]);
+  const double d1 = negate_dy ? -dy1[i] : dy1[i], d2 = negate_dy ? -dy2[i] : dy2[i];
+  out[i] = hermite_apply(w, y1[i], y2[i], d1, d2);
+}
+__global__ __launch_bounds__(kBlock) void fill_f64_kernel(double* __restrict__ p, int64_t n, double v) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+hipError_t launch_hermite(double x, double x1, double x2, const double* y1, const double* y2, const double* dy1, const double* dy2, double* out, int64_t n,
+                          int negate_dy, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  return launch_kernel(hermite_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), s, x, x1, x2, y1, y2, dy1, dy2, out, n, negate_dy);
+}
+hipError_t launch_fill_f64(double* p, int64_t n, double v, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  return launch_kernel(fill_f64_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), s, p, n, v);
 }
 
 // newHermiteSpline(X, Y, dY).eval / .derivEval over M independent series (interpolate.nim:186-217, 299-390).
@@ -172,9 +187,8 @@ int nnhip_hermite_spline_f64_dev(double x, double x1, double x2, const double* y
                                  const double* dy2, double* out, int64_t n, void* stream) {
   if (n < 0 || (n > 0 && (!y1 || !y2 || !dy1 || !dy2 || !out))) return nnhip::fail_msg(NNHIP_EVALUE, "hermite_spline: n < 0 or a NULL array");
   if (n == 0) return NNHIP_OK;
-  const int64_t grid = (n + nnhip::kBlock - 1) / nnhip::kBlock;
-  return nnhip::launch_kernel(nnhip::hermite_kernel, dim3((unsigned)grid), dim3(nnhip::kBlock), (hipStream_t)stream, x, x1, x2, y1,
-                              y2, dy1, dy2, out, n) == hipSuccess ? NNHIP_OK : nnhip::fail_msg(NNHIP_EHIP, "hermite_spline: kernel launch failed");
+  return nnhip::launch_hermite(x, x1, x2, y1, y2, dy1, dy2, out, n, 0, (hipStream_t)stream) == hipSuccess
+             ? NNHIP_OK : nnhip::fail_msg(NNHIP_EHIP, "hermite_spline: kernel launch failed");
 }
 
 static nnhip::HermSet herm_set(const double* X, int n, double x, bool deriv) {

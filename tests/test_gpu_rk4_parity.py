@@ -254,3 +254,36 @@ def test_fixed_step_vectorised_streaming_kernel(nn, oracle, dev, integrator, ipl
                         assert np.array_equal(got[i], np.atleast_1d(ryn)), (integrator, dim, i)
     finally:
         L.nnhip_tune_set(b"fixed_vec_ipl", 2)
+
+
+@pytest.mark.parametrize("integrator", ["rk4", "heun2", "kutta3", "ssprk3", "ralston4"])
+def test_fixed_step_dense_output_through_the_step_streaming_seam(nn, oracle, dev, integrator):
+    """nnhip_ode_fixed_stream_dense_f64_dev: the whole ODESolver driver (ode.nim:471-586) over one IntegratorProc launch per time
+    step — the reference's own harness (tests/test_ode.nim:15: linspace(-10, 10, 100), both directions, dense Hermite rows) and
+    the awkward grids (tStart inside / outside / duplicated, unsorted, single point, rows the reference drops) — bitwise equal to
+    the fused solve and to the oracle, for scalar, small-vector, lanes-per-system and run-time compiled right-hand sides."""
+    import torch
+    O = oracle
+    rng = np.random.default_rng(33)
+    ts_h = O.linspace(-10.0, 10.0, 100)
+    y0s = torch.from_numpy(1.0 + np.arange(50) * 2.0 ** -7).to(dev)
+    t, y, ny, ns = nn.fixedStreamSolve(nn.Rhs.linear(-0.1), y0s, ts_h, nn.newODEoptions(dt=2.0 ** -6), integrator=integrator)
+    tf, yf, cf = nn.solveODE(nn.Rhs.linear(-0.1), y0s, ts_h, nn.newODEoptions(dt=2.0 ** -6), integrator=integrator, return_counts=True)
+    assert np.array_equal(t, ts_h) and np.array_equal(t, tf) and torch.equal(y, yf) and ny == 100
+    assert ns == int(cf["steps"][0])
+    rt, ry, st = O.solve_ode(O.RHS_LINEAR, [-0.1], float(y0s[3]), ts_h, O.new_options(dt=2.0 ** -6), integrator)
+    assert np.array_equal(y[:, 3].cpu().numpy(), np.asarray(ry))
+    cases = [(nn.Rhs.lorenz(), 3, 0), (nn.Rhs.lorenz(), 3, 1), (nn.Rhs.ring(0.1), 16, 1), (nn.Rhs.ring(0.1), 6, 0), (nn.Rhs.neg_y(), 1, 0)]
+    grids = [[1.0, -1.0, 0.0], [0.0, 0.0, 1.0], [-2.0, -1.0], [2.0], [0.5, 0.25, 0.75, 1.0], [0.3, 0.301, 0.302, 0.9], [-0.5, -0.501, -0.2, 0.7, 0.701], []]
+    for f, dim, layout in cases:
+        n = 77
+        y0 = rng.uniform(0.5, 1.5, (n, dim)) + (np.array([0.0, 0.0, 20.0]) if dim == 3 else 0.0)
+        y0l = torch.from_numpy(np.ascontiguousarray(y0 if layout == 1 else y0.T) if dim > 1 else y0[:, 0].copy()).to(dev)
+        for ts in grids:
+            for tstart in (0.0, 0.25):
+                opt = nn.newODEoptions(dt=0.0625 if len(ts) != 4 else 0.01, tStart=tstart)   # dt > spacing: the reference drops rows
+                t, y, ny, ns = nn.fixedStreamSolve(f, y0l, ts, opt, integrator=integrator, layout=layout)
+                tf, yf, cf = nn.solveODE(f, y0l, ts, opt, integrator=integrator, layout=layout, return_counts=True)
+                assert np.array_equal(t, tf), (dim, ts)
+                assert torch.equal(torch.nan_to_num(y, nan=-7.0), torch.nan_to_num(yf, nan=-7.0)), (dim, layout, ts, tstart)
+                assert bool((cf["ny"] == ny).all()) and bool((cf["steps"] == ns).all()), (dim, ts, tstart)
