@@ -224,6 +224,19 @@ int nnhip_ode_fixed_stream_dense_f64_dev(const nnhip_ode_options* opt, int integ
                                          double* t_out, double* y_out, int* ny_out, int64_t max_steps, void* ws, int64_t ws_bytes,
                                          int64_t* n_steps_out, void* stream);
 
+/* The WHOLE of ODESolver (ode.nim:471-586) for ADAPTIVE integrators through the IntegratorProc seam: per launch every unfinished
+ * IVP runs one loop iteration including the emission of the requested times its last step passed (Hermite interpolation from the
+ * per-IVP history lastIter = (t, y, dy), ode.nim:512-530); y, FSAL, t, dt, lastIter and denseIndex are resident in HBM between
+ * launches.  Both directions around options.tStart, any tspan, the reference's row assembly and quirks.  y0 / y_out / ny_out
+ * (int32 [N], required: rows the reference returns for IVP i; rows beyond are NaN) are device pointers, tspan / t_out host.
+ * Compiled-in thread-per-IVP right-hand sides.  `ws`: nnhip_ode_adaptive_stream_dense_workspace_bytes(N, dim, n_t) bytes.
+ * Bitwise equal to nnhip_ode_solve_batch_f64_dev. */
+int64_t nnhip_ode_adaptive_stream_dense_workspace_bytes(int64_t N, int dim, int n_t);
+int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
+                                            int n_params, const double* y0, int64_t N, int dim, int layout, const double* tspan, int n_t,
+                                            double* t_out, double* y_out, int32_t* ny_out, void* ws, int64_t ws_bytes, int check_every,
+                                            int64_t max_launches, int64_t* launches_out, void* stream);
+
 /* Adaptive time loop of ODESolver (ode.nim:506-542 with adaptive=true, tspan.len == 2) driven from the host over an
  * `advance` kernel: per launch, every unfinished IVP does dt = min(dt, tEnd-t); step; t += dt; controller — with y, FSAL,
  * t, dt resident in HBM between launches (8*(4*dim+5) algorithmic bytes per attempted step).  y (device, in `layout`) is

@@ -60,6 +60,9 @@ SIGNATURES = {
     "nnhip_ode_fixed_stream_dense_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int]),
     "nnhip_ode_fixed_stream_dense_f64_dev": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, _vp, C.c_int64, C.c_int, C.c_int, _dp, C.c_int,
                                                        _dp, _vp, C.POINTER(C.c_int), C.c_int64, _vp, C.c_int64, C.POINTER(C.c_int64), _vp]),
+    "nnhip_ode_adaptive_stream_dense_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
+    "nnhip_ode_adaptive_stream_dense_f64_dev": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, _vp, C.c_int64, C.c_int, C.c_int, _dp, C.c_int,
+                                                          _dp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int64, C.POINTER(C.c_int64), _vp]),
     "nnhip_ode_adaptive_stream_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int]),
     "nnhip_ode_adaptive_stream_f64_dev": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, C.c_int64, C.c_int, C.c_int,
                                                     C.c_double, C.c_double, _vp, _vp, C.c_int64, C.c_int, C.c_int64, C.POINTER(C.c_int64), _vp]),

@@ -118,6 +118,16 @@ nnhip::FixedVecLaunchFn find_fixed_vec(int integrator, int rhs_kind, int dim) {
   return nullptr;
 }
 
+nnhip::DenseAdvLaunch find_advance_dense(int integrator, int rhs_kind, int dim) {
+  switch (integrator) {
+#define X(id, name) \
+  case id: return nnhip::find_advance_dense_##name(rhs_kind, dim);
+    NNHIP_FOR_EACH_METHOD(X)
+#undef X
+  }
+  return nnhip::DenseAdvLaunch{nullptr, nullptr};
+}
+
 bool elementwise_rhs(int k) { return k == NNHIP_RHS_NEG_Y || k == NNHIP_RHS_LINEAR || k == NNHIP_RHS_AFFINE_T; }
 
 int check_common(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
@@ -1358,6 +1368,127 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
     }
     ++g;
   }
+  if (launches_out) *launches_out = launches;
+  return NNHIP_OK;
+}
+
+// ---- ODESolver through the IntegratorProc seam, adaptive methods, WITH dense output --------------------------------------------
+int64_t nnhip_ode_adaptive_stream_dense_workspace_bytes(int64_t N, int dim, int n_t) {
+  if (N < 0 || dim < 1) return 0;
+  const int64_t nt = n_t < 0 ? 0 : n_t;
+  // y, FSAL, lastIter.y, lastIter.dy [dim*N]; t, dt, error, lastIter.t [N]; denseIndex [N] (int32); flags; requested times
+  return (int64_t)sizeof(double) * (4 * N * dim + 4 * N + nt + 8) + (int64_t)sizeof(int32_t) * (N + 2) + (int64_t)sizeof(unsigned int) * nnhip::kAggSlots + 64;
+}
+
+// The whole ODESolver driver (ode.nim:471-586) for adaptive integrators over the HBM-resident `advance` kernel: both directions,
+// per-IVP (t, dt, FSAL), per-IVP Hermite history and denseIndex, requested rows emitted by the kernel as each IVP's steps pass them
+// (:512-524).  y0 / y_out / ny_out are device pointers, tspan / t_out host.  ny_out[i] (required, int32 [N]) = rows the
+// reference returns for IVP i; rows beyond are NaN.  Thread-per-IVP right-hand sides (compiled-in kinds, dim <= 4).  Bitwise equal to
+// nnhip_ode_solve_batch_f64_dev.
+int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
+                                            const double* y0, int64_t N, int dim, int layout, const double* tspan, int n_t, double* t_out,
+                                            double* y_out, int32_t* ny_out, void* ws, int64_t ws_bytes, int check_every, int64_t max_launches,
+                                            int64_t* launches_out, void* stream) {
+  nnhip::Params P;
+  int rc = check_common(opt, integrator, rhs_kind, rhs_params, n_params, N, dim, layout, P);
+  if (rc) return rc;
+  if (!kMethods[integrator].adaptive) return fail(NNHIP_EVALUE, "nnhip_ode_adaptive_stream_dense_f64_dev needs an adaptive integrator");
+  if (n_t < 0 || (n_t > 0 && !tspan)) return fail(NNHIP_EVALUE, "bad tspan");
+  for (int j = 0; j < n_t; ++j) if (!std::isfinite(tspan[j])) return fail(NNHIP_EVALUE, "tspan[%d] is not finite", j);
+  if (!std::isfinite(opt->tStart)) return fail(NNHIP_EVALUE, "options.tStart is not finite");
+  if (!(opt->dtMin > 0.0) && max_launches <= 0) return fail(NNHIP_EVALUE, "adaptive integrators need options.dtMin > 0 or max_launches > 0");
+  const nnhip::DenseAdvLaunch fn = rhs_kind < NNHIP_RHS_USER_BASE ? find_advance_dense(integrator, rhs_kind, dim) : nnhip::DenseAdvLaunch{nullptr, nullptr};
+  if (!fn.advance) return fail(NNHIP_EUNSUPPORTED, "no dense advance kernel for integrator=%s rhs_kind=%d dim=%d (compiled-in thread-per-IVP right-hand sides)", kMethods[integrator].name, rhs_kind, dim);
+  TimeGrid g;
+  make_grid(opt, tspan, n_t, g);
+  if (t_out) std::copy(g.tOut.begin(), g.tOut.end(), t_out);
+  if (launches_out) *launches_out = 0;
+  if (N == 0) return NNHIP_OK;
+  if (!y0 || (!y_out && n_t > 0) || !ny_out || !ws || ws_bytes < nnhip_ode_adaptive_stream_dense_workspace_bytes(N, dim, n_t))
+    return fail(NNHIP_EVALUE, "y0 / y_out / ny_out / workspace missing or too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t nState = N * dim;
+  double* yW = (double*)ws;
+  double* fsal = yW + nState;
+  double* lastY = fsal + nState;
+  double* lastDy = lastY + nState;
+  double* tArr = lastDy + nState;
+  double* dtArr = tArr + N;
+  double* errArr = dtArr + N;
+  double* lastT = errArr + N;
+  double* tReqDev = lastT + N;                       // n_t doubles (+ padding)
+  int32_t* denseIdx = (int32_t*)(tReqDev + n_t + 8);
+  unsigned int* active = (unsigned int*)(denseIdx + N + 2);
+  // requested times of both directions, as the reference holds them
+  const int nPos = (int)g.tPos.size(), nNeg = (int)g.tNeg.size();
+  if (nPos + nNeg > 0) {
+    rc = stage_reserve((size_t)(nPos + nNeg));
+    if (rc) return rc;
+    std::copy(g.tPos.begin(), g.tPos.end(), g_stage.host);
+    std::copy(g.tNeg.begin(), g.tNeg.end(), g_stage.host + nPos);
+    HIP_TRY(hipMemcpyAsync(tReqDev, g_stage.host, (size_t)(nPos + nNeg) * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(g_stage.ev, s));
+    g_stage.pending = true;
+  }
+  rc = adv_poll_reserve();
+  if (rc) return rc;
+  AdvPoll& poll = g_adv_poll;
+  nnhip::StepArgs a{};
+  a.N = N;
+  if (layout == NNHIP_LAYOUT_SOA) { a.ivpStride = 1; a.compStride = N; } else { a.ivpStride = dim; a.compStride = 1; }
+  a.y_in = yW; a.y_out = yW; a.fsal_in = fsal; a.fsal_out = fsal; a.error = errArr;
+  a.ctl = ctl_of(opt); a.P = P;
+  a.t_io = tArr; a.dt_io = dtArr;
+  a.denseIdx_io = denseIdx; a.lastT_io = lastT; a.lastY_io = lastY; a.lastDy_io = lastDy;
+  a.rows = y_out; a.rowStride = nState;
+  if (check_every <= 0) check_every = 8;
+  const double dtInit = std::sqrt(opt->dtMax * opt->dtMin);  // :491-493
+  const dim3 grid((unsigned)((N + nnhip::kBlock - 1) / nnhip::kBlock)), block(nnhip::kBlock);
+  int64_t launches = 0;
+  auto finalize = [&](int mode) -> int {
+    HIP_TRY(nnhip::launch_kernel(nnhip::advance_dense_finalize_kernel<0>, grid, block, s, a, mode, dim, y0, ny_out, n_t));
+    return NNHIP_OK;
+  };
+  auto run_dir = [&](bool neg, double tStartEff, double tEnd, const double* req, int nReq, const int32_t* rowBase) -> int {
+    a.negate = neg ? 1 : 0; a.tEnd = tEnd; a.tReq = req; a.nReq = nReq; a.rowBase = rowBase;
+    a.useDense = n_t != 2 ? 1 : 0;  // :499-502: with a 2-point tspan the only row of a direction is the final yPositive.add(y)
+    nnhip::StepArgs run = a;
+    HIP_TRY(fn.init(run, y0, tStartEff, dtInit, s));
+    for (;;) {
+      HIP_TRY(hipMemsetAsync(active, 0, nnhip::kAggSlots * sizeof(unsigned int), s));
+      for (int k = 0; k < check_every; ++k) {
+        run.active = k == check_every - 1 ? active : nullptr;
+        HIP_TRY(fn.advance(run, s));
+        ++launches;
+      }
+      HIP_TRY(hipMemcpyAsync(poll.h, active, nnhip::kAggSlots * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      unsigned int any = 0;
+      for (int k = 0; k < nnhip::kAggSlots; ++k) any |= poll.h[k];
+      if (!any) break;
+      if (max_launches > 0 && launches >= max_launches) break;
+    }
+    return NNHIP_OK;
+  };
+  HIP_TRY(hipMemsetAsync(ny_out, 0, (size_t)N * sizeof(int32_t), s));
+  if (nNeg > 0) {  // backward branch (:544-584)
+    rc = run_dir(true, -opt->tStart, g.tEndNeg, tReqDev + nPos, nNeg, nullptr);
+    if (rc) return rc;
+    rc = finalize(0);
+    if (rc) return rc;
+  }
+  if (g.nZero) {  // `if t0 in tspan` (:485-487)
+    rc = finalize(1);
+    if (rc) return rc;
+  }
+  if (nPos > 0) {
+    rc = run_dir(false, opt->tStart, g.tEndPos, tReqDev, nPos, ny_out);
+    if (rc) return rc;
+    rc = finalize(2);
+    if (rc) return rc;
+  }
+  rc = finalize(3);
+  if (rc) return rc;
   if (launches_out) *launches_out = launches;
   return NNHIP_OK;
 }

@@ -87,6 +87,18 @@ struct StepArgs {
   // advance mode: issue the loads of (y, FSAL, dt) together with the load of t instead of after the `t < tEnd` test: one memory
   // round trip per launch less; IVPs that are already finished then still READ their state (they never write)
   int speculate;
+  // advance mode WITH dense output (adaptive streaming through the IntegratorProc seam, ode.nim:512-530): tReq == nullptr -> none.
+  const double* tReq;   // requested times of this direction as the reference holds them (tPositive ascending / tNegative descending)
+  int nReq;
+  int useDense;         // tspan.len != 2 (:499-502); 0: no emission block, the only row is the final yPositive.add(y) / yNegative.add(y)
+  int negate;           // backward branch: integrate g(t, y) = -f(-t, y); requested times are negated on read
+  int32_t* denseIdx_io; // per-IVP denseIndex
+  double* lastT_io;     // per-IVP lastIter.t
+  double* lastY_io;     // per-IVP lastIter.y   (layout and strides of y)
+  double* lastDy_io;    // per-IVP lastIter.dy
+  double* rows;         // result tensor [n_t][dim][N] / [n_t][N][dim]
+  int64_t rowStride;
+  const int32_t* rowBase;  // forward: emission k of IVP i goes to row rowBase[i] + k; backward (rowBase == nullptr): row nReq-1-k
 };
 
 constexpr int kBlock = 256;
@@ -445,7 +457,6 @@ hipError_t launch_step_tpi(const StepArgs& a, int negate, hipStream_t s) {
 template <int METHOD, class Ops>
 NNHIP_DEV unsigned int advance_body(const StepArgs& a, const Ops& ops, int64_t i, int64_t base, bool writeScalars) {
   constexpr int D = Ops::D;
-  using MT = MethodTraits<METHOD>;
   double t = a.t_io[i];
   double y[D], yNew[D], fsal[D];
   double dt;
@@ -548,6 +559,189 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_LPS_ATTR void advance_lps_kernel(
   }
   if (a.active) {
     if (__syncthreads_or((int)stillActive) && threadIdx.x == 0) a.active[blockIdx.x % kAggSlots] = 1u;
+  }
+}
+
+// ---- adaptive streaming WITH dense output (thread-per-IVP systems) ------------------------------------------------------------
+// ODESolver's loop iteration including the emission block :512-524 and the lastIter update :526-530, per IVP and launch, with
+// the Hermite history (lastIter.t, .y, .dy) and denseIndex resident in HBM next to (y, FSAL, t, dt).  One kernel serves both
+// directions: the backward branch g(t, y) = -f(-t, y) is a run-time flag here (exact sign flips, same bits as the compile-time
+// NEG of the fused kernels).
+template <class RHS>
+struct TpiOpsRt {
+  static constexpr int D = RHS::dim;
+  const Params& P;
+  bool neg;
+  NNHIP_DEV static constexpr bool owns(int) { return true; }
+  NNHIP_DEV void rhs(double t, const double (&y)[D], double (&dy)[D]) const {
+    RHS::eval(neg ? -t : t, y, dy, P);
+    if (neg) {
+#pragma unroll
+      for (int c = 0; c < D; ++c) dy[c] = -dy[c];
+    }
+  }
+  NNHIP_DEV double norm(const double (&yNew)[D], const double (&err_y)[D], const StepCtl& o) const {
+    const TpiOps<RHS, false> base{P};
+    return base.norm(yNew, err_y, o);
+  }
+};
+
+// y = y0, FSAL = f(t0, y0) / g(-t0, y0) (:506,:546), t, dt, denseIndex = 0, lastIter = (t, y, FSAL) (:498,:548)
+template <class RHS>
+__global__ __launch_bounds__(kBlock) void advance_dense_init_kernel(const StepArgs a, const double* __restrict__ y0, double tStartEff, double dtInit) {
+  constexpr int D = RHS::dim;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= a.N) return;
+  const Params P = params_of(a, i);
+  const TpiOpsRt<RHS> ops{P, a.negate != 0};
+  const int64_t base = i * a.ivpStride;
+  double y[D], f[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) y[c] = y0[base + c * a.compStride];
+  ops.rhs(tStartEff, y, f);
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    a.y_out[base + c * a.compStride] = y[c];
+    a.fsal_out[base + c * a.compStride] = f[c];
+    a.lastY_io[base + c * a.compStride] = y[c];
+    a.lastDy_io[base + c * a.compStride] = f[c];
+  }
+  a.t_io[i] = tStartEff;
+  a.dt_io[i] = dtInit;
+  a.lastT_io[i] = tStartEff;
+  a.denseIdx_io[i] = 0;
+}
+
+template <int METHOD, class RHS>
+__global__ __launch_bounds__(kBlock) void advance_dense_tpi_kernel(const StepArgs a) {
+  constexpr int D = RHS::dim;
+  using MT = MethodTraits<METHOD>;
+  static_assert(MT::adaptive, "adaptive methods only");
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  unsigned int stillActive = 0;
+  if (i < a.N) {
+    double t = a.t_io[i];
+    if (t < a.tEnd) {  // :511
+      const Params P = params_of(a, i);
+      const bool neg = a.negate != 0;
+      const TpiOpsRt<RHS> ops{P, neg};
+      const int64_t base = i * a.ivpStride, cs = a.compStride;
+      double y[D], yNew[D], fsal[D];
+#pragma unroll
+      for (int c = 0; c < D; ++c) { y[c] = a.y_in[base + c * cs]; fsal[c] = a.fsal_in[base + c * cs]; }
+      double dt = a.dt_io[i];
+      int denseIndex = a.denseIdx_io[i];
+      const int high = a.nReq - 1;
+      bool done = false;
+      // :512-524 — requested times that the step just taken has passed
+      if (!a.useDense) {
+      } else if (high < denseIndex) {
+        done = true;  // :513-514 `break`: the loop ends without another step
+      } else {
+        double treq = neg ? -a.tReq[denseIndex] : a.tReq[denseIndex];
+        if (treq <= t) {
+          const double lastT = a.lastT_io[i];
+          double lastY[D], lastDy[D], dyNow[D];
+#pragma unroll
+          for (int c = 0; c < D; ++c) { lastY[c] = a.lastY_io[base + c * cs]; lastDy[c] = a.lastDy_io[base + c * cs]; }
+          if constexpr (MT::fsal) {
+#pragma unroll
+            for (int c = 0; c < D; ++c) dyNow[c] = fsal[c];
+          } else {
+            ops.rhs(t, y, dyNow);  // f(t, y, ctx) (:521)
+          }
+          while (treq <= t) {  // :515
+            const HermiteW w = hermite_weights(treq, lastT, t);
+            const int64_t r = a.rowBase ? (int64_t)a.rowBase[i] + denseIndex : (int64_t)(a.nReq - 1 - denseIndex);
+#pragma unroll
+            for (int c = 0; c < D; ++c) a.rows[r * a.rowStride + base + c * cs] = hermite_apply(w, lastY[c], y[c], lastDy[c], dyNow[c]);
+            denseIndex += 1;
+            if (high < denseIndex) { done = true; break; }  // :523-524
+            treq = neg ? -a.tReq[denseIndex] : a.tReq[denseIndex];
+          }
+          a.denseIdx_io[i] = denseIndex;
+        }
+      }
+      if (done) {
+        // every requested time has been emitted: the reference leaves the loop here; the final yPositive.add(y) falls outside the
+        // requested rows.  Retire the IVP (denseIndex == nReq tells the finalize kernel that nothing is left to add).
+        a.t_io[i] = a.tEnd;
+      } else {
+        dt = nmin(dt, a.tEnd - t);  // :525
+        if (a.useDense) {  // lastIter = (t, y, dy) (:526-530): dy = FSAL for FSAL methods, f(t, y) otherwise
+          a.lastT_io[i] = t;
+          if constexpr (MT::fsal) {
+#pragma unroll
+            for (int c = 0; c < D; ++c) { a.lastY_io[base + c * cs] = y[c]; a.lastDy_io[base + c * cs] = fsal[c]; }
+          } else {
+            double dy0[D];
+            ops.rhs(t, y, dy0);
+#pragma unroll
+            for (int c = 0; c < D; ++c) { a.lastY_io[base + c * cs] = y[c]; a.lastDy_io[base + c * cs] = dy0[c]; }
+          }
+        }
+        double error = 0.0, factor;
+        int64_t rej = 0;
+        embedded_step<METHOD>(ops, t, dt, y, fsal, yNew, error, a.ctl, rej, factor);  // :531
+        t += dt;                                                                      // :532
+        if (error == 0.0) dt *= 5.0;
+        else dt = dt * factor;
+        if (dt < a.ctl.dtMin) dt = a.ctl.dtMin;
+        else if (a.ctl.dtMax < dt) dt = a.ctl.dtMax;
+        if (error != error) t = a.tEnd;  // NaN abort, as in the fused driver
+#pragma unroll
+        for (int c = 0; c < D; ++c) { a.y_out[base + c * cs] = yNew[c]; a.fsal_out[base + c * cs] = fsal[c]; }
+        a.t_io[i] = t;
+        a.dt_io[i] = dt;
+        if (a.error) a.error[i] = error;
+        if (a.steps_io) a.steps_io[i] += 1;
+        stillActive = t < a.tEnd ? 1u : 0u;
+      }
+    }
+  }
+  if (a.active) {
+    if (__syncthreads_or((int)stillActive) && threadIdx.x == 0) a.active[blockIdx.x % kAggSlots] = 1u;
+  }
+}
+
+// After a direction's loop: yPositive.add(y) / yNegative.add(y) (:542,:584) at row denseIndex if it is still a requested row, the
+// backward rows closed up when fewer than requested were produced (reference quirk), and the per-IVP row count.
+//   mode 0: backward direction finished   (ny[i] = rows produced)
+//   mode 1: `t0 in tspan` row             (rows[ny[i]] = y0; ny[i] += 1)
+//   mode 2: forward direction finished    (ny[i] += rows produced)
+//   mode 3: NaN fill of rows ny[i] .. n_t-1
+template <int DIM_UNUSED = 0>
+__global__ __launch_bounds__(kBlock) void advance_dense_finalize_kernel(const StepArgs a, int mode, int dim, const double* __restrict__ y0, int32_t* __restrict__ ny,
+                                                                        int n_t) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= a.N) return;
+  const int64_t base = i * a.ivpStride, cs = a.compStride, rs = a.rowStride;
+  if (mode == 0 || mode == 2) {
+    const int k = a.denseIdx_io[i];
+    const int produced = k + 1 < a.nReq ? k + 1 : a.nReq;
+    if (mode == 0) {
+      if (k < a.nReq)
+        for (int c = 0; c < dim; ++c) a.rows[(int64_t)(a.nReq - 1 - k) * rs + base + c * cs] = a.y_in[base + c * cs];
+      if (produced < a.nReq) {
+        const int shift = a.nReq - produced;
+        for (int j = 0; j < produced; ++j)
+          for (int c = 0; c < dim; ++c) a.rows[(int64_t)j * rs + base + c * cs] = a.rows[(int64_t)(j + shift) * rs + base + c * cs];
+      }
+      ny[i] = produced;
+    } else {
+      const int rb = ny[i];
+      if (k < a.nReq)
+        for (int c = 0; c < dim; ++c) a.rows[(int64_t)(rb + k) * rs + base + c * cs] = a.y_in[base + c * cs];
+      ny[i] = rb + produced;
+    }
+  } else if (mode == 1) {
+    const int rb = ny[i];
+    for (int c = 0; c < dim; ++c) a.rows[(int64_t)rb * rs + base + c * cs] = y0[base + c * cs];
+    ny[i] = rb + 1;
+  } else {
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+    for (int j = ny[i]; j < n_t; ++j)
+      for (int c = 0; c < dim; ++c) a.rows[(int64_t)j * rs + base + c * cs] = qnan;
   }
 }
 
@@ -899,6 +1093,36 @@ StepLaunchFn find_step_tpi(int rhs_kind, int dim) {
   return nullptr;
 }
 
+// dense adaptive streaming: (init, advance) launchers of one (method, RHS)
+struct DenseAdvLaunch {
+  hipError_t (*init)(const StepArgs&, const double* y0, double tStartEff, double dtInit, hipStream_t);
+  hipError_t (*advance)(const StepArgs&, hipStream_t);
+};
+template <class RHS>
+hipError_t launch_advance_dense_init(const StepArgs& a, const double* y0, double tStartEff, double dtInit, hipStream_t s) {
+  const int64_t grid = (a.N + kBlock - 1) / kBlock;
+  if (grid <= 0) return hipSuccess;
+  return launch_kernel(advance_dense_init_kernel<RHS>, dim3((unsigned)grid), dim3(kBlock), s, a, y0, tStartEff, dtInit);
+}
+template <int METHOD, class RHS>
+hipError_t launch_advance_dense(const StepArgs& a, hipStream_t s) {
+  if constexpr (MethodTraits<METHOD>::adaptive) {
+    const int64_t grid = (a.N + kBlock - 1) / kBlock;
+    if (grid <= 0) return hipSuccess;
+    return launch_kernel(advance_dense_tpi_kernel<METHOD, RHS>, dim3((unsigned)grid), dim3(kBlock), s, a);
+  } else {
+    return hipErrorInvalidValue;
+  }
+}
+template <int METHOD>
+DenseAdvLaunch find_advance_dense_tpi(int rhs_kind, int dim) {
+#define X(kind, d, T) \
+  if (rhs_kind == kind && dim == d) return DenseAdvLaunch{&launch_advance_dense_init<T>, &launch_advance_dense<METHOD, T>};
+  NNHIP_FOR_EACH_TPI_RHS(X)
+#undef X
+  return DenseAdvLaunch{nullptr, nullptr};
+}
+
 template <int METHOD>
 FixedVecLaunchFn find_fixed_vec_tpi(int rhs_kind, int dim) {
 #define X(kind, d, T) \
@@ -930,7 +1154,8 @@ StepLaunchFn find_advance_tpi(int rhs_kind, int dim) {
   SolveLaunchFn find_solve_##name(int rhs_kind, int dim, int dim16_variant);  \
   StepLaunchFn find_step_##name(int rhs_kind, int dim);                  \
   StepLaunchFn find_advance_##name(int rhs_kind, int dim);               \
-  FixedVecLaunchFn find_fixed_vec_##name(int rhs_kind, int dim);
+  FixedVecLaunchFn find_fixed_vec_##name(int rhs_kind, int dim);         \
+  DenseAdvLaunch find_advance_dense_##name(int rhs_kind, int dim);
 NNHIP_FOR_EACH_METHOD(X)
 #undef X
 // scalar RK4 streaming (vectorised); rhs_kind must be an elementwise kind. Defined in ode_tu_rk4_stream.hip

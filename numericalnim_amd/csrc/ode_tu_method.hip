@@ -18,4 +18,8 @@ FixedVecLaunchFn NNHIP_CAT(find_fixed_vec_, NNHIP_TU_NAME)(int rhs_kind, int dim
   if constexpr (!MethodTraits<NNHIP_TU_METHOD>::adaptive) return find_fixed_vec_tpi<NNHIP_TU_METHOD>(rhs_kind, dim);
   else return nullptr;
 }
+DenseAdvLaunch NNHIP_CAT(find_advance_dense_, NNHIP_TU_NAME)(int rhs_kind, int dim) {
+  if constexpr (MethodTraits<NNHIP_TU_METHOD>::adaptive) return find_advance_dense_tpi<NNHIP_TU_METHOD>(rhs_kind, dim);
+  else return DenseAdvLaunch{nullptr, nullptr};
+}
 }  // namespace NNHIP_NS

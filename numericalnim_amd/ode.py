@@ -385,6 +385,35 @@ def fixedStreamSolve(f, y0, tspan, options=None, ctx=None, integrator="rk4", lay
     return t_out[:ntout.value].copy(), y, ny.value, ns.value
 
 
+def adaptiveStreamSolve(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=LAYOUT_SOA, check_every=8):
+    """solveODE (ode.nim:589-651) for an adaptive integrator THROUGH THE IntegratorProc SEAM: the whole ODESolver driver over the
+    HBM-resident advance kernel with per-IVP Hermite history (nnhip_ode_adaptive_stream_dense_f64_dev).  Returns (t, y, ny, launches);
+    bitwise equal to solveODE."""
+    import torch
+    L = _lib.lib()
+    options = options if options is not None else _default_options()
+    integ = integrator_id(integrator)
+    p, pp = _params_array(f, ctx)
+    N, dim, scalar = _shape_info(y0, layout)
+    tspan = np.ascontiguousarray(np.asarray(tspan, dtype=np.float64))
+    n_t = int(tspan.size)
+    t_out = np.empty(max(n_t, 1), dtype=np.float64)
+    ntout = C.c_int(0)
+    dpt = C.POINTER(C.c_double)
+    _check(L.nnhip_ode_time_grid(C.byref(options), tspan.ctypes.data_as(dpt), n_t, t_out.ctypes.data_as(dpt), C.byref(ntout)))
+    y0c = y0.contiguous()
+    nl = C.c_int64(0)
+    with torch.cuda.device(y0c.device):
+        y = torch.empty((n_t,) + tuple(y0c.shape), dtype=torch.float64, device=y0c.device)
+        ny = torch.empty(max(N, 1), dtype=torch.int32, device=y0c.device)
+        wsb = int(L.nnhip_ode_adaptive_stream_dense_workspace_bytes(N, dim, n_t))
+        ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=y0c.device)
+        _check(L.nnhip_ode_adaptive_stream_dense_f64_dev(C.byref(options), integ, f.kind, pp, int(p.size), y0c.data_ptr(), N, dim, layout,
+                                                         tspan.ctypes.data_as(dpt), n_t, t_out.ctypes.data_as(dpt), y.data_ptr(), ny.data_ptr(),
+                                                         ws.data_ptr(), wsb, int(check_every), 0, C.byref(nl), torch.cuda.current_stream().cuda_stream))
+    return t_out[:ntout.value].copy(), y, ny[:N], nl.value
+
+
 def adaptiveStream(f, y, t0, tEnd, options=None, ctx=None, integrator="dopri54", layout=LAYOUT_SOA, check_every=8):
     """ODESolver's adaptive loop (ode.nim:506-542) over the HBM-resident `advance` kernel; y (CUDA tensor) is advanced
     in place from t0 to tEnd.  Returns (y, number of launches).  Bitwise equal to solveODE(f, y0, [t0, tEnd])[1][-1]."""

@@ -591,3 +591,37 @@ def test_parameter_sweep_through_the_host_pointer_entry(nn, dev):
     assert np.array_equal(yh, yd.cpu().numpy()) and np.array_equal(ch["steps"], cd["steps"].cpu().numpy())
     plain = nn.solveODE(nn.Rhs.lorenz(), y0, ts, nn.newODEoptions(), integrator="tsit54")[1]
     assert not np.array_equal(plain, yh)  # the sweep really changes the trajectories
+
+
+@pytest.mark.parametrize("integrator", ["dopri54", "tsit54", "vern65", "bs32", "rk21"])
+def test_adaptive_dense_output_through_the_step_streaming_seam(nn, oracle, dev, integrator):
+    """nnhip_ode_adaptive_stream_dense_f64_dev: the whole ODESolver driver (ode.nim:471-586) over the HBM-resident advance kernel
+    with per-IVP Hermite history — the reference's own harness (tests/test_ode.nim:15: linspace(-10, 10, 100), both directions)
+    and the awkward grids (tStart inside / outside / duplicated, unsorted, one point, two points on one side, requested times
+    closer than the steps so that the reference drops rows, per IVP differently) — bitwise equal to the fused solve and to the oracle."""
+    import torch
+    O = oracle
+    rng = np.random.default_rng(44)
+    ts_h = O.linspace(-10.0, 10.0, 100)
+    y0s = torch.from_numpy(1.0 + np.arange(40) * 2.0 ** -6).to(dev)
+    opt = nn.newODEoptions(relTol=1e-8, dt=1e-2)
+    t, y, ny, launches = nn.adaptiveStreamSolve(nn.Rhs.linear(-0.1), y0s, ts_h, opt, integrator=integrator)
+    tf, yf, cf = nn.solveODE(nn.Rhs.linear(-0.1), y0s, ts_h, opt, integrator=integrator, return_counts=True)
+    assert np.array_equal(t, ts_h) and torch.equal(y, yf) and torch.equal(ny, cf["ny"]) and bool((ny == 100).all())
+    rt, ry, st = O.solve_ode(O.RHS_LINEAR, [-0.1], float(y0s[5]), ts_h, O.new_options(relTol=1e-8, dt=1e-2), integrator)
+    assert np.array_equal(y[:, 5].cpu().numpy(), np.asarray(ry))
+    # (Lorenz is unstable backwards in time: long backward spans with a tiny dtMin take 1e7+ steps in the reference as well)
+    grids = [[0.6, -0.3, 0.0], [0.0, 0.0, 1.0], [-0.3, -0.1], [1.2], [0.5, 1.0], [0.5, 0.25, 0.75, 1.0], [0.3, 0.30001, 0.30002, 0.9],
+             [-0.2, -0.20001, -0.1, 0.7, 0.70001, 0.70002], []]
+    for f, dim, layout in ((nn.Rhs.lorenz(), 3, 0), (nn.Rhs.lorenz(), 3, 1), (nn.Rhs.vanderpol(2.0), 2, 0), (nn.Rhs.neg_y(), 1, 0)):
+        n = 203
+        y0 = rng.uniform(0.5, 1.5, (n, dim)) + (np.array([0.0, 0.0, 20.0]) if dim == 3 else 0.0)
+        y0l = torch.from_numpy(np.ascontiguousarray(y0 if layout == 1 else y0.T) if dim > 1 else y0[:, 0].copy()).to(dev)
+        for ts in grids:
+            for tstart, kw in ((0.0, {}), (0.25, dict(absTol=1e-7, relTol=1e-7, dtMin=1e-6, dtMax=0.5))):
+                o2 = nn.newODEoptions(tStart=tstart, **kw)
+                t, y, ny, launches = nn.adaptiveStreamSolve(f, y0l, ts, o2, integrator=integrator, layout=layout, check_every=3)
+                tf, yf, cf = nn.solveODE(f, y0l, ts, o2, integrator=integrator, layout=layout, return_counts=True)
+                assert np.array_equal(t, tf), (dim, ts)
+                assert torch.equal(ny, cf["ny"]), (dim, layout, ts, tstart)
+                assert torch.equal(torch.nan_to_num(y, nan=-7.0), torch.nan_to_num(yf, nan=-7.0)), (dim, layout, ts, tstart)
