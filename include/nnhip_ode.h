@@ -174,6 +174,16 @@ int nnhip_ode_solve_batch_sweep_f64_dev(const nnhip_ode_options* opt, int integr
                                         int32_t* ny_out, int64_t* steps_out, int64_t* rejected_out, int64_t max_steps, void* ws,
                                         int64_t ws_bytes, void* stream);
 
+/* Every IVP its own tspan end: tspan_i = [options.tStart, t_end[i]], t_end a device array [N] (in the reference every IVP is a
+ * solveODE call with its own tspan, ode.nim:589-591, 476-480).  y_out [2][dim][N] / [2][N][dim] holds per IVP the rows the reference
+ * returns for tspan_i.sorted(): (y0, y(tEnd)) when tEnd > tStart; (y(tEnd), y0) when tEnd < tStart (backward branch, :544-584);
+ * the single row y0 when they coincide (ny_out[i] = 1, second row NaN — the reference returns one state for two times there).
+ * Non-finite t_end[i] is not checked on the device: such an IVP runs until max_steps (give one) — as the reference would never return. */
+int nnhip_ode_solve_batch_tend_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
+                                       int n_params, const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t N, int dim,
+                                       int layout, const double* t_end, double* y_out, int32_t* ny_out, int64_t* steps_out,
+                                       int64_t* rejected_out, int64_t max_steps, void* stream);
+
 /* Divergence binning: the same fused solve for batches whose members take very different step sequences (the reference runs
  * them one after the other, ode.nim:589-591; on a wavefront they share an instruction stream).  The IVPs are INTEGRATED in
  * ascending order of `sort_key` (device array [N]) and every result is WRITTEN at the IVP's own index, so outputs are in the

@@ -624,6 +624,30 @@ int nnhip_ode_solve_batch_sweep_f64_dev(const nnhip_ode_options* opt, int integr
   return launch_solve_range(ps, 0, N, (hipStream_t)stream);
 }
 
+// ---- every IVP its own tspan end -------------------------------------------------------------------------------------
+// In the reference every IVP is a solveODE call with its own tspan (ode.nim:589-591, 476-480).  Here: tspan_i = [options.tStart,
+// t_end[i]] (device array [N]).  Output y_out [2][dim][N] (SoA) / [2][N][dim] (AoS) holds, per IVP, the rows the reference returns
+// for tspan.sorted(): (y0, y(tEnd)) when tEnd > tStart, (y(tEnd), y0) when tEnd < tStart (backward branch), and the single row y0
+// when they coincide (ny_out[i] = 1, second row NaN).  Everything else as nnhip_ode_solve_batch_sweep_f64_dev.
+int nnhip_ode_solve_batch_tend_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
+                                       const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t N, int dim, int layout,
+                                       const double* t_end, double* y_out, int32_t* ny_out, int64_t* steps_out, int64_t* rejected_out,
+                                       int64_t max_steps, void* stream) {
+  if (N > 0 && !t_end) return fail(NNHIP_EVALUE, "t_end is NULL");
+  if (!opt) return fail(NNHIP_EVALUE, "options is NULL");
+  // a 2-point placeholder tspan on the forward side: validation, dispatch and the option-derived fields; the directions are per IVP
+  const double tspan[2] = {opt->tStart, opt->tStart + 1.0};
+  PreparedSolve ps;
+  int rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y0, N, dim, layout, tspan, 2, nullptr, y_out, ny_out,
+                         steps_out, rejected_out, max_steps, nullptr, 0, nullptr, nullptr, (hipStream_t)stream, ps);
+  if (rc) return rc;
+  ps.a.tEndPerIvp = t_end;
+  ps.a.nZero = 1;                                   // t0 is in every tspan_i
+  ps.a.uniformFull[0] = ps.a.uniformFull[1] = -1;   // no batch-wide step schedule: the spans differ
+  ps.a.nTail[0] = ps.a.nTail[1] = 0;
+  return launch_solve_range(ps, 0, N, (hipStream_t)stream);
+}
+
 // ---- divergence binning below the boundary -----------------------------------------------------------------------
 // Workspace of nnhip_ode_solve_batch_sorted_f64_dev: requested times + order of integration (4N) + probe progress / key (8N)
 // + the device sort's scratch.

@@ -58,6 +58,10 @@ struct SolveArgs {
   const uint32_t* perm;
   // nullable [N]: how far the IVP got, |t - t0| summed over the directions integrated (= the full span unless max_steps cut it short)
   double* progress_out;
+  // nullable [N]: every IVP its own tspan = [t0, tEndPerIvp[i]] (each reference call owns its tspan, ode.nim:589-591); n_t == 2.
+  // Overrides nPos / nNeg / tEndPos / tEndNeg per IVP: tEnd > t0 integrates forward (rows y0, y(tEnd)), tEnd < t0 backward (rows
+  // y(tEnd), y0), tEnd == t0 yields the reference's single row y0.
+  const double* tEndPerIvp;
 };
 
 struct StepArgs {
@@ -156,8 +160,30 @@ struct LaneStats {
   double progress = 0.0;
 };
 
-template <int METHOD, bool DENSE = true, class OpsF, class OpsB>
-NNHIP_DEV void solve_body(const SolveArgs& a, const OpsF& opsF, const OpsB& opsB, const double* y0p, double* out, LaneStats& ls) {
+// MODE: 1 = general (dense output capable), 0 = lean (tspan.len == 2: no Hermite history), 2 = lean + per-IVP tEnd
+template <int METHOD, int MODE = 1, class OpsF, class OpsB>
+NNHIP_DEV void solve_body(const SolveArgs& a0, const OpsF& opsF, const OpsB& opsB, const double* y0p, double* out, LaneStats& ls, int64_t ivp) {
+  // the direction bookkeeping of this IVP: the batch-wide one, or its own 2-point tspan
+  struct Dir { int nPos, nNeg, nZero, n_t, useDense; double t0, tEndPos, tEndNeg, dtInit; int64_t rowStride, compStride, maxSteps; const double *tPos, *tNeg;
+               StepCtl ctl; int64_t uniformFull[2]; int nTail[2]; double tailDt[2][4]; };
+  Dir a;
+  a.nPos = a0.nPos; a.nNeg = a0.nNeg; a.nZero = a0.nZero; a.n_t = a0.n_t; a.useDense = a0.useDense; a.t0 = a0.t0; a.tEndPos = a0.tEndPos;
+  a.tEndNeg = a0.tEndNeg; a.dtInit = a0.dtInit; a.rowStride = a0.rowStride; a.compStride = a0.compStride; a.maxSteps = a0.maxSteps;
+  a.tPos = a0.tPos; a.tNeg = a0.tNeg; a.ctl = a0.ctl;
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    a.uniformFull[d] = a0.uniformFull[d]; a.nTail[d] = a0.nTail[d];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a.tailDt[d][q] = a0.tailDt[d][q];
+  }
+  constexpr bool DENSE = MODE == 1;
+  if constexpr (MODE == 2) {  // its own instantiation: per-lane direction bookkeeping costs registers the other kernels do not have to spare
+    const double te = a0.tEndPerIvp[ivp];
+    a.nPos = a.t0 < te ? 1 : 0;   // tspan.filterIt(it > t0) (:479)
+    a.nNeg = te < a.t0 ? 1 : 0;   // :480
+    a.tEndPos = te;
+    a.tEndNeg = -te;
+  }
   constexpr int D = OpsF::D;
   double y0[D];
 #pragma unroll
@@ -292,9 +318,10 @@ NNHIP_DEV void aggregate_stats(unsigned long long* aggBase, LaneStats ls) {
   }
 }
 
-template <int METHOD, class RHS, bool DENSE = true>
+template <int METHOD, class RHS, int MODE = 1>
 __global__ __launch_bounds__(kBlock) void solve_tpi_kernel(const SolveArgs a) {
   controller_prologue<MethodTraits<METHOD>::adaptive>();
+  [[maybe_unused]] constexpr bool DENSE = MODE == 1;
   const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   LaneStats ls;
   if (k < a.N) {
@@ -302,7 +329,7 @@ __global__ __launch_bounds__(kBlock) void solve_tpi_kernel(const SolveArgs a) {
     const Params P = params_of(a, i);
     const TpiOps<RHS, false> opsF{P};
     const TpiOps<RHS, true> opsB{P};
-    solve_body<METHOD, DENSE>(a, opsF, opsB, a.y0 + i * a.ivpStride, a.y_out + i * a.ivpStride, ls);
+    solve_body<METHOD, MODE>(a, opsF, opsB, a.y0 + i * a.ivpStride, a.y_out + i * a.ivpStride, ls, i);
     if (a.ny_out) a.ny_out[i] = ls.ny;
     if (a.steps_out) a.steps_out[i] = (int64_t)ls.steps;
     if (a.rejected_out) a.rejected_out[i] = (int64_t)ls.rejected;
@@ -316,8 +343,9 @@ template <int METHOD, class RHS>
 hipError_t launch_solve_tpi(const SolveArgs& a, hipStream_t s) {
   const int64_t grid = (a.N + kBlock - 1) / kBlock;
   if (grid <= 0) return hipSuccess;
-  if (!a.useDense) return launch_kernel(solve_tpi_kernel<METHOD, RHS, false>, dim3((unsigned)grid), dim3(kBlock), s, a);  // lean: no Hermite history
-  return launch_kernel(solve_tpi_kernel<METHOD, RHS, true>, dim3((unsigned)grid), dim3(kBlock), s, a);
+  if (a.tEndPerIvp) return launch_kernel(solve_tpi_kernel<METHOD, RHS, 2>, dim3((unsigned)grid), dim3(kBlock), s, a);  // every IVP its own tEnd
+  if (!a.useDense) return launch_kernel(solve_tpi_kernel<METHOD, RHS, 0>, dim3((unsigned)grid), dim3(kBlock), s, a);  // lean: no Hermite history
+  return launch_kernel(solve_tpi_kernel<METHOD, RHS, 1>, dim3((unsigned)grid), dim3(kBlock), s, a);
 }
 #endif
 
@@ -330,13 +358,13 @@ hipError_t launch_solve_tpi(const SolveArgs& a, hipStream_t s) {
 // VALU-bound solve gains ~9 % (C4 Tsit54 default 7.45 -> 6.75 ms, DOPRI54 6.71 -> 6.17 ms; profiles/r02_c4_fused_ab.txt).  The
 // dense instantiations (215+ VGPRs) would spill 140-170 B and keep 2 waves.  A/B hook: -DNNHIP_LPS_WPE=n forces n for all of them.
 #ifndef NNHIP_LPS_WPE
-template <int CPL, bool DENSE>
-constexpr int lps_solve_waves() { return (CPL >= 4 && !DENSE) ? 3 : 1; }
-#define NNHIP_LPS_ATTR __attribute__((amdgpu_waves_per_eu(lps_solve_waves<CPL, DENSE>())))
+template <int CPL, int MODE>
+constexpr int lps_solve_waves() { return (CPL >= 4 && MODE == 0) ? 3 : 1; }
+#define NNHIP_LPS_ATTR __attribute__((amdgpu_waves_per_eu(lps_solve_waves<CPL, MODE>())))
 #else
 #define NNHIP_LPS_ATTR __attribute__((amdgpu_waves_per_eu(NNHIP_LPS_WPE, NNHIP_LPS_WPE)))
 #endif
-template <int METHOD, class RHS, int CPL, bool SHUFFLE_NORM = false, bool DENSE = true>
+template <int METHOD, class RHS, int CPL, bool SHUFFLE_NORM = false, int MODE = 1>
 __global__ __launch_bounds__(kBlock) NNHIP_LPS_ATTR void solve_lps_kernel(const SolveArgs a) {
   constexpr int DIM = RHS::dim;
   constexpr int LPSYS = DIM / CPL;  // lanes per system
@@ -353,7 +381,7 @@ __global__ __launch_bounds__(kBlock) NNHIP_LPS_ATTR void solve_lps_kernel(const 
     const Params P = params_of(a, i);
     const LpsOps<RHS, false, CPL, SHUFFLE_NORM> opsF{P, ys, es, c};
     const LpsOps<RHS, true, CPL, SHUFFLE_NORM> opsB{P, ys, es, c};
-    solve_body<METHOD, DENSE>(a, opsF, opsB, a.y0 + i * a.ivpStride + c * a.compStride, a.y_out + i * a.ivpStride + c * a.compStride, ls);
+    solve_body<METHOD, MODE>(a, opsF, opsB, a.y0 + i * a.ivpStride + c * a.compStride, a.y_out + i * a.ivpStride + c * a.compStride, ls, i);
     if (c == 0) {
       if (a.ny_out) a.ny_out[i] = ls.ny;
       if (a.steps_out) a.steps_out[i] = (int64_t)ls.steps;
@@ -372,8 +400,9 @@ hipError_t launch_solve_lps(const SolveArgs& a, hipStream_t s) {
   constexpr int perBlock = kBlock / (RHS::dim / CPL);
   const int64_t grid = (a.N + perBlock - 1) / perBlock;
   if (grid <= 0) return hipSuccess;
-  if (!a.useDense) return launch_kernel(solve_lps_kernel<METHOD, RHS, CPL, SHUFFLE_NORM, false>, dim3((unsigned)grid), dim3(kBlock), s, a);
-  return launch_kernel(solve_lps_kernel<METHOD, RHS, CPL, SHUFFLE_NORM, true>, dim3((unsigned)grid), dim3(kBlock), s, a);
+  if (a.tEndPerIvp) return launch_kernel(solve_lps_kernel<METHOD, RHS, CPL, SHUFFLE_NORM, 2>, dim3((unsigned)grid), dim3(kBlock), s, a);
+  if (!a.useDense) return launch_kernel(solve_lps_kernel<METHOD, RHS, CPL, SHUFFLE_NORM, 0>, dim3((unsigned)grid), dim3(kBlock), s, a);
+  return launch_kernel(solve_lps_kernel<METHOD, RHS, CPL, SHUFFLE_NORM, 1>, dim3((unsigned)grid), dim3(kBlock), s, a);
 }
 #endif
 

@@ -356,6 +356,36 @@ def fixedStream(f, y, t0, tEnd, options=None, ctx=None, integrator="rk4", layout
     return final, nsteps.value
 
 
+def solveODEPerIvpEnd(f, y0, t_end, options=None, ctx=None, integrator="dopri54", layout=LAYOUT_SOA, max_steps=0, sweep=None):
+    """A batch of solveODE(f, y0_i, [options.tStart, t_end[i]], options, ctx, integrator) calls — every IVP with its own tspan end
+    (ode.nim:589-591: each reference call owns its tspan).  t_end: CUDA float64 tensor [N].  Returns (y [2, *y0.shape], counts):
+    the two rows the reference returns for the sorted 2-point tspan of each IVP (nnhip_ode_solve_batch_tend_f64_dev)."""
+    import torch
+    L = _lib.lib()
+    options = options if options is not None else _default_options()
+    integ = integrator_id(integrator)
+    p, pp = _params_array(f, ctx)
+    N, dim, scalar = _shape_info(y0, layout)
+    y0c = y0.contiguous()
+    te = t_end.contiguous()
+    if te.dim() != 1 or te.shape[0] != N or te.dtype != torch.float64 or not te.is_cuda:
+        raise ValueError("t_end must be a CUDA float64 tensor of shape [N]")
+    sw = None
+    if sweep is not None:
+        sw = sweep.contiguous()
+        if sw.dim() != 2 or sw.shape[1] != N or sw.dtype != torch.float64 or not sw.is_cuda:
+            raise ValueError("sweep must be a CUDA float64 tensor of shape [k, N]")
+    with torch.cuda.device(y0c.device):
+        y = torch.empty((2,) + tuple(y0c.shape), dtype=torch.float64, device=y0c.device)
+        ny = torch.empty(N, dtype=torch.int32, device=y0c.device)
+        st = torch.empty(N, dtype=torch.int64, device=y0c.device)
+        rj = torch.empty(N, dtype=torch.int64, device=y0c.device)
+        _check(L.nnhip_ode_solve_batch_tend_f64_dev(C.byref(options), integ, f.kind, pp, int(p.size), sw.data_ptr() if sw is not None else None,
+                                                    int(sw.shape[0]) if sw is not None else 0, y0c.data_ptr(), N, dim, layout, te.data_ptr(), y.data_ptr(),
+                                                    ny.data_ptr(), st.data_ptr(), rj.data_ptr(), int(max_steps), torch.cuda.current_stream().cuda_stream))
+    return y, dict(ny=ny, steps=st, rejected=rj)
+
+
 def fixedStreamSolve(f, y0, tspan, options=None, ctx=None, integrator="rk4", layout=LAYOUT_SOA, max_steps=0):
     """solveODE (ode.nim:589-651) for a fixed-step integrator THROUGH THE IntegratorProc SEAM: the whole ODESolver driver — both
     directions, dense Hermite rows, output assembly — over the step-streaming kernels, state in HBM between steps

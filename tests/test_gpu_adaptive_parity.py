@@ -625,3 +625,35 @@ def test_adaptive_dense_output_through_the_step_streaming_seam(nn, oracle, dev, 
                 assert np.array_equal(t, tf), (dim, ts)
                 assert torch.equal(ny, cf["ny"]), (dim, layout, ts, tstart)
                 assert torch.equal(torch.nan_to_num(y, nan=-7.0), torch.nan_to_num(yf, nan=-7.0)), (dim, layout, ts, tstart)
+
+
+@pytest.mark.parametrize("integrator", ["dopri54", "tsit54", "rk4", "bs32", "heun3"])
+def test_every_ivp_its_own_tspan_end(nn, oracle, dev, integrator):
+    """nnhip_ode_solve_batch_tend_f64_dev: IVP i is solveODE(f, y0_i, [tStart, t_end[i]]) (each reference call owns its tspan,
+    ode.nim:589-591, 476-480): forward, backward and zero-length spans in one batch, thread-per-IVP and lanes-per-system kernels,
+    bitwise equal to one oracle call per IVP — rows in the reference's sorted order, ny = 1 where tEnd == tStart."""
+    import torch
+    O = oracle
+    rng = np.random.default_rng(7)
+    for f, okind, params, dim, layout in ((nn.Rhs.lorenz(), O.RHS_LORENZ, LOR, 3, 0), (nn.Rhs.ring(0.1), O.RHS_RING, [0.1], 16, 1),
+                                          (nn.Rhs.linear(-0.4), O.RHS_LINEAR, [-0.4], 1, 0)):
+        n = 333
+        y0 = rng.uniform(0.5, 1.5, (n, dim)) + (np.array([0.0, 0.0, 20.0]) if dim == 3 else 0.0)
+        te = rng.uniform(-0.3, 1.0, n)
+        te[::17] = 0.25          # tEnd == tStart
+        te[5] = np.nextafter(0.25, 1.0)
+        te[6] = np.nextafter(0.25, -1.0)
+        kw = dict(tStart=0.25, dt=1e-2, absTol=1e-7, relTol=1e-7, dtMin=1e-6, dtMax=0.25)
+        y0l = np.ascontiguousarray(y0 if layout == 1 else y0.T) if dim > 1 else y0[:, 0].copy()
+        y, cnt = nn.solveODEPerIvpEnd(f, torch.from_numpy(y0l).to(dev), torch.from_numpy(te).to(dev), nn.newODEoptions(**kw), integrator=integrator, layout=layout)
+        got = y.cpu().numpy()
+        ny, steps = cnt["ny"].cpu().numpy(), cnt["steps"].cpu().numpy()
+        for i in list(range(0, n, 7)) + [5, 6]:
+            yi = list(y0[i]) if dim > 1 else float(y0[i, 0])
+            rt, ry, st = O.solve_ode(okind, params, yi, [0.25, te[i]], O.new_options(**kw), integrator)
+            gi = got[:, i] if dim == 1 else (got[:, :, i] if layout == 0 else got[:, i, :])
+            assert ny[i] == st.n_y and steps[i] == st.steps, (i, te[i])
+            assert _same_bits(gi[:st.n_y].reshape(st.n_y, -1), np.asarray(ry).reshape(st.n_y, -1)), (integrator, dim, i, te[i])
+            assert np.isnan(gi[st.n_y:]).all()
+            if te[i] == 0.25:
+                assert st.n_y == 1
