@@ -13,6 +13,7 @@
 #include <cstring>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -28,8 +29,22 @@ const Header kHeaders[] = {
 #include "embedded_headers.inc"
 };
 
-struct Program {  // the kernels of one (rhs, integrator) code object as loaded on ONE device
+struct Program {  // the kernels of one (rhs, integrator) code object as loaded on ONE device; shared_ptr-owned: a launch in flight keeps
+                   // its module alive across a concurrent nnhip_ode_rhs_release(), the module is unloaded when the last holder lets go
+  int device = -1;
   hipModule_t module = nullptr;
+  Program() = default;
+  Program(const Program&) = delete;
+  Program& operator=(const Program&) = delete;
+  ~Program() {
+    if (!module) return;
+    int prev = 0;
+    const bool have = hipGetDevice(&prev) == hipSuccess;
+    if (device >= 0) (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();  // kernels of this module may still be queued
+    (void)hipModuleUnload(module);
+    if (have) (void)hipSetDevice(prev);
+  }
   hipFunction_t solve = nullptr, stepPos = nullptr, stepNeg = nullptr, advance = nullptr, rhs = nullptr, quad[2] = {nullptr, nullptr};
   int ivpsPerBlockSolve = kBlock, ivpsPerBlockStep = kBlock;  // thread-per-IVP: 256; lanes-per-system: 256 / lanes per system
 };
@@ -37,7 +52,7 @@ struct CodeObject {  // compiled once per (rhs, integrator); hipModuleLoadData b
   std::vector<char> code;
   std::vector<std::string> lowered;
   int ivpsPerBlockSolve = kBlock, ivpsPerBlockStep = kBlock;
-  std::map<int, Program> loaded;  // by device ordinal
+  std::map<int, std::shared_ptr<Program>> loaded;  // by device ordinal
 };
 struct UserRhsEntry {
   std::string name, body;
@@ -178,23 +193,43 @@ bool load(const CodeObject& co, int integrator, Program& out) {
   return true;
 }
 
-Program* get_program(int rhs_kind, int integrator) {
+std::shared_ptr<Program> get_program(int rhs_kind, int integrator) {
   const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
   int device = 0;
   if (hipGetDevice(&device) != hipSuccess) { g_rtc_err = "hipGetDevice failed (no HIP device?)"; return nullptr; }
+  UserRhsEntry snapshot;  // what the compiler needs, copied out so that hiprtc runs WITHOUT the registry lock
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (idx < 0 || idx >= (int)g_user.size() || !g_user[idx].alive) { g_rtc_err = "unknown user rhs_kind"; return nullptr; }
+    auto it = g_user[idx].programs.find(integrator);
+    if (it != g_user[idx].programs.end()) {
+      auto ld = it->second.loaded.find(device);
+      if (ld != it->second.loaded.end()) return ld->second;
+    } else {
+      snapshot.name = g_user[idx].name; snapshot.body = g_user[idx].body; snapshot.dim = g_user[idx].dim;
+      snapshot.n_params = g_user[idx].n_params; snapshot.perComponent = g_user[idx].perComponent; snapshot.alive = true;
+    }
+  }
+  CodeObject fresh;
+  bool compiled = false;
+  if (snapshot.alive) {  // not compiled yet: do it outside the lock (seconds); a concurrent caller may do the same, the first to insert wins
+    if (!compile(snapshot, integrator, fresh)) return nullptr;
+    compiled = true;
+  }
   std::lock_guard<std::mutex> lk(g_mu);
-  if (idx < 0 || idx >= (int)g_user.size() || !g_user[idx].alive) { g_rtc_err = "unknown user rhs_kind"; return nullptr; }
+  if (idx >= (int)g_user.size() || !g_user[idx].alive) { g_rtc_err = "user rhs_kind was released during compilation"; return nullptr; }
   auto it = g_user[idx].programs.find(integrator);
   if (it == g_user[idx].programs.end()) {
-    CodeObject co;
-    if (!compile(g_user[idx], integrator, co)) return nullptr;
-    it = g_user[idx].programs.emplace(integrator, std::move(co)).first;
+    if (!compiled) { g_rtc_err = "user rhs_kind was released and re-registered concurrently"; return nullptr; }
+    it = g_user[idx].programs.emplace(integrator, std::move(fresh)).first;
   }
   auto ld = it->second.loaded.find(device);
-  if (ld != it->second.loaded.end()) return &ld->second;
-  Program p;
-  if (!load(it->second, integrator, p)) return nullptr;
-  return &(it->second.loaded[device] = p);
+  if (ld != it->second.loaded.end()) return ld->second;
+  auto p = std::make_shared<Program>();
+  p->device = device;
+  if (!load(it->second, integrator, *p)) return nullptr;
+  it->second.loaded[device] = p;
+  return p;
 }
 
 }  // namespace
@@ -240,10 +275,7 @@ int rtc_release(int rhs_kind) {
   const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
   std::lock_guard<std::mutex> lk(g_mu);
   if (idx < 0 || idx >= (int)g_user.size() || !g_user[idx].alive) return -1;
-  for (auto& kv : g_user[idx].programs)
-    for (auto& ld : kv.second.loaded)
-      if (ld.second.module) (void)hipModuleUnload(ld.second.module);
-  g_user[idx].programs.clear();
+  g_user[idx].programs.clear();  // drops the registry's references; a module is unloaded when its last launch in flight lets go (~Program)
   g_user[idx].alive = false;
   return 0;
 }
@@ -271,19 +303,19 @@ static hipError_t launch(hipFunction_t f, int64_t n, int perBlock, void* arg, hi
 }
 
 hipError_t rtc_launch_solve(int rhs_kind, int integrator, const SolveArgs& a, hipStream_t s) {
-  Program* p = get_program(rhs_kind, integrator);
+  const std::shared_ptr<Program> p = get_program(rhs_kind, integrator);
   if (!p) return hipErrorInvalidValue;
   SolveArgs copy = a;
   return launch(p->solve, a.N, p->ivpsPerBlockSolve, &copy, s);
 }
 hipError_t rtc_launch_step(int rhs_kind, int integrator, const StepArgs& a, int negate, hipStream_t s) {
-  Program* p = get_program(rhs_kind, integrator);
+  const std::shared_ptr<Program> p = get_program(rhs_kind, integrator);
   if (!p) return hipErrorInvalidValue;
   StepArgs copy = a;
   return launch(negate ? p->stepNeg : p->stepPos, a.N, p->ivpsPerBlockStep, &copy, s);
 }
 hipError_t rtc_launch_advance(int rhs_kind, int integrator, const StepArgs& a, hipStream_t s) {
-  Program* p = get_program(rhs_kind, integrator);
+  const std::shared_ptr<Program> p = get_program(rhs_kind, integrator);
   if (!p) return hipErrorInvalidValue;
   if (!p->advance) { g_rtc_err = "no advance kernel: fixed-step integrator"; return hipErrorInvalidValue; }
   StepArgs copy = a;
@@ -291,7 +323,7 @@ hipError_t rtc_launch_advance(int rhs_kind, int integrator, const StepArgs& a, h
 }
 hipError_t rtc_launch_rhs(int rhs_kind, int64_t N, int64_t is, int64_t cs, double t, const double* y, double* dy, const Params& P,
                           hipStream_t s) {
-  Program* p = get_program(rhs_kind, -1);
+  const std::shared_ptr<Program> p = get_program(rhs_kind, -1);
   if (!p) return hipErrorInvalidValue;
   const int64_t grid = (N + kBlock - 1) / kBlock;
   if (grid <= 0) return hipSuccess;
@@ -331,7 +363,7 @@ int rtc_builtin_kind(int rhs_kind, int dim) {
 
 
 hipError_t rtc_launch_quad(int rhs_kind, int rule, const QuadArgs& a, hipStream_t s) {
-  Program* p = get_program(rhs_kind, -2);
+  const std::shared_ptr<Program> p = get_program(rhs_kind, -2);
   if (!p) return hipErrorInvalidValue;
   QuadArgs copy = a;
   return launch(p->quad[rule ? 1 : 0], a.N, kBlock, &copy, s);
