@@ -406,6 +406,23 @@ hipError_t launch_solve_lps(const SolveArgs& a, hipStream_t s) {
 }
 #endif
 
+// Kernel-argument prefetch: the argument struct is ~300 bytes and the compiler fetches it piecemeal, one s_load + s_waitcnt round
+// trip per basic block that first touches a field (five serialized scalar round trips before the first vector load of the advance
+// kernel).  Pinning the hot fields in SGPRs at the top of the kernel makes them ONE batch of s_loads behind one wait.
+#define NNHIP_PIN_SGPR64(x) asm volatile("" ::"s"(__builtin_bit_cast(unsigned long long, (x))))
+#define NNHIP_PIN_SGPR32(x) asm volatile("" ::"s"(x))
+NNHIP_DEV void pin_step_args(const StepArgs& a) {
+  NNHIP_PIN_SGPR64(a.N); NNHIP_PIN_SGPR64(a.ivpStride); NNHIP_PIN_SGPR64(a.compStride);
+  NNHIP_PIN_SGPR64(a.y_in); NNHIP_PIN_SGPR64(a.fsal_in); NNHIP_PIN_SGPR64(a.y_out); NNHIP_PIN_SGPR64(a.fsal_out);
+  NNHIP_PIN_SGPR64(a.t_io); NNHIP_PIN_SGPR64(a.dt_io); NNHIP_PIN_SGPR64(a.error); NNHIP_PIN_SGPR64(a.tEnd);
+  NNHIP_PIN_SGPR64(a.ctl.absTol); NNHIP_PIN_SGPR64(a.ctl.relTol); NNHIP_PIN_SGPR64(a.ctl.dtMax); NNHIP_PIN_SGPR64(a.ctl.dtMin);
+  NNHIP_PIN_SGPR64(a.perIvpParams); NNHIP_PIN_SGPR64(a.active); NNHIP_PIN_SGPR64(a.steps_io);
+  NNHIP_PIN_SGPR32(a.speculate); NNHIP_PIN_SGPR32(a.nPerIvp);
+  NNHIP_PIN_SGPR64(a.t_dev); NNHIP_PIN_SGPR64(a.dt_dev); NNHIP_PIN_SGPR64(a.t_uniform); NNHIP_PIN_SGPR64(a.dt_uniform); NNHIP_PIN_SGPR64(a.dt_used);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) NNHIP_PIN_SGPR64(a.P.p[k]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // one IntegratorProc call (step-streaming; state in HBM between calls)
 // ------------------------------------------------------------------------------------------------
@@ -459,6 +476,7 @@ NNHIP_DEV void step_body(const StepArgs& a, const Ops& ops, int64_t i, int64_t b
 template <int METHOD, class RHS, bool NEG>
 __global__ __launch_bounds__(kBlock) void step_tpi_kernel(const StepArgs a) {
   controller_prologue<MethodTraits<METHOD>::adaptive>();
+  pin_step_args(a);
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= a.N) return;
   const Params P = params_of(a, i);
@@ -496,6 +514,18 @@ NNHIP_DEV unsigned int advance_body(const StepArgs& a, const Ops& ops, int64_t i
       fsal[c] = ops.owns(c) ? a.fsal_in[base + c * a.compStride] : 0.0;
     }
     dt = a.dt_io[i];
+    // tie t to the other loads: without this the compiler schedules the `t < tEnd` test (and the wait for t) BEFORE it issues them
+    {
+      unsigned long long tb = __builtin_bit_cast(unsigned long long, t), db = __builtin_bit_cast(unsigned long long, dt);
+      asm volatile("" : "+v"(tb), "+v"(db));
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        unsigned long long yb = __builtin_bit_cast(unsigned long long, y[c]), fb = __builtin_bit_cast(unsigned long long, fsal[c]);
+        asm volatile("" : "+v"(tb), "+v"(yb), "+v"(fb));
+        y[c] = __builtin_bit_cast(double, yb); fsal[c] = __builtin_bit_cast(double, fb);
+      }
+      t = __builtin_bit_cast(double, tb); dt = __builtin_bit_cast(double, db);
+    }
     if (!(t < a.tEnd)) return 0u;  // :511
   } else {
     if (!(t < a.tEnd)) return 0u;  // :511 — finished IVPs touch no other memory
@@ -551,6 +581,7 @@ template <int METHOD, class RHS>
 __global__ __launch_bounds__(kBlock) NNHIP_ADV_TPI_ATTR void advance_tpi_kernel(const StepArgs a) {
   static_assert(MethodTraits<METHOD>::adaptive, "fixed-step methods share (t, dt): use the uniform streaming loop");
   controller_prologue();
+  pin_step_args(a);
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   unsigned int stillActive = 0;
   if (i < a.N) {
@@ -578,6 +609,7 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_LPS_ATTR void advance_lps_kernel(
   static_assert(DIM % CPL == 0 && 64 % LPSYS == 0, "a system must not straddle wavefronts");
   __shared__ double lds[2 * kBlock * CPL];
   controller_prologue();
+  pin_step_args(a);
   const int sysInBlock = threadIdx.x / LPSYS, c = (threadIdx.x % LPSYS) * CPL;
   const int64_t i = (int64_t)blockIdx.x * (kBlock / LPSYS) + sysInBlock;
   unsigned int stillActive = 0;
@@ -821,6 +853,7 @@ __global__ __launch_bounds__(kBlock) void step_lps_kernel(const StepArgs a) {
   static_assert(DIM % CPL == 0 && 64 % LPSYS == 0, "a system must not straddle wavefronts");
   __shared__ double lds[2 * kBlock * CPL];
   controller_prologue<MethodTraits<METHOD>::adaptive>();
+  pin_step_args(a);
   const int sysInBlock = threadIdx.x / LPSYS, c = (threadIdx.x % LPSYS) * CPL;
   const int64_t i = (int64_t)blockIdx.x * (kBlock / LPSYS) + sysInBlock;
   if (i >= a.N) return;
@@ -849,9 +882,12 @@ hipError_t launch_step_lps(const StepArgs& a, int negate, hipStream_t s) {
 // MODE 0: plain loads/stores, one tile per workgroup.   MODE 1: non-temporal loads+stores (streaming hint).
 // MODE 2: persistent grid-stride over tiles (grid = a few workgroups per CU).  MODE 3: MODE 2 + non-temporal.
 template <class RHS1, bool NEG, int VEC, int MODE>
+// The scalar arguments come first and as scalars (not structs): ode_tu_rk4_stream.hip is compiled with kernarg preloading, so
+// yin, yout, n, t, dt, dt/2, dt/6 arrive in SGPRs with the wave and the first global_load needs no scalar-load round trip.
 __global__ __launch_bounds__(kBlock) void rk4_stream_vec_kernel(const double* yin, double* yout,  // may alias (in-place stepping): no __restrict__
-                                                                int64_t n, double t, const Rk4Dt h, const Params P) {
+                                                                int64_t n, double t, double h_dt, double h_hdt, double h_dt6, const Params P) {
   static_assert(RHS1::dim == 1, "scalar RHS only");
+  const Rk4Dt h{h_dt, h_hdt, h_dt6};
   constexpr bool NT = (MODE & 1) != 0;
   constexpr bool PERSIST = (MODE & 2) != 0;
   constexpr int64_t TILE = (int64_t)kBlock * 2 * VEC;
@@ -924,6 +960,10 @@ __global__ __launch_bounds__(kBlock) void fixed_stream_vec_kernel(const FixedVec
   static_assert(!MethodTraits<METHOD>::adaptive && IPL % 2 == 0, "fixed-step methods, an even number of IVPs per lane");
   constexpr int D = RHS::dim;
   constexpr int PAIRS = IPL / 2;
+  NNHIP_PIN_SGPR64(a.yin); NNHIP_PIN_SGPR64(a.yout); NNHIP_PIN_SGPR64(a.fsalOut); NNHIP_PIN_SGPR64(a.tDev); NNHIP_PIN_SGPR64(a.dtDev);
+  NNHIP_PIN_SGPR64(a.N); NNHIP_PIN_SGPR32(a.aos); NNHIP_PIN_SGPR64(a.t); NNHIP_PIN_SGPR64(a.dt);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) NNHIP_PIN_SGPR64(a.P.p[k]);
   const TpiOps<RHS, NEG> ops{a.P};
   const int64_t N = a.N;
   const int aos = a.aos;
@@ -1041,8 +1081,8 @@ hipError_t launch_rk4_stream_vec(const double* yin, double* yout, int64_t n, dou
   if (grid <= 0) return hipSuccess;
   if (MODE & 2) { const int64_t cap = 256LL * tune.blocksPerCU; if (grid > cap) grid = cap; }
   const Rk4Dt h{dt, 0.5 * dt, dt / 6.0};  // host IEEE double ops == the device's (this TU is built -ffp-contract=off)
-  if (negate) return launch_kernel(rk4_stream_vec_kernel<RHS1, true, VEC, MODE>, dim3((unsigned)grid), dim3(kBlock), s, yin, yout, n, t, h, P);
-  return launch_kernel(rk4_stream_vec_kernel<RHS1, false, VEC, MODE>, dim3((unsigned)grid), dim3(kBlock), s, yin, yout, n, t, h, P);
+  if (negate) return launch_kernel(rk4_stream_vec_kernel<RHS1, true, VEC, MODE>, dim3((unsigned)grid), dim3(kBlock), s, yin, yout, n, t, h.dt, h.hdt, h.dt6, P);
+  return launch_kernel(rk4_stream_vec_kernel<RHS1, false, VEC, MODE>, dim3((unsigned)grid), dim3(kBlock), s, yin, yout, n, t, h.dt, h.hdt, h.dt6, P);
 }
 
 using FixedVecLaunchFn = hipError_t (*)(const FixedVecArgs& a, int negate, int ipl, hipStream_t s);
