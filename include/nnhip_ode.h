@@ -192,6 +192,11 @@ int nnhip_ode_solve_batch_tend_f64_dev(const nnhip_ode_options* opt, int integra
  * integrated in that order.  Fixed-step integrators run unsorted (no divergence).  per_ivp_params may be NULL (n_per_ivp = 0).
  * `ws`: device workspace of nnhip_ode_solve_sorted_workspace_bytes(N, n_t) bytes.  N < 2^31. */
 int64_t nnhip_ode_solve_sorted_workspace_bytes(int64_t N, int n_t);
+/* host-pointer form (all arrays in host memory, incl. sort_key; staged through `device` in one piece) */
+int nnhip_ode_solve_batch_sorted_f64(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
+                                     const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t N, int dim, int layout,
+                                     const double* tspan, int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
+                                     int64_t* rejected_out, int64_t max_steps, const double* sort_key, int probe_steps, int device);
 int nnhip_ode_solve_batch_sorted_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
                                          int n_params, const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t N,
                                          int dim, int layout, const double* tspan, int n_t, double* t_out, double* y_out,

@@ -119,8 +119,10 @@ template <class T = double>
 inline OdeSolution solveODE(const RhsSpec& f, const OdeBatch& y0, const std::vector<double>& tspan,
                             const ODEoptions& options = DEFAULT_ODEoptions(), const NumContext<T>* ctx = nullptr,
                             const std::string& integrator = "dopri54", int device = 0, int n_gpus = 1,
-                            const std::vector<std::vector<double>>& sweep = {}) {
+                            const std::vector<std::vector<double>>& sweep = {}, const std::vector<double>& sortBy = {}, bool autoSort = false) {
   // sweep[k][i]: value of RHS parameter k for IVP i (a parameter sweep: every IVP its own ctx); empty = one ctx for the batch
+  // sortBy (one key per IVP) / autoSort: divergence binning below the C ABI (nnhip_ode_solve_batch_sorted_f64) for heterogeneous
+  // batches of adaptive solves; results stay in the caller's order and are bit-identical
   const int integ = nnhip_ode_integrator_id(integrator.c_str());
   if (integ < 0) throw std::invalid_argument(integrator + " is not a valid integrator");  // ode.nim:651
   const std::vector<double> p = f.params(ctx);
@@ -134,6 +136,19 @@ inline OdeSolution solveODE(const RhsSpec& f, const OdeBatch& y0, const std::vec
     if (!sweep.empty()) throw std::invalid_argument("parameter sweeps are single-device");
     rc = nnhip_ode_solve_batch_multi_gpu_f64(&options, integ, f.kind, p.data(), (int)p.size(), y0.data.data(), y0.N, y0.dim, y0.layout,
                                              tspan.data(), n_t, sol.t.data(), yout.data(), sol.ny.data(), 0, &sol.stats, n_gpus);
+  } else if (!sortBy.empty() || autoSort) {
+    if (!sortBy.empty() && (int64_t)sortBy.size() != y0.N) throw std::invalid_argument("sortBy needs one key per IVP");
+    std::vector<double> flat;
+    for (const auto& row : sweep) {
+      if ((int64_t)row.size() != y0.N) throw std::invalid_argument("sweep rows must have one value per IVP");
+      flat.insert(flat.end(), row.begin(), row.end());
+    }
+    rc = nnhip_ode_solve_batch_sorted_f64(&options, integ, f.kind, p.data(), (int)p.size(), flat.empty() ? nullptr : flat.data(), (int)sweep.size(),
+                                          y0.data.data(), y0.N, y0.dim, y0.layout, tspan.data(), n_t, sol.t.data(), yout.data(), sol.ny.data(), nullptr,
+                                          nullptr, 0, sortBy.empty() ? nullptr : sortBy.data(), 0, device);
+    int nt = 0;
+    if (rc == 0) rc = nnhip_ode_time_grid(&options, tspan.data(), n_t, nullptr, &nt);
+    sol.stats.n_t_out = nt;
   } else {
     std::vector<double> flat;
     for (const auto& row : sweep) {

@@ -46,9 +46,12 @@ proc check(rc: cint) =
 
 proc solveODE*(f: RhsSpec, y0: OdeBatch, tspan: openArray[float],
                options: ODEoptions = newODEoptions(), ctx: NumContext[OdeBatch, float] = nil,
-               integrator = "dopri54", nGpus = 1, sweep: seq[seq[float]] = @[]): (seq[float], seq[OdeBatch]) =
+               integrator = "dopri54", nGpus = 1, sweep: seq[seq[float]] = @[],
+               sortBy: seq[float] = @[], autoSort = false): (seq[float], seq[OdeBatch]) =
   ## Batched drop-in for ode.nim:589-651: same parameter names, order and defaults; returns (t, y) where
   ## y[j] is the whole batch at t[j].  sweep[k][i] = value of RHS parameter k for IVP i (every IVP its own ctx); single device.
+  ## sortBy (one key per IVP) / autoSort: integrate heterogeneous batches in a divergence-friendly order below the C ABI
+  ## (nnhip_ode_solve_batch_sorted_f64); results stay in the caller's order and are bit-identical.
   var ctx = ctx
   if ctx.isNil: ctx = newNumContext[OdeBatch, float]()               # ode.nim:604-606
   let integ = nnhip_ode_integrator_id(integrator.cstring)           # toLower + dispatch, ode.nim:607-651
@@ -68,6 +71,21 @@ proc solveODE*(f: RhsSpec, y0: OdeBatch, tspan: openArray[float],
     check nnhip_ode_solve_batch_multi_gpu_f64(addr opt, integ, rhsKind, pp, params.len.cint, addr y0d[0], y0.n.int64,
                                               y0.dim.cint, y0.layout.cint, addr ts[0], ts.len.cint, addr tOut[0],
                                               addr yOut[0], addr ny[0], 0, addr stats, nGpus.cint)
+  elif sortBy.len > 0 or autoSort:
+    if sortBy.len > 0 and sortBy.len != y0.n: raise newException(ValueError, "sortBy needs one key per IVP")
+    var flat: seq[cdouble]
+    for row in sweep:
+      for v in row: flat.add(v.cdouble)
+    let sp = if flat.len > 0: addr flat[0] else: nil
+    var keys: seq[cdouble]
+    for v in sortBy: keys.add(v.cdouble)
+    let kp = if keys.len > 0: addr keys[0] else: nil
+    check nnhip_ode_solve_batch_sorted_f64(addr opt, integ, rhsKind, pp, params.len.cint, sp, sweep.len.cint, addr y0d[0], y0.n.int64,
+                                           y0.dim.cint, y0.layout.cint, addr ts[0], ts.len.cint, addr tOut[0], addr yOut[0],
+                                           addr ny[0], nil, nil, 0, kp, 0, 0)
+    var nt: cint
+    check nnhip_ode_time_grid(addr opt, addr ts[0], ts.len.cint, nil, addr nt)
+    stats.nTOut = nt
   else:
     var flat: seq[cdouble]
     for row in sweep:

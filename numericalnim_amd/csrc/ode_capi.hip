@@ -702,6 +702,54 @@ int nnhip_ode_solve_batch_sorted_f64_dev(const nnhip_ode_options* opt, int integ
   return launch_solve_range(ps, 0, N, s);
 }
 
+// Host-pointer form of the sorted solve (what a Nim host holding `seq`s calls): everything staged through the device in one piece —
+// the order of integration needs the whole batch resident, so the chunked transfer overlap of the plain host entry does not apply.
+int nnhip_ode_solve_batch_sorted_f64(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
+                                     const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t N, int dim, int layout,
+                                     const double* tspan, int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
+                                     int64_t* rejected_out, int64_t max_steps, const double* sort_key, int probe_steps, int device) {
+  if (N < 0 || dim < 1 || n_t < 0) return fail(NNHIP_EVALUE, "bad sizes");
+  int ndev = nnhip_device_count();
+  if (ndev < 0) return ndev;
+  if (ndev == 0) return fail(NNHIP_EHIP, "no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(NNHIP_EVALUE, "device %d out of range [0,%d)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  HostSolveCtx* hc = nullptr;
+  int rc = host_ctx_acquire(device, 0, &hc);
+  if (rc) { host_ctx_release(hc); return rc; }
+  hipStream_t st = hc->s[0];
+  const size_t nState = (size_t)N * dim, nOut = nState * (size_t)n_t;
+  const int64_t wsBytes = nnhip_ode_solve_sorted_workspace_bytes(N, n_t);
+  // one allocation: y0 | out | ny | steps | rejected | key | per-IVP table | workspace
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t oY0 = 0, oOut = oY0 + up(nState * 8), oNy = oOut + up(nOut * 8), oSt = oNy + up((size_t)N * 4), oRj = oSt + up((size_t)N * 8),
+               oKey = oRj + up((size_t)N * 8), oPer = oKey + up((size_t)N * 8), oWs = oPer + up((size_t)(n_per_ivp > 0 ? n_per_ivp : 0) * (size_t)N * 8),
+               total = oWs + up((size_t)wsBytes) + 256;
+  char* d = nullptr;
+  hipError_t e = hipMalloc((void**)&d, total);
+  if (e != hipSuccess) { host_ctx_release(hc); return fail(e == hipErrorOutOfMemory ? NNHIP_ENOMEM : NNHIP_EHIP, "hipMalloc(%zu) failed: %s", total, hipGetErrorString(e)); }
+  auto done = [&](int code) { (void)hipStreamSynchronize(st); (void)hipFree(d); host_ctx_release(hc); return code; };
+#define HIP_TRY_S(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return done(fail(NNHIP_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e))); } while (0)
+  if (nState) HIP_TRY_S(hipMemcpyAsync(d + oY0, y0, nState * 8, hipMemcpyHostToDevice, st));
+  if (sort_key && N) HIP_TRY_S(hipMemcpyAsync(d + oKey, sort_key, (size_t)N * 8, hipMemcpyHostToDevice, st));
+  if (n_per_ivp > 0 && N) {
+    if (!per_ivp_params) return done(fail(NNHIP_EVALUE, "bad per-IVP parameter table"));
+    HIP_TRY_S(hipMemcpyAsync(d + oPer, per_ivp_params, (size_t)n_per_ivp * (size_t)N * 8, hipMemcpyHostToDevice, st));
+  }
+  rc = nnhip_ode_solve_batch_sorted_f64_dev(opt, integrator, rhs_kind, rhs_params, n_params, n_per_ivp > 0 ? (const double*)(d + oPer) : nullptr, n_per_ivp,
+                                            (const double*)(d + oY0), N, dim, layout, tspan, n_t, t_out, (double*)(d + oOut), ny_out ? (int32_t*)(d + oNy) : nullptr,
+                                            steps_out ? (int64_t*)(d + oSt) : nullptr, rejected_out ? (int64_t*)(d + oRj) : nullptr, max_steps,
+                                            sort_key ? (const double*)(d + oKey) : nullptr, probe_steps, d + oWs, wsBytes, st);
+  if (rc) return done(rc);
+  if (nOut) HIP_TRY_S(hipMemcpyAsync(y_out, d + oOut, nOut * 8, hipMemcpyDeviceToHost, st));
+  if (ny_out && N) HIP_TRY_S(hipMemcpyAsync(ny_out, d + oNy, (size_t)N * 4, hipMemcpyDeviceToHost, st));
+  if (steps_out && N) HIP_TRY_S(hipMemcpyAsync(steps_out, d + oSt, (size_t)N * 8, hipMemcpyDeviceToHost, st));
+  if (rejected_out && N) HIP_TRY_S(hipMemcpyAsync(rejected_out, d + oRj, (size_t)N * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY_S(hipStreamSynchronize(st));
+#undef HIP_TRY_S
+  return done(NNHIP_OK);
+}
+
 int nnhip_ode_solve_batch_f64(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
                               int n_params, const double* y0, int64_t N, int dim, int layout, const double* tspan,
                               int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,

@@ -270,8 +270,6 @@ def solveODE(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=
                                                        rj.data_ptr() if return_counts else None, int(max_steps), ws.data_ptr(), wsb,
                                                        stream))
     else:
-        if sort_by is not None:
-            raise ValueError("sort_by needs a torch CUDA batch")
         y0c = np.ascontiguousarray(np.asarray(y0, dtype=np.float64))
         if out is not None:
             if not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.flags.c_contiguous and out.shape == (n_t,) + y0c.shape):
@@ -289,6 +287,20 @@ def solveODE(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=
             if swa.ndim != 2 or swa.shape[1] != N:
                 raise ValueError("sweep must have shape [k, N]")
             swh, kh = swa.ctypes.data, int(swa.shape[0])
+        if sort_by is not None:  # host-pointer form of the sorted solve (the entry a Nim host holding seqs would call)
+            keyh = None
+            if not isinstance(sort_by, str):
+                keya = np.ascontiguousarray(np.asarray(sort_by, dtype=np.float64))
+                if keya.shape != (N,):
+                    raise ValueError("sort_by must have shape [N]")
+                keyh = keya.ctypes.data
+            elif sort_by != "auto":
+                raise ValueError('sort_by must be an array of shape [N] or "auto"')
+            _check(L.nnhip_ode_solve_batch_sorted_f64(C.byref(options), integ, f.kind, pp, int(p.size), swh, kh, y0c.ctypes.data, N, dim, layout, tsp, n_t, tp,
+                                                      y.ctypes.data, ny.ctypes.data if return_counts else None, st.ctypes.data if return_counts else None,
+                                                      rj.ctypes.data if return_counts else None, int(max_steps), keyh, 0, 0))
+            t = t_out[:ntout.value].copy()
+            return (t, y, dict(ny=ny, steps=st, rejected=rj)) if return_counts else (t, y)
         _check(L.nnhip_ode_solve_batch_sweep_f64(C.byref(options), integ, f.kind, pp, int(p.size), swh, kh, y0c.ctypes.data, N, dim, layout, tsp,
                                                  n_t, tp, y.ctypes.data, ny.ctypes.data if return_counts else None,
                                                  st.ctypes.data if return_counts else None, rj.ctypes.data if return_counts else None,

@@ -88,6 +88,15 @@ int main() {
       OdeSolution one = solveODE(f, y1, tspan, DEFAULT_ODEoptions(), &ci, "dopri54");
       for (size_t j = 0; j < one.y.size(); ++j) CHECK(all.y[j].at(i, 0) == one.y[j].at(0, 0));
     }
+    // divergence binning below the C ABI: caller's key and automatic probe give the bits of the unsorted solve, rows in caller order
+    OdeBatch yw = OdeBatch::zeros(257, 1);
+    std::vector<double> aw(257);
+    for (int i = 0; i < 257; ++i) { yw.at(i, 0) = 1.0 + 0.001 * i; aw[i] = -0.05 - 0.037 * ((i * 73) % 257); }
+    const OdeSolution plain = solveODE(f, yw, tspan, DEFAULT_ODEoptions(), &ctx, "tsit54", 0, 1, {aw});
+    const OdeSolution byKey = solveODE(f, yw, tspan, DEFAULT_ODEoptions(), &ctx, "tsit54", 0, 1, {aw}, aw);
+    const OdeSolution byProbe = solveODE(f, yw, tspan, DEFAULT_ODEoptions(), &ctx, "tsit54", 0, 1, {aw}, {}, true);
+    CHECK(byKey.t == plain.t && byProbe.t == plain.t && byKey.ny == plain.ny && byProbe.ny == plain.ny);
+    for (size_t j = 0; j < plain.y.size(); ++j) CHECK(byKey.y[j].data == plain.y[j].data && byProbe.y[j].data == plain.y[j].data);
   }
   // the consumers, as tests/test_integrate.nim:19-21, 67-95 and tests/test_interpolate.nim:5-18, 104-145 use them
   {

@@ -575,6 +575,11 @@ def test_sort_by_returns_identical_results_in_caller_order(nn, dev):
                          sort_by=key)
         assert torch.equal(h0[1], h1[1]) and all(torch.equal(h0[2][k], h1[2][k]) for k in h0[2])
     assert int(h0[2]["steps"].max()) > 2 * int(h0[2]["steps"].min())   # the batch really is heterogeneous
+    # host-pointer form (numpy batch, numpy key / "auto"): nnhip_ode_solve_batch_sorted_f64, what a Nim host holding seqs calls
+    a = nn.solveODE(nn.Rhs.vanderpol(), y0, ts, opt, integrator="tsit54", sweep=mu[None, :], return_counts=True)
+    for key in (mu.cpu().numpy(), "auto"):
+        hh = nn.solveODE(nn.Rhs.vanderpol(), y0.cpu().numpy(), ts, opt, integrator="tsit54", sweep=mu[None, :].cpu().numpy(), return_counts=True, sort_by=key)
+        assert np.array_equal(hh[1], a[1].cpu().numpy()) and all(np.array_equal(hh[2][k], a[2][k].cpu().numpy()) for k in a[2])
 
 
 def test_parameter_sweep_through_the_host_pointer_entry(nn, dev):
