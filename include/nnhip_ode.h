@@ -178,11 +178,23 @@ int nnhip_ode_solve_batch_sweep_f64_dev(const nnhip_ode_options* opt, int integr
  * solveODE call with its own tspan, ode.nim:589-591, 476-480).  y_out [2][dim][N] / [2][N][dim] holds per IVP the rows the reference
  * returns for tspan_i.sorted(): (y0, y(tEnd)) when tEnd > tStart; (y(tEnd), y0) when tEnd < tStart (backward branch, :544-584);
  * the single row y0 when they coincide (ny_out[i] = 1, second row NaN — the reference returns one state for two times there).
- * Non-finite t_end[i] is not checked on the device: such an IVP runs until max_steps (give one) — as the reference would never return. */
+ * A non-finite t_end[i] gives ny_out[i] = -1 and NaN rows (the reference would never return from that call). */
 int nnhip_ode_solve_batch_tend_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
                                        int n_params, const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t N, int dim,
                                        int layout, const double* t_end, double* y_out, int32_t* ny_out, int64_t* steps_out,
                                        int64_t* rejected_out, int64_t max_steps, void* stream);
+
+/* Every IVP its own solveODE call: per-IVP tspan ends AND per-IVP ODEoptions fields (each reference call owns both, ode.nim:589-591,
+ * 26-34).  t_end is required; t_start, abs_tol, rel_tol, dt_max, dt_min, dt_fixed are nullable device arrays [N] (NULL = the value in
+ * `opt`).  Per-IVP option values go through abs() like newODEoptions does (ode.nim:101-102).  An IVP whose options newODEoptions would
+ * reject (dtMax < dtMin), that could never finish (fixed-step dt == 0; dtMin == 0 without max_steps) or whose span is not finite gets
+ * ny_out[i] = -1 and NaN rows (the reference raises ValueError / never returns for that call; the other calls are unaffected). */
+int nnhip_ode_solve_batch_calls_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
+                                        int n_params, const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t N, int dim,
+                                        int layout, const double* t_end, const double* t_start, const double* abs_tol,
+                                        const double* rel_tol, const double* dt_max, const double* dt_min, const double* dt_fixed,
+                                        double* y_out, int32_t* ny_out, int64_t* steps_out, int64_t* rejected_out, int64_t max_steps,
+                                        void* stream);
 
 /* Divergence binning: the same fused solve for batches whose members take very different step sequences (the reference runs
  * them one after the other, ode.nim:589-591; on a wavefront they share an instruction stream).  The IVPs are INTEGRATED in

@@ -624,28 +624,46 @@ int nnhip_ode_solve_batch_sweep_f64_dev(const nnhip_ode_options* opt, int integr
   return launch_solve_range(ps, 0, N, (hipStream_t)stream);
 }
 
-// ---- every IVP its own tspan end -------------------------------------------------------------------------------------
-// In the reference every IVP is a solveODE call with its own tspan (ode.nim:589-591, 476-480).  Here: tspan_i = [options.tStart,
-// t_end[i]] (device array [N]).  Output y_out [2][dim][N] (SoA) / [2][N][dim] (AoS) holds, per IVP, the rows the reference returns
-// for tspan.sorted(): (y0, y(tEnd)) when tEnd > tStart, (y(tEnd), y0) when tEnd < tStart (backward branch), and the single row y0
-// when they coincide (ny_out[i] = 1, second row NaN).  Everything else as nnhip_ode_solve_batch_sweep_f64_dev.
+// ---- every IVP its own solveODE call ------------------------------------------------------------------------------------
+// In the reference every IVP is a solveODE call with its own tspan AND its own ODEoptions (ode.nim:589-591, 476-480, 26-34).
+// Here: tspan_i = [t_start[i] (or options.tStart), t_end[i]] and, optionally, per-IVP absTol / relTol / dtMax / dtMin / dt (device
+// arrays [N]; NULL = the batch-wide value of `opt`).  Output y_out [2][dim][N] (SoA) / [2][N][dim] (AoS) holds, per IVP, the rows the
+// reference returns for tspan.sorted(): (y0, y(tEnd)) when tEnd > tStart, (y(tEnd), y0) when tEnd < tStart (backward branch), the
+// single row y0 when they coincide (ny_out[i] = 1, second row NaN).  Per-IVP option values go through abs() like newODEoptions
+// does; an IVP whose options the reference's newODEoptions would reject (dtMax < dtMin), that could never finish (fixed-step dt == 0;
+// dtMin == 0 without max_steps) or whose span is not finite gets ny_out[i] = -1 and NaN rows.
+int nnhip_ode_solve_batch_calls_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
+                                        const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t N, int dim, int layout,
+                                        const double* t_end, const double* t_start, const double* abs_tol, const double* rel_tol,
+                                        const double* dt_max, const double* dt_min, const double* dt_fixed, double* y_out, int32_t* ny_out,
+                                        int64_t* steps_out, int64_t* rejected_out, int64_t max_steps, void* stream) {
+  if (N > 0 && !t_end) return fail(NNHIP_EVALUE, "t_end is NULL");
+  if (!opt) return fail(NNHIP_EVALUE, "options is NULL");
+  // a 2-point placeholder tspan on the forward side: validation, dispatch and the batch-wide option fields; the rest is per IVP
+  const double tspan[2] = {opt->tStart, opt->tStart + 1.0};
+  nnhip_ode_options o = *opt;
+  if (integrator >= 0 && integrator < NNHIP_N_INTEGRATORS) {  // per-IVP values replace the fields prepare_solve would refuse as batch-wide ones
+    if (!kMethods[integrator].adaptive && dt_fixed && !(o.dt > 0.0)) o.dt = 1.0;
+    if (kMethods[integrator].adaptive && dt_min && !(o.dtMin > 0.0)) o.dtMin = o.dtMax > 0.0 ? o.dtMax : 1.0;
+  }
+  PreparedSolve ps;
+  int rc = prepare_solve(&o, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y0, N, dim, layout, tspan, 2, nullptr, y_out, ny_out,
+                         steps_out, rejected_out, max_steps, nullptr, 0, nullptr, nullptr, (hipStream_t)stream, ps);
+  if (rc) return rc;
+  ps.a.perCall.tEnd = t_end; ps.a.perCall.tStart = t_start; ps.a.perCall.absTol = abs_tol; ps.a.perCall.relTol = rel_tol;
+  ps.a.perCall.dtMax = dt_max; ps.a.perCall.dtMin = dt_min; ps.a.perCall.dt = dt_fixed;
+  ps.a.nZero = 1;                                   // tStart_i is in every tspan_i
+  ps.a.uniformFull[0] = ps.a.uniformFull[1] = -1;   // no batch-wide step schedule: the spans differ
+  ps.a.nTail[0] = ps.a.nTail[1] = 0;
+  return launch_solve_range(ps, 0, N, (hipStream_t)stream);
+}
+
 int nnhip_ode_solve_batch_tend_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
                                        const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t N, int dim, int layout,
                                        const double* t_end, double* y_out, int32_t* ny_out, int64_t* steps_out, int64_t* rejected_out,
                                        int64_t max_steps, void* stream) {
-  if (N > 0 && !t_end) return fail(NNHIP_EVALUE, "t_end is NULL");
-  if (!opt) return fail(NNHIP_EVALUE, "options is NULL");
-  // a 2-point placeholder tspan on the forward side: validation, dispatch and the option-derived fields; the directions are per IVP
-  const double tspan[2] = {opt->tStart, opt->tStart + 1.0};
-  PreparedSolve ps;
-  int rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y0, N, dim, layout, tspan, 2, nullptr, y_out, ny_out,
-                         steps_out, rejected_out, max_steps, nullptr, 0, nullptr, nullptr, (hipStream_t)stream, ps);
-  if (rc) return rc;
-  ps.a.tEndPerIvp = t_end;
-  ps.a.nZero = 1;                                   // t0 is in every tspan_i
-  ps.a.uniformFull[0] = ps.a.uniformFull[1] = -1;   // no batch-wide step schedule: the spans differ
-  ps.a.nTail[0] = ps.a.nTail[1] = 0;
-  return launch_solve_range(ps, 0, N, (hipStream_t)stream);
+  return nnhip_ode_solve_batch_calls_f64_dev(opt, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y0, N, dim, layout, t_end, nullptr,
+                                             nullptr, nullptr, nullptr, nullptr, nullptr, y_out, ny_out, steps_out, rejected_out, max_steps, stream);
 }
 
 // ---- divergence binning below the boundary -----------------------------------------------------------------------

@@ -58,10 +58,14 @@ struct SolveArgs {
   const uint32_t* perm;
   // nullable [N]: how far the IVP got, |t - t0| summed over the directions integrated (= the full span unless max_steps cut it short)
   double* progress_out;
-  // nullable [N]: every IVP its own tspan = [t0, tEndPerIvp[i]] (each reference call owns its tspan, ode.nim:589-591); n_t == 2.
-  // Overrides nPos / nNeg / tEndPos / tEndNeg per IVP: tEnd > t0 integrates forward (rows y0, y(tEnd)), tEnd < t0 backward (rows
-  // y(tEnd), y0), tEnd == t0 yields the reference's single row y0.
-  const double* tEndPerIvp;
+  // Every IVP its own solveODE call (each reference call owns its tspan AND its ODEoptions, ode.nim:589-591, 476-480): device
+  // arrays [N], all nullable except tEnd (tEnd == nullptr: feature off).  tspan_i = [tStart_i, tEnd_i]; n_t == 2.  tEnd > tStart
+  // integrates forward (rows y0, y(tEnd)), tEnd < tStart backward (rows y(tEnd), y0), tEnd == tStart yields the reference's single
+  // row y0.  Option values go through abs() as in newODEoptions (:101-102); an IVP whose options newODEoptions would reject
+  // (dtMax < dtMin) or that could never finish (fixed-step dt == 0; dtMin == 0 without max_steps) gets ny = -1 and NaN rows.
+  struct PerCall {
+    const double *tEnd, *tStart, *absTol, *relTol, *dtMax, *dtMin, *dt;
+  } perCall;
 };
 
 struct StepArgs {
@@ -177,14 +181,40 @@ NNHIP_DEV void solve_body(const SolveArgs& a0, const OpsF& opsF, const OpsB& ops
     for (int q = 0; q < 4; ++q) a.tailDt[d][q] = a0.tailDt[d][q];
   }
   constexpr bool DENSE = MODE == 1;
-  if constexpr (MODE == 2) {  // its own instantiation: per-lane direction bookkeeping costs registers the other kernels do not have to spare
-    const double te = a0.tEndPerIvp[ivp];
+  [[maybe_unused]] bool callInvalid = false;
+  if constexpr (MODE == 2) {  // its own instantiation: per-lane call data costs registers the other kernels do not have to spare
+    const SolveArgs::PerCall& pc = a0.perCall;
+    const double te = pc.tEnd[ivp];
+    if (pc.tStart) a.t0 = pc.tStart[ivp];
+    if (pc.absTol) a.ctl.absTol = fabs(pc.absTol[ivp]);
+    if (pc.relTol) a.ctl.relTol = fabs(pc.relTol[ivp]);
+    if (pc.dtMax) a.ctl.dtMax = fabs(pc.dtMax[ivp]);
+    if (pc.dtMin) a.ctl.dtMin = fabs(pc.dtMin[ivp]);
+    if constexpr (MethodTraits<METHOD>::adaptive) {
+      if (pc.dtMax || pc.dtMin) a.dtInit = sqrt(a.ctl.dtMax * a.ctl.dtMin);             // :491-493
+      callInvalid = a.ctl.dtMax < a.ctl.dtMin || (!(a.ctl.dtMin > 0.0) && a.maxSteps <= 0);   // newODEoptions :95-96 / would never finish
+    } else {
+      if (pc.dt) a.dtInit = fabs(pc.dt[ivp]);                                             // :495-496
+      callInvalid = !(a.dtInit > 0.0);
+    }
     a.nPos = a.t0 < te ? 1 : 0;   // tspan.filterIt(it > t0) (:479)
     a.nNeg = te < a.t0 ? 1 : 0;   // :480
     a.tEndPos = te;
     a.tEndNeg = -te;
+    if (!(te == te) || !(a.t0 == a.t0) || fabs(te) == __longlong_as_double(0x7ff0000000000000LL)) callInvalid = true;  // non-finite spans never end
   }
   constexpr int D = OpsF::D;
+  if constexpr (MODE == 2) {
+    if (callInvalid) {
+      const double qn = __longlong_as_double(0x7ff8000000000000LL);
+      for (int j = 0; j < a.n_t; ++j)
+#pragma unroll
+        for (int c = 0; c < D; ++c)
+          if (opsF.owns(c)) out[(int64_t)j * a.rowStride + c * a.compStride] = qn;
+      ls.ny = -1;
+      return;
+    }
+  }
   double y0[D];
 #pragma unroll
   for (int c = 0; c < D; ++c) y0[c] = opsF.owns(c) ? y0p[c * a.compStride] : 0.0;
@@ -343,7 +373,7 @@ template <int METHOD, class RHS>
 hipError_t launch_solve_tpi(const SolveArgs& a, hipStream_t s) {
   const int64_t grid = (a.N + kBlock - 1) / kBlock;
   if (grid <= 0) return hipSuccess;
-  if (a.tEndPerIvp) return launch_kernel(solve_tpi_kernel<METHOD, RHS, 2>, dim3((unsigned)grid), dim3(kBlock), s, a);  // every IVP its own tEnd
+  if (a.perCall.tEnd) return launch_kernel(solve_tpi_kernel<METHOD, RHS, 2>, dim3((unsigned)grid), dim3(kBlock), s, a);  // every IVP its own tEnd
   if (!a.useDense) return launch_kernel(solve_tpi_kernel<METHOD, RHS, 0>, dim3((unsigned)grid), dim3(kBlock), s, a);  // lean: no Hermite history
   return launch_kernel(solve_tpi_kernel<METHOD, RHS, 1>, dim3((unsigned)grid), dim3(kBlock), s, a);
 }
@@ -400,7 +430,7 @@ hipError_t launch_solve_lps(const SolveArgs& a, hipStream_t s) {
   constexpr int perBlock = kBlock / (RHS::dim / CPL);
   const int64_t grid = (a.N + perBlock - 1) / perBlock;
   if (grid <= 0) return hipSuccess;
-  if (a.tEndPerIvp) return launch_kernel(solve_lps_kernel<METHOD, RHS, CPL, SHUFFLE_NORM, 2>, dim3((unsigned)grid), dim3(kBlock), s, a);
+  if (a.perCall.tEnd) return launch_kernel(solve_lps_kernel<METHOD, RHS, CPL, SHUFFLE_NORM, 2>, dim3((unsigned)grid), dim3(kBlock), s, a);
   if (!a.useDense) return launch_kernel(solve_lps_kernel<METHOD, RHS, CPL, SHUFFLE_NORM, 0>, dim3((unsigned)grid), dim3(kBlock), s, a);
   return launch_kernel(solve_lps_kernel<METHOD, RHS, CPL, SHUFFLE_NORM, 1>, dim3((unsigned)grid), dim3(kBlock), s, a);
 }

@@ -368,10 +368,13 @@ def fixedStream(f, y, t0, tEnd, options=None, ctx=None, integrator="rk4", layout
     return final, nsteps.value
 
 
-def solveODEPerIvpEnd(f, y0, t_end, options=None, ctx=None, integrator="dopri54", layout=LAYOUT_SOA, max_steps=0, sweep=None):
-    """A batch of solveODE(f, y0_i, [options.tStart, t_end[i]], options, ctx, integrator) calls — every IVP with its own tspan end
-    (ode.nim:589-591: each reference call owns its tspan).  t_end: CUDA float64 tensor [N].  Returns (y [2, *y0.shape], counts):
-    the two rows the reference returns for the sorted 2-point tspan of each IVP (nnhip_ode_solve_batch_tend_f64_dev)."""
+def solveODEPerIvpEnd(f, y0, t_end, options=None, ctx=None, integrator="dopri54", layout=LAYOUT_SOA, max_steps=0, sweep=None,
+                      t_start=None, absTol=None, relTol=None, dtMax=None, dtMin=None, dt=None):
+    """A batch of solveODE(f, y0_i, [tStart_i, t_end[i]], options_i, ctx, integrator) calls — every IVP with its own tspan and,
+    optionally, its own ODEoptions fields (ode.nim:589-591, 26-34: each reference call owns both).  t_end and the optional
+    t_start / absTol / relTol / dtMax / dtMin / dt: CUDA float64 tensors [N].  Returns (y [2, *y0.shape], counts): the two rows the
+    reference returns for the sorted 2-point tspan of each IVP; ny = -1 marks a call the reference would have refused
+    (nnhip_ode_solve_batch_calls_f64_dev)."""
     import torch
     L = _lib.lib()
     options = options if options is not None else _default_options()
@@ -392,9 +395,17 @@ def solveODEPerIvpEnd(f, y0, t_end, options=None, ctx=None, integrator="dopri54"
         ny = torch.empty(N, dtype=torch.int32, device=y0c.device)
         st = torch.empty(N, dtype=torch.int64, device=y0c.device)
         rj = torch.empty(N, dtype=torch.int64, device=y0c.device)
-        _check(L.nnhip_ode_solve_batch_tend_f64_dev(C.byref(options), integ, f.kind, pp, int(p.size), sw.data_ptr() if sw is not None else None,
-                                                    int(sw.shape[0]) if sw is not None else 0, y0c.data_ptr(), N, dim, layout, te.data_ptr(), y.data_ptr(),
-                                                    ny.data_ptr(), st.data_ptr(), rj.data_ptr(), int(max_steps), torch.cuda.current_stream().cuda_stream))
+        opts = []
+        for name, v in (("t_start", t_start), ("absTol", absTol), ("relTol", relTol), ("dtMax", dtMax), ("dtMin", dtMin), ("dt", dt)):
+            if v is not None:
+                v = v.contiguous()
+                if v.dim() != 1 or v.shape[0] != N or v.dtype != torch.float64 or not v.is_cuda:
+                    raise ValueError(f"{name} must be a CUDA float64 tensor of shape [N]")
+            opts.append(v)
+        _check(L.nnhip_ode_solve_batch_calls_f64_dev(C.byref(options), integ, f.kind, pp, int(p.size), sw.data_ptr() if sw is not None else None,
+                                                     int(sw.shape[0]) if sw is not None else 0, y0c.data_ptr(), N, dim, layout, te.data_ptr(),
+                                                     *[v.data_ptr() if v is not None else None for v in opts], y.data_ptr(),
+                                                     ny.data_ptr(), st.data_ptr(), rj.data_ptr(), int(max_steps), torch.cuda.current_stream().cuda_stream))
     return y, dict(ny=ny, steps=st, rejected=rj)
 
 

@@ -662,3 +662,45 @@ def test_every_ivp_its_own_tspan_end(nn, oracle, dev, integrator):
             assert np.isnan(gi[st.n_y:]).all()
             if te[i] == 0.25:
                 assert st.n_y == 1
+
+
+@pytest.mark.parametrize("integrator", ["dopri54", "tsit54", "rk4", "vern65"])
+def test_every_ivp_its_own_options_and_tspan(nn, oracle, dev, integrator):
+    """nnhip_ode_solve_batch_calls_f64_dev: IVP i is solveODE(f, y0_i, [tStart_i, tEnd_i], newODEoptions(dt_i, absTol_i, relTol_i,
+    dtMax_i, dtMin_i, tStart = tStart_i)) — each reference call owns its ODEoptions and its tspan (ode.nim:589-591, 26-34, 78-102).
+    Bitwise equal to one oracle call per IVP; negative option values go through abs() like newODEoptions; calls the reference
+    refuses (dtMax < dtMin) are flagged ny = -1."""
+    import torch
+    O = oracle
+    rng = np.random.default_rng(11)
+    for f, okind, params, dim, layout in ((nn.Rhs.lorenz(), O.RHS_LORENZ, LOR, 3, 0), (nn.Rhs.ring(0.1), O.RHS_RING, [0.1], 16, 1)):
+        n = 200
+        y0 = rng.uniform(0.5, 1.5, (n, dim)) + (np.array([0.0, 0.0, 20.0]) if dim == 3 else 0.0)
+        ts = rng.uniform(-0.2, 0.2, n)
+        te = ts + rng.uniform(-0.3, 0.8, n)
+        at = 10 ** rng.uniform(-9, -4, n) * rng.choice([1.0, -1.0], n)      # sign is dropped by newODEoptions' abs()
+        rt_ = 10 ** rng.uniform(-9, -4, n)
+        dmax = 10 ** rng.uniform(-2, -0.5, n)
+        dmin = 10 ** rng.uniform(-6, -4, n)
+        dts = 10 ** rng.uniform(-2.5, -1.5, n)
+        dmin[3] = 1.0        # dtMax < dtMin: newODEoptions raises ValueError for this call
+        dev_t = lambda a: torch.from_numpy(a).to(dev)
+        y0l = np.ascontiguousarray(y0 if layout == 1 else y0.T)
+        y, cnt = nn.solveODEPerIvpEnd(f, dev_t(y0l), dev_t(te), nn.newODEoptions(), integrator=integrator, layout=layout, t_start=dev_t(ts), absTol=dev_t(at),
+                                      relTol=dev_t(rt_), dtMax=dev_t(dmax), dtMin=dev_t(dmin), dt=dev_t(dts))
+        got = y.cpu().numpy()
+        ny, steps, rej = (cnt[k].cpu().numpy() for k in ("ny", "steps", "rejected"))
+        fixed = integrator in nn.fixedODE
+        assert (ny[3] == -1) == (not fixed)       # fixed-step methods never look at dtMax / dtMin
+        for i in list(range(0, n, 9)) + [3]:
+            if i == 3 and not fixed:
+                gi = got[:, :, i] if layout == 0 else got[:, i, :]
+                assert np.isnan(gi).all()
+                with pytest.raises(ValueError):
+                    O.new_options(dt=dts[i], absTol=at[i], relTol=rt_[i], dtMax=dmax[i], dtMin=dmin[i], tStart=ts[i])
+                continue
+            oi = O.new_options(dt=dts[i], absTol=at[i], relTol=rt_[i], dtMax=dmax[i], dtMin=min(dmin[i], dmax[i]) if fixed else dmin[i], tStart=ts[i])
+            rt, ry, st = O.solve_ode(okind, params, list(y0[i]), [ts[i], te[i]], oi, integrator)
+            gi = got[:, :, i] if layout == 0 else got[:, i, :]
+            assert ny[i] == st.n_y and steps[i] == st.steps and rej[i] == st.rejected, (i, integrator)
+            assert _same_bits(gi[:st.n_y].reshape(st.n_y, -1), np.asarray(ry).reshape(st.n_y, -1)), (integrator, dim, i)
