@@ -15,22 +15,30 @@ __global__ void negate_kernel(const double* in, double* out, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { const double v = in[i]; out[i] = (v == v) ? -v : __longlong_as_double(0x7ff0000000000000LL); }
 }
-// Binning needs the ORDER of the keys only coarsely: the float64 keys are narrowed to float32 (monotone) — 4 radix passes
-// instead of 8.  IVPs whose keys agree in float32 keep the caller's relative order (stable sort), as good a binning as any.
-__global__ void narrow_keys_kernel(const double* in, float* out, uint32_t* iota, int64_t n) {
+// Binning needs the ORDER of the keys only coarsely: a float64 key is narrowed to the top 16 bits of its float32 image in
+// order-preserving unsigned form (sign, exponent, 7 mantissa bits: 128 bins per octave, so skewed key distributions still spread) —
+// 2 radix passes instead of 8 (1e6 keys: 21 sort kernels / 170 us -> measured in profiles/r02_bench_divergence.json).  IVPs whose keys
+// share a bin keep the caller's relative order (stable sort), as good a binning as any.
+__global__ void narrow_keys_kernel(const double* in, uint16_t* out, uint32_t* iota, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { const double v = in[i]; out[i] = (v == v) ? (float)v : __int_as_float(0x7f800000); iota[i] = (uint32_t)i; }
+  if (i < n) {
+    const double v = in[i];
+    uint32_t b = __float_as_uint((v == v) ? (float)v : __int_as_float(0x7f800000));  // NaN keys sort last
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);                                  // IEEE order -> unsigned order
+    out[i] = (uint16_t)(b >> 16);
+    iota[i] = (uint32_t)i;
+  }
 }
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 }  // namespace
 
-// layout of the workspace: [keys_in: 4N][keys_out: 4N][iota: 4N][cub temp]
+// layout of the workspace: [keys_in: 2N][keys_out: 2N][iota: 4N][cub temp]
 int64_t argsort_workspace_bytes(int64_t N) {
   if (N <= 0) return 0;
   size_t temp = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const float*)nullptr, (float*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const uint16_t*)nullptr, (uint16_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
                                            (int)N);
-  return (int64_t)(3 * align256((size_t)N * 4) + align256(temp) + 256);
+  return (int64_t)(2 * align256((size_t)N * 2) + align256((size_t)N * 4) + align256(temp) + 256);
 }
 
 // perm_out[k] = index of the k-th smallest key (stable).  N < 2^31.
@@ -41,17 +49,17 @@ hipError_t argsort_f64(const double* keys, int64_t N, uint32_t* perm_out, void* 
     return hipErrorInvalidValue;
   }
   char* base = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-  float* keysIn = (float*)base;
-  float* keysOut = (float*)(base + align256((size_t)N * 4));
-  uint32_t* iota = (uint32_t*)(base + 2 * align256((size_t)N * 4));
-  void* temp = base + 3 * align256((size_t)N * 4);
+  uint16_t* keysIn = (uint16_t*)base;
+  uint16_t* keysOut = (uint16_t*)(base + align256((size_t)N * 2));
+  uint32_t* iota = (uint32_t*)(base + 2 * align256((size_t)N * 2));
+  void* temp = base + 2 * align256((size_t)N * 2) + align256((size_t)N * 4);
   size_t tempBytes = (size_t)ws_bytes - (size_t)((char*)temp - (char*)ws);
   {  // hipLaunchKernel's own status (hipGetLastError() can hand back a stale error of an unrelated earlier call)
     void* args[] = {(void*)&keys, (void*)&keysIn, (void*)&iota, (void*)&N};
     const hipError_t e = hipLaunchKernel((const void*)narrow_keys_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), args, 0, s);
     if (e != hipSuccess) return e;
   }
-  const hipError_t e2 = hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, keysIn, keysOut, iota, perm_out, (int)N, 0, 32, s);
+  const hipError_t e2 = hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, keysIn, keysOut, iota, perm_out, (int)N, 0, 16, s);
   if (e2 != hipSuccess) fprintf(stderr, "argsort_f64: SortPairs failed: %s (N=%lld tempBytes=%zu)\n", hipGetErrorString(e2), (long long)N, tempBytes);
   return e2;
 }
