@@ -13,4 +13,6 @@ timeout 300 python scripts/bench_extra.py > gpurun_out/bench_extra.log 2>&1
 timeout 300 python scripts/bench_adaptive_stream.py > gpurun_out/bench_adaptive_stream.log 2>&1
 timeout 300 python scripts/bench_cumquad.py > gpurun_out/bench_cumquad.log 2>&1
 timeout 300 python scripts/bench_wide.py > gpurun_out/bench_wide.log 2>&1
+timeout 300 python scripts/bench_divergence.py > gpurun_out/bench_divergence.log 2>&1
+ADV_BENCH_ONLY=C3_lorenz_N1e+07 bash scripts/profile_adv.sh > gpurun_out/profile_adv.log 2>&1
 echo "then, in the build container: python scripts/summarize_profiles.py --round N; python scripts/summarize_configs_pmc.py --round N   (summaries into profiles/)"
