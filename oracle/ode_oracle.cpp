@@ -18,9 +18,11 @@
 // `t == tspan`, at the reference's own tolerances; tests/test_vector.nim operator semantics;
 // tests/test_utils.nim:15-23 linspace; tests/test_integrate.nim:67-95 cumtrapz / cumsimpson, discrete and
 // function forms) — see tests/test_oracle_reference_kats.py — and against the
-// survey's independent scratch known-answer values.  Bit-level identity with
-// a Nim build is by construction (same IEEE-754 double operations in the same order, compiled
-// -ffp-contract=off, no fast-math), not by execution.
+// survey's independent scratch known-answer values, and — bit for bit — against a second
+// restatement written independently from ode.nim / utils.nim in plain Python floats (oracle/py_restatement.py;
+// tests/test_oracle_two_restatements.py: 14 integrators, scalar and Vector states, both directions, dense rows).
+// Bit-level identity with a Nim build is by construction (same IEEE-754 double operations in the same order,
+// compiled -ffp-contract=off, no fast-math, the same libm pow), not by execution.
 //
 // Build: see oracle/Makefile  (g++ -O2 -ffp-contract=off -fno-fast-math)
 // =============================================================================
