@@ -63,9 +63,10 @@ int g_host_register = 0;  // tuning knob "host_register": page-lock the caller's
 int g_fast_math = 0;     // tuning knob "fp_contract": 1 = FMA-contracted instantiations of the fused kernels (not bit-exact)
 int g_stream_graph = 2;  // tuning knob "stream_graph": 0 eager launches; 1 hipGraph capture + replay of the streaming loop;
                          // 2 (default) = replay only launch-bound batches, from the second identical call on
-int g_fixed_vec_ipl = 2;  // tuning knob "fixed_vec_ipl": IVPs per lane of the vectorised fixed-step streaming kernel (0 = off, 2, 4)
+int g_fixed_vec_ipl = 2;  // tuning knob "fixed_vec_ipl": IVPs per lane of the vectorised fixed-step streaming kernel (0 = off, 2)
 int g_mg_oversubscribe = 0;  // tuning knob "multi_gpu_oversubscribe": the multi-GPU host entry accepts more shards than devices (shard r on device
                              // r mod #devices) — lets a one-GPU box exercise the sharded code path (index ranges, strided copies, empty shards)
+int g_adv_nt = -1;        // tuning knob "adv_nontemporal": -1 = automatic (thread-per-IVP state beyond 192 MiB), 0 / 1 = force
 int g_adv_speculate = 0;  // tuning knob "adv_speculate": advance kernels issue all loads before the `t < tEnd` test (see StepArgs::speculate);
                           // measured: no gain (1e7 Lorenz IVPs 274.9 vs 273.6 us per iteration), so finished IVPs keep touching no memory
 int g_adv_split = 0;      // tuning knob "adv_split": index ranges the adaptive streaming loop interleaves on separate streams (0 = auto, 1, 2, 4)
@@ -370,8 +371,9 @@ int nnhip_tune_set(const char* key, int value) {
   if (k == "host_register") { g_host_register = value != 0; return NNHIP_OK; }
   if (k == "fp_contract") { g_fast_math = value != 0; return NNHIP_OK; }
   if (k == "stream_graph") { if (value < 0 || value > 2) return fail(NNHIP_EVALUE, "stream_graph must be 0, 1 or 2"); g_stream_graph = value; return NNHIP_OK; }
-  if (k == "fixed_vec_ipl") { if (value != 0 && value != 2 && value != 4) return fail(NNHIP_EVALUE, "fixed_vec_ipl must be 0, 2 or 4"); g_fixed_vec_ipl = value; return NNHIP_OK; }
+  if (k == "fixed_vec_ipl") { if (value != 0 && value != 2) return fail(NNHIP_EVALUE, "fixed_vec_ipl must be 0 (off) or 2"); g_fixed_vec_ipl = value; return NNHIP_OK; }
   if (k == "multi_gpu_oversubscribe") { g_mg_oversubscribe = value != 0; return NNHIP_OK; }
+  if (k == "adv_nontemporal") { if (value < -1 || value > 1) return fail(NNHIP_EVALUE, "adv_nontemporal must be -1, 0 or 1"); g_adv_nt = value; return NNHIP_OK; }
   if (k == "adv_speculate") { g_adv_speculate = value != 0; return NNHIP_OK; }
   if (k == "adv_split") { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(NNHIP_EVALUE, "adv_split must be 0, 1, 2 or 4"); g_adv_split = value; return NNHIP_OK; }
   if (k == "dim16_variant") { if (value < 0 || value > 4) return fail(NNHIP_EVALUE, "dim16_variant must be 0..4"); g_dim16_variant = value; return NNHIP_OK; }
@@ -975,7 +977,10 @@ int nnhip_ode_step_batch_f64_dev(const nnhip_ode_options* opt, int integrator, i
       va.yin = y_in; va.yout = y_out; va.fsalOut = fsal_out; va.tDev = t_dev; va.dtDev = dt_dev; va.N = N;
       va.aos = layout == NNHIP_LAYOUT_AOS && dim > 1 ? 1 : 0;
       va.t = t_uniform; va.dt = dt_uniform; va.P = P;
-      HIP_TRY(vf(va, negate_time, g_fixed_vec_ipl, (hipStream_t)stream));
+      // arrays beyond the Infinity Cache: non-temporal hint (knob "adv_nontemporal"; 5.06 -> see profiles/r02_bench_extra.json)
+      const int64_t bytes = (int64_t)sizeof(double) * N * ((y_in == y_out ? 1 : 2) * dim + (fsal_out ? dim : 0) + (t_dev ? 1 : 0) + (dt_dev ? 1 : 0));
+      const int ntv = g_adv_nt >= 0 ? g_adv_nt : (bytes > (192LL << 20) ? 1 : 0);
+      HIP_TRY(vf(va, negate_time, ntv, (hipStream_t)stream));
       return NNHIP_OK;
     }
   }
@@ -992,6 +997,8 @@ int nnhip_ode_step_batch_f64_dev(const nnhip_ode_options* opt, int integrator, i
   a.t_dev = t_dev; a.t_uniform = t_uniform; a.dt_dev = dt_dev; a.dt_uniform = dt_uniform;
   a.y_in = y_in; a.fsal_in = fsal_in; a.y_out = y_out; a.fsal_out = fsal_out; a.dt_used = dt_used; a.error = error;
   a.ctl = ctl_of(opt); a.P = P;
+  // state beyond the Infinity Cache: non-temporal hint (adaptive thread-per-IVP kernels; knob "adv_nontemporal")
+  a.nontemporal = g_adv_nt >= 0 ? g_adv_nt : ((dim <= 4 && (int64_t)sizeof(double) * (4 * dim + 5) * N > (192LL << 20)) ? 1 : 0);
   if (user) {
     if (nnhip::rtc_launch_step(rhs_kind, integrator, a, negate_time, (hipStream_t)stream) != hipSuccess)
       return fail(NNHIP_EHIP, "user RHS launch failed: %s", nnhip::rtc_last_error());
@@ -1377,6 +1384,8 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
   a.ctl = ctl_of(opt); a.P = P;
   a.tEnd = tEnd; a.t_io = tArr; a.dt_io = dtArr; a.active = nullptr; a.steps_io = nullptr;
   a.speculate = g_adv_speculate;
+  // thread-per-IVP kernels (the lanes-per-system ones are not memory-bound enough to gain: measured -3 %)
+  a.nontemporal = g_adv_nt >= 0 ? g_adv_nt : ((dim <= 4 && (int64_t)sizeof(double) * (2 * dim + 3) * N > (192LL << 20)) ? 1 : 0);
   if (check_every <= 0) check_every = 8;
   rc = adv_poll_reserve();
   if (rc) return rc;

@@ -95,6 +95,7 @@ struct StepArgs {
   // advance mode: issue the loads of (y, FSAL, dt) together with the load of t instead of after the `t < tEnd` test: one memory
   // round trip per launch less; IVPs that are already finished then still READ their state (they never write)
   int speculate;
+  int nontemporal;  // advance mode: non-temporal hint on the streamed state arrays (working set beyond the Infinity Cache)
   // advance mode WITH dense output (adaptive streaming through the IntegratorProc seam, ode.nim:512-530): tReq == nullptr -> none.
   const double* tReq;   // requested times of this direction as the reference holds them (tPositive ascending / tNegative descending)
   int nReq;
@@ -456,12 +457,24 @@ NNHIP_DEV void pin_step_args(const StepArgs& a) {
 // ------------------------------------------------------------------------------------------------
 // one IntegratorProc call (step-streaming; state in HBM between calls)
 // ------------------------------------------------------------------------------------------------
-template <int METHOD, class Ops>
+// NT: non-temporal hint on the state arrays (see the advance kernels below: a template parameter, chosen by the host from the
+// working-set size; instantiated for the adaptive methods' forward direction only)
+template <bool NT>
+NNHIP_DEV double ld_state(const double* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <bool NT>
+NNHIP_DEV void st_state(double v, double* p) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+template <int METHOD, bool NT = false, class Ops>
 NNHIP_DEV void step_body(const StepArgs& a, const Ops& ops, int64_t i, int64_t base, bool writeScalars) {
   constexpr int D = Ops::D;
   double y[D], yNew[D];
 #pragma unroll
-  for (int c = 0; c < D; ++c) y[c] = ops.owns(c) ? a.y_in[base + c * a.compStride] : 0.0;
+  for (int c = 0; c < D; ++c) y[c] = ops.owns(c) ? ld_state<NT>(&a.y_in[base + c * a.compStride]) : 0.0;
   const double t = a.t_dev ? a.t_dev[i] : a.t_uniform;
   double dt = a.dt_dev ? a.dt_dev[i] : a.dt_uniform;
   double error = 0.0;
@@ -483,7 +496,7 @@ NNHIP_DEV void step_body(const StepArgs& a, const Ops& ops, int64_t i, int64_t b
     double fsal[D];
     if constexpr (has_tableau(METHOD)) {  // only the tableau methods read FSAL (k1 = FSAL); RK21 / BS32 ignore it
 #pragma unroll
-      for (int c = 0; c < D; ++c) fsal[c] = ops.owns(c) ? a.fsal_in[base + c * a.compStride] : 0.0;
+      for (int c = 0; c < D; ++c) fsal[c] = ops.owns(c) ? ld_state<NT>(&a.fsal_in[base + c * a.compStride]) : 0.0;
     }
     int64_t rej = 0;
     double factor;
@@ -491,19 +504,19 @@ NNHIP_DEV void step_body(const StepArgs& a, const Ops& ops, int64_t i, int64_t b
     if (a.fsal_out) {
 #pragma unroll
       for (int c = 0; c < D; ++c)
-        if (ops.owns(c)) a.fsal_out[base + c * a.compStride] = fsal[c];
+        if (ops.owns(c)) st_state<NT>(fsal[c], &a.fsal_out[base + c * a.compStride]);
     }
   }
 #pragma unroll
   for (int c = 0; c < D; ++c)
-    if (ops.owns(c)) a.y_out[base + c * a.compStride] = yNew[c];
+    if (ops.owns(c)) st_state<NT>(yNew[c], &a.y_out[base + c * a.compStride]);
   if (writeScalars) {
     if (a.dt_used) a.dt_used[i] = dt;
     if (a.error) a.error[i] = error;
   }
 }
 
-template <int METHOD, class RHS, bool NEG>
+template <int METHOD, class RHS, bool NEG, bool NT = false>
 __global__ __launch_bounds__(kBlock) void step_tpi_kernel(const StepArgs a) {
   controller_prologue<MethodTraits<METHOD>::adaptive>();
   pin_step_args(a);
@@ -511,7 +524,7 @@ __global__ __launch_bounds__(kBlock) void step_tpi_kernel(const StepArgs a) {
   if (i >= a.N) return;
   const Params P = params_of(a, i);
   const TpiOps<RHS, NEG> ops{P};
-  step_body<METHOD>(a, ops, i, i * a.ivpStride, true);
+  step_body<METHOD, NT>(a, ops, i, i * a.ivpStride, true);
 }
 
 #if !NNHIP_RTC
@@ -520,6 +533,9 @@ hipError_t launch_step_tpi(const StepArgs& a, int negate, hipStream_t s) {
   const int64_t grid = (a.N + kBlock - 1) / kBlock;
   if (grid <= 0) return hipSuccess;
   if (negate) return launch_kernel(step_tpi_kernel<METHOD, RHS, true>, dim3((unsigned)grid), dim3(kBlock), s, a);
+  if constexpr (MethodTraits<METHOD>::adaptive) {
+    if (a.nontemporal) return launch_kernel(step_tpi_kernel<METHOD, RHS, false, true>, dim3((unsigned)grid), dim3(kBlock), s, a);
+  }
   return launch_kernel(step_tpi_kernel<METHOD, RHS, false>, dim3((unsigned)grid), dim3(kBlock), s, a);
 }
 #endif
@@ -529,20 +545,39 @@ hipError_t launch_step_tpi(const StepArgs& a, int negate, hipStream_t s) {
 // in HBM between launches:  dt = min(dt, tEnd - t); (y, FSAL, dt, error) = integrator(...); t += dt; controller.
 // Algorithmic traffic per attempted step: read y(d)+FSAL(d)+t+dt, write y(d)+FSAL(d)+t+dt+error = 8*(4d+5) B.
 // ------------------------------------------------------------------------------------------------
+// StepArgs::nontemporal gives the streamed state arrays of the advance kernels the non-temporal hint: once a launch's state
+// (y, FSAL, t, dt, error: 8*(2d+3) B per IVP) no longer fits the 256 MiB Infinity Cache, keeping it out of the cache is worth
+// +11 % (1e7 Lorenz IVPs: 241 -> 216 us per iteration = 6.3 TB/s); below that it costs 4 % (1e6: 26.1 -> 27.6 us); the host
+// picks per call (profiles/r02_pow_tables_ab.txt, section 7).  The hint is a TEMPLATE parameter of the kernel: a run-time branch
+// between hinted and plain accesses of the same addresses is merged by the compiler into the plain ones (the hint is dropped).
+template <bool NT, class Ops, int D>
+NNHIP_DEV void adv_load_state(const StepArgs& a, const Ops& ops, int64_t base, double (&y)[D], double (&fsal)[D]) {
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    if (!ops.owns(c)) { y[c] = 0.0; fsal[c] = 0.0; continue; }
+    if constexpr (NT) { y[c] = __builtin_nontemporal_load(&a.y_in[base + c * a.compStride]); fsal[c] = __builtin_nontemporal_load(&a.fsal_in[base + c * a.compStride]); }
+    else { y[c] = a.y_in[base + c * a.compStride]; fsal[c] = a.fsal_in[base + c * a.compStride]; }
+  }
+}
+template <bool NT, class Ops, int D>
+NNHIP_DEV void adv_store_state(const StepArgs& a, const Ops& ops, int64_t base, const double (&yNew)[D], const double (&fsal)[D]) {
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    if (!ops.owns(c)) continue;
+    if constexpr (NT) { __builtin_nontemporal_store(yNew[c], &a.y_out[base + c * a.compStride]); __builtin_nontemporal_store(fsal[c], &a.fsal_out[base + c * a.compStride]); }
+    else { a.y_out[base + c * a.compStride] = yNew[c]; a.fsal_out[base + c * a.compStride] = fsal[c]; }
+  }
+}
 // Shared by the thread-per-IVP and the lanes-per-system form.  `base` addresses this lane's first owned component of IVP i; all
 // lanes of a system read the same (t, dt) and compute bit-identical values for them; lane `writeScalars` stores them.
-template <int METHOD, class Ops>
+template <int METHOD, bool NT = false, class Ops>
 NNHIP_DEV unsigned int advance_body(const StepArgs& a, const Ops& ops, int64_t i, int64_t base, bool writeScalars) {
   constexpr int D = Ops::D;
   double t = a.t_io[i];
   double y[D], yNew[D], fsal[D];
   double dt;
   if (a.speculate) {  // all loads in flight at once; the exit test comes after them
-#pragma unroll
-    for (int c = 0; c < D; ++c) {
-      y[c] = ops.owns(c) ? a.y_in[base + c * a.compStride] : 0.0;
-      fsal[c] = ops.owns(c) ? a.fsal_in[base + c * a.compStride] : 0.0;
-    }
+    adv_load_state<NT>(a, ops, base, y, fsal);
     dt = a.dt_io[i];
     // tie t to the other loads: without this the compiler schedules the `t < tEnd` test (and the wait for t) BEFORE it issues them
     {
@@ -559,11 +594,7 @@ NNHIP_DEV unsigned int advance_body(const StepArgs& a, const Ops& ops, int64_t i
     if (!(t < a.tEnd)) return 0u;  // :511
   } else {
     if (!(t < a.tEnd)) return 0u;  // :511 — finished IVPs touch no other memory
-#pragma unroll
-    for (int c = 0; c < D; ++c) {
-      y[c] = ops.owns(c) ? a.y_in[base + c * a.compStride] : 0.0;
-      fsal[c] = ops.owns(c) ? a.fsal_in[base + c * a.compStride] : 0.0;
-    }
+    adv_load_state<NT>(a, ops, base, y, fsal);
     dt = a.dt_io[i];
   }
   dt = nmin(dt, a.tEnd - t);  // :525
@@ -577,9 +608,7 @@ NNHIP_DEV unsigned int advance_body(const StepArgs& a, const Ops& ops, int64_t i
   if (dt < a.ctl.dtMin) dt = a.ctl.dtMin;                               // :538-539
   else if (a.ctl.dtMax < dt) dt = a.ctl.dtMax;                          // :540-541
   if (error != error) t = a.tEnd;  // NaN abort (same deviation as the fused driver): retire the IVP
-#pragma unroll
-  for (int c = 0; c < D; ++c)
-    if (ops.owns(c)) { a.y_out[base + c * a.compStride] = yNew[c]; a.fsal_out[base + c * a.compStride] = fsal[c]; }
+  adv_store_state<NT>(a, ops, base, yNew, fsal);
   if (writeScalars) {
     a.t_io[i] = t;
     a.dt_io[i] = dt;
@@ -607,7 +636,7 @@ constexpr int adv_tpi_waves() { return (RHS::dim <= 3 && METHOD != NNHIP_VERN65)
 #else
 #define NNHIP_ADV_LPS_ATTR
 #endif
-template <int METHOD, class RHS>
+template <int METHOD, class RHS, bool NT = false>
 __global__ __launch_bounds__(kBlock) NNHIP_ADV_TPI_ATTR void advance_tpi_kernel(const StepArgs a) {
   static_assert(MethodTraits<METHOD>::adaptive, "fixed-step methods share (t, dt): use the uniform streaming loop");
   controller_prologue();
@@ -617,7 +646,7 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_TPI_ATTR void advance_tpi_kernel(
   if (i < a.N) {
     const Params P = params_of(a, i);
     const TpiOps<RHS, false> ops{P};
-    stillActive = advance_body<METHOD>(a, ops, i, i * a.ivpStride, true);
+    stillActive = advance_body<METHOD, NT>(a, ops, i, i * a.ivpStride, true);
   }
   // "is anyone still integrating?" — a plain flag store per workgroup into one of kAggSlots words (no atomics: 1e5 waves
   // hitting one address cost ~170 us per launch), and only in the launches whose answer the host will read
@@ -849,7 +878,8 @@ hipError_t launch_advance_tpi(const StepArgs& a, int, hipStream_t s) {
   if constexpr (MethodTraits<METHOD>::adaptive) {
     const int64_t grid = (a.N + kBlock - 1) / kBlock;
     if (grid <= 0) return hipSuccess;
-    return launch_kernel(advance_tpi_kernel<METHOD, RHS>, dim3((unsigned)grid), dim3(kBlock), s, a);
+    if (a.nontemporal) return launch_kernel(advance_tpi_kernel<METHOD, RHS, true>, dim3((unsigned)grid), dim3(kBlock), s, a);
+    return launch_kernel(advance_tpi_kernel<METHOD, RHS, false>, dim3((unsigned)grid), dim3(kBlock), s, a);
   } else {
     return hipErrorInvalidValue;
   }
@@ -985,9 +1015,19 @@ struct FixedVecArgs {
   Params P;
 };
 
-template <int METHOD, class RHS, bool NEG, int IPL>
+// NT: non-temporal hint on the state accesses, chosen by the host when the arrays no longer fit the Infinity Cache (a template
+// parameter: see the advance kernels).  IPL = 2 (4 was measured: no gain, profiles/r02_fixed_vec_ab.json).
+template <int METHOD, class RHS, bool NEG, int IPL, bool NT = false>
 __global__ __launch_bounds__(kBlock) void fixed_stream_vec_kernel(const FixedVecArgs a) {
   static_assert(!MethodTraits<METHOD>::adaptive && IPL % 2 == 0, "fixed-step methods, an even number of IVPs per lane");
+  auto ld2 = [](const double* p) -> double2 {
+    if constexpr (NT) { double2 r; r.x = __builtin_nontemporal_load(p); r.y = __builtin_nontemporal_load(p + 1); return r; }
+    else return *reinterpret_cast<const double2*>(p);
+  };
+  auto st2 = [](double2 v, double* p) {
+    if constexpr (NT) { __builtin_nontemporal_store(v.x, p); __builtin_nontemporal_store(v.y, p + 1); }
+    else *reinterpret_cast<double2*>(p) = v;
+  };
   constexpr int D = RHS::dim;
   constexpr int PAIRS = IPL / 2;
   NNHIP_PIN_SGPR64(a.yin); NNHIP_PIN_SGPR64(a.yout); NNHIP_PIN_SGPR64(a.fsalOut); NNHIP_PIN_SGPR64(a.tDev); NNHIP_PIN_SGPR64(a.dtDev);
@@ -1013,12 +1053,11 @@ __global__ __launch_bounds__(kBlock) void fixed_stream_vec_kernel(const FixedVec
     for (int u = 0; u < PAIRS; ++u) {
       const int64_t i = tile + (int64_t)u * 2 * kBlock + 2 * threadIdx.x;
       if (aos) {
-        const double2* src = reinterpret_cast<const double2*>(yin + i * D);
 #pragma unroll
-        for (int c = 0; c < D; ++c) v[u][c] = src[c];
+        for (int c = 0; c < D; ++c) v[u][c] = ld2(yin + i * D + 2 * c);
       } else {
 #pragma unroll
-        for (int c = 0; c < D; ++c) v[u][c] = *reinterpret_cast<const double2*>(yin + (int64_t)c * N + i);
+        for (int c = 0; c < D; ++c) v[u][c] = ld2(yin + (int64_t)c * N + i);
       }
       tt[u] = a.tDev ? *reinterpret_cast<const double2*>(a.tDev + i) : double2{a.t, a.t};
       dd[u] = a.dtDev ? *reinterpret_cast<const double2*>(a.dtDev + i) : double2{a.dt, a.dt};
@@ -1053,20 +1092,18 @@ __global__ __launch_bounds__(kBlock) void fixed_stream_vec_kernel(const FixedVec
     for (int u = 0; u < PAIRS; ++u) {
       const int64_t i = tile + (int64_t)u * 2 * kBlock + 2 * threadIdx.x;
       if (aos) {
-        double2* dst = reinterpret_cast<double2*>(yout + i * D);
 #pragma unroll
-        for (int c = 0; c < D; ++c) dst[c] = v[u][c];
+        for (int c = 0; c < D; ++c) st2(v[u][c], yout + i * D + 2 * c);
         if (a.fsalOut) {
-          double2* fd = reinterpret_cast<double2*>(a.fsalOut + i * D);
 #pragma unroll
-          for (int c = 0; c < D; ++c) fd[c] = v[u][c];
+          for (int c = 0; c < D; ++c) st2(v[u][c], a.fsalOut + i * D + 2 * c);
         }
       } else {
 #pragma unroll
-        for (int c = 0; c < D; ++c) *reinterpret_cast<double2*>(yout + (int64_t)c * N + i) = v[u][c];
+        for (int c = 0; c < D; ++c) st2(v[u][c], yout + (int64_t)c * N + i);
         if (a.fsalOut) {
 #pragma unroll
-          for (int c = 0; c < D; ++c) *reinterpret_cast<double2*>(a.fsalOut + (int64_t)c * N + i) = v[u][c];
+          for (int c = 0; c < D; ++c) st2(v[u][c], a.fsalOut + (int64_t)c * N + i);
         }
       }
     }
@@ -1115,19 +1152,16 @@ hipError_t launch_rk4_stream_vec(const double* yin, double* yout, int64_t n, dou
   return launch_kernel(rk4_stream_vec_kernel<RHS1, false, VEC, MODE>, dim3((unsigned)grid), dim3(kBlock), s, yin, yout, n, t, h.dt, h.hdt, h.dt6, P);
 }
 
-using FixedVecLaunchFn = hipError_t (*)(const FixedVecArgs& a, int negate, int ipl, hipStream_t s);
+using FixedVecLaunchFn = hipError_t (*)(const FixedVecArgs& a, int negate, int nontemporal, hipStream_t s);
 template <int METHOD, class RHS>
-hipError_t launch_fixed_stream_vec(const FixedVecArgs& a, int negate, int ipl, hipStream_t s) {
+hipError_t launch_fixed_stream_vec(const FixedVecArgs& a, int negate, int nontemporal, hipStream_t s) {
   if constexpr (!MethodTraits<METHOD>::adaptive) {
     if (a.N <= 0) return hipSuccess;
-    const int64_t per = (int64_t)kBlock * (ipl == 4 ? 4 : 2);
+    const int64_t per = (int64_t)kBlock * 2;
     const dim3 grid((unsigned)((a.N + per - 1) / per)), block(kBlock);
-    if (ipl == 4) {
-      if (negate) return launch_kernel(fixed_stream_vec_kernel<METHOD, RHS, true, 4>, grid, block, s, a);
-      return launch_kernel(fixed_stream_vec_kernel<METHOD, RHS, false, 4>, grid, block, s, a);
-    }
-    if (negate) return launch_kernel(fixed_stream_vec_kernel<METHOD, RHS, true, 2>, grid, block, s, a);
-    return launch_kernel(fixed_stream_vec_kernel<METHOD, RHS, false, 2>, grid, block, s, a);
+    if (negate) return launch_kernel(fixed_stream_vec_kernel<METHOD, RHS, true, 2, false>, grid, block, s, a);
+    if (nontemporal) return launch_kernel(fixed_stream_vec_kernel<METHOD, RHS, false, 2, true>, grid, block, s, a);
+    return launch_kernel(fixed_stream_vec_kernel<METHOD, RHS, false, 2, false>, grid, block, s, a);
   } else {
     return hipErrorInvalidValue;
   }

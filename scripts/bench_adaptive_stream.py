@@ -56,9 +56,10 @@ for name, f, y0, layout, d, n in cases:
         fused_ms = (time.perf_counter() - c0) * 1e3
         iters = int(cnt["steps"].max())                       # loop iterations until the slowest IVP is done
         attempted = int(cnt["steps"].sum() + cnt["rejected"].sum())
-        for mode, knob, spec in (("graph", 2, 0), ("graph_spec", 2, 1), ("eager", 0, 0)):
+        # graph = defaults (non-temporal hint chosen from the working-set size); nt0 / nt1 force it off / on; eager = no graph replay
+        for mode, knob, nt in (("graph", 2, -1), ("graph_nt0", 2, 0), ("graph_nt1", 2, 1), ("eager", 0, -1)):
             L.nnhip_tune_set(b"stream_graph", knob)
-            L.nnhip_tune_set(b"adv_speculate", spec)
+            L.nnhip_tune_set(b"adv_nontemporal", nt)
             dt, launches, ys = run(f, y0, integ, layout, 8)
             # algorithmic bytes: 8*(4d+5) per attempted step; with default options no step is rejected, so every IVP moves
             # them once per loop iteration it takes part in
@@ -66,5 +67,5 @@ for name, f, y0, layout, d, n in cases:
                                                  GBps=8 * (4 * d + 5) * attempted / dt / 1e9, frac_of_8TBps=8 * (4 * d + 5) * attempted / dt / 8e12,
                                                  fused_ms=fused_ms, equal_to_fused=bool(torch.equal(ys, yf[-1])))
         L.nnhip_tune_set(b"stream_graph", 2)
-        L.nnhip_tune_set(b"adv_speculate", 0)
+        L.nnhip_tune_set(b"adv_nontemporal", -1)
 print(json.dumps(res, indent=1))

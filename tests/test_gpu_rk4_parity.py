@@ -211,11 +211,12 @@ def test_host_path_result_array_reuse_and_page_locked_buffers(nn, oracle):
         nn.solveODE(nn.Rhs.neg_y(), y0, ts, opt, integrator="rk4", out=np.zeros((2, n)))
 
 
-@pytest.mark.parametrize("ipl", [2, 4])
+@pytest.mark.parametrize("ipl", [2, -2])
 @pytest.mark.parametrize("integrator", ["rk4", "heun2", "ralston2", "kutta3", "heun3", "ralston3", "ssprk3", "ralston4", "kutta4"])
 def test_fixed_step_vectorised_streaming_kernel(nn, oracle, dev, integrator, ipl):
-    """fixed_stream_vec_kernel (any fixed-step IntegratorProc over a thread-per-IVP system, 16-byte lane accesses, 2 or 4
-    IVPs per lane; ode.nim:107-189) vs the one-IVP-per-lane step kernel (tuning knob fixed_vec_ipl = 0) and vs the oracle's
+    """fixed_stream_vec_kernel (any fixed-step IntegratorProc over a thread-per-IVP system, 16-byte lane accesses, 2 IVPs per
+    lane, plain (ipl = 2) and non-temporal (ipl = -2 here: knob adv_nontemporal forced on) instantiations; ode.nim:107-189) vs the
+    one-IVP-per-lane step kernel (tuning knob fixed_vec_ipl = 0) and vs the oracle's
     stepper: same bits for both layouts, uniform and per-IVP (t, dt), with and without the FSAL slot, full tiles + ragged
     tail, negated time, and in-place (y_out == y_in)."""
     import torch
@@ -237,7 +238,8 @@ def test_fixed_step_vectorised_streaming_kernel(nn, oracle, dev, integrator, ipl
                     for tt, dd, fsal, neg in ((0.25, 2.0 ** -6, None, False), (tarr, dtarr, yt, False), (0.25, dtarr, None, True), (tarr, 2.0 ** -6, yt, True)):
                         L.nnhip_tune_set(b"fixed_vec_ipl", 0)
                         r0 = nn.integratorStep(f, tt, yt, fsal, dd, opt, integrator=integrator, layout=layout, negate_time=neg)
-                        L.nnhip_tune_set(b"fixed_vec_ipl", ipl)
+                        L.nnhip_tune_set(b"fixed_vec_ipl", abs(ipl))
+                        L.nnhip_tune_set(b"adv_nontemporal", 1 if ipl < 0 else 0)
                         r1 = nn.integratorStep(f, tt, yt, fsal, dd, opt, integrator=integrator, layout=layout, negate_time=neg)
                         assert torch.equal(r0[0], r1[0]), (integrator, dim, n, layout)
                         if fsal is not None:
@@ -254,6 +256,7 @@ def test_fixed_step_vectorised_streaming_kernel(nn, oracle, dev, integrator, ipl
                         assert np.array_equal(got[i], np.atleast_1d(ryn)), (integrator, dim, i)
     finally:
         L.nnhip_tune_set(b"fixed_vec_ipl", 2)
+        L.nnhip_tune_set(b"adv_nontemporal", -1)
 
 
 @pytest.mark.parametrize("integrator", ["rk4", "heun2", "kutta3", "ssprk3", "ralston4"])
