@@ -67,8 +67,6 @@ int g_fixed_vec_ipl = 2;  // tuning knob "fixed_vec_ipl": IVPs per lane of the v
 int g_mg_oversubscribe = 0;  // tuning knob "multi_gpu_oversubscribe": the multi-GPU host entry accepts more shards than devices (shard r on device
                              // r mod #devices) — lets a one-GPU box exercise the sharded code path (index ranges, strided copies, empty shards)
 int g_adv_nt = -1;        // tuning knob "adv_nontemporal": -1 = automatic (thread-per-IVP state beyond 192 MiB), 0 / 1 = force
-int g_adv_speculate = 0;  // tuning knob "adv_speculate": advance kernels issue all loads before the `t < tEnd` test (see StepArgs::speculate);
-                          // measured: no gain (1e7 Lorenz IVPs 274.9 vs 273.6 us per iteration), so finished IVPs keep touching no memory
 int g_adv_split = 0;      // tuning knob "adv_split": index ranges the adaptive streaming loop interleaves on separate streams (0 = auto, 1, 2, 4)
 int g_dim16_variant = 0;  // tuning knob "dim16_variant": A/B mappings of the fused 16-component kernels (see ode_kernels.hpp)
 
@@ -374,7 +372,6 @@ int nnhip_tune_set(const char* key, int value) {
   if (k == "fixed_vec_ipl") { if (value != 0 && value != 2) return fail(NNHIP_EVALUE, "fixed_vec_ipl must be 0 (off) or 2"); g_fixed_vec_ipl = value; return NNHIP_OK; }
   if (k == "multi_gpu_oversubscribe") { g_mg_oversubscribe = value != 0; return NNHIP_OK; }
   if (k == "adv_nontemporal") { if (value < -1 || value > 1) return fail(NNHIP_EVALUE, "adv_nontemporal must be -1, 0 or 1"); g_adv_nt = value; return NNHIP_OK; }
-  if (k == "adv_speculate") { g_adv_speculate = value != 0; return NNHIP_OK; }
   if (k == "adv_split") { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(NNHIP_EVALUE, "adv_split must be 0, 1, 2 or 4"); g_adv_split = value; return NNHIP_OK; }
   if (k == "dim16_variant") { if (value < 0 || value > 4) return fail(NNHIP_EVALUE, "dim16_variant must be 0..4"); g_dim16_variant = value; return NNHIP_OK; }
   if (k == "rk4_stream_auto") { g_tune_auto = value != 0; return NNHIP_OK; }
@@ -1383,7 +1380,6 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
   a.y_in = y; a.y_out = y; a.fsal_in = fsal; a.fsal_out = fsal; a.error = errArr;
   a.ctl = ctl_of(opt); a.P = P;
   a.tEnd = tEnd; a.t_io = tArr; a.dt_io = dtArr; a.active = nullptr; a.steps_io = nullptr;
-  a.speculate = g_adv_speculate;
   // thread-per-IVP kernels (the lanes-per-system ones are not memory-bound enough to gain: measured -3 %)
   a.nontemporal = g_adv_nt >= 0 ? g_adv_nt : ((dim <= 4 && (int64_t)sizeof(double) * (2 * dim + 3) * N > (192LL << 20)) ? 1 : 0);
   if (check_every <= 0) check_every = 8;

@@ -92,9 +92,7 @@ struct StepArgs {
   const double* perIvpParams;  // nullable [nPerIvp][N], as in SolveArgs
   int nPerIvp;
   int64_t perIvpStride;
-  // advance mode: issue the loads of (y, FSAL, dt) together with the load of t instead of after the `t < tEnd` test: one memory
-  // round trip per launch less; IVPs that are already finished then still READ their state (they never write)
-  int speculate;
+  int speculate;    // unused (round 2 measured issuing the state loads together with the load of t: no gain; removed)
   int nontemporal;  // advance mode: non-temporal hint on the streamed state arrays (working set beyond the Infinity Cache)
   // advance mode WITH dense output (adaptive streaming through the IntegratorProc seam, ode.nim:512-530): tReq == nullptr -> none.
   const double* tReq;   // requested times of this direction as the reference holds them (tPositive ascending / tNegative descending)
@@ -448,7 +446,7 @@ NNHIP_DEV void pin_step_args(const StepArgs& a) {
   NNHIP_PIN_SGPR64(a.t_io); NNHIP_PIN_SGPR64(a.dt_io); NNHIP_PIN_SGPR64(a.error); NNHIP_PIN_SGPR64(a.tEnd);
   NNHIP_PIN_SGPR64(a.ctl.absTol); NNHIP_PIN_SGPR64(a.ctl.relTol); NNHIP_PIN_SGPR64(a.ctl.dtMax); NNHIP_PIN_SGPR64(a.ctl.dtMin);
   NNHIP_PIN_SGPR64(a.perIvpParams); NNHIP_PIN_SGPR64(a.active); NNHIP_PIN_SGPR64(a.steps_io);
-  NNHIP_PIN_SGPR32(a.speculate); NNHIP_PIN_SGPR32(a.nPerIvp);
+  NNHIP_PIN_SGPR32(a.nPerIvp);
   NNHIP_PIN_SGPR64(a.t_dev); NNHIP_PIN_SGPR64(a.dt_dev); NNHIP_PIN_SGPR64(a.t_uniform); NNHIP_PIN_SGPR64(a.dt_uniform); NNHIP_PIN_SGPR64(a.dt_used);
 #pragma unroll
   for (int k = 0; k < 4; ++k) NNHIP_PIN_SGPR64(a.P.p[k]);
@@ -570,45 +568,39 @@ NNHIP_DEV void adv_store_state(const StepArgs& a, const Ops& ops, int64_t base, 
 }
 // Shared by the thread-per-IVP and the lanes-per-system form.  `base` addresses this lane's first owned component of IVP i; all
 // lanes of a system read the same (t, dt) and compute bit-identical values for them; lane `writeScalars` stores them.
-template <int METHOD, bool NT = false, class Ops>
-NNHIP_DEV unsigned int advance_body(const StepArgs& a, const Ops& ops, int64_t i, int64_t base, bool writeScalars) {
-  constexpr int D = Ops::D;
-  double t = a.t_io[i];
-  double y[D], yNew[D], fsal[D];
-  double dt;
-  if (a.speculate) {  // all loads in flight at once; the exit test comes after them
-    adv_load_state<NT>(a, ops, base, y, fsal);
-    dt = a.dt_io[i];
-    // tie t to the other loads: without this the compiler schedules the `t < tEnd` test (and the wait for t) BEFORE it issues them
-    {
-      unsigned long long tb = __builtin_bit_cast(unsigned long long, t), db = __builtin_bit_cast(unsigned long long, dt);
-      asm volatile("" : "+v"(tb), "+v"(db));
-#pragma unroll
-      for (int c = 0; c < D; ++c) {
-        unsigned long long yb = __builtin_bit_cast(unsigned long long, y[c]), fb = __builtin_bit_cast(unsigned long long, fsal[c]);
-        asm volatile("" : "+v"(tb), "+v"(yb), "+v"(fb));
-        y[c] = __builtin_bit_cast(double, yb); fsal[c] = __builtin_bit_cast(double, fb);
-      }
-      t = __builtin_bit_cast(double, tb); dt = __builtin_bit_cast(double, db);
-    }
-    if (!(t < a.tEnd)) return 0u;  // :511
-  } else {
-    if (!(t < a.tEnd)) return 0u;  // :511 — finished IVPs touch no other memory
-    adv_load_state<NT>(a, ops, base, y, fsal);
-    dt = a.dt_io[i];
+template <int D>
+struct AdvState {
+  double t, dt, y[D], fsal[D];
+  bool live;
+};
+// phase 1: t, and — for IVPs still short of tEnd — dt, y, FSAL (finished IVPs touch no other memory)
+template <bool NT, class Ops>
+NNHIP_DEV void adv_fetch(const StepArgs& a, const Ops& ops, int64_t i, int64_t base, AdvState<Ops::D>& s) {
+  s.t = a.t_io[i];
+  s.live = s.t < a.tEnd;  // :511
+  if (s.live) {
+    adv_load_state<NT>(a, ops, base, s.y, s.fsal);
+    s.dt = a.dt_io[i];
   }
-  dt = nmin(dt, a.tEnd - t);  // :525
+}
+// phase 2: the loop iteration itself and the write-back
+template <int METHOD, bool NT, class Ops>
+NNHIP_DEV unsigned int adv_advance(const StepArgs& a, const Ops& ops, int64_t i, int64_t base, bool writeScalars, AdvState<Ops::D>& s) {
+  constexpr int D = Ops::D;
+  if (!s.live) return 0u;
+  double t = s.t, yNew[D];
+  double dt = nmin(s.dt, a.tEnd - t);  // :525
   double error = 0.0;
   int64_t rej = 0;
   double factor;
-  embedded_step<METHOD>(ops, t, dt, y, fsal, yNew, error, a.ctl, rej, factor);  // :531
+  embedded_step<METHOD>(ops, t, dt, s.y, s.fsal, yNew, error, a.ctl, rej, factor);  // :531
   t += dt;                                                              // :532
   if (error == 0.0) dt *= 5.0;                                          // :534-535
   else dt = dt * factor;                                                // :537 (the factor of the accepted attempt's error)
   if (dt < a.ctl.dtMin) dt = a.ctl.dtMin;                               // :538-539
   else if (a.ctl.dtMax < dt) dt = a.ctl.dtMax;                          // :540-541
   if (error != error) t = a.tEnd;  // NaN abort (same deviation as the fused driver): retire the IVP
-  adv_store_state<NT>(a, ops, base, yNew, fsal);
+  adv_store_state<NT>(a, ops, base, yNew, s.fsal);
   if (writeScalars) {
     a.t_io[i] = t;
     a.dt_io[i] = dt;
@@ -616,6 +608,12 @@ NNHIP_DEV unsigned int advance_body(const StepArgs& a, const Ops& ops, int64_t i
     if (a.steps_io) a.steps_io[i] += 1;
   }
   return t < a.tEnd ? 1u : 0u;
+}
+template <int METHOD, bool NT = false, class Ops>
+NNHIP_DEV unsigned int advance_body(const StepArgs& a, const Ops& ops, int64_t i, int64_t base, bool writeScalars) {
+  AdvState<Ops::D> s;
+  adv_fetch<NT>(a, ops, i, base, s);
+  return adv_advance<METHOD, NT>(a, ops, i, base, writeScalars, s);
 }
 
 // Occupancy of the thread-per-IVP advance kernel.  glibc's pow keeps six 64-bit polynomial constants in VGPRs (an FMA takes
@@ -660,22 +658,43 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_TPI_ATTR void advance_tpi_kernel(
 // layout a wave moves 512 contiguous bytes per array), stage argument vector and error components through LDS (LpsOps).
 // Algorithmic traffic 8*(4d+5) B per attempted step: 552 B at d = 16, so 1e6 systems stream 552 MB per launch — far
 // beyond the 256 MiB Infinity Cache.
+// SPG (A/B hook -DNNHIP_ADV_LPS_SPG=2): systems per lane group — with 2, a group fetches two systems up front and advances them one
+// after the other: twice the bytes in flight per wave at +2*(2*CPL+2) VGPRs.
+#ifndef NNHIP_ADV_LPS_SPG
+#define NNHIP_ADV_LPS_SPG 1
+#endif
 template <int METHOD, class RHS, int CPL = 1>
 __global__ __launch_bounds__(kBlock) NNHIP_ADV_LPS_ATTR void advance_lps_kernel(const StepArgs a) {
   static_assert(MethodTraits<METHOD>::adaptive, "fixed-step methods share (t, dt): use the uniform streaming loop");
   constexpr int DIM = RHS::dim;
   constexpr int LPSYS = DIM / CPL;
+  constexpr int SPG = NNHIP_ADV_LPS_SPG;
   static_assert(DIM % CPL == 0 && 64 % LPSYS == 0, "a system must not straddle wavefronts");
   __shared__ double lds[2 * kBlock * CPL];
   controller_prologue();
   pin_step_args(a);
   const int sysInBlock = threadIdx.x / LPSYS, c = (threadIdx.x % LPSYS) * CPL;
-  const int64_t i = (int64_t)blockIdx.x * (kBlock / LPSYS) + sysInBlock;
+  constexpr int perBlock = kBlock / LPSYS;
   unsigned int stillActive = 0;
-  if (i < a.N) {
-    const Params P = params_of(a, i);
-    const LpsOps<RHS, false, CPL> ops{P, lds + sysInBlock * DIM, lds + kBlock * CPL + sysInBlock * DIM, c};
-    stillActive = advance_body<METHOD>(a, ops, i, i * a.ivpStride + c * a.compStride, c == 0);
+  int64_t idx[SPG];
+  AdvState<CPL> st[SPG];
+#pragma unroll
+  for (int g = 0; g < SPG; ++g) {
+    idx[g] = ((int64_t)blockIdx.x * SPG + g) * perBlock + sysInBlock;
+    st[g].live = false;
+    if (idx[g] < a.N) {
+      const Params P = params_of(a, idx[g]);
+      const LpsOps<RHS, false, CPL> ops{P, lds + sysInBlock * DIM, lds + kBlock * CPL + sysInBlock * DIM, c};
+      adv_fetch<false>(a, ops, idx[g], idx[g] * a.ivpStride + c * a.compStride, st[g]);
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < SPG; ++g) {
+    if (idx[g] < a.N) {
+      const Params P = params_of(a, idx[g]);
+      const LpsOps<RHS, false, CPL> ops{P, lds + sysInBlock * DIM, lds + kBlock * CPL + sysInBlock * DIM, c};
+      stillActive |= adv_advance<METHOD, false>(a, ops, idx[g], idx[g] * a.ivpStride + c * a.compStride, c == 0, st[g]);
+    }
   }
   if (a.active) {
     if (__syncthreads_or((int)stillActive) && threadIdx.x == 0) a.active[blockIdx.x % kAggSlots] = 1u;
@@ -896,7 +915,7 @@ hipError_t launch_advance_tpi(const StepArgs& a, int, hipStream_t s) {
 template <int METHOD, class RHS, int CPL>
 hipError_t launch_advance_lps(const StepArgs& a, int, hipStream_t s) {
   if constexpr (MethodTraits<METHOD>::adaptive) {
-    constexpr int perBlock = kBlock / (RHS::dim / CPL);
+    constexpr int perBlock = kBlock / (RHS::dim / CPL) * NNHIP_ADV_LPS_SPG;
     const int64_t grid = (a.N + perBlock - 1) / perBlock;
     if (grid <= 0) return hipSuccess;
     return launch_kernel(advance_lps_kernel<METHOD, RHS, CPL>, dim3((unsigned)grid), dim3(kBlock), s, a);

@@ -46,12 +46,12 @@ struct Program {  // the kernels of one (rhs, integrator) code object as loaded 
     if (have) (void)hipSetDevice(prev);
   }
   hipFunction_t solve = nullptr, stepPos = nullptr, stepNeg = nullptr, advance = nullptr, rhs = nullptr, quad[2] = {nullptr, nullptr};
-  int ivpsPerBlockSolve = kBlock, ivpsPerBlockStep = kBlock;  // thread-per-IVP: 256; lanes-per-system: 256 / lanes per system
+  int ivpsPerBlockSolve = kBlock, ivpsPerBlockStep = kBlock, ivpsPerBlockAdvance = kBlock;  // thread-per-IVP: 256; lanes-per-system: 256 / lanes per system
 };
 struct CodeObject {  // compiled once per (rhs, integrator); hipModuleLoadData binds it to the device that is current at the time
   std::vector<char> code;
   std::vector<std::string> lowered;
-  int ivpsPerBlockSolve = kBlock, ivpsPerBlockStep = kBlock;
+  int ivpsPerBlockSolve = kBlock, ivpsPerBlockStep = kBlock, ivpsPerBlockAdvance = kBlock;
   std::map<int, std::shared_ptr<Program>> loaded;  // by device ordinal
 };
 struct UserRhsEntry {
@@ -128,6 +128,7 @@ bool compile(const UserRhsEntry& e, int integrator, CodeObject& out) {
       if (adaptive) names.push_back("nnhip::advance_lps_kernel<" + m + ", nnhip::UserRhs, " + std::to_string(scpl) + ">");  // adaptive streaming
       out.ivpsPerBlockSolve = kBlock / (padded_dim(e) / cpl);
       out.ivpsPerBlockStep = kBlock / (padded_dim(e) / scpl);
+      out.ivpsPerBlockAdvance = out.ivpsPerBlockStep * NNHIP_ADV_LPS_SPG;
     } else {
       names.push_back("nnhip::solve_tpi_kernel<" + m + ", nnhip::UserRhs>");
       names.push_back("nnhip::step_tpi_kernel<" + m + ", nnhip::UserRhs, false>");
@@ -176,6 +177,7 @@ bool compile(const UserRhsEntry& e, int integrator, CodeObject& out) {
 bool load(const CodeObject& co, int integrator, Program& out) {
   out.ivpsPerBlockSolve = co.ivpsPerBlockSolve;
   out.ivpsPerBlockStep = co.ivpsPerBlockStep;
+  out.ivpsPerBlockAdvance = co.ivpsPerBlockAdvance;
   if (hipModuleLoadData(&out.module, co.code.data()) != hipSuccess) {
     g_rtc_err = "hipModuleLoadData failed (no HIP device?)";
     return false;
@@ -319,7 +321,7 @@ hipError_t rtc_launch_advance(int rhs_kind, int integrator, const StepArgs& a, h
   if (!p) return hipErrorInvalidValue;
   if (!p->advance) { g_rtc_err = "no advance kernel: fixed-step integrator"; return hipErrorInvalidValue; }
   StepArgs copy = a;
-  return launch(p->advance, a.N, p->ivpsPerBlockStep, &copy, s);
+  return launch(p->advance, a.N, p->ivpsPerBlockAdvance, &copy, s);
 }
 hipError_t rtc_launch_rhs(int rhs_kind, int64_t N, int64_t is, int64_t cs, double t, const double* y, double* dy, const Params& P,
                           hipStream_t s) {
