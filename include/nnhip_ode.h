@@ -88,7 +88,8 @@ int nnhip_device_count(void);            /* >=0, or NNHIP_EHIP                  
 const char* nnhip_last_error(void);      /* thread-local, never NULL                                        */
 const char* nnhip_build_info(void);      /* arch, fp-contract mode, compiler                                */
 
-/* Frees what the library caches between calls: the calling thread's pinned staging buffer and hipGraph cache, the idle
+/* Frees what the library caches between calls: the calling thread's pinned staging buffer, hipGraph caches (they are per
+ * thread: other threads keep theirs until they call this or change a tuning knob) and side streams, the idle
  * stream / event contexts of the host-pointer solve, the RCCL communicators.  Everything is rebuilt on demand; compiled user
  * right-hand sides are released one by one with nnhip_ode_rhs_release.  Call it from each thread that used the library if a
  * clean shutdown matters; not calling it is harmless. */
@@ -104,10 +105,16 @@ int nnhip_host_free(void* p);
  *   "rk4_stream_auto" 0|1 (default 1: choose vec/mode from the working-set size), "rk4_stream_vec" 1|2|4|8,
  *   "rk4_stream_mode" 0..3 (0 plain, 1 non-temporal, 2 persistent, 3 both), "rk4_stream_blocks_per_cu" 1..64,
  *   "stream_graph" 0|1|2 (0 eager launches; 1 capture nnhip_ode_fixed_stream_f64_dev's launch sequence in a hipGraph
- *   and replay it; default 2 = do so for launch-bound batches — up to 2e6 states, 16..1e5 steps, a non-default stream — from the
- *   second identical call on), "dim16_variant" 0..4 (A/B mappings of the fused 16-component kernels), "fp_contract" 0|1 (opt-in FMA-contracted fused
+ *   and replay it; default 2 = do so for launch-bound batches — up to 2e6 states, 16..1e4 steps, a non-default stream — from the
+ *   second identical call on; the polling groups of nnhip_ode_adaptive_stream_f64_dev are replayed from a graph unless 0),
+ *   "adv_nontemporal" -1|0|1 (non-temporal instantiations of the streaming kernels; -1 = automatic: when the state of one launch
+ *   exceeds 192 MiB), "adv_split" 0|1|2|4 (index ranges of the adaptive streaming loop on separate streams; measured slower, default 1),
+ *   "fixed_vec_ipl" 0|2 (0 = one IVP per lane instead of the vectorised fixed-step streaming kernel),
+ *   "multi_gpu_oversubscribe" 0|1 (nnhip_ode_solve_batch_multi_gpu_f64 accepts more shards than devices: shard r on device r mod #devices),
+ *   "dim16_variant" 0..4 (A/B mappings of the fused 16-component kernels), "fp_contract" 0|1 (opt-in FMA-contracted fused
  *   kernels: NOT bit-exact, within 1e-10 / 1e-6), "host_chunks" 0..64 (0 = automatic: 8 when the caller's buffers are page-locked, else 1) and
  *   "host_register" 0|1 (pipelining of the host-pointer solve) */
+/* Changing a knob drops the calling thread's hipGraph caches so that the new setting takes effect on its next call. */
 int nnhip_tune_set(const char* key, int value);
 
 /* ---- options / dispatch (host only, no device needed) ---------------------------------------- */
