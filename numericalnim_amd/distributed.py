@@ -22,15 +22,29 @@ def c2_y0_torch(lo, hi, device):
     return 1.0 + (i % (1 << 20)).to(torch.float64) * 2.0 ** -20
 
 
-def all_gather_states(local, group=None):
-    """All-gather equal-sized per-rank final states (last axis = IVP index) into the global tensor."""
+def all_gather_states(local, group=None, n_total=None):
+    """All-gather per-rank final states (last axis = IVP index) into the global tensor on every rank.
+
+    Equal shards (C5: 8e7 IVPs over 8 GPUs) are ONE all_gather_into_tensor.  Ragged shards (n_total not divisible by the world
+    size; pass n_total so that every rank knows every shard size from shard_range without a size exchange) are padded to the
+    largest shard for the same single collective and trimmed afterwards."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     loc = local.contiguous()
-    flat = torch.empty(world * loc.numel(), dtype=loc.dtype, device=loc.device)
-    dist.all_gather_into_tensor(flat, loc.view(-1), group=group)  # one collective: RCCL over xGMI on GPUs, gloo on CPU
-    if loc.dim() == 1:
-        return flat
-    parts = flat.view((world,) + tuple(loc.shape))  # [world, ..., n_local] -> concatenate along the IVP axis
-    return torch.cat(list(parts.unbind(0)), dim=-1)
+    if n_total is None or n_total % world == 0:
+        flat = torch.empty(world * loc.numel(), dtype=loc.dtype, device=loc.device)
+        dist.all_gather_into_tensor(flat, loc.view(-1), group=group)  # one collective: RCCL over xGMI on GPUs, gloo on CPU
+        if loc.dim() == 1:
+            return flat
+        parts = flat.view((world,) + tuple(loc.shape))  # [world, ..., n_local] -> concatenate along the IVP axis
+        return torch.cat(list(parts.unbind(0)), dim=-1)
+    sizes = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
+    nmax = max(sizes)
+    lead = tuple(loc.shape[:-1])
+    padded = torch.zeros(lead + (nmax,), dtype=loc.dtype, device=loc.device)
+    padded[..., :loc.shape[-1]] = loc
+    flat = torch.empty(world * padded.numel(), dtype=loc.dtype, device=loc.device)
+    dist.all_gather_into_tensor(flat, padded.view(-1), group=group)
+    parts = flat.view((world,) + lead + (nmax,))
+    return torch.cat([parts[r][..., :sizes[r]] for r in range(world)], dim=-1)

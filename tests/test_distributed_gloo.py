@@ -1,4 +1,4 @@
-"""N>1 path on CPU: world_size-2 gloo.  The batch shards as contiguous IVP index ranges; the only collective
+"""N>1 path on CPU: gloo at world sizes 2, 3 (ragged shards) and 8 (BASELINE config C5's rank count).  The batch shards as contiguous IVP index ranges; the only collective
 is the all-gather that reassembles the final-state tensor (numericalnim_amd/distributed.py, used by bench.py).
 No GPU here, so each rank integrates its shard with the ORACLE (tests may) and the gathered result must equal
 the unsharded oracle run bit for bit."""
@@ -40,19 +40,19 @@ def _worker(rank, world, port, n_total, dim, q):
         y0 = np.stack([base, np.ones_like(base), np.ones_like(base)])
         r = O.solve_ode_batch(O.RHS_LORENZ, [10.0, 28.0, 8.0 / 3.0], y0, hi - lo, 3, [0.0, 0.25], O.new_options(), "dopri54")
         local = torch.from_numpy(r["y"][-1].copy())  # [3, n_local]
-    full = nd.all_gather_states(local)
+    full = nd.all_gather_states(local, n_total=n_total)
     if rank == 0:
         q.put(full.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("world,n_total", [(2, 512), (3, 500), (8, 1000)], ids=["world2", "world3_ragged", "world8"])
 @pytest.mark.parametrize("dim", [1, 3])
-def test_shard_integrate_allgather_world2(oracle, dim):
+def test_shard_integrate_allgather(oracle, dim, world, n_total):
     import torch.multiprocessing as mp
     from numericalnim_amd import distributed as nd
     O = oracle
-    world, n_total = 2, 512
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
