@@ -203,6 +203,16 @@ int nnhip_ode_solve_batch_calls_f64_dev(const nnhip_ode_options* opt, int integr
                                         double* y_out, int32_t* ny_out, int64_t* steps_out, int64_t* rejected_out, int64_t max_steps,
                                         void* stream);
 
+/* Host-pointer form: N reference calls solveODE(f, y0_i, [options_i.tStart, t_end[i]], options_i) (ode.nim:589-591) in one launch.
+ * opt_per_ivp: array of N option objects in host memory (NULL: every call uses `opt`; when given, `opt` still supplies nothing but
+ * validation defaults).  t_end, y0, per_ivp_params, y_out [2][dim][N] / [2][N][dim], ny_out, steps_out, rejected_out: host arrays,
+ * staged through `device` in one piece.  The objects' fields become the per-IVP tables of nnhip_ode_solve_batch_calls_f64_dev, whose
+ * semantics apply (an adaptive call with dtMax < dtMin fails alone: ny_out[i] = -1, NaN rows). */
+int nnhip_ode_solve_batch_calls_f64(const nnhip_ode_options* opt, const nnhip_ode_options* opt_per_ivp, int integrator, int rhs_kind,
+                                    const double* rhs_params, int n_params, const double* per_ivp_params, int n_per_ivp,
+                                    const double* y0, int64_t N, int dim, int layout, const double* t_end, double* y_out,
+                                    int32_t* ny_out, int64_t* steps_out, int64_t* rejected_out, int64_t max_steps, int device);
+
 /* Divergence binning: the same fused solve for batches whose members take very different step sequences (the reference runs
  * them one after the other, ode.nim:589-591; on a wavefront they share an instruction stream).  The IVPs are INTEGRATED in
  * ascending order of `sort_key` (device array [N]) and every result is WRITTEN at the IVP's own index, so outputs are in the
@@ -263,7 +273,9 @@ int nnhip_ode_fixed_stream_dense_f64_dev(const nnhip_ode_options* opt, int integ
  * per-IVP history lastIter = (t, y, dy), ode.nim:512-530); y, FSAL, t, dt, lastIter and denseIndex are resident in HBM between
  * launches.  Both directions around options.tStart, any tspan, the reference's row assembly and quirks.  y0 / y_out / ny_out
  * (int32 [N], required: rows the reference returns for IVP i; rows beyond are NaN) are device pointers, tspan / t_out host.
- * Compiled-in thread-per-IVP right-hand sides.  `ws`: nnhip_ode_adaptive_stream_dense_workspace_bytes(N, dim, n_t) bytes.
+ * Every right-hand side kind (thread-per-IVP and lanes-per-system, compiled-in and run-time compiled).  `ws`:
+ * nnhip_ode_adaptive_stream_dense_workspace_bytes(N, dim, n_t) bytes.  The host polls one group of `check_every` launches behind the
+ * device (launches_out counts the group issued past the end as well).
  * Bitwise equal to nnhip_ode_solve_batch_f64_dev. */
 int64_t nnhip_ode_adaptive_stream_dense_workspace_bytes(int64_t N, int dim, int n_t);
 int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,

@@ -170,6 +170,42 @@ inline OdeSolution solveODE(const RhsSpec& f, const OdeBatch& y0, const std::vec
   return sol;
 }
 
+// N separate reference calls in one launch: result row set i == solveODE(f, y0_i, {options_i.tStart, tEnd[i]}, options_i)
+// (ode.nim:589-591: every call owns its tspan and its options).  `options` holds one object per IVP, or one for all, or none
+// (DEFAULT_ODEoptions).  y[0], y[1] are the two rows the reference returns per call (y0 first when tEnd > tStart, last when
+// tEnd < tStart); ny[i] = 1 when the span is empty, -1 for a call the reference would refuse (see nnhip_ode.h); sol.t stays empty
+// (the times differ per IVP: they are {min, max} of (tStart_i, tEnd[i])).
+template <class T = double>
+inline OdeSolution solveODECalls(const RhsSpec& f, const OdeBatch& y0, const std::vector<double>& tEnd,
+                                 const std::vector<ODEoptions>& options = {}, const NumContext<T>* ctx = nullptr,
+                                 const std::string& integrator = "dopri54", int device = 0,
+                                 const std::vector<std::vector<double>>& sweep = {}) {
+  const int integ = nnhip_ode_integrator_id(integrator.c_str());
+  if (integ < 0) throw std::invalid_argument(integrator + " is not a valid integrator");  // ode.nim:651
+  if ((int64_t)tEnd.size() != y0.N) throw std::invalid_argument("tEnd needs one value per IVP");
+  if (options.size() > 1 && (int64_t)options.size() != y0.N) throw std::invalid_argument("options: one object, or one per IVP");
+  const std::vector<double> p = f.params(ctx);
+  std::vector<double> flat;
+  for (const auto& row : sweep) {
+    if ((int64_t)row.size() != y0.N) throw std::invalid_argument("sweep rows must have one value per IVP");
+    flat.insert(flat.end(), row.begin(), row.end());
+  }
+  OdeSolution sol;
+  const size_t row = (size_t)y0.N * y0.dim;
+  std::vector<double> yout(2 * row);
+  sol.ny.assign((size_t)y0.N, 0);
+  const ODEoptions& base = options.size() == 1 ? options[0] : DEFAULT_ODEoptions();
+  throwOn(nnhip_ode_solve_batch_calls_f64(&base, options.size() > 1 ? options.data() : nullptr, integ, f.kind, p.data(), (int)p.size(),
+                                          flat.empty() ? nullptr : flat.data(), (int)sweep.size(), y0.data.data(), y0.N, y0.dim, y0.layout,
+                                          tEnd.data(), yout.data(), sol.ny.data(), nullptr, nullptr, 0, device));
+  sol.y.resize(2);
+  for (int j = 0; j < 2; ++j) {
+    sol.y[j].N = y0.N; sol.y[j].dim = y0.dim; sol.y[j].layout = y0.layout;
+    sol.y[j].data.assign(yout.begin() + (size_t)j * row, yout.begin() + (size_t)(j + 1) * row);
+  }
+  return sol;
+}
+
 // ---- the consumers on either side of the solver: same names as the reference's procs, batched, over the
 // host-pointer entries (arrays are staged through the device per call) ---------------------------------------------------------
 namespace detail {

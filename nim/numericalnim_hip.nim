@@ -99,6 +99,43 @@ proc solveODE*(f: RhsSpec, y0: OdeBatch, tspan: openArray[float],
   for j in 0 ..< ts.len:
     result[1].add OdeBatch(n: y0.n, dim: y0.dim, layout: y0.layout, data: yOut[j*row ..< (j+1)*row])
 
+proc solveODE*(f: RhsSpec, y0: OdeBatch, tEnd: openArray[float], options: openArray[ODEoptions],
+               ctx: NumContext[OdeBatch, float] = nil, integrator = "dopri54",
+               sweep: seq[seq[float]] = @[]): (seq[OdeBatch], seq[int32]) =
+  ## N separate reference calls in one launch: IVP i is `solveODE(f, y0_i, [options[i].tStart, tEnd[i]], options[i])`
+  ## (ode.nim:589-591: every call owns its tspan and its options).  `options` holds one object per IVP, or a single one for all.
+  ## Returns the two rows the reference returns per call (y0 first when tEnd > tStart, last when tEnd < tStart) and ny:
+  ## 2, 1 when the span is empty, -1 for a call the reference would refuse (rows NaN); the other calls are unaffected.
+  if tEnd.len != y0.n: raise newException(ValueError, "tEnd needs one value per IVP")
+  if options.len != 1 and options.len != y0.n: raise newException(ValueError, "options: one object, or one per IVP")
+  var ctx = ctx
+  if ctx.isNil: ctx = newNumContext[OdeBatch, float]()
+  let integ = nnhip_ode_integrator_id(integrator.cstring)
+  if integ < 0: raise newException(ValueError, &"{integrator} is not a valid integrator")
+  var params: seq[cdouble]
+  for k in f.keys: params.add(ctx.fValues[k].cdouble)
+  var base = options[0].toC
+  var each: seq[NnhipOptions]
+  if options.len > 1:
+    for o in options: each.add(o.toC)
+  var flat: seq[cdouble]
+  for row in sweep:
+    for v in row: flat.add(v.cdouble)
+  var te = @tEnd
+  var y0d = y0.data
+  var yOut = newSeq[cdouble](2 * y0.n * y0.dim)
+  var ny = newSeq[int32](y0.n)
+  let pp = if params.len > 0: addr params[0] else: nil
+  let sp = if flat.len > 0: addr flat[0] else: nil
+  let ep = if each.len > 0: addr each[0] else: nil
+  let rhsKind = (if f.userKind > 0: f.userKind else: f.kind.int).cint
+  check nnhip_ode_solve_batch_calls_f64(addr base, ep, integ, rhsKind, pp, params.len.cint, sp, sweep.len.cint, addr y0d[0], y0.n.int64,
+                                        y0.dim.cint, y0.layout.cint, addr te[0], addr yOut[0], addr ny[0], nil, nil, 0, 0)
+  let row = y0.n * y0.dim
+  for j in 0 ..< 2:
+    result[0].add OdeBatch(n: y0.n, dim: y0.dim, layout: y0.layout, data: yOut[j*row ..< (j+1)*row])
+  result[1] = ny
+
 # ---- the consumers on either side of the solver (SURVEY §8 f4), same names as the reference's procs -------------------------
 proc paramsOf(f: RhsSpec, ctx: NumContext[OdeBatch, float]): seq[cdouble] =
   for k in f.keys: result.add(ctx.fValues[k].cdouble)

@@ -767,6 +767,70 @@ int nnhip_ode_solve_batch_sorted_f64(const nnhip_ode_options* opt, int integrato
   return done(NNHIP_OK);
 }
 
+// Host-pointer form of the per-call solve: N reference calls `solveODE(f, y0_i, [options_i.tStart, t_end[i]], options_i)` in one
+// launch (ode.nim:589-591).  opt_per_ivp is an array of N option objects (NULL: every call uses `opt`); their fields are transposed
+// into the per-IVP tables of nnhip_ode_solve_batch_calls_f64_dev here, whose per-field semantics apply (scaleMax / scaleMin are unused
+// after construction, ode.nim:97-102).
+int nnhip_ode_solve_batch_calls_f64(const nnhip_ode_options* opt, const nnhip_ode_options* opt_per_ivp, int integrator, int rhs_kind,
+                                    const double* rhs_params, int n_params, const double* per_ivp_params, int n_per_ivp, const double* y0,
+                                    int64_t N, int dim, int layout, const double* t_end, double* y_out, int32_t* ny_out, int64_t* steps_out,
+                                    int64_t* rejected_out, int64_t max_steps, int device) {
+  if (N < 0 || dim < 1) return fail(NNHIP_EVALUE, "bad sizes");
+  if (N > 0 && (!t_end || !y0 || !y_out)) return fail(NNHIP_EVALUE, "t_end / y0 / y_out is NULL");
+  if (n_per_ivp < 0 || n_per_ivp > nnhip::kMaxParams || (n_per_ivp > 0 && !per_ivp_params && N > 0)) return fail(NNHIP_EVALUE, "bad per-IVP parameter table");
+  int ndev = nnhip_device_count();
+  if (ndev < 0) return ndev;
+  if (ndev == 0) return fail(NNHIP_EHIP, "no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(NNHIP_EVALUE, "device %d out of range [0,%d)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  HostSolveCtx* hc = nullptr;
+  int rc = host_ctx_acquire(device, 0, &hc);
+  if (rc) { host_ctx_release(hc); return rc; }
+  hipStream_t st = hc->s[0];
+  const size_t nState = (size_t)N * dim, nOut = nState * 2;
+  const int nOpt = opt_per_ivp ? 6 : 0;  // tStart, absTol, relTol, dtMax, dtMin, dt
+  std::vector<double> cols;
+  if (nOpt && N) {
+    cols.resize((size_t)nOpt * (size_t)N);
+    for (int64_t i = 0; i < N; ++i) {
+      const nnhip_ode_options& o = opt_per_ivp[i];
+      cols[0 * (size_t)N + i] = o.tStart;
+      cols[1 * (size_t)N + i] = o.absTol;
+      cols[2 * (size_t)N + i] = o.relTol;
+      cols[3 * (size_t)N + i] = o.dtMax;
+      cols[4 * (size_t)N + i] = o.dtMin;
+      cols[5 * (size_t)N + i] = o.dt;
+    }
+  }
+  // one allocation: y0 | out | ny | steps | rejected | t_end | option columns | per-IVP table
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t oY0 = 0, oOut = oY0 + up(nState * 8), oNy = oOut + up(nOut * 8), oSt = oNy + up((size_t)N * 4), oRj = oSt + up((size_t)N * 8),
+               oEnd = oRj + up((size_t)N * 8), oCols = oEnd + up((size_t)N * 8), oPer = oCols + up((size_t)nOpt * (size_t)N * 8),
+               total = oPer + up((size_t)n_per_ivp * (size_t)N * 8) + 256;
+  char* d = nullptr;
+  hipError_t e = hipMalloc((void**)&d, total);
+  if (e != hipSuccess) { host_ctx_release(hc); return fail(e == hipErrorOutOfMemory ? NNHIP_ENOMEM : NNHIP_EHIP, "hipMalloc(%zu) failed: %s", total, hipGetErrorString(e)); }
+  auto done = [&](int code) { (void)hipStreamSynchronize(st); (void)hipFree(d); host_ctx_release(hc); return code; };
+#define HIP_TRY_S(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return done(fail(NNHIP_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e))); } while (0)
+  if (nState) HIP_TRY_S(hipMemcpyAsync(d + oY0, y0, nState * 8, hipMemcpyHostToDevice, st));
+  if (N) HIP_TRY_S(hipMemcpyAsync(d + oEnd, t_end, (size_t)N * 8, hipMemcpyHostToDevice, st));
+  if (!cols.empty()) HIP_TRY_S(hipMemcpyAsync(d + oCols, cols.data(), cols.size() * 8, hipMemcpyHostToDevice, st));
+  if (n_per_ivp > 0 && N) HIP_TRY_S(hipMemcpyAsync(d + oPer, per_ivp_params, (size_t)n_per_ivp * (size_t)N * 8, hipMemcpyHostToDevice, st));
+  auto col = [&](int k) -> const double* { return nOpt && N ? (const double*)(d + oCols) + (size_t)k * (size_t)N : nullptr; };
+  rc = nnhip_ode_solve_batch_calls_f64_dev(opt, integrator, rhs_kind, rhs_params, n_params, n_per_ivp > 0 ? (const double*)(d + oPer) : nullptr, n_per_ivp,
+                                           (const double*)(d + oY0), N, dim, layout, (const double*)(d + oEnd), col(0), col(1), col(2), col(3), col(4), col(5),
+                                           (double*)(d + oOut), ny_out ? (int32_t*)(d + oNy) : nullptr, steps_out ? (int64_t*)(d + oSt) : nullptr,
+                                           rejected_out ? (int64_t*)(d + oRj) : nullptr, max_steps, st);
+  if (rc) return done(rc);
+  if (nOut) HIP_TRY_S(hipMemcpyAsync(y_out, d + oOut, nOut * 8, hipMemcpyDeviceToHost, st));
+  if (ny_out && N) HIP_TRY_S(hipMemcpyAsync(ny_out, d + oNy, (size_t)N * 4, hipMemcpyDeviceToHost, st));
+  if (steps_out && N) HIP_TRY_S(hipMemcpyAsync(steps_out, d + oSt, (size_t)N * 8, hipMemcpyDeviceToHost, st));
+  if (rejected_out && N) HIP_TRY_S(hipMemcpyAsync(rejected_out, d + oRj, (size_t)N * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY_S(hipStreamSynchronize(st));
+#undef HIP_TRY_S
+  return done(NNHIP_OK);
+}
+
 int nnhip_ode_solve_batch_f64(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
                               int n_params, const double* y0, int64_t N, int dim, int layout, const double* tspan,
                               int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
@@ -1478,8 +1542,8 @@ int64_t nnhip_ode_adaptive_stream_dense_workspace_bytes(int64_t N, int dim, int 
 // The whole ODESolver driver (ode.nim:471-586) for adaptive integrators over the HBM-resident `advance` kernel: both directions,
 // per-IVP (t, dt, FSAL), per-IVP Hermite history and denseIndex, requested rows emitted by the kernel as each IVP's steps pass them
 // (:512-524).  y0 / y_out / ny_out are device pointers, tspan / t_out host.  ny_out[i] (required, int32 [N]) = rows the
-// reference returns for IVP i; rows beyond are NaN.  Thread-per-IVP right-hand sides (compiled-in kinds, dim <= 4).  Bitwise equal to
-// nnhip_ode_solve_batch_f64_dev.
+// reference returns for IVP i; rows beyond are NaN.  Every right-hand side kind: thread-per-IVP and lanes-per-system, compiled-in and
+// run-time compiled.  Bitwise equal to nnhip_ode_solve_batch_f64_dev.
 int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
                                             const double* y0, int64_t N, int dim, int layout, const double* tspan, int n_t, double* t_out,
                                             double* y_out, int32_t* ny_out, void* ws, int64_t ws_bytes, int check_every, int64_t max_launches,
@@ -1492,8 +1556,10 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
   for (int j = 0; j < n_t; ++j) if (!std::isfinite(tspan[j])) return fail(NNHIP_EVALUE, "tspan[%d] is not finite", j);
   if (!std::isfinite(opt->tStart)) return fail(NNHIP_EVALUE, "options.tStart is not finite");
   if (!(opt->dtMin > 0.0) && max_launches <= 0) return fail(NNHIP_EVALUE, "adaptive integrators need options.dtMin > 0 or max_launches > 0");
-  const nnhip::DenseAdvLaunch fn = rhs_kind < NNHIP_RHS_USER_BASE ? find_advance_dense(integrator, rhs_kind, dim) : nnhip::DenseAdvLaunch{nullptr, nullptr};
-  if (!fn.advance) return fail(NNHIP_EUNSUPPORTED, "no dense advance kernel for integrator=%s rhs_kind=%d dim=%d (compiled-in thread-per-IVP right-hand sides)", kMethods[integrator].name, rhs_kind, dim);
+  nnhip::DenseAdvLaunch fn = rhs_kind < NNHIP_RHS_USER_BASE ? find_advance_dense(integrator, rhs_kind, dim) : nnhip::DenseAdvLaunch{nullptr, nullptr};
+  int userKind = rhs_kind >= NNHIP_RHS_USER_BASE ? rhs_kind : -1;
+  if (!fn.advance && userKind < 0) userKind = nnhip::rtc_builtin_kind(rhs_kind, dim);  // a built-in right-hand side at a size without an ahead-of-time kernel
+  if (!fn.advance && userKind < 0) return fail(NNHIP_EUNSUPPORTED, "no dense advance kernel for integrator=%s rhs_kind=%d dim=%d", kMethods[integrator].name, rhs_kind, dim);
   TimeGrid g;
   make_grid(opt, tspan, n_t, g);
   if (t_out) std::copy(g.tOut.begin(), g.tOut.end(), t_out);
@@ -1544,24 +1610,63 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
     HIP_TRY(nnhip::launch_kernel(nnhip::advance_dense_finalize_kernel<0>, grid, block, s, a, mode, dim, y0, ny_out, n_t));
     return NNHIP_OK;
   };
+  auto advance = [&](const nnhip::StepArgs& run) -> int {
+    if (fn.advance) { HIP_TRY(fn.advance(run, s)); return NNHIP_OK; }
+    if (nnhip::rtc_launch_advance_dense(userKind, integrator, run, s) != hipSuccess) return fail(NNHIP_EHIP, "run-time compiled dense advance kernel: %s", nnhip::rtc_last_error());
+    return NNHIP_OK;
+  };
+  // y = y0, FSAL = f(t0, y0) / g(-t0, y0) = -f(t0, y0) (:506,:546), t, dt, denseIndex = 0, lastIter = (t, y, FSAL) (:498,:548)
+  auto init = [&](const nnhip::StepArgs& run, bool neg, double tStartEff) -> int {
+    if (fn.init) { HIP_TRY(fn.init(run, y0, tStartEff, dtInit, s)); return NNHIP_OK; }
+    const size_t bytes = (size_t)nState * sizeof(double);
+    HIP_TRY(hipMemcpyAsync(yW, y0, bytes, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(lastY, y0, bytes, hipMemcpyDeviceToDevice, s));
+    const int r = nnhip_ode_rhs_batch_f64_dev(rhs_kind, rhs_params, n_params, N, dim, layout, neg ? -tStartEff : tStartEff, y0, fsal, stream);
+    if (r) return r;
+    if (neg) HIP_TRY(nnhip::negate_f64(fsal, fsal, nState, s));
+    HIP_TRY(hipMemcpyAsync(lastDy, fsal, bytes, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(nnhip::launch_kernel(nnhip::fill_t_dt_kernel<0>, grid, block, s, tArr, dtArr, N, tStartEff, dtInit));
+    HIP_TRY(nnhip::launch_fill_f64(lastT, N, tStartEff, s));
+    HIP_TRY(hipMemsetAsync(denseIdx, 0, (size_t)N * sizeof(int32_t), s));
+    return NNHIP_OK;
+  };
   auto run_dir = [&](bool neg, double tStartEff, double tEnd, const double* req, int nReq, const int32_t* rowBase) -> int {
     a.negate = neg ? 1 : 0; a.tEnd = tEnd; a.tReq = req; a.nReq = nReq; a.rowBase = rowBase;
     a.useDense = n_t != 2 ? 1 : 0;  // :499-502: with a 2-point tspan the only row of a direction is the final yPositive.add(y)
     nnhip::StepArgs run = a;
-    HIP_TRY(fn.init(run, y0, tStartEff, dtInit, s));
-    for (;;) {
+    int r = init(run, neg, tStartEff);
+    if (r) return r;
+    // groups of check_every launches; the host reads group g's "anyone still integrating?" flags while group g + 1 runs (a retired
+    // IVP returns at once, so the one group issued past the end costs only its launches)
+    auto issue = [&](int64_t grp) -> int {
       HIP_TRY(hipMemsetAsync(active, 0, nnhip::kAggSlots * sizeof(unsigned int), s));
       for (int k = 0; k < check_every; ++k) {
         run.active = k == check_every - 1 ? active : nullptr;
-        HIP_TRY(fn.advance(run, s));
+        const int ra = advance(run);
+        if (ra) return ra;
         ++launches;
       }
-      HIP_TRY(hipMemcpyAsync(poll.h, active, nnhip::kAggSlots * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
+      HIP_TRY(hipMemcpyAsync(poll.h + (grp & 1) * nnhip::kAggSlots, active, nnhip::kAggSlots * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipEventRecord(poll.ev[grp & 1], s));
+      return NNHIP_OK;
+    };
+    int64_t grp = 0;
+    r = issue(0);
+    if (r) return r;
+    for (;;) {
+      const bool more = !(max_launches > 0 && launches >= max_launches);
+      if (more) {
+        r = issue(grp + 1);
+        if (r) return r;
+      }
+      HIP_TRY(hipEventSynchronize(poll.ev[grp & 1]));
       unsigned int any = 0;
-      for (int k = 0; k < nnhip::kAggSlots; ++k) any |= poll.h[k];
-      if (!any) break;
-      if (max_launches > 0 && launches >= max_launches) break;
+      for (int k = 0; k < nnhip::kAggSlots; ++k) any |= poll.h[(grp & 1) * nnhip::kAggSlots + k];
+      if (!any || !more) {
+        if (more) HIP_TRY(hipEventSynchronize(poll.ev[(grp + 1) & 1]));
+        break;
+      }
+      ++grp;
     }
     return NNHIP_OK;
   };

@@ -751,92 +751,152 @@ __global__ __launch_bounds__(kBlock) void advance_dense_init_kernel(const StepAr
   a.denseIdx_io[i] = 0;
 }
 
+// One loop iteration of one IVP; `ops` owns D of its components (all of them: thread-per-IVP; CPL: lanes-per-system — the lanes
+// of a system read the same per-IVP scalars, so they take every branch together; the `lead` lane stores the scalars).
+template <int METHOD, class OPS>
+NNHIP_DEV unsigned int advance_dense_body(const StepArgs& a, const OPS& ops, int64_t i, int64_t base, bool lead, bool neg) {
+  constexpr int D = OPS::D;
+  using MT = MethodTraits<METHOD>;
+  double t = a.t_io[i];
+  if (!(t < a.tEnd)) return 0u;  // :511
+  const int64_t cs = a.compStride;
+  double y[D], yNew[D], fsal[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    y[c] = ops.owns(c) ? a.y_in[base + c * cs] : 0.0;
+    fsal[c] = ops.owns(c) ? a.fsal_in[base + c * cs] : 0.0;
+  }
+  double dt = a.dt_io[i];
+  int denseIndex = a.denseIdx_io[i];
+  const int high = a.nReq - 1;
+  bool done = false;
+  // :512-524 — requested times that the step just taken has passed
+  if (!a.useDense) {
+  } else if (high < denseIndex) {
+    done = true;  // :513-514 `break`: the loop ends without another step
+  } else {
+    double treq = neg ? -a.tReq[denseIndex] : a.tReq[denseIndex];
+    if (treq <= t) {
+      const double lastT = a.lastT_io[i];
+      double lastY[D], lastDy[D], dyNow[D];
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        lastY[c] = ops.owns(c) ? a.lastY_io[base + c * cs] : 0.0;
+        lastDy[c] = ops.owns(c) ? a.lastDy_io[base + c * cs] : 0.0;
+      }
+      if constexpr (MT::fsal) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) dyNow[c] = fsal[c];
+      } else {
+        ops.rhs(t, y, dyNow);  // f(t, y, ctx) (:521)
+      }
+      while (treq <= t) {  // :515
+        const HermiteW w = hermite_weights(treq, lastT, t);
+        const int64_t r = a.rowBase ? (int64_t)a.rowBase[i] + denseIndex : (int64_t)(a.nReq - 1 - denseIndex);
+#pragma unroll
+        for (int c = 0; c < D; ++c)
+          if (ops.owns(c)) a.rows[r * a.rowStride + base + c * cs] = hermite_apply(w, lastY[c], y[c], lastDy[c], dyNow[c]);
+        denseIndex += 1;
+        if (high < denseIndex) { done = true; break; }  // :523-524
+        treq = neg ? -a.tReq[denseIndex] : a.tReq[denseIndex];
+      }
+      if (lead) a.denseIdx_io[i] = denseIndex;
+    }
+  }
+  if (done) {
+    // every requested time has been emitted: the reference leaves the loop here; the final yPositive.add(y) falls outside the
+    // requested rows.  Retire the IVP (denseIndex == nReq tells the finalize kernel that nothing is left to add).
+    if (lead) a.t_io[i] = a.tEnd;
+    return 0u;
+  }
+  dt = nmin(dt, a.tEnd - t);  // :525
+  if (a.useDense) {  // lastIter = (t, y, dy) (:526-530): dy = FSAL for FSAL methods, f(t, y) otherwise
+    if (lead) a.lastT_io[i] = t;
+    if constexpr (MT::fsal) {
+#pragma unroll
+      for (int c = 0; c < D; ++c)
+        if (ops.owns(c)) { a.lastY_io[base + c * cs] = y[c]; a.lastDy_io[base + c * cs] = fsal[c]; }
+    } else {
+      double dy0[D];
+      ops.rhs(t, y, dy0);
+#pragma unroll
+      for (int c = 0; c < D; ++c)
+        if (ops.owns(c)) { a.lastY_io[base + c * cs] = y[c]; a.lastDy_io[base + c * cs] = dy0[c]; }
+    }
+  }
+  double error = 0.0, factor;
+  int64_t rej = 0;
+  embedded_step<METHOD>(ops, t, dt, y, fsal, yNew, error, a.ctl, rej, factor);  // :531
+  t += dt;                                                                      // :532
+  if (error == 0.0) dt *= 5.0;
+  else dt = dt * factor;
+  if (dt < a.ctl.dtMin) dt = a.ctl.dtMin;
+  else if (a.ctl.dtMax < dt) dt = a.ctl.dtMax;
+  if (error != error) t = a.tEnd;  // NaN abort, as in the fused driver
+#pragma unroll
+  for (int c = 0; c < D; ++c)
+    if (ops.owns(c)) { a.y_out[base + c * cs] = yNew[c]; a.fsal_out[base + c * cs] = fsal[c]; }
+  if (lead) {
+    a.t_io[i] = t;
+    a.dt_io[i] = dt;
+    if (a.error) a.error[i] = error;
+    if (a.steps_io) a.steps_io[i] += 1;
+  }
+  return t < a.tEnd ? 1u : 0u;
+}
+
 template <int METHOD, class RHS>
 __global__ __launch_bounds__(kBlock) void advance_dense_tpi_kernel(const StepArgs a) {
-  constexpr int D = RHS::dim;
-  using MT = MethodTraits<METHOD>;
-  static_assert(MT::adaptive, "adaptive methods only");
+  static_assert(MethodTraits<METHOD>::adaptive, "adaptive methods only");
+  controller_prologue();
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   unsigned int stillActive = 0;
   if (i < a.N) {
-    double t = a.t_io[i];
-    if (t < a.tEnd) {  // :511
-      const Params P = params_of(a, i);
-      const bool neg = a.negate != 0;
-      const TpiOpsRt<RHS> ops{P, neg};
-      const int64_t base = i * a.ivpStride, cs = a.compStride;
-      double y[D], yNew[D], fsal[D];
-#pragma unroll
-      for (int c = 0; c < D; ++c) { y[c] = a.y_in[base + c * cs]; fsal[c] = a.fsal_in[base + c * cs]; }
-      double dt = a.dt_io[i];
-      int denseIndex = a.denseIdx_io[i];
-      const int high = a.nReq - 1;
-      bool done = false;
-      // :512-524 — requested times that the step just taken has passed
-      if (!a.useDense) {
-      } else if (high < denseIndex) {
-        done = true;  // :513-514 `break`: the loop ends without another step
-      } else {
-        double treq = neg ? -a.tReq[denseIndex] : a.tReq[denseIndex];
-        if (treq <= t) {
-          const double lastT = a.lastT_io[i];
-          double lastY[D], lastDy[D], dyNow[D];
-#pragma unroll
-          for (int c = 0; c < D; ++c) { lastY[c] = a.lastY_io[base + c * cs]; lastDy[c] = a.lastDy_io[base + c * cs]; }
-          if constexpr (MT::fsal) {
-#pragma unroll
-            for (int c = 0; c < D; ++c) dyNow[c] = fsal[c];
-          } else {
-            ops.rhs(t, y, dyNow);  // f(t, y, ctx) (:521)
-          }
-          while (treq <= t) {  // :515
-            const HermiteW w = hermite_weights(treq, lastT, t);
-            const int64_t r = a.rowBase ? (int64_t)a.rowBase[i] + denseIndex : (int64_t)(a.nReq - 1 - denseIndex);
-#pragma unroll
-            for (int c = 0; c < D; ++c) a.rows[r * a.rowStride + base + c * cs] = hermite_apply(w, lastY[c], y[c], lastDy[c], dyNow[c]);
-            denseIndex += 1;
-            if (high < denseIndex) { done = true; break; }  // :523-524
-            treq = neg ? -a.tReq[denseIndex] : a.tReq[denseIndex];
-          }
-          a.denseIdx_io[i] = denseIndex;
-        }
-      }
-      if (done) {
-        // every requested time has been emitted: the reference leaves the loop here; the final yPositive.add(y) falls outside the
-        // requested rows.  Retire the IVP (denseIndex == nReq tells the finalize kernel that nothing is left to add).
-        a.t_io[i] = a.tEnd;
-      } else {
-        dt = nmin(dt, a.tEnd - t);  // :525
-        if (a.useDense) {  // lastIter = (t, y, dy) (:526-530): dy = FSAL for FSAL methods, f(t, y) otherwise
-          a.lastT_io[i] = t;
-          if constexpr (MT::fsal) {
-#pragma unroll
-            for (int c = 0; c < D; ++c) { a.lastY_io[base + c * cs] = y[c]; a.lastDy_io[base + c * cs] = fsal[c]; }
-          } else {
-            double dy0[D];
-            ops.rhs(t, y, dy0);
-#pragma unroll
-            for (int c = 0; c < D; ++c) { a.lastY_io[base + c * cs] = y[c]; a.lastDy_io[base + c * cs] = dy0[c]; }
-          }
-        }
-        double error = 0.0, factor;
-        int64_t rej = 0;
-        embedded_step<METHOD>(ops, t, dt, y, fsal, yNew, error, a.ctl, rej, factor);  // :531
-        t += dt;                                                                      // :532
-        if (error == 0.0) dt *= 5.0;
-        else dt = dt * factor;
-        if (dt < a.ctl.dtMin) dt = a.ctl.dtMin;
-        else if (a.ctl.dtMax < dt) dt = a.ctl.dtMax;
-        if (error != error) t = a.tEnd;  // NaN abort, as in the fused driver
-#pragma unroll
-        for (int c = 0; c < D; ++c) { a.y_out[base + c * cs] = yNew[c]; a.fsal_out[base + c * cs] = fsal[c]; }
-        a.t_io[i] = t;
-        a.dt_io[i] = dt;
-        if (a.error) a.error[i] = error;
-        if (a.steps_io) a.steps_io[i] += 1;
-        stillActive = t < a.tEnd ? 1u : 0u;
-      }
-    }
+    const Params P = params_of(a, i);
+    const bool neg = a.negate != 0;
+    const TpiOpsRt<RHS> ops{P, neg};
+    stillActive = advance_dense_body<METHOD>(a, ops, i, i * a.ivpStride, true, neg);
+  }
+  if (a.active) {
+    if (__syncthreads_or((int)stillActive) && threadIdx.x == 0) a.active[blockIdx.x % kAggSlots] = 1u;
+  }
+}
+
+// Lanes-per-system form (Vector[float] states of 8 / 16 / 32 ... components, and run-time compiled per-component systems): the
+// direction is a kernel-wide flag, so the two compile-time variants of LpsOps are selected by one wave-uniform branch.
+template <class RHS, int CPL>
+struct LpsOpsRt {
+  static constexpr int D = CPL;
+  LpsOps<RHS, false, CPL> f;
+  LpsOps<RHS, true, CPL> b;
+  bool neg;
+  NNHIP_DEV bool owns(int j) const { return f.owns(j); }
+  NNHIP_DEV void rhs(double t, const double (&y)[CPL], double (&dy)[CPL]) const {
+    if (neg) b.rhs(t, y, dy);
+    else f.rhs(t, y, dy);
+  }
+  NNHIP_DEV double norm(const double (&yNew)[CPL], const double (&err_y)[CPL], const StepCtl& o) const { return f.norm(yNew, err_y, o); }
+};
+
+template <int METHOD, class RHS, int CPL = 1>
+__global__ __launch_bounds__(kBlock) void advance_dense_lps_kernel(const StepArgs a) {
+  static_assert(MethodTraits<METHOD>::adaptive, "adaptive methods only");
+  constexpr int DIM = RHS::dim;
+  constexpr int LPSYS = DIM / CPL;
+  static_assert(DIM % CPL == 0 && 64 % LPSYS == 0, "a system must not straddle wavefronts");
+  __shared__ double lds[2 * kBlock * CPL];
+  controller_prologue();
+  const int sysInBlock = threadIdx.x / LPSYS, c = (threadIdx.x % LPSYS) * CPL;
+  constexpr int perBlock = kBlock / LPSYS;
+  const int64_t i = (int64_t)blockIdx.x * perBlock + sysInBlock;
+  unsigned int stillActive = 0;
+  if (i < a.N) {
+    const Params P = params_of(a, i);
+    const bool neg = a.negate != 0;
+    double* ys = lds + sysInBlock * DIM;
+    double* es = lds + kBlock * CPL + sysInBlock * DIM;
+    const LpsOpsRt<RHS, CPL> ops{{P, ys, es, c}, {P, ys, es, c}, neg};
+    stillActive = advance_dense_body<METHOD>(a, ops, i, i * a.ivpStride + c * a.compStride, c == 0, neg);
   }
   if (a.active) {
     if (__syncthreads_or((int)stillActive) && threadIdx.x == 0) a.active[blockIdx.x % kAggSlots] = 1u;
@@ -1266,11 +1326,27 @@ hipError_t launch_advance_dense(const StepArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
   }
 }
+template <int METHOD, class RHS, int CPL>
+hipError_t launch_advance_dense_lps(const StepArgs& a, hipStream_t s) {
+  if constexpr (MethodTraits<METHOD>::adaptive) {
+    constexpr int perBlock = kBlock / (RHS::dim / CPL);
+    const int64_t grid = (a.N + perBlock - 1) / perBlock;
+    if (grid <= 0) return hipSuccess;
+    return launch_kernel(advance_dense_lps_kernel<METHOD, RHS, CPL>, dim3((unsigned)grid), dim3(kBlock), s, a);
+  } else {
+    return hipErrorInvalidValue;
+  }
+}
+// init == nullptr: the driver initialises the state with the generic pieces (copies + the RHS batch kernel)
 template <int METHOD>
 DenseAdvLaunch find_advance_dense_tpi(int rhs_kind, int dim) {
 #define X(kind, d, T) \
   if (rhs_kind == kind && dim == d) return DenseAdvLaunch{&launch_advance_dense_init<T>, &launch_advance_dense<METHOD, T>};
   NNHIP_FOR_EACH_TPI_RHS(X)
+#undef X
+#define X(kind, d, T, CA, CF) \
+  if (rhs_kind == kind && dim == d) return DenseAdvLaunch{nullptr, &launch_advance_dense_lps<METHOD, T, NNHIP_ADV_CPL(CA)>};
+  NNHIP_FOR_EACH_LPS_RHS(X)
 #undef X
   return DenseAdvLaunch{nullptr, nullptr};
 }

@@ -45,7 +45,7 @@ struct Program {  // the kernels of one (rhs, integrator) code object as loaded 
     (void)hipModuleUnload(module);
     if (have) (void)hipSetDevice(prev);
   }
-  hipFunction_t solve = nullptr, stepPos = nullptr, stepNeg = nullptr, advance = nullptr, rhs = nullptr, quad[2] = {nullptr, nullptr};
+  hipFunction_t solve = nullptr, stepPos = nullptr, stepNeg = nullptr, advance = nullptr, advanceDense = nullptr, rhs = nullptr, quad[2] = {nullptr, nullptr};
   int ivpsPerBlockSolve = kBlock, ivpsPerBlockStep = kBlock, ivpsPerBlockAdvance = kBlock;  // thread-per-IVP: 256; lanes-per-system: 256 / lanes per system
 };
 struct CodeObject {  // compiled once per (rhs, integrator); hipModuleLoadData binds it to the device that is current at the time
@@ -59,10 +59,12 @@ struct UserRhsEntry {
   int dim = 0, n_params = 0;
   bool perComponent = false;  // body computes ONE component (usable by the lanes-per-system kernels) instead of the whole vector
   bool alive = false;
-  std::map<int, CodeObject> programs;  // by integrator; key -1 = the rhs_batch kernel only, key -2 = the cumulative-quadrature kernels
+  std::map<int, CodeObject> programs;  // by integrator; key -1 = the rhs_batch kernel only, key -2 = the cumulative-quadrature kernels,
+                                       // 1000 + integrator = the dense-output adaptive streaming kernel
 };
 
 std::mutex g_mu;
+constexpr int kDenseKey = 1000;  // programs[kDenseKey + integrator]: advance_dense_*_kernel of that integrator
 std::deque<UserRhsEntry> g_user;  // deque: registering a new RHS never moves existing entries (programs are handed out by pointer)
 thread_local std::string g_rtc_err;
 
@@ -115,7 +117,16 @@ bool compile(const UserRhsEntry& e, int integrator, CodeObject& out) {
     return false;
   }
   std::vector<std::string> names;
-  if (integrator >= 0) {
+  if (integrator >= kDenseKey) {  // the dense-output form of the adaptive streaming kernel: its own code object, compiled when first asked for
+    const std::string m = std::to_string(integrator - kDenseKey);
+    if (uses_lps(e)) {
+      const int scpl = lps_step_cpl(e);
+      names.push_back("nnhip::advance_dense_lps_kernel<" + m + ", nnhip::UserRhs, " + std::to_string(scpl) + ">");
+      out.ivpsPerBlockAdvance = kBlock / (padded_dim(e) / scpl);
+    } else {
+      names.push_back("nnhip::advance_dense_tpi_kernel<" + m + ", nnhip::UserRhs>");
+    }
+  } else if (integrator >= 0) {
     const std::string m = std::to_string(integrator);
     if (uses_lps(e)) {
       int adaptive = 0;
@@ -185,6 +196,7 @@ bool load(const CodeObject& co, int integrator, Program& out) {
   hipFunction_t* slots[4] = {&out.solve, &out.stepPos, &out.stepNeg, &out.advance};
   if (integrator == -1) slots[0] = &out.rhs;
   if (integrator == -2) { slots[0] = &out.quad[0]; slots[1] = &out.quad[1]; }
+  if (integrator >= kDenseKey) slots[0] = &out.advanceDense;
   for (size_t i = 0; i < co.lowered.size(); ++i)
     if (hipModuleGetFunction(slots[i], out.module, co.lowered[i].c_str()) != hipSuccess) {
       g_rtc_err = "hipModuleGetFunction failed for " + co.lowered[i];
@@ -322,6 +334,12 @@ hipError_t rtc_launch_advance(int rhs_kind, int integrator, const StepArgs& a, h
   if (!p->advance) { g_rtc_err = "no advance kernel: fixed-step integrator"; return hipErrorInvalidValue; }
   StepArgs copy = a;
   return launch(p->advance, a.N, p->ivpsPerBlockAdvance, &copy, s);
+}
+hipError_t rtc_launch_advance_dense(int rhs_kind, int integrator, const StepArgs& a, hipStream_t s) {
+  const std::shared_ptr<Program> p = get_program(rhs_kind, kDenseKey + integrator);
+  if (!p) return hipErrorInvalidValue;
+  StepArgs copy = a;
+  return launch(p->advanceDense, a.N, p->ivpsPerBlockAdvance, &copy, s);
 }
 hipError_t rtc_launch_rhs(int rhs_kind, int64_t N, int64_t is, int64_t cs, double t, const double* y, double* dy, const Params& P,
                           hipStream_t s) {

@@ -11,6 +11,7 @@ bool rtc_info(int rhs_kind, int* dim, int* n_params);
 hipError_t rtc_launch_solve(int rhs_kind, int integrator, const SolveArgs& a, hipStream_t s);
 hipError_t rtc_launch_step(int rhs_kind, int integrator, const StepArgs& a, int negate, hipStream_t s);
 hipError_t rtc_launch_advance(int rhs_kind, int integrator, const StepArgs& a, hipStream_t s);  // adaptive streaming (thread-per-IVP kinds)
+hipError_t rtc_launch_advance_dense(int rhs_kind, int integrator, const StepArgs& a, hipStream_t s);  // ... with dense output (any user kind)
 bool rtc_is_thread_per_ivp(int rhs_kind);
 hipError_t rtc_launch_rhs(int rhs_kind, int64_t N, int64_t is, int64_t cs, double t, const double* y, double* dy, const Params& P,
                           hipStream_t s);

@@ -409,6 +409,45 @@ def solveODEPerIvpEnd(f, y0, t_end, options=None, ctx=None, integrator="dopri54"
     return y, dict(ny=ny, steps=st, rejected=rj)
 
 
+def solveODECalls(f, y0, t_end, options=None, ctx=None, integrator="dopri54", layout=LAYOUT_SOA, max_steps=0, sweep=None, device=0):
+    """N reference calls `solveODE(f, y0_i, [options_i.tStart, t_end[i]], options_i, ctx, integrator)` in one launch, host arrays in
+    and out (nnhip_ode_solve_batch_calls_f64).  y0: numpy [dim, N] (SoA) / [N, dim] (AoS) / [N]; t_end: numpy [N]; options: one
+    ODEoptions object, a sequence of N of them, or None.  Returns (y [2, *y0.shape], counts) like solveODEPerIvpEnd."""
+    L = _lib.lib()
+    integ = integrator_id(integrator)
+    p, pp = _params_array(f, ctx)
+    y0c = np.ascontiguousarray(np.asarray(y0, dtype=np.float64))
+    N, dim, scalar = _shape_info(y0c, layout)
+    te = np.ascontiguousarray(np.asarray(t_end, dtype=np.float64))
+    if te.shape != (N,):
+        raise ValueError("t_end needs one value per IVP")
+    each = None
+    if options is None:
+        base = _default_options()
+    elif isinstance(options, _lib.Options):
+        base = options
+    else:
+        options = list(options)
+        if len(options) != N:
+            raise ValueError("options: one object, or one per IVP")
+        base = options[0] if N else _default_options()
+        each = (_lib.Options * N)(*options)
+    sw = None
+    if sweep is not None:
+        sw = np.ascontiguousarray(np.asarray(sweep, dtype=np.float64))
+        if sw.ndim != 2 or sw.shape[1] != N:
+            raise ValueError("sweep must have shape [k, N]")
+    y = np.empty((2,) + y0c.shape, dtype=np.float64)
+    ny = np.empty(N, dtype=np.int32)
+    st = np.empty(N, dtype=np.int64)
+    rj = np.empty(N, dtype=np.int64)
+    _check(L.nnhip_ode_solve_batch_calls_f64(C.byref(base), C.cast(each, C.c_void_p) if each is not None else None, integ, f.kind, pp, int(p.size),
+                                             sw.ctypes.data if sw is not None else None, int(sw.shape[0]) if sw is not None else 0,
+                                             y0c.ctypes.data, N, dim, layout, te.ctypes.data, y.ctypes.data, ny.ctypes.data, st.ctypes.data,
+                                             rj.ctypes.data, int(max_steps), int(device)))
+    return y, dict(ny=ny, steps=st, rejected=rj)
+
+
 def fixedStreamSolve(f, y0, tspan, options=None, ctx=None, integrator="rk4", layout=LAYOUT_SOA, max_steps=0):
     """solveODE (ode.nim:589-651) for a fixed-step integrator THROUGH THE IntegratorProc SEAM: the whole ODESolver driver — both
     directions, dense Hermite rows, output assembly — over the step-streaming kernels, state in HBM between steps

@@ -98,6 +98,40 @@ int main() {
     CHECK(byKey.t == plain.t && byProbe.t == plain.t && byKey.ny == plain.ny && byProbe.ny == plain.ny);
     for (size_t j = 0; j < plain.y.size(); ++j) CHECK(byKey.y[j].data == plain.y[j].data && byProbe.y[j].data == plain.y[j].data);
   }
+  // N separate calls in one launch: call i owns its tspan end and its option object, and must equal the 1-IVP solve with them
+  {
+    std::printf("test \"per-call tspan and options\"\n");
+    const int n = 9;
+    OdeBatch yb = OdeBatch::zeros(n, 1);
+    std::vector<double> tEnd(n);
+    std::vector<ODEoptions> opts(n);
+    for (int i = 0; i < n; ++i) {
+      yb.at(i, 0) = 1.0 + 0.125 * i;
+      tEnd[i] = (i == 4) ? 0.25 : (i % 2 ? -1.0 - 0.5 * i : 0.5 + 0.75 * i);   // both directions; IVP 4: tEnd == tStart below
+      opts[i] = newODEoptions(1e-3 * (1 + i), i % 3 ? 1e-6 : 1e-9, i % 3 ? 1e-6 : 1e-9, 0.05 + 0.01 * i, 1e-5, 4.0, 0.1, i == 4 ? 0.25 : 0.0);
+    }
+    opts[7].dtMax = 1e-6;  // dtMax < dtMin: newODEoptions raises for this call alone (ode.nim:95-96)
+    for (const char* integ : {"tsit54", "rk4"}) {
+      const OdeSolution all = solveODECalls(f, yb, tEnd, opts, &ctx, integ);
+      CHECK(all.y.size() == 2 && all.ny.size() == (size_t)n);
+      for (int i = 0; i < n; ++i) {
+        if (i == 7 && std::string(integ) == "tsit54") { CHECK(all.ny[i] == -1 && std::isnan(all.y[0].at(i, 0)) && std::isnan(all.y[1].at(i, 0))); continue; }
+        OdeBatch y1 = OdeBatch::zeros(1, 1);
+        y1.at(0, 0) = yb.at(i, 0);
+        const OdeSolution one = solveODE(f, y1, {opts[i].tStart, tEnd[i]}, opts[i], &ctx, integ);
+        CHECK(all.ny[i] == one.ny[0]);
+        for (int j = 0; j < one.ny[0]; ++j) CHECK(all.y[j].at(i, 0) == one.y[j].at(0, 0));
+      }
+      const OdeSolution same = solveODECalls(f, yb, tEnd, {opts[2]}, &ctx, integ);   // one option object for every call
+      OdeBatch y1 = OdeBatch::zeros(1, 1);
+      y1.at(0, 0) = yb.at(5, 0);
+      const OdeSolution one = solveODE(f, y1, {opts[2].tStart, tEnd[5]}, opts[2], &ctx, integ);
+      for (int j = 0; j < 2; ++j) CHECK(same.y[j].at(5, 0) == one.y[j].at(0, 0));
+    }
+    bool threwLen = false;
+    try { solveODECalls(f, yb, {1.0, 2.0}, opts, &ctx); } catch (const std::invalid_argument&) { threwLen = true; }
+    CHECK(threwLen);
+  }
   // the consumers, as tests/test_integrate.nim:19-21, 67-95 and tests/test_interpolate.nim:5-18, 104-145 use them
   {
     std::printf("test \"cumtrapz / cumsimpson / HermiteSpline\"\n");

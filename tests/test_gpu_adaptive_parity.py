@@ -704,3 +704,69 @@ def test_every_ivp_its_own_options_and_tspan(nn, oracle, dev, integrator):
             gi = got[:, :, i] if layout == 0 else got[:, i, :]
             assert ny[i] == st.n_y and steps[i] == st.steps and rej[i] == st.rejected, (i, integrator)
             assert _same_bits(gi[:st.n_y].reshape(st.n_y, -1), np.asarray(ry).reshape(st.n_y, -1)), (integrator, dim, i)
+
+
+@pytest.mark.parametrize("integrator", ["tsit54", "rk4"])
+def test_host_form_of_the_per_call_solve(nn, dev, integrator):
+    """nnhip_ode_solve_batch_calls_f64 (host arrays, one ODEoptions OBJECT per call) == the device-table entry on the same calls,
+    bit for bit; and each call equals the ordinary 1-IVP solveODE with its own tspan and options (ode.nim:589-591)."""
+    import torch
+    rng = np.random.default_rng(5)
+    n = 300
+    y0 = np.ascontiguousarray((rng.uniform(0.5, 1.5, (n, 3)) + np.array([0.0, 0.0, 20.0])).T)   # SoA [3][n]
+    ts = rng.uniform(-0.2, 0.2, n)
+    te = ts + rng.uniform(-0.3, 0.6, n)
+    te[17] = ts[17]
+    opts = [nn.newODEoptions(dt=10 ** rng.uniform(-2.5, -1.5), absTol=10 ** rng.uniform(-9, -4), relTol=10 ** rng.uniform(-9, -4),
+                             dtMax=10 ** rng.uniform(-2, -0.5), dtMin=10 ** rng.uniform(-6, -4), tStart=ts[i]) for i in range(n)]
+    f = nn.Rhs.lorenz()
+    y, cnt = nn.solveODECalls(f, y0, te, opts, integrator=integrator)
+    col = lambda name: torch.tensor([getattr(o, name) for o in opts], dtype=torch.float64, device=dev)
+    yd, cd = nn.solveODEPerIvpEnd(f, torch.from_numpy(y0).to(dev), torch.from_numpy(te).to(dev), nn.newODEoptions(), integrator=integrator,
+                                  t_start=col("tStart"), absTol=col("absTol"), relTol=col("relTol"), dtMax=col("dtMax"), dtMin=col("dtMin"), dt=col("dt"))
+    assert _same_bits(y, yd.cpu().numpy())
+    for k in ("ny", "steps", "rejected"):
+        assert (cnt[k] == cd[k].cpu().numpy()).all(), k
+    assert cnt["ny"][17] == 1 and np.isnan(y[1, :, 17]).all()
+    for i in (0, 17, 101, 299):
+        t1, y1 = nn.solveODE(f, torch.from_numpy(np.ascontiguousarray(y0[:, i:i + 1])).to(dev), [ts[i], te[i]], opts[i], integrator=integrator)
+        assert _same_bits(y1.cpu().numpy()[:, :, 0][:cnt["ny"][i]], y[:cnt["ny"][i], :, i]), i
+    # one object for every call; and the argument checks
+    y2, c2 = nn.solveODECalls(f, y0, te, opts[3], integrator=integrator)
+    t1, y1 = nn.solveODE(f, torch.from_numpy(np.ascontiguousarray(y0[:, 8:9])).to(dev), [opts[3].tStart, te[8]], opts[3], integrator=integrator)
+    assert _same_bits(y1.cpu().numpy()[:, :, 0], y2[:, :, 8])
+    with pytest.raises(ValueError):
+        nn.solveODECalls(f, y0, te[:5], opts, integrator=integrator)
+    with pytest.raises(ValueError):
+        nn.solveODECalls(f, y0, te, opts[:5], integrator=integrator)
+    ye, ce = nn.solveODECalls(f, np.zeros((3, 0)), np.zeros(0), [], integrator=integrator)
+    assert ye.shape == (2, 3, 0)
+
+
+@pytest.mark.parametrize("integrator", ["tsit54", "dopri54", "bs32", "vern65"])
+def test_adaptive_dense_stream_every_rhs_kind(nn, dev, integrator):
+    """nnhip_ode_adaptive_stream_dense_f64_dev beyond the compiled-in thread-per-IVP kinds: lanes-per-system systems (Vector[float]
+    states of 8 / 16 / 32 components, C4's shape), run-time compiled right-hand sides (whole-vector and per-component bodies), and
+    a built-in kind at a size that is instantiated at run time — both directions, dense rows, bitwise equal to the fused solve."""
+    import torch
+    rng = np.random.default_rng(99)
+    heat = "const int l = (c + dim - 1) % dim, r = (c + 1) % dim; return p[0] * ((y[l] - 2.0 * y[c]) + y[r]);"
+    kinds = [(nn.Rhs.ring(0.1), 16, 1), (nn.Rhs.ring(0.1), 16, 0), (nn.Rhs.ring(0.2), 8, 1), (nn.Rhs.ring(0.05), 32, 1), (nn.Rhs.affine_t(-0.3, 0.2), 16, 1),
+             (nn.Rhs.ring(0.1), 12, 1),                                                                      # built-in kind, run-time size
+             (nn.Rhs.custom(2, "dy[0] = y[1]; dy[1] = p[0] * (1.0 - y[0] * y[0]) * y[1] - y[0];", keys=("mu",), defaults={"mu": 1.5}, name="vdp_src"), 2, 0),
+             (nn.Rhs.custom(24, heat, keys=("kappa",), defaults={"kappa": 0.4}, name="heat24_dense", per_component=True), 24, 1)]
+    grids = [[0.6, -0.3, 0.0, 0.2, 0.45], [0.5, 1.0], [-0.4, -0.2], [0.3, 0.30001, 0.30002, 0.9], [-0.2, -0.20001, -0.1, 0.7, 0.70001]]
+    if integrator == "vern65":
+        kinds, grids = kinds[:3] + kinds[6:], grids[:2]   # keeps the run-time compilations of the slowest method few
+    for f, dim, layout in kinds:
+        n = 131
+        y0 = rng.uniform(0.5, 1.5, (n, dim))
+        y0l = torch.from_numpy(np.ascontiguousarray(y0 if layout == 1 else y0.T)).to(dev)
+        for ts in grids:
+            for tstart, kw in ((0.0, {}), (0.25, dict(absTol=1e-7, relTol=1e-7, dtMin=1e-6, dtMax=0.5))):
+                o2 = nn.newODEoptions(tStart=tstart, **kw)
+                t, y, ny, launches = nn.adaptiveStreamSolve(f, y0l, ts, o2, integrator=integrator, layout=layout, check_every=4)
+                tf, yf, cf = nn.solveODE(f, y0l, ts, o2, integrator=integrator, layout=layout, return_counts=True)
+                assert np.array_equal(t, tf), (dim, ts)
+                assert torch.equal(ny, cf["ny"]), (dim, layout, ts, tstart)
+                assert torch.equal(torch.nan_to_num(y, nan=-7.0), torch.nan_to_num(yf, nan=-7.0)), (f.kind, dim, layout, ts, tstart)
