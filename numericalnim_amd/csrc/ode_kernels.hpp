@@ -387,6 +387,17 @@ hipError_t launch_solve_tpi(const SolveArgs& a, hipStream_t s) {
 // VALU-bound solve gains ~9 % (C4 Tsit54 default 7.45 -> 6.75 ms, DOPRI54 6.71 -> 6.17 ms; profiles/r02_c4_fused_ab.txt).  The
 // dense instantiations (215+ VGPRs) would spill 140-170 B and keep 2 waves.  A/B hook: -DNNHIP_LPS_WPE=n forces n for all of them.
 #ifndef NNHIP_LPS_WPE
+// LDS slots of the lanes-per-system kernels: per system DIM doubles of stage arguments (ys) and DIM of squared error components (es).
+// A/B hook -DNNHIP_LPS_PAD=n: consecutive systems n doubles further apart than DIM (at a stride of exactly 128 B, DIM = 16, every
+// system of a wavefront starts in the same LDS bank and the ordered error sum reads es[j] of 8 or 16 systems at once).
+#ifndef NNHIP_LPS_PAD
+#define NNHIP_LPS_PAD 0  // measured: no effect either way (profiles/r02_pow_tables_ab.txt section 10); hook kept
+#endif
+template <int DIM>
+constexpr int lps_stride() { return DIM + NNHIP_LPS_PAD; }
+template <int DIM, int CPL>
+constexpr int lps_lds_doubles() { return 2 * (kBlock / (DIM / CPL)) * lps_stride<DIM>(); }
+
 template <int CPL, int MODE>
 constexpr int lps_solve_waves() { return (CPL >= 4 && MODE == 0) ? 3 : 1; }
 #define NNHIP_LPS_ATTR __attribute__((amdgpu_waves_per_eu(lps_solve_waves<CPL, MODE>())))
@@ -398,15 +409,15 @@ __global__ __launch_bounds__(kBlock) NNHIP_LPS_ATTR void solve_lps_kernel(const 
   constexpr int DIM = RHS::dim;
   constexpr int LPSYS = DIM / CPL;  // lanes per system
   static_assert(DIM % CPL == 0 && 64 % LPSYS == 0, "a system must not straddle wavefronts");
-  __shared__ double lds[2 * kBlock * CPL];
+  __shared__ double lds[lps_lds_doubles<DIM, CPL>()];
   controller_prologue<MethodTraits<METHOD>::adaptive>();
   const int sysInBlock = threadIdx.x / LPSYS, c = (threadIdx.x % LPSYS) * CPL;
   const int64_t k = (int64_t)blockIdx.x * (kBlock / LPSYS) + sysInBlock;
   LaneStats ls;
   if (k < a.N) {
     const int64_t i = a.perm ? (int64_t)a.perm[k] : k;  // the system this group of lanes integrates
-    double* ys = lds + sysInBlock * DIM;
-    double* es = lds + kBlock * CPL + sysInBlock * DIM;
+    double* ys = lds + sysInBlock * lps_stride<DIM>();
+    double* es = lds + lps_lds_doubles<DIM, CPL>() / 2 + sysInBlock * lps_stride<DIM>();
     const Params P = params_of(a, i);
     const LpsOps<RHS, false, CPL, SHUFFLE_NORM> opsF{P, ys, es, c};
     const LpsOps<RHS, true, CPL, SHUFFLE_NORM> opsB{P, ys, es, c};
@@ -548,8 +559,33 @@ hipError_t launch_step_tpi(const StepArgs& a, int negate, hipStream_t s) {
 // +11 % (1e7 Lorenz IVPs: 241 -> 216 us per iteration = 6.3 TB/s); below that it costs 4 % (1e6: 26.1 -> 27.6 us); the host
 // picks per call (profiles/r02_pow_tables_ab.txt, section 7).  The hint is a TEMPLATE parameter of the kernel: a run-time branch
 // between hinted and plain accesses of the same addresses is merged by the compiler into the plain ones (the hint is dropped).
+// A lane's components are contiguous in the AoS layout (compStride == 1): with an even number of them per lane and 16-byte aligned
+// arrays the state moves as 16-byte accesses (global_load/store_dwordx4) instead of pairs of 8-byte ones at a 16-byte stride.
+template <class Ops>
+struct OpsAllOwned { static constexpr bool value = true; };
+template <class RHS, bool NEG, int CPL, bool SH>
+struct OpsAllOwned<LpsOps<RHS, NEG, CPL, SH>> { static constexpr bool value = RhsSize<RHS>::value == RHS::dim; };
+NNHIP_DEV bool adv_vec2(const StepArgs& a) {
+#ifdef NNHIP_ADV_NO_VEC2
+  return false;
+#else
+  return a.compStride == 1 && (a.ivpStride & 1) == 0 &&
+         ((((uintptr_t)a.y_in | (uintptr_t)a.fsal_in | (uintptr_t)a.y_out | (uintptr_t)a.fsal_out) & 15) == 0);
+#endif
+}
 template <bool NT, class Ops, int D>
 NNHIP_DEV void adv_load_state(const StepArgs& a, const Ops& ops, int64_t base, double (&y)[D], double (&fsal)[D]) {
+  if constexpr (D % 2 == 0 && OpsAllOwned<Ops>::value && !NT) {
+    if (adv_vec2(a)) {
+#pragma unroll
+      for (int c = 0; c < D; c += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(&a.y_in[base + c]);
+        const double2 w = *reinterpret_cast<const double2*>(&a.fsal_in[base + c]);
+        y[c] = v.x; y[c + 1] = v.y; fsal[c] = w.x; fsal[c + 1] = w.y;
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int c = 0; c < D; ++c) {
     if (!ops.owns(c)) { y[c] = 0.0; fsal[c] = 0.0; continue; }
@@ -559,6 +595,16 @@ NNHIP_DEV void adv_load_state(const StepArgs& a, const Ops& ops, int64_t base, d
 }
 template <bool NT, class Ops, int D>
 NNHIP_DEV void adv_store_state(const StepArgs& a, const Ops& ops, int64_t base, const double (&yNew)[D], const double (&fsal)[D]) {
+  if constexpr (D % 2 == 0 && OpsAllOwned<Ops>::value && !NT) {
+    if (adv_vec2(a)) {
+#pragma unroll
+      for (int c = 0; c < D; c += 2) {
+        *reinterpret_cast<double2*>(&a.y_out[base + c]) = make_double2(yNew[c], yNew[c + 1]);
+        *reinterpret_cast<double2*>(&a.fsal_out[base + c]) = make_double2(fsal[c], fsal[c + 1]);
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int c = 0; c < D; ++c) {
     if (!ops.owns(c)) continue;
@@ -574,13 +620,25 @@ struct AdvState {
   bool live;
 };
 // phase 1: t, and — for IVPs still short of tEnd — dt, y, FSAL (finished IVPs touch no other memory)
-template <bool NT, class Ops>
+template <bool NT, class Ops, bool SPECULATE = false>
 NNHIP_DEV void adv_fetch(const StepArgs& a, const Ops& ops, int64_t i, int64_t base, AdvState<Ops::D>& s) {
-  s.t = a.t_io[i];
-  s.live = s.t < a.tEnd;  // :511
-  if (s.live) {
+  if constexpr (SPECULATE) {
+    // all loads of the IVP in ONE round trip (finished IVPs read their state for nothing): `t` first would put the state loads
+    // behind a dependent branch = two serialized memory latencies per wave.  The empty asm keeps the loads above the branch.
     adv_load_state<NT>(a, ops, base, s.y, s.fsal);
     s.dt = a.dt_io[i];
+    s.t = a.t_io[i];
+#pragma unroll
+    for (int c = 0; c < Ops::D; ++c) asm volatile("" : "+v"(s.y[c]), "+v"(s.fsal[c]));
+    asm volatile("" : "+v"(s.dt), "+v"(s.t));
+    s.live = s.t < a.tEnd;  // :511
+  } else {
+    s.t = a.t_io[i];
+    s.live = s.t < a.tEnd;  // :511
+    if (s.live) {
+      adv_load_state<NT>(a, ops, base, s.y, s.fsal);
+      s.dt = a.dt_io[i];
+    }
   }
 }
 // phase 2: the loop iteration itself and the write-back
@@ -658,10 +716,20 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_TPI_ATTR void advance_tpi_kernel(
 // layout a wave moves 512 contiguous bytes per array), stage argument vector and error components through LDS (LpsOps).
 // Algorithmic traffic 8*(4d+5) B per attempted step: 552 B at d = 16, so 1e6 systems stream 552 MB per launch — far
 // beyond the 256 MiB Infinity Cache.
-// SPG (A/B hook -DNNHIP_ADV_LPS_SPG=2): systems per lane group — with 2, a group fetches two systems up front and advances them one
-// after the other: twice the bytes in flight per wave at +2*(2*CPL+2) VGPRs.
+// A block advances SPG tiles of kBlock / LPSYS systems, software-pipelined (NNHIP_ADV_LPS_PIPE): the state of tile g + 1 is loaded
+// (unconditionally, one round trip) before tile g is advanced, so a wave's memory latency runs under its own arithmetic — the
+// kernel's two floors are close (1e6 x 16: VALU 65 us, HBM 86 us), its waves start together and stay in phase, and with 4 waves per
+// SIMD nothing else overlaps them.  Measured (profiles/r02_pow_tables_ab.txt section 11): 125 -> 118 us per iteration with 2 tiles;
+// 4 and 8 tiles no better; fetching 2 tiles up front WITHOUT the pipeline (PIPE=0, SPG=2), the speculative single round trip alone
+// (NNHIP_ADV_LPS_SPECULATE), 16-byte accesses (adv_vec2) and padded LDS slots each change nothing measurable.
 #ifndef NNHIP_ADV_LPS_SPG
-#define NNHIP_ADV_LPS_SPG 1
+#define NNHIP_ADV_LPS_SPG 2
+#endif
+#ifndef NNHIP_ADV_LPS_SPECULATE
+#define NNHIP_ADV_LPS_SPECULATE 0
+#endif
+#ifndef NNHIP_ADV_LPS_PIPE
+#define NNHIP_ADV_LPS_PIPE 1
 #endif
 template <int METHOD, class RHS, int CPL = 1>
 __global__ __launch_bounds__(kBlock) NNHIP_ADV_LPS_ATTR void advance_lps_kernel(const StepArgs a) {
@@ -670,12 +738,49 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_LPS_ATTR void advance_lps_kernel(
   constexpr int LPSYS = DIM / CPL;
   constexpr int SPG = NNHIP_ADV_LPS_SPG;
   static_assert(DIM % CPL == 0 && 64 % LPSYS == 0, "a system must not straddle wavefronts");
-  __shared__ double lds[2 * kBlock * CPL];
+  __shared__ double lds[lps_lds_doubles<DIM, CPL>()];
   controller_prologue();
   pin_step_args(a);
   const int sysInBlock = threadIdx.x / LPSYS, c = (threadIdx.x % LPSYS) * CPL;
   constexpr int perBlock = kBlock / LPSYS;
   unsigned int stillActive = 0;
+#if NNHIP_ADV_LPS_PIPE
+  {
+    // software pipeline over the block's SPG tiles: the state of tile g + 1 is loaded (unconditionally, one round trip, index
+    // clamped) BEFORE tile g is advanced, so a wave's memory latency runs under its own arithmetic
+    double* ys = lds + sysInBlock * lps_stride<DIM>();
+    double* es = lds + lps_lds_doubles<DIM, CPL>() / 2 + sysInBlock * lps_stride<DIM>();
+    const int64_t i0 = (int64_t)blockIdx.x * SPG * perBlock + sysInBlock;
+    const Params P0 = a.P;
+    const LpsOps<RHS, false, CPL> ops0{P0, ys, es, c};
+    auto prefetch = [&](int64_t i, AdvState<CPL>& s, Params& P) {
+      const int64_t ic = i < a.N ? i : a.N - 1;
+      adv_load_state<false>(a, ops0, ic * a.ivpStride + c * a.compStride, s.y, s.fsal);
+      s.dt = a.dt_io[ic];
+      s.t = a.t_io[ic];
+      P = params_of(a, ic);           // per-IVP parameters (sweeps) belong to the tile's loads as well
+      asm volatile("" ::: "memory");  // keeps the tiles' loads in program order: the wait for tile g must not cover tile g + 1's loads
+    };
+    AdvState<CPL> cur, nxt;
+    Params Pcur, Pnxt;
+    prefetch(i0, cur, Pcur);
+#pragma unroll
+    for (int g = 0; g < SPG; ++g) {
+      const int64_t i = i0 + (int64_t)g * perBlock;
+      if (g + 1 < SPG) prefetch(i + perBlock, nxt, Pnxt);
+      cur.live = i < a.N && cur.t < a.tEnd;  // :511
+      if (i < a.N) {
+        const LpsOps<RHS, false, CPL> ops{Pcur, ys, es, c};
+        stillActive |= adv_advance<METHOD, false>(a, ops, i, i * a.ivpStride + c * a.compStride, c == 0, cur);
+      }
+      if (g + 1 < SPG) { cur = nxt; Pcur = Pnxt; }
+    }
+    if (a.active) {
+      if (__syncthreads_or((int)stillActive) && threadIdx.x == 0) a.active[blockIdx.x % kAggSlots] = 1u;
+    }
+    return;
+  }
+#endif
   int64_t idx[SPG];
   AdvState<CPL> st[SPG];
 #pragma unroll
@@ -684,15 +789,15 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_LPS_ATTR void advance_lps_kernel(
     st[g].live = false;
     if (idx[g] < a.N) {
       const Params P = params_of(a, idx[g]);
-      const LpsOps<RHS, false, CPL> ops{P, lds + sysInBlock * DIM, lds + kBlock * CPL + sysInBlock * DIM, c};
-      adv_fetch<false>(a, ops, idx[g], idx[g] * a.ivpStride + c * a.compStride, st[g]);
+      const LpsOps<RHS, false, CPL> ops{P, lds + sysInBlock * lps_stride<DIM>(), lds + lps_lds_doubles<DIM, CPL>() / 2 + sysInBlock * lps_stride<DIM>(), c};
+      adv_fetch<false, decltype(ops), NNHIP_ADV_LPS_SPECULATE != 0>(a, ops, idx[g], idx[g] * a.ivpStride + c * a.compStride, st[g]);
     }
   }
 #pragma unroll
   for (int g = 0; g < SPG; ++g) {
     if (idx[g] < a.N) {
       const Params P = params_of(a, idx[g]);
-      const LpsOps<RHS, false, CPL> ops{P, lds + sysInBlock * DIM, lds + kBlock * CPL + sysInBlock * DIM, c};
+      const LpsOps<RHS, false, CPL> ops{P, lds + sysInBlock * lps_stride<DIM>(), lds + lps_lds_doubles<DIM, CPL>() / 2 + sysInBlock * lps_stride<DIM>(), c};
       stillActive |= adv_advance<METHOD, false>(a, ops, idx[g], idx[g] * a.ivpStride + c * a.compStride, c == 0, st[g]);
     }
   }
@@ -884,7 +989,7 @@ __global__ __launch_bounds__(kBlock) void advance_dense_lps_kernel(const StepArg
   constexpr int DIM = RHS::dim;
   constexpr int LPSYS = DIM / CPL;
   static_assert(DIM % CPL == 0 && 64 % LPSYS == 0, "a system must not straddle wavefronts");
-  __shared__ double lds[2 * kBlock * CPL];
+  __shared__ double lds[lps_lds_doubles<DIM, CPL>()];
   controller_prologue();
   const int sysInBlock = threadIdx.x / LPSYS, c = (threadIdx.x % LPSYS) * CPL;
   constexpr int perBlock = kBlock / LPSYS;
@@ -893,8 +998,8 @@ __global__ __launch_bounds__(kBlock) void advance_dense_lps_kernel(const StepArg
   if (i < a.N) {
     const Params P = params_of(a, i);
     const bool neg = a.negate != 0;
-    double* ys = lds + sysInBlock * DIM;
-    double* es = lds + kBlock * CPL + sysInBlock * DIM;
+    double* ys = lds + sysInBlock * lps_stride<DIM>();
+    double* es = lds + lps_lds_doubles<DIM, CPL>() / 2 + sysInBlock * lps_stride<DIM>();
     const LpsOpsRt<RHS, CPL> ops{{P, ys, es, c}, {P, ys, es, c}, neg};
     stillActive = advance_dense_body<METHOD>(a, ops, i, i * a.ivpStride + c * a.compStride, c == 0, neg);
   }
@@ -990,14 +1095,14 @@ __global__ __launch_bounds__(kBlock) void step_lps_kernel(const StepArgs a) {
   constexpr int DIM = RHS::dim;
   constexpr int LPSYS = DIM / CPL;  // lanes per system (CPL > 1 only for systems wider than a wavefront)
   static_assert(DIM % CPL == 0 && 64 % LPSYS == 0, "a system must not straddle wavefronts");
-  __shared__ double lds[2 * kBlock * CPL];
+  __shared__ double lds[lps_lds_doubles<DIM, CPL>()];
   controller_prologue<MethodTraits<METHOD>::adaptive>();
   pin_step_args(a);
   const int sysInBlock = threadIdx.x / LPSYS, c = (threadIdx.x % LPSYS) * CPL;
   const int64_t i = (int64_t)blockIdx.x * (kBlock / LPSYS) + sysInBlock;
   if (i >= a.N) return;
   const Params P = params_of(a, i);
-  const LpsOps<RHS, NEG, CPL> ops{P, lds + sysInBlock * DIM, lds + kBlock * CPL + sysInBlock * DIM, c};
+  const LpsOps<RHS, NEG, CPL> ops{P, lds + sysInBlock * lps_stride<DIM>(), lds + lps_lds_doubles<DIM, CPL>() / 2 + sysInBlock * lps_stride<DIM>(), c};
   step_body<METHOD>(a, ops, i, i * a.ivpStride + c * a.compStride, c == 0);
 }
 
