@@ -770,3 +770,22 @@ def test_adaptive_dense_stream_every_rhs_kind(nn, dev, integrator):
                 assert np.array_equal(t, tf), (dim, ts)
                 assert torch.equal(ny, cf["ny"]), (dim, layout, ts, tstart)
                 assert torch.equal(torch.nan_to_num(y, nan=-7.0), torch.nan_to_num(yf, nan=-7.0)), (f.kind, dim, layout, ts, tstart)
+
+
+def test_adaptive_stream_state_that_is_not_16_byte_aligned(nn, dev):
+    """The lanes-per-system advance kernel moves AoS states with 16-byte accesses when the arrays allow it; a state tensor that starts
+    8 bytes off (a slice of a larger buffer) must take the 8-byte path and give the same bits."""
+    import torch
+    n, dim = 500, 16
+    y0 = torch.from_numpy(_ring_y0(n, dim)).to(dev)
+    kw = dict(absTol=1e-8, relTol=1e-8, dtMin=1e-7, dtMax=0.25)
+    t, yf = nn.solveODE(nn.Rhs.ring(0.1), y0, [0.0, 1.0], nn.newODEoptions(**kw), integrator="tsit54", layout=1)
+    buf = torch.zeros(n * dim + 1, dtype=torch.float64, device=dev)
+    view = buf[1:].view(n, dim)
+    view.copy_(y0)
+    assert view.data_ptr() % 16 == 8 and view.is_contiguous()
+    ys, launches = nn.adaptiveStream(nn.Rhs.ring(0.1), view, 0.0, 1.0, nn.newODEoptions(**kw), integrator="tsit54", layout=1, check_every=4)
+    torch.cuda.synchronize()
+    assert torch.equal(ys, yf[-1])
+    ya, _ = nn.adaptiveStream(nn.Rhs.ring(0.1), y0.clone(), 0.0, 1.0, nn.newODEoptions(**kw), integrator="tsit54", layout=1, check_every=4)
+    assert torch.equal(ya, yf[-1])
