@@ -789,3 +789,30 @@ def test_adaptive_stream_state_that_is_not_16_byte_aligned(nn, dev):
     assert torch.equal(ys, yf[-1])
     ya, _ = nn.adaptiveStream(nn.Rhs.ring(0.1), y0.clone(), 0.0, 1.0, nn.newODEoptions(**kw), integrator="tsit54", layout=1, check_every=4)
     assert torch.equal(ya, yf[-1])
+
+
+@pytest.mark.parametrize("integrator", ["tsit54", "rk4", "bs32"])
+def test_per_call_solve_with_runtime_compiled_right_hand_sides(nn, dev, integrator):
+    """nnhip_ode_solve_batch_calls_f64_dev for right-hand sides that are compiled at run time (user source; built-in kinds at sizes
+    without an ahead-of-time kernel; thread-per-IVP and lanes-per-system): every IVP's own tspan end, bits of the 2-point fused solves.
+    (Found by tests/tools/soak_paths.py: the run-time compiled solve kernel used to ignore the per-call data.)"""
+    import torch
+    rng = np.random.default_rng(3)
+    heat = "const int l = (c + dim - 1) % dim, r = (c + 1) % dim; return p[0] * ((y[l] - 2.0 * y[c]) + y[r]);"
+    kinds = [(nn.Rhs.linear(-0.4), 5, 0), (nn.Rhs.ring(0.1), 20, 1), (nn.Rhs.ring(0.1), 40, 0),
+             (nn.Rhs.custom(2, "dy[0] = y[1]; dy[1] = p[0] * (1.0 - y[0] * y[0]) * y[1] - y[0];", keys=("mu",), defaults={"mu": 1.5}, name="vdp_calls"), 2, 0),
+             (nn.Rhs.custom(24, heat, keys=("kappa",), defaults={"kappa": 0.4}, name="heat24_calls", per_component=True), 24, 1)]
+    o = nn.newODEoptions(dt=2.0 ** -7, absTol=1e-7, relTol=1e-7, dtMin=1e-6, dtMax=0.05, tStart=0.25)
+    for f, dim, layout in kinds:
+        n = 97
+        y0 = rng.uniform(0.5, 1.5, (n, dim))
+        yt = torch.from_numpy(np.ascontiguousarray(y0 if layout == 1 else y0.T)).to(dev)
+        ends = np.array([0.25, 0.6, -0.1, 0.31])
+        te = ends[rng.integers(0, 4, n)]
+        yc, cc = nn.solveODEPerIvpEnd(f, yt, torch.from_numpy(te).to(dev), o, integrator=integrator, layout=layout)
+        for e in ends:
+            tt, ye, ce = nn.solveODE(f, yt, [0.25, float(e)], o, integrator=integrator, layout=layout, return_counts=True)
+            m = torch.from_numpy(te == e).to(dev)
+            a, b = (yc[:, :, m], ye[:, :, m]) if layout == 0 else (yc[:, m, :], ye[:, m, :])
+            assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)), (dim, layout, e)
+            assert torch.equal(cc["ny"][m], ce["ny"][m]) and torch.equal(cc["steps"][m], ce["steps"][m])
