@@ -29,7 +29,8 @@ def same(a, b):
     return a.shape == b.shape and bool(torch.equal(torch.nan_to_num(a, nan=-7.25), torch.nan_to_num(b, nan=-7.25)))
 
 
-tab = {k: dict(cases=0, ivps=0, mismatching_cases=0, errors=0) for k in ("stream_solve", "sorted_key", "sorted_probe", "calls_dev", "calls_host")}
+tab = {k: dict(cases=0, ivps=0, mismatching_cases=0, errors=0) for k in ("stream_solve", "sorted_key", "sorted_probe", "calls_dev", "calls_host", "host_solve",
+                                                                         "sweep_host", "sweep_sorted", "sweep_calls", "stream_final")}
 bad = []
 for seed in range(5000, 5000 + n_seeds):
     rng = np.random.default_rng(seed)
@@ -95,6 +96,38 @@ for seed in range(5000, 5000 + n_seeds):
     except Exception as e:
         tab["calls_dev"]["errors"] += 1
         bad.append(dict(path="calls", seed=seed, error=str(e)[:200], integ=integ, kind=kind, dim=dim))
+    # host-pointer entry (chunked pinned pipeline) vs device entry; per-IVP parameter sweeps through host / binned / per-call entries
+    try:
+        th, yh2, ch2 = nn.solveODE(f, y0l, ts, o, integrator=integ, layout=layout, return_counts=True)
+        note("host_solve", np.array_equal(t, th) and same(torch.from_numpy(yh2), y.cpu()) and np.array_equal(ch2["steps"], cnt["steps"].cpu().numpy()))
+        if len(params) >= 1:
+            sw = np.ascontiguousarray(params[0] * rng.uniform(0.5, 1.5, (1, n)))
+            swt = torch.from_numpy(sw).to(dev)
+            ts_, ys_, cs_ = nn.solveODE(f, yt, ts, o, integrator=integ, layout=layout, return_counts=True, sweep=swt)
+            tsh, ysh, csh = nn.solveODE(f, y0l, ts, o, integrator=integ, layout=layout, return_counts=True, sweep=sw)
+            note("sweep_host", same(torch.from_numpy(ysh), ys_.cpu()) and np.array_equal(csh["steps"], cs_["steps"].cpu().numpy()))
+            tso, yso, cso = nn.solveODE(f, yt, ts, o, integrator=integ, layout=layout, return_counts=True, sweep=swt, sort_by="auto")
+            note("sweep_sorted", same(yso, ys_) and bool(torch.equal(cso["steps"], cs_["steps"])))
+            e = float(np.round(opt["tStart"] + rng.uniform(0.05, 0.4), 3))
+            t2p, y2p, c2p = nn.solveODE(f, yt, [opt["tStart"], e], o, integrator=integ, layout=layout, return_counts=True, sweep=swt)
+            ycs, ccs = nn.solveODEPerIvpEnd(f, yt, torch.full((n,), e, dtype=torch.float64, device=dev), o, integrator=integ, layout=layout, sweep=swt)
+            note("sweep_calls", same(ycs, y2p) and bool(torch.equal(ccs["steps"], c2p["steps"])))
+    except Exception as e:
+        tab["host_solve"]["errors"] += 1
+        bad.append(dict(path="host/sweep", seed=seed, error=str(e)[:200], integ=integ, kind=kind, dim=dim))
+    # the streaming loops without dense output: final state of a forward 2-point span
+    try:
+        e = float(np.round(opt["tStart"] + rng.uniform(0.05, 0.4), 3))
+        t2p, y2p = nn.solveODE(f, yt, [opt["tStart"], e], o, integrator=integ, layout=layout)
+        if fixed:
+            yfin, _ = nn.fixedStream(f, yt.clone(), opt["tStart"], e, o, integrator=integ, layout=layout)
+        else:
+            yfin, _ = nn.adaptiveStream(f, yt.clone(), opt["tStart"], e, o, integrator=integ, layout=layout, check_every=int(rng.choice([1, 4, 8])))
+        torch.cuda.synchronize()
+        note("stream_final", same(yfin, y2p[-1]))
+    except Exception as e:
+        tab["stream_final"]["errors"] += 1
+        bad.append(dict(path="stream_final", seed=seed, error=str(e)[:200], integ=integ, kind=kind, dim=dim))
 res = {"seeds": [5000, 5000 + n_seeds], "per_path": tab, "findings": bad[:40]}
 os.makedirs(os.path.dirname(out_path), exist_ok=True)
 json.dump(res, open(out_path, "w"), indent=1)
