@@ -90,14 +90,14 @@ def test_reference_harness_dense_forward_backward(nn, oracle, dev):
 
 
 def test_c2_full_size_properties(nn, oracle, dev):
-    """BASELINE config C2 at full size (1e7 IVPs) through size-independent properties:
+    """BASELINE config C2 at full size (1e7 IVPs, 1000 RK4 steps) through size-independent properties:
     (1) oracle parity on a fixed 4096-index subsample, (2) exact linearity in y0 under power-of-two
     scaling (RK4 on a linear RHS commutes with exact scalings), (3) fused == streamed bitwise,
     (4) monotone in y0 (the RK4 amplification factor is a positive constant)."""
     import torch
     from numericalnim_amd import distributed as nd
     O = oracle
-    n, dt, nsteps = 10_000_000, 2.0 ** -10, 100
+    n, dt, nsteps = 10_000_000, 2.0 ** -10, 1000   # C2 itself: 1e7 IVPs x 1000 steps
     y0 = nd.c2_y0_torch(0, n, dev)
     opt = nn.newODEoptions(dt=dt)
     y = y0.clone()
