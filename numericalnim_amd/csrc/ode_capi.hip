@@ -67,6 +67,7 @@ int g_fixed_vec_ipl = 2;  // tuning knob "fixed_vec_ipl": IVPs per lane of the v
 int g_mg_oversubscribe = 0;  // tuning knob "multi_gpu_oversubscribe": the multi-GPU host entry accepts more shards than devices (shard r on device
                              // r mod #devices) — lets a one-GPU box exercise the sharded code path (index ranges, strided copies, empty shards)
 int g_adv_nt = -1;        // tuning knob "adv_nontemporal": -1 = automatic (thread-per-IVP state beyond 192 MiB), 0 / 1 = force
+int g_adv_block = 0;      // tuning knob "adv_block": workgroup size of the thread-per-IVP advance kernel (0 = auto: 64 with the non-temporal instantiation, else 256)
 int g_adv_split = 0;      // tuning knob "adv_split": index ranges the adaptive streaming loop interleaves on separate streams (0 = auto, 1, 2, 4)
 int g_dim16_variant = 0;  // tuning knob "dim16_variant": A/B mappings of the fused 16-component kernels (see ode_kernels.hpp)
 
@@ -372,6 +373,7 @@ int nnhip_tune_set(const char* key, int value) {
   if (k == "fixed_vec_ipl") { if (value != 0 && value != 2) return fail(NNHIP_EVALUE, "fixed_vec_ipl must be 0 (off) or 2"); g_fixed_vec_ipl = value; return NNHIP_OK; }
   if (k == "multi_gpu_oversubscribe") { g_mg_oversubscribe = value != 0; return NNHIP_OK; }
   if (k == "adv_nontemporal") { if (value < -1 || value > 1) return fail(NNHIP_EVALUE, "adv_nontemporal must be -1, 0 or 1"); g_adv_nt = value; return NNHIP_OK; }
+  if (k == "adv_block") { if (value != 0 && value != 64 && value != 128 && value != 256) return fail(NNHIP_EVALUE, "adv_block must be 0, 64, 128 or 256"); g_adv_block = value; release_adv_graphs(); return NNHIP_OK; }
   if (k == "adv_split") { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(NNHIP_EVALUE, "adv_split must be 0, 1, 2 or 4"); g_adv_split = value; return NNHIP_OK; }
   if (k == "dim16_variant") { if (value < 0 || value > 4) return fail(NNHIP_EVALUE, "dim16_variant must be 0..4"); g_dim16_variant = value; return NNHIP_OK; }
   if (k == "rk4_stream_auto") { g_tune_auto = value != 0; return NNHIP_OK; }
@@ -1390,7 +1392,7 @@ int adv_issue_group(nnhip::StepLaunchFn fn, int userKind, int integrator, const 
       nnhip::StepArgs a = split > 1 ? adv_range(full, lo, hi - lo) : full;
       a.active = k == checkEvery - 1 ? active : nullptr;
       hipStream_t st = r == 0 ? s : p.side[r - 1];
-      if (fn) HIP_TRY(fn(a, 0, st));
+      if (fn) HIP_TRY(fn(a, g_adv_block ? g_adv_block : (a.nontemporal ? 64 : 256), st));  // beyond the Infinity Cache one-wave workgroups retire and refill sooner: 208 -> 203 us at 1e7 Lorenz IVPs
       else if (nnhip::rtc_launch_advance(userKind, integrator, a, st) != hipSuccess) return fail(NNHIP_EHIP, "user RHS launch failed: %s", nnhip::rtc_last_error());
     }
   }

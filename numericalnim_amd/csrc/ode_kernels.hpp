@@ -697,7 +697,7 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_TPI_ATTR void advance_tpi_kernel(
   static_assert(MethodTraits<METHOD>::adaptive, "fixed-step methods share (t, dt): use the uniform streaming loop");
   controller_prologue();
   pin_step_args(a);
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // workgroup size chosen by the launcher (<= kBlock)
   unsigned int stillActive = 0;
   if (i < a.N) {
     const Params P = params_of(a, i);
@@ -1058,12 +1058,13 @@ __global__ __launch_bounds__(kBlock) void fill_t_dt_kernel(double* __restrict__ 
 
 #if !NNHIP_RTC
 template <int METHOD, class RHS>
-hipError_t launch_advance_tpi(const StepArgs& a, int, hipStream_t s) {
+hipError_t launch_advance_tpi(const StepArgs& a, int block, hipStream_t s) {
   if constexpr (MethodTraits<METHOD>::adaptive) {
-    const int64_t grid = (a.N + kBlock - 1) / kBlock;
+    const int bs = (block == 64 || block == 128) ? block : kBlock;  // tuning knob "adv_block"
+    const int64_t grid = (a.N + bs - 1) / bs;
     if (grid <= 0) return hipSuccess;
-    if (a.nontemporal) return launch_kernel(advance_tpi_kernel<METHOD, RHS, true>, dim3((unsigned)grid), dim3(kBlock), s, a);
-    return launch_kernel(advance_tpi_kernel<METHOD, RHS, false>, dim3((unsigned)grid), dim3(kBlock), s, a);
+    if (a.nontemporal) return launch_kernel(advance_tpi_kernel<METHOD, RHS, true>, dim3((unsigned)grid), dim3(bs), s, a);
+    return launch_kernel(advance_tpi_kernel<METHOD, RHS, false>, dim3((unsigned)grid), dim3(bs), s, a);
   } else {
     return hipErrorInvalidValue;
   }

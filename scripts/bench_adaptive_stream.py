@@ -36,6 +36,8 @@ def run(f, y0, integ, layout, check_every, reps=3):
     return best
 
 
+if os.environ.get("ADV_BLOCK"):   # workgroup size of the thread-per-IVP advance kernel (tuning knob "adv_block")
+    assert L.nnhip_tune_set(b"adv_block", int(os.environ["ADV_BLOCK"])) == 0
 cases = []
 ONLY = os.environ.get("ADV_BENCH_ONLY", "")   # e.g. "C3_lorenz_N1e+07" to profile one config
 for n in (1_000_000, 10_000_000):
