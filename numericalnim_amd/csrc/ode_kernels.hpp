@@ -1126,16 +1126,21 @@ hipError_t launch_step_lps(const StepArgs& a, int negate, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // MODE 0: plain loads/stores, one tile per workgroup.   MODE 1: non-temporal loads+stores (streaming hint).
 // MODE 2: persistent grid-stride over tiles (grid = a few workgroups per CU).  MODE 3: MODE 2 + non-temporal.
+// workgroup size of the headline kernel (A/B hook -DNNHIP_RK4_STREAM_BLOCK=64|128|256)
+#ifndef NNHIP_RK4_STREAM_BLOCK
+#define NNHIP_RK4_STREAM_BLOCK 256
+#endif
+constexpr int kRk4Block = NNHIP_RK4_STREAM_BLOCK;
 template <class RHS1, bool NEG, int VEC, int MODE>
 // The scalar arguments come first and as scalars (not structs): ode_tu_rk4_stream.hip is compiled with kernarg preloading, so
 // yin, yout, n, t, dt, dt/2, dt/6 arrive in SGPRs with the wave and the first global_load needs no scalar-load round trip.
-__global__ __launch_bounds__(kBlock) void rk4_stream_vec_kernel(const double* yin, double* yout,  // may alias (in-place stepping): no __restrict__
+__global__ __launch_bounds__(kRk4Block) void rk4_stream_vec_kernel(const double* yin, double* yout,  // may alias (in-place stepping): no __restrict__
                                                                 int64_t n, double t, double h_dt, double h_hdt, double h_dt6, const Params P) {
   static_assert(RHS1::dim == 1, "scalar RHS only");
   const Rk4Dt h{h_dt, h_hdt, h_dt6};
   constexpr bool NT = (MODE & 1) != 0;
   constexpr bool PERSIST = (MODE & 2) != 0;
-  constexpr int64_t TILE = (int64_t)kBlock * 2 * VEC;
+  constexpr int64_t TILE = (int64_t)kRk4Block * 2 * VEC;
   const TpiOps<RHS1, NEG> ops{P};
   const int64_t nTiles = (n + TILE - 1) / TILE;
   for (int64_t tileIdx = blockIdx.x; tileIdx < nTiles; tileIdx += PERSIST ? (int64_t)gridDim.x : nTiles) {
@@ -1146,10 +1151,10 @@ __global__ __launch_bounds__(kBlock) void rk4_stream_vec_kernel(const double* yi
 #pragma unroll
       for (int u = 0; u < VEC; ++u) {
         if constexpr (NT) {
-          v[u].x = __builtin_nontemporal_load(&src[u * kBlock].x);
-          v[u].y = __builtin_nontemporal_load(&src[u * kBlock].y);
+          v[u].x = __builtin_nontemporal_load(&src[u * kRk4Block].x);
+          v[u].y = __builtin_nontemporal_load(&src[u * kRk4Block].y);
         } else {
-          v[u] = src[u * kBlock];
+          v[u] = src[u * kRk4Block];
         }
       }
 #pragma unroll
@@ -1164,14 +1169,14 @@ __global__ __launch_bounds__(kBlock) void rk4_stream_vec_kernel(const double* yi
 #pragma unroll
       for (int u = 0; u < VEC; ++u) {
         if constexpr (NT) {
-          __builtin_nontemporal_store(v[u].x, &dst[u * kBlock].x);
-          __builtin_nontemporal_store(v[u].y, &dst[u * kBlock].y);
+          __builtin_nontemporal_store(v[u].x, &dst[u * kRk4Block].x);
+          __builtin_nontemporal_store(v[u].y, &dst[u * kRk4Block].y);
         } else {
-          dst[u * kBlock] = v[u];
+          dst[u * kRk4Block] = v[u];
         }
       }
     } else {  // ragged tail tile: scalar, bounds-checked
-      for (int64_t j = tile + threadIdx.x; j < n; j += kBlock) {
+      for (int64_t j = tile + threadIdx.x; j < n; j += kRk4Block) {
         double a0[1] = {yin[j]}, r0[1];
         rk4_step(ops, t, h, a0, r0);
         yout[j] = r0[0];
@@ -1328,13 +1333,13 @@ __global__ __launch_bounds__(kBlock) void rhs_batch_kernel(int64_t N, int64_t iv
 template <class RHS1, int VEC, int MODE>
 hipError_t launch_rk4_stream_vec(const double* yin, double* yout, int64_t n, double t, double dt, const Params& P, int negate,
                                  const StreamTune& tune, hipStream_t s) {
-  const int64_t per = (int64_t)kBlock * 2 * VEC;
+  const int64_t per = (int64_t)kRk4Block * 2 * VEC;
   int64_t grid = (n + per - 1) / per;
   if (grid <= 0) return hipSuccess;
   if (MODE & 2) { const int64_t cap = 256LL * tune.blocksPerCU; if (grid > cap) grid = cap; }
   const Rk4Dt h{dt, 0.5 * dt, dt / 6.0};  // host IEEE double ops == the device's (this TU is built -ffp-contract=off)
-  if (negate) return launch_kernel(rk4_stream_vec_kernel<RHS1, true, VEC, MODE>, dim3((unsigned)grid), dim3(kBlock), s, yin, yout, n, t, h.dt, h.hdt, h.dt6, P);
-  return launch_kernel(rk4_stream_vec_kernel<RHS1, false, VEC, MODE>, dim3((unsigned)grid), dim3(kBlock), s, yin, yout, n, t, h.dt, h.hdt, h.dt6, P);
+  if (negate) return launch_kernel(rk4_stream_vec_kernel<RHS1, true, VEC, MODE>, dim3((unsigned)grid), dim3(kRk4Block), s, yin, yout, n, t, h.dt, h.hdt, h.dt6, P);
+  return launch_kernel(rk4_stream_vec_kernel<RHS1, false, VEC, MODE>, dim3((unsigned)grid), dim3(kRk4Block), s, yin, yout, n, t, h.dt, h.hdt, h.dt6, P);
 }
 
 using FixedVecLaunchFn = hipError_t (*)(const FixedVecArgs& a, int negate, int nontemporal, hipStream_t s);
