@@ -304,6 +304,16 @@ int nnhip_ode_solve_batch_multi_gpu_f64(const nnhip_ode_options* opt, int integr
                                         int layout, const double* tspan, int n_t, double* t_out, double* y_out,
                                         int32_t* ny_out, int64_t max_steps, nnhip_ode_stats* stats, int n_gpus);
 
+/* The same with per-IVP right-hand-side parameters (table [n_per_ivp][N] in host memory, as nnhip_ode_solve_batch_sweep_f64) and the
+ * per-IVP step counters (nullable): a parameter sweep — N solveODE calls with their own ctx each, ode.nim:589-591, 599 — sharded
+ * over n_gpus devices; every device reads its columns of the caller's table in place. */
+int nnhip_ode_solve_batch_multi_gpu_sweep_f64(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
+                                              int n_params, const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t N,
+                                              int dim, int layout, const double* tspan, int n_t, double* t_out, double* y_out,
+                                              int32_t* ny_out, int64_t* steps_out, int64_t* rejected_out, int64_t max_steps,
+                                              nnhip_ode_stats* stats, int n_gpus);
+
+
 /* ---- user-supplied right-hand side (run-time compiled) ------------------------------------------
  * The reference accepts any closure f(t, y, ctx) (ODEProc[T], ode.nim:36).  A host closure cannot run on the
  * device, its source can: `body` is the HIP C++ body of

@@ -132,10 +132,15 @@ inline OdeSolution solveODE(const RhsSpec& f, const OdeBatch& y0, const std::vec
   std::vector<double> yout((size_t)n_t * y0.N * y0.dim);
   sol.ny.assign((size_t)y0.N, 0);
   int rc;
-  if (n_gpus > 1) {
-    if (!sweep.empty()) throw std::invalid_argument("parameter sweeps are single-device");
-    rc = nnhip_ode_solve_batch_multi_gpu_f64(&options, integ, f.kind, p.data(), (int)p.size(), y0.data.data(), y0.N, y0.dim, y0.layout,
-                                             tspan.data(), n_t, sol.t.data(), yout.data(), sol.ny.data(), 0, &sol.stats, n_gpus);
+  if (n_gpus > 1) {  // contiguous shards of the batch (and of the sweep table) per device
+    std::vector<double> flat;
+    for (const auto& row : sweep) {
+      if ((int64_t)row.size() != y0.N) throw std::invalid_argument("sweep rows must have one value per IVP");
+      flat.insert(flat.end(), row.begin(), row.end());
+    }
+    rc = nnhip_ode_solve_batch_multi_gpu_sweep_f64(&options, integ, f.kind, p.data(), (int)p.size(), flat.empty() ? nullptr : flat.data(), (int)sweep.size(),
+                                                   y0.data.data(), y0.N, y0.dim, y0.layout, tspan.data(), n_t, sol.t.data(), yout.data(), sol.ny.data(),
+                                                   nullptr, nullptr, 0, &sol.stats, n_gpus);
   } else if (!sortBy.empty() || autoSort) {
     if (!sortBy.empty() && (int64_t)sortBy.size() != y0.N) throw std::invalid_argument("sortBy needs one key per IVP");
     std::vector<double> flat;

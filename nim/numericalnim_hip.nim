@@ -49,7 +49,7 @@ proc solveODE*(f: RhsSpec, y0: OdeBatch, tspan: openArray[float],
                integrator = "dopri54", nGpus = 1, sweep: seq[seq[float]] = @[],
                sortBy: seq[float] = @[], autoSort = false): (seq[float], seq[OdeBatch]) =
   ## Batched drop-in for ode.nim:589-651: same parameter names, order and defaults; returns (t, y) where
-  ## y[j] is the whole batch at t[j].  sweep[k][i] = value of RHS parameter k for IVP i (every IVP its own ctx); single device.
+  ## y[j] is the whole batch at t[j].  sweep[k][i] = value of RHS parameter k for IVP i (every IVP its own ctx).
   ## sortBy (one key per IVP) / autoSort: integrate heterogeneous batches in a divergence-friendly order below the C ABI
   ## (nnhip_ode_solve_batch_sorted_f64); results stay in the caller's order and are bit-identical.
   var ctx = ctx
@@ -67,10 +67,14 @@ proc solveODE*(f: RhsSpec, y0: OdeBatch, tspan: openArray[float],
   var y0d = y0.data
   let pp = if params.len > 0: addr params[0] else: nil
   let rhsKind = (if f.userKind > 0: f.userKind else: f.kind.int).cint
-  if nGpus > 1:
-    check nnhip_ode_solve_batch_multi_gpu_f64(addr opt, integ, rhsKind, pp, params.len.cint, addr y0d[0], y0.n.int64,
-                                              y0.dim.cint, y0.layout.cint, addr ts[0], ts.len.cint, addr tOut[0],
-                                              addr yOut[0], addr ny[0], 0, addr stats, nGpus.cint)
+  if nGpus > 1:                                                      # contiguous shards of the batch (and of the sweep table) per device
+    var flat: seq[cdouble]
+    for row in sweep:
+      for v in row: flat.add(v.cdouble)
+    let sp = if flat.len > 0: addr flat[0] else: nil
+    check nnhip_ode_solve_batch_multi_gpu_sweep_f64(addr opt, integ, rhsKind, pp, params.len.cint, sp, sweep.len.cint, addr y0d[0], y0.n.int64,
+                                                    y0.dim.cint, y0.layout.cint, addr ts[0], ts.len.cint, addr tOut[0],
+                                                    addr yOut[0], addr ny[0], nil, nil, 0, addr stats, nGpus.cint)
   elif sortBy.len > 0 or autoSort:
     if sortBy.len > 0 and sortBy.len != y0.n: raise newException(ValueError, "sortBy needs one key per IVP")
     var flat: seq[cdouble]

@@ -74,6 +74,8 @@ SIGNATURES = {
     "nnhip_ode_adaptive_stream_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int]),
     "nnhip_ode_adaptive_stream_f64_dev": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, C.c_int64, C.c_int, C.c_int,
                                                     C.c_double, C.c_double, _vp, _vp, C.c_int64, C.c_int, C.c_int64, C.POINTER(C.c_int64), _vp]),
+    "nnhip_ode_solve_batch_multi_gpu_sweep_f64": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, _vp, C.c_int, _vp, C.c_int64, C.c_int,
+                                                            C.c_int, _dp, C.c_int, _dp, _vp, _vp, _vp, _vp, C.c_int64, C.POINTER(Stats), C.c_int]),
     "nnhip_ode_solve_batch_multi_gpu_f64": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, _vp, C.c_int64, C.c_int,
                                                       C.c_int, _dp, C.c_int, _dp, _vp, _vp, C.c_int64, C.POINTER(Stats), C.c_int]),
     "nnhip_allgather_states_f64_dev": (C.c_int, [C.c_int, C.POINTER(_vp), C.POINTER(C.c_int64), C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]),

@@ -372,6 +372,16 @@ int nnhip_ode_solve_batch_multi_gpu_f64(const nnhip_ode_options* opt, int integr
                                         const double* rhs_params, int n_params, const double* y0, int64_t N, int dim,
                                         int layout, const double* tspan, int n_t, double* t_out, double* y_out,
                                         int32_t* ny_out, int64_t max_steps, nnhip_ode_stats* stats, int n_gpus) {
+  return nnhip_ode_solve_batch_multi_gpu_sweep_f64(opt, integrator, rhs_kind, rhs_params, n_params, nullptr, 0, y0, N, dim, layout, tspan, n_t, t_out, y_out,
+                                                   ny_out, nullptr, nullptr, max_steps, stats, n_gpus);
+}
+
+// The same with per-IVP right-hand-side parameters (every IVP its own ctx, ode.nim:589-591, 599) and the per-IVP step counters: a
+// parameter sweep sharded over the devices.  Shard r reads columns [lo_r, hi_r) of the caller's [n_per_ivp][N] table in place.
+int nnhip_ode_solve_batch_multi_gpu_sweep_f64(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
+                                              const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t N, int dim, int layout,
+                                              const double* tspan, int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
+                                              int64_t* rejected_out, int64_t max_steps, nnhip_ode_stats* stats, int n_gpus) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return nnhip::fail_msg(NNHIP_EHIP, "no HIP device available (this library has no CPU fallback)");
   if (n_gpus <= 0 || (n_gpus > ndev && !nnhip::multi_gpu_oversubscribe()) || n_gpus > 64)
@@ -395,8 +405,8 @@ int nnhip_ode_solve_batch_multi_gpu_f64(const nnhip_ode_options* opt, int integr
       std::memset(&sts[r], 0, sizeof(nnhip_ode_stats));
       sts[r].ny_min = 0x7fffffff;
       if (n == 0) return;
-      rcs[r] = nnhip::solve_host_range(opt, integrator, rhs_kind, rhs_params, n_params, nullptr, 0, y0, N, lo, n, dim, layout, tspan, n_t,
-                                       nullptr, y_out, ny_out, nullptr, nullptr, max_steps, &sts[r], r % ndev);
+      rcs[r] = nnhip::solve_host_range(opt, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y0, N, lo, n, dim, layout, tspan, n_t,
+                                       nullptr, y_out, ny_out, steps_out, rejected_out, max_steps, &sts[r], r % ndev);
       if (rcs[r]) errs[r] = nnhip::thread_error();  // the message lives in THIS thread's buffer: hand it to the caller
       nnhip::release_thread_staging();              // pinned staging + event of this (short-lived) thread
     });

@@ -149,3 +149,39 @@ def test_rccl_allgather_states_all_devices(nn, dev, layout, dim):
         for r in range(G):
             torch.cuda.synchronize(r)
             assert np.array_equal(fulls[r].cpu().numpy(), full_ref), (r, counts)
+
+
+@pytest.mark.parametrize("layout", [0, 1], ids=["soa", "aos"])
+@pytest.mark.parametrize("n_shards", [1, 3, 8])
+def test_sharded_parameter_sweep(nn, dev, layout, n_shards):
+    """nnhip_ode_solve_batch_multi_gpu_sweep_f64: N solveODE calls with their own ctx each (per-IVP sigma, rho), sharded — every shard
+    reads its columns of the caller's [k][N] table in place; bits and per-IVP counters of the single-device sweep."""
+    import torch
+    L = nn._lib.lib()
+    ndev = torch.cuda.device_count()
+    n, dim = 1001, 3
+    rng = np.random.default_rng(8)
+    y0 = np.stack([1.0 + rng.random(n), np.ones(n), np.ones(n)])
+    y0l = np.ascontiguousarray(y0 if layout == 0 else y0.T)
+    sw = np.ascontiguousarray(np.stack([np.full(n, 10.0), rng.uniform(20, 30, n)]))
+    ts = np.array([-0.1, 0.0, 0.2, 0.3])
+    tr, yr, cr = nn.solveODE(nn.Rhs.lorenz(), y0l, ts, nn.newODEoptions(), integrator="tsit54", layout=layout, sweep=sw, return_counts=True)
+    out = np.full((len(ts),) + y0l.shape, -777.0)
+    t_out = np.full(len(ts), -1.0)
+    ny = np.full(n, -5, dtype=np.int32)
+    steps = np.full(n, -5, dtype=np.int64)
+    rej = np.full(n, -5, dtype=np.int64)
+    st = nn.ode.Stats()
+    p = np.asarray(LOR)
+    opt = nn.newODEoptions()
+    try:
+        L.nnhip_tune_set(b"multi_gpu_oversubscribe", 1 if n_shards > ndev else 0)
+        rc = L.nnhip_ode_solve_batch_multi_gpu_sweep_f64(C.byref(opt), 2, 2, p.ctypes.data_as(dp), 3, sw.ctypes.data, 2, y0l.ctypes.data, n, dim, layout,
+                                                         ts.ctypes.data_as(dp), len(ts), t_out.ctypes.data_as(dp), out.ctypes.data, ny.ctypes.data,
+                                                         steps.ctypes.data, rej.ctypes.data, 0, C.byref(st), n_shards)
+        assert rc == 0, nn._lib.last_error()
+    finally:
+        L.nnhip_tune_set(b"multi_gpu_oversubscribe", 0)
+    assert np.array_equal(t_out, tr) and np.array_equal(out, yr)
+    assert np.array_equal(ny, cr["ny"]) and np.array_equal(steps, cr["steps"]) and np.array_equal(rej, cr["rejected"])
+    assert st.steps_total == int(cr["steps"].sum())
