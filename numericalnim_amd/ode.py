@@ -315,7 +315,9 @@ def integratorStep(f, t, y, FSAL, dt, options=None, ctx=None, integrator="dopri5
                    out=None):
     """One IntegratorProc call (ode.nim:38) over a device batch: returns (yNew, FSAL', dtUsed, error).
 
-    y / FSAL: torch CUDA float64 batches; t / dt: Python floats (uniform) or [N] CUDA tensors."""
+    y / FSAL: torch CUDA float64 batches; t / dt: Python floats (uniform) or [N] CUDA tensors.  out: a preallocated yNew tensor, or a
+    tuple (yNew, FSAL', dtUsed, error) of preallocated tensors (None entries are allocated) — a loop that reuses its buffers then
+    pays no allocations per call."""
     import torch
     L = _lib.lib()
     options = options if options is not None else _default_options()
@@ -327,13 +329,17 @@ def integratorStep(f, t, y, FSAL, dt, options=None, ctx=None, integrator="dopri5
     adaptive = C.c_int()
     _check(L.nnhip_ode_integrator_traits(integ, C.byref(use_fsal), None, C.byref(adaptive)))
     with torch.cuda.device(yc.device):
-        y_new = out if out is not None else torch.empty_like(yc)
+        o = tuple(out) + (None,) * (4 - len(out)) if isinstance(out, (tuple, list)) else (out, None, None, None)
+        for b in o:
+            if b is not None and (not b.is_contiguous() or b.dtype != torch.float64 or b.device != yc.device):
+                raise ValueError("out buffers must be contiguous float64 tensors on y's device")
+        y_new = o[0] if o[0] is not None else torch.empty_like(yc)
         fs_in = FSAL.contiguous() if FSAL is not None else None
-        fs_new = torch.empty_like(yc) if (use_fsal.value or FSAL is not None) else None
+        fs_new = (o[1] if o[1] is not None else torch.empty_like(yc)) if (use_fsal.value or FSAL is not None) else None
         t_dev = t.contiguous() if _is_torch(t) else None
         dt_dev = dt.contiguous() if _is_torch(dt) else None
-        dt_used = torch.empty(N, dtype=torch.float64, device=yc.device) if adaptive.value else None
-        err = torch.empty(N, dtype=torch.float64, device=yc.device) if adaptive.value else None
+        dt_used = (o[2] if o[2] is not None else torch.empty(N, dtype=torch.float64, device=yc.device)) if adaptive.value else None
+        err = (o[3] if o[3] is not None else torch.empty(N, dtype=torch.float64, device=yc.device)) if adaptive.value else None
         stream = torch.cuda.current_stream().cuda_stream
         _check(L.nnhip_ode_step_batch_f64_dev(C.byref(options), integ, f.kind, pp, int(p.size), N, dim, layout,
                                               t_dev.data_ptr() if t_dev is not None else None, 0.0 if t_dev is not None else float(t),

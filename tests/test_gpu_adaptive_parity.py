@@ -68,6 +68,12 @@ def test_step_api_matches_oracle_step(nn, oracle, dev, integrator):
     yn, fn, dtu, err = nn.integratorStep(nn.Rhs.lorenz(), torch.from_numpy(t).to(dev), torch.from_numpy(y).to(dev),
                                          torch.from_numpy(fs).to(dev), torch.from_numpy(dt).to(dev), nn.newODEoptions(**opt_kw),
                                          integrator=integrator)
+    # the same call into preallocated buffers (a loop that reuses them allocates nothing per call): the tensors handed in come back
+    bufs = (torch.empty_like(yn), torch.empty_like(fn), torch.empty_like(dtu), None)
+    r2 = nn.integratorStep(nn.Rhs.lorenz(), torch.from_numpy(t).to(dev), torch.from_numpy(y).to(dev), torch.from_numpy(fs).to(dev),
+                           torch.from_numpy(dt).to(dev), nn.newODEoptions(**opt_kw), integrator=integrator, out=bufs)
+    assert r2[0] is bufs[0] and r2[1] is bufs[1] and r2[2] is bufs[2]
+    assert all(torch.equal(a, b) for a, b in zip(r2, (yn, fn, dtu, err)))
     yn, fn, dtu, err = (x.cpu().numpy() for x in (yn, fn, dtu, err))
     oo = O.new_options(**opt_kw)
     shrunk = 0
