@@ -731,6 +731,9 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_TPI_ATTR void advance_tpi_kernel(
 #ifndef NNHIP_ADV_LPS_PIPE
 #define NNHIP_ADV_LPS_PIPE 1
 #endif
+#ifndef NNHIP_ADV_LPS_DEPTH
+#define NNHIP_ADV_LPS_DEPTH 1
+#endif
 template <int METHOD, class RHS, int CPL = 1>
 __global__ __launch_bounds__(kBlock) NNHIP_ADV_LPS_ATTR void advance_lps_kernel(const StepArgs a) {
   static_assert(MethodTraits<METHOD>::adaptive, "fixed-step methods share (t, dt): use the uniform streaming loop");
@@ -761,6 +764,23 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_LPS_ATTR void advance_lps_kernel(
       P = params_of(a, ic);           // per-IVP parameters (sweeps) belong to the tile's loads as well
       asm volatile("" ::: "memory");  // keeps the tiles' loads in program order: the wait for tile g must not cover tile g + 1's loads
     };
+#if NNHIP_ADV_LPS_DEPTH == 2  // A/B: two tiles ahead (state of tiles g + 1 and g + 2 in registers while tile g is advanced)
+    AdvState<CPL> st[3];
+    Params Ps[3];
+    prefetch(i0, st[0], Ps[0]);
+    if (SPG > 1) prefetch(i0 + perBlock, st[1], Ps[1]);
+#pragma unroll
+    for (int g = 0; g < SPG; ++g) {
+      const int64_t i = i0 + (int64_t)g * perBlock;
+      if (g + 2 < SPG) prefetch(i + 2 * perBlock, st[(g + 2) % 3], Ps[(g + 2) % 3]);
+      AdvState<CPL>& cur = st[g % 3];
+      cur.live = i < a.N && cur.t < a.tEnd;
+      if (i < a.N) {
+        const LpsOps<RHS, false, CPL> ops{Ps[g % 3], ys, es, c};
+        stillActive |= adv_advance<METHOD, false>(a, ops, i, i * a.ivpStride + c * a.compStride, c == 0, cur);
+      }
+    }
+#else
     AdvState<CPL> cur, nxt;
     Params Pcur, Pnxt;
     prefetch(i0, cur, Pcur);
@@ -775,6 +795,7 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_LPS_ATTR void advance_lps_kernel(
       }
       if (g + 1 < SPG) { cur = nxt; Pcur = Pnxt; }
     }
+#endif
     if (a.active) {
       if (__syncthreads_or((int)stillActive) && threadIdx.x == 0) a.active[blockIdx.x % kAggSlots] = 1u;
     }
