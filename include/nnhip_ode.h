@@ -204,6 +204,29 @@ int nnhip_ode_solve_batch_calls_f64_dev(const nnhip_ode_options* opt, int integr
                                         double* y_out, int32_t* ny_out, int64_t* steps_out, int64_t* rejected_out, int64_t max_steps,
                                         void* stream);
 
+/* Every IVP its own n_t-point tspan (and, optionally, its own option fields): N reference calls solveODE(f, y0_i, tspans[i], options_i)
+ * in one launch (ode.nim:589-591, 476-487, 609).  tspans: device array [N][n_t], every row in any order, on either side of its tStart,
+ * with duplicates, with or without tStart itself; t_start, abs_tol, rel_tol, dt_max, dt_min, dt_fixed: nullable device arrays [N] as in
+ * nnhip_ode_solve_batch_calls_f64_dev.  t_out (nullable): device array [N][n_t], row i = the times the reference returns for call i
+ * (tspan_i sorted, ode.nim:585), NaN beyond; y_out [n_t][dim][N] / [n_t][N][dim]: row j of IVP i belongs to t_out[i][j]; ny_out[i] =
+ * rows the reference returns (NaN beyond), -1 for a call it would refuse or never finish (non-finite tspan, dtMax < dtMin, ...).
+ * `ws`: nnhip_ode_solve_tspans_workspace_bytes(N, n_t) bytes of device scratch.  Bitwise equal to one fused solve per IVP. */
+int64_t nnhip_ode_solve_tspans_workspace_bytes(int64_t N, int n_t);
+int nnhip_ode_solve_batch_tspans_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
+                                         int n_params, const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t N, int dim,
+                                         int layout, const double* tspans, int n_t, const double* t_start, const double* abs_tol,
+                                         const double* rel_tol, const double* dt_max, const double* dt_min, const double* dt_fixed,
+                                         double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out, int64_t* rejected_out,
+                                         int64_t max_steps, void* ws, int64_t ws_bytes, void* stream);
+
+/* Host-pointer form of the per-IVP-tspan solve: tspans [N][n_t], t_out [N][n_t] (nullable), y0, y_out, counters in host memory;
+ * opt_per_ivp: N option objects (NULL: every call uses `opt`), as in nnhip_ode_solve_batch_calls_f64. */
+int nnhip_ode_solve_batch_tspans_f64(const nnhip_ode_options* opt, const nnhip_ode_options* opt_per_ivp, int integrator, int rhs_kind,
+                                     const double* rhs_params, int n_params, const double* per_ivp_params, int n_per_ivp,
+                                     const double* y0, int64_t N, int dim, int layout, const double* tspans, int n_t, double* t_out,
+                                     double* y_out, int32_t* ny_out, int64_t* steps_out, int64_t* rejected_out, int64_t max_steps,
+                                     int device);
+
 /* Host-pointer form: N reference calls solveODE(f, y0_i, [options_i.tStart, t_end[i]], options_i) (ode.nim:589-591) in one launch.
  * opt_per_ivp: array of N option objects in host memory (NULL: every call uses `opt`; when given, `opt` still supplies nothing but
  * validation defaults).  t_end, y0, per_ivp_params, y_out [2][dim][N] / [2][N][dim], ny_out, steps_out, rejected_out: host arrays,

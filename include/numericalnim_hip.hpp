@@ -211,6 +211,44 @@ inline OdeSolution solveODECalls(const RhsSpec& f, const OdeBatch& y0, const std
   return sol;
 }
 
+// The same for n_t-point tspans: result row set i == solveODE(f, y0_i, tspans[i], options_i) — tspans[i] in any order, on both sides
+// of options_i.tStart, with duplicates.  sol.y[j] is the batch at output slot j; the times of IVP i are tOut[i] (its sorted tspan,
+// what the reference returns as `t`; shorter than n_t when tspan_i holds tStart_i more than once).
+template <class T = double>
+inline OdeSolution solveODECalls(const RhsSpec& f, const OdeBatch& y0, const std::vector<std::vector<double>>& tspans,
+                                 std::vector<std::vector<double>>& tOut, const std::vector<ODEoptions>& options = {},
+                                 const NumContext<T>* ctx = nullptr, const std::string& integrator = "dopri54", int device = 0) {
+  const int integ = nnhip_ode_integrator_id(integrator.c_str());
+  if (integ < 0) throw std::invalid_argument(integrator + " is not a valid integrator");  // ode.nim:651
+  if ((int64_t)tspans.size() != y0.N) throw std::invalid_argument("tspans needs one row per IVP");
+  if (options.size() > 1 && (int64_t)options.size() != y0.N) throw std::invalid_argument("options: one object, or one per IVP");
+  const int n_t = tspans.empty() ? 0 : (int)tspans[0].size();
+  std::vector<double> flat;
+  for (const auto& row : tspans) {
+    if ((int)row.size() != n_t) throw std::invalid_argument("every tspan needs the same number of points");
+    flat.insert(flat.end(), row.begin(), row.end());
+  }
+  const std::vector<double> p = f.params(ctx);
+  OdeSolution sol;
+  const size_t rowSz = (size_t)y0.N * y0.dim;
+  std::vector<double> yout((size_t)n_t * rowSz), tflat((size_t)y0.N * n_t);
+  sol.ny.assign((size_t)y0.N, 0);
+  const ODEoptions& base = options.size() == 1 ? options[0] : DEFAULT_ODEoptions();
+  throwOn(nnhip_ode_solve_batch_tspans_f64(&base, options.size() > 1 ? options.data() : nullptr, integ, f.kind, p.data(), (int)p.size(), nullptr, 0,
+                                           y0.data.data(), y0.N, y0.dim, y0.layout, flat.data(), n_t, tflat.data(), yout.data(), sol.ny.data(), nullptr,
+                                           nullptr, 0, device));
+  tOut.assign((size_t)y0.N, {});
+  for (int64_t i = 0; i < y0.N; ++i)
+    for (int j = 0; j < n_t; ++j)
+      if (tflat[(size_t)i * n_t + j] == tflat[(size_t)i * n_t + j]) tOut[(size_t)i].push_back(tflat[(size_t)i * n_t + j]);  // NaN = beyond the returned times
+  sol.y.resize((size_t)n_t);
+  for (int j = 0; j < n_t; ++j) {
+    sol.y[j].N = y0.N; sol.y[j].dim = y0.dim; sol.y[j].layout = y0.layout;
+    sol.y[j].data.assign(yout.begin() + (size_t)j * rowSz, yout.begin() + (size_t)(j + 1) * rowSz);
+  }
+  return sol;
+}
+
 // ---- the consumers on either side of the solver: same names as the reference's procs, batched, over the
 // host-pointer entries (arrays are staged through the device per call) ---------------------------------------------------------
 namespace detail {

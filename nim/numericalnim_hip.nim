@@ -140,6 +140,49 @@ proc solveODE*(f: RhsSpec, y0: OdeBatch, tEnd: openArray[float], options: openAr
     result[0].add OdeBatch(n: y0.n, dim: y0.dim, layout: y0.layout, data: yOut[j*row ..< (j+1)*row])
   result[1] = ny
 
+proc solveODE*(f: RhsSpec, y0: OdeBatch, tspans: seq[seq[float]], options: openArray[ODEoptions],
+               ctx: NumContext[OdeBatch, float] = nil, integrator = "dopri54"): (seq[seq[float]], seq[OdeBatch], seq[int32]) =
+  ## N separate reference calls with n_t-point tspans in one launch: IVP i is `solveODE(f, y0_i, tspans[i], options[i])` — any order,
+  ## both sides of tStart, duplicates (ode.nim:589-591, 476-487, 609).  Returns (t, y, ny): t[i] = the times the reference returns for
+  ## call i, y[j] = the batch at output slot j, ny[i] = rows call i returns (-1: a call the reference would refuse).
+  if tspans.len != y0.n: raise newException(ValueError, "tspans needs one row per IVP")
+  if options.len != 1 and options.len != y0.n: raise newException(ValueError, "options: one object, or one per IVP")
+  let nT = (if tspans.len > 0: tspans[0].len else: 0)
+  var ctx = ctx
+  if ctx.isNil: ctx = newNumContext[OdeBatch, float]()
+  let integ = nnhip_ode_integrator_id(integrator.cstring)
+  if integ < 0: raise newException(ValueError, &"{integrator} is not a valid integrator")
+  var params: seq[cdouble]
+  for k in f.keys: params.add(ctx.fValues[k].cdouble)
+  var base = options[0].toC
+  var each: seq[NnhipOptions]
+  if options.len > 1:
+    for o in options: each.add(o.toC)
+  var flat: seq[cdouble]
+  for row in tspans:
+    if row.len != nT: raise newException(ValueError, "every tspan needs the same number of points")
+    for v in row: flat.add(v.cdouble)
+  var y0d = y0.data
+  var tFlat = newSeq[cdouble](max(y0.n * nT, 1))
+  var yOut = newSeq[cdouble](max(nT * y0.n * y0.dim, 1))
+  var ny = newSeq[int32](y0.n)
+  let pp = if params.len > 0: addr params[0] else: nil
+  let ep = if each.len > 0: addr each[0] else: nil
+  let fp = if flat.len > 0: addr flat[0] else: nil
+  let rhsKind = (if f.userKind > 0: f.userKind else: f.kind.int).cint
+  check nnhip_ode_solve_batch_tspans_f64(addr base, ep, integ, rhsKind, pp, params.len.cint, nil, 0, addr y0d[0], y0.n.int64, y0.dim.cint,
+                                         y0.layout.cint, fp, nT.cint, addr tFlat[0], addr yOut[0], addr ny[0], nil, nil, 0, 0)
+  for i in 0 ..< y0.n:
+    var ti: seq[float]
+    for j in 0 ..< nT:
+      let v = tFlat[i*nT + j]
+      if v == v: ti.add(v)                                            # NaN = beyond the returned times
+    result[0].add ti
+  let row = y0.n * y0.dim
+  for j in 0 ..< nT:
+    result[1].add OdeBatch(n: y0.n, dim: y0.dim, layout: y0.layout, data: yOut[j*row ..< (j+1)*row])
+  result[2] = ny
+
 # ---- the consumers on either side of the solver (SURVEY §8 f4), same names as the reference's procs -------------------------
 proc paramsOf(f: RhsSpec, ctx: NumContext[OdeBatch, float]): seq[cdouble] =
   for k in f.keys: result.add(ctx.fValues[k].cdouble)

@@ -7,7 +7,7 @@ it, used by the tests and bench.py.  There is no CPU fallback: without the built
 call raises.
 """
 from .ode import (  # noqa: F401
-    ODEoptions, newODEoptions, NumContext, newNumContext, Rhs, solveODE, integratorStep, fixedStream, fixedStreamSolve, adaptiveStream, adaptiveStreamSolve, solveODEPerIvpEnd, solveODECalls,
+    ODEoptions, newODEoptions, NumContext, newNumContext, Rhs, solveODE, integratorStep, fixedStream, fixedStreamSolve, adaptiveStream, adaptiveStreamSolve, solveODEPerIvpEnd, solveODEPerIvpTspan, solveODECalls, solveODECallsTspan,
     fixedODE, adaptiveODE, allODE, implementedODE, LAYOUT_SOA, LAYOUT_AOS, NnhipError,
 )
 from .interpolate import newHermiteSpline, HermiteSpline, rhsBatch, cumtrapz, cumsimpson, trapz  # noqa: F401

@@ -54,6 +54,11 @@ SIGNATURES = {
                                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "nnhip_ode_solve_batch_calls_f64": (C.c_int, [C.POINTER(Options), _vp, C.c_int, C.c_int, _dp, C.c_int, _vp, C.c_int, _vp, C.c_int64, C.c_int, C.c_int,
                                                   _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int]),
+    "nnhip_ode_solve_tspans_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int]),
+    "nnhip_ode_solve_batch_tspans_f64_dev": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, _vp, C.c_int, _vp, C.c_int64, C.c_int, C.c_int,
+                                                       _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, C.c_int64, _vp]),
+    "nnhip_ode_solve_batch_tspans_f64": (C.c_int, [C.POINTER(Options), _vp, C.c_int, C.c_int, _dp, C.c_int, _vp, C.c_int, _vp, C.c_int64, C.c_int, C.c_int,
+                                                   _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int]),
     "nnhip_ode_solve_batch_tend_f64_dev": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, _vp, C.c_int, _vp, C.c_int64, C.c_int, C.c_int,
                                                      _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "nnhip_ode_solve_sorted_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int]),

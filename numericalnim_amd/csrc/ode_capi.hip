@@ -277,6 +277,8 @@ hipError_t launch_fill_f64(double* p, int64_t n, double v, hipStream_t s);
 int64_t argsort_workspace_bytes(int64_t N);
 hipError_t argsort_f64(const double* keys, int64_t N, uint32_t* perm_out, void* ws, int64_t ws_bytes, hipStream_t s);
 hipError_t negate_f64(const double* in, double* out, int64_t N, hipStream_t s);
+hipError_t prepare_tspans(const double* tspans, int n_t, int64_t N, const double* tStart, double t0, double* grid, int32_t* counts, double* t_out,
+                          hipStream_t s);
 void multigpu_release();  // ode_multigpu.hip
 int solve_host_range(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
                      const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t NFull, int64_t lo0, int64_t N, int dim,
@@ -667,6 +669,58 @@ int nnhip_ode_solve_batch_tend_f64_dev(const nnhip_ode_options* opt, int integra
                                              nullptr, nullptr, nullptr, nullptr, nullptr, y_out, ny_out, steps_out, rejected_out, max_steps, stream);
 }
 
+// ---- every IVP its own n_t-point tspan ------------------------------------------------------------------------------
+// N reference calls solveODE(f, y0_i, tspan_i, options_i) with tspan_i = tspans[i][0 .. n_t) — any order, both sides of tStart_i,
+// duplicates, tStart_i inside or not (ode.nim:589-591, 476-487, 609).  A device pre-pass sorts and splits every row
+// (nnhip::prepare_tspans); the fused kernels then read their own requested times.  Workspace: the prepared rows + the counts.
+int64_t nnhip_ode_solve_tspans_workspace_bytes(int64_t N, int n_t) {
+  if (N < 0 || n_t < 0) return 0;
+  return (((int64_t)N * n_t * 8 + 255) & ~(int64_t)255) + (((int64_t)N * 3 * 4 + 255) & ~(int64_t)255) + 256;
+}
+
+int nnhip_ode_solve_batch_tspans_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
+                                         const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t N, int dim, int layout,
+                                         const double* tspans, int n_t, const double* t_start, const double* abs_tol, const double* rel_tol,
+                                         const double* dt_max, const double* dt_min, const double* dt_fixed, double* t_out, double* y_out,
+                                         int32_t* ny_out, int64_t* steps_out, int64_t* rejected_out, int64_t max_steps, void* ws, int64_t ws_bytes,
+                                         void* stream) {
+  if (!opt) return fail(NNHIP_EVALUE, "options is NULL");
+  if (n_t < 0 || N < 0) return fail(NNHIP_EVALUE, "bad sizes");
+  if (N > 0 && n_t > 0 && (!tspans || !y_out)) return fail(NNHIP_EVALUE, "tspans / y_out is NULL");
+  if (N > 0 && n_t > 0 && (!ws || ws_bytes < nnhip_ode_solve_tspans_workspace_bytes(N, n_t)))
+    return fail(NNHIP_EVALUE, "workspace missing or too small: need %lld bytes", (long long)nnhip_ode_solve_tspans_workspace_bytes(N, n_t));
+  hipStream_t s = (hipStream_t)stream;
+  const double tspan2[2] = {opt->tStart, opt->tStart + 1.0};  // placeholder for validation, dispatch and the batch-wide option fields
+  nnhip_ode_options o = *opt;
+  if (integrator >= 0 && integrator < NNHIP_N_INTEGRATORS) {  // per-IVP values replace the fields prepare_solve would refuse as batch-wide ones
+    if (!kMethods[integrator].adaptive && dt_fixed && !(o.dt > 0.0)) o.dt = 1.0;
+    if (kMethods[integrator].adaptive && dt_min && !(o.dtMin > 0.0)) o.dtMin = o.dtMax > 0.0 ? o.dtMax : 1.0;
+  }
+  PreparedSolve ps;
+  int rc = prepare_solve(&o, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y0, N, dim, layout, tspan2, 2, nullptr,
+                         y_out ? y_out : (double*)y0 /* n_t == 0: nothing is written */, ny_out, steps_out, rejected_out, max_steps, nullptr, 0, nullptr,
+                         nullptr, s, ps);
+  if (rc) return rc;
+  if (N == 0) return NNHIP_OK;
+  if (n_t == 0) {  // solveODE with an empty tspan returns no rows
+    if (ny_out) HIP_TRY(hipMemsetAsync(ny_out, 0, (size_t)N * sizeof(int32_t), s));
+    if (steps_out) HIP_TRY(hipMemsetAsync(steps_out, 0, (size_t)N * sizeof(int64_t), s));
+    if (rejected_out) HIP_TRY(hipMemsetAsync(rejected_out, 0, (size_t)N * sizeof(int64_t), s));
+    return NNHIP_OK;
+  }
+  double* grid = (double*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  int32_t* counts = (int32_t*)((char*)grid + (((size_t)N * (size_t)n_t * 8 + 255) & ~(size_t)255));
+  HIP_TRY(nnhip::prepare_tspans(tspans, n_t, N, t_start, opt->tStart, grid, counts, t_out, s));
+  ps.a.n_t = n_t;
+  ps.a.useDense = n_t != 2 ? 1 : 0;  // :499-502
+  ps.a.perCall.tGrid = grid; ps.a.perCall.tCounts = counts;
+  ps.a.perCall.tStart = t_start; ps.a.perCall.absTol = abs_tol; ps.a.perCall.relTol = rel_tol;
+  ps.a.perCall.dtMax = dt_max; ps.a.perCall.dtMin = dt_min; ps.a.perCall.dt = dt_fixed;
+  ps.a.uniformFull[0] = ps.a.uniformFull[1] = -1;   // no batch-wide step schedule: the spans differ
+  ps.a.nTail[0] = ps.a.nTail[1] = 0;
+  return launch_solve_range(ps, 0, N, s);
+}
+
 // ---- divergence binning below the boundary -----------------------------------------------------------------------
 // Workspace of nnhip_ode_solve_batch_sorted_f64_dev: requested times + order of integration (4N) + probe progress / key (8N)
 // + the device sort's scratch.
@@ -825,6 +879,72 @@ int nnhip_ode_solve_batch_calls_f64(const nnhip_ode_options* opt, const nnhip_od
                                            rejected_out ? (int64_t*)(d + oRj) : nullptr, max_steps, st);
   if (rc) return done(rc);
   if (nOut) HIP_TRY_S(hipMemcpyAsync(y_out, d + oOut, nOut * 8, hipMemcpyDeviceToHost, st));
+  if (ny_out && N) HIP_TRY_S(hipMemcpyAsync(ny_out, d + oNy, (size_t)N * 4, hipMemcpyDeviceToHost, st));
+  if (steps_out && N) HIP_TRY_S(hipMemcpyAsync(steps_out, d + oSt, (size_t)N * 8, hipMemcpyDeviceToHost, st));
+  if (rejected_out && N) HIP_TRY_S(hipMemcpyAsync(rejected_out, d + oRj, (size_t)N * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY_S(hipStreamSynchronize(st));
+#undef HIP_TRY_S
+  return done(NNHIP_OK);
+}
+
+// Host-pointer form of the per-IVP-tspan solve: N reference calls `solveODE(f, y0_i, tspans[i], options_i)` in one launch
+// (ode.nim:589-591); tspans [N][n_t] and t_out [N][n_t] in host memory.  opt_per_ivp is an array of N option objects (NULL: every call uses `opt`); their fields are transposed
+// into the per-IVP tables of nnhip_ode_solve_batch_calls_f64_dev here, whose per-field semantics apply (scaleMax / scaleMin are unused
+// after construction, ode.nim:97-102).
+int nnhip_ode_solve_batch_tspans_f64(const nnhip_ode_options* opt, const nnhip_ode_options* opt_per_ivp, int integrator, int rhs_kind,
+                                     const double* rhs_params, int n_params, const double* per_ivp_params, int n_per_ivp, const double* y0,
+                                     int64_t N, int dim, int layout, const double* tspans, int n_t, double* t_out, double* y_out, int32_t* ny_out,
+                                     int64_t* steps_out, int64_t* rejected_out, int64_t max_steps, int device) {
+  if (N < 0 || dim < 1 || n_t < 0) return fail(NNHIP_EVALUE, "bad sizes");
+  if (N > 0 && (!y0 || (n_t > 0 && (!tspans || !y_out)))) return fail(NNHIP_EVALUE, "tspans / y0 / y_out is NULL");
+  if (n_per_ivp < 0 || n_per_ivp > nnhip::kMaxParams || (n_per_ivp > 0 && !per_ivp_params && N > 0)) return fail(NNHIP_EVALUE, "bad per-IVP parameter table");
+  int ndev = nnhip_device_count();
+  if (ndev < 0) return ndev;
+  if (ndev == 0) return fail(NNHIP_EHIP, "no HIP device available (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(NNHIP_EVALUE, "device %d out of range [0,%d)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  HostSolveCtx* hc = nullptr;
+  int rc = host_ctx_acquire(device, 0, &hc);
+  if (rc) { host_ctx_release(hc); return rc; }
+  hipStream_t st = hc->s[0];
+  const size_t nState = (size_t)N * dim, nOut = nState * (size_t)n_t, nGrid = (size_t)N * (size_t)n_t;
+  const int64_t wsBytes = nnhip_ode_solve_tspans_workspace_bytes(N, n_t);
+  const int nOpt = opt_per_ivp ? 6 : 0;  // tStart, absTol, relTol, dtMax, dtMin, dt
+  std::vector<double> cols;
+  if (nOpt && N) {
+    cols.resize((size_t)nOpt * (size_t)N);
+    for (int64_t i = 0; i < N; ++i) {
+      const nnhip_ode_options& o = opt_per_ivp[i];
+      cols[0 * (size_t)N + i] = o.tStart;
+      cols[1 * (size_t)N + i] = o.absTol;
+      cols[2 * (size_t)N + i] = o.relTol;
+      cols[3 * (size_t)N + i] = o.dtMax;
+      cols[4 * (size_t)N + i] = o.dtMin;
+      cols[5 * (size_t)N + i] = o.dt;
+    }
+  }
+  // one allocation: y0 | out | ny | steps | rejected | tspans | t_out | option columns | per-IVP table | workspace
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t oY0 = 0, oOut = oY0 + up(nState * 8), oNy = oOut + up(nOut * 8), oSt = oNy + up((size_t)N * 4), oRj = oSt + up((size_t)N * 8),
+               oEnd = oRj + up((size_t)N * 8), oTout = oEnd + up(nGrid * 8), oCols = oTout + up(nGrid * 8), oPer = oCols + up((size_t)nOpt * (size_t)N * 8),
+               oWs = oPer + up((size_t)n_per_ivp * (size_t)N * 8), total = oWs + up((size_t)wsBytes) + 256;
+  char* d = nullptr;
+  hipError_t e = hipMalloc((void**)&d, total);
+  if (e != hipSuccess) { host_ctx_release(hc); return fail(e == hipErrorOutOfMemory ? NNHIP_ENOMEM : NNHIP_EHIP, "hipMalloc(%zu) failed: %s", total, hipGetErrorString(e)); }
+  auto done = [&](int code) { (void)hipStreamSynchronize(st); (void)hipFree(d); host_ctx_release(hc); return code; };
+#define HIP_TRY_S(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return done(fail(NNHIP_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e))); } while (0)
+  if (nState) HIP_TRY_S(hipMemcpyAsync(d + oY0, y0, nState * 8, hipMemcpyHostToDevice, st));
+  if (nGrid) HIP_TRY_S(hipMemcpyAsync(d + oEnd, tspans, nGrid * 8, hipMemcpyHostToDevice, st));
+  if (!cols.empty()) HIP_TRY_S(hipMemcpyAsync(d + oCols, cols.data(), cols.size() * 8, hipMemcpyHostToDevice, st));
+  if (n_per_ivp > 0 && N) HIP_TRY_S(hipMemcpyAsync(d + oPer, per_ivp_params, (size_t)n_per_ivp * (size_t)N * 8, hipMemcpyHostToDevice, st));
+  auto col = [&](int k) -> const double* { return nOpt && N ? (const double*)(d + oCols) + (size_t)k * (size_t)N : nullptr; };
+  rc = nnhip_ode_solve_batch_tspans_f64_dev(opt, integrator, rhs_kind, rhs_params, n_params, n_per_ivp > 0 ? (const double*)(d + oPer) : nullptr, n_per_ivp,
+                                            (const double*)(d + oY0), N, dim, layout, (const double*)(d + oEnd), n_t, col(0), col(1), col(2), col(3), col(4), col(5),
+                                            t_out ? (double*)(d + oTout) : nullptr, (double*)(d + oOut), ny_out ? (int32_t*)(d + oNy) : nullptr,
+                                            steps_out ? (int64_t*)(d + oSt) : nullptr, rejected_out ? (int64_t*)(d + oRj) : nullptr, max_steps, d + oWs, wsBytes, st);
+  if (rc) return done(rc);
+  if (nOut) HIP_TRY_S(hipMemcpyAsync(y_out, d + oOut, nOut * 8, hipMemcpyDeviceToHost, st));
+  if (t_out && nGrid) HIP_TRY_S(hipMemcpyAsync(t_out, d + oTout, nGrid * 8, hipMemcpyDeviceToHost, st));
   if (ny_out && N) HIP_TRY_S(hipMemcpyAsync(ny_out, d + oNy, (size_t)N * 4, hipMemcpyDeviceToHost, st));
   if (steps_out && N) HIP_TRY_S(hipMemcpyAsync(steps_out, d + oSt, (size_t)N * 8, hipMemcpyDeviceToHost, st));
   if (rejected_out && N) HIP_TRY_S(hipMemcpyAsync(rejected_out, d + oRj, (size_t)N * 8, hipMemcpyDeviceToHost, st));

@@ -63,8 +63,13 @@ struct SolveArgs {
   // integrates forward (rows y0, y(tEnd)), tEnd < tStart backward (rows y(tEnd), y0), tEnd == tStart yields the reference's single
   // row y0.  Option values go through abs() as in newODEoptions (:101-102); an IVP whose options newODEoptions would reject
   // (dtMax < dtMin) or that could never finish (fixed-step dt == 0; dtMin == 0 without max_steps) gets ny = -1 and NaN rows.
+  // tGrid != nullptr (instead of tEnd): every IVP its own n_t-point tspan (MODE 3).  Row i of tGrid [N][n_t], prepared on the device by
+  // prepare_tspans (ode_sort.hip): the requested times < tStart_i in DESCENDING order first (tNegative as the reference holds it),
+  // those > tStart_i in ascending order last (tPositive); tCounts [N][3] = (nNeg, nZero, nPos), nNeg < 0: non-finite tspan (ny = -1).
   struct PerCall {
     const double *tEnd, *tStart, *absTol, *relTol, *dtMax, *dtMin, *dt;
+    const double* tGrid;
+    const int32_t* tCounts;
   } perCall;
 };
 
@@ -163,7 +168,8 @@ struct LaneStats {
   double progress = 0.0;
 };
 
-// MODE: 1 = general (dense output capable), 0 = lean (tspan.len == 2: no Hermite history), 2 = lean + per-IVP tEnd
+// MODE: 1 = general (dense output capable), 0 = lean (tspan.len == 2: no Hermite history), 2 = lean + per-IVP 2-point tspan and
+// options, 3 = general + per-IVP n_t-point tspan and options
 template <int METHOD, int MODE = 1, class OpsF, class OpsB>
 NNHIP_DEV void solve_body(const SolveArgs& a0, const OpsF& opsF, const OpsB& opsB, const double* y0p, double* out, LaneStats& ls, int64_t ivp) {
   // the direction bookkeeping of this IVP: the batch-wide one, or its own 2-point tspan
@@ -179,11 +185,10 @@ NNHIP_DEV void solve_body(const SolveArgs& a0, const OpsF& opsF, const OpsB& ops
 #pragma unroll
     for (int q = 0; q < 4; ++q) a.tailDt[d][q] = a0.tailDt[d][q];
   }
-  constexpr bool DENSE = MODE == 1;
+  constexpr bool DENSE = MODE == 1 || MODE == 3;
   [[maybe_unused]] bool callInvalid = false;
-  if constexpr (MODE == 2) {  // its own instantiation: per-lane call data costs registers the other kernels do not have to spare
+  if constexpr (MODE == 2 || MODE == 3) {  // their own instantiations: per-lane call data costs registers the other kernels do not have to spare
     const SolveArgs::PerCall& pc = a0.perCall;
-    const double te = pc.tEnd[ivp];
     if (pc.tStart) a.t0 = pc.tStart[ivp];
     if (pc.absTol) a.ctl.absTol = fabs(pc.absTol[ivp]);
     if (pc.relTol) a.ctl.relTol = fabs(pc.relTol[ivp]);
@@ -196,14 +201,26 @@ NNHIP_DEV void solve_body(const SolveArgs& a0, const OpsF& opsF, const OpsB& ops
       if (pc.dt) a.dtInit = fabs(pc.dt[ivp]);                                             // :495-496
       callInvalid = !(a.dtInit > 0.0);
     }
-    a.nPos = a.t0 < te ? 1 : 0;   // tspan.filterIt(it > t0) (:479)
-    a.nNeg = te < a.t0 ? 1 : 0;   // :480
-    a.tEndPos = te;
-    a.tEndNeg = -te;
-    if (!(te == te) || !(a.t0 == a.t0) || fabs(te) == __longlong_as_double(0x7ff0000000000000LL)) callInvalid = true;  // non-finite spans never end
+    if constexpr (MODE == 2) {
+      const double te = pc.tEnd[ivp];
+      a.nPos = a.t0 < te ? 1 : 0;   // tspan.filterIt(it > t0) (:479)
+      a.nNeg = te < a.t0 ? 1 : 0;   // :480
+      a.tEndPos = te;
+      a.tEndNeg = -te;
+      if (!(te == te) || !(a.t0 == a.t0) || fabs(te) == __longlong_as_double(0x7ff0000000000000LL)) callInvalid = true;  // non-finite spans never end
+    } else {
+      const int32_t* cnt = pc.tCounts + 3 * ivp;
+      const double* row = pc.tGrid + ivp * (int64_t)a.n_t;
+      a.nNeg = cnt[0]; a.nZero = cnt[1]; a.nPos = cnt[2];
+      if (a.nNeg < 0 || !(a.t0 == a.t0) || fabs(a.t0) == __longlong_as_double(0x7ff0000000000000LL)) { callInvalid = true; a.nNeg = a.nZero = a.nPos = 0; }
+      a.tNeg = row;                       // descending: row[0] = max(tNegative) ... row[nNeg-1] = min
+      a.tPos = row + (a.n_t - a.nPos);    // ascending, ends with max(tPositive)
+      a.tEndPos = a.nPos > 0 ? row[a.n_t - 1] : a.t0;            // tPositive.max (:510)
+      a.tEndNeg = a.nNeg > 0 ? -row[a.nNeg - 1] : -a.t0;         // -tNegative.min (:549)
+    }
   }
   constexpr int D = OpsF::D;
-  if constexpr (MODE == 2) {
+  if constexpr (MODE == 2 || MODE == 3) {
     if (callInvalid) {
       const double qn = __longlong_as_double(0x7ff8000000000000LL);
       for (int j = 0; j < a.n_t; ++j)
@@ -350,7 +367,6 @@ NNHIP_DEV void aggregate_stats(unsigned long long* aggBase, LaneStats ls) {
 template <int METHOD, class RHS, int MODE = 1>
 __global__ __launch_bounds__(kBlock) void solve_tpi_kernel(const SolveArgs a) {
   controller_prologue<MethodTraits<METHOD>::adaptive>();
-  [[maybe_unused]] constexpr bool DENSE = MODE == 1;
   const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   LaneStats ls;
   if (k < a.N) {
@@ -372,6 +388,7 @@ template <int METHOD, class RHS>
 hipError_t launch_solve_tpi(const SolveArgs& a, hipStream_t s) {
   const int64_t grid = (a.N + kBlock - 1) / kBlock;
   if (grid <= 0) return hipSuccess;
+  if (a.perCall.tGrid) return launch_kernel(solve_tpi_kernel<METHOD, RHS, 3>, dim3((unsigned)grid), dim3(kBlock), s, a);  // every IVP its own n_t-point tspan
   if (a.perCall.tEnd) return launch_kernel(solve_tpi_kernel<METHOD, RHS, 2>, dim3((unsigned)grid), dim3(kBlock), s, a);  // every IVP its own tEnd
   if (!a.useDense) return launch_kernel(solve_tpi_kernel<METHOD, RHS, 0>, dim3((unsigned)grid), dim3(kBlock), s, a);  // lean: no Hermite history
   return launch_kernel(solve_tpi_kernel<METHOD, RHS, 1>, dim3((unsigned)grid), dim3(kBlock), s, a);
@@ -440,6 +457,7 @@ hipError_t launch_solve_lps(const SolveArgs& a, hipStream_t s) {
   constexpr int perBlock = kBlock / (RHS::dim / CPL);
   const int64_t grid = (a.N + perBlock - 1) / perBlock;
   if (grid <= 0) return hipSuccess;
+  if (a.perCall.tGrid) return launch_kernel(solve_lps_kernel<METHOD, RHS, CPL, SHUFFLE_NORM, 3>, dim3((unsigned)grid), dim3(kBlock), s, a);
   if (a.perCall.tEnd) return launch_kernel(solve_lps_kernel<METHOD, RHS, CPL, SHUFFLE_NORM, 2>, dim3((unsigned)grid), dim3(kBlock), s, a);
   if (!a.useDense) return launch_kernel(solve_lps_kernel<METHOD, RHS, CPL, SHUFFLE_NORM, 0>, dim3((unsigned)grid), dim3(kBlock), s, a);
   return launch_kernel(solve_lps_kernel<METHOD, RHS, CPL, SHUFFLE_NORM, 1>, dim3((unsigned)grid), dim3(kBlock), s, a);

@@ -66,6 +66,7 @@ struct UserRhsEntry {
 std::mutex g_mu;
 constexpr int kDenseKey = 1000;  // programs[kDenseKey + integrator]: advance_dense_*_kernel of that integrator
 constexpr int kCallsKey = 2000;  // programs[kCallsKey + integrator]: the solve kernel with per-IVP call data (MODE 2)
+constexpr int kGridKey = 3000;   // programs[kGridKey + integrator]: the solve kernel with per-IVP n_t-point tspans (MODE 3)
 std::deque<UserRhsEntry> g_user;  // deque: registering a new RHS never moves existing entries (programs are handed out by pointer)
 thread_local std::string g_rtc_err;
 
@@ -118,17 +119,18 @@ bool compile(const UserRhsEntry& e, int integrator, CodeObject& out) {
     return false;
   }
   std::vector<std::string> names;
-  if (integrator >= kCallsKey) {  // the fused solve with per-IVP tspan / options (nnhip_ode_solve_batch_calls_f64_dev): its own code object
-    const int method = integrator - kCallsKey;
-    const std::string m = std::to_string(method);
+  if (integrator >= kCallsKey) {  // the fused solve with per-IVP tspan / options (nnhip_ode_solve_batch_calls_f64_dev / _tspans_): its own code object
+    const bool grid = integrator >= kGridKey;
+    const int method = integrator - (grid ? kGridKey : kCallsKey);
+    const std::string m = std::to_string(method), mode = grid ? "3" : "2";
     if (uses_lps(e)) {
       int adaptive = 0;
       nnhip_ode_integrator_traits(method, nullptr, nullptr, &adaptive);
       const int cpl = lps_cpl(e, adaptive != 0);
-      names.push_back("nnhip::solve_lps_kernel<" + m + ", nnhip::UserRhs, " + std::to_string(cpl) + ", false, 2>");
+      names.push_back("nnhip::solve_lps_kernel<" + m + ", nnhip::UserRhs, " + std::to_string(cpl) + ", false, " + mode + ">");
       out.ivpsPerBlockSolve = kBlock / (padded_dim(e) / cpl);
     } else {
-      names.push_back("nnhip::solve_tpi_kernel<" + m + ", nnhip::UserRhs, 2>");
+      names.push_back("nnhip::solve_tpi_kernel<" + m + ", nnhip::UserRhs, " + mode + ">");
     }
   } else if (integrator >= kDenseKey) {  // the dense-output form of the adaptive streaming kernel: its own code object, compiled when first asked for
     const std::string m = std::to_string(integrator - kDenseKey);
@@ -331,7 +333,7 @@ static hipError_t launch(hipFunction_t f, int64_t n, int perBlock, void* arg, hi
 }
 
 hipError_t rtc_launch_solve(int rhs_kind, int integrator, const SolveArgs& a, hipStream_t s) {
-  const std::shared_ptr<Program> p = get_program(rhs_kind, a.perCall.tEnd ? kCallsKey + integrator : integrator);
+  const std::shared_ptr<Program> p = get_program(rhs_kind, a.perCall.tGrid ? kGridKey + integrator : (a.perCall.tEnd ? kCallsKey + integrator : integrator));
   if (!p) return hipErrorInvalidValue;
   SolveArgs copy = a;
   return launch(p->solve, a.N, p->ivpsPerBlockSolve, &copy, s);

@@ -30,7 +30,58 @@ __global__ void narrow_keys_kernel(const double* in, uint16_t* out, uint32_t* io
   }
 }
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// ODESolver's bookkeeping before the loops (ode.nim:476-487, 609) for EVERY IVP its own tspan: one thread sorts its row (insertion
+// sort: stable like Nim's `sorted`, rows are short), splits it around its tStart and lays it out as the solve kernels read it —
+// tNegative (values < tStart) in descending order at the front, tPositive (values > tStart) ascending at the back — and writes the
+// row of output times the reference returns: tNegative.reversed ++ (tStart if it is in tspan) ++ tPositive (:585), NaN beyond.
+__global__ void prepare_tspans_kernel(const double* tspans, int n_t, int64_t N, const double* tStart, double t0u, double* grid, int32_t* counts,
+                                      double* t_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double* in = tspans + i * n_t;
+  double* g = grid + i * n_t;
+  const double t0 = tStart ? tStart[i] : t0u;
+  const double qnan = __longlong_as_double(0x7ff8000000000000LL), inf = __longlong_as_double(0x7ff0000000000000LL);
+  bool ok = true;
+  for (int j = 0; j < n_t; ++j) {
+    const double v = in[j];
+    g[j] = v;
+    ok = ok && (v == v) && fabs(v) != inf;
+  }
+  if (!ok) {  // the reference's loop would never end on a non-finite requested time: this call is refused, the others are not
+    counts[3 * i] = -1; counts[3 * i + 1] = 0; counts[3 * i + 2] = 0;
+    if (t_out) for (int j = 0; j < n_t; ++j) t_out[i * n_t + j] = qnan;
+    return;
+  }
+  for (int j = 1; j < n_t; ++j) {
+    const double v = g[j];
+    int k = j - 1;
+    while (k >= 0 && g[k] > v) { g[k + 1] = g[k]; --k; }
+    g[k + 1] = v;
+  }
+  int nNeg = 0, nPos = 0;
+  for (int j = 0; j < n_t; ++j) { nNeg += g[j] < t0 ? 1 : 0; nPos += g[j] > t0 ? 1 : 0; }   // :479-480
+  int nZero = 0;
+  for (int j = nNeg; j < n_t - nPos; ++j) nZero |= (g[j] == t0) ? 1 : 0;                      // `t0 in tspan` (:485); false for every j when t0 is NaN
+  if (t_out) {
+    int w = 0;
+    for (int j = 0; j < nNeg; ++j) t_out[i * n_t + w++] = g[j];
+    if (nZero) t_out[i * n_t + w++] = t0;
+    for (int j = n_t - nPos; j < n_t; ++j) t_out[i * n_t + w++] = g[j];
+    for (; w < n_t; ++w) t_out[i * n_t + w] = qnan;
+  }
+  for (int lo = 0, hi = nNeg - 1; lo < hi; ++lo, --hi) { const double v = g[lo]; g[lo] = g[hi]; g[hi] = v; }  // tNegative as the reference holds it
+  counts[3 * i] = nNeg; counts[3 * i + 1] = nZero; counts[3 * i + 2] = nPos;
+}
 }  // namespace
+
+hipError_t prepare_tspans(const double* tspans, int n_t, int64_t N, const double* tStart, double t0, double* grid, int32_t* counts, double* t_out,
+                          hipStream_t s) {
+  if (N <= 0) return hipSuccess;
+  void* args[] = {(void*)&tspans, (void*)&n_t, (void*)&N, (void*)&tStart, (void*)&t0, (void*)&grid, (void*)&counts, (void*)&t_out};
+  return hipLaunchKernel((const void*)prepare_tspans_kernel, dim3((unsigned)((N + 127) / 128)), dim3(128), args, 0, s);
+}
 
 // layout of the workspace: [keys_in: 2N][keys_out: 2N][iota: 4N][cub temp]
 int64_t argsort_workspace_bytes(int64_t N) {

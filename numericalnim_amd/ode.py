@@ -415,6 +415,51 @@ def solveODEPerIvpEnd(f, y0, t_end, options=None, ctx=None, integrator="dopri54"
     return y, dict(ny=ny, steps=st, rejected=rj)
 
 
+def solveODEPerIvpTspan(f, y0, tspans, options=None, ctx=None, integrator="dopri54", layout=LAYOUT_SOA, max_steps=0, sweep=None,
+                        t_start=None, absTol=None, relTol=None, dtMax=None, dtMin=None, dt=None):
+    """A batch of solveODE(f, y0_i, tspans[i], options_i, ctx, integrator) calls — every IVP its own n_t-point tspan (any order, both
+    sides of its tStart, duplicates) and, optionally, its own ODEoptions fields (nnhip_ode_solve_batch_tspans_f64_dev).  tspans: CUDA
+    float64 tensor [N, n_t].  Returns (t [N, n_t] — row i = the sorted times the reference returns for call i, NaN beyond —,
+    y [n_t, *y0.shape], counts); ny = -1 marks a call the reference would refuse."""
+    import torch
+    L = _lib.lib()
+    options = options if options is not None else _default_options()
+    integ = integrator_id(integrator)
+    p, pp = _params_array(f, ctx)
+    N, dim, scalar = _shape_info(y0, layout)
+    y0c = y0.contiguous()
+    ts = tspans.contiguous()
+    if ts.dim() != 2 or ts.shape[0] != N or ts.dtype != torch.float64 or not ts.is_cuda:
+        raise ValueError("tspans must be a CUDA float64 tensor of shape [N, n_t]")
+    n_t = int(ts.shape[1])
+    sw = None
+    if sweep is not None:
+        sw = sweep.contiguous()
+        if sw.dim() != 2 or sw.shape[1] != N or sw.dtype != torch.float64 or not sw.is_cuda:
+            raise ValueError("sweep must be a CUDA float64 tensor of shape [k, N]")
+    with torch.cuda.device(y0c.device):
+        t_out = torch.empty((N, n_t), dtype=torch.float64, device=y0c.device)
+        y = torch.empty((n_t,) + tuple(y0c.shape), dtype=torch.float64, device=y0c.device)
+        ny = torch.empty(N, dtype=torch.int32, device=y0c.device)
+        st = torch.empty(N, dtype=torch.int64, device=y0c.device)
+        rj = torch.empty(N, dtype=torch.int64, device=y0c.device)
+        wsb = int(L.nnhip_ode_solve_tspans_workspace_bytes(N, n_t))
+        ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=y0c.device)
+        opts = []
+        for name, v in (("t_start", t_start), ("absTol", absTol), ("relTol", relTol), ("dtMax", dtMax), ("dtMin", dtMin), ("dt", dt)):
+            if v is not None:
+                v = v.contiguous()
+                if v.dim() != 1 or v.shape[0] != N or v.dtype != torch.float64 or not v.is_cuda:
+                    raise ValueError(f"{name} must be a CUDA float64 tensor of shape [N]")
+            opts.append(v)
+        _check(L.nnhip_ode_solve_batch_tspans_f64_dev(C.byref(options), integ, f.kind, pp, int(p.size), sw.data_ptr() if sw is not None else None,
+                                                      int(sw.shape[0]) if sw is not None else 0, y0c.data_ptr(), N, dim, layout, ts.data_ptr(), n_t,
+                                                      *[v.data_ptr() if v is not None else None for v in opts], t_out.data_ptr(), y.data_ptr(),
+                                                      ny.data_ptr(), st.data_ptr(), rj.data_ptr(), int(max_steps), ws.data_ptr(), wsb,
+                                                      torch.cuda.current_stream().cuda_stream))
+    return t_out, y, dict(ny=ny, steps=st, rejected=rj)
+
+
 def solveODECalls(f, y0, t_end, options=None, ctx=None, integrator="dopri54", layout=LAYOUT_SOA, max_steps=0, sweep=None, device=0):
     """N reference calls `solveODE(f, y0_i, [options_i.tStart, t_end[i]], options_i, ctx, integrator)` in one launch, host arrays in
     and out (nnhip_ode_solve_batch_calls_f64).  y0: numpy [dim, N] (SoA) / [N, dim] (AoS) / [N]; t_end: numpy [N]; options: one
@@ -452,6 +497,47 @@ def solveODECalls(f, y0, t_end, options=None, ctx=None, integrator="dopri54", la
                                              y0c.ctypes.data, N, dim, layout, te.ctypes.data, y.ctypes.data, ny.ctypes.data, st.ctypes.data,
                                              rj.ctypes.data, int(max_steps), int(device)))
     return y, dict(ny=ny, steps=st, rejected=rj)
+
+
+def solveODECallsTspan(f, y0, tspans, options=None, ctx=None, integrator="dopri54", layout=LAYOUT_SOA, max_steps=0, sweep=None, device=0):
+    """N reference calls `solveODE(f, y0_i, tspans[i], options_i, ctx, integrator)` in one launch, host arrays in and out
+    (nnhip_ode_solve_batch_tspans_f64).  y0: numpy; tspans: numpy [N, n_t]; options: one ODEoptions object, a sequence of N, or None.
+    Returns (t [N, n_t], y [n_t, *y0.shape], counts) like solveODEPerIvpTspan."""
+    L = _lib.lib()
+    integ = integrator_id(integrator)
+    p, pp = _params_array(f, ctx)
+    y0c = np.ascontiguousarray(np.asarray(y0, dtype=np.float64))
+    N, dim, scalar = _shape_info(y0c, layout)
+    ts = np.ascontiguousarray(np.asarray(tspans, dtype=np.float64))
+    if ts.ndim != 2 or ts.shape[0] != N:
+        raise ValueError("tspans must have shape [N, n_t]")
+    n_t = int(ts.shape[1])
+    each = None
+    if options is None:
+        base = _default_options()
+    elif isinstance(options, _lib.Options):
+        base = options
+    else:
+        options = list(options)
+        if len(options) != N:
+            raise ValueError("options: one object, or one per IVP")
+        base = options[0] if N else _default_options()
+        each = (_lib.Options * N)(*options)
+    sw = None
+    if sweep is not None:
+        sw = np.ascontiguousarray(np.asarray(sweep, dtype=np.float64))
+        if sw.ndim != 2 or sw.shape[1] != N:
+            raise ValueError("sweep must have shape [k, N]")
+    t_out = np.empty((N, n_t), dtype=np.float64)
+    y = np.empty((n_t,) + y0c.shape, dtype=np.float64)
+    ny = np.empty(N, dtype=np.int32)
+    st = np.empty(N, dtype=np.int64)
+    rj = np.empty(N, dtype=np.int64)
+    _check(L.nnhip_ode_solve_batch_tspans_f64(C.byref(base), C.cast(each, C.c_void_p) if each is not None else None, integ, f.kind, pp, int(p.size),
+                                              sw.ctypes.data if sw is not None else None, int(sw.shape[0]) if sw is not None else 0,
+                                              y0c.ctypes.data, N, dim, layout, ts.ctypes.data, n_t, t_out.ctypes.data, y.ctypes.data, ny.ctypes.data,
+                                              st.ctypes.data, rj.ctypes.data, int(max_steps), int(device)))
+    return t_out, y, dict(ny=ny, steps=st, rejected=rj)
 
 
 def fixedStreamSolve(f, y0, tspan, options=None, ctx=None, integrator="rk4", layout=LAYOUT_SOA, max_steps=0):

@@ -131,6 +131,19 @@ int main() {
     bool threwLen = false;
     try { solveODECalls(f, yb, {1.0, 2.0}, opts, &ctx); } catch (const std::invalid_argument&) { threwLen = true; }
     CHECK(threwLen);
+    // every call its own 4-point tspan (unsorted, both sides of its tStart): rows and times of the 1-IVP solves
+    std::vector<std::vector<double>> tspans(n), tOut;
+    for (int i = 0; i < n; ++i) tspans[i] = {opts[i].tStart + 0.4 + 0.05 * i, opts[i].tStart - 0.3, opts[i].tStart, opts[i].tStart + 0.1};
+    opts[7] = opts[6];
+    const OdeSolution grid = solveODECalls(f, yb, tspans, tOut, opts, &ctx, "dopri54");
+    CHECK(grid.y.size() == 4 && tOut.size() == (size_t)n);
+    for (int i = 0; i < n; ++i) {
+      OdeBatch y1 = OdeBatch::zeros(1, 1);
+      y1.at(0, 0) = yb.at(i, 0);
+      const OdeSolution one = solveODE(f, y1, tspans[i], opts[i], &ctx, "dopri54");
+      CHECK(tOut[i] == one.t && grid.ny[i] == one.ny[0]);
+      for (int j = 0; j < one.ny[0]; ++j) CHECK(grid.y[j].at(i, 0) == one.y[j].at(0, 0));
+    }
   }
   // the consumers, as tests/test_integrate.nim:19-21, 67-95 and tests/test_interpolate.nim:5-18, 104-145 use them
   {

@@ -822,3 +822,85 @@ def test_per_call_solve_with_runtime_compiled_right_hand_sides(nn, dev, integrat
             a, b = (yc[:, :, m], ye[:, :, m]) if layout == 0 else (yc[:, m, :], ye[:, m, :])
             assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)), (dim, layout, e)
             assert torch.equal(cc["ny"][m], ce["ny"][m]) and torch.equal(cc["steps"][m], ce["steps"][m])
+
+
+@pytest.mark.parametrize("integrator", ["dopri54", "tsit54", "rk4", "vern65", "heun3"])
+def test_every_ivp_its_own_dense_tspan(nn, oracle, dev, integrator):
+    """nnhip_ode_solve_batch_tspans_f64_dev: IVP i is solveODE(f, y0_i, tspans[i], options) with its OWN n_t-point tspan — unsorted,
+    on both sides of tStart, with duplicates, tStart inside or not, requested times closer than the steps (the reference then returns
+    fewer rows) — thread-per-IVP, lanes-per-system and run-time compiled kernels: times, rows, row counts and step counters of one
+    oracle call per IVP, bit for bit; a non-finite tspan fails its own call only."""
+    import torch
+    O = oracle
+    rng = np.random.default_rng(17)
+    kw = dict(dt=2.0 ** -7, absTol=1e-7, relTol=1e-7, dtMin=1e-6, dtMax=0.05, tStart=0.25)
+    o, oo = nn.newODEoptions(**kw), O.new_options(**kw)
+    for f, okind, params, dim, layout in ((nn.Rhs.lorenz(), O.RHS_LORENZ, LOR, 3, 0), (nn.Rhs.ring(0.1), O.RHS_RING, [0.1], 16, 1),
+                                          (nn.Rhs.linear(-0.4), O.RHS_LINEAR, [-0.4], 5, 0), (nn.Rhs.linear(-0.4), O.RHS_LINEAR, [-0.4], 1, 0)):
+        for n_t in (1, 2, 6):
+            n = 150
+            y0 = rng.uniform(0.5, 1.5, (n, dim)) + (np.array([0.0, 0.0, 20.0]) if dim == 3 else 0.0)
+            ts = np.round(rng.uniform(0.25 - 0.4, 0.25 + 0.5, (n, n_t)), 3)
+            ts[::7, 0] = 0.25                                   # tStart inside
+            if n_t > 2:
+                ts[::5, 1] = ts[::5, 2]                         # duplicates
+                ts[3::11] = np.abs(ts[3::11] - 0.25) + 0.25     # forward side only
+                ts[4::13, 1] = ts[4::13, 0] + 1e-5              # closer than a step: the reference drops rows
+            ts[9, 0] = np.nan                                   # a call the reference would never return from
+            y0l = np.ascontiguousarray(y0 if layout == 1 else y0.T) if dim > 1 else y0[:, 0].copy()
+            lay = layout if dim > 1 else 0
+            t, y, cnt = nn.solveODEPerIvpTspan(f, torch.from_numpy(y0l).to(dev), torch.from_numpy(ts).to(dev), o, integrator=integrator, layout=lay)
+            t, y = t.cpu().numpy(), y.cpu().numpy()
+            ny, steps, rej = (cnt[k].cpu().numpy() for k in ("ny", "steps", "rejected"))
+            assert ny[9] == -1 and np.isnan(t[9]).all()
+            for i in list(range(0, n, 4)) + [9]:
+                gi = y[:, i] if dim == 1 else (y[:, :, i] if lay == 0 else y[:, i, :])
+                if i == 9:
+                    assert np.isnan(gi).all()
+                    continue
+                yi = list(y0[i]) if dim > 1 else float(y0[i, 0])
+                rt, ry, st = O.solve_ode(okind, params, yi, list(ts[i]), oo, integrator)
+                assert len(rt) <= n_t and _same_bits(t[i, :len(rt)], np.asarray(rt)) and np.isnan(t[i, len(rt):]).all(), (dim, n_t, i)
+                assert ny[i] == st.n_y and steps[i] == st.steps and rej[i] == st.rejected, (dim, n_t, i, integrator)
+                assert _same_bits(gi[:st.n_y].reshape(st.n_y, -1), np.asarray(ry).reshape(st.n_y, -1)), (integrator, dim, n_t, i)
+                assert np.isnan(gi[st.n_y:]).all()
+    # all rows equal -> the plain batched solve, bit for bit; per-IVP options ride along
+    n = 64
+    y0 = torch.from_numpy(np.ascontiguousarray((rng.uniform(0.5, 1.5, (n, 3)) + np.array([0.0, 0.0, 20.0])).T)).to(dev)
+    row = np.array([0.7, -0.1, 0.25, 0.4, 0.55])
+    tp, yp, cp = nn.solveODE(nn.Rhs.lorenz(), y0, row, o, integrator=integrator, return_counts=True)
+    tq, yq, cq = nn.solveODEPerIvpTspan(nn.Rhs.lorenz(), y0, torch.from_numpy(np.tile(row, (n, 1))).to(dev), o, integrator=integrator)
+    assert np.array_equal(tq.cpu().numpy(), np.tile(tp, (n, 1))) and torch.equal(torch.nan_to_num(yq, nan=-7.0), torch.nan_to_num(yp, nan=-7.0))
+    assert torch.equal(cq["ny"], cp["ny"]) and torch.equal(cq["steps"], cp["steps"])
+    ye = nn.solveODEPerIvpTspan(nn.Rhs.lorenz(), y0, torch.empty((n, 0), dtype=torch.float64, device=dev), o, integrator=integrator)
+    assert ye[1].shape[0] == 0 and int(ye[2]["ny"].abs().sum()) == 0
+
+
+def test_host_form_of_the_per_ivp_tspan_solve(nn, dev):
+    """nnhip_ode_solve_batch_tspans_f64 (host arrays, option OBJECTS per call) == the device entry with the same rows and option
+    columns, and every call == the ordinary 1-IVP solveODE with its tspan and options."""
+    import torch
+    rng = np.random.default_rng(23)
+    n, n_t = 120, 5
+    y0 = np.ascontiguousarray((rng.uniform(0.5, 1.5, (n, 3)) + np.array([0.0, 0.0, 20.0])).T)
+    tstart = rng.uniform(-0.2, 0.2, n)
+    ts = np.round(tstart[:, None] + rng.uniform(-0.3, 0.5, (n, n_t)), 3)
+    ts[::6, 2] = tstart[::6]
+    opts = [nn.newODEoptions(dt=10 ** rng.uniform(-2.5, -1.5), absTol=10 ** rng.uniform(-9, -5), relTol=10 ** rng.uniform(-9, -5),
+                             dtMax=10 ** rng.uniform(-2, -0.5), dtMin=10 ** rng.uniform(-6, -4), tStart=tstart[i]) for i in range(n)]
+    f = nn.Rhs.lorenz()
+    for integrator in ("tsit54", "ralston4"):
+        th, yh, ch = nn.solveODECallsTspan(f, y0, ts, opts, integrator=integrator)
+        col = lambda name: torch.tensor([getattr(o, name) for o in opts], dtype=torch.float64, device=dev)
+        td, yd, cd = nn.solveODEPerIvpTspan(f, torch.from_numpy(y0).to(dev), torch.from_numpy(ts).to(dev), nn.newODEoptions(), integrator=integrator,
+                                            t_start=col("tStart"), absTol=col("absTol"), relTol=col("relTol"), dtMax=col("dtMax"), dtMin=col("dtMin"), dt=col("dt"))
+        assert _same_bits(th, td.cpu().numpy()) and _same_bits(yh, yd.cpu().numpy())
+        for k in ("ny", "steps", "rejected"):
+            assert (ch[k] == cd[k].cpu().numpy()).all(), k
+        for i in (0, 6, 55, 119):
+            t1, y1, c1 = nn.solveODE(f, torch.from_numpy(np.ascontiguousarray(y0[:, i:i + 1])).to(dev), ts[i], opts[i], integrator=integrator, return_counts=True)
+            k = int(ch["ny"][i])
+            assert k == int(c1["ny"][0]) and np.array_equal(th[i, :len(t1)], t1) and np.isnan(th[i, len(t1):]).all()
+            assert _same_bits(y1.cpu().numpy()[:k, :, 0], yh[:k, :, i]), (integrator, i)
+    with pytest.raises(ValueError):
+        nn.solveODECallsTspan(f, y0, ts[:5], opts)

@@ -3,7 +3,7 @@
 size, layout, tspan incl. both directions / duplicates / tStart inside or outside, options) the results of
   * the whole ODESolver through the IntegratorProc seam (nnhip_ode_fixed_stream_dense_f64_dev / nnhip_ode_adaptive_stream_dense_f64_dev),
   * the divergence-binned solve (caller's key and automatic probe),
-  * the per-call solve (every IVP its own tspan end and option fields; device tables and the host form with option objects)
+  * the per-call solves (every IVP its own 2-point or n_t-point tspan and option fields; device tables and the host forms with option objects)
 must be the bits of the plain fused solve (which tests/tools/soak_fuzz.py compares with the oracle).  COUNTS mismatching cases instead
 of asserting; writes JSON.   usage: python tests/tools/soak_paths.py [n_seeds] [out.json]"""
 import json
@@ -30,7 +30,7 @@ def same(a, b):
 
 
 tab = {k: dict(cases=0, ivps=0, mismatching_cases=0, errors=0) for k in ("stream_solve", "sorted_key", "sorted_probe", "calls_dev", "calls_host", "host_solve",
-                                                                         "sweep_host", "sweep_sorted", "sweep_calls", "stream_final")}
+                                                                         "sweep_host", "sweep_sorted", "sweep_calls", "stream_final", "tspans_dev", "tspans_host")}
 bad = []
 for seed in range(5000, 5000 + n_seeds):
     rng = np.random.default_rng(seed)
@@ -128,6 +128,19 @@ for seed in range(5000, 5000 + n_seeds):
     except Exception as e:
         tab["stream_final"]["errors"] += 1
         bad.append(dict(path="stream_final", seed=seed, error=str(e)[:200], integ=integ, kind=kind, dim=dim))
+    # per-IVP n_t-point tspans: every row a permutation of the batch tspan -> the plain solve's bits, times in sorted order
+    try:
+        if len(ts) > 0:
+            rows = np.stack([rng.permutation(ts) for _ in range(n)])
+            tq, yq, cq = nn.solveODEPerIvpTspan(f, yt, torch.from_numpy(rows).to(dev), o, integrator=integ, layout=layout)
+            tq = tq.cpu().numpy()
+            ok = all(np.array_equal(tq[i, :len(t)], t) and np.isnan(tq[i, len(t):]).all() for i in range(0, n, max(1, n // 7)))
+            note("tspans_dev", ok and same(yq, y) and all(bool(torch.equal(cnt[k], cq[k])) for k in ("ny", "steps", "rejected")))
+            th, yh3, ch3 = nn.solveODECallsTspan(f, y0l, rows, o, integrator=integ, layout=layout)
+            note("tspans_host", same(torch.from_numpy(yh3), yq.cpu()) and np.array_equal(ch3["steps"], cq["steps"].cpu().numpy()))
+    except Exception as e:
+        tab["tspans_dev"]["errors"] += 1
+        bad.append(dict(path="tspans", seed=seed, error=str(e)[:200], integ=integ, kind=kind, dim=dim))
 res = {"seeds": [5000, 5000 + n_seeds], "per_path": tab, "findings": bad[:40]}
 os.makedirs(os.path.dirname(out_path), exist_ok=True)
 json.dump(res, open(out_path, "w"), indent=1)
