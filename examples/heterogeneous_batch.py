@@ -47,3 +47,8 @@ small = slice(0, 20_000)
 tt, yd, ny, launches = nn.adaptiveStreamSolve(nn.Rhs.vanderpol(2.0), y0[:, small].contiguous(), ts, opt, integrator="dopri54")
 tf, yf = nn.solveODE(nn.Rhs.vanderpol(2.0), y0[:, small].contiguous(), ts, opt, integrator="dopri54")
 print(f"stream-solve through the IntegratorProc seam: {launches} launches, rows {tuple(yd.shape)}, identical to the fused solve: {torch.equal(yd, yf)}")
+
+# every IVP its own output grid as well: 8 requested times per IVP, unsorted, on both sides of tStart
+grids = torch.from_numpy(rng.uniform(-1.0, 4.0, (n, 8))).to(dev)
+tg, yg, cg = nn.solveODEPerIvpTspan(f, y0, grids, opt, integrator="dopri54", sweep=mu[None, :])
+print(f"per-IVP grids: t {tuple(tg.shape)} (row i = IVP i's sorted times), y {tuple(yg.shape)}, rows returned per IVP {int(cg['ny'].min())}..{int(cg['ny'].max())}")
