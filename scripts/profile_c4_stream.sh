@@ -3,7 +3,8 @@
 # (counters only, each group in its own pass; the per-channel TCC_EA0_* groups made rocprofv3 abort on this pool and are left out) over scripts/bench_adaptive_stream.py restricted to the C4 config.
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
-export TMPDIR=/tmp ADV_BENCH_ONLY=C4
+export TMPDIR=/tmp ADV_BENCH_ONLY="${ADV_BENCH_ONLY:-C4}"
+export KFILTER="${KFILTER:-advance_lps_kernel<2,}" TAG="${TAG:-c4}"   # e.g. ADV_BENCH_ONLY=C3_lorenz_N1e+06 KFILTER="advance_tpi_kernel<2," TAG=c3
 mkdir -p gpurun_out
 G=(
  "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LEVEL_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"
@@ -14,21 +15,23 @@ G=(
  )
 i=0
 for g in "${G[@]}"; do
-  timeout 300 rocprofv3 --pmc $g --output-format csv -d gpurun_out/prof_c4_$i -o c4 -- python scripts/bench_adaptive_stream.py > gpurun_out/prof_c4_$i.log 2>&1 || tail -3 gpurun_out/prof_c4_$i.log
+  timeout 300 rocprofv3 --pmc $g --output-format csv -d gpurun_out/prof_${TAG}_$i -o c4 -- python scripts/bench_adaptive_stream.py > gpurun_out/prof_${TAG}_$i.log 2>&1 || tail -3 gpurun_out/prof_${TAG}_$i.log
   i=$((i+1))
 done
 python - <<'PY'
 import csv, glob, collections, json
 out = {}
-for d in sorted(glob.glob("gpurun_out/prof_c4_*/")):
+import os
+TAG, KF = os.environ["TAG"], os.environ["KFILTER"]
+for d in sorted(glob.glob(f"gpurun_out/prof_{TAG}_*/")):
     for f in glob.glob(d + "**/*counter_collection.csv", recursive=True):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "advance_lps_kernel<2," in r["Kernel_Name"]:   # Tsit54 = method id 2 (kernel names are demangled)
+            if KF in r["Kernel_Name"]:   # e.g. "advance_lps_kernel<2," = Tsit54 (kernel names are demangled)
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for c, v in agg.items():
             v.sort()
             out[c] = dict(p50=v[len(v) // 2], p75=v[int(len(v) * 0.75)], n=len(v))   # working launches: upper part of the distribution
 print(json.dumps(out, indent=1))
-json.dump(out, open("gpurun_out/prof_c4_counters.json", "w"), indent=1)
+json.dump(out, open(f"gpurun_out/prof_{TAG}_counters.json", "w"), indent=1)
 PY
