@@ -171,6 +171,30 @@ def test_argument_validation(nn):
     assert ctx["k"] == 3
 
 
+def test_per_call_wrappers_validate_before_touching_the_device(nn):
+    """The host forms of the per-call solves (one ODEoptions object / one tspan per IVP) check their shapes on the host; with valid
+    arguments and no GPU they fail loudly like every compute entry (no CPU fallback)."""
+    import torch
+    y0 = np.ones((3, 5))
+    opts = [nn.newODEoptions() for _ in range(5)]
+    with pytest.raises(ValueError):
+        nn.solveODECalls(nn.Rhs.lorenz(), y0, np.ones(4), opts)            # t_end: one value per IVP
+    with pytest.raises(ValueError):
+        nn.solveODECalls(nn.Rhs.lorenz(), y0, np.ones(5), opts[:3])        # options: one object, or one per IVP
+    with pytest.raises(ValueError):
+        nn.solveODECallsTspan(nn.Rhs.lorenz(), y0, np.ones((4, 3)), opts)  # tspans: one row per IVP
+    with pytest.raises(ValueError):
+        nn.solveODECallsTspan(nn.Rhs.lorenz(), y0, np.ones((5, 3)), opts, sweep=np.ones((2, 4)))
+    L = nn._lib.lib()
+    assert L.nnhip_ode_solve_tspans_workspace_bytes(1000, 7) >= 1000 * 7 * 8 + 1000 * 12
+    assert L.nnhip_tune_set(b"adv_block", 96) == -1 and L.nnhip_tune_set(b"adv_block", 0) == 0
+    if not torch.cuda.is_available():
+        with pytest.raises(nn.NnhipError, match="(no CPU fallback|hipGetDeviceCount|HIP)"):
+            nn.solveODECalls(nn.Rhs.lorenz(), y0, np.ones(5), opts)
+        with pytest.raises(nn.NnhipError, match="(no CPU fallback|hipGetDeviceCount|HIP)"):
+            nn.solveODECallsTspan(nn.Rhs.lorenz(), y0, np.ones((5, 3)), opts)
+
+
 def test_non_finite_times_are_refused(nn):
     """inf / NaN in tspan or tStart would make the reference loop forever; the ABI refuses them before touching the device."""
     for ts in ([0.0, float("inf")], [float("nan"), 1.0]):
