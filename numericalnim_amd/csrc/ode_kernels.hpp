@@ -659,31 +659,52 @@ NNHIP_DEV void adv_fetch(const StepArgs& a, const Ops& ops, int64_t i, int64_t b
     }
   }
 }
-// phase 2: the loop iteration itself and the write-back
-template <int METHOD, bool NT, class Ops>
-NNHIP_DEV unsigned int adv_advance(const StepArgs& a, const Ops& ops, int64_t i, int64_t base, bool writeScalars, AdvState<Ops::D>& s) {
+// phase 2: the loop iteration itself (registers only) ...
+template <int D>
+struct AdvResult {
+  double t, dt, error, y[D], fsal[D];
+  bool live;  // the lane advanced an IVP in this launch: the members above are to be written back
+};
+template <int METHOD, class Ops>
+NNHIP_DEV unsigned int adv_compute(const StepArgs& a, const Ops& ops, AdvState<Ops::D>& s, AdvResult<Ops::D>& r) {
   constexpr int D = Ops::D;
+  r.live = s.live;
   if (!s.live) return 0u;
-  double t = s.t, yNew[D];
+  double t = s.t;
   double dt = nmin(s.dt, a.tEnd - t);  // :525
   double error = 0.0;
   int64_t rej = 0;
   double factor;
-  embedded_step<METHOD>(ops, t, dt, s.y, s.fsal, yNew, error, a.ctl, rej, factor);  // :531
+  embedded_step<METHOD>(ops, t, dt, s.y, s.fsal, r.y, error, a.ctl, rej, factor);  // :531
   t += dt;                                                              // :532
   if (error == 0.0) dt *= 5.0;                                          // :534-535
   else dt = dt * factor;                                                // :537 (the factor of the accepted attempt's error)
   if (dt < a.ctl.dtMin) dt = a.ctl.dtMin;                               // :538-539
   else if (a.ctl.dtMax < dt) dt = a.ctl.dtMax;                          // :540-541
   if (error != error) t = a.tEnd;  // NaN abort (same deviation as the fused driver): retire the IVP
-  adv_store_state<NT>(a, ops, base, yNew, s.fsal);
+#pragma unroll
+  for (int c = 0; c < D; ++c) r.fsal[c] = s.fsal[c];
+  r.t = t; r.dt = dt; r.error = error;
+  return t < a.tEnd ? 1u : 0u;
+}
+// ... and its write-back
+template <bool NT, class Ops>
+NNHIP_DEV void adv_commit(const StepArgs& a, const Ops& ops, int64_t i, int64_t base, bool writeScalars, const AdvResult<Ops::D>& r) {
+  if (!r.live) return;
+  adv_store_state<NT>(a, ops, base, r.y, r.fsal);
   if (writeScalars) {
-    a.t_io[i] = t;
-    a.dt_io[i] = dt;
-    if (a.error) a.error[i] = error;
+    a.t_io[i] = r.t;
+    a.dt_io[i] = r.dt;
+    if (a.error) a.error[i] = r.error;
     if (a.steps_io) a.steps_io[i] += 1;
   }
-  return t < a.tEnd ? 1u : 0u;
+}
+template <int METHOD, bool NT, class Ops>
+NNHIP_DEV unsigned int adv_advance(const StepArgs& a, const Ops& ops, int64_t i, int64_t base, bool writeScalars, AdvState<Ops::D>& s) {
+  AdvResult<Ops::D> r;
+  const unsigned int more = adv_compute<METHOD>(a, ops, s, r);
+  adv_commit<NT>(a, ops, i, base, writeScalars, r);
+  return more;
 }
 template <int METHOD, bool NT = false, class Ops>
 NNHIP_DEV unsigned int advance_body(const StepArgs& a, const Ops& ops, int64_t i, int64_t base, bool writeScalars) {
