@@ -110,6 +110,9 @@ int nnhip_host_free(void* p);
  *   "adv_nontemporal" -1|0|1 (non-temporal instantiations of the streaming kernels; -1 = automatic: when the state of one launch
  *   exceeds 192 MiB), "adv_split" 0|1|2|4 (index ranges of the adaptive streaming loop on separate streams; measured slower, default 1),
  *   "adv_block" 0|64|128|256 (workgroup size of the thread-per-IVP advance kernel; 0 = automatic: 64 with the non-temporal instantiation),
+ *   "adv_steps_per_launch" 1..1024 (loop iterations of ode.nim:525-541 per IVP and launch of nnhip_ode_adaptive_stream_f64_dev; default 1 = one
+ *   IntegratorProc call per launch, state through HBM between any two; K > 1 keeps an IVP's state in registers for up to K iterations:
+ *   the same bits, 1/K of the launches and 8*(4d+5)/K bytes per attempted step — a different traffic model, never quoted against the one-per-launch figures),
  *   "fixed_vec_ipl" 0|2 (0 = one IVP per lane instead of the vectorised fixed-step streaming kernel),
  *   "multi_gpu_oversubscribe" 0|1 (nnhip_ode_solve_batch_multi_gpu_f64 accepts more shards than devices: shard r on device r mod #devices),
  *   "dim16_variant" 0..4 (A/B mappings of the fused 16-component kernels), "fp_contract" 0|1 (opt-in FMA-contracted fused

@@ -97,7 +97,8 @@ struct StepArgs {
   const double* perIvpParams;  // nullable [nPerIvp][N], as in SolveArgs
   int nPerIvp;
   int64_t perIvpStride;
-  int speculate;    // unused (round 2 measured issuing the state loads together with the load of t: no gain; removed)
+  int stepsPerLaunch;  // advance mode: loop iterations per IVP and launch with the state kept in registers in between (<= 1: one, the
+                       // IntegratorProc seam proper; K > 1 moves 8*(4d+5)/K bytes per attempted step — a different traffic model, reported apart)
   int nontemporal;  // advance mode: non-temporal hint on the streamed state arrays (working set beyond the Infinity Cache)
   // advance mode WITH dense output (adaptive streaming through the IntegratorProc seam, ode.nim:512-530): tReq == nullptr -> none.
   const double* tReq;   // requested times of this direction as the reference holds them (tPositive ascending / tNegative descending)
@@ -664,11 +665,13 @@ template <int D>
 struct AdvResult {
   double t, dt, error, y[D], fsal[D];
   bool live;  // the lane advanced an IVP in this launch: the members above are to be written back
+  int steps;  // loop iterations it took (1 unless StepArgs::stepsPerLaunch > 1)
 };
 template <int METHOD, class Ops>
 NNHIP_DEV unsigned int adv_compute(const StepArgs& a, const Ops& ops, AdvState<Ops::D>& s, AdvResult<Ops::D>& r) {
   constexpr int D = Ops::D;
   r.live = s.live;
+  r.steps = 1;
   if (!s.live) return 0u;
   double t = s.t;
   double dt = nmin(s.dt, a.tEnd - t);  // :525
@@ -696,21 +699,40 @@ NNHIP_DEV void adv_commit(const StepArgs& a, const Ops& ops, int64_t i, int64_t 
     a.t_io[i] = r.t;
     a.dt_io[i] = r.dt;
     if (a.error) a.error[i] = r.error;
-    if (a.steps_io) a.steps_io[i] += 1;
+    if (a.steps_io) a.steps_io[i] += r.steps;
   }
 }
-template <int METHOD, bool NT, class Ops>
+// MULTI: StepArgs::stepsPerLaunch iterations per launch.  A template parameter, not a run-time trip count of one loop: carrying the
+// state around a loop costs the one-iteration kernels a spill and 10-15 % (C3 1e6: 22.9 -> 26.4 us, C4: 123 -> 131 us per launch).
+template <int METHOD, bool NT, bool MULTI = false, class Ops>
 NNHIP_DEV unsigned int adv_advance(const StepArgs& a, const Ops& ops, int64_t i, int64_t base, bool writeScalars, AdvState<Ops::D>& s) {
-  AdvResult<Ops::D> r;
-  const unsigned int more = adv_compute<METHOD>(a, ops, s, r);
+  constexpr int D = Ops::D;
+  AdvResult<D> r;
+  unsigned int more;
+  if constexpr (!MULTI) {
+    more = adv_compute<METHOD>(a, ops, s, r);  // the IntegratorProc seam proper: one loop iteration per launch
+  } else {
+    // the IVP keeps iterating ode.nim:525-541 on the registers it has (what K launches would do through HBM; the same operations
+    // in the same order, so the same bits) until it reaches tEnd or has taken its K iterations
+    int k = 0;
+    for (;;) {
+      more = adv_compute<METHOD>(a, ops, s, r);
+      ++k;
+      if (!more || k >= a.stepsPerLaunch) break;
+      s.t = r.t; s.dt = r.dt;
+#pragma unroll
+      for (int c = 0; c < D; ++c) { s.y[c] = r.y[c]; s.fsal[c] = r.fsal[c]; }
+    }
+    r.steps = k;
+  }
   adv_commit<NT>(a, ops, i, base, writeScalars, r);
   return more;
 }
-template <int METHOD, bool NT = false, class Ops>
+template <int METHOD, bool NT = false, bool MULTI = false, class Ops>
 NNHIP_DEV unsigned int advance_body(const StepArgs& a, const Ops& ops, int64_t i, int64_t base, bool writeScalars) {
   AdvState<Ops::D> s;
   adv_fetch<NT>(a, ops, i, base, s);
-  return adv_advance<METHOD, NT>(a, ops, i, base, writeScalars, s);
+  return adv_advance<METHOD, NT, MULTI>(a, ops, i, base, writeScalars, s);
 }
 
 // Occupancy of the thread-per-IVP advance kernel.  glibc's pow keeps six 64-bit polynomial constants in VGPRs (an FMA takes
@@ -731,7 +753,7 @@ constexpr int adv_tpi_waves() { return (RHS::dim <= 3 && METHOD != NNHIP_VERN65)
 #else
 #define NNHIP_ADV_LPS_ATTR
 #endif
-template <int METHOD, class RHS, bool NT = false>
+template <int METHOD, class RHS, bool NT = false, bool MULTI = false>
 __global__ __launch_bounds__(kBlock) NNHIP_ADV_TPI_ATTR void advance_tpi_kernel(const StepArgs a) {
   static_assert(MethodTraits<METHOD>::adaptive, "fixed-step methods share (t, dt): use the uniform streaming loop");
   controller_prologue();
@@ -741,7 +763,7 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_TPI_ATTR void advance_tpi_kernel(
   if (i < a.N) {
     const Params P = params_of(a, i);
     const TpiOps<RHS, false> ops{P};
-    stillActive = advance_body<METHOD, NT>(a, ops, i, i * a.ivpStride, true);
+    stillActive = advance_body<METHOD, NT, MULTI>(a, ops, i, i * a.ivpStride, true);
   }
   // "is anyone still integrating?" — a plain flag store per workgroup into one of kAggSlots words (no atomics: 1e5 waves
   // hitting one address cost ~170 us per launch), and only in the launches whose answer the host will read
@@ -773,7 +795,7 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_TPI_ATTR void advance_tpi_kernel(
 #ifndef NNHIP_ADV_LPS_DEPTH
 #define NNHIP_ADV_LPS_DEPTH 1
 #endif
-template <int METHOD, class RHS, int CPL = 1>
+template <int METHOD, class RHS, int CPL = 1, bool MULTI = false>
 __global__ __launch_bounds__(kBlock) NNHIP_ADV_LPS_ATTR void advance_lps_kernel(const StepArgs a) {
   static_assert(MethodTraits<METHOD>::adaptive, "fixed-step methods share (t, dt): use the uniform streaming loop");
   constexpr int DIM = RHS::dim;
@@ -816,7 +838,7 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_LPS_ATTR void advance_lps_kernel(
       cur.live = i < a.N && cur.t < a.tEnd;
       if (i < a.N) {
         const LpsOps<RHS, false, CPL> ops{Ps[g % 3], ys, es, c};
-        stillActive |= adv_advance<METHOD, false>(a, ops, i, i * a.ivpStride + c * a.compStride, c == 0, cur);
+        stillActive |= adv_advance<METHOD, false, MULTI>(a, ops, i, i * a.ivpStride + c * a.compStride, c == 0, cur);
       }
     }
 #else
@@ -830,7 +852,7 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_LPS_ATTR void advance_lps_kernel(
       cur.live = i < a.N && cur.t < a.tEnd;  // :511
       if (i < a.N) {
         const LpsOps<RHS, false, CPL> ops{Pcur, ys, es, c};
-        stillActive |= adv_advance<METHOD, false>(a, ops, i, i * a.ivpStride + c * a.compStride, c == 0, cur);
+        stillActive |= adv_advance<METHOD, false, MULTI>(a, ops, i, i * a.ivpStride + c * a.compStride, c == 0, cur);
       }
       if (g + 1 < SPG) { cur = nxt; Pcur = Pnxt; }
     }
@@ -858,7 +880,7 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_LPS_ATTR void advance_lps_kernel(
     if (idx[g] < a.N) {
       const Params P = params_of(a, idx[g]);
       const LpsOps<RHS, false, CPL> ops{P, lds + sysInBlock * lps_stride<DIM>(), lds + lps_lds_doubles<DIM, CPL>() / 2 + sysInBlock * lps_stride<DIM>(), c};
-      stillActive |= adv_advance<METHOD, false>(a, ops, idx[g], idx[g] * a.ivpStride + c * a.compStride, c == 0, st[g]);
+      stillActive |= adv_advance<METHOD, false, MULTI>(a, ops, idx[g], idx[g] * a.ivpStride + c * a.compStride, c == 0, st[g]);
     }
   }
   if (a.active) {
@@ -1123,6 +1145,7 @@ hipError_t launch_advance_tpi(const StepArgs& a, int block, hipStream_t s) {
     const int bs = (block == 64 || block == 128) ? block : kBlock;  // tuning knob "adv_block"
     const int64_t grid = (a.N + bs - 1) / bs;
     if (grid <= 0) return hipSuccess;
+    if (a.stepsPerLaunch > 1) return launch_kernel(advance_tpi_kernel<METHOD, RHS, false, true>, dim3((unsigned)grid), dim3(bs), s, a);
     if (a.nontemporal) return launch_kernel(advance_tpi_kernel<METHOD, RHS, true>, dim3((unsigned)grid), dim3(bs), s, a);
     return launch_kernel(advance_tpi_kernel<METHOD, RHS, false>, dim3((unsigned)grid), dim3(bs), s, a);
   } else {
@@ -1144,6 +1167,7 @@ hipError_t launch_advance_lps(const StepArgs& a, int, hipStream_t s) {
     constexpr int perBlock = kBlock / (RHS::dim / CPL) * NNHIP_ADV_LPS_SPG;
     const int64_t grid = (a.N + perBlock - 1) / perBlock;
     if (grid <= 0) return hipSuccess;
+    if (a.stepsPerLaunch > 1) return launch_kernel(advance_lps_kernel<METHOD, RHS, CPL, true>, dim3((unsigned)grid), dim3(kBlock), s, a);
     return launch_kernel(advance_lps_kernel<METHOD, RHS, CPL>, dim3((unsigned)grid), dim3(kBlock), s, a);
   } else {
     return hipErrorInvalidValue;

@@ -64,6 +64,7 @@ struct UserRhsEntry {
 };
 
 std::mutex g_mu;
+constexpr int kMultiKey = 500;   // programs[kMultiKey + integrator]: the advance kernel with several loop iterations per launch (StepArgs::stepsPerLaunch > 1)
 constexpr int kDenseKey = 1000;  // programs[kDenseKey + integrator]: advance_dense_*_kernel of that integrator
 constexpr int kCallsKey = 2000;  // programs[kCallsKey + integrator]: the solve kernel with per-IVP call data (MODE 2)
 constexpr int kGridKey = 3000;   // programs[kGridKey + integrator]: the solve kernel with per-IVP n_t-point tspans (MODE 3)
@@ -141,6 +142,15 @@ bool compile(const UserRhsEntry& e, int integrator, CodeObject& out) {
     } else {
       names.push_back("nnhip::advance_dense_tpi_kernel<" + m + ", nnhip::UserRhs>");
     }
+  } else if (integrator >= kMultiKey) {  // K loop iterations per launch: its own code object, compiled when first asked for
+    const std::string m = std::to_string(integrator - kMultiKey);
+    if (uses_lps(e)) {
+      const int scpl = lps_step_cpl(e);
+      names.push_back("nnhip::advance_lps_kernel<" + m + ", nnhip::UserRhs, " + std::to_string(scpl) + ", true>");
+      out.ivpsPerBlockAdvance = kBlock / (padded_dim(e) / scpl) * NNHIP_ADV_LPS_SPG;
+    } else {
+      names.push_back("nnhip::advance_tpi_kernel<" + m + ", nnhip::UserRhs, false, true>");
+    }
   } else if (integrator >= 0) {
     const std::string m = std::to_string(integrator);
     if (uses_lps(e)) {
@@ -211,6 +221,7 @@ bool load(const CodeObject& co, int integrator, Program& out) {
   hipFunction_t* slots[4] = {&out.solve, &out.stepPos, &out.stepNeg, &out.advance};
   if (integrator == -1) slots[0] = &out.rhs;
   if (integrator == -2) { slots[0] = &out.quad[0]; slots[1] = &out.quad[1]; }
+  if (integrator >= kMultiKey) slots[0] = &out.advance;
   if (integrator >= kDenseKey) slots[0] = &out.advanceDense;
   if (integrator >= kCallsKey) slots[0] = &out.solve;
   for (size_t i = 0; i < co.lowered.size(); ++i)
@@ -345,7 +356,7 @@ hipError_t rtc_launch_step(int rhs_kind, int integrator, const StepArgs& a, int 
   return launch(negate ? p->stepNeg : p->stepPos, a.N, p->ivpsPerBlockStep, &copy, s);
 }
 hipError_t rtc_launch_advance(int rhs_kind, int integrator, const StepArgs& a, hipStream_t s) {
-  const std::shared_ptr<Program> p = get_program(rhs_kind, integrator);
+  const std::shared_ptr<Program> p = get_program(rhs_kind, a.stepsPerLaunch > 1 ? kMultiKey + integrator : integrator);
   if (!p) return hipErrorInvalidValue;
   if (!p->advance) { g_rtc_err = "no advance kernel: fixed-step integrator"; return hipErrorInvalidValue; }
   StepArgs copy = a;

@@ -598,9 +598,11 @@ def adaptiveStreamSolve(f, y0, tspan, options=None, ctx=None, integrator="dopri5
     return t_out[:ntout.value].copy(), y, ny[:N], nl.value
 
 
-def adaptiveStream(f, y, t0, tEnd, options=None, ctx=None, integrator="dopri54", layout=LAYOUT_SOA, check_every=8):
+def adaptiveStream(f, y, t0, tEnd, options=None, ctx=None, integrator="dopri54", layout=LAYOUT_SOA, check_every=8, steps_per_launch=None):
     """ODESolver's adaptive loop (ode.nim:506-542) over the HBM-resident `advance` kernel; y (CUDA tensor) is advanced
-    in place from t0 to tEnd.  Returns (y, number of launches).  Bitwise equal to solveODE(f, y0, [t0, tEnd])[1][-1]."""
+    in place from t0 to tEnd.  Returns (y, number of launches).  Bitwise equal to solveODE(f, y0, [t0, tEnd])[1][-1].
+    steps_per_launch (None = leave the process-wide knob "adv_steps_per_launch" as it is, default 1): loop iterations per IVP and
+    launch; K > 1 keeps the state in registers for K iterations (same bits, 1/K of the launches, 1/K of the HBM traffic per step)."""
     import torch
     L = _lib.lib()
     options = options if options is not None else _default_options()
@@ -610,6 +612,8 @@ def adaptiveStream(f, y, t0, tEnd, options=None, ctx=None, integrator="dopri54",
     if not y.is_contiguous():
         raise ValueError("y must be contiguous (it is updated in place)")
     nl = C.c_int64(0)
+    if steps_per_launch is not None:
+        _check(L.nnhip_tune_set(b"adv_steps_per_launch", int(steps_per_launch)))
     with torch.cuda.device(y.device):
         wsb = int(L.nnhip_ode_adaptive_stream_workspace_bytes(N, dim))
         ws = torch.empty(wsb, dtype=torch.uint8, device=y.device)

@@ -483,6 +483,49 @@ def test_adaptive_stream_graph_replay_thread_per_ivp(nn, oracle, dev):
                 assert torch.equal(ys, yf[-1]) and launches >= 102
 
 
+@pytest.mark.parametrize("K", [2, 3, 7, 1000])
+def test_adaptive_stream_several_iterations_per_launch(nn, oracle, dev, K):
+    """Tuning knob "adv_steps_per_launch": K iterations of ode.nim:525-541 per IVP and launch, state in registers in between.  Same
+    operations in the same order as K launches, so the bits of the fused solve — thread-per-IVP and lanes-per-system kernels, a
+    run-time compiled right-hand side, rejections, IVPs that finish in the middle of a launch — with about 1/K of the launches."""
+    import torch
+    O = oracle
+    L = nn._lib.lib()
+    try:
+        n = 3001
+        y0 = _lorenz_y0(n)
+        kw = dict(absTol=1e-6, relTol=1e-6, dtMin=1e-9, dtMax=1.0)
+        yt = torch.from_numpy(y0).to(dev)
+        for integ in ("dopri54", "tsit54", "vern65", "bs32", "rk21"):
+            t, yf, cnt = nn.solveODE(nn.Rhs.lorenz(), yt, [0.0, 1.5], nn.newODEoptions(**kw), integrator=integ, return_counts=True)
+            ys, launches = nn.adaptiveStream(nn.Rhs.lorenz(), yt.clone(), 0.0, 1.5, nn.newODEoptions(**kw), integrator=integ, check_every=3,
+                                             steps_per_launch=K)
+            assert torch.equal(ys, yf[-1]), integ
+            need = -(-int(cnt["steps"].max()) // K)   # launches until the slowest IVP is done
+            assert need <= launches < need + 6, (integ, launches, need)
+        ref = O.solve_ode_batch(O.RHS_LORENZ, LOR, y0, n, 3, [0.0, 1.5], O.new_options(**kw), "rk21", n_threads=8)
+        assert _same_bits(ys.cpu().numpy(), ref["y"][-1])
+        kw = dict(absTol=1e-8, relTol=1e-8, dtMin=1e-7, dtMax=0.25)
+        for dim, n, layout in ((16, 1000, 1), (16, 777, 0), (24, 100, 1)):   # 24: run-time compiled lanes-per-system kernel
+            y0 = _ring_y0(n, dim)
+            y0l = y0 if layout == 1 else np.ascontiguousarray(y0.T)
+            yt = torch.from_numpy(y0l).to(dev)
+            t, yf = nn.solveODE(nn.Rhs.ring(0.1), yt, [0.0, 1.0], nn.newODEoptions(**kw), integrator="tsit54", layout=layout)
+            ys, launches = nn.adaptiveStream(nn.Rhs.ring(0.1), yt.clone(), 0.0, 1.0, nn.newODEoptions(**kw), integrator="tsit54", layout=layout,
+                                             check_every=4, steps_per_launch=K)
+            assert torch.equal(ys, yf[-1]), (dim, layout)
+        duff = nn.Rhs.custom(2, "dy[0] = y[1]; dy[1] = ((-p[0] * y[1] - p[1] * y[0]) - p[2] * (y[0] * y[0] * y[0])) + p[3] * t;",
+                             keys=("delta", "alpha", "beta", "gamma"), defaults=dict(delta=0.2, alpha=1.0, beta=0.5, gamma=0.3), name="duffing_stream_k")
+        y0 = torch.from_numpy(0.5 + np.random.default_rng(9).random((2, 2000))).to(dev)
+        t, yf = nn.solveODE(duff, y0, [0.0, 2.0], nn.newODEoptions(absTol=1e-7, relTol=1e-7, dtMin=1e-9, dtMax=0.5), integrator="dopri54")
+        ys, launches = nn.adaptiveStream(duff, y0.clone(), 0.0, 2.0, nn.newODEoptions(absTol=1e-7, relTol=1e-7, dtMin=1e-9, dtMax=0.5),
+                                         integrator="dopri54", steps_per_launch=K)
+        assert torch.equal(ys, yf[-1])
+    finally:
+        assert L.nnhip_tune_set(b"adv_steps_per_launch", 1) == 0
+    assert L.nnhip_tune_set(b"adv_steps_per_launch", 0) != 0 and L.nnhip_tune_set(b"adv_steps_per_launch", 1025) != 0
+
+
 @pytest.mark.parametrize("layout,dim", [(0, 1), (0, 3), (1, 3)])
 def test_rccl_allgather_states_single_device(nn, dev, layout, dim):
     """nnhip_allgather_states_f64_dev (one process, G devices, RCCL): with the one device of this box the gather must

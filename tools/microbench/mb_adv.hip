@@ -52,7 +52,7 @@ static StepArgs make_args(const Problem& p, DevState& s) {
   return a;
 }
 using Launch = std::function<hipError_t(const StepArgs&, hipStream_t)>;
-struct Candidate { std::string name; Launch launch; };
+struct Candidate { std::string name; Launch launch; int K = 1; };  // K: loop iterations per launch (the harness then issues 1/K of the launches)
 
 static std::vector<double> fetch(const DevState& s) {
   std::vector<double> h((size_t)s.N * (2 * s.dim + 3));
@@ -79,9 +79,9 @@ static void run_all(const char* title, const Problem& p, std::vector<Candidate>&
     for (int r = 0; r < reps; ++r) {
       init_state<RHS>(p, s);
       StepArgs a = make_args(p, s);
-      for (int k = 0; k < warm; ++k) CK(c.launch(a, st));
+      for (int k = 0; k < warm / c.K; ++k) CK(c.launch(a, st));
       CK(hipEventRecord(e0, st));
-      for (int k = 0; k < iters; ++k) CK(c.launch(a, st));
+      for (int k = 0; k < iters / c.K; ++k) CK(c.launch(a, st));
       CK(hipEventRecord(e1, st));
       CK(hipStreamSynchronize(st));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -106,16 +106,16 @@ static void run_all(const char* title, const Problem& p, std::vector<Candidate>&
     if (ref.empty()) ref = out;
     else same = out.size() == ref.size() && std::memcmp(out.data(), ref.data(), out.size() * sizeof(double)) == 0;
     const double us = best * 1e3 / iters;
-    printf("%-34s %8.2f us/iter  %7.1f GB/s  frac8T %.3f  %s\n", c.name.c_str(), us, bytesPerIvpStep * p.N / us * 1e-3, bytesPerIvpStep * p.N / us * 1e-3 / 8000.0,
-           same ? "bit-identical" : "** DIFFERS **");
+    printf("%-34s %8.2f us/iter  %7.1f GB/s  frac8T %.3f  %s%s\n", c.name.c_str(), us, bytesPerIvpStep / c.K * p.N / us * 1e-3, bytesPerIvpStep / c.K * p.N / us * 1e-3 / 8000.0,
+           same ? "bit-identical" : "** DIFFERS **", c.K > 1 ? "  [K iterations per launch: bytes = 8(4d+5)/K per step]" : "");
     fflush(stdout);
   }
   s.release();
 }
 
 template <int METHOD, class RHS, int CPL>
-static Launch lps_base() {
-  return [](const StepArgs& a, hipStream_t st) { return launch_advance_lps<METHOD, RHS, CPL>(a, 0, st); };
+static Launch lps_base(int K = 1) {
+  return [K](const StepArgs& a0, hipStream_t st) { StepArgs a = a0; a.stepsPerLaunch = K; return launch_advance_lps<METHOD, RHS, CPL>(a, 0, st); };
 }
 template <int METHOD, class RHS, int CPL, bool PP = false, int PROBE = 0>
 static Launch lps_persist(int blocksPerCU) {
@@ -138,8 +138,8 @@ static Launch lps_mc(int blocksPerCU) {
   };
 }
 template <int METHOD, class RHS>
-static Launch tpi_base(int block, int nt) {
-  return [block, nt](const StepArgs& a0, hipStream_t st) { StepArgs a = a0; a.nontemporal = nt; return launch_advance_tpi<METHOD, RHS>(a, block, st); };
+static Launch tpi_base(int block, int nt, int K = 1) {
+  return [block, nt, K](const StepArgs& a0, hipStream_t st) { StepArgs a = a0; a.nontemporal = nt; a.stepsPerLaunch = K; return launch_advance_tpi<METHOD, RHS>(a, block, st); };
 }
 template <int METHOD, class RHS, bool NT>
 static Launch tpi_persist(int block, int blocksPerCU) {
@@ -166,6 +166,7 @@ int main(int argc, char** argv) {
     for (int b : {3, 4}) c.push_back({"tsit54 persist grid=256x" + std::to_string(b), lps_persist<NNHIP_TSIT54, R, 2>(b)});
     c.push_back({"tsit54 pingpong grid=256x4", lps_persist<NNHIP_TSIT54, R, 2, true>(4)});
     c.push_back({"tsit54 base again", lps_base<NNHIP_TSIT54, R, 2>()});
+    for (int K : {2, 5, 10}) c.push_back({"tsit54 base K=" + std::to_string(K), lps_base<NNHIP_TSIT54, R, 2>(K), K});
     for (int b : {2, 3}) c.push_back({"tsit54 mover/consumer CPL=4 grid=256x" + std::to_string(b), lps_mc<NNHIP_TSIT54, R, 4>(b)});
     c.push_back({"tsit54 mc 3 groups per WG grid=256x1", lps_mc<NNHIP_TSIT54, R, 4, 0, 0, 3>(1)});
     c.push_back({"tsit54 mc 3 groups per WG prio3", lps_mc<NNHIP_TSIT54, R, 4, 0, 3, 3>(1)});
@@ -211,6 +212,8 @@ int main(int argc, char** argv) {
     c.push_back({"dopri54 persist nt b256 grid=256x4", tpi_persist<M, R, true>(256, 4)});
     c.push_back({"dopri54 persist nt b64 grid=256x16", tpi_persist<M, R, true>(64, 16)});
     c.push_back({"dopri54 base b256 again", tpi_base<M, R>(256, 0)});
+    for (int K : {2, 5, 10}) c.push_back({"dopri54 base b256 K=" + std::to_string(K), tpi_base<M, R>(256, 0, K), K});
+    for (int K : {2, 5, 10}) c.push_back({"dopri54 base b64 nt K=" + std::to_string(K), tpi_base<M, R>(64, 1, K), K});
     run_all<R>(("C3 streamed, DOPRI54 " + tag).c_str(), p, c, 10, 60, 3, 8.0 * (4 * 3 + 5));
     std::vector<Candidate> d;
     d.push_back({"tsit54 base b256", tpi_base<NNHIP_TSIT54, R>(256, 0)});
