@@ -1216,7 +1216,8 @@ thread_local std::vector<StreamGraphEntry> g_graphs;
 thread_local std::vector<StreamGraphKey> g_graph_seen;  // automatic mode: keys that ran eagerly once (a repeat is worth capturing)
 thread_local bool g_capturing = false;
 void release_stream_graphs() {
-  for (auto& e : g_graphs) if (e.exec) { (void)hipStreamSynchronize(e.key.stream); (void)hipGraphExecDestroy(e.exec); }
+  if (!g_graphs.empty()) (void)hipDeviceSynchronize();  // not the cached stream handles: a caller may have destroyed its stream since
+  for (auto& e : g_graphs) if (e.exec) (void)hipGraphExecDestroy(e.exec);
   g_graphs.clear();
   g_graph_seen.clear();
 }
@@ -1277,7 +1278,7 @@ int nnhip_ode_fixed_stream_f64_dev(const nnhip_ode_options* opt, int integrator,
     (void)hipGraphDestroy(graph);
     if (ie != hipSuccess) return fail(NNHIP_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
     if (g_graphs.size() >= 8) {  // evict the oldest; it may still be executing on its stream
-      (void)hipStreamSynchronize(g_graphs.front().key.stream);
+      (void)hipDeviceSynchronize();
       (void)hipGraphExecDestroy(g_graphs.front().exec);
       g_graphs.erase(g_graphs.begin());
     }
@@ -1440,6 +1441,7 @@ namespace {
 struct AdvGraphKey {
   nnhip::StepArgs a;
   const void* fn;
+  const void* active;  // which half of the pinned flag block the group's last launch writes
   int userKind, integrator, checkEvery, device, split;
   hipStream_t stream;
 };
@@ -1447,7 +1449,12 @@ struct AdvGraphEntry {
   AdvGraphKey key;
   hipGraphExec_t exec = nullptr;
 };
-struct AdvPoll {  // pinned landing zone of the "anyone still integrating?" flags: two groups in flight
+// The "anyone still integrating?" flags live in page-locked, device-visible HOST memory and the last launch of a polling group stores
+// into them directly (a few thousand 4-byte writes over PCIe, once per group).  Round 2 kept them in device memory: every group then
+// carried a memset node in front and a device-to-host copy behind (~13 us per group, 1.5 us per loop iteration at C3's size).  Two
+// halves for the two groups in flight; the host zeroes a half itself before it issues the group that writes it (the previous
+// group on that half has been waited for by then).
+struct AdvPoll {
   unsigned int* h = nullptr;
   hipEvent_t ev[2] = {nullptr, nullptr};
   // side streams + fork/join events for interleaving index ranges of the batch (see adv_issue_group)
@@ -1465,7 +1472,7 @@ int adv_poll_reserve() {
   if (g_adv_poll.device != device) release_adv_graphs();  // streams and events belong to one device
   AdvPoll& p = g_adv_poll;
   p.device = device;
-  if (!p.h) HIP_TRY(hipHostMalloc((void**)&p.h, 2 * nnhip::kAggSlots * sizeof(unsigned int), hipHostMallocDefault));
+  if (!p.h) HIP_TRY(hipHostMalloc((void**)&p.h, 2 * nnhip::kAggSlots * sizeof(unsigned int), hipHostMallocMapped | hipHostMallocCoherent));
   for (hipEvent_t& e : p.ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (hipStream_t& st : p.side) if (!st) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   if (!p.fork) HIP_TRY(hipEventCreateWithFlags(&p.fork, hipEventDisableTiming));
@@ -1473,7 +1480,8 @@ int adv_poll_reserve() {
   return NNHIP_OK;
 }
 void release_adv_graphs() {
-  for (auto& e : g_adv_graphs) if (e.exec) { (void)hipStreamSynchronize(e.key.stream); (void)hipGraphExecDestroy(e.exec); }
+  if (!g_adv_graphs.empty()) (void)hipDeviceSynchronize();  // not the cached stream handles: a caller may have destroyed its stream since
+  for (auto& e : g_adv_graphs) if (e.exec) (void)hipGraphExecDestroy(e.exec);
   g_adv_graphs.clear();
   AdvPoll& p = g_adv_poll;
   if (p.h) (void)hipHostFree(p.h);
@@ -1504,7 +1512,6 @@ nnhip::StepArgs adv_range(const nnhip::StepArgs& full, int64_t lo, int64_t n) {
 int adv_issue_group(nnhip::StepLaunchFn fn, int userKind, int integrator, const nnhip::StepArgs& full, unsigned int* active, int checkEvery,
                     int split, hipStream_t s) {
   AdvPoll& p = g_adv_poll;
-  HIP_TRY(hipMemsetAsync(active, 0, nnhip::kAggSlots * sizeof(unsigned int), s));
   if (split > 1) {
     HIP_TRY(hipEventRecord(p.fork, s));
     for (int r = 1; r < split; ++r) HIP_TRY(hipStreamWaitEvent(p.side[r - 1], p.fork, 0));
@@ -1557,7 +1564,6 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
   double* tArr = fsal + N * dim;
   double* dtArr = tArr + N;
   double* errArr = dtArr + N;
-  unsigned int* active = (unsigned int*)(errArr + N);
   // FSAL = f(t0, y) (:506); t = t0; dt = sqrt(dtMax*dtMin) (:491-493)
   rc = nnhip_ode_rhs_batch_f64_dev(rhs_kind, rhs_params, n_params, N, dim, layout, t0, y, fsal, stream);
   if (rc) return fail(rc, "initial RHS evaluation failed");
@@ -1582,55 +1588,63 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
                               // (profiles/r02_pow_tables_ab.txt) — the launches were never gap-bound: the kernel itself takes 27 us
   if ((int64_t)split > N) split = 1;
 
-  // ---- the polling group as a graph (cached per thread; key = everything the launches depend on) ----
-  hipGraphExec_t exec = nullptr;
+  // ---- the polling group as a graph (cached per thread; key = everything the launches depend on), one per half of the flag block ----
+  hipGraphExec_t execs[2] = {nullptr, nullptr};
   if (g_stream_graph != 0 && s != nullptr) {
     int device = 0;
     HIP_TRY(hipGetDevice(&device));
-    AdvGraphKey key;
-    std::memset(&key, 0, sizeof(key));
-    std::memcpy(&key.a, &a, sizeof(a));
-    key.fn = (const void*)fn; key.userKind = userKind; key.integrator = integrator; key.checkEvery = check_every; key.device = device; key.split = split; key.stream = s;
-    for (auto& e : g_adv_graphs)
-      if (std::memcmp(&e.key, &key, sizeof(key)) == 0) { exec = e.exec; break; }
-    if (!exec) {
-      if (fn == nullptr) {  // run-time compiled kernels: make sure the module is loaded before the stream goes into capture mode
-        nnhip::StepArgs warm = a;
-        warm.N = 0;
-        (void)nnhip::rtc_launch_advance(userKind, integrator, warm, s);
-      }
-      hipGraph_t graph = nullptr;
-      if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-        rc = adv_issue_group(fn, userKind, integrator, a, active, check_every, split, s);
-        const hipError_t ce = hipStreamEndCapture(s, &graph);
-        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-        if (ce == hipSuccess && graph) {
-          const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-          (void)hipGraphDestroy(graph);
-          if (ie != hipSuccess) { exec = nullptr; (void)hipGetLastError(); }
+    for (int half = 0; half < 2; ++half) {
+      unsigned int* flags = poll.h + half * nnhip::kAggSlots;
+      AdvGraphKey key;
+      std::memset(&key, 0, sizeof(key));
+      std::memcpy(&key.a, &a, sizeof(a));
+      key.fn = (const void*)fn; key.active = flags; key.userKind = userKind; key.integrator = integrator; key.checkEvery = check_every; key.device = device; key.split = split; key.stream = s;
+      hipGraphExec_t exec = nullptr;
+      for (auto& e : g_adv_graphs)
+        if (std::memcmp(&e.key, &key, sizeof(key)) == 0) { exec = e.exec; break; }
+      if (!exec) {
+        if (fn == nullptr) {  // run-time compiled kernels: make sure the module is loaded before the stream goes into capture mode
+          nnhip::StepArgs warm = a;
+          warm.N = 0;
+          (void)nnhip::rtc_launch_advance(userKind, integrator, warm, s);
+        }
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+          rc = adv_issue_group(fn, userKind, integrator, a, flags, check_every, split, s);
+          const hipError_t ce = hipStreamEndCapture(s, &graph);
+          if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+          if (ce == hipSuccess && graph) {
+            const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ie != hipSuccess) { exec = nullptr; (void)hipGetLastError(); }
+          } else {
+            (void)hipGetLastError();
+          }
         } else {
-          (void)hipGetLastError();
+          (void)hipGetLastError();  // e.g. the caller is capturing this stream itself: plain launches below
         }
-      } else {
-        (void)hipGetLastError();  // e.g. the caller is capturing this stream itself: plain launches below
-      }
-      if (exec) {
-        if (g_adv_graphs.size() >= 8) {  // evict the oldest; it may still be executing on its stream
-          (void)hipStreamSynchronize(g_adv_graphs.front().key.stream);
-          (void)hipGraphExecDestroy(g_adv_graphs.front().exec);
-          g_adv_graphs.erase(g_adv_graphs.begin());
+        if (exec) {
+          if (g_adv_graphs.size() >= 16) {  // evict the oldest; it may still be executing
+            (void)hipDeviceSynchronize();
+            (void)hipGraphExecDestroy(g_adv_graphs.front().exec);
+            g_adv_graphs.erase(g_adv_graphs.begin());
+          }
+          AdvGraphEntry e;
+          e.key = key; e.exec = exec;
+          g_adv_graphs.push_back(e);
         }
-        AdvGraphEntry e;
-        e.key = key; e.exec = exec;
-        g_adv_graphs.push_back(e);
       }
+      execs[half] = exec;
     }
+    if (!execs[0] || !execs[1]) execs[0] = execs[1] = nullptr;
   }
   auto issue = [&](int64_t g) -> int {
-    if (exec) HIP_TRY(hipGraphLaunch(exec, s));
-    else { const int r = adv_issue_group(fn, userKind, integrator, a, active, check_every, split, s); if (r) return r; }
-    HIP_TRY(hipMemcpyAsync(poll.h + (g & 1) * nnhip::kAggSlots, active, nnhip::kAggSlots * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipEventRecord(poll.ev[g & 1], s));
+    const int half = (int)(g & 1);
+    unsigned int* flags = poll.h + half * nnhip::kAggSlots;
+    std::memset(flags, 0, nnhip::kAggSlots * sizeof(unsigned int));  // host memory; the group that last wrote this half has been waited for
+    if (execs[half]) HIP_TRY(hipGraphLaunch(execs[half], s));
+    else { const int r = adv_issue_group(fn, userKind, integrator, a, flags, check_every, split, s); if (r) return r; }
+    HIP_TRY(hipEventRecord(poll.ev[half], s));
     return NNHIP_OK;
   };
   int64_t launches = 0, g = 0;
