@@ -357,6 +357,41 @@ int nnhip_ode_rhs_compile(const char* name, int dim, int n_params, const char* b
  * wavefront of lanes x 4 components per system; sizes that are not a power of two use the next one with the tail slots
  * switched off); the other sizes up to 16 run thread-per-IVP. */
 int nnhip_ode_rhs_compile_comp(const char* name, int dim, int n_params, const char* comp_body, int* rhs_kind_out);
+/* NumContext in full (src/numericalnim/common/commonTypes.nim:4-27; the ctx the solver passes through to f, ode.nim:36,498,506,521,
+ * 530,531, "IT IS MUTABLE", :599): a user right-hand side compiled with a CONTEXT LAYOUT.  Besides t, y, dy (or c) its body sees
+ *   p[k], k < n_params       ctx.fValues in key order — ANY count: up to 8 travel as kernel arguments (rhs_params of each call, as
+ *                            before); with more than 8 they are the first n_params doubles of the shared block and calls pass n_params = 0
+ *   NAME[j]                  a SHARED vector (a ctx.tValues entry every IVP of the batch uses: a forcing vector, a coefficient table),
+ *                            vec_lens[k] doubles, any length
+ *   NAME(j) or NAME[j]       a PER-IVP vector (vec_per_ivp[k] != 0): entry j of THIS IVP's own vector — the batch form of N reference
+ *                            calls that each had their own ctx (e.g. a 16 x 16 matrix per system: length 256)
+ *   aux(j), j < n_aux        per-IVP MUTABLE doubles the body may read and write (event counters, running maxima): the mutable-ctx
+ *                            analogue.  The device evaluates f exactly where ODESolver does for a 2-point tspan — FSAL = f(t0, y0)
+ *                            (:506), then the stages of every attempt in order (k1 = FSAL is not re-evaluated) — so a body that
+ *                            accumulates over its calls sees the reference's call sequence; with dense output (tspan.len > 2) the
+ *                            non-FSAL methods' extra evaluations (:521,530) are made lazily and the call COUNT differs.  Whole-vector
+ *                            bodies only (per_component bodies run once per lane of a system).
+ * per_component: 0 = body of `void rhs(t, y[dim], dy[dim], ...)` as nnhip_ode_rhs_compile, 1 = body returning dy_c as
+ * nnhip_ode_rhs_compile_comp.  Names must be C identifiers other than p, y, dy, t, c, aux, dim, size. */
+int nnhip_ode_rhs_compile_ctx(const char* name, int dim, int n_params, const char* body, int per_component, int n_vectors,
+                              const char* const* vec_names, const int64_t* vec_lens, const int* vec_per_ivp, int n_aux, int* rhs_kind_out);
+/* Binds device memory to the layout of `rhs_kind` (the closure capturing its ctx); every later call that takes this rhs_kind reads it,
+ * until the next bind.  The caller owns the memory and keeps it alive while such calls are in flight.
+ *   shared   [shared_len]: the n_params scalars (only when n_params > 8) followed by the shared vectors in declaration order
+ *   per_ivp  [per_ivp_rows][stride]: the per-IVP vectors in declaration order, row r of IVP i at per_ivp[r*stride + i]
+ *   aux      [n_aux][stride], updated in place
+ * shared_len / per_ivp_rows / n_aux must equal what the layout declares (NNHIP_EVALUE otherwise); stride = IVPs of the bound batch
+ * (calls may solve any N <= stride: IVP i of a call reads column i).  A binding belongs to one device's memory: the multi-GPU host
+ * entries refuse such right-hand sides (bind and solve per device).  Process-wide per rhs_kind: two host threads that need
+ * different bindings at the same time compile the source twice. */
+int nnhip_ode_rhs_bind_ctx_f64_dev(int rhs_kind, const double* shared, int64_t shared_len, const double* per_ivp, int64_t per_ivp_rows,
+                                   double* aux, int n_aux, int64_t stride);
+/* The same for hosts without device-memory management (the Nim shim): the three parts are HOST arrays, copied into device memory of
+ * `device` that the library owns until the next bind / nnhip_ode_rhs_release; aux_init [n_aux][stride] seeds the mutable slots and
+ * nnhip_ode_rhs_read_aux_f64 copies their current content back ([n_aux][stride], after synchronising the device). */
+int nnhip_ode_rhs_bind_ctx_f64(int rhs_kind, const double* shared, int64_t shared_len, const double* per_ivp, int64_t per_ivp_rows,
+                               const double* aux_init, int n_aux, int64_t stride, int device);
+int nnhip_ode_rhs_read_aux_f64(int rhs_kind, double* aux_out);
 int nnhip_ode_rhs_release(int rhs_kind);
 
 /* Device-resident reassembly (BASELINE.json config C5): one process, n_gpus devices, RCCL over xGMI.  shard[r] lives on

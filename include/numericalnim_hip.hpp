@@ -58,8 +58,14 @@ struct RhsSpec {
   nnhip_rhs_kind kind;
   std::vector<std::string> keys;
   std::map<std::string, double> defaults;
+  bool scalarsInBlock = false;  // a right-hand side with a context layout and more than 8 keys: its scalars lead the shared block (bindCtx)
   template <class T>
   std::vector<double> params(const NumContext<T>* ctx) const {
+    if (scalarsInBlock) return {};
+    return allParams(ctx);
+  }
+  template <class T>
+  std::vector<double> allParams(const NumContext<T>* ctx) const {
     std::vector<double> p;
     for (const auto& k : keys) {
       if (ctx) {
@@ -89,6 +95,36 @@ inline RhsSpec rhsFromSource(int dim, const std::string& body, std::vector<std::
   int kind = 0;
   throwOn(nnhip_ode_rhs_compile(name.c_str(), dim, (int)keys.size(), body.c_str(), &kind));
   return {static_cast<nnhip_rhs_kind>(kind), std::move(keys), std::move(defaults)};
+}
+
+// NumContext in full (commonTypes.nim:4-27; nnhip_ode_rhs_compile_ctx): a right-hand side from source whose body also reads named
+// ctx.tValues entries — NAME[j] of a vector the batch shares, NAME(j) of the IVP's own vector — any number of fValues (p[k]) and
+// per-IVP mutable slots aux(j) (the mutable ctx of ode.nim:599).
+struct CtxVector { std::string name; int64_t len; bool perIvp; };
+inline RhsSpec rhsFromSourceCtx(int dim, const std::string& body, std::vector<std::string> keys, const std::vector<CtxVector>& vectors, int nAux = 0,
+                                std::map<std::string, double> defaults = {}, const std::string& name = "user", bool perComponent = false) {
+  int kind = 0;
+  std::vector<const char*> names;
+  std::vector<int64_t> lens;
+  std::vector<int> per;
+  for (const auto& v : vectors) { names.push_back(v.name.c_str()); lens.push_back(v.len); per.push_back(v.perIvp ? 1 : 0); }
+  throwOn(nnhip_ode_rhs_compile_ctx(name.c_str(), dim, (int)keys.size(), body.c_str(), perComponent ? 1 : 0, (int)vectors.size(), names.data(), lens.data(),
+                                    per.data(), nAux, &kind));
+  RhsSpec r{static_cast<nnhip_rhs_kind>(kind), std::move(keys), std::move(defaults)};
+  r.scalarsInBlock = r.keys.size() > 8;
+  return r;
+}
+// The closure capturing its ctx: `shared` = the shared vectors concatenated in declaration order (after the scalars, when there are
+// more than 8 keys: pass f.allParams(&ctx) in front), perIvp [rows][N], auxInit [nAux][N] (host arrays, uploaded to `device`).
+inline void bindCtx(const RhsSpec& f, const std::vector<double>& shared, const std::vector<double>& perIvp, const std::vector<double>& auxInit, int nAux,
+                    int64_t N, int device = 0) {
+  throwOn(nnhip_ode_rhs_bind_ctx_f64(f.kind, shared.empty() ? nullptr : shared.data(), (int64_t)shared.size(), perIvp.empty() ? nullptr : perIvp.data(),
+                                     N > 0 ? (int64_t)perIvp.size() / N : 0, auxInit.empty() ? nullptr : auxInit.data(), nAux, N, device));
+}
+inline std::vector<double> readAux(const RhsSpec& f, int nAux, int64_t N) {
+  std::vector<double> a((size_t)nAux * (size_t)N);
+  throwOn(nnhip_ode_rhs_read_aux_f64(f.kind, a.data()));
+  return a;
 }
 
 // A batch of N initial states of `dim` float64 components (host memory).  dim == 1 is the reference's

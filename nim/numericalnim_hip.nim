@@ -34,6 +34,38 @@ proc rhsFromSource*(dim: int, body: string, keys: seq[string] = @[], name = "use
   if rc != 0: raise newException(ValueError, $nnhip_last_error())
   RhsSpec(kind: RhsKind(0), keys: keys, userKind: kind.int)
 
+type CtxVector* = object                  ## one ctx.tValues entry a right-hand side from source reads
+  name*: string
+  len*: int
+  perIvp*: bool                            ## false: NAME[j], shared by the batch; true: NAME(j), the IVP's own vector ([len][N])
+
+proc rhsFromSourceCtx*(dim: int, body: string, keys: seq[string], vectors: seq[CtxVector], nAux = 0, name = "user",
+                       perComponent = false): RhsSpec =
+  ## NumContext in full (commonTypes.nim:4-27, nnhip_ode_rhs_compile_ctx): the body also sees the named ctx.tValues entries, any number
+  ## of fValues (p[k]) and `aux(j)`, per-IVP doubles it may mutate (ode.nim:599).  Bind the values with `bindCtx` before solving.
+  var kind: cint
+  var names = allocCStringArray(block: (var n: seq[string]; (for v in vectors: n.add v.name); n))
+  var lens: seq[int64]
+  var per: seq[cint]
+  for v in vectors: (lens.add v.len.int64; per.add (if v.perIvp: 1 else: 0).cint)
+  let rc = nnhip_ode_rhs_compile_ctx(name.cstring, dim.cint, keys.len.cint, body.cstring, (if perComponent: 1 else: 0).cint, vectors.len.cint, names,
+                                     (if lens.len > 0: addr lens[0] else: nil), (if per.len > 0: addr per[0] else: nil), nAux.cint, addr kind)
+  deallocCStringArray(names)
+  if rc != 0: raise newException(ValueError, $nnhip_last_error())
+  RhsSpec(kind: RhsKind(0), keys: (if keys.len > 8: @[] else: keys), userKind: kind.int)   # more than 8 scalars lead the shared block
+
+proc bindCtx*(f: RhsSpec, shared, perIvp, auxInit: seq[float], nAux: int, n: int, device = 0) =
+  ## shared = [the scalars, when the right-hand side has more than 8][the shared vectors in declaration order]; perIvp [rows][n];
+  ## auxInit [nAux][n].  Host arrays; the backend keeps device copies until the next bindCtx / release.
+  var s = shared; var p = perIvp; var a = auxInit
+  let rc = nnhip_ode_rhs_bind_ctx_f64(f.userKind.cint, (if s.len > 0: addr s[0] else: nil), s.len.int64, (if p.len > 0: addr p[0] else: nil),
+                                      (if n > 0: p.len div n else: 0).int64, (if a.len > 0: addr a[0] else: nil), nAux.cint, n.int64, device.cint)
+  if rc != 0: raise newException(ValueError, $nnhip_last_error())
+
+proc readAux*(f: RhsSpec, nAux: int, n: int): seq[float] =
+  result = newSeq[float](nAux * n)
+  if result.len > 0 and nnhip_ode_rhs_read_aux_f64(f.userKind.cint, addr result[0]) != 0: raise newException(ValueError, $nnhip_last_error())
+
 proc toC(o: ODEoptions): NnhipOptions =
   NnhipOptions(dt: o.dt, dtMax: o.dtMax, dtMin: o.dtMin, tStart: o.tStart, absTol: o.absTol, relTol: o.relTol,
                scaleMax: o.scaleMax, scaleMin: o.scaleMin)
@@ -67,6 +99,8 @@ proc solveODE*(f: RhsSpec, y0: OdeBatch, tspan: openArray[float],
   var y0d = y0.data
   let pp = if params.len > 0: addr params[0] else: nil
   let rhsKind = (if f.userKind > 0: f.userKind else: f.kind.int).cint
+  if nGpus > 1 and (sortBy.len > 0 or autoSort):
+    raise newException(ValueError, "sortBy / autoSort order ONE device's batch: not available together with nGpus > 1")
   if nGpus > 1:                                                      # contiguous shards of the batch (and of the sweep table) per device
     var flat: seq[cdouble]
     for row in sweep:
@@ -118,7 +152,7 @@ proc solveODE*(f: RhsSpec, y0: OdeBatch, tEnd: openArray[float], options: openAr
   if integ < 0: raise newException(ValueError, &"{integrator} is not a valid integrator")
   var params: seq[cdouble]
   for k in f.keys: params.add(ctx.fValues[k].cdouble)
-  var base = options[0].toC
+  var base = (if options.len > 0: options[0] else: newODEoptions()).toC   # an empty batch may come with no options at all
   var each: seq[NnhipOptions]
   if options.len > 1:
     for o in options: each.add(o.toC)
@@ -154,7 +188,7 @@ proc solveODE*(f: RhsSpec, y0: OdeBatch, tspans: seq[seq[float]], options: openA
   if integ < 0: raise newException(ValueError, &"{integrator} is not a valid integrator")
   var params: seq[cdouble]
   for k in f.keys: params.add(ctx.fValues[k].cdouble)
-  var base = options[0].toC
+  var base = (if options.len > 0: options[0] else: newODEoptions()).toC   # an empty batch may come with no options at all
   var each: seq[NnhipOptions]
   if options.len > 1:
     for o in options: each.add(o.toC)

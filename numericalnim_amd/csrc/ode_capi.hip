@@ -150,7 +150,14 @@ int check_common(const nnhip_ode_options* opt, int integrator, int rhs_kind, con
   if (n_params < 0 || n_params > nnhip::kMaxParams) return fail(NNHIP_EVALUE, "n_params must be in [0, %d]", nnhip::kMaxParams);
   if (n_params > 0 && !rhs_params) return fail(NNHIP_EVALUE, "rhs_params is NULL");
   static const int need[NNHIP_N_RHS] = {0, 1, 3, 1, 2, 1};
-  const int needed = user ? userParams : need[rhs_kind];
+  int needed = user ? userParams : need[rhs_kind];
+  // the context block of a run-time compiled right-hand side (NumContext beyond eight scalars): bound device pointers travel in P
+  int inBlock = 0;
+  if (nnhip::rtc_ctx_fill(rhs_kind, N, P, &inBlock) < 0) return fail(NNHIP_EVALUE, "rhs_kind %d: %s", rhs_kind, nnhip::rtc_last_error());
+  if (inBlock > 0) {
+    if (n_params != 0) return fail(NNHIP_EVALUE, "rhs_kind %d keeps its %d scalars in its context block: pass n_params = 0", rhs_kind, inBlock);
+    needed = 0;
+  }
   if (n_params < needed) return fail(NNHIP_EVALUE, "rhs_kind %d needs %d parameters, got %d", rhs_kind, needed, n_params);
   for (int k = 0; k < nnhip::kMaxParams; ++k) P.p[k] = k < n_params ? rhs_params[k] : 0.0;
   return NNHIP_OK;
@@ -455,6 +462,51 @@ int nnhip_ode_rhs_compile_comp(const char* name, int dim, int n_params, const ch
   return NNHIP_OK;
 }
 
+// NumContext beyond eight scalars (commonTypes.nim:4-27, ode.nim:36,599).  See include/nnhip_ode.h.
+int nnhip_ode_rhs_compile_ctx(const char* name, int dim, int n_params, const char* body, int per_component, int n_vectors,
+                              const char* const* vec_names, const int64_t* vec_lens, const int* vec_per_ivp, int n_aux, int* rhs_kind_out) {
+  if (!body || !rhs_kind_out) return fail(NNHIP_EVALUE, "body / rhs_kind_out is NULL");
+  if (per_component ? (dim < 1 || dim > 256) : (dim < 1 || dim > 16)) return fail(NNHIP_EVALUE, "user RHS dim must be in [1, %d]", per_component ? 256 : 16);
+  if (n_params < 0 || n_params > (1 << 20)) return fail(NNHIP_EVALUE, "n_params must be in [0, 2^20]");
+  if (n_vectors < 0 || n_vectors > 64 || (n_vectors > 0 && (!vec_names || !vec_lens || !vec_per_ivp))) return fail(NNHIP_EVALUE, "bad vector declarations");
+  if (n_aux < 0 || n_aux > 1024) return fail(NNHIP_EVALUE, "n_aux must be in [0, 1024]");
+  if (n_aux > 0 && per_component) return fail(NNHIP_EVALUE, "per-component bodies run once per lane of a system: mutable slots (n_aux) need a whole-vector body");
+  static const char* reserved[] = {"p", "y", "dy", "t", "c", "aux", "dim", "size", "P_", "ys"};
+  for (int k = 0; k < n_vectors; ++k) {
+    const char* nm = vec_names[k];
+    if (!nm || !*nm || !(std::isalpha((unsigned char)nm[0]) || nm[0] == '_')) return fail(NNHIP_EVALUE, "vector %d: the name must be a C identifier", k);
+    for (const char* q = nm; *q; ++q) if (!(std::isalnum((unsigned char)*q) || *q == '_')) return fail(NNHIP_EVALUE, "vector %d: the name must be a C identifier", k);
+    for (const char* r : reserved) if (std::strcmp(nm, r) == 0) return fail(NNHIP_EVALUE, "vector name '%s' is reserved", nm);
+    for (int j = 0; j < k; ++j) if (std::strcmp(nm, vec_names[j]) == 0) return fail(NNHIP_EVALUE, "vector name '%s' is declared twice", nm);
+    if (vec_lens[k] < 1) return fail(NNHIP_EVALUE, "vector '%s': length must be >= 1", nm);
+  }
+  nnhip::RtcCtxLayout lay{n_vectors, vec_names, vec_lens, vec_per_ivp, n_aux};
+  const int k = nnhip::rtc_register(name, dim, n_params, body, per_component != 0, true, &lay);
+  if (k < 0) return fail(NNHIP_EVALUE, "%s", nnhip::rtc_last_error());
+  *rhs_kind_out = k;
+  return NNHIP_OK;
+}
+
+int nnhip_ode_rhs_bind_ctx_f64_dev(int rhs_kind, const double* shared, int64_t shared_len, const double* per_ivp, int64_t per_ivp_rows,
+                                   double* aux, int n_aux, int64_t stride) {
+  if (nnhip::rtc_bind_ctx(rhs_kind, shared, shared_len, per_ivp, per_ivp_rows, aux, n_aux, stride) != 0)
+    return fail(NNHIP_EVALUE, "rhs_kind %d: %s", rhs_kind, nnhip::rtc_last_error());
+  nnhip::rtc_drop_owned_ctx(rhs_kind);
+  return NNHIP_OK;
+}
+
+int nnhip_ode_rhs_bind_ctx_f64(int rhs_kind, const double* shared, int64_t shared_len, const double* per_ivp, int64_t per_ivp_rows,
+                               const double* aux_init, int n_aux, int64_t stride, int device) {
+  if (nnhip::rtc_bind_ctx_host(rhs_kind, shared, shared_len, per_ivp, per_ivp_rows, aux_init, n_aux, stride, device) != 0)
+    return fail(NNHIP_EVALUE, "rhs_kind %d: %s", rhs_kind, nnhip::rtc_last_error());
+  return NNHIP_OK;
+}
+
+int nnhip_ode_rhs_read_aux_f64(int rhs_kind, double* aux_out) {
+  if (nnhip::rtc_read_aux(rhs_kind, aux_out) != 0) return fail(NNHIP_EVALUE, "rhs_kind %d: %s", rhs_kind, nnhip::rtc_last_error());
+  return NNHIP_OK;
+}
+
 int nnhip_ode_rhs_release(int rhs_kind) {
   return nnhip::rtc_release(rhs_kind) == 0 ? NNHIP_OK : fail(NNHIP_EVALUE, "unknown user rhs_kind %d", rhs_kind);
 }
@@ -596,6 +648,8 @@ static int launch_solve_range(const PreparedSolve& ps, int64_t lo, int64_t n, hi
     if (a.rejected_out) a.rejected_out += lo;
     if (a.progress_out) a.progress_out += lo;
     if (a.perIvpParams) a.perIvpParams += lo;
+    if (a.P.ivp) a.P.ivp += lo;
+    if (a.P.aux) a.P.aux += lo;
   }
   a.N = n;
   if (ps.user) {
@@ -1501,6 +1555,8 @@ nnhip::StepArgs adv_range(const nnhip::StepArgs& full, int64_t lo, int64_t n) {
   if (a.error) a.error += lo;
   if (a.steps_io) a.steps_io += lo;
   if (a.perIvpParams) a.perIvpParams += lo;
+  if (a.P.ivp) a.P.ivp += lo;
+  if (a.P.aux) a.P.aux += lo;
   return a;
 }
 
@@ -1565,6 +1621,10 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
   double* dtArr = tArr + N;
   double* errArr = dtArr + N;
   // FSAL = f(t0, y) (:506); t = t0; dt = sqrt(dtMax*dtMin) (:491-493)
+  if (nnhip::rtc_has_aux(rhs_kind)) {  // lastIter.dy = f(t0, y, ctx) (:498): the first of the reference's two evaluations at t0, observable through aux
+    rc = nnhip_ode_rhs_batch_f64_dev(rhs_kind, rhs_params, n_params, N, dim, layout, t0, y, fsal, stream);
+    if (rc) return fail(rc, "initial RHS evaluation failed");
+  }
   rc = nnhip_ode_rhs_batch_f64_dev(rhs_kind, rhs_params, n_params, N, dim, layout, t0, y, fsal, stream);
   if (rc) return fail(rc, "initial RHS evaluation failed");
   HIP_TRY(nnhip::launch_kernel(nnhip::fill_t_dt_kernel<0>, dim3((unsigned)((N + nnhip::kBlock - 1) / nnhip::kBlock)), dim3(nnhip::kBlock), s, tArr,

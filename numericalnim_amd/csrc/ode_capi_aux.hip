@@ -338,6 +338,7 @@ int nnhip_ode_rhs_batch_f64_dev(int rhs_kind, const double* rhs_params, int n_pa
   if (N == 0) return NNHIP_OK;
   nnhip::Params P;
   for (int k = 0; k < nnhip::kMaxParams; ++k) P.p[k] = k < n_params ? rhs_params[k] : 0.0;
+  if (nnhip::rtc_ctx_fill(rhs_kind, N, P, nullptr) < 0) return nnhip::fail_msg(NNHIP_EVALUE, "rhs_batch: rhs_kind %d: %s", rhs_kind, nnhip::rtc_last_error());
   const int64_t is = layout == NNHIP_LAYOUT_SOA ? 1 : dim, cs = layout == NNHIP_LAYOUT_SOA ? N : 1;
   if (rhs_kind >= NNHIP_RHS_USER_BASE) {
     int d = 0;
@@ -386,6 +387,8 @@ int nnhip_ode_solve_batch_multi_gpu_sweep_f64(const nnhip_ode_options* opt, int 
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return nnhip::fail_msg(NNHIP_EHIP, "no HIP device available (this library has no CPU fallback)");
   if (n_gpus <= 0 || (n_gpus > ndev && !nnhip::multi_gpu_oversubscribe()) || n_gpus > 64)
     return nnhip::fail_msg(NNHIP_EVALUE, "n_gpus = %d, but this node has %d HIP device(s)", n_gpus, ndev);
+  if (n_gpus > 1 && nnhip::rtc_has_per_ivp_ctx(rhs_kind))
+    return nnhip::fail_msg(NNHIP_EUNSUPPORTED, "rhs_kind %d reads a context block bound to ONE device's memory: bind and solve per device", rhs_kind);
   if (N < 0 || dim < 1 || n_t < 0 || !opt || (n_t > 0 && !tspan)) return nnhip::fail_msg(NNHIP_EVALUE, "bad sizes / NULL options or tspan");
   // The output time grid depends on (options, tspan) only: assembled once, on the calling thread (ode.nim:476-487, 585) — also
   // when some (or all) shards are empty.

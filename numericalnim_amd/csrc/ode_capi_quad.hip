@@ -180,6 +180,7 @@ int cumquad_fn(int rule, int rhs_kind, const double* rhs_params, int n_params, c
   a.compStride = layout == NNHIP_LAYOUT_SOA ? N : 1;
   a.rowStride = N * dim;
   for (int k = 0; k < kMaxParams; ++k) a.P.p[k] = k < n_params ? rhs_params[k] : 0.0;
+  if (rtc_ctx_fill(rhs_kind, N, a.P, nullptr) < 0) return fail_msg(NNHIP_EVALUE, "%s(f, X): rhs_kind %d: %s", what, rhs_kind, rtc_last_error());
   a.perIvpParams = n_per_item > 0 ? per_item_params : nullptr;
   a.nPerIvp = n_per_item;
   a.perIvpStride = N;

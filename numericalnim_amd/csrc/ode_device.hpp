@@ -33,9 +33,15 @@
 #endif
 
 namespace nnhip_abi {
-constexpr int kMaxParams = 8;
+constexpr int kMaxParams = 8;  // scalars that travel as kernel arguments (SGPRs); a run-time compiled right-hand side may declare more
 struct Params {
   double p[kMaxParams];
+  // NumContext beyond eight scalars (commonTypes.nim:4-27; run-time compiled right-hand sides, nnhip_ode_rhs_compile_ctx).  Device
+  // pointers, all nullable; the compiled-in right-hand sides never look at them.
+  const double* shared;  // [the scalars, when there are more than kMaxParams][shared vectors, concatenated]   (ctx.fValues / ctx.tValues)
+  const double* ivp;     // per-IVP vectors [rows][stride]; inside a kernel already advanced to the IVP: entry j = ivp[j * stride]
+  double* aux;           // per-IVP mutable slots [n_aux][stride] ("IT IS MUTABLE", ode.nim:599), advanced like ivp
+  long long stride;      // IVPs of the bound batch
 };
 struct StepCtl {  // the option fields the steppers read (ode.nim:283-286)
   double absTol, relTol, dtMax, dtMin;
@@ -787,6 +793,10 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
   [[maybe_unused]] double lastT = in.tStartEff;
 #pragma unroll
   for (int c = 0; c < D; ++c) y[c] = y0[c];
+  // The reference evaluates f(t0, y, ctx) twice before the forward loop — lastIter.dy (:498) and FSAL (:506) — and g(-t0, y0) once before
+  // the backward one (:546).  Same value; the repetition only matters to a right-hand side that mutates its ctx (aux slots), and is
+  // removed by the compiler for every other one.
+  if constexpr (!NEG) ops.rhs(t, y, fsal);
   ops.rhs(t, y, fsal);  // FSAL = f(t0, y) (:506) / g(-t0, y0) (:546)
   if constexpr (DENSE) {
 #pragma unroll

@@ -155,6 +155,8 @@ NNHIP_DEV Params params_of(const Args& a, int64_t i) {
     for (int k = 0; k < kMaxParams; ++k)
       if (k < a.nPerIvp) P.p[k] = a.perIvpParams[(int64_t)k * a.perIvpStride + i];
   }
+  if (P.ivp) P.ivp += i;  // the context block of a run-time compiled right-hand side: this IVP's column
+  if (P.aux) P.aux += i;
   return P;
 }
 
@@ -235,6 +237,11 @@ NNHIP_DEV void solve_body(const SolveArgs& a0, const OpsF& opsF, const OpsB& ops
   double y0[D];
 #pragma unroll
   for (int c = 0; c < D; ++c) y0[c] = opsF.owns(c) ? y0p[c * a.compStride] : 0.0;
+  if (a.nPos == 0) {  // ode.nim:498,506 run whether or not a forward branch follows (visible only to a right-hand side that mutates its ctx)
+    double tmp[D];
+    opsF.rhs(a.t0, y0, tmp);
+    opsF.rhs(a.t0, y0, tmp);
+  }
   int rowBase = 0;
   int status = 0;
   DriveIn in;
@@ -1407,7 +1414,10 @@ __global__ __launch_bounds__(kBlock) void rhs_batch_kernel(int64_t N, int64_t iv
   double yv[D], d[D];
 #pragma unroll
   for (int c = 0; c < D; ++c) yv[c] = c < SIZE ? y[i * ivpStride + c * compStride] : 0.0;
-  RHS::eval(t, yv, d, P);
+  Params Pi = P;
+  if (Pi.ivp) Pi.ivp += i;
+  if (Pi.aux) Pi.aux += i;
+  RHS::eval(t, yv, d, Pi);
 #pragma unroll
   for (int c = 0; c < SIZE; ++c) dy[i * ivpStride + c * compStride] = d[c];
 }

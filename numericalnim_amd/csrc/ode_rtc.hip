@@ -54,11 +54,25 @@ struct CodeObject {  // compiled once per (rhs, integrator); hipModuleLoadData b
   int ivpsPerBlockSolve = kBlock, ivpsPerBlockStep = kBlock, ivpsPerBlockAdvance = kBlock;
   std::map<int, std::shared_ptr<Program>> loaded;  // by device ordinal
 };
+struct CtxVec { std::string name; int64_t len = 0; bool perIvp = false; int64_t offset = 0; };  // offset: doubles into the shared block / row of the per-IVP block
 struct UserRhsEntry {
   std::string name, body;
   int dim = 0, n_params = 0;
   bool perComponent = false;  // body computes ONE component (usable by the lanes-per-system kernels) instead of the whole vector
   bool alive = false;
+  // context layout (nnhip_ode_rhs_compile_ctx): NumContext beyond eight scalars
+  bool hasCtx = false;
+  std::vector<CtxVec> vecs;
+  int n_aux = 0;
+  int64_t sharedLen = 0, ivpRows = 0;  // doubles of the shared block (scalars beyond kMaxParams included) / rows of the per-IVP block
+  // what is bound to the layout right now (nnhip_ode_rhs_bind_ctx_f64_dev): device pointers, the caller keeps them alive
+  const double* boundShared = nullptr;
+  const double* boundIvp = nullptr;
+  double* boundAux = nullptr;
+  int64_t boundStride = 0;
+  // device copies the library made itself for a host that has no device-memory management (nnhip_ode_rhs_bind_ctx_f64); freed at the next bind / release
+  int ownedDevice = -1;
+  void* owned[3] = {nullptr, nullptr, nullptr};
   std::map<int, CodeObject> programs;  // by integrator; key -1 = the rhs_batch kernel only, key -2 = the cumulative-quadrature kernels,
                                        // 1000 + integrator = the dense-output adaptive streaming kernel
 };
@@ -86,21 +100,40 @@ int padded_dim(const UserRhsEntry& e) {
 int lps_cpl(const UserRhsEntry& e, bool adaptive) { return padded_dim(e) == 8 ? 2 : (padded_dim(e) >= 64 ? 4 : (adaptive ? 4 : 2)); }
 int lps_step_cpl(const UserRhsEntry& e) { return padded_dim(e) <= 64 ? 1 : padded_dim(e) / 64; }
 
+// what a body sees of its context: `p` (scalars, wherever they live), one name per declared vector, `aux`
+std::string ctx_preamble(const UserRhsEntry& e) {
+  std::string s;
+  if (e.hasCtx && e.n_params > kMaxParams) s += "    const double* p = P_.shared; (void)p;\n";
+  else s += "    const double* p = P_.p; (void)p;\n";
+  if (!e.hasCtx) return s;
+  for (const CtxVec& v : e.vecs) {
+    if (v.perIvp) s += "    const nnhip_ctx::IvpVec " + v.name + "{P_.ivp + " + std::to_string(v.offset) + "LL * P_.stride, P_.stride}; (void)" + v.name + ";\n";
+    else s += "    const double* " + v.name + " = P_.shared + " + std::to_string(v.offset) + "; (void)" + v.name + ";\n";
+  }
+  if (e.n_aux > 0) s += "    const nnhip_ctx::AuxRef aux{P_.aux, P_.stride}; (void)aux;\n";
+  return s;
+}
+
 std::string make_source(const UserRhsEntry& e) {
   std::string s;
   s += "#include \"ode_kernels.hpp\"\n#include \"quad_kernels.hpp\"\n";
+  s += "namespace nnhip_ctx {\n"
+       "struct IvpVec { const double* b; long long s; __device__ __forceinline__ double operator()(long long j) const { return b[j * s]; }\n"
+       "                __device__ __forceinline__ double operator[](long long j) const { return b[j * s]; } };\n"
+       "struct AuxRef { double* b; long long s; __device__ __forceinline__ double& operator()(long long j) const { return b[j * s]; }\n"
+       "                __device__ __forceinline__ double& operator[](long long j) const { return b[j * s]; } };\n}\n";
   s += "namespace nnhip {\nstruct UserRhs {\n  static constexpr int dim = " + std::to_string(padded_dim(e)) + ";\n";
   s += "  static constexpr int size = " + std::to_string(e.dim) + ";\n";
   if (!e.perComponent) {
     s += "  NNHIP_DEV static void eval(double t, const double (&y)[dim], double (&dy)[dim], const Params& P_) {\n";
-    s += "    const double* p = P_.p; (void)p; (void)t;\n";
+    s += ctx_preamble(e) + "    (void)t;\n";
     s += "    {\n" + e.body + "\n    }\n  }\n";
     s += "  NNHIP_DEV static double comp(double t, int c, const double* ys, const Params& P_) {\n";
     s += "    double y[dim], dy[dim];\n    for (int k = 0; k < dim; ++k) y[k] = ys[k];\n    eval(t, y, dy, P_);\n";
     s += "    double r = dy[0];\n    for (int k = 1; k < dim; ++k) if (c == k) r = dy[k];\n    return r;\n  }\n};\n}\n";
   } else {
     s += "  NNHIP_DEV static double comp(double t, int c, const double* y, const Params& P_) {\n";
-    s += "    const double* p = P_.p; (void)p; (void)t; (void)c;\n";
+    s += ctx_preamble(e) + "    (void)t; (void)c;\n";
     s += "    if (c >= size) return 0.0;\n";
     s += "    constexpr int dim = size; (void)dim;  // inside the body `dim` is the real number of components\n";
     s += "    {\n" + e.body + "\n    }\n  }\n";
@@ -249,6 +282,8 @@ std::shared_ptr<Program> get_program(int rhs_kind, int integrator) {
     } else {
       snapshot.name = g_user[idx].name; snapshot.body = g_user[idx].body; snapshot.dim = g_user[idx].dim;
       snapshot.n_params = g_user[idx].n_params; snapshot.perComponent = g_user[idx].perComponent; snapshot.alive = true;
+      snapshot.hasCtx = g_user[idx].hasCtx; snapshot.vecs = g_user[idx].vecs; snapshot.n_aux = g_user[idx].n_aux;
+      snapshot.sharedLen = g_user[idx].sharedLen; snapshot.ivpRows = g_user[idx].ivpRows;
     }
   }
   CodeObject fresh;
@@ -275,9 +310,11 @@ std::shared_ptr<Program> get_program(int rhs_kind, int integrator) {
 
 }  // namespace
 
+static void free_owned(UserRhsEntry& e);
+
 const char* rtc_last_error() { return g_rtc_err.c_str(); }
 
-int rtc_register(const char* name, int dim, int n_params, const char* body, bool per_component, bool check_compiles) {
+int rtc_register(const char* name, int dim, int n_params, const char* body, bool per_component, bool check_compiles, const RtcCtxLayout* ctx) {
   UserRhsEntry e;
   e.name = name ? name : "user";
   e.body = body;
@@ -285,6 +322,20 @@ int rtc_register(const char* name, int dim, int n_params, const char* body, bool
   e.n_params = n_params;
   e.perComponent = per_component;
   e.alive = true;
+  if (ctx) {
+    e.hasCtx = true;
+    e.n_aux = ctx->n_aux;
+    e.sharedLen = n_params > kMaxParams ? n_params : 0;  // scalars that do not fit the kernel arguments lead the shared block
+    for (int k = 0; k < ctx->n_vectors; ++k) {
+      CtxVec v;
+      v.name = ctx->names[k];
+      v.len = ctx->lens[k];
+      v.perIvp = ctx->per_ivp[k] != 0;
+      if (v.perIvp) { v.offset = e.ivpRows; e.ivpRows += v.len; }
+      else { v.offset = e.sharedLen; e.sharedLen += v.len; }
+      e.vecs.push_back(v);
+    }
+  }
   if (check_compiles) {  // syntax check now (device-independent), so errors surface at registration
     const std::string src = make_source(e) + "\n";
     hiprtcProgram prog;
@@ -317,6 +368,8 @@ int rtc_release(int rhs_kind) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (idx < 0 || idx >= (int)g_user.size() || !g_user[idx].alive) return -1;
   g_user[idx].programs.clear();  // drops the registry's references; a module is unloaded when its last launch in flight lets go (~Program)
+  free_owned(g_user[idx]);
+  g_user[idx].boundShared = nullptr; g_user[idx].boundIvp = nullptr; g_user[idx].boundAux = nullptr;
   g_user[idx].alive = false;
   return 0;
 }
@@ -334,6 +387,122 @@ bool rtc_info(int rhs_kind, int* dim, int* n_params) {
   if (dim) *dim = g_user[idx].dim;
   if (n_params) *n_params = g_user[idx].n_params;
   return true;
+}
+
+static void free_owned(UserRhsEntry& e) {  // caller holds g_mu
+  if (e.ownedDevice < 0) return;
+  int prev = 0;
+  const bool have = hipGetDevice(&prev) == hipSuccess;
+  (void)hipSetDevice(e.ownedDevice);
+  (void)hipDeviceSynchronize();  // launches reading the block may still be queued
+  for (void*& q : e.owned) { if (q) (void)hipFree(q); q = nullptr; }
+  if (have) (void)hipSetDevice(prev);
+  e.ownedDevice = -1;
+}
+
+int rtc_bind_ctx_host(int rhs_kind, const double* shared, int64_t shared_len, const double* per_ivp, int64_t per_ivp_rows, const double* aux_init, int n_aux,
+                      int64_t stride, int device) {
+  const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
+  int prev = 0;
+  if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device) != hipSuccess) { g_rtc_err = "bad device ordinal"; return -1; }
+  void* d[3] = {nullptr, nullptr, nullptr};
+  const size_t bytes[3] = {(size_t)shared_len * 8, (size_t)per_ivp_rows * (size_t)stride * 8, (size_t)n_aux * (size_t)stride * 8};
+  const void* src[3] = {shared, per_ivp, aux_init};
+  bool ok = true;
+  for (int k = 0; k < 3 && ok; ++k) {
+    if (!bytes[k]) continue;
+    ok = src[k] != nullptr && hipMalloc(&d[k], bytes[k]) == hipSuccess && hipMemcpy(d[k], src[k], bytes[k], hipMemcpyHostToDevice) == hipSuccess;
+  }
+  int rc = -1;
+  if (ok) rc = rtc_bind_ctx(rhs_kind, (const double*)d[0], shared_len, (const double*)d[1], per_ivp_rows, (double*)d[2], n_aux, stride);
+  else g_rtc_err = "context block: a declared part is NULL or the device allocation failed";
+  if (rc == 0) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    UserRhsEntry& e = g_user[idx];
+    free_owned(e);
+    (void)hipSetDevice(device);
+    e.ownedDevice = device;
+    for (int k = 0; k < 3; ++k) e.owned[k] = d[k];
+  } else {
+    for (void* q : d) if (q) (void)hipFree(q);
+  }
+  (void)hipSetDevice(prev);
+  return rc;
+}
+
+int rtc_read_aux(int rhs_kind, double* aux_out) {
+  const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
+  const double* src = nullptr;
+  size_t bytes = 0;
+  int device = -1;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (idx < 0 || idx >= (int)g_user.size() || !g_user[idx].alive || !g_user[idx].hasCtx || g_user[idx].n_aux == 0 || !g_user[idx].boundAux) {
+      g_rtc_err = "no mutable slots bound to this rhs_kind";
+      return -1;
+    }
+    src = g_user[idx].boundAux; bytes = (size_t)g_user[idx].n_aux * (size_t)g_user[idx].boundStride * 8; device = g_user[idx].ownedDevice;
+  }
+  if (!aux_out) { g_rtc_err = "aux_out is NULL"; return -1; }
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  if (device >= 0) (void)hipSetDevice(device);
+  const bool ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(aux_out, src, bytes, hipMemcpyDeviceToHost) == hipSuccess;
+  (void)hipSetDevice(prev);
+  if (!ok) { g_rtc_err = "copying the mutable slots back failed"; return -1; }
+  return 0;
+}
+
+int rtc_bind_ctx(int rhs_kind, const double* shared, int64_t shared_len, const double* per_ivp, int64_t per_ivp_rows, double* aux, int n_aux, int64_t stride) {
+  const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (idx < 0 || idx >= (int)g_user.size() || !g_user[idx].alive) { g_rtc_err = "unknown user rhs_kind"; return -1; }
+  UserRhsEntry& e = g_user[idx];
+  if (!e.hasCtx) { g_rtc_err = "this right-hand side was compiled without a context layout (nnhip_ode_rhs_compile_ctx)"; return -1; }
+  if (shared_len != e.sharedLen || per_ivp_rows != e.ivpRows || n_aux != e.n_aux) {
+    g_rtc_err = "context block does not match the compiled layout: shared " + std::to_string(e.sharedLen) + " doubles, per-IVP " + std::to_string(e.ivpRows) +
+                " rows, " + std::to_string(e.n_aux) + " aux slots";
+    return -1;
+  }
+  if ((e.sharedLen > 0 && !shared) || (e.ivpRows > 0 && !per_ivp) || (e.n_aux > 0 && !aux) || ((e.ivpRows > 0 || e.n_aux > 0) && stride < 1)) {
+    g_rtc_err = "context block: a declared part is NULL (or the stride is not positive)";
+    return -1;
+  }
+  e.boundShared = shared; e.boundIvp = per_ivp; e.boundAux = aux; e.boundStride = stride;
+  return 0;
+}
+void rtc_drop_owned_ctx(int rhs_kind) {  // a binding to the caller's own device memory replaces one the library had uploaded itself
+  const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (idx >= 0 && idx < (int)g_user.size()) free_owned(g_user[idx]);
+}
+
+// 0: no context layout (P untouched apart from zeroed pointers); 1: filled; -1: declared but not bound / N beyond the bound batch
+int rtc_ctx_fill(int rhs_kind, int64_t N, Params& P, int* n_scalars_in_block) {
+  P.shared = nullptr; P.ivp = nullptr; P.aux = nullptr; P.stride = 0;
+  if (n_scalars_in_block) *n_scalars_in_block = 0;
+  const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
+  if (idx < 0) return 0;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (idx >= (int)g_user.size() || !g_user[idx].alive) return 0;
+  const UserRhsEntry& e = g_user[idx];
+  if (!e.hasCtx) return 0;
+  const bool needsBlock = e.sharedLen > 0 || e.ivpRows > 0 || e.n_aux > 0;
+  if (needsBlock && !e.boundShared && !e.boundIvp && !e.boundAux) { g_rtc_err = "the right-hand side declares a context block but none is bound (nnhip_ode_rhs_bind_ctx_f64_dev)"; return -1; }
+  if ((e.ivpRows > 0 || e.n_aux > 0) && N > e.boundStride) { g_rtc_err = "N exceeds the batch the context block was bound for"; return -1; }
+  P.shared = e.boundShared; P.ivp = e.boundIvp; P.aux = e.boundAux; P.stride = e.boundStride;
+  if (n_scalars_in_block) *n_scalars_in_block = e.n_params > kMaxParams ? e.n_params : 0;
+  return 1;
+}
+bool rtc_has_aux(int rhs_kind) {
+  const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
+  std::lock_guard<std::mutex> lk(g_mu);
+  return idx >= 0 && idx < (int)g_user.size() && g_user[idx].alive && g_user[idx].hasCtx && g_user[idx].n_aux > 0;
+}
+bool rtc_has_per_ivp_ctx(int rhs_kind) {
+  const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
+  std::lock_guard<std::mutex> lk(g_mu);
+  return idx >= 0 && idx < (int)g_user.size() && g_user[idx].alive && g_user[idx].hasCtx && (g_user[idx].ivpRows > 0 || g_user[idx].n_aux > 0 || g_user[idx].sharedLen > 0);
 }
 
 static hipError_t launch(hipFunction_t f, int64_t n, int perBlock, void* arg, hipStream_t s) {

@@ -5,7 +5,24 @@
 
 namespace nnhip {
 const char* rtc_last_error();
-int rtc_register(const char* name, int dim, int n_params, const char* body, bool per_component, bool check_compiles);  // -> rhs_kind or -1
+// context layout of a user right-hand side (NumContext beyond eight scalars): named vectors, shared by the batch or one per IVP, and
+// per-IVP mutable slots
+struct RtcCtxLayout {
+  int n_vectors;
+  const char* const* names;
+  const int64_t* lens;
+  const int* per_ivp;
+  int n_aux;
+};
+int rtc_register(const char* name, int dim, int n_params, const char* body, bool per_component, bool check_compiles, const RtcCtxLayout* ctx = nullptr);  // -> rhs_kind or -1
+int rtc_bind_ctx(int rhs_kind, const double* shared, int64_t shared_len, const double* per_ivp, int64_t per_ivp_rows, double* aux, int n_aux, int64_t stride);
+int rtc_ctx_fill(int rhs_kind, int64_t N, Params& P, int* n_scalars_in_block);
+int rtc_bind_ctx_host(int rhs_kind, const double* shared, int64_t shared_len, const double* per_ivp, int64_t per_ivp_rows, const double* aux_init, int n_aux,
+                      int64_t stride, int device);  // uploads into device memory the library owns
+int rtc_read_aux(int rhs_kind, double* aux_out);
+void rtc_drop_owned_ctx(int rhs_kind);
+bool rtc_has_per_ivp_ctx(int rhs_kind);
+bool rtc_has_aux(int rhs_kind);  // the right-hand side mutates per-IVP slots: the number and order of its evaluations are observable
 int rtc_release(int rhs_kind);
 bool rtc_info(int rhs_kind, int* dim, int* n_params);
 hipError_t rtc_launch_solve(int rhs_kind, int integrator, const SolveArgs& a, hipStream_t s);

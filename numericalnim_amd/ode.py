@@ -108,6 +108,8 @@ class Rhs:
         self.defaults = dict(defaults or {})
 
     def params(self, ctx):
+        if len(self.keys) > 8 and getattr(self, "ctx_layout", None) is not None:
+            return []  # more scalars than travel as kernel arguments: they lead the shared block of the context (bind)
         out = []
         for k in self.keys:
             if ctx is not None and k in ctx.fValues:
@@ -119,24 +121,117 @@ class Rhs:
         return out
 
     @staticmethod
-    def custom(dim, body, keys=(), defaults=None, name="user", per_component=False):
+    def custom(dim, body, keys=(), defaults=None, name="user", per_component=False, tvalues=None, per_ivp=(), n_aux=0, aux_key="aux"):
         """A user right-hand side from HIP C++ source (compiled at run time with hiprtc; include/nnhip_ode.h,
         nnhip_ode_rhs_compile).  `body` sees t, y[dim], dy[dim] and p[len(keys)] — e.g. for a damped oscillator
         Rhs.custom(2, "dy[0] = y[1]; dy[1] = -p[0]*y[0] - p[1]*y[1];", keys=("k", "c")).
         per_component=True: `body` returns dy_c for the component index `c` (nnhip_ode_rhs_compile_comp); systems of
-        8 / 16 / 32 components then run on the lanes-per-system (LDS-staged) kernels."""
-        key = (int(dim), body, len(keys), bool(per_component))
+        8 / 16 / 32 components then run on the lanes-per-system (LDS-staged) kernels.
+
+        NumContext in full (commonTypes.nim:4-27; nnhip_ode_rhs_compile_ctx) — any of the following makes it a right-hand side with
+        a context layout, bound to the `ctx` given to solveODE & co. at every call:
+          keys       more than 8 of them (ctx.fValues, any count): p[k] as before
+          tvalues    mapping NAME -> length: the ctx.tValues entries the body reads, as NAME[j]; names in `per_ivp` are per-IVP
+                     vectors (ctx.tValues[NAME] is a [length, N] array / CUDA tensor: column i belongs to IVP i, the batch form of N
+                     reference calls with their own ctx), the others are shared by the batch (1-D, `length` entries)
+          n_aux      per-IVP mutable doubles aux(j) the body may read and write (the mutable ctx of ode.nim:599); they live in
+                     ctx.tValues[aux_key], a [n_aux, N] float64 CUDA tensor updated in place"""
+        tvalues = dict(tvalues or {})
+        per_ivp = tuple(per_ivp)
+        has_ctx = bool(tvalues) or n_aux > 0 or len(keys) > 8
+        for nm in per_ivp:
+            if nm not in tvalues:
+                raise ValueError(f"per_ivp names '{nm}', which tvalues does not declare")
+        key = (int(dim), body, len(keys), bool(per_component), tuple(tvalues.items()), per_ivp, int(n_aux))
         k = Rhs._compiled.get(key)  # the same source is registered (and compiled) once per process
         if k is not None and not _lib.lib().nnhip_ode_supported(0, k, int(dim), LAYOUT_SOA, 0):
             k = None  # released in the meantime (nnhip_ode_rhs_release)
         if k is None:
             kind = C.c_int(0)
-            fn = _lib.lib().nnhip_ode_rhs_compile_comp if per_component else _lib.lib().nnhip_ode_rhs_compile
-            _check(fn(str(name).encode(), int(dim), len(keys), body.encode(), C.byref(kind)))
+            if has_ctx:
+                names = list(tvalues.keys())
+                nv = len(names)
+                c_names = (C.c_char_p * max(nv, 1))(*[n.encode() for n in names])
+                c_lens = (C.c_int64 * max(nv, 1))(*[int(tvalues[n]) for n in names])
+                c_per = (C.c_int * max(nv, 1))(*[1 if n in per_ivp else 0 for n in names])
+                _check(_lib.lib().nnhip_ode_rhs_compile_ctx(str(name).encode(), int(dim), len(keys), body.encode(), 1 if per_component else 0, nv,
+                                                            c_names, c_lens, c_per, int(n_aux), C.byref(kind)))
+            else:
+                fn = _lib.lib().nnhip_ode_rhs_compile_comp if per_component else _lib.lib().nnhip_ode_rhs_compile
+                _check(fn(str(name).encode(), int(dim), len(keys), body.encode(), C.byref(kind)))
             k = Rhs._compiled[key] = kind.value
         r = Rhs(k, keys, defaults)
         r.dim = int(dim)
+        if has_ctx:
+            r.ctx_layout = dict(tvalues=tvalues, per_ivp=per_ivp, n_aux=int(n_aux), aux_key=aux_key)
         return r
+
+    def bind(self, ctx):
+        """Binds `ctx` to this right-hand side's context layout (nnhip_ode_rhs_bind_ctx_f64_dev): the closure capturing its ctx.
+        Called by solveODE & co. with the ctx they are given; arrays are uploaded, CUDA tensors are used in place."""
+        lay = getattr(self, "ctx_layout", None)
+        if lay is None:
+            return
+        import torch
+        if ctx is None:
+            raise ValueError("this right-hand side reads a context block: pass ctx")
+        tv = ctx.tValues
+        dev = None
+        for v in tv.values():
+            if _is_torch(v) and v.is_cuda:
+                dev = v.device
+                break
+        dev = dev or torch.device("cuda", torch.cuda.current_device())
+
+        def to_dev(v):
+            if _is_torch(v):
+                return v.to(device=dev, dtype=torch.float64).contiguous()
+            return torch.from_numpy(np.ascontiguousarray(np.asarray(v, dtype=np.float64))).to(dev)
+
+        shared_parts, ivp_parts, stride = [], [], 0
+        if len(self.keys) > 8:
+            shared_parts.append(to_dev(np.asarray(Rhs.params_all(self, ctx), dtype=np.float64)))
+        for nm, ln in lay["tvalues"].items():
+            if nm not in tv:
+                raise KeyError(f"ctx.tValues has no '{nm}' for this RHS")
+            t = to_dev(tv[nm])
+            if nm in lay["per_ivp"]:
+                if t.dim() != 2 or t.shape[0] != ln:
+                    raise ValueError(f"ctx.tValues['{nm}'] must be [{ln}, N]")
+                if stride and t.shape[1] != stride:
+                    raise ValueError("per-IVP vectors of one ctx must agree in N")
+                stride = int(t.shape[1])
+                ivp_parts.append(t)
+            else:
+                if t.numel() != ln:
+                    raise ValueError(f"ctx.tValues['{nm}'] must have {ln} entries")
+                shared_parts.append(t.reshape(-1))
+        aux = None
+        if lay["n_aux"] > 0:
+            aux = tv.get(lay["aux_key"])
+            if aux is None or not _is_torch(aux) or not aux.is_cuda or aux.dtype != torch.float64 or not aux.is_contiguous() or aux.dim() != 2 \
+                    or aux.shape[0] != lay["n_aux"]:
+                raise ValueError(f"ctx.tValues['{lay['aux_key']}'] must be a contiguous float64 CUDA tensor [{lay['n_aux']}, N] (it is updated in place)")
+            if stride and aux.shape[1] != stride:
+                raise ValueError("aux and the per-IVP vectors of one ctx must agree in N")
+            stride = int(aux.shape[1])
+        shared = torch.cat(shared_parts) if len(shared_parts) > 1 else (shared_parts[0] if shared_parts else None)
+        ivp = torch.cat(ivp_parts, dim=0) if len(ivp_parts) > 1 else (ivp_parts[0] if ivp_parts else None)
+        _check(_lib.lib().nnhip_ode_rhs_bind_ctx_f64_dev(self.kind, shared.data_ptr() if shared is not None else None, int(shared.numel()) if shared is not None else 0,
+                                                         ivp.data_ptr() if ivp is not None else None, int(ivp.shape[0]) if ivp is not None else 0,
+                                                         aux.data_ptr() if aux is not None else None, lay["n_aux"], stride))
+        self._bound = (shared, ivp, aux)  # keeps the device memory alive while calls are in flight
+
+    def params_all(self, ctx):
+        out = []
+        for k in self.keys:
+            if ctx is not None and k in ctx.fValues:
+                out.append(float(ctx.fValues[k]))
+            elif k in self.defaults:
+                out.append(float(self.defaults[k]))
+            else:
+                raise KeyError(f"ctx.fValues has no '{k}' for this RHS")
+        return out
 
     @staticmethod
     def neg_y():  # dy = -y (ode.nim:16-17)
@@ -179,6 +274,8 @@ def _shape_info(y0, layout):
 
 
 def _params_array(f, ctx):
+    if getattr(f, "ctx_layout", None) is not None:
+        f.bind(ctx)  # NumContext.tValues / many fValues / mutable slots: the closure captures its ctx
     p = np.asarray(f.params(ctx), dtype=np.float64)
     return p, (p.ctypes.data_as(C.POINTER(C.c_double)) if p.size else None)
 

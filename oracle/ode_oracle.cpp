@@ -547,7 +547,9 @@ enum RhsKind { RHS_NEG_Y = 0, RHS_LINEAR = 1, RHS_LORENZ = 2, RHS_RING = 3, RHS_
                RHS_DUFFING = 6 /* oracle-only: checks run-time compiled user RHS */,
                RHS_COS_T = 7 /* oracle-only integrand a*cos(t): tests/test_integrate.nim:5-6 */,
                RHS_POLY_T = 8 /* oracle-only integrand ((a t + b) t)(1 + c) + d for component c */,
-               RHS_HEAT = 9 /* oracle-only: method-of-lines heat equation, checks wide run-time compiled systems */ };
+               RHS_HEAT = 9 /* oracle-only: method-of-lines heat equation, checks wide run-time compiled systems */,
+               RHS_MATVEC = 10 /* oracle-only: dy = s * (A y) + g with the closure's own d x d matrix A (ctx.tValues, commonTypes.nim:4-27) */,
+               RHS_LORENZ_ZCROSS = 11 /* oracle-only: Lorenz whose closure MUTATES its ctx (ode.nim:599): counts crossings of z = 25 between calls */ };
 
 static double rhsScalar(double t, const double& y, const void* env) {
   const double* p = (const double*)env;  // p[0] = kind, p[1..] = params
@@ -599,6 +601,27 @@ static Vec rhsVector(double t, const Vec& y, const void* env) {
         const double left = i > 0 ? y.components[i - 1] : 0.0, right = i + 1 < d ? y.components[i + 1] : 0.0;
         r.components[i] = p[1] * ((left - 2.0 * y.components[i]) + right);
       }
+      break;
+    }
+    case RHS_MATVEC: {  // env: [kind, s, g[0..d), A[0..d*d) row-major]: dy_r = s * (((A_r0 y_0) + A_r1 y_1) + ...) + g_r
+      const double* g = p + 2;
+      const double* A = g + d;
+      for (size_t i = 0; i < d; ++i) {
+        double acc = A[i * d] * y.components[0];
+        for (size_t c = 1; c < d; ++c) acc = acc + A[i * d + c] * y.components[c];
+        r.components[i] = p[1] * acc + g[i];
+      }
+      break;
+    }
+    case RHS_LORENZ_ZCROSS: {  // env: [kind, sigma, rho, beta, count, last z, calls] — the last three are the closure's mutable ctx
+      double* m = const_cast<double*>(p) + 4;
+      const double x = y.components[0], yy = y.components[1], z = y.components[2];
+      if (m[2] > 0.0 && (m[1] - 25.0) * (z - 25.0) < 0.0) m[0] = m[0] + 1.0;
+      m[1] = z;
+      m[2] = m[2] + 1.0;
+      r.components[0] = p[1] * (yy - x);
+      r.components[1] = x * (p[2] - z) - yy;
+      r.components[2] = x * yy - p[3] * z;
       break;
     }
     default: for (size_t i = 0; i < d; ++i) r.components[i] = NAN;
@@ -812,6 +835,56 @@ int oracle_solve_ode_batch(int rhs_kind, const double* rhs_params, int n_params,
         if (layout == 0) y_out[((size_t)j * dimv + c) * N + i] = v;
         else y_out[((size_t)j * N + i) * dimv + c] = v;
       }
+    if (ny_out) ny_out[i] = st.n_y;
+    if (steps_out) steps_out[i] = st.steps;
+    if (rejected_out) rejected_out[i] = st.rejected;
+  }
+  return rc_all;
+}
+
+// A batch whose members each have their own ctx (N reference calls, each closure capturing its own NumContext): the closure's
+// environment of IVP i = [kind, shared[0..n_shared), per_ivp[r*N + i] for r < rows, aux_io[k*N + i] for k < n_aux]; the aux part is
+// what the closure mutates (ode.nim:599) and is copied back after the call.  Layout of y0 / y_out as oracle_solve_ode_batch.
+int oracle_solve_ode_batch_ctx(int rhs_kind, const double* shared, int n_shared, const double* per_ivp, int rows, double* aux_io, int n_aux,
+                               int dim, int layout, const double* y0, int64_t N, const double* tspan, int n_t, const oracle_options* opt,
+                               const char* integrator, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
+                               int64_t* rejected_out, int n_threads) {
+  if (oracle_integrator_id(integrator) < 0) return -2;
+  const int dimv = dim > 0 ? dim : 1;
+  int rc_all = 0;
+#pragma omp parallel for schedule(static) num_threads(n_threads) if (n_threads > 1)
+  for (int64_t i = 0; i < N; ++i) {
+    std::vector<double> y0i(dimv), tO(n_t), yO((size_t)n_t * dimv), par((size_t)n_shared + rows + n_aux);
+    for (int k = 0; k < n_shared; ++k) par[k] = shared[k];
+    for (int r = 0; r < rows; ++r) par[(size_t)n_shared + r] = per_ivp[(size_t)r * N + i];
+    for (int k = 0; k < n_aux; ++k) par[(size_t)n_shared + rows + k] = aux_io[(size_t)k * N + i];
+    for (int c = 0; c < dimv; ++c) y0i[c] = layout == 0 ? y0[(size_t)c * N + i] : y0[(size_t)i * dimv + c];
+    oracle_stats st{};
+    // oracle_solve_ode copies the parameters into the closure's env; the mutable tail is needed back, so the env is built here
+    using namespace oracle;
+    std::vector<double> env(1 + par.size());
+    env[0] = rhs_kind;
+    for (size_t k = 0; k < par.size(); ++k) env[1 + k] = par[k];
+    ODEoptions o; std::memcpy(&o, opt, sizeof(o));
+    Counters cnt;
+    std::vector<double> tV;
+    std::vector<Vec> yV;
+    int rc;
+    try {
+      ODEProc<Vec> f{rhsVector, env.data(), &cnt};
+      Vec v0; v0.components.assign(y0i.begin(), y0i.end());
+      rc = solveODE<Vec>(f, v0, tspan, n_t, o, integrator, tV, yV);
+    } catch (const std::invalid_argument&) { rc = -1; }
+    if (rc) { rc_all = rc; continue; }
+    st.n_t = (int)tV.size(); st.n_y = (int)yV.size(); st.steps = cnt.steps; st.rejected = cnt.rejected;
+    if (i == 0 && t_out) for (int j = 0; j < st.n_t; ++j) t_out[j] = tV[j];
+    for (int j = 0; j < n_t; ++j)
+      for (int c = 0; c < dimv; ++c) {
+        const double v = j < st.n_y ? yV[j].components[c] : NAN;
+        if (layout == 0) y_out[((size_t)j * dimv + c) * N + i] = v;
+        else y_out[((size_t)j * N + i) * dimv + c] = v;
+      }
+    for (int k = 0; k < n_aux; ++k) aux_io[(size_t)k * N + i] = env[1 + (size_t)n_shared + rows + k];
     if (ny_out) ny_out[i] = st.n_y;
     if (steps_out) steps_out[i] = st.steps;
     if (rejected_out) rejected_out[i] = st.rejected;

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liboracle_ode.so")
 
 # RHS kinds — must match include/nnhip_ode.h (enum nnhip_rhs_kind)
-RHS_NEG_Y, RHS_LINEAR, RHS_LORENZ, RHS_RING, RHS_AFFINE_T, RHS_VANDERPOL, RHS_DUFFING, RHS_COS_T, RHS_POLY_T, RHS_HEAT = range(10)  # DUFFING.. : oracle-only
+RHS_NEG_Y, RHS_LINEAR, RHS_LORENZ, RHS_RING, RHS_AFFINE_T, RHS_VANDERPOL, RHS_DUFFING, RHS_COS_T, RHS_POLY_T, RHS_HEAT, RHS_MATVEC, RHS_LORENZ_ZCROSS = range(12)  # DUFFING.. : oracle-only
 LAYOUT_SOA, LAYOUT_AOS = 0, 1
 
 ALL_ODE = ["heun2", "ralston2", "kutta3", "heun3", "ralston3", "ssprk3", "ralston4", "kutta4", "rk4",
@@ -146,6 +146,36 @@ def solve_ode_batch(rhs_kind, params, y0, N, dim, tspan, options=None, integrato
         raise ValueError("oracle error %d" % rc)
     shape = (n_t, dimv, N) if layout == LAYOUT_SOA else (n_t, N, dimv)
     return dict(t=t_out, y=y_out.reshape(shape), ny=ny, steps=steps, rejected=rej)
+
+
+def solve_ode_batch_ctx(rhs_kind, shared, per_ivp, aux, y0, N, dim, tspan, options=None, integrator="dopri54", layout=LAYOUT_SOA, n_threads=1):
+    """N reference calls whose closures each capture their own ctx: env_i = [shared..., per_ivp[:, i]..., aux[:, i]...]; `aux`
+    ([n_aux, N] float64, may be None) is the part the closure mutates and is updated in place.  Returns dict(t, y, ny, steps, rejected, aux)."""
+    options = options or new_options()
+    shared = np.ascontiguousarray(np.atleast_1d(np.asarray(shared, dtype=np.float64)))
+    per_ivp = np.zeros((0, N)) if per_ivp is None else np.ascontiguousarray(np.asarray(per_ivp, dtype=np.float64).reshape(-1, N))
+    auxa = np.zeros((0, N)) if aux is None else np.ascontiguousarray(np.asarray(aux, dtype=np.float64).reshape(-1, N))
+    tspan = np.ascontiguousarray(np.asarray(tspan, dtype=np.float64))
+    y0 = np.ascontiguousarray(np.asarray(y0, dtype=np.float64).ravel())
+    n_t = len(tspan)
+    assert y0.size == N * dim and dim >= 1
+    t_out = np.empty(n_t, dtype=np.float64)
+    y_out = np.empty(n_t * dim * N, dtype=np.float64)
+    ny = np.empty(N, dtype=np.int32)
+    steps = np.empty(N, dtype=np.int64)
+    rej = np.empty(N, dtype=np.int64)
+    f = lib().oracle_solve_ode_batch_ctx
+    f.restype = C.c_int
+    f.argtypes = [C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int,
+                  C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double), C.c_int, C.c_void_p, C.c_char_p, C.POINTER(C.c_double),
+                  C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int]
+    rc = f(rhs_kind, _dp(shared), len(shared), _dp(per_ivp), per_ivp.shape[0], _dp(auxa), auxa.shape[0], dim, layout, _dp(y0), N, _dp(tspan), n_t,
+           C.cast(C.byref(options), C.c_void_p), integrator.encode(), _dp(t_out), _dp(y_out), ny.ctypes.data_as(C.POINTER(C.c_int32)),
+           steps.ctypes.data_as(C.POINTER(C.c_int64)), rej.ctypes.data_as(C.POINTER(C.c_int64)), n_threads)
+    if rc != 0:
+        raise ValueError("oracle error %d" % rc)
+    shape = (n_t, dim, N) if layout == LAYOUT_SOA else (n_t, N, dim)
+    return dict(t=t_out, y=y_out.reshape(shape), ny=ny, steps=steps, rejected=rej, aux=auxa)
 
 
 def step(rhs_kind, params, integrator, options, t, y, fsal, dt):

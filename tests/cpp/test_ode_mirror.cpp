@@ -181,6 +181,32 @@ int main() {
     try { h2.eval({11.0}, ExtrapolateKind::Error); } catch (const std::invalid_argument&) { threwX = true; }
     CHECK(threwX);
   }
+  {  // NumContext in full: every system its own 3 x 3 matrix (per-IVP tValues), a shared forcing vector, and a mutable call counter
+    const int n = 64, d = 3;
+    const RhsSpec fm = rhsFromSourceCtx(d, "for (int r = 0; r < dim; ++r) { double acc = A(r*dim)*y[0]; for (int k = 1; k < dim; ++k) acc = acc + A(r*dim+k)*y[k];"
+                                           " dy[r] = p[0]*acc + g[r]; } aux(0) = aux(0) + 1.0;", {"s"}, {{"g", d, false}, {"A", d * d, true}}, /*nAux=*/1, {}, "mirror_matvec");
+    NumContext<double> c2;
+    c2.setF("s", 0.5);
+    std::vector<double> g = {0.1, -0.2, 0.05}, A((size_t)d * d * n), aux0((size_t)n, 0.0);
+    for (int i = 0; i < n; ++i)
+      for (int r = 0; r < d; ++r)
+        for (int k = 0; k < d; ++k) A[(size_t)(r * d + k) * n + i] = (r == k ? -1.0 - 0.01 * i : 0.1 * (r - k));   // row r*d+k of IVP i
+    bindCtx(fm, g, A, aux0, 1, n);
+    OdeBatch yb = OdeBatch::zeros(n, d);
+    for (int i = 0; i < n; ++i) for (int k = 0; k < d; ++k) yb.at(i, k) = 1.0 + 0.1 * k;
+    const OdeSolution all = solveODE(fm, yb, {0.0, 1.0}, DEFAULT_ODEoptions(), &c2, "tsit54");
+    const std::vector<double> calls = readAux(fm, 1, n);
+    // IVP 5 alone, bound as a batch of one with its own matrix: the same bits (N reference calls, each closure its own ctx)
+    std::vector<double> A5((size_t)d * d), one0(1, 0.0);
+    for (int q = 0; q < d * d; ++q) A5[q] = A[(size_t)q * n + 5];
+    bindCtx(fm, g, A5, one0, 1, 1);
+    OdeBatch y5 = OdeBatch::zeros(1, d);
+    for (int k = 0; k < d; ++k) y5.at(0, k) = yb.at(5, k);
+    const OdeSolution one = solveODE(fm, y5, {0.0, 1.0}, DEFAULT_ODEoptions(), &c2, "tsit54");
+    for (int k = 0; k < d; ++k) CHECK(all.y[1].at(5, k) == one.y[1].at(0, k));
+    CHECK(calls[5] == readAux(fm, 1, 1)[0] && calls[5] > 100.0);   // f(t0) twice, then six stages per attempt (ode.nim:498,506,362-374)
+    CHECK(std::fabs(all.y[1].at(5, 0)) < 1.0);
+  }
   // error behaviour: ValueError analogues
   bool threw = false;
   try { solveODE(f, y0, tspan, DEFAULT_ODEoptions(), &ctx, "rk5"); } catch (const std::invalid_argument&) { threw = true; }

@@ -1,0 +1,139 @@
+"""NumContext in full for run-time compiled right-hand sides (commonTypes.nim:4-27; ode.nim:36 ODEProc's `ctx`, :599 "IT IS MUTABLE"):
+any number of fValues, tValues entries shared by the batch or one per IVP (each member of the batch its own ctx), and per-IVP mutable
+slots — nnhip_ode_rhs_compile_ctx / nnhip_ode_rhs_bind_ctx_f64_dev.  Parity: bit for bit against the oracle's closures with the same ctx."""
+import os
+
+import numpy as np
+import pytest
+
+# dy = s * (A y) + g: A is THIS IVP's 16 x 16 matrix (a per-IVP tValues entry), g a forcing vector every IVP shares, s an fValue.
+# Association as the oracle's closure (oracle/ode_oracle.cpp RHS_MATVEC): ((A_r0 y_0 + A_r1 y_1) + ...), then s * acc + g_r.
+MATVEC_SRC = ("for (int r = 0; r < dim; ++r) { double acc = A(r * dim) * y[0]; for (int k = 1; k < dim; ++k) acc = acc + A(r * dim + k) * y[k];"
+              " dy[r] = p[0] * acc + g[r]; }")
+# Lorenz whose closure mutates its ctx: aux(0) counts crossings of z = 25 between consecutive calls, aux(1) = z of the last call, aux(2) = calls
+ZCROSS_SRC = ("const double z = y[2]; if (aux(2) > 0.0 && (aux(1) - 25.0) * (z - 25.0) < 0.0) aux(0) = aux(0) + 1.0; aux(1) = z; aux(2) = aux(2) + 1.0;"
+              " dy[0] = p[0] * (y[1] - y[0]); dy[1] = y[0] * (p[1] - y[2]) - y[1]; dy[2] = y[0] * y[1] - p[2] * y[2];")
+DUFF12_SRC = "const double x = y[0], v = y[1]; dy[0] = v; dy[1] = ((-p[8]*v - p[9]*x) - p[10]*(x*x*x)) + p[11]*t;"
+
+
+def _matvec(nn):
+    return nn.Rhs.custom(16, MATVEC_SRC, keys=("s",), tvalues={"g": 16, "A": 256}, per_ivp=("A",), name="matvec16")
+
+
+def test_layout_declarations_are_checked_without_gpu(nn):
+    import ctypes as C
+    L = nn._lib.lib()
+    f = _matvec(nn)
+    assert f.kind >= 1000 and f.ctx_layout["per_ivp"] == ("A",)
+    with pytest.raises(ValueError, match="reserved"):
+        nn.Rhs.custom(2, "dy[0] = y[1]; dy[1] = 0;", tvalues={"dy": 3})
+    with pytest.raises(ValueError, match="identifier"):
+        nn.Rhs.custom(2, "dy[0] = y[1]; dy[1] = 0;", tvalues={"2x": 3})
+    with pytest.raises(ValueError, match="whole-vector"):
+        nn.Rhs.custom(16, "return -y[c];", per_component=True, n_aux=1)
+    with pytest.raises(ValueError, match="per_ivp names"):
+        nn.Rhs.custom(2, "dy[0] = y[1]; dy[1] = 0;", tvalues={"a": 3}, per_ivp=("b",))
+    # a body that uses an undeclared vector does not compile
+    with pytest.raises(ValueError, match="undeclared identifier"):
+        nn.Rhs.custom(2, "dy[0] = B[0]; dy[1] = 0;", tvalues={"A": 3})
+    # binding what the layout does not declare is refused; so is a right-hand side compiled without a layout
+    assert L.nnhip_ode_rhs_bind_ctx_f64_dev(f.kind, None, 16, None, 256, None, 0, 10) != 0   # NULL parts
+    assert L.nnhip_ode_rhs_bind_ctx_f64_dev(f.kind, C.c_void_p(16), 15, C.c_void_p(16), 256, None, 0, 10) != 0  # wrong shared length
+    assert b"layout" in L.nnhip_last_error()
+    plain = nn.Rhs.custom(2, "dy[0] = y[1]; dy[1] = -y[0];")
+    assert L.nnhip_ode_rhs_bind_ctx_f64_dev(plain.kind, None, 0, None, 0, None, 0, 0) != 0
+    # more than eight scalars need the layout entry (the plain one still refuses them)
+    k = C.c_int(0)
+    assert L.nnhip_ode_rhs_compile(b"x", 2, 12, DUFF12_SRC.encode(), C.byref(k)) != 0
+    f12 = nn.Rhs.custom(2, DUFF12_SRC, keys=tuple("k%02d" % i for i in range(12)))
+    assert f12.kind >= 1000 and f12.params(None) == []   # the scalars lead the shared block instead of travelling as kernel arguments
+
+
+@pytest.mark.gpu
+def test_unbound_or_too_small_context_is_refused(nn, dev):
+    import torch
+    f = nn.Rhs.custom(3, ZCROSS_SRC, keys=("sigma", "rho", "beta"), defaults=dict(sigma=10.0, rho=28.0, beta=8.0 / 3.0), n_aux=3, name="zcross_unbound_probe")
+    y0 = torch.ones((3, 10), dtype=torch.float64, device=dev)
+    with pytest.raises(ValueError, match="pass ctx|must be a contiguous float64 CUDA tensor"):
+        nn.solveODE(f, y0, [0.0, 0.1])
+    ctx = nn.newNumContext(tValues={"aux": torch.zeros((3, 4), dtype=torch.float64, device=dev)})   # bound for 4 IVPs, asked for 10
+    with pytest.raises(ValueError, match="exceeds the batch"):
+        nn.solveODE(f, y0, [0.0, 0.1], ctx=ctx)
+
+
+@pytest.mark.gpu
+def test_each_system_its_own_16x16_matrix_1e5(nn, oracle, dev):
+    """1e5 systems y' = s A_i y + g, every one with its own 16 x 16 A_i (ctx.tValues), through Rhs.custom — fused solve
+    (2-point and dense tspan, both layouts), the IntegratorProc seam and the HBM-resident adaptive loop — equal to the oracle's N closures."""
+    import torch
+    O = oracle
+    n, d = 100_000, 16
+    rng = np.random.default_rng(11)
+    A = (rng.standard_normal((n, d, d)) * 0.35 - 0.6 * np.eye(d)[None])            # [N, 16, 16]
+    g = rng.standard_normal(d) * 0.2
+    s = 0.75
+    y0 = 0.5 + rng.random((d, n))
+    per = np.ascontiguousarray(A.reshape(n, d * d).T)                                # [256, N]: row r*16+c of IVP i
+    f = _matvec(nn)
+    ctx = nn.newNumContext(fValues={"s": s}, tValues={"g": g, "A": torch.from_numpy(per).to(dev)})
+    kw = dict(absTol=1e-7, relTol=1e-7, dtMin=1e-8, dtMax=0.25)
+    threads = min(64, os.cpu_count() or 1)
+    for integ, ts in (("tsit54", [0.0, 1.0]), ("dopri54", [0.0, 0.2, 0.4, 0.7, 1.0])):
+        ref = O.solve_ode_batch_ctx(O.RHS_MATVEC, [s] + list(g), per, None, y0, n, d, ts, O.new_options(**kw), integ, n_threads=threads)
+        t, y, cnt = nn.solveODE(f, torch.from_numpy(y0).to(dev), ts, nn.newODEoptions(**kw), ctx=ctx, integrator=integ, return_counts=True)
+        assert np.array_equal(t, ref["t"])
+        assert np.array_equal(y.cpu().numpy(), ref["y"]), integ
+        assert np.array_equal(cnt["steps"].cpu().numpy(), ref["steps"]) and np.array_equal(cnt["rejected"].cpu().numpy(), ref["rejected"])
+    # AoS layout, a sub-batch (N < the bound stride: IVP i reads column i), and the streaming seam
+    m = 4096
+    y0a = torch.from_numpy(np.ascontiguousarray(y0[:, :m].T)).to(dev)
+    ta, ya = nn.solveODE(f, y0a, [0.0, 1.0], nn.newODEoptions(**kw), ctx=ctx, integrator="tsit54", layout=1)
+    refm = O.solve_ode_batch_ctx(O.RHS_MATVEC, [s] + list(g), per[:, :m], None, y0[:, :m], m, d, [0.0, 1.0], O.new_options(**kw), "tsit54", n_threads=threads)
+    assert np.array_equal(ya.cpu().numpy()[-1], refm["y"][-1].T)
+    ys, launches = nn.adaptiveStream(f, torch.from_numpy(np.ascontiguousarray(y0[:, :m])).to(dev), 0.0, 1.0, nn.newODEoptions(**kw), ctx=ctx, integrator="tsit54")
+    assert np.array_equal(ys.cpu().numpy(), refm["y"][-1]) and launches >= int(refm["steps"].max())
+
+
+@pytest.mark.gpu
+def test_twelve_scalars_live_in_the_shared_block(nn, oracle, dev):
+    """ctx.fValues of any size: twelve keys, the right-hand side reads the last four (a Duffing oscillator the oracle has as a closure)."""
+    import torch
+    O = oracle
+    keys = tuple("k%02d" % i for i in range(12))
+    vals = dict(zip(keys, [9.0, 8.0, 7.0, 6.0, 5.0, 4.0, 3.0, 2.0, 0.3, -1.0, 1.0, 0.37]))
+    f = nn.Rhs.custom(2, DUFF12_SRC, keys=keys, name="duffing12")
+    ctx = nn.newNumContext(fValues=vals)
+    rng = np.random.default_rng(4)
+    n = 3000
+    y0 = rng.uniform(-1.5, 1.5, (2, n))
+    ts = O.linspace(-1.0, 2.0, 31)
+    kw = dict(dt=1e-2, absTol=1e-8, relTol=1e-8, dtMin=1e-6, dtMax=5e-2)
+    for integ in ("rk4", "tsit54", "vern65"):
+        t, y = nn.solveODE(f, torch.from_numpy(y0).to(dev), ts, nn.newODEoptions(**kw), ctx=ctx, integrator=integ)
+        ref = O.solve_ode_batch(O.RHS_DUFFING, [0.3, -1.0, 1.0, 0.37], y0, n, 2, ts, O.new_options(**kw), integ, n_threads=8)
+        assert np.array_equal(t, ref["t"]) and np.array_equal(y.cpu().numpy(), ref["y"]), integ
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("integrator", ["dopri54", "tsit54", "vern65", "bs32", "rk21", "rk4", "heun2"])
+def test_mutable_ctx_counts_z_crossings(nn, oracle, dev, integrator):
+    """the closure mutates its ctx (ode.nim:599).  A Lorenz right-hand side that counts, across its own calls, how often z
+    crossed 25 — per IVP, in aux — must end with the oracle's counts, last z and number of calls: the device evaluates f where ODESolver does."""
+    import torch
+    O = oracle
+    n = 4000
+    y0 = np.stack([1.0 + (np.arange(n) % 1024) * 2.0 ** -10, np.ones(n), np.ones(n)])
+    kw = dict(dt=2e-3, absTol=1e-6, relTol=1e-6, dtMin=1e-8, dtMax=0.05)
+    f = nn.Rhs.custom(3, ZCROSS_SRC, keys=("sigma", "rho", "beta"), defaults=dict(sigma=10.0, rho=28.0, beta=8.0 / 3.0), n_aux=3, name="lorenz_zcross")
+    aux = torch.zeros((3, n), dtype=torch.float64, device=dev)
+    ctx = nn.newNumContext(tValues={"aux": aux})
+    t, y = nn.solveODE(f, torch.from_numpy(y0).to(dev), [0.0, 3.0], nn.newODEoptions(**kw), ctx=ctx, integrator=integrator)
+    ref = O.solve_ode_batch_ctx(O.RHS_LORENZ_ZCROSS, [10.0, 28.0, 8.0 / 3.0], None, np.zeros((3, n)), y0, n, 3, [0.0, 3.0], O.new_options(**kw), integrator, n_threads=8)
+    assert np.array_equal(y.cpu().numpy(), ref["y"])
+    got = aux.cpu().numpy()
+    assert np.array_equal(got, ref["aux"]), (got[:, :3], ref["aux"][:, :3])
+    assert got[0].max() >= 2 and got[2].min() > 100          # it did count something
+    if integrator in ("dopri54", "tsit54"):                   # the same through the HBM-resident loop: FSAL from the RHS batch kernel, then one launch per iteration
+        aux2 = torch.zeros((3, n), dtype=torch.float64, device=dev)
+        ys, launches = nn.adaptiveStream(f, torch.from_numpy(y0).to(dev), 0.0, 3.0, nn.newODEoptions(**kw), ctx=nn.newNumContext(tValues={"aux": aux2}), integrator=integrator)
+        assert np.array_equal(ys.cpu().numpy(), ref["y"][-1]) and np.array_equal(aux2.cpu().numpy(), ref["aux"])
