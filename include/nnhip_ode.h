@@ -401,6 +401,29 @@ int nnhip_ode_rhs_release(int rhs_kind);
  * RCCL is loaded lazily (dlopen); failure text: nnhip_multigpu_last_error(). */
 int nnhip_allgather_states_f64_dev(int n_gpus, const double* const* shard, const int64_t* counts, int dim, int layout,
                                    double* const* full, void* const* streams);
+/* BASELINE.json config C5 behind ONE call: "shards across the 8 GPUs with an RCCL all-gather over xGMI only to reassemble".  One
+ * process, n_gpus devices; device r holds its contiguous shard y[r] (counts[r] IVPs, `layout`) resident in its own memory.  Every
+ * shard is integrated by the step-streaming loop of nnhip_ode_fixed_stream_f64_dev (one reference call per IVP, ode.nim:589-591:
+ * nothing couples trajectories) on streams[r] — one non-default stream per device, required — and the final shards are then
+ * reassembled on EVERY device into full[r] ([dim][N] SoA / [N][dim] AoS, N = sum counts; nullable array: no gather) with one
+ * ncclAllGather per component plane (equal counts) or grouped ncclBroadcasts (ragged).  The collective is enqueued behind the
+ * solve on streams[r], or on gather_streams[r] (nullable array) behind an event: the caller's next solve on streams[r] then overlaps
+ * the gather (rotate the state buffers so that a shard being gathered is not overwritten).  scratch (nullable array): ping-pong
+ * buffers as in the single-device entry.  y_final[r] (nullable array) = the buffer that holds shard r's final state (y[r] or
+ * scratch[r]); *n_steps_out = steps taken.  Asynchronous: returns after enqueueing, the caller synchronises its streams.  No host
+ * copy of state anywhere; RCCL is loaded lazily (failure text in nnhip_last_error()). */
+int nnhip_ode_fixed_stream_multi_gpu_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
+                                             int n_gpus, const int64_t* counts, int dim, int layout, double t0, double tEnd, double* const* y,
+                                             double* const* scratch, double* const* full, void* const* streams, void* const* gather_streams,
+                                             int64_t* n_steps_out, double** y_final);
+/* The same composition around the fused solve (any integrator, any tspan): y0[r] / y_out[r] ([n_t][dim][counts[r]] SoA,
+ * [n_t][counts[r]][dim] AoS) / ny_out[r] (nullable array) / ws[r] (nnhip_ode_solve_workspace_bytes(n_t) bytes) live on device r; the
+ * whole trajectory tensor is reassembled on every device into full[r] ([n_t][dim][N] / [n_t][N][dim]; nullable array: no gather) —
+ * plane by plane in one RCCL group for SoA, one block per row for AoS.  t_out host, as nnhip_ode_solve_batch_f64_dev. */
+int nnhip_ode_solve_batch_multi_gpu_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
+                                            int n_gpus, const int64_t* counts, int dim, int layout, const double* tspan, int n_t, double* t_out,
+                                            const double* const* y0, double* const* y_out, int32_t* const* ny_out, int64_t max_steps,
+                                            void* const* ws, int64_t ws_bytes, double* const* full, void* const* streams, void* const* gather_streams);
 const char* nnhip_multigpu_last_error(void);
 
 /* ---- consumers either side of the path ------------------------------------------------------- */

@@ -84,6 +84,12 @@ SIGNATURES = {
     "nnhip_ode_solve_batch_multi_gpu_f64": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, _vp, C.c_int64, C.c_int,
                                                       C.c_int, _dp, C.c_int, _dp, _vp, _vp, C.c_int64, C.POINTER(Stats), C.c_int]),
     "nnhip_allgather_states_f64_dev": (C.c_int, [C.c_int, C.POINTER(_vp), C.POINTER(C.c_int64), C.c_int, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]),
+    "nnhip_ode_fixed_stream_multi_gpu_f64_dev": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_double,
+                                                           C.c_double, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
+                                                           C.POINTER(C.c_int64), C.POINTER(_vp)]),
+    "nnhip_ode_solve_batch_multi_gpu_f64_dev": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_int, C.c_int, _dp, C.c_int,
+                                                          _dp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.c_int64, C.POINTER(_vp), C.c_int64,
+                                                          C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "nnhip_multigpu_last_error": (C.c_char_p, []),
     "nnhip_hermite_spline_f64_dev": (C.c_int, [C.c_double] * 3 + [_vp] * 5 + [C.c_int64, _vp]),
     "nnhip_ode_rhs_compile": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int)]),

@@ -1258,6 +1258,7 @@ struct StreamGraphKey {
   double t0, tEnd, dt, p[nnhip::kMaxParams];
   const void *y, *scratch;
   hipStream_t stream;
+  int device;
   bool operator==(const StreamGraphKey& o) const { return std::memcmp(this, &o, sizeof(*this)) == 0; }
 };
 struct StreamGraphEntry {
@@ -1266,12 +1267,21 @@ struct StreamGraphEntry {
   int64_t nSteps = 0;
   double* yFinal = nullptr;
 };
-thread_local std::vector<StreamGraphEntry> g_graphs;
-thread_local std::vector<StreamGraphKey> g_graph_seen;  // automatic mode: keys that ran eagerly once (a repeat is worth capturing)
+// Process-wide since round 3 (they were per thread): nnhip_release() and a knob change free every thread's captures, and the worker
+// threads of the multi-GPU entries find what an earlier call's workers captured.  The mutex covers lookup / insert / erase only.
+std::mutex g_graph_mu;
+std::vector<StreamGraphEntry> g_graphs;
+std::vector<StreamGraphKey> g_graph_seen;  // automatic mode: keys that ran eagerly once (a repeat is worth capturing)
 thread_local bool g_capturing = false;
+void sync_device_of(int device) {  // a cached graph may still be executing; its stream handle may be gone: synchronise its device
+  int prev = 0;
+  const bool have = hipGetDevice(&prev) == hipSuccess;
+  if (device >= 0 && hipSetDevice(device) == hipSuccess) (void)hipDeviceSynchronize();
+  if (have) (void)hipSetDevice(prev);
+}
 void release_stream_graphs() {
-  if (!g_graphs.empty()) (void)hipDeviceSynchronize();  // not the cached stream handles: a caller may have destroyed its stream since
-  for (auto& e : g_graphs) if (e.exec) (void)hipGraphExecDestroy(e.exec);
+  std::lock_guard<std::mutex> lk(g_graph_mu);
+  for (auto& e : g_graphs) if (e.exec) { sync_device_of(e.key.device); (void)hipGraphExecDestroy(e.exec); }
   g_graphs.clear();
   g_graph_seen.clear();
 }
@@ -1295,21 +1305,30 @@ int nnhip_ode_fixed_stream_f64_dev(const nnhip_ode_options* opt, int integrator,
     key.t0 = t0; key.tEnd = tEnd; key.dt = opt->dt;
     for (int k = 0; k < nnhip::kMaxParams; ++k) key.p[k] = P.p[k];
     key.y = y; key.scratch = scratch; key.stream = (hipStream_t)stream;
-    for (auto& e : g_graphs)
-      if (e.key == key) {
-        HIP_TRY(hipGraphLaunch(e.exec, (hipStream_t)stream));
-        if (n_steps_out) *n_steps_out = e.nSteps;
-        if (y_final) *y_final = e.yFinal;
-        return NNHIP_OK;
-      }
+    HIP_TRY(hipGetDevice(&key.device));
     bool eager = false;
-    if (g_stream_graph == 2) {
-      bool seen = false;
-      for (auto& k2 : g_graph_seen) seen = seen || k2 == key;
-      if (!seen) {
-        if (g_graph_seen.size() >= 32) g_graph_seen.erase(g_graph_seen.begin());
-        g_graph_seen.push_back(key);
-        eager = true;  // first sight of this call: run it eagerly below
+    {
+      StreamGraphEntry hit;
+      bool found = false;
+      {
+        std::lock_guard<std::mutex> lk(g_graph_mu);
+        for (auto& e : g_graphs)
+          if (e.key == key) { hit = e; found = true; break; }
+        if (!found && g_stream_graph == 2) {
+          bool seen = false;
+          for (auto& k2 : g_graph_seen) seen = seen || k2 == key;
+          if (!seen) {
+            if (g_graph_seen.size() >= 64) g_graph_seen.erase(g_graph_seen.begin());
+            g_graph_seen.push_back(key);
+            eager = true;  // first sight of this call: run it eagerly below
+          }
+        }
+      }
+      if (found) {
+        HIP_TRY(hipGraphLaunch(hit.exec, (hipStream_t)stream));
+        if (n_steps_out) *n_steps_out = hit.nSteps;
+        if (y_final) *y_final = hit.yFinal;
+        return NNHIP_OK;
       }
     }
     hipGraph_t graph = nullptr;
@@ -1331,12 +1350,15 @@ int nnhip_ode_fixed_stream_f64_dev(const nnhip_ode_options* opt, int integrator,
     const hipError_t ie = hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (ie != hipSuccess) return fail(NNHIP_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
-    if (g_graphs.size() >= 8) {  // evict the oldest; it may still be executing on its stream
-      (void)hipDeviceSynchronize();
-      (void)hipGraphExecDestroy(g_graphs.front().exec);
-      g_graphs.erase(g_graphs.begin());
+    {
+      std::lock_guard<std::mutex> lk(g_graph_mu);
+      if (g_graphs.size() >= 32) {  // evict the oldest; it may still be executing
+        sync_device_of(g_graphs.front().key.device);
+        (void)hipGraphExecDestroy(g_graphs.front().exec);
+        g_graphs.erase(g_graphs.begin());
+      }
+      g_graphs.push_back(e);
     }
-    g_graphs.push_back(e);
     HIP_TRY(hipGraphLaunch(e.exec, (hipStream_t)stream));
     if (n_steps_out) *n_steps_out = e.nSteps;
     if (y_final) *y_final = e.yFinal;
@@ -1516,14 +1538,15 @@ struct AdvPoll {
   hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
   int device = -1;
 };
-thread_local std::vector<AdvGraphEntry> g_adv_graphs;
-thread_local AdvPoll g_adv_poll;
+std::vector<AdvGraphEntry> g_adv_graphs;  // process-wide, under g_graph_mu (see g_graphs)
+thread_local AdvPoll g_adv_poll;          // the calling thread's flag block, events and side streams (its graphs bake the flag addresses in)
 
 void release_adv_graphs();
+void free_adv_poll(AdvPoll& p);
 int adv_poll_reserve() {
   int device = 0;
   HIP_TRY(hipGetDevice(&device));
-  if (g_adv_poll.device != device) release_adv_graphs();  // streams and events belong to one device
+  if (g_adv_poll.device != device) free_adv_poll(g_adv_poll);  // streams and events belong to one device
   AdvPoll& p = g_adv_poll;
   p.device = device;
   if (!p.h) HIP_TRY(hipHostMalloc((void**)&p.h, 2 * nnhip::kAggSlots * sizeof(unsigned int), hipHostMallocMapped | hipHostMallocCoherent));
@@ -1534,10 +1557,25 @@ int adv_poll_reserve() {
   return NNHIP_OK;
 }
 void release_adv_graphs() {
-  if (!g_adv_graphs.empty()) (void)hipDeviceSynchronize();  // not the cached stream handles: a caller may have destroyed its stream since
-  for (auto& e : g_adv_graphs) if (e.exec) (void)hipGraphExecDestroy(e.exec);
-  g_adv_graphs.clear();
-  AdvPoll& p = g_adv_poll;
+  {
+    std::lock_guard<std::mutex> lk(g_graph_mu);
+    for (auto& e : g_adv_graphs) if (e.exec) { sync_device_of(e.key.device); (void)hipGraphExecDestroy(e.exec); }
+    g_adv_graphs.clear();
+  }
+  free_adv_poll(g_adv_poll);
+}
+void free_adv_poll(AdvPoll& p) {
+  if (p.device >= 0) {  // graphs that bake this block's flag addresses in go with it
+    std::lock_guard<std::mutex> lk(g_graph_mu);
+    for (size_t k = 0; k < g_adv_graphs.size();) {
+      const unsigned int* f = (const unsigned int*)g_adv_graphs[k].key.active;
+      if (p.h && f >= p.h && f < p.h + 2 * nnhip::kAggSlots) {
+        sync_device_of(g_adv_graphs[k].key.device);
+        (void)hipGraphExecDestroy(g_adv_graphs[k].exec);
+        g_adv_graphs.erase(g_adv_graphs.begin() + (long)k);
+      } else ++k;
+    }
+  }
   if (p.h) (void)hipHostFree(p.h);
   for (hipEvent_t e : p.ev) if (e) (void)hipEventDestroy(e);
   for (hipStream_t st : p.side) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
@@ -1660,8 +1698,11 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
       std::memcpy(&key.a, &a, sizeof(a));
       key.fn = (const void*)fn; key.active = flags; key.userKind = userKind; key.integrator = integrator; key.checkEvery = check_every; key.device = device; key.split = split; key.stream = s;
       hipGraphExec_t exec = nullptr;
-      for (auto& e : g_adv_graphs)
-        if (std::memcmp(&e.key, &key, sizeof(key)) == 0) { exec = e.exec; break; }
+      {
+        std::lock_guard<std::mutex> lk(g_graph_mu);
+        for (auto& e : g_adv_graphs)
+          if (std::memcmp(&e.key, &key, sizeof(key)) == 0) { exec = e.exec; break; }
+      }
       if (!exec) {
         if (fn == nullptr) {  // run-time compiled kernels: make sure the module is loaded before the stream goes into capture mode
           nnhip::StepArgs warm = a;
@@ -1684,8 +1725,9 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
           (void)hipGetLastError();  // e.g. the caller is capturing this stream itself: plain launches below
         }
         if (exec) {
-          if (g_adv_graphs.size() >= 16) {  // evict the oldest; it may still be executing
-            (void)hipDeviceSynchronize();
+          std::lock_guard<std::mutex> lk(g_graph_mu);
+          if (g_adv_graphs.size() >= 32) {  // evict the oldest; it may still be executing
+            sync_device_of(g_adv_graphs.front().key.device);
             (void)hipGraphExecDestroy(g_adv_graphs.front().exec);
             g_adv_graphs.erase(g_adv_graphs.begin());
           }

@@ -433,4 +433,140 @@ int nnhip_ode_solve_batch_multi_gpu_sweep_f64(const nnhip_ode_options* opt, int 
   return NNHIP_OK;
 }
 
+// ---- C5 behind one call (BASELINE.json config 5) ------------------------------------------------------------------
+// One process, n_gpus devices.  Device r holds its contiguous shard (counts[r] IVPs) resident in its own memory; every shard is
+// integrated on its device's stream (one worker thread per device enqueues it: the reference is one solveODE call per IVP,
+// ode.nim:589-591, nothing couples trajectories), then the shards are reassembled ON EVERY DEVICE with RCCL over xGMI
+// (ncclAllGather for equal shards, grouped ncclBroadcasts for ragged ones) into device-resident full tensors.  No host copy anywhere.
+// The collective is enqueued behind the solve — on the solve's own stream, or on gather_streams[r] behind an event, so that the
+// caller's next solve on streams[r] overlaps the gather (as bench.py does).  Returns after enqueueing; the caller synchronises.
+namespace {
+int mg_check(int n_gpus, const int64_t* counts, int* ndev_out) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return nnhip::fail_msg(NNHIP_EHIP, "no HIP device available (this library has no CPU fallback)");
+  if (n_gpus <= 0 || n_gpus > 64 || n_gpus > ndev) return nnhip::fail_msg(NNHIP_EVALUE, "n_gpus = %d, but this node has %d HIP device(s)", n_gpus, ndev);
+  if (!counts) return nnhip::fail_msg(NNHIP_EVALUE, "counts is NULL");
+  for (int r = 0; r < n_gpus; ++r) if (counts[r] < 0) return nnhip::fail_msg(NNHIP_EVALUE, "counts[%d] < 0", r);
+  if (ndev_out) *ndev_out = ndev;
+  return NNHIP_OK;
+}
+// gather on gather_streams[r] (nullable array) behind whatever streams[r] holds now
+int mg_gather(int n_gpus, const double* const* shard, const int64_t* counts, int planesOrDim, int layout, double* const* full, void* const* streams,
+              void* const* gather_streams) {
+  if (gather_streams) {
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (int r = 0; r < n_gpus; ++r) {
+      if (gather_streams[r] == (streams ? streams[r] : nullptr)) continue;
+      hipEvent_t ev = nullptr;
+      if (hipSetDevice(r) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess ||
+          hipEventRecord(ev, streams ? (hipStream_t)streams[r] : nullptr) != hipSuccess ||
+          hipStreamWaitEvent((hipStream_t)gather_streams[r], ev, 0) != hipSuccess) {
+        if (ev) (void)hipEventDestroy(ev);
+        (void)hipSetDevice(prev);
+        return nnhip::fail_msg(NNHIP_EHIP, "device %d: ordering the gather behind the solve failed", r);
+      }
+      (void)hipEventDestroy(ev);  // released by the runtime once the recorded work has completed
+    }
+    (void)hipSetDevice(prev);
+  }
+  const int rc = nnhip_allgather_states_f64_dev(n_gpus, shard, counts, planesOrDim, layout, full, gather_streams ? gather_streams : streams);
+  if (rc) return nnhip::fail_msg(rc, "reassembling the shards: %s", nnhip_multigpu_last_error());
+  return NNHIP_OK;
+}
+}  // namespace
+
+int nnhip_ode_fixed_stream_multi_gpu_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
+                                             int n_gpus, const int64_t* counts, int dim, int layout, double t0, double tEnd, double* const* y,
+                                             double* const* scratch, double* const* full, void* const* streams, void* const* gather_streams,
+                                             int64_t* n_steps_out, double** y_final) {
+  int rc = mg_check(n_gpus, counts, nullptr);
+  if (rc) return rc;
+  if (!y || !streams) return nnhip::fail_msg(NNHIP_EVALUE, "y / streams is NULL (one non-default stream per device)");
+  if (n_gpus > 1 && nnhip::rtc_has_per_ivp_ctx(rhs_kind))
+    return nnhip::fail_msg(NNHIP_EUNSUPPORTED, "rhs_kind %d reads a context block bound to ONE device's memory: bind and solve per device", rhs_kind);
+  std::vector<int> rcs(n_gpus, NNHIP_OK);
+  std::vector<std::string> errs(n_gpus);
+  std::vector<int64_t> steps(n_gpus, 0);
+  std::vector<double*> fin(n_gpus, nullptr);
+  auto work = [&](int r) {
+    if (hipSetDevice(r) != hipSuccess) { rcs[r] = NNHIP_EHIP; errs[r] = "hipSetDevice failed"; return; }
+    fin[r] = y[r];
+    if (counts[r] == 0) return;
+    rcs[r] = nnhip_ode_fixed_stream_f64_dev(opt, integrator, rhs_kind, rhs_params, n_params, counts[r], dim, layout, t0, tEnd, y[r],
+                                            scratch ? scratch[r] : nullptr, &steps[r], &fin[r], streams[r]);
+    if (rcs[r]) errs[r] = nnhip::thread_error();
+  };
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  if (n_gpus == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int r = 0; r < n_gpus; ++r) th.emplace_back(work, r);
+    for (auto& t : th) t.join();
+  }
+  (void)hipSetDevice(prev);
+  for (int r = 0; r < n_gpus; ++r) if (rcs[r]) return nnhip::fail_msg(rcs[r], "device %d: %s", r, errs[r].c_str());
+  if (n_steps_out) { *n_steps_out = 0; for (int r = 0; r < n_gpus; ++r) if (steps[r] > *n_steps_out) *n_steps_out = steps[r]; }
+  if (y_final) for (int r = 0; r < n_gpus; ++r) y_final[r] = fin[r];
+  if (!full) return NNHIP_OK;
+  return mg_gather(n_gpus, fin.data(), counts, dim, layout, full, streams, gather_streams);
+}
+
+// The fused solve (any integrator, any tspan) per device-resident shard, then the trajectory tensor reassembled on every device:
+// y0[r] / y_out[r] on device r ([dim][counts[r]] / [n_t][dim][counts[r]] for SoA), full[r] = [n_t][dim][N] (SoA) or [n_t][N][dim] (AoS)
+// on device r (nullable array: no gather).  ny_out[r] (nullable array, int32 [counts[r]] on device r) as nnhip_ode_solve_batch_f64_dev.
+// ws[r]: device scratch of nnhip_ode_solve_workspace_bytes(n_t) on device r.
+int nnhip_ode_solve_batch_multi_gpu_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
+                                            int n_gpus, const int64_t* counts, int dim, int layout, const double* tspan, int n_t, double* t_out,
+                                            const double* const* y0, double* const* y_out, int32_t* const* ny_out, int64_t max_steps,
+                                            void* const* ws, int64_t ws_bytes, double* const* full, void* const* streams, void* const* gather_streams) {
+  int rc = mg_check(n_gpus, counts, nullptr);
+  if (rc) return rc;
+  if (!y0 || !y_out || !streams || !ws) return nnhip::fail_msg(NNHIP_EVALUE, "y0 / y_out / ws / streams is NULL");
+  if (n_gpus > 1 && nnhip::rtc_has_per_ivp_ctx(rhs_kind))
+    return nnhip::fail_msg(NNHIP_EUNSUPPORTED, "rhs_kind %d reads a context block bound to ONE device's memory: bind and solve per device", rhs_kind);
+  int nTOut = 0;
+  rc = nnhip_ode_time_grid(opt, tspan, n_t, t_out, &nTOut);  // (options, tspan) only: once, also when shards are empty
+  if (rc) return rc;
+  std::vector<int> rcs(n_gpus, NNHIP_OK);
+  std::vector<std::string> errs(n_gpus);
+  auto work = [&](int r) {
+    if (hipSetDevice(r) != hipSuccess) { rcs[r] = NNHIP_EHIP; errs[r] = "hipSetDevice failed"; return; }
+    if (counts[r] == 0) return;
+    rcs[r] = nnhip_ode_solve_batch_f64_dev(opt, integrator, rhs_kind, rhs_params, n_params, y0[r], counts[r], dim, layout, tspan, n_t, nullptr, y_out[r],
+                                           ny_out ? ny_out[r] : nullptr, nullptr, nullptr, max_steps, ws[r], ws_bytes, streams[r]);
+    if (rcs[r]) errs[r] = nnhip::thread_error();
+    nnhip::release_thread_staging();
+  };
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  if (n_gpus == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int r = 0; r < n_gpus; ++r) th.emplace_back(work, r);
+    for (auto& t : th) t.join();
+  }
+  (void)hipSetDevice(prev);
+  for (int r = 0; r < n_gpus; ++r) if (rcs[r]) return nnhip::fail_msg(rcs[r], "device %d: %s", r, errs[r].c_str());
+  if (!full || n_t == 0) return NNHIP_OK;
+  std::vector<const double*> sh(n_gpus);
+  std::vector<double*> fu(n_gpus);
+  if (layout == NNHIP_LAYOUT_SOA) {  // [n_t][dim][count] -> [n_t][dim][N]: n_t * dim planes, gathered plane by plane in one group
+    for (int r = 0; r < n_gpus; ++r) { sh[r] = y_out[r]; fu[r] = full[r]; }
+    return mg_gather(n_gpus, sh.data(), counts, n_t * dim, NNHIP_LAYOUT_SOA, fu.data(), streams, gather_streams);
+  }
+  int64_t N = 0;
+  for (int r = 0; r < n_gpus; ++r) N += counts[r];
+  for (int j = 0; j < n_t; ++j) {  // [n_t][count][dim] -> [n_t][N][dim]: one contiguous block per shard and row
+    for (int r = 0; r < n_gpus; ++r) { sh[r] = y_out[r] + (int64_t)j * counts[r] * dim; fu[r] = full[r] + (int64_t)j * N * dim; }
+    rc = mg_gather(n_gpus, sh.data(), counts, dim, NNHIP_LAYOUT_AOS, fu.data(), streams, j == 0 ? gather_streams : nullptr);
+    if (rc) return rc;
+    if (j == 0 && gather_streams) streams = gather_streams;  // the rows after the first follow on the gather streams
+  }
+  return NNHIP_OK;
+}
+
 }  // extern "C"

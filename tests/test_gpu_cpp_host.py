@@ -30,3 +30,22 @@ def test_cpp_device_entries_standalone(nn, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0 and r.stdout.strip().endswith("OK")
+
+
+def test_c5_cpp_harness(nn, tmp_path):
+    """tests/cpp/bench_c5.cpp: config C5 through ONE C call from a process without PyTorch — shards resident per device, step-streaming
+    solve, RCCL reassembly on a second stream — at every device count this box has (1 on the one-GPU boxes), verified, bench.py's JSON keys."""
+    import json
+    import torch
+    exe = str(tmp_path / "bench_c5")
+    libdir = os.path.join(ROOT, "numericalnim_amd", "csrc")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "bench_c5.cpp"), "-L", libdir, "-lnnhip_ode", "-L", "/opt/rocm/lib",
+                           "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    for g in sorted({1, torch.cuda.device_count()}):
+        r = subprocess.run([exe, "--gpus", str(g), "--steps", "3", "--warmup", "1", "--n-per-gpu", "1000000", "--rk4-steps", "200", "--verify"],
+                           capture_output=True, text=True, timeout=600)
+        print(r.stdout[-2000:], r.stderr[-2000:])
+        assert r.returncode == 0
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        assert out["n_gpus"] == g and out["verified"] is True and out["value"] > 1e9 and out["unit"] == "trajectory-steps/s"

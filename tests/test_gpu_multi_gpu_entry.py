@@ -185,3 +185,120 @@ def test_sharded_parameter_sweep(nn, dev, layout, n_shards):
     assert np.array_equal(t_out, tr) and np.array_equal(out, yr)
     assert np.array_equal(ny, cr["ny"]) and np.array_equal(steps, cr["steps"]) and np.array_equal(rej, cr["rejected"])
     assert st.steps_total == int(cr["steps"].sum())
+
+
+def _c5_composite(nn, L, G, counts, n_steps, layout, dim, rhs, params, integ, use_gather_streams):
+    """nnhip_ode_fixed_stream_multi_gpu_f64_dev on G devices; returns (full tensors per device, reference full tensor)."""
+    import torch
+    N = sum(counts)
+    rng = np.random.default_rng(5)
+    y0 = 1.0 + rng.random((dim, N)) if layout == 0 else 1.0 + rng.random((N, dim))
+    dt = 2.0 ** -10
+    opt = nn.newODEoptions(dt=dt)
+    tEnd = n_steps * dt
+    lo = np.concatenate([[0], np.cumsum(counts)])
+    ys, scr, fulls, streams, gstreams = [], [], [], [], []
+    for r in range(G):
+        with torch.cuda.device(r):
+            sh = y0[:, lo[r]:lo[r + 1]] if layout == 0 else y0[lo[r]:lo[r + 1]]
+            ys.append(torch.from_numpy(np.ascontiguousarray(sh)).to(f"cuda:{r}"))
+            scr.append(torch.empty_like(ys[-1]))
+            fulls.append(torch.zeros(y0.shape, dtype=torch.float64, device=f"cuda:{r}"))
+            streams.append(torch.cuda.Stream(device=r))
+            gstreams.append(torch.cuda.Stream(device=r))
+    for r in range(G):
+        torch.cuda.synchronize(r)
+    arr = lambda xs: (C.c_void_p * G)(*xs)
+    pp = np.asarray(params, dtype=np.float64)
+    nst = C.c_int64(0)
+    fin = (C.c_void_p * G)()
+    rc = L.nnhip_ode_fixed_stream_multi_gpu_f64_dev(C.byref(opt), nn.ode.integrator_id(integ), rhs.kind, pp.ctypes.data_as(C.POINTER(C.c_double)) if pp.size else None, int(pp.size),
+                                                    G, (C.c_int64 * G)(*counts), dim, layout, 0.0, tEnd, arr([y.data_ptr() for y in ys]),
+                                                    arr([s.data_ptr() for s in scr]), arr([f.data_ptr() for f in fulls]),
+                                                    arr([s.cuda_stream for s in streams]), arr([s.cuda_stream for s in gstreams]) if use_gather_streams else None,
+                                                    C.byref(nst), fin)
+    assert rc == 0, L.nnhip_last_error()
+    for r in range(G):
+        torch.cuda.synchronize(r)
+    assert nst.value == n_steps
+    for r in range(G):
+        assert fin[r] in (ys[r].data_ptr(), scr[r].data_ptr())
+    with torch.cuda.device(0):
+        t, yref = nn.solveODE(rhs, torch.from_numpy(y0).to("cuda:0"), [0.0, tEnd], opt, integrator=integ, layout=layout)
+    return fulls, yref[-1].cpu().numpy()
+
+
+@pytest.mark.parametrize("gather_streams", [False, True], ids=["same_stream", "gather_stream"])
+@pytest.mark.parametrize("layout,dim", [(0, 1), (0, 3), (1, 3)])
+def test_c5_one_call_single_device_rccl(nn, dev, layout, dim, gather_streams):
+    """BASELINE config C5 behind ONE C entry (nnhip_ode_fixed_stream_multi_gpu_f64_dev): shard resident on its device, step-streaming solve on
+    the device's stream, RCCL reassembly into a device-resident full tensor.  n_gpus = 1 is what a one-GPU box can run: the whole
+    composition incl. ncclCommInitAll / ncclAllGather, against the fused solve."""
+    L = nn._lib.lib()
+    rhs = nn.Rhs.neg_y() if dim == 1 else nn.Rhs.lorenz()
+    params = [] if dim == 1 else LOR
+    fulls, ref = _c5_composite(nn, L, 1, [4096 if dim == 1 else 1500], 64, layout, dim, rhs, params, "rk4", gather_streams)
+    assert np.array_equal(fulls[0].cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("ragged", [False, True], ids=["equal", "ragged"])
+def test_c5_one_call_all_devices(nn, dev, ragged):
+    """The same at n_gpus = device_count (equal shards: ncclAllGather; ragged: grouped ncclBroadcasts), gather overlapped on its own
+    streams.  Needs >= 2 devices: skipped on the one-GPU boxes, runs on the first multi-GPU lease."""
+    import torch
+    G = torch.cuda.device_count()
+    if G < 2:
+        pytest.skip(f"needs >= 2 HIP devices, this box has {G} (the 8-GPU run is the driver's)")
+    L = nn._lib.lib()
+    counts = [3000 + (37 * r if ragged else 0) for r in range(G)]
+    for layout, dim, rhs, params in ((0, 1, nn.Rhs.neg_y(), []), (0, 3, nn.Rhs.lorenz(), LOR), (1, 3, nn.Rhs.lorenz(), LOR)):
+        fulls, ref = _c5_composite(nn, L, G, counts, 100, layout, dim, rhs, params, "rk4", True)
+        for r in range(G):
+            assert np.array_equal(fulls[r].cpu().numpy(), ref), (r, layout, dim)
+
+
+@pytest.mark.parametrize("layout", [0, 1], ids=["soa", "aos"])
+def test_fused_solve_multi_gpu_dev_one_call(nn, dev, layout):
+    """nnhip_ode_solve_batch_multi_gpu_f64_dev: device-resident shards, fused adaptive solve with a dense tspan per device, the whole
+    trajectory tensor reassembled on every device.  Runs at n_gpus = 1 everywhere and at device_count where there are more."""
+    import torch
+    L = nn._lib.lib()
+    for G in sorted({1, torch.cuda.device_count()}):
+        counts = [700 + 13 * r for r in range(G)]
+        N, dim = sum(counts), 3
+        rng = np.random.default_rng(6)
+        y0 = np.stack([1.0 + rng.random(N), np.ones(N), np.ones(N)])
+        y0l = np.ascontiguousarray(y0 if layout == 0 else y0.T)
+        ts = np.array([-0.1, 0.0, 0.2, 0.3, 0.45])
+        n_t = len(ts)
+        opt = nn.newODEoptions()
+        lo = np.concatenate([[0], np.cumsum(counts)])
+        y0s, outs, nys, wss, fulls, streams = [], [], [], [], [], []
+        wsb = int(L.nnhip_ode_solve_workspace_bytes(n_t))
+        for r in range(G):
+            with torch.cuda.device(r):
+                sh = y0l[:, lo[r]:lo[r + 1]] if layout == 0 else y0l[lo[r]:lo[r + 1]]
+                y0s.append(torch.from_numpy(np.ascontiguousarray(sh)).to(f"cuda:{r}"))
+                outs.append(torch.empty((n_t,) + tuple(y0s[-1].shape), dtype=torch.float64, device=f"cuda:{r}"))
+                nys.append(torch.empty(counts[r], dtype=torch.int32, device=f"cuda:{r}"))
+                wss.append(torch.empty(max(wsb, 8), dtype=torch.uint8, device=f"cuda:{r}"))
+                fulls.append(torch.zeros((n_t,) + y0l.shape, dtype=torch.float64, device=f"cuda:{r}"))
+                streams.append(torch.cuda.Stream(device=r))
+        for r in range(G):
+            torch.cuda.synchronize(r)
+        arr = lambda xs: (C.c_void_p * G)(*xs)
+        p = np.asarray(LOR)
+        t_out = np.empty(n_t)
+        rc = L.nnhip_ode_solve_batch_multi_gpu_f64_dev(C.byref(opt), nn.ode.integrator_id("tsit54"), nn.Rhs.LORENZ, p.ctypes.data_as(C.POINTER(C.c_double)), 3, G,
+                                                       (C.c_int64 * G)(*counts), dim, layout, ts.ctypes.data_as(C.POINTER(C.c_double)), n_t,
+                                                       t_out.ctypes.data_as(C.POINTER(C.c_double)), arr([y.data_ptr() for y in y0s]),
+                                                       arr([o.data_ptr() for o in outs]), arr([q.data_ptr() for q in nys]), 0, arr([w.data_ptr() for w in wss]),
+                                                       wsb, arr([f.data_ptr() for f in fulls]), arr([s.cuda_stream for s in streams]), None)
+        assert rc == 0, L.nnhip_last_error()
+        for r in range(G):
+            torch.cuda.synchronize(r)
+        with torch.cuda.device(0):
+            tr, yr = nn.solveODE(nn.Rhs.lorenz(), torch.from_numpy(y0l).to("cuda:0"), ts, opt, integrator="tsit54", layout=layout)
+        assert np.array_equal(t_out[:len(tr)], tr)
+        for r in range(G):
+            assert np.array_equal(fulls[r].cpu().numpy(), yr.cpu().numpy()), (G, r)
