@@ -1626,6 +1626,38 @@ int adv_issue_group(nnhip::StepLaunchFn fn, int userKind, int integrator, const 
   }
   return NNHIP_OK;
 }
+
+// The polling group `issue()` enqueues on `s`, as a cached hipGraph (nullptr: not available — the caller issues eagerly).  rc receives
+// the status of `issue` when it had to be run for the capture.
+template <class IssueFn>
+hipGraphExec_t adv_cached_graph(const AdvGraphKey& key, hipStream_t s, IssueFn&& issue, int& rc) {
+  rc = NNHIP_OK;
+  {
+    std::lock_guard<std::mutex> lk(g_graph_mu);
+    for (auto& e : g_adv_graphs)
+      if (std::memcmp(&e.key, &key, sizeof(key)) == 0) return e.exec;
+  }
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return nullptr; }  // e.g. the caller is capturing this stream itself
+  rc = issue();
+  const hipError_t ce = hipStreamEndCapture(s, &graph);
+  if (rc) { if (graph) (void)hipGraphDestroy(graph); return nullptr; }
+  if (ce != hipSuccess || !graph) { (void)hipGetLastError(); return nullptr; }
+  const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (ie != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  std::lock_guard<std::mutex> lk(g_graph_mu);
+  if (g_adv_graphs.size() >= 32) {  // evict the oldest; it may still be executing
+    sync_device_of(g_adv_graphs.front().key.device);
+    (void)hipGraphExecDestroy(g_adv_graphs.front().exec);
+    g_adv_graphs.erase(g_adv_graphs.begin());
+  }
+  AdvGraphEntry e;
+  e.key = key; e.exec = exec;
+  g_adv_graphs.push_back(e);
+  return exec;
+}
 }  // namespace
 
 extern "C" {
@@ -1697,45 +1729,13 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
       std::memset(&key, 0, sizeof(key));
       std::memcpy(&key.a, &a, sizeof(a));
       key.fn = (const void*)fn; key.active = flags; key.userKind = userKind; key.integrator = integrator; key.checkEvery = check_every; key.device = device; key.split = split; key.stream = s;
-      hipGraphExec_t exec = nullptr;
-      {
-        std::lock_guard<std::mutex> lk(g_graph_mu);
-        for (auto& e : g_adv_graphs)
-          if (std::memcmp(&e.key, &key, sizeof(key)) == 0) { exec = e.exec; break; }
+      if (fn == nullptr) {  // run-time compiled kernels: make sure the module is loaded before the stream goes into capture mode
+        nnhip::StepArgs warm = a;
+        warm.N = 0;
+        (void)nnhip::rtc_launch_advance(userKind, integrator, warm, s);
       }
-      if (!exec) {
-        if (fn == nullptr) {  // run-time compiled kernels: make sure the module is loaded before the stream goes into capture mode
-          nnhip::StepArgs warm = a;
-          warm.N = 0;
-          (void)nnhip::rtc_launch_advance(userKind, integrator, warm, s);
-        }
-        hipGraph_t graph = nullptr;
-        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-          rc = adv_issue_group(fn, userKind, integrator, a, flags, check_every, split, s);
-          const hipError_t ce = hipStreamEndCapture(s, &graph);
-          if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-          if (ce == hipSuccess && graph) {
-            const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            if (ie != hipSuccess) { exec = nullptr; (void)hipGetLastError(); }
-          } else {
-            (void)hipGetLastError();
-          }
-        } else {
-          (void)hipGetLastError();  // e.g. the caller is capturing this stream itself: plain launches below
-        }
-        if (exec) {
-          std::lock_guard<std::mutex> lk(g_graph_mu);
-          if (g_adv_graphs.size() >= 32) {  // evict the oldest; it may still be executing
-            sync_device_of(g_adv_graphs.front().key.device);
-            (void)hipGraphExecDestroy(g_adv_graphs.front().exec);
-            g_adv_graphs.erase(g_adv_graphs.begin());
-          }
-          AdvGraphEntry e;
-          e.key = key; e.exec = exec;
-          g_adv_graphs.push_back(e);
-        }
-      }
+      hipGraphExec_t exec = adv_cached_graph(key, s, [&]() { return adv_issue_group(fn, userKind, integrator, a, flags, check_every, split, s); }, rc);
+      if (rc) return rc;
       execs[half] = exec;
     }
     if (!execs[0] || !execs[1]) execs[0] = execs[1] = nullptr;
@@ -1821,7 +1821,6 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
   double* lastT = errArr + N;
   double* tReqDev = lastT + N;                       // n_t doubles (+ padding)
   int32_t* denseIdx = (int32_t*)(tReqDev + n_t + 8);
-  unsigned int* active = (unsigned int*)(denseIdx + N + 2);
   // requested times of both directions, as the reference holds them
   const int nPos = (int)g.tPos.size(), nNeg = (int)g.tNeg.size();
   if (nPos + nNeg > 0) {
@@ -1844,6 +1843,8 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
   a.t_io = tArr; a.dt_io = dtArr;
   a.denseIdx_io = denseIdx; a.lastT_io = lastT; a.lastY_io = lastY; a.lastDy_io = lastDy;
   a.rows = y_out; a.rowStride = nState;
+  // state + Hermite history of one launch beyond the Infinity Cache: non-temporal instantiation (thread-per-IVP kernels; knob "adv_nontemporal")
+  a.nontemporal = g_adv_nt >= 0 ? g_adv_nt : ((dim <= 4 && (int64_t)sizeof(double) * (4 * dim + 4) * N > (192LL << 20)) ? 1 : 0);
   if (check_every <= 0) check_every = 8;
   const double dtInit = std::sqrt(opt->dtMax * opt->dtMin);  // :491-493
   const dim3 grid((unsigned)((N + nnhip::kBlock - 1) / nnhip::kBlock)), block(nnhip::kBlock);
@@ -1880,16 +1881,47 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
     if (r) return r;
     // groups of check_every launches; the host reads group g's "anyone still integrating?" flags while group g + 1 runs (a retired
     // IVP returns at once, so the one group issued past the end costs only its launches)
-    auto issue = [&](int64_t grp) -> int {
-      HIP_TRY(hipMemsetAsync(active, 0, nnhip::kAggSlots * sizeof(unsigned int), s));
+    // the last launch of a group stores the flags straight into page-locked host memory (no memset / copy nodes); the groups replay
+    // as hipGraphs, one per half of the flag block, as the loop without dense output does
+    auto issue_group = [&](unsigned int* flags) -> int {
       for (int k = 0; k < check_every; ++k) {
-        run.active = k == check_every - 1 ? active : nullptr;
+        run.active = k == check_every - 1 ? flags : nullptr;
         const int ra = advance(run);
         if (ra) return ra;
-        ++launches;
       }
-      HIP_TRY(hipMemcpyAsync(poll.h + (grp & 1) * nnhip::kAggSlots, active, nnhip::kAggSlots * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipEventRecord(poll.ev[grp & 1], s));
+      return NNHIP_OK;
+    };
+    hipGraphExec_t execs[2] = {nullptr, nullptr};
+    if (g_stream_graph != 0 && s != nullptr) {
+      int device = 0;
+      HIP_TRY(hipGetDevice(&device));
+      if (!fn.advance) {  // run-time compiled kernels: load the module before the stream goes into capture mode
+        nnhip::StepArgs warm = run;
+        warm.N = 0; warm.active = nullptr;
+        (void)nnhip::rtc_launch_advance_dense(userKind, integrator, warm, s);
+      }
+      for (int half = 0; half < 2; ++half) {
+        unsigned int* flags = poll.h + half * nnhip::kAggSlots;
+        AdvGraphKey key;
+        std::memset(&key, 0, sizeof(key));
+        run.active = nullptr;
+        std::memcpy(&key.a, &run, sizeof(run));
+        key.fn = (const void*)fn.advance; key.active = flags; key.userKind = userKind; key.integrator = integrator; key.checkEvery = check_every;
+        key.device = device; key.split = -1 /* dense */; key.stream = s;
+        int rcg = NNHIP_OK;
+        execs[half] = adv_cached_graph(key, s, [&]() { return issue_group(flags); }, rcg);
+        if (rcg) return rcg;
+      }
+      if (!execs[0] || !execs[1]) execs[0] = execs[1] = nullptr;
+    }
+    auto issue = [&](int64_t grp) -> int {
+      const int half = (int)(grp & 1);
+      unsigned int* flags = poll.h + half * nnhip::kAggSlots;
+      std::memset(flags, 0, nnhip::kAggSlots * sizeof(unsigned int));  // host memory; the group that last wrote this half has been waited for
+      if (execs[half]) HIP_TRY(hipGraphLaunch(execs[half], s));
+      else { const int ra = issue_group(flags); if (ra) return ra; }
+      launches += check_every;
+      HIP_TRY(hipEventRecord(poll.ev[half], s));
       return NNHIP_OK;
     };
     int64_t grp = 0;

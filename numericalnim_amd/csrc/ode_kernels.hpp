@@ -947,7 +947,9 @@ __global__ __launch_bounds__(kBlock) void advance_dense_init_kernel(const StepAr
 
 // One loop iteration of one IVP; `ops` owns D of its components (all of them: thread-per-IVP; CPL: lanes-per-system — the lanes
 // of a system read the same per-IVP scalars, so they take every branch together; the `lead` lane stores the scalars).
-template <int METHOD, class OPS>
+// NT: non-temporal hint on the streamed arrays (state and Hermite history), chosen by the host from the working-set size like the
+// loop without dense output (a template parameter: see StepArgs::nontemporal)
+template <int METHOD, bool NT = false, class OPS>
 NNHIP_DEV unsigned int advance_dense_body(const StepArgs& a, const OPS& ops, int64_t i, int64_t base, bool lead, bool neg) {
   constexpr int D = OPS::D;
   using MT = MethodTraits<METHOD>;
@@ -957,8 +959,8 @@ NNHIP_DEV unsigned int advance_dense_body(const StepArgs& a, const OPS& ops, int
   double y[D], yNew[D], fsal[D];
 #pragma unroll
   for (int c = 0; c < D; ++c) {
-    y[c] = ops.owns(c) ? a.y_in[base + c * cs] : 0.0;
-    fsal[c] = ops.owns(c) ? a.fsal_in[base + c * cs] : 0.0;
+    y[c] = ops.owns(c) ? ld_state<NT>(&a.y_in[base + c * cs]) : 0.0;
+    fsal[c] = ops.owns(c) ? ld_state<NT>(&a.fsal_in[base + c * cs]) : 0.0;
   }
   double dt = a.dt_io[i];
   int denseIndex = a.denseIdx_io[i];
@@ -1009,13 +1011,13 @@ NNHIP_DEV unsigned int advance_dense_body(const StepArgs& a, const OPS& ops, int
     if constexpr (MT::fsal) {
 #pragma unroll
       for (int c = 0; c < D; ++c)
-        if (ops.owns(c)) { a.lastY_io[base + c * cs] = y[c]; a.lastDy_io[base + c * cs] = fsal[c]; }
+        if (ops.owns(c)) { st_state<NT>(y[c], &a.lastY_io[base + c * cs]); st_state<NT>(fsal[c], &a.lastDy_io[base + c * cs]); }
     } else {
       double dy0[D];
       ops.rhs(t, y, dy0);
 #pragma unroll
       for (int c = 0; c < D; ++c)
-        if (ops.owns(c)) { a.lastY_io[base + c * cs] = y[c]; a.lastDy_io[base + c * cs] = dy0[c]; }
+        if (ops.owns(c)) { st_state<NT>(y[c], &a.lastY_io[base + c * cs]); st_state<NT>(dy0[c], &a.lastDy_io[base + c * cs]); }
     }
   }
   double error = 0.0, factor;
@@ -1029,7 +1031,7 @@ NNHIP_DEV unsigned int advance_dense_body(const StepArgs& a, const OPS& ops, int
   if (error != error) t = a.tEnd;  // NaN abort, as in the fused driver
 #pragma unroll
   for (int c = 0; c < D; ++c)
-    if (ops.owns(c)) { a.y_out[base + c * cs] = yNew[c]; a.fsal_out[base + c * cs] = fsal[c]; }
+    if (ops.owns(c)) { st_state<NT>(yNew[c], &a.y_out[base + c * cs]); st_state<NT>(fsal[c], &a.fsal_out[base + c * cs]); }
   if (lead) {
     a.t_io[i] = t;
     a.dt_io[i] = dt;
@@ -1039,7 +1041,7 @@ NNHIP_DEV unsigned int advance_dense_body(const StepArgs& a, const OPS& ops, int
   return t < a.tEnd ? 1u : 0u;
 }
 
-template <int METHOD, class RHS>
+template <int METHOD, class RHS, bool NT = false>
 __global__ __launch_bounds__(kBlock) void advance_dense_tpi_kernel(const StepArgs a) {
   static_assert(MethodTraits<METHOD>::adaptive, "adaptive methods only");
   controller_prologue();
@@ -1049,7 +1051,7 @@ __global__ __launch_bounds__(kBlock) void advance_dense_tpi_kernel(const StepArg
     const Params P = params_of(a, i);
     const bool neg = a.negate != 0;
     const TpiOpsRt<RHS> ops{P, neg};
-    stillActive = advance_dense_body<METHOD>(a, ops, i, i * a.ivpStride, true, neg);
+    stillActive = advance_dense_body<METHOD, NT>(a, ops, i, i * a.ivpStride, true, neg);
   }
   if (a.active) {
     if (__syncthreads_or((int)stillActive) && threadIdx.x == 0) a.active[blockIdx.x % kAggSlots] = 1u;
@@ -1526,6 +1528,7 @@ hipError_t launch_advance_dense(const StepArgs& a, hipStream_t s) {
   if constexpr (MethodTraits<METHOD>::adaptive) {
     const int64_t grid = (a.N + kBlock - 1) / kBlock;
     if (grid <= 0) return hipSuccess;
+    if (a.nontemporal) return launch_kernel(advance_dense_tpi_kernel<METHOD, RHS, true>, dim3((unsigned)grid), dim3(kBlock), s, a);
     return launch_kernel(advance_dense_tpi_kernel<METHOD, RHS>, dim3((unsigned)grid), dim3(kBlock), s, a);
   } else {
     return hipErrorInvalidValue;

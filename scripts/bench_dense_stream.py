@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""The dense adaptive streaming driver (nnhip_ode_adaptive_stream_dense_f64_dev: ODESolver INCLUDING the emission block ode.nim:512-530 through
+the IntegratorProc seam, per-IVP Hermite history resident in HBM) against its own byte model and against the loop without dense output.
+
+  bytes per attempted step   8*(4d+5)   state in/out (y, FSAL, t, dt, error)          as the non-dense loop
+                           + 8*(2d+1)   lastIter = (t, y, dy) written per step (:526-530)
+  bytes per emitted row      8*d        the row itself (the history it interpolates from was read with the step that passed it: + 8*(2d+1) read)
+
+C3 shape (Lorenz, SoA, default options), 1e6 and 1e7 IVPs, 11 and 101 requested times; hipGraph-replayed polling groups and eager launches.
+Wall clock of the whole call (both init kernels, every polling group, the finalize kernels, the speculative tail group), best of 3."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import numericalnim_amd as nn
+
+dev = torch.device("cuda:0")
+L = nn._lib.lib()
+side = torch.cuda.Stream()
+res = {}
+d = 3
+for n in (1_000_000, 10_000_000):
+    y0 = torch.from_numpy(np.stack([1.0 + (np.arange(n) % 1024) * 2.0 ** -20, np.ones(n), np.ones(n)])).to(dev)
+    for integ in ("dopri54", "tsit54"):
+        t2, y2, cnt = nn.solveODE(nn.Rhs.lorenz(), y0, [0.0, 1.0], nn.newODEoptions(), integrator=integ, return_counts=True)
+        iters = int(cnt["steps"].max())
+        attempted = int(cnt["steps"].sum() + cnt["rejected"].sum())
+        # the loop WITHOUT dense output, same call pattern, for the ratio
+        base = None
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                y = y0.clone()
+                side.synchronize()
+                c0 = time.perf_counter()
+                nn.adaptiveStream(nn.Rhs.lorenz(), y, 0.0, 1.0, nn.newODEoptions(), integrator=integ)
+                side.synchronize()
+                dt_ = time.perf_counter() - c0
+                base = dt_ if base is None or dt_ < base else base
+        for n_t in (11, 101):
+            ts = np.linspace(0.0, 1.0, n_t)
+            tf, yf = nn.solveODE(nn.Rhs.lorenz(), y0, ts, nn.newODEoptions(), integrator=integ)
+            for mode, knob in (("graph", 2), ("eager", 0)):
+                L.nnhip_tune_set(b"stream_graph", knob)
+                best, out = None, None
+                with torch.cuda.stream(side):
+                    for _ in range(4):  # first call: capture
+                        side.synchronize()
+                        c0 = time.perf_counter()
+                        t, y, ny, launches = nn.adaptiveStreamSolve(nn.Rhs.lorenz(), y0, ts, nn.newODEoptions(), integrator=integ)
+                        side.synchronize()
+                        dt_ = time.perf_counter() - c0
+                        if best is None or dt_ < best:
+                            best, out = dt_, (y, launches)
+                rows = (n_t - 1) * n  # emitted rows besides y0's own (t0 is in tspan)
+                nbytes = attempted * (8 * (4 * d + 5) + 8 * (2 * d + 1)) + rows * (8 * d + 8 * (2 * d + 1))
+                res[f"C3_N{n:.0e}_{integ}_nt{n_t}_{mode}"] = dict(
+                    ms=best * 1e3, launches=out[1], iterations=iters, us_per_iteration=best * 1e6 / iters, GBps=nbytes / best / 1e9,
+                    frac_of_8TBps=nbytes / best / 8e12, bytes_model="attempted*(8(4d+5)+8(2d+1)) + rows*(8d+8(2d+1))",
+                    nondense_stream_ms=base * 1e3, ratio_to_nondense=best / base, equal_to_fused=bool(torch.equal(out[0], yf)))
+            L.nnhip_tune_set(b"stream_graph", 2)
+print(json.dumps(res, indent=1))
