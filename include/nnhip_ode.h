@@ -113,6 +113,8 @@ int nnhip_host_free(void* p);
  *   "adv_steps_per_launch" 1..1024 (loop iterations of ode.nim:525-541 per IVP and launch of nnhip_ode_adaptive_stream_f64_dev; default 1 = one
  *   IntegratorProc call per launch, state through HBM between any two; K > 1 keeps an IVP's state in registers for up to K iterations:
  *   the same bits, 1/K of the launches and 8*(4d+5)/K bytes per attempted step — a different traffic model, never quoted against the one-per-launch figures),
+ *   "sort_copy" 0|1 (1: the binned solve nnhip_ode_solve_batch_sorted_f64[_dev] gathers the batch into integration order, solves it with
+ *   coalesced accesses and scatters the results back; default 0: the solve kernel follows the order array itself — measured faster),
  *   "fixed_vec_ipl" 0|2 (0 = one IVP per lane instead of the vectorised fixed-step streaming kernel),
  *   "multi_gpu_oversubscribe" 0|1 (nnhip_ode_solve_batch_multi_gpu_f64 accepts more shards than devices: shard r on device r mod #devices),
  *   "dim16_variant" 0..4 (A/B mappings of the fused 16-component kernels), "fp_contract" 0|1 (opt-in FMA-contracted fused

@@ -68,6 +68,10 @@ int g_mg_oversubscribe = 0;  // tuning knob "multi_gpu_oversubscribe": the multi
                              // r mod #devices) — lets a one-GPU box exercise the sharded code path (index ranges, strided copies, empty shards)
 int g_adv_nt = -1;        // tuning knob "adv_nontemporal": -1 = automatic (thread-per-IVP state beyond 192 MiB), 0 / 1 = force
 int g_adv_block = 0;      // tuning knob "adv_block": workgroup size of the thread-per-IVP advance kernel (0 = auto: 64 with the non-temporal instantiation, else 256)
+int g_sort_copy = 0;      // tuning knob "sort_copy": the binned solve reorders the batch physically (gather, solve, scatter) instead of following perm[] inside the
+                          // kernel.  Measured and NOT the default (profiles/r03_bench_divergence.json, 1e6 Van der Pol IVPs): 1.77 ms against 1.65 ms with the
+                          // order array followed in the kernel (pre-sorted by the caller: 1.52) — the five extra kernels and the stream-ordered allocation cost
+                          // more than the scattered first load and last stores they remove
 int g_adv_steps = 1;      // tuning knob "adv_steps_per_launch": loop iterations per IVP and launch of nnhip_ode_adaptive_stream_f64_dev (1 = the IntegratorProc
                           // seam proper; K > 1 keeps the state in registers for K iterations: 8*(4d+5)/K bytes per attempted step, a different traffic model)
 int g_adv_split = 0;      // tuning knob "adv_split": index ranges the adaptive streaming loop interleaves on separate streams (0 = auto, 1, 2, 4)
@@ -286,6 +290,10 @@ hipError_t launch_fill_f64(double* p, int64_t n, double v, hipStream_t s);
 int64_t argsort_workspace_bytes(int64_t N);
 hipError_t argsort_f64(const double* keys, int64_t N, uint32_t* perm_out, void* ws, int64_t ws_bytes, hipStream_t s);
 hipError_t negate_f64(const double* in, double* out, int64_t N, hipStream_t s);
+hipError_t gather_f64(const double* src, double* dst, const uint32_t* perm, int64_t N, int R, int W, hipStream_t s);
+hipError_t scatter_f64(const double* src, double* dst, const uint32_t* perm, int64_t N, int R, int W, hipStream_t s);
+hipError_t scatter_i32(const int32_t* src, int32_t* dst, const uint32_t* perm, int64_t N, hipStream_t s);
+hipError_t scatter_i64(const int64_t* src, int64_t* dst, const uint32_t* perm, int64_t N, hipStream_t s);
 hipError_t prepare_tspans(const double* tspans, int n_t, int64_t N, const double* tStart, double t0, double* grid, int32_t* counts, double* t_out,
                           hipStream_t s);
 void multigpu_release();  // ode_multigpu.hip
@@ -385,6 +393,7 @@ int nnhip_tune_set(const char* key, int value) {
   if (k == "multi_gpu_oversubscribe") { g_mg_oversubscribe = value != 0; return NNHIP_OK; }
   if (k == "adv_nontemporal") { if (value < -1 || value > 1) return fail(NNHIP_EVALUE, "adv_nontemporal must be -1, 0 or 1"); g_adv_nt = value; return NNHIP_OK; }
   if (k == "adv_block") { if (value != 0 && value != 64 && value != 128 && value != 256) return fail(NNHIP_EVALUE, "adv_block must be 0, 64, 128 or 256"); g_adv_block = value; release_adv_graphs(); return NNHIP_OK; }
+  if (k == "sort_copy") { g_sort_copy = value != 0; return NNHIP_OK; }
   if (k == "adv_steps_per_launch") { if (value < 1 || value > 1024) return fail(NNHIP_EVALUE, "adv_steps_per_launch must be 1..1024"); g_adv_steps = value; return NNHIP_OK; }
   if (k == "adv_split") { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(NNHIP_EVALUE, "adv_split must be 0, 1, 2 or 4"); g_adv_split = value; return NNHIP_OK; }
   if (k == "dim16_variant") { if (value < 0 || value > 4) return fail(NNHIP_EVALUE, "dim16_variant must be 0..4"); g_dim16_variant = value; return NNHIP_OK; }
@@ -824,6 +833,37 @@ int nnhip_ode_solve_batch_sorted_f64_dev(const nnhip_ode_options* opt, int integ
       sort_key = key;
     }
     HIP_TRY(nnhip::argsort_f64(sort_key, N, perm, sortWs, sortWsBytes, s));
+  }
+  if (adaptive && N > 1 && g_sort_copy && dim >= 1) {
+    // The batch in integration order, physically: gather y0 (and the per-IVP parameter table), solve with coalesced accesses, scatter the
+    // rows and counters back to the caller's order.  Temporaries come from the stream-ordered allocator; if that fails the solve
+    // kernel follows `perm` itself (SolveArgs::perm, below).
+    const size_t nState = (size_t)N * (size_t)dim, nOut = nState * (size_t)(n_t > 0 ? n_t : 0);
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t oY0 = 0, oOut = oY0 + up(nState * 8), oPer = oOut + up(nOut * 8), oNy = oPer + up((size_t)(n_per_ivp > 0 ? n_per_ivp : 0) * (size_t)N * 8),
+                 oSt = oNy + up((size_t)N * 4), oRj = oSt + up((size_t)N * 8), total = oRj + up((size_t)N * 8);
+    char* d = nullptr;
+    if (hipMallocAsync((void**)&d, total, s) == hipSuccess && d) {
+      const int R0 = layout == NNHIP_LAYOUT_SOA ? dim : 1, W0 = layout == NNHIP_LAYOUT_SOA ? 1 : dim;
+      auto bail = [&](int code) { (void)hipFreeAsync(d, s); return code; };
+      if (nnhip::gather_f64(y0, (double*)(d + oY0), perm, N, R0, W0, s) != hipSuccess) return bail(fail(NNHIP_EHIP, "gathering y0 into integration order failed"));
+      if (n_per_ivp > 0 && nnhip::gather_f64(per_ivp_params, (double*)(d + oPer), perm, N, n_per_ivp, 1, s) != hipSuccess)
+        return bail(fail(NNHIP_EHIP, "gathering the per-IVP parameters into integration order failed"));
+      int rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, n_per_ivp > 0 ? (const double*)(d + oPer) : nullptr, n_per_ivp, (const double*)(d + oY0), N, dim,
+                             layout, tspan, n_t, t_out, (double*)(d + oOut), ny_out ? (int32_t*)(d + oNy) : nullptr, steps_out ? (int64_t*)(d + oSt) : nullptr,
+                             rejected_out ? (int64_t*)(d + oRj) : nullptr, max_steps, ws, wsTimes, nullptr, nullptr, s, ps);
+      if (rc) return bail(rc);
+      if (ps.a.P.ivp || ps.a.P.aux) return bail(fail(NNHIP_EUNSUPPORTED, "a right-hand side with a per-IVP context block is not available in the binned solve"));
+      rc = launch_solve_range(ps, 0, N, s);
+      if (rc) return bail(rc);
+      bool ok = nnhip::scatter_f64((const double*)(d + oOut), y_out, perm, N, (layout == NNHIP_LAYOUT_SOA ? dim : 1) * n_t, W0, s) == hipSuccess;
+      if (ny_out) ok = ok && nnhip::scatter_i32((const int32_t*)(d + oNy), ny_out, perm, N, s) == hipSuccess;
+      if (steps_out) ok = ok && nnhip::scatter_i64((const int64_t*)(d + oSt), steps_out, perm, N, s) == hipSuccess;
+      if (rejected_out) ok = ok && nnhip::scatter_i64((const int64_t*)(d + oRj), rejected_out, perm, N, s) == hipSuccess;
+      (void)hipFreeAsync(d, s);
+      return ok ? NNHIP_OK : fail(NNHIP_EHIP, "scattering the results back to the caller's order failed");
+    }
+    (void)hipGetLastError();
   }
   int rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y0, N, dim, layout, tspan, n_t, t_out, y_out, ny_out,
                          steps_out, rejected_out, max_steps, ws, wsTimes, nullptr, nullptr, s, ps);

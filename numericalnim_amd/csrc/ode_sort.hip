@@ -1,11 +1,11 @@
 // ode_sort.hip — order of integration for divergence binning: a stable argsort of one float64 key per IVP on the device
-// (hipCUB radix sort of (key, index) pairs).  Used by nnhip_ode_solve_batch_sorted_f64_dev (ode_capi.hip): the fused adaptive
+// (rocPRIM radix sort of (key, index) pairs, called directly: no CUB-shaped layer in between).  Used by nnhip_ode_solve_batch_sorted_f64_dev (ode_capi.hip): the fused adaptive
 // kernels integrate IVP perm[k] in work item k, so lanes of a wavefront hold IVPs with similar step sequences.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <cstdint>
-#include <cstdio>
 
 namespace nnhip {
 
@@ -15,17 +15,18 @@ __global__ void negate_kernel(const double* in, double* out, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { const double v = in[i]; out[i] = (v == v) ? -v : __longlong_as_double(0x7ff0000000000000LL); }
 }
-// Binning needs the ORDER of the keys only coarsely: a float64 key is narrowed to the top 16 bits of its float32 image in
-// order-preserving unsigned form (sign, exponent, 7 mantissa bits: 128 bins per octave, so skewed key distributions still spread) —
-// 2 radix passes instead of 8 (1e6 keys: 21 sort kernels / 170 us -> measured in profiles/r02_bench_divergence.json).  IVPs whose keys
-// share a bin keep the caller's relative order (stable sort), as good a binning as any.
-__global__ void narrow_keys_kernel(const double* in, uint16_t* out, uint32_t* iota, int64_t n) {
+// Binning needs the ORDER of the keys, not their values: a float64 key is narrowed to its float32 image in order-preserving unsigned
+// form and the pairs are sorted on all 32 bits (4 radix passes).  Round 2 kept only the top 16 bits (sign, exponent, 7 mantissa bits:
+// 2 passes, ~35 us less at 1e6 keys) — but keys with a small RELATIVE spread (mu in [100, 101], probe progress in [0.10, 0.12]) then
+// fell into one or two bins and the "sorted" order was the caller's: the speed-up vanished silently.  float32 resolves 2^-24 of the
+// key's magnitude; IVPs whose keys still tie keep the caller's relative order (stable sort).
+__global__ void narrow_keys_kernel(const double* in, uint32_t* out, uint32_t* iota, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     const double v = in[i];
-    uint32_t b = __float_as_uint((v == v) ? (float)v : __int_as_float(0x7f800000));  // NaN keys sort last
+    uint32_t b = __float_as_uint((v == v) ? (float)v : __int_as_float(0x7f800000));  // NaN keys sort last (with +inf)
     b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);                                  // IEEE order -> unsigned order
-    out[i] = (uint16_t)(b >> 16);
+    out[i] = b;
     iota[i] = (uint32_t)i;
   }
 }
@@ -83,37 +84,62 @@ hipError_t prepare_tspans(const double* tspans, int n_t, int64_t N, const double
   return hipLaunchKernel((const void*)prepare_tspans_kernel, dim3((unsigned)((N + 127) / 128)), dim3(128), args, 0, s);
 }
 
-// layout of the workspace: [keys_in: 2N][keys_out: 2N][iota: 4N][cub temp]
+// layout of the workspace: [keys_in: 4N][keys_out: 4N][iota: 4N][rocPRIM temp]
 int64_t argsort_workspace_bytes(int64_t N) {
   if (N <= 0) return 0;
   size_t temp = 0;
-  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const uint16_t*)nullptr, (uint16_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                           (int)N);
-  return (int64_t)(2 * align256((size_t)N * 2) + align256((size_t)N * 4) + align256(temp) + 256);
+  (void)rocprim::radix_sort_pairs(nullptr, temp, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)N, 0, 32);
+  return (int64_t)(3 * align256((size_t)N * 4) + align256(temp) + 256);
 }
 
-// perm_out[k] = index of the k-th smallest key (stable).  N < 2^31.
+// perm_out[k] = index of the k-th smallest key (stable).  N < 2^31.  Failures come back as the hipError_t; the C entry that called turns
+// them into its NNHIP_* code and thread-local message (nothing is printed from here).
 hipError_t argsort_f64(const double* keys, int64_t N, uint32_t* perm_out, void* ws, int64_t ws_bytes, hipStream_t s) {
   if (N <= 0) return hipSuccess;
-  if (N >= (int64_t)1 << 31 || ws_bytes < argsort_workspace_bytes(N)) {
-    fprintf(stderr, "argsort_f64: N=%lld ws_bytes=%lld need=%lld\n", (long long)N, (long long)ws_bytes, (long long)argsort_workspace_bytes(N));
-    return hipErrorInvalidValue;
-  }
+  if (N >= (int64_t)1 << 31 || ws_bytes < argsort_workspace_bytes(N)) return hipErrorInvalidValue;
   char* base = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-  uint16_t* keysIn = (uint16_t*)base;
-  uint16_t* keysOut = (uint16_t*)(base + align256((size_t)N * 2));
-  uint32_t* iota = (uint32_t*)(base + 2 * align256((size_t)N * 2));
-  void* temp = base + 2 * align256((size_t)N * 2) + align256((size_t)N * 4);
+  uint32_t* keysIn = (uint32_t*)base;
+  uint32_t* keysOut = (uint32_t*)(base + align256((size_t)N * 4));
+  uint32_t* iota = (uint32_t*)(base + 2 * align256((size_t)N * 4));
+  void* temp = base + 3 * align256((size_t)N * 4);
   size_t tempBytes = (size_t)ws_bytes - (size_t)((char*)temp - (char*)ws);
   {  // hipLaunchKernel's own status (hipGetLastError() can hand back a stale error of an unrelated earlier call)
     void* args[] = {(void*)&keys, (void*)&keysIn, (void*)&iota, (void*)&N};
     const hipError_t e = hipLaunchKernel((const void*)narrow_keys_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), args, 0, s);
     if (e != hipSuccess) return e;
   }
-  const hipError_t e2 = hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, keysIn, keysOut, iota, perm_out, (int)N, 0, 16, s);
-  if (e2 != hipSuccess) fprintf(stderr, "argsort_f64: SortPairs failed: %s (N=%lld tempBytes=%zu)\n", hipGetErrorString(e2), (long long)N, tempBytes);
-  return e2;
+  return rocprim::radix_sort_pairs(temp, tempBytes, keysIn, keysOut, iota, perm_out, (size_t)N, 0, 32, s);
 }
+
+namespace {
+// arrays viewed as [R][N][W]: GATHER dst[r][k][w] = src[r][perm[k]][w];  else (scatter) dst[r][perm[k]][w] = src[r][k][w]
+template <class T, bool GATHER>
+__global__ void permute_kernel(const T* __restrict__ src, T* __restrict__ dst, const uint32_t* __restrict__ perm, int64_t N, int R, int W) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // element (k, w) of one [N][W] plane
+  if (e >= N * W) return;
+  const int64_t k = e / W;
+  const int w = (int)(e - k * W);
+  const int64_t o = (int64_t)perm[k] * W + w;
+  for (int r = 0; r < R; ++r) {
+    const int64_t plane = (int64_t)r * N * W;
+    if (GATHER) dst[plane + e] = src[plane + o];
+    else dst[plane + o] = src[plane + e];
+  }
+}
+template <class T, bool GATHER>
+hipError_t permute_launch(const T* src, T* dst, const uint32_t* perm, int64_t N, int R, int W, hipStream_t s) {
+  if (N <= 0 || R <= 0 || W <= 0) return hipSuccess;
+  void* args[] = {(void*)&src, (void*)&dst, (void*)&perm, (void*)&N, (void*)&R, (void*)&W};
+  return hipLaunchKernel((const void*)permute_kernel<T, GATHER>, dim3((unsigned)((N * W + 255) / 256)), dim3(256), args, 0, s);
+}
+}  // namespace
+// Physical reordering around a binned solve: the batch is gathered into integration order once (8 bytes per element, one side of the
+// copy scattered), solved with plain coalesced accesses, and the results are scattered back — cheaper than the same indirection inside
+// the solve kernel, where every lane's first load and last stores waited on it (measured: 10 % of a 1.8 ms solve against ~60 us of copies).
+hipError_t gather_f64(const double* src, double* dst, const uint32_t* perm, int64_t N, int R, int W, hipStream_t s) { return permute_launch<double, true>(src, dst, perm, N, R, W, s); }
+hipError_t scatter_f64(const double* src, double* dst, const uint32_t* perm, int64_t N, int R, int W, hipStream_t s) { return permute_launch<double, false>(src, dst, perm, N, R, W, s); }
+hipError_t scatter_i32(const int32_t* src, int32_t* dst, const uint32_t* perm, int64_t N, hipStream_t s) { return permute_launch<int32_t, false>(src, dst, perm, N, 1, 1, s); }
+hipError_t scatter_i64(const int64_t* src, int64_t* dst, const uint32_t* perm, int64_t N, hipStream_t s) { return permute_launch<int64_t, false>(src, dst, perm, N, 1, 1, s); }
 
 hipError_t negate_f64(const double* in, double* out, int64_t N, hipStream_t s) {
   if (N <= 0) return hipSuccess;

@@ -36,3 +36,26 @@ for name, order, mode in cases:
     elif mode is not None:
         res[name]["bit_identical_to_unsorted"] = bool(torch.equal(torch.nan_to_num(y, nan=-1.0), torch.nan_to_num(ref, nan=-1.0)))
 print(json.dumps(res, indent=1))
+# the order array followed inside the solve kernel (round 2's form) instead of the physical reorder, and a narrow-range key
+# (mu in [100, 101]: float32 image resolves it; round 2's 16-bit keys put the whole batch into two bins)
+L = nn._lib.lib()
+sw = torch.from_numpy(mu[None, :].copy()).to(dev)
+for knob, tag in ((0, "perm_in_kernel"), (1, "physical_reorder")):
+    L.nnhip_tune_set(b"sort_copy", knob)
+    tt = []
+    for r in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); e0.record()
+        t, y = nn.solveODE(nn.Rhs.vanderpol(), y0, [0.0, 10.0], opt, integrator="dopri54", sweep=sw, sort_by=sw[0]); e1.record()
+        torch.cuda.synchronize(); tt.append(e0.elapsed_time(e1))
+    res["sort_key_mu_" + tag] = dict(ms=sorted(tt[1:])[1], bit_identical_to_unsorted=bool(torch.equal(torch.nan_to_num(y, nan=-1.0), torch.nan_to_num(ref, nan=-1.0))))
+L.nnhip_tune_set(b"sort_copy", 0)
+mu2 = 100.0 + rng.random(n)
+sw2 = torch.from_numpy(mu2[None, :].copy()).to(dev)
+for name2, sort_by in (("narrow_key_random_order", None), ("narrow_key_sort_key_mu", sw2[0])):
+    tt = []
+    for r in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); e0.record()
+        t, y = nn.solveODE(nn.Rhs.vanderpol(), y0, [0.0, 0.5], opt, integrator="dopri54", sweep=sw2, sort_by=sort_by); e1.record()
+        torch.cuda.synchronize(); tt.append(e0.elapsed_time(e1))
+    res[name2] = dict(ms=sorted(tt[1:])[1])
+print(json.dumps(res, indent=1))
