@@ -39,6 +39,8 @@ typedef enum nnhip_status {
   NNHIP_EHIP = -3,         /* HIP runtime / device failure (incl. no device)                                 */
   NNHIP_EUNSUPPORTED = -4, /* (integrator, rhs_kind, dim, layout) combination has no compiled kernel         */
   NNHIP_ENOMEM = -5,
+  NNHIP_TRUNCATED = 1,     /* NOT an error: the call completed, but max_steps ended an integration short of its tEnd (the last
+                            * row holds the state reached, not the state at tEnd).  Only entries whose text says so return it. */
 } nnhip_status;
 
 /* ODEoptions, field for field (ode.nim:26-34). Build with nnhip_ode_new_options to get the reference's
@@ -290,7 +292,8 @@ int nnhip_ode_fixed_stream_f64_dev(const nnhip_ode_options* opt, int integrator,
  * Hermite kernel per requested time are launched — the two ping-pong buffers are (lastIter.y, y).  y0 / y_out [n_t][dim][N] (SoA)
  * or [n_t][N][dim] (AoS) are device pointers, tspan / t_out host.  (t, dt) are shared by the batch, so the number of rows the
  * reference would return is the same for every IVP: *ny_out (host, nullable); rows beyond it are NaN.  `ws`: device scratch of
- * nnhip_ode_fixed_stream_dense_workspace_bytes(N, dim).  Bitwise equal to nnhip_ode_solve_batch_f64_dev. */
+ * nnhip_ode_fixed_stream_dense_workspace_bytes(N, dim).  Bitwise equal to nnhip_ode_solve_batch_f64_dev.  Returns NNHIP_TRUNCATED (> 0, all
+ * outputs written) when max_steps cut a direction short of its end time — what the fused solve reports as stats.truncated. */
 int64_t nnhip_ode_fixed_stream_dense_workspace_bytes(int64_t N, int dim);
 int nnhip_ode_fixed_stream_dense_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
                                          int n_params, const double* y0, int64_t N, int dim, int layout, const double* tspan, int n_t,

@@ -7,6 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("NNHIP_LIB") or os.path.join(_HERE, "csrc", "libnnhip_ode.so")
 
 NNHIP_OK, NNHIP_EVALUE, NNHIP_EINTEGRATOR, NNHIP_EHIP, NNHIP_EUNSUPPORTED, NNHIP_ENOMEM = 0, -1, -2, -3, -4, -5
+NNHIP_TRUNCATED = 1  # not an error: max_steps ended an integration short of tEnd
 
 
 class Options(C.Structure):  # nnhip_ode_options == ODEoptions (ode.nim:26-34)

@@ -1538,7 +1538,7 @@ int nnhip_ode_fixed_stream_dense_f64_dev(const nnhip_ode_options* opt, int integ
   if (rowBase < n_t) HIP_TRY(nnhip::launch_fill_f64(row(rowBase), (int64_t)(n_t - rowBase) * nState, std::nan(""), s));
   if (ny_out) *ny_out = rowBase;
   if (n_steps_out) *n_steps_out = stepsTotal;
-  (void)truncated;
+  if (truncated) { (void)fail(NNHIP_TRUNCATED, "max_steps = %lld ended the integration before tEnd: the last row is the state reached, not y(tEnd)", (long long)max_steps); return NNHIP_TRUNCATED; }
   return NNHIP_OK;
 }
 

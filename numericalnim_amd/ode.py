@@ -640,7 +640,8 @@ def solveODECallsTspan(f, y0, tspans, options=None, ctx=None, integrator="dopri5
 def fixedStreamSolve(f, y0, tspan, options=None, ctx=None, integrator="rk4", layout=LAYOUT_SOA, max_steps=0):
     """solveODE (ode.nim:589-651) for a fixed-step integrator THROUGH THE IntegratorProc SEAM: the whole ODESolver driver — both
     directions, dense Hermite rows, output assembly — over the step-streaming kernels, state in HBM between steps
-    (nnhip_ode_fixed_stream_dense_f64_dev).  Returns (t, y [n_t, *y0.shape], ny, n_steps); bitwise equal to solveODE."""
+    (nnhip_ode_fixed_stream_dense_f64_dev).  Returns (t, y [n_t, *y0.shape], ny, n_steps); bitwise equal to solveODE.  When max_steps ends a
+    direction short of its end time a RuntimeWarning is issued (the last row is then the state reached, as with solveODE's stats.truncated)."""
     import torch
     L = _lib.lib()
     options = options if options is not None else _default_options()
@@ -660,9 +661,14 @@ def fixedStreamSolve(f, y0, tspan, options=None, ctx=None, integrator="rk4", lay
         y = torch.empty((n_t,) + tuple(y0c.shape), dtype=torch.float64, device=y0c.device)
         wsb = int(L.nnhip_ode_fixed_stream_dense_workspace_bytes(N, dim))
         ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=y0c.device)
-        _check(L.nnhip_ode_fixed_stream_dense_f64_dev(C.byref(options), integ, f.kind, pp, int(p.size), y0c.data_ptr(), N, dim, layout,
-                                                      tspan.ctypes.data_as(dpt), n_t, t_out.ctypes.data_as(dpt), y.data_ptr(), C.byref(ny), int(max_steps),
-                                                      ws.data_ptr(), wsb, C.byref(ns), torch.cuda.current_stream().cuda_stream))
+        rc = L.nnhip_ode_fixed_stream_dense_f64_dev(C.byref(options), integ, f.kind, pp, int(p.size), y0c.data_ptr(), N, dim, layout,
+                                                    tspan.ctypes.data_as(dpt), n_t, t_out.ctypes.data_as(dpt), y.data_ptr(), C.byref(ny), int(max_steps),
+                                                    ws.data_ptr(), wsb, C.byref(ns), torch.cuda.current_stream().cuda_stream)
+        if rc == _lib.NNHIP_TRUNCATED:
+            import warnings
+            warnings.warn(_lib.last_error(), RuntimeWarning)
+        else:
+            _check(rc)
     return t_out[:ntout.value].copy(), y, ny.value, ns.value
 
 
@@ -718,3 +724,27 @@ def adaptiveStream(f, y, t0, tEnd, options=None, ctx=None, integrator="dopri54",
                                                    y.data_ptr(), ws.data_ptr(), wsb, int(check_every), 0, C.byref(nl),
                                                    torch.cuda.current_stream().cuda_stream))
     return y, nl.value
+
+
+def hostLibmMatchesDevicePow(n=20000, seed=1234):
+    """Does THIS host's C library evaluate the controller's pow(1/error, 1/order) (ode.nim:71,537) to the bits the device evaluates?
+    The device restates glibc's table-driven pow (x86-64, glibc >= 2.28, the FMA variant its ifunc resolver picks on every CPU with
+    FMA3 + AVX2) operation for operation; a host with another libm (musl, macOS, aarch64, an x86-64 CPU without FMA3) rounds a fraction
+    of the calls differently, and an adaptive solve can then take a different step sequence on knife-edge steps — inside the 1e-6
+    tolerance, but not bit for bit.  Checked on a sample of error norms in the pow's working range, against Python's math.pow (= the
+    process's libm).  Needs a device.  Used by smoke() and by the GPU tests to decide whether bit-level comparisons are meaningful."""
+    import math
+    import torch
+    L = _lib.lib()
+    rng = np.random.default_rng(seed)
+    ok = True
+    for order in (2, 3, 5, 6):
+        err = np.concatenate([10.0 ** rng.uniform(-6.0, 2.0, n), rng.uniform(0.5, 1.5, n // 4)])
+        e = torch.from_numpy(err).cuda()
+        out = torch.empty_like(e)
+        _check(L.nnhip_ode_controller_factor_f64_dev(order, e.data_ptr(), out.data_ptr(), e.numel(), None))
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        ref = np.array([min(4.0, max(0.125, 0.9 * math.pow(1.0 / x, 1.0 / order))) for x in err])
+        ok = ok and bool(np.array_equal(got, ref))
+    return ok

@@ -32,3 +32,21 @@ def dev():
     import torch
     assert torch.cuda.is_available(), "-m gpu tests need a HIP device"
     return torch.device("cuda:0")
+
+
+_LIBM = {}
+
+
+@pytest.fixture(autouse=True)
+def _bit_level_comparisons_need_the_glibc_pow_the_device_restates(request):
+    """The -m gpu parity tests compare adaptive solves with the oracle BIT FOR BIT.  That is meaningful only where the oracle's std::pow is
+    the glibc pow the device restates (x86-64, glibc >= 2.28, FMA variant): checked once per session on a sample
+    (numericalnim_amd.hostLibmMatchesDevicePow); on any other host the tests that use the oracle are skipped with that reason instead
+    of failing on last-bit differences that are inside the north-star tolerance (smoke() still gates on 1e-10 / 1e-6 there)."""
+    if request.node.get_closest_marker("gpu") is None or "oracle" not in request.fixturenames:
+        return
+    if "ok" not in _LIBM:
+        import numericalnim_amd
+        _LIBM["ok"] = numericalnim_amd.hostLibmMatchesDevicePow()
+    if not _LIBM["ok"]:
+        pytest.skip("this host's libm pow differs from the glibc pow the device restates: bit-level comparison with the oracle is not meaningful here")

@@ -290,3 +290,24 @@ def test_fixed_step_dense_output_through_the_step_streaming_seam(nn, oracle, dev
                 assert np.array_equal(t, tf), (dim, ts)
                 assert torch.equal(torch.nan_to_num(y, nan=-7.0), torch.nan_to_num(yf, nan=-7.0)), (dim, layout, ts, tstart)
                 assert bool((cf["ny"] == ny).all()) and bool((cf["steps"] == ns).all()), (dim, ts, tstart)
+
+
+def test_fixed_stream_dense_reports_truncation(nn, dev):
+    """when max_steps cuts a direction short, nnhip_ode_fixed_stream_dense_f64_dev says so (NNHIP_TRUNCATED, a warning in the
+    Python mirror) instead of returning OK with a last row that is not y(tEnd); the rows equal the fused solve's, which flags `truncated`."""
+    import ctypes as C
+    import warnings
+    import torch
+    y0 = torch.from_numpy(1.0 + np.arange(40) * 2.0 ** -7).to(dev)
+    opt = nn.newODEoptions(dt=2.0 ** -6)
+    ts = [0.0, 0.5, 1.0]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        t, y, ny, ns = nn.fixedStreamSolve(nn.Rhs.linear(-0.1), y0, ts, opt, integrator="rk4", max_steps=40)
+    assert ns == 40 and any("max_steps" in str(x.message) for x in w)
+    tf, yf = nn.solveODE(nn.Rhs.linear(-0.1), y0, ts, opt, integrator="rk4", max_steps=40)
+    assert torch.equal(torch.nan_to_num(y, nan=-7.0), torch.nan_to_num(yf, nan=-7.0))
+    with warnings.catch_warnings(record=True) as w:   # enough steps: no warning
+        warnings.simplefilter("always")
+        t, y, ny, ns = nn.fixedStreamSolve(nn.Rhs.linear(-0.1), y0, ts, opt, integrator="rk4", max_steps=64)
+    assert ns == 64 and not w
