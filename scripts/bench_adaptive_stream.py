@@ -59,15 +59,20 @@ for name, f, y0, layout, d, n in cases:
         iters = int(cnt["steps"].max())                       # loop iterations until the slowest IVP is done
         attempted = int(cnt["steps"].sum() + cnt["rejected"].sum())
         # graph = defaults (non-temporal hint chosen from the working-set size); nt0 / nt1 force it off / on; eager = no graph replay
-        for mode, knob, nt in (("graph", 2, -1), ("graph_nt0", 2, 0), ("graph_nt1", 2, 1), ("eager", 0, -1)):
+        # K > 1 (knob "adv_steps_per_launch"): K loop iterations per IVP and launch with the state kept in registers in between — ITS OWN
+        # traffic model (8*(4d+5)/K bytes per attempted step), reported beside the one-iteration-per-launch figures, never mixed with them
+        for mode, knob, nt, K in (("graph", 2, -1, 1), ("graph_nt0", 2, 0, 1), ("graph_nt1", 2, 1, 1), ("eager", 0, -1, 1), ("graph_K2", 2, -1, 2), ("graph_K5", 2, -1, 5)):
             L.nnhip_tune_set(b"stream_graph", knob)
             L.nnhip_tune_set(b"adv_nontemporal", nt)
+            L.nnhip_tune_set(b"adv_steps_per_launch", K)
             dt, launches, ys = run(f, y0, integ, layout, 8)
             # algorithmic bytes: 8*(4d+5) per attempted step; with default options no step is rejected, so every IVP moves
             # them once per loop iteration it takes part in
-            res[f"{name}_{integ}_{mode}"] = dict(stream_ms=dt * 1e3, launches=launches, iterations=iters, us_per_iteration=dt * 1e6 / iters,
-                                                 GBps=8 * (4 * d + 5) * attempted / dt / 1e9, frac_of_8TBps=8 * (4 * d + 5) * attempted / dt / 8e12,
+            nb = 8 * (4 * d + 5) * attempted / K
+            res[f"{name}_{integ}_{mode}"] = dict(stream_ms=dt * 1e3, launches=launches, iterations=iters, us_per_iteration=dt * 1e6 / iters, steps_per_launch=K,
+                                                 bytes_per_attempted_step=8 * (4 * d + 5) / K, GBps=nb / dt / 1e9, frac_of_8TBps=nb / dt / 8e12,
                                                  fused_ms=fused_ms, equal_to_fused=bool(torch.equal(ys, yf[-1])))
         L.nnhip_tune_set(b"stream_graph", 2)
         L.nnhip_tune_set(b"adv_nontemporal", -1)
+        L.nnhip_tune_set(b"adv_steps_per_launch", 1)
 print(json.dumps(res, indent=1))
