@@ -250,9 +250,41 @@ NNHIP_DEV void solve_body(const SolveArgs& a0, const OpsF& opsF, const OpsB& ops
   in.ctl = a.ctl;
   in.dtInit = a.dtInit;
   const int64_t rs = a.rowStride, cs = a.compStride;
-  // Backward branch first (ode.nim:544-584; the two branches are independent, both restart from y0).
-  // Emission k of this branch is element k of yNegative; the result holds yNegative.reversed(), so it
-  // lands in row nNeg-1-k.
+  // Forward branch first, as the reference runs them (ode.nim:508-542, then :544-584): the two branches are independent (both restart
+  // from y0), so the order only matters to a right-hand side that mutates its ctx — which then sees the reference's call sequence.
+  // Result rows are yNegative.reversed ++ yZero ++ yPositive (:585): the forward rows go to base nNeg + nZero, and move up afterwards
+  // in the rare case that the backward branch returns fewer rows than requested (reference quirk).
+  int mPos = 0;
+  const int posBase = a.nNeg + (a.nZero > 0 ? 1 : 0);
+  if (a.nPos > 0) {  // ode.nim:508-542
+    in.tStartEff = a.t0;
+    in.tEnd = a.tEndPos;
+    in.tReq = a.tPos;
+    in.nReq = a.nPos;
+    in.uniformFull = a.uniformFull[0];
+    in.nTail = a.nTail[0];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) in.tailDt[q] = a.tailDt[0][q];
+    DriveOut o;
+    const int nPos = a.nPos;
+    const int rb = posBase;
+    drive<METHOD, false, DENSE>(opsF, in, y0,
+                         [=](int k, const double(&yv)[D]) {
+                           if (k < nPos) {
+#pragma unroll
+                             for (int c = 0; c < D; ++c)
+                               if (opsF.owns(c)) out[(int64_t)(rb + k) * rs + c * cs] = yv[c];
+                           }
+                         },
+                         o);
+    mPos = o.emitted < nPos ? o.emitted : nPos;
+    status |= o.status;
+    ls.steps += o.steps;
+    ls.rejected += o.rejected;
+    ls.progress += o.tFinal - in.tStartEff;
+  }
+  // Backward branch (ode.nim:544-584).  Emission k of this branch is element k of yNegative; the result holds
+  // yNegative.reversed(), so it lands in row nNeg-1-k.
   if (a.nNeg > 0) {
     in.tStartEff = -a.t0;
     in.tEnd = a.tEndNeg;
@@ -293,33 +325,13 @@ NNHIP_DEV void solve_body(const SolveArgs& a0, const OpsF& opsF, const OpsB& ops
       if (opsF.owns(c)) out[(int64_t)rowBase * rs + c * cs] = y0[c];
     rowBase += 1;
   }
-  if (a.nPos > 0) {  // ode.nim:508-542
-    in.tStartEff = a.t0;
-    in.tEnd = a.tEndPos;
-    in.tReq = a.tPos;
-    in.nReq = a.nPos;
-    in.uniformFull = a.uniformFull[0];
-    in.nTail = a.nTail[0];
+  if (mPos > 0 && rowBase != posBase) {  // the backward branch closed up: the forward rows follow it
+    for (int j = 0; j < mPos; ++j)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) in.tailDt[q] = a.tailDt[0][q];
-    DriveOut o;
-    const int nPos = a.nPos;
-    const int rb = rowBase;
-    drive<METHOD, false, DENSE>(opsF, in, y0,
-                         [=](int k, const double(&yv)[D]) {
-                           if (k < nPos) {
-#pragma unroll
-                             for (int c = 0; c < D; ++c)
-                               if (opsF.owns(c)) out[(int64_t)(rb + k) * rs + c * cs] = yv[c];
-                           }
-                         },
-                         o);
-    rowBase += o.emitted < nPos ? o.emitted : nPos;
-    status |= o.status;
-    ls.steps += o.steps;
-    ls.rejected += o.rejected;
-    ls.progress += o.tFinal - in.tStartEff;
+      for (int c = 0; c < D; ++c)
+        if (opsF.owns(c)) out[(int64_t)(rowBase + j) * rs + c * cs] = out[(int64_t)(posBase + j) * rs + c * cs];
   }
+  rowBase += mPos;
   const double qnan = __longlong_as_double(0x7ff8000000000000LL);
   for (int j = rowBase; j < a.n_t; ++j)
 #pragma unroll

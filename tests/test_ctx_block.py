@@ -137,3 +137,23 @@ def test_mutable_ctx_counts_z_crossings(nn, oracle, dev, integrator):
         aux2 = torch.zeros((3, n), dtype=torch.float64, device=dev)
         ys, launches = nn.adaptiveStream(f, torch.from_numpy(y0).to(dev), 0.0, 3.0, nn.newODEoptions(**kw), ctx=nn.newNumContext(tValues={"aux": aux2}), integrator=integrator)
         assert np.array_equal(ys.cpu().numpy(), ref["y"][-1]) and np.array_equal(aux2.cpu().numpy(), ref["aux"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("integrator", ["dopri54", "tsit54", "vern65"])
+def test_mutable_ctx_sees_the_reference_order_of_both_directions(nn, oracle, dev, integrator):
+    """tspan straddling tStart: the reference integrates the forward branch, THEN the backward one (ode.nim:508-542, 544-584), on the same
+    mutable ctx.  The fused kernel runs them in that order too (round 3), so a ctx-mutating closure ends with the oracle's slots — here with
+    requested rows on both sides (the FSAL methods' dense output evaluates f nowhere else)."""
+    import torch
+    O = oracle
+    n = 1500
+    y0 = np.stack([1.0 + (np.arange(n) % 512) * 2.0 ** -9, np.ones(n), np.full(n, 20.0)])
+    kw = dict(absTol=1e-6, relTol=1e-6, dtMin=1e-8, dtMax=0.05)
+    f = nn.Rhs.custom(3, ZCROSS_SRC, keys=("sigma", "rho", "beta"), defaults=dict(sigma=10.0, rho=28.0, beta=8.0 / 3.0), n_aux=3, name="lorenz_zcross")
+    ts = [-0.4, -0.1, 0.0, 0.5, 1.5]
+    aux = torch.zeros((3, n), dtype=torch.float64, device=dev)
+    t, y = nn.solveODE(f, torch.from_numpy(y0).to(dev), ts, nn.newODEoptions(**kw), ctx=nn.newNumContext(tValues={"aux": aux}), integrator=integrator)
+    ref = O.solve_ode_batch_ctx(O.RHS_LORENZ_ZCROSS, [10.0, 28.0, 8.0 / 3.0], None, np.zeros((3, n)), y0, n, 3, ts, O.new_options(**kw), integrator, n_threads=8)
+    assert np.array_equal(t, ref["t"]) and np.array_equal(y.cpu().numpy(), ref["y"], equal_nan=True)
+    assert np.array_equal(aux.cpu().numpy(), ref["aux"])

@@ -21,7 +21,7 @@ import test_gpu_fuzz_parity as T
 
 dev = torch.device("cuda:0")
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 600
-out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "r02_paths_soak.json")
+out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "r03_paths_soak.json")
 KEYS = T.KEYS
 
 
@@ -30,7 +30,7 @@ def same(a, b):
 
 
 tab = {k: dict(cases=0, ivps=0, mismatching_cases=0, errors=0) for k in ("stream_solve", "sorted_key", "sorted_probe", "calls_dev", "calls_host", "host_solve",
-                                                                         "sweep_host", "sweep_sorted", "sweep_calls", "stream_final", "tspans_dev", "tspans_host")}
+                                                                         "sweep_host", "sweep_sorted", "sweep_calls", "stream_final", "stream_final_k", "tspans_dev", "tspans_host")}
 bad = []
 for seed in range(5000, 5000 + n_seeds):
     rng = np.random.default_rng(seed)
@@ -125,6 +125,14 @@ for seed in range(5000, 5000 + n_seeds):
             yfin, _ = nn.adaptiveStream(f, yt.clone(), opt["tStart"], e, o, integrator=integ, layout=layout, check_every=int(rng.choice([1, 4, 8])))
         torch.cuda.synchronize()
         note("stream_final", same(yfin, y2p[-1]))
+        if not fixed:  # round 3: K loop iterations per launch (own kernel instantiation) must give the same bits
+            K = int(rng.choice([2, 3, 5, 16]))
+            try:
+                yk, _ = nn.adaptiveStream(f, yt.clone(), opt["tStart"], e, o, integrator=integ, layout=layout, check_every=int(rng.choice([1, 4])), steps_per_launch=K)
+                torch.cuda.synchronize()
+                note("stream_final_k", same(yk, y2p[-1]))
+            finally:
+                nn._lib.lib().nnhip_tune_set(b"adv_steps_per_launch", 1)
     except Exception as e:
         tab["stream_final"]["errors"] += 1
         bad.append(dict(path="stream_final", seed=seed, error=str(e)[:200], integ=integ, kind=kind, dim=dim))
