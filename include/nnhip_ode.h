@@ -301,13 +301,16 @@ int nnhip_ode_fixed_stream_dense_f64_dev(const nnhip_ode_options* opt, int integ
                                          int64_t* n_steps_out, void* stream);
 
 /* The WHOLE of ODESolver (ode.nim:471-586) for ADAPTIVE integrators through the IntegratorProc seam: per launch every unfinished
- * IVP runs one loop iteration including the emission of the requested times its last step passed (Hermite interpolation from the
- * per-IVP history lastIter = (t, y, dy), ode.nim:512-530); y, FSAL, t, dt, lastIter and denseIndex are resident in HBM between
- * launches.  Both directions around options.tStart, any tspan, the reference's row assembly and quirks.  y0 / y_out / ny_out
+ * IVP takes one step (ode.nim:525-541) and emits the requested times that step passed (the emission block :511-524 of the next loop
+ * iteration, Hermite interpolation from lastIter = (t, y, dy) — both ends of the step are in the kernel's registers, so the history never
+ * goes to HBM); y, FSAL, t, dt and denseIndex are resident in HBM between launches: 8*(4*dim+5) + 4 bytes per step and IVP, 8*dim per
+ * emitted row.  Both directions around options.tStart, any tspan, the reference's row assembly and quirks.  y0 / y_out / ny_out
  * (int32 [N], required: rows the reference returns for IVP i; rows beyond are NaN) are device pointers, tspan / t_out host.
  * Every right-hand side kind (thread-per-IVP and lanes-per-system, compiled-in and run-time compiled).  `ws`:
  * nnhip_ode_adaptive_stream_dense_workspace_bytes(N, dim, n_t) bytes.  The host polls one group of `check_every` launches behind the
- * device (launches_out counts the group issued past the end as well).
+ * device (launches_out counts the group issued past the end as well).  max_launches > 0 bounds the loop of EACH direction exactly as
+ * max_steps bounds the fused solve's (same rows, same ny_out); the call then returns NNHIP_TRUNCATED (> 0, all outputs written) if an
+ * integration was cut short.
  * Bitwise equal to nnhip_ode_solve_batch_f64_dev. */
 int64_t nnhip_ode_adaptive_stream_dense_workspace_bytes(int64_t N, int dim, int n_t);
 int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,

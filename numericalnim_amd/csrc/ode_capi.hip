@@ -1817,8 +1817,8 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
 int64_t nnhip_ode_adaptive_stream_dense_workspace_bytes(int64_t N, int dim, int n_t) {
   if (N < 0 || dim < 1) return 0;
   const int64_t nt = n_t < 0 ? 0 : n_t;
-  // y, FSAL, lastIter.y, lastIter.dy [dim*N]; t, dt, error, lastIter.t [N]; denseIndex [N] (int32); flags; requested times
-  return (int64_t)sizeof(double) * (4 * N * dim + 4 * N + nt + 8) + (int64_t)sizeof(int32_t) * (N + 2) + (int64_t)sizeof(unsigned int) * nnhip::kAggSlots + 64;
+  // y, FSAL [dim*N]; (t, dt) [N][2]; denseIndex [N] (int32); requested times (lastIter = (t, y, dy) lives in the kernel's registers)
+  return (int64_t)sizeof(double) * (2 * N * dim + 2 * N + nt + 8) + (int64_t)sizeof(int32_t) * (N + 2) + 64;
 }
 
 // The whole ODESolver driver (ode.nim:471-586) for adaptive integrators over the HBM-resident `advance` kernel: both directions,
@@ -1849,17 +1849,13 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
   if (N == 0) return NNHIP_OK;
   if (!y0 || (!y_out && n_t > 0) || !ny_out || !ws || ws_bytes < nnhip_ode_adaptive_stream_dense_workspace_bytes(N, dim, n_t))
     return fail(NNHIP_EVALUE, "y0 / y_out / ny_out / workspace missing or too small");
+  if (((uintptr_t)ws & 15u) != 0) return fail(NNHIP_EVALUE, "the workspace must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const int64_t nState = N * dim;
   double* yW = (double*)ws;
   double* fsal = yW + nState;
-  double* lastY = fsal + nState;
-  double* lastDy = lastY + nState;
-  double* tArr = lastDy + nState;
-  double* dtArr = tArr + N;
-  double* errArr = dtArr + N;
-  double* lastT = errArr + N;
-  double* tReqDev = lastT + N;                       // n_t doubles (+ padding)
+  double* tdArr = fsal + nState;                     // (t, dt) of IVP i side by side: [N][2] (16-byte aligned: ws is, nState * 16 is)
+  double* tReqDev = tdArr + 2 * N;                   // n_t doubles (+ padding)
   int32_t* denseIdx = (int32_t*)(tReqDev + n_t + 8);
   // requested times of both directions, as the reference holds them
   const int nPos = (int)g.tPos.size(), nNeg = (int)g.tNeg.size();
@@ -1878,17 +1874,18 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
   nnhip::StepArgs a{};
   a.N = N;
   if (layout == NNHIP_LAYOUT_SOA) { a.ivpStride = 1; a.compStride = N; } else { a.ivpStride = dim; a.compStride = 1; }
-  a.y_in = yW; a.y_out = yW; a.fsal_in = fsal; a.fsal_out = fsal; a.error = errArr;
+  a.y_in = yW; a.y_out = yW; a.fsal_in = fsal; a.fsal_out = fsal; a.error = nullptr;
   a.ctl = ctl_of(opt); a.P = P;
-  a.t_io = tArr; a.dt_io = dtArr;
-  a.denseIdx_io = denseIdx; a.lastT_io = lastT; a.lastY_io = lastY; a.lastDy_io = lastDy;
+  a.t_io = tdArr; a.dt_io = nullptr;
+  a.denseIdx_io = denseIdx; a.emitAfter = 1;
   a.rows = y_out; a.rowStride = nState;
-  // state + Hermite history of one launch beyond the Infinity Cache: non-temporal instantiation (thread-per-IVP kernels; knob "adv_nontemporal")
-  a.nontemporal = g_adv_nt >= 0 ? g_adv_nt : ((dim <= 4 && (int64_t)sizeof(double) * (4 * dim + 4) * N > (192LL << 20)) ? 1 : 0);
+  // state of one launch beyond the Infinity Cache: non-temporal instantiation (thread-per-IVP kernels; knob "adv_nontemporal")
+  a.nontemporal = g_adv_nt >= 0 ? g_adv_nt : ((dim <= 4 && (int64_t)sizeof(double) * (2 * dim + 3) * N > (192LL << 20)) ? 1 : 0);
   if (check_every <= 0) check_every = 8;
   const double dtInit = std::sqrt(opt->dtMax * opt->dtMin);  // :491-493
   const dim3 grid((unsigned)((N + nnhip::kBlock - 1) / nnhip::kBlock)), block(nnhip::kBlock);
   int64_t launches = 0;
+  bool truncated = false;
   auto finalize = [&](int mode) -> int {
     HIP_TRY(nnhip::launch_kernel(nnhip::advance_dense_finalize_kernel<0>, grid, block, s, a, mode, dim, y0, ny_out, n_t));
     return NNHIP_OK;
@@ -1898,23 +1895,20 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
     if (nnhip::rtc_launch_advance_dense(userKind, integrator, run, s) != hipSuccess) return fail(NNHIP_EHIP, "run-time compiled dense advance kernel: %s", nnhip::rtc_last_error());
     return NNHIP_OK;
   };
-  // y = y0, FSAL = f(t0, y0) / g(-t0, y0) = -f(t0, y0) (:506,:546), t, dt, denseIndex = 0, lastIter = (t, y, FSAL) (:498,:548)
+  // y = y0, FSAL = f(t0, y0) / g(-t0, y0) = -f(t0, y0) (:506,:546), t, dt, denseIndex = 0
   auto init = [&](const nnhip::StepArgs& run, bool neg, double tStartEff) -> int {
     if (fn.init) { HIP_TRY(fn.init(run, y0, tStartEff, dtInit, s)); return NNHIP_OK; }
     const size_t bytes = (size_t)nState * sizeof(double);
     HIP_TRY(hipMemcpyAsync(yW, y0, bytes, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemcpyAsync(lastY, y0, bytes, hipMemcpyDeviceToDevice, s));
     const int r = nnhip_ode_rhs_batch_f64_dev(rhs_kind, rhs_params, n_params, N, dim, layout, neg ? -tStartEff : tStartEff, y0, fsal, stream);
     if (r) return r;
     if (neg) HIP_TRY(nnhip::negate_f64(fsal, fsal, nState, s));
-    HIP_TRY(hipMemcpyAsync(lastDy, fsal, bytes, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(nnhip::launch_kernel(nnhip::fill_t_dt_kernel<0>, grid, block, s, tArr, dtArr, N, tStartEff, dtInit));
-    HIP_TRY(nnhip::launch_fill_f64(lastT, N, tStartEff, s));
+    HIP_TRY(nnhip::launch_kernel(nnhip::fill_td_kernel<0>, grid, block, s, (double2*)tdArr, N, tStartEff, dtInit));
     HIP_TRY(hipMemsetAsync(denseIdx, 0, (size_t)N * sizeof(int32_t), s));
     return NNHIP_OK;
   };
-  auto run_dir = [&](bool neg, double tStartEff, double tEnd, const double* req, int nReq, const int32_t* rowBase) -> int {
-    a.negate = neg ? 1 : 0; a.tEnd = tEnd; a.tReq = req; a.nReq = nReq; a.rowBase = rowBase;
+  auto run_dir = [&](bool neg, double tStartEff, double tEnd, const double* req, int nReq, const int32_t* rowBase, int rowBase0) -> int {
+    a.negate = neg ? 1 : 0; a.tEnd = tEnd; a.tReq = req; a.nReq = nReq; a.rowBase = rowBase; a.rowBase0 = rowBase0;
     a.useDense = n_t != 2 ? 1 : 0;  // :499-502: with a 2-point tspan the only row of a direction is the final yPositive.add(y)
     nnhip::StepArgs run = a;
     int r = init(run, neg, tStartEff);
@@ -1923,14 +1917,17 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
     // IVP returns at once, so the one group issued past the end costs only its launches)
     // the last launch of a group stores the flags straight into page-locked host memory (no memset / copy nodes); the groups replay
     // as hipGraphs, one per half of the flag block, as the loop without dense output does
-    auto issue_group = [&](unsigned int* flags) -> int {
-      for (int k = 0; k < check_every; ++k) {
-        run.active = k == check_every - 1 ? flags : nullptr;
+    auto issue_group = [&](unsigned int* flags, int n, bool lastPermitted) -> int {
+      for (int k = 0; k < n; ++k) {
+        run.active = k == n - 1 ? flags : nullptr;
+        run.emitAfter = (lastPermitted && k == n - 1) ? 0 : 1;  // the cut of max_launches falls where the fused solve's max_steps does
         const int ra = advance(run);
         if (ra) return ra;
       }
+      run.emitAfter = 1;
       return NNHIP_OK;
     };
+    int64_t dirLaunches = 0;  // max_launches bounds each direction's loop, as max_steps does in the fused solve
     hipGraphExec_t execs[2] = {nullptr, nullptr};
     if (g_stream_graph != 0 && s != nullptr) {
       int device = 0;
@@ -1949,7 +1946,7 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
         key.fn = (const void*)fn.advance; key.active = flags; key.userKind = userKind; key.integrator = integrator; key.checkEvery = check_every;
         key.device = device; key.split = -1 /* dense */; key.stream = s;
         int rcg = NNHIP_OK;
-        execs[half] = adv_cached_graph(key, s, [&]() { return issue_group(flags); }, rcg);
+        execs[half] = adv_cached_graph(key, s, [&]() { return issue_group(flags, check_every, false); }, rcg);
         if (rcg) return rcg;
       }
       if (!execs[0] || !execs[1]) execs[0] = execs[1] = nullptr;
@@ -1958,9 +1955,12 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
       const int half = (int)(grp & 1);
       unsigned int* flags = poll.h + half * nnhip::kAggSlots;
       std::memset(flags, 0, nnhip::kAggSlots * sizeof(unsigned int));  // host memory; the group that last wrote this half has been waited for
-      if (execs[half]) HIP_TRY(hipGraphLaunch(execs[half], s));
-      else { const int ra = issue_group(flags); if (ra) return ra; }
-      launches += check_every;
+      const bool lastPermitted = max_launches > 0 && dirLaunches + check_every >= max_launches;
+      const int n = lastPermitted ? (int)(max_launches - dirLaunches) : check_every;
+      if (execs[half] && !lastPermitted) HIP_TRY(hipGraphLaunch(execs[half], s));
+      else { const int ra = issue_group(flags, n, lastPermitted); if (ra) return ra; }
+      launches += n;
+      dirLaunches += n;
       HIP_TRY(hipEventRecord(poll.ev[half], s));
       return NNHIP_OK;
     };
@@ -1968,7 +1968,7 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
     r = issue(0);
     if (r) return r;
     for (;;) {
-      const bool more = !(max_launches > 0 && launches >= max_launches);
+      const bool more = !(max_launches > 0 && dirLaunches >= max_launches);
       if (more) {
         r = issue(grp + 1);
         if (r) return r;
@@ -1978,6 +1978,7 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
       for (int k = 0; k < nnhip::kAggSlots; ++k) any |= poll.h[(grp & 1) * nnhip::kAggSlots + k];
       if (!any || !more) {
         if (more) HIP_TRY(hipEventSynchronize(poll.ev[(grp + 1) & 1]));
+        else if (any) truncated = true;
         break;
       }
       ++grp;
@@ -1986,7 +1987,7 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
   };
   HIP_TRY(hipMemsetAsync(ny_out, 0, (size_t)N * sizeof(int32_t), s));
   if (nNeg > 0) {  // backward branch (:544-584)
-    rc = run_dir(true, -opt->tStart, g.tEndNeg, tReqDev + nPos, nNeg, nullptr);
+    rc = run_dir(true, -opt->tStart, g.tEndNeg, tReqDev + nPos, nNeg, nullptr, 0);
     if (rc) return rc;
     rc = finalize(0);
     if (rc) return rc;
@@ -1996,7 +1997,9 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
     if (rc) return rc;
   }
   if (nPos > 0) {
-    rc = run_dir(false, opt->tStart, g.tEndPos, tReqDev, nPos, ny_out);
+    // the forward rows follow whatever the backward branch and `t0 in tspan` produced: per IVP (ny_out) after a backward branch (it may
+    // return fewer rows than asked), the same row for every IVP otherwise
+    rc = nNeg > 0 ? run_dir(false, opt->tStart, g.tEndPos, tReqDev, nPos, ny_out, 0) : run_dir(false, opt->tStart, g.tEndPos, tReqDev, nPos, nullptr, g.nZero ? 1 : 0);
     if (rc) return rc;
     rc = finalize(2);
     if (rc) return rc;
@@ -2004,7 +2007,7 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
   rc = finalize(3);
   if (rc) return rc;
   if (launches_out) *launches_out = launches;
-  return NNHIP_OK;
+  return truncated ? NNHIP_TRUNCATED : NNHIP_OK;
 }
 
 }  // extern "C"

@@ -105,13 +105,12 @@ struct StepArgs {
   int nReq;
   int useDense;         // tspan.len != 2 (:499-502); 0: no emission block, the only row is the final yPositive.add(y) / yNegative.add(y)
   int negate;           // backward branch: integrate g(t, y) = -f(-t, y); requested times are negated on read
+  int emitAfter;        // 1: a launch ends with the emission block of the next iteration (:511-524); 0: the last permitted launch (max_launches)
   int32_t* denseIdx_io; // per-IVP denseIndex
-  double* lastT_io;     // per-IVP lastIter.t
-  double* lastY_io;     // per-IVP lastIter.y   (layout and strides of y)
-  double* lastDy_io;    // per-IVP lastIter.dy
   double* rows;         // result tensor [n_t][dim][N] / [n_t][N][dim]
   int64_t rowStride;
-  const int32_t* rowBase;  // forward: emission k of IVP i goes to row rowBase[i] + k; backward (rowBase == nullptr): row nReq-1-k
+  const int32_t* rowBase;  // forward: emission k of IVP i goes to row rowBase0 + rowBase[i] + k (rowBase == nullptr: no backward branch ran, the
+  int rowBase0;            // same base for every IVP); backward (negate): row nReq-1-k
 };
 
 constexpr int kBlock = 256;
@@ -931,7 +930,7 @@ struct TpiOpsRt {
   }
 };
 
-// y = y0, FSAL = f(t0, y0) / g(-t0, y0) (:506,:546), t, dt, denseIndex = 0, lastIter = (t, y, FSAL) (:498,:548)
+// y = y0, FSAL = f(t0, y0) / g(-t0, y0) (:506,:546), t, dt, denseIndex = 0 (lastIter (:498,:548) lives in the advance kernel's registers)
 template <class RHS>
 __global__ __launch_bounds__(kBlock) void advance_dense_init_kernel(const StepArgs a, const double* __restrict__ y0, double tStartEff, double dtInit) {
   constexpr int D = RHS::dim;
@@ -948,24 +947,64 @@ __global__ __launch_bounds__(kBlock) void advance_dense_init_kernel(const StepAr
   for (int c = 0; c < D; ++c) {
     a.y_out[base + c * a.compStride] = y[c];
     a.fsal_out[base + c * a.compStride] = f[c];
-    a.lastY_io[base + c * a.compStride] = y[c];
-    a.lastDy_io[base + c * a.compStride] = f[c];
   }
-  a.t_io[i] = tStartEff;
-  a.dt_io[i] = dtInit;
-  a.lastT_io[i] = tStartEff;
+  reinterpret_cast<double2*>(a.t_io)[i] = make_double2(tStartEff, dtInit);  // (t, dt) side by side, see advance_dense_body
   a.denseIdx_io[i] = 0;
 }
 
+// The emission block of ODESolver's loop (:511-524) for the step from lastIter = (lastT, yOld, lastDy) to (t, yNew, dyNow): every requested
+// time up to t is interpolated and stored; returns the new denseIndex, `done` when the last requested time has been emitted.
+template <int D>
+struct DenseEmitIn {
+  double t, lastT, treq, treqNext;
+  double yOld[D], yNew[D], lastDy[D], dyNow[D];
+  int denseIndex, rowBase;
+  int64_t i, base;
+  bool neg, lead;
+};
+template <class OPS>
+NNHIP_DEV int dense_emit(const StepArgs& a, const OPS& ops, const DenseEmitIn<OPS::D>& e, bool& done) {
+  constexpr int D = OPS::D;
+  const int high = a.nReq - 1;
+  const int64_t cs = a.compStride;
+  int denseIndex = e.denseIndex;
+  double treq = e.treq, treqNext = e.treqNext;
+  while (treq <= e.t) {  // :515
+    const HermiteW w = hermite_weights(treq, e.lastT, e.t);
+    const int64_t r = e.neg ? (int64_t)(a.nReq - 1 - denseIndex) : (int64_t)(e.rowBase + a.rowBase0 + denseIndex);
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+      if (ops.owns(c))  // written once, never read back by the loop: kept out of the caches the state lives in
+        st_state<true>(hermite_apply(w, e.yOld[c], e.yNew[c], e.lastDy[c], e.dyNow[c]), &a.rows[r * a.rowStride + e.base + c * cs]);
+    denseIndex += 1;
+    if (high < denseIndex) { done = true; break; }  // :513-514 / :523-524: the loop ends without another step
+    treq = treqNext;
+    if (treq <= e.t && denseIndex < high) treqNext = e.neg ? -a.tReq[denseIndex + 1] : a.tReq[denseIndex + 1];
+  }
+  if (e.lead) a.denseIdx_io[e.i] = denseIndex;
+  return denseIndex;
+}
 // One loop iteration of one IVP; `ops` owns D of its components (all of them: thread-per-IVP; CPL: lanes-per-system — the lanes
 // of a system read the same per-IVP scalars, so they take every branch together; the `lead` lane stores the scalars).
-// NT: non-temporal hint on the streamed arrays (state and Hermite history), chosen by the host from the working-set size like the
-// loop without dense output (a template parameter: see StepArgs::nontemporal)
+// A launch runs the reference's loop body from `dt = min(dt, tEnd - t)` (:525) through the controller (:541) AND the top of the NEXT
+// iteration (:511-524: the requested times the step just taken has passed) — the same statements in the same order per IVP, cut one
+// third of an iteration later than the reference's `while`.  At that cut both ends of the step are in registers, so lastIter =
+// (t, y, dy) (:526-530) never goes to HBM: a launch moves the 8*(4d+4) bytes of the state plus denseIndex, and 8*d per emitted row.
+// `emitAfter == 0` (the last launch a caller's max_launches permits) leaves the emission to the iteration that never comes, as the
+// fused solve does when max_steps ends its loop.
+// NT: non-temporal hint on the streamed state arrays, chosen by the host from the working-set size like the loop without dense
+// output (a template parameter: see StepArgs::nontemporal)
 template <int METHOD, bool NT = false, class OPS>
 NNHIP_DEV unsigned int advance_dense_body(const StepArgs& a, const OPS& ops, int64_t i, int64_t base, bool lead, bool neg) {
   constexpr int D = OPS::D;
   using MT = MethodTraits<METHOD>;
-  double t = a.t_io[i];
+  // the loop variables (t, dt) of an IVP sit side by side in the driver's workspace (t_io = [N][2]): one 16-byte access each way
+  double2* const td_io = reinterpret_cast<double2*>(a.t_io) + i;
+  // denseIndex and the requested times it points at are only needed after the step; fetched first (with t, in one round trip), the
+  // dependent read of the times passes under the state loads and the stage arithmetic instead of at the tail of every wave
+  int denseIndex = a.useDense ? a.denseIdx_io[i] : 0;  // <= nReq - 1: an IVP whose last requested time has been emitted is retired below
+  const double2 td = *td_io;
+  double t = td.x;
   if (!(t < a.tEnd)) return 0u;  // :511
   const int64_t cs = a.compStride;
   double y[D], yNew[D], fsal[D];
@@ -974,63 +1013,29 @@ NNHIP_DEV unsigned int advance_dense_body(const StepArgs& a, const OPS& ops, int
     y[c] = ops.owns(c) ? ld_state<NT>(&a.y_in[base + c * cs]) : 0.0;
     fsal[c] = ops.owns(c) ? ld_state<NT>(&a.fsal_in[base + c * cs]) : 0.0;
   }
-  double dt = a.dt_io[i];
-  int denseIndex = a.denseIdx_io[i];
+  double dt = td.y;
   const int high = a.nReq - 1;
-  bool done = false;
-  // :512-524 — requested times that the step just taken has passed
-  if (!a.useDense) {
-  } else if (high < denseIndex) {
-    done = true;  // :513-514 `break`: the loop ends without another step
-  } else {
-    double treq = neg ? -a.tReq[denseIndex] : a.tReq[denseIndex];
-    if (treq <= t) {
-      const double lastT = a.lastT_io[i];
-      double lastY[D], lastDy[D], dyNow[D];
-#pragma unroll
-      for (int c = 0; c < D; ++c) {
-        lastY[c] = ops.owns(c) ? a.lastY_io[base + c * cs] : 0.0;
-        lastDy[c] = ops.owns(c) ? a.lastDy_io[base + c * cs] : 0.0;
-      }
-      if constexpr (MT::fsal) {
-#pragma unroll
-        for (int c = 0; c < D; ++c) dyNow[c] = fsal[c];
-      } else {
-        ops.rhs(t, y, dyNow);  // f(t, y, ctx) (:521)
-      }
-      while (treq <= t) {  // :515
-        const HermiteW w = hermite_weights(treq, lastT, t);
-        const int64_t r = a.rowBase ? (int64_t)a.rowBase[i] + denseIndex : (int64_t)(a.nReq - 1 - denseIndex);
-#pragma unroll
-        for (int c = 0; c < D; ++c)
-          if (ops.owns(c)) a.rows[r * a.rowStride + base + c * cs] = hermite_apply(w, lastY[c], y[c], lastDy[c], dyNow[c]);
-        denseIndex += 1;
-        if (high < denseIndex) { done = true; break; }  // :523-524
-        treq = neg ? -a.tReq[denseIndex] : a.tReq[denseIndex];
-      }
-      if (lead) a.denseIdx_io[i] = denseIndex;
-    }
-  }
-  if (done) {
-    // every requested time has been emitted: the reference leaves the loop here; the final yPositive.add(y) falls outside the
-    // requested rows.  Retire the IVP (denseIndex == nReq tells the finalize kernel that nothing is left to add).
-    if (lead) a.t_io[i] = a.tEnd;
-    return 0u;
+  // A step rarely passes more than one requested time: the next two are fetched.  Neighbouring IVPs are mostly at the same denseIndex:
+  // a wave that agrees on it reads the two times through the scalar cache into SGPRs (no vector-memory instruction — what this
+  // HBM-bound kernel is short of — and no VGPRs held across the stages); a wave that does not gathers them per lane after the step.
+  bool uniformIdx = false;
+  double sTreq = 0.0, sTreqNext = 0.0;
+  int rowBase = 0;
+  if (a.useDense) {
+    const int idx0 = __builtin_amdgcn_readfirstlane(denseIndex);
+    uniformIdx = __all(denseIndex == idx0) != 0;
+    sTreq = a.tReq[idx0];
+    sTreqNext = a.tReq[idx0 < high ? idx0 + 1 : high];
+    if (a.rowBase) rowBase = a.rowBase[i];
   }
   dt = nmin(dt, a.tEnd - t);  // :525
-  if (a.useDense) {  // lastIter = (t, y, dy) (:526-530): dy = FSAL for FSAL methods, f(t, y) otherwise
-    if (lead) a.lastT_io[i] = t;
-    if constexpr (MT::fsal) {
+  // lastIter = (t, y, dy) (:526-530), in registers: dy = FSAL for FSAL methods; f(t, y) otherwise, evaluated only if a requested
+  // time falls into this step (the same call on the same operands, hence the same bits)
+  const double lastT = t;
+  DenseEmitIn<D> e;
+  if constexpr (MT::fsal) {
 #pragma unroll
-      for (int c = 0; c < D; ++c)
-        if (ops.owns(c)) { st_state<NT>(y[c], &a.lastY_io[base + c * cs]); st_state<NT>(fsal[c], &a.lastDy_io[base + c * cs]); }
-    } else {
-      double dy0[D];
-      ops.rhs(t, y, dy0);
-#pragma unroll
-      for (int c = 0; c < D; ++c)
-        if (ops.owns(c)) { st_state<NT>(y[c], &a.lastY_io[base + c * cs]); st_state<NT>(dy0[c], &a.lastDy_io[base + c * cs]); }
-    }
+    for (int c = 0; c < D; ++c) e.lastDy[c] = fsal[c];
   }
   double error = 0.0, factor;
   int64_t rej = 0;
@@ -1041,23 +1046,57 @@ NNHIP_DEV unsigned int advance_dense_body(const StepArgs& a, const OPS& ops, int
   if (dt < a.ctl.dtMin) dt = a.ctl.dtMin;
   else if (a.ctl.dtMax < dt) dt = a.ctl.dtMax;
   if (error != error) t = a.tEnd;  // NaN abort, as in the fused driver
+  bool done = false;
+  if (a.useDense && a.emitAfter && t < a.tEnd) {  // :511-524 of the next iteration
+    double treq = sTreq, treqNext = sTreqNext;
+    if (!uniformIdx) {
+      treq = a.tReq[denseIndex];
+      treqNext = a.tReq[denseIndex < high ? denseIndex + 1 : high];
+    }
+    if (neg) { treq = -treq; treqNext = -treqNext; }
+    if (treq <= t) {
+      if constexpr (!MT::fsal) {
+        ops.rhs(t, yNew, e.dyNow);    // f(t, y, ctx) (:521)
+        ops.rhs(lastT, y, e.lastDy);  // lastIter.dy (:530)
+      } else {
+#pragma unroll
+        for (int c = 0; c < D; ++c) e.dyNow[c] = fsal[c];
+      }
+#pragma unroll
+      for (int c = 0; c < D; ++c) { e.yOld[c] = y[c]; e.yNew[c] = yNew[c]; }
+      e.t = t; e.lastT = lastT; e.treq = treq; e.treqNext = treqNext;
+      e.denseIndex = denseIndex; e.rowBase = rowBase; e.i = i; e.base = base; e.neg = neg; e.lead = lead;
+      denseIndex = dense_emit(a, ops, e, done);
+    }
+  }
 #pragma unroll
   for (int c = 0; c < D; ++c)
     if (ops.owns(c)) { st_state<NT>(yNew[c], &a.y_out[base + c * cs]); st_state<NT>(fsal[c], &a.fsal_out[base + c * cs]); }
+  // every requested time has been emitted: the reference leaves the loop here and its final yPositive.add(y) falls outside the
+  // requested rows.  Retire the IVP (denseIndex == nReq tells the finalize kernel that nothing is left to add).
+  if (done) t = a.tEnd;
   if (lead) {
-    a.t_io[i] = t;
-    a.dt_io[i] = dt;
+    *td_io = make_double2(t, dt);
     if (a.error) a.error[i] = error;
     if (a.steps_io) a.steps_io[i] += 1;
   }
   return t < a.tEnd ? 1u : 0u;
 }
 
+// Workgroup size: 64 for the non-temporal instantiation (beyond the Infinity Cache one-wave workgroups retire and refill sooner, as
+// launch_advance_tpi's default), kBlock otherwise.
+template <bool NT>
+constexpr int adv_dense_block() { return NT ? 64 : kBlock; }
+// (Held to 4 waves per SIMD like advance_tpi_kernel this kernel spills: the emission block's operands put it at 147 VGPRs for d = 3 against
+// the 128 of the loop without dense output, and neither parking lastIter in LDS, nor re-reading it in the emission branch, nor compiling
+// the block as a function of its own brought that down without 50-600 B of scratch per lane — 3 waves it is: 217 against 200 us per launch
+// at 1e7 Lorenz IVPs.)
 template <int METHOD, class RHS, bool NT = false>
 __global__ __launch_bounds__(kBlock) void advance_dense_tpi_kernel(const StepArgs a) {
   static_assert(MethodTraits<METHOD>::adaptive, "adaptive methods only");
   controller_prologue();
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  pin_step_args(a);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // workgroup size chosen by the launcher (<= kBlock)
   unsigned int stillActive = 0;
   if (i < a.N) {
     const Params P = params_of(a, i);
@@ -1150,6 +1189,13 @@ __global__ __launch_bounds__(kBlock) void advance_dense_finalize_kernel(const St
     for (int j = ny[i]; j < n_t; ++j)
       for (int c = 0; c < dim; ++c) a.rows[(int64_t)j * rs + base + c * cs] = qnan;
   }
+}
+
+// (t, dt)[i] = (t0, dt0), the dense driver's interleaved form
+template <int UNUSED = 0>
+__global__ __launch_bounds__(kBlock) void fill_td_kernel(double2* __restrict__ td, int64_t n, double t0, double dt0) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) td[i] = make_double2(t0, dt0);
 }
 
 // t[i] = t0, dt[i] = dt0: the per-IVP loop variables before the first iteration (ode.nim:477, 491-493)
@@ -1538,10 +1584,11 @@ hipError_t launch_advance_dense_init(const StepArgs& a, const double* y0, double
 template <int METHOD, class RHS>
 hipError_t launch_advance_dense(const StepArgs& a, hipStream_t s) {
   if constexpr (MethodTraits<METHOD>::adaptive) {
-    const int64_t grid = (a.N + kBlock - 1) / kBlock;
+    const int bs = a.nontemporal ? adv_dense_block<true>() : adv_dense_block<false>();
+    const int64_t grid = (a.N + bs - 1) / bs;
     if (grid <= 0) return hipSuccess;
-    if (a.nontemporal) return launch_kernel(advance_dense_tpi_kernel<METHOD, RHS, true>, dim3((unsigned)grid), dim3(kBlock), s, a);
-    return launch_kernel(advance_dense_tpi_kernel<METHOD, RHS>, dim3((unsigned)grid), dim3(kBlock), s, a);
+    if (a.nontemporal) return launch_kernel(advance_dense_tpi_kernel<METHOD, RHS, true>, dim3((unsigned)grid), dim3(bs), s, a);
+    return launch_kernel(advance_dense_tpi_kernel<METHOD, RHS>, dim3((unsigned)grid), dim3(bs), s, a);
   } else {
     return hipErrorInvalidValue;
   }

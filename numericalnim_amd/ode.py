@@ -672,10 +672,11 @@ def fixedStreamSolve(f, y0, tspan, options=None, ctx=None, integrator="rk4", lay
     return t_out[:ntout.value].copy(), y, ny.value, ns.value
 
 
-def adaptiveStreamSolve(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=LAYOUT_SOA, check_every=8):
+def adaptiveStreamSolve(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=LAYOUT_SOA, check_every=8, max_launches=0):
     """solveODE (ode.nim:589-651) for an adaptive integrator THROUGH THE IntegratorProc SEAM: the whole ODESolver driver over the
-    HBM-resident advance kernel with per-IVP Hermite history (nnhip_ode_adaptive_stream_dense_f64_dev).  Returns (t, y, ny, launches);
-    bitwise equal to solveODE."""
+    HBM-resident advance kernel, requested rows interpolated inside the launch that steps past them (nnhip_ode_adaptive_stream_dense_f64_dev).
+    Returns (t, y, ny, launches); bitwise equal to solveODE.  max_launches > 0 bounds each direction's loop exactly as solveODE's
+    max_steps does (a warning is issued when it cut an integration short)."""
     import torch
     L = _lib.lib()
     options = options if options is not None else _default_options()
@@ -695,9 +696,15 @@ def adaptiveStreamSolve(f, y0, tspan, options=None, ctx=None, integrator="dopri5
         ny = torch.empty(max(N, 1), dtype=torch.int32, device=y0c.device)
         wsb = int(L.nnhip_ode_adaptive_stream_dense_workspace_bytes(N, dim, n_t))
         ws = torch.empty(max(wsb, 8), dtype=torch.uint8, device=y0c.device)
-        _check(L.nnhip_ode_adaptive_stream_dense_f64_dev(C.byref(options), integ, f.kind, pp, int(p.size), y0c.data_ptr(), N, dim, layout,
-                                                         tspan.ctypes.data_as(dpt), n_t, t_out.ctypes.data_as(dpt), y.data_ptr(), ny.data_ptr(),
-                                                         ws.data_ptr(), wsb, int(check_every), 0, C.byref(nl), torch.cuda.current_stream().cuda_stream))
+        rc = L.nnhip_ode_adaptive_stream_dense_f64_dev(C.byref(options), integ, f.kind, pp, int(p.size), y0c.data_ptr(), N, dim, layout,
+                                                       tspan.ctypes.data_as(dpt), n_t, t_out.ctypes.data_as(dpt), y.data_ptr(), ny.data_ptr(),
+                                                       ws.data_ptr(), wsb, int(check_every), int(max_launches), C.byref(nl),
+                                                       torch.cuda.current_stream().cuda_stream)
+        if rc == _lib.NNHIP_TRUNCATED:
+            import warnings
+            warnings.warn("adaptiveStreamSolve: max_launches ended an integration short of its end time", RuntimeWarning)
+        else:
+            _check(rc)
     return t_out[:ntout.value].copy(), y, ny[:N], nl.value
 
 

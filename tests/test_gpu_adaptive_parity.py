@@ -681,6 +681,30 @@ def test_adaptive_dense_output_through_the_step_streaming_seam(nn, oracle, dev, 
                 assert torch.equal(torch.nan_to_num(y, nan=-7.0), torch.nan_to_num(yf, nan=-7.0)), (dim, layout, ts, tstart)
 
 
+@pytest.mark.parametrize("integrator", ["dopri54", "vern65", "bs32"])
+def test_adaptive_dense_stream_cut_by_max_launches_is_the_fused_max_steps(nn, dev, integrator):
+    """max_launches bounds each direction's loop where max_steps bounds the fused solve's: the launch that is the last one permitted
+    leaves its emission to the iteration that never comes (StepArgs::emitAfter), so rows, row counts and the NaN fill are the fused
+    solve's with max_steps = max_launches — also when the cut is not a multiple of check_every, and on both sides of tStart."""
+    import warnings
+    import torch
+    rng = np.random.default_rng(5)
+    n = 301
+    y0 = rng.uniform(0.5, 1.5, (n, 3)) + np.array([0.0, 0.0, 20.0])
+    y0l = torch.from_numpy(np.ascontiguousarray(y0.T)).to(dev)
+    for ts, tstart in (([0.1, 0.2, 0.4, 0.8, 1.6], 0.0), ([-0.2, -0.1, 0.3, 0.30001, 0.9], 0.0), ([0.5, 1.0], 0.25)):
+        opt = nn.newODEoptions(tStart=tstart, absTol=1e-7, relTol=1e-7, dtMin=1e-6, dtMax=0.5)
+        full = nn.solveODE(nn.Rhs.lorenz(), y0l, ts, opt, integrator=integrator, return_counts=True)[2]["steps"]
+        for cut, ce in ((7, 3), (16, 8), (1, 8), (int(full.max()) + 40, 8)):
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                t, y, ny, launches = nn.adaptiveStreamSolve(nn.Rhs.lorenz(), y0l, ts, opt, integrator=integrator, check_every=ce, max_launches=cut)
+            tf, yf, cf = nn.solveODE(nn.Rhs.lorenz(), y0l, ts, opt, integrator=integrator, max_steps=cut, return_counts=True)
+            assert torch.equal(ny, cf["ny"]), (ts, cut)
+            assert torch.equal(torch.nan_to_num(y, nan=-7.0), torch.nan_to_num(yf, nan=-7.0)), (ts, cut)
+            assert bool(w) == (cut < int(full.max())), (ts, cut, len(w))
+
+
 @pytest.mark.parametrize("integrator", ["dopri54", "tsit54", "rk4", "bs32", "heun3"])
 def test_every_ivp_its_own_tspan_end(nn, oracle, dev, integrator):
     """nnhip_ode_solve_batch_tend_f64_dev: IVP i is solveODE(f, y0_i, [tStart, t_end[i]]) (each reference call owns its tspan,
