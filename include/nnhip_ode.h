@@ -111,10 +111,12 @@ int nnhip_host_free(void* p);
  *   second identical call on; the polling groups of nnhip_ode_adaptive_stream_f64_dev are replayed from a graph unless 0),
  *   "adv_nontemporal" -1|0|1 (non-temporal instantiations of the streaming kernels; -1 = automatic: when the state of one launch
  *   exceeds 192 MiB), "adv_split" 0|1|2|4 (index ranges of the adaptive streaming loop on separate streams; measured slower, default 1),
- *   "adv_block" 0|64|128|256 (workgroup size of the thread-per-IVP advance kernel; 0 = automatic: 64 with the non-temporal instantiation),
+ *   "adv_block" 0|64|128|256 (workgroup size of the thread-per-IVP advance kernel; 0 = automatic: 64),
+ *   "adv_recompute_fsal" -1|0|1 (the streaming loops of DOPRI54 / Tsit54 re-evaluate FSAL = f(t, y) per launch instead of carrying it through
+ *   HBM: 16*dim bytes per step less for one more evaluation of f, the same bits; -1 = automatic: on unless the right-hand side has mutable slots),
  *   "adv_steps_per_launch" 1..1024 (loop iterations of ode.nim:525-541 per IVP and launch of nnhip_ode_adaptive_stream_f64_dev; default 1 = one
  *   IntegratorProc call per launch, state through HBM between any two; K > 1 keeps an IVP's state in registers for up to K iterations:
- *   the same bits, 1/K of the launches and 8*(4d+5)/K bytes per attempted step — a different traffic model, never quoted against the one-per-launch figures),
+ *   the same bits, 1/K of the launches and 1/K of the bytes per step — a different traffic model, never quoted against the one-per-launch figures),
  *   "sort_copy" 0|1 (1: the binned solve nnhip_ode_solve_batch_sorted_f64[_dev] gathers the batch into integration order, solves it with
  *   coalesced accesses and scatters the results back; default 0: the solve kernel follows the order array itself — measured faster),
  *   "fixed_vec_ipl" 0|2 (0 = one IVP per lane instead of the vectorised fixed-step streaming kernel),
@@ -303,8 +305,8 @@ int nnhip_ode_fixed_stream_dense_f64_dev(const nnhip_ode_options* opt, int integ
 /* The WHOLE of ODESolver (ode.nim:471-586) for ADAPTIVE integrators through the IntegratorProc seam: per launch every unfinished
  * IVP takes one step (ode.nim:525-541) and emits the requested times that step passed (the emission block :511-524 of the next loop
  * iteration, Hermite interpolation from lastIter = (t, y, dy) — both ends of the step are in the kernel's registers, so the history never
- * goes to HBM); y, FSAL, t, dt and denseIndex are resident in HBM between launches: 8*(4*dim+5) + 4 bytes per step and IVP, 8*dim per
- * emitted row.  Both directions around options.tStart, any tspan, the reference's row assembly and quirks.  y0 / y_out / ny_out
+ * goes to HBM); y, (t, dt), denseIndex and — as in nnhip_ode_adaptive_stream_f64_dev — FSAL where it is carried are resident in HBM
+ * between launches: 8*(4*dim+4) + 4 or 8*(2*dim+4) + 4 bytes per step and IVP, 8*dim per emitted row.  Both directions around options.tStart, any tspan, the reference's row assembly and quirks.  y0 / y_out / ny_out
  * (int32 [N], required: rows the reference returns for IVP i; rows beyond are NaN) are device pointers, tspan / t_out host.
  * Every right-hand side kind (thread-per-IVP and lanes-per-system, compiled-in and run-time compiled).  `ws`:
  * nnhip_ode_adaptive_stream_dense_workspace_bytes(N, dim, n_t) bytes.  The host polls one group of `check_every` launches behind the
@@ -319,8 +321,12 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
                                             int64_t max_launches, int64_t* launches_out, void* stream);
 
 /* Adaptive time loop of ODESolver (ode.nim:506-542 with adaptive=true, tspan.len == 2) driven from the host over an
- * `advance` kernel: per launch, every unfinished IVP does dt = min(dt, tEnd-t); step; t += dt; controller — with y, FSAL,
- * t, dt resident in HBM between launches (8*(4*dim+5) algorithmic bytes per attempted step).  y (device, in `layout`) is
+ * `advance` kernel: per launch, every unfinished IVP does dt = min(dt, tEnd-t); step; t += dt; controller — with y, (t, dt) and,
+ * where the next step reads it, FSAL resident in HBM between launches.  Algorithmic bytes per step: 8*(4*dim+4) with FSAL carried
+ * (Vern65; DOPRI54 / Tsit54 with knob "adv_recompute_fsal" = 0, the IntegratorProc signature as the reference passes it),
+ * 8*(2*dim+4) without (BS32 / RK21 never read the slot; DOPRI54 / Tsit54 by default re-evaluate FSAL = f(t, y) at the start of the
+ * launch — it is the previous step's last stage f(t + dt, yNew), the same bits — unless the right-hand side has mutable slots).
+ * y (device, in `layout`) is
  * advanced in place from t0 to tEnd; `ws` is device scratch of nnhip_ode_adaptive_stream_workspace_bytes(N, dim).  The host
  * learns whether anyone is still integrating every `check_every` launches (<= 0: 8) and always has the next group enqueued
  * before it waits (groups are replayed from a hipGraph on a non-default stream), so up to 2*check_every trailing launches

@@ -67,7 +67,10 @@ int g_fixed_vec_ipl = 2;  // tuning knob "fixed_vec_ipl": IVPs per lane of the v
 int g_mg_oversubscribe = 0;  // tuning knob "multi_gpu_oversubscribe": the multi-GPU host entry accepts more shards than devices (shard r on device
                              // r mod #devices) — lets a one-GPU box exercise the sharded code path (index ranges, strided copies, empty shards)
 int g_adv_nt = -1;        // tuning knob "adv_nontemporal": -1 = automatic (thread-per-IVP state beyond 192 MiB), 0 / 1 = force
-int g_adv_block = 0;      // tuning knob "adv_block": workgroup size of the thread-per-IVP advance kernel (0 = auto: 64 with the non-temporal instantiation, else 256)
+int g_adv_refsal = -1;    // tuning knob "adv_recompute_fsal": DOPRI54 / Tsit54 streaming loops re-evaluate FSAL = f(t, y) per launch instead of carrying it through
+                          // HBM (16*d bytes per step less, the same bits).  -1 = automatic (on, unless the right-hand side has mutable slots: the extra
+                          // evaluation would be observable), 0 = carry (the IntegratorProc signature as the reference passes it), 1 = force
+int g_adv_block = 0;      // tuning knob "adv_block": workgroup size of the thread-per-IVP advance kernel (0 = auto: 64)
 int g_sort_copy = 0;      // tuning knob "sort_copy": the binned solve reorders the batch physically (gather, solve, scatter) instead of following perm[] inside the
                           // kernel.  Measured and NOT the default (profiles/r03_bench_divergence.json, 1e6 Van der Pol IVPs): 1.77 ms against 1.65 ms with the
                           // order array followed in the kernel (pre-sorted by the caller: 1.52) — the five extra kernels and the stream-ordered allocation cost
@@ -391,6 +394,7 @@ int nnhip_tune_set(const char* key, int value) {
   if (k == "stream_graph") { if (value < 0 || value > 2) return fail(NNHIP_EVALUE, "stream_graph must be 0, 1 or 2"); g_stream_graph = value; return NNHIP_OK; }
   if (k == "fixed_vec_ipl") { if (value != 0 && value != 2) return fail(NNHIP_EVALUE, "fixed_vec_ipl must be 0 (off) or 2"); g_fixed_vec_ipl = value; return NNHIP_OK; }
   if (k == "multi_gpu_oversubscribe") { g_mg_oversubscribe = value != 0; return NNHIP_OK; }
+  if (k == "adv_recompute_fsal") { if (value < -1 || value > 1) return fail(NNHIP_EVALUE, "adv_recompute_fsal must be -1, 0 or 1"); g_adv_refsal = value; release_adv_graphs(); return NNHIP_OK; }
   if (k == "adv_nontemporal") { if (value < -1 || value > 1) return fail(NNHIP_EVALUE, "adv_nontemporal must be -1, 0 or 1"); g_adv_nt = value; return NNHIP_OK; }
   if (k == "adv_block") { if (value != 0 && value != 64 && value != 128 && value != 256) return fail(NNHIP_EVALUE, "adv_block must be 0, 64, 128 or 256"); g_adv_block = value; release_adv_graphs(); return NNHIP_OK; }
   if (k == "sort_copy") { g_sort_copy = value != 0; return NNHIP_OK; }
@@ -1544,7 +1548,7 @@ int nnhip_ode_fixed_stream_dense_f64_dev(const nnhip_ode_options* opt, int integ
 
 int64_t nnhip_ode_adaptive_stream_workspace_bytes(int64_t N, int dim) {
   if (N < 0 || dim < 1) return 0;
-  return (int64_t)sizeof(double) * (N * dim /*FSAL*/ + 3 * N /*t, dt, error*/) + (int64_t)sizeof(unsigned int) * nnhip::kAggSlots;
+  return (int64_t)sizeof(double) * (N * dim /*FSAL*/ + 3 * N /*(t, dt) + one spare column*/) + (int64_t)sizeof(unsigned int) * nnhip::kAggSlots;
 }
 
 }  // extern "C"
@@ -1656,7 +1660,7 @@ int adv_issue_group(nnhip::StepLaunchFn fn, int userKind, int integrator, const 
       nnhip::StepArgs a = split > 1 ? adv_range(full, lo, hi - lo) : full;
       a.active = k == checkEvery - 1 ? active : nullptr;
       hipStream_t st = r == 0 ? s : p.side[r - 1];
-      if (fn) HIP_TRY(fn(a, g_adv_block ? g_adv_block : (a.nontemporal ? 64 : 256), st));  // beyond the Infinity Cache one-wave workgroups retire and refill sooner: 208 -> 203 us at 1e7 Lorenz IVPs
+      if (fn) HIP_TRY(fn(a, g_adv_block ? g_adv_block : 64, st));  // one-wave workgroups retire and refill sooner: 1e7 Lorenz IVPs 208 -> 203 us, 1e6 24.0 -> 23.0 us (mb_adv c3a)
       else if (nnhip::rtc_launch_advance(userKind, integrator, a, st) != hipSuccess) return fail(NNHIP_EHIP, "user RHS launch failed: %s", nnhip::rtc_last_error());
     }
   }
@@ -1726,28 +1730,41 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
   if (!fn && userKind < 0)
     return fail(NNHIP_EUNSUPPORTED, "no advance kernel for integrator=%s rhs_kind=%d dim=%d", kMethods[integrator].name, rhs_kind, dim);
   hipStream_t s = (hipStream_t)stream;
-  double* fsal = (double*)ws;
-  double* tArr = fsal + N * dim;
-  double* dtArr = tArr + N;
-  double* errArr = dtArr + N;
+  // workspace: (t, dt) of IVP i side by side when `ws` is 16-byte aligned (one 16-byte access each way per launch instead of two of 8;
+  // every allocator's blocks are), two columns otherwise; then FSAL.  `error` (ode.nim:531) is a local of the loop: it is not stored.
+  const bool packed = ((uintptr_t)ws & 15u) == 0;
+  double* tArr = (double*)ws;
+  double* dtArr = packed ? nullptr : tArr + N;
+  double* fsal = tArr + 2 * N;
+  // DOPRI54 / Tsit54: FSAL re-evaluated by each launch instead of carried through HBM (knob "adv_recompute_fsal"; see adv_fsal_in_hbm in ode_kernels.hpp)
+  const bool fsalRecomputable = integrator == NNHIP_DOPRI54 || integrator == NNHIP_TSIT54;
+  const int recomputeFsal = !fsalRecomputable ? 0 : (g_adv_refsal >= 0 ? g_adv_refsal : (nnhip::rtc_has_aux(rhs_kind) ? 0 : 1));
+  const bool fsalInHbm = !(recomputeFsal || integrator == NNHIP_BS32 || integrator == NNHIP_RK21);  // BS32 / RK21 never read the slot
   // FSAL = f(t0, y) (:506); t = t0; dt = sqrt(dtMax*dtMin) (:491-493)
   if (nnhip::rtc_has_aux(rhs_kind)) {  // lastIter.dy = f(t0, y, ctx) (:498): the first of the reference's two evaluations at t0, observable through aux
     rc = nnhip_ode_rhs_batch_f64_dev(rhs_kind, rhs_params, n_params, N, dim, layout, t0, y, fsal, stream);
     if (rc) return fail(rc, "initial RHS evaluation failed");
   }
-  rc = nnhip_ode_rhs_batch_f64_dev(rhs_kind, rhs_params, n_params, N, dim, layout, t0, y, fsal, stream);
-  if (rc) return fail(rc, "initial RHS evaluation failed");
-  HIP_TRY(nnhip::launch_kernel(nnhip::fill_t_dt_kernel<0>, dim3((unsigned)((N + nnhip::kBlock - 1) / nnhip::kBlock)), dim3(nnhip::kBlock), s, tArr,
-                               dtArr, N, t0, std::sqrt(opt->dtMax * opt->dtMin)));
+  if (fsalInHbm || nnhip::rtc_has_aux(rhs_kind)) {
+    rc = nnhip_ode_rhs_batch_f64_dev(rhs_kind, rhs_params, n_params, N, dim, layout, t0, y, fsal, stream);
+    if (rc) return fail(rc, "initial RHS evaluation failed");
+  }
+  if (packed)
+    HIP_TRY(nnhip::launch_kernel(nnhip::fill_td_kernel<0>, dim3((unsigned)((N + nnhip::kBlock - 1) / nnhip::kBlock)), dim3(nnhip::kBlock), s, (double2*)tArr, N, t0,
+                                 std::sqrt(opt->dtMax * opt->dtMin)));
+  else
+    HIP_TRY(nnhip::launch_kernel(nnhip::fill_t_dt_kernel<0>, dim3((unsigned)((N + nnhip::kBlock - 1) / nnhip::kBlock)), dim3(nnhip::kBlock), s, tArr, dtArr, N, t0,
+                                 std::sqrt(opt->dtMax * opt->dtMin)));
   nnhip::StepArgs a{};
   a.N = N;
   if (layout == NNHIP_LAYOUT_SOA) { a.ivpStride = 1; a.compStride = N; } else { a.ivpStride = dim; a.compStride = 1; }
-  a.y_in = y; a.y_out = y; a.fsal_in = fsal; a.fsal_out = fsal; a.error = errArr;
+  a.y_in = y; a.y_out = y; a.fsal_in = fsal; a.fsal_out = fsal; a.error = nullptr;
   a.ctl = ctl_of(opt); a.P = P;
   a.tEnd = tEnd; a.t_io = tArr; a.dt_io = dtArr; a.active = nullptr; a.steps_io = nullptr;
   a.stepsPerLaunch = g_adv_steps;
-  // thread-per-IVP kernels (the lanes-per-system ones are not memory-bound enough to gain: measured -3 %)
-  a.nontemporal = g_adv_nt >= 0 ? g_adv_nt : ((dim <= 4 && (int64_t)sizeof(double) * (2 * dim + 3) * N > (192LL << 20)) ? 1 : 0);
+  a.recomputeFsal = recomputeFsal;
+  // thread-per-IVP kernels (the lanes-per-system ones are not memory-bound enough to gain: measured -3 %); the state of one launch = y, (t, dt) and FSAL if carried
+  a.nontemporal = g_adv_nt >= 0 ? g_adv_nt : ((dim <= 4 && (int64_t)sizeof(double) * ((fsalInHbm ? 2 : 1) * dim + 2) * N > (192LL << 20)) ? 1 : 0);
   if (check_every <= 0) check_every = 8;
   rc = adv_poll_reserve();
   if (rc) return rc;
@@ -1878,9 +1895,14 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
   a.ctl = ctl_of(opt); a.P = P;
   a.t_io = tdArr; a.dt_io = nullptr;
   a.denseIdx_io = denseIdx; a.emitAfter = 1;
+  {
+    const bool fsalRecomputable = integrator == NNHIP_DOPRI54 || integrator == NNHIP_TSIT54;
+    a.recomputeFsal = !fsalRecomputable ? 0 : (g_adv_refsal >= 0 ? g_adv_refsal : (nnhip::rtc_has_aux(rhs_kind) ? 0 : 1));
+  }
+  const bool fsalInHbm = !(a.recomputeFsal || integrator == NNHIP_RK21);
   a.rows = y_out; a.rowStride = nState;
   // state of one launch beyond the Infinity Cache: non-temporal instantiation (thread-per-IVP kernels; knob "adv_nontemporal")
-  a.nontemporal = g_adv_nt >= 0 ? g_adv_nt : ((dim <= 4 && (int64_t)sizeof(double) * (2 * dim + 3) * N > (192LL << 20)) ? 1 : 0);
+  a.nontemporal = g_adv_nt >= 0 ? g_adv_nt : ((dim <= 4 && (int64_t)sizeof(double) * ((fsalInHbm ? 2 : 1) * dim + 2) * N > (192LL << 20)) ? 1 : 0);
   if (check_every <= 0) check_every = 8;
   const double dtInit = std::sqrt(opt->dtMax * opt->dtMin);  // :491-493
   const dim3 grid((unsigned)((N + nnhip::kBlock - 1) / nnhip::kBlock)), block(nnhip::kBlock);

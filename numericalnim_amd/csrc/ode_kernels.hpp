@@ -91,7 +91,8 @@ struct StepArgs {
   // advance mode (adaptive streaming driver): one iteration of ODESolver's loop body per launch (ode.nim:525-541)
   double tEnd;           // IVPs with t >= tEnd are finished and touch no memory
   double* t_io;          // per-IVP time, read and updated in place
-  double* dt_io;         // per-IVP step size, read and updated in place
+  double* dt_io;         // per-IVP step size, read and updated in place; nullptr: t_io holds (t, dt) of IVP i side by side ([N][2], 16-byte
+                         // aligned) — one 16-byte access each way instead of two of 8: the streaming drivers' own workspace is laid out so
   unsigned int* active;  // nullable; kAggSlots flags, set when a workgroup still has IVPs short of tEnd after this launch
   int64_t* steps_io;     // nullable: per-IVP accepted-step counter
   const double* perIvpParams;  // nullable [nPerIvp][N], as in SolveArgs
@@ -100,6 +101,8 @@ struct StepArgs {
   int stepsPerLaunch;  // advance mode: loop iterations per IVP and launch with the state kept in registers in between (<= 1: one, the
                        // IntegratorProc seam proper; K > 1 moves 8*(4d+5)/K bytes per attempted step — a different traffic model, reported apart)
   int nontemporal;  // advance mode: non-temporal hint on the streamed state arrays (working set beyond the Infinity Cache)
+  int recomputeFsal;  // advance mode, DOPRI54 / Tsit54: FSAL is not carried through HBM but re-evaluated as f(t, y) at the start of the launch
+                      // (see adv_fsal_in_hbm): 16*d bytes per step less for one more evaluation of f — the same bits
   // advance mode WITH dense output (adaptive streaming through the IntegratorProc seam, ode.nim:512-530): tReq == nullptr -> none.
   const double* tReq;   // requested times of this direction as the reference holds them (tPositive ascending / tNegative descending)
   int nReq;
@@ -610,34 +613,65 @@ NNHIP_DEV bool adv_vec2(const StepArgs& a) {
          ((((uintptr_t)a.y_in | (uintptr_t)a.fsal_in | (uintptr_t)a.y_out | (uintptr_t)a.fsal_out) & 15) == 0);
 #endif
 }
+// Does the FSAL slot of the IntegratorProc signature (ode.nim:38) travel through HBM between launches?
+//   BS32, RK21     never: they evaluate k1 = f(t, y) themselves (:203, :224) and nothing reads the slot they return;
+//   DOPRI54, Tsit54  unless StepArgs::recomputeFsal: their FSAL is the last stage f(t + dt, yNew) with yNew the stage's own argument
+//                  (b = the tableau's last row, c_S = 1), i.e. f of exactly the (t, y) the next launch reads — a pure right-hand side
+//                  evaluated there again returns the same bits, for 16*d bytes per step less;
+//   Vern65         always: its last stage's argument is not yNew (separate b literals, :426-433).
+template <int METHOD>
+NNHIP_DEV bool adv_fsal_in_hbm(const StepArgs& a) {
+  if constexpr (METHOD == NNHIP_BS32 || METHOD == NNHIP_RK21) return false;
+  else if constexpr (METHOD == NNHIP_DOPRI54 || METHOD == NNHIP_TSIT54) return a.recomputeFsal == 0;
+  else return true;
+}
 template <bool NT, class Ops, int D>
-NNHIP_DEV void adv_load_state(const StepArgs& a, const Ops& ops, int64_t base, double (&y)[D], double (&fsal)[D]) {
+NNHIP_DEV void adv_load_state(const StepArgs& a, const Ops& ops, int64_t base, double (&y)[D], double (&fsal)[D], bool withFsal = true) {
   if constexpr (D % 2 == 0 && OpsAllOwned<Ops>::value && !NT) {
     if (adv_vec2(a)) {
 #pragma unroll
       for (int c = 0; c < D; c += 2) {
         const double2 v = *reinterpret_cast<const double2*>(&a.y_in[base + c]);
-        const double2 w = *reinterpret_cast<const double2*>(&a.fsal_in[base + c]);
-        y[c] = v.x; y[c + 1] = v.y; fsal[c] = w.x; fsal[c + 1] = w.y;
+        y[c] = v.x; y[c + 1] = v.y;
+      }
+      if (withFsal) {
+#pragma unroll
+        for (int c = 0; c < D; c += 2) {
+          const double2 w = *reinterpret_cast<const double2*>(&a.fsal_in[base + c]);
+          fsal[c] = w.x; fsal[c + 1] = w.y;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < D; ++c) fsal[c] = 0.0;
       }
       return;
     }
   }
 #pragma unroll
   for (int c = 0; c < D; ++c) {
-    if (!ops.owns(c)) { y[c] = 0.0; fsal[c] = 0.0; continue; }
-    if constexpr (NT) { y[c] = __builtin_nontemporal_load(&a.y_in[base + c * a.compStride]); fsal[c] = __builtin_nontemporal_load(&a.fsal_in[base + c * a.compStride]); }
-    else { y[c] = a.y_in[base + c * a.compStride]; fsal[c] = a.fsal_in[base + c * a.compStride]; }
+    fsal[c] = 0.0;
+    if (!ops.owns(c)) { y[c] = 0.0; continue; }
+    if constexpr (NT) y[c] = __builtin_nontemporal_load(&a.y_in[base + c * a.compStride]);
+    else y[c] = a.y_in[base + c * a.compStride];
+  }
+  if (withFsal) {
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      if (!ops.owns(c)) continue;
+      if constexpr (NT) fsal[c] = __builtin_nontemporal_load(&a.fsal_in[base + c * a.compStride]);
+      else fsal[c] = a.fsal_in[base + c * a.compStride];
+    }
   }
 }
 template <bool NT, class Ops, int D>
-NNHIP_DEV void adv_store_state(const StepArgs& a, const Ops& ops, int64_t base, const double (&yNew)[D], const double (&fsal)[D]) {
+NNHIP_DEV void adv_store_state(const StepArgs& a, const Ops& ops, int64_t base, const double (&yNew)[D], const double (&fsal)[D], bool withFsal = true) {
   if constexpr (D % 2 == 0 && OpsAllOwned<Ops>::value && !NT) {
     if (adv_vec2(a)) {
 #pragma unroll
-      for (int c = 0; c < D; c += 2) {
-        *reinterpret_cast<double2*>(&a.y_out[base + c]) = make_double2(yNew[c], yNew[c + 1]);
-        *reinterpret_cast<double2*>(&a.fsal_out[base + c]) = make_double2(fsal[c], fsal[c + 1]);
+      for (int c = 0; c < D; c += 2) *reinterpret_cast<double2*>(&a.y_out[base + c]) = make_double2(yNew[c], yNew[c + 1]);
+      if (withFsal) {
+#pragma unroll
+        for (int c = 0; c < D; c += 2) *reinterpret_cast<double2*>(&a.fsal_out[base + c]) = make_double2(fsal[c], fsal[c + 1]);
       }
       return;
     }
@@ -645,8 +679,16 @@ NNHIP_DEV void adv_store_state(const StepArgs& a, const Ops& ops, int64_t base, 
 #pragma unroll
   for (int c = 0; c < D; ++c) {
     if (!ops.owns(c)) continue;
-    if constexpr (NT) { __builtin_nontemporal_store(yNew[c], &a.y_out[base + c * a.compStride]); __builtin_nontemporal_store(fsal[c], &a.fsal_out[base + c * a.compStride]); }
-    else { a.y_out[base + c * a.compStride] = yNew[c]; a.fsal_out[base + c * a.compStride] = fsal[c]; }
+    if constexpr (NT) __builtin_nontemporal_store(yNew[c], &a.y_out[base + c * a.compStride]);
+    else a.y_out[base + c * a.compStride] = yNew[c];
+  }
+  if (withFsal) {
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      if (!ops.owns(c)) continue;
+      if constexpr (NT) __builtin_nontemporal_store(fsal[c], &a.fsal_out[base + c * a.compStride]);
+      else a.fsal_out[base + c * a.compStride] = fsal[c];
+    }
   }
 }
 // Shared by the thread-per-IVP and the lanes-per-system form.  `base` addresses this lane's first owned component of IVP i; all
@@ -656,25 +698,35 @@ struct AdvState {
   double t, dt, y[D], fsal[D];
   bool live;
 };
+// (t, dt) of IVP i in either form of StepArgs::t_io / dt_io
+NNHIP_DEV void adv_ld_t_dt(const StepArgs& a, int64_t i, double& t, double& dt) {
+  if (a.dt_io) { dt = a.dt_io[i]; t = a.t_io[i]; }
+  else { const double2 v = reinterpret_cast<const double2*>(a.t_io)[i]; t = v.x; dt = v.y; }
+}
+NNHIP_DEV void adv_st_t_dt(const StepArgs& a, int64_t i, double t, double dt) {
+  if (a.dt_io) { a.t_io[i] = t; a.dt_io[i] = dt; }
+  else reinterpret_cast<double2*>(a.t_io)[i] = make_double2(t, dt);
+}
 // phase 1: t, and — for IVPs still short of tEnd — dt, y, FSAL (finished IVPs touch no other memory)
-template <bool NT, class Ops, bool SPECULATE = false>
+template <int METHOD, bool NT, class Ops, bool SPECULATE = false>
 NNHIP_DEV void adv_fetch(const StepArgs& a, const Ops& ops, int64_t i, int64_t base, AdvState<Ops::D>& s) {
+  const bool withFsal = adv_fsal_in_hbm<METHOD>(a);
   if constexpr (SPECULATE) {
     // all loads of the IVP in ONE round trip (finished IVPs read their state for nothing): `t` first would put the state loads
     // behind a dependent branch = two serialized memory latencies per wave.  The empty asm keeps the loads above the branch.
-    adv_load_state<NT>(a, ops, base, s.y, s.fsal);
-    s.dt = a.dt_io[i];
-    s.t = a.t_io[i];
+    adv_load_state<NT>(a, ops, base, s.y, s.fsal, withFsal);
+    adv_ld_t_dt(a, i, s.t, s.dt);
 #pragma unroll
     for (int c = 0; c < Ops::D; ++c) asm volatile("" : "+v"(s.y[c]), "+v"(s.fsal[c]));
     asm volatile("" : "+v"(s.dt), "+v"(s.t));
     s.live = s.t < a.tEnd;  // :511
   } else {
-    s.t = a.t_io[i];
+    if (a.dt_io) s.t = a.t_io[i];
+    else adv_ld_t_dt(a, i, s.t, s.dt);
     s.live = s.t < a.tEnd;  // :511
     if (s.live) {
-      adv_load_state<NT>(a, ops, base, s.y, s.fsal);
-      s.dt = a.dt_io[i];
+      adv_load_state<NT>(a, ops, base, s.y, s.fsal, withFsal);
+      if (a.dt_io) s.dt = a.dt_io[i];
     }
   }
 }
@@ -709,13 +761,12 @@ NNHIP_DEV unsigned int adv_compute(const StepArgs& a, const Ops& ops, AdvState<O
   return t < a.tEnd ? 1u : 0u;
 }
 // ... and its write-back
-template <bool NT, class Ops>
+template <int METHOD, bool NT, class Ops>
 NNHIP_DEV void adv_commit(const StepArgs& a, const Ops& ops, int64_t i, int64_t base, bool writeScalars, const AdvResult<Ops::D>& r) {
   if (!r.live) return;
-  adv_store_state<NT>(a, ops, base, r.y, r.fsal);
+  adv_store_state<NT>(a, ops, base, r.y, r.fsal, adv_fsal_in_hbm<METHOD>(a));
   if (writeScalars) {
-    a.t_io[i] = r.t;
-    a.dt_io[i] = r.dt;
+    adv_st_t_dt(a, i, r.t, r.dt);
     if (a.error) a.error[i] = r.error;
     if (a.steps_io) a.steps_io[i] += r.steps;
   }
@@ -727,6 +778,9 @@ NNHIP_DEV unsigned int adv_advance(const StepArgs& a, const Ops& ops, int64_t i,
   constexpr int D = Ops::D;
   AdvResult<D> r;
   unsigned int more;
+  if constexpr (METHOD == NNHIP_DOPRI54 || METHOD == NNHIP_TSIT54) {
+    if (a.recomputeFsal && s.live) ops.rhs(s.t, s.y, s.fsal);  // FSAL = f(t, y): what the previous launch's last stage evaluated (adv_fsal_in_hbm)
+  }
   if constexpr (!MULTI) {
     more = adv_compute<METHOD>(a, ops, s, r);  // the IntegratorProc seam proper: one loop iteration per launch
   } else {
@@ -743,13 +797,13 @@ NNHIP_DEV unsigned int adv_advance(const StepArgs& a, const Ops& ops, int64_t i,
     }
     r.steps = k;
   }
-  adv_commit<NT>(a, ops, i, base, writeScalars, r);
+  adv_commit<METHOD, NT>(a, ops, i, base, writeScalars, r);
   return more;
 }
 template <int METHOD, bool NT = false, bool MULTI = false, class Ops>
 NNHIP_DEV unsigned int advance_body(const StepArgs& a, const Ops& ops, int64_t i, int64_t base, bool writeScalars) {
   AdvState<Ops::D> s;
-  adv_fetch<NT>(a, ops, i, base, s);
+  adv_fetch<METHOD, NT>(a, ops, i, base, s);
   return adv_advance<METHOD, NT, MULTI>(a, ops, i, base, writeScalars, s);
 }
 
@@ -837,9 +891,8 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_LPS_ATTR void advance_lps_kernel(
     const LpsOps<RHS, false, CPL> ops0{P0, ys, es, c};
     auto prefetch = [&](int64_t i, AdvState<CPL>& s, Params& P) {
       const int64_t ic = i < a.N ? i : a.N - 1;
-      adv_load_state<false>(a, ops0, ic * a.ivpStride + c * a.compStride, s.y, s.fsal);
-      s.dt = a.dt_io[ic];
-      s.t = a.t_io[ic];
+      adv_load_state<false>(a, ops0, ic * a.ivpStride + c * a.compStride, s.y, s.fsal, adv_fsal_in_hbm<METHOD>(a));
+      adv_ld_t_dt(a, ic, s.t, s.dt);
       P = params_of(a, ic);           // per-IVP parameters (sweeps) belong to the tile's loads as well
       asm volatile("" ::: "memory");  // keeps the tiles' loads in program order: the wait for tile g must not cover tile g + 1's loads
     };
@@ -890,7 +943,7 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_LPS_ATTR void advance_lps_kernel(
     if (idx[g] < a.N) {
       const Params P = params_of(a, idx[g]);
       const LpsOps<RHS, false, CPL> ops{P, lds + sysInBlock * lps_stride<DIM>(), lds + lps_lds_doubles<DIM, CPL>() / 2 + sysInBlock * lps_stride<DIM>(), c};
-      adv_fetch<false, decltype(ops), NNHIP_ADV_LPS_SPECULATE != 0>(a, ops, idx[g], idx[g] * a.ivpStride + c * a.compStride, st[g]);
+      adv_fetch<METHOD, false, decltype(ops), NNHIP_ADV_LPS_SPECULATE != 0>(a, ops, idx[g], idx[g] * a.ivpStride + c * a.compStride, st[g]);
     }
   }
 #pragma unroll
@@ -1007,11 +1060,17 @@ NNHIP_DEV unsigned int advance_dense_body(const StepArgs& a, const OPS& ops, int
   double t = td.x;
   if (!(t < a.tEnd)) return 0u;  // :511
   const int64_t cs = a.compStride;
+  // DOPRI54 / Tsit54 re-evaluate FSAL instead (StepArgs::recomputeFsal); RK21 never reads the slot; BS32's stepper does not either, but the
+  // slot it returns (k4 = f(t + dt, yNew)) is lastIter.dy of the dense output (MethodTraits::fsal), so here it travels
+  const bool withFsal = METHOD == NNHIP_BS32 ? true : adv_fsal_in_hbm<METHOD>(a);
   double y[D], yNew[D], fsal[D];
 #pragma unroll
   for (int c = 0; c < D; ++c) {
     y[c] = ops.owns(c) ? ld_state<NT>(&a.y_in[base + c * cs]) : 0.0;
-    fsal[c] = ops.owns(c) ? ld_state<NT>(&a.fsal_in[base + c * cs]) : 0.0;
+    fsal[c] = (withFsal && ops.owns(c)) ? ld_state<NT>(&a.fsal_in[base + c * cs]) : 0.0;
+  }
+  if constexpr (METHOD == NNHIP_DOPRI54 || METHOD == NNHIP_TSIT54) {
+    if (a.recomputeFsal) ops.rhs(t, y, fsal);
   }
   double dt = td.y;
   const int high = a.nReq - 1;
@@ -1071,7 +1130,10 @@ NNHIP_DEV unsigned int advance_dense_body(const StepArgs& a, const OPS& ops, int
   }
 #pragma unroll
   for (int c = 0; c < D; ++c)
-    if (ops.owns(c)) { st_state<NT>(yNew[c], &a.y_out[base + c * cs]); st_state<NT>(fsal[c], &a.fsal_out[base + c * cs]); }
+    if (ops.owns(c)) {
+      st_state<NT>(yNew[c], &a.y_out[base + c * cs]);
+      if (withFsal) st_state<NT>(fsal[c], &a.fsal_out[base + c * cs]);
+    }
   // every requested time has been emitted: the reference leaves the loop here and its final yPositive.add(y) falls outside the
   // requested rows.  Retire the IVP (denseIndex == nReq tells the finalize kernel that nothing is left to add).
   if (done) t = a.tEnd;
@@ -1228,8 +1290,14 @@ hipError_t launch_advance_tpi(const StepArgs& a, int block, hipStream_t s) {
 #define NNHIP_ADV_CPL_MAX 2  // with one component per lane the controller (norm, division, sqrt, pow: ~200 VALU) runs 16x per system and the
 #endif                       // kernel is VALU-bound; two per lane halve that and still move 16 B per lane access (AoS)
 #define NNHIP_ADV_CPL(ca) ((ca) < NNHIP_ADV_CPL_MAX ? (ca) : NNHIP_ADV_CPL_MAX)
-template <int METHOD, class RHS, int CPL>
-hipError_t launch_advance_lps(const StepArgs& a, int, hipStream_t s) {
+// CPLR: components per lane when FSAL is re-evaluated instead of carried (StepArgs::recomputeFsal).  The launch then moves 8*(2d+4) bytes
+// per step instead of 8*(4d+4) and is no longer bound by HBM but by the VALU, where halving the replicated controller arithmetic once more
+// pays: 1e6 x 16, Tsit54: 2 per lane 106-108 us, 4 per lane 96.6-97.3 us, 8 per lane 129 us (tools/microbench/mb_adv c4quick).
+template <int METHOD, class RHS, int CPL, int CPLR = CPL>
+hipError_t launch_advance_lps(const StepArgs& a, int block, hipStream_t s) {
+  if constexpr (CPLR != CPL && (METHOD == NNHIP_DOPRI54 || METHOD == NNHIP_TSIT54)) {
+    if (a.recomputeFsal) return launch_advance_lps<METHOD, RHS, CPLR, CPLR>(a, block, s);
+  }
   if constexpr (MethodTraits<METHOD>::adaptive) {
     constexpr int perBlock = kBlock / (RHS::dim / CPL) * NNHIP_ADV_LPS_SPG;
     const int64_t grid = (a.N + perBlock - 1) / perBlock;
@@ -1634,7 +1702,7 @@ StepLaunchFn find_advance_tpi(int rhs_kind, int dim) {
   NNHIP_FOR_EACH_TPI_RHS(X)
 #undef X
 #define X(kind, d, T, CA, CF) \
-  if (rhs_kind == kind && dim == d) return &launch_advance_lps<METHOD, T, NNHIP_ADV_CPL(CA)>;
+  if (rhs_kind == kind && dim == d) return &launch_advance_lps<METHOD, T, NNHIP_ADV_CPL(CA), ((CA) < 4 ? (CA) : 4)>;
   NNHIP_FOR_EACH_LPS_RHS(X)
 #undef X
   return nullptr;

@@ -1,9 +1,14 @@
 #!/usr/bin/env python3
-"""HBM-resident adaptive streaming (advance kernels, 8*(4d+5) B per attempted step) vs the fused solve:
+"""HBM-resident adaptive streaming (advance kernels) vs the fused solve:
 C3 shape (Lorenz, thread-per-IVP) at 1e6 and 1e7 IVPs and C4 shape (16-component ring, lanes-per-system) at 1e6 systems.
-Each config runs on a side stream twice: hipGraph-replayed polling groups (default) and eager launches (stream_graph=0).
+Algorithmic bytes per step and IVP (a rejected attempt is retried inside the launch, so the state moves once per ACCEPTED step):
+  FSAL carried through HBM (knob adv_recompute_fsal = 0: the IntegratorProc signature as the reference passes it)   8*(4d+4)
+  FSAL re-evaluated per launch (default for DOPRI54 / Tsit54 since round 3: the same bits, one more evaluation of f) 8*(2d+4)
+(rounds 1-2 also stored the error estimate: 8*(4d+5); `frac_of_8TBps_round2_bytes` prices the time with that figure for continuity.)
+Each config runs on a side stream: hipGraph-replayed polling groups (default) and eager launches (stream_graph=0), non-temporal hint forced
+off / on, FSAL carried, K = 2 / 5 loop iterations per launch.
 Wall clock of the whole loop incl. host polling; `us_per_iteration` divides by the loop iterations that do work
-(= max attempted... accepted steps over the batch), speculative tail launches are overhead, not work."""
+(= max accepted steps over the batch), speculative tail launches are overhead, not work."""
 import json
 import os
 import sys
@@ -57,21 +62,27 @@ for name, f, y0, layout, d, n in cases:
         torch.cuda.synchronize()
         fused_ms = (time.perf_counter() - c0) * 1e3
         iters = int(cnt["steps"].max())                       # loop iterations until the slowest IVP is done
-        attempted = int(cnt["steps"].sum() + cnt["rejected"].sum())
-        # graph = defaults (non-temporal hint chosen from the working-set size); nt0 / nt1 force it off / on; eager = no graph replay
+        accepted = int(cnt["steps"].sum())
+        # graph = defaults (non-temporal hint chosen from the working-set size, FSAL re-evaluated); nt0 / nt1 force the hint off / on; eager = no
+        # graph replay; fsal_carried = knob adv_recompute_fsal 0
         # K > 1 (knob "adv_steps_per_launch"): K loop iterations per IVP and launch with the state kept in registers in between — ITS OWN
-        # traffic model (8*(4d+5)/K bytes per attempted step), reported beside the one-iteration-per-launch figures, never mixed with them
-        for mode, knob, nt, K in (("graph", 2, -1, 1), ("graph_nt0", 2, 0, 1), ("graph_nt1", 2, 1, 1), ("eager", 0, -1, 1), ("graph_K2", 2, -1, 2), ("graph_K5", 2, -1, 5)):
+        # traffic model (1/K of the bytes per step), reported beside the one-iteration-per-launch figures, never mixed with them
+        for mode, knob, nt, K, refsal in (("graph", 2, -1, 1, -1), ("graph_nt0", 2, 0, 1, -1), ("graph_nt1", 2, 1, 1, -1), ("eager", 0, -1, 1, -1),
+                                         ("graph_fsal_carried", 2, -1, 1, 0), ("eager_fsal_carried", 0, -1, 1, 0), ("graph_K2", 2, -1, 2, -1), ("graph_K5", 2, -1, 5, -1),
+                                         ("graph_K5_fsal_carried", 2, -1, 5, 0)):
             L.nnhip_tune_set(b"stream_graph", knob)
             L.nnhip_tune_set(b"adv_nontemporal", nt)
             L.nnhip_tune_set(b"adv_steps_per_launch", K)
+            L.nnhip_tune_set(b"adv_recompute_fsal", refsal)
             dt, launches, ys = run(f, y0, integ, layout, 8)
-            # algorithmic bytes: 8*(4d+5) per attempted step; with default options no step is rejected, so every IVP moves
-            # them once per loop iteration it takes part in
-            nb = 8 * (4 * d + 5) * attempted / K
+            per_step = 8 * (4 * d + 4) if refsal == 0 else 8 * (2 * d + 4)
+            nb = per_step * accepted / K
             res[f"{name}_{integ}_{mode}"] = dict(stream_ms=dt * 1e3, launches=launches, iterations=iters, us_per_iteration=dt * 1e6 / iters, steps_per_launch=K,
-                                                 bytes_per_attempted_step=8 * (4 * d + 5) / K, GBps=nb / dt / 1e9, frac_of_8TBps=nb / dt / 8e12,
+                                                 fsal="carried through HBM" if refsal == 0 else "re-evaluated per launch", bytes_per_step=per_step / K,
+                                                 GBps=nb / dt / 1e9, frac_of_8TBps=nb / dt / 8e12,
+                                                 frac_of_8TBps_round2_bytes=8 * (4 * d + 5) * accepted / K / dt / 8e12,
                                                  fused_ms=fused_ms, equal_to_fused=bool(torch.equal(ys, yf[-1])))
+        L.nnhip_tune_set(b"adv_recompute_fsal", -1)
         L.nnhip_tune_set(b"stream_graph", 2)
         L.nnhip_tune_set(b"adv_nontemporal", -1)
         L.nnhip_tune_set(b"adv_steps_per_launch", 1)

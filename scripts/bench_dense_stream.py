@@ -2,7 +2,7 @@
 """The dense adaptive streaming driver (nnhip_ode_adaptive_stream_dense_f64_dev: ODESolver INCLUDING the emission block ode.nim:512-530 through
 the IntegratorProc seam) against its own byte model and against the loop without dense output.
 
-  bytes per step             8*(4d+5)   state in/out (y, FSAL, t, dt, error)          as the non-dense loop
+  bytes per step             8*(2d+4)   state in/out (y, t, dt; FSAL is re-evaluated per launch by DOPRI54 / Tsit54)  as the non-dense loop
                            + 4          denseIndex read (lastIter = (t, y, dy), :526-530, stays in the launch's registers since round 3:
                                         the launch that takes a step also emits the requested times that step passed)
   bytes per emitted row      8*d + 4    the row itself, denseIndex written back
@@ -60,10 +60,10 @@ for n in (1_000_000, 10_000_000):
                             best, out = dt_, (y, launches)
                 rows = (n_t - 1) * n  # emitted rows besides y0's own (t0 is in tspan)
                 accepted = int(cnt["steps"].sum())
-                nbytes = accepted * (8 * (4 * d + 5) + 4) + rows * (8 * d + 4)
+                nbytes = accepted * (8 * (2 * d + 4) + 4) + rows * (8 * d + 4)
                 res[f"C3_N{n:.0e}_{integ}_nt{n_t}_{mode}"] = dict(
                     ms=best * 1e3, launches=out[1], iterations=iters, us_per_iteration=best * 1e6 / iters, GBps=nbytes / best / 1e9,
-                    frac_of_8TBps=nbytes / best / 8e12, bytes_model="accepted*(8(4d+5)+4) + rows*(8d+4)",
+                    frac_of_8TBps=nbytes / best / 8e12, bytes_model="accepted*(8(2d+4)+4) + rows*(8d+4)",
                     nondense_stream_ms=base * 1e3, ratio_to_nondense=best / base, equal_to_fused=bool(torch.equal(out[0], yf)))
             L.nnhip_tune_set(b"stream_graph", 2)
 print(json.dumps(res, indent=1))

@@ -483,6 +483,73 @@ def test_adaptive_stream_graph_replay_thread_per_ivp(nn, oracle, dev):
                 assert torch.equal(ys, yf[-1]) and launches >= 102
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_adaptive_stream_fsal_carried_or_reevaluated(nn, dev, mode):
+    """Tuning knob "adv_recompute_fsal": the streaming loops of DOPRI54 / Tsit54 either carry FSAL through HBM (0: the IntegratorProc
+    signature as the reference passes it, ode.nim:38) or re-evaluate it as f(t, y) at the start of each launch (1: it IS the last
+    stage f(t + dt, yNew) of the step before, ode.nim:299-305 / 362-374).  Both must give the bits of the fused solve — thread-per-IVP
+    and lanes-per-system kernels (2 and 4 components per lane), a NON-autonomous run-time compiled right-hand side (t + dt*c_7 with
+    c_7 = 1 must be the t the next launch reads), K iterations per launch, the dense streaming driver, and a workspace that is only
+    8-byte aligned (two columns for t and dt instead of one of pairs).  Vern65 / BS32 / RK21 ignore the knob."""
+    import ctypes as C
+    import torch
+    L = nn._lib.lib()
+    assert L.nnhip_tune_set(b"adv_recompute_fsal", mode) == 0
+    try:
+        n = 2001
+        yt = torch.from_numpy(_lorenz_y0(n)).to(dev)
+        kw = dict(absTol=1e-6, relTol=1e-6, dtMin=1e-9, dtMax=1.0)
+        for integ in ("dopri54", "tsit54", "vern65", "bs32", "rk21"):
+            t, yf = nn.solveODE(nn.Rhs.lorenz(), yt, [0.0, 1.5], nn.newODEoptions(**kw), integrator=integ)
+            for K in (1, 3):
+                ys, launches = nn.adaptiveStream(nn.Rhs.lorenz(), yt.clone(), 0.0, 1.5, nn.newODEoptions(**kw), integrator=integ, check_every=3, steps_per_launch=K)
+                assert torch.equal(ys, yf[-1]), (integ, K)
+            ts = [0.0, 0.2, 0.20001, 0.9, 1.5]
+            t2, yd, ny, launches = nn.adaptiveStreamSolve(nn.Rhs.lorenz(), yt, ts, nn.newODEoptions(**kw), integrator=integ)
+            assert torch.equal(yd, nn.solveODE(nn.Rhs.lorenz(), yt, ts, nn.newODEoptions(**kw), integrator=integ)[1]), integ
+        assert L.nnhip_tune_set(b"adv_steps_per_launch", 1) == 0
+        kw = dict(absTol=1e-8, relTol=1e-8, dtMin=1e-7, dtMax=0.25)
+        for dim, n, layout in ((16, 1000, 1), (16, 777, 0), (8, 500, 1), (24, 100, 1)):   # 24: run-time compiled lanes-per-system kernel
+            y0 = _ring_y0(n, dim)
+            yl = torch.from_numpy(y0 if layout == 1 else np.ascontiguousarray(y0.T)).to(dev)
+            for integ in ("tsit54", "dopri54"):
+                t, yf = nn.solveODE(nn.Rhs.ring(0.1), yl, [0.0, 1.0], nn.newODEoptions(**kw), integrator=integ, layout=layout)
+                ys, launches = nn.adaptiveStream(nn.Rhs.ring(0.1), yl.clone(), 0.0, 1.0, nn.newODEoptions(**kw), integrator=integ, layout=layout, check_every=4)
+                assert torch.equal(ys, yf[-1]), (dim, layout, integ)
+            ts = [0.0, 0.3, 1.0]
+            t2, yd, ny, launches = nn.adaptiveStreamSolve(nn.Rhs.ring(0.1), yl, ts, nn.newODEoptions(**kw), integrator="tsit54", layout=layout)
+            assert torch.equal(yd, nn.solveODE(nn.Rhs.ring(0.1), yl, ts, nn.newODEoptions(**kw), integrator="tsit54", layout=layout)[1]), (dim, layout)
+        duff = nn.Rhs.custom(2, "dy[0] = y[1]; dy[1] = ((-p[0] * y[1] - p[1] * y[0]) - p[2] * (y[0] * y[0] * y[0])) + p[3] * t;",
+                             keys=("delta", "alpha", "beta", "gamma"), defaults=dict(delta=0.2, alpha=1.0, beta=0.5, gamma=0.3), name="duffing_fsal_modes")
+        y0 = torch.from_numpy(0.5 + np.random.default_rng(9).random((2, 2000))).to(dev)
+        o = nn.newODEoptions(absTol=1e-7, relTol=1e-7, dtMin=1e-9, dtMax=0.5, tStart=0.125)
+        for integ in ("dopri54", "tsit54"):
+            t, yf = nn.solveODE(duff, y0, [0.125, 2.0], o, integrator=integ)
+            ys, launches = nn.adaptiveStream(duff, y0.clone(), 0.125, 2.0, o, integrator=integ)
+            assert torch.equal(ys, yf[-1]), integ
+            ts = [-0.3, 0.125, 0.5, 2.0]
+            t2, yd, ny, launches = nn.adaptiveStreamSolve(duff, y0, ts, o, integrator=integ)
+            assert torch.equal(yd, nn.solveODE(duff, y0, ts, o, integrator=integ)[1]), integ
+        # a workspace at an odd multiple of 8 bytes: (t, dt) fall back to two columns
+        yt = torch.from_numpy(_lorenz_y0(n)).to(dev)
+        opt = nn.newODEoptions(absTol=1e-6, relTol=1e-6, dtMin=1e-9, dtMax=1.0)
+        yf = nn.solveODE(nn.Rhs.lorenz(), yt, [0.0, 1.0], opt, integrator="dopri54")[1][-1]
+        wsb = int(L.nnhip_ode_adaptive_stream_workspace_bytes(n, 3))
+        ws = torch.empty(wsb + 16, dtype=torch.uint8, device=dev)
+        y = yt.clone()
+        nl = C.c_int64(0)
+        p = (C.c_double * 3)(10.0, 28.0, 8.0 / 3.0)
+        rc = L.nnhip_ode_adaptive_stream_f64_dev(C.byref(opt), nn.ode.integrator_id("dopri54"), nn.Rhs.lorenz().kind, p, 3, n, 3, 0, 0.0, 1.0, y.data_ptr(),
+                                                 ws.data_ptr() + 8, wsb, 4, 0, C.byref(nl), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, nn._lib.last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(y, yf)
+    finally:
+        assert L.nnhip_tune_set(b"adv_recompute_fsal", -1) == 0
+        assert L.nnhip_tune_set(b"adv_steps_per_launch", 1) == 0
+    assert L.nnhip_tune_set(b"adv_recompute_fsal", 2) != 0 and L.nnhip_tune_set(b"adv_recompute_fsal", -2) != 0
+
+
 @pytest.mark.parametrize("K", [2, 3, 7, 1000])
 def test_adaptive_stream_several_iterations_per_launch(nn, oracle, dev, K):
     """Tuning knob "adv_steps_per_launch": K iterations of ode.nim:525-541 per IVP and launch, state in registers in between.  Same

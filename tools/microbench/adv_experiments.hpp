@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_LPS_ATTR void advance_lps_persist
     NNHIP_ADV_TIMING_MARK(0)
     adv_touch(cur);                                                                          // the wait
     NNHIP_ADV_TIMING_MARK(1)
-    if constexpr (PROBE != 1) adv_commit<false>(a, ops, iRes, iRes * a.ivpStride + c * a.compStride, c == 0, res);     // tile g-1 goes out
+    if constexpr (PROBE != 1) adv_commit<METHOD, false>(a, ops, iRes, iRes * a.ivpStride + c * a.compStride, c == 0, res);     // tile g-1 goes out
     const int64_t nt = tile + gridDim.x;
     if constexpr (PROBE == 1) nxt = cur;
     else if (nt < nTiles) prefetch(nt, nxt);                                                 // tile g+1 comes in
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_LPS_ATTR void advance_lps_persist
     NNHIP_ADV_TIMING_MARK(3)
   }
   if (PINGPONG && !lateHalf) __builtin_amdgcn_s_barrier();
-  adv_commit<false>(a, ops, iRes, iRes * a.ivpStride + c * a.compStride, c == 0, res);
+  adv_commit<METHOD, false>(a, ops, iRes, iRes * a.ivpStride + c * a.compStride, c == 0, res);
   NNHIP_ADV_TIMING_FLUSH
   if (a.active) {
     if (__syncthreads_or((int)stillActive) && threadIdx.x == 0) a.active[blockIdx.x % kAggSlots] = 1u;
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_TPI_ATTR void advance_tpi_persist
   if (tile < nTiles) prefetch(tile, cur);
   for (; tile < nTiles; tile += gridDim.x) {
     adv_touch(cur);
-    adv_commit<NT>(a, ops, iRes, iRes * a.ivpStride, true, res);
+    adv_commit<METHOD, NT>(a, ops, iRes, iRes * a.ivpStride, true, res);
     const int64_t nt = tile + gridDim.x;
     if (nt < nTiles) prefetch(nt, nxt);
     const int64_t i = tile * blockDim.x + threadIdx.x;
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_TPI_ATTR void advance_tpi_persist
     iRes = i;
     cur = nxt;
   }
-  adv_commit<NT>(a, ops, iRes, iRes * a.ivpStride, true, res);
+  adv_commit<METHOD, NT>(a, ops, iRes, iRes * a.ivpStride, true, res);
   if (a.active) {
     if (__syncthreads_or((int)stillActive) && threadIdx.x == 0) a.active[blockIdx.x % kAggSlots] = 1u;
   }

@@ -22,15 +22,15 @@ struct Problem {
   Params P; StepCtl ctl; double t0, tEnd, dt0;
 };
 struct DevState {
-  double *y, *fsal, *t, *dt, *err; unsigned int* active;
+  double *y, *fsal, *t, *dt, *err, *td; unsigned int* active;
   int64_t N; int dim;
   void alloc(int64_t n, int d) {
     N = n; dim = d;
     CK(hipMalloc(&y, sizeof(double) * n * d)); CK(hipMalloc(&fsal, sizeof(double) * n * d));
-    CK(hipMalloc(&t, sizeof(double) * n)); CK(hipMalloc(&dt, sizeof(double) * n)); CK(hipMalloc(&err, sizeof(double) * n));
+    CK(hipMalloc(&t, sizeof(double) * n)); CK(hipMalloc(&dt, sizeof(double) * n)); CK(hipMalloc(&err, sizeof(double) * n)); CK(hipMalloc(&td, sizeof(double) * 2 * n));
     CK(hipMalloc(&active, sizeof(unsigned) * kAggSlots));
   }
-  void release() { (void)hipFree(y); (void)hipFree(fsal); (void)hipFree(t); (void)hipFree(dt); (void)hipFree(err); (void)hipFree(active); }
+  void release() { (void)hipFree(y); (void)hipFree(fsal); (void)hipFree(t); (void)hipFree(dt); (void)hipFree(err); (void)hipFree(td); (void)hipFree(active); }
 };
 
 template <class RHS>
@@ -39,29 +39,40 @@ static void init_state(const Problem& p, DevState& s) {
   const int64_t is = p.layout ? p.dim : 1, cs = p.layout ? 1 : p.N;
   CK(launch_kernel(rhs_batch_kernel<RHS>, dim3((unsigned)((p.N + kBlock - 1) / kBlock)), dim3(kBlock), nullptr, p.N, is, cs, p.t0, (const double*)s.y, s.fsal, p.P));
   CK(launch_kernel(fill_t_dt_kernel<0>, dim3((unsigned)((p.N + kBlock - 1) / kBlock)), dim3(kBlock), nullptr, s.t, s.dt, p.N, p.t0, p.dt0));
+  CK(launch_kernel(fill_td_kernel<0>, dim3((unsigned)((p.N + kBlock - 1) / kBlock)), dim3(kBlock), nullptr, (double2*)s.td, p.N, p.t0, p.dt0));
   CK(hipMemset(s.err, 0, sizeof(double) * p.N));
   CK(hipMemset(s.active, 0, sizeof(unsigned) * kAggSlots));
   CK(hipDeviceSynchronize());
 }
-static StepArgs make_args(const Problem& p, DevState& s) {
+// mode 0: t, dt, error as three columns (the layout up to round 3's first half); 1: (t, dt) side by side, error not stored (production
+// since); 2: columns, error not stored
+static StepArgs make_args(const Problem& p, DevState& s, int mode = 0) {
   StepArgs a{};
   a.N = p.N;
   if (p.layout == 0) { a.ivpStride = 1; a.compStride = p.N; } else { a.ivpStride = p.dim; a.compStride = 1; }
   a.y_in = s.y; a.y_out = s.y; a.fsal_in = s.fsal; a.fsal_out = s.fsal; a.error = s.err;
   a.ctl = p.ctl; a.P = p.P; a.tEnd = p.tEnd; a.t_io = s.t; a.dt_io = s.dt; a.active = nullptr; a.steps_io = nullptr;
+  if (mode) a.error = nullptr;
+  if (mode == 1 || mode == 3) { a.t_io = s.td; a.dt_io = nullptr; }
+  if (mode == 3) a.recomputeFsal = 1;  // mode 3: mode 1 + FSAL re-evaluated at the start of the launch instead of carried through HBM
   return a;
 }
 using Launch = std::function<hipError_t(const StepArgs&, hipStream_t)>;
-struct Candidate { std::string name; Launch launch; int K = 1; };  // K: loop iterations per launch (the harness then issues 1/K of the launches)
+struct Candidate { std::string name; Launch launch; int K = 1; int mode = 0; };  // K: loop iterations per launch (the harness then issues 1/K of the launches)
 
-static std::vector<double> fetch(const DevState& s) {
-  std::vector<double> h((size_t)s.N * (2 * s.dim + 3));
+static std::vector<double> fetch(const DevState& s, int mode) {  // y, FSAL, t, dt (the error column is not compared: modes 1 and 2 do not store it)
+  std::vector<double> h((size_t)s.N * (2 * s.dim + 2));
   double* q = h.data();
   CK(hipMemcpy(q, s.y, sizeof(double) * s.N * s.dim, hipMemcpyDeviceToHost)); q += s.N * s.dim;
   CK(hipMemcpy(q, s.fsal, sizeof(double) * s.N * s.dim, hipMemcpyDeviceToHost)); q += s.N * s.dim;
-  CK(hipMemcpy(q, s.t, sizeof(double) * s.N, hipMemcpyDeviceToHost)); q += s.N;
-  CK(hipMemcpy(q, s.dt, sizeof(double) * s.N, hipMemcpyDeviceToHost)); q += s.N;
-  CK(hipMemcpy(q, s.err, sizeof(double) * s.N, hipMemcpyDeviceToHost));
+  if (mode == 1 || mode == 3) {
+    std::vector<double> td((size_t)s.N * 2);
+    CK(hipMemcpy(td.data(), s.td, sizeof(double) * 2 * s.N, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < s.N; ++i) { q[i] = td[2 * i]; q[s.N + i] = td[2 * i + 1]; }
+  } else {
+    CK(hipMemcpy(q, s.t, sizeof(double) * s.N, hipMemcpyDeviceToHost)); q += s.N;
+    CK(hipMemcpy(q, s.dt, sizeof(double) * s.N, hipMemcpyDeviceToHost));
+  }
   return h;
 }
 
@@ -78,7 +89,7 @@ static void run_all(const char* title, const Problem& p, std::vector<Candidate>&
     std::vector<double> out;
     for (int r = 0; r < reps; ++r) {
       init_state<RHS>(p, s);
-      StepArgs a = make_args(p, s);
+      StepArgs a = make_args(p, s, c.mode);
       for (int k = 0; k < warm / c.K; ++k) CK(c.launch(a, st));
       CK(hipEventRecord(e0, st));
       for (int k = 0; k < iters / c.K; ++k) CK(c.launch(a, st));
@@ -86,7 +97,15 @@ static void run_all(const char* title, const Problem& p, std::vector<Candidate>&
       CK(hipStreamSynchronize(st));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       if (ms < best) best = ms;
-      if (r == 0) out = fetch(s);
+      if (r == 0) {
+        if (c.mode == 3) {  // the FSAL array was not touched: fill it with f(t, y) of the final state (the right-hand sides here are autonomous), so that
+                            // the comparison also checks that the carried FSAL of the other candidates IS f of the state they end in
+          const int64_t is = p.layout ? p.dim : 1, cs = p.layout ? 1 : p.N;
+          CK(launch_kernel(rhs_batch_kernel<RHS>, dim3((unsigned)((p.N + kBlock - 1) / kBlock)), dim3(kBlock), st, p.N, is, cs, p.t0, (const double*)s.y, s.fsal, p.P));
+          CK(hipStreamSynchronize(st));
+        }
+        out = fetch(s, c.mode);
+      }
     }
 #ifdef NNHIP_ADV_TIMING
     {
@@ -163,6 +182,23 @@ int main(int argc, char** argv) {
     using R = RhsRing<16>;
     std::vector<Candidate> c;
     c.push_back({"tsit54 base (2 tiles/block)", lps_base<NNHIP_TSIT54, R, 2>()});
+    c.push_back({"tsit54 base, error not stored", lps_base<NNHIP_TSIT54, R, 2>(), 1, 2});
+    c.push_back({"tsit54 base, (t,dt) packed", lps_base<NNHIP_TSIT54, R, 2>(), 1, 1});
+    c.push_back({"tsit54 base again", lps_base<NNHIP_TSIT54, R, 2>()});
+    c.push_back({"tsit54 base, (t,dt) packed again", lps_base<NNHIP_TSIT54, R, 2>(), 1, 1});
+    c.push_back({"tsit54 packed, FSAL recomputed", lps_base<NNHIP_TSIT54, R, 2>(), 1, 3});
+    c.push_back({"tsit54 packed, FSAL recomputed CPL=4", lps_base<NNHIP_TSIT54, R, 4>(), 1, 3});
+    if (strstr(only, "quick")) {
+      c.push_back({"dopri54 base", lps_base<NNHIP_DOPRI54, R, 2>()});
+      c.push_back({"dopri54 base, (t,dt) packed", lps_base<NNHIP_DOPRI54, R, 2>(), 1, 1});
+      c.push_back({"dopri54 packed, FSAL recomputed", lps_base<NNHIP_DOPRI54, R, 2>(), 1, 3});
+      c.push_back({"dopri54 packed, FSAL recomputed CPL=4", lps_base<NNHIP_DOPRI54, R, 4>(), 1, 3});
+      c.push_back({"dopri54 packed, FSAL recomputed CPL=8", lps_base<NNHIP_DOPRI54, R, 8>(), 1, 3});
+      c.push_back({"tsit54 packed, FSAL recomputed CPL=8", lps_base<NNHIP_TSIT54, R, 8>(), 1, 3});
+      c.push_back({"tsit54 packed CPL=4 (FSAL carried)", lps_base<NNHIP_TSIT54, R, 4>(), 1, 1});
+      c.push_back({"tsit54 packed, FSAL recomputed CPL=4 again", lps_base<NNHIP_TSIT54, R, 4>(), 1, 3});
+      run_all<R>("C4 streamed (quick list)", p, c, 10, 60, 5, 8.0 * (4 * 16 + 5));
+    } else {
     for (int b : {3, 4}) c.push_back({"tsit54 persist grid=256x" + std::to_string(b), lps_persist<NNHIP_TSIT54, R, 2>(b)});
     c.push_back({"tsit54 pingpong grid=256x4", lps_persist<NNHIP_TSIT54, R, 2, true>(4)});
     c.push_back({"tsit54 base again", lps_base<NNHIP_TSIT54, R, 2>()});
@@ -193,6 +229,7 @@ int main(int argc, char** argv) {
     d.push_back({"dopri54 persist grid=256x4", lps_persist<NNHIP_DOPRI54, R, 2>(4)});
     d.push_back({"dopri54 pingpong grid=256x4", lps_persist<NNHIP_DOPRI54, R, 2, true>(4)});
     run_all<R>("C4 streamed, DOPRI54", p, d, 10, 60, 3, 8.0 * (4 * 16 + 5));
+    }
   }
   for (int64_t n : {(int64_t)1000000, (int64_t)10000000}) {  // C3: Lorenz, SoA, default options
     const std::string tag = n == 1000000 ? "c3a" : "c3b";
@@ -207,6 +244,19 @@ int main(int argc, char** argv) {
     c.push_back({"dopri54 base b256", tpi_base<M, R>(256, 0)});
     c.push_back({"dopri54 base b64", tpi_base<M, R>(64, 0)});
     c.push_back({"dopri54 base b64 nt", tpi_base<M, R>(64, 1)});
+    c.push_back({"dopri54 base b256 err not stored", tpi_base<M, R>(256, 0), 1, 2});
+    c.push_back({"dopri54 base b256 packed", tpi_base<M, R>(256, 0), 1, 1});
+    c.push_back({"dopri54 base b64 packed", tpi_base<M, R>(64, 0), 1, 1});
+    c.push_back({"dopri54 base b64 nt packed", tpi_base<M, R>(64, 1), 1, 1});
+    c.push_back({"dopri54 base b256 again", tpi_base<M, R>(256, 0)});
+    c.push_back({"dopri54 base b256 packed again", tpi_base<M, R>(256, 0), 1, 1});
+    c.push_back({"tsit54 base b256", tpi_base<NNHIP_TSIT54, R>(256, 0)});
+    c.push_back({"tsit54 base b256 packed", tpi_base<NNHIP_TSIT54, R>(256, 0), 1, 1});
+    c.push_back({"dopri54 b256 packed FSAL recomputed", tpi_base<M, R>(256, 0), 1, 3});
+    c.push_back({"dopri54 b64 packed FSAL recomputed", tpi_base<M, R>(64, 0), 1, 3});
+    c.push_back({"dopri54 b64 nt packed FSAL recomputed", tpi_base<M, R>(64, 1), 1, 3});
+    c.push_back({"tsit54 b64 packed FSAL recomputed", tpi_base<NNHIP_TSIT54, R>(64, 0), 1, 3});
+    if (strstr(only, "quick")) { run_all<R>(("C3 streamed (quick list) " + tag).c_str(), p, c, 10, 60, 5, 8.0 * (4 * 3 + 5)); continue; }
     for (int b : {3, 4, 5, 8}) c.push_back({"dopri54 persist b256 grid=256x" + std::to_string(b), tpi_persist<M, R, false>(256, b)});
     for (int b : {12, 16, 20}) c.push_back({"dopri54 persist b64 grid=256x" + std::to_string(b), tpi_persist<M, R, false>(64, b)});
     c.push_back({"dopri54 persist nt b256 grid=256x4", tpi_persist<M, R, true>(256, 4)});
