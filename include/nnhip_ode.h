@@ -108,7 +108,8 @@ int nnhip_host_free(void* p);
  *   "rk4_stream_mode" 0..3 (0 plain, 1 non-temporal, 2 persistent, 3 both), "rk4_stream_blocks_per_cu" 1..64,
  *   "stream_graph" 0|1|2 (0 eager launches; 1 capture nnhip_ode_fixed_stream_f64_dev's launch sequence in a hipGraph
  *   and replay it; default 2 = do so for launch-bound batches — up to 2e6 states, 16..1e4 steps, a non-default stream — from the
- *   second identical call on; the polling groups of nnhip_ode_adaptive_stream_f64_dev are replayed from a graph unless 0),
+ *   second identical call on; the polling groups of nnhip_ode_adaptive_stream[_dense]_f64_dev are replayed from a graph only with 1 —
+ *   measured: eager launches are as fast or faster at every batch size),
  *   "adv_nontemporal" -1|0|1 (non-temporal instantiations of the streaming kernels; -1 = automatic: when the state of one launch
  *   exceeds 192 MiB), "adv_split" 0|1|2|4 (index ranges of the adaptive streaming loop on separate streams; measured slower, default 1),
  *   "adv_block" 0|64|128|256 (workgroup size of the thread-per-IVP advance kernel; 0 = automatic: 64),
@@ -329,7 +330,7 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
  * y (device, in `layout`) is
  * advanced in place from t0 to tEnd; `ws` is device scratch of nnhip_ode_adaptive_stream_workspace_bytes(N, dim).  The host
  * learns whether anyone is still integrating every `check_every` launches (<= 0: 8) and always has the next group enqueued
- * before it waits (groups are replayed from a hipGraph on a non-default stream), so up to 2*check_every trailing launches
+ * before it waits (groups can be replayed from a hipGraph on a non-default stream: knob "stream_graph" = 1), so up to 2*check_every trailing launches
  * find nothing to do (they read t only).  Results are bitwise those of the fused solve.  Thread-per-IVP kernels for small
  * systems, lanes-per-system kernels for Vector[float] states of 8 / 16 / 32 ... components (ahead of time or run-time compiled). */
 int64_t nnhip_ode_adaptive_stream_workspace_bytes(int64_t N, int dim);

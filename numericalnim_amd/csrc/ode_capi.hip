@@ -1777,7 +1777,10 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
 
   // ---- the polling group as a graph (cached per thread; key = everything the launches depend on), one per half of the flag block ----
   hipGraphExec_t execs[2] = {nullptr, nullptr};
-  if (g_stream_graph != 0 && s != nullptr) {
+  // Replayed only when asked for (knob 1) since round 3: with (t, dt) interleaved and FSAL re-evaluated a launch takes 5-300 us, the command
+  // processor pipelines eager launches behind each other, and a graph's node-to-node hand-over costs 1-2 us more than that (Lorenz 1e4 ... 3e6
+  // IVPs and 16-component rings: eager 0-8 % faster at every size, scripts/ab_stream_graph_vs_eager.py)
+  if (g_stream_graph == 1 && s != nullptr) {
     int device = 0;
     HIP_TRY(hipGetDevice(&device));
     for (int half = 0; half < 2; ++half) {
@@ -1951,7 +1954,7 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
     };
     int64_t dirLaunches = 0;  // max_launches bounds each direction's loop, as max_steps does in the fused solve
     hipGraphExec_t execs[2] = {nullptr, nullptr};
-    if (g_stream_graph != 0 && s != nullptr) {
+    if (g_stream_graph == 1 && s != nullptr) {  // as the loop without dense output: eager launches unless asked for
       int device = 0;
       HIP_TRY(hipGetDevice(&device));
       if (!fn.advance) {  // run-time compiled kernels: load the module before the stream goes into capture mode

@@ -5,8 +5,8 @@ Algorithmic bytes per step and IVP (a rejected attempt is retried inside the lau
   FSAL carried through HBM (knob adv_recompute_fsal = 0: the IntegratorProc signature as the reference passes it)   8*(4d+4)
   FSAL re-evaluated per launch (default for DOPRI54 / Tsit54 since round 3: the same bits, one more evaluation of f) 8*(2d+4)
 (rounds 1-2 also stored the error estimate: 8*(4d+5); `frac_of_8TBps_round2_bytes` prices the time with that figure for continuity.)
-Each config runs on a side stream: hipGraph-replayed polling groups (default) and eager launches (stream_graph=0), non-temporal hint forced
-off / on, FSAL carried, K = 2 / 5 loop iterations per launch.
+Each config runs on a side stream: eager launches (default since round 3) and hipGraph-replayed polling groups (stream_graph=1), non-temporal hint
+forced off / on, FSAL carried, K = 2 / 5 loop iterations per launch.
 Wall clock of the whole loop incl. host polling; `us_per_iteration` divides by the loop iterations that do work
 (= max accepted steps over the batch), speculative tail launches are overhead, not work."""
 import json
@@ -45,6 +45,8 @@ if os.environ.get("ADV_BLOCK"):   # workgroup size of the thread-per-IVP advance
     assert L.nnhip_tune_set(b"adv_block", int(os.environ["ADV_BLOCK"])) == 0
 cases = []
 ONLY = os.environ.get("ADV_BENCH_ONLY", "")   # e.g. "C3_lorenz_N1e+07" to profile one config
+MODES = [m for m in os.environ.get("ADV_BENCH_MODES", "").split(",") if m]     # e.g. "default,fsal_carried"
+INTEGS = [m for m in os.environ.get("ADV_BENCH_INTEGRATORS", "").split(",") if m] or ["dopri54", "tsit54"]
 for n in (1_000_000, 10_000_000):
     y0 = torch.from_numpy(np.stack([1.0 + (np.arange(n) % 1024) * 2.0 ** -20, np.ones(n), np.ones(n)])).to(dev)
     cases.append((f"C3_lorenz_N{n:.0e}", nn.Rhs.lorenz(), y0, 0, 3, n))
@@ -54,7 +56,7 @@ cases.append(("C4_ring16_N1e+06", nn.Rhs.ring(0.1), y16, 1, 16, n))
 for name, f, y0, layout, d, n in cases:
     if ONLY and ONLY not in name:
         continue
-    for integ in ("dopri54", "tsit54"):
+    for integ in INTEGS:
         t, yf, cnt = nn.solveODE(f, y0, [0.0, 1.0], nn.newODEoptions(), integrator=integ, layout=layout, return_counts=True)
         torch.cuda.synchronize()
         c0 = time.perf_counter()
@@ -63,13 +65,15 @@ for name, f, y0, layout, d, n in cases:
         fused_ms = (time.perf_counter() - c0) * 1e3
         iters = int(cnt["steps"].max())                       # loop iterations until the slowest IVP is done
         accepted = int(cnt["steps"].sum())
-        # graph = defaults (non-temporal hint chosen from the working-set size, FSAL re-evaluated); nt0 / nt1 force the hint off / on; eager = no
-        # graph replay; fsal_carried = knob adv_recompute_fsal 0
+        # default = eager launches, non-temporal hint chosen from the working-set size, FSAL re-evaluated; nt0 / nt1 force the hint off / on;
+        # graph = polling groups replayed from a hipGraph (knob stream_graph 1); fsal_carried = knob adv_recompute_fsal 0
         # K > 1 (knob "adv_steps_per_launch"): K loop iterations per IVP and launch with the state kept in registers in between — ITS OWN
         # traffic model (1/K of the bytes per step), reported beside the one-iteration-per-launch figures, never mixed with them
-        for mode, knob, nt, K, refsal in (("graph", 2, -1, 1, -1), ("graph_nt0", 2, 0, 1, -1), ("graph_nt1", 2, 1, 1, -1), ("eager", 0, -1, 1, -1),
-                                         ("graph_fsal_carried", 2, -1, 1, 0), ("eager_fsal_carried", 0, -1, 1, 0), ("graph_K2", 2, -1, 2, -1), ("graph_K5", 2, -1, 5, -1),
-                                         ("graph_K5_fsal_carried", 2, -1, 5, 0)):
+        for mode, knob, nt, K, refsal in (("default", 2, -1, 1, -1), ("nt0", 2, 0, 1, -1), ("nt1", 2, 1, 1, -1), ("graph", 1, -1, 1, -1),
+                                         ("fsal_carried", 2, -1, 1, 0), ("graph_fsal_carried", 1, -1, 1, 0), ("K2", 2, -1, 2, -1), ("K5", 2, -1, 5, -1),
+                                         ("K5_fsal_carried", 2, -1, 5, 0)):
+            if MODES and mode not in MODES:
+                continue
             L.nnhip_tune_set(b"stream_graph", knob)
             L.nnhip_tune_set(b"adv_nontemporal", nt)
             L.nnhip_tune_set(b"adv_steps_per_launch", K)

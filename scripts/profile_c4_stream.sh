@@ -19,19 +19,18 @@ for g in "${G[@]}"; do
   i=$((i+1))
 done
 python - <<'PY'
-import csv, glob, collections, json
-out = {}
-import os
+import csv, glob, collections, json, os
 TAG, KF = os.environ["TAG"], os.environ["KFILTER"]
+out = collections.defaultdict(dict)   # per kernel instantiation (carried / re-evaluated FSAL and K > 1 are different template arguments)
 for d in sorted(glob.glob(f"gpurun_out/prof_{TAG}_*/")):
     for f in glob.glob(d + "**/*counter_collection.csv", recursive=True):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if KF in r["Kernel_Name"]:   # e.g. "advance_lps_kernel<2," = Tsit54 (kernel names are demangled)
-                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        for c, v in agg.items():
+                agg[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (k, c), v in agg.items():
             v.sort()
-            out[c] = dict(p50=v[len(v) // 2], p75=v[int(len(v) * 0.75)], n=len(v))   # working launches: upper part of the distribution
+            out[k][c] = dict(p50=v[len(v) // 2], p75=v[int(len(v) * 0.75)], n=len(v))   # working launches: upper part of the distribution
 print(json.dumps(out, indent=1))
 json.dump(out, open(f"gpurun_out/prof_{TAG}_counters.json", "w"), indent=1)
 PY

@@ -468,19 +468,37 @@ def test_adaptive_stream_lanes_per_system_equals_fused(nn, oracle, dev, integrat
 
 
 def test_adaptive_stream_graph_replay_thread_per_ivp(nn, oracle, dev):
-    """Graph-replayed polling groups (non-default stream) for the thread-per-IVP advance kernel: C3-shaped, bits of the fused solve."""
+    """Graph-replayed polling groups (tuning knob "stream_graph" = 1, non-default stream; eager launches are the default since round 3) for
+    the thread-per-IVP and the lanes-per-system advance kernels and for the dense streaming driver: bits of the fused solve, call after call
+    (the second and third replay the cached graphs)."""
     import torch
+    L = nn._lib.lib()
     n = 5000
     yt = torch.from_numpy(_lorenz_y0(n)).to(dev)
-    for integ in ("dopri54", "tsit54"):
-        t, yf = nn.solveODE(nn.Rhs.lorenz(), yt, [0.0, 1.0], integrator=integ)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for rep in range(3):
-                ys, launches = nn.adaptiveStream(nn.Rhs.lorenz(), yt.clone(), 0.0, 1.0, integrator=integ)
-                side.synchronize()
-                assert torch.equal(ys, yf[-1]) and launches >= 102
+    yr = torch.from_numpy(_ring_y0(700, 16)).to(dev)
+    ts = [0.0, 0.25, 0.5, 1.0]
+    try:
+        for knob in (1, 2):
+            assert L.nnhip_tune_set(b"stream_graph", knob) == 0
+            for integ in ("dopri54", "tsit54"):
+                t, yf = nn.solveODE(nn.Rhs.lorenz(), yt, [0.0, 1.0], integrator=integ)
+                td, yd = nn.solveODE(nn.Rhs.lorenz(), yt, ts, integrator=integ)
+                tr, yrf = nn.solveODE(nn.Rhs.ring(0.1), yr, [0.0, 1.0], integrator=integ, layout=1)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for rep in range(3):
+                        ys, launches = nn.adaptiveStream(nn.Rhs.lorenz(), yt.clone(), 0.0, 1.0, integrator=integ)
+                        side.synchronize()
+                        assert torch.equal(ys, yf[-1]) and launches >= 102
+                        t2, y2, ny, launches = nn.adaptiveStreamSolve(nn.Rhs.lorenz(), yt, ts, integrator=integ)
+                        side.synchronize()
+                        assert torch.equal(y2, yd)
+                        ys, launches = nn.adaptiveStream(nn.Rhs.ring(0.1), yr.clone(), 0.0, 1.0, integrator=integ, layout=1)
+                        side.synchronize()
+                        assert torch.equal(ys, yrf[-1])
+    finally:
+        assert L.nnhip_tune_set(b"stream_graph", 2) == 0
 
 
 @pytest.mark.parametrize("mode", [0, 1])
