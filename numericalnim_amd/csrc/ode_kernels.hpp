@@ -855,8 +855,13 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_TPI_ATTR void advance_tpi_kernel(
 // SIMD nothing else overlaps them.  Measured (profiles/r02_pow_tables_ab.txt section 11): 125 -> 118 us per iteration with 2 tiles;
 // 4 and 8 tiles no better; fetching 2 tiles up front WITHOUT the pipeline (PIPE=0, SPG=2), the speculative single round trip alone
 // (NNHIP_ADV_LPS_SPECULATE), 16-byte accesses (adv_vec2) and padded LDS slots each change nothing measurable.
-#ifndef NNHIP_ADV_LPS_SPG
-#define NNHIP_ADV_LPS_SPG 2
+// Tiles per block by components per lane: the prefetched tile costs 2 * CPL + 2 doubles of VGPRs per lane; at 4 components per lane that is the
+// difference between 2 waves per SIMD and fewer, and ONE tile per block (no prefetch, twice the blocks) is faster in both FSAL modes
+// (1e6 x 16 Tsit54, kernel alone: FSAL re-evaluated 96-98 -> 88.5-91 us, carried 120.6 -> 108.3 us; at 2 per lane 2 tiles stay better: 119 vs 121 us).
+#ifdef NNHIP_ADV_LPS_SPG  // A/B hook: forces the number of tiles for every instantiation
+constexpr int adv_lps_spg(int) { return NNHIP_ADV_LPS_SPG; }
+#else
+constexpr int adv_lps_spg(int cpl) { return cpl >= 4 ? 1 : 2; }
 #endif
 #ifndef NNHIP_ADV_LPS_SPECULATE
 #define NNHIP_ADV_LPS_SPECULATE 0
@@ -872,7 +877,7 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_LPS_ATTR void advance_lps_kernel(
   static_assert(MethodTraits<METHOD>::adaptive, "fixed-step methods share (t, dt): use the uniform streaming loop");
   constexpr int DIM = RHS::dim;
   constexpr int LPSYS = DIM / CPL;
-  constexpr int SPG = NNHIP_ADV_LPS_SPG;
+  constexpr int SPG = adv_lps_spg(CPL);
   static_assert(DIM % CPL == 0 && 64 % LPSYS == 0, "a system must not straddle wavefronts");
   __shared__ double lds[lps_lds_doubles<DIM, CPL>()];
   controller_prologue();
@@ -1106,6 +1111,11 @@ NNHIP_DEV unsigned int advance_dense_body(const StepArgs& a, const OPS& ops, int
   else if (a.ctl.dtMax < dt) dt = a.ctl.dtMax;
   if (error != error) t = a.tEnd;  // NaN abort, as in the fused driver
   bool done = false;
+#ifndef NNHIP_DENSE_NO_FENCE
+  // everything the emission block derives from denseIndex / rowBase (row addresses, the index of the next requested time) is computed
+  // AFTER the stages: left to the compiler it is hoisted to the top of the kernel and held in VGPRs across them
+  asm volatile("" : "+v"(denseIndex), "+v"(rowBase));
+#endif
   if (a.useDense && a.emitAfter && t < a.tEnd) {  // :511-524 of the next iteration
     double treq = sTreq, treqNext = sTreqNext;
     if (!uniformIdx) {
@@ -1145,10 +1155,9 @@ NNHIP_DEV unsigned int advance_dense_body(const StepArgs& a, const OPS& ops, int
   return t < a.tEnd ? 1u : 0u;
 }
 
-// Workgroup size: 64 for the non-temporal instantiation (beyond the Infinity Cache one-wave workgroups retire and refill sooner, as
-// launch_advance_tpi's default), kBlock otherwise.
+// Workgroup size: one wave, as launch_advance_tpi's default (one-wave workgroups retire and refill sooner)
 template <bool NT>
-constexpr int adv_dense_block() { return NT ? 64 : kBlock; }
+constexpr int adv_dense_block() { return 64; }
 // (Held to 4 waves per SIMD like advance_tpi_kernel this kernel spills: the emission block's operands put it at 147 VGPRs for d = 3 against
 // the 128 of the loop without dense output, and neither parking lastIter in LDS, nor re-reading it in the emission branch, nor compiling
 // the block as a function of its own brought that down without 50-600 B of scratch per lane — 3 waves it is: 217 against 200 us per launch
@@ -1286,9 +1295,9 @@ hipError_t launch_advance_tpi(const StepArgs& a, int block, hipStream_t s) {
 #if !NNHIP_RTC
 // components per lane of the lanes-per-system advance kernel, from the fused kernels' value `ca`
 // (A/B hook: -DNNHIP_ADV_CPL_MAX=1|2|4 caps it)
-#ifndef NNHIP_ADV_CPL_MAX  // measured, 1e6 16-component systems (profiles/r02_pow_tables_ab.txt): 1 -> 200 us, 2 -> 152 us, 4 -> 170 us per iteration:
-#define NNHIP_ADV_CPL_MAX 2  // with one component per lane the controller (norm, division, sqrt, pow: ~200 VALU) runs 16x per system and the
-#endif                       // kernel is VALU-bound; two per lane halve that and still move 16 B per lane access (AoS)
+#ifndef NNHIP_ADV_CPL_MAX  // measured, 1e6 16-component systems: round 2 (two tiles per block, error column, FSAL carried) 1 -> 200 us, 2 -> 152 us, 4 -> 170 us
+#define NNHIP_ADV_CPL_MAX 4  // per iteration: with one component per lane the controller (norm, division, sqrt, pow: ~200 VALU) runs 16x per system.  Round 3
+#endif                       // (one tile per block at 4 per lane, see adv_lps_spg): FSAL carried 2 -> 118-120 us, 4 -> 108 us; re-evaluated 2 -> 106 us, 4 -> 88.5-91 us
 #define NNHIP_ADV_CPL(ca) ((ca) < NNHIP_ADV_CPL_MAX ? (ca) : NNHIP_ADV_CPL_MAX)
 // CPLR: components per lane when FSAL is re-evaluated instead of carried (StepArgs::recomputeFsal).  The launch then moves 8*(2d+4) bytes
 // per step instead of 8*(4d+4) and is no longer bound by HBM but by the VALU, where halving the replicated controller arithmetic once more
@@ -1299,7 +1308,7 @@ hipError_t launch_advance_lps(const StepArgs& a, int block, hipStream_t s) {
     if (a.recomputeFsal) return launch_advance_lps<METHOD, RHS, CPLR, CPLR>(a, block, s);
   }
   if constexpr (MethodTraits<METHOD>::adaptive) {
-    constexpr int perBlock = kBlock / (RHS::dim / CPL) * NNHIP_ADV_LPS_SPG;
+    constexpr int perBlock = kBlock / (RHS::dim / CPL) * adv_lps_spg(CPL);
     const int64_t grid = (a.N + perBlock - 1) / perBlock;
     if (grid <= 0) return hipSuccess;
     if (a.stepsPerLaunch > 1) return launch_kernel(advance_lps_kernel<METHOD, RHS, CPL, true>, dim3((unsigned)grid), dim3(kBlock), s, a);

@@ -99,6 +99,9 @@ int padded_dim(const UserRhsEntry& e) {
 // step-streaming kernels keep one component per lane until a system would no longer fit one wavefront
 int lps_cpl(const UserRhsEntry& e, bool adaptive) { return padded_dim(e) == 8 ? 2 : (padded_dim(e) >= 64 ? 4 : (adaptive ? 4 : 2)); }
 int lps_step_cpl(const UserRhsEntry& e) { return padded_dim(e) <= 64 ? 1 : padded_dim(e) / 64; }
+// the adaptive streaming (advance) kernels: as the built-in systems' (NNHIP_ADV_CPL: the per-lane controller arithmetic is replicated over a
+// system's lanes, so fewer, fatter lanes win — 4 components per lane, 2 for 8-component systems)
+int lps_adv_cpl(const UserRhsEntry& e) { const int c = padded_dim(e) == 8 ? 2 : 4; return c > lps_step_cpl(e) ? c : lps_step_cpl(e); }
 
 // what a body sees of its context: `p` (scalars, wherever they live), one name per declared vector, `aux`
 std::string ctx_preamble(const UserRhsEntry& e) {
@@ -178,9 +181,9 @@ bool compile(const UserRhsEntry& e, int integrator, CodeObject& out) {
   } else if (integrator >= kMultiKey) {  // K loop iterations per launch: its own code object, compiled when first asked for
     const std::string m = std::to_string(integrator - kMultiKey);
     if (uses_lps(e)) {
-      const int scpl = lps_step_cpl(e);
-      names.push_back("nnhip::advance_lps_kernel<" + m + ", nnhip::UserRhs, " + std::to_string(scpl) + ", true>");
-      out.ivpsPerBlockAdvance = kBlock / (padded_dim(e) / scpl) * NNHIP_ADV_LPS_SPG;
+      const int acpl = lps_adv_cpl(e);
+      names.push_back("nnhip::advance_lps_kernel<" + m + ", nnhip::UserRhs, " + std::to_string(acpl) + ", true>");
+      out.ivpsPerBlockAdvance = kBlock / (padded_dim(e) / acpl) * adv_lps_spg(acpl);
     } else {
       names.push_back("nnhip::advance_tpi_kernel<" + m + ", nnhip::UserRhs, false, true>");
     }
@@ -194,10 +197,11 @@ bool compile(const UserRhsEntry& e, int integrator, CodeObject& out) {
       const int scpl = lps_step_cpl(e);
       names.push_back("nnhip::step_lps_kernel<" + m + ", nnhip::UserRhs, false, " + std::to_string(scpl) + ">");
       names.push_back("nnhip::step_lps_kernel<" + m + ", nnhip::UserRhs, true, " + std::to_string(scpl) + ">");
-      if (adaptive) names.push_back("nnhip::advance_lps_kernel<" + m + ", nnhip::UserRhs, " + std::to_string(scpl) + ">");  // adaptive streaming
+      const int acpl = lps_adv_cpl(e);
+      if (adaptive) names.push_back("nnhip::advance_lps_kernel<" + m + ", nnhip::UserRhs, " + std::to_string(acpl) + ">");  // adaptive streaming
       out.ivpsPerBlockSolve = kBlock / (padded_dim(e) / cpl);
       out.ivpsPerBlockStep = kBlock / (padded_dim(e) / scpl);
-      out.ivpsPerBlockAdvance = out.ivpsPerBlockStep * NNHIP_ADV_LPS_SPG;
+      out.ivpsPerBlockAdvance = kBlock / (padded_dim(e) / acpl) * adv_lps_spg(acpl);
     } else {
       names.push_back("nnhip::solve_tpi_kernel<" + m + ", nnhip::UserRhs>");
       names.push_back("nnhip::step_tpi_kernel<" + m + ", nnhip::UserRhs, false>");
