@@ -803,7 +803,12 @@ NNHIP_DEV unsigned int adv_advance(const StepArgs& a, const Ops& ops, int64_t i,
 template <int METHOD, bool NT = false, bool MULTI = false, class Ops>
 NNHIP_DEV unsigned int advance_body(const StepArgs& a, const Ops& ops, int64_t i, int64_t base, bool writeScalars) {
   AdvState<Ops::D> s;
-  adv_fetch<METHOD, NT>(a, ops, i, base, s);
+  // (A/B -DNNHIP_ADV_TPI_SPECULATE=1: every load of the IVP in ONE round trip instead of `t` first — 2-4 % on C3 (1e6: 21.3 -> 20.6 us, 1e7: 186 -> 183 us),
+  // not adopted: IVPs that are finished would keep reading their state, +50 % load traffic in the late launches of a heterogeneous batch)
+#ifndef NNHIP_ADV_TPI_SPECULATE
+#define NNHIP_ADV_TPI_SPECULATE 0
+#endif
+  adv_fetch<METHOD, NT, Ops, NNHIP_ADV_TPI_SPECULATE != 0>(a, ops, i, base, s);
   return adv_advance<METHOD, NT, MULTI>(a, ops, i, base, writeScalars, s);
 }
 
@@ -1158,10 +1163,11 @@ NNHIP_DEV unsigned int advance_dense_body(const StepArgs& a, const OPS& ops, int
 // Workgroup size: one wave, as launch_advance_tpi's default (one-wave workgroups retire and refill sooner)
 template <bool NT>
 constexpr int adv_dense_block() { return 64; }
-// (Held to 4 waves per SIMD like advance_tpi_kernel this kernel spills: the emission block's operands put it at 147 VGPRs for d = 3 against
-// the 128 of the loop without dense output, and neither parking lastIter in LDS, nor re-reading it in the emission branch, nor compiling
-// the block as a function of its own brought that down without 50-600 B of scratch per lane — 3 waves it is: 217 against 200 us per launch
-// at 1e7 Lorenz IVPs.)
+// (Held to 4 waves per SIMD like advance_tpi_kernel this kernel spills: it sits at 145-147 VGPRs for d = 3 against the 128 of the loop without
+// dense output, and neither parking lastIter in LDS (generic pointer or a real LDS array: 153 VGPRs unconstrained, 76-100 B of scratch at 4
+// waves), nor re-reading it in the emission branch, nor compiling the block as a function of its own, nor fencing the block's address
+// arithmetic behind the stages brought that down without 50-600 B of scratch per lane: the pressure is inside the stages, not in what the
+// emission keeps alive.  3 waves it is: 205-223 against 166 us per launch at 1e7 Lorenz IVPs.)
 template <int METHOD, class RHS, bool NT = false>
 __global__ __launch_bounds__(kBlock) void advance_dense_tpi_kernel(const StepArgs a) {
   static_assert(MethodTraits<METHOD>::adaptive, "adaptive methods only");
