@@ -251,7 +251,7 @@ int nnhip_ode_solve_batch_calls_f64(const nnhip_ode_options* opt, const nnhip_od
  * them one after the other, ode.nim:589-591; on a wavefront they share an instruction stream).  The IVPs are INTEGRATED in
  * ascending order of `sort_key` (device array [N]) and every result is WRITTEN at the IVP's own index, so outputs are in the
  * caller's order and bit-identical to nnhip_ode_solve_batch_sweep_f64_dev.  sort_key == NULL: automatic two-pass mode — a probe
- * solve of `probe_steps` accepted steps per IVP (<= 0: 12) ranks the IVPs by the progress they make, then the batch is
+ * solve of `probe_steps` accepted steps per IVP (<= 0: 8) ranks the IVPs by the progress they make, then the batch is
  * integrated in that order.  Fixed-step integrators run unsorted (no divergence).  per_ivp_params may be NULL (n_per_ivp = 0).
  * `ws`: device workspace of nnhip_ode_solve_sorted_workspace_bytes(N, n_t) bytes.  N < 2^31. */
 int64_t nnhip_ode_solve_sorted_workspace_bytes(int64_t N, int n_t);

@@ -804,7 +804,7 @@ int64_t nnhip_ode_solve_sorted_workspace_bytes(int64_t N, int n_t) {
 // IVPs are integrated in ascending order of `sort_key` — neighbouring lanes of a wavefront then agree on accept / reject and
 // finish together — and every result is written at the IVP's own index (SolveArgs::perm), so the output is in the caller's
 // order and bit-identical to the unsorted solve.  sort_key == NULL selects the automatic two-pass mode: a probe solve of
-// `probe_steps` accepted steps per IVP (default 12) measures how far each IVP gets, which ranks the step sizes the controller
+// `probe_steps` accepted steps per IVP (default 8) measures how far each IVP gets, which ranks the step sizes the controller
 // settles on; the batch is then integrated in that order.  Fixed-step methods have no divergence: they run unsorted.
 int nnhip_ode_solve_batch_sorted_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
                                          const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t N, int dim, int layout,
@@ -825,7 +825,7 @@ int nnhip_ode_solve_batch_sorted_f64_dev(const nnhip_ode_options* opt, int integ
   PreparedSolve ps;
   if (adaptive && N > 1) {
     if (!sort_key) {  // pass 1: the probe.  Same solve, cut off after probe_steps accepted steps; only the progress is kept.
-      if (probe_steps <= 0) probe_steps = 12;
+      if (probe_steps <= 0) probe_steps = 8;  // scripts/ab_probe_steps.py (1e6 Van der Pol IVPs): 4 steps do not rank (the controller is still ramping up from dtInit), 6 -> 1.73 ms, 8 -> 1.62 ms, 12 -> 1.68 ms, 16 -> 1.73 ms
       if (max_steps > 0 && probe_steps > max_steps) probe_steps = (int)max_steps;
       int rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y0, N, dim, layout, tspan, n_t, nullptr, y_out,
                              nullptr, nullptr, nullptr, probe_steps, ws, wsTimes, nullptr, nullptr, s, ps);

@@ -288,7 +288,7 @@ def integrator_id(integrator):
 
 
 def solveODE(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=LAYOUT_SOA, max_steps=0, stats=None,
-             return_counts=False, sweep=None, sort_by=None, out=None):
+             return_counts=False, sweep=None, sort_by=None, out=None, probe_steps=0):
     """Batched solveODE (ode.nim:589-651): returns (t, y) with t = the sorted output grid (ndarray) and
     y = [n_t, *y0.shape] holding the state of every IVP at every t (rows the reference would not
     return for an IVP are NaN; see include/nnhip_ode.h).
@@ -300,7 +300,7 @@ def solveODE(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=
     every result is written at the IVP's own index (nnhip_ode_solve_batch_sorted_f64_dev: the ordering lives below the C ABI).
     Results are bit-identical; neighbouring lanes of a wavefront then take similar step sequences, which removes most of the
     divergence of adaptive methods on heterogeneous batches (1.7x on a Van der Pol mu-sweep, scripts/bench_divergence.py).
-    "auto" ranks the IVPs with a short probe solve instead of a user key.
+    "auto" ranks the IVPs with a short probe solve (probe_steps accepted steps per IVP; 0 = the library's default) instead of a user key.
     out: optional result array for numpy batches, float64 C-contiguous of shape [len(tspan), *y0.shape], returned as y.  Reusing
     it across calls avoids the first-touch page faults of a fresh 100+ MB array inside the device-to-host copy (2x on C2), and if
     both y0 and out are page-locked the transfers are overlapped with the kernel (another 1.6x)."""
@@ -354,7 +354,7 @@ def solveODE(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=
                                                               int(sw.shape[0]) if sw is not None else 0, y0c.data_ptr(), N, dim, layout, tsp, n_t, tp,
                                                               y.data_ptr(), ny.data_ptr() if return_counts else None,
                                                               st.data_ptr() if return_counts else None, rj.data_ptr() if return_counts else None,
-                                                              int(max_steps), key.data_ptr() if key is not None else None, 0, ws.data_ptr(), wsb, stream))
+                                                              int(max_steps), key.data_ptr() if key is not None else None, int(probe_steps), ws.data_ptr(), wsb, stream))
             elif sweep is not None:
                 _check(L.nnhip_ode_solve_batch_sweep_f64_dev(C.byref(options), integ, f.kind, pp, int(p.size), sw.data_ptr(), int(sw.shape[0]),
                                                              y0c.data_ptr(), N, dim, layout, tsp, n_t, tp, y.data_ptr(),
