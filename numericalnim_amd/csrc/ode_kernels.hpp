@@ -627,6 +627,10 @@ NNHIP_DEV bool adv_fsal_in_hbm(const StepArgs& a) {
 }
 template <bool NT, class Ops, int D>
 NNHIP_DEV void adv_load_state(const StepArgs& a, const Ops& ops, int64_t base, double (&y)[D], double (&fsal)[D], bool withFsal = true) {
+  // (FSAL is zeroed once, up front: zeroing it separately on the two paths below left the state arrays in scratch — 96 B per lane and twice
+  // the time for BS32 / RK21 on 16-component systems — because the merged stores addressed them through a run-time offset)
+#pragma unroll
+  for (int c = 0; c < D; ++c) fsal[c] = 0.0;
   if constexpr (D % 2 == 0 && OpsAllOwned<Ops>::value && !NT) {
     if (adv_vec2(a)) {
 #pragma unroll
@@ -640,16 +644,12 @@ NNHIP_DEV void adv_load_state(const StepArgs& a, const Ops& ops, int64_t base, d
           const double2 w = *reinterpret_cast<const double2*>(&a.fsal_in[base + c]);
           fsal[c] = w.x; fsal[c + 1] = w.y;
         }
-      } else {
-#pragma unroll
-        for (int c = 0; c < D; ++c) fsal[c] = 0.0;
       }
       return;
     }
   }
 #pragma unroll
   for (int c = 0; c < D; ++c) {
-    fsal[c] = 0.0;
     if (!ops.owns(c)) { y[c] = 0.0; continue; }
     if constexpr (NT) y[c] = __builtin_nontemporal_load(&a.y_in[base + c * a.compStride]);
     else y[c] = a.y_in[base + c * a.compStride];
@@ -904,7 +904,9 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_LPS_ATTR void advance_lps_kernel(
       adv_load_state<false>(a, ops0, ic * a.ivpStride + c * a.compStride, s.y, s.fsal, adv_fsal_in_hbm<METHOD>(a));
       adv_ld_t_dt(a, ic, s.t, s.dt);
       P = params_of(a, ic);           // per-IVP parameters (sweeps) belong to the tile's loads as well
-      asm volatile("" ::: "memory");  // keeps the tiles' loads in program order: the wait for tile g must not cover tile g + 1's loads
+      if constexpr (SPG > 1) asm volatile("" ::: "memory");  // keeps the tiles' loads in program order: the wait for tile g must not cover tile g + 1's loads
+                                                             // (with one tile there is nothing to order, and the clobber would pin the tile's state in scratch
+                                                             // for the methods whose FSAL slot is never read: BS32 / RK21 at 4 components per lane, 96 B per lane)
     };
 #if NNHIP_ADV_LPS_DEPTH == 2  // A/B: two tiles ahead (state of tiles g + 1 and g + 2 in registers while tile g is advanced)
     AdvState<CPL> st[3];

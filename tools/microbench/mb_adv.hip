@@ -198,6 +198,21 @@ int main(int argc, char** argv) {
       c.push_back({"tsit54 packed CPL=4 (FSAL carried)", lps_base<NNHIP_TSIT54, R, 4>(), 1, 1});
       c.push_back({"tsit54 packed, FSAL recomputed CPL=4 again", lps_base<NNHIP_TSIT54, R, 4>(), 1, 3});
       run_all<R>("C4 streamed (quick list)", p, c, 10, 60, 5, 8.0 * (4 * 16 + 5));
+      std::vector<Candidate> b;   // the methods that never read the FSAL slot
+      b.push_back({"bs32 CPL=2", lps_base<NNHIP_BS32, R, 2>(), 1, 1});
+      b.push_back({"bs32 CPL=4", lps_base<NNHIP_BS32, R, 4>(), 1, 1});
+      b.push_back({"bs32 CPL=1", lps_base<NNHIP_BS32, R, 1>(), 1, 1});
+      b.push_back({"bs32 CPL=2 again", lps_base<NNHIP_BS32, R, 2>(), 1, 1});
+      run_all<R>("C4 streamed, BS32 (quick list)", p, b, 10, 60, 5, 8.0 * (2 * 16 + 4));
+      std::vector<Candidate> k;
+      k.push_back({"rk21 CPL=2", lps_base<NNHIP_RK21, R, 2>(), 1, 1});
+      k.push_back({"rk21 CPL=4", lps_base<NNHIP_RK21, R, 4>(), 1, 1});
+      k.push_back({"rk21 CPL=1", lps_base<NNHIP_RK21, R, 1>(), 1, 1});
+      run_all<R>("C4 streamed, RK21 (quick list)", p, k, 10, 60, 5, 8.0 * (2 * 16 + 4));
+      std::vector<Candidate> v;
+      v.push_back({"vern65 CPL=2", lps_base<NNHIP_VERN65, R, 2>(), 1, 1});
+      v.push_back({"vern65 CPL=4", lps_base<NNHIP_VERN65, R, 4>(), 1, 1});
+      run_all<R>("C4 streamed, Vern65 (quick list)", p, v, 10, 60, 5, 8.0 * (4 * 16 + 4));
     } else {
     for (int b : {3, 4}) c.push_back({"tsit54 persist grid=256x" + std::to_string(b), lps_persist<NNHIP_TSIT54, R, 2>(b)});
     c.push_back({"tsit54 pingpong grid=256x4", lps_persist<NNHIP_TSIT54, R, 2, true>(4)});
