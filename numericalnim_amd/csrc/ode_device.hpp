@@ -821,7 +821,7 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
         t += dt;
       }
       for (int k = 0; k < in.nTail; ++k) {
-        const double dk = in.tailDt[k];
+        const double dk = k == 0 ? in.tailDt[0] : k == 1 ? in.tailDt[1] : k == 2 ? in.tailDt[2] : in.tailDt[3];  // (selects: indexing by k put the whole DriveIn in scratch, 136 B per lane)
         if constexpr (METHOD == NNHIP_RK4) rk4_step(ops, t, rk4_dt(dk), y, yNew);
         else fixed_step<METHOD>(ops, t, dk, y, yNew);
 #pragma unroll
