@@ -437,9 +437,10 @@ constexpr int lps_stride() { return DIM + NNHIP_LPS_PAD; }
 template <int DIM, int CPL>
 constexpr int lps_lds_doubles() { return 2 * (kBlock / (DIM / CPL)) * lps_stride<DIM>(); }
 
-template <int CPL, int MODE>
-constexpr int lps_solve_waves() { return (CPL >= 4 && MODE == 0) ? 3 : 1; }
-#define NNHIP_LPS_ATTR __attribute__((amdgpu_waves_per_eu(lps_solve_waves<CPL, MODE>())))
+// (not the 9-stage Vern65: held to 3 waves it spills 200-340 B per lane and the 16-component solve takes 14.6 ms instead of 9.9, r03_dim16_variants.json)
+template <int METHOD, int CPL, int MODE>
+constexpr int lps_solve_waves() { return (METHOD != NNHIP_VERN65 && CPL >= 4 && MODE == 0) ? 3 : 1; }
+#define NNHIP_LPS_ATTR __attribute__((amdgpu_waves_per_eu(lps_solve_waves<METHOD, CPL, MODE>())))
 #else
 #define NNHIP_LPS_ATTR __attribute__((amdgpu_waves_per_eu(NNHIP_LPS_WPE, NNHIP_LPS_WPE)))
 #endif
