@@ -10,5 +10,5 @@ timeout 600 python scripts/bench_adaptive_stream.py > gpurun_out/r03_bench_adapt
 timeout 300 python scripts/ab_host_pinned.py > gpurun_out/r03_host_path.json 2> gpurun_out/host_path.err
 timeout 300 python scripts/bench_extra.py > gpurun_out/r03_bench_extra.json 2> gpurun_out/bench_extra.err
 bash scripts/profile_configs.sh > gpurun_out/profile_cfg.log 2>&1
-tools/bin/bench_c5 --gpus 1 --steps 10 --warmup 2 --verify > gpurun_out/r03_bench_c5_cpp.json 2>/dev/null
+tools/bin/bench_c5 --gpus 1 --steps 10 --warmup 2 --verify 2>/dev/null | grep "^{" > gpurun_out/r03_bench_c5_cpp.json
 tail -1 gpurun_out/r03_bench_default.json | cut -c1-400
