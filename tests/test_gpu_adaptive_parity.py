@@ -568,6 +568,44 @@ def test_adaptive_stream_fsal_carried_or_reevaluated(nn, dev, mode):
     assert L.nnhip_tune_set(b"adv_recompute_fsal", 2) != 0 and L.nnhip_tune_set(b"adv_recompute_fsal", -2) != 0
 
 
+def test_adaptive_stream_edge_shapes(nn, dev):
+    """The streaming drivers at the edges of their index arithmetic: one IVP, odd batch sizes (the (t, dt) pairs and the 16-byte state accesses
+    must not assume an even N), a scalar state, one launch per polling group, an empty integration span, and a launch limit of one —
+    thread-per-IVP and lanes-per-system kernels, both FSAL modes (default and carried), bits of the fused solve."""
+    import warnings
+    import torch
+    L = nn._lib.lib()
+    kw = dict(absTol=1e-7, relTol=1e-7, dtMin=1e-8, dtMax=0.5)
+    try:
+        for mode in (-1, 0):
+            assert L.nnhip_tune_set(b"adv_recompute_fsal", mode) == 0
+            for n in (1, 3, 65, 257):
+                yl = torch.from_numpy(_lorenz_y0(n)).to(dev)
+                yr = torch.from_numpy(_ring_y0(n, 16)).to(dev)
+                ys1 = torch.from_numpy(1.0 + np.arange(n) * 2.0 ** -8).to(dev)
+                for f, y0, layout in ((nn.Rhs.lorenz(), yl, 0), (nn.Rhs.ring(0.1), yr, 1), (nn.Rhs.linear(-0.7), ys1, 0)):
+                    for integ in ("dopri54", "tsit54", "bs32"):
+                        opt = nn.newODEoptions(**kw)
+                        yf = nn.solveODE(f, y0, [0.0, 0.8], opt, integrator=integ, layout=layout)[1][-1]
+                        ys, launches = nn.adaptiveStream(f, y0.clone(), 0.0, 0.8, opt, integrator=integ, layout=layout, check_every=1)
+                        assert torch.equal(ys, yf), (mode, n, integ, layout)
+                        ts = [0.0, 0.05, 0.8]
+                        t2, yd, ny, l2 = nn.adaptiveStreamSolve(f, y0, ts, opt, integrator=integ, layout=layout, check_every=1)
+                        assert torch.equal(yd, nn.solveODE(f, y0, ts, opt, integrator=integ, layout=layout)[1]), (mode, n, integ, layout)
+            # nothing to integrate: the state comes back untouched, no launch is issued
+            y = yl.clone()
+            ys, launches = nn.adaptiveStream(nn.Rhs.lorenz(), y, 1.0, 1.0, nn.newODEoptions(**kw), integrator="dopri54")
+            assert torch.equal(ys, yl) and launches == 0
+            # a launch limit of one: exactly the fused solve's max_steps = 1
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                t2, yd, ny, l2 = nn.adaptiveStreamSolve(nn.Rhs.lorenz(), yl, [0.0, 0.5, 1.0], nn.newODEoptions(**kw), integrator="tsit54", max_launches=1)
+            tf, yf, cf = nn.solveODE(nn.Rhs.lorenz(), yl, [0.0, 0.5, 1.0], nn.newODEoptions(**kw), integrator="tsit54", max_steps=1, return_counts=True)
+            assert l2 == 1 and torch.equal(ny, cf["ny"]) and torch.equal(torch.nan_to_num(yd, nan=-7.0), torch.nan_to_num(yf, nan=-7.0)) and len(w) == 1
+    finally:
+        assert L.nnhip_tune_set(b"adv_recompute_fsal", -1) == 0
+
+
 @pytest.mark.parametrize("K", [2, 3, 7, 1000])
 def test_adaptive_stream_several_iterations_per_launch(nn, oracle, dev, K):
     """Tuning knob "adv_steps_per_launch": K iterations of ode.nim:525-541 per IVP and launch, state in registers in between.  Same
