@@ -1166,16 +1166,17 @@ NNHIP_DEV unsigned int advance_dense_body(const StepArgs& a, const OPS& ops, int
 // Workgroup size: one wave, as launch_advance_tpi's default (one-wave workgroups retire and refill sooner)
 template <bool NT>
 constexpr int adv_dense_block() { return 64; }
-// (Held to 4 waves per SIMD like advance_tpi_kernel this kernel spills: it sits at 145-147 VGPRs for d = 3 against the 128 of the loop without
-// dense output, and neither parking lastIter in LDS (generic pointer or a real LDS array: 153 VGPRs unconstrained, 76-100 B of scratch at 4
-// waves), nor re-reading it in the emission branch, nor compiling the block as a function of its own, nor fencing the block's address
-// arithmetic behind the stages brought that down without 50-600 B of scratch per lane: the pressure is inside the stages, not in what the
-// emission keeps alive.  3 waves it is: 205-223 against 166 us per launch at 1e7 Lorenz IVPs.)
+// Held to 4 waves per SIMD like advance_tpi_kernel (NNHIP_ADV_TPI_ATTR).  Unconstrained the kernel sits at 145-147 VGPRs for d = 3 (3 waves);
+// what kept it from fitting 128 was not what the emission keeps alive (parking lastIter in LDS, re-reading it in the emission branch,
+// compiling the block as a function of its own, fencing its address arithmetic behind the stages: all 50-600 B of scratch at 4 waves) but
+// SGPR pressure: with the emission block's extra uniform arguments, pin_step_args' pinned kernel arguments leave the allocator 52 B of
+// scratch per lane at 4 waves; without the pins 12 B (2 VGPRs), like the loop without dense output.  1e7 Lorenz IVPs: 205-223 -> 196-200 us
+// per launch (n_t = 2 / 11), 270 -> 242 us with a row emitted per launch.
 template <int METHOD, class RHS, bool NT = false>
-__global__ __launch_bounds__(kBlock) void advance_dense_tpi_kernel(const StepArgs a) {
+__global__ __launch_bounds__(kBlock) NNHIP_ADV_TPI_ATTR void advance_dense_tpi_kernel(const StepArgs a) {
   static_assert(MethodTraits<METHOD>::adaptive, "adaptive methods only");
   controller_prologue();
-  pin_step_args(a);
+  // (no pin_step_args here: with the extra uniform arguments of the emission block the pinned SGPRs push the allocator from 12 to 52 B of scratch at 4 waves per SIMD)
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // workgroup size chosen by the launcher (<= kBlock)
   unsigned int stillActive = 0;
   if (i < a.N) {
