@@ -1692,6 +1692,9 @@ hipError_t launch_advance_dense_lps(const StepArgs& a, hipStream_t s) {
   }
 }
 // init == nullptr: the driver initialises the state with the generic pieces (copies + the RHS batch kernel)
+#ifndef NNHIP_ADV_DENSE_CPL_MAX  // components per lane of the lanes-per-system DENSE advance kernel (its emission operands come on top of the step's registers)
+#define NNHIP_ADV_DENSE_CPL_MAX 2
+#endif
 template <int METHOD>
 DenseAdvLaunch find_advance_dense_tpi(int rhs_kind, int dim) {
 #define X(kind, d, T) \
@@ -1699,7 +1702,7 @@ DenseAdvLaunch find_advance_dense_tpi(int rhs_kind, int dim) {
   NNHIP_FOR_EACH_TPI_RHS(X)
 #undef X
 #define X(kind, d, T, CA, CF) \
-  if (rhs_kind == kind && dim == d) return DenseAdvLaunch{nullptr, &launch_advance_dense_lps<METHOD, T, NNHIP_ADV_CPL(CA)>};
+  if (rhs_kind == kind && dim == d) return DenseAdvLaunch{nullptr, &launch_advance_dense_lps<METHOD, T, ((CA) < NNHIP_ADV_DENSE_CPL_MAX ? (CA) : NNHIP_ADV_DENSE_CPL_MAX)>};
   NNHIP_FOR_EACH_LPS_RHS(X)
 #undef X
   return DenseAdvLaunch{nullptr, nullptr};

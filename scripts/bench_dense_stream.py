@@ -66,4 +66,27 @@ for n in (1_000_000, 10_000_000):
                     frac_of_8TBps=nbytes / best / 8e12, bytes_model="accepted*(8(2d+4)+4) + rows*(8d+4)",
                     nondense_stream_ms=base * 1e3, ratio_to_nondense=best / base, equal_to_fused=bool(torch.equal(out[0], yf)))
             L.nnhip_tune_set(b"stream_graph", 2)
+# C4 shape through the lanes-per-system dense kernel (16-component ring, AoS, Tsit54), 11 requested times
+n, d = 1_000_000, 16
+y16 = torch.from_numpy(1.0 + np.arange(16)[None, :] / 16 + ((np.arange(n) % 1024) * 2.0 ** -20)[:, None]).to(dev)
+for integ in ("tsit54", "dopri54"):
+    t2, y2, cnt = nn.solveODE(nn.Rhs.ring(0.1), y16, [0.0, 1.0], nn.newODEoptions(), integrator=integ, layout=1, return_counts=True)
+    iters, accepted = int(cnt["steps"].max()), int(cnt["steps"].sum())
+    ts = np.linspace(0.0, 1.0, 11)
+    tf, yf = nn.solveODE(nn.Rhs.ring(0.1), y16, ts, nn.newODEoptions(), integrator=integ, layout=1)
+    base = best = None
+    with torch.cuda.stream(side):
+        for _ in range(4):
+            y = y16.clone(); side.synchronize(); c0 = time.perf_counter()
+            nn.adaptiveStream(nn.Rhs.ring(0.1), y, 0.0, 1.0, nn.newODEoptions(), integrator=integ, layout=1)
+            side.synchronize(); dt_ = time.perf_counter() - c0
+            base = dt_ if base is None or dt_ < base else base
+            side.synchronize(); c0 = time.perf_counter()
+            t, y, ny, launches = nn.adaptiveStreamSolve(nn.Rhs.ring(0.1), y16, ts, nn.newODEoptions(), integrator=integ, layout=1)
+            side.synchronize(); dt_ = time.perf_counter() - c0
+            best = dt_ if best is None or dt_ < best else best
+    nbytes = accepted * (8 * (2 * d + 4) + 4) + 10 * n * (8 * d + 4)
+    res[f"C4_N1e+06_{integ}_nt11"] = dict(ms=best * 1e3, launches=launches, iterations=iters, us_per_iteration=best * 1e6 / iters, GBps=nbytes / best / 1e9, frac_of_8TBps=nbytes / best / 8e12,
+                                         bytes_model="accepted*(8(2d+4)+4) + rows*(8d+4)", nondense_stream_ms=base * 1e3, ratio_to_nondense=best / base,
+                                         equal_to_fused=bool(torch.equal(y, yf)))
 print(json.dumps(res, indent=1))
