@@ -328,7 +328,8 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
  * 8*(2*dim+4) without (BS32 / RK21 never read the slot; DOPRI54 / Tsit54 by default re-evaluate FSAL = f(t, y) at the start of the
  * launch — it is the previous step's last stage f(t + dt, yNew), the same bits — unless the right-hand side has mutable slots).
  * y (device, in `layout`) is
- * advanced in place from t0 to tEnd; `ws` is device scratch of nnhip_ode_adaptive_stream_workspace_bytes(N, dim).  The host
+ * advanced in place from t0 to tEnd; `ws` is device scratch of nnhip_ode_adaptive_stream_workspace_bytes(N, dim) (16-byte aligned, as
+ * every allocator's blocks are, it holds (t, dt) of an IVP side by side — one 16-byte access each way per launch; otherwise two columns).  The host
  * learns whether anyone is still integrating every `check_every` launches (<= 0: 8) and always has the next group enqueued
  * before it waits (groups can be replayed from a hipGraph on a non-default stream: knob "stream_graph" = 1), so up to 2*check_every trailing launches
  * find nothing to do (they read t only).  Results are bitwise those of the fused solve.  Thread-per-IVP kernels for small
