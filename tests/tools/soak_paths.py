@@ -23,6 +23,10 @@ dev = torch.device("cuda:0")
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "r03_paths_soak.json")
 KEYS = T.KEYS
+# optional: the streaming loops with FSAL carried through HBM (knob adv_recompute_fsal = 0) / polling groups replayed from hipGraphs (stream_graph = 1)
+for _knob, _env in ((b"adv_recompute_fsal", "NNHIP_SOAK_RECOMPUTE_FSAL"), (b"stream_graph", "NNHIP_SOAK_STREAM_GRAPH")):
+    if os.environ.get(_env, "") != "":
+        assert nn._lib.lib().nnhip_tune_set(_knob, int(os.environ[_env])) == 0
 
 
 def same(a, b):
