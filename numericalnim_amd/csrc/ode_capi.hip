@@ -297,6 +297,9 @@ hipError_t gather_f64(const double* src, double* dst, const uint32_t* perm, int6
 hipError_t scatter_f64(const double* src, double* dst, const uint32_t* perm, int64_t N, int R, int W, hipStream_t s);
 hipError_t scatter_i32(const int32_t* src, int32_t* dst, const uint32_t* perm, int64_t N, hipStream_t s);
 hipError_t scatter_i64(const int64_t* src, int64_t* dst, const uint32_t* perm, int64_t N, hipStream_t s);
+hipError_t gather_i32(const int32_t* src, int32_t* dst, const uint32_t* perm, int64_t N, hipStream_t s);
+hipError_t gather_i64(const int64_t* src, int64_t* dst, const uint32_t* perm, int64_t N, hipStream_t s);
+hipError_t invert_perm(const uint32_t* perm, uint32_t* inv, int64_t N, hipStream_t s);
 hipError_t prepare_tspans(const double* tspans, int n_t, int64_t N, const double* tStart, double t0, double* grid, int32_t* counts, double* t_out,
                           hipStream_t s);
 void multigpu_release();  // ode_multigpu.hip
@@ -845,7 +848,7 @@ int nnhip_ode_solve_batch_sorted_f64_dev(const nnhip_ode_options* opt, int integ
     const size_t nState = (size_t)N * (size_t)dim, nOut = nState * (size_t)(n_t > 0 ? n_t : 0);
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t oY0 = 0, oOut = oY0 + up(nState * 8), oPer = oOut + up(nOut * 8), oNy = oPer + up((size_t)(n_per_ivp > 0 ? n_per_ivp : 0) * (size_t)N * 8),
-                 oSt = oNy + up((size_t)N * 4), oRj = oSt + up((size_t)N * 8), total = oRj + up((size_t)N * 8);
+                 oSt = oNy + up((size_t)N * 4), oRj = oSt + up((size_t)N * 8), oInv = oRj + up((size_t)N * 8), total = oInv + up((size_t)N * 4);
     char* d = nullptr;
     if (hipMallocAsync((void**)&d, total, s) == hipSuccess && d) {
       const int R0 = layout == NNHIP_LAYOUT_SOA ? dim : 1, W0 = layout == NNHIP_LAYOUT_SOA ? 1 : dim;
@@ -860,10 +863,13 @@ int nnhip_ode_solve_batch_sorted_f64_dev(const nnhip_ode_options* opt, int integ
       if (ps.a.P.ivp || ps.a.P.aux) return bail(fail(NNHIP_EUNSUPPORTED, "a right-hand side with a per-IVP context block is not available in the binned solve"));
       rc = launch_solve_range(ps, 0, N, s);
       if (rc) return bail(rc);
-      bool ok = nnhip::scatter_f64((const double*)(d + oOut), y_out, perm, N, (layout == NNHIP_LAYOUT_SOA ? dim : 1) * n_t, W0, s) == hipSuccess;
-      if (ny_out) ok = ok && nnhip::scatter_i32((const int32_t*)(d + oNy), ny_out, perm, N, s) == hipSuccess;
-      if (steps_out) ok = ok && nnhip::scatter_i64((const int64_t*)(d + oSt), steps_out, perm, N, s) == hipSuccess;
-      if (rejected_out) ok = ok && nnhip::scatter_i64((const int64_t*)(d + oRj), rejected_out, perm, N, s) == hipSuccess;
+      // back to the caller's order through the inverse order, as gathers (full-line writes; see invert_perm)
+      const uint32_t* inv = (const uint32_t*)(d + oInv);
+      bool ok = nnhip::invert_perm(perm, (uint32_t*)(d + oInv), N, s) == hipSuccess;
+      ok = ok && nnhip::gather_f64((const double*)(d + oOut), y_out, inv, N, (layout == NNHIP_LAYOUT_SOA ? dim : 1) * n_t, W0, s) == hipSuccess;
+      if (ny_out) ok = ok && nnhip::gather_i32((const int32_t*)(d + oNy), ny_out, inv, N, s) == hipSuccess;
+      if (steps_out) ok = ok && nnhip::gather_i64((const int64_t*)(d + oSt), steps_out, inv, N, s) == hipSuccess;
+      if (rejected_out) ok = ok && nnhip::gather_i64((const int64_t*)(d + oRj), rejected_out, inv, N, s) == hipSuccess;
       (void)hipFreeAsync(d, s);
       return ok ? NNHIP_OK : fail(NNHIP_EHIP, "scattering the results back to the caller's order failed");
     }

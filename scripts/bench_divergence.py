@@ -2,60 +2,68 @@
 """Wavefront divergence in the fused adaptive kernels: a Van der Pol sweep over mu (step counts differ ~2x across IVPs, and lanes
 disagree on accept / reject).  The batch in random order — as a caller would hand it over — integrated (a) as is, (b) through the
 C ABI's divergence binning with the caller's key (nnhip_ode_solve_batch_sorted_f64_dev, sort_key = mu), (c) in its automatic
-two-pass mode (probe solve + device argsort), and (d) pre-sorted by the caller (the bound: no indirection, no sort)."""
+two-pass mode (probe solve + device argsort), and (d) pre-sorted by the caller (the bound: no indirection, no sort); (b) and (c) with the
+order array followed inside the solve kernel (default) and with the batch physically reordered around the solve (knob sort_copy), each
+with and without the per-IVP counters (rows, steps, rejected) written.
+All cases are timed INTERLEAVED (one call of each per round, 11 rounds after a warm-up, median of the last 9): timed one case after the
+other, the cases were ranked by their position in the file as much as by what they do (clock and power state drift by several percent)."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import numericalnim_amd as nn
 dev = torch.device("cuda:0"); n = 1_000_000
+L = nn._lib.lib()
 rng = np.random.default_rng(0)
 mu = rng.uniform(0.1, 20.0, n)
 y0 = torch.from_numpy(np.stack([np.full(n, 2.0), np.zeros(n)])).to(dev)
 opt = nn.newODEoptions(absTol=1e-6, relTol=1e-6, dtMin=1e-9, dtMax=1.0)
-res = {}
-ref = None
-mu_d = torch.from_numpy(mu).to(dev)
-cases = (("random_order", np.arange(n), None), ("random_order_sort_key_mu", np.arange(n), "key"), ("random_order_auto_probe", np.arange(n), "auto"),
-         ("presorted_by_caller", np.argsort(mu), None))
-for name, order, mode in cases:
-    sw = torch.from_numpy(mu[order][None, :].copy()).to(dev)
-    sort_by = None if mode is None else (sw[0] if mode == "key" else "auto")
-    tt = []
-    for r in range(9):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); e0.record()
-        t, y, cnt = nn.solveODE(nn.Rhs.vanderpol(), y0, [0.0, 10.0], opt, integrator="dopri54", sweep=sw, return_counts=True, sort_by=sort_by); e1.record()
-        torch.cuda.synchronize(); tt.append(e0.elapsed_time(e1))
-    st = (cnt["steps"] + cnt["rejected"]).double()
-    res[name] = dict(ms=sorted(tt[4:])[2],  # median of the last five of nine (the first calls of a process run at ramping clocks)
-                      attempted_steps_mean=float(st.mean()), attempted_steps_max=float(st.max()))
-    if mode is None:  # lane utilisation of the order the kernel saw
-        w = st[: n // 64 * 64].reshape(-1, 64)
-        res[name]["lane_utilisation"] = float(w.mean() / w.max(dim=1).values.mean())
-    if name == "random_order":
-        ref = y
-    elif mode is not None:
-        res[name]["bit_identical_to_unsorted"] = bool(torch.equal(torch.nan_to_num(y, nan=-1.0), torch.nan_to_num(ref, nan=-1.0)))
-# the order array followed inside the solve kernel (round 2's form) instead of the physical reorder, and a narrow-range key
-# (mu in [100, 101]: float32 image resolves it; round 2's 16-bit keys put the whole batch into two bins)
-L = nn._lib.lib()
 sw = torch.from_numpy(mu[None, :].copy()).to(dev)
-for knob, tag in ((0, "perm_in_kernel"), (1, "physical_reorder")):
-    L.nnhip_tune_set(b"sort_copy", knob)
-    tt = []
-    for r in range(4):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); e0.record()
-        t, y = nn.solveODE(nn.Rhs.vanderpol(), y0, [0.0, 10.0], opt, integrator="dopri54", sweep=sw, sort_by=sw[0]); e1.record()
-        torch.cuda.synchronize(); tt.append(e0.elapsed_time(e1))
-    res["sort_key_mu_" + tag] = dict(ms=sorted(tt[1:])[1], bit_identical_to_unsorted=bool(torch.equal(torch.nan_to_num(y, nan=-1.0), torch.nan_to_num(ref, nan=-1.0))))
-L.nnhip_tune_set(b"sort_copy", 0)
-mu2 = 100.0 + rng.random(n)
+sw_sorted = torch.from_numpy(np.sort(mu)[None, :].copy()).to(dev)
+mu2 = 100.0 + rng.random(n)   # a narrow-range key (float32 image resolves it; round 2's 16-bit keys put the whole batch into two bins)
 sw2 = torch.from_numpy(mu2[None, :].copy()).to(dev)
-for name2, sort_by in (("narrow_key_random_order", None), ("narrow_key_sort_key_mu", sw2[0])):
-    tt = []
-    for r in range(4):
+
+
+def solve(sweep, sort_by=None, counts=False, copy=0, tend=10.0):
+    L.nnhip_tune_set(b"sort_copy", copy)
+    return nn.solveODE(nn.Rhs.vanderpol(), y0, [0.0, tend], opt, integrator="dopri54", sweep=sweep, sort_by=sort_by, return_counts=counts)
+
+
+cases = {
+    "random_order": lambda: solve(sw, None, True),
+    "random_order_sort_key_mu": lambda: solve(sw, sw[0], True),
+    "random_order_auto_probe": lambda: solve(sw, "auto", True),
+    "presorted_by_caller": lambda: solve(sw_sorted, None, True),
+    "sort_key_mu_perm_in_kernel": lambda: solve(sw, sw[0], False),
+    "auto_probe_perm_in_kernel": lambda: solve(sw, "auto", False),
+    "sort_key_mu_physical_reorder": lambda: solve(sw, sw[0], False, 1),
+    "sort_key_mu_physical_reorder_with_counters": lambda: solve(sw, sw[0], True, 1),
+    "auto_probe_physical_reorder_with_counters": lambda: solve(sw, "auto", True, 1),
+    "narrow_key_random_order": lambda: solve(sw2, None, False, 0, 0.5),
+    "narrow_key_sort_key_mu": lambda: solve(sw2, sw2[0], False, 0, 0.5),
+}
+for _ in range(150):   # sustained clocks before anything is timed
+    cases["random_order"]()
+torch.cuda.synchronize()
+times = {k: [] for k in cases}
+outs = {}
+for r in range(11):
+    for k, fn in cases.items():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); e0.record()
-        t, y = nn.solveODE(nn.Rhs.vanderpol(), y0, [0.0, 0.5], opt, integrator="dopri54", sweep=sw2, sort_by=sort_by); e1.record()
-        torch.cuda.synchronize(); tt.append(e0.elapsed_time(e1))
-    res[name2] = dict(ms=sorted(tt[1:])[1])
+        out = fn(); e1.record()
+        torch.cuda.synchronize(); times[k].append(e0.elapsed_time(e1))
+        if r == 0:
+            outs[k] = out
+L.nnhip_tune_set(b"sort_copy", 0)
+res = {}
+ref = outs["random_order"][1]
+for k, tt in times.items():
+    res[k] = dict(ms=sorted(tt[2:])[len(tt[2:]) // 2])
+    if ("sort_key_mu" in k or "auto_probe" in k) and "narrow" not in k:
+        res[k]["bit_identical_to_unsorted"] = bool(torch.equal(torch.nan_to_num(outs[k][1], nan=-1.0), torch.nan_to_num(ref, nan=-1.0)))
+for k in ("random_order", "presorted_by_caller"):
+    cnt = outs[k][2]
+    st = (cnt["steps"] + cnt["rejected"]).double()
+    w = st[: n // 64 * 64].reshape(-1, 64)
+    res[k].update(attempted_steps_mean=float(st.mean()), attempted_steps_max=float(st.max()), lane_utilisation=float(w.mean() / w.max(dim=1).values.mean()))
 print(json.dumps(res, indent=1))
