@@ -704,7 +704,17 @@ def test_parameter_sweep_per_ivp_params(nn, oracle, dev, integrator):
         assert _same_bits(got[:, i, :], ry)
 
 
-def test_sort_by_returns_identical_results_in_caller_order(nn, dev):
+@pytest.fixture(params=[0, 1], ids=["order_array_in_kernel", "physical_reorder"])
+def sort_copy(request, nn):
+    """Tuning knob "sort_copy": the binned solve follows the order array inside the kernel (0, default) or gathers the batch into integration
+    order, solves it with coalesced accesses and brings the results back through the inverse order (1)."""
+    L = nn._lib.lib()
+    assert L.nnhip_tune_set(b"sort_copy", request.param) == 0
+    yield request.param
+    assert L.nnhip_tune_set(b"sort_copy", 0) == 0
+
+
+def test_sort_by_returns_identical_results_in_caller_order(nn, dev, sort_copy):
     """solveODE(sort_by=...) integrates in sorted order (less wavefront divergence) and un-permutes: bit-identical output."""
     import torch
     n = 5000
