@@ -1785,7 +1785,7 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
   hipGraphExec_t execs[2] = {nullptr, nullptr};
   // Replayed only when asked for (knob 1) since round 3: with (t, dt) interleaved and FSAL re-evaluated a launch takes 5-300 us, the command
   // processor pipelines eager launches behind each other, and a graph's node-to-node hand-over costs 1-2 us more than that (Lorenz 1e4 ... 3e6
-  // IVPs and 16-component rings: eager 0-8 % faster at every size, scripts/ab_stream_graph_vs_eager.py)
+  // IVPs and 16-component rings: eager 1-5 % faster at every size, scripts/ab_stream_graph_vs_eager.py)
   if (g_stream_graph == 1 && s != nullptr) {
     int device = 0;
     HIP_TRY(hipGetDevice(&device));
