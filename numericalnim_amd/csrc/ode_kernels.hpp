@@ -606,6 +606,10 @@ template <class Ops>
 struct OpsAllOwned { static constexpr bool value = true; };
 template <class RHS, bool NEG, int CPL, bool SH>
 struct OpsAllOwned<LpsOps<RHS, NEG, CPL, SH>> { static constexpr bool value = RhsSize<RHS>::value == RHS::dim; };
+template <class RHS, int CPL>
+struct LpsOpsRt;  // the lanes-per-system ops of the dense streaming kernel (direction chosen at run time), defined with it
+template <class RHS, int CPL>
+struct OpsAllOwned<LpsOpsRt<RHS, CPL>> { static constexpr bool value = RhsSize<RHS>::value == RHS::dim; };
 NNHIP_DEV bool adv_vec2(const StepArgs& a) {
 #ifdef NNHIP_ADV_NO_VEC2
   return false;
@@ -1060,7 +1064,7 @@ NNHIP_DEV int dense_emit(const StepArgs& a, const OPS& ops, const DenseEmitIn<OP
 // fused solve does when max_steps ends its loop.
 // NT: non-temporal hint on the streamed state arrays, chosen by the host from the working-set size like the loop without dense
 // output (a template parameter: see StepArgs::nontemporal)
-template <int METHOD, bool NT = false, class OPS>
+template <int METHOD, bool NT = false, bool SPEC = false, class OPS>
 NNHIP_DEV unsigned int advance_dense_body(const StepArgs& a, const OPS& ops, int64_t i, int64_t base, bool lead, bool neg) {
   constexpr int D = OPS::D;
   using MT = MethodTraits<METHOD>;
@@ -1071,17 +1075,16 @@ NNHIP_DEV unsigned int advance_dense_body(const StepArgs& a, const OPS& ops, int
   int denseIndex = a.useDense ? a.denseIdx_io[i] : 0;  // <= nReq - 1: an IVP whose last requested time has been emitted is retired below
   const double2 td = *td_io;
   double t = td.x;
-  if (!(t < a.tEnd)) return 0u;  // :511
   const int64_t cs = a.compStride;
   // DOPRI54 / Tsit54 re-evaluate FSAL instead (StepArgs::recomputeFsal); RK21 never reads the slot; BS32's stepper does not either, but the
   // slot it returns (k4 = f(t + dt, yNew)) is lastIter.dy of the dense output (MethodTraits::fsal), so here it travels
   const bool withFsal = METHOD == NNHIP_BS32 ? true : adv_fsal_in_hbm<METHOD>(a);
   double y[D], yNew[D], fsal[D];
-#pragma unroll
-  for (int c = 0; c < D; ++c) {
-    y[c] = ops.owns(c) ? ld_state<NT>(&a.y_in[base + c * cs]) : 0.0;
-    fsal[c] = (withFsal && ops.owns(c)) ? ld_state<NT>(&a.fsal_in[base + c * cs]) : 0.0;
-  }
+  // the state through the loop's own accessors (16-byte accesses where a lane's components are contiguous).  SPEC (lanes-per-system kernel): issued
+  // with t, in one round trip, as advance_lps_kernel's tile fetch does — a finished system then reads its state for nothing
+  if constexpr (SPEC) adv_load_state<NT>(a, ops, base, y, fsal, withFsal);
+  if (!(t < a.tEnd)) return 0u;  // :511
+  if constexpr (!SPEC) adv_load_state<NT>(a, ops, base, y, fsal, withFsal);
   if constexpr (METHOD == NNHIP_DOPRI54 || METHOD == NNHIP_TSIT54) {
     if (a.recomputeFsal) ops.rhs(t, y, fsal);
   }
@@ -1146,12 +1149,7 @@ NNHIP_DEV unsigned int advance_dense_body(const StepArgs& a, const OPS& ops, int
       denseIndex = dense_emit(a, ops, e, done);
     }
   }
-#pragma unroll
-  for (int c = 0; c < D; ++c)
-    if (ops.owns(c)) {
-      st_state<NT>(yNew[c], &a.y_out[base + c * cs]);
-      if (withFsal) st_state<NT>(fsal[c], &a.fsal_out[base + c * cs]);
-    }
+  adv_store_state<NT>(a, ops, base, yNew, fsal, withFsal);
   // every requested time has been emitted: the reference leaves the loop here and its final yPositive.add(y) falls outside the
   // requested rows.  Retire the IVP (denseIndex == nReq tells the finalize kernel that nothing is left to add).
   if (done) t = a.tEnd;
@@ -1206,6 +1204,9 @@ struct LpsOpsRt {
   NNHIP_DEV double norm(const double (&yNew)[CPL], const double (&err_y)[CPL], const StepCtl& o) const { return f.norm(yNew, err_y, o); }
 };
 
+#ifndef NNHIP_ADV_DENSE_LPS_SPECULATE
+#define NNHIP_ADV_DENSE_LPS_SPECULATE 1
+#endif
 template <int METHOD, class RHS, int CPL = 1>
 __global__ __launch_bounds__(kBlock) void advance_dense_lps_kernel(const StepArgs a) {
   static_assert(MethodTraits<METHOD>::adaptive, "adaptive methods only");
@@ -1224,7 +1225,7 @@ __global__ __launch_bounds__(kBlock) void advance_dense_lps_kernel(const StepArg
     double* ys = lds + sysInBlock * lps_stride<DIM>();
     double* es = lds + lps_lds_doubles<DIM, CPL>() / 2 + sysInBlock * lps_stride<DIM>();
     const LpsOpsRt<RHS, CPL> ops{{P, ys, es, c}, {P, ys, es, c}, neg};
-    stillActive = advance_dense_body<METHOD>(a, ops, i, i * a.ivpStride + c * a.compStride, c == 0, neg);
+    stillActive = advance_dense_body<METHOD, false, NNHIP_ADV_DENSE_LPS_SPECULATE != 0>(a, ops, i, i * a.ivpStride + c * a.compStride, c == 0, neg);
   }
   if (a.active) {
     if (__syncthreads_or((int)stillActive) && threadIdx.x == 0) a.active[blockIdx.x % kAggSlots] = 1u;
