@@ -1693,8 +1693,8 @@ hipError_t launch_advance_dense_lps(const StepArgs& a, hipStream_t s) {
   }
 }
 // init == nullptr: the driver initialises the state with the generic pieces (copies + the RHS batch kernel)
-#ifndef NNHIP_ADV_DENSE_CPL_MAX  // components per lane of the lanes-per-system DENSE advance kernel (its emission operands come on top of the step's registers)
-#define NNHIP_ADV_DENSE_CPL_MAX 2
+#ifndef NNHIP_ADV_DENSE_CPL_MAX  // components per lane of the lanes-per-system DENSE advance kernel: 1e6 x 16 Tsit54, 11 requested times: 2 per lane 121 us, 4 per lane 117 us per iteration
+#define NNHIP_ADV_DENSE_CPL_MAX 4
 #endif
 template <int METHOD>
 DenseAdvLaunch find_advance_dense_tpi(int rhs_kind, int dim) {
