@@ -278,6 +278,41 @@ def main():
                                         "note": "same kernel family, 1 GB working set: the unambiguous HBM figure (the headline batch's 160 MB fit the Infinity Cache)"}
         del yb, sb
 
+    # ---- informational: BASELINE.json's adaptive configs C3 / C4 (1e6 IVPs / systems), fused and through the HBM-resident loop ----
+    if not args.no_fused and world == 1:
+        cfg = {}
+        n6 = 1_000_000
+        y3 = torch.from_numpy(np.stack([1.0 + (np.arange(n6) % 1024) * 2.0 ** -20, np.ones(n6), np.ones(n6)])).to(dev)
+        y16 = torch.from_numpy(1.0 + np.arange(16)[None, :] / 16 + ((np.arange(n6) % 1024) * 2.0 ** -20)[:, None]).to(dev)
+        side = torch.cuda.Stream()
+        for name, fr, yy, layout, integ, d in (("C3_dopri54_lorenz_1e6", nn.Rhs.lorenz(), y3, 0, "dopri54", 3), ("C4_tsit54_ring16_1e6", nn.Rhs.ring(0.1), y16, 1, "tsit54", 16)):
+            _, yfu, cnt = nn.solveODE(fr, yy, [0.0, 1.0], nn.newODEoptions(), integrator=integ, layout=layout, return_counts=True)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                nn.solveODE(fr, yy, [0.0, 1.0], nn.newODEoptions(), integrator=integ, layout=layout)
+            e1.record()
+            torch.cuda.synchronize()
+            iters = int(cnt["steps"].max())
+            best, ys = None, None
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    yw = yy.clone()
+                    side.synchronize()
+                    c0 = time.perf_counter()
+                    ys, _l = nn.adaptiveStream(fr, yw, 0.0, 1.0, nn.newODEoptions(), integrator=integ, layout=layout)
+                    side.synchronize()
+                    dtw = time.perf_counter() - c0
+                    best = dtw if best is None or dtw < best else best
+            per_step = 8 * (2 * d + 4)  # y in / out and (t, dt) in / out; FSAL is re-evaluated per launch
+            cfg[name] = {"fused_ms": e0.elapsed_time(e1) / 3, "streamed_ms": best * 1e3, "loop_iterations": iters, "streamed_us_per_iteration": best * 1e6 / iters,
+                         "streamed_bytes_per_step": per_step, "streamed_GBps": per_step * float(cnt["steps"].sum()) / best / 1e9,
+                         "streamed_bitwise_equal_to_fused": bool(torch.equal(ys, yfu[-1]))}
+        out["adaptive_configs"] = cfg
+        del y3, y16
+
     # ---- CPU baseline: the oracle (C++ restatement of the reference) on this box's host cores -------------
     if not args.no_cpu_baseline and world == 1:
         from oracle import oracle as O
