@@ -1843,8 +1843,9 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
 int64_t nnhip_ode_adaptive_stream_dense_workspace_bytes(int64_t N, int dim, int n_t) {
   if (N < 0 || dim < 1) return 0;
   const int64_t nt = n_t < 0 ? 0 : n_t;
-  // y, FSAL [dim*N]; (t, dt) [N][2]; denseIndex [N] (int32); requested times (lastIter = (t, y, dy) lives in the kernel's registers)
-  return (int64_t)sizeof(double) * (2 * N * dim + 2 * N + nt + 8) + (int64_t)sizeof(int32_t) * (N + 2) + 64;
+  // y, FSAL [dim*N]; (t, dt) [N][2]; denseIndex [N] and the forward direction's row count [N] (int32); requested times (lastIter = (t, y, dy)
+  // lives in the kernel's registers)
+  return (int64_t)sizeof(double) * (2 * N * dim + 2 * N + nt + 8) + (int64_t)sizeof(int32_t) * (2 * N + 4) + 64;
 }
 
 // The whole ODESolver driver (ode.nim:471-586) for adaptive integrators over the HBM-resident `advance` kernel: both directions,
@@ -1883,6 +1884,7 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
   double* tdArr = fsal + nState;                     // (t, dt) of IVP i side by side: [N][2] (16-byte aligned: ws is, nState * 16 is)
   double* tReqDev = tdArr + 2 * N;                   // n_t doubles (+ padding)
   int32_t* denseIdx = (int32_t*)(tReqDev + n_t + 8);
+  int32_t* fwdRows = denseIdx + N + 2;  // rows the forward direction produced (both directions asked for: it runs first)
   // requested times of both directions, as the reference holds them
   const int nPos = (int)g.tPos.size(), nNeg = (int)g.tNeg.size();
   if (nPos + nNeg > 0) {
@@ -1918,7 +1920,7 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
   int64_t launches = 0;
   bool truncated = false;
   auto finalize = [&](int mode) -> int {
-    HIP_TRY(nnhip::launch_kernel(nnhip::advance_dense_finalize_kernel<0>, grid, block, s, a, mode, dim, y0, ny_out, n_t));
+    HIP_TRY(nnhip::launch_kernel(nnhip::advance_dense_finalize_kernel<0>, grid, block, s, a, mode, dim, y0, ny_out, n_t, fwdRows));
     return NNHIP_OK;
   };
   auto advance = [&](const nnhip::StepArgs& run) -> int {
@@ -1931,6 +1933,10 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
     if (fn.init) { HIP_TRY(fn.init(run, y0, tStartEff, dtInit, s)); return NNHIP_OK; }
     const size_t bytes = (size_t)nState * sizeof(double);
     HIP_TRY(hipMemcpyAsync(yW, y0, bytes, hipMemcpyDeviceToDevice, s));
+    if (!neg && nnhip::rtc_has_aux(rhs_kind)) {  // lastIter.dy = f(t0, y, ctx) (:498): the first of the reference's two evaluations at t0, observable through aux
+      const int r0 = nnhip_ode_rhs_batch_f64_dev(rhs_kind, rhs_params, n_params, N, dim, layout, tStartEff, y0, fsal, stream);
+      if (r0) return r0;
+    }
     const int r = nnhip_ode_rhs_batch_f64_dev(rhs_kind, rhs_params, n_params, N, dim, layout, neg ? -tStartEff : tStartEff, y0, fsal, stream);
     if (r) return r;
     if (neg) HIP_TRY(nnhip::negate_f64(fsal, fsal, nState, s));
@@ -2017,6 +2023,14 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
     return NNHIP_OK;
   };
   HIP_TRY(hipMemsetAsync(ny_out, 0, (size_t)N * sizeof(int32_t), s));
+  const bool bothDirections = nNeg > 0 && nPos > 0;
+  const int fwdBase = nNeg + (g.nZero ? 1 : 0);
+  if (bothDirections) {  // forward branch FIRST, as the reference runs them (:508-542): its rows go where they belong if the backward branch returns all of its rows
+    rc = run_dir(false, opt->tStart, g.tEndPos, tReqDev, nPos, nullptr, fwdBase);
+    if (rc) return rc;
+    rc = finalize(5);
+    if (rc) return rc;
+  }
   if (nNeg > 0) {  // backward branch (:544-584)
     rc = run_dir(true, -opt->tStart, g.tEndNeg, tReqDev + nPos, nNeg, nullptr, 0);
     if (rc) return rc;
@@ -2027,10 +2041,12 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
     rc = finalize(1);
     if (rc) return rc;
   }
-  if (nPos > 0) {
-    // the forward rows follow whatever the backward branch and `t0 in tspan` produced: per IVP (ny_out) after a backward branch (it may
-    // return fewer rows than asked), the same row for every IVP otherwise
-    rc = nNeg > 0 ? run_dir(false, opt->tStart, g.tEndPos, tReqDev, nPos, ny_out, 0) : run_dir(false, opt->tStart, g.tEndPos, tReqDev, nPos, nullptr, g.nZero ? 1 : 0);
+  if (bothDirections) {  // the forward rows follow whatever the backward branch and `t0 in tspan` produced (it may return fewer rows than asked: close up)
+    a.rowBase0 = fwdBase;
+    rc = finalize(4);
+    if (rc) return rc;
+  } else if (nPos > 0) {
+    rc = run_dir(false, opt->tStart, g.tEndPos, tReqDev, nPos, nullptr, g.nZero ? 1 : 0);
     if (rc) return rc;
     rc = finalize(2);
     if (rc) return rc;

@@ -1238,12 +1238,31 @@ __global__ __launch_bounds__(kBlock) void advance_dense_lps_kernel(const StepArg
 //   mode 1: `t0 in tspan` row             (rows[ny[i]] = y0; ny[i] += 1)
 //   mode 2: forward direction finished    (ny[i] += rows produced)
 //   mode 3: NaN fill of rows ny[i] .. n_t-1
+// When both directions are asked for, the forward one runs FIRST (as in the reference, ode.nim:508-542 then :544-584 — observable only through
+// a mutable ctx), its rows placed where they belong if the backward branch returns all of its rows:
+//   mode 5: forward direction finished first (rows at rowBase0 + k; fwd[i] = rows produced)
+//   mode 4: after the backward rows and the t0 row: move the forward rows up if the backward branch returned fewer rows; ny[i] += fwd[i]
 template <int DIM_UNUSED = 0>
 __global__ __launch_bounds__(kBlock) void advance_dense_finalize_kernel(const StepArgs a, int mode, int dim, const double* __restrict__ y0, int32_t* __restrict__ ny,
-                                                                        int n_t) {
+                                                                        int n_t, int32_t* __restrict__ fwd = nullptr) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= a.N) return;
   const int64_t base = i * a.ivpStride, cs = a.compStride, rs = a.rowStride;
+  if (mode == 5) {
+    const int k = a.denseIdx_io[i];
+    if (k < a.nReq)
+      for (int c = 0; c < dim; ++c) a.rows[(int64_t)(a.rowBase0 + k) * rs + base + c * cs] = a.y_in[base + c * cs];
+    fwd[i] = k + 1 < a.nReq ? k + 1 : a.nReq;
+    return;
+  }
+  if (mode == 4) {
+    const int rb = ny[i], m = fwd[i];
+    if (rb != a.rowBase0)
+      for (int j = 0; j < m; ++j)
+        for (int c = 0; c < dim; ++c) a.rows[(int64_t)(rb + j) * rs + base + c * cs] = a.rows[(int64_t)(a.rowBase0 + j) * rs + base + c * cs];
+    ny[i] = rb + m;
+    return;
+  }
   if (mode == 0 || mode == 2) {
     const int k = a.denseIdx_io[i];
     const int produced = k + 1 < a.nReq ? k + 1 : a.nReq;

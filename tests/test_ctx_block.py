@@ -143,8 +143,8 @@ def test_mutable_ctx_counts_z_crossings(nn, oracle, dev, integrator):
 @pytest.mark.parametrize("integrator", ["dopri54", "tsit54", "vern65"])
 def test_mutable_ctx_sees_the_reference_order_of_both_directions(nn, oracle, dev, integrator):
     """tspan straddling tStart: the reference integrates the forward branch, THEN the backward one (ode.nim:508-542, 544-584), on the same
-    mutable ctx.  The fused kernel runs them in that order too (round 3), so a ctx-mutating closure ends with the oracle's slots — here with
-    requested rows on both sides (the FSAL methods' dense output evaluates f nowhere else)."""
+    mutable ctx.  The fused kernel and the dense streaming driver run them in that order too (round 3), so a ctx-mutating closure ends with
+    the oracle's slots — here with requested rows on both sides (the FSAL methods' dense output evaluates f nowhere else)."""
     import torch
     O = oracle
     n = 1500
@@ -157,3 +157,8 @@ def test_mutable_ctx_sees_the_reference_order_of_both_directions(nn, oracle, dev
     ref = O.solve_ode_batch_ctx(O.RHS_LORENZ_ZCROSS, [10.0, 28.0, 8.0 / 3.0], None, np.zeros((3, n)), y0, n, 3, ts, O.new_options(**kw), integrator, n_threads=8)
     assert np.array_equal(t, ref["t"]) and np.array_equal(y.cpu().numpy(), ref["y"], equal_nan=True)
     assert np.array_equal(aux.cpu().numpy(), ref["aux"])
+    # the same through the IntegratorProc seam (dense streaming driver): forward direction first there too, two evaluations at t0 before it
+    aux2 = torch.zeros((3, n), dtype=torch.float64, device=dev)
+    t2, y2, ny, launches = nn.adaptiveStreamSolve(f, torch.from_numpy(y0).to(dev), ts, nn.newODEoptions(**kw), ctx=nn.newNumContext(tValues={"aux": aux2}), integrator=integrator)
+    assert np.array_equal(t2, ref["t"]) and np.array_equal(y2.cpu().numpy(), ref["y"], equal_nan=True)
+    assert np.array_equal(aux2.cpu().numpy(), ref["aux"])
