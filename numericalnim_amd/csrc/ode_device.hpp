@@ -154,9 +154,18 @@ struct RhsSize { static constexpr int value = R::dim; };
 template <class R>
 struct RhsSize<R, decltype((void)R::size)> { static constexpr int value = R::size; };
 
+// A right-hand side that writes to its context (run-time compiled ones with `aux` slots declare `mutates`): the drivers then make every
+// evaluation of f the reference makes, where it makes it — including the ones whose VALUE is only needed if a requested time falls into a
+// step (ode.nim:521, :530), which are otherwise evaluated lazily.
+template <class R, class = void>
+struct RhsMutates { static constexpr bool value = false; };
+template <class R>
+struct RhsMutates<R, decltype((void)R::mutates)> { static constexpr bool value = R::mutates; };
+
 template <class RHS, bool NEG>
 struct TpiOps {
   static constexpr int D = RHS::dim;
+  static constexpr bool mutates = RhsMutates<RHS>::value;
   const Params& P;
   NNHIP_DEV static constexpr bool owns(int) { return true; }  // every component slot of the lane is a real component
   NNHIP_DEV void rhs(double t, const double (&y)[D], double (&dy)[D]) const {
@@ -225,6 +234,7 @@ NNHIP_DEV double lane_rotate(double v) {
 
 template <class RHS, bool NEG, int CPL = 1, bool SHUFFLE_NORM = false>
 struct LpsOps {
+  static constexpr bool mutates = RhsMutates<RHS>::value;
   static constexpr int D = CPL;            // components per lane
   static constexpr int DIM = RHS::dim;     // component slots per system; DIM / CPL lanes of one wavefront share a system
   static constexpr int SIZE = RhsSize<RHS>::value;  // real components (<= DIM); slots SIZE..DIM-1 stay 0 and touch no memory
@@ -843,11 +853,12 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
     if constexpr (DENSE) if (in.useDense) {
       if (high < denseIndex) break;  // :513-514
       if (treq <= t) {
-        if constexpr (!MT::fsal) {
+        if constexpr (!MT::fsal && !Ops::mutates) {
           ops.rhs(t, y, dyNow);  // f(t, y, ctx) per emitted point (:521); same value each time
           if (!lastDyValid) { ops.rhs(lastT, lastY, lastDy); lastDyValid = true; }  // deferred lastIter.dy (see below)
         }
         while (treq <= t) {  // :515
+          if constexpr (!MT::fsal && Ops::mutates) ops.rhs(t, y, dyNow);  // a mutating f: once per emitted point, as the reference calls it (:521)
           const HermiteW w = hermite_weights(treq, lastT, t);
           double yv[D];
 #pragma unroll
@@ -869,8 +880,10 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
         for (int c = 0; c < D; ++c) lastDy[c] = fsal[c];
       } else {
         // lastIter.dy = f(t, y, ctx) (:530) is only ever read when a requested time falls into the coming step, so it is
-        // evaluated lazily at emission time from (lastT, lastY) — the same call, hence the same bits — instead of once per step.
-        lastDyValid = false;
+        // evaluated lazily at emission time from (lastT, lastY) — the same call, hence the same bits — instead of once per step
+        // (a mutating f: once per step, here, as the reference calls it).
+        if constexpr (Ops::mutates) ops.rhs(t, y, lastDy);
+        else lastDyValid = false;
       }
     }
     if constexpr (METHOD == NNHIP_RK4) {

@@ -984,6 +984,7 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_LPS_ATTR void advance_lps_kernel(
 template <class RHS>
 struct TpiOpsRt {
   static constexpr int D = RHS::dim;
+  static constexpr bool mutates = RhsMutates<RHS>::value;
   const Params& P;
   bool neg;
   NNHIP_DEV static constexpr bool owns(int) { return true; }
@@ -1111,6 +1112,8 @@ NNHIP_DEV unsigned int advance_dense_body(const StepArgs& a, const OPS& ops, int
   if constexpr (MT::fsal) {
 #pragma unroll
     for (int c = 0; c < D; ++c) e.lastDy[c] = fsal[c];
+  } else if constexpr (OPS::mutates) {
+    if (a.useDense) ops.rhs(t, y, e.lastDy);  // a mutating f: lastIter.dy = f(t, y, ctx) once per step, as the reference calls it (:530)
   }
   double error = 0.0, factor;
   int64_t rej = 0;
@@ -1136,8 +1139,8 @@ NNHIP_DEV unsigned int advance_dense_body(const StepArgs& a, const OPS& ops, int
     if (neg) { treq = -treq; treqNext = -treqNext; }
     if (treq <= t) {
       if constexpr (!MT::fsal) {
-        ops.rhs(t, yNew, e.dyNow);    // f(t, y, ctx) (:521)
-        ops.rhs(lastT, y, e.lastDy);  // lastIter.dy (:530)
+        ops.rhs(t, yNew, e.dyNow);                                // f(t, y, ctx) (:521)
+        if constexpr (!OPS::mutates) ops.rhs(lastT, y, e.lastDy);  // lastIter.dy (:530), lazily
       } else {
 #pragma unroll
         for (int c = 0; c < D; ++c) e.dyNow[c] = fsal[c];
@@ -1146,7 +1149,11 @@ NNHIP_DEV unsigned int advance_dense_body(const StepArgs& a, const OPS& ops, int
       for (int c = 0; c < D; ++c) { e.yOld[c] = y[c]; e.yNew[c] = yNew[c]; }
       e.t = t; e.lastT = lastT; e.treq = treq; e.treqNext = treqNext;
       e.denseIndex = denseIndex; e.rowBase = rowBase; e.i = i; e.base = base; e.neg = neg; e.lead = lead;
+      [[maybe_unused]] const int firstEmitted = denseIndex;
       denseIndex = dense_emit(a, ops, e, done);
+      if constexpr (!MT::fsal && OPS::mutates) {  // a mutating f: f(t, y, ctx) once per emitted point (:521) — the first was made above
+        for (int q = firstEmitted + 1; q < denseIndex; ++q) { double again[D]; ops.rhs(t, yNew, again); }
+      }
     }
   }
   adv_store_state<NT>(a, ops, base, yNew, fsal, withFsal);
@@ -1193,6 +1200,7 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_TPI_ATTR void advance_dense_tpi_k
 template <class RHS, int CPL>
 struct LpsOpsRt {
   static constexpr int D = CPL;
+  static constexpr bool mutates = RhsMutates<RHS>::value;
   LpsOps<RHS, false, CPL> f;
   LpsOps<RHS, true, CPL> b;
   bool neg;

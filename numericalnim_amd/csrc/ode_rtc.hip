@@ -127,6 +127,7 @@ std::string make_source(const UserRhsEntry& e) {
        "                __device__ __forceinline__ double& operator[](long long j) const { return b[j * s]; } };\n}\n";
   s += "namespace nnhip {\nstruct UserRhs {\n  static constexpr int dim = " + std::to_string(padded_dim(e)) + ";\n";
   s += "  static constexpr int size = " + std::to_string(e.dim) + ";\n";
+  if (e.n_aux > 0) s += "  static constexpr bool mutates = true;\n";  // the drivers then make every evaluation the reference makes (RhsMutates)
   if (!e.perComponent) {
     s += "  NNHIP_DEV static void eval(double t, const double (&y)[dim], double (&dy)[dim], const Params& P_) {\n";
     s += ctx_preamble(e) + "    (void)t;\n";

@@ -162,3 +162,30 @@ def test_mutable_ctx_sees_the_reference_order_of_both_directions(nn, oracle, dev
     t2, y2, ny, launches = nn.adaptiveStreamSolve(f, torch.from_numpy(y0).to(dev), ts, nn.newODEoptions(**kw), ctx=nn.newNumContext(tValues={"aux": aux2}), integrator=integrator)
     assert np.array_equal(t2, ref["t"]) and np.array_equal(y2.cpu().numpy(), ref["y"], equal_nan=True)
     assert np.array_equal(aux2.cpu().numpy(), ref["aux"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("integrator", ["rk4", "heun2", "kutta3", "ralston4", "rk21"])
+def test_mutable_ctx_call_sequence_of_methods_without_fsal_with_dense_output(nn, oracle, dev, integrator):
+    """Methods that do not use FSAL for their dense output make the reference evaluate f once more per step (lastIter.dy, ode.nim:530) and
+    once per emitted point (:521).  For a pure f the device makes those evaluations lazily (same values); a right-hand side that mutates
+    its ctx gets every one of them where the reference makes it (RhsMutates): slots and rows equal to the oracle's closures, on both
+    sides of tStart, with requested times closer than the steps (several points per step) — fused solve, and for the adaptive RK21 also
+    the dense streaming driver."""
+    import torch
+    O = oracle
+    n = 700
+    y0 = np.stack([1.0 + (np.arange(n) % 256) * 2.0 ** -8, np.ones(n), np.full(n, 20.0)])
+    kw = dict(dt=1e-2, absTol=1e-5, relTol=1e-5, dtMin=1e-6, dtMax=0.05)
+    f = nn.Rhs.custom(3, ZCROSS_SRC, keys=("sigma", "rho", "beta"), defaults=dict(sigma=10.0, rho=28.0, beta=8.0 / 3.0), n_aux=3, name="lorenz_zcross")
+    for ts in ([0.0, 0.3, 0.301, 0.302, 0.9], [-0.2, -0.1, 0.0, 0.25, 0.2501, 0.6]):
+        aux = torch.zeros((3, n), dtype=torch.float64, device=dev)
+        t, y = nn.solveODE(f, torch.from_numpy(y0).to(dev), ts, nn.newODEoptions(**kw), ctx=nn.newNumContext(tValues={"aux": aux}), integrator=integrator)
+        ref = O.solve_ode_batch_ctx(O.RHS_LORENZ_ZCROSS, [10.0, 28.0, 8.0 / 3.0], None, np.zeros((3, n)), y0, n, 3, ts, O.new_options(**kw), integrator, n_threads=8)
+        assert np.array_equal(t, ref["t"]) and np.array_equal(y.cpu().numpy(), ref["y"], equal_nan=True), (integrator, ts)
+        assert np.array_equal(aux.cpu().numpy(), ref["aux"]), (integrator, ts, aux[2, :4].tolist(), ref["aux"][2, :4].tolist())
+        if integrator == "rk21":
+            aux2 = torch.zeros((3, n), dtype=torch.float64, device=dev)
+            t2, y2, ny, launches = nn.adaptiveStreamSolve(f, torch.from_numpy(y0).to(dev), ts, nn.newODEoptions(**kw), ctx=nn.newNumContext(tValues={"aux": aux2}),
+                                                          integrator=integrator)
+            assert np.array_equal(y2.cpu().numpy(), ref["y"], equal_nan=True) and np.array_equal(aux2.cpu().numpy(), ref["aux"]), (ts, aux2[2, :4].tolist(), ref["aux"][2, :4].tolist())
