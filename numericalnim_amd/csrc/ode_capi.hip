@@ -1474,6 +1474,7 @@ int nnhip_ode_fixed_stream_dense_f64_dev(const nnhip_ode_options* opt, int integ
   double* d1 = bufB + nState;
   double* d2 = d1 + nState;
   const bool useDense = n_t != 2;  // ode.nim:499-502
+  const bool exactCalls = nnhip::rtc_has_aux(rhs_kind);  // a right-hand side with mutable slots: every evaluation the reference makes, in its order
   int64_t stepsTotal = 0;
   bool truncated = false;
   auto row = [&](int j) { return y_out + (int64_t)j * nState; };
@@ -1487,17 +1488,25 @@ int nnhip_ode_fixed_stream_dense_f64_dev(const nnhip_ode_options* opt, int integ
     double t = tStartEff, dt = opt->dt, lastT = tStartEff;
     int denseIndex = 0;
     int64_t steps = 0;
+    auto evalF = [&](double tEff, const double* yy, double* out) { return nnhip_ode_rhs_batch_f64_dev(rhs_kind, rhs_params, n_params, N, dim, layout, neg ? -tEff : tEff, yy, out, stream); };
+    if (exactCalls && nState) {  // a mutating f: lastIter.dy (:498) and FSAL (:506) before the forward loop, g(-t0, y0) (:546) before the backward one
+      int r0 = evalF(t, cur, d1);
+      if (!r0 && !neg) r0 = evalF(t, cur, d1);
+      if (r0) return r0;
+    }
     while (t < tEnd) {  // :511
       if (useDense) {
         if (high < denseIndex) break;  // :513-514
         double treq = neg ? -req[denseIndex] : req[denseIndex];
         if (treq <= t) {
           const double* lb = lastBuf ? lastBuf : cur;
-          // lastIter.dy = f(lastT, lastY) (:530) and f(t, y) (:521); for the backward branch the kernels negate them (g = -f(-t, y))
-          int r2 = nnhip_ode_rhs_batch_f64_dev(rhs_kind, rhs_params, n_params, N, dim, layout, neg ? -lastT : lastT, lb, d1, stream);
-          if (!r2) r2 = nnhip_ode_rhs_batch_f64_dev(rhs_kind, rhs_params, n_params, N, dim, layout, neg ? -t : t, cur, d2, stream);
+          // lastIter.dy = f(lastT, lastY) (:530) and f(t, y) (:521); for the backward branch the kernels negate them (g = -f(-t, y)).
+          // Lazily — only when a requested time has been passed — unless f mutates its ctx (then d1 was evaluated with the step, :530)
+          int r2 = exactCalls ? NNHIP_OK : evalF(lastT, lb, d1);
+          if (!r2 && !exactCalls) r2 = evalF(t, cur, d2);
           if (r2) return r2;
           while (treq <= t) {  // :515
+            if (exactCalls) { const int r4 = evalF(t, cur, d2); if (r4) return r4; }  // once per emitted point (:521)
             HIP_TRY(nnhip::launch_hermite(treq, lastT, t, lb, cur, d1, d2, row(rowOf(denseIndex)), nState, neg ? 1 : 0, s));
             denseIndex += 1;
             if (high < denseIndex) break;  // :523-524
@@ -1506,6 +1515,7 @@ int nnhip_ode_fixed_stream_dense_f64_dev(const nnhip_ode_options* opt, int integ
         }
       }
       dt = nmin_h(dt, tEnd - t);  // :525
+      if (exactCalls && useDense && nState) { const int r5 = evalF(t, cur, d1); if (r5) return r5; }  // lastIter.dy = f(t, y, ctx) (:530)
       const int r3 = nnhip_ode_step_batch_f64_dev(opt, integrator, rhs_kind, rhs_params, n_params, N, dim, layout, nullptr, t, nullptr, dt, cur, nullptr,
                                                   nxt, nullptr, nullptr, nullptr, neg ? 1 : 0, stream);  // :531
       if (r3) return r3;
@@ -1523,6 +1533,14 @@ int nnhip_ode_fixed_stream_dense_f64_dev(const nnhip_ode_options* opt, int integ
     return NNHIP_OK;
   };
   int rowBase = 0;
+  int mPosFirst = -1;  // both directions: the forward one runs first, as in the reference (:508-542) — observable through a mutable ctx
+  const int fwdBase = (int)g.tNeg.size() + (g.nZero ? 1 : 0);
+  if (!g.tNeg.empty() && !g.tPos.empty()) {
+    int m = 0;
+    rc = run_dir(false, opt->tStart, g.tEndPos, g.tPos, [&](int k) { return fwdBase + k; }, m);
+    if (rc) return rc;
+    mPosFirst = m;
+  }
   if (!g.tNeg.empty()) {  // backward branch (:544-584): element k of yNegative lands in row nNeg-1-k (yNegative.reversed, :585)
     const int nNeg = (int)g.tNeg.size();
     int m = 0;
@@ -1538,7 +1556,11 @@ int nnhip_ode_fixed_stream_dense_f64_dev(const nnhip_ode_options* opt, int integ
     if (nState) HIP_TRY(hipMemcpyAsync(row(rowBase), y0, (size_t)nState * 8, hipMemcpyDeviceToDevice, s));
     rowBase += 1;
   }
-  if (!g.tPos.empty()) {
+  if (mPosFirst >= 0) {  // the forward rows were written for a backward branch that returns all of its rows: close up if it did not
+    if (rowBase != fwdBase && nState)
+      for (int j = 0; j < mPosFirst; ++j) HIP_TRY(hipMemcpyAsync(row(rowBase + j), row(fwdBase + j), (size_t)nState * 8, hipMemcpyDeviceToDevice, s));
+    rowBase += mPosFirst;
+  } else if (!g.tPos.empty()) {
     int m = 0;
     const int rb = rowBase;
     rc = run_dir(false, opt->tStart, g.tEndPos, g.tPos, [&](int k) { return rb + k; }, m);

@@ -184,6 +184,10 @@ def test_mutable_ctx_call_sequence_of_methods_without_fsal_with_dense_output(nn,
         ref = O.solve_ode_batch_ctx(O.RHS_LORENZ_ZCROSS, [10.0, 28.0, 8.0 / 3.0], None, np.zeros((3, n)), y0, n, 3, ts, O.new_options(**kw), integrator, n_threads=8)
         assert np.array_equal(t, ref["t"]) and np.array_equal(y.cpu().numpy(), ref["y"], equal_nan=True), (integrator, ts)
         assert np.array_equal(aux.cpu().numpy(), ref["aux"]), (integrator, ts, aux[2, :4].tolist(), ref["aux"][2, :4].tolist())
+        if integrator != "rk21":  # the fixed-step methods also through the host-driven dense streaming entry (forward direction first there too)
+            aux3 = torch.zeros((3, n), dtype=torch.float64, device=dev)
+            t3, y3, ny3, ns3 = nn.fixedStreamSolve(f, torch.from_numpy(y0).to(dev), ts, nn.newODEoptions(**kw), ctx=nn.newNumContext(tValues={"aux": aux3}), integrator=integrator)
+            assert np.array_equal(y3.cpu().numpy()[:ny3], ref["y"][:ny3], equal_nan=True) and np.array_equal(aux3.cpu().numpy(), ref["aux"]), (integrator, ts, aux3[2, :4].tolist(), ref["aux"][2, :4].tolist())
         if integrator == "rk21":
             aux2 = torch.zeros((3, n), dtype=torch.float64, device=dev)
             t2, y2, ny, launches = nn.adaptiveStreamSolve(f, torch.from_numpy(y0).to(dev), ts, nn.newODEoptions(**kw), ctx=nn.newNumContext(tValues={"aux": aux2}),
