@@ -579,7 +579,7 @@ def test_adaptive_stream_edge_shapes(nn, dev):
     try:
         for mode in (-1, 0):
             assert L.nnhip_tune_set(b"adv_recompute_fsal", mode) == 0
-            for n in (1, 3, 65, 257):
+            for n in (1, 2, 3, 64, 65, 258):
                 yl = torch.from_numpy(_lorenz_y0(n)).to(dev)
                 yr = torch.from_numpy(_ring_y0(n, 16)).to(dev)
                 ys1 = torch.from_numpy(1.0 + np.arange(n) * 2.0 ** -8).to(dev)
@@ -602,6 +602,17 @@ def test_adaptive_stream_edge_shapes(nn, dev):
                 t2, yd, ny, l2 = nn.adaptiveStreamSolve(nn.Rhs.lorenz(), yl, [0.0, 0.5, 1.0], nn.newODEoptions(**kw), integrator="tsit54", max_launches=1)
             tf, yf, cf = nn.solveODE(nn.Rhs.lorenz(), yl, [0.0, 0.5, 1.0], nn.newODEoptions(**kw), integrator="tsit54", max_steps=1, return_counts=True)
             assert l2 == 1 and torch.equal(ny, cf["ny"]) and torch.equal(torch.nan_to_num(yd, nan=-7.0), torch.nan_to_num(yf, nan=-7.0)) and len(w) == 1
+        # a batch whose members finish at very different launches (finished IVPs next to live ones in every wave)
+        assert L.nnhip_tune_set(b"adv_recompute_fsal", -1) == 0
+        rng = np.random.default_rng(12)
+        n = 4096
+        yh = torch.from_numpy(np.stack([rng.uniform(-15.0, 15.0, n), rng.uniform(-15.0, 15.0, n), rng.uniform(5.0, 40.0, n)])).to(dev)
+        for integ in ("dopri54", "tsit54", "bs32", "rk21"):
+            opt = nn.newODEoptions(absTol=1e-6, relTol=1e-6, dtMin=1e-9, dtMax=0.5)
+            yf, cf = nn.solveODE(nn.Rhs.lorenz(), yh, [0.0, 0.6], opt, integrator=integ, return_counts=True)[1:]
+            ys, launches = nn.adaptiveStream(nn.Rhs.lorenz(), yh.clone(), 0.0, 0.6, opt, integrator=integ, check_every=2)
+            assert torch.equal(ys, yf[-1]), integ
+            assert int(cf["steps"].max()) > int(cf["steps"].min())   # neighbours really finish at different launches
     finally:
         assert L.nnhip_tune_set(b"adv_recompute_fsal", -1) == 0
 

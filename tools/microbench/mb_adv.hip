@@ -170,6 +170,14 @@ static Launch tpi_persist(int block, int blocksPerCU) {
   };
 }
 
+template <int METHOD, class RHS, bool NT>
+static Launch tpi_pair(int block) {
+  return [block](const StepArgs& a, hipStream_t st) {
+    const int64_t pairs = (a.N + 1) / 2;
+    return launch_kernel(advance_tpi_pair_kernel<METHOD, RHS, NT>, dim3((unsigned)((pairs + block - 1) / block)), dim3(block), st, a);
+  };
+}
+
 int main(int argc, char** argv) {
   const char* only = argc > 1 ? argv[1] : "";
   int dev = 0; CK(hipSetDevice(dev));
@@ -271,6 +279,10 @@ int main(int argc, char** argv) {
     c.push_back({"dopri54 b64 packed FSAL recomputed", tpi_base<M, R>(64, 0), 1, 3});
     c.push_back({"dopri54 b64 nt packed FSAL recomputed", tpi_base<M, R>(64, 1), 1, 3});
     c.push_back({"tsit54 b64 packed FSAL recomputed", tpi_base<NNHIP_TSIT54, R>(64, 0), 1, 3});
+    c.push_back({"dopri54 PAIRS b64", tpi_pair<M, R, false>(64), 1, 3});
+    c.push_back({"dopri54 PAIRS b64 nt", tpi_pair<M, R, true>(64), 1, 3});
+    c.push_back({"dopri54 PAIRS b256", tpi_pair<M, R, false>(256), 1, 3});
+    c.push_back({"dopri54 b64 nt packed FSAL recomputed again", tpi_base<M, R>(64, 1), 1, 3});
     if (strstr(only, "quick")) { run_all<R>(("C3 streamed (quick list) " + tag).c_str(), p, c, 10, 60, 5, 8.0 * (4 * 3 + 5)); continue; }
     for (int b : {3, 4, 5, 8}) c.push_back({"dopri54 persist b256 grid=256x" + std::to_string(b), tpi_persist<M, R, false>(256, b)});
     for (int b : {12, 16, 20}) c.push_back({"dopri54 persist b64 grid=256x" + std::to_string(b), tpi_persist<M, R, false>(64, b)});
