@@ -408,6 +408,13 @@ int nnhip_ode_rhs_bind_ctx_f64_dev(int rhs_kind, const double* shared, int64_t s
 int nnhip_ode_rhs_bind_ctx_f64(int rhs_kind, const double* shared, int64_t shared_len, const double* per_ivp, int64_t per_ivp_rows,
                                const double* aux_init, int n_aux, int64_t stride, int device);
 int nnhip_ode_rhs_read_aux_f64(int rhs_kind, double* aux_out);
+/* A per-component body that reads only components c - lo .. c + hi of its system (cyclically: y[(c + 1) % dim] is one to the right) may say
+ * so: on the lanes-per-system kernels (systems of 8, 16, 32 ... components whose size is a power of two) the neighbours then come from the
+ * adjacent lanes through DPP rotations instead of the LDS stage vector — the form the compiled-in ring system uses; the same expression,
+ * hence the same bits (2x on the streamed 16-component ring).  0 <= lo, hi <= 4.  A body that reads outside the declared window computes
+ * with clamped neighbours, i.e. wrong numbers: declare what the body reads (the Python mirror checks a declaration against the undeclared
+ * form on a random batch).  Call before the first solve; code objects compiled earlier are dropped. */
+int nnhip_ode_rhs_set_halo(int rhs_kind, int lo, int hi);
 int nnhip_ode_rhs_release(int rhs_kind);
 
 /* Device-resident reassembly (BASELINE.json config C5): one process, n_gpus devices, RCCL over xGMI.  shard[r] lives on

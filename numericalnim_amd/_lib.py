@@ -100,6 +100,7 @@ SIGNATURES = {
     "nnhip_ode_rhs_bind_ctx_f64_dev": (C.c_int, [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int64]),
     "nnhip_ode_rhs_bind_ctx_f64": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_double), C.c_int, C.c_int64, C.c_int]),
     "nnhip_ode_rhs_read_aux_f64": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
+    "nnhip_ode_rhs_set_halo": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "nnhip_ode_rhs_release": (C.c_int, [C.c_int]),
     "nnhip_hermite_spline_eval_batch_f64_dev": (C.c_int, [_dp, C.c_int, _vp, _vp, C.c_int64, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _vp, _vp]),
     "nnhip_hermite_spline_slopes_f64_dev": (C.c_int, [_dp, C.c_int, _vp, C.c_int64, _vp, _vp]),

@@ -523,6 +523,12 @@ int nnhip_ode_rhs_read_aux_f64(int rhs_kind, double* aux_out) {
   return NNHIP_OK;
 }
 
+int nnhip_ode_rhs_set_halo(int rhs_kind, int lo, int hi) {
+  if (nnhip::rtc_set_halo(rhs_kind, lo, hi) != 0) return fail(NNHIP_EVALUE, "rhs_kind %d: %s", rhs_kind, nnhip::rtc_last_error());
+  release_adv_graphs();  // captured launches of the previous code objects
+  return NNHIP_OK;
+}
+
 int nnhip_ode_rhs_release(int rhs_kind) {
   return nnhip::rtc_release(rhs_kind) == 0 ? NNHIP_OK : fail(NNHIP_EVALUE, "unknown user rhs_kind %d", rhs_kind);
 }

@@ -207,6 +207,11 @@ struct RhsBanded { static constexpr bool value = false; };
 template <class R>
 struct RhsBanded<R, decltype((void)R::halo_hi)> { static constexpr bool value = true; };
 
+template <class R, int CPL>
+constexpr bool rhs_banded_applies() {
+  if constexpr (RhsBanded<R>::value) return RhsSize<R>::value == R::dim && R::dim / CPL >= 2 && R::halo_lo <= CPL && R::halo_hi <= CPL;
+  else return false;
+}
 // value of `v` in the next (DIR = +1) / previous (DIR = -1) lane of this lane's group of L consecutive lanes, cyclically
 template <int L, int DIR>
 NNHIP_DEV double lane_rotate(double v) {
@@ -248,9 +253,8 @@ struct LpsOps {
   }
   NNHIP_DEV void rhs(double t, const double (&y)[CPL], double (&dy)[CPL]) const {
 #ifndef NNHIP_NO_BANDED_RHS
-    if constexpr (RhsBanded<RHS>::value && SIZE == DIM && DIM / CPL >= 2) {
+    if constexpr (rhs_banded_applies<RHS, CPL>()) {  // (a halo wider than a lane's share, a padded system, one lane per system: the LDS path below)
       constexpr int LO = RHS::halo_lo, HI = RHS::halo_hi, L = DIM / CPL;
-      static_assert(LO <= CPL && HI <= CPL, "halo wider than a lane's share");
       double w[LO + CPL + HI];
 #pragma unroll
       for (int j = 0; j < CPL; ++j) w[LO + j] = y[j];

@@ -59,6 +59,7 @@ struct UserRhsEntry {
   std::string name, body;
   int dim = 0, n_params = 0;
   bool perComponent = false;  // body computes ONE component (usable by the lanes-per-system kernels) instead of the whole vector
+  int haloLo = -1, haloHi = -1;  // per-component body that reads components c - haloLo .. c + haloHi (cyclically) only: neighbours come through DPP lane rotations (RhsBanded) instead of the LDS stage vector; -1: not declared
   bool alive = false;
   // context layout (nnhip_ode_rhs_compile_ctx): NumContext beyond eight scalars
   bool hasCtx = false;
@@ -142,7 +143,22 @@ std::string make_source(const UserRhsEntry& e) {
     s += "    constexpr int dim = size; (void)dim;  // inside the body `dim` is the real number of components\n";
     s += "    {\n" + e.body + "\n    }\n  }\n";
     s += "  NNHIP_DEV static void eval(double t, const double (&y)[dim], double (&dy)[dim], const Params& P_) {\n";
-    s += "#pragma unroll\n    for (int c = 0; c < dim; ++c) dy[c] = comp(t, c, &y[0], P_);\n  }\n};\n}\n";
+    s += "#pragma unroll\n    for (int c = 0; c < dim; ++c) dy[c] = comp(t, c, &y[0], P_);\n  }\n";
+    if (e.haloLo >= 0 && e.haloHi >= 0) {
+      // the SAME body over a window of the components it declared it reads: `y[j]` resolves into the window (cyclically), so the
+      // expression — and its bits — are those of comp()
+      const std::string lo = std::to_string(e.haloLo), hi = std::to_string(e.haloHi);
+      s += "  static constexpr int halo_lo = " + lo + ", halo_hi = " + hi + ";\n";
+      s += "  struct WinRef_ { const double* w; int c;\n"
+           "    NNHIP_DEV double operator[](int j) const { int k = j - c; if (k < -" + lo + ") k += size; else if (k > " + hi + ") k -= size;\n"
+           "      k = k < -" + lo + " ? -" + lo + " : (k > " + hi + " ? " + hi + " : k);  // outside the declared window: clamped (a wrong declaration gives wrong numbers, not a fault; the Python mirror checks it)\n"
+           "      return w[k + " + lo + "]; } };\n";
+      s += "  NNHIP_DEV static double comp_window(double t, int c, const double* w_, const Params& P_) {\n";
+      s += ctx_preamble(e) + "    (void)t; (void)c;\n";
+      s += "    constexpr int dim = size; (void)dim;\n    const WinRef_ y{w_, c};\n";
+      s += "    {\n" + e.body + "\n    }\n  }\n";
+    }
+    s += "};\n}\n";
   }
   return s;
 }
@@ -289,6 +305,7 @@ std::shared_ptr<Program> get_program(int rhs_kind, int integrator) {
       snapshot.n_params = g_user[idx].n_params; snapshot.perComponent = g_user[idx].perComponent; snapshot.alive = true;
       snapshot.hasCtx = g_user[idx].hasCtx; snapshot.vecs = g_user[idx].vecs; snapshot.n_aux = g_user[idx].n_aux;
       snapshot.sharedLen = g_user[idx].sharedLen; snapshot.ivpRows = g_user[idx].ivpRows;
+      snapshot.haloLo = g_user[idx].haloLo; snapshot.haloHi = g_user[idx].haloHi;
     }
   }
   CodeObject fresh;
@@ -474,6 +491,19 @@ int rtc_bind_ctx(int rhs_kind, const double* shared, int64_t shared_len, const d
     return -1;
   }
   e.boundShared = shared; e.boundIvp = per_ivp; e.boundAux = aux; e.boundStride = stride;
+  return 0;
+}
+// Declares that the per-component body of `rhs_kind` reads components c - lo .. c + hi (cyclically) only.  Code objects compiled before are dropped.
+int rtc_set_halo(int rhs_kind, int lo, int hi) {
+  const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (idx < 0 || idx >= (int)g_user.size() || !g_user[idx].alive) { g_rtc_err = "unknown user rhs_kind"; return -1; }
+  UserRhsEntry& e = g_user[idx];
+  if (!e.perComponent) { g_rtc_err = "a halo can only be declared for a per-component body"; return -1; }
+  if (lo < 0 || hi < 0 || lo > 4 || hi > 4 || lo + hi + 1 > e.dim) { g_rtc_err = "halo must be 0..4 components on each side and narrower than the system"; return -1; }
+  if (e.haloLo == lo && e.haloHi == hi) return 0;
+  e.haloLo = lo; e.haloHi = hi;
+  e.programs.clear();  // shared_ptr-owned modules: launches in flight keep theirs alive
   return 0;
 }
 void rtc_drop_owned_ctx(int rhs_kind) {  // a binding to the caller's own device memory replaces one the library had uploaded itself

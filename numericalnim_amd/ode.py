@@ -121,12 +121,16 @@ class Rhs:
         return out
 
     @staticmethod
-    def custom(dim, body, keys=(), defaults=None, name="user", per_component=False, tvalues=None, per_ivp=(), n_aux=0, aux_key="aux"):
+    def custom(dim, body, keys=(), defaults=None, name="user", per_component=False, tvalues=None, per_ivp=(), n_aux=0, aux_key="aux", halo=None):
         """A user right-hand side from HIP C++ source (compiled at run time with hiprtc; include/nnhip_ode.h,
         nnhip_ode_rhs_compile).  `body` sees t, y[dim], dy[dim] and p[len(keys)] — e.g. for a damped oscillator
         Rhs.custom(2, "dy[0] = y[1]; dy[1] = -p[0]*y[0] - p[1]*y[1];", keys=("k", "c")).
         per_component=True: `body` returns dy_c for the component index `c` (nnhip_ode_rhs_compile_comp); systems of
         8 / 16 / 32 components then run on the lanes-per-system (LDS-staged) kernels.
+        halo=(lo, hi) (per-component bodies): the body reads components c - lo .. c + hi of its system only (cyclically:
+        y[(c + 1) % dim] is one to the right) — stencils, rings, banded couplings.  Systems whose size is a power of two then take their
+        neighbours from the adjacent lanes (DPP) instead of the LDS stage vector (nnhip_ode_rhs_set_halo): the same bits, up to 2x faster.
+        The declaration is checked once against the undeclared form on a random batch (a body that reads outside its window raises).
 
         NumContext in full (commonTypes.nim:4-27; nnhip_ode_rhs_compile_ctx) — any of the following makes it a right-hand side with
         a context layout, bound to the `ctx` given to solveODE & co. at every call:
@@ -142,7 +146,11 @@ class Rhs:
         for nm in per_ivp:
             if nm not in tvalues:
                 raise ValueError(f"per_ivp names '{nm}', which tvalues does not declare")
-        key = (int(dim), body, len(keys), bool(per_component), tuple(tvalues.items()), per_ivp, int(n_aux))
+        if halo is not None:
+            halo = (int(halo[0]), int(halo[1]))
+            if not per_component:
+                raise ValueError("halo needs per_component=True")
+        key = (int(dim), body, len(keys), bool(per_component), tuple(tvalues.items()), per_ivp, int(n_aux), halo)
         k = Rhs._compiled.get(key)  # the same source is registered (and compiled) once per process
         if k is not None and not _lib.lib().nnhip_ode_supported(0, k, int(dim), LAYOUT_SOA, 0):
             k = None  # released in the meantime (nnhip_ode_rhs_release)
@@ -159,12 +167,39 @@ class Rhs:
             else:
                 fn = _lib.lib().nnhip_ode_rhs_compile_comp if per_component else _lib.lib().nnhip_ode_rhs_compile
                 _check(fn(str(name).encode(), int(dim), len(keys), body.encode(), C.byref(kind)))
-            k = Rhs._compiled[key] = kind.value
+            k = kind.value
+            if halo is not None:
+                _check(_lib.lib().nnhip_ode_rhs_set_halo(k, halo[0], halo[1]))
+                if not has_ctx:
+                    Rhs._check_halo(k, int(dim), body, keys, defaults, name)
+            Rhs._compiled[key] = k
         r = Rhs(k, keys, defaults)
         r.dim = int(dim)
         if has_ctx:
             r.ctx_layout = dict(tvalues=tvalues, per_ivp=per_ivp, n_aux=int(n_aux), aux_key=aux_key)
         return r
+
+    @staticmethod
+    def _check_halo(kind, dim, body, keys, defaults, name):
+        """A declared halo against the undeclared form of the same body: three RK4 steps of 64 random systems through both must agree bit for
+        bit (they evaluate the same expression on the same values unless the body reads outside its window).  Needs a GPU; skipped without."""
+        try:
+            import torch
+            if not torch.cuda.is_available():
+                return
+        except ImportError:
+            return
+        plain = Rhs.custom(dim, body, keys=keys, defaults=defaults, name=str(name) + "_nohalo", per_component=True)
+        declared = Rhs(kind, keys, defaults)
+        declared.dim = dim
+        rng = np.random.default_rng(20260928)
+        y0 = torch.from_numpy(rng.uniform(-1.0, 1.0, (64, dim))).cuda()
+        opt = newODEoptions(dt=1e-3)
+        a = solveODE(declared, y0, [0.0, 3e-3], opt, integrator="rk4", layout=LAYOUT_AOS)[1]
+        b = solveODE(plain, y0, [0.0, 3e-3], opt, integrator="rk4", layout=LAYOUT_AOS)[1]
+        if not torch.equal(a, b):
+            _lib.lib().nnhip_ode_rhs_release(kind)
+            raise ValueError("halo=(lo, hi) does not cover what the body reads: the banded form and the plain form of this right-hand side disagree")
 
     def bind(self, ctx):
         """Binds `ctx` to this right-hand side's context layout (nnhip_ode_rhs_bind_ctx_f64_dev): the closure capturing its ctx.

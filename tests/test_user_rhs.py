@@ -110,3 +110,55 @@ def test_user_rhs_reads_a_device_table_through_a_parameter_slot(nn, dev):
         _, yb = nn.solveODE(f_ref, y0, ts, nn.newODEoptions(dt=1e-3), integrator=m)
         assert float((ya - yb).abs().max()) < 1e-6      # table interpolation error of a quadratic on a 4096-cell grid ~ 6e-8
         assert torch.isfinite(ya).all()
+
+
+@pytest.mark.gpu
+def test_per_component_source_with_a_declared_halo(nn, dev):
+    """Rhs.custom(..., per_component=True, halo=(lo, hi)) (nnhip_ode_rhs_set_halo): a body that reads only its neighbours takes them from the
+    adjacent lanes (the banded form of LpsOps::rhs, what the compiled-in ring uses) instead of the LDS stage vector — the same expression,
+    so the same bits as the undeclared form and as the compiled-in system: fused and streamed, FSAL and non-FSAL methods, both
+    layouts, dense output, a non-cyclic stencil (heat equation), and sizes where the banded form does not apply (a padded system, a
+    thread-per-IVP one).  A declaration that does not cover the body is refused at registration."""
+    import torch
+    ring_src = "return -((double)(c + 1) / (double)dim) * y[c] + p[0] * y[(c + 1) % dim];"
+    heat_src = "const double l = c > 0 ? y[c - 1] : 0.0; const double r = c + 1 < dim ? y[c + 1] : 0.0; return p[0] * ((l - 2.0 * y[c]) + r);"
+    rng = np.random.default_rng(3)
+    kw = dict(absTol=1e-8, relTol=1e-8, dtMin=1e-8, dtMax=0.25)
+    for dim in (16, 32, 8):
+        f_h = nn.Rhs.custom(dim, ring_src, keys=("c",), defaults={"c": 0.1}, name=f"ring{dim}_halo", per_component=True, halo=(0, 1))
+        f_p = nn.Rhs.custom(dim, ring_src, keys=("c",), defaults={"c": 0.1}, name=f"ring{dim}_plain", per_component=True)
+        assert f_h.kind != f_p.kind
+        n = 513
+        y0 = rng.uniform(0.5, 1.5, (n, dim))
+        for layout, y in ((1, torch.from_numpy(y0).to(dev)), (0, torch.from_numpy(np.ascontiguousarray(y0.T)).to(dev))):
+            for integ in ("tsit54", "dopri54", "vern65", "rk4", "bs32"):
+                opt = nn.newODEoptions(dt=1e-2, **kw)
+                ts = [-0.2, 0.0, 0.3, 1.0]
+                a = nn.solveODE(f_h, y, ts, opt, integrator=integ, layout=layout)[1]
+                b = nn.solveODE(f_p, y, ts, opt, integrator=integ, layout=layout)[1]
+                c = nn.solveODE(nn.Rhs.ring(0.1), y, ts, opt, integrator=integ, layout=layout)[1]
+                assert torch.equal(a, b) and torch.equal(a, c), (dim, layout, integ)
+            for integ in ("tsit54", "bs32"):
+                opt = nn.newODEoptions(**kw)
+                yf = nn.solveODE(f_p, y, [0.0, 1.0], opt, integrator=integ, layout=layout)[1][-1]
+                ys, launches = nn.adaptiveStream(f_h, y.clone(), 0.0, 1.0, opt, integrator=integ, layout=layout)
+                assert torch.equal(ys, yf), (dim, layout, integ)
+                t2, yd, ny, l2 = nn.adaptiveStreamSolve(f_h, y, [0.0, 0.4, 1.0], opt, integrator=integ, layout=layout)
+                assert torch.equal(yd, nn.solveODE(f_p, y, [0.0, 0.4, 1.0], opt, integrator=integ, layout=layout)[1]), (dim, layout, integ)
+    # a non-cyclic stencil; 24 unknowns are padded to 32 (the banded form does not apply: same results through the LDS path); 4: thread-per-IVP
+    for dim in (64, 24, 4):
+        f_h = nn.Rhs.custom(dim, heat_src, keys=("kappa",), defaults={"kappa": 0.4}, name=f"heat{dim}_halo", per_component=True, halo=(1, 1))
+        f_p = nn.Rhs.custom(dim, heat_src, keys=("kappa",), defaults={"kappa": 0.4}, name=f"heat{dim}_plain", per_component=True)
+        y = torch.from_numpy(rng.uniform(0.0, 1.0, (300, dim))).to(dev)
+        for integ in ("dopri54", "rk4"):
+            opt = nn.newODEoptions(dt=1e-2, **kw)
+            assert torch.equal(nn.solveODE(f_h, y, [0.0, 0.5, 1.0], opt, integrator=integ, layout=1)[1], nn.solveODE(f_p, y, [0.0, 0.5, 1.0], opt, integrator=integ, layout=1)[1]), (dim, integ)
+        ys, launches = nn.adaptiveStream(f_h, y.clone(), 0.0, 1.0, nn.newODEoptions(**kw), integrator="tsit54", layout=1)
+        assert torch.equal(ys, nn.solveODE(f_p, y, [0.0, 1.0], nn.newODEoptions(**kw), integrator="tsit54", layout=1)[1][-1]), dim
+    # declarations that do not cover the body, or make no sense
+    with pytest.raises(ValueError):
+        nn.Rhs.custom(16, ring_src, keys=("c",), defaults={"c": 0.1}, name="ring16_bad_halo", per_component=True, halo=(1, 0))
+    with pytest.raises(ValueError):
+        nn.Rhs.custom(16, "dy[0] = y[1];", name="whole_vector_halo", halo=(1, 1))
+    L = nn._lib.lib()
+    assert L.nnhip_ode_rhs_set_halo(f_h.kind, 9, 0) != 0 and L.nnhip_ode_rhs_set_halo(12345, 1, 1) != 0 and L.nnhip_ode_rhs_set_halo(nn.Rhs.ring(0.1).kind, 1, 1) != 0
