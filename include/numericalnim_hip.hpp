@@ -97,6 +97,17 @@ inline RhsSpec rhsFromSource(int dim, const std::string& body, std::vector<std::
   return {static_cast<nnhip_rhs_kind>(kind), std::move(keys), std::move(defaults)};
 }
 
+// A per-component right-hand side from source (`body` returns dy_c for the component index c) that reads components c - lo .. c + hi of
+// its system only (cyclically): stencils, rings, banded couplings.  On the lanes-per-system kernels the neighbours then come from the
+// adjacent lanes instead of the LDS stage vector (nnhip_ode_rhs_compile_comp + nnhip_ode_rhs_set_halo) — the same bits, up to 2x faster.
+inline RhsSpec rhsFromSourcePerComponent(int dim, const std::string& body, std::vector<std::string> keys = {}, std::map<std::string, double> defaults = {},
+                                         const std::string& name = "user", int haloLo = -1, int haloHi = -1) {
+  int kind = 0;
+  throwOn(nnhip_ode_rhs_compile_comp(name.c_str(), dim, (int)keys.size(), body.c_str(), &kind));
+  if (haloLo >= 0 && haloHi >= 0) throwOn(nnhip_ode_rhs_set_halo(kind, haloLo, haloHi));
+  return {static_cast<nnhip_rhs_kind>(kind), std::move(keys), std::move(defaults)};
+}
+
 // NumContext in full (commonTypes.nim:4-27; nnhip_ode_rhs_compile_ctx): a right-hand side from source whose body also reads named
 // ctx.tValues entries — NAME[j] of a vector the batch shares, NAME(j) of the IVP's own vector — any number of fValues (p[k]) and
 // per-IVP mutable slots aux(j) (the mutable ctx of ode.nim:599).

@@ -34,6 +34,15 @@ proc rhsFromSource*(dim: int, body: string, keys: seq[string] = @[], name = "use
   if rc != 0: raise newException(ValueError, $nnhip_last_error())
   RhsSpec(kind: RhsKind(0), keys: keys, userKind: kind.int)
 
+proc rhsFromSourcePerComponent*(dim: int, body: string, keys: seq[string] = @[], name = "user", haloLo = -1, haloHi = -1): RhsSpec =
+  ## A right-hand side given per component: `body` returns dy_c for the component index `c`.  haloLo / haloHi >= 0: it reads components
+  ## c - haloLo .. c + haloHi of its system only (cyclically) — neighbours then come from the adjacent lanes (nnhip_ode_rhs_set_halo).
+  var kind: cint
+  var rc = nnhip_ode_rhs_compile_comp(name.cstring, dim.cint, keys.len.cint, body.cstring, addr kind)
+  if rc == 0 and haloLo >= 0 and haloHi >= 0: rc = nnhip_ode_rhs_set_halo(kind, haloLo.cint, haloHi.cint)
+  if rc != 0: raise newException(ValueError, $nnhip_last_error())
+  RhsSpec(kind: RhsKind(0), keys: keys, userKind: kind.int)
+
 type CtxVector* = object                  ## one ctx.tValues entry a right-hand side from source reads
   name*: string
   len*: int
