@@ -83,6 +83,7 @@ constexpr int kMultiKey = 500;   // programs[kMultiKey + integrator]: the advanc
 constexpr int kDenseKey = 1000;  // programs[kDenseKey + integrator]: advance_dense_*_kernel of that integrator
 constexpr int kCallsKey = 2000;  // programs[kCallsKey + integrator]: the solve kernel with per-IVP call data (MODE 2)
 constexpr int kGridKey = 3000;   // programs[kGridKey + integrator]: the solve kernel with per-IVP n_t-point tspans (MODE 3)
+constexpr int kLeanKey = 4000;   // programs[kLeanKey + integrator]: the solve kernel without dense output (MODE 0: no Hermite history in registers; 2-point tspans)
 std::deque<UserRhsEntry> g_user;  // deque: registering a new RHS never moves existing entries (programs are handed out by pointer)
 thread_local std::string g_rtc_err;
 
@@ -174,9 +175,9 @@ bool compile(const UserRhsEntry& e, int integrator, CodeObject& out) {
   }
   std::vector<std::string> names;
   if (integrator >= kCallsKey) {  // the fused solve with per-IVP tspan / options (nnhip_ode_solve_batch_calls_f64_dev / _tspans_): its own code object
-    const bool grid = integrator >= kGridKey;
-    const int method = integrator - (grid ? kGridKey : kCallsKey);
-    const std::string m = std::to_string(method), mode = grid ? "3" : "2";
+    const bool lean = integrator >= kLeanKey, grid = !lean && integrator >= kGridKey;
+    const int method = integrator - (lean ? kLeanKey : (grid ? kGridKey : kCallsKey));
+    const std::string m = std::to_string(method), mode = lean ? "0" : (grid ? "3" : "2");
     if (uses_lps(e)) {
       int adaptive = 0;
       nnhip_ode_integrator_traits(method, nullptr, nullptr, &adaptive);
@@ -548,7 +549,9 @@ static hipError_t launch(hipFunction_t f, int64_t n, int perBlock, void* arg, hi
 }
 
 hipError_t rtc_launch_solve(int rhs_kind, int integrator, const SolveArgs& a, hipStream_t s) {
-  const std::shared_ptr<Program> p = get_program(rhs_kind, a.perCall.tGrid ? kGridKey + integrator : (a.perCall.tEnd ? kCallsKey + integrator : integrator));
+  // one code object per mode of the solve kernel, compiled when first asked for: per-IVP grids / per-IVP spans / no dense output (the lean instantiation the
+  // compiled-in systems use for 2-point tspans) / dense output
+  const std::shared_ptr<Program> p = get_program(rhs_kind, a.perCall.tGrid ? kGridKey + integrator : (a.perCall.tEnd ? kCallsKey + integrator : (!a.useDense ? kLeanKey + integrator : integrator)));
   if (!p) return hipErrorInvalidValue;
   SolveArgs copy = a;
   return launch(p->solve, a.N, p->ivpsPerBlockSolve, &copy, s);
