@@ -88,7 +88,12 @@ typedef struct nnhip_ode_stats {
 int nnhip_abi_version(void);
 int nnhip_device_count(void);            /* >=0, or NNHIP_EHIP                                              */
 const char* nnhip_last_error(void);      /* thread-local, never NULL                                        */
-const char* nnhip_build_info(void);      /* arch, fp-contract mode, compiler                                */
+const char* nnhip_build_info(void);
+/* Which libhiprtc (path, version) compiles right-hand sides given as source.  A host process may bundle an older ROCm than the one this library
+ * was built with (PyTorch wheels do); when the system's libhiprtc is newer than the process's own, it is loaded into a link namespace of its
+ * own and used instead — the same compiler generation as the library's ahead-of-time kernels (1.7-2.2x on the 16-component systems).
+ * Environment: NNHIP_HIPRTC=process keeps the process's own, NNHIP_HIPRTC=/path/to/libhiprtc.so names one. */
+const char* nnhip_rtc_compiler(void);
 
 /* Frees what the library caches between calls: the calling thread's pinned staging buffer, hipGraph caches (they are per
  * thread: other threads keep theirs until they call this or change a tuning knob) and side streams, the idle

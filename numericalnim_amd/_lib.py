@@ -31,6 +31,7 @@ SIGNATURES = {
     "nnhip_device_count": (C.c_int, []),
     "nnhip_last_error": (C.c_char_p, []),
     "nnhip_build_info": (C.c_char_p, []),
+    "nnhip_rtc_compiler": (C.c_char_p, []),
     "nnhip_release": (C.c_int, []),
     "nnhip_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64]),
     "nnhip_host_free": (C.c_int, [C.c_void_p]),

@@ -341,6 +341,8 @@ const char* nnhip_build_info(void) {
          "compiler " __VERSION__;
 }
 
+const char* nnhip_rtc_compiler(void) { return nnhip::rtc_compiler_origin(); }
+
 int nnhip_release(void) {
   // calling thread: pinned staging buffer of the requested-time arrays and the hipGraph cache of the streaming loop
   Staging& st = g_stage;

@@ -10,6 +10,9 @@
 #include <hip/hiprtc.h>
 
 #include <cstdio>
+#include <climits>
+#include <cstdlib>
+#include <dlfcn.h>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -23,6 +26,62 @@
 
 namespace nnhip {
 namespace {
+
+// Which compiler builds the user's right-hand sides.  A host process may carry its own, older copy of hiprtc + comgr (PyTorch wheels bundle the
+// ROCm they were built with: 7.0.2 / clang 20 in this image, against the system's 7.2 / clang 22 that built this library) — and the run-time
+// compiled kernels are then those of that compiler: the same templates come out at 179 instead of 168 VGPRs (2 instead of 3 waves per
+// SIMD) and run 1.7-2.2x slower (profiles/r03_bench_rtc_stream.json; "faster under rocprofv3" was this: the profiler's environment puts
+// /opt/rocm/lib first).  So: if the system's libhiprtc is another file than the one the process resolves, it is loaded into a link namespace of its
+// own (dlmopen: its comgr comes with it, nothing the process already uses is touched) and used for the compilations; only source text goes
+// in and a code object comes out.  (hiprtcVersion reports the API level, 9.0 for both, so the rule is not "newer" but "the ROCm this library was
+// built with, if it is installed and is not what the process already uses".)  NNHIP_HIPRTC=process keeps the process's own;
+// NNHIP_HIPRTC=/path/libhiprtc.so names another.
+struct RtcApi {
+  hiprtcResult (*createProgram)(hiprtcProgram*, const char*, const char*, int, const char* const*, const char* const*);
+  hiprtcResult (*compileProgram)(hiprtcProgram, int, const char* const*);
+  hiprtcResult (*getProgramLogSize)(hiprtcProgram, size_t*);
+  hiprtcResult (*getProgramLog)(hiprtcProgram, char*);
+  hiprtcResult (*getCodeSize)(hiprtcProgram, size_t*);
+  hiprtcResult (*getCode)(hiprtcProgram, char*);
+  hiprtcResult (*addNameExpression)(hiprtcProgram, const char*);
+  hiprtcResult (*getLoweredName)(hiprtcProgram, const char*, const char**);
+  hiprtcResult (*destroyProgram)(hiprtcProgram*);
+  std::string origin;
+};
+const RtcApi& rtc_api() {
+  static const RtcApi api = [] {
+    RtcApi a{&hiprtcCreateProgram, &hiprtcCompileProgram, &hiprtcGetProgramLogSize, &hiprtcGetProgramLog, &hiprtcGetCodeSize, &hiprtcGetCode,
+             &hiprtcAddNameExpression, &hiprtcGetLoweredName, &hiprtcDestroyProgram, "the process's libhiprtc"};
+    const char* pref = std::getenv("NNHIP_HIPRTC");
+    if (pref && std::strcmp(pref, "process") == 0) return a;
+    const std::string path = pref && *pref ? pref : "/opt/rocm/lib/libhiprtc.so";  // the ROCm this library was built with
+    Dl_info info;
+    char mine[PATH_MAX] = "", theirs[PATH_MAX] = "";
+    if (!realpath(path.c_str(), theirs)) return a;  // no such ROCm next to the process's
+    if (dladdr((void*)&hiprtcCreateProgram, &info) && info.dli_fname && realpath(info.dli_fname, mine)) {
+      a.origin = std::string(mine) + " (the process's own)";
+      if (std::strcmp(mine, theirs) == 0) return a;
+    }
+    void* h = dlmopen(LM_ID_NEWLM, theirs, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return a;
+    RtcApi b;
+    b.createProgram = (decltype(b.createProgram))dlsym(h, "hiprtcCreateProgram");
+    b.compileProgram = (decltype(b.compileProgram))dlsym(h, "hiprtcCompileProgram");
+    b.getProgramLogSize = (decltype(b.getProgramLogSize))dlsym(h, "hiprtcGetProgramLogSize");
+    b.getProgramLog = (decltype(b.getProgramLog))dlsym(h, "hiprtcGetProgramLog");
+    b.getCodeSize = (decltype(b.getCodeSize))dlsym(h, "hiprtcGetCodeSize");
+    b.getCode = (decltype(b.getCode))dlsym(h, "hiprtcGetCode");
+    b.addNameExpression = (decltype(b.addNameExpression))dlsym(h, "hiprtcAddNameExpression");
+    b.getLoweredName = (decltype(b.getLoweredName))dlsym(h, "hiprtcGetLoweredName");
+    b.destroyProgram = (decltype(b.destroyProgram))dlsym(h, "hiprtcDestroyProgram");
+    if (!b.createProgram || !b.compileProgram || !b.getProgramLogSize || !b.getProgramLog || !b.getCodeSize || !b.getCode || !b.addNameExpression || !b.getLoweredName ||
+        !b.destroyProgram)
+      return a;
+    b.origin = std::string(theirs) + " (in a link namespace of its own; the process's own is " + (mine[0] ? mine : "unknown") + ")";
+    return b;
+  }();
+  return api;
+}
 
 struct Header { const char* name; const char* text; };
 const Header kHeaders[] = {
@@ -169,7 +228,7 @@ bool compile(const UserRhsEntry& e, int integrator, CodeObject& out) {
   hiprtcProgram prog;
   std::vector<const char*> hsrc, hname;
   for (const Header& h : kHeaders) { hsrc.push_back(h.text); hname.push_back(h.name); }
-  if (hiprtcCreateProgram(&prog, src.c_str(), "nnhip_user_rhs.hip", (int)hsrc.size(), hsrc.data(), hname.data()) != HIPRTC_SUCCESS) {
+  if (rtc_api().createProgram(&prog, src.c_str(), "nnhip_user_rhs.hip", (int)hsrc.size(), hsrc.data(), hname.data()) != HIPRTC_SUCCESS) {
     g_rtc_err = "hiprtcCreateProgram failed";
     return false;
   }
@@ -234,34 +293,38 @@ bool compile(const UserRhsEntry& e, int integrator, CodeObject& out) {
   } else {
     names.push_back("nnhip::rhs_batch_kernel<nnhip::UserRhs>");
   }
-  for (auto& n : names) hiprtcAddNameExpression(prog, n.c_str());
+  for (auto& n : names) rtc_api().addNameExpression(prog, n.c_str());
   // same numerical contract as the ahead-of-time kernels
   const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
-  const hiprtcResult rc = hiprtcCompileProgram(prog, 4, opts);
+  const hiprtcResult rc = rtc_api().compileProgram(prog, 4, opts);
   if (rc != HIPRTC_SUCCESS) {
     size_t n = 0;
-    hiprtcGetProgramLogSize(prog, &n);
+    rtc_api().getProgramLogSize(prog, &n);
     std::string log(n, '\0');
-    if (n) hiprtcGetProgramLog(prog, log.data());
+    if (n) rtc_api().getProgramLog(prog, log.data());
     g_rtc_err = "hiprtc compilation of user RHS '" + e.name + "' failed:\n" + log;
-    hiprtcDestroyProgram(&prog);
+    rtc_api().destroyProgram(&prog);
     return false;
   }
   size_t codeSize = 0;
-  hiprtcGetCodeSize(prog, &codeSize);
+  rtc_api().getCodeSize(prog, &codeSize);
   out.code.resize(codeSize);
-  hiprtcGetCode(prog, out.code.data());
+  rtc_api().getCode(prog, out.code.data());
+  if (const char* dump = std::getenv("NNHIP_RTC_DUMP")) {  // debugging aid: the code object of every run-time compilation, as DIR/<name>_<key>.co
+    const std::string path = std::string(dump) + "/" + e.name + "_" + std::to_string(integrator) + ".co";
+    if (FILE* fdump = std::fopen(path.c_str(), "wb")) { std::fwrite(out.code.data(), 1, out.code.size(), fdump); std::fclose(fdump); }
+  }
   out.lowered.clear();
   for (auto& n : names) {
     const char* ln = nullptr;
-    if (hiprtcGetLoweredName(prog, n.c_str(), &ln) != HIPRTC_SUCCESS || !ln) {
+    if (rtc_api().getLoweredName(prog, n.c_str(), &ln) != HIPRTC_SUCCESS || !ln) {
       g_rtc_err = "hiprtcGetLoweredName failed for " + n;
-      hiprtcDestroyProgram(&prog);
+      rtc_api().destroyProgram(&prog);
       return false;
     }
     out.lowered.push_back(ln);
   }
-  hiprtcDestroyProgram(&prog);
+  rtc_api().destroyProgram(&prog);
   return true;
 }
 
@@ -336,6 +399,7 @@ std::shared_ptr<Program> get_program(int rhs_kind, int integrator) {
 static void free_owned(UserRhsEntry& e);
 
 const char* rtc_last_error() { return g_rtc_err.c_str(); }
+const char* rtc_compiler_origin() { return rtc_api().origin.c_str(); }  // which libhiprtc builds the user's right-hand sides
 
 int rtc_register(const char* name, int dim, int n_params, const char* body, bool per_component, bool check_compiles, const RtcCtxLayout* ctx) {
   UserRhsEntry e;
@@ -364,22 +428,22 @@ int rtc_register(const char* name, int dim, int n_params, const char* body, bool
     hiprtcProgram prog;
     std::vector<const char*> hsrc, hname;
     for (const Header& h : kHeaders) { hsrc.push_back(h.text); hname.push_back(h.name); }
-    if (hiprtcCreateProgram(&prog, src.c_str(), "nnhip_user_rhs.hip", (int)hsrc.size(), hsrc.data(), hname.data()) != HIPRTC_SUCCESS) {
+    if (rtc_api().createProgram(&prog, src.c_str(), "nnhip_user_rhs.hip", (int)hsrc.size(), hsrc.data(), hname.data()) != HIPRTC_SUCCESS) {
       g_rtc_err = "hiprtcCreateProgram failed";
       return -1;
     }
-    hiprtcAddNameExpression(prog, "nnhip::rhs_batch_kernel<nnhip::UserRhs>");
+    rtc_api().addNameExpression(prog, "nnhip::rhs_batch_kernel<nnhip::UserRhs>");
     const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
-    if (hiprtcCompileProgram(prog, 4, opts) != HIPRTC_SUCCESS) {
+    if (rtc_api().compileProgram(prog, 4, opts) != HIPRTC_SUCCESS) {
       size_t n = 0;
-      hiprtcGetProgramLogSize(prog, &n);
+      rtc_api().getProgramLogSize(prog, &n);
       std::string log(n, '\0');
-      if (n) hiprtcGetProgramLog(prog, log.data());
+      if (n) rtc_api().getProgramLog(prog, log.data());
       g_rtc_err = "hiprtc compilation of user RHS '" + e.name + "' failed:\n" + log;
-      hiprtcDestroyProgram(&prog);
+      rtc_api().destroyProgram(&prog);
       return -1;
     }
-    hiprtcDestroyProgram(&prog);
+    rtc_api().destroyProgram(&prog);
   }
   std::lock_guard<std::mutex> lk(g_mu);
   g_user.push_back(std::move(e));

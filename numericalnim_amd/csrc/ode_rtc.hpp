@@ -23,6 +23,7 @@ int rtc_read_aux(int rhs_kind, double* aux_out);
 void rtc_drop_owned_ctx(int rhs_kind);
 bool rtc_has_per_ivp_ctx(int rhs_kind);
 int rtc_set_halo(int rhs_kind, int lo, int hi);  // per-component body reads components c - lo .. c + hi only (banded form: DPP instead of the LDS stage vector); 0 / -1
+const char* rtc_compiler_origin();  // the libhiprtc in use (path, version), see rtc_api() in ode_rtc.hip
 bool rtc_has_aux(int rhs_kind);  // the right-hand side mutates per-IVP slots: the number and order of its evaluations are observable
 int rtc_release(int rhs_kind);
 bool rtc_info(int rhs_kind, int* dim, int* n_params);

@@ -230,3 +230,22 @@ def test_tune_set_validation(nn):
         if reset is not None:
             assert L.nnhip_tune_set(key, reset) == 0
     assert L.nnhip_tune_set(b"rk4_stream_auto", 1) == 0  # back to automatic variant selection
+
+
+def test_rtc_compiler_choice(nn):
+    """nnhip_rtc_compiler(): which libhiprtc builds right-hand sides given as source.  In a process that carries its own copy (PyTorch's
+    wheels do) the ROCm the library was built with is loaded into a link namespace of its own, unless NNHIP_HIPRTC=process; both
+    compile the same source to kernels with the same results (the GPU suite runs on the default)."""
+    import subprocess
+    import sys
+    who = nn._lib.lib().nnhip_rtc_compiler().decode()
+    assert "libhiprtc" in who
+    code = ("import torch, numericalnim_amd as nn; L = nn._lib.lib(); print(L.nnhip_rtc_compiler().decode()); "
+            "f = nn.Rhs.custom(2, 'dy[0] = y[1]; dy[1] = -p[0] * y[0];', keys=('k',), defaults={'k': 2.0}, name='osc_rtc_choice'); print('kind', f.kind)")
+    for env_val, expect in (("process", "the process's libhiprtc"), (None, "libhiprtc")):
+        env = dict(os.environ)
+        env.pop("NNHIP_HIPRTC", None)
+        if env_val:
+            env["NNHIP_HIPRTC"] = env_val
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0 and expect in r.stdout and "kind" in r.stdout, (env_val, r.stdout[-400:], r.stderr[-400:])
