@@ -145,6 +145,12 @@ int nnhip_ode_integrator_id(const char* name);
 const char* nnhip_ode_integrator_name(int integrator);
 /* (useFSAL, order, adaptive) triple the dispatch passes to ODESolver (ode.nim:608-649). */
 int nnhip_ode_integrator_traits(int integrator, int* use_fsal, double* order, int* adaptive);
+/* The Butcher tableau the kernels of a tableau method are compiled with — DOPRI54 (ode.nim:240-282), Tsit54 (:310-352), Vern65 (:380-443) —
+ * for verification against the reference's text: out = [S, NB, c_1..c_S, a_21, a_31, a_32, .. a_S,S-1, b_1..b_NB, bHat_1..bHat_S]
+ * (43 / 43 / 64 values).  device < 0: read on the host from the constexpr tables; device >= 0: written by a kernel on that device through
+ * the accessors the steppers use.  Returns the number of values, NNHIP_EINTEGRATOR for the other 11 methods (their coefficients are
+ * literals inside their step expressions, ode.nim:107-234), NNHIP_EVALUE if cap is too small. */
+int nnhip_ode_tableau_f64(int integrator, int device, double* out, int cap);
 /* Output time grid exactly as ODESolver assembles it (ode.nim:476-480, 585): tspan.sorted(), split
  * around tStart, tNegative.reversed ++ tZero ++ tPositive.  t_out has room for n_t doubles. */
 int nnhip_ode_time_grid(const nnhip_ode_options* opt, const double* tspan, int n_t, double* t_out, int* n_t_out);

@@ -41,6 +41,7 @@ SIGNATURES = {
     "nnhip_ode_integrator_id": (C.c_int, [C.c_char_p]),
     "nnhip_ode_integrator_name": (C.c_char_p, [C.c_int]),
     "nnhip_ode_integrator_traits": (C.c_int, [C.c_int, C.POINTER(C.c_int), _dp, C.POINTER(C.c_int)]),
+    "nnhip_ode_tableau_f64": (C.c_int, [C.c_int, C.c_int, _dp, C.c_int]),
     "nnhip_ode_time_grid": (C.c_int, [C.POINTER(Options), _dp, C.c_int, _dp, C.POINTER(C.c_int)]),
     "nnhip_ode_supported": (C.c_int, [C.c_int] * 5),
     "nnhip_ode_solve_batch_f64": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, _vp, C.c_int64, C.c_int, C.c_int,

@@ -1669,7 +1669,8 @@ nnhip::StepArgs adv_range(const nnhip::StepArgs& full, int64_t lo, int64_t n) {
   nnhip::StepArgs a = full;
   a.N = n;
   a.y_in += lo * a.ivpStride; a.y_out += lo * a.ivpStride; a.fsal_in += lo * a.ivpStride; a.fsal_out += lo * a.ivpStride;
-  a.t_io += lo; a.dt_io += lo;
+  if (a.dt_io) { a.t_io += lo; a.dt_io += lo; }
+  else a.t_io += 2 * lo;  // packed layout: (t, dt) of IVP i side by side, [N][2]
   if (a.error) a.error += lo;
   if (a.steps_io) a.steps_io += lo;
   if (a.perIvpParams) a.perIvpParams += lo;

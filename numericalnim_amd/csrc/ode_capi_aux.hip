@@ -56,6 +56,45 @@ hipError_t launch_fill_f64(double* p, int64_t n, double v, hipStream_t s) {
   return launch_kernel(fill_f64_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), s, p, n, v);
 }
 
+// ---- the tableaux the kernels are compiled with, for verification against the reference's text ----------------------------------
+// [S, NB, c_1..c_S, a_21, a_31, a_32, ..., a_S,S-1, b_1..b_NB, bHat_1..bHat_S] through Tableau<M>'s own accessors, on either side.
+template <int METHOD>
+__host__ __device__ inline int tableau_flatten(double* out) {
+  using T = Tableau<METHOD>;
+  int k = 0;
+  out[k++] = (double)T::S;
+  out[k++] = (double)T::NB;
+  for (int s = 0; s < T::S; ++s) out[k++] = T::c(s);
+  for (int s = 1; s < T::S; ++s)
+    for (int j = 0; j < s; ++j) out[k++] = T::a(s, j);
+  for (int j = 0; j < T::NB; ++j) out[k++] = T::b(j);
+  for (int j = 0; j < T::S; ++j) out[k++] = T::bhat(j);
+  return k;
+}
+template <int METHOD>
+constexpr int tableau_count() { return 2 + Tableau<METHOD>::S + Tableau<METHOD>::S * (Tableau<METHOD>::S - 1) / 2 + Tableau<METHOD>::NB + Tableau<METHOD>::S; }
+template <int METHOD>
+__global__ void tableau_dump_kernel(double* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) (void)tableau_flatten<METHOD>(out);
+}
+template <int METHOD>
+int tableau_read(int device, double* out, int cap) {
+  constexpr int n = tableau_count<METHOD>();
+  if (cap < n) return fail_msg(NNHIP_EVALUE, "nnhip_ode_tableau_f64: out has room for %d values, %d needed", cap, n);
+  if (device < 0) return tableau_flatten<METHOD>(out);
+  int prev = 0;
+  if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device) != hipSuccess) return fail_msg(NNHIP_EHIP, "nnhip_ode_tableau_f64: no HIP device %d", device);
+  double* d = nullptr;
+  hipError_t e = hipMalloc((void**)&d, sizeof(double) * n);
+  if (e == hipSuccess) e = hipMemset(d, 0xff, sizeof(double) * n);
+  if (e == hipSuccess) e = launch_kernel(tableau_dump_kernel<METHOD>, dim3(1), dim3(64), (hipStream_t) nullptr, d);
+  if (e == hipSuccess) e = hipMemcpy(out, d, sizeof(double) * n, hipMemcpyDeviceToHost);
+  if (d) (void)hipFree(d);
+  (void)hipSetDevice(prev);
+  if (e != hipSuccess) return fail_msg(NNHIP_EHIP, "nnhip_ode_tableau_f64: %s", hipGetErrorString(e));
+  return n;
+}
+
 // newHermiteSpline(X, Y, dY).eval / .derivEval over M independent series (interpolate.nim:186-217, 299-390).
 // Everything that depends only on the query point (interval, basis weights, extrapolation branch) is computed on
 // the host in the reference's expression order and shipped as a descriptor; the kernel does the per-series part.
@@ -330,6 +369,16 @@ int nnhip_ode_controller_factor_f64_dev(int order, const double* error, double* 
     default: return nnhip::fail_msg(NNHIP_EVALUE, "controller_factor: order must be 2, 3, 5 or 6 (got %d)", order);
   }
   return e == hipSuccess ? NNHIP_OK : nnhip::fail_msg(NNHIP_EHIP, "controller_factor: kernel launch failed: %s", hipGetErrorString(e));
+}
+
+int nnhip_ode_tableau_f64(int integrator, int device, double* out, int cap) {
+  if (!out) return nnhip::fail_msg(NNHIP_EVALUE, "nnhip_ode_tableau_f64: out is null");
+  switch (integrator) {
+    case NNHIP_DOPRI54: return nnhip::tableau_read<NNHIP_DOPRI54>(device, out, cap);
+    case NNHIP_TSIT54: return nnhip::tableau_read<NNHIP_TSIT54>(device, out, cap);
+    case NNHIP_VERN65: return nnhip::tableau_read<NNHIP_VERN65>(device, out, cap);
+    default: return nnhip::fail_msg(NNHIP_EINTEGRATOR, "nnhip_ode_tableau_f64: integrator %d has no tableau (its coefficients are literals of its step expression)", integrator);
+  }
 }
 
 int nnhip_ode_rhs_batch_f64_dev(int rhs_kind, const double* rhs_params, int n_params, int64_t N, int dim, int layout, double t,

@@ -52,6 +52,7 @@ namespace NNHIP_NS {
 using namespace nnhip_abi;
 
 #define NNHIP_DEV __device__ __forceinline__
+#define NNHIP_HD __host__ __device__ __forceinline__  // the tableau accessors: the host reads the same constexpr tables (nnhip_ode_tableau_f64)
 
 // Nim's system.min/max on floats: `if x <= y: x else: y` / `if y <= x: x else: y` (NaN falls through
 // to the second operand exactly as in the reference).
@@ -322,11 +323,11 @@ struct Tableau<NNHIP_DOPRI54> {  // ode.nim:240-282
   static constexpr bool DIRECT_ERR = false;  // error_y = yNew - yLow (:303)
   static constexpr int NB = 6;               // terms in yNew
   static constexpr bool B_IS_LAST_ROW = true;  // b_i = a_7i literally (:269-274): yNew == the last stage argument
-  NNHIP_DEV static double c(int s) {
+  NNHIP_HD static double c(int s) {
     constexpr double C[7] = {0.0, 1.0 / 5.0, 3.0 / 10.0, 4.0 / 5.0, 8.0 / 9.0, 1.0, 1.0};
     return C[s];
   }
-  NNHIP_DEV static double a(int s, int j) {
+  NNHIP_HD static double a(int s, int j) {
     constexpr double A[7][6] = {
         {0, 0, 0, 0, 0, 0},
         {1.0 / 5.0, 0, 0, 0, 0, 0},
@@ -337,8 +338,8 @@ struct Tableau<NNHIP_DOPRI54> {  // ode.nim:240-282
         {35.0 / 384.0, 0.0, 500.0 / 1113.0, 125.0 / 192.0, -2187.0 / 6784.0, 11.0 / 84.0}};
     return A[s][j];
   }
-  NNHIP_DEV static double b(int j) { return a(6, j); }  // b_i = a_7i (:269-274)
-  NNHIP_DEV static double bhat(int j) {
+  NNHIP_HD static double b(int j) { return a(6, j); }  // b_i = a_7i (:269-274)
+  NNHIP_HD static double bhat(int j) {
     constexpr double B[7] = {5179.0 / 57600.0, 0.0, 7571.0 / 16695.0, 393.0 / 640.0, -92097.0 / 339200.0, 187.0 / 2100.0, 1.0 / 40.0};
     return B[j];
   }
@@ -351,11 +352,11 @@ struct Tableau<NNHIP_TSIT54> {  // ode.nim:310-352
   static constexpr bool DIRECT_ERR = true;  // error_y = dt * (sum bHat_i k_i) (:372)
   static constexpr int NB = 6;
   static constexpr bool B_IS_LAST_ROW = true;  // :339-344
-  NNHIP_DEV static double c(int s) {
+  NNHIP_HD static double c(int s) {
     constexpr double C[7] = {0.0, 0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0};
     return C[s];
   }
-  NNHIP_DEV static double a(int s, int j) {
+  NNHIP_HD static double a(int s, int j) {
     constexpr double A[7][6] = {
         {0, 0, 0, 0, 0, 0},
         {0.161, 0, 0, 0, 0, 0},
@@ -366,8 +367,8 @@ struct Tableau<NNHIP_TSIT54> {  // ode.nim:310-352
         {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774}};
     return A[s][j];
   }
-  NNHIP_DEV static double b(int j) { return a(6, j); }
-  NNHIP_DEV static double bhat(int j) {
+  NNHIP_HD static double b(int j) { return a(6, j); }
+  NNHIP_HD static double bhat(int j) {
     constexpr double B[7] = {-0.001780011052226, -0.000816434459657, 0.007880878010262, -0.144711007173263,
                              0.582357165452555,  -0.458082105929187, 1.0 / 66.0};
     return B[j];
@@ -381,11 +382,11 @@ struct Tableau<NNHIP_VERN65> {  // ode.nim:380-443
   static constexpr bool DIRECT_ERR = false;     // error_y = yNew - yLow (:466)
   static constexpr int NB = 8;
   static constexpr bool B_IS_LAST_ROW = false;  // b4..b7 are separate literals (:426-433), not a9j
-  NNHIP_DEV static double c(int s) {
+  NNHIP_HD static double c(int s) {
     constexpr double C[9] = {0.0, 0.06, 0.09593333333333333, 0.1439, 0.4973, 0.9725, 0.9995, 1.0, 1.0};
     return C[s];
   }
-  NNHIP_DEV static double a(int s, int j) {
+  NNHIP_HD static double a(int s, int j) {
     constexpr double A[9][8] = {
         {0, 0, 0, 0, 0, 0, 0, 0},
         {0.06, 0, 0, 0, 0, 0, 0, 0},
@@ -398,12 +399,12 @@ struct Tableau<NNHIP_VERN65> {  // ode.nim:380-443
         {0.03438957868357036, 0.0, 0.0, 0.25826245556335037, 0.4209371189673537, 4.405396469669310, -176.48311902429865, 172.36413340141507}};
     return A[s][j];
   }
-  NNHIP_DEV static double b(int j) {
+  NNHIP_HD static double b(int j) {
     constexpr double B[8] = {0.03438957868357036, 0.0, 0.0, 0.25826245556335034, 0.42093711896735372, 4.4053964696693102,
                              -176.48311902429866, 172.36413340141507};
     return B[j];
   }
-  NNHIP_DEV static double bhat(int j) {
+  NNHIP_HD static double bhat(int j) {
     constexpr double B[9] = {0.04909967648382, 0.0, 0.0, 0.22511122295165, 0.46946822530296, 0.80657922499889, 0.0,
                              -0.60711948917780, 0.05686113944048};
     return B[j];

@@ -288,17 +288,44 @@ template <class T> static StepResult<T> BS32_step(const ODEProc<T>& f, double t,
   return {yNew, k4, dt, error};
 }
 
+// The Butcher tableaux of the three tableau methods, as name/value lists: the step procs below declare them as their constants
+// (in the reference's declaration order, ode.nim:240-282, 310-352, 380-443) and oracle_tableau() exports the very same values,
+// so that tests/test_reference_text_pin.py can compare them bit for bit with the `const` sections of the reference's text.
+#define DOPRI54_CONSTS(X) \
+  X(c2, 1.0 / 5.0) X(c3, 3.0 / 10.0) X(c4, 4.0 / 5.0) X(c5, 8.0 / 9.0) X(c6, 1.0) X(c7, 1.0) X(a21, 1.0 / 5.0) X(a31, 3.0 / 40.0) \
+  X(a32, 9.0 / 40.0) X(a41, 44.0 / 45.0) X(a42, -56.0 / 15.0) X(a43, 32.0 / 9.0) X(a51, 19372.0 / 6561.0) \
+  X(a52, -25360.0 / 2187.0) X(a53, 64448.0 / 6561.0) X(a54, -212.0 / 729.0) X(a61, 9017.0 / 3168.0) X(a62, -355.0 / 33.0) \
+  X(a63, 46732.0 / 5247.0) X(a64, 49.0 / 176.0) X(a65, -5103.0 / 18656.0) X(a71, 35.0 / 384.0) X(a72, 0.0) X(a73, 500.0 / 1113.0) \
+  X(a74, 125.0 / 192.0) X(a75, -2187.0 / 6784.0) X(a76, 11.0 / 84.0) X(b1, a71) X(b2, a72) X(b3, a73) X(b4, a74) X(b5, a75) \
+  X(b6, a76) X(bHat1, 5179.0 / 57600.0) X(bHat2, 0.0) X(bHat3, 7571.0 / 16695.0) X(bHat4, 393.0 / 640.0) \
+  X(bHat5, -92097.0 / 339200.0) X(bHat6, 187.0 / 2100.0) X(bHat7, 1.0 / 40.0)
+#define TSIT54_CONSTS(X) \
+  X(c2, 0.161) X(c3, 0.327) X(c4, 0.9) X(c5, 0.9800255409045097) X(c6, 1.0) X(c7, 1.0) X(a21, 0.161) \
+  X(a31, -0.008480655492356989) X(a32, 0.335480655492357) X(a41, 2.8971530571054935) X(a42, -6.359448489975075) \
+  X(a43, 4.3622954328695815) X(a51, 5.325864828439257) X(a52, -11.748883564062828) X(a53, 7.4955393428898365) \
+  X(a54, -0.09249506636175525) X(a61, 5.86145544294642) X(a62, -12.92096931784711) X(a63, 8.159367898576159) \
+  X(a64, -0.071584973281401) X(a65, -0.028269050394068383) X(a71, 0.09646076681806523) X(a72, 0.01) X(a73, 0.4798896504144996) \
+  X(a74, 1.379008574103742) X(a75, -3.290069515436081) X(a76, 2.324710524099774) X(b1, a71) X(b2, a72) X(b3, a73) X(b4, a74) \
+  X(b5, a75) X(b6, a76) X(bHat1, -0.001780011052226) X(bHat2, -0.000816434459657) X(bHat3, 0.007880878010262) \
+  X(bHat4, -0.144711007173263) X(bHat5, 0.582357165452555) X(bHat6, -0.458082105929187) X(bHat7, 1.0 / 66.0)
+#define VERN65_CONSTS(X) \
+  X(c2, 0.06) X(c3, 0.09593333333333333) X(c4, 0.1439) X(c5, 0.4973) X(c6, 0.9725) X(c7, 0.9995) X(c8, 1.0) X(c9, 1.0) \
+  X(a21, 0.06) X(a31, 0.019239962962962962) X(a32, 0.07669337037037037) X(a41, 0.035975) X(a42, 0.0) X(a43, 0.107925) \
+  X(a51, 1.3186834152331484) X(a52, 0.0) X(a53, -5.042058063628562) X(a54, 4.220674648395414) X(a61, -41.87259166432751) \
+  X(a62, 0.0) X(a63, 159.43256216313748) X(a64, -122.11921356501004) X(a65, 5.531743066200053) X(a71, -54.430156935316504) \
+  X(a72, 0.0) X(a73, 207.06725136501848) X(a74, -158.61081378459) X(a75, 6.991816585950242) X(a76, -0.01859723106220323) \
+  X(a81, -54.66374178728198) X(a82, 0.0) X(a83, 207.95280625538936) X(a84, -159.2889574744995) X(a85, 7.018743740796944) \
+  X(a86, -0.018338785905045722) X(a87, -0.0005119484997882099) X(a91, 0.03438957868357036) X(a92, 0.0) X(a93, 0.0) \
+  X(a94, 0.25826245556335037) X(a95, 0.4209371189673537) X(a96, 4.405396469669310) X(a97, -176.48311902429865) \
+  X(a98, 172.36413340141507) X(b1, 0.03438957868357036) X(b2, 0.0) X(b3, 0.0) X(b4, 0.25826245556335034) \
+  X(b5, 0.42093711896735372) X(b6, 4.4053964696693102) X(b7, -176.48311902429866) X(b8, 172.36413340141507) \
+  X(bHat1, 0.04909967648382) X(bHat2, 0.0) X(bHat3, 0.0) X(bHat4, 0.22511122295165) X(bHat5, 0.46946822530296) \
+  X(bHat6, 0.80657922499889) X(bHat7, 0.0) X(bHat8, -0.60711948917780) X(bHat9, 0.05686113944048)
+
 template <class T> static StepResult<T> DOPRI54_step(const ODEProc<T>& f, double t, const T& y, const T& FSAL, double dt_in, const ODEoptions& options) {  // :237-305
-  constexpr double c2 = 1.0 / 5.0, c3 = 3.0 / 10.0, c4 = 4.0 / 5.0, c5 = 8.0 / 9.0, c6 = 1.0, c7 = 1.0;
-  constexpr double a21 = 1.0 / 5.0;
-  constexpr double a31 = 3.0 / 40.0, a32 = 9.0 / 40.0;
-  constexpr double a41 = 44.0 / 45.0, a42 = -56.0 / 15.0, a43 = 32.0 / 9.0;
-  constexpr double a51 = 19372.0 / 6561.0, a52 = -25360.0 / 2187.0, a53 = 64448.0 / 6561.0, a54 = -212.0 / 729.0;
-  constexpr double a61 = 9017.0 / 3168.0, a62 = -355.0 / 33.0, a63 = 46732.0 / 5247.0, a64 = 49.0 / 176.0, a65 = -5103.0 / 18656.0;
-  constexpr double a71 = 35.0 / 384.0, a72 = 0.0, a73 = 500.0 / 1113.0, a74 = 125.0 / 192.0, a75 = -2187.0 / 6784.0, a76 = 11.0 / 84.0;
-  constexpr double b1 = a71, b2 = a72, b3 = a73, b4 = a74, b5 = a75, b6 = a76;
-  constexpr double bHat1 = 5179.0 / 57600.0, bHat2 = 0.0, bHat3 = 7571.0 / 16695.0, bHat4 = 393.0 / 640.0,
-                   bHat5 = -92097.0 / 339200.0, bHat6 = 187.0 / 2100.0, bHat7 = 1.0 / 40.0;
+#define X(n, v) constexpr double n = v;
+  DOPRI54_CONSTS(X)
+#undef X
   const double absTol = options.absTol, relTol = options.relTol, dtMax = options.dtMax, dtMin = options.dtMin;
   T k1, k2, k3, k4, k5, k6, k7, yNew, yLow;
   double error = 0.0; int limitCounter = 0; double dt = dt_in;
@@ -319,16 +346,9 @@ template <class T> static StepResult<T> DOPRI54_step(const ODEProc<T>& f, double
 }
 
 template <class T> static StepResult<T> TSIT54_step(const ODEProc<T>& f, double t, const T& y, const T& FSAL, double dt_in, const ODEoptions& options) {  // :307-374
-  constexpr double c2 = 0.161, c3 = 0.327, c4 = 0.9, c5 = 0.9800255409045097, c6 = 1.0, c7 = 1.0;
-  constexpr double a21 = 0.161;
-  constexpr double a31 = -0.008480655492356989, a32 = 0.335480655492357;
-  constexpr double a41 = 2.8971530571054935, a42 = -6.359448489975075, a43 = 4.3622954328695815;
-  constexpr double a51 = 5.325864828439257, a52 = -11.748883564062828, a53 = 7.4955393428898365, a54 = -0.09249506636175525;
-  constexpr double a61 = 5.86145544294642, a62 = -12.92096931784711, a63 = 8.159367898576159, a64 = -0.071584973281401, a65 = -0.028269050394068383;
-  constexpr double a71 = 0.09646076681806523, a72 = 0.01, a73 = 0.4798896504144996, a74 = 1.379008574103742, a75 = -3.290069515436081, a76 = 2.324710524099774;
-  constexpr double b1 = a71, b2 = a72, b3 = a73, b4 = a74, b5 = a75, b6 = a76;
-  constexpr double bHat1 = -0.001780011052226, bHat2 = -0.000816434459657, bHat3 = 0.007880878010262, bHat4 = -0.144711007173263,
-                   bHat5 = 0.582357165452555, bHat6 = -0.458082105929187, bHat7 = 1.0 / 66.0;
+#define X(n, v) constexpr double n = v;
+  TSIT54_CONSTS(X)
+#undef X
   const double absTol = options.absTol, relTol = options.relTol, dtMax = options.dtMax, dtMin = options.dtMin;
   T k1, k2, k3, k4, k5, k6, k7, yNew;
   double error = 0.0; int limitCounter = 0; double dt = dt_in;
@@ -348,17 +368,9 @@ template <class T> static StepResult<T> TSIT54_step(const ODEProc<T>& f, double 
 }
 
 template <class T> static StepResult<T> VERN65_step(const ODEProc<T>& f, double t, const T& y, const T& FSAL, double dt_in, const ODEoptions& options) {  // :377-468
-  constexpr double c2 = 0.06, c3 = 0.09593333333333333, c4 = 0.1439, c5 = 0.4973, c6 = 0.9725, c7 = 0.9995, c8 = 1.0, c9 = 1.0;
-  constexpr double a21 = 0.06;
-  constexpr double a31 = 0.019239962962962962, a32 = 0.07669337037037037;
-  constexpr double a41 = 0.035975, a42 = 0.0, a43 = 0.107925;
-  constexpr double a51 = 1.3186834152331484, a52 = 0.0, a53 = -5.042058063628562, a54 = 4.220674648395414;
-  constexpr double a61 = -41.87259166432751, a62 = 0.0, a63 = 159.43256216313748, a64 = -122.11921356501004, a65 = 5.531743066200053;
-  constexpr double a71 = -54.430156935316504, a72 = 0.0, a73 = 207.06725136501848, a74 = -158.61081378459, a75 = 6.991816585950242, a76 = -0.01859723106220323;
-  constexpr double a81 = -54.66374178728198, a82 = 0.0, a83 = 207.95280625538936, a84 = -159.2889574744995, a85 = 7.018743740796944, a86 = -0.018338785905045722, a87 = -0.0005119484997882099;
-  constexpr double a91 = 0.03438957868357036, a92 = 0.0, a93 = 0.0, a94 = 0.25826245556335037, a95 = 0.4209371189673537, a96 = 4.405396469669310, a97 = -176.48311902429865, a98 = 172.36413340141507;
-  constexpr double b1 = 0.03438957868357036, b2 = 0.0, b3 = 0.0, b4 = 0.25826245556335034, b5 = 0.42093711896735372, b6 = 4.4053964696693102, b7 = -176.48311902429866, b8 = 172.36413340141507;
-  constexpr double bHat1 = 0.04909967648382, bHat2 = 0.0, bHat3 = 0.0, bHat4 = 0.22511122295165, bHat5 = 0.46946822530296, bHat6 = 0.80657922499889, bHat7 = 0.0, bHat8 = -0.60711948917780, bHat9 = 0.05686113944048;
+#define X(n, v) constexpr double n = v;
+  VERN65_CONSTS(X)
+#undef X
   const double absTol = options.absTol, relTol = options.relTol, dtMax = options.dtMax, dtMin = options.dtMin;
   T k1, k2, k3, k4, k5, k6, k7, k8, k9, yNew, yLow;
   double error = 0.0; int limitCounter = 0; double dt = dt_in;
@@ -765,6 +777,30 @@ int oracle_new_options(oracle_options* out, double dt, double absTol, double rel
 int oracle_integrator_id(const char* name) {
   const oracle::Method* m = oracle::methodByName(name);
   return m ? m->id : -2;
+}
+
+// The constants the tableau step procs above are compiled with, in declaration order: `names` receives them '\n'-separated, `values`
+// their values.  Returns the count (or -1: not a tableau method, -2: buffers too small).  For tests/test_reference_text_pin.py.
+int oracle_tableau(const char* integrator, char* names, int names_cap, double* values, int values_cap) {
+  struct Entry { const char* name; double value; };
+  std::vector<Entry> e;
+  const oracle::Method* m = oracle::methodByName(integrator);
+  if (!m) return -1;
+  const std::string nm = m->name;
+#define X(n, v) constexpr double n = v;
+#define Y(n, v) e.push_back({#n, n});
+  if (nm == "dopri54") { DOPRI54_CONSTS(X) DOPRI54_CONSTS(Y) }
+  else if (nm == "tsit54") { TSIT54_CONSTS(X) TSIT54_CONSTS(Y) }
+  else if (nm == "vern65") { VERN65_CONSTS(X) VERN65_CONSTS(Y) }
+  else return -1;
+#undef X
+#undef Y
+  std::string joined;
+  for (size_t i = 0; i < e.size(); ++i) { if (i) joined += '\n'; joined += e[i].name; }
+  if ((int)joined.size() + 1 > names_cap || (int)e.size() > values_cap) return -2;
+  std::memcpy(names, joined.c_str(), joined.size() + 1);
+  for (size_t i = 0; i < e.size(); ++i) values[i] = e[i].value;
+  return (int)e.size();
 }
 
 // One IVP. dim == 0 → scalar `float` state path (T = float); dim >= 1 → Vector[float] path of that length.

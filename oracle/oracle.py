@@ -280,3 +280,16 @@ def vector_op(op, a, b=None, d=0.0):
     if n == -1:
         raise ValueError("Vectors must have the same size.")
     return out[:n].copy()
+
+
+def tableau(integrator):
+    """The constants the oracle's DOPRI54 / TSIT54 / VERN65 step procs are compiled with, in declaration order: [(name, value)]."""
+    f = lib().oracle_tableau
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.c_int]
+    names = C.create_string_buffer(4096)
+    vals = np.empty(128, dtype=np.float64)
+    n = f(integrator.encode(), names, 4096, _dp(vals), 128)
+    if n < 0:
+        raise ValueError(f"{integrator} has no tableau")
+    return list(zip(names.value.decode().split("\n"), vals[:n].tolist()))

@@ -568,6 +568,46 @@ def test_adaptive_stream_fsal_carried_or_reevaluated(nn, dev, mode):
     assert L.nnhip_tune_set(b"adv_recompute_fsal", 2) != 0 and L.nnhip_tune_set(b"adv_recompute_fsal", -2) != 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("split", [2, 4])
+def test_adaptive_stream_split_ranges(nn, dev, split):
+    """Tuning knob "adv_split": the streaming loop cut into 2 or 4 index ranges on separate streams.  Range r >= 1 must address ITS slice
+    of the packed (t, dt) pairs (t_io advanced by two doubles per IVP, dt_io staying null) as well as of the two-column layout an
+    8-byte-aligned workspace falls back to — same bits as the fused solve either way (ode.nim:525-541 per IVP)."""
+    import ctypes as C
+    import torch
+    L = nn._lib.lib()
+    assert L.nnhip_tune_set(b"adv_split", split) == 0
+    try:
+        n = 3001
+        yt = torch.from_numpy(_lorenz_y0(n)).to(dev)
+        opt = nn.newODEoptions(absTol=1e-6, relTol=1e-6, dtMin=1e-9, dtMax=1.0)
+        for integ in ("dopri54", "tsit54", "bs32"):
+            yf = nn.solveODE(nn.Rhs.lorenz(), yt, [0.0, 1.25], opt, integrator=integ)[1][-1]
+            ys, launches = nn.adaptiveStream(nn.Rhs.lorenz(), yt.clone(), 0.0, 1.25, opt, integrator=integ, check_every=3)
+            assert torch.equal(ys, yf), integ
+        y0 = _ring_y0(777, 16)
+        yl = torch.from_numpy(y0).to(dev)
+        o2 = nn.newODEoptions(absTol=1e-8, relTol=1e-8, dtMin=1e-7, dtMax=0.25)
+        yf = nn.solveODE(nn.Rhs.ring(0.1), yl, [0.0, 1.0], o2, integrator="tsit54")[1][-1]
+        ys, launches = nn.adaptiveStream(nn.Rhs.ring(0.1), yl.clone(), 0.0, 1.0, o2, integrator="tsit54", check_every=4)
+        assert torch.equal(ys, yf)
+        # two-column (t, dt): a workspace at an odd multiple of 8 bytes
+        yf = nn.solveODE(nn.Rhs.lorenz(), yt, [0.0, 1.0], opt, integrator="dopri54")[1][-1]
+        wsb = int(L.nnhip_ode_adaptive_stream_workspace_bytes(n, 3))
+        ws = torch.empty(wsb + 16, dtype=torch.uint8, device=dev)
+        y = yt.clone()
+        nl = C.c_int64(0)
+        p = (C.c_double * 3)(10.0, 28.0, 8.0 / 3.0)
+        rc = L.nnhip_ode_adaptive_stream_f64_dev(C.byref(opt), nn.ode.integrator_id("dopri54"), nn.Rhs.lorenz().kind, p, 3, n, 3, 0, 0.0, 1.0, y.data_ptr(),
+                                                 ws.data_ptr() + 8, wsb, 4, 0, C.byref(nl), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, nn._lib.last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(y, yf)
+    finally:
+        assert L.nnhip_tune_set(b"adv_split", 0) == 0
+
+
 def test_adaptive_stream_edge_shapes(nn, dev):
     """The streaming drivers at the edges of their index arithmetic: one IVP, odd batch sizes (the (t, dt) pairs and the 16-byte state accesses
     must not assume an even N), a scalar state, one launch per polling group, an empty integration span, and a launch limit of one —

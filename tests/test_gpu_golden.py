@@ -5,7 +5,13 @@ step counts."""
 import numpy as np
 import pytest
 
+import json
+import os
+
 from golden_util import fh, load_cases
+
+# what the REFERENCE'S OWN TEXT returns on the same inputs (tests/golden/make_reference_text_vectors.py; oracle/nim_subset.py)
+_REFTEXT = {c["name"]: c for c in json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_text_vectors.json")))["cases"]}
 
 pytestmark = pytest.mark.gpu
 TOL_FIXED, TOL_ADAPTIVE = 1e-10, 1e-6
@@ -39,6 +45,8 @@ def test_hip_matches_golden(nn, dev, case, layout):
     t, y, cnt = nn.solveODE(_rhs(nn, case["rhs_kind"], fh(case["params"])), y0t, fh(case["tspan"]), opt,
                             integrator=case["integrator"], layout=layout, return_counts=True)
     assert np.array_equal(t, fh(case["t"]))
+    reftext = _REFTEXT[case["name"]]
+    assert [float(v).hex() for v in t] == reftext["t"]
     got = y.cpu().numpy()
     ny, steps, rej = (cnt[k].cpu().numpy() for k in ("ny", "steps", "rejected"))
     for i, exp in enumerate(case["ivps"]):
@@ -53,6 +61,8 @@ def test_hip_matches_golden(nn, dev, case, layout):
         gi = g.reshape(len(t), -1)
         assert np.isnan(gi[exp["n_y"]:]).all()
         gi = gi[:exp["n_y"]]
+        # the HIP path against the reference's text directly (no oracle in between): rows returned and every bit of them
+        assert reftext["ivps"][i]["n_y"] == ny[i] and [float(v).hex() for v in gi.ravel()] == reftext["ivps"][i]["y"], "differs from the reference's text"
         if case["integrator"] in FIXED:
             assert np.abs(gi - want).max() <= TOL_FIXED
             assert np.array_equal(gi, want), "fixed-step results must be bit-exact"
