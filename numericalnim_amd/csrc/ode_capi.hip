@@ -551,8 +551,8 @@ int nnhip_ode_supported(int integrator, int rhs_kind, int dim, int layout, int m
 }
 
 int64_t nnhip_ode_solve_workspace_bytes(int n_t) {
-  const int64_t n = n_t < 0 ? 0 : n_t;
-  return (n + 8) * (int64_t)sizeof(double) + 8 * (int64_t)sizeof(unsigned long long);
+  const int64_t n = n_t < 0 ? 0 : n_t;  // requested times + the fixed-step emission schedule (4 weights and a step index per row)
+  return (6 * n + 8) * (int64_t)sizeof(double) + 8 * (int64_t)sizeof(unsigned long long);
 }
 
 // ---- fused solve ---------------------------------------------------------------------------------
@@ -616,44 +616,78 @@ static int prepare_solve(const nnhip_ode_options* opt, int integrator, int rhs_k
   a.perIvpStride = N;
   a.uniformFull[0] = a.uniformFull[1] = -1;
   a.nTail[0] = a.nTail[1] = 0;
-  if (!adaptive && !a.useDense) {
-    // Replay ODESolver's fixed-step time loop on the host (same IEEE double operations, ode.nim:511,525,532): it does not
-    // depend on the state, so the device loop needs no `tEnd - t` / compare / select per step.
+  a.emitW[0] = a.emitW[1] = nullptr; a.emitStep[0] = a.emitStep[1] = nullptr; a.nEmit[0] = a.nEmit[1] = 0;
+  std::vector<double> emitW[2];
+  std::vector<int64_t> emitStep[2];
+  if (!adaptive) {
+    // Replay ODESolver's fixed-step time loop on the host (same IEEE double operations, ode.nim:511-532): it does not depend on the
+    // state, so the device loop needs no `tEnd - t` / compare / select per step — and, with dense output, no `tReq <= t` test, no
+    // per-step lastIter copy and no per-lane Hermite weights either: the step at whose start each requested row is interpolated and the
+    // four weights of utils.nim:273-279 come out of the same replay (DriveIn::emitStep / emitW).
     const double tS[2] = {opt->tStart, -opt->tStart}, tE[2] = {g.tEndPos, g.tEndNeg};
     const bool have[2] = {a.nPos > 0, a.nNeg > 0};
     for (int dir = 0; dir < 2; ++dir) {
       if (!have[dir]) { a.uniformFull[dir] = 0; continue; }
       if (!((tE[dir] - tS[dir]) / opt->dt < 5e7)) continue;  // keep the replay itself negligible; generic path otherwise
-      double t = tS[dir], dt = opt->dt;
+      const std::vector<double>& req = dir == 0 ? g.tPos : g.tNeg;
+      const int high = (int)req.size() - 1;
+      double t = tS[dir], dt = opt->dt, lastT = tS[dir];
       int64_t full = 0, total = 0;
-      int nTail = 0;
+      int nTail = 0, denseIndex = 0;
       bool ok = true;
-      while (t < tE[dir]) {
+      while (t < tE[dir]) {  // :511
         if (max_steps > 0 && total >= max_steps) break;
-        const double dtc = nmin_h(dt, tE[dir] - t);
+        if (a.useDense) {      // :512-524
+          if (high < denseIndex) break;
+          while ((dir == 0 ? req[denseIndex] : -req[denseIndex]) <= t) {
+            if (total == 0) { ok = false; break; }  // (a requested time at or before the start of the first step: cannot happen, tPositive > t0)
+            const nnhip::HermiteW w = nnhip::hermite_weights(dir == 0 ? req[denseIndex] : -req[denseIndex], lastT, t);
+            emitW[dir].insert(emitW[dir].end(), {w.h00, w.h10w, w.h01, w.h11w});
+            emitStep[dir].push_back(total);
+            denseIndex += 1;
+            if (high < denseIndex) break;
+          }
+          if (!ok) break;
+        }
+        const double dtc = nmin_h(dt, tE[dir] - t);  // :525
+        lastT = t;                                   // :526-530
         if (nTail == 0 && dtc == opt->dt) ++full;
         else if (nTail < 4) a.tailDt[dir][nTail++] = dtc;
         else { ok = false; break; }
         dt = dtc;  // fixed-step steppers hand their input dt back (ode.nim:189): a clipped dt persists
-        t += dtc;
+        t += dtc;  // :532
         ++total;
       }
-      if (ok) { a.uniformFull[dir] = full; a.nTail[dir] = nTail; }
+      if (ok) { a.uniformFull[dir] = full; a.nTail[dir] = nTail; a.nEmit[dir] = (int)emitStep[dir].size(); }
+      else { emitW[dir].clear(); emitStep[dir].clear(); }
     }
   }
   a.tPos = nullptr; a.tNeg = nullptr;
   if (N > 0 && a.useDense && (a.nPos + a.nNeg) > 0) {
     const size_t n = (size_t)a.nPos + (size_t)a.nNeg;
-    if (!ws || ws_bytes < (int64_t)(n * sizeof(double))) return fail(NNHIP_EVALUE, "workspace too small: need %zu bytes", n * sizeof(double));
-    rc = stage_reserve(n);
+    const size_t nE = (size_t)a.nEmit[0] + (size_t)a.nEmit[1];
+    const size_t words = n + 5 * nE;  // [tPos][tNeg][weights fwd][weights bwd][step indices fwd][step indices bwd]
+    if (!ws || ws_bytes < (int64_t)(words * sizeof(double))) return fail(NNHIP_EVALUE, "workspace too small: need %zu bytes (nnhip_ode_solve_workspace_bytes)", words * sizeof(double));
+    rc = stage_reserve(words);
     if (rc) return rc;
     std::copy(g.tPos.begin(), g.tPos.end(), g_stage.host);
     std::copy(g.tNeg.begin(), g.tNeg.end(), g_stage.host + a.nPos);
-    HIP_TRY(hipMemcpyAsync(ws, g_stage.host, n * sizeof(double), hipMemcpyHostToDevice, stream));
+    double* hw = g_stage.host + n;
+    std::copy(emitW[0].begin(), emitW[0].end(), hw);
+    std::copy(emitW[1].begin(), emitW[1].end(), hw + 4 * (size_t)a.nEmit[0]);
+    static_assert(sizeof(int64_t) == sizeof(double), "step indices share the staging buffer");
+    if (nE) {
+      std::memcpy(hw + 4 * nE, emitStep[0].data(), sizeof(int64_t) * emitStep[0].size());
+      std::memcpy(hw + 4 * nE + a.nEmit[0], emitStep[1].data(), sizeof(int64_t) * emitStep[1].size());
+    }
+    HIP_TRY(hipMemcpyAsync(ws, g_stage.host, words * sizeof(double), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(g_stage.ev, stream));
     g_stage.pending = true;
     a.tPos = (const double*)ws;
     a.tNeg = (const double*)ws + a.nPos;
+    const double* dw = (const double*)ws + n;
+    a.emitW[0] = dw; a.emitW[1] = dw + 4 * (size_t)a.nEmit[0];
+    a.emitStep[0] = (const int64_t*)(dw + 4 * nE); a.emitStep[1] = a.emitStep[0] + a.nEmit[0];
   }
   return NNHIP_OK;
 }

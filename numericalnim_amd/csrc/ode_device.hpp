@@ -747,11 +747,19 @@ NNHIP_DEV int embedded_step(const Ops& ops, double t, double& dt, const double (
   return status;
 }
 
+// A value that is the same in every lane, moved to scalar registers (loop bounds loaded after a vector store come back in VGPRs: the scalar
+// cache is not coherent with them, so the compiler may not use s_load — and would then compare per lane).
+NNHIP_DEV int64_t uniform_i64(int64_t v) {
+  const int lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v & 0xffffffffu));
+  const int hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
+}
+
 // hermiteSpline per component (utils.nim:273-279)
 struct HermiteW {
   double h00, h10w, h01, h11w;  // h10*(x2-x1), h11*(x2-x1) pre-multiplied exactly as the expression does
 };
-NNHIP_DEV HermiteW hermite_weights(double x, double x1, double x2) {
+NNHIP_HD HermiteW hermite_weights(double x, double x1, double x2) {  // (host too: the fixed-step emission schedule is replayed there)
   const double t = (x - x1) / (x2 - x1);
   const double omt = 1.0 - t;
   HermiteW w;
@@ -786,6 +794,12 @@ struct DriveIn {
   int64_t uniformFull;
   int nTail;
   double tailDt[4];
+  // ... and, with dense output, the emission block of that replay (ode.nim:512-524): requested row k < nEmit is interpolated at the START of
+  // step emitStep[k] (non-decreasing) between the states before and after step emitStep[k] - 1, with the Hermite weights emitW[4k .. 4k+3]
+  // = (h00, h10*(x2-x1), h01, h11*(x2-x1)) of utils.nim:273-279 — times, step indices and weights are the same for every IVP of the batch.
+  const double* emitW;
+  const int64_t* emitStep;
+  int nEmit;
 };
 struct DriveOut {
   int emitted;
@@ -827,26 +841,79 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
   int status = 0;
   int64_t steps = 0, rejected = 0;
   if constexpr (!MT::adaptive) {
-    if (in.uniformFull >= 0) {  // pre-computed schedule: the loop carries no FP64 bookkeeping besides t itself
-      for (int64_t n = 0; n < in.uniformFull; ++n) {
-        if constexpr (METHOD == NNHIP_RK4) rk4_step(ops, t, h4, y, yNew);
-        else fixed_step<METHOD>(ops, t, dt, y, yNew);
-#pragma unroll
-        for (int c = 0; c < D; ++c) y[c] = yNew[c];
-        t += dt;
+    if (in.uniformFull >= 0 && (!DENSE || !in.useDense || !Ops::mutates)) {
+      // Pre-computed schedule: the loop carries no FP64 bookkeeping besides t itself.  With dense output the emission block is scheduled
+      // too: scalar comparisons of the step counter decide when a row is due; the state before the step is kept only across steps whose
+      // end is interpolated, and lastIter.dy / f(t, y) (:521, :530) are evaluated only there — the same calls on the same arguments as the
+      // general loop below makes, hence the same bits.  (A right-hand side that mutates its ctx takes the general loop: it must see every
+      // evaluation the reference makes, where it makes it.)
+      [[maybe_unused]] int ek = 0;
+      [[maybe_unused]] int64_t nextEmit = -1;
+      [[maybe_unused]] double yPrev[DH], tPrev = t;
+      const int64_t total = in.uniformFull + in.nTail;
+      if constexpr (DENSE) {
+        if (in.useDense && in.nEmit > 0) nextEmit = uniform_i64(in.emitStep[0]);
       }
-      for (int k = 0; k < in.nTail; ++k) {
-        const double dk = k == 0 ? in.tailDt[0] : k == 1 ? in.tailDt[1] : k == 2 ? in.tailDt[2] : in.tailDt[3];  // (selects: indexing by k put the whole DriveIn in scratch, 136 B per lane)
-        if constexpr (METHOD == NNHIP_RK4) rk4_step(ops, t, rk4_dt(dk), y, yNew);
-        else fixed_step<METHOD>(ops, t, dk, y, yNew);
+      // The steps run in segments that end where something other than a plain step is due, so that the step loops themselves are the lean
+      // ones (every VALU instruction added to a scalar RK4 step costs 6 % of the solve): first up to the step BEFORE the next scheduled
+      // row (`stop` = its index), whose start is kept; then that one step; then the rows due at its end.  One copy of the loops serves all.
+      int64_t n = 0, stop = nextEmit >= 0 ? nextEmit - 1 : total;
+      [[maybe_unused]] bool startKept = false;
+      for (;;) {
+        // (trip counts compared with != : the scalar ALU has no ordered 64-bit compare, `n < stop` would be a VALU instruction per step)
+        const int64_t stopU = stop < in.uniformFull ? stop : in.uniformFull;
+        if (n < stopU) {
+          for (int64_t k = stopU - n; k != 0; --k) {
+            if constexpr (METHOD == NNHIP_RK4) rk4_step(ops, t, h4, y, yNew);
+            else fixed_step<METHOD>(ops, t, dt, y, yNew);
 #pragma unroll
-        for (int c = 0; c < D; ++c) y[c] = yNew[c];
-        t += dk;
+            for (int c = 0; c < D; ++c) y[c] = yNew[c];
+            t += dt;
+          }
+          n = stopU;
+        }
+        if (n < stop) {
+          for (int k = (int)(n - in.uniformFull), kEnd = (int)(stop - in.uniformFull); k != kEnd; ++k) {
+            const double dk = k == 0 ? in.tailDt[0] : k == 1 ? in.tailDt[1] : k == 2 ? in.tailDt[2] : in.tailDt[3];  // (selects: indexing by k put the whole DriveIn in scratch, 136 B per lane)
+            if constexpr (METHOD == NNHIP_RK4) rk4_step(ops, t, rk4_dt(dk), y, yNew);
+            else fixed_step<METHOD>(ops, t, dk, y, yNew);
+#pragma unroll
+            for (int c = 0; c < D; ++c) y[c] = yNew[c];
+            t += dk;
+          }
+          n = stop;
+        }
+        if (nextEmit < 0) break;  // n == total
+        if constexpr (DENSE) {
+          if (!startKept) {  // n == nextEmit - 1: the step about to be taken ends where a row is due
+            tPrev = t;
+#pragma unroll
+            for (int c = 0; c < D; ++c) yPrev[c] = y[c];
+            startKept = true;
+            stop = nextEmit;
+            continue;
+          }
+          ops.rhs(tPrev, yPrev, lastDy);  // lastIter.dy (:530)
+          ops.rhs(t, y, dyNow);           // f(t, y, ctx) (:521)
+          do {
+            HermiteW w;
+            w.h00 = in.emitW[4 * ek + 0]; w.h10w = in.emitW[4 * ek + 1]; w.h01 = in.emitW[4 * ek + 2]; w.h11w = in.emitW[4 * ek + 3];
+            double yv[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) yv[c] = hermite_apply(w, yPrev[c], y[c], lastDy[c], dyNow[c]);
+            emit(ek, yv);
+            ek += 1;
+            nextEmit = ek < in.nEmit ? uniform_i64(in.emitStep[ek]) : -1;
+          } while (nextEmit == n);
+          startKept = false;
+          stop = nextEmit >= 0 ? nextEmit - 1 : total;
+        }
       }
-      emit(0, y);  // yPositive.add(y) / yNegative.add(y) (:542,:584)
-      out.emitted = 1;
-      out.status = (in.maxSteps > 0 && in.uniformFull + in.nTail >= in.maxSteps && t < in.tEnd) ? 2 : 0;
-      out.steps = in.uniformFull + in.nTail;
+      emit(ek, y);  // yPositive.add(y) / yNegative.add(y) (:542,:584), after whatever was emitted
+      out.emitted = ek + 1;
+      if constexpr (DENSE) out.status = (in.useDense ? (in.maxSteps > 0 && total >= in.maxSteps) : (in.maxSteps > 0 && total >= in.maxSteps && t < in.tEnd)) ? 2 : 0;
+      else out.status = (in.maxSteps > 0 && total >= in.maxSteps && t < in.tEnd) ? 2 : 0;
+      out.steps = total;
       out.rejected = 0;
       out.tFinal = t;
       return;

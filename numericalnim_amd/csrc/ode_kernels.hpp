@@ -52,6 +52,10 @@ struct SolveArgs {
   int64_t uniformFull[2];
   int nTail[2];
   double tailDt[2][4];
+  // ... and the emission block of that replay when there is dense output (device arrays in the workspace; see DriveIn)
+  const double* emitW[2];
+  const int64_t* emitStep[2];
+  int nEmit[2];
   // Order of integration (divergence binning): nullable device array [N]; work item k integrates IVP perm[k].  Every per-IVP
   // array (y0, y_out, counters, per-IVP parameters) is still addressed by the IVP's own index, so results land in the caller's
   // order without an un-permute pass; neighbouring lanes then hold IVPs with similar step sequences.
@@ -179,7 +183,7 @@ template <int METHOD, int MODE = 1, class OpsF, class OpsB>
 NNHIP_DEV void solve_body(const SolveArgs& a0, const OpsF& opsF, const OpsB& opsB, const double* y0p, double* out, LaneStats& ls, int64_t ivp) {
   // the direction bookkeeping of this IVP: the batch-wide one, or its own 2-point tspan
   struct Dir { int nPos, nNeg, nZero, n_t, useDense; double t0, tEndPos, tEndNeg, dtInit; int64_t rowStride, compStride, maxSteps; const double *tPos, *tNeg;
-               StepCtl ctl; int64_t uniformFull[2]; int nTail[2]; double tailDt[2][4]; };
+               StepCtl ctl; int64_t uniformFull[2]; int nTail[2]; double tailDt[2][4]; const double* emitW[2]; const int64_t* emitStep[2]; int nEmit[2]; };
   Dir a;
   a.nPos = a0.nPos; a.nNeg = a0.nNeg; a.nZero = a0.nZero; a.n_t = a0.n_t; a.useDense = a0.useDense; a.t0 = a0.t0; a.tEndPos = a0.tEndPos;
   a.tEndNeg = a0.tEndNeg; a.dtInit = a0.dtInit; a.rowStride = a0.rowStride; a.compStride = a0.compStride; a.maxSteps = a0.maxSteps;
@@ -187,6 +191,7 @@ NNHIP_DEV void solve_body(const SolveArgs& a0, const OpsF& opsF, const OpsB& ops
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
     a.uniformFull[d] = a0.uniformFull[d]; a.nTail[d] = a0.nTail[d];
+    a.emitW[d] = a0.emitW[d]; a.emitStep[d] = a0.emitStep[d]; a.nEmit[d] = a0.nEmit[d];
 #pragma unroll
     for (int q = 0; q < 4; ++q) a.tailDt[d][q] = a0.tailDt[d][q];
   }
@@ -265,6 +270,7 @@ NNHIP_DEV void solve_body(const SolveArgs& a0, const OpsF& opsF, const OpsB& ops
     in.nReq = a.nPos;
     in.uniformFull = a.uniformFull[0];
     in.nTail = a.nTail[0];
+    in.emitW = a.emitW[0]; in.emitStep = a.emitStep[0]; in.nEmit = a.nEmit[0];
 #pragma unroll
     for (int q = 0; q < 4; ++q) in.tailDt[q] = a.tailDt[0][q];
     DriveOut o;
@@ -294,6 +300,7 @@ NNHIP_DEV void solve_body(const SolveArgs& a0, const OpsF& opsF, const OpsB& ops
     in.nReq = a.nNeg;
     in.uniformFull = a.uniformFull[1];
     in.nTail = a.nTail[1];
+    in.emitW = a.emitW[1]; in.emitStep = a.emitStep[1]; in.nEmit = a.nEmit[1];
 #pragma unroll
     for (int q = 0; q < 4; ++q) in.tailDt[q] = a.tailDt[1][q];
     DriveOut o;

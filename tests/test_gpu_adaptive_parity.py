@@ -587,10 +587,10 @@ def test_adaptive_stream_split_ranges(nn, dev, split):
             ys, launches = nn.adaptiveStream(nn.Rhs.lorenz(), yt.clone(), 0.0, 1.25, opt, integrator=integ, check_every=3)
             assert torch.equal(ys, yf), integ
         y0 = _ring_y0(777, 16)
-        yl = torch.from_numpy(y0).to(dev)
+        yl = torch.from_numpy(y0).to(dev)  # [n, dim]: AoS
         o2 = nn.newODEoptions(absTol=1e-8, relTol=1e-8, dtMin=1e-7, dtMax=0.25)
-        yf = nn.solveODE(nn.Rhs.ring(0.1), yl, [0.0, 1.0], o2, integrator="tsit54")[1][-1]
-        ys, launches = nn.adaptiveStream(nn.Rhs.ring(0.1), yl.clone(), 0.0, 1.0, o2, integrator="tsit54", check_every=4)
+        yf = nn.solveODE(nn.Rhs.ring(0.1), yl, [0.0, 1.0], o2, integrator="tsit54", layout=1)[1][-1]
+        ys, launches = nn.adaptiveStream(nn.Rhs.ring(0.1), yl.clone(), 0.0, 1.0, o2, integrator="tsit54", layout=1, check_every=4)
         assert torch.equal(ys, yf)
         # two-column (t, dt): a workspace at an odd multiple of 8 bytes
         yf = nn.solveODE(nn.Rhs.lorenz(), yt, [0.0, 1.0], opt, integrator="dopri54")[1][-1]
