@@ -238,6 +238,34 @@ NNHIP_DEV double lane_rotate(double v) {
   return __hiloint2double(hi, lo);
 }
 
+// value of `v` in the LAST lane of this lane's group of L consecutive lanes
+template <int L>
+NNHIP_DEV double lane_last(double v) {
+  static_assert(L >= 1 && L <= 64 && (L & (L - 1)) == 0, "group size must be a power of two");
+  if constexpr (L == 1) return v;
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  if constexpr (L == 2) {         // quad_perm [1,1,3,3]
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0xF5, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0xF5, 0xf, 0xf, false);
+  } else if constexpr (L == 4) {  // quad_perm [3,3,3,3]
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0xFF, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0xFF, 0xf, 0xf, false);
+  } else {                        // ds_bpermute (crossbar only, no LDS memory)
+    const int src = ((int)(threadIdx.x & 63)) | (L - 1);
+    lo = __builtin_amdgcn_ds_bpermute(src << 2, lo);
+    hi = __builtin_amdgcn_ds_bpermute(src << 2, hi);
+  }
+  return __hiloint2double(hi, lo);
+}
+
+// The ordered register chain of LpsOps::norm costs L - 1 lane hops on top of the DIM dependent additions every variant has; it replaces an LDS
+// write, two wave syncs and DIM LDS reads per lane.  Systems of up to NNHIP_LPS_CHAIN_MAX_L lanes use it (measured: profiles/r04_norm_chain_ab.json).
+#ifndef NNHIP_LPS_CHAIN_MAX_L
+#define NNHIP_LPS_CHAIN_MAX_L 4
+#endif
+template <int L>
+constexpr bool lps_chain_norm() { return L <= NNHIP_LPS_CHAIN_MAX_L; }
+
 template <class RHS, bool NEG, int CPL = 1, bool SHUFFLE_NORM = false>
 struct LpsOps {
   static constexpr bool mutates = RhsMutates<RHS>::value;
@@ -282,11 +310,12 @@ struct LpsOps {
     wave_lds_sync();  // the next stage overwrites ys
   }
   NNHIP_DEV double norm(const double (&yNew)[CPL], const double (&err_y)[CPL], const StepCtl& o) const {
+    double e2[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
       const double totalTol = fabs(yNew[j]) * o.relTol + o.absTol;
       const double e = err_y[j] / totalTol;
-      es[c0 + j] = e * e;
+      e2[j] = e * e;
     }
     if constexpr (SHUFFLE_NORM) {
       // A/B variant (tuning knob "lps_shuffle_norm"): butterfly all-reduce across the system's lanes with wavefront
@@ -294,11 +323,34 @@ struct LpsOps {
       // left-to-right sum, so `error` can differ in the last ulp (all lanes of a system still get identical bits).
       double part = 0.0;
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) part = part + (owns(j) ? es[c0 + j] : 0.0);
+      for (int j = 0; j < CPL; ++j) part = part + (owns(j) ? e2[j] : 0.0);
 #pragma unroll
       for (int off = 1; off < DIM / CPL; off <<= 1) part = part + __shfl_xor(part, off, 64);
       return sqrt(1.0 / (double)SIZE * part);
+    } else if constexpr (lps_chain_norm<DIM / CPL>()) {
+      // Ordered chain through registers: the reference's sum is sequential — ((0 + e_0) + e_1) + ... (utils.nim:233-235) — so it is passed
+      // from lane to lane of the system: in round r every lane adds its CPL terms, left to right, to the running sum it receives from the
+      // previous lane (DPP / lane permute), and lane r's result of round r is the exact prefix sum through its last component (lane r - 1
+      // held the exact prefix after round r - 1; what the other lanes compute in that round is never read).  After L rounds the last lane
+      // holds the total, which is broadcast.  Same association as the LDS loop below, hence the same bits; no LDS traffic, no wave sync:
+      // with a banded right-hand side the kernel touches no LDS at all.  Switched-off tail components add +0.0 (exact: the terms are >= +0).
+      constexpr int L = DIM / CPL;
+      double acc = 0.0;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) acc = acc + (owns(j) ? e2[j] : 0.0);  // round 0: exact in the system's first lane
+      if constexpr (L > 1) {
+#pragma unroll
+        for (int r = 1; r < L; ++r) {
+          double run = lane_rotate<L, -1>(acc);
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) run = run + (owns(j) ? e2[j] : 0.0);
+          acc = run;
+        }
+      }
+      return sqrt(1.0 / (double)SIZE * lane_last<L>(acc));
     } else {
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) es[c0 + j] = e2[j];
       wave_lds_sync();
       double sum = 0.0;
 #pragma unroll
