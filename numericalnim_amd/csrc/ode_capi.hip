@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <cstdio>
 #include <cstring>
@@ -1353,14 +1354,26 @@ struct StreamGraphKey {
   int device;
   bool operator==(const StreamGraphKey& o) const { return std::memcmp(this, &o, sizeof(*this)) == 0; }
 };
+void sync_device_of(int device);
+// An instantiated graph, shared between the cache and whoever is launching it right now: eviction, nnhip_release() or a knob change on another
+// thread only drop the cache's reference; the executable is destroyed (after its device has drained) when the last launcher lets go of it.
+struct GraphExec {
+  hipGraphExec_t exec = nullptr;
+  int device = -1;
+  GraphExec(hipGraphExec_t e, int d) : exec(e), device(d) {}
+  GraphExec(const GraphExec&) = delete;
+  GraphExec& operator=(const GraphExec&) = delete;
+  ~GraphExec() { if (exec) { sync_device_of(device); (void)hipGraphExecDestroy(exec); } }
+};
 struct StreamGraphEntry {
   StreamGraphKey key;
-  hipGraphExec_t exec = nullptr;
+  std::shared_ptr<GraphExec> exec;
   int64_t nSteps = 0;
   double* yFinal = nullptr;
 };
 // Process-wide since round 3 (they were per thread): nnhip_release() and a knob change free every thread's captures, and the worker
-// threads of the multi-GPU entries find what an earlier call's workers captured.  The mutex covers lookup / insert / erase only.
+// threads of the multi-GPU entries find what an earlier call's workers captured.  The mutex covers lookup / insert / erase only; a launcher
+// holds a reference to the executable it found (GraphExec) while it launches it outside the lock.
 std::mutex g_graph_mu;
 std::vector<StreamGraphEntry> g_graphs;
 std::vector<StreamGraphKey> g_graph_seen;  // automatic mode: keys that ran eagerly once (a repeat is worth capturing)
@@ -1372,10 +1385,12 @@ void sync_device_of(int device) {  // a cached graph may still be executing; its
   if (have) (void)hipSetDevice(prev);
 }
 void release_stream_graphs() {
-  std::lock_guard<std::mutex> lk(g_graph_mu);
-  for (auto& e : g_graphs) if (e.exec) { sync_device_of(e.key.device); (void)hipGraphExecDestroy(e.exec); }
-  g_graphs.clear();
-  g_graph_seen.clear();
+  std::vector<StreamGraphEntry> dropped;  // destroyed outside the lock (the destructor synchronises a device)
+  {
+    std::lock_guard<std::mutex> lk(g_graph_mu);
+    dropped.swap(g_graphs);
+    g_graph_seen.clear();
+  }
 }
 }  // namespace
 
@@ -1417,7 +1432,7 @@ int nnhip_ode_fixed_stream_f64_dev(const nnhip_ode_options* opt, int integrator,
         }
       }
       if (found) {
-        HIP_TRY(hipGraphLaunch(hit.exec, (hipStream_t)stream));
+        HIP_TRY(hipGraphLaunch(hit.exec->exec, (hipStream_t)stream));
         if (n_steps_out) *n_steps_out = hit.nSteps;
         if (y_final) *y_final = hit.yFinal;
         return NNHIP_OK;
@@ -1439,19 +1454,21 @@ int nnhip_ode_fixed_stream_f64_dev(const nnhip_ode_options* opt, int integrator,
     hipError_t ce = hipStreamEndCapture((hipStream_t)stream, &graph);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (ce != hipSuccess) return fail(NNHIP_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
-    const hipError_t ie = hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0);
+    hipGraphExec_t raw = nullptr;
+    const hipError_t ie = hipGraphInstantiate(&raw, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (ie != hipSuccess) return fail(NNHIP_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+    e.exec = std::make_shared<GraphExec>(raw, key.device);
     {
+      std::shared_ptr<GraphExec> evicted;  // the oldest; it may still be executing or being launched: released outside the lock
       std::lock_guard<std::mutex> lk(g_graph_mu);
-      if (g_graphs.size() >= 32) {  // evict the oldest; it may still be executing
-        sync_device_of(g_graphs.front().key.device);
-        (void)hipGraphExecDestroy(g_graphs.front().exec);
+      if (g_graphs.size() >= 32) {
+        evicted = std::move(g_graphs.front().exec);
         g_graphs.erase(g_graphs.begin());
       }
       g_graphs.push_back(e);
     }
-    HIP_TRY(hipGraphLaunch(e.exec, (hipStream_t)stream));
+    HIP_TRY(hipGraphLaunch(e.exec->exec, (hipStream_t)stream));
     if (n_steps_out) *n_steps_out = e.nSteps;
     if (y_final) *y_final = e.yFinal;
     return NNHIP_OK;
@@ -1637,7 +1654,7 @@ struct AdvGraphKey {
 };
 struct AdvGraphEntry {
   AdvGraphKey key;
-  hipGraphExec_t exec = nullptr;
+  std::shared_ptr<GraphExec> exec;
 };
 // The "anyone still integrating?" flags live in page-locked, device-visible HOST memory and the last launch of a polling group stores
 // into them directly (a few thousand 4-byte writes over PCIe, once per group).  Round 2 kept them in device memory: every group then
@@ -1672,22 +1689,26 @@ int adv_poll_reserve() {
 }
 void release_adv_graphs() {
   {
-    std::lock_guard<std::mutex> lk(g_graph_mu);
-    for (auto& e : g_adv_graphs) if (e.exec) { sync_device_of(e.key.device); (void)hipGraphExecDestroy(e.exec); }
-    g_adv_graphs.clear();
+    std::vector<AdvGraphEntry> dropped;
+    {
+      std::lock_guard<std::mutex> lk(g_graph_mu);
+      dropped.swap(g_adv_graphs);
+    }
   }
   free_adv_poll(g_adv_poll);
 }
 void free_adv_poll(AdvPoll& p) {
-  if (p.device >= 0) {  // graphs that bake this block's flag addresses in go with it
-    std::lock_guard<std::mutex> lk(g_graph_mu);
-    for (size_t k = 0; k < g_adv_graphs.size();) {
-      const unsigned int* f = (const unsigned int*)g_adv_graphs[k].key.active;
-      if (p.h && f >= p.h && f < p.h + 2 * nnhip::kAggSlots) {
-        sync_device_of(g_adv_graphs[k].key.device);
-        (void)hipGraphExecDestroy(g_adv_graphs[k].exec);
-        g_adv_graphs.erase(g_adv_graphs.begin() + (long)k);
-      } else ++k;
+  if (p.device >= 0) {  // graphs that bake this block's flag addresses in go with it (they are this thread's own: nobody else launches them)
+    std::vector<std::shared_ptr<GraphExec>> dropped;
+    {
+      std::lock_guard<std::mutex> lk(g_graph_mu);
+      for (size_t k = 0; k < g_adv_graphs.size();) {
+        const unsigned int* f = (const unsigned int*)g_adv_graphs[k].key.active;
+        if (p.h && f >= p.h && f < p.h + 2 * nnhip::kAggSlots) {
+          dropped.push_back(std::move(g_adv_graphs[k].exec));
+          g_adv_graphs.erase(g_adv_graphs.begin() + (long)k);
+        } else ++k;
+      }
     }
   }
   if (p.h) (void)hipHostFree(p.h);
@@ -1745,7 +1766,7 @@ int adv_issue_group(nnhip::StepLaunchFn fn, int userKind, int integrator, const 
 // The polling group `issue()` enqueues on `s`, as a cached hipGraph (nullptr: not available — the caller issues eagerly).  rc receives
 // the status of `issue` when it had to be run for the capture.
 template <class IssueFn>
-hipGraphExec_t adv_cached_graph(const AdvGraphKey& key, hipStream_t s, IssueFn&& issue, int& rc) {
+std::shared_ptr<GraphExec> adv_cached_graph(const AdvGraphKey& key, hipStream_t s, IssueFn&& issue, int& rc) {
   rc = NNHIP_OK;
   {
     std::lock_guard<std::mutex> lk(g_graph_mu);
@@ -1762,16 +1783,16 @@ hipGraphExec_t adv_cached_graph(const AdvGraphKey& key, hipStream_t s, IssueFn&&
   const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
   (void)hipGraphDestroy(graph);
   if (ie != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  AdvGraphEntry e;
+  e.key = key; e.exec = std::make_shared<GraphExec>(exec, key.device);
+  std::shared_ptr<GraphExec> evicted;  // released after the lock
   std::lock_guard<std::mutex> lk(g_graph_mu);
   if (g_adv_graphs.size() >= 32) {  // evict the oldest; it may still be executing
-    sync_device_of(g_adv_graphs.front().key.device);
-    (void)hipGraphExecDestroy(g_adv_graphs.front().exec);
+    evicted = std::move(g_adv_graphs.front().exec);
     g_adv_graphs.erase(g_adv_graphs.begin());
   }
-  AdvGraphEntry e;
-  e.key = key; e.exec = exec;
   g_adv_graphs.push_back(e);
-  return exec;
+  return e.exec;
 }
 }  // namespace
 
@@ -1847,7 +1868,7 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
   if ((int64_t)split > N) split = 1;
 
   // ---- the polling group as a graph (cached per thread; key = everything the launches depend on), one per half of the flag block ----
-  hipGraphExec_t execs[2] = {nullptr, nullptr};
+  std::shared_ptr<GraphExec> execs[2];  // held for the whole call: another thread's eviction / nnhip_release() cannot destroy them under it
   // Replayed only when asked for (knob 1) since round 3: with (t, dt) interleaved and FSAL re-evaluated a launch takes 5-300 us, the command
   // processor pipelines eager launches behind each other, and a graph's node-to-node hand-over costs 1-2 us more than that (Lorenz 1e4 ... 3e6
   // IVPs and 16-component rings: eager 1-5 % faster at every size, scripts/ab_stream_graph_vs_eager.py)
@@ -1865,9 +1886,8 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
         warm.N = 0;
         (void)nnhip::rtc_launch_advance(userKind, integrator, warm, s);
       }
-      hipGraphExec_t exec = adv_cached_graph(key, s, [&]() { return adv_issue_group(fn, userKind, integrator, a, flags, check_every, split, s); }, rc);
+      execs[half] = adv_cached_graph(key, s, [&]() { return adv_issue_group(fn, userKind, integrator, a, flags, check_every, split, s); }, rc);
       if (rc) return rc;
-      execs[half] = exec;
     }
     if (!execs[0] || !execs[1]) execs[0] = execs[1] = nullptr;
   }
@@ -1875,7 +1895,7 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
     const int half = (int)(g & 1);
     unsigned int* flags = poll.h + half * nnhip::kAggSlots;
     std::memset(flags, 0, nnhip::kAggSlots * sizeof(unsigned int));  // host memory; the group that last wrote this half has been waited for
-    if (execs[half]) HIP_TRY(hipGraphLaunch(execs[half], s));
+    if (execs[half]) HIP_TRY(hipGraphLaunch(execs[half]->exec, s));
     else { const int r = adv_issue_group(fn, userKind, integrator, a, flags, check_every, split, s); if (r) return r; }
     HIP_TRY(hipEventRecord(poll.ev[half], s));
     return NNHIP_OK;
@@ -2030,7 +2050,7 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
       return NNHIP_OK;
     };
     int64_t dirLaunches = 0;  // max_launches bounds each direction's loop, as max_steps does in the fused solve
-    hipGraphExec_t execs[2] = {nullptr, nullptr};
+    std::shared_ptr<GraphExec> execs[2];
     if (g_stream_graph == 1 && s != nullptr) {  // as the loop without dense output: eager launches unless asked for
       int device = 0;
       HIP_TRY(hipGetDevice(&device));
@@ -2059,7 +2079,7 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
       std::memset(flags, 0, nnhip::kAggSlots * sizeof(unsigned int));  // host memory; the group that last wrote this half has been waited for
       const bool lastPermitted = max_launches > 0 && dirLaunches + check_every >= max_launches;
       const int n = lastPermitted ? (int)(max_launches - dirLaunches) : check_every;
-      if (execs[half] && !lastPermitted) HIP_TRY(hipGraphLaunch(execs[half], s));
+      if (execs[half] && !lastPermitted) HIP_TRY(hipGraphLaunch(execs[half]->exec, s));
       else { const int ra = issue_group(flags, n, lastPermitted); if (ra) return ra; }
       launches += n;
       dirLaunches += n;

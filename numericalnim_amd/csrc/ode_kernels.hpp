@@ -1091,7 +1091,6 @@ NNHIP_DEV unsigned int advance_dense_body(const StepArgs& a, const OPS& ops, int
   int denseIndex = a.useDense ? a.denseIdx_io[i] : 0;  // <= nReq - 1: an IVP whose last requested time has been emitted is retired below
   const double2 td = *td_io;
   double t = td.x;
-  const int64_t cs = a.compStride;
   // DOPRI54 / Tsit54 re-evaluate FSAL instead (StepArgs::recomputeFsal); RK21 never reads the slot; BS32's stepper does not either, but the
   // slot it returns (k4 = f(t + dt, yNew)) is lastIter.dy of the dense output (MethodTraits::fsal), so here it travels
   const bool withFsal = METHOD == NNHIP_BS32 ? true : adv_fsal_in_hbm<METHOD>(a);

@@ -49,3 +49,21 @@ def test_c5_cpp_harness(nn, tmp_path):
         assert r.returncode == 0
         out = json.loads(r.stdout.strip().splitlines()[-1])
         assert out["n_gpus"] == g and out["verified"] is True and out["value"] > 1e9 and out["unit"] == "trajectory-steps/s"
+
+
+def test_multithread_launch_harness(nn, tmp_path):
+    """tests/cpp/bench_multithread_launch.cpp: G = 1, 2, 4, 8 host threads, each driving its own stream and shard on device 0 through the worker
+    of the one-call multi-GPU entry (nnhip_ode_fixed_stream_f64_dev), eager and graph-replayed — the process-wide graph cache is hit from
+    several threads at once, entries are released while other threads launch.  Here: it runs and every solve takes its steps; the numbers
+    are recorded by scripts/run_r04_gpu.sh into profiles/r04_multithread_launch.json."""
+    import json
+    exe = str(tmp_path / "bench_multithread_launch")
+    libdir = os.path.join(ROOT, "numericalnim_amd", "csrc")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "bench_multithread_launch.cpp"), "-L", libdir, "-lnnhip_ode", "-L", "/opt/rocm/lib",
+                           "-lamdhip64", "-lpthread", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    r = subprocess.run([exe, "--rk4-steps", "100", "--reps", "2"], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["ok"] is True and out["c5_eager_G8"]["launches_per_s_aggregate"] > 0

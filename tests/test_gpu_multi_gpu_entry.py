@@ -129,7 +129,7 @@ def test_rccl_allgather_states_all_devices(nn, dev, layout, dim):
         pytest.skip(f"needs >= 2 HIP devices, this box has {G} (the 8-GPU run is the driver's)")
     L = nn._lib.lib()
     rng = np.random.default_rng(3)
-    for counts in ([500] * G, [300 + 17 * r for r in range(G)]):
+    for counts in ([500] * G, [300 + 17 * r for r in range(G)], [0 if r == 1 else 200 + 5 * r for r in range(G)], [0] * (G - 1) + [64]):  # equal, ragged, an empty shard, all but one empty
         N = sum(counts)
         full_ref = rng.normal(size=(dim, N)) if layout == 0 else rng.normal(size=(N, dim))
         lo = np.concatenate([[0], np.cumsum(counts)])
@@ -222,7 +222,7 @@ def _c5_composite(nn, L, G, counts, n_steps, layout, dim, rhs, params, integ, us
         torch.cuda.synchronize(r)
     assert nst.value == n_steps
     for r in range(G):
-        assert fin[r] in (ys[r].data_ptr(), scr[r].data_ptr())
+        assert (fin[r] or 0) in (ys[r].data_ptr(), scr[r].data_ptr())  # (an empty shard's tensors have a null data pointer)
     with torch.cuda.device(0):
         t, yref = nn.solveODE(rhs, torch.from_numpy(y0).to("cuda:0"), [0.0, tEnd], opt, integrator=integ, layout=layout)
     return fulls, yref[-1].cpu().numpy()
@@ -241,7 +241,7 @@ def test_c5_one_call_single_device_rccl(nn, dev, layout, dim, gather_streams):
     assert np.array_equal(fulls[0].cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize("ragged", [False, True], ids=["equal", "ragged"])
+@pytest.mark.parametrize("ragged", [0, 1, 2], ids=["equal", "ragged", "ragged_with_empty_shard"])
 def test_c5_one_call_all_devices(nn, dev, ragged):
     """The same at n_gpus = device_count (equal shards: ncclAllGather; ragged: grouped ncclBroadcasts), gather overlapped on its own
     streams.  Needs >= 2 devices: skipped on the one-GPU boxes, runs on the first multi-GPU lease."""
@@ -250,7 +250,7 @@ def test_c5_one_call_all_devices(nn, dev, ragged):
     if G < 2:
         pytest.skip(f"needs >= 2 HIP devices, this box has {G} (the 8-GPU run is the driver's)")
     L = nn._lib.lib()
-    counts = [3000 + (37 * r if ragged else 0) for r in range(G)]
+    counts = [0 if (ragged == 2 and r == G - 1) else 3000 + (37 * r if ragged else 0) for r in range(G)]
     for layout, dim, rhs, params in ((0, 1, nn.Rhs.neg_y(), []), (0, 3, nn.Rhs.lorenz(), LOR), (1, 3, nn.Rhs.lorenz(), LOR)):
         fulls, ref = _c5_composite(nn, L, G, counts, 100, layout, dim, rhs, params, "rk4", True)
         for r in range(G):
