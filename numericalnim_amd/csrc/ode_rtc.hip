@@ -7,7 +7,10 @@
 // as text) for it — same steppers, same driver, same -ffp-contract=off numerics — one hiprtc program per
 // (rhs, integrator), cached for the life of the process.
 #include <hip/hip_runtime.h>
+#include <hip/hip_version.h>
 #include <hip/hiprtc.h>
+
+#include <atomic>
 
 #include <cstdio>
 #include <climits>
@@ -48,22 +51,44 @@ struct RtcApi {
   hiprtcResult (*destroyProgram)(hiprtcProgram*);
   std::string origin;
 };
-const RtcApi& rtc_api() {
-  static const RtcApi api = [] {
-    RtcApi a{&hiprtcCreateProgram, &hiprtcCompileProgram, &hiprtcGetProgramLogSize, &hiprtcGetProgramLog, &hiprtcGetCodeSize, &hiprtcGetCode,
-             &hiprtcAddNameExpression, &hiprtcGetLoweredName, &hiprtcDestroyProgram, "the process's libhiprtc"};
+#ifndef NNHIP_BUILD_ROCM_PATH
+#define NNHIP_BUILD_ROCM_PATH "/opt/rocm"  // (the Makefile bakes in the ROCm the library is built with: `hipconfig --rocmpath`)
+#endif
+struct RtcState {
+  RtcApi process;            // the libhiprtc the process resolves (always usable)
+  RtcApi priv;               // the build's ROCm in a link namespace of its own, if it was loaded
+  bool havePriv = false;
+  std::atomic<bool> privDisabled{false};
+  std::mutex mu;
+  std::string why;           // why the private one is not (or no longer) used
+};
+RtcState& rtc_state() {
+  static RtcState st;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    RtcState& s = st;
+    s.process = RtcApi{&hiprtcCreateProgram, &hiprtcCompileProgram, &hiprtcGetProgramLogSize, &hiprtcGetProgramLog, &hiprtcGetCodeSize, &hiprtcGetCode,
+                       &hiprtcAddNameExpression, &hiprtcGetLoweredName, &hiprtcDestroyProgram, "the process's libhiprtc"};
     const char* pref = std::getenv("NNHIP_HIPRTC");
-    if (pref && std::strcmp(pref, "process") == 0) return a;
-    const std::string path = pref && *pref ? pref : "/opt/rocm/lib/libhiprtc.so";  // the ROCm this library was built with
+    if (pref && std::strcmp(pref, "process") == 0) { s.why = "NNHIP_HIPRTC=process"; return; }
+    const std::string path = pref && *pref ? pref : NNHIP_BUILD_ROCM_PATH "/lib/libhiprtc.so";  // the ROCm this library was built with
     Dl_info info;
     char mine[PATH_MAX] = "", theirs[PATH_MAX] = "";
-    if (!realpath(path.c_str(), theirs)) return a;  // no such ROCm next to the process's
+    if (!realpath(path.c_str(), theirs)) { s.why = path + " does not exist on this host"; return; }
     if (dladdr((void*)&hiprtcCreateProgram, &info) && info.dli_fname && realpath(info.dli_fname, mine)) {
-      a.origin = std::string(mine) + " (the process's own)";
-      if (std::strcmp(mine, theirs) == 0) return a;
+      s.process.origin = std::string(mine) + " (the process's own)";
+      if (std::strcmp(mine, theirs) == 0) { s.why = "the process already uses the build's libhiprtc"; return; }
+    }
+    // A code object from the build's compiler is loaded by the PROCESS's runtime: only within one major version of HIP (the code-object
+    // ABI and the kernel-descriptor layout are stable there); across majors the process's own compiler is the safe one.
+    int rt = 0;
+    if (!(pref && *pref) && hipRuntimeGetVersion(&rt) == hipSuccess && rt / 10000000 != HIP_VERSION_MAJOR) {
+      s.why = "the process's HIP runtime is version " + std::to_string(rt / 10000000) + ".x, this library was built with " + std::to_string(HIP_VERSION_MAJOR) + "." +
+              std::to_string(HIP_VERSION_MINOR) + ": code objects stay with the process's own compiler";
+      return;
     }
     void* h = dlmopen(LM_ID_NEWLM, theirs, RTLD_NOW | RTLD_LOCAL);
-    if (!h) return a;
+    if (!h) { const char* de = dlerror(); s.why = std::string("dlmopen(") + theirs + ") failed: " + (de ? de : "?"); return; }
     RtcApi b;
     b.createProgram = (decltype(b.createProgram))dlsym(h, "hiprtcCreateProgram");
     b.compileProgram = (decltype(b.compileProgram))dlsym(h, "hiprtcCompileProgram");
@@ -75,12 +100,34 @@ const RtcApi& rtc_api() {
     b.getLoweredName = (decltype(b.getLoweredName))dlsym(h, "hiprtcGetLoweredName");
     b.destroyProgram = (decltype(b.destroyProgram))dlsym(h, "hiprtcDestroyProgram");
     if (!b.createProgram || !b.compileProgram || !b.getProgramLogSize || !b.getProgramLog || !b.getCodeSize || !b.getCode || !b.addNameExpression || !b.getLoweredName ||
-        !b.destroyProgram)
-      return a;
+        !b.destroyProgram) { s.why = std::string(theirs) + " lacks a hiprtc entry point"; return; }
     b.origin = std::string(theirs) + " (in a link namespace of its own; the process's own is " + (mine[0] ? mine : "unknown") + ")";
-    return b;
-  }();
-  return api;
+    s.priv = b;
+    s.havePriv = true;
+  });
+  return st;
+}
+bool rtc_is_private(const RtcApi& api) { return &api == &rtc_state().priv; }
+// Fault injection for the fall-back paths (tests/test_gpu_hiprtc_modes.py): NNHIP_HIPRTC_INJECT=compile makes the first compilation in the
+// private namespace report failure, =load makes the first module load of a privately compiled code object report failure.
+bool rtc_inject(const char* what) {
+  static std::atomic<int> armed{-1};
+  if (armed.load() < 0) { const char* e = std::getenv("NNHIP_HIPRTC_INJECT"); armed = e && *e ? 1 : 0; }
+  const char* e = std::getenv("NNHIP_HIPRTC_INJECT");
+  if (!e || std::strcmp(e, what) != 0) return false;
+  int one = 1;
+  return armed.compare_exchange_strong(one, 0);
+}
+const RtcApi& rtc_api() {
+  RtcState& s = rtc_state();
+  return s.havePriv && !s.privDisabled.load() ? s.priv : s.process;
+}
+// The private compiler produced something unusable here (its comgr / device libraries are not found, or the process's runtime refuses its
+// code object): from now on the process's own libhiprtc compiles, and nnhip_rtc_compiler() says why.
+void rtc_disable_private(const std::string& reason) {
+  RtcState& s = rtc_state();
+  std::lock_guard<std::mutex> lk(s.mu);
+  if (!s.privDisabled.exchange(true)) s.why = reason;
 }
 
 struct Header { const char* name; const char* text; };
@@ -109,6 +156,7 @@ struct Program {  // the kernels of one (rhs, integrator) code object as loaded 
 };
 struct CodeObject {  // compiled once per (rhs, integrator); hipModuleLoadData binds it to the device that is current at the time
   std::vector<char> code;
+  bool fromPrivate = false;  // compiled by the build's libhiprtc in its private link namespace (see rtc_state)
   std::vector<std::string> lowered;
   int ivpsPerBlockSolve = kBlock, ivpsPerBlockStep = kBlock, ivpsPerBlockAdvance = kBlock;
   std::map<int, std::shared_ptr<Program>> loaded;  // by device ordinal
@@ -223,12 +271,12 @@ std::string make_source(const UserRhsEntry& e) {
   return s;
 }
 
-bool compile(const UserRhsEntry& e, int integrator, CodeObject& out) {
+bool compile_with(const RtcApi& api, const UserRhsEntry& e, int integrator, CodeObject& out) {
   const std::string src = make_source(e);
   hiprtcProgram prog;
   std::vector<const char*> hsrc, hname;
   for (const Header& h : kHeaders) { hsrc.push_back(h.text); hname.push_back(h.name); }
-  if (rtc_api().createProgram(&prog, src.c_str(), "nnhip_user_rhs.hip", (int)hsrc.size(), hsrc.data(), hname.data()) != HIPRTC_SUCCESS) {
+  if (api.createProgram(&prog, src.c_str(), "nnhip_user_rhs.hip", (int)hsrc.size(), hsrc.data(), hname.data()) != HIPRTC_SUCCESS) {
     g_rtc_err = "hiprtcCreateProgram failed";
     return false;
   }
@@ -293,23 +341,23 @@ bool compile(const UserRhsEntry& e, int integrator, CodeObject& out) {
   } else {
     names.push_back("nnhip::rhs_batch_kernel<nnhip::UserRhs>");
   }
-  for (auto& n : names) rtc_api().addNameExpression(prog, n.c_str());
+  for (auto& n : names) api.addNameExpression(prog, n.c_str());
   // same numerical contract as the ahead-of-time kernels
   const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
-  const hiprtcResult rc = rtc_api().compileProgram(prog, 4, opts);
+  const hiprtcResult rc = api.compileProgram(prog, 4, opts);
   if (rc != HIPRTC_SUCCESS) {
     size_t n = 0;
-    rtc_api().getProgramLogSize(prog, &n);
+    api.getProgramLogSize(prog, &n);
     std::string log(n, '\0');
-    if (n) rtc_api().getProgramLog(prog, log.data());
+    if (n) api.getProgramLog(prog, log.data());
     g_rtc_err = "hiprtc compilation of user RHS '" + e.name + "' failed:\n" + log;
-    rtc_api().destroyProgram(&prog);
+    api.destroyProgram(&prog);
     return false;
   }
   size_t codeSize = 0;
-  rtc_api().getCodeSize(prog, &codeSize);
+  api.getCodeSize(prog, &codeSize);
   out.code.resize(codeSize);
-  rtc_api().getCode(prog, out.code.data());
+  api.getCode(prog, out.code.data());
   if (const char* dump = std::getenv("NNHIP_RTC_DUMP")) {  // debugging aid: the code object of every run-time compilation, as DIR/<name>_<key>.co
     const std::string path = std::string(dump) + "/" + e.name + "_" + std::to_string(integrator) + ".co";
     if (FILE* fdump = std::fopen(path.c_str(), "wb")) { std::fwrite(out.code.data(), 1, out.code.size(), fdump); std::fclose(fdump); }
@@ -317,22 +365,43 @@ bool compile(const UserRhsEntry& e, int integrator, CodeObject& out) {
   out.lowered.clear();
   for (auto& n : names) {
     const char* ln = nullptr;
-    if (rtc_api().getLoweredName(prog, n.c_str(), &ln) != HIPRTC_SUCCESS || !ln) {
+    if (api.getLoweredName(prog, n.c_str(), &ln) != HIPRTC_SUCCESS || !ln) {
       g_rtc_err = "hiprtcGetLoweredName failed for " + n;
-      rtc_api().destroyProgram(&prog);
+      api.destroyProgram(&prog);
       return false;
     }
     out.lowered.push_back(ln);
   }
-  rtc_api().destroyProgram(&prog);
+  api.destroyProgram(&prog);
   return true;
+}
+
+// With the build's compiler in its private namespace first; if it fails where the process's own succeeds, the failure was not the user's
+// source (comgr / device libraries of that ROCm not found, a code generator problem): the process's own takes over for good.
+bool compile(const UserRhsEntry& e, int integrator, CodeObject& out) {
+  const RtcApi& api = rtc_api();
+  const bool injected = rtc_is_private(api) && rtc_inject("compile");
+  if (injected) g_rtc_err = "hiprtc compilation failed (injected by NNHIP_HIPRTC_INJECT=compile)\n";
+  if (!injected && compile_with(api, e, integrator, out)) { out.fromPrivate = rtc_is_private(api); return true; }
+  if (!rtc_is_private(api)) return false;
+  const std::string first = g_rtc_err;
+  CodeObject alt;
+  if (compile_with(rtc_state().process, e, integrator, alt)) {
+    rtc_disable_private("a compilation failed with " + api.origin + " and succeeded with the process's own: " + first.substr(0, first.find('\n', first.find('\n') + 1)));
+    out = std::move(alt);
+    out.fromPrivate = false;
+    return true;
+  }
+  g_rtc_err = first;  // both refuse it: the user's source
+  return false;
 }
 
 bool load(const CodeObject& co, int integrator, Program& out) {
   out.ivpsPerBlockSolve = co.ivpsPerBlockSolve;
   out.ivpsPerBlockStep = co.ivpsPerBlockStep;
   out.ivpsPerBlockAdvance = co.ivpsPerBlockAdvance;
-  if (hipModuleLoadData(&out.module, co.code.data()) != hipSuccess) {
+  if ((co.fromPrivate && rtc_inject("load")) || hipModuleLoadData(&out.module, co.code.data()) != hipSuccess) {
+    out.module = nullptr;
     g_rtc_err = "hipModuleLoadData failed (no HIP device?)";
     return false;
   }
@@ -389,7 +458,18 @@ std::shared_ptr<Program> get_program(int rhs_kind, int integrator) {
   if (ld != it->second.loaded.end()) return ld->second;
   auto p = std::make_shared<Program>();
   p->device = device;
-  if (!load(it->second, integrator, *p)) return nullptr;
+  if (!load(it->second, integrator, *p)) {
+    if (!it->second.fromPrivate || !it->second.loaded.empty()) return nullptr;
+    // the process's runtime refuses a code object of the build's compiler: recompile with the process's own (rare: once per process)
+    const std::string first = g_rtc_err;
+    rtc_disable_private("the process's HIP runtime could not load a code object compiled by " + rtc_state().priv.origin + " (" + first + ")");
+    CodeObject again;
+    if (!compile_with(rtc_state().process, g_user[idx], integrator, again)) return nullptr;
+    it->second = std::move(again);
+    p = std::make_shared<Program>();
+    p->device = device;
+    if (!load(it->second, integrator, *p)) return nullptr;
+  }
   it->second.loaded[device] = p;
   return p;
 }
@@ -399,7 +479,14 @@ std::shared_ptr<Program> get_program(int rhs_kind, int integrator) {
 static void free_owned(UserRhsEntry& e);
 
 const char* rtc_last_error() { return g_rtc_err.c_str(); }
-const char* rtc_compiler_origin() { return rtc_api().origin.c_str(); }  // which libhiprtc builds the user's right-hand sides
+const char* rtc_compiler_origin() {  // which libhiprtc builds the user's right-hand sides, and why not the other
+  static thread_local std::string text;
+  RtcState& s = rtc_state();
+  std::lock_guard<std::mutex> lk(s.mu);
+  text = rtc_api().origin;
+  if (!s.why.empty()) text += "; the build's (" NNHIP_BUILD_ROCM_PATH ") is not used: " + s.why;
+  return text.c_str();
+}
 
 int rtc_register(const char* name, int dim, int n_params, const char* body, bool per_component, bool check_compiles, const RtcCtxLayout* ctx) {
   UserRhsEntry e;
@@ -424,26 +511,8 @@ int rtc_register(const char* name, int dim, int n_params, const char* body, bool
     }
   }
   if (check_compiles) {  // syntax check now (device-independent), so errors surface at registration
-    const std::string src = make_source(e) + "\n";
-    hiprtcProgram prog;
-    std::vector<const char*> hsrc, hname;
-    for (const Header& h : kHeaders) { hsrc.push_back(h.text); hname.push_back(h.name); }
-    if (rtc_api().createProgram(&prog, src.c_str(), "nnhip_user_rhs.hip", (int)hsrc.size(), hsrc.data(), hname.data()) != HIPRTC_SUCCESS) {
-      g_rtc_err = "hiprtcCreateProgram failed";
-      return -1;
-    }
-    rtc_api().addNameExpression(prog, "nnhip::rhs_batch_kernel<nnhip::UserRhs>");
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
-    if (rtc_api().compileProgram(prog, 4, opts) != HIPRTC_SUCCESS) {
-      size_t n = 0;
-      rtc_api().getProgramLogSize(prog, &n);
-      std::string log(n, '\0');
-      if (n) rtc_api().getProgramLog(prog, log.data());
-      g_rtc_err = "hiprtc compilation of user RHS '" + e.name + "' failed:\n" + log;
-      rtc_api().destroyProgram(&prog);
-      return -1;
-    }
-    rtc_api().destroyProgram(&prog);
+    CodeObject scratch;
+    if (!compile(e, -1, scratch)) return -1;  // the rhs_batch kernel only; same private-then-process order as every other compilation
   }
   std::lock_guard<std::mutex> lk(g_mu);
   g_user.push_back(std::move(e));
