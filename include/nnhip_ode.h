@@ -125,6 +125,8 @@ int nnhip_host_free(void* p);
  *   the same bits, 1/K of the launches and 1/K of the bytes per step — a different traffic model, never quoted against the one-per-launch figures),
  *   "sort_copy" 0|1 (1: the binned solve nnhip_ode_solve_batch_sorted_f64[_dev] gathers the batch into integration order, solves it with
  *   coalesced accesses and scatters the results back; default 0: the solve kernel follows the order array itself — measured faster),
+ *   "sort_min_spread_permille" 0..1000 (the binned solve sorts only when its keys differ by more than this fraction of their magnitude; default 50 =
+ *   5 %; 0 = always sort),
  *   "fixed_vec_ipl" 0|2 (0 = one IVP per lane instead of the vectorised fixed-step streaming kernel),
  *   "multi_gpu_oversubscribe" 0|1 (nnhip_ode_solve_batch_multi_gpu_f64 accepts more shards than devices: shard r on device r mod #devices),
  *   "dim16_variant" 0..4 (A/B mappings of the fused 16-component kernels), "fp_contract" 0|1 (opt-in FMA-contracted fused
@@ -263,7 +265,9 @@ int nnhip_ode_solve_batch_calls_f64(const nnhip_ode_options* opt, const nnhip_od
  * ascending order of `sort_key` (device array [N]) and every result is WRITTEN at the IVP's own index, so outputs are in the
  * caller's order and bit-identical to nnhip_ode_solve_batch_sweep_f64_dev.  sort_key == NULL: automatic two-pass mode — a probe
  * solve of `probe_steps` accepted steps per IVP (<= 0: 8) ranks the IVPs by the progress they make, then the batch is
- * integrated in that order.  Fixed-step integrators run unsorted (no divergence).  per_ivp_params may be NULL (n_per_ivp = 0).
+ * integrated in that order.  Fixed-step integrators run unsorted (no divergence), and so does a batch (of 4096 IVPs or more) whose keys lie
+ * within 5 % of each other (knob "sort_min_spread_permille"): nothing to gain, and the sort + indirection would cost ~20 % of such a solve.
+ * Reading the keys' range synchronises `stream` once.  per_ivp_params may be NULL (n_per_ivp = 0).
  * `ws`: device workspace of nnhip_ode_solve_sorted_workspace_bytes(N, n_t) bytes.  N < 2^31. */
 int64_t nnhip_ode_solve_sorted_workspace_bytes(int64_t N, int n_t);
 /* host-pointer form (all arrays in host memory, incl. sort_key; staged through `device` in one piece) */

@@ -78,6 +78,7 @@ int g_sort_copy = 0;      // tuning knob "sort_copy": the binned solve reorders 
                           // more than the scattered first load and last stores they remove
 int g_adv_steps = 1;      // tuning knob "adv_steps_per_launch": loop iterations per IVP and launch of nnhip_ode_adaptive_stream_f64_dev (1 = the IntegratorProc
                           // seam proper; K > 1 keeps the state in registers for K iterations: 8*(4d+5)/K bytes per attempted step, a different traffic model)
+double g_sort_min_spread = 0.05;  // tuning knob "sort_min_spread_permille": the binned solve sorts only when the keys differ by more than this fraction of their magnitude
 int g_adv_split = 0;      // tuning knob "adv_split": index ranges the adaptive streaming loop interleaves on separate streams (0 = auto, 1, 2, 4)
 int g_dim16_variant = 0;  // tuning knob "dim16_variant": A/B mappings of the fused 16-component kernels (see ode_kernels.hpp)
 
@@ -294,6 +295,9 @@ hipError_t launch_fill_f64(double* p, int64_t n, double v, hipStream_t s);
 int64_t argsort_workspace_bytes(int64_t N);
 hipError_t argsort_f64(const double* keys, int64_t N, uint32_t* perm_out, void* ws, int64_t ws_bytes, hipStream_t s);
 hipError_t negate_f64(const double* in, double* out, int64_t N, hipStream_t s);
+hipError_t key_range_f64(const double* keys, int64_t N, void* scratch, unsigned long long* pinned2, hipStream_t s);
+int64_t key_range_scratch_bytes();
+void key_range_decode(const unsigned long long* img, double* mn, double* mx);
 hipError_t gather_f64(const double* src, double* dst, const uint32_t* perm, int64_t N, int R, int W, hipStream_t s);
 hipError_t scatter_f64(const double* src, double* dst, const uint32_t* perm, int64_t N, int R, int W, hipStream_t s);
 hipError_t scatter_i32(const int32_t* src, int32_t* dst, const uint32_t* perm, int64_t N, hipStream_t s);
@@ -405,6 +409,7 @@ int nnhip_tune_set(const char* key, int value) {
   if (k == "adv_block") { if (value != 0 && value != 64 && value != 128 && value != 256) return fail(NNHIP_EVALUE, "adv_block must be 0, 64, 128 or 256"); g_adv_block = value; release_adv_graphs(); return NNHIP_OK; }
   if (k == "sort_copy") { g_sort_copy = value != 0; return NNHIP_OK; }
   if (k == "adv_steps_per_launch") { if (value < 1 || value > 1024) return fail(NNHIP_EVALUE, "adv_steps_per_launch must be 1..1024"); g_adv_steps = value; return NNHIP_OK; }
+  if (k == "sort_min_spread_permille") { if (value < 0 || value > 1000) return fail(NNHIP_EVALUE, "sort_min_spread_permille must be in 0..1000"); g_sort_min_spread = value / 1000.0; return NNHIP_OK; }
   if (k == "adv_split") { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(NNHIP_EVALUE, "adv_split must be 0, 1, 2 or 4"); g_adv_split = value; return NNHIP_OK; }
   if (k == "dim16_variant") { if (value < 0 || value > 4) return fail(NNHIP_EVALUE, "dim16_variant must be 0..4"); g_dim16_variant = value; return NNHIP_OK; }
   if (k == "rk4_stream_auto") { g_tune_auto = value != 0; return NNHIP_OK; }
@@ -869,12 +874,14 @@ int nnhip_ode_solve_batch_sorted_f64_dev(const nnhip_ode_options* opt, int integ
   const int64_t sortWsBytes = ws_bytes - (int64_t)((char*)sortWs - base);
   const bool adaptive = kMethods[integrator].adaptive != 0;
   PreparedSolve ps;
+  bool sorted = adaptive && N > 1;  // integrate in the order of `perm`
+  int rc = NNHIP_OK;
   if (adaptive && N > 1) {
     if (!sort_key) {  // pass 1: the probe.  Same solve, cut off after probe_steps accepted steps; only the progress is kept.
       if (probe_steps <= 0) probe_steps = 8;  // scripts/ab_probe_steps.py (1e6 Van der Pol IVPs): 4 steps do not rank (the controller is still ramping up from dtInit), 6 -> 1.73 ms, 8 -> 1.62 ms, 12 -> 1.68 ms, 16 -> 1.73 ms
       if (max_steps > 0 && probe_steps > max_steps) probe_steps = (int)max_steps;
-      int rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y0, N, dim, layout, tspan, n_t, nullptr, y_out,
-                             nullptr, nullptr, nullptr, probe_steps, ws, wsTimes, nullptr, nullptr, s, ps);
+      rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y0, N, dim, layout, tspan, n_t, nullptr, y_out,
+                         nullptr, nullptr, nullptr, probe_steps, ws, wsTimes, nullptr, nullptr, s, ps);
       if (rc) return rc;
       ps.a.progress_out = key;
       rc = launch_solve_range(ps, 0, N, s);
@@ -882,9 +889,28 @@ int nnhip_ode_solve_batch_sorted_f64_dev(const nnhip_ode_options* opt, int integ
       HIP_TRY(nnhip::negate_f64(key, key, N, s));  // furthest first; the order among equal keys is the caller's (stable sort)
       sort_key = key;
     }
-    HIP_TRY(nnhip::argsort_f64(sort_key, N, perm, sortWs, sortWsBytes, s));
+    // Nothing to gain?  Keys within 5 % of each other (relative to their magnitude: a parameter sweep over [100, 101], a probe in which every
+    // IVP got equally far) promise no better lane utilisation than the caller's order, and the sort + the indirection would cost ~20 % of such a
+    // solve (profiles/r03_bench_divergence.json: 0.78 vs 0.65 ms).  The key's range is reduced on the device into page-locked host memory;
+    // reading it synchronises `stream` once (the one place this entry waits for the device).
+    static_assert(sizeof(unsigned long long) == sizeof(double), "the key range shares the pinned staging buffer");
+    bool worthSorting = true;
+    if (g_sort_min_spread > 0.0 && N >= 4096) {  // (a small batch is sorted in any case: the check would cost as much)
+      rc = stage_reserve(2);
+      if (rc) return rc;
+      unsigned long long* img = (unsigned long long*)g_stage.host;
+      if (sortWsBytes < nnhip::key_range_scratch_bytes()) return fail(NNHIP_EVALUE, "workspace too small");
+      HIP_TRY(nnhip::key_range_f64(sort_key, N, sortWs, img, s));  // (the sort's own workspace is free until the sort)
+      HIP_TRY(hipStreamSynchronize(s));
+      double mn = 0.0, mx = 0.0;
+      nnhip::key_range_decode(img, &mn, &mx);
+      const double scale = std::fabs(mn) > std::fabs(mx) ? std::fabs(mn) : std::fabs(mx);
+      worthSorting = mn <= mx && scale > 0.0 && (mx - mn) > g_sort_min_spread * scale;
+    }
+    if (worthSorting) HIP_TRY(nnhip::argsort_f64(sort_key, N, perm, sortWs, sortWsBytes, s));
+    else sorted = false;
   }
-  if (adaptive && N > 1 && g_sort_copy && dim >= 1) {
+  if (sorted && g_sort_copy && dim >= 1) {
     // The batch in integration order, physically: gather y0 (and the per-IVP parameter table), solve with coalesced accesses, scatter the
     // rows and counters back to the caller's order.  Temporaries come from the stream-ordered allocator; if that fails the solve
     // kernel follows `perm` itself (SolveArgs::perm, below).
@@ -918,10 +944,10 @@ int nnhip_ode_solve_batch_sorted_f64_dev(const nnhip_ode_options* opt, int integ
     }
     (void)hipGetLastError();
   }
-  int rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y0, N, dim, layout, tspan, n_t, t_out, y_out, ny_out,
-                         steps_out, rejected_out, max_steps, ws, wsTimes, nullptr, nullptr, s, ps);
+  rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y0, N, dim, layout, tspan, n_t, t_out, y_out, ny_out,
+                     steps_out, rejected_out, max_steps, ws, wsTimes, nullptr, nullptr, s, ps);
   if (rc) return rc;
-  if (adaptive && N > 1) ps.a.perm = perm;
+  if (sorted) ps.a.perm = perm;
   return launch_solve_range(ps, 0, N, s);
 }
 

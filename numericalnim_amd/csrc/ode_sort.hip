@@ -157,6 +157,72 @@ hipError_t invert_perm(const uint32_t* perm, uint32_t* inv, int64_t N, hipStream
   return hipLaunchKernel((const void*)invert_perm_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), args, 0, s);
 }
 
+// min / max of the finite keys, written straight into page-locked host memory (`out2`: {min, max}; {+inf, -inf} when no key is finite): one
+// kernel, one stream synchronisation by the caller.  Order-preserving 64-bit images make it an integer atomicMin / atomicMax.
+namespace {
+__device__ unsigned long long ordered_u64(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+// stage 1: one partial {min, max} per block into device scratch; stage 2 (FINAL, one block): the partials into page-locked host memory, plain stores
+template <bool FINAL>
+__global__ void key_range_kernel(const double* __restrict__ keys, const unsigned long long* __restrict__ partials, int64_t n, unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long smn[4], smx[4];
+  unsigned long long mn = ~0ULL, mx = 0ULL;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if constexpr (FINAL) {
+      const unsigned long long a = partials[2 * i], b = partials[2 * i + 1];
+      mn = a < mn ? a : mn;
+      mx = b > mx ? b : mx;
+    } else {
+      const double v = keys[i];
+      if (v == v && fabs(v) != __longlong_as_double(0x7ff0000000000000LL)) {
+        const unsigned long long o = ordered_u64(v);
+        mn = o < mn ? o : mn;
+        mx = o > mx ? o : mx;
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long a = __shfl_down(mn, off, 64), b = __shfl_down(mx, off, 64);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+  if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) { mn = smn[w] < mn ? smn[w] : mn; mx = smx[w] > mx ? smx[w] : mx; }
+    out[2 * (FINAL ? 0 : blockIdx.x)] = mn;
+    out[2 * (FINAL ? 0 : blockIdx.x) + 1] = mx;
+  }
+}
+}  // namespace
+// host side of the images: {min, max} as doubles
+void key_range_decode(const unsigned long long* img, double* mn, double* mx) {
+  auto dec = [](unsigned long long o) { const unsigned long long b = (o >> 63) ? (o & 0x7fffffffffffffffULL) : ~o; double v; std::memcpy(&v, &b, 8); return v; };
+  *mn = img[0] == ~0ULL ? __builtin_inf() : dec(img[0]);
+  *mx = img[1] == 0ULL ? -__builtin_inf() : dec(img[1]);
+}
+constexpr int kKeyRangeBlocks = 256;
+int64_t key_range_scratch_bytes() { return (int64_t)kKeyRangeBlocks * 16; }
+// `scratch`: device memory of key_range_scratch_bytes(); `pinned2`: two words of page-locked host memory, valid once the stream has drained
+hipError_t key_range_f64(const double* keys, int64_t N, void* scratch, unsigned long long* pinned2, hipStream_t s) {
+  pinned2[0] = ~0ULL; pinned2[1] = 0ULL;  // host memory: the previous use has been waited for
+  if (N <= 0) return hipSuccess;
+  int64_t blocks = (N + 255) / 256;
+  if (blocks > kKeyRangeBlocks) blocks = kKeyRangeBlocks;
+  unsigned long long* part = (unsigned long long*)scratch;
+  const unsigned long long* none = nullptr;
+  {
+    void* args[] = {(void*)&keys, (void*)&none, (void*)&N, (void*)&part};
+    const hipError_t e = hipLaunchKernel((const void*)key_range_kernel<false>, dim3((unsigned)blocks), dim3(256), args, 0, s);
+    if (e != hipSuccess) return e;
+  }
+  const double* nokeys = nullptr;
+  void* args[] = {(void*)&nokeys, (void*)&part, (void*)&blocks, (void*)&pinned2};
+  return hipLaunchKernel((const void*)key_range_kernel<true>, dim3(1), dim3(256), args, 0, s);
+}
+
 hipError_t negate_f64(const double* in, double* out, int64_t N, hipStream_t s) {
   if (N <= 0) return hipSuccess;
   void* args[] = {(void*)&in, (void*)&out, (void*)&N};

@@ -797,6 +797,21 @@ def test_sort_by_returns_identical_results_in_caller_order(nn, dev, sort_copy):
         g0 = nn.solveODE(nn.Rhs.vanderpol(), y0[:, :m].contiguous(), ts, opt, integrator="tsit54", sweep=mu[None, :m].contiguous())
         g1 = nn.solveODE(nn.Rhs.vanderpol(), y0[:, :m].contiguous(), ts, opt, integrator="tsit54", sweep=mu[None, :m].contiguous(), sort_by="auto")
         assert torch.equal(g0[1], g1[1])
+    # keys within 5 % of each other (and constant / all-NaN / negative ones): the batch runs in the caller's order — same bits either way, and
+    # with the check switched off (knob 0: always sort) too
+    L = nn._lib.lib()
+    a = nn.solveODE(nn.Rhs.vanderpol(), y0, ts, opt, integrator="tsit54", sweep=mu[None, :], return_counts=True)
+    for key in (100.0 + torch.rand(n, dtype=torch.float64, device=dev), torch.full((n,), 3.0, dtype=torch.float64, device=dev),
+                torch.full((n,), float("nan"), dtype=torch.float64, device=dev), -100.0 - 2.0 * torch.rand(n, dtype=torch.float64, device=dev),
+                torch.zeros(n, dtype=torch.float64, device=dev)):
+        for permille in (50, 0):
+            assert L.nnhip_tune_set(b"sort_min_spread_permille", permille) == 0
+            try:
+                h = nn.solveODE(nn.Rhs.vanderpol(), y0, ts, opt, integrator="tsit54", sweep=mu[None, :], return_counts=True, sort_by=key)
+            finally:
+                assert L.nnhip_tune_set(b"sort_min_spread_permille", 50) == 0
+            assert torch.equal(a[1], h[1]) and all(torch.equal(a[2][k], h[2][k]) for k in a[2])
+    assert L.nnhip_tune_set(b"sort_min_spread_permille", 1001) != 0
     # lanes-per-system kernels: 16-component ring systems with per-system coupling, sorted by the coupling and automatically
     rngc = np.random.default_rng(4)
     y16 = torch.from_numpy(_ring_y0(700)).to(dev)
