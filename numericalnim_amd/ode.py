@@ -311,15 +311,45 @@ def _shape_info(y0, layout):
 def _params_array(f, ctx):
     if getattr(f, "ctx_layout", None) is not None:
         f.bind(ctx)  # NumContext.tValues / many fValues / mutable slots: the closure captures its ctx
+    elif ctx is None:  # parameters from the defaults only: marshalled once per Rhs object
+        cached = getattr(f, "_marshalled", None)
+        if cached is None or cached[0] != (f.kind, f.keys, tuple(sorted(f.defaults.items()))):
+            p = np.asarray(f.params(None), dtype=np.float64)
+            cached = f._marshalled = ((f.kind, f.keys, tuple(sorted(f.defaults.items()))), p, (p.ctypes.data_as(C.POINTER(C.c_double)) if p.size else None))
+        return cached[1], cached[2]
     p = np.asarray(f.params(ctx), dtype=np.float64)
     return p, (p.ctypes.data_as(C.POINTER(C.c_double)) if p.size else None)
 
 
+_INTEG = {}  # name as given -> (id, useFSAL, adaptive): the per-step seams are called in loops, a C call per lookup is host time
+
+
+def _integ_info(integrator):
+    info = _INTEG.get(integrator)
+    if info is None:
+        L = _lib.lib()
+        rc = L.nnhip_ode_integrator_id(str(integrator).encode())
+        if rc < 0:
+            raise ValueError(f"{integrator} is not a valid integrator")  # ode.nim:651
+        use_fsal, adaptive = C.c_int(), C.c_int()
+        _check(L.nnhip_ode_integrator_traits(rc, C.byref(use_fsal), None, C.byref(adaptive)))
+        info = _INTEG[integrator] = (rc, bool(use_fsal.value), bool(adaptive.value))
+    return info
+
+
 def integrator_id(integrator):
-    rc = _lib.lib().nnhip_ode_integrator_id(str(integrator).encode())
-    if rc < 0:
-        raise ValueError(f"{integrator} is not a valid integrator")  # ode.nim:651
-    return rc
+    return _integ_info(integrator)[0]
+
+
+def _device_scope(dev):
+    """The stream a launch on `dev` goes to, and a context manager only when `dev` is not the current device (entering torch.cuda.device costs
+    ~10 us of host time per call; a per-step driver calls the seams thousands of times)."""
+    import torch
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if idx == torch.cuda.current_device():
+        return None, (raw(idx) if raw is not None else torch.cuda.current_stream().cuda_stream)
+    return torch.cuda.device(idx), None
 
 
 def solveODE(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=LAYOUT_SOA, max_steps=0, stats=None,
@@ -453,34 +483,40 @@ def integratorStep(f, t, y, FSAL, dt, options=None, ctx=None, integrator="dopri5
     import torch
     L = _lib.lib()
     options = options if options is not None else _default_options()
-    integ = integrator_id(integrator)
+    integ, use_fsal, adaptive = _integ_info(integrator)
     p, pp = _params_array(f, ctx)
     N, dim, scalar = _shape_info(y, layout)
-    yc = y.contiguous()
-    use_fsal = C.c_int()
-    adaptive = C.c_int()
-    _check(L.nnhip_ode_integrator_traits(integ, C.byref(use_fsal), None, C.byref(adaptive)))
-    with torch.cuda.device(yc.device):
+    yc = y if y.is_contiguous() else y.contiguous()
+    scope, stream = _device_scope(yc.device)
+    if scope is not None:
+        scope.__enter__()
+    try:
         o = tuple(out) + (None,) * (4 - len(out)) if isinstance(out, (tuple, list)) else (out, None, None, None)
         for b in o:
             if b is not None and (not b.is_contiguous() or b.dtype != torch.float64 or b.device != yc.device):
                 raise ValueError("out buffers must be contiguous float64 tensors on y's device")
         y_new = o[0] if o[0] is not None else torch.empty_like(yc)
-        fs_in = FSAL.contiguous() if FSAL is not None else None
-        fs_new = (o[1] if o[1] is not None else torch.empty_like(yc)) if (use_fsal.value or FSAL is not None) else None
+        fs_in = (FSAL if FSAL.is_contiguous() else FSAL.contiguous()) if FSAL is not None else None
+        fs_new = (o[1] if o[1] is not None else torch.empty_like(yc)) if (use_fsal or FSAL is not None) else None
         t_dev = t.contiguous() if _is_torch(t) else None
         dt_dev = dt.contiguous() if _is_torch(dt) else None
-        dt_used = (o[2] if o[2] is not None else torch.empty(N, dtype=torch.float64, device=yc.device)) if adaptive.value else None
-        err = (o[3] if o[3] is not None else torch.empty(N, dtype=torch.float64, device=yc.device)) if adaptive.value else None
-        stream = torch.cuda.current_stream().cuda_stream
-        _check(L.nnhip_ode_step_batch_f64_dev(C.byref(options), integ, f.kind, pp, int(p.size), N, dim, layout,
-                                              t_dev.data_ptr() if t_dev is not None else None, 0.0 if t_dev is not None else float(t),
-                                              dt_dev.data_ptr() if dt_dev is not None else None,
-                                              0.0 if dt_dev is not None else float(dt), yc.data_ptr(),
-                                              fs_in.data_ptr() if fs_in is not None else None, y_new.data_ptr(),
-                                              fs_new.data_ptr() if fs_new is not None else None,
-                                              dt_used.data_ptr() if dt_used is not None else None,
-                                              err.data_ptr() if err is not None else None, 1 if negate_time else 0, stream))
+        dt_used = (o[2] if o[2] is not None else torch.empty(N, dtype=torch.float64, device=yc.device)) if adaptive else None
+        err = (o[3] if o[3] is not None else torch.empty(N, dtype=torch.float64, device=yc.device)) if adaptive else None
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        rc = L.nnhip_ode_step_batch_f64_dev(options, integ, f.kind, pp, p.size, N, dim, layout,
+                                            t_dev.data_ptr() if t_dev is not None else None, 0.0 if t_dev is not None else t,
+                                            dt_dev.data_ptr() if dt_dev is not None else None,
+                                            0.0 if dt_dev is not None else dt, yc.data_ptr(),
+                                            fs_in.data_ptr() if fs_in is not None else None, y_new.data_ptr(),
+                                            fs_new.data_ptr() if fs_new is not None else None,
+                                            dt_used.data_ptr() if dt_used is not None else None,
+                                            err.data_ptr() if err is not None else None, 1 if negate_time else 0, stream)
+        if rc:
+            _check(rc)
+    finally:
+        if scope is not None:
+            scope.__exit__(None, None, None)
     return y_new, fs_new, dt_used, err
 
 

@@ -44,6 +44,25 @@ for n in (1_000_000, 10_000_000):
             continue
         s, _ = timed(lambda: nn.integratorStep(nn.Rhs.lorenz(), tdev, y0, fs, dtdev, opt, integrator=integ, out=ynew))
         out[f"step_stream_lorenz_{integ}_N{n:.0e}"] = dict(us=s * 1e6, GBps=8 * (4 * 3 + 5) * n / s / 1e9)
+# the Python seam itself: 20 back-to-back integratorStep calls with preallocated outputs (what a per-step Python driver does) at C3's size, and the
+# host time of one call (1024 IVPs: the kernel is a few microseconds, the loop is bound by the wrapper)
+import time
+for n, tag in ((1_000_000, "N1e+06"), (1024, "host_bound_N1024")):
+    y0 = torch.from_numpy(np.stack([1.0 + (np.arange(n) % 1024) * 2.0 ** -20, np.ones(n), np.ones(n)])).to(dev)
+    fs = nn.rhsBatch(nn.Rhs.lorenz(), 0.0, y0)
+    tdev = torch.zeros(n, dtype=torch.float64, device=dev)
+    dtdev = torch.full((n,), 1e-3, dtype=torch.float64, device=dev)
+    opt = nn.newODEoptions(**tight)
+    bufs = (torch.empty_like(y0), torch.empty_like(y0), torch.empty(n, dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev))
+    rhs = nn.Rhs.lorenz()
+    for integ in ("rk4", "dopri54"):
+        def calls(k=20):
+            for _ in range(k):
+                nn.integratorStep(rhs, tdev, y0, fs, dtdev, opt, integrator=integ, out=bufs)
+        s, _ = timed(calls, reps=5)
+        calls(200); torch.cuda.synchronize()
+        c0 = time.perf_counter(); calls(200); c1 = time.perf_counter(); torch.cuda.synchronize()
+        out[f"python_seam_integratorStep_{integ}_{tag}"] = dict(us_per_call_back_to_back=s / 20 * 1e6, host_us_per_call_enqueue_only=(c1 - c0) / 200 * 1e6)
 # dense output: C2-like, RK4 fused, 1e7 IVPs, 33 requested times -> 33 x 80 MB written
 n = 10_000_000
 y2 = nd.c2_y0_torch(0, n, dev)
