@@ -182,28 +182,39 @@ class Rhs:
     @staticmethod
     def _check_halo(kind, dim, body, keys, defaults, name):
         """A declared halo against the undeclared form of the same body: three RK4 steps of 64 random systems through both must agree bit for
-        bit (they evaluate the same expression on the same values unless the body reads outside its window).  Needs a GPU; skipped without."""
+        bit (they evaluate the same expression on the same values unless the body reads outside its window).  Needs a GPU; skipped without.
+        Not run for a right-hand side with a context block (its vectors have no stand-in values here): there the halo is the caller's promise."""
         try:
             import torch
             if not torch.cuda.is_available():
                 return
         except ImportError:
             return
-        plain = Rhs.custom(dim, body, keys=keys, defaults=defaults, name=str(name) + "_nohalo", per_component=True)
-        declared = Rhs(kind, keys, defaults)
-        declared.dim = dim
         rng = np.random.default_rng(20260928)
-        y0 = torch.from_numpy(rng.uniform(-1.0, 1.0, (64, dim))).cuda()
-        opt = newODEoptions(dt=1e-3)
-        a = solveODE(declared, y0, [0.0, 3e-3], opt, integrator="rk4", layout=LAYOUT_AOS)[1]
-        b = solveODE(plain, y0, [0.0, 3e-3], opt, integrator="rk4", layout=LAYOUT_AOS)[1]
-        if not torch.equal(a, b):
+        # every declared key gets a value for the check (the caller's default where there is one): the check must not depend on defaults
+        syn = {k: (defaults or {}).get(k, float(rng.uniform(0.5, 1.5))) for k in keys}
+        try:
+            plain = Rhs.custom(dim, body, keys=keys, defaults=syn, name=str(name) + "_nohalo", per_component=True)
+            declared = Rhs(kind, keys, syn)
+            declared.dim = dim
+            y0 = torch.from_numpy(rng.uniform(-1.0, 1.0, (64, dim))).cuda()
+            opt = newODEoptions(dt=1e-3)
+            a = solveODE(declared, y0, [0.0, 3e-3], opt, integrator="rk4", layout=LAYOUT_AOS)[1]
+            b = solveODE(plain, y0, [0.0, 3e-3], opt, integrator="rk4", layout=LAYOUT_AOS)[1]
+            same = torch.equal(a, b)
+        except Exception:
+            _lib.lib().nnhip_ode_rhs_release(kind)  # a body that does not compile against the window, a launch failure: the kind is not kept
+            raise
+        if not same:
             _lib.lib().nnhip_ode_rhs_release(kind)
             raise ValueError("halo=(lo, hi) does not cover what the body reads: the banded form and the plain form of this right-hand side disagree")
 
-    def bind(self, ctx):
+    def bind(self, ctx, device=None):
         """Binds `ctx` to this right-hand side's context layout (nnhip_ode_rhs_bind_ctx_f64_dev): the closure capturing its ctx.
-        Called by solveODE & co. with the ctx they are given; arrays are uploaded, CUDA tensors are used in place."""
+        Called by solveODE & co. with the ctx they are given; arrays are uploaded — to `device`, the device of the batch being solved —
+        and CUDA tensors are used in place (a tensor on another device than the batch is refused).
+        The binding belongs to the compiled right-hand side (process-wide, like the reference's closure object): concurrent solves of the SAME
+        source with DIFFERENT contexts must be serialised by the caller."""
         lay = getattr(self, "ctx_layout", None)
         if lay is None:
             return
@@ -211,11 +222,12 @@ class Rhs:
         if ctx is None:
             raise ValueError("this right-hand side reads a context block: pass ctx")
         tv = ctx.tValues
-        dev = None
+        dev = device if (device is not None and device.type == "cuda") else None
         for v in tv.values():
             if _is_torch(v) and v.is_cuda:
-                dev = v.device
-                break
+                if dev is not None and v.device != dev and (dev.index is not None or v.device.index != torch.cuda.current_device()):
+                    raise ValueError(f"ctx tensor on {v.device}, batch on {dev}: the context block must live on the device that integrates")
+                dev = dev or v.device
         dev = dev or torch.device("cuda", torch.cuda.current_device())
 
         def to_dev(v):
@@ -308,9 +320,10 @@ def _shape_info(y0, layout):
     return shp[0], shp[1], False
 
 
-def _params_array(f, ctx):
+def _params_array(f, ctx, like=None):
+    """like: the state batch of the call (its device is where a context block has to live)"""
     if getattr(f, "ctx_layout", None) is not None:
-        f.bind(ctx)  # NumContext.tValues / many fValues / mutable slots: the closure captures its ctx
+        f.bind(ctx, like.device if (like is not None and _is_torch(like)) else None)  # NumContext.tValues / many fValues / mutable slots: the closure captures its ctx
     elif ctx is None:  # parameters from the defaults only: marshalled once per Rhs object
         cached = getattr(f, "_marshalled", None)
         if cached is None or cached[0] != (f.kind, f.keys, tuple(sorted(f.defaults.items()))):
@@ -375,7 +388,7 @@ def solveODE(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=
     integ = integrator_id(integrator)
     tspan = np.ascontiguousarray(np.asarray(tspan, dtype=np.float64))
     n_t = int(tspan.size)
-    p, pp = _params_array(f, ctx)
+    p, pp = _params_array(f, ctx, y0)
     t_out = np.empty(max(n_t, 1), dtype=np.float64)
     tp = t_out.ctypes.data_as(C.POINTER(C.c_double))
     tsp = tspan.ctypes.data_as(C.POINTER(C.c_double))
@@ -484,7 +497,7 @@ def integratorStep(f, t, y, FSAL, dt, options=None, ctx=None, integrator="dopri5
     L = _lib.lib()
     options = options if options is not None else _default_options()
     integ, use_fsal, adaptive = _integ_info(integrator)
-    p, pp = _params_array(f, ctx)
+    p, pp = _params_array(f, ctx, y)
     N, dim, scalar = _shape_info(y, layout)
     yc = y if y.is_contiguous() else y.contiguous()
     scope, stream = _device_scope(yc.device)
@@ -527,7 +540,7 @@ def fixedStream(f, y, t0, tEnd, options=None, ctx=None, integrator="rk4", layout
     L = _lib.lib()
     options = options if options is not None else _default_options()
     integ = integrator_id(integrator)
-    p, pp = _params_array(f, ctx)
+    p, pp = _params_array(f, ctx, y)
     N, dim, scalar = _shape_info(y, layout)
     if not y.is_contiguous():
         raise ValueError("y must be contiguous (it is updated in place)")
@@ -553,7 +566,7 @@ def solveODEPerIvpEnd(f, y0, t_end, options=None, ctx=None, integrator="dopri54"
     L = _lib.lib()
     options = options if options is not None else _default_options()
     integ = integrator_id(integrator)
-    p, pp = _params_array(f, ctx)
+    p, pp = _params_array(f, ctx, y0)
     N, dim, scalar = _shape_info(y0, layout)
     y0c = y0.contiguous()
     te = t_end.contiguous()
@@ -593,7 +606,7 @@ def solveODEPerIvpTspan(f, y0, tspans, options=None, ctx=None, integrator="dopri
     L = _lib.lib()
     options = options if options is not None else _default_options()
     integ = integrator_id(integrator)
-    p, pp = _params_array(f, ctx)
+    p, pp = _params_array(f, ctx, y0)
     N, dim, scalar = _shape_info(y0, layout)
     y0c = y0.contiguous()
     ts = tspans.contiguous()
@@ -634,7 +647,7 @@ def solveODECalls(f, y0, t_end, options=None, ctx=None, integrator="dopri54", la
     ODEoptions object, a sequence of N of them, or None.  Returns (y [2, *y0.shape], counts) like solveODEPerIvpEnd."""
     L = _lib.lib()
     integ = integrator_id(integrator)
-    p, pp = _params_array(f, ctx)
+    p, pp = _params_array(f, ctx, y0)
     y0c = np.ascontiguousarray(np.asarray(y0, dtype=np.float64))
     N, dim, scalar = _shape_info(y0c, layout)
     te = np.ascontiguousarray(np.asarray(t_end, dtype=np.float64))
@@ -673,7 +686,7 @@ def solveODECallsTspan(f, y0, tspans, options=None, ctx=None, integrator="dopri5
     Returns (t [N, n_t], y [n_t, *y0.shape], counts) like solveODEPerIvpTspan."""
     L = _lib.lib()
     integ = integrator_id(integrator)
-    p, pp = _params_array(f, ctx)
+    p, pp = _params_array(f, ctx, y0)
     y0c = np.ascontiguousarray(np.asarray(y0, dtype=np.float64))
     N, dim, scalar = _shape_info(y0c, layout)
     ts = np.ascontiguousarray(np.asarray(tspans, dtype=np.float64))
@@ -717,7 +730,7 @@ def fixedStreamSolve(f, y0, tspan, options=None, ctx=None, integrator="rk4", lay
     L = _lib.lib()
     options = options if options is not None else _default_options()
     integ = integrator_id(integrator)
-    p, pp = _params_array(f, ctx)
+    p, pp = _params_array(f, ctx, y0)
     N, dim, scalar = _shape_info(y0, layout)
     tspan = np.ascontiguousarray(np.asarray(tspan, dtype=np.float64))
     n_t = int(tspan.size)
@@ -752,7 +765,7 @@ def adaptiveStreamSolve(f, y0, tspan, options=None, ctx=None, integrator="dopri5
     L = _lib.lib()
     options = options if options is not None else _default_options()
     integ = integrator_id(integrator)
-    p, pp = _params_array(f, ctx)
+    p, pp = _params_array(f, ctx, y0)
     N, dim, scalar = _shape_info(y0, layout)
     tspan = np.ascontiguousarray(np.asarray(tspan, dtype=np.float64))
     n_t = int(tspan.size)
@@ -788,7 +801,7 @@ def adaptiveStream(f, y, t0, tEnd, options=None, ctx=None, integrator="dopri54",
     L = _lib.lib()
     options = options if options is not None else _default_options()
     integ = integrator_id(integrator)
-    p, pp = _params_array(f, ctx)
+    p, pp = _params_array(f, ctx, y)
     N, dim, scalar = _shape_info(y, layout)
     if not y.is_contiguous():
         raise ValueError("y must be contiguous (it is updated in place)")

@@ -73,3 +73,39 @@ echo "nim shim ok"
                         str(prog)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "nim shim ok" in r.stdout
+
+
+def test_rhs_macro_translates_a_nim_body(tmp_path):
+    """nim/rhs_macro.nim: `deviceRhs` turns a restricted Nim body (the user's f(t, y, ctx), ode.nim:36) into the HIP source the backend compiles;
+    its self-test compares the emitted text for Lorenz with the expected one, and a Lorenz batch solved through the macro must equal the
+    compiled-in kind bit for bit.  Needs Nim AND the numericalnim package (the shim imports it)."""
+    nim = _nim()
+    probe = subprocess.run([nim, "c", "--hints:off", "--eval:import numericalnim"], capture_output=True, text=True, timeout=300)
+    if probe.returncode != 0:
+        pytest.skip("Nim is here but the numericalnim package is not installed: nim/rhs_macro.nim imports the shim, which imports it")
+    r = subprocess.run([nim, "c", "-r", "--hints:off", f"--passL:-L{LIBDIR} -lnnhip_ode -Wl,-rpath,{LIBDIR}", f"--nimcache:{tmp_path}/cache0",
+                        os.path.join(ROOT, "nim", "rhs_macro.nim")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    prog = tmp_path / "macro_lorenz.nim"
+    prog.write_text(f'''
+import std/tables
+import numericalnim
+import "{os.path.join(ROOT, "nim", "numericalnim_hip")}"
+import "{os.path.join(ROOT, "nim", "rhs_macro")}"
+let f = deviceRhs(3, ["sigma", "rho", "beta"]):
+  dy[0] = ctx.fValues["sigma"] * (y[1] - y[0])
+  dy[1] = y[0] * (ctx.fValues["rho"] - y[2]) - y[1]
+  dy[2] = y[0] * y[1] - ctx.fValues["beta"] * y[2]
+var ctx = newNumContext[OdeBatch, float]()
+ctx.fValues["sigma"] = 10.0; ctx.fValues["rho"] = 28.0; ctx.fValues["beta"] = 8.0 / 3.0
+let batch = OdeBatch(n: 2, dim: 3, layout: layoutSoA, data: @[1.0, 1.5, 1.0, 1.0, 1.0, 1.0])
+let (t1, y1) = solveODE(f, batch, @[0.0, 0.5, 1.0], ctx = ctx, integrator = "tsit54")
+let (t2, y2) = solveODE(RhsSpec(kind: rhsLorenz, keys: @["sigma", "rho", "beta"]), batch, @[0.0, 0.5, 1.0], ctx = ctx, integrator = "tsit54")
+doAssert t1 == t2
+for j in 0 ..< t1.len: doAssert y1[j].data == y2[j].data
+echo "nim rhs macro ok"
+''')
+    r = subprocess.run([nim, "c", "-r", "--hints:off", "-d:release", f"--passL:-L{LIBDIR} -lnnhip_ode -Wl,-rpath,{LIBDIR}", f"--nimcache:{tmp_path}/cache",
+                        str(prog)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "nim rhs macro ok" in r.stdout
