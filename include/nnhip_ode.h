@@ -6,6 +6,17 @@
  * (see INTEGRATION.md for the Nim stub).  Each entry cites the reference interface it replaces,
  * relative to /root/reference/src/numericalnim/.
  *
+ * CORE ABI (frozen at NNHIP_ABI_VERSION 1 — what a Nim host needs; everything else in this file is an extension built on the same
+ * conventions and may grow): entries marked [core] below —
+ *   nnhip_abi_version, nnhip_last_error, nnhip_device_count, nnhip_release                       library
+ *   nnhip_ode_new_options, nnhip_ode_integrator_id                                               newODEoptions / the `integrator` string
+ *   nnhip_ode_solve_batch_f64                                                                    solveODE over a batch, host arrays
+ *   nnhip_ode_solve_workspace_bytes, nnhip_ode_solve_batch_f64_dev                               the same on device-resident batches
+ *   nnhip_ode_step_batch_f64_dev                                                                 one IntegratorProc call (the plugin seam)
+ *   nnhip_ode_fixed_stream_f64_dev, nnhip_ode_adaptive_stream_workspace_bytes, nnhip_ode_adaptive_stream_f64_dev   ODESolver's loops over that seam
+ *   nnhip_ode_rhs_compile, nnhip_ode_rhs_release                                                 a user right-hand side (from nim/rhs_macro.nim's output)
+ *   nnhip_ode_solve_batch_multi_gpu_f64, nnhip_allgather_states_f64_dev                          shards over the devices of one node
+ *
  * Conventions
  *   - A *batch* is N independent IVPs that share (f, tspan, options, integrator); IVP i has its own y0.
  *   - State arrays are float64.  dim = components per IVP; the scalar `float` state path of the
@@ -85,8 +96,11 @@ typedef struct nnhip_ode_stats {
 } nnhip_ode_stats;
 
 /* ---- library / device ------------------------------------------------------------------------ */
+/* [core] */
 int nnhip_abi_version(void);
+/* [core] */
 int nnhip_device_count(void);            /* >=0, or NNHIP_EHIP                                              */
+/* [core] */
 const char* nnhip_last_error(void);      /* thread-local, never NULL                                        */
 const char* nnhip_build_info(void);
 /* Which libhiprtc (path, version) compiles right-hand sides given as source.  A host process may bundle an older ROCm than the one this library
@@ -100,6 +114,7 @@ const char* nnhip_rtc_compiler(void);
  * stream / event contexts of the host-pointer solve, the RCCL communicators.  Everything is rebuilt on demand; compiled user
  * right-hand sides are released one by one with nnhip_ode_rhs_release.  Call it from each thread that used the library if a
  * clean shutdown matters; not calling it is harmless. */
+/* [core] */
 int nnhip_release(void);
 
 /* Page-locked host memory for the buffers handed to nnhip_ode_solve_batch_f64: with page-locked y0 and y_out the transfers
@@ -138,11 +153,13 @@ int nnhip_tune_set(const char* key, int value);
 /* ---- options / dispatch (host only, no device needed) ---------------------------------------- */
 /* newODEoptions (ode.nim:78-102): abs() of everything but tStart; NNHIP_EVALUE if |dtMax| < |dtMin|,
  * |scaleMax| < 1 or 1 < |scaleMin|.  Argument order = the Nim proc's. */
+/* [core] */
 int nnhip_ode_new_options(nnhip_ode_options* out, double dt, double absTol, double relTol, double dtMax, double dtMin,
                           double scaleMax, double scaleMin, double tStart);
 /* DEFAULT_ODEoptions (ode.nim:104): dt=1e-4 absTol=relTol=1e-4 dtMax=1e-2 dtMin=1e-4 scale 4/0.1 tStart=0 */
 int nnhip_ode_default_options(nnhip_ode_options* out);
 /* `case integrator.toLower()` (ode.nim:607-651): id, or NNHIP_EINTEGRATOR. */
+/* [core] */
 int nnhip_ode_integrator_id(const char* name);
 const char* nnhip_ode_integrator_name(int integrator);
 /* (useFSAL, order, adaptive) triple the dispatch passes to ODESolver (ode.nim:608-649). */
@@ -174,6 +191,7 @@ int nnhip_ode_supported(int integrator, int rhs_kind, int dim, int layout, int m
  *   steps_out / rejected_out [N] nullable per-IVP counters
  *   max_steps              safety cap on integrator calls per IVP and direction; <= 0 = unlimited
  * Host-pointer form; device = HIP device ordinal. */
+/* [core] */
 int nnhip_ode_solve_batch_f64(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
                               int n_params, const double* y0, int64_t N, int dim, int layout, const double* tspan,
                               int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
@@ -189,7 +207,9 @@ int nnhip_ode_solve_batch_sweep_f64(const nnhip_ode_options* opt, int integrator
 /* Device-pointer form (asynchronous on `stream`).  y0/y_out/ny_out/steps_out/rejected_out are device
  * pointers on the current device; tspan/t_out stay host pointers (tiny, shared by the batch).
  * `ws` is a device workspace of at least nnhip_ode_solve_workspace_bytes(n_t) bytes. */
+/* [core] */
 int64_t nnhip_ode_solve_workspace_bytes(int n_t);
+/* [core] */
 int nnhip_ode_solve_batch_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
                                   int n_params, const double* y0, int64_t N, int dim, int layout, const double* tspan,
                                   int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
@@ -288,6 +308,7 @@ int nnhip_ode_solve_batch_sorted_f64_dev(const nnhip_ode_options* opt, int integ
  * fsal_in/fsal_out may be NULL for non-FSAL methods; dt_used/error may be NULL for fixed-step methods
  * (they return their input dt and 0.0).  In-place (y_out == y_in, fsal_out == fsal_in) is allowed.
  * negate_time != 0 integrates g(t,y) = -f(-t,y) (backward branch, ode.nim:545). */
+/* [core] */
 int nnhip_ode_step_batch_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
                                  int n_params, int64_t N, int dim, int layout, const double* t_dev, double t_uniform,
                                  const double* dt_dev, double dt_uniform, const double* y_in, const double* fsal_in,
@@ -299,6 +320,7 @@ int nnhip_ode_step_batch_f64_dev(const nnhip_ode_options* opt, int integrator, i
  * y (device, in `layout`) is advanced in place from t0 to tEnd; `scratch` (device, dim*N doubles,
  * nullable) enables ping-pong instead of in-place.  Returns the number of steps via n_steps_out.
  * Works for every fixed-step integrator; asynchronous on `stream`. */
+/* [core] */
 int nnhip_ode_fixed_stream_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
                                    int n_params, int64_t N, int dim, int layout, double t0, double tEnd, double* y,
                                    double* scratch, int64_t* n_steps_out, double** y_final, void* stream);
@@ -349,13 +371,16 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
  * before it waits (groups can be replayed from a hipGraph on a non-default stream: knob "stream_graph" = 1), so up to 2*check_every trailing launches
  * find nothing to do (they read t only).  Results are bitwise those of the fused solve.  Thread-per-IVP kernels for small
  * systems, lanes-per-system kernels for Vector[float] states of 8 / 16 / 32 ... components (ahead of time or run-time compiled). */
+/* [core] */
 int64_t nnhip_ode_adaptive_stream_workspace_bytes(int64_t N, int dim);
+/* [core] */
 int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
                                       int n_params, int64_t N, int dim, int layout, double t0, double tEnd, double* y, void* ws,
                                       int64_t ws_bytes, int check_every, int64_t max_launches, int64_t* launches_out, void* stream);
 
 /* ---- multi-GPU (one process, n_gpus devices): contiguous shards of the IVP index range, no exchange
  * during integration, final trajectory tensor reassembled on every device's host view.  Host pointers. */
+/* [core] */
 int nnhip_ode_solve_batch_multi_gpu_f64(const nnhip_ode_options* opt, int integrator, int rhs_kind,
                                         const double* rhs_params, int n_params, const double* y0, int64_t N, int dim,
                                         int layout, const double* tspan, int n_t, double* t_out, double* y_out,
@@ -380,6 +405,7 @@ int nnhip_ode_solve_batch_multi_gpu_sweep_f64(const nnhip_ode_options* opt, int 
  * *rhs_kind_out receives a handle (>= NNHIP_RHS_USER_BASE) accepted by every entry that takes rhs_kind
  * (thread-per-IVP kernels; dim 1..16).  The body is syntax-checked at registration; NNHIP_EVALUE + the compiler
  * log in nnhip_last_error() on failure. */
+/* [core] */
 int nnhip_ode_rhs_compile(const char* name, int dim, int n_params, const char* body, int* rhs_kind_out);
 /* Per-component form: `comp_body` is the body of
  *     __device__ double rhs_comp(double t, int c, const double* y, const double* p)   // returns dy_c
@@ -430,6 +456,7 @@ int nnhip_ode_rhs_read_aux_f64(int rhs_kind, double* aux_out);
  * with clamped neighbours, i.e. wrong numbers: declare what the body reads (the Python mirror checks a declaration against the undeclared
  * form on a random batch).  Call before the first solve; code objects compiled earlier are dropped. */
 int nnhip_ode_rhs_set_halo(int rhs_kind, int lo, int hi);
+/* [core] */
 int nnhip_ode_rhs_release(int rhs_kind);
 
 /* Device-resident reassembly (BASELINE.json config C5): one process, n_gpus devices, RCCL over xGMI.  shard[r] lives on
@@ -437,6 +464,7 @@ int nnhip_ode_rhs_release(int rhs_kind);
  * receives the whole tensor ([dim][N] / [N][dim], N = sum counts).  Equal shards use one ncclAllGather per component
  * plane (SoA) or one in total (AoS); ragged shards one ncclBroadcast per shard.  Enqueued on streams[r] (nullable).
  * RCCL is loaded lazily (dlopen); failure text: nnhip_multigpu_last_error(). */
+/* [core] */
 int nnhip_allgather_states_f64_dev(int n_gpus, const double* const* shard, const int64_t* counts, int dim, int layout,
                                    double* const* full, void* const* streams);
 /* BASELINE.json config C5 behind ONE call: "shards across the 8 GPUs with an RCCL all-gather over xGMI only to reassemble".  One
