@@ -703,7 +703,7 @@ NNHIP_DEV void controller_prologue() {
 // (ode.nim:537) evaluates exactly that expression on the error this call returns, so the one pow per attempt is evaluated at
 // one place — here — for both the in-step shrink (:71) and the caller's post-step update (same operands, same bits).
 template <int METHOD, bool PEEL = false, class Ops>
-NNHIP_DEV int embedded_step(const Ops& ops, double t, double& dt, const double (&y)[Ops::D], double (&fsal)[Ops::D],
+NNHIP_DEV int embedded_step(const Ops& ops, double t, double& dt, const double (&y)[Ops::D], const double (&fsal)[Ops::D], double (&fsalOut)[Ops::D],
                             double (&yNew)[Ops::D], double& error, const StepCtl& o, int64_t& rejected, double& factor) {
   constexpr int D = Ops::D;
   double ya[D], err_y[D], fsalNew[D];
@@ -827,7 +827,7 @@ NNHIP_DEV int embedded_step(const Ops& ops, double t, double& dt, const double (
   }
   }
 #pragma unroll
-  for (int c = 0; c < D; ++c) fsal[c] = fsalNew[c];
+  for (int c = 0; c < D; ++c) fsalOut[c] = fsalNew[c];  // (may be the array `fsal` itself: every read of it is done)
   return status;
 }
 
@@ -902,8 +902,7 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
   using MT = MethodTraits<METHOD>;
   double t = in.tStartEff;
   double y[D], fsal[D], yNew[D];
-  [[maybe_unused]] double lastY[DH], lastDy[DH], dyNow[DH];
-  [[maybe_unused]] double lastT = in.tStartEff;
+  [[maybe_unused]] double lastDy[DH], dyNow[DH];  // slopes at the two ends of a step whose end is interpolated (methods without FSAL evaluate them there)
 #pragma unroll
   for (int c = 0; c < D; ++c) y[c] = y0[c];
   // The reference evaluates f(t0, y, ctx) twice before the forward loop — lastIter.dy (:498) and FSAL (:506) — and g(-t0, y0) once before
@@ -913,9 +912,8 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
   ops.rhs(t, y, fsal);  // FSAL = f(t0, y) (:506) / g(-t0, y0) (:546)
   if constexpr (DENSE) {
 #pragma unroll
-    for (int c = 0; c < D; ++c) { lastY[c] = y[c]; lastDy[c] = fsal[c]; }  // lastIter (:498,:548)
+    for (int c = 0; c < D; ++c) lastDy[c] = fsal[c];  // lastIter.dy (:498,:548)
   }
-  [[maybe_unused]] bool lastDyValid = true;
   double dt = in.dtInit;
   [[maybe_unused]] Rk4Dt h4 = rk4_dt(dt);
   double error = 0.0;
@@ -1005,43 +1003,44 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
   }
   // next requested time, kept in a register and re-read only after an emission (a per-step global load otherwise)
   [[maybe_unused]] double treq = (DENSE && in.useDense && in.nReq > 0) ? (NEG ? -in.tReq[0] : in.tReq[0]) : 0.0;
-  while (t < in.tEnd) {  // :511
-    if constexpr (DENSE) if (in.useDense) {
-      if (high < denseIndex) break;  // :513-514
+  // The emission block at the head of ODESolver's loop (:512-524) interpolates between lastIter = (t, y, dy) at the START of the step just taken and
+  // the state at its end.  It is evaluated right AFTER that step (= at the head of the next iteration: nothing happens in between), where the
+  // step's own inputs — y and k1 = FSAL — are still in registers and ARE lastIter: the dense instantiation keeps no copy of the history across the
+  // step (two state vectors of VGPRs less at the step's peak: the adaptive dense solves ran 10-19 % behind the lean ones, now the same occupancy).
+  // Same operations on the same values as at the reference's place, hence the same bits.  Returns true when every requested row has been emitted
+  // (`if tPositive.high < denseIndex: break`, :513-514).
+  auto emit_due = [&](double tA, const double (&yA)[D], const double (&dyA)[D], const double (&yB)[D], const double (&dyB)[D]) -> bool {
+    if constexpr (DENSE) {
+      if (!in.useDense) return false;
+      if (high < denseIndex) return true;  // :513-514
       if (treq <= t) {
         if constexpr (!MT::fsal && !Ops::mutates) {
-          ops.rhs(t, y, dyNow);  // f(t, y, ctx) per emitted point (:521); same value each time
-          if (!lastDyValid) { ops.rhs(lastT, lastY, lastDy); lastDyValid = true; }  // deferred lastIter.dy (see below)
+          ops.rhs(t, yB, dyNow);    // f(t, y, ctx) per emitted point (:521); same value each time
+          ops.rhs(tA, yA, lastDy);  // lastIter.dy = f(t, y, ctx) of the step's start (:530): only ever read here, so evaluated here — the same call
         }
         while (treq <= t) {  // :515
-          if constexpr (!MT::fsal && Ops::mutates) ops.rhs(t, y, dyNow);  // a mutating f: once per emitted point, as the reference calls it (:521)
-          const HermiteW w = hermite_weights(treq, lastT, t);
+          if constexpr (!MT::fsal && Ops::mutates) ops.rhs(t, yB, dyNow);  // a mutating f: once per emitted point, as the reference calls it (:521)
+          const HermiteW w = hermite_weights(treq, tA, t);
           double yv[D];
 #pragma unroll
-          for (int c = 0; c < D; ++c) yv[c] = hermite_apply(w, lastY[c], y[c], lastDy[c], MT::fsal ? fsal[c] : dyNow[c]);
+          for (int c = 0; c < D; ++c) yv[c] = hermite_apply(w, yA[c], yB[c], MT::fsal ? dyA[c] : lastDy[c], MT::fsal ? dyB[c] : dyNow[c]);
           emit(denseIndex, yv);
           denseIndex += 1;
-          if (high < denseIndex) break;  // :523-524
+          if (high < denseIndex) break;  // :523-524 (the inner loop only: the iteration goes on, the next head check ends the loop)
           treq = NEG ? -in.tReq[denseIndex] : in.tReq[denseIndex];
         }
       }
     }
+    return false;
+  };
+  [[maybe_unused]] double fsalNew[D];
+  bool allEmitted = (t < in.tEnd) ? emit_due(t, y, fsal, y, fsal) : false;  // head of the first iteration: lastIter is the initial state (:498)
+  while (!allEmitted && t < in.tEnd) {  // :511
     dt = nmin(dt, in.tEnd - t);  // :525
-    if constexpr (DENSE) if (in.useDense) {           // :526-530
-      lastT = t;
-#pragma unroll
-      for (int c = 0; c < D; ++c) lastY[c] = y[c];
-      if constexpr (MT::fsal) {
-#pragma unroll
-        for (int c = 0; c < D; ++c) lastDy[c] = fsal[c];
-      } else {
-        // lastIter.dy = f(t, y, ctx) (:530) is only ever read when a requested time falls into the coming step, so it is
-        // evaluated lazily at emission time from (lastT, lastY) — the same call, hence the same bits — instead of once per step
-        // (a mutating f: once per step, here, as the reference calls it).
-        if constexpr (Ops::mutates) ops.rhs(t, y, lastDy);
-        else lastDyValid = false;
-      }
+    if constexpr (DENSE && !MT::fsal && Ops::mutates) {
+      if (in.useDense) ops.rhs(t, y, lastDy);  // lastIter.dy = f(t, y, ctx) (:530): a mutating f is called once per step, here, as the reference calls it
     }
+    const double tOld = t;
     if constexpr (METHOD == NNHIP_RK4) {
       if (dt != h4.dt) h4 = rk4_dt(dt);  // only the clipped last step changes dt
       rk4_step(ops, t, h4, y, yNew);     // :531
@@ -1050,10 +1049,8 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
       fixed_step<METHOD>(ops, t, dt, y, yNew);
       error = 0.0;
     } else {
-      status |= embedded_step<METHOD, NNHIP_PEEL_FUSED != 0>(ops, t, dt, y, fsal, yNew, error, in.ctl, rejected, factor);
+      status |= embedded_step<METHOD, NNHIP_PEEL_FUSED != 0>(ops, t, dt, y, fsal, fsalNew, yNew, error, in.ctl, rejected, factor);
     }
-#pragma unroll
-    for (int c = 0; c < D; ++c) y[c] = yNew[c];
     t += dt;  // :532
     steps += 1;
     if constexpr (MT::adaptive) {  // :533-541
@@ -1062,8 +1059,21 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
       if (dt < in.ctl.dtMin) dt = in.ctl.dtMin;
       else if (in.ctl.dtMax < dt) dt = in.ctl.dtMax;
     }
+    const bool cut = in.maxSteps > 0 && steps >= in.maxSteps;
+    if constexpr (DENSE) {
+      if (!status && !cut && t < in.tEnd) {  // the loop goes on: head of the next iteration
+        if constexpr (MT::adaptive) allEmitted = emit_due(tOld, y, fsal, yNew, fsalNew);
+        else allEmitted = emit_due(tOld, y, fsal, yNew, fsal);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < D; ++c) y[c] = yNew[c];
+    if constexpr (MT::adaptive) {
+#pragma unroll
+      for (int c = 0; c < D; ++c) fsal[c] = fsalNew[c];
+    }
     if (status) break;
-    if (in.maxSteps > 0 && steps >= in.maxSteps) { status |= 2; break; }
+    if (cut) { status |= 2; break; }
   }
   // yPositive.add(y) / yNegative.add(y) (:542,:584): appended after whatever was emitted so far
   // (denseIndex stays 0 when tspan.len == 2, so a non-dense solve returns exactly this one row).

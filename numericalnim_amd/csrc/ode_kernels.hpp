@@ -565,7 +565,7 @@ NNHIP_DEV void step_body(const StepArgs& a, const Ops& ops, int64_t i, int64_t b
     }
     int64_t rej = 0;
     double factor;
-    embedded_step<METHOD, NNHIP_PEEL_STREAM != 0>(ops, t, dt, y, fsal, yNew, error, a.ctl, rej, factor);
+    embedded_step<METHOD, NNHIP_PEEL_STREAM != 0>(ops, t, dt, y, fsal, fsal, yNew, error, a.ctl, rej, factor);
     if (a.fsal_out) {
 #pragma unroll
       for (int c = 0; c < D; ++c)
@@ -768,7 +768,7 @@ NNHIP_DEV unsigned int adv_compute(const StepArgs& a, const Ops& ops, AdvState<O
   double error = 0.0;
   int64_t rej = 0;
   double factor;
-  embedded_step<METHOD, NNHIP_PEEL_STREAM != 0>(ops, t, dt, s.y, s.fsal, r.y, error, a.ctl, rej, factor);  // :531
+  embedded_step<METHOD, NNHIP_PEEL_STREAM != 0>(ops, t, dt, s.y, s.fsal, s.fsal, r.y, error, a.ctl, rej, factor);  // :531
   t += dt;                                                              // :532
   if (error == 0.0) dt *= 5.0;                                          // :534-535
   else dt = dt * factor;                                                // :537 (the factor of the accepted attempt's error)
@@ -1131,7 +1131,7 @@ NNHIP_DEV unsigned int advance_dense_body(const StepArgs& a, const OPS& ops, int
   }
   double error = 0.0, factor;
   int64_t rej = 0;
-  embedded_step<METHOD, NNHIP_PEEL_STREAM != 0>(ops, t, dt, y, fsal, yNew, error, a.ctl, rej, factor);  // :531
+  embedded_step<METHOD, NNHIP_PEEL_STREAM != 0>(ops, t, dt, y, fsal, fsal, yNew, error, a.ctl, rej, factor);  // :531
   t += dt;                                                                      // :532
   if (error == 0.0) dt *= 5.0;
   else dt = dt * factor;
