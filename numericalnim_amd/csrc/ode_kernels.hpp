@@ -439,8 +439,9 @@ hipError_t launch_solve_tpi(const SolveArgs& a, hipStream_t s) {
 // Occupancy of the fused lanes-per-system kernels.  With 4 components per lane a 7-stage method holds ~190 VGPRs (2 waves per
 // SIMD) even without the dense-output history; asked for 3 waves the allocator fits 168 with 28-56 B of scratch per lane, and the
 // VALU-bound solve gains ~9 % (C4 Tsit54 default 7.45 -> 6.75 ms, DOPRI54 6.71 -> 6.17 ms; profiles/r02_c4_fused_ab.txt).  The
-// dense instantiations (215+ VGPRs) would spill 140-170 B and keep 2 waves.  A/B hook: -DNNHIP_LPS_WPE=n forces n for all of them.
-#ifndef NNHIP_LPS_WPE
+// dense instantiations held 215+ VGPRs while they carried the Hermite history across the step; since round 4 (rows interpolated right after the
+// step, drive()) they need 203 and are held to 3 waves as well: 16-component Tsit54 / DOPRI54 with one interior row 5.70 -> 5.37 ms, tight 1.65 -> 1.50 ms
+// (same box, scripts/ab_dense_wpe.sh).  A/B hooks: -DNNHIP_LPS_WPE=n forces n for all of them, -DNNHIP_LPS_DENSE_WAVES=n for the dense ones.
 // LDS slots of the lanes-per-system kernels: per system DIM doubles of stage arguments (ys) and DIM of squared error components (es).
 // A/B hook -DNNHIP_LPS_PAD=n: consecutive systems n doubles further apart than DIM (at a stride of exactly 128 B, DIM = 16, every
 // system of a wavefront starts in the same LDS bank and the ordered error sum reads es[j] of 8 or 16 systems at once).
@@ -453,8 +454,12 @@ template <int DIM, int CPL>
 constexpr int lps_lds_doubles() { return 2 * (kBlock / (DIM / CPL)) * lps_stride<DIM>(); }
 
 // (not the 9-stage Vern65: held to 3 waves it spills 200-340 B per lane and the 16-component solve takes 14.6 ms instead of 9.9, r03_dim16_variants.json)
+#ifndef NNHIP_LPS_DENSE_WAVES
+#define NNHIP_LPS_DENSE_WAVES 3  // waves per SIMD asked for the dense-output instantiations (MODE 1 / 3); 1 = leave it to the allocator (A/B)
+#endif
 template <int METHOD, int CPL, int MODE>
-constexpr int lps_solve_waves() { return (METHOD != NNHIP_VERN65 && CPL >= 4 && MODE == 0) ? 3 : 1; }
+constexpr int lps_solve_waves() { return (METHOD != NNHIP_VERN65 && CPL >= 4) ? (MODE == 0 ? 3 : ((MODE == 1 || MODE == 3) ? NNHIP_LPS_DENSE_WAVES : 1)) : 1; }
+#ifndef NNHIP_LPS_WPE
 #define NNHIP_LPS_ATTR __attribute__((amdgpu_waves_per_eu(lps_solve_waves<METHOD, CPL, MODE>())))
 #else
 #define NNHIP_LPS_ATTR __attribute__((amdgpu_waves_per_eu(NNHIP_LPS_WPE, NNHIP_LPS_WPE)))
