@@ -10,8 +10,11 @@ oracle restates (the 14 `*_step` procs incl. their `const` tableaux, `commonAdap
 `newODEoptions`, `hermiteSpline`, `linspace`) are run from the reference's text on the same inputs, and the oracle — and, through the
 committed vectors of tests/golden/reference_text_vectors.json, the HIP path on the GPU box — is compared with the result bit for bit.
 
+`Vector[float]` states are the reference's own object too: `newVector`, `[]`, `@`, `+ - * /`, `+. -. *. /.`, unary `-`, `abs`, `sum` -> `norm`,
+`size`, `checkVectorSizes` are utils.nim's procs, interpreted (overloads resolved by the arguments' run-time types); the Vec class below is a 20 x
+faster stand-in for runs where the state type is not what is being checked (load_reference_ode(interpret_vector=False)) — the two agree bit for bit.
+
 What is NOT interpreted (restated here instead, with citations):
-  * `Vector[T]` arithmetic (utils.nim:57-250): the Vec class below (element-wise loops, `sum` = left-to-right from 0.0);
   * the handful of std-lib procs the path calls (system.min/max/abs, math.sqrt/pow/`^`, sequtils.filter/concat, algorithm.sorted/
     reversed, strutils.toLower): `_BUILTINS`.
 Floating point: every Nim `float` operation is one Python float operation = one IEEE-754 binary64 operation of the C double CPython is
@@ -38,8 +41,8 @@ class NimError(Exception):
 # lexer
 # ----------------------------------------------------------------------------------------------------------------------------------
 _KEYWORDS = {"let", "var", "const", "proc", "template", "func", "if", "elif", "else", "while", "break", "return", "case", "of", "raise",
-             "discard", "in", "notin", "and", "or", "not", "for", "true", "false", "nil", "when"}
-_OPS = ["+.=", "-.=", "*.=", "/.=", "+.", "-.", "*.", "/.", "+=", "-=", "*=", "/=", "==", "<=", ">=", "!=", "..", "+", "-", "*", "/", "<", ">",
+             "discard", "in", "notin", "and", "or", "not", "for", "true", "false", "nil", "when", "is"}
+_OPS = ["+.=", "-.=", "*.=", "/.=", "+.", "-.", "*.", "/.", "+=", "-=", "*=", "/=", "==", "<=", ">=", "!=", "..<", "..", "+", "-", "*", "/", "<", ">",
         "=", "^", ".", ",", ":", ";", "(", ")", "[", "]", "{", "}", "@", "&", "$"]
 
 
@@ -144,8 +147,8 @@ def tokenize(text):
 # ----------------------------------------------------------------------------------------------------------------------------------
 # parser -> tuples
 # ----------------------------------------------------------------------------------------------------------------------------------
-_BIN_PREC = {"^": 10, "*": 9, "/": 9, "*.": 9, "/.": 9, "+": 8, "-": 8, "+.": 8, "-.": 8, "&": 7, "..": 6,
-             "==": 5, "<=": 5, "<": 5, ">=": 5, ">": 5, "!=": 5, "in": 5, "notin": 5, "and": 4, "or": 3}
+_BIN_PREC = {"^": 10, "*": 9, "/": 9, "*.": 9, "/.": 9, "+": 8, "-": 8, "+.": 8, "-.": 8, "&": 7, "..": 6, "..<": 6,
+             "==": 5, "<=": 5, "<": 5, ">=": 5, ">": 5, "!=": 5, "in": 5, "notin": 5, "is": 5, "and": 4, "or": 3}
 
 
 class Parser:
@@ -460,14 +463,45 @@ class Vec:
 
 
 class NimObj:
-    def __init__(self, names, values):
-        self.names, self.values = list(names), list(values)
+    def __init__(self, names, values, tname=None):
+        self.names, self.values, self.tname = list(names), list(values), tname
 
     def get(self, n):
         return self.values[self.names.index(n)]
 
     def has(self, n):
         return n in self.names
+
+
+def is_vector(v):
+    """an object built by the reference's own `Vector[T](components: ..., len: ...)` (utils.nim:14-20), interpreted"""
+    return isinstance(v, NimObj) and v.tname == "Vector"
+
+
+def _arg_fits(tword, a):
+    """How well a run-time value fits a parameter whose type starts with `tword` (overload resolution, reduced to what utils.nim / ode.nim need):
+    0 = not at all, higher = more specific."""
+    if tword in (None, "T", "auto", "untyped", "typed"): return 1
+    if is_vector(a): return 3 if tword == "Vector" else (2 if tword == "var" else 0)
+    if isinstance(a, bool): return 3 if tword == "bool" else 0
+    if isinstance(a, int): return 3 if tword in ("int", "Natural") else (2 if tword in ("float", "float64") else 0)
+    if isinstance(a, float): return 3 if tword in ("float", "float64") else 0
+    if isinstance(a, list): return 3 if tword in ("seq", "openArray", "openarray") else 0
+    return 1 if tword not in ("Vector", "float", "float64", "int", "seq", "openArray") else 0
+
+
+def pick_overload(routines, args):
+    """The routine of an overload set that accepts `args` (positional), most specific first, declaration order on ties; None if none does."""
+    best, best_score = None, -1
+    for r in routines:
+        if len(args) > len(r.params) or any(p[2] is None for p in r.params[len(args):]): continue
+        score = 0
+        for a, (pname, tword, _d) in zip(args, r.params):
+            f = _arg_fits(tword, a)
+            if f == 0: score = -1; break
+            score += f
+        if score > best_score: best, best_score = r, score
+    return best
 
 
 class Routine:
@@ -574,6 +608,8 @@ _BUILTINS = {
     "ValueError": "ValueError",
     "newVector": lambda comps: Vec(comps),                         # utils.nim:19-20
     "sgn": lambda x: (x > 0) - (x < 0),
+    "sum": nim_sum,                                                # math.sum(openArray): `for i in items(x): result = result + i` from 0.0
+    "newSeq": lambda n=0: [0.0] * int(n),                          # system.newSeq[T](n): zero-initialised
 }
 _BUILTINS = {norm_ident(k): v for k, v in _BUILTINS.items()}
 _VEC_FIRST = {"size": lambda v: len(v.c), "sum": nim_sum}          # utils.nim:57, :243-250 (overloads chosen by the argument's type)
@@ -620,7 +656,10 @@ class Interp:
         return r[0]
 
     def call(self, name, *args, **kw):
-        return self.invoke(self.routine(name), list(args), {norm_ident(k): v for k, v in kw.items()})
+        key = norm_ident(name) if name[0].isalpha() else name
+        cands = self.globals.vars.get(key) or []
+        r = (pick_overload(cands, list(args)) if len(cands) > 1 else None) or self.routine(name)
+        return self.invoke(r, list(args), {norm_ident(k): v for k, v in kw.items()})
 
     def consts_of(self, name):
         """The `const` section of a loaded proc, evaluated: {identifier as normalised: value} in declaration order."""
@@ -638,6 +677,11 @@ class Interp:
         if r.kind == "template" and any(p[1] == "untyped" for p in r.params):
             env = Env(caller_env)  # substituted in the caller's scope
         pos = list(args)
+        for a in pos:  # the generic parameter T of `proc f*[T](v: Vector[T], ...)`: the element type, for `when T is Vector` (utils.nim:244)
+            if is_vector(a):
+                comps = a.get("components")
+                env.vars["T"] = "Vector" if (comps and is_vector(comps[0])) else "float"
+                break
         for i, (pname, tword, default) in enumerate(r.params):
             if tword == "untyped":
                 if i < len(pos): env.vars[pname] = Alias(arg_nodes[i], caller_env)
@@ -661,7 +705,14 @@ class Interp:
 
     def call_value(self, fn, args, kwargs, env, arg_nodes=None, block=None):
         if isinstance(fn, list) and fn and isinstance(fn[0], Routine):
-            fn = fn[0]
+            if len(fn) == 1 and fn[0].name not in _BUILTINS:
+                fn = fn[0]
+            else:
+                r = pick_overload(fn, args)
+                if r is None:  # no user overload takes these: the std-lib proc of that name (abs(float) next to utils.nim's abs(Vector))
+                    if fn[0].name in _BUILTINS: return _BUILTINS[fn[0].name](*args, **kwargs)
+                    raise NimError(f"no overload of {fn[0].name} accepts {[type(a).__name__ for a in args]}")
+                fn = r
         if isinstance(fn, Routine):
             return self.invoke(fn, args, kwargs, caller_env=env, block=block, arg_nodes=arg_nodes)
         if callable(fn):
@@ -789,7 +840,15 @@ class Interp:
             raise NimError(f"cannot assign to {lhs[0]}")
 
     # ---- expressions ----
+    def user_op(self, op, args):
+        """utils.nim's operator procs / templates on its Vector type, from the text: the overload that takes these operands"""
+        cands = self.globals.vars.get(op)
+        r = pick_overload(cands, args) if cands else None
+        if r is None: raise NimError(f"the reference's text (as loaded) has no `{op}` for {[('Vector' if is_vector(a) else type(a).__name__) for a in args]}")
+        return self.invoke(r, list(args), {})
+
     def binop(self, op, a, b, env):
+        if is_vector(a) or is_vector(b): return self.user_op(op, [a, b])
         if hasattr(a, "binop"): return a.binop(op, b, False)  # Vec, or a caller-supplied state type (symbolic execution of a step proc)
         if hasattr(b, "binop"): return b.binop(op, a, True)
         if op in ("+.", "*.", "/.", "-."):  # ode.nim:45-52: templates on floats, interpreted from the reference's text when loaded
@@ -810,6 +869,7 @@ class Interp:
         if op == "in": return any(x == a for x in b)
         if op == "notin": return not any(x == a for x in b)
         if op == "..": return range(a, b + 1)
+        if op == "..<": return range(a, b)
         raise NimError(f"operator {op} not supported")
 
     def eval(self, node, env):
@@ -829,9 +889,12 @@ class Interp:
             op = node[1]
             if op == "and": return self.eval(node[2], env) and self.eval(node[3], env)
             if op == "or": return self.eval(node[2], env) or self.eval(node[3], env)
+            if op == "is":  # `when T is Vector`: T was bound to the element type's name when the generic proc was entered
+                return self.eval(node[2], env) == (node[3][1] if node[3][0] == "id" else None)
             return self.binop(op, self.eval(node[2], env), self.eval(node[3], env), env)
         if k == "un":
             v = self.eval(node[2], env)
+            if is_vector(v) and node[1] in ("-", "@"): return self.user_op(node[1], [v])  # utils.nim:214-218 / :43
             if node[1] == "-": return v.neg() if hasattr(v, "neg") else -v
             if node[1] == "not": return not v
             if node[1] == "@": return list(v.c) if isinstance(v, Vec) else list(v)
@@ -853,11 +916,13 @@ class Interp:
             if isinstance(base, (Routine,)) or (isinstance(base, list) and base and isinstance(base[0], Routine)) or callable(base):
                 return base  # generic instantiation: DOPRI54_step[T], newNumContext[T, float]
             i = self.eval(node[2][0][2], env)
+            if is_vector(base): return self.user_op("[]", [base, i])  # utils.nim:29
             return base.c[i] if isinstance(base, Vec) else base[i]
         if k == "call":
             fnode, arglist = node[1], node[2]
-            if arglist and arglist[0][1] == ":":  # object construction: ODEoptions(dt: ..., ...)
-                return NimObj([a[0] for a in arglist], [self.eval(a[2], env) for a in arglist])
+            if arglist and arglist[0][1] == ":":  # object construction: ODEoptions(dt: ..., ...), Vector[T](components: ..., len: ...)
+                tnode = fnode[1] if fnode[0] == "idx" else fnode
+                return NimObj([a[0] for a in arglist], [self.eval(a[2], env) for a in arglist], tname=tnode[1] if tnode[0] == "id" else None)
             args, kwargs, nodes = [], {}, []
             recv_first = None
             if fnode[0] == "dot":  # method-call syntax a.f(x) = f(a, x), unless a has a field f
@@ -897,11 +962,27 @@ def reference_available(root=REFERENCE_ROOT):
     return os.path.exists(os.path.join(root, "src", "numericalnim", "ode.nim"))
 
 
-def load_reference_ode(root=REFERENCE_ROOT):
-    """An interpreter holding ode.nim's solver procs and the utils.nim procs they call."""
+VECTOR_PROCS = ["newVector", "checkVectorSizes", "[]", "@", "size", "+", "-", "*", "/", "+.", "-.", "*.", "/.", "abs", "norm", "sum", "clone"]
+
+
+def load_reference_ode(root=REFERENCE_ROOT, interpret_vector=True):
+    """An interpreter holding ode.nim's solver procs and the utils.nim procs they call.  interpret_vector: `Vector[float]` states are the
+    reference's own object and every operator on them is utils.nim's proc, interpreted (build them with `vector(it, [...])`); False: the Vec
+    class above stands in (several times faster; used where the state type is not what is being checked)."""
     it = Interp()
     src = os.path.join(root, "src", "numericalnim")
     it.load(os.path.join(src, "ode.nim"), names=list(STEP_PROCS.values()) + ["+.", "/.", "*.", "size", "sum", "commonAdaptiveMethodCode", "newODEoptions",
                                                                           "DEFAULT_ODEoptions", "ODESolver", "solveODE"])
-    it.load(os.path.join(src, "utils.nim"), names=["hermiteSpline", "linspace"])
+    it.load(os.path.join(src, "utils.nim"), names=["hermiteSpline", "linspace"] + (VECTOR_PROCS if interpret_vector else []))
+    it.interpret_vector = interpret_vector
     return it
+
+
+def vector(it, comps):
+    """A Vector[float] state for the interpreter `it`: newVector(@[...]) of the reference's text (utils.nim:19-20), or the stand-in class."""
+    comps = [float(x) for x in comps]
+    return it.call("newVector", comps) if getattr(it, "interpret_vector", False) else Vec(comps)
+
+
+def components(v):
+    return list(v.get("components")) if is_vector(v) else list(v.c)

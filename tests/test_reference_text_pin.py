@@ -94,16 +94,42 @@ def test_linspace_of_the_reference_text(oracle):
 # ---- build container only: the interpreter re-run against the committed vectors, and the tableaux ------------------------------------
 
 def test_interpreter_rerun_matches_committed_vectors():
-    """The committed vectors are what the reference's text produces TODAY: all single steps and a sample of the solves (every 7th fixture and
-    the reference-quirk ones) are re-run from /root/reference; the full set is regenerated by tests/golden/make_reference_text_vectors.py."""
+    """The committed vectors are what the reference's text produces TODAY.  Re-run from /root/reference: all 42 single steps and the Vector-state
+    fixtures that are cheap with utils.nim's Vector operators INTERPRETED as well (every `+`, `*`, `/.`, `abs`, `sum` on a state is the
+    reference's own proc); a wider sample — every 7th fixture, the reference-quirk and dtMin ones — with a stand-in class for the Vector type (20 x
+    faster; the two agree bit for bit, which the first part shows).  The full set is regenerated by tests/golden/make_reference_text_vectors.py."""
     N, it = _ref()
     import make_reference_text_vectors as M
+    assert it.interpret_vector
     assert M.step_cases(it) == VEC["steps"]
     gold = load_cases()
+    want = {v["name"]: v for v in VEC["cases"]}
+    cheap = [c for c in gold if c["dim"] > 0 and (c["name"].startswith(("lorenz_tight", "ring16_tight", "rejecting_lorenz", "vdp_rk4", "ring4_")) or c["name"] in ("lorenz_default_vern65", "ring16_bs32"))]
+    assert len(cheap) >= 8
+    for c in cheap:
+        assert M.solve_case(it, c) == want[c["name"]], c["name"]
+    fast = N.load_reference_ode(interpret_vector=False)
     sample = [c for k, c in enumerate(gold) if k % 7 == 0 or c["name"].startswith("quirk") or c["name"].startswith("dtmin_escape")]
     for c in sample:
-        assert M.solve_case(it, c) == next(v for v in VEC["cases"] if v["name"] == c["name"]), c["name"]
+        assert M.solve_case(fast, c) == want[c["name"]], c["name"]
     assert [float(v).hex() for v in it.call("linspace", -10.0, 10.0, 100)] == VEC["linspace_m10_10_100"]
+
+
+def test_vector_operators_of_the_reference_text(oracle):
+    """utils.nim's Vector procs, interpreted, against the oracle's restatement of them (oracle_vector_op) — the operators the path uses, incl. the
+    size check that raises (utils.nim:22-26) and `sum` = left-to-right from 0.0 (utils.nim:243-250 -> :233-235)."""
+    N, it = _ref()
+    rng = np.random.default_rng(11)
+    a, b = rng.normal(size=7), rng.normal(size=7)
+    va, vb = N.vector(it, a), N.vector(it, b)
+    for op, got in (("+", it.user_op("+", [va, vb])), ("-", it.user_op("-", [va, vb])), ("*.", it.user_op("*.", [va, vb])), ("/.", it.user_op("/.", [va, vb]))):
+        assert [float(x).hex() for x in N.components(got)] == [float(x).hex() for x in oracle.vector_op(op, a, b)], op
+    assert [float(x).hex() for x in N.components(it.user_op("*", [0.3, va]))] == [float(x).hex() for x in oracle.vector_op("s*", a, d=0.3)]
+    assert [float(x).hex() for x in N.components(it.user_op("+.", [0.3, va]))] == [float(x).hex() for x in oracle.vector_op("+.", a, d=0.3)]
+    assert [float(x).hex() for x in N.components(it.call("abs", va))] == [float(x).hex() for x in oracle.vector_op("abs", a)]
+    assert float(it.call("sum", va)).hex() == float(oracle.vector_op("sum", a)[0]).hex()
+    with pytest.raises(N.NimError):
+        it.user_op("+", [va, N.vector(it, [1.0, 2.0])])
 
 
 def _device_tableau(nn, integrator, device=-1):
