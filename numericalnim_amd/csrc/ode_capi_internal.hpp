@@ -1,0 +1,102 @@
+// ode_capi_internal.hpp — what the translation units of the C ABI share (ode_capi.hip: library, options, dispatch, fused solve;
+// ode_capi_stream.hip: the step-streaming entries).  Not part of the product's interface: include/nnhip_ode.h is.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "ode_kernels.hpp"
+#include "ode_rtc.hpp"
+
+namespace nnhip_capi {
+
+int fail(int code, const char* fmt, ...);  // sets the calling thread's nnhip_last_error() text, returns `code`
+
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t _e = (expr);                                                                             \
+    if (_e != hipSuccess) return fail(NNHIP_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                      __FILE__, __LINE__);                                              \
+  } while (0)
+
+struct MethodInfo {
+  const char* name;
+  int useFSAL;
+  double order;
+  int adaptive;
+  int implemented;
+};
+// solveODE's dispatch (ode.nim:607-649), indexed by nnhip_integrator
+extern const MethodInfo kMethods[NNHIP_N_INTEGRATORS];
+
+// tuning knobs (nnhip_tune_set; defined and documented in ode_capi.hip)
+extern int g_stream_graph, g_fixed_vec_ipl, g_adv_nt, g_adv_refsal, g_adv_block, g_adv_steps, g_adv_split;
+extern nnhip::StreamTune g_tune;
+extern bool g_tune_auto;
+
+nnhip::StepLaunchFn find_step(int integrator, int rhs_kind, int dim);
+nnhip::StepLaunchFn find_advance(int integrator, int rhs_kind, int dim);
+nnhip::FixedVecLaunchFn find_fixed_vec(int integrator, int rhs_kind, int dim);
+nnhip::DenseAdvLaunch find_advance_dense(int integrator, int rhs_kind, int dim);
+bool elementwise_rhs(int k);
+int check_common(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params, int64_t N, int dim, int layout,
+                 nnhip::Params& P);
+nnhip::StepCtl ctl_of(const nnhip_ode_options* o);
+
+// Nim system.min/max (`if x <= y: x else: y`), host copy for the time loop
+inline double nmin_h(double x, double y) { return (x <= y) ? x : y; }
+inline double nmax_h(double x, double y) { return (y <= x) ? x : y; }
+
+struct TimeGrid {
+  std::vector<double> sorted, tPos, tNeg /*descending*/, tOut;
+  int nZero = 0;
+  double tEndPos = 0, tEndNeg = 0;
+};
+// ODESolver's bookkeeping before the loops (ode.nim:476-487, 510, 549, 585)
+void make_grid(const nnhip_ode_options* opt, const double* tspan, int n_t, TimeGrid& g);
+
+// pinned staging for the (tiny) requested-time arrays of the device-pointer entries
+struct Staging {
+  double* host = nullptr;
+  size_t cap = 0;
+  hipEvent_t ev = nullptr;
+  bool pending = false;
+};
+extern thread_local Staging g_stage;
+int stage_reserve(size_t n);
+
+// hipGraph caches and polling blocks of the streaming loops (ode_capi_stream.hip), released by nnhip_release() / knob changes
+void release_stream_graphs();
+void release_adv_graphs();
+
+}  // namespace nnhip_capi
+
+namespace nnhip {
+// ode_capi_aux.hip
+hipError_t launch_hermite(double x, double x1, double x2, const double* y1, const double* y2, const double* dy1, const double* dy2, double* out, int64_t n,
+                          int negate_dy, hipStream_t s);
+hipError_t launch_fill_f64(double* p, int64_t n, double v, hipStream_t s);
+// ode_sort.hip
+int64_t argsort_workspace_bytes(int64_t N);
+hipError_t argsort_f64(const double* keys, int64_t N, uint32_t* perm_out, void* ws, int64_t ws_bytes, hipStream_t s);
+hipError_t negate_f64(const double* in, double* out, int64_t N, hipStream_t s);
+hipError_t key_range_f64(const double* keys, int64_t N, void* scratch, unsigned long long* pinned2, hipStream_t s);
+int64_t key_range_scratch_bytes();
+void key_range_decode(const unsigned long long* img, double* mn, double* mx);
+hipError_t gather_f64(const double* src, double* dst, const uint32_t* perm, int64_t N, int R, int W, hipStream_t s);
+hipError_t scatter_f64(const double* src, double* dst, const uint32_t* perm, int64_t N, int R, int W, hipStream_t s);
+hipError_t scatter_i32(const int32_t* src, int32_t* dst, const uint32_t* perm, int64_t N, hipStream_t s);
+hipError_t scatter_i64(const int64_t* src, int64_t* dst, const uint32_t* perm, int64_t N, hipStream_t s);
+hipError_t gather_i32(const int32_t* src, int32_t* dst, const uint32_t* perm, int64_t N, hipStream_t s);
+hipError_t gather_i64(const int64_t* src, int64_t* dst, const uint32_t* perm, int64_t N, hipStream_t s);
+hipError_t invert_perm(const uint32_t* perm, uint32_t* inv, int64_t N, hipStream_t s);
+hipError_t prepare_tspans(const double* tspans, int n_t, int64_t N, const double* tStart, double t0, double* grid, int32_t* counts, double* t_out,
+                          hipStream_t s);
+void multigpu_release();  // ode_multigpu.hip
+int solve_host_range(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
+                     const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t NFull, int64_t lo0, int64_t N, int dim,
+                     int layout, const double* tspan, int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
+                     int64_t* rejected_out, int64_t max_steps, nnhip_ode_stats* stats, int device);
+}
