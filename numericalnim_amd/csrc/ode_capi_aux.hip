@@ -31,6 +31,21 @@ hipError_t launch_rhs_batch(int64_t N, int64_t is, int64_t cs, double t, const d
   return launch_kernel(rhs_batch_kernel<RHS>, dim3((unsigned)grid), dim3(kBlock), s, N, is, cs, t, y, dy, P);
 }
 
+// dense_rows_kernel of a compiled-in right-hand side; returns false when (rhs_kind, dim) has no ahead-of-time instantiation (the caller then
+// evaluates f and hermiteSpline in separate launches, as for run-time compiled kinds)
+bool launch_dense_rows_kind(int rhs_kind, int dim, int64_t N, int64_t is, int64_t cs, double tA, double tB, int neg, const double* yA, const double* yB,
+                            const DenseRows& r, const Params& P, hipStream_t s, hipError_t* err) {
+#define X(kind, d, T) \
+  if (rhs_kind == kind && dim == d) { *err = launch_dense_rows<T>(N, is, cs, tA, tB, neg, yA, yB, r, P, s); return true; }
+  NNHIP_FOR_EACH_TPI_RHS(X)
+#undef X
+#define X(kind, d, T, CA, CF) \
+  if (rhs_kind == kind && dim == d) { *err = launch_dense_rows<T>(N, is, cs, tA, tB, neg, yA, yB, r, P, s); return true; }
+  NNHIP_FOR_EACH_LPS_RHS(X)
+#undef X
+  return false;
+}
+
 // hermiteSpline (utils.nim:273-279) over a flat batch
 // negate_dy: the slopes are those of g(t, y) = -f(-t, y) (backward branch, ode.nim:545) while dy1 / dy2 hold f: use their negatives
 __global__ __launch_bounds__(kBlock) void hermite_kernel(double x, double x1, double x2, const double* __restrict__ y1,

@@ -78,6 +78,8 @@ namespace nnhip {
 hipError_t launch_hermite(double x, double x1, double x2, const double* y1, const double* y2, const double* dy1, const double* dy2, double* out, int64_t n,
                           int negate_dy, hipStream_t s);
 hipError_t launch_fill_f64(double* p, int64_t n, double v, hipStream_t s);
+bool launch_dense_rows_kind(int rhs_kind, int dim, int64_t N, int64_t is, int64_t cs, double tA, double tB, int neg, const double* yA, const double* yB,
+                            const DenseRows& r, const Params& P, hipStream_t s, hipError_t* err);
 // ode_sort.hip
 int64_t argsort_workspace_bytes(int64_t N);
 hipError_t argsort_f64(const double* keys, int64_t N, uint32_t* perm_out, void* ws, int64_t ws_bytes, hipStream_t s);

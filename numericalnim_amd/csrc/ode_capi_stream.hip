@@ -309,6 +309,32 @@ int nnhip_ode_fixed_stream_dense_f64_dev(const nnhip_ode_options* opt, int integ
         double treq = neg ? -req[denseIndex] : req[denseIndex];
         if (treq <= t) {
           const double* lb = lastBuf ? lastBuf : cur;
+          bool fused = false;
+          if (!exactCalls && nState) {
+            // compiled-in right-hand sides: every row due now in one pass over (lastY, y) — f at both ends and hermiteSpline inside the kernel
+            nnhip::DenseRows rows;
+            int di = denseIndex;
+            double tq = treq;
+            bool stop = false;
+            while (!stop && tq <= t) {
+              rows.n = 0;
+              while (rows.n < 8 && tq <= t) {  // :515
+                rows.treq[rows.n] = tq;
+                rows.out[rows.n] = row(rowOf(di));
+                rows.n += 1;
+                di += 1;
+                if (high < di) { stop = true; break; }  // :523-524
+                tq = neg ? -req[di] : req[di];
+              }
+              hipError_t le = hipSuccess;
+              if (!nnhip::launch_dense_rows_kind(rhs_kind, dim, N, layout == NNHIP_LAYOUT_SOA ? 1 : dim, layout == NNHIP_LAYOUT_SOA ? N : 1, lastT, t, neg ? 1 : 0,
+                                                 lb, cur, rows, P, s, &le)) break;  // no instantiation (first batch): the separate launches below
+              HIP_TRY(le);
+              fused = true;
+            }
+            if (fused) { denseIndex = di; treq = tq; }
+          }
+          if (!fused) {
           // lastIter.dy = f(lastT, lastY) (:530) and f(t, y) (:521); for the backward branch the kernels negate them (g = -f(-t, y)).
           // Lazily — only when a requested time has been passed — unless f mutates its ctx (then d1 was evaluated with the step, :530)
           int r2 = exactCalls ? NNHIP_OK : evalF(lastT, lb, d1);
@@ -320,6 +346,7 @@ int nnhip_ode_fixed_stream_dense_f64_dev(const nnhip_ode_options* opt, int integ
             denseIndex += 1;
             if (high < denseIndex) break;  // :523-524
             treq = neg ? -req[denseIndex] : req[denseIndex];
+          }
           }
         }
       }

@@ -1616,6 +1616,53 @@ __global__ __launch_bounds__(kBlock) void rhs_batch_kernel(int64_t N, int64_t iv
   for (int c = 0; c < SIZE; ++c) dy[i * ivpStride + c * compStride] = d[c];
 }
 
+// The rows due at the head of an iteration of ODESolver's loop (ode.nim:512-524), for the host-driven fixed-step dense streaming driver, in ONE
+// pass over the two ends of the step: lastIter.dy = f(lastT, lastY) (:530), f(t, y) (:521) and hermiteSpline (utils.nim:273-279) per requested time
+// — 2 state reads + 1 write per row instead of the 9 array passes of three separate launches.  neg: the backward branch's g(t, y) = -f(-t, y).
+struct DenseRows {
+  int n;            // rows of this launch (<= 8)
+  double treq[8];   // requested times (already negated for the backward branch)
+  double* out[8];   // row tensors, laid out like the state
+};
+template <class RHS>
+__global__ __launch_bounds__(kBlock) void dense_rows_kernel(int64_t N, int64_t ivpStride, int64_t compStride, double tA, double tB, int neg,
+                                                            const double* __restrict__ yA, const double* __restrict__ yB, const DenseRows r, const Params P) {
+  constexpr int D = RHS::dim, SIZE = RhsSize<RHS>::value;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N) return;
+  double a[D], b[D], da[D], db[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    a[c] = c < SIZE ? yA[i * ivpStride + c * compStride] : 0.0;
+    b[c] = c < SIZE ? yB[i * ivpStride + c * compStride] : 0.0;
+  }
+  Params Pi = P;
+  if (Pi.ivp) Pi.ivp += i;
+  if (Pi.aux) Pi.aux += i;
+  RHS::eval(neg ? -tA : tA, a, da, Pi);
+  RHS::eval(neg ? -tB : tB, b, db, Pi);
+  if (neg) {
+#pragma unroll
+    for (int c = 0; c < D; ++c) { da[c] = -da[c]; db[c] = -db[c]; }
+  }
+  for (int k = 0; k < r.n; ++k) {
+    const HermiteW w = hermite_weights(r.treq[k], tA, tB);
+    double* o = r.out[k];
+#pragma unroll
+    for (int c = 0; c < SIZE; ++c) o[i * ivpStride + c * compStride] = hermite_apply(w, a[c], b[c], da[c], db[c]);
+  }
+}
+
+#if !NNHIP_RTC
+template <class RHS>
+hipError_t launch_dense_rows(int64_t N, int64_t is, int64_t cs, double tA, double tB, int neg, const double* yA, const double* yB, const DenseRows& r, const Params& P,
+                             hipStream_t s) {
+  const int64_t grid = (N + kBlock - 1) / kBlock;
+  if (grid <= 0 || r.n <= 0) return hipSuccess;
+  return launch_kernel(dense_rows_kernel<RHS>, dim3((unsigned)grid), dim3(kBlock), s, N, is, cs, tA, tB, neg, yA, yB, r, P);
+}
+#endif
+
 #if !NNHIP_RTC
 
 template <class RHS1, int VEC, int MODE>
