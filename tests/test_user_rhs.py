@@ -23,6 +23,35 @@ def test_registration_and_compile_errors_without_gpu(nn):
     assert nn._lib.lib().nnhip_ode_rhs_release(f.kind) != 0
 
 
+def _rhs_macro_expected_sources():
+    """The HIP source nim/rhs_macro.nim's self-test says `deviceRhsSource` emits for the Lorenz body (the doAssert in its `when isMainModule`)."""
+    import os
+    import re
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nim", "rhs_macro.nim")).read()
+    m = re.search(r'doAssert src == "((?:[^"\\]|\\.)*)"', text)
+    assert m, "nim/rhs_macro.nim lost its self-test"
+    return m.group(1).encode().decode("unicode_escape")
+
+
+def test_rhs_macro_self_test_text_is_the_documented_form():
+    src = _rhs_macro_expected_sources()
+    assert src.count(";") == 3 and "p[0] * ((y[1] - y[0]))" in src and "nnhip" not in src  # one parenthesised C operation per Nim infix node
+
+
+@pytest.mark.gpu
+def test_source_the_nim_macro_emits_for_lorenz_is_the_builtin_bit_for_bit(nn, dev):
+    """nim/rhs_macro.nim cannot be compiled here, but what it EMITS can: the source text its self-test pins for the Lorenz body goes through
+    nnhip_ode_rhs_compile and must give the bits of the compiled-in kind (same association order, -ffp-contract=off)."""
+    import torch
+    f = nn.Rhs.custom(3, _rhs_macro_expected_sources(), keys=("sigma", "rho", "beta"), defaults=dict(sigma=10.0, rho=28.0, beta=8.0 / 3.0), name="lorenz_from_nim_macro")
+    n = 300
+    y0 = torch.from_numpy(np.stack([1.0 + (np.arange(n) % 1024) * 2.0 ** -20, np.ones(n), np.ones(n)])).to(dev)
+    for m in ("rk4", "tsit54", "vern65"):
+        ta, ya = nn.solveODE(f, y0, [-0.2, 0.0, 0.35, 0.5], nn.newODEoptions(dt=1e-3), integrator=m)
+        tb, yb = nn.solveODE(nn.Rhs.lorenz(), y0, [-0.2, 0.0, 0.35, 0.5], nn.newODEoptions(dt=1e-3), integrator=m)
+        assert np.array_equal(ta, tb) and torch.equal(ya, yb), m
+
+
 @pytest.mark.gpu
 def test_user_lorenz_equals_builtin_bitwise(nn, dev):
     import torch
