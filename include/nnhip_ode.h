@@ -142,6 +142,8 @@ int nnhip_host_free(void* p);
  *   coalesced accesses and scatters the results back; default 0: the solve kernel follows the order array itself — measured faster),
  *   "sort_min_spread_permille" 0..1000 (the binned solve sorts only when its keys differ by more than this fraction of their magnitude; default 50 =
  *   5 %; 0 = always sort),
+ *   "sort_resume" 0|1 (1: the automatic binned solve continues from its probe's state — forward 2-point tspans, DOPRI54 / Tsit54 / BS32 / RK21 —
+ *   instead of integrating the probed steps twice; default 0: measured no faster, the resumed pass needs the per-call instantiation of the kernel),
  *   "fixed_vec_ipl" 0|2 (0 = one IVP per lane instead of the vectorised fixed-step streaming kernel),
  *   "multi_gpu_oversubscribe" 0|1 (nnhip_ode_solve_batch_multi_gpu_f64 accepts more shards than devices: shard r on device r mod #devices),
  *   "dim16_variant" 0..4 (A/B mappings of the fused 16-component kernels), "fp_contract" 0|1 (opt-in FMA-contracted fused

@@ -66,6 +66,9 @@ int g_sort_copy = 0;      // tuning knob "sort_copy": the binned solve reorders 
                           // more than the scattered first load and last stores they remove
 int g_adv_steps = 1;      // tuning knob "adv_steps_per_launch": loop iterations per IVP and launch of nnhip_ode_adaptive_stream_f64_dev (1 = the IntegratorProc
                           // seam proper; K > 1 keeps the state in registers for K iterations: 8*(4d+5)/K bytes per attempted step, a different traffic model)
+int g_sort_resume = 0;     // tuning knob "sort_resume": the automatic binned solve continues from its probe's state instead of restarting (where the loop's state is (t, dt, y)).
+                          // Built, bit-identical, measured and NOT the default (profiles/r04_bench_divergence.json): the resumed pass has to run on the per-call instantiation of
+                          // the solve kernel (per-lane tStart / dt), which takes 1.61 ms for 122 steps where the lean one takes 1.46 ms for all 130: 1.70 vs 1.68 ms
 double g_sort_min_spread = 0.05;  // tuning knob "sort_min_spread_permille": the binned solve sorts only when the keys differ by more than this fraction of their magnitude
 int g_adv_split = 0;      // tuning knob "adv_split": index ranges the adaptive streaming loop interleaves on separate streams (0 = auto, 1, 2, 4)
 int g_dim16_variant = 0;  // tuning knob "dim16_variant": A/B mappings of the fused 16-component kernels (see ode_kernels.hpp)
@@ -353,6 +356,7 @@ int nnhip_tune_set(const char* key, int value) {
   if (k == "adv_block") { if (value != 0 && value != 64 && value != 128 && value != 256) return fail(NNHIP_EVALUE, "adv_block must be 0, 64, 128 or 256"); g_adv_block = value; release_adv_graphs(); return NNHIP_OK; }
   if (k == "sort_copy") { g_sort_copy = value != 0; return NNHIP_OK; }
   if (k == "adv_steps_per_launch") { if (value < 1 || value > 1024) return fail(NNHIP_EVALUE, "adv_steps_per_launch must be 1..1024"); g_adv_steps = value; return NNHIP_OK; }
+  if (k == "sort_resume") { if (value != 0 && value != 1) return fail(NNHIP_EVALUE, "sort_resume must be 0 or 1"); g_sort_resume = value; return NNHIP_OK; }
   if (k == "sort_min_spread_permille") { if (value < 0 || value > 1000) return fail(NNHIP_EVALUE, "sort_min_spread_permille must be in 0..1000"); g_sort_min_spread = value / 1000.0; return NNHIP_OK; }
   if (k == "adv_split") { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(NNHIP_EVALUE, "adv_split must be 0, 1, 2 or 4"); g_adv_split = value; return NNHIP_OK; }
   if (k == "dim16_variant") { if (value < 0 || value > 4) return fail(NNHIP_EVALUE, "dim16_variant must be 0..4"); g_dim16_variant = value; return NNHIP_OK; }
@@ -655,6 +659,9 @@ static int launch_solve_range(const PreparedSolve& ps, int64_t lo, int64_t n, hi
     if (a.steps_out) a.steps_out += lo;
     if (a.rejected_out) a.rejected_out += lo;
     if (a.progress_out) a.progress_out += lo;
+    if (a.tfinal_out) a.tfinal_out += lo;
+    if (a.dtfinal_out) a.dtfinal_out += lo;
+    if (a.perCall.dtInit) a.perCall.dtInit += lo;
     if (a.perIvpParams) a.perIvpParams += lo;
     if (a.P.ivp) a.P.ivp += lo;
     if (a.P.aux) a.P.aux += lo;
@@ -791,7 +798,8 @@ int nnhip_ode_solve_batch_tspans_f64_dev(const nnhip_ode_options* opt, int integ
 // + the device sort's scratch.
 int64_t nnhip_ode_solve_sorted_workspace_bytes(int64_t N, int n_t) {
   if (N < 0) return 0;
-  return ((nnhip_ode_solve_workspace_bytes(n_t) + 255) & ~(int64_t)255) + (((int64_t)N * 4 + 255) & ~(int64_t)255) + (((int64_t)N * 8 + 255) & ~(int64_t)255) +
+  // [requested times / schedule][perm: 4N][key: 8N][resume state t, dt, tEnd: 3 x 8N][argsort workspace]
+  return ((nnhip_ode_solve_workspace_bytes(n_t) + 255) & ~(int64_t)255) + (((int64_t)N * 4 + 255) & ~(int64_t)255) + 4 * (((int64_t)N * 8 + 255) & ~(int64_t)255) +
          nnhip::argsort_workspace_bytes(N) + 256;
 }
 
@@ -813,25 +821,43 @@ int nnhip_ode_solve_batch_sorted_f64_dev(const nnhip_ode_options* opt, int integ
   char* base = (char*)ws;
   const int64_t wsTimes = (nnhip_ode_solve_workspace_bytes(n_t) + 255) & ~(int64_t)255;
   uint32_t* perm = (uint32_t*)(base + wsTimes);
+  const int64_t colBytes = ((int64_t)N * 8 + 255) & ~(int64_t)255;
   double* key = (double*)(base + wsTimes + (((int64_t)N * 4 + 255) & ~(int64_t)255));
-  void* sortWs = (char*)key + (((int64_t)N * 8 + 255) & ~(int64_t)255);
+  double* resT = (double*)((char*)key + colBytes);    // resume state of the automatic mode: t, dt where the probe stopped, and tEnd as a column
+  double* resDt = (double*)((char*)resT + colBytes);
+  double* resEnd = (double*)((char*)resDt + colBytes);
+  void* sortWs = (char*)resEnd + colBytes;
   const int64_t sortWsBytes = ws_bytes - (int64_t)((char*)sortWs - base);
   const bool adaptive = kMethods[integrator].adaptive != 0;
   PreparedSolve ps;
   bool sorted = adaptive && N > 1;  // integrate in the order of `perm`
+  bool resumed = false;             // the probe's steps are kept: the sorted pass continues from where the probe stopped
   int rc = NNHIP_OK;
   if (adaptive && N > 1) {
-    if (!sort_key) {  // pass 1: the probe.  Same solve, cut off after probe_steps accepted steps; only the progress is kept.
+    if (!sort_key) {  // pass 1: the probe.  The same solve, cut off after probe_steps accepted steps; its progress is the key.
       if (probe_steps <= 0) probe_steps = 8;  // scripts/ab_probe_steps.py (1e6 Van der Pol IVPs): 4 steps do not rank (the controller is still ramping up from dtInit), 6 -> 1.73 ms, 8 -> 1.62 ms, 12 -> 1.68 ms, 16 -> 1.73 ms
       if (max_steps > 0 && probe_steps > max_steps) probe_steps = (int)max_steps;
-      rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y0, N, dim, layout, tspan, n_t, nullptr, y_out,
-                         nullptr, nullptr, nullptr, probe_steps, ws, wsTimes, nullptr, nullptr, s, ps);
+      // Resume instead of restart where the loop's whole state is (t, dt, y): a forward 2-point tspan [tStart, tEnd], a method whose FSAL is f(t, y) of
+      // the state it returns (DOPRI54, Tsit54, BS32) or that has none (RK21), a right-hand side without mutable slots.  The probe then writes its
+      // state into the caller's own output rows and the sorted pass takes it up as N per-IVP calls [t_i, tEnd] with dtInit_i = the probe's dt (the
+      // per-call instantiation of the solve kernel, nnhip_ode_solve_batch_calls_f64_dev): the same loop iterations on the same values, 8 of ~130 steps
+      // not integrated twice.  Everything else restarts after the probe, as before.
+      TimeGrid g0;
+      if (opt && tspan && n_t == 2) make_grid(opt, tspan, n_t, g0);
+      const bool fsalIsF = integrator == NNHIP_DOPRI54 || integrator == NNHIP_TSIT54 || integrator == NNHIP_BS32 || integrator == NNHIP_RK21;
+      const bool canResume = g_sort_resume && n_t == 2 && opt && g0.tNeg.empty() && g0.tPos.size() == 1 && g0.nZero == 1 && fsalIsF && !g_sort_copy &&
+                             !nnhip::rtc_has_aux(rhs_kind) && (max_steps <= 0 || max_steps > probe_steps) && y_out != nullptr;
+      rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y0, N, dim, layout, tspan, n_t, canResume ? t_out : nullptr, y_out,
+                         nullptr, canResume ? steps_out : nullptr, canResume ? rejected_out : nullptr, probe_steps, ws, wsTimes, nullptr, nullptr, s, ps);
       if (rc) return rc;
       ps.a.progress_out = key;
+      if (canResume) { ps.a.tfinal_out = resT; ps.a.dtfinal_out = resDt; }
       rc = launch_solve_range(ps, 0, N, s);
       if (rc) return rc;
       HIP_TRY(nnhip::negate_f64(key, key, N, s));  // furthest first; the order among equal keys is the caller's (stable sort)
       sort_key = key;
+      resumed = canResume;
+      if (resumed) HIP_TRY(nnhip::launch_fill_f64(resEnd, N, g0.tEndPos, s));
     }
     // Nothing to gain?  Keys within 5 % of each other (relative to their magnitude: a parameter sweep over [100, 101], a probe in which every
     // IVP got equally far) promise no better lane utilisation than the caller's order, and the sort + the indirection would cost ~20 % of such a
@@ -887,6 +913,24 @@ int nnhip_ode_solve_batch_sorted_f64_dev(const nnhip_ode_options* opt, int integ
       return ok ? NNHIP_OK : fail(NNHIP_EHIP, "scattering the results back to the caller's order failed");
     }
     (void)hipGetLastError();
+  }
+  if (resumed) {
+    // pass 2 of the automatic mode, resuming: N per-IVP calls [t_i, tEnd] from the probe's state (row 1 of the caller's output, where the probe left it),
+    // first step size = the probe's dt, in sorted order; per-IVP counters are added to the probe's; row 0 is restored from y0 afterwards.
+    const double span2[2] = {opt->tStart, opt->tStart + 1.0};  // placeholder for validation and dispatch: the spans are per IVP
+    rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y_out + (int64_t)dim * N, N, dim, layout, span2, 2, nullptr, y_out,
+                       ny_out, steps_out, rejected_out, max_steps > 0 ? max_steps - probe_steps : 0, nullptr, 0, nullptr, nullptr, s, ps);
+    if (rc) return rc;
+    ps.a.perCall.tEnd = resEnd; ps.a.perCall.tStart = resT; ps.a.perCall.dtInit = resDt; ps.a.perCall.resume = 1;
+    ps.a.nZero = 1;
+    ps.a.uniformFull[0] = ps.a.uniformFull[1] = -1;
+    ps.a.nTail[0] = ps.a.nTail[1] = 0;
+    ps.a.accumulate = 1;
+    if (sorted) ps.a.perm = perm;
+    rc = launch_solve_range(ps, 0, N, s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(y_out, y0, (size_t)dim * (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));  // row 0 = y0 (`t0 in tspan`, ode.nim:485-487)
+    return NNHIP_OK;
   }
   rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y0, N, dim, layout, tspan, n_t, t_out, y_out, ny_out,
                      steps_out, rejected_out, max_steps, ws, wsTimes, nullptr, nullptr, s, ps);

@@ -890,6 +890,7 @@ struct DriveOut {
   int status;
   int64_t steps, rejected;
   double tFinal;  // loop variable t when the direction ended (= tEnd unless truncated by maxSteps / aborted)
+  double dtFinal; // the loop's dt at that point (after the controller's update): with tFinal and the state, where a truncated integration resumes
 };
 
 // DENSE = false is the lean instantiation for tspan.len == 2 (in.useDense must be 0): the Hermite history lastIter = (t, y, dy)
@@ -998,6 +999,7 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
       out.steps = total;
       out.rejected = 0;
       out.tFinal = t;
+      out.dtFinal = dt;
       return;
     }
   }
@@ -1083,6 +1085,7 @@ NNHIP_DEV void drive(const Ops& ops, const DriveIn& in, const double (&y0)[Ops::
   out.steps = steps;
   out.rejected = rejected;
   out.tFinal = t;
+  out.dtFinal = dt;
 }
 
 }  // namespace NNHIP_NS

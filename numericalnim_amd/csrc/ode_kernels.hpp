@@ -70,6 +70,13 @@ struct SolveArgs {
   const uint32_t* perm;
   // nullable [N]: how far the IVP got, |t - t0| summed over the directions integrated (= the full span unless max_steps cut it short)
   double* progress_out;
+  // Resuming a truncated forward integration (the automatic divergence binning continues from its probe instead of restarting): nullable [N] —
+  // the loop's t and dt when the forward branch ended.  With the state (last row) they are everything the loop carries for the methods whose
+  // FSAL is f(t, y) of that state (DOPRI54, Tsit54, BS32; RK21 has none): perCall.tStart / dtInit / resume take them back in.  NaN-aborted IVPs
+  // report tEnd (nothing to resume).  accumulate: the per-IVP counters are added to what steps_out / rejected_out hold.
+  double* tfinal_out;
+  double* dtfinal_out;
+  int accumulate;
   // Every IVP its own solveODE call (each reference call owns its tspan AND its ODEoptions, ode.nim:589-591, 476-480): device
   // arrays [N], all nullable except tEnd (tEnd == nullptr: feature off).  tspan_i = [tStart_i, tEnd_i]; n_t == 2.  tEnd > tStart
   // integrates forward (rows y0, y(tEnd)), tEnd < tStart backward (rows y(tEnd), y0), tEnd == tStart yields the reference's single
@@ -82,6 +89,8 @@ struct SolveArgs {
     const double *tEnd, *tStart, *absTol, *relTol, *dtMax, *dtMin, *dt;
     const double* tGrid;
     const int32_t* tCounts;
+    const double* dtInit;  // nullable [N] (MODE 2, adaptive): the first step size of IVP i instead of sqrt(dtMax * dtMin) — a resumed integration's dt
+    int resume;            // MODE 2: tStart_i is where a truncated forward integration stopped: tEnd_i <= tStart_i means "already there" (rows y, y; ny = 2), never backward
   } perCall;
 };
 
@@ -183,6 +192,7 @@ struct LaneStats {
   unsigned long long steps = 0, rejected = 0;
   int ny = 0x7fffffff, nanAb = 0, trunc = 0;
   double progress = 0.0;
+  double tFinal = 0.0, dtFinal = 0.0;  // of the forward branch (SolveArgs::tfinal_out)
 };
 
 // MODE: 1 = general (dense output capable), 0 = lean (tspan.len == 2: no Hermite history), 2 = lean + per-IVP 2-point tspan and
@@ -214,6 +224,7 @@ NNHIP_DEV void solve_body(const SolveArgs& a0, const OpsF& opsF, const OpsB& ops
     if (pc.dtMin) a.ctl.dtMin = fabs(pc.dtMin[ivp]);
     if constexpr (MethodTraits<METHOD>::adaptive) {
       if (pc.dtMax || pc.dtMin) a.dtInit = sqrt(a.ctl.dtMax * a.ctl.dtMin);             // :491-493
+      if constexpr (MODE == 2) { if (pc.dtInit) a.dtInit = pc.dtInit[ivp]; }             // a resumed integration's step size
       callInvalid = a.ctl.dtMax < a.ctl.dtMin || (!(a.ctl.dtMin > 0.0) && a.maxSteps <= 0);   // newODEoptions :95-96 / would never finish
     } else {
       if (pc.dt) a.dtInit = fabs(pc.dt[ivp]);                                             // :495-496
@@ -222,7 +233,7 @@ NNHIP_DEV void solve_body(const SolveArgs& a0, const OpsF& opsF, const OpsB& ops
     if constexpr (MODE == 2) {
       const double te = pc.tEnd[ivp];
       a.nPos = a.t0 < te ? 1 : 0;   // tspan.filterIt(it > t0) (:479)
-      a.nNeg = te < a.t0 ? 1 : 0;   // :480
+      a.nNeg = (te < a.t0 && !pc.resume) ? 1 : 0;   // :480 (a resumed forward integration that is already at or past its tEnd is finished)
       a.tEndPos = te;
       a.tEndNeg = -te;
       if (!(te == te) || !(a.t0 == a.t0) || fabs(te) == __longlong_as_double(0x7ff0000000000000LL)) callInvalid = true;  // non-finite spans never end
@@ -298,6 +309,8 @@ NNHIP_DEV void solve_body(const SolveArgs& a0, const OpsF& opsF, const OpsB& ops
     ls.steps += o.steps;
     ls.rejected += o.rejected;
     ls.progress += o.tFinal - in.tStartEff;
+    ls.tFinal = (o.status & kStatusNaN) ? in.tEnd : o.tFinal;
+    ls.dtFinal = o.dtFinal;
   }
   // Backward branch (ode.nim:544-584).  Emission k of this branch is element k of yNegative; the result holds
   // yNegative.reversed(), so it lands in row nNeg-1-k.
@@ -349,6 +362,16 @@ NNHIP_DEV void solve_body(const SolveArgs& a0, const OpsF& opsF, const OpsB& ops
         if (opsF.owns(c)) out[(int64_t)(rowBase + j) * rs + c * cs] = out[(int64_t)(posBase + j) * rs + c * cs];
   }
   rowBase += mPos;
+  if constexpr (MODE == 2) {
+    if (a0.perCall.resume && a.nPos == 0 && a.nNeg == 0 && rowBase == 1 && a.n_t >= 2) {  // resumed where it had already arrived: the final row is the state itself
+#pragma unroll
+      for (int c = 0; c < D; ++c)
+        if (opsF.owns(c)) out[(int64_t)rowBase * rs + c * cs] = y0[c];
+      rowBase += 1;
+      ls.tFinal = a.t0;
+      ls.dtFinal = a.dtInit;
+    }
+  }
   const double qnan = __longlong_as_double(0x7ff8000000000000LL);
   for (int j = rowBase; j < a.n_t; ++j)
 #pragma unroll
@@ -413,9 +436,11 @@ __global__ __launch_bounds__(kBlock) void solve_tpi_kernel(const SolveArgs a) {
     const TpiOps<RHS, true> opsB{P};
     solve_body<METHOD, MODE>(a, opsF, opsB, a.y0 + i * a.ivpStride, a.y_out + i * a.ivpStride, ls, i);
     if (a.ny_out) a.ny_out[i] = ls.ny;
-    if (a.steps_out) a.steps_out[i] = (int64_t)ls.steps;
-    if (a.rejected_out) a.rejected_out[i] = (int64_t)ls.rejected;
+    if (a.steps_out) a.steps_out[i] = (int64_t)ls.steps + (a.accumulate ? a.steps_out[i] : 0);
+    if (a.rejected_out) a.rejected_out[i] = (int64_t)ls.rejected + (a.accumulate ? a.rejected_out[i] : 0);
     if (a.progress_out) a.progress_out[i] = ls.progress;
+    if (a.tfinal_out) a.tfinal_out[i] = ls.tFinal;
+    if (a.dtfinal_out) a.dtfinal_out[i] = ls.dtFinal;
   }
   if (a.agg) aggregate_stats(a.agg, ls);
 }
@@ -484,9 +509,11 @@ __global__ __launch_bounds__(kBlock) NNHIP_LPS_ATTR void solve_lps_kernel(const 
     solve_body<METHOD, MODE>(a, opsF, opsB, a.y0 + i * a.ivpStride + c * a.compStride, a.y_out + i * a.ivpStride + c * a.compStride, ls, i);
     if (c == 0) {
       if (a.ny_out) a.ny_out[i] = ls.ny;
-      if (a.steps_out) a.steps_out[i] = (int64_t)ls.steps;
-      if (a.rejected_out) a.rejected_out[i] = (int64_t)ls.rejected;
+      if (a.steps_out) a.steps_out[i] = (int64_t)ls.steps + (a.accumulate ? a.steps_out[i] : 0);
+      if (a.rejected_out) a.rejected_out[i] = (int64_t)ls.rejected + (a.accumulate ? a.rejected_out[i] : 0);
       if (a.progress_out) a.progress_out[i] = ls.progress;
+      if (a.tfinal_out) a.tfinal_out[i] = ls.tFinal;
+      if (a.dtfinal_out) a.dtfinal_out[i] = ls.dtFinal;
     } else {  // count each system once in the aggregate sums
       ls.steps = 0; ls.rejected = 0; ls.nanAb = 0; ls.trunc = 0;
     }

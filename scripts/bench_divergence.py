@@ -24,8 +24,9 @@ mu2 = 100.0 + rng.random(n)   # a narrow-range key (float32 image resolves it; r
 sw2 = torch.from_numpy(mu2[None, :].copy()).to(dev)
 
 
-def solve(sweep, sort_by=None, counts=False, copy=0, tend=10.0):
+def solve(sweep, sort_by=None, counts=False, copy=0, tend=10.0, resume=0):
     L.nnhip_tune_set(b"sort_copy", copy)
+    L.nnhip_tune_set(b"sort_resume", resume)
     return nn.solveODE(nn.Rhs.vanderpol(), y0, [0.0, tend], opt, integrator="dopri54", sweep=sweep, sort_by=sort_by, return_counts=counts)
 
 
@@ -33,6 +34,7 @@ cases = {
     "random_order": lambda: solve(sw, None, True),
     "random_order_sort_key_mu": lambda: solve(sw, sw[0], True),
     "random_order_auto_probe": lambda: solve(sw, "auto", True),
+    "random_order_auto_probe_resuming": lambda: solve(sw, "auto", True, 0, 10.0, 1),   # knob sort_resume: the sorted pass continues from the probe's (t, dt, y)
     "presorted_by_caller": lambda: solve(sw_sorted, None, True),
     "sort_key_mu_perm_in_kernel": lambda: solve(sw, sw[0], False),
     "auto_probe_perm_in_kernel": lambda: solve(sw, "auto", False),
@@ -55,6 +57,7 @@ for r in range(11):
         if r == 0:
             outs[k] = out
 L.nnhip_tune_set(b"sort_copy", 0)
+L.nnhip_tune_set(b"sort_resume", 0)
 res = {}
 ref = outs["random_order"][1]
 for k, tt in times.items():

@@ -812,6 +812,33 @@ def test_sort_by_returns_identical_results_in_caller_order(nn, dev, sort_copy):
                 assert L.nnhip_tune_set(b"sort_min_spread_permille", 50) == 0
             assert torch.equal(a[1], h[1]) and all(torch.equal(a[2][k], h[2][k]) for k in a[2])
     assert L.nnhip_tune_set(b"sort_min_spread_permille", 1001) != 0
+    # automatic mode on a forward 2-point tspan: the sorted pass RESUMES from the probe's state (t, dt, y) instead of restarting — rows, row count and both
+    # counters must be those of the plain solve: every adaptive method (Vern65 restarts: its FSAL is not f(t, y)), IVPs that arrive within the probe, a
+    # max_steps cap above and below the probe, per-IVP parameters, both layouts, a probe of another length, and the knob switched off
+    tsf = [0.0, 2.0]
+    y0a = y0.t().contiguous()
+    assert L.nnhip_tune_set(b"sort_resume", 1) == 0   # (not the default: measured no faster, see ode_capi.hip)
+    for integ in ("dopri54", "tsit54", "bs32", "rk21", "vern65"):
+        for kw in (dict(), dict(max_steps=30), dict(max_steps=5), dict(probe_steps=3)):
+            kw0 = {k: v for k, v in kw.items() if k != "probe_steps"}
+            a2 = nn.solveODE(nn.Rhs.vanderpol(), y0, tsf, opt, integrator=integ, sweep=mu[None, :], return_counts=True, **kw0)
+            d2 = nn.solveODE(nn.Rhs.vanderpol(), y0, tsf, opt, integrator=integ, sweep=mu[None, :], return_counts=True, sort_by="auto", **kw)
+            assert np.array_equal(a2[0], d2[0]) and torch.equal(torch.nan_to_num(a2[1], nan=-1.0), torch.nan_to_num(d2[1], nan=-1.0)), (integ, kw)
+            assert all(torch.equal(a2[2][k], d2[2][k]) for k in a2[2]), (integ, kw)
+    short = nn.solveODE(nn.Rhs.vanderpol(), y0, [0.0, 1e-3], opt, integrator="tsit54", sweep=mu[None, :], return_counts=True)           # done within 8 steps
+    short2 = nn.solveODE(nn.Rhs.vanderpol(), y0, [0.0, 1e-3], opt, integrator="tsit54", sweep=mu[None, :], return_counts=True, sort_by="auto")
+    assert torch.equal(short[1], short2[1]) and all(torch.equal(short[2][k], short2[2][k]) for k in short[2])
+    e = nn.solveODE(nn.Rhs.vanderpol(), y0a, tsf, opt, integrator="dopri54", sweep=mu[None, :], layout=1, return_counts=True)
+    e2 = nn.solveODE(nn.Rhs.vanderpol(), y0a, tsf, opt, integrator="dopri54", sweep=mu[None, :], layout=1, return_counts=True, sort_by="auto")
+    assert torch.equal(e[1], e2[1]) and all(torch.equal(e[2][k], e2[2][k]) for k in e[2])
+    o_shift = nn.newODEoptions(absTol=1e-6, relTol=1e-6, dtMin=1e-9, dtMax=1.0, tStart=0.5)
+    g = nn.solveODE(nn.Rhs.vanderpol(), y0, [0.5, 2.5], o_shift, integrator="tsit54", sweep=mu[None, :], return_counts=True)
+    g2 = nn.solveODE(nn.Rhs.vanderpol(), y0, [2.5, 0.5], o_shift, integrator="tsit54", sweep=mu[None, :], return_counts=True, sort_by="auto")
+    assert torch.equal(g[1], g2[1]) and all(torch.equal(g[2][k], g2[2][k]) for k in g[2])
+    assert L.nnhip_tune_set(b"sort_resume", 0) == 0
+    d3 = nn.solveODE(nn.Rhs.vanderpol(), y0, tsf, opt, integrator="tsit54", sweep=mu[None, :], return_counts=True, sort_by="auto")
+    a3 = nn.solveODE(nn.Rhs.vanderpol(), y0, tsf, opt, integrator="tsit54", sweep=mu[None, :], return_counts=True)
+    assert torch.equal(a3[1], d3[1]) and all(torch.equal(a3[2][k], d3[2][k]) for k in a3[2])
     # lanes-per-system kernels: 16-component ring systems with per-system coupling, sorted by the coupling and automatically
     rngc = np.random.default_rng(4)
     y16 = torch.from_numpy(_ring_y0(700)).to(dev)
