@@ -82,7 +82,8 @@ proc tr(n: NimNode, keys: seq[string], ints: seq[string], vectors: var seq[strin
       if n[0][1].kind notin {nnkStrLit, nnkRStrLit}: fail(n, "a non-literal tValues key")
       let name = n[0][1].strVal
       if name notin vectors: vectors.add name
-      return name & "[" & trIndex(n[1], ints) & "]"
+      # brackets of a ctx vector are emitted as \x01 .. \x02: whether NAME is shared (NAME[j]) or per IVP (NAME(j)) is decided where the layout is known
+      return name & "\x01" & trIndex(n[1], ints) & "\x02"
     fail(n, "indexing")
   of nnkCall, nnkCommand:
     let f = $n[0]
@@ -152,7 +153,16 @@ template deviceRhsCtx*(dim: int, keys: static[openArray[string]], lens: openArra
     var src = st[0]
     for k, nm in st[1]:
       vs.add CtxVector(name: nm, len: lens[k], perIvp: perIvp[k])
-      if perIvp[k]: src = src.replace(nm & "[", nm & "(").replace("]", ")")  # NAME[j] -> NAME(j): per-IVP vectors are function-like on the device
+      # this vector's accesses: NAME(j) for a per-IVP vector (function-like on the device), NAME[j] for a shared one
+      var res = ""
+      var i = 0
+      while i < src.len:
+        let at = src.find(nm & "\x01", i)
+        if at < 0: (res.add src[i .. ^1]; break)
+        let close = src.find('\x02', at)
+        res.add src[i ..< at] & nm & (if perIvp[k]: "(" else: "[") & src[at + nm.len + 1 ..< close] & (if perIvp[k]: ")" else: "]")
+        i = close + 1
+      src = res
     rhsFromSourceCtx(dim, src, @keys, vs)
 
 when isMainModule:

@@ -98,10 +98,11 @@ extern "C" int nnhip_allgather_states_f64_dev(int n_gpus, const double* const* s
       if (equal) {
         rc = g_rccl.AllGather(sendPlane, recvPlane, (size_t)(counts[r] * width), ncclDouble, g_comms[r], s);
       } else {
-        for (int root = 0; root < n_gpus && rc == ncclSuccess; ++root)
-          if (counts[root] > 0)  // an empty shard (fewer IVPs than devices) contributes nothing: no zero-length collective is issued
+        for (int root = 0; root < n_gpus && rc == ncclSuccess; ++root) {
+          if (counts[root] == 0) continue;  // an empty shard (fewer IVPs than devices) contributes nothing: no zero-length collective is issued
           rc = g_rccl.Broadcast(root == r ? sendPlane : nullptr, recvPlane + lo[root] * width, (size_t)(counts[root] * width), ncclDouble, root,
                                 g_comms[r], s);
+        }
       }
     }
   }

@@ -111,12 +111,10 @@ bool rtc_is_private(const RtcApi& api) { return &api == &rtc_state().priv; }
 // Fault injection for the fall-back paths (tests/test_gpu_hiprtc_modes.py): NNHIP_HIPRTC_INJECT=compile makes the first compilation in the
 // private namespace report failure, =load makes the first module load of a privately compiled code object report failure.
 bool rtc_inject(const char* what) {
-  static std::atomic<int> armed{-1};
-  if (armed.load() < 0) { const char* e = std::getenv("NNHIP_HIPRTC_INJECT"); armed = e && *e ? 1 : 0; }
+  static std::atomic<bool> spent{false};  // one injected failure per process
   const char* e = std::getenv("NNHIP_HIPRTC_INJECT");
   if (!e || std::strcmp(e, what) != 0) return false;
-  int one = 1;
-  return armed.compare_exchange_strong(one, 0);
+  return !spent.exchange(true);
 }
 const RtcApi& rtc_api() {
   RtcState& s = rtc_state();
