@@ -142,8 +142,12 @@ int nnhip_host_free(void* p);
  *   coalesced accesses and scatters the results back; default 0: the solve kernel follows the order array itself — measured faster),
  *   "sort_min_spread_permille" 0..1000 (the binned solve sorts only when its keys differ by more than this fraction of their magnitude; default 50 =
  *   5 %; 0 = always sort),
+ *   "sort_auto_key" 0|1 (what the automatic binned solve ranks the IVPs by after its probe: 1, default, the steps still to take (tEnd - t) / dt on a
+ *   forward tspan; 0 the distance the probe covered — also what backward / two-sided tspans use; most work first either way),
+ *   "sort_rebin_steps" 0..1000000 (S > 0: the automatic binned solve — where it can resume, see "sort_resume" — takes S more accepted steps per IVP after its
+ *   probe, bins the batch again by the steps still to take, and finishes: for step sizes that change late in the span; default 0 = the probe's order throughout),
  *   "sort_resume" 0|1 (1: the automatic binned solve continues from its probe's state — forward 2-point tspans, DOPRI54 / Tsit54 / BS32 / RK21 —
- *   instead of integrating the probed steps twice; default 0: measured no faster, the resumed pass needs the per-call instantiation of the kernel),
+ *   instead of integrating the probed steps twice; default 0: within 1 % either way, the resumed pass needs the per-call instantiation of the kernel),
  *   "fixed_vec_ipl" 0|2 (0 = one IVP per lane instead of the vectorised fixed-step streaming kernel),
  *   "multi_gpu_oversubscribe" 0|1 (nnhip_ode_solve_batch_multi_gpu_f64 accepts more shards than devices: shard r on device r mod #devices),
  *   "dim16_variant" 0..4 (A/B mappings of the fused 16-component kernels), "fp_contract" 0|1 (opt-in FMA-contracted fused
@@ -285,9 +289,12 @@ int nnhip_ode_solve_batch_calls_f64(const nnhip_ode_options* opt, const nnhip_od
 /* Divergence binning: the same fused solve for batches whose members take very different step sequences (the reference runs
  * them one after the other, ode.nim:589-591; on a wavefront they share an instruction stream).  The IVPs are INTEGRATED in
  * ascending order of `sort_key` (device array [N]) and every result is WRITTEN at the IVP's own index, so outputs are in the
- * caller's order and bit-identical to nnhip_ode_solve_batch_sweep_f64_dev.  sort_key == NULL: automatic two-pass mode — a probe
- * solve of `probe_steps` accepted steps per IVP (<= 0: 8) ranks the IVPs by the progress they make, then the batch is
- * integrated in that order.  Fixed-step integrators run unsorted (no divergence), and so does a batch (of 4096 IVPs or more) whose keys lie
+ * caller's order and bit-identical to nnhip_ode_solve_batch_sweep_f64_dev.  "Order" means bins: the keys are counted into 4096 bins over the range they
+ * cover and integrated bin after bin (inside a bin in no particular order) — neighbouring lanes need similar step sequences, not a total order.
+ * Choose the key so that the IVPs with the MOST work come first (e.g. minus the stiffness parameter): the workgroups dispatched last then hold the
+ * short solves (1e6 Van der Pol IVPs: 1.33 ms against 1.44 ms for the same key ascending, profiles/r04_bench_divergence.json).
+ * sort_key == NULL: automatic two-pass mode — a probe solve of `probe_steps` accepted steps per IVP (<= 0: 8) ranks the IVPs by the steps they still have
+ * to take (knob "sort_auto_key"), most first, then the batch is integrated in that order.  Fixed-step integrators run unsorted (no divergence), and so does a batch (of 4096 IVPs or more) whose keys lie
  * within 5 % of each other (knob "sort_min_spread_permille"): nothing to gain, and the sort + indirection would cost ~20 % of such a solve.
  * Reading the keys' range synchronises `stream` once.  per_ivp_params may be NULL (n_per_ivp = 0).
  * `ws`: device workspace of nnhip_ode_solve_sorted_workspace_bytes(N, n_t) bytes.  N < 2^31. */

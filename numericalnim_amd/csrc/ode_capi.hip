@@ -66,6 +66,8 @@ int g_sort_copy = 0;      // tuning knob "sort_copy": the binned solve reorders 
                           // more than the scattered first load and last stores they remove
 int g_adv_steps = 1;      // tuning knob "adv_steps_per_launch": loop iterations per IVP and launch of nnhip_ode_adaptive_stream_f64_dev (1 = the IntegratorProc
                           // seam proper; K > 1 keeps the state in registers for K iterations: 8*(4d+5)/K bytes per attempted step, a different traffic model)
+int g_sort_auto_key = 1;   // tuning knob "sort_auto_key": what the automatic binned solve ranks by — 0 the probe's progress, 1 the steps still to take (tEnd - t) / dt (forward spans)
+int g_sort_rebin_steps = 0;  // tuning knob "sort_rebin_steps": > 0 = the resumed automatic binned solve stops after that many further accepted steps per IVP, re-bins by the steps still to take, and finishes
 int g_sort_resume = 0;     // tuning knob "sort_resume": the automatic binned solve continues from its probe's state instead of restarting (where the loop's state is (t, dt, y)).
                           // Built, bit-identical, measured and NOT the default (profiles/r04_bench_divergence.json): the resumed pass has to run on the per-call instantiation of
                           // the solve kernel (per-lane tStart / dt), which takes 1.61 ms for 122 steps where the lean one takes 1.46 ms for all 130: 1.70 vs 1.68 ms
@@ -356,6 +358,8 @@ int nnhip_tune_set(const char* key, int value) {
   if (k == "adv_block") { if (value != 0 && value != 64 && value != 128 && value != 256) return fail(NNHIP_EVALUE, "adv_block must be 0, 64, 128 or 256"); g_adv_block = value; release_adv_graphs(); return NNHIP_OK; }
   if (k == "sort_copy") { g_sort_copy = value != 0; return NNHIP_OK; }
   if (k == "adv_steps_per_launch") { if (value < 1 || value > 1024) return fail(NNHIP_EVALUE, "adv_steps_per_launch must be 1..1024"); g_adv_steps = value; return NNHIP_OK; }
+  if (k == "sort_auto_key") { if (value != 0 && value != 1) return fail(NNHIP_EVALUE, "sort_auto_key must be 0 or 1"); g_sort_auto_key = value; return NNHIP_OK; }
+  if (k == "sort_rebin_steps") { if (value < 0 || value > 1000000) return fail(NNHIP_EVALUE, "sort_rebin_steps must be in 0..1000000"); g_sort_rebin_steps = value; return NNHIP_OK; }
   if (k == "sort_resume") { if (value != 0 && value != 1) return fail(NNHIP_EVALUE, "sort_resume must be 0 or 1"); g_sort_resume = value; return NNHIP_OK; }
   if (k == "sort_min_spread_permille") { if (value < 0 || value > 1000) return fail(NNHIP_EVALUE, "sort_min_spread_permille must be in 0..1000"); g_sort_min_spread = value / 1000.0; return NNHIP_OK; }
   if (k == "adv_split") { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(NNHIP_EVALUE, "adv_split must be 0, 1, 2 or 4"); g_adv_split = value; return NNHIP_OK; }
@@ -831,6 +835,7 @@ int nnhip_ode_solve_batch_sorted_f64_dev(const nnhip_ode_options* opt, int integ
   const bool adaptive = kMethods[integrator].adaptive != 0;
   PreparedSolve ps;
   bool sorted = adaptive && N > 1;  // integrate in the order of `perm`
+  double g0End = 0.0;               // tEnd of the forward span (resumed automatic mode)
   bool resumed = false;             // the probe's steps are kept: the sorted pass continues from where the probe stopped
   int rc = NNHIP_OK;
   if (adaptive && N > 1) {
@@ -843,21 +848,25 @@ int nnhip_ode_solve_batch_sorted_f64_dev(const nnhip_ode_options* opt, int integ
       // per-call instantiation of the solve kernel, nnhip_ode_solve_batch_calls_f64_dev): the same loop iterations on the same values, 8 of ~130 steps
       // not integrated twice.  Everything else restarts after the probe, as before.
       TimeGrid g0;
-      if (opt && tspan && n_t == 2) make_grid(opt, tspan, n_t, g0);
+      if (opt && tspan && n_t >= 1) make_grid(opt, tspan, n_t, g0);
       const bool fsalIsF = integrator == NNHIP_DOPRI54 || integrator == NNHIP_TSIT54 || integrator == NNHIP_BS32 || integrator == NNHIP_RK21;
-      const bool canResume = g_sort_resume && n_t == 2 && opt && g0.tNeg.empty() && g0.tPos.size() == 1 && g0.nZero == 1 && fsalIsF && !g_sort_copy &&
+      const bool canResume = (g_sort_resume || g_sort_rebin_steps > 0) && n_t == 2 && opt && opt->dtMin > 0.0 && opt->dtMax >= opt->dtMin && g0.tNeg.empty() && g0.tPos.size() == 1 && g0.nZero == 1 && fsalIsF && !g_sort_copy &&
                              !nnhip::rtc_has_aux(rhs_kind) && (max_steps <= 0 || max_steps > probe_steps) && y_out != nullptr;
       rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y0, N, dim, layout, tspan, n_t, canResume ? t_out : nullptr, y_out,
                          nullptr, canResume ? steps_out : nullptr, canResume ? rejected_out : nullptr, probe_steps, ws, wsTimes, nullptr, nullptr, s, ps);
       if (rc) return rc;
       ps.a.progress_out = key;
-      if (canResume) { ps.a.tfinal_out = resT; ps.a.dtfinal_out = resDt; }
+      const bool byRemaining = g_sort_auto_key == 1 && g0.tNeg.empty() && !g0.tPos.empty();
+      if (canResume || byRemaining) { ps.a.tfinal_out = resT; ps.a.dtfinal_out = resDt; }
       rc = launch_solve_range(ps, 0, N, s);
       if (rc) return rc;
-      HIP_TRY(nnhip::negate_f64(key, key, N, s));  // furthest first; the order among equal keys is the caller's (stable sort)
+      // The IVPs with the most work left go FIRST (the workgroups dispatched last then hold the short solves and the kernel's tail is short:
+      // 1.35 -> 1.27 ms on the pre-sorted sweep of scripts/bench_divergence.py): ascending progress, or descending estimate of the steps still to
+      // take.  Non-finite keys sort last; the order among equal keys is the caller's (stable sort).
+      if (byRemaining) HIP_TRY(nnhip::remaining_key_f64(resT, resDt, g0.tEndPos, key, N, s));
       sort_key = key;
       resumed = canResume;
-      if (resumed) HIP_TRY(nnhip::launch_fill_f64(resEnd, N, g0.tEndPos, s));
+      if (resumed) { g0End = g0.tEndPos; HIP_TRY(nnhip::launch_fill_f64(resEnd, N, g0.tEndPos, s)); }
     }
     // Nothing to gain?  Keys within 5 % of each other (relative to their magnitude: a parameter sweep over [100, 101], a probe in which every
     // IVP got equally far) promise no better lane utilisation than the caller's order, and the sort + the indirection would cost ~20 % of such a
@@ -865,17 +874,18 @@ int nnhip_ode_solve_batch_sorted_f64_dev(const nnhip_ode_options* opt, int integ
     // reading it synchronises `stream` once (the one place this entry waits for the device).
     static_assert(sizeof(unsigned long long) == sizeof(double), "the key range shares the pinned staging buffer");
     bool worthSorting = true;
-    if (g_sort_min_spread > 0.0 && N >= 4096) {  // (a small batch is sorted in any case: the check would cost as much)
+    if (g_sort_min_spread > 0.0 && N >= 4096) {  // (a small batch is binned in any case: the check would cost as much)
       rc = stage_reserve(2);
       if (rc) return rc;
       unsigned long long* img = (unsigned long long*)g_stage.host;
-      if (sortWsBytes < nnhip::key_range_scratch_bytes()) return fail(NNHIP_EVALUE, "workspace too small");
-      HIP_TRY(nnhip::key_range_f64(sort_key, N, sortWs, img, s));  // (the sort's own workspace is free until the sort)
+      HIP_TRY(nnhip::key_range_f64(sort_key, N, sortWs, img, s));
       HIP_TRY(hipStreamSynchronize(s));
       double mn = 0.0, mx = 0.0;
       nnhip::key_range_decode(img, &mn, &mx);
       const double scale = std::fabs(mn) > std::fabs(mx) ? std::fabs(mn) : std::fabs(mx);
       worthSorting = mn <= mx && scale > 0.0 && (mx - mn) > g_sort_min_spread * scale;
+    } else {
+      HIP_TRY(nnhip::key_range_f64(sort_key, N, sortWs, nullptr, s));  // the binning reads the range on the device; nothing waits
     }
     if (worthSorting) HIP_TRY(nnhip::argsort_f64(sort_key, N, perm, sortWs, sortWsBytes, s));
     else sorted = false;
@@ -917,18 +927,35 @@ int nnhip_ode_solve_batch_sorted_f64_dev(const nnhip_ode_options* opt, int integ
   if (resumed) {
     // pass 2 of the automatic mode, resuming: N per-IVP calls [t_i, tEnd] from the probe's state (row 1 of the caller's output, where the probe left it),
     // first step size = the probe's dt, in sorted order; per-IVP counters are added to the probe's; row 0 is restored from y0 afterwards.
+    // With knob "sort_rebin_steps" = S > 0 there is a pass in between: every IVP takes up to S more accepted steps in the probe's order, the batch is
+    // binned again by the steps still to take where each IVP stands NOW, and the last pass finishes it — for batches whose step sizes change late in
+    // the span, where the order found after 8 steps has gone stale.  Cut-offs by step count leave the step sequence alone (as the probe's does), so
+    // the bits stay those of the plain solve.
     const double span2[2] = {opt->tStart, opt->tStart + 1.0};  // placeholder for validation and dispatch: the spans are per IVP
-    rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y_out + (int64_t)dim * N, N, dim, layout, span2, 2, nullptr, y_out,
-                       ny_out, steps_out, rejected_out, max_steps > 0 ? max_steps - probe_steps : 0, nullptr, 0, nullptr, nullptr, s, ps);
-    if (rc) return rc;
-    ps.a.perCall.tEnd = resEnd; ps.a.perCall.tStart = resT; ps.a.perCall.dtInit = resDt; ps.a.perCall.resume = 1;
-    ps.a.nZero = 1;
-    ps.a.uniformFull[0] = ps.a.uniformFull[1] = -1;
-    ps.a.nTail[0] = ps.a.nTail[1] = 0;
-    ps.a.accumulate = 1;
-    if (sorted) ps.a.perm = perm;
-    rc = launch_solve_range(ps, 0, N, s);
-    if (rc) return rc;
+    int64_t used = probe_steps;
+    const bool rebin = g_sort_rebin_steps > 0 && (max_steps <= 0 || max_steps - used > g_sort_rebin_steps);
+    for (int pass = rebin ? 0 : 1; pass < 2; ++pass) {
+      const bool last = pass == 1;
+      rc = prepare_solve(opt, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y_out + (int64_t)dim * N, N, dim, layout, span2, 2, nullptr, y_out,
+                         ny_out, steps_out, rejected_out, last ? (max_steps > 0 ? max_steps - used : 0) : (int64_t)g_sort_rebin_steps, nullptr, 0, nullptr, nullptr, s, ps);
+      if (rc) return rc;
+      ps.a.perCall.tEnd = resEnd; ps.a.perCall.tStart = resT; ps.a.perCall.dtInit = resDt; ps.a.perCall.resume = 1;
+      ps.a.nZero = 1;
+      ps.a.uniformFull[0] = ps.a.uniformFull[1] = -1;
+      ps.a.nTail[0] = ps.a.nTail[1] = 0;
+      ps.a.accumulate = 1;
+      if (sorted) ps.a.perm = perm;
+      if (!last) { ps.a.tfinal_out = resT; ps.a.dtfinal_out = resDt; }  // (each work item reads its own start before it writes where it stopped)
+      rc = launch_solve_range(ps, 0, N, s);
+      if (rc) return rc;
+      if (!last) {
+        used += g_sort_rebin_steps;
+        HIP_TRY(nnhip::remaining_key_f64(resT, resDt, g0End, key, N, s));
+        HIP_TRY(nnhip::key_range_f64(key, N, sortWs, nullptr, s));
+        HIP_TRY(nnhip::argsort_f64(key, N, perm, sortWs, sortWsBytes, s));
+        sorted = true;
+      }
+    }
     HIP_TRY(hipMemcpyAsync(y_out, y0, (size_t)dim * (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, s));  // row 0 = y0 (`t0 in tspan`, ode.nim:485-487)
     return NNHIP_OK;
   }

@@ -83,9 +83,9 @@ bool launch_dense_rows_kind(int rhs_kind, int dim, int64_t N, int64_t is, int64_
 // ode_sort.hip
 int64_t argsort_workspace_bytes(int64_t N);
 hipError_t argsort_f64(const double* keys, int64_t N, uint32_t* perm_out, void* ws, int64_t ws_bytes, hipStream_t s);
+hipError_t remaining_key_f64(const double* t, const double* dt, double tEnd, double* out, int64_t N, hipStream_t s);
 hipError_t negate_f64(const double* in, double* out, int64_t N, hipStream_t s);
-hipError_t key_range_f64(const double* keys, int64_t N, void* scratch, unsigned long long* pinned2, hipStream_t s);
-int64_t key_range_scratch_bytes();
+hipError_t key_range_f64(const double* keys, int64_t N, void* ws, unsigned long long* pinned2, hipStream_t s);
 void key_range_decode(const unsigned long long* img, double* mn, double* mx);
 hipError_t gather_f64(const double* src, double* dst, const uint32_t* perm, int64_t N, int R, int W, hipStream_t s);
 hipError_t scatter_f64(const double* src, double* dst, const uint32_t* perm, int64_t N, int R, int W, hipStream_t s);

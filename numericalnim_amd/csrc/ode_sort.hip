@@ -1,9 +1,8 @@
-// ode_sort.hip — order of integration for divergence binning: a stable argsort of one float64 key per IVP on the device
-// (rocPRIM radix sort of (key, index) pairs, called directly: no CUB-shaped layer in between).  Used by nnhip_ode_solve_batch_sorted_f64_dev (ode_capi.hip): the fused adaptive
+// ode_sort.hip — order of integration for divergence binning: one float64 key per IVP counted into bins on the device (hand-written
+// counting sort; no library sort).  Used by nnhip_ode_solve_batch_sorted_f64_dev (ode_capi.hip): the fused adaptive
 // kernels integrate IVP perm[k] in work item k, so lanes of a wavefront hold IVPs with similar step sequences.
 #include <hip/hip_runtime.h>
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include <cstdint>
 
@@ -15,19 +14,81 @@ __global__ void negate_kernel(const double* in, double* out, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { const double v = in[i]; out[i] = (v == v) ? -v : __longlong_as_double(0x7ff0000000000000LL); }
 }
-// Binning needs the ORDER of the keys, not their values: a float64 key is narrowed to its float32 image in order-preserving unsigned
-// form and the pairs are sorted on all 32 bits (4 radix passes).  Round 2 kept only the top 16 bits (sign, exponent, 7 mantissa bits:
-// 2 passes, ~35 us less at 1e6 keys) — but keys with a small RELATIVE spread (mu in [100, 101], probe progress in [0.10, 0.12]) then
-// fell into one or two bins and the "sorted" order was the caller's: the speed-up vanished silently.  float32 resolves 2^-24 of the
-// key's magnitude; IVPs whose keys still tie keep the caller's relative order (stable sort).
-__global__ void narrow_keys_kernel(const double* in, uint32_t* out, uint32_t* iota, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    const double v = in[i];
-    uint32_t b = __float_as_uint((v == v) ? (float)v : __int_as_float(0x7f800000));  // NaN keys sort last (with +inf)
-    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);                                  // IEEE order -> unsigned order
-    out[i] = b;
-    iota[i] = (uint32_t)i;
+// The ORDER OF INTEGRATION is a binning, not a sort: what the solve kernels gain from is that the 64 lanes of a wavefront hold IVPs with similar step
+// sequences, and IVPs whose keys agree to 1 part in 4096 of the key range are as similar as the key can tell.  So the keys are counted into kBins
+// bins and laid out bin after bin (a one-pass counting sort, three small launches, ~20 us at 1e6 keys) — rocPRIM's radix_sort_pairs, which round 3
+// called, picks a 10-pass merge sort for 1e6 32-bit keys (168 us; 61 us with 16-bit keys and its one-sweep passes: profiles/r04_bench_divergence.json).
+// The bin of a key: its order-preserving 64-bit image (monotone; logarithmic across binades, linear inside one) minus the image of the smallest
+// finite key, shifted so that the largest lands in bin kBins-2.  The bins are spent on the range the keys actually cover: a sweep over [100, 101]
+// and a probe whose progress spans six decades both use all of them.  Non-finite keys go last (-inf first).  Inside a bin the order is whatever
+// the atomics produce — it differs from run to run and changes nothing but which wavefront an IVP rides in (the results are per IVP).
+constexpr int kBins = 4096, kBinThreads = 1024, kBinItems = 4;
+__device__ unsigned long long ordered_img(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
+}
+__device__ int bin_shift(const unsigned long long* range) {  // smallest shift with (max - min) >> shift <= kBins - 2
+  const unsigned long long span = range[1] > range[0] ? range[1] - range[0] : 0ULL;
+  int shift = 64 - __clzll((long long)span) - 12;
+  shift = shift < 0 ? 0 : shift;
+  return ((span >> shift) > (unsigned long long)(kBins - 2)) ? shift + 1 : shift;
+}
+// pass 1: the bin of every key (kept as 16 bits for pass 2) and the global histogram; `hist` arrives zeroed
+__global__ __launch_bounds__(kBinThreads) void bin_count_kernel(const double* __restrict__ keys, const unsigned long long* __restrict__ range, uint16_t* __restrict__ bins,
+                                                                 uint32_t* __restrict__ hist, int64_t n) {
+  __shared__ uint32_t lh[kBins];
+  for (int b = threadIdx.x; b < kBins; b += kBinThreads) lh[b] = 0;
+  __syncthreads();
+  const unsigned long long imgMin = range[0];
+  const int shift = bin_shift(range);
+  const int64_t base = (int64_t)blockIdx.x * (kBinThreads * kBinItems);
+  for (int k = 0; k < kBinItems; ++k) {
+    const int64_t i = base + k * kBinThreads + threadIdx.x;
+    if (i < n) {
+      const double v = keys[i];
+      uint32_t q = kBins - 1;
+      if (v == v && v != __longlong_as_double(0x7ff0000000000000LL)) {
+        const unsigned long long o = ordered_img(v);
+        const unsigned long long d = o > imgMin ? (o - imgMin) >> shift : 0ULL;
+        q = d > (unsigned long long)(kBins - 2) ? kBins - 2 : (uint32_t)d;
+      }
+      bins[i] = (uint16_t)q;
+      atomicAdd(&lh[q], 1u);
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < kBins; b += kBinThreads) { const uint32_t c = lh[b]; if (c) atomicAdd(&hist[b], c); }
+}
+// pass 2: every block scans the histogram into bin starts (4096 counters: cheaper than a launch of its own), reserves its share of each bin with one
+// atomic per bin it holds keys of, and writes the indices of its keys there; `cursor` arrives zeroed
+__global__ __launch_bounds__(kBinThreads) void bin_place_kernel(const uint16_t* __restrict__ bins, const uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor,
+                                                                 uint32_t* __restrict__ perm, int64_t n) {
+  __shared__ uint32_t start[kBins];  // bin starts, then this block's base inside each bin
+  __shared__ uint32_t lh[kBins];
+  __shared__ uint32_t waveSum[kBinThreads / 64];
+  constexpr int per = kBins / kBinThreads;  // consecutive bins per thread
+  uint32_t c[per], sum = 0;
+  for (int j = 0; j < per; ++j) { c[j] = hist[threadIdx.x * per + j]; sum += c[j]; lh[threadIdx.x * per + j] = 0; }
+  uint32_t incl = sum;
+  for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off, 64); if ((int)(threadIdx.x & 63) >= off) incl += v; }
+  if ((threadIdx.x & 63) == 63) waveSum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  uint32_t run = incl - sum;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += waveSum[w];
+  for (int j = 0; j < per; ++j) { start[threadIdx.x * per + j] = run; run += c[j]; }
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * (kBinThreads * kBinItems);
+  uint32_t q[kBinItems], rank[kBinItems];
+  for (int k = 0; k < kBinItems; ++k) {
+    const int64_t i = base + k * kBinThreads + threadIdx.x;
+    if (i < n) { q[k] = bins[i]; rank[k] = atomicAdd(&lh[q[k]], 1u); }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < kBins; b += kBinThreads) { const uint32_t cnt = lh[b]; if (cnt) start[b] += atomicAdd(&cursor[b], cnt); }
+  __syncthreads();
+  for (int k = 0; k < kBinItems; ++k) {
+    const int64_t i = base + k * kBinThreads + threadIdx.x;
+    if (i < n) perm[start[q[k]] + rank[k]] = (uint32_t)i;
   }
 }
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -84,31 +145,103 @@ hipError_t prepare_tspans(const double* tspans, int n_t, int64_t N, const double
   return hipLaunchKernel((const void*)prepare_tspans_kernel, dim3((unsigned)((N + 127) / 128)), dim3(128), args, 0, s);
 }
 
-// layout of the workspace: [keys_in: 4N][keys_out: 4N][iota: 4N][rocPRIM temp]
-int64_t argsort_workspace_bytes(int64_t N) {
-  if (N <= 0) return 0;
-  size_t temp = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, temp, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)N, 0, 32);
-  return (int64_t)(3 * align256((size_t)N * 4) + align256(temp) + 256);
+// min / max of the finite keys as order-preserving 64-bit images ({~0, 0} when no key is finite), reduced in two small launches: one partial pair
+// per block, then one block over the partials.  The result goes to the head of the binning workspace (the binning kernels read it there) and, if the
+// caller wants to look at it, to two words of page-locked host memory (`pinned2`, valid once the stream has drained; plain stores, no host atomics).
+namespace {
+constexpr int kKeyRangeBlocks = 1024;
+constexpr size_t kRangeBytes = 256 + (size_t)kKeyRangeBlocks * 16;  // [range: 2 words, padded][partials]
+template <bool FINAL>
+__global__ void key_range_kernel(const double* __restrict__ keys, const unsigned long long* __restrict__ partials, int64_t n, unsigned long long* __restrict__ out,
+                                 unsigned long long* __restrict__ pinned2) {
+  __shared__ unsigned long long smn[4], smx[4];
+  unsigned long long mn = ~0ULL, mx = 0ULL;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if constexpr (FINAL) {
+      const unsigned long long a = partials[2 * i], b = partials[2 * i + 1];
+      mn = a < mn ? a : mn;
+      mx = b > mx ? b : mx;
+    } else {
+      const double v = keys[i];
+      if (v == v && fabs(v) != __longlong_as_double(0x7ff0000000000000LL)) {
+        const unsigned long long o = ordered_img(v);
+        mn = o < mn ? o : mn;
+        mx = o > mx ? o : mx;
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long a = __shfl_down(mn, off, 64), b = __shfl_down(mx, off, 64);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+  if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) { mn = smn[w] < mn ? smn[w] : mn; mx = smx[w] > mx ? smx[w] : mx; }
+    out[2 * (FINAL ? 0 : blockIdx.x)] = mn;
+    out[2 * (FINAL ? 0 : blockIdx.x) + 1] = mx;
+    if (FINAL && pinned2) { pinned2[0] = mn; pinned2[1] = mx; }
+  }
+}
+}  // namespace
+// host side of the images: {min, max} as doubles
+void key_range_decode(const unsigned long long* img, double* mn, double* mx) {
+  auto dec = [](unsigned long long o) { const unsigned long long b = (o >> 63) ? (o & 0x7fffffffffffffffULL) : ~o; double v; std::memcpy(&v, &b, 8); return v; };
+  *mn = img[0] == ~0ULL ? __builtin_inf() : dec(img[0]);
+  *mx = img[1] == 0ULL ? -__builtin_inf() : dec(img[1]);
+}
+// `ws`: the workspace argsort_f64 is given afterwards (the range stays at its head)
+hipError_t key_range_f64(const double* keys, int64_t N, void* ws, unsigned long long* pinned2, hipStream_t s) {
+  if (pinned2) { pinned2[0] = ~0ULL; pinned2[1] = 0ULL; }  // host memory: the previous use has been waited for
+  if (N <= 0) return hipSuccess;
+  char* base = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  unsigned long long* range = (unsigned long long*)base;
+  unsigned long long* part = (unsigned long long*)(base + 256);
+  int64_t blocks = (N + 255) / 256;
+  if (blocks > kKeyRangeBlocks) blocks = kKeyRangeBlocks;
+  const unsigned long long* none = nullptr;
+  unsigned long long* nohost = nullptr;
+  {
+    void* args[] = {(void*)&keys, (void*)&none, (void*)&N, (void*)&part, (void*)&nohost};
+    const hipError_t e = hipLaunchKernel((const void*)key_range_kernel<false>, dim3((unsigned)blocks), dim3(256), args, 0, s);
+    if (e != hipSuccess) return e;
+  }
+  const double* nokeys = nullptr;
+  const unsigned long long* cpart = part;
+  void* args[] = {(void*)&nokeys, (void*)&cpart, (void*)&blocks, (void*)&range, (void*)&pinned2};
+  return hipLaunchKernel((const void*)key_range_kernel<true>, dim3(1), dim3(256), args, 0, s);
 }
 
-// perm_out[k] = index of the k-th smallest key (stable).  N < 2^31.  Failures come back as the hipError_t; the C entry that called turns
-// them into its NNHIP_* code and thread-local message (nothing is printed from here).
+// layout of the workspace: [range of the keys: two 64-bit images, + the partials of its reduction][histogram + cursors: 2 x kBins x 4][bins: 2N]
+int64_t argsort_workspace_bytes(int64_t N) {
+  if (N <= 0) return 0;
+  return (int64_t)(align256(kRangeBytes) + align256(2 * kBins * 4) + align256((size_t)N * 2) + 256);
+}
+
+// perm_out[k] = index of an IVP of the k-th bin in ascending key order.  N < 2^31.  key_range_f64(keys, N, ws, ..) has been enqueued on the same
+// stream before.  Failures come back as the hipError_t; the C entry that called turns them into its NNHIP_* code and thread-local message
+// (nothing is printed from here).
 hipError_t argsort_f64(const double* keys, int64_t N, uint32_t* perm_out, void* ws, int64_t ws_bytes, hipStream_t s) {
   if (N <= 0) return hipSuccess;
   if (N >= (int64_t)1 << 31 || ws_bytes < argsort_workspace_bytes(N)) return hipErrorInvalidValue;
   char* base = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-  uint32_t* keysIn = (uint32_t*)base;
-  uint32_t* keysOut = (uint32_t*)(base + align256((size_t)N * 4));
-  uint32_t* iota = (uint32_t*)(base + 2 * align256((size_t)N * 4));
-  void* temp = base + 3 * align256((size_t)N * 4);
-  size_t tempBytes = (size_t)ws_bytes - (size_t)((char*)temp - (char*)ws);
+  const unsigned long long* range = (const unsigned long long*)base;
+  uint32_t* hist = (uint32_t*)(base + align256(kRangeBytes));
+  uint32_t* cursor = hist + kBins;
+  uint16_t* bins = (uint16_t*)((char*)hist + align256(2 * kBins * 4));
+  hipError_t e = hipMemsetAsync(hist, 0, 2 * kBins * 4, s);
+  if (e != hipSuccess) return e;
+  const unsigned blocks = (unsigned)((N + kBinThreads * kBinItems - 1) / (kBinThreads * kBinItems));
   {  // hipLaunchKernel's own status (hipGetLastError() can hand back a stale error of an unrelated earlier call)
-    void* args[] = {(void*)&keys, (void*)&keysIn, (void*)&iota, (void*)&N};
-    const hipError_t e = hipLaunchKernel((const void*)narrow_keys_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), args, 0, s);
+    void* args[] = {(void*)&keys, (void*)&range, (void*)&bins, (void*)&hist, (void*)&N};
+    e = hipLaunchKernel((const void*)bin_count_kernel, dim3(blocks), dim3(kBinThreads), args, 0, s);
     if (e != hipSuccess) return e;
   }
-  return rocprim::radix_sort_pairs(temp, tempBytes, keysIn, keysOut, iota, perm_out, (size_t)N, 0, 32, s);
+  const uint16_t* b = bins;
+  const uint32_t* h = hist;
+  void* args[] = {(void*)&b, (void*)&h, (void*)&cursor, (void*)&perm_out, (void*)&N};
+  return hipLaunchKernel((const void*)bin_place_kernel, dim3(blocks), dim3(kBinThreads), args, 0, s);
 }
 
 namespace {
@@ -157,70 +290,20 @@ hipError_t invert_perm(const uint32_t* perm, uint32_t* inv, int64_t N, hipStream
   return hipLaunchKernel((const void*)invert_perm_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), args, 0, s);
 }
 
-// min / max of the finite keys, written straight into page-locked host memory (`out2`: {min, max}; {+inf, -inf} when no key is finite): one
-// kernel, one stream synchronisation by the caller.  Order-preserving 64-bit images make it an integer atomicMin / atomicMax.
+// key of the automatic mode, variant "steps still to take": -(tEnd - t) / dt from where the probe stopped (most work first; anything non-finite last)
 namespace {
-__device__ unsigned long long ordered_u64(double v) {
-  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-  return (b >> 63) ? ~b : (b | 0x8000000000000000ULL);
-}
-// stage 1: one partial {min, max} per block into device scratch; stage 2 (FINAL, one block): the partials into page-locked host memory, plain stores
-template <bool FINAL>
-__global__ void key_range_kernel(const double* __restrict__ keys, const unsigned long long* __restrict__ partials, int64_t n, unsigned long long* __restrict__ out) {
-  __shared__ unsigned long long smn[4], smx[4];
-  unsigned long long mn = ~0ULL, mx = 0ULL;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    if constexpr (FINAL) {
-      const unsigned long long a = partials[2 * i], b = partials[2 * i + 1];
-      mn = a < mn ? a : mn;
-      mx = b > mx ? b : mx;
-    } else {
-      const double v = keys[i];
-      if (v == v && fabs(v) != __longlong_as_double(0x7ff0000000000000LL)) {
-        const unsigned long long o = ordered_u64(v);
-        mn = o < mn ? o : mn;
-        mx = o > mx ? o : mx;
-      }
-    }
-  }
-  for (int off = 32; off > 0; off >>= 1) {
-    const unsigned long long a = __shfl_down(mn, off, 64), b = __shfl_down(mx, off, 64);
-    mn = a < mn ? a : mn;
-    mx = b > mx ? b : mx;
-  }
-  if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; ++w) { mn = smn[w] < mn ? smn[w] : mn; mx = smx[w] > mx ? smx[w] : mx; }
-    out[2 * (FINAL ? 0 : blockIdx.x)] = mn;
-    out[2 * (FINAL ? 0 : blockIdx.x) + 1] = mx;
+__global__ void remaining_key_kernel(const double* __restrict__ t, const double* __restrict__ dt, double tEnd, double* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const double r = (tEnd - t[i]) / dt[i];
+    out[i] = (r == r && r >= 0.0 && r != __longlong_as_double(0x7ff0000000000000LL)) ? -r : __longlong_as_double(0x7ff0000000000000LL);
   }
 }
 }  // namespace
-// host side of the images: {min, max} as doubles
-void key_range_decode(const unsigned long long* img, double* mn, double* mx) {
-  auto dec = [](unsigned long long o) { const unsigned long long b = (o >> 63) ? (o & 0x7fffffffffffffffULL) : ~o; double v; std::memcpy(&v, &b, 8); return v; };
-  *mn = img[0] == ~0ULL ? __builtin_inf() : dec(img[0]);
-  *mx = img[1] == 0ULL ? -__builtin_inf() : dec(img[1]);
-}
-constexpr int kKeyRangeBlocks = 256;
-int64_t key_range_scratch_bytes() { return (int64_t)kKeyRangeBlocks * 16; }
-// `scratch`: device memory of key_range_scratch_bytes(); `pinned2`: two words of page-locked host memory, valid once the stream has drained
-hipError_t key_range_f64(const double* keys, int64_t N, void* scratch, unsigned long long* pinned2, hipStream_t s) {
-  pinned2[0] = ~0ULL; pinned2[1] = 0ULL;  // host memory: the previous use has been waited for
+hipError_t remaining_key_f64(const double* t, const double* dt, double tEnd, double* out, int64_t N, hipStream_t s) {
   if (N <= 0) return hipSuccess;
-  int64_t blocks = (N + 255) / 256;
-  if (blocks > kKeyRangeBlocks) blocks = kKeyRangeBlocks;
-  unsigned long long* part = (unsigned long long*)scratch;
-  const unsigned long long* none = nullptr;
-  {
-    void* args[] = {(void*)&keys, (void*)&none, (void*)&N, (void*)&part};
-    const hipError_t e = hipLaunchKernel((const void*)key_range_kernel<false>, dim3((unsigned)blocks), dim3(256), args, 0, s);
-    if (e != hipSuccess) return e;
-  }
-  const double* nokeys = nullptr;
-  void* args[] = {(void*)&nokeys, (void*)&part, (void*)&blocks, (void*)&pinned2};
-  return hipLaunchKernel((const void*)key_range_kernel<true>, dim3(1), dim3(256), args, 0, s);
+  void* args[] = {(void*)&t, (void*)&dt, (void*)&tEnd, (void*)&out, (void*)&N};
+  return hipLaunchKernel((const void*)remaining_key_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), args, 0, s);
 }
 
 hipError_t negate_f64(const double* in, double* out, int64_t N, hipStream_t s) {

@@ -781,10 +781,22 @@ def test_sort_by_returns_identical_results_in_caller_order(nn, dev, sort_copy):
     c = nn.solveODE(nn.Rhs.vanderpol(), y0a, ts, opt, integrator="tsit54", sweep=mu[None, :], layout=1, sort_by=mu)
     assert torch.equal(c[1].permute(0, 2, 1), a[1])
     # automatic two-pass mode (probe solve -> device argsort -> solve in that order), every adaptive integrator, with counters
+    # (ranked by the steps still to take — knob "sort_auto_key" 1, the default — or by the probe's progress, 0; a two-sided tspan always uses the latter)
+    Lk = nn._lib.lib()
     for integ in ("dopri54", "vern65", "bs32", "rk21"):
         a = nn.solveODE(nn.Rhs.vanderpol(), y0, ts, opt, integrator=integ, sweep=mu[None, :], return_counts=True)
-        d = nn.solveODE(nn.Rhs.vanderpol(), y0, ts, opt, integrator=integ, sweep=mu[None, :], return_counts=True, sort_by="auto")
-        assert torch.equal(a[1], d[1]) and all(torch.equal(a[2][k], d[2][k]) for k in a[2]), integ
+        a2s = nn.solveODE(nn.Rhs.vanderpol(), y0, [-1.0, 0.0, 2.0], opt, integrator=integ, sweep=mu[None, :], return_counts=True)
+        for auto_key in (1, 0):
+            assert Lk.nnhip_tune_set(b"sort_auto_key", auto_key) == 0
+            try:
+                d = nn.solveODE(nn.Rhs.vanderpol(), y0, ts, opt, integrator=integ, sweep=mu[None, :], return_counts=True, sort_by="auto")
+                d2s = nn.solveODE(nn.Rhs.vanderpol(), y0, [-1.0, 0.0, 2.0], opt, integrator=integ, sweep=mu[None, :], return_counts=True, sort_by="auto")
+            finally:
+                assert Lk.nnhip_tune_set(b"sort_auto_key", 1) == 0
+            assert torch.equal(a[1], d[1]) and all(torch.equal(a[2][k], d[2][k]) for k in a[2]), (integ, auto_key)
+            assert torch.equal(torch.nan_to_num(a2s[1], nan=-1.0), torch.nan_to_num(d2s[1], nan=-1.0)), (integ, auto_key)   # (backwards, Van der Pol blows up for the larger mu: NaN rows on both sides)
+            assert all(torch.equal(a2s[2][k], d2s[2][k]) for k in a2s[2]), (integ, auto_key)
+    assert Lk.nnhip_tune_set(b"sort_auto_key", 2) != 0
     # max_steps smaller than the probe, a fixed-step method (runs unsorted), N = 1 and N = 0
     e0 = nn.solveODE(nn.Rhs.vanderpol(), y0, ts, opt, integrator="tsit54", sweep=mu[None, :], max_steps=5, return_counts=True)
     e1 = nn.solveODE(nn.Rhs.vanderpol(), y0, ts, opt, integrator="tsit54", sweep=mu[None, :], max_steps=5, return_counts=True, sort_by="auto")
@@ -801,7 +813,10 @@ def test_sort_by_returns_identical_results_in_caller_order(nn, dev, sort_copy):
     # with the check switched off (knob 0: always sort) too
     L = nn._lib.lib()
     a = nn.solveODE(nn.Rhs.vanderpol(), y0, ts, opt, integrator="tsit54", sweep=mu[None, :], return_counts=True)
-    for key in (100.0 + torch.rand(n, dtype=torch.float64, device=dev), torch.full((n,), 3.0, dtype=torch.float64, device=dev),
+    wild = torch.from_numpy(np.concatenate([10.0 ** rng.uniform(-300, 300, n - 8) * rng.choice([-1.0, 1.0], n - 8),   # 600 decades, both signs, and every special value
+                                            [np.inf, -np.inf, np.nan, 0.0, -0.0, 5e-324, -5e-324, 1.7976931348623157e308]])).to(dev)
+    for key in (wild, 10.0 ** (6.0 * torch.rand(n, dtype=torch.float64, device=dev)),
+                100.0 + torch.rand(n, dtype=torch.float64, device=dev), torch.full((n,), 3.0, dtype=torch.float64, device=dev),
                 torch.full((n,), float("nan"), dtype=torch.float64, device=dev), -100.0 - 2.0 * torch.rand(n, dtype=torch.float64, device=dev),
                 torch.zeros(n, dtype=torch.float64, device=dev)):
         for permille in (50, 0):
@@ -817,7 +832,7 @@ def test_sort_by_returns_identical_results_in_caller_order(nn, dev, sort_copy):
     # max_steps cap above and below the probe, per-IVP parameters, both layouts, a probe of another length, and the knob switched off
     tsf = [0.0, 2.0]
     y0a = y0.t().contiguous()
-    assert L.nnhip_tune_set(b"sort_resume", 1) == 0   # (not the default: measured no faster, see ode_capi.hip)
+    assert L.nnhip_tune_set(b"sort_resume", 1) == 0   # (not the default: within 1 % either way, see ode_capi.hip)
     for integ in ("dopri54", "tsit54", "bs32", "rk21", "vern65"):
         for kw in (dict(), dict(max_steps=30), dict(max_steps=5), dict(probe_steps=3)):
             kw0 = {k: v for k, v in kw.items() if k != "probe_steps"}
@@ -835,6 +850,28 @@ def test_sort_by_returns_identical_results_in_caller_order(nn, dev, sort_copy):
     g = nn.solveODE(nn.Rhs.vanderpol(), y0, [0.5, 2.5], o_shift, integrator="tsit54", sweep=mu[None, :], return_counts=True)
     g2 = nn.solveODE(nn.Rhs.vanderpol(), y0, [2.5, 0.5], o_shift, integrator="tsit54", sweep=mu[None, :], return_counts=True, sort_by="auto")
     assert torch.equal(g[1], g2[1]) and all(torch.equal(g[2][k], g2[2][k]) for k in g[2])
+    # ... and re-binned mid-solve (knob "sort_rebin_steps" = S: probe -> S more steps in the probe's order -> binned again by the steps still to take -> the rest):
+    # S below and above what the IVPs need, caps on either side of probe + S, the second layout, a span that ends inside the probe, dtMin = 0 (refused either way)
+    for S in (1, 10, 60, 100000):
+        assert L.nnhip_tune_set(b"sort_rebin_steps", S) == 0
+        try:
+            for integ in ("dopri54", "tsit54", "bs32", "rk21", "vern65"):
+                for kw in (dict(), dict(max_steps=8 + S), dict(max_steps=9 + S), dict(max_steps=30)):
+                    a2 = nn.solveODE(nn.Rhs.vanderpol(), y0, tsf, opt, integrator=integ, sweep=mu[None, :], return_counts=True, **kw)
+                    d2 = nn.solveODE(nn.Rhs.vanderpol(), y0, tsf, opt, integrator=integ, sweep=mu[None, :], return_counts=True, sort_by="auto", **kw)
+                    assert np.array_equal(a2[0], d2[0]) and torch.equal(torch.nan_to_num(a2[1], nan=-1.0), torch.nan_to_num(d2[1], nan=-1.0)), (S, integ, kw)
+                    assert all(torch.equal(a2[2][k], d2[2][k]) for k in a2[2]), (S, integ, kw)
+            short2 = nn.solveODE(nn.Rhs.vanderpol(), y0, [0.0, 1e-3], opt, integrator="tsit54", sweep=mu[None, :], return_counts=True, sort_by="auto")
+            assert torch.equal(short[1], short2[1]) and all(torch.equal(short[2][k], short2[2][k]) for k in short[2])
+            e2 = nn.solveODE(nn.Rhs.vanderpol(), y0a, tsf, opt, integrator="dopri54", sweep=mu[None, :], layout=1, return_counts=True, sort_by="auto")
+            assert torch.equal(e[1], e2[1]) and all(torch.equal(e[2][k], e2[2][k]) for k in e[2])
+            o_zero = nn.newODEoptions(absTol=1e-6, relTol=1e-6, dtMin=0.0, dtMax=1.0)
+            z = nn.solveODE(nn.Rhs.vanderpol(), y0, tsf, o_zero, integrator="tsit54", sweep=mu[None, :], return_counts=True, max_steps=50)
+            z2 = nn.solveODE(nn.Rhs.vanderpol(), y0, tsf, o_zero, integrator="tsit54", sweep=mu[None, :], return_counts=True, max_steps=50, sort_by="auto")
+            assert torch.equal(torch.nan_to_num(z[1], nan=-1.0), torch.nan_to_num(z2[1], nan=-1.0)) and all(torch.equal(z[2][k], z2[2][k]) for k in z[2])
+        finally:
+            assert L.nnhip_tune_set(b"sort_rebin_steps", 0) == 0
+    assert L.nnhip_tune_set(b"sort_rebin_steps", -1) != 0
     assert L.nnhip_tune_set(b"sort_resume", 0) == 0
     d3 = nn.solveODE(nn.Rhs.vanderpol(), y0, tsf, opt, integrator="tsit54", sweep=mu[None, :], return_counts=True, sort_by="auto")
     a3 = nn.solveODE(nn.Rhs.vanderpol(), y0, tsf, opt, integrator="tsit54", sweep=mu[None, :], return_counts=True)
