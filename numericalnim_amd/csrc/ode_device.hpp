@@ -217,22 +217,28 @@ constexpr bool rhs_banded_applies() {
   if constexpr (RhsBanded<R>::value) return RhsSize<R>::value == R::dim && R::dim / CPL >= 2 && R::halo_lo <= CPL && R::halo_hi <= CPL;
   else return false;
 }
+// The DPP moves below have a source lane for every lane, so bound_ctrl changes no value — but it tells the compiler that the destination's previous
+// content is dead: with bound_ctrl off and `old` = 0 it zeroed the destination first, two v_mov_b32 per exchanged double (24 of the 587 VALU
+// instructions of a 16-component Tsit54 attempt; profiles/r04_dpp_bound_ctrl_ab.json).
+#ifndef NNHIP_DPP_BOUND_CTRL
+#define NNHIP_DPP_BOUND_CTRL 1
+#endif
 // value of `v` in the next (DIR = +1) / previous (DIR = -1) lane of this lane's group of L consecutive lanes, cyclically
 template <int L, int DIR>
 NNHIP_DEV double lane_rotate(double v) {
   static_assert(L >= 2 && L <= 64 && (L & (L - 1)) == 0, "group size must be a power of two");
   int lo = __double2loint(v), hi = __double2hiint(v);
   if constexpr (L == 2) {         // quad_perm [1,0,3,2]
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, NNHIP_DPP_BOUND_CTRL != 0);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, NNHIP_DPP_BOUND_CTRL != 0);
   } else if constexpr (L == 4) {  // quad_perm [1,2,3,0] / [3,0,1,2]
     constexpr int ctrl = DIR > 0 ? 0x39 : 0x93;
-    lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, NNHIP_DPP_BOUND_CTRL != 0);
+    hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, NNHIP_DPP_BOUND_CTRL != 0);
   } else if constexpr (L == 16) {  // row_ror: lane i <- lane (i - n) mod 16
     constexpr int ctrl = DIR > 0 ? 0x12F : 0x121;
-    lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, NNHIP_DPP_BOUND_CTRL != 0);
+    hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, NNHIP_DPP_BOUND_CTRL != 0);
   } else {                         // any other group size: ds_bpermute (no LDS memory involved)
     const int lane = (int)(threadIdx.x & 63);
     const int src = (lane & ~(L - 1)) | ((lane + (DIR > 0 ? 1 : L - 1)) & (L - 1));
@@ -249,11 +255,11 @@ NNHIP_DEV double lane_last(double v) {
   if constexpr (L == 1) return v;
   int lo = __double2loint(v), hi = __double2hiint(v);
   if constexpr (L == 2) {         // quad_perm [1,1,3,3]
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0xF5, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0xF5, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0xF5, 0xf, 0xf, NNHIP_DPP_BOUND_CTRL != 0);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0xF5, 0xf, 0xf, NNHIP_DPP_BOUND_CTRL != 0);
   } else if constexpr (L == 4) {  // quad_perm [3,3,3,3]
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0xFF, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0xFF, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0xFF, 0xf, 0xf, NNHIP_DPP_BOUND_CTRL != 0);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0xFF, 0xf, 0xf, NNHIP_DPP_BOUND_CTRL != 0);
   } else {                        // ds_bpermute (crossbar only, no LDS memory)
     const int src = ((int)(threadIdx.x & 63)) | (L - 1);
     lo = __builtin_amdgcn_ds_bpermute(src << 2, lo);
