@@ -840,7 +840,7 @@ int nnhip_ode_solve_batch_sorted_f64_dev(const nnhip_ode_options* opt, int integ
   int rc = NNHIP_OK;
   if (adaptive && N > 1) {
     if (!sort_key) {  // pass 1: the probe.  The same solve, cut off after probe_steps accepted steps; its progress is the key.
-      if (probe_steps <= 0) probe_steps = 8;  // scripts/ab_probe_steps.py (1e6 Van der Pol IVPs): 4 steps do not rank (the controller is still ramping up from dtInit), 6 -> 1.73 ms, 8 -> 1.62 ms, 12 -> 1.68 ms, 16 -> 1.73 ms
+      if (probe_steps <= 0) probe_steps = 8;  // scripts/ab_probe_steps.py (1e6 Van der Pol IVPs, round 4): <= 4 steps do not rank (every controller is still ramping up from dtInit: the keys tie and the batch runs unsorted, 2.48 ms), 6 -> 1.47 ms, 8 -> 1.45 ms, 12 -> 1.55 ms, 16 -> 1.81 ms
       if (max_steps > 0 && probe_steps > max_steps) probe_steps = (int)max_steps;
       // Resume instead of restart where the loop's whole state is (t, dt, y): a forward 2-point tspan [tStart, tEnd], a method whose FSAL is f(t, y) of
       // the state it returns (DOPRI54, Tsit54, BS32) or that has none (RK21), a right-hand side without mutable slots.  The probe then writes its
