@@ -24,7 +24,8 @@ n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", "r02_fuzz_soak.json")
 KEYS = T.KEYS
 tab = {}
-for seed in range(120, 120 + n_seeds):
+seed0 = int(os.environ.get("NNHIP_SOAK_SEED0", "120"))
+for seed in range(seed0, seed0 + n_seeds):
     rng = np.random.default_rng(1000 + seed)
     kind, dim, params, integ, ts, opt, n, layout = T._draw(rng, nn)
     y0 = rng.uniform(-1.5, 1.5, (n, dim)) + (np.array([0.0, 0.0, 15.0]) if kind == 2 else 0.0)
@@ -52,7 +53,7 @@ for seed in range(120, 120 + n_seeds):
     r["same_path_not_bit_identical"] += int((neq_ivp & same_path).sum())
     r["outside_1e6"] += int(far_ivp.sum())
 tot = {k: sum(r[k] for r in tab.values()) for k in next(iter(tab.values()))}
-res = {"seeds": [120, 120 + n_seeds], "per_integrator": dict(sorted(tab.items())), "total": tot,
+res = {"seeds": [seed0, seed0 + n_seeds], "per_integrator": dict(sorted(tab.items())), "total": tot,
        "adaptive_total": {k: sum(r[k] for i, r in tab.items() if i not in nn.fixedODE) for k in tot}}
 os.makedirs(os.path.dirname(out_path), exist_ok=True)
 json.dump(res, open(out_path, "w"), indent=1)

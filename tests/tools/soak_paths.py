@@ -36,7 +36,8 @@ def same(a, b):
 tab = {k: dict(cases=0, ivps=0, mismatching_cases=0, errors=0) for k in ("stream_solve", "sorted_key", "sorted_probe", "calls_dev", "calls_host", "host_solve",
                                                                          "sweep_host", "sweep_sorted", "sweep_calls", "stream_final", "stream_final_k", "tspans_dev", "tspans_host")}
 bad = []
-for seed in range(5000, 5000 + n_seeds):
+seed0 = int(os.environ.get("NNHIP_SOAK_SEED0", "5000"))
+for seed in range(seed0, seed0 + n_seeds):
     rng = np.random.default_rng(seed)
     kind, dim, params, integ, ts, opt, n, layout = T._draw(rng, nn)
     y0 = rng.uniform(-1.5, 1.5, (n, dim)) + (np.array([0.0, 0.0, 15.0]) if kind == 2 else 0.0)
@@ -153,7 +154,7 @@ for seed in range(5000, 5000 + n_seeds):
     except Exception as e:
         tab["tspans_dev"]["errors"] += 1
         bad.append(dict(path="tspans", seed=seed, error=str(e)[:200], integ=integ, kind=kind, dim=dim))
-res = {"seeds": [5000, 5000 + n_seeds], "per_path": tab, "findings": bad[:40]}
+res = {"seeds": [seed0, seed0 + n_seeds], "per_path": tab, "findings": bad[:40]}
 os.makedirs(os.path.dirname(out_path), exist_ok=True)
 json.dump(res, open(out_path, "w"), indent=1)
 print(json.dumps(tab))
