@@ -53,10 +53,14 @@ proc rhsFromSourceCtx*(dim: int, body: string, keys: seq[string], vectors: seq[C
   ## NumContext in full (commonTypes.nim:4-27, nnhip_ode_rhs_compile_ctx): the body also sees the named ctx.tValues entries, any number
   ## of fValues (p[k]) and `aux(j)`, per-IVP doubles it may mutate (ode.nim:599).  Bind the values with `bindCtx` before solving.
   var kind: cint
-  var names = allocCStringArray(block: (var n: seq[string]; (for v in vectors: n.add v.name); n))
+  var vnames: seq[string]
   var lens: seq[int64]
   var per: seq[cint]
-  for v in vectors: (lens.add v.len.int64; per.add (if v.perIvp: 1 else: 0).cint)
+  for v in vectors:
+    vnames.add(v.name)
+    lens.add(v.len.int64)
+    per.add((if v.perIvp: 1 else: 0).cint)
+  var names = allocCStringArray(vnames)
   let rc = nnhip_ode_rhs_compile_ctx(name.cstring, dim.cint, keys.len.cint, body.cstring, (if perComponent: 1 else: 0).cint, vectors.len.cint, names,
                                      (if lens.len > 0: addr lens[0] else: nil), (if per.len > 0: addr per[0] else: nil), nAux.cint, addr kind)
   deallocCStringArray(names)
@@ -66,7 +70,9 @@ proc rhsFromSourceCtx*(dim: int, body: string, keys: seq[string], vectors: seq[C
 proc bindCtx*(f: RhsSpec, shared, perIvp, auxInit: seq[float], nAux: int, n: int, device = 0) =
   ## shared = [the scalars, when the right-hand side has more than 8][the shared vectors in declaration order]; perIvp [rows][n];
   ## auxInit [nAux][n].  Host arrays; the backend keeps device copies until the next bindCtx / release.
-  var s = shared; var p = perIvp; var a = auxInit
+  var s = shared
+  var p = perIvp
+  var a = auxInit
   let rc = nnhip_ode_rhs_bind_ctx_f64(f.userKind.cint, (if s.len > 0: addr s[0] else: nil), s.len.int64, (if p.len > 0: addr p[0] else: nil),
                                       (if n > 0: p.len div n else: 0).int64, (if a.len > 0: addr a[0] else: nil), nAux.cint, n.int64, device.cint)
   if rc != 0: raise newException(ValueError, $nnhip_last_error())
