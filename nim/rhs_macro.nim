@@ -29,13 +29,17 @@
 import std/[macros, strutils, sequtils]
 import ./numericalnim_hip
 
+const
+  brOpen = $chr(1)    ## brackets of a ctx-vector access in the emitted text until its layout (shared: NAME[j], per IVP: NAME(j)) is known
+  brClose = $chr(2)
+
 proc fail(n: NimNode, what: string) {.compileTime.} =
   error("deviceRhs: " & what & " is not in the translatable subset: " & n.repr, n)
 
 proc cDouble(f: BiggestFloat): string {.compileTime.} =
   # shortest text that reads back as the same double (Nim's `$` on a float is round-trip exact), always with a decimal point or exponent
   result = $f
-  if not (result.contains('.') or result.contains('e') or result.contains("inf") or result.contains("nan")): result.add ".0"
+  if not (result.contains(".") or result.contains("e") or result.contains("inf") or result.contains("nan")): result.add ".0"
 
 proc tr(n: NimNode, keys: seq[string], ints: seq[string], vectors: var seq[string]): string {.compileTime.}
 
@@ -82,8 +86,8 @@ proc tr(n: NimNode, keys: seq[string], ints: seq[string], vectors: var seq[strin
       if n[0][1].kind notin {nnkStrLit, nnkRStrLit}: fail(n, "a non-literal tValues key")
       let name = n[0][1].strVal
       if name notin vectors: vectors.add name
-      # brackets of a ctx vector are emitted as \x01 .. \x02: whether NAME is shared (NAME[j]) or per IVP (NAME(j)) is decided where the layout is known
-      return name & "\x01" & trIndex(n[1], ints) & "\x02"
+      # brackets of a ctx vector are emitted as brOpen .. brClose: whether NAME is shared (NAME[j]) or per IVP (NAME(j)) is decided where the layout is known
+      return name & brOpen & trIndex(n[1], ints) & brClose
     fail(n, "indexing")
   of nnkCall, nnkCommand:
     let f = $n[0]
@@ -157,9 +161,11 @@ template deviceRhsCtx*(dim: int, keys: static[openArray[string]], lens: openArra
       var res = ""
       var i = 0
       while i < src.len:
-        let at = src.find(nm & "\x01", i)
-        if at < 0: (res.add src[i .. ^1]; break)
-        let close = src.find('\x02', at)
+        let at = src.find(nm & brOpen, i)
+        if at < 0:
+          res.add src[i ..< src.len]
+          break
+        let close = src.find(brClose, at)
         res.add src[i ..< at] & nm & (if perIvp[k]: "(" else: "[") & src[at + nm.len + 1 ..< close] & (if perIvp[k]: ")" else: "]")
         i = close + 1
       src = res

@@ -80,9 +80,40 @@ class ShimParser(Parser):
         w.full = re.sub(r"\s+", " ", w.full)
         return w if first is not None else None
 
+    def routine(self, kind):
+        """as the base parser's, plus forward declarations (a header without `=`) — skipped, the definition follows"""
+        save = self.p
+        name = self.next()[1]
+        self.accept("op", "*")
+        if self.at("op", "["):
+            depth = 0
+            while True:
+                tok = self.next()
+                if tok[1] == "[": depth += 1
+                elif tok[1] == "]":
+                    depth -= 1
+                    if depth == 0: break
+        self.expect("op", "(")
+        params = self.params()
+        rtype = None
+        if self.accept("op", ":"):
+            rtype = self.skip_type({"="})
+        if not self.accept("op", "="):
+            return ("pass",)
+        return (kind, name, params, rtype, self.block_or_stmt())
+
     # -- statements ---------------------------------------------------------------------------------------------------------------
     def stmt(self):
         tok = self.peek()
+        if tok[0] == "id" and tok[1] == "macro" and self.peek(1)[0] == "id":
+            self.next(); return self.routine("proc")
+        if tok[0] == "id" and tok[1] == "block" and self.peek(1)[0] == "op" and self.peek(1)[1] == ":":
+            self.next(); return ("blockstmt", self.colon_block())
+        if tok[0] == "kw" and tok[1] == "for" and self.peek(2)[0] == "op" and self.peek(2)[1] == ",":
+            self.next()
+            v1 = self.expect("id")[1]; self.expect("op", ","); v2 = self.expect("id")[1]
+            self.expect("kw", "in")
+            return ("for2", v1, v2, self.expr(), self.colon_block())
         if tok[0] == "id" and tok[1] == "import":
             while not self.at("nl"): self.next()
             return ("pass",)
@@ -195,6 +226,9 @@ class ShimParser(Parser):
 
     def primary(self):
         tok = self.peek()
+        if tok[0] == "op" and tok[1] == "{":   # set literal
+            self.next()
+            return ("set", [a[2] for a in self.call_args("}")])
         if tok[0] == "kw" and tok[1] == "if":  # if-expression
             self.next()
             branches = []
@@ -206,8 +240,102 @@ class ShimParser(Parser):
         return super().primary()
 
 
+_ESC = {"n": "\n", "t": "\t", "r": "\r", "0": "\0"}
+
+
 def _tokenize(text):
-    return tokenize(text)
+    """the base tokenizer keeps the character after a backslash as it is (the reference's numerical code has no escapes); a binding module
+    writes \\n in the text it emits: escapes are carried through it as private-use characters and put back in the string tokens"""
+    def protect(m):
+        body = re.sub(r"\\([ntr0])", lambda e: chr(0xE000 + ord(_ESC[e.group(1)])), m.group(0))
+        return body
+    marked = re.sub(r'"(?:[^"\\\n]|\\.)*"', protect, text)
+    toks = tokenize(marked)
+    return [(k, "".join(chr(ord(c) - 0xE000) if 0xE000 <= ord(c) < 0xE100 else c for c in v), ln) if k == "str" else (k, v, ln) for k, v, ln in toks]
+
+
+class NimNode:
+    """macros.NimNode, as far as a translating macro reads it: kind, children, the literal values, `$`, repr"""
+    KINDS = ["nnkNone", "nnkEmpty", "nnkIdent", "nnkSym", "nnkType", "nnkCharLit", "nnkIntLit", "nnkInt8Lit", "nnkInt16Lit", "nnkInt32Lit", "nnkInt64Lit", "nnkUIntLit",
+             "nnkUInt8Lit", "nnkUInt16Lit", "nnkUInt32Lit", "nnkUInt64Lit", "nnkFloatLit", "nnkFloat32Lit", "nnkFloat64Lit", "nnkFloat128Lit", "nnkStrLit", "nnkRStrLit",
+             "nnkTripleStrLit", "nnkNilLit", "nnkCommand", "nnkCall", "nnkInfix", "nnkPrefix", "nnkPar", "nnkBracketExpr", "nnkDotExpr", "nnkAsgn", "nnkStmtList",
+             "nnkLetSection", "nnkIdentDefs", "nnkForStmt", "nnkDiscardStmt", "nnkCommentStmt", "nnkTupleConstr", "nnkIfStmt", "nnkWhileStmt", "nnkVarSection"]   # (the order of system's NimNodeKind up to nnkNilLit: the ranges a macro writes rely on it)
+    FIELDS = {"kind", "intval", "floatval", "strval", "repr"}
+
+    def __init__(self, kind, sons=(), value=None, text=""):
+        self.kind, self.sons, self.value, self.text = NimNode.KINDS.index(kind), list(sons), value, text
+
+    def field(self, name):
+        if name == "kind": return self.kind
+        if name == "repr": return self.text or str(self)
+        return self.value
+
+    def __len__(self): return len(self.sons)
+    def __iter__(self): return iter(self.sons)
+
+    def __str__(self):
+        return str(self.value) if self.value is not None else (self.text or NimNode.KINDS[self.kind])
+
+
+class BodyParser(ShimParser):
+    """parses the body a user hands to `deviceRhs` into the tree the Nim compiler would give the macro: parentheses are nodes of their own (nnkPar)"""
+    def primary(self):
+        tok = self.peek()
+        if tok[0] == "op" and tok[1] == "(":
+            self.next()
+            items = self.call_args(")")
+            if len(items) != 1 or items[0][0] is not None: raise NimError("tuples are not part of a right-hand side")
+            node = ("par", items[0][2])
+            while True:
+                tok = self.peek()
+                if tok[0] == "op" and tok[1] == ".":
+                    self.next(); node = ("dot", node, self.next()[1])
+                elif tok[0] == "op" and tok[1] == "[":
+                    self.next(); node = ("idx", node, self.call_args("]"))
+                else:
+                    return node
+        return super().primary()
+
+
+def nim_ast(body_text):
+    """the body of a `deviceRhs(...): body` block as a NimNode tree (identifiers keep the spelling of the source: the macro compares them)"""
+    spelled = {}
+    for w in re.findall(r"[A-Za-z_]\w*", body_text):
+        spelled.setdefault(norm_ident(w), w)
+    ident = lambda n: NimNode("nnkIdent", value=spelled.get(n, n))
+
+    def conv(a):
+        k = a[0]
+        if k == "num": return NimNode("nnkFloatLit" if isinstance(a[1], float) else "nnkIntLit", value=a[1])
+        if k == "str": return NimNode("nnkStrLit", value=a[1])
+        if k == "id": return ident(a[1])
+        if k == "par": return NimNode("nnkPar", [conv(a[1])])
+        if k == "bin": return NimNode("nnkInfix", [ident(a[1]), conv(a[2]), conv(a[3])])
+        if k == "un": return NimNode("nnkPrefix", [ident(a[1]), conv(a[2])])
+        if k == "idx": return NimNode("nnkBracketExpr", [conv(a[1])] + [conv(x[2]) for x in a[2]])
+        if k == "dot": return NimNode("nnkDotExpr", [conv(a[1]), ident(a[2])])
+        if k == "call": return NimNode("nnkCall", [conv(a[1])] + [conv(x[2]) for x in a[2]])
+        raise NimError(f"expression {k} has no NimNode form here")
+
+    def stmt(st):
+        k = st[0]
+        if k == "assign" and st[1] == "=": return NimNode("nnkAsgn", [conv(st[2]), conv(st[3])])
+        if k == "decl" and st[2] == "let":
+            return NimNode("nnkLetSection", [NimNode("nnkIdentDefs", [ident(names[0]), NimNode("nnkEmpty"), conv(init)]) for names, _t, init in st[1]])
+        if k == "decl": return NimNode("nnkVarSection")
+        if k == "for": return NimNode("nnkForStmt", [ident(st[1]), conv(st[2]), NimNode("nnkStmtList", [stmt(x) for x in st[3]])])
+        if k == "pass": return NimNode("nnkDiscardStmt")
+        if k == "if": return NimNode("nnkIfStmt")
+        if k == "while": return NimNode("nnkWhileStmt")
+        if k == "expr": return conv(st[1])
+        raise NimError(f"statement {k} has no NimNode form here")
+
+    ps = BodyParser(_tokenize(body_text))
+    out = []
+    while not ps.at("eof"):
+        if ps.accept("nl") or ps.accept("dedent") or ps.accept("indent"): continue
+        out.append(stmt(ps.stmt()))
+    return NimNode("nnkStmtList", out)
 
 
 class FFIProc:
@@ -246,7 +374,22 @@ class ShimInterp(Interp):
         g[norm_ident("allocCStringArray")] = lambda s: CStringArray(s)
         g[norm_ident("deallocCStringArray")] = lambda a: None
         g[norm_ident("IOError")] = "IOError"
+        for i, kname in enumerate(NimNode.KINDS): g[norm_ident(kname)] = i
+        g["chr"] = chr
+        g["contains"] = lambda s, sub: sub in s
+        g["find"] = lambda s, sub, start=0: (s.find(sub, start) if isinstance(s, str) else (s.index(sub) if sub in s else -1))
+        g["join"] = lambda parts, sep="": sep.join(parts)
+        g["delete"] = lambda s, i: s.pop(i) and None
+        g["error"] = self._macro_error
+        g[norm_ident("BiggestFloat")] = float
+        g[norm_ident("isMainModule")] = False
+        g[norm_ident("newLit")] = lambda v: v
+        g[norm_ident("newTree")] = lambda kind, *sons: list(sons)
         self.types["Odeoptions"] = ("object", [(n, "float") for n in ("dt", "dtmax", "dtmin", "tstart", "abstol", "reltol", "scalemax", "scalemin")])
+
+    @staticmethod
+    def _macro_error(msg, node=None):
+        raise NimError(f"compile-time error: {msg}")
 
     # stand-in for the reference's constructor (ode.nim:78-104): defaults, abs() of every field but tStart, the two checks it makes
     @staticmethod
@@ -374,6 +517,31 @@ class ShimInterp(Interp):
     # ---- statements ----------------------------------------------------------------------------------------------------------------
     def exec_stmt(self, st, env):
         k = st[0]
+        if k == "case":   # as the base interpreter's, plus `of a .. b` ranges
+            subject = self.eval(st[1], env)
+            for vals, body in st[2]:
+                for v in vals:
+                    x = self.eval(v, env)
+                    if (subject in x) if isinstance(x, range) else (x == subject):
+                        self.exec_block(body, env); return None
+            if st[3] is not None: self.exec_block(st[3], env)
+            return None
+        if k == "blockstmt":
+            from oracle.nim_subset import _Break
+            try:
+                return self.exec_block(st[1], env, want_value=True)   # a block is an expression: its last statement's value
+            except _Break:
+                pass
+            return None
+        if k == "for2":
+            from oracle.nim_subset import _Break
+            try:
+                for i, v in enumerate(self.eval(st[3], env)):
+                    scope = Env(env); scope.vars[st[1]] = i; scope.vars[st[2]] = v
+                    self.exec_block(st[4], scope, new_scope=False)
+            except _Break:
+                pass
+            return None
         if k == "typedef":
             for name, kind, payload in st[1]:
                 self.types[name] = (kind, payload)
@@ -484,7 +652,12 @@ class ShimInterp(Interp):
             raise NimError("addr of this expression is not modelled")
         if k == "un" and node[1] == "$":
             v = self.eval(node[2], env)
+            if isinstance(v, float): return repr(v)           # Nim's `$` on a float: shortest text that reads back as the same double
             return "" if v is None else str(v)
+        if k == "set": return [self.eval(a, env) for a in node[1]]
+        if k == "par": return self.eval(node[1], env)
+        if k == "bin" and node[1] == "&":
+            return str(self.eval(node[2], env)) + str(self.eval(node[3], env))
         if k == "bin" and node[1] in ("div", "mod"):
             a, b = self.eval(node[2], env), self.eval(node[3], env)
             q = abs(a) // abs(b) * (1 if (a < 0) == (b < 0) else -1)      # Nim's div truncates
@@ -493,6 +666,7 @@ class ShimInterp(Interp):
             recv = self.eval(node[1], env)
             if isinstance(recv, NimObj) and recv.has(node[2]): return recv.get(node[2])
             if node[2] in self._CONV: return self._CONV[node[2]](recv)
+            if isinstance(recv, NimNode) and node[2] in NimNode.FIELDS: return recv.field(node[2])
             if node[2] == "len": return len(recv)
             if node[2] == "isnil" or node[2] == "isNil": return recv is None
             return self.call_value(self.resolve_callable(node[2], recv, env), [recv], {}, env)
@@ -502,7 +676,8 @@ class ShimInterp(Interp):
                 return ("generic", head[1], node[2])
             base = self.eval(node[1], env)
             i = self.eval(node[2][0][2], env)
-            if isinstance(i, range): return list(base[i.start:i.stop])
+            if isinstance(i, range): return base[i.start:i.stop] if isinstance(base, str) else list(base[i.start:i.stop])
+            if isinstance(base, NimNode): return base.sons[i]
             if isinstance(base, dict):
                 if i not in base: raise NimError(f"KeyError: key not found: {i}")
                 return base[i]
@@ -529,12 +704,17 @@ class ShimInterp(Interp):
                 recv = self.eval(fnode[1], env)
                 if isinstance(recv, list):
                     recv.append(self.eval(arglist[0][2], env)); return None
+                if isinstance(recv, str):                  # strings are values: the variable gets the longer string
+                    self.assign(fnode[1], recv + str(self.eval(arglist[0][2], env)), env); return None
             if fnode[0] == "dot" and fnode[2] == "toc" and False: pass
         return super().eval(node, env)
 
 
-def load(lib_path=LIB_PATH):
+def load(lib_path=LIB_PATH, macros=False):
     it = ShimInterp(lib_path)
     it.load_bindings()
     it.load_shim()
+    if macros:   # nim/rhs_macro.nim: its translating procs, macros and templates (not its `when isMainModule` self-test, which needs the compiler's own macro expansion)
+        text = open(os.path.join(NIM_DIR, "rhs_macro.nim")).read()
+        it.exec_toplevel(text[:text.index("when isMainModule")])
     return it

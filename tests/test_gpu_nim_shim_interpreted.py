@@ -190,3 +190,44 @@ def test_consumers(env):
         got = it.call(name, poly, X, ctx, 0.1, sw)
         ref = fn(ppoly, X, ctx=pctx, dx=0.1, sweep=np.array(sw), n=3)
         assert np.array_equal(_rows(got, (3,)), ref if isinstance(ref, np.ndarray) else ref.cpu().numpy()), name
+
+
+def test_right_hand_sides_written_in_nim(env):
+    """nim/rhs_macro.nim: `deviceRhs(dim, keys): body` — the user's f(t, y, ctx) (ode.nim:36) as a restricted Nim body, translated by the macro's own
+    procs (interpreted), compiled by the backend, solved through the interpreted shim: the bits of the compiled-in kinds written the same way."""
+    nn, _, nimrun = env
+    it = nimrun.load(macros=True)
+    rng = np.random.default_rng(21)
+    n = 10
+    y0 = np.stack([rng.uniform(-5, 5, n) for _ in range(3)])
+    tspan = [0.0, 0.2, 0.5]
+    f = it.call("deviceRhs", 3, ["sigma", "rho", "beta"], body=nimrun.nim_ast('''
+dy[0] = ctx.fValues["sigma"] * (y[1] - y[0])
+dy[1] = y[0] * (ctx.fValues["rho"] - y[2]) - y[1]
+dy[2] = y[0] * y[1] - ctx.fValues["beta"] * y[2]
+'''))
+    _, ys = it.call("solveODE", f, _batch(it, y0), tspan, ctx=_ctx(it, sigma=10.0, rho=28.0, beta=8.0 / 3.0), integrator="dopri54")
+    _, yr = nn.solveODE(nn.Rhs.lorenz(), y0, tspan, integrator="dopri54")
+    assert np.array_equal(_rows(ys, y0.shape), np.asarray(yr))
+    # a loop over the components, a `let`, an integer-to-float conversion, `mod` in an index: the ring of 16
+    yr0 = rng.uniform(-1, 1, (16, n))
+    ring = it.call("deviceRhs", 16, ["c"], body=nimrun.nim_ast('''
+for i in 0 ..< 16:
+  dy[i] = -(float(i + 1) / 16.0) * y[i] + ctx.fValues["c"] * y[(i + 1) mod 16]
+'''))
+    _, ys = it.call("solveODE", ring, _batch(it, yr0), tspan, ctx=_ctx(it, c=0.1), integrator="tsit54")
+    _, yref = nn.solveODE(nn.Rhs.ring(), yr0, tspan, ctx=nn.newNumContext({"c": 0.1}), integrator="tsit54")
+    assert np.array_equal(_rows(ys, yr0.shape), np.asarray(yref))
+    # ctx.tValues: a shared vector and a per-IVP one, their layout given next to the body (deviceRhsCtx) — against the same right-hand side as C++ source
+    import torch
+    m = 6
+    gains = [float(v) for v in rng.uniform(-1, 1, m)]
+    g = it.call("deviceRhsCtx", 1, ["a"], [2, 1], [False, True],
+                body=nimrun.nim_ast('dy[0] = ctx.fValues["a"] * y[0] * ctx.tValues["w"][1] + ctx.tValues["g"][0] * ctx.tValues["w"][0]'))
+    it.call("bindCtx", g, [0.5, 2.0], gains, [], 0, m)
+    yc0 = rng.uniform(0.5, 1.5, m)
+    _, ys = it.call("solveODE", g, _batch(it, yc0), [0.0, 0.3], ctx=_ctx(it, a=-0.7), integrator="tsit54")
+    pg = nn.Rhs.custom(1, "dy[0] = (((p[0] * y[0]) * w[1]) + (g(0) * w[0]));", keys=("a",), tvalues={"w": 2, "g": 1}, per_ivp=("g",), name="ctx_macro_py")
+    pctx = nn.newNumContext({"a": -0.7}, {"w": np.array([0.5, 2.0]), "g": np.array([gains])})
+    _, yr = nn.solveODE(pg, torch.from_numpy(yc0).cuda(), [0.0, 0.3], ctx=pctx, integrator="tsit54")
+    assert np.array_equal(_rows(ys, yc0.shape), yr.cpu().numpy())

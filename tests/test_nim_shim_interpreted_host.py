@@ -59,3 +59,53 @@ def test_a_solve_reaches_the_library(it):
         with pytest.raises(Exception, match="nnhip error|IOError|device"):
             it.call("solveODE", spec, batch, [0.0, 1.0], ctx=ctx, integrator="rk4")
     assert it.ffi_log[n0:n0 + 2] == ["nnhip_ode_integrator_id", "nnhip_ode_solve_batch_sweep_f64"]
+
+
+# ---- nim/rhs_macro.nim: the translating procs of the `deviceRhs` macro, run on the tree of a Nim body ------------------------------------------
+LORENZ = '''
+dy[0] = ctx.fValues["sigma"] * (y[1] - y[0])
+dy[1] = y[0] * (ctx.fValues["rho"] - y[2]) - y[1]
+dy[2] = y[0] * y[1] - ctx.fValues["beta"] * y[2]
+'''
+
+
+@pytest.fixture(scope="module")
+def mac():
+    import nimrun
+    return nimrun.load(macros=True), nimrun
+
+
+def test_the_macro_emits_what_its_own_self_test_expects(mac):
+    import os
+    import re
+    it, nimrun = mac
+    text = open(os.path.join(nimrun.NIM_DIR, "rhs_macro.nim")).read()
+    expected = re.search(r'doAssert src == "(.*)"', text).group(1).replace("\\n", "\n")          # the literal of the file's `when isMainModule` block
+    assert it.call("deviceRhsSource", ["sigma", "rho", "beta"], nimrun.nim_ast(LORENZ)) == expected
+    # every Nim infix node is one parenthesised C operation, integer literals and loop variables become doubles where Nim would convert them
+    src = it.call("deviceRhsSource", ["c"], nimrun.nim_ast('''
+for i in 0 ..< 16:
+  let w = float(i + 1) / 16.0
+  dy[i] = -w * y[i] + ctx.fValues["c"] * y[(i + 1) mod 16]
+'''))
+    assert src == ("for (int i = 0; i < 16; ++i) {\n  const double w = ((double)(((double)i + 1.0)) / 16.0);\n"
+                   "  dy[i] = (((-w) * y[i]) + (p[0] * y[(((i + 1)) % 16)]));\n}\n")
+    assert it.call("deviceRhsSource", ["a"], nimrun.nim_ast("dy[0] = sqrt(abs(y[0])) * ctx.fValues[\"a\"] + min(t, 2) - 1e-3")) == \
+        "dy[0] = (((sqrt(fabs(y[0])) * p[0]) + nnhip::nmin(t, 2.0)) - 0.001);\n"
+
+
+@pytest.mark.parametrize("body,why", [
+    ("dy[0] = y[0] ^ 2", "operator"), ("dy[0] = ctx.fValues[\"nope\"]", "not in `keys`"), ("y[0] = 1.0", "assignment"), ("dy[0] = foo(y[0])", "call of"),
+    ("dy[k] = 1.0", "index variable"), ("dy[0] = ctx.tValues[\"w\"][0]", "use deviceRhsCtx"), ("if t > 0.0: dy[0] = 1.0", "statement of kind")])
+def test_the_macro_refuses_what_it_cannot_translate(mac, body, why):
+    it, nimrun = mac
+    with pytest.raises(Exception, match=why):
+        it.call("deviceRhsSource", ["a"], nimrun.nim_ast(body))
+
+
+def test_ctx_vectors_get_their_layout_late(mac):
+    """deviceRhsCtxSource: (text with the vector accesses still bracket-neutral, the vectors in order of first use)"""
+    it, nimrun = mac
+    src, vectors = it.call("deviceRhsCtxSource", ["a"], nimrun.nim_ast('dy[0] = ctx.fValues["a"] * y[0] * ctx.tValues["w"][1] + ctx.tValues["g"][0] * ctx.tValues["w"][0]'))
+    assert vectors == ["w", "g"]
+    assert src.replace(chr(1), "<").replace(chr(2), ">") == "dy[0] = (((p[0] * y[0]) * w<1>) + (g<0> * w<0>));\n"
