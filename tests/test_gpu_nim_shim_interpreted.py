@@ -231,3 +231,38 @@ for i in 0 ..< 16:
     pctx = nn.newNumContext({"a": -0.7}, {"w": np.array([0.5, 2.0]), "g": np.array([gains])})
     _, yr = nn.solveODE(pg, torch.from_numpy(yc0).cuda(), [0.0, 0.3], ctx=pctx, integrator="tsit54")
     assert np.array_equal(_rows(ys, yc0.shape), yr.cpu().numpy())
+
+
+def test_shim_plus_library_return_what_the_references_text_returns(env):
+    """The closing of the loop: nim/numericalnim_hip.nim (interpreted) over the library (GPU) against tests/golden/reference_text_vectors.json — what
+    the reference's OWN ode.nim returns, executed by the same interpreter, on the inputs of all 101 fixtures: the times and every bit of every row."""
+    import json
+    import os
+    from golden_util import fh, load_cases
+    nn, it, _ = env
+    here = os.path.dirname(os.path.abspath(__file__))
+    reftext = {c["name"]: c for c in json.load(open(os.path.join(here, "golden", "reference_text_vectors.json")))["cases"]}
+    kinds = {0: ("rhsNegY", ()), 1: ("rhsLinear", ("a",)), 2: ("rhsLorenz", ("sigma", "rho", "beta")), 3: ("rhsRing", ("c",)), 4: ("rhsAffineT", ("a", "b")),
+             5: ("rhsVanDerPol", ("mu",))}
+    done = 0
+    for case in load_cases():
+        dim = max(case["dim"], 1)
+        integ = nn._lib.lib().nnhip_ode_integrator_id(case["integrator"].encode())
+        if not nn._lib.lib().nnhip_ode_supported(integ, case["rhs_kind"], dim, 0, 0):
+            continue
+        kname, keys = kinds[case["rhs_kind"]]
+        spec = it.expr(f"RhsSpec(kind: {kname}, keys: k)", k=list(keys))
+        ctx = _ctx(it, **dict(zip(keys, fh(case["params"]))))
+        y0 = np.stack([fh(y) for y in case["y0"]])                      # [n, dim]
+        batch = _batch(it, y0[:, 0] if case["dim"] == 0 else np.ascontiguousarray(y0.T))
+        opt = it.call("newODEoptions", **case["options"])
+        t, ys = it.call("solveODE", spec, batch, [float(v) for v in fh(case["tspan"])], opt, ctx, case["integrator"])
+        ref = reftext[case["name"]]
+        assert [float(v).hex() for v in t] == ref["t"], case["name"]
+        rows = _rows(ys, (dim, len(case["y0"])))                          # [n_t, dim, n]
+        for i, r in enumerate(ref["ivps"]):
+            got = rows[:r["n_y"], :, i]
+            assert [float(v).hex() for v in got.ravel()] == r["y"], (case["name"], i)
+            assert np.isnan(rows[r["n_y"]:, :, i]).all(), (case["name"], i)
+        done += 1
+    assert done >= 95, done
