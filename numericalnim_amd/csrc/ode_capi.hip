@@ -67,6 +67,7 @@ int g_sort_copy = 0;      // tuning knob "sort_copy": the binned solve reorders 
 int g_adv_steps = 1;      // tuning knob "adv_steps_per_launch": loop iterations per IVP and launch of nnhip_ode_adaptive_stream_f64_dev (1 = the IntegratorProc
                           // seam proper; K > 1 keeps the state in registers for K iterations: 8*(4d+5)/K bytes per attempted step, a different traffic model)
 int g_sort_auto_key = 1;   // tuning knob "sort_auto_key": what the automatic binned solve ranks by — 0 the probe's progress, 1 the steps still to take (tEnd - t) / dt (forward spans)
+int g_calls_bin = 1;       // tuning knob "calls_bin": the per-IVP-call solves (every IVP its own tEnd) of 4096 IVPs or more integrate the longest spans first, binned by span
 int g_sort_rebin_steps = 0;  // tuning knob "sort_rebin_steps": > 0 = the resumed automatic binned solve stops after that many further accepted steps per IVP, re-bins by the steps still to take, and finishes
 int g_sort_resume = 0;     // tuning knob "sort_resume": the automatic binned solve continues from its probe's state instead of restarting (where the loop's state is (t, dt, y)).
                           // Built, bit-identical, measured and NOT the default (profiles/r04_bench_divergence.json): the resumed pass has to run on the per-call instantiation of
@@ -359,6 +360,7 @@ int nnhip_tune_set(const char* key, int value) {
   if (k == "sort_copy") { g_sort_copy = value != 0; return NNHIP_OK; }
   if (k == "adv_steps_per_launch") { if (value < 1 || value > 1024) return fail(NNHIP_EVALUE, "adv_steps_per_launch must be 1..1024"); g_adv_steps = value; return NNHIP_OK; }
   if (k == "sort_auto_key") { if (value != 0 && value != 1) return fail(NNHIP_EVALUE, "sort_auto_key must be 0 or 1"); g_sort_auto_key = value; return NNHIP_OK; }
+  if (k == "calls_bin") { if (value != 0 && value != 1) return fail(NNHIP_EVALUE, "calls_bin must be 0 or 1"); g_calls_bin = value; return NNHIP_OK; }
   if (k == "sort_rebin_steps") { if (value < 0 || value > 1000000) return fail(NNHIP_EVALUE, "sort_rebin_steps must be in 0..1000000"); g_sort_rebin_steps = value; return NNHIP_OK; }
   if (k == "sort_resume") { if (value != 0 && value != 1) return fail(NNHIP_EVALUE, "sort_resume must be 0 or 1"); g_sort_resume = value; return NNHIP_OK; }
   if (k == "sort_min_spread_permille") { if (value < 0 || value > 1000) return fail(NNHIP_EVALUE, "sort_min_spread_permille must be in 0..1000"); g_sort_min_spread = value / 1000.0; return NNHIP_OK; }
@@ -734,7 +736,30 @@ int nnhip_ode_solve_batch_calls_f64_dev(const nnhip_ode_options* opt, int integr
   ps.a.nZero = 1;                                   // tStart_i is in every tspan_i
   ps.a.uniformFull[0] = ps.a.uniformFull[1] = -1;   // no batch-wide step schedule: the spans differ
   ps.a.nTail[0] = ps.a.nTail[1] = 0;
-  return launch_solve_range(ps, 0, N, (hipStream_t)stream);
+  // N separate calls rarely take the same number of steps: lanes of a wavefront finish together when the calls are integrated longest span first, binned
+  // by |tEnd_i - tStart_i| (results are written at the call's own index: the same bits, in the caller's order).  Nothing here waits for the device: whether
+  // the spans differ enough to bother (5 %, knob "sort_min_spread_permille") is decided by the binning kernel itself; the scratch comes from the stream-ordered
+  // allocator, and without it the calls run in the caller's order.
+  hipStream_t s = (hipStream_t)stream;
+  if (g_calls_bin && N >= 4096 && N < ((int64_t)1 << 31)) {
+    const size_t colKey = ((size_t)N * 8 + 255) & ~(size_t)255, colPerm = ((size_t)N * 4 + 255) & ~(size_t)255;
+    const int64_t sortBytes = nnhip::argsort_workspace_bytes(N);
+    char* d = nullptr;
+    if (hipMallocAsync((void**)&d, colKey + colPerm + (size_t)sortBytes, s) == hipSuccess && d) {
+      double* key = (double*)d;
+      uint32_t* perm = (uint32_t*)(d + colKey);
+      void* sortWs = d + colKey + colPerm;
+      bool ok = nnhip::span_key_f64(t_end, t_start, opt->tStart, key, N, s) == hipSuccess;
+      ok = ok && nnhip::key_range_f64(key, N, sortWs, nullptr, s) == hipSuccess;
+      ok = ok && nnhip::argsort_f64(key, N, perm, sortWs, sortBytes, s, g_sort_min_spread > 0.0 ? g_sort_min_spread : 1e-300) == hipSuccess;
+      if (ok) ps.a.perm = perm;
+      rc = launch_solve_range(ps, 0, N, s);
+      (void)hipFreeAsync(d, s);
+      return rc;
+    }
+    (void)hipGetLastError();
+  }
+  return launch_solve_range(ps, 0, N, s);
 }
 
 int nnhip_ode_solve_batch_tend_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,

@@ -82,7 +82,8 @@ bool launch_dense_rows_kind(int rhs_kind, int dim, int64_t N, int64_t is, int64_
                             const DenseRows& r, const Params& P, hipStream_t s, hipError_t* err);
 // ode_sort.hip
 int64_t argsort_workspace_bytes(int64_t N);
-hipError_t argsort_f64(const double* keys, int64_t N, uint32_t* perm_out, void* ws, int64_t ws_bytes, hipStream_t s);
+hipError_t argsort_f64(const double* keys, int64_t N, uint32_t* perm_out, void* ws, int64_t ws_bytes, hipStream_t s, double min_spread_on_device = 0.0);
+hipError_t span_key_f64(const double* tEnd, const double* tStart, double t0, double* out, int64_t N, hipStream_t s);
 hipError_t remaining_key_f64(const double* t, const double* dt, double tEnd, double* out, int64_t N, hipStream_t s);
 hipError_t negate_f64(const double* in, double* out, int64_t N, hipStream_t s);
 hipError_t key_range_f64(const double* keys, int64_t N, void* ws, unsigned long long* pinned2, hipStream_t s);

@@ -61,8 +61,30 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_kernel(const double* __
 }
 // pass 2: every block scans the histogram into bin starts (4096 counters: cheaper than a launch of its own), reserves its share of each bin with one
 // atomic per bin it holds keys of, and writes the indices of its keys there; `cursor` arrives zeroed
+__device__ double img_to_double(unsigned long long o) {
+  const unsigned long long b = (o >> 63) ? (o & 0x7fffffffffffffffULL) : ~o;
+  return __longlong_as_double((long long)b);
+}
+// `minSpread` > 0: keys within that fraction of their magnitude of each other (or no finite key at all) leave the batch in the caller's order — decided here, on
+// the device, for callers that must not wait for the range (the per-IVP-call entries); the sorted entry decides on the host and passes 0
 __global__ __launch_bounds__(kBinThreads) void bin_place_kernel(const uint16_t* __restrict__ bins, const uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor,
-                                                                 uint32_t* __restrict__ perm, int64_t n) {
+                                                                 uint32_t* __restrict__ perm, int64_t n, const unsigned long long* __restrict__ range, double minSpread) {
+  if (minSpread > 0.0) {
+    bool narrow = range[0] > range[1];
+    if (!narrow) {
+      const double mn = img_to_double(range[0]), mx = img_to_double(range[1]);
+      const double scale = fabs(mn) > fabs(mx) ? fabs(mn) : fabs(mx);
+      narrow = !(scale > 0.0 && (mx - mn) > minSpread * scale);
+    }
+    if (narrow) {  // uniform: the whole grid takes this branch
+      const int64_t base = (int64_t)blockIdx.x * (kBinThreads * kBinItems);
+      for (int k = 0; k < kBinItems; ++k) {
+        const int64_t i = base + k * kBinThreads + threadIdx.x;
+        if (i < n) perm[i] = (uint32_t)i;
+      }
+      return;
+    }
+  }
   __shared__ uint32_t start[kBins];  // bin starts, then this block's base inside each bin
   __shared__ uint32_t lh[kBins];
   __shared__ uint32_t waveSum[kBinThreads / 64];
@@ -222,7 +244,7 @@ int64_t argsort_workspace_bytes(int64_t N) {
 // perm_out[k] = index of an IVP of the k-th bin in ascending key order.  N < 2^31.  key_range_f64(keys, N, ws, ..) has been enqueued on the same
 // stream before.  Failures come back as the hipError_t; the C entry that called turns them into its NNHIP_* code and thread-local message
 // (nothing is printed from here).
-hipError_t argsort_f64(const double* keys, int64_t N, uint32_t* perm_out, void* ws, int64_t ws_bytes, hipStream_t s) {
+hipError_t argsort_f64(const double* keys, int64_t N, uint32_t* perm_out, void* ws, int64_t ws_bytes, hipStream_t s, double min_spread_on_device) {
   if (N <= 0) return hipSuccess;
   if (N >= (int64_t)1 << 31 || ws_bytes < argsort_workspace_bytes(N)) return hipErrorInvalidValue;
   char* base = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
@@ -240,7 +262,7 @@ hipError_t argsort_f64(const double* keys, int64_t N, uint32_t* perm_out, void* 
   }
   const uint16_t* b = bins;
   const uint32_t* h = hist;
-  void* args[] = {(void*)&b, (void*)&h, (void*)&cursor, (void*)&perm_out, (void*)&N};
+  void* args[] = {(void*)&b, (void*)&h, (void*)&cursor, (void*)&perm_out, (void*)&N, (void*)&range, (void*)&min_spread_on_device};
   return hipLaunchKernel((const void*)bin_place_kernel, dim3(blocks), dim3(kBinThreads), args, 0, s);
 }
 
@@ -304,6 +326,22 @@ hipError_t remaining_key_f64(const double* t, const double* dt, double tEnd, dou
   if (N <= 0) return hipSuccess;
   void* args[] = {(void*)&t, (void*)&dt, (void*)&tEnd, (void*)&out, (void*)&N};
   return hipLaunchKernel((const void*)remaining_key_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), args, 0, s);
+}
+
+// key of the per-IVP-call solves: the longest spans first, -|tEnd_i - tStart_i| (t_start NULL: the batch-wide t0); non-finite spans last
+namespace {
+__global__ void span_key_kernel(const double* __restrict__ tEnd, const double* __restrict__ tStart, double t0, double* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const double r = fabs(tEnd[i] - (tStart ? tStart[i] : t0));
+    out[i] = (r == r && r != __longlong_as_double(0x7ff0000000000000LL)) ? -r : __longlong_as_double(0x7ff0000000000000LL);
+  }
+}
+}  // namespace
+hipError_t span_key_f64(const double* tEnd, const double* tStart, double t0, double* out, int64_t N, hipStream_t s) {
+  if (N <= 0) return hipSuccess;
+  void* args[] = {(void*)&tEnd, (void*)&tStart, (void*)&t0, (void*)&out, (void*)&N};
+  return hipLaunchKernel((const void*)span_key_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), args, 0, s);
 }
 
 hipError_t negate_f64(const double* in, double* out, int64_t N, hipStream_t s) {

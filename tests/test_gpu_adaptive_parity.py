@@ -1234,3 +1234,43 @@ def test_host_form_of_the_per_ivp_tspan_solve(nn, dev):
             assert _same_bits(y1.cpu().numpy()[:k, :, 0], yh[:k, :, i]), (integrator, i)
     with pytest.raises(ValueError):
         nn.solveODECallsTspan(f, y0, ts[:5], opts)
+
+
+@pytest.mark.parametrize("integrator", ["dopri54", "tsit54", "rk4", "bs32"])
+def test_per_call_solves_binned_by_span_are_the_same_calls(nn, dev, integrator):
+    """4096 calls or more are integrated longest span first (knob "calls_bin", default on): the same rows, row counts and step counters at the caller's
+    indices as in the caller's order — every IVP its own tEnd / tStart / tolerances, both directions, refused calls, non-finite ends, both layouts, a
+    16-component system; equal spans (nothing to bin: the order stays the caller's) and a batch below the threshold."""
+    import torch
+    L = nn._lib.lib()
+    rng = np.random.default_rng(17)
+    dev_t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    def both(fn):
+        out = []
+        for knob in (1, 0):
+            assert L.nnhip_tune_set(b"calls_bin", knob) == 0
+            try:
+                out.append(fn())
+            finally:
+                assert L.nnhip_tune_set(b"calls_bin", 1) == 0
+        (ya, ca), (yb, cb) = out
+        assert torch.equal(torch.nan_to_num(ya, nan=-1.0), torch.nan_to_num(yb, nan=-1.0)) and torch.equal(torch.isnan(ya), torch.isnan(yb))
+        assert all(torch.equal(ca[k], cb[k]) for k in ca)
+        return ya, ca
+
+    for f, dim, layout, n in ((nn.Rhs.vanderpol(1.5), 2, 0, 9000), (nn.Rhs.lorenz(), 3, 1, 5000), (nn.Rhs.ring(0.1), 16, 1, 4200), (nn.Rhs.lorenz(), 3, 0, 700)):
+        y0 = rng.uniform(0.5, 1.5, (n, dim)) + (np.array([0.0, 0.0, 20.0]) if dim == 3 else 0.0)
+        ts = rng.uniform(-0.2, 0.2, n)
+        te = ts + rng.uniform(-0.5, 1.5, n) * rng.choice([1.0, 0.05], n)
+        te[5], te[6], te[7] = ts[5], np.nan, np.inf                       # an empty span and two ends no call can reach
+        tol = 10 ** rng.uniform(-8, -4, n)
+        dmin = np.full(n, 1e-7); dmin[11] = 10.0                           # dtMax < dtMin: refused
+        y0l = y0 if layout == 1 else y0.T
+        kw = dict(integrator=integrator, layout=layout, t_start=dev_t(ts), absTol=dev_t(tol), relTol=dev_t(tol), dtMax=dev_t(np.full(n, 0.3)), dtMin=dev_t(dmin),
+                  dt=dev_t(np.full(n, 1e-2)))
+        y, cnt = both(lambda: nn.solveODEPerIvpEnd(f, dev_t(y0l), dev_t(te), nn.newODEoptions(), **kw))
+        assert int(cnt["steps"].max()) >= 2 * max(int(cnt["steps"].float().median()), 1) or n < 4096   # the calls really differ in length
+        both(lambda: nn.solveODEPerIvpEnd(f, dev_t(y0l), dev_t(np.full(n, 0.7)), nn.newODEoptions(absTol=1e-6, relTol=1e-6, dtMax=0.3, dtMin=1e-7, dt=1e-2),
+                                          integrator=integrator, layout=layout))                                             # equal spans
+    assert L.nnhip_tune_set(b"calls_bin", 2) != 0
