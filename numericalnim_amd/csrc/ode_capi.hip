@@ -811,7 +811,17 @@ int nnhip_ode_solve_batch_tspans_f64_dev(const nnhip_ode_options* opt, int integ
   }
   double* grid = (double*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
   int32_t* counts = (int32_t*)((char*)grid + (((size_t)N * (size_t)n_t * 8 + 255) & ~(size_t)255));
-  HIP_TRY(nnhip::prepare_tspans(tspans, n_t, N, t_start, opt->tStart, grid, counts, t_out, s));
+  // as for the per-IVP tEnd solves: from 4096 calls on, the calls that integrate over the longest time go first (the key comes out of the pre-pass)
+  char* d = nullptr;
+  double* spanKey = nullptr;
+  const size_t colKey = ((size_t)N * 8 + 255) & ~(size_t)255, colPerm = ((size_t)N * 4 + 255) & ~(size_t)255;
+  const int64_t sortBytes = nnhip::argsort_workspace_bytes(N);
+  if (g_calls_bin && N >= 4096 && N < ((int64_t)1 << 31)) {
+    if (hipMallocAsync((void**)&d, colKey + colPerm + (size_t)sortBytes, s) == hipSuccess && d) spanKey = (double*)d;
+    else { d = nullptr; (void)hipGetLastError(); }
+  }
+  auto done = [&](int code) { if (d) (void)hipFreeAsync(d, s); return code; };
+  if (nnhip::prepare_tspans(tspans, n_t, N, t_start, opt->tStart, grid, counts, t_out, s, spanKey) != hipSuccess) return done(fail(NNHIP_EHIP, "preparing the per-IVP tspans failed"));
   ps.a.n_t = n_t;
   ps.a.useDense = n_t != 2 ? 1 : 0;  // :499-502
   ps.a.perCall.tGrid = grid; ps.a.perCall.tCounts = counts;
@@ -819,7 +829,14 @@ int nnhip_ode_solve_batch_tspans_f64_dev(const nnhip_ode_options* opt, int integ
   ps.a.perCall.dtMax = dt_max; ps.a.perCall.dtMin = dt_min; ps.a.perCall.dt = dt_fixed;
   ps.a.uniformFull[0] = ps.a.uniformFull[1] = -1;   // no batch-wide step schedule: the spans differ
   ps.a.nTail[0] = ps.a.nTail[1] = 0;
-  return launch_solve_range(ps, 0, N, s);
+  if (spanKey) {
+    uint32_t* perm = (uint32_t*)(d + colKey);
+    void* sortWs = d + colKey + colPerm;
+    bool ok = nnhip::key_range_f64(spanKey, N, sortWs, nullptr, s) == hipSuccess;
+    ok = ok && nnhip::argsort_f64(spanKey, N, perm, sortWs, sortBytes, s, g_sort_min_spread > 0.0 ? g_sort_min_spread : 1e-300) == hipSuccess;
+    if (ok) ps.a.perm = perm;
+  }
+  return done(launch_solve_range(ps, 0, N, s));
 }
 
 // ---- divergence binning below the boundary -----------------------------------------------------------------------

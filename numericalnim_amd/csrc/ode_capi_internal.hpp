@@ -96,7 +96,7 @@ hipError_t gather_i32(const int32_t* src, int32_t* dst, const uint32_t* perm, in
 hipError_t gather_i64(const int64_t* src, int64_t* dst, const uint32_t* perm, int64_t N, hipStream_t s);
 hipError_t invert_perm(const uint32_t* perm, uint32_t* inv, int64_t N, hipStream_t s);
 hipError_t prepare_tspans(const double* tspans, int n_t, int64_t N, const double* tStart, double t0, double* grid, int32_t* counts, double* t_out,
-                          hipStream_t s);
+                          hipStream_t s, double* span_key = nullptr);
 void multigpu_release();  // ode_multigpu.hip
 int solve_host_range(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
                      const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t NFull, int64_t lo0, int64_t N, int dim,

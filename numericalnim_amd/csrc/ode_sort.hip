@@ -120,7 +120,7 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // tNegative (values < tStart) in descending order at the front, tPositive (values > tStart) ascending at the back — and writes the
 // row of output times the reference returns: tNegative.reversed ++ (tStart if it is in tspan) ++ tPositive (:585), NaN beyond.
 __global__ void prepare_tspans_kernel(const double* tspans, int n_t, int64_t N, const double* tStart, double t0u, double* grid, int32_t* counts,
-                                      double* t_out) {
+                                      double* t_out, double* span_key) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const double* in = tspans + i * n_t;
@@ -134,6 +134,7 @@ __global__ void prepare_tspans_kernel(const double* tspans, int n_t, int64_t N, 
     ok = ok && (v == v) && fabs(v) != inf;
   }
   if (!ok) {  // the reference's loop would never end on a non-finite requested time: this call is refused, the others are not
+    if (span_key) span_key[i] = inf;  // (binning key: refused calls last)
     counts[3 * i] = -1; counts[3 * i + 1] = 0; counts[3 * i + 2] = 0;
     if (t_out) for (int j = 0; j < n_t; ++j) t_out[i * n_t + j] = qnan;
     return;
@@ -146,6 +147,10 @@ __global__ void prepare_tspans_kernel(const double* tspans, int n_t, int64_t N, 
   }
   int nNeg = 0, nPos = 0;
   for (int j = 0; j < n_t; ++j) { nNeg += g[j] < t0 ? 1 : 0; nPos += g[j] > t0 ? 1 : 0; }   // :479-480
+  if (span_key) {  // binning key of the call: minus the time it integrates over (both directions), longest first; NaN t0: last
+    const double span = (nPos > 0 ? g[n_t - 1] - t0 : 0.0) + (nNeg > 0 ? t0 - g[0] : 0.0);
+    span_key[i] = (span == span) ? -span : inf;
+  }
   int nZero = 0;
   for (int j = nNeg; j < n_t - nPos; ++j) nZero |= (g[j] == t0) ? 1 : 0;                      // `t0 in tspan` (:485); false for every j when t0 is NaN
   if (t_out) {
@@ -161,9 +166,9 @@ __global__ void prepare_tspans_kernel(const double* tspans, int n_t, int64_t N, 
 }  // namespace
 
 hipError_t prepare_tspans(const double* tspans, int n_t, int64_t N, const double* tStart, double t0, double* grid, int32_t* counts, double* t_out,
-                          hipStream_t s) {
+                          hipStream_t s, double* span_key) {
   if (N <= 0) return hipSuccess;
-  void* args[] = {(void*)&tspans, (void*)&n_t, (void*)&N, (void*)&tStart, (void*)&t0, (void*)&grid, (void*)&counts, (void*)&t_out};
+  void* args[] = {(void*)&tspans, (void*)&n_t, (void*)&N, (void*)&tStart, (void*)&t0, (void*)&grid, (void*)&counts, (void*)&t_out, (void*)&span_key};
   return hipLaunchKernel((const void*)prepare_tspans_kernel, dim3((unsigned)((N + 127) / 128)), dim3(128), args, 0, s);
 }
 

@@ -1274,3 +1274,30 @@ def test_per_call_solves_binned_by_span_are_the_same_calls(nn, dev, integrator):
         both(lambda: nn.solveODEPerIvpEnd(f, dev_t(y0l), dev_t(np.full(n, 0.7)), nn.newODEoptions(absTol=1e-6, relTol=1e-6, dtMax=0.3, dtMin=1e-7, dt=1e-2),
                                           integrator=integrator, layout=layout))                                             # equal spans
     assert L.nnhip_tune_set(b"calls_bin", 2) != 0
+
+
+@pytest.mark.parametrize("integrator", ["tsit54", "rk4"])
+def test_per_call_tspans_binned_by_span_are_the_same_calls(nn, dev, integrator):
+    """the n_t-point form (nnhip_ode_solve_batch_tspans_f64_dev) from 4096 calls on: longest integration time first — both directions counted, refused rows last"""
+    import torch
+    L = nn._lib.lib()
+    rng = np.random.default_rng(23)
+    n, n_t = 6000, 5
+    y0 = torch.from_numpy(np.stack([rng.uniform(1.5, 2.5, n), np.zeros(n)])).to(dev)
+    scale = rng.choice([0.05, 0.3, 1.0], n)
+    tspans = rng.uniform(-0.5, 1.5, (n, n_t)) * scale[:, None]
+    tspans[::7, 2] = 0.0                                  # tStart inside some rows
+    tspans[9, 1] = np.nan                                  # a refused call
+    ts = torch.from_numpy(tspans).to(dev)
+    opt = nn.newODEoptions(absTol=1e-6, relTol=1e-6, dtMax=0.3, dtMin=1e-8, dt=1e-2)
+    out = []
+    for knob in (1, 0):
+        assert L.nnhip_tune_set(b"calls_bin", knob) == 0
+        try:
+            out.append(nn.solveODEPerIvpTspan(nn.Rhs.vanderpol(1.5), y0, ts, opt, integrator=integrator))
+        finally:
+            assert L.nnhip_tune_set(b"calls_bin", 1) == 0
+    (ta, ya, ca), (tb, yb, cb) = out
+    same = lambda a, b: torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0)) and torch.equal(torch.isnan(a), torch.isnan(b))
+    assert same(ta, tb) and same(ya, yb) and all(torch.equal(ca[k], cb[k]) for k in ca)
+    assert int(ca["ny"][9]) == -1 and int(ca["ny"].max()) == n_t
