@@ -706,7 +706,6 @@ class ShimInterp(Interp):
                     recv.append(self.eval(arglist[0][2], env)); return None
                 if isinstance(recv, str):                  # strings are values: the variable gets the longer string
                     self.assign(fnode[1], recv + str(self.eval(arglist[0][2], env)), env); return None
-            if fnode[0] == "dot" and fnode[2] == "toc" and False: pass
         return super().eval(node, env)
 
 

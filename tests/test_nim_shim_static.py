@@ -101,8 +101,6 @@ def _decl_of(name, before):
         best = ("local", (m.group(1) or "").lstrip(":").strip(), (m.group(2) or "").lstrip("=").strip())
     if best:
         return best
-    for m in re.finditer(r"\bproc\s+[\w`*]+\s*\(", before):
-        pass
     heads = list(re.finditer(r"^proc\s+[\w`*]+\s*\(", before, re.M))
     if heads:
         h = heads[-1]
