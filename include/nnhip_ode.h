@@ -144,7 +144,7 @@ int nnhip_host_free(void* p);
  *   5 %; 0 = always sort),
  *   "sort_auto_key" 0|1 (what the automatic binned solve ranks the IVPs by after its probe: 1, default, the steps still to take (tEnd - t) / dt on a
  *   forward tspan; 0 the distance the probe covered — also what backward / two-sided tspans use; most work first either way),
- *   "calls_bin" 0|1 (1, default: nnhip_ode_solve_batch_calls_f64[_dev] / _tend_ / _tspans_ of 4096 calls or more integrate the longest spans first, binned by
+ *   "calls_bin" 0|1 (1, default: nnhip_ode_solve_batch_calls_f64[_dev] / _tend_ / _tspans_ of 32768 calls or more integrate the longest spans first, binned by
  *   the time each call integrates over — same bits, same order of results; 0: in the caller's order),
  *   "sort_rebin_steps" 0..1000000 (S > 0: the automatic binned solve — where it can resume, see "sort_resume" — takes S more accepted steps per IVP after its
  *   probe, bins the batch again by the steps still to take, and finishes: for step sizes that change late in the span; default 0 = the probe's order throughout),

@@ -1238,7 +1238,7 @@ def test_host_form_of_the_per_ivp_tspan_solve(nn, dev):
 
 @pytest.mark.parametrize("integrator", ["dopri54", "tsit54", "rk4", "bs32"])
 def test_per_call_solves_binned_by_span_are_the_same_calls(nn, dev, integrator):
-    """4096 calls or more are integrated longest span first (knob "calls_bin", default on): the same rows, row counts and step counters at the caller's
+    """32768 calls or more are integrated longest span first (knob "calls_bin", default on): the same rows, row counts and step counters at the caller's
     indices as in the caller's order — every IVP its own tEnd / tStart / tolerances, both directions, refused calls, non-finite ends, both layouts, a
     16-component system; equal spans (nothing to bin: the order stays the caller's) and a batch below the threshold."""
     import torch
@@ -1259,7 +1259,7 @@ def test_per_call_solves_binned_by_span_are_the_same_calls(nn, dev, integrator):
         assert all(torch.equal(ca[k], cb[k]) for k in ca)
         return ya, ca
 
-    for f, dim, layout, n in ((nn.Rhs.vanderpol(1.5), 2, 0, 9000), (nn.Rhs.lorenz(), 3, 1, 5000), (nn.Rhs.ring(0.1), 16, 1, 4200), (nn.Rhs.lorenz(), 3, 0, 700)):
+    for f, dim, layout, n in ((nn.Rhs.vanderpol(1.5), 2, 0, 70000), (nn.Rhs.lorenz(), 3, 1, 40000), (nn.Rhs.ring(0.1), 16, 1, 33000), (nn.Rhs.lorenz(), 3, 0, 7000)):
         y0 = rng.uniform(0.5, 1.5, (n, dim)) + (np.array([0.0, 0.0, 20.0]) if dim == 3 else 0.0)
         ts = rng.uniform(-0.2, 0.2, n)
         te = ts + rng.uniform(-0.5, 1.5, n) * rng.choice([1.0, 0.05], n)
@@ -1270,7 +1270,7 @@ def test_per_call_solves_binned_by_span_are_the_same_calls(nn, dev, integrator):
         kw = dict(integrator=integrator, layout=layout, t_start=dev_t(ts), absTol=dev_t(tol), relTol=dev_t(tol), dtMax=dev_t(np.full(n, 0.3)), dtMin=dev_t(dmin),
                   dt=dev_t(np.full(n, 1e-2)))
         y, cnt = both(lambda: nn.solveODEPerIvpEnd(f, dev_t(y0l), dev_t(te), nn.newODEoptions(), **kw))
-        assert int(cnt["steps"].max()) >= 2 * max(int(cnt["steps"].float().median()), 1) or n < 4096   # the calls really differ in length
+        assert int(cnt["steps"].max()) >= 2 * max(int(cnt["steps"].float().median()), 1) or n < 32768   # the calls really differ in length
         both(lambda: nn.solveODEPerIvpEnd(f, dev_t(y0l), dev_t(np.full(n, 0.7)), nn.newODEoptions(absTol=1e-6, relTol=1e-6, dtMax=0.3, dtMin=1e-7, dt=1e-2),
                                           integrator=integrator, layout=layout))                                             # equal spans
     assert L.nnhip_tune_set(b"calls_bin", 2) != 0
@@ -1278,11 +1278,11 @@ def test_per_call_solves_binned_by_span_are_the_same_calls(nn, dev, integrator):
 
 @pytest.mark.parametrize("integrator", ["tsit54", "rk4"])
 def test_per_call_tspans_binned_by_span_are_the_same_calls(nn, dev, integrator):
-    """the n_t-point form (nnhip_ode_solve_batch_tspans_f64_dev) from 4096 calls on: longest integration time first — both directions counted, refused rows last"""
+    """the n_t-point form (nnhip_ode_solve_batch_tspans_f64_dev) from 32768 calls on: longest integration time first — both directions counted, refused rows last"""
     import torch
     L = nn._lib.lib()
     rng = np.random.default_rng(23)
-    n, n_t = 6000, 5
+    n, n_t = 40000, 5
     y0 = torch.from_numpy(np.stack([rng.uniform(1.5, 2.5, n), np.zeros(n)])).to(dev)
     scale = rng.choice([0.05, 0.3, 1.0], n)
     tspans = rng.uniform(-0.5, 1.5, (n, n_t)) * scale[:, None]
