@@ -424,8 +424,18 @@ NNHIP_DEV void aggregate_stats(unsigned long long* aggBase, LaneStats ls) {
   }
 }
 
+// Waves per SIMD the thread-per-IVP solve kernels are compiled for: the compiler's own choice everywhere (2, 3 and 5 forced: DOPRI54 / Tsit54 on 1-3 components
+// 0-17 % slower, profiles/r04_tpi_occupancy_ab.json) except the lean Vern65 solve of 3-component systems, which it leaves at 2 waves: held to 3, 1.43 -> 1.35 ms.
+// -DNNHIP_SOLVE_TPI_WPE=n forces n for all of them (A/B).
+template <int METHOD, class RHS, int MODE>
+constexpr int solve_tpi_min_waves() { return (METHOD == NNHIP_VERN65 && MODE == 0 && RhsSize<RHS>::value == 3) ? 3 : 1; }
+#ifdef NNHIP_SOLVE_TPI_WPE
+#define NNHIP_SOLVE_TPI_ATTR __attribute__((amdgpu_waves_per_eu(NNHIP_SOLVE_TPI_WPE, NNHIP_SOLVE_TPI_WPE)))
+#else
+#define NNHIP_SOLVE_TPI_ATTR __attribute__((amdgpu_waves_per_eu(solve_tpi_min_waves<METHOD, RHS, MODE>())))
+#endif
 template <int METHOD, class RHS, int MODE = 1>
-__global__ __launch_bounds__(kBlock) void solve_tpi_kernel(const SolveArgs a) {
+__global__ __launch_bounds__(kBlock) NNHIP_SOLVE_TPI_ATTR void solve_tpi_kernel(const SolveArgs a) {
   controller_prologue<MethodTraits<METHOD>::adaptive>();
   const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   LaneStats ls;
