@@ -266,3 +266,32 @@ def test_shim_plus_library_return_what_the_references_text_returns(env):
             assert np.isnan(rows[r["n_y"]:, :, i]).all(), (case["name"], i)
         done += 1
     assert done >= 95, done
+
+
+def test_the_shims_multi_gpu_branch(env):
+    """solveODE(..., nGpus = k): contiguous shards of the batch (and of the sweep table) per device, nnhip_ode_solve_batch_multi_gpu_sweep_f64.  On a one-GPU box the
+    shards over-subscribe the device (knob multi_gpu_oversubscribe, as tests/test_gpu_multi_gpu_entry.py does); with k devices they run one per device."""
+    import torch
+    nn, it, _ = env
+    L = nn._lib.lib()
+    rng = np.random.default_rng(31)
+    n = 1001                                                                # ragged for 2, 3 and 8 shards
+    y0 = np.stack([rng.uniform(-10, 10, n), rng.uniform(-10, 10, n), rng.uniform(5, 30, n)])
+    tspan = [-0.1, 0.0, 0.2, 0.3]
+    spec = it.expr('RhsSpec(kind: rhsLorenz, keys: @["sigma", "rho", "beta"])')
+    ctx = _ctx(it, sigma=10.0, rho=28.0, beta=8.0 / 3.0)
+    rho = [float(v) for v in rng.uniform(20.0, 35.0, n)]
+    t1, y1 = it.call("solveODE", spec, _batch(it, y0), tspan, ctx=ctx, integrator="tsit54")
+    _, y1s = it.call("solveODE", spec, _batch(it, y0), tspan, ctx=ctx, integrator="tsit54", sweep=[[10.0] * n, rho])
+    ndev = torch.cuda.device_count()
+    for k in (2, 3, 8):
+        assert L.nnhip_tune_set(b"multi_gpu_oversubscribe", 1 if k > ndev else 0) == 0
+        try:
+            tk, yk = it.call("solveODE", spec, _batch(it, y0), tspan, ctx=ctx, integrator="tsit54", nGpus=k)
+            _, yks = it.call("solveODE", spec, _batch(it, y0), tspan, ctx=ctx, integrator="tsit54", nGpus=k, sweep=[[10.0] * n, rho])
+        finally:
+            assert L.nnhip_tune_set(b"multi_gpu_oversubscribe", 0) == 0
+        assert it.ffi_log[-1] == "nnhip_ode_solve_batch_multi_gpu_sweep_f64"
+        assert tk == t1 and np.array_equal(_rows(yk, y0.shape), _rows(y1, y0.shape)) and np.array_equal(_rows(yks, y0.shape), _rows(y1s, y0.shape)), k
+    with pytest.raises(Exception, match="not available together with nGpus"):
+        it.call("solveODE", spec, _batch(it, y0), tspan, ctx=ctx, integrator="tsit54", nGpus=2, autoSort=True)
