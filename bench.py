@@ -313,6 +313,42 @@ def main():
         out["adaptive_configs"] = cfg
         del y3, y16
 
+    # ---- informational: batches whose members take different step sequences (every reference call is its own, ode.nim:589-591) ----
+    # 1e6 Van der Pol IVPs with their own stiffness in random order: as handed over / binned below the boundary (automatic probe; the caller's key), and
+    # 1e6 separate calls with their own tEnd: in the caller's order / longest span first.  All must equal the plain solves bit for bit.
+    if not args.no_fused and world == 1:
+        n6 = 1_000_000
+        rng = np.random.default_rng(0)
+        mu = torch.from_numpy(rng.uniform(0.1, 20.0, n6)[None, :].copy()).to(dev)
+        yv = torch.from_numpy(np.stack([np.full(n6, 2.0), np.zeros(n6)])).to(dev)
+        ov = nn.newODEoptions(absTol=1e-6, relTol=1e-6, dtMin=1e-9, dtMax=1.0)
+        L = nn._lib.lib()
+
+        def med_ms(fn, reps=5):
+            fn(); torch.cuda.synchronize()
+            tt = []
+            for _ in range(reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); r = fn(); e1.record(); torch.cuda.synchronize(); tt.append(e0.elapsed_time(e1))
+            return sorted(tt)[len(tt) // 2], r
+
+        het = {}
+        het["sweep_as_handed_over_ms"], ref = med_ms(lambda: nn.solveODE(nn.Rhs.vanderpol(), yv, [0.0, 10.0], ov, integrator="dopri54", sweep=mu))
+        het["sweep_binned_automatic_probe_ms"], ra = med_ms(lambda: nn.solveODE(nn.Rhs.vanderpol(), yv, [0.0, 10.0], ov, integrator="dopri54", sweep=mu, sort_by="auto"))
+        key = (-mu[0]).contiguous()   # the stiffest first
+        het["sweep_binned_by_callers_key_ms"], rk = med_ms(lambda: nn.solveODE(nn.Rhs.vanderpol(), yv, [0.0, 10.0], ov, integrator="dopri54", sweep=mu, sort_by=key))
+        het["sweep_bitwise_equal"] = bool(torch.equal(ref[1], ra[1]) and torch.equal(ref[1], rk[1]))
+        te = torch.from_numpy(rng.uniform(0.05, 10.0, n6)).to(dev)
+        try:
+            L.nnhip_tune_set(b"calls_bin", 0)
+            het["calls_in_callers_order_ms"], c0 = med_ms(lambda: nn.solveODEPerIvpEnd(nn.Rhs.vanderpol(2.0), yv, te, ov, integrator="dopri54"))
+        finally:
+            L.nnhip_tune_set(b"calls_bin", 1)
+        het["calls_longest_span_first_ms"], c1 = med_ms(lambda: nn.solveODEPerIvpEnd(nn.Rhs.vanderpol(2.0), yv, te, ov, integrator="dopri54"))
+        het["calls_bitwise_equal"] = bool(torch.equal(c0[0], c1[0]) and all(torch.equal(c0[1][k], c1[1][k]) for k in c0[1]))
+        out["heterogeneous_batches"] = het
+        del mu, yv, te
+
     # ---- CPU baseline: the oracle (C++ restatement of the reference) on this box's host cores -------------
     if not args.no_cpu_baseline and world == 1:
         from oracle import oracle as O
