@@ -68,6 +68,11 @@ int g_adv_steps = 1;      // tuning knob "adv_steps_per_launch": loop iterations
                           // seam proper; K > 1 keeps the state in registers for K iterations: 8*(4d+5)/K bytes per attempted step, a different traffic model)
 int g_sort_auto_key = 1;   // tuning knob "sort_auto_key": what the automatic binned solve ranks by — 0 the probe's progress, 1 the steps still to take (tEnd - t) / dt (forward spans)
 int g_calls_bin = 1;       // tuning knob "calls_bin": the per-IVP-call solves (every IVP its own tEnd / tspan) of kCallsBinMinN calls or more integrate the longest spans first, binned by span
+// (not while the caller's stream is being captured into a graph: the scratch comes from the stream-ordered allocator, which a capture may refuse)
+static bool stream_is_capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
 constexpr int64_t kCallsBinMinN = 32768;  // five small launches (~30 us) in front of the solve: worth it where the solve is long
 int g_sort_rebin_steps = 0;  // tuning knob "sort_rebin_steps": > 0 = the resumed automatic binned solve stops after that many further accepted steps per IVP, re-bins by the steps still to take, and finishes
 int g_sort_resume = 0;     // tuning knob "sort_resume": the automatic binned solve continues from its probe's state instead of restarting (where the loop's state is (t, dt, y)).
@@ -742,7 +747,7 @@ int nnhip_ode_solve_batch_calls_f64_dev(const nnhip_ode_options* opt, int integr
   // the spans differ enough to bother (5 %, knob "sort_min_spread_permille") is decided by the binning kernel itself; the scratch comes from the stream-ordered
   // allocator, and without it the calls run in the caller's order.
   hipStream_t s = (hipStream_t)stream;
-  if (g_calls_bin && N >= kCallsBinMinN && N < ((int64_t)1 << 31)) {
+  if (g_calls_bin && N >= kCallsBinMinN && N < ((int64_t)1 << 31) && !stream_is_capturing(s)) {
     const size_t colKey = ((size_t)N * 8 + 255) & ~(size_t)255, colPerm = ((size_t)N * 4 + 255) & ~(size_t)255;
     const int64_t sortBytes = nnhip::argsort_workspace_bytes(N);
     char* d = nullptr;
@@ -817,7 +822,7 @@ int nnhip_ode_solve_batch_tspans_f64_dev(const nnhip_ode_options* opt, int integ
   double* spanKey = nullptr;
   const size_t colKey = ((size_t)N * 8 + 255) & ~(size_t)255, colPerm = ((size_t)N * 4 + 255) & ~(size_t)255;
   const int64_t sortBytes = nnhip::argsort_workspace_bytes(N);
-  if (g_calls_bin && N >= kCallsBinMinN && N < ((int64_t)1 << 31)) {
+  if (g_calls_bin && N >= kCallsBinMinN && N < ((int64_t)1 << 31) && !stream_is_capturing(s)) {
     if (hipMallocAsync((void**)&d, colKey + colPerm + (size_t)sortBytes, s) == hipSuccess && d) spanKey = (double*)d;
     else { d = nullptr; (void)hipGetLastError(); }
   }
