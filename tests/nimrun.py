@@ -461,7 +461,8 @@ class ShimInterp(Interp):
         if low in _INTS: return isinstance(v, int) and not isinstance(v, bool)
         if low in _FLOATS: return isinstance(v, (int, float)) and not isinstance(v, bool)
         if low == "bool": return isinstance(v, bool)
-        if low == "string": return isinstance(v, str)
+        if low in ("string", "cstring"): return isinstance(v, str) or (low == "cstring" and v is None)
+        if low in ("nimnode", "static", "untyped", "typed", "auto", "biggestfloat", "openarray", "seq"): return True
         d = self.types.get(t[1])
         if d and d[0] == "object": return isinstance(v, NimObj) and v.tname == t[1]
         if d and d[0] == "enum": return isinstance(v, int)
@@ -555,6 +556,8 @@ class ShimInterp(Interp):
                         v = self.eval(init, env)
                         if st[2] == "var" and isinstance(v, list) and not isinstance(v, CStringArray): v = list(v)   # seqs have value semantics
                         if st[2] == "var" and isinstance(v, NimObj) and v.tname != "Numcontext": v = NimObj(v.names, v.values, v.tname)
+                        if tword is not None and not self.fits(parse_type(tword.full if isinstance(tword, TWord) else tword), v):
+                            raise NimError(f"type mismatch: {st[2]} {n}: {getattr(tword, 'full', tword)} = {getattr(v, 'tname', type(v).__name__)}")
                     else:
                         v = self.default_of(tword) if tword is not None else None
                     env.vars[n] = v
@@ -605,6 +608,14 @@ class ShimInterp(Interp):
             elif pname in kwargs: v = kwargs[pname]
             elif default is not None: v = self.eval(default, r.env)
             else: raise NimError(f"{r.name}: missing argument {pname}")
+            if tword is None and default is not None and default[0] in ("str", "num") and not isinstance(v, (Alias, NimNode)):   # `integrator = "dopri54"`: the type of the default
+                want = type(default[1])
+                if not (isinstance(v, want) or (want is float and isinstance(v, int) and not isinstance(v, bool))) or (isinstance(v, bool) != (want is bool)):
+                    raise NimError(f"type mismatch: {r.name}({pname} = {default[1]!r}) got {type(v).__name__}")
+            if tword is not None and tword not in ("untyped", "typed", "auto") and not isinstance(v, (Alias, NimNode)):
+                t = parse_type(tword.full if isinstance(tword, TWord) else tword)
+                if not self.fits(t, v):   # a run-time stand-in for the compiler's check: every argument is of the kind its parameter declares
+                    raise NimError(f"type mismatch: {r.name}({pname}: {getattr(tword, 'full', tword)}) got {getattr(v, 'tname', type(v).__name__)}")
             env.vars[pname] = v
         if len(r.body) == 1 and r.body[0][0] == "expr" and not (r.body[0][1][0] == "call" and r.rtype is None):
             return self.eval(r.body[0][1], env)

@@ -109,3 +109,17 @@ def test_ctx_vectors_get_their_layout_late(mac):
     src, vectors = it.call("deviceRhsCtxSource", ["a"], nimrun.nim_ast('dy[0] = ctx.fValues["a"] * y[0] * ctx.tValues["w"][1] + ctx.tValues["g"][0] * ctx.tValues["w"][0]'))
     assert vectors == ["w", "g"]
     assert src.replace(chr(1), "<").replace(chr(2), ">") == "dy[0] = (((p[0] * y[0]) * w<1>) + (g<0> * w<0>));\n"
+
+
+def test_arguments_are_checked_against_the_declared_parameter_types(it):
+    """a run-time stand-in for the compiler's check: a proc of the shim called with an argument of the wrong kind is refused, not coerced"""
+    spec = it.expr('RhsSpec(kind: rhsLinear, keys: @["a"])')
+    batch = it.expr("OdeBatch(n: 1, dim: 1, layout: layoutSoA, data: @[1.0])")
+    with pytest.raises(Exception, match="no overload|type mismatch"):
+        it.call("solveODE", spec, [1.0], [0.0, 1.0])                                  # a seq where an OdeBatch is declared
+    with pytest.raises(Exception, match="type mismatch"):
+        it.call("solveODE", spec, batch, [0.0, 1.0], integrator=5)                   # integrator: string
+    with pytest.raises(Exception, match="no overload|type mismatch"):
+        it.call("bindCtx", spec, [1.0], [], [], "one", 1)                            # nAux: int
+    with pytest.raises(Exception, match="type mismatch"):
+        it.exec_toplevel("proc badDecl(): int =\n  var n: int = @[1.0]\n  result = n\n") or it.call("badDecl")
