@@ -4,7 +4,7 @@ conditions of Runge-Kutta methods, and measured convergence orders on a NONLINEA
 The reference's own known-answer tests integrate y' = -0.1*y (tests/test_ode.nim:5-8): a linear scalar right-hand side satisfies every
 order condition that differs only in the shape of its rooted tree, so those tests cannot see most coefficient errors.  These can:
   * SciPy's RK45 *is* the Dormand-Prince 5(4) pair (scipy.integrate._ivp.rk): one step of the oracle's DOPRI54_step on Lorenz must agree with
-    scipy's rk_step to a few ulp, the embedded error estimate included (ode.nim:240-305);
+    scipy's rk_step to a few ulp, the embedded error estimate included (ode.nim:240-305); its RK23 is the Bogacki-Shampine pair (bs32, :212-234): the same;
   * the tableaux the HIP kernels are compiled with (nnhip_ode_tableau_f64) must satisfy all 17 / 37 rooted-tree order conditions of order
     5 / 6, their embedded weights those of order 4 / 5, and the row-sum conditions (ode.nim:240-282, 310-352, 380-443);
   * all 14 methods must converge at their nominal order — 2/3/4/5/6 — on Van der Pol against a 30-digit Taylor-series solution (mpmath), and the
@@ -50,6 +50,28 @@ def test_dopri54_step_agrees_with_scipy_rk45(oracle, t, y, h):
     want = math.sqrt(float(np.mean(err_sp ** 2)))
     assert abs(err - want) <= 64 * np.spacing(h * np.abs(f(t, y)).max()), (err, want)
     assert err > 0 and abs(err - want) <= 1e-6 * want + 64 * np.spacing(h * np.abs(f(t, y)).max())
+
+
+@pytest.mark.parametrize("t,y,h", [(0.3, [-8.1, -7.9, 27.2], 1e-2), (0.0, [1.0, 1.0, 1.0], 1e-3), (-2.0, [3.0, 4.5, 20.0], 5e-2)])
+def test_bs32_step_agrees_with_scipy_rk23(oracle, t, y, h):
+    """SciPy's RK23 is the Bogacki-Shampine 3(2) pair the reference calls bs32 (ode.nim:212-234): same stages, same weights, the same embedded estimate."""
+    from scipy.integrate._ivp import rk
+    O = oracle
+    s, r, b = LORENZ_P
+
+    def f(_t, v):
+        return np.array([s * (v[1] - v[0]), v[0] * (r - v[2]) - v[1], v[0] * v[1] - b * v[2]])
+    y = np.array(y)
+    K = np.empty((rk.RK23.n_stages + 1, 3))
+    y_sp, f_sp = rk.rk_step(f, t, y, f(t, y), h, rk.RK23.A, rk.RK23.B, rk.RK23.C, K)
+    err_sp = np.dot(K.T, rk.RK23.E) * h
+    yN, fs, dtU, err = O.step(O.RHS_LORENZ, LORENZ_P, "bs32", O.new_options(**LOOSE), t, y, f(t, y), h)
+    assert dtU == h
+    for c in range(3):
+        assert _ulps(yN[c], y_sp[c]) <= 4, (c, yN[c], y_sp[c])
+        assert _ulps(fs[c], f_sp[c]) <= 16
+    want = math.sqrt(float(np.mean(err_sp ** 2)))
+    assert err > 0 and abs(err - want) <= 1e-6 * want + 64 * np.spacing(h * np.abs(f(t, y)).max()), (err, want)
 
 
 def test_dopri54_tableau_is_scipys(nn):
