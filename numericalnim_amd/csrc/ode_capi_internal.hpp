@@ -1,5 +1,5 @@
 // ode_capi_internal.hpp — what the translation units of the C ABI share (ode_capi.hip: library, options, dispatch, fused solve;
-// ode_capi_stream.hip: the step-streaming entries).  Not part of the product's interface: include/nnhip_ode.h is.
+// ode_capi_calls.hip: per-IVP calls and the binned solves; ode_capi_stream.hip: the step-streaming entries).  Not part of the product's interface: include/nnhip_ode.h is.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -67,6 +67,31 @@ struct Staging {
 extern thread_local Staging g_stage;
 int stage_reserve(size_t n);
 
+// host-pointer solves borrow their streams and events from a process-wide pool keyed by device (ode_capi.hip)
+struct HostSolveCtx {
+  int device = -1;
+  bool busy = false;
+  hipStream_t s[2] = {nullptr, nullptr};
+  hipEvent_t evPrep = nullptr;
+  std::vector<hipEvent_t> evs;  // timing events, grown on demand
+};
+int host_ctx_acquire(int device, int nEvents, HostSolveCtx** out);
+void host_ctx_release(HostSolveCtx* c);
+
+// the fused solve, prepared once and launched over index ranges of the batch (ode_capi.hip)
+struct PreparedSolve {
+  nnhip::SolveArgs a{};       // arguments for the FULL batch
+  nnhip::SolveLaunchFn fn = nullptr;
+  bool user = false;
+  int integrator = 0, rhs_kind = 0;
+};
+int prepare_solve(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params, const double* per_ivp_params, int n_per_ivp,
+                  const double* y0, int64_t N, int dim, int layout, const double* tspan, int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
+                  int64_t* rejected_out, int64_t max_steps, void* ws, int64_t ws_bytes, unsigned long long* agg, int* n_t_out, hipStream_t stream, PreparedSolve& ps);
+int launch_solve_range(const PreparedSolve& ps, int64_t lo, int64_t n, hipStream_t stream);
+// knobs of the binned solves (defined and documented in ode_capi.hip)
+extern int g_sort_copy, g_sort_auto_key, g_calls_bin, g_sort_rebin_steps, g_sort_resume;
+extern double g_sort_min_spread;
 // hipGraph caches and polling blocks of the streaming loops (ode_capi_stream.hip), released by nnhip_release() / knob changes
 void release_stream_graphs();
 void release_adv_graphs();
