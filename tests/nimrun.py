@@ -103,7 +103,15 @@ class ShimParser(Parser):
         return (kind, name, params, rtype, self.block_or_stmt())
 
     # -- statements ---------------------------------------------------------------------------------------------------------------
+    LINES = {}   # id(statement node) -> source line (the nodes live as long as the loaded module): statement coverage of an interpreted run
+
     def stmt(self):
+        line = self.peek()[2]
+        node = self._stmt()
+        if node[0] not in ("proc", "template", "typedef", "pass"): ShimParser.LINES[id(node)] = (getattr(self, "unit", "?"), line, node)
+        return node
+
+    def _stmt(self):
         tok = self.peek()
         if tok[0] == "id" and tok[1] == "macro" and self.peek(1)[0] == "id":
             self.next(); return self.routine("proc")
@@ -415,14 +423,15 @@ class ShimInterp(Interp):
                 params.append((norm_ident(n.strip()), " ".join(norm_ident(w) if w not in ("ptr",) else w for w in t.split())))
             self.globals.vars[norm_ident(m.group(1))] = FFIProc(self, m.group(1), params, (m.group(3) or "void").strip())
 
-    def exec_toplevel(self, text):
+    def exec_toplevel(self, text, unit="?"):
         ps = ShimParser(_tokenize(text))
+        ps.unit = unit
         while not ps.at("eof"):
             if ps.accept("nl") or ps.accept("dedent"): continue
             self.exec_stmt(ps.stmt(), self.globals)
 
     def load_shim(self, path=os.path.join(NIM_DIR, "numericalnim_hip.nim")):
-        self.exec_toplevel(open(path).read())
+        self.exec_toplevel(open(path).read(), unit=os.path.basename(path))
 
     @staticmethod
     def ctype_of(t):
@@ -518,6 +527,8 @@ class ShimInterp(Interp):
     # ---- statements ----------------------------------------------------------------------------------------------------------------
     def exec_stmt(self, st, env):
         k = st[0]
+        rec = ShimParser.LINES.get(id(st))
+        if rec is not None and rec[2] is st: EXECUTED.add((rec[0], rec[1]))
         if k == "case":   # as the base interpreter's, plus `of a .. b` ranges
             subject = self.eval(st[1], env)
             for vals, body in st[2]:
@@ -726,5 +737,14 @@ def load(lib_path=LIB_PATH, macros=False):
     it.load_shim()
     if macros:   # nim/rhs_macro.nim: its translating procs, macros and templates (not its `when isMainModule` self-test, which needs the compiler's own macro expansion)
         text = open(os.path.join(NIM_DIR, "rhs_macro.nim")).read()
-        it.exec_toplevel(text[:text.index("when isMainModule")])
+        it.exec_toplevel(text[:text.index("when isMainModule")], unit="rhs_macro.nim")
     return it
+
+
+EXECUTED = set()   # (unit, line) of every statement any interpreter instance of this process has executed
+
+
+def coverage(unit):
+    """(statement lines of `unit` inside proc bodies, those executed so far)"""
+    lines = {ln for u, ln, _n in ShimParser.LINES.values() if u == unit}
+    return lines, {ln for u, ln in EXECUTED if u == unit}

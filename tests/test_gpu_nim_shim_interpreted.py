@@ -295,3 +295,13 @@ def test_the_shims_multi_gpu_branch(env):
         assert tk == t1 and np.array_equal(_rows(yk, y0.shape), _rows(y1, y0.shape)) and np.array_equal(_rows(yks, y0.shape), _rows(y1s, y0.shape)), k
     with pytest.raises(Exception, match="not available together with nGpus"):
         it.call("solveODE", spec, _batch(it, y0), tspan, ctx=ctx, integrator="tsit54", nGpus=2, autoSort=True)
+
+
+def test_zz_how_much_of_the_shim_ran(env):
+    """Statement coverage of the interpreted runs above (this module's tests, in this process): which lines of nim/numericalnim_hip.nim and of
+    nim/rhs_macro.nim's translating procs were executed at least once.  What stays unexecuted is named in the failure message, not hidden."""
+    _, _, nimrun = env
+    for unit, floor in (("numericalnim_hip.nim", 0.90), ("rhs_macro.nim", 0.75)):
+        lines, ran = nimrun.coverage(unit)
+        missed = sorted(lines - ran)
+        assert len(lines) > 50 and len(ran & lines) >= floor * len(lines), f"{unit}: {len(ran & lines)} of {len(lines)} statement lines ran; not run: {missed}"
