@@ -629,6 +629,8 @@ class ShimInterp(Interp):
                     raise NimError(f"type mismatch: {r.name}({pname}: {getattr(tword, 'full', tword)}) got {getattr(v, 'tname', type(v).__name__)}")
             env.vars[pname] = v
         if len(r.body) == 1 and r.body[0][0] == "expr" and not (r.body[0][1][0] == "call" and r.rtype is None):
+            rec = ShimParser.LINES.get(id(r.body[0]))      # an expression-bodied proc: its one statement runs here
+            if rec is not None and rec[2] is r.body[0]: EXECUTED.add((rec[0], rec[1]))
             return self.eval(r.body[0][1], env)
         env.vars["result"] = self.default_of(r.rtype) if r.rtype is not None else None
         last = None

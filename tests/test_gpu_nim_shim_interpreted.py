@@ -109,6 +109,14 @@ def test_per_ivp_calls_overloads(env):
     assert np.array_equal(np.nan_to_num(_rows(one[0], y0.shape)), np.nan_to_num(np.asarray(yr1))) and list(one[1]) == list(cr1["ny"])
     with pytest.raises(Exception, match="one value per IVP"):
         it.call("solveODE", spec, _batch(it, y0), [0.5], opts, ctx, "dopri54")
+    # ... with a sweep of mu on top (every call its own ctx as well)
+    mus = [[float(v) for v in rng.uniform(0.5, 3.0, n)]]
+    ysw, nysw = it.call("solveODE", spec, _batch(it, y0), [float(v) for v in t_end], opts, ctx, "dopri54", mus)
+    yrw, crw = nn.solveODECalls(nn.Rhs.vanderpol(), y0, t_end, popts, ctx=pctx, integrator="dopri54", sweep=np.array(mus))
+    assert np.array_equal(np.nan_to_num(_rows(ysw, y0.shape)), np.nan_to_num(np.asarray(yrw))) and list(nysw) == list(crw["ny"])
+    # what the library refuses comes back through `check` as the reference's kind of exception: a requested time that is not finite
+    with pytest.raises(Exception, match="ValueError|nnhip error"):
+        it.call("solveODE", spec, _batch(it, y0), [0.0, float("nan")], ctx=ctx, integrator="dopri54")
     # every IVP its own tspan: any order, both sides of tStart, duplicates
     tspans = np.stack([rng.permutation(np.concatenate([rng.uniform(-1, 1.5, 4), [okw[i]["tStart"]]])) for i in range(n)])
     t, ys, ny = it.call("solveODE", spec, _batch(it, y0), [[float(v) for v in row] for row in tspans], opts, ctx, "tsit54")
@@ -301,7 +309,7 @@ def test_zz_how_much_of_the_shim_ran(env):
     """Statement coverage of the interpreted runs above (this module's tests, in this process): which lines of nim/numericalnim_hip.nim and of
     nim/rhs_macro.nim's translating procs were executed at least once.  What stays unexecuted is named in the failure message, not hidden."""
     _, _, nimrun = env
-    for unit, floor in (("numericalnim_hip.nim", 0.90), ("rhs_macro.nim", 0.75)):
+    for unit, floor in (("numericalnim_hip.nim", 0.95), ("rhs_macro.nim", 0.75)):
         lines, ran = nimrun.coverage(unit)
         missed = sorted(lines - ran)
         assert len(lines) > 50 and len(ran & lines) >= floor * len(lines), f"{unit}: {len(ran & lines)} of {len(lines)} statement lines ran; not run: {missed}"
