@@ -9,7 +9,10 @@ state resident in HBM between launches (16 algorithmic bytes per trajectory-step
 Multi-GPU (weak scaling, config C5): every rank owns a contiguous shard of the global IVP index
 range; the only collective is one all-gather of the final states per solve (RCCL over xGMI).
 
-Usage: python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+Usage: python bench.py --gpus N --steps K --warmup W
+  N>1 either way: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (the launcher's RANK /
+  LOCAL_RANK / WORLD_SIZE are used), or plain `python bench.py --gpus N ...` — with WORLD_SIZE unset bench.py starts its own N ranks
+  through torch.distributed.run on 127.0.0.1 (a free port) and rank 0's line is the output.  --gpus != WORLD_SIZE is an error.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -39,6 +42,8 @@ def parse():
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (nccl=RCCL) and run the all-gather even at world size 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=float, default=2e5, help="IVPs in the CPU-baseline sample (2e5 x 1000 steps = ~3 s on one core; the rate extrapolates linearly: IVPs are independent)")
+    ap.add_argument("--cpu-ivps-per-thread", type=float, default=2e4, help="all-cores CPU leg: IVPs per thread (C2)")
+    ap.add_argument("--cpu-adaptive-sample", type=float, default=1e4, help="IVPs in the 1-core CPU sample of C3 / C4 (all cores: an eighth of it per thread)")
     ap.add_argument("--no-fused", action="store_true", help="skip the informational fused-solve measurement")
     ap.add_argument("--verify-gathers", action="store_true",
                     help="debug: after every overlapped all-gather completes, compare this rank's slice of the gathered tensor with the "
@@ -47,8 +52,29 @@ def parse():
     return ap.parse_args()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run the same command line under torch.distributed.run, one rank per GPU, on this
+    node (127.0.0.1, a port the kernel just handed out).  The children inherit stdout / stderr: rank 0's JSON line is this process's."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this platform's driver shares device memory across processes by dmabuf only
+    env.setdefault("OMP_NUM_THREADS", "1")             # what torchrun would set anyway (and warn about)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -59,9 +85,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit("bench.py: --gpus %d but the launcher's WORLD_SIZE is %d: start one rank per GPU (or leave WORLD_SIZE unset "
+                         "and bench.py starts its own ranks)" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    if args.backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit("bench.py: %d ranks over RCCL need %d devices, this node has %d (one rank per GPU; --backend gloo lets ranks share "
+                         "a device to exercise the path)" % (world, world, torch.cuda.device_count()))
     dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -154,10 +183,16 @@ def main():
         yf = one_solve(k)
     sync_all()
     elapsed = time.perf_counter() - t0
+    rank_elapsed = [elapsed]
+    world_reported = 1
     if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        per_rank = torch.zeros(world, dtype=torch.float64, device=dev)   # every rank's wall time of the timed region, in rank order
+        per_rank[rank] = elapsed
+        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
+        rank_elapsed = [float(v) for v in per_rank.cpu()]
+        elapsed = max(rank_elapsed)                                       # the job is as slow as its slowest rank
+        world_reported = dist.get_world_size()                            # what the communicator says, not what the command line asked for
+        assert world_reported == world == args.gpus, (world_reported, world, args.gpus)
 
     total_traj_steps = float(n) * world * nsteps * args.steps
     value = total_traj_steps / elapsed
@@ -199,6 +234,17 @@ def main():
             pm = json.load(open(pj))
             traffic = pm.get("rk4_stream", {}).get("hbm_bytes_per_launch")
             traffic_src = "profiles/pmc_traffic.json (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round %s, scripts/profile_gpu.sh; not measured in this run)" % pm.get("round")
+            # the counters belong to ONE instantiation of the kernel: attach them only if it is the one this run launched
+            import ctypes, re
+            vec, mode = ctypes.c_int(0), ctypes.c_int(0)
+            assert nn._lib.lib().nnhip_ode_rk4_stream_variant(n, 0 if args.pingpong else 1, ctypes.byref(vec), ctypes.byref(mode)) == 0
+            m = re.search(r"rk4_stream_vec_kernel<.*?, (?:false|true), (\d+), (\d+)>", pm["rk4_stream"]["kernel"])
+            launched = "rk4_stream_vec_kernel<RhsNegY<1>, false, %d, %d>" % (vec.value, mode.value)
+            if not m or (int(m.group(1)), int(m.group(2))) != (vec.value, mode.value):
+                traffic = None
+                traffic_src = "NOT ATTACHED: profiles/pmc_traffic.json was collected on %s, this run launched %s" % (pm["rk4_stream"]["kernel"], launched)
+            else:
+                traffic_src += "; variant checked: this run launched %s, the profiled kernel" % launched
         except Exception:
             traffic = None
 
@@ -210,6 +256,8 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed * 1e3 / args.steps,
+        "world_size_reported_by_backend": world_reported,
+        "ms_per_step_per_rank": {"min": min(rank_elapsed) * 1e3 / args.steps, "max": max(rank_elapsed) * 1e3 / args.steps},
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -279,6 +327,7 @@ def main():
         del yb, sb
 
     # ---- informational: BASELINE.json's adaptive configs C3 / C4 (1e6 IVPs / systems), fused and through the HBM-resident loop ----
+    adaptive_inputs = {}
     if not args.no_fused and world == 1:
         cfg = {}
         n6 = 1_000_000
@@ -308,10 +357,46 @@ def main():
                     best = dtw if best is None or dtw < best else best
             per_step = 8 * (2 * d + 4)  # y in / out and (t, dt) in / out; FSAL is re-evaluated per launch
             cfg[name] = {"fused_ms": e0.elapsed_time(e1) / 3, "streamed_ms": best * 1e3, "loop_iterations": iters, "streamed_us_per_iteration": best * 1e6 / iters,
+                         "streamed_launches": int(_l),
                          "streamed_bytes_per_step": per_step, "streamed_GBps": per_step * float(cnt["steps"].sum()) / best / 1e9,
-                         "streamed_bitwise_equal_to_fused": bool(torch.equal(ys, yfu[-1]))}
+                         "streamed_bitwise_equal_to_fused": bool(torch.equal(ys, yfu[-1])),
+                         "accepted_steps": int(cnt["steps"].sum()), "fused_ivps_per_s": n6 / (e0.elapsed_time(e1) / 3 * 1e-3),
+                         "fused_accepted_steps_per_s": float(cnt["steps"].sum()) / (e0.elapsed_time(e1) / 3 * 1e-3)}
+            adaptive_inputs[name] = (fr, yy, layout, integ, d, yfu[-1])
         out["adaptive_configs"] = cfg
-        del y3, y16
+
+    # ---- informational: what bit parity costs the FP64-VALU-bound fused kernels.  The default build never contracts a*b+c (every
+    # operation rounds once, in the reference's order: the results ARE the reference's bits); the opt-in knob "fp_contract" runs the
+    # same kernels compiled with FMA contraction: within north_star's tolerance (1e-10 fixed-step / 1e-6 adaptive), not bit-equal.
+    if not args.no_fused and world == 1:
+        L = nn._lib.lib()
+
+        def timed(fn, reps=3):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                r = fn()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps, r
+
+        trade = {}
+        legs = [("C2_rk4_neg_y_1e7", lambda: nn.solveODE(f, y0, [0.0, t_end], opt, integrator="rk4")[1][-1], 1e-10)]
+        if "C4_tsit54_ring16_1e6" in adaptive_inputs:
+            fr, yy, layout, integ, d, _y = adaptive_inputs["C4_tsit54_ring16_1e6"]
+            legs.append(("C4_tsit54_ring16_1e6", lambda: nn.solveODE(fr, yy, [0.0, 1.0], nn.newODEoptions(), integrator=integ, layout=layout)[1][-1], 1e-6))
+        for name, fn, tol in legs:
+            exact_ms, ye = timed(fn)
+            try:
+                L.nnhip_tune_set(b"fp_contract", 1)
+                fast_ms, yc = timed(fn)
+            finally:
+                L.nnhip_tune_set(b"fp_contract", 0)
+            dev_abs = float((ye - yc).abs().max())
+            assert dev_abs <= tol, (name, dev_abs)
+            trade[name] = {"bit_exact_ms": exact_ms, "contracted_ms": fast_ms, "speedup": exact_ms / fast_ms, "max_abs_deviation": dev_abs,
+                           "north_star_tolerance": tol}
+        out["fused_solve_fp_contract"] = trade
 
     # ---- informational: batches whose members take different step sequences (every reference call is its own, ode.nim:589-591) ----
     # 1e6 Van der Pol IVPs with their own stiffness in random order: as handed over / binned below the boundary (automatic probe; the caller's key), and
@@ -349,13 +434,17 @@ def main():
         out["heterogeneous_batches"] = het
         del mu, yv, te
 
-    # ---- CPU baseline: the oracle (C++ restatement of the reference) on this box's host cores -------------
+    # ---- CPU baseline: the oracle (C++ restatement of the reference, -O3 as BASELINE.md section 2 states) on this box's host cores -----
+    # One core = the reference as it is (single-threaded, one solveODE call per IVP).  All cores = the same calls spread over an
+    # OpenMP team: the team is started before the clock, and the sample is sized so that every thread has >= 2e4 IVPs x 1000 steps
+    # (C2) of work — a 12 ms slice per thread measured the fork, not the cores.
     if not args.no_cpu_baseline and world == 1:
         from oracle import oracle as O
+        ncores = os.cpu_count() or 1
         ns = int(args.cpu_sample)
         y0s = nd.c2_y0_numpy(0, ns)
         oo = O.new_options(dt=dt)
-        O.solve_ode_batch(O.RHS_NEG_Y, [], y0s[:1000], 1000, 0, [0.0, t_end], oo, "rk4")  # warm
+        O.solve_ode_batch(O.RHS_NEG_Y, [], y0s[:1000], 1000, 0, [0.0, t_end], oo, "rk4")  # warm (page in the library)
         c0 = time.perf_counter()
         cpu = O.solve_ode_batch(O.RHS_NEG_Y, [], y0s, ns, 0, [0.0, t_end], oo, "rk4", n_threads=1)
         c1 = time.perf_counter()
@@ -365,15 +454,47 @@ def main():
             assert check <= 1e-10, f"parity failure vs oracle: max abs err {check}"
             out["parity_max_abs_err_vs_oracle"] = check
             out["parity_checked_ivps"] = k
-        ncores = os.cpu_count() or 1
-        O.solve_ode_batch(O.RHS_NEG_Y, [], y0s, ns, 0, [0.0, t_end], oo, "rk4", n_threads=ncores)
-        c2 = time.perf_counter()
+        one_core = ns * nsteps / (c1 - c0)
+
+        def all_cores(run, n_small):
+            run(n_small, ncores)           # start the OpenMP team (and touch every thread's stack) before the clock
+            a = time.perf_counter()
+            r = run(None, ncores)
+            return time.perf_counter() - a, r
+
+        na = int(min(n, max(ns, args.cpu_ivps_per_thread * ncores))) if ncores > 1 else ns
+        y0a = nd.c2_y0_numpy(0, na)
+        ta, _ = all_cores(lambda m, th: O.solve_ode_batch(O.RHS_NEG_Y, [], y0a[:m] if m else y0a, m or na, 0, [0.0, t_end], oo, "rk4", n_threads=th), ncores * 8)
         out["cpu_baseline"] = {
-            "value": ns * nsteps / (c1 - c0), "unit": "trajectory-steps/s", "cores": 1, "kind": "port",
+            "value": one_core, "unit": "trajectory-steps/s", "cores": 1, "kind": "port",
             "sample": "first %d IVPs of the C2 batch x %d RK4 steps through the oracle's solveODE (closure-style RHS call), "
                       "1 thread = the single-threaded reference; IVPs are independent so the rate extrapolates linearly" % (ns, nsteps),
-            "all_cores": {"value": ns * nsteps / (c2 - c1), "cores": ncores},
+            "all_cores": {"value": na * nsteps / ta, "cores": ncores, "speedup_over_1_core": na * nsteps / ta / one_core,
+                          "sample": "first %d IVPs x %d steps (%d per thread), OpenMP team started before the clock" % (na, nsteps, na // ncores)},
         }
+        # C3 / C4 beside their GPU figures: the oracle's Vector path allocates a fresh seq per operator like the reference's
+        # (utils.nim:59-64,113-118,176-180) — that is where the reference's CPU time goes for vector states
+        for name, (fr, yy, layout, integ, d, y_gpu) in adaptive_inputs.items():
+            kind, par = (O.RHS_LORENZ, [10.0, 28.0, 8.0 / 3.0]) if d == 3 else (O.RHS_RING, [0.1])
+            n1 = int(args.cpu_adaptive_sample)
+            nall = int(min(yy.shape[1 - layout] if yy.dim() == 2 else yy.shape[0], max(n1, (n1 // 8) * ncores)))
+            yh = yy.cpu().numpy()
+            sub = (lambda m: np.ascontiguousarray(yh[:, :m])) if layout == 0 else (lambda m: np.ascontiguousarray(yh[:m]))
+            run = lambda m, th, tot: O.solve_ode_batch(kind, par, sub(m or tot), m or tot, d, [0.0, 1.0], O.new_options(), integ, layout=layout, n_threads=th)
+            run(64, 1, n1)
+            a = time.perf_counter(); r1 = run(None, 1, n1); t1 = time.perf_counter() - a
+            tall, rall = all_cores(lambda m, th: run(m, th, nall), ncores * 2)
+            got = (y_gpu[:, :n1] if layout == 0 else y_gpu[:n1]).cpu().numpy()
+            devi = float(np.abs(got - r1["y"][-1]).max())
+            assert devi <= 1e-6, (name, devi)   # north_star's tolerance for adaptive methods (bit-equal when the host libm is the glibc the device restates)
+            st1, sta = float(r1["steps"].sum()), float(rall["steps"].sum())
+            out["adaptive_configs"][name]["cpu_baseline"] = {
+                "kind": "port", "unit": "IVPs/s", "value": n1 / t1, "cores": 1, "accepted_steps_per_s": st1 / t1,
+                "sample": "first %d IVPs of the batch, one solveODE call each (Vector[float] path: a fresh seq per operator)" % n1,
+                "all_cores": {"value": nall / tall, "cores": ncores, "accepted_steps_per_s": sta / tall, "speedup_over_1_core": (nall / tall) / (n1 / t1),
+                              "sample": "first %d IVPs, OpenMP team started before the clock" % nall},
+                "max_abs_dev_gpu_vs_cpu": devi,
+            }
     # RCCL prints a banner ("Librccl path : ...") through C stdio, which would otherwise be flushed AFTER this line at
     # exit; flush C stdio first so that the JSON line is the last thing on stdout.
     try:

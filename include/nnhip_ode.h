@@ -157,6 +157,10 @@ int nnhip_host_free(void* p);
  *   "host_register" 0|1 (pipelining of the host-pointer solve) */
 /* Changing a knob drops the calling thread's hipGraph caches so that the new setting takes effect on its next call. */
 int nnhip_tune_set(const char* key, int value);
+/* Which instantiation of the headline kernel (rk4_stream_vec_kernel<RHS, NEG, VEC, MODE>) the scalar RK4 step entry launches for
+ * `n_states` flat float64 states (in_place: y_out == y_in, else two buffers): the knobs above, or the automatic choice by working set.
+ * Lets a profile be matched to the variant it was taken on (bench.py checks profiles/pmc_traffic.json's kernel name with it). */
+int nnhip_ode_rk4_stream_variant(int64_t n_states, int in_place, int* vec, int* mode);
 
 /* ---- options / dispatch (host only, no device needed) ---------------------------------------- */
 /* newODEoptions (ode.nim:78-102): abs() of everything but tStart; NNHIP_EVALUE if |dtMax| < |dtMin|,

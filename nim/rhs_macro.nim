@@ -32,6 +32,7 @@ import ./numericalnim_hip
 const
   brOpen = $chr(1)    ## brackets of a ctx-vector access in the emitted text until its layout (shared: NAME[j], per IVP: NAME(j)) is known
   brClose = $chr(2)
+  brName = $chr(3)    ## precedes the NAME of such an access: a vector "b" must not be found at the end of a vector "ab"
 
 proc fail(n: NimNode, what: string) {.compileTime.} =
   error("deviceRhs: " & what & " is not in the translatable subset: " & n.repr, n)
@@ -87,7 +88,7 @@ proc tr(n: NimNode, keys: seq[string], ints: seq[string], vectors: var seq[strin
       let name = n[0][1].strVal
       if name notin vectors: vectors.add name
       # brackets of a ctx vector are emitted as brOpen .. brClose: whether NAME is shared (NAME[j]) or per IVP (NAME(j)) is decided where the layout is known
-      return name & brOpen & trIndex(n[1], ints) & brClose
+      return brName & name & brOpen & trIndex(n[1], ints) & brClose
     fail(n, "indexing")
   of nnkCall, nnkCommand:
     let f = $n[0]
@@ -161,12 +162,12 @@ template deviceRhsCtx*(dim: int, keys: static[openArray[string]], lens: openArra
       var res = ""
       var i = 0
       while i < src.len:
-        let at = src.find(nm & brOpen, i)
+        let at = src.find(brName & nm & brOpen, i)
         if at < 0:
           res.add src[i ..< src.len]
           break
         let close = src.find(brClose, at)
-        res.add src[i ..< at] & nm & (if perIvp[k]: "(" else: "[") & src[at + nm.len + 1 ..< close] & (if perIvp[k]: ")" else: "]")
+        res.add src[i ..< at] & nm & (if perIvp[k]: "(" else: "[") & src[at + nm.len + 2 ..< close] & (if perIvp[k]: ")" else: "]")
         i = close + 1
       src = res
     rhsFromSourceCtx(dim, src, @keys, vs)

@@ -17,7 +17,26 @@
 
 using namespace nnhip_capi;
 
+// The variant of the headline kernel a streamed working set of `workingSet` bytes gets.
+// Measured on MI355X (profiles/r01_stream_tuning.txt): while the streamed working set fits the 256 MiB
+// Infinity Cache plain accesses with one 16-B load per lane win (6.9 TB/s); beyond it, non-temporal
+// accesses with 4 loads in flight per lane do (6.4 TB/s vs 5.9).
+static nnhip::StreamTune rk4_stream_tune_for(int64_t workingSet) {
+  nnhip::StreamTune tune = g_tune;
+  if (g_tune_auto) {
+    if (workingSet <= (192LL << 20)) { tune.vec = 1; tune.mode = 0; } else { tune.vec = 4; tune.mode = 1; }
+  }
+  return tune;
+}
+
 extern "C" {
+
+int nnhip_ode_rk4_stream_variant(int64_t n_states, int in_place, int* vec, int* mode) {
+  if (n_states < 0 || !vec || !mode) return fail(NNHIP_EVALUE, "n_states < 0 or vec / mode is NULL");
+  const nnhip::StreamTune tune = rk4_stream_tune_for(8 * n_states * (in_place ? 1 : 2));
+  *vec = tune.vec; *mode = tune.mode;
+  return NNHIP_OK;
+}
 
 // ---- step-streaming ---------------------------------------------------------------------------------
 int nnhip_ode_step_batch_f64_dev(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params,
@@ -36,14 +55,7 @@ int nnhip_ode_step_batch_f64_dev(const nnhip_ode_options* opt, int integrator, i
   // scalar elementwise RK4 with uniform (t, dt): the vectorised streaming kernel over N*dim flat states
   if (integrator == NNHIP_RK4 && elementwise_rhs(rhs_kind) && !t_dev && !dt_dev && !fsal_out && !dt_used && !error &&
       (((uintptr_t)y_in | (uintptr_t)y_out) & 15) == 0) {
-    nnhip::StreamTune tune = g_tune;
-    if (g_tune_auto) {
-      // Measured on MI355X (profiles/r01_stream_tuning.txt): while the streamed working set fits the 256 MiB
-      // Infinity Cache plain accesses with one 16-B load per lane win (6.9 TB/s); beyond it, non-temporal
-      // accesses with 4 loads in flight per lane do (6.4 TB/s vs 5.9).
-      const int64_t workingSet = 8 * N * dim * (y_in == y_out ? 1 : 2);
-      if (workingSet <= (192LL << 20)) { tune.vec = 1; tune.mode = 0; } else { tune.vec = 4; tune.mode = 1; }
-    }
+    const nnhip::StreamTune tune = rk4_stream_tune_for(8 * N * dim * (y_in == y_out ? 1 : 2));
     HIP_TRY(nnhip::launch_rk4_stream(rhs_kind, y_in, y_out, N * dim, t_uniform, dt_uniform, P, negate_time, tune, (hipStream_t)stream));
     return NNHIP_OK;
   }

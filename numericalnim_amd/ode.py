@@ -328,6 +328,7 @@ def _params_array(f, ctx, like=None):
         cached = getattr(f, "_marshalled", None)
         if cached is None or cached[0] != (f.kind, f.keys, tuple(sorted(f.defaults.items()))):
             p = np.asarray(f.params(None), dtype=np.float64)
+            p.flags.writeable = False  # handed out by reference on every call: a caller's write would corrupt later calls
             cached = f._marshalled = ((f.kind, f.keys, tuple(sorted(f.defaults.items()))), p, (p.ctypes.data_as(C.POINTER(C.c_double)) if p.size else None))
         return cached[1], cached[2]
     p = np.asarray(f.params(ctx), dtype=np.float64)
@@ -512,8 +513,13 @@ def integratorStep(f, t, y, FSAL, dt, options=None, ctx=None, integrator="dopri5
         y_new = o[0] if o[0] is not None else torch.empty_like(yc)
         fs_in = (FSAL if FSAL.is_contiguous() else FSAL.contiguous()) if FSAL is not None else None
         fs_new = (o[1] if o[1] is not None else torch.empty_like(yc)) if (use_fsal or FSAL is not None) else None
-        t_dev = t.contiguous() if _is_torch(t) else None
-        dt_dev = dt.contiguous() if _is_torch(dt) else None
+        t_dev = t.contiguous() if (_is_torch(t) and t.is_cuda) else None
+        dt_dev = dt.contiguous() if (_is_torch(dt) and dt.is_cuda) else None
+        # host scalars that are not Python floats (np.float32, np.int64, 0-d arrays, 0-d CPU tensors): ctypes refuses them
+        if t_dev is None and type(t) is not float:
+            t = float(t)
+        if dt_dev is None and type(dt) is not float:
+            dt = float(dt)
         dt_used = (o[2] if o[2] is not None else torch.empty(N, dtype=torch.float64, device=yc.device)) if adaptive else None
         err = (o[3] if o[3] is not None else torch.empty(N, dtype=torch.float64, device=yc.device)) if adaptive else None
         if stream is None:

@@ -249,3 +249,26 @@ def test_rtc_compiler_choice(nn):
             env["NNHIP_HIPRTC"] = env_val
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         assert r.returncode == 0 and expect in r.stdout and "kind" in r.stdout, (env_val, r.stdout[-400:], r.stderr[-400:])
+
+
+def test_the_profiled_headline_variant_is_the_one_the_tuner_picks(nn):
+    """profiles/pmc_traffic.json's counters belong to one instantiation of rk4_stream_vec_kernel; bench.py attaches them to the line only
+    if nnhip_ode_rk4_stream_variant names the same (VEC, MODE) for the same batch — for both committed regimes it must."""
+    import ctypes as C
+    import json
+    import re
+    L = nn._lib.lib()
+    pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    for key in ("rk4_stream", "rk4_stream_beyond_infinity_cache"):
+        vec, mode = C.c_int(-1), C.c_int(-1)
+        assert L.nnhip_ode_rk4_stream_variant(int(pm[key]["ivps_per_launch"]), 0, C.byref(vec), C.byref(mode)) == 0
+        m = re.search(r"rk4_stream_vec_kernel<.*?, (?:false|true), (\d+), (\d+)>", pm[key]["kernel"])
+        assert (int(m.group(1)), int(m.group(2))) == (vec.value, mode.value), (key, pm[key]["kernel"], vec.value, mode.value)
+    assert L.nnhip_ode_rk4_stream_variant(-1, 0, C.byref(vec), C.byref(mode)) == -1
+    # an explicit knob pins the variant; "rk4_stream_auto" hands the choice back
+    try:
+        assert L.nnhip_tune_set(b"rk4_stream_vec", 8) == 0
+        assert L.nnhip_ode_rk4_stream_variant(10, 0, C.byref(vec), C.byref(mode)) == 0 and vec.value == 8
+    finally:
+        assert L.nnhip_tune_set(b"rk4_stream_vec", 4) == 0 and L.nnhip_tune_set(b"rk4_stream_auto", 1) == 0
+    assert L.nnhip_ode_rk4_stream_variant(10, 0, C.byref(vec), C.byref(mode)) == 0 and (vec.value, mode.value) == (1, 0)

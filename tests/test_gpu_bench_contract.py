@@ -25,6 +25,7 @@ def test_single_process_line():
     out = _run(SMALL)
     assert KEYS <= set(out), KEYS - set(out)
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["dtype"] == "f64" and out["scaling"] == "weak"
+    assert out["world_size_reported_by_backend"] == 1 and out["ms_per_step_per_rank"]["min"] == out["ms_per_step_per_rank"]["max"] == out["ms_per_step"]
     assert out["vs_baseline"] is None and out["higher_is_better"] is True and "workload" in out["config"]
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
@@ -82,3 +83,37 @@ def test_eight_ranks_share_the_gpu_over_gloo():
     assert KEYS <= set(out) and out["n_gpus"] == 8 and out["scaling"] == "weak" and out["config"]["ivps_per_gpu"] == 100000
     assert out["gathers_verified"] == 4 and out["config"]["allgather_overlapped_with_next_solve"] is True
     assert abs(out["value"] - 8 * 100000 * 32 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 1e-9
+
+
+def test_gpus_2_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with WORLD_SIZE unset — the shape of the driver's N = 1 line with another N: bench.py re-executes
+    itself under torch.distributed.run (two ranks sharing this box's GPU over gloo) and the one JSON line still comes from rank 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--verify-gathers", "--steps", "3", "--warmup", "1",
+                        "--n-ivp", "300000", "--rk4-steps", "64"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert KEYS <= set(out) and out["n_gpus"] == 2 and out["world_size_reported_by_backend"] == 2 and out["config"]["backend"] == "gloo"
+    assert out["gathers_verified"] == 4 and out["allgather_ms_per_solve"] > 0
+    pr = out["ms_per_step_per_rank"]
+    assert 0 < pr["min"] <= pr["max"] == out["ms_per_step"]          # the job is as slow as its slowest rank
+    assert abs(out["value"] - 2 * 300000 * 64 * 3 / (out["ms_per_step"] * 3e-3)) / out["value"] < 1e-9
+
+
+def test_a_launcher_of_another_size_is_refused():
+    """--gpus N under a launcher whose WORLD_SIZE is not N: an error, not a silently different job"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29579", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE is 1" in r.stderr
+
+
+def test_more_rccl_ranks_than_devices_is_refused():
+    """RCCL wants one device per rank: 2 ranks on a 1-GPU box must say so instead of hanging in the communicator's set-up"""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 devices")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29580", RANK="0", LOCAL_RANK="0", WORLD_SIZE="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "need 2 devices" in r.stderr

@@ -108,7 +108,10 @@ def test_ctx_vectors_get_their_layout_late(mac):
     it, nimrun = mac
     src, vectors = it.call("deviceRhsCtxSource", ["a"], nimrun.nim_ast('dy[0] = ctx.fValues["a"] * y[0] * ctx.tValues["w"][1] + ctx.tValues["g"][0] * ctx.tValues["w"][0]'))
     assert vectors == ["w", "g"]
-    assert src.replace(chr(1), "<").replace(chr(2), ">") == "dy[0] = (((p[0] * y[0]) * w<1>) + (g<0> * w<0>));\n"
+    assert src.replace(chr(3), "").replace(chr(1), "<").replace(chr(2), ">") == "dy[0] = (((p[0] * y[0]) * w<1>) + (g<0> * w<0>));\n"
+    # a vector whose name ends another's ("b" / "ab") is still told apart: every access carries a marker in front of its name
+    src, vectors = it.call("deviceRhsCtxSource", ["a"], nimrun.nim_ast('dy[0] = ctx.tValues["ab"][1] + ctx.tValues["b"][0]'))
+    assert vectors == ["ab", "b"] and src == "dy[0] = (%sab%s1%s + %sb%s0%s);\n" % (chr(3), chr(1), chr(2), chr(3), chr(1), chr(2))
 
 
 def test_arguments_are_checked_against_the_declared_parameter_types(it):
