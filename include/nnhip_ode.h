@@ -150,6 +150,7 @@ int nnhip_host_free(void* p);
  *   probe, bins the batch again by the steps still to take, and finishes: for step sizes that change late in the span; default 0 = the probe's order throughout),
  *   "sort_resume" 0|1 (1: the automatic binned solve continues from its probe's state — forward 2-point tspans, DOPRI54 / Tsit54 / BS32 / RK21 —
  *   instead of integrating the probed steps twice; default 0: within 1 % either way, the resumed pass needs the per-call instantiation of the kernel),
+ *   "adv_lean" 0|1 (0: the adaptive streaming loop keeps its general kernels where the lean ones — the driver's own layout as the kernel's contract — apply; same bits),
  *   "fixed_vec_ipl" 0|2 (0 = one IVP per lane instead of the vectorised fixed-step streaming kernel),
  *   "multi_gpu_oversubscribe" 0|1 (nnhip_ode_solve_batch_multi_gpu_f64 accepts more shards than devices: shard r on device r mod #devices),
  *   "dim16_variant" 0..4 (A/B mappings of the fused 16-component kernels), "fp_contract" 0|1 (opt-in FMA-contracted fused
@@ -382,9 +383,10 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
  * y (device, in `layout`) is
  * advanced in place from t0 to tEnd; `ws` is device scratch of nnhip_ode_adaptive_stream_workspace_bytes(N, dim) (16-byte aligned, as
  * every allocator's blocks are, it holds (t, dt) of an IVP side by side — one 16-byte access each way per launch; otherwise two columns).  The host
- * learns whether anyone is still integrating every `check_every` launches (<= 0: 8) and always has the next group enqueued
+ * learns whether anyone is still integrating every `check_every` launches and always has the next group enqueued
  * before it waits (groups can be replayed from a hipGraph on a non-default stream: knob "stream_graph" = 1), so up to 2*check_every trailing launches
- * find nothing to do (they read t only).  Results are bitwise those of the fused solve.  Thread-per-IVP kernels for small
+ * find nothing to do (they read t only).  check_every <= 0: the library's own schedule — no step is longer than dtMax, so nobody finishes within
+ * the first ceil((tEnd - t0) / dtMax) launches, which go out unpolled; then groups of 2, 2, 4, 8, 8 ... (graph replay: uniform groups of 8).  Results are bitwise those of the fused solve.  Thread-per-IVP kernels for small
  * systems, lanes-per-system kernels for Vector[float] states of 8 / 16 / 32 ... components (ahead of time or run-time compiled). */
 /* [core] */
 int64_t nnhip_ode_adaptive_stream_workspace_bytes(int64_t N, int dim);

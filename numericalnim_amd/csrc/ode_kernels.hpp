@@ -124,6 +124,8 @@ struct StepArgs {
   int nontemporal;  // advance mode: non-temporal hint on the streamed state arrays (working set beyond the Infinity Cache)
   int recomputeFsal;  // advance mode, DOPRI54 / Tsit54: FSAL is not carried through HBM but re-evaluated as f(t, y) at the start of the launch
                       // (see adv_fsal_in_hbm): 16*d bytes per step less for one more evaluation of f — the same bits
+  int noLean;         // advance mode: 1 keeps the general kernels where the lean ones (advance_*_lean_kernel: the streaming driver's own layout as the
+                      // kernel's contract) would apply — A/B and parity tests, tuning knob "adv_lean"
   // advance mode WITH dense output (adaptive streaming through the IntegratorProc seam, ode.nim:512-530): tReq == nullptr -> none.
   const double* tReq;   // requested times of this direction as the reference holds them (tPositive ascending / tNegative descending)
   int nReq;
@@ -1033,6 +1035,150 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_LPS_ATTR void advance_lps_kernel(
   }
 }
 
+// ---- the same loop iteration for the layout the streaming driver itself sets up (round 5) --------------------------------------------
+// nnhip_ode_adaptive_stream_f64_dev's default state: updated in place, (t, dt) side by side, FSAL re-evaluated (DOPRI54 / Tsit54), no error /
+// step-count columns, no per-IVP parameters, AoS systems back to back (lanes-per-system form) or SoA planes (thread-per-IVP form).  The general
+// kernels above decide all of that per launch from StepArgs — strides, four state pointers, three nullable columns, two (t, dt) forms — and pay
+// for it in every wave: 64-bit address arithmetic per array (v_lshl_add_u64, v_mad_u64_u32), pointer selects (v_cndmask), and so many live
+// scalars that EXEC masks of the nested accept / reject branches are spilled through v_writelane / v_readlane.  Here the layout is the
+// kernel's contract: ONE uniform 64-bit base per block in SGPRs + a 32-bit lane offset (global_load/store ... v_off, s[base]), seven scalar
+// arguments.  The arithmetic is the same inlined code (ops.rhs, embedded_step, the controller lines :525-541), hence the same bits.
+struct AdvLeanArgs {
+  double* y;        // [N][DIM] (lanes-per-system) / [DIM][N] (thread-per-IVP), advanced in place
+  double2* td;      // (t, dt) of IVP i
+  int64_t N;
+  double tEnd;
+  StepCtl ctl;
+  Params P;         // scalars only (ivp / aux == nullptr)
+  unsigned int* active;  // nullable, see StepArgs::active
+};
+NNHIP_DEV void pin_lean_args(const AdvLeanArgs& a) {
+  NNHIP_PIN_SGPR64(a.y); NNHIP_PIN_SGPR64(a.td); NNHIP_PIN_SGPR64(a.N); NNHIP_PIN_SGPR64(a.tEnd);
+  NNHIP_PIN_SGPR64(a.ctl.absTol); NNHIP_PIN_SGPR64(a.ctl.relTol); NNHIP_PIN_SGPR64(a.ctl.dtMax); NNHIP_PIN_SGPR64(a.ctl.dtMin);
+  NNHIP_PIN_SGPR64(a.active);
+}
+// ode.nim:525-541 on registers: (t, dt, y) -> (t', dt', yNew); returns t' < tEnd.  FSAL = f(t, y) is evaluated here (adv_fsal_in_hbm).
+template <int METHOD, class Ops>
+NNHIP_DEV bool adv_lean_iteration(const Ops& ops, const StepCtl& ctl, double tEnd, double& t, double& dt, const double (&y)[Ops::D], double (&yNew)[Ops::D]) {
+  static_assert(METHOD == NNHIP_DOPRI54 || METHOD == NNHIP_TSIT54, "the lean form re-evaluates FSAL: methods whose last stage is f(t + dt, yNew)");
+  double fsal[Ops::D];
+  ops.rhs(t, y, fsal);
+  dt = nmin(dt, tEnd - t);                                               // :525
+  double error = 0.0, factor;
+  int64_t rej = 0;
+  embedded_step<METHOD, NNHIP_PEEL_STREAM != 0>(ops, t, dt, y, fsal, fsal, yNew, error, ctl, rej, factor);  // :531
+  t += dt;                                                               // :532
+  if (error == 0.0) dt *= 5.0;                                           // :534-535
+  else dt = dt * factor;                                                 // :537
+  if (dt < ctl.dtMin) dt = ctl.dtMin;                                    // :538-539
+  else if (ctl.dtMax < dt) dt = ctl.dtMax;                               // :540-541
+  if (error != error) t = tEnd;  // NaN abort (same deviation as the fused driver): retire the IVP
+  return t < tEnd;
+}
+#ifdef NNHIP_ADV_LEAN_WPE
+#define NNHIP_ADV_LEAN_ATTR __attribute__((amdgpu_waves_per_eu(NNHIP_ADV_LEAN_WPE)))
+#else
+#define NNHIP_ADV_LEAN_ATTR
+#endif
+template <int METHOD, class RHS, int CPL>
+__global__ __launch_bounds__(kBlock) NNHIP_ADV_LEAN_ATTR void advance_lps_lean_kernel(const AdvLeanArgs a) {
+  constexpr int DIM = RHS::dim;
+  constexpr int LPSYS = DIM / CPL;
+  constexpr int perBlock = kBlock / LPSYS;
+  static_assert(DIM % CPL == 0 && 64 % LPSYS == 0 && CPL % 2 == 0 && RhsSize<RHS>::value == DIM, "whole systems inside a wavefront, 16-byte lane accesses");
+  __shared__ double lds[lps_lds_doubles<DIM, CPL>()];  // (untouched — and dropped — for banded right-hand sides with the register-chain norm)
+  controller_prologue();
+  pin_lean_args(a);
+  const unsigned int tid = threadIdx.x;
+  const unsigned int sysInBlock = tid / LPSYS;
+  const int c = (int)(tid % LPSYS) * CPL;
+  const int64_t sys0 = (int64_t)blockIdx.x * perBlock;                   // uniform
+  const int64_t left = a.N - sys0;
+  const unsigned int nHere = left < (int64_t)perBlock ? (unsigned int)left : (unsigned int)perBlock;  // uniform, >= 1
+  double* const yb = a.y + sys0 * DIM;                                    // uniform: the block's systems, back to back
+  double2* const tb = a.td + sys0;
+  const bool in = sysInBlock < nHere;
+  const unsigned int so = in ? sysInBlock : 0u;                           // lanes past the batch read (never write) the block's first system
+  const unsigned int yo = in ? tid * (unsigned int)CPL : (unsigned int)c; // = so * DIM + c
+  const double2 td = tb[so];
+  double y[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; j += 2) {
+    const double2 v = *reinterpret_cast<const double2*>(&yb[yo + j]);
+    y[j] = v.x; y[j + 1] = v.y;
+  }
+  double t = td.x, dt = td.y;
+  // every load of the system in ONE round trip, above the branch on `t` (left alone the compiler sinks the state loads below it: two serialized
+  // memory latencies per wave, and the kernel's waves start together and stay in phase).  The general kernel's tile prefetch does the same.
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) asm volatile("" : "+v"(y[j]));
+  asm volatile("" : "+v"(t), "+v"(dt));
+  unsigned int stillActive = 0;
+  if (in && t < a.tEnd) {                                                 // :511
+    const LpsOps<RHS, false, CPL> ops{a.P, lds + sysInBlock * lps_stride<DIM>(), lds + lps_lds_doubles<DIM, CPL>() / 2 + sysInBlock * lps_stride<DIM>(), c};
+    double yNew[CPL];
+    stillActive = adv_lean_iteration<METHOD>(ops, a.ctl, a.tEnd, t, dt, y, yNew) ? 1u : 0u;
+#pragma unroll
+    for (int j = 0; j < CPL; j += 2) *reinterpret_cast<double2*>(&yb[yo + j]) = make_double2(yNew[j], yNew[j + 1]);
+    if (c == 0) tb[so] = make_double2(t, dt);
+  }
+  if (a.active) {
+    if (__syncthreads_or((int)stillActive) && tid == 0) a.active[blockIdx.x % kAggSlots] = 1u;
+  }
+}
+// thread-per-IVP form: SoA planes y[c * N + i]; a block's part of plane c starts at y + c * N + blockIdx.x * blockDim.x (uniform)
+template <int METHOD, class RHS>
+__global__ __launch_bounds__(kBlock) NNHIP_ADV_TPI_ATTR void advance_tpi_lean_kernel(const AdvLeanArgs a) {
+  constexpr int D = RHS::dim;
+  controller_prologue();
+  pin_lean_args(a);
+  const unsigned int tid = threadIdx.x;
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x;                    // uniform
+  const int64_t left = a.N - i0;
+  const bool in = (int64_t)tid < left;
+  const unsigned int o = in ? tid : 0u;
+  double* const yb = a.y + i0;
+  double2* const tb = a.td + i0;
+  const double2 td = tb[o];
+  double t = td.x, dt = td.y;
+  unsigned int stillActive = 0;
+  if (in && t < a.tEnd) {                                                 // :511 (finished IVPs touch no other memory)
+    double y[D], yNew[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) y[c] = (yb + (int64_t)c * a.N)[o];
+    const TpiOps<RHS, false> ops{a.P};
+    stillActive = adv_lean_iteration<METHOD>(ops, a.ctl, a.tEnd, t, dt, y, yNew) ? 1u : 0u;
+#pragma unroll
+    for (int c = 0; c < D; ++c) (yb + (int64_t)c * a.N)[o] = yNew[c];
+    tb[o] = make_double2(t, dt);
+  }
+  if (a.active) {
+    if (__syncthreads_or((int)stillActive) && tid == 0) a.active[blockIdx.x % kAggSlots] = 1u;
+  }
+}
+#if !NNHIP_RTC
+// Does this launch have the layout the lean kernels are written for?  (Everything the streaming driver's default set-up produces.)
+#ifndef NNHIP_ADV_LEAN
+#define NNHIP_ADV_LEAN 1
+#endif
+template <int METHOD>
+inline bool adv_lean_applies(const StepArgs& a, int dim, bool aos) {
+  if constexpr (!(METHOD == NNHIP_DOPRI54 || METHOD == NNHIP_TSIT54)) return false;
+  else {
+    if (!NNHIP_ADV_LEAN || a.noLean || !a.recomputeFsal || a.stepsPerLaunch > 1 || a.nontemporal) return false;
+    if (a.y_in != a.y_out || a.dt_io || !a.t_io || a.error || a.steps_io || a.perIvpParams || a.P.ivp || a.P.aux || a.tReq) return false;
+    if ((((uintptr_t)a.y_in | (uintptr_t)a.t_io) & 15) != 0) return false;
+    if (aos) return a.compStride == 1 && a.ivpStride == dim;
+    return a.ivpStride == 1 && a.compStride == a.N;
+  }
+}
+inline AdvLeanArgs adv_lean_args(const StepArgs& a) {
+  AdvLeanArgs l{};
+  l.y = a.y_out; l.td = reinterpret_cast<double2*>(a.t_io); l.N = a.N; l.tEnd = a.tEnd; l.ctl = a.ctl; l.P = a.P; l.active = a.active;
+  return l;
+}
+#endif
+
 // ---- adaptive streaming WITH dense output (thread-per-IVP systems) ------------------------------------------------------------
 // ODESolver's loop iteration including the emission block :512-524 and the lastIter update :526-530, per IVP and launch, with
 // the Hermite history (lastIter.t, .y, .dy) and denseIndex resident in HBM next to (y, FSAL, t, dt).  One kernel serves both
@@ -1377,6 +1523,9 @@ hipError_t launch_advance_tpi(const StepArgs& a, int block, hipStream_t s) {
     const int bs = (block == 64 || block == 128) ? block : kBlock;  // tuning knob "adv_block"
     const int64_t grid = (a.N + bs - 1) / bs;
     if (grid <= 0) return hipSuccess;
+    if constexpr (METHOD == NNHIP_DOPRI54 || METHOD == NNHIP_TSIT54) {
+      if (adv_lean_applies<METHOD>(a, RHS::dim, false)) return launch_kernel(advance_tpi_lean_kernel<METHOD, RHS>, dim3((unsigned)grid), dim3(bs), s, adv_lean_args(a));
+    }
     if (a.stepsPerLaunch > 1) return launch_kernel(advance_tpi_kernel<METHOD, RHS, false, true>, dim3((unsigned)grid), dim3(bs), s, a);
     if (a.nontemporal) return launch_kernel(advance_tpi_kernel<METHOD, RHS, true>, dim3((unsigned)grid), dim3(bs), s, a);
     return launch_kernel(advance_tpi_kernel<METHOD, RHS, false>, dim3((unsigned)grid), dim3(bs), s, a);
@@ -1405,6 +1554,9 @@ hipError_t launch_advance_lps(const StepArgs& a, int block, hipStream_t s) {
     constexpr int perBlock = kBlock / (RHS::dim / CPL) * adv_lps_spg(CPL);
     const int64_t grid = (a.N + perBlock - 1) / perBlock;
     if (grid <= 0) return hipSuccess;
+    if constexpr ((METHOD == NNHIP_DOPRI54 || METHOD == NNHIP_TSIT54) && CPL % 2 == 0 && adv_lps_spg(CPL) == 1 && RhsSize<RHS>::value == RHS::dim) {
+      if (adv_lean_applies<METHOD>(a, RHS::dim, true)) return launch_kernel(advance_lps_lean_kernel<METHOD, RHS, CPL>, dim3((unsigned)grid), dim3(kBlock), s, adv_lean_args(a));
+    }
     if (a.stepsPerLaunch > 1) return launch_kernel(advance_lps_kernel<METHOD, RHS, CPL, true>, dim3((unsigned)grid), dim3(kBlock), s, a);
     return launch_kernel(advance_lps_kernel<METHOD, RHS, CPL>, dim3((unsigned)grid), dim3(kBlock), s, a);
   } else {

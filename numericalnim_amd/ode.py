@@ -799,7 +799,7 @@ def adaptiveStreamSolve(f, y0, tspan, options=None, ctx=None, integrator="dopri5
     return t_out[:ntout.value].copy(), y, ny[:N], nl.value
 
 
-def adaptiveStream(f, y, t0, tEnd, options=None, ctx=None, integrator="dopri54", layout=LAYOUT_SOA, check_every=8, steps_per_launch=None):
+def adaptiveStream(f, y, t0, tEnd, options=None, ctx=None, integrator="dopri54", layout=LAYOUT_SOA, check_every=0, steps_per_launch=None):
     """ODESolver's adaptive loop (ode.nim:506-542) over the HBM-resident `advance` kernel; y (CUDA tensor) is advanced
     in place from t0 to tEnd.  Returns (y, number of launches).  Bitwise equal to solveODE(f, y0, [t0, tEnd])[1][-1].
     steps_per_launch (None = leave the process-wide knob "adv_steps_per_launch" as it is, default 1): loop iterations per IVP and

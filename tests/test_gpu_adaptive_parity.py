@@ -1301,3 +1301,64 @@ def test_per_call_tspans_binned_by_span_are_the_same_calls(nn, dev, integrator):
     same = lambda a, b: torch.equal(torch.nan_to_num(a, nan=-1.0), torch.nan_to_num(b, nan=-1.0)) and torch.equal(torch.isnan(a), torch.isnan(b))
     assert same(ta, tb) and same(ya, yb) and all(torch.equal(ca[k], cb[k]) for k in ca)
     assert int(ca["ny"][9]) == -1 and int(ca["ny"].max()) == n_t
+
+
+def test_automatic_polling_schedule_wastes_at_most_two_launches_beyond_the_speculative_pair(nn, dev):
+    """check_every <= 0 (the Python default): no step is longer than dtMax, so the first ceil((tEnd - t0) / dtMax) launches go out unpolled,
+    then the host polls every 2 launches (2, 2, 4, 8 ...).  BASELINE's C3 / C4 options (defaults, tspan [0, 1], dtMax 1e-2): 102 loop
+    iterations, 104 launches (uniform groups of 8 took 112) — and the bits of the fused solve, lanes-per-system form included."""
+    import torch
+    n = 5000
+    for f, y0, layout, integ in ((nn.Rhs.lorenz(), _lorenz_y0(n), 0, "dopri54"), (nn.Rhs.ring(0.1), _ring_y0(n, 16), 1, "tsit54")):
+        yt = torch.from_numpy(y0).to(dev)
+        t, yf, cnt = nn.solveODE(f, yt, [0.0, 1.0], integrator=integ, layout=layout, return_counts=True)
+        ys, launches = nn.adaptiveStream(f, yt.clone(), 0.0, 1.0, integrator=integ, layout=layout)
+        need = int(cnt["steps"].max())
+        assert torch.equal(ys, yf[-1]) and need == 102 and launches == 104, (integ, need, launches)
+    # a span that is not a multiple of dtMax, a batch that finishes at different launches, a bound on the launches
+    opt = nn.newODEoptions(absTol=1e-7, relTol=1e-7, dtMin=1e-9, dtMax=0.03)
+    yh = _lorenz_y0(4000)
+    yh[0] *= np.linspace(1.0, 30.0, 4000)
+    yt = torch.from_numpy(yh).to(dev)
+    t, yf, cnt = nn.solveODE(nn.Rhs.lorenz(), yt, [0.0, 0.5], opt, integrator="tsit54", return_counts=True)
+    ys, launches = nn.adaptiveStream(nn.Rhs.lorenz(), yt.clone(), 0.0, 0.5, opt, integrator="tsit54")
+    need = int(cnt["steps"].max())
+    assert torch.equal(ys, yf[-1]) and need <= launches <= need + 16, (need, launches)
+    assert need > 17  # = ceil(0.5 / 0.03): the unpolled part was really shorter than the loop
+
+
+def test_lean_advance_kernels_give_the_general_kernels_bits(nn, oracle, dev):
+    """advance_lps_lean_kernel / advance_tpi_lean_kernel (the streaming driver's own layout as the kernel's contract: one uniform base per
+    block + a 32-bit lane offset, seven scalar arguments) against the general kernels (knob "adv_lean" = 0) and the oracle: DOPRI54 and Tsit54,
+    thread-per-IVP (SoA planes) and lanes-per-system (AoS) systems, batches that do not fill their last block, rejections, tight and loose
+    tolerances, heterogeneous finishing times."""
+    import torch
+    O = oracle
+    L = nn._lib.lib()
+    cases = []
+    for n in (1, 63, 64, 257, 3001):
+        cases.append(("lorenz", nn.Rhs.lorenz(), _lorenz_y0(n), 0, 3, (O.RHS_LORENZ, LOR)))
+        cases.append(("ring16", nn.Rhs.ring(0.1), _ring_y0(n, 16), 1, 16, (O.RHS_RING, [0.1])))
+    cases.append(("ring8", nn.Rhs.ring(0.1), _ring_y0(500, 8), 1, 8, (O.RHS_RING, [0.1])))
+    cases.append(("ring32", nn.Rhs.ring(0.1), _ring_y0(130, 32), 1, 32, (O.RHS_RING, [0.1])))
+    cases.append(("vdp", nn.Rhs.vanderpol(3.0), np.stack([np.linspace(0.5, 2.5, 999), np.zeros(999)]), 0, 2, None))
+    for name, f, y0, layout, dim, orc in cases:
+        for integ in ("dopri54", "tsit54"):
+            for kw in ({}, dict(absTol=1e-9, relTol=1e-9, dtMin=1e-8, dtMax=0.2)):
+                y0 = np.ascontiguousarray(y0)
+                yt = torch.from_numpy(y0).to(dev)
+                opt = nn.newODEoptions(**kw)
+                got = {}
+                for lean in (1, 0):
+                    try:
+                        assert L.nnhip_tune_set(b"adv_lean", lean) == 0
+                        got[lean], launches = nn.adaptiveStream(f, yt.clone(), 0.0, 0.7, opt, integrator=integ, layout=layout)
+                    finally:
+                        assert L.nnhip_tune_set(b"adv_lean", 1) == 0
+                assert torch.equal(got[1], got[0]), (name, integ, kw)
+                t, yf = nn.solveODE(f, yt, [0.0, 0.7], opt, integrator=integ, layout=layout)
+                assert torch.equal(got[1], yf[-1]), (name, integ, kw)
+                if orc is not None and y0.shape[1 - layout] <= 300:
+                    n = y0.shape[1 - layout]
+                    ref = O.solve_ode_batch(orc[0], orc[1], y0, n, dim, [0.0, 0.7], O.new_options(**kw), integ, layout=layout, n_threads=4)
+                    assert _same_bits(got[1].cpu().numpy(), ref["y"][-1]), (name, integ, kw)
