@@ -486,8 +486,13 @@ def _arg_fits(tword, a):
     if isinstance(a, bool): return 3 if tword == "bool" else 0
     if isinstance(a, int): return 3 if tword in ("int", "Natural") else (2 if tword in ("float", "float64") else 0)
     if isinstance(a, float): return 3 if tword in ("float", "float64") else 0
-    if isinstance(a, list): return 3 if tword in ("seq", "openArray", "openarray") else 0
-    return 1 if tword not in ("Vector", "float", "float64", "int", "seq", "openArray") else 0
+    if isinstance(a, list):
+        if tword not in ("seq", "openArray", "openarray"): return 0
+        full = getattr(tword, "full", "")  # seq[seq[Ty]] next to seq[Ty] (utils.nim:385,406): told apart by the first element
+        if full.replace(" ", "").lower().startswith(("seq[seq[", "openarray[seq[")): return 4 if (a and isinstance(a[0], list)) else 0
+        if full and a and isinstance(a[0], list) and "T" in full: return 2
+        return 3
+    return 1 if tword not in ("Vector", "float", "float64", "int", "seq", "openArray", "openarray") else 0
 
 
 def pick_overload(routines, args):
@@ -535,6 +540,8 @@ class _Return(Exception):
 
 
 def _default_for(tword):
+    if getattr(tword, "fields", None):  # `tuple[x: ..., y: ...]` result (a parser that keeps the field names): fields assigned one by one
+        return NimObj(list(tword.fields), [None] * len(tword.fields))
     return {"seq": lambda: [], "float": lambda: 0.0, "float64": lambda: 0.0, "int": lambda: 0, "bool": lambda: False}.get(tword, lambda: None)()
 
 
@@ -619,12 +626,16 @@ _VEC_FIRST = {"size": lambda v: len(v.c), "sum": nim_sum}          # utils.nim:5
 # interpreter
 # ----------------------------------------------------------------------------------------------------------------------------------
 class Interp:
+    parser_class = None  # set below (Parser); a subclass that reads more of the language brings its own (nim_subset_quad.py)
+    tokenizer = None
+
     def __init__(self):
         self.globals = Env()
         self.lazy_consts = {}
 
     # ---- loading: only column-0 `proc` / `template` / `const NAME = expr` declarations with the wanted names are parsed ----
-    def load(self, path, names=None):
+    def load(self, path, names=None, accept=None):
+        """accept: optional predicate on a declaration's first line (tells overloads of one name apart: only the accepted ones are parsed)"""
         text = open(path).read()
         chunks, cur = [], None
         for lineno, line in enumerate(text.split("\n"), 1):
@@ -639,8 +650,9 @@ class Interp:
             if head[1].startswith("`"): raw = head[1][1:head[1].index("`", 1)]
             key = norm_ident(raw) if raw[:1].isalpha() else raw
             if wanted is not None and key not in wanted: continue
-            toks = tokenize("\n" * (start - 1) + "\n".join(lines))
-            ps = Parser(toks)
+            if accept is not None and not accept(lines[0]): continue
+            toks = (self.tokenizer or tokenize)("\n" * (start - 1) + "\n".join(lines))
+            ps = (self.parser_class or Parser)(toks)
             while ps.accept("nl"): pass
             node = ps.stmt()
             if node[0] in ("proc", "template"):
