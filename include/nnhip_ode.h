@@ -455,14 +455,19 @@ int nnhip_ode_rhs_compile_ctx(const char* name, int dim, int n_params, const cha
  *   per_ivp  [per_ivp_rows][stride]: the per-IVP vectors in declaration order, row r of IVP i at per_ivp[r*stride + i]
  *   aux      [n_aux][stride], updated in place
  * shared_len / per_ivp_rows / n_aux must equal what the layout declares (NNHIP_EVALUE otherwise); stride = IVPs of the bound batch
- * (calls may solve any N <= stride: IVP i of a call reads column i).  A binding belongs to one device's memory: the multi-GPU host
- * entries refuse such right-hand sides (bind and solve per device).  Process-wide per rhs_kind: two host threads that need
- * different bindings at the same time compile the source twice. */
+ * (calls may solve any N <= stride: IVP i of a call reads column i).  A binding belongs to the THREAD that made it: that thread's later calls
+ * read it whatever other threads bind in the meantime (two host threads can solve one compiled source with different contexts at the same
+ * time); a thread that never bound this rhs_kind reads the most recent binding of any thread.  Device pointers belong to one device's
+ * memory: the multi-GPU entries refuse a block bound this way — bind it from host arrays (below) and they cut it along the shards. */
 int nnhip_ode_rhs_bind_ctx_f64_dev(int rhs_kind, const double* shared, int64_t shared_len, const double* per_ivp, int64_t per_ivp_rows,
                                    double* aux, int n_aux, int64_t stride);
 /* The same for hosts without device-memory management (the Nim shim): the three parts are HOST arrays, copied into device memory of
- * `device` that the library owns until the next bind / nnhip_ode_rhs_release; aux_init [n_aux][stride] seeds the mutable slots and
- * nnhip_ode_rhs_read_aux_f64 copies their current content back ([n_aux][stride], after synchronising the device). */
+ * `device` that the library owns until the binding is replaced / nnhip_ode_rhs_release; aux_init [n_aux][stride] seeds the mutable slots and
+ * nnhip_ode_rhs_read_aux_f64 copies their current content back ([n_aux][stride], after synchronising the device).  The library keeps the host
+ * values too: the multi-GPU entries (nnhip_ode_solve_batch_multi_gpu[_sweep]_f64 and the two ..._multi_gpu_f64_dev ones) upload to shard r's
+ * device the columns [lo_r, hi_r) of the per-IVP rows and of the mutable slots (the shared block whole) — every member of the batch keeps its
+ * own ctx wherever it is integrated (commonTypes.nim:4-27, ode.nim:599) — and the slots are gathered back into the caller's order before
+ * anything reads them again (read_aux, a single-device call, the next sharded one). */
 int nnhip_ode_rhs_bind_ctx_f64(int rhs_kind, const double* shared, int64_t shared_len, const double* per_ivp, int64_t per_ivp_rows,
                                const double* aux_init, int n_aux, int64_t stride, int device);
 int nnhip_ode_rhs_read_aux_f64(int rhs_kind, double* aux_out);

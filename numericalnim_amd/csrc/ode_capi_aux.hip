@@ -451,9 +451,17 @@ int nnhip_ode_solve_batch_multi_gpu_sweep_f64(const nnhip_ode_options* opt, int 
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return nnhip::fail_msg(NNHIP_EHIP, "no HIP device available (this library has no CPU fallback)");
   if (n_gpus <= 0 || (n_gpus > ndev && !nnhip::multi_gpu_oversubscribe()) || n_gpus > 64)
     return nnhip::fail_msg(NNHIP_EVALUE, "n_gpus = %d, but this node has %d HIP device(s)", n_gpus, ndev);
-  if (n_gpus > 1 && nnhip::rtc_has_per_ivp_ctx(rhs_kind))
-    return nnhip::fail_msg(NNHIP_EUNSUPPORTED, "rhs_kind %d reads a context block bound to ONE device's memory: bind and solve per device", rhs_kind);
   if (N < 0 || dim < 1 || n_t < 0 || !opt || (n_t > 0 && !tspan)) return nnhip::fail_msg(NNHIP_EVALUE, "bad sizes / NULL options or tspan");
+  // A context block (NumContext beyond eight scalars: every IVP its own vectors / mutable slots, commonTypes.nim:4-27, ode.nim:599) travels with
+  // the batch: device r gets the columns [lo_r, hi_r) of the per-IVP rows and slots, the shared block whole
+  std::shared_ptr<void> ctxShards;
+  if (n_gpus > 1 && nnhip::rtc_has_per_ivp_ctx(rhs_kind)) {
+    std::vector<int> devs(n_gpus);
+    std::vector<int64_t> los(n_gpus), ns(n_gpus);
+    for (int r = 0; r < n_gpus; ++r) { devs[r] = r % ndev; los[r] = N * r / n_gpus; ns[r] = N * (r + 1) / n_gpus - los[r]; }
+    if (nnhip::rtc_ctx_shards_prepare(rhs_kind, n_gpus, devs.data(), los.data(), ns.data(), &ctxShards) != 0)
+      return nnhip::fail_msg(NNHIP_EUNSUPPORTED, "rhs_kind %d: %s", rhs_kind, nnhip::rtc_last_error());
+  }
   // The output time grid depends on (options, tspan) only: assembled once, on the calling thread (ode.nim:476-487, 585) — also
   // when some (or all) shards are empty.
   int nTOut = 0;
@@ -472,13 +480,17 @@ int nnhip_ode_solve_batch_multi_gpu_sweep_f64(const nnhip_ode_options* opt, int 
       std::memset(&sts[r], 0, sizeof(nnhip_ode_stats));
       sts[r].ny_min = 0x7fffffff;
       if (n == 0) return;
+      if (ctxShards) (void)nnhip::rtc_ctx_shard_enter(rhs_kind, ctxShards, r);  // this thread's calls read shard r of the context block
       rcs[r] = nnhip::solve_host_range(opt, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y0, N, lo, n, dim, layout, tspan, n_t,
                                        nullptr, y_out, ny_out, steps_out, rejected_out, max_steps, &sts[r], r % ndev);
       if (rcs[r]) errs[r] = nnhip::thread_error();  // the message lives in THIS thread's buffer: hand it to the caller
+      if (ctxShards) nnhip::rtc_ctx_shard_leave(rhs_kind);
       nnhip::release_thread_staging();              // pinned staging + event of this (short-lived) thread
     });
   }
   for (auto& t : th) t.join();
+  if (ctxShards && nnhip::rtc_ctx_shards_collect(ctxShards) != 0)  // the mutable slots back where nnhip_ode_rhs_read_aux_f64 and single-device calls read them
+    return nnhip::fail_msg(NNHIP_EHIP, "rhs_kind %d: %s", rhs_kind, nnhip::rtc_last_error());
   for (int r = 0; r < n_gpus; ++r)
     if (rcs[r]) return nnhip::fail_msg(rcs[r], "device %d (IVPs %lld..%lld): %s", r, (long long)(N * r / n_gpus), (long long)(N * (r + 1) / n_gpus), errs[r].c_str());
   if (stats) {
@@ -505,13 +517,27 @@ int nnhip_ode_solve_batch_multi_gpu_sweep_f64(const nnhip_ode_options* opt, int 
 // The collective is enqueued behind the solve — on the solve's own stream, or on gather_streams[r] behind an event, so that the
 // caller's next solve on streams[r] overlaps the gather (as bench.py does).  Returns after enqueueing; the caller synchronises.
 namespace {
-int mg_check(int n_gpus, const int64_t* counts, int* ndev_out) {
+int mg_check(int n_gpus, const int64_t* counts, bool gather, int* ndev_out) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return nnhip::fail_msg(NNHIP_EHIP, "no HIP device available (this library has no CPU fallback)");
-  if (n_gpus <= 0 || n_gpus > 64 || n_gpus > ndev) return nnhip::fail_msg(NNHIP_EVALUE, "n_gpus = %d, but this node has %d HIP device(s)", n_gpus, ndev);
+  // (knob "multi_gpu_oversubscribe": more shards than devices, shard r on device r mod #devices — exercises the sharding on a small box; RCCL itself
+  // wants one device per rank, so the gather is refused then)
+  if (n_gpus <= 0 || n_gpus > 64 || (n_gpus > ndev && !(nnhip::multi_gpu_oversubscribe() && !gather)))
+    return nnhip::fail_msg(NNHIP_EVALUE, "n_gpus = %d, but this node has %d HIP device(s)", n_gpus, ndev);
   if (!counts) return nnhip::fail_msg(NNHIP_EVALUE, "counts is NULL");
   for (int r = 0; r < n_gpus; ++r) if (counts[r] < 0) return nnhip::fail_msg(NNHIP_EVALUE, "counts[%d] < 0", r);
   if (ndev_out) *ndev_out = ndev;
+  return NNHIP_OK;
+}
+// the context block of `rhs_kind` cut along `counts` (shard r on device r mod ndev); *out stays empty when there is nothing to cut
+int mg_ctx_shards(int rhs_kind, int n_gpus, const int64_t* counts, int ndev, std::shared_ptr<void>* out) {
+  if (n_gpus <= 1 || !nnhip::rtc_has_per_ivp_ctx(rhs_kind)) return NNHIP_OK;
+  std::vector<int> devs(n_gpus);
+  std::vector<int64_t> los(n_gpus), ns(n_gpus);
+  int64_t lo = 0;
+  for (int r = 0; r < n_gpus; ++r) { devs[r] = r % ndev; los[r] = lo; ns[r] = counts[r]; lo += counts[r]; }
+  if (nnhip::rtc_ctx_shards_prepare(rhs_kind, n_gpus, devs.data(), los.data(), ns.data(), out) != 0)
+    return nnhip::fail_msg(NNHIP_EUNSUPPORTED, "rhs_kind %d: %s", rhs_kind, nnhip::rtc_last_error());
   return NNHIP_OK;
 }
 // gather on gather_streams[r] (nullable array) behind whatever streams[r] holds now
@@ -544,22 +570,26 @@ int nnhip_ode_fixed_stream_multi_gpu_f64_dev(const nnhip_ode_options* opt, int i
                                              int n_gpus, const int64_t* counts, int dim, int layout, double t0, double tEnd, double* const* y,
                                              double* const* scratch, double* const* full, void* const* streams, void* const* gather_streams,
                                              int64_t* n_steps_out, double** y_final) {
-  int rc = mg_check(n_gpus, counts, nullptr);
+  int ndev = 1;
+  int rc = mg_check(n_gpus, counts, full != nullptr, &ndev);
   if (rc) return rc;
   if (!y || !streams) return nnhip::fail_msg(NNHIP_EVALUE, "y / streams is NULL (one non-default stream per device)");
-  if (n_gpus > 1 && nnhip::rtc_has_per_ivp_ctx(rhs_kind))
-    return nnhip::fail_msg(NNHIP_EUNSUPPORTED, "rhs_kind %d reads a context block bound to ONE device's memory: bind and solve per device", rhs_kind);
+  std::shared_ptr<void> ctxShards;  // a context block travels with the batch: shard r's columns on shard r's device (asynchronous entry: the mutable
+  rc = mg_ctx_shards(rhs_kind, n_gpus, counts, ndev, &ctxShards);  // slots are gathered by their next reader, e.g. nnhip_ode_rhs_read_aux_f64)
+  if (rc) return rc;
   std::vector<int> rcs(n_gpus, NNHIP_OK);
   std::vector<std::string> errs(n_gpus);
   std::vector<int64_t> steps(n_gpus, 0);
   std::vector<double*> fin(n_gpus, nullptr);
   auto work = [&](int r) {
-    if (hipSetDevice(r) != hipSuccess) { rcs[r] = NNHIP_EHIP; errs[r] = "hipSetDevice failed"; return; }
+    if (hipSetDevice(r % ndev) != hipSuccess) { rcs[r] = NNHIP_EHIP; errs[r] = "hipSetDevice failed"; return; }
     fin[r] = y[r];
     if (counts[r] == 0) return;
+    if (ctxShards) (void)nnhip::rtc_ctx_shard_enter(rhs_kind, ctxShards, r);
     rcs[r] = nnhip_ode_fixed_stream_f64_dev(opt, integrator, rhs_kind, rhs_params, n_params, counts[r], dim, layout, t0, tEnd, y[r],
                                             scratch ? scratch[r] : nullptr, &steps[r], &fin[r], streams[r]);
     if (rcs[r]) errs[r] = nnhip::thread_error();
+    if (ctxShards) nnhip::rtc_ctx_shard_leave(rhs_kind);
   };
   int prev = 0;
   (void)hipGetDevice(&prev);
@@ -586,22 +616,26 @@ int nnhip_ode_solve_batch_multi_gpu_f64_dev(const nnhip_ode_options* opt, int in
                                             int n_gpus, const int64_t* counts, int dim, int layout, const double* tspan, int n_t, double* t_out,
                                             const double* const* y0, double* const* y_out, int32_t* const* ny_out, int64_t max_steps,
                                             void* const* ws, int64_t ws_bytes, double* const* full, void* const* streams, void* const* gather_streams) {
-  int rc = mg_check(n_gpus, counts, nullptr);
+  int ndev = 1;
+  int rc = mg_check(n_gpus, counts, full != nullptr, &ndev);
   if (rc) return rc;
   if (!y0 || !y_out || !streams || !ws) return nnhip::fail_msg(NNHIP_EVALUE, "y0 / y_out / ws / streams is NULL");
-  if (n_gpus > 1 && nnhip::rtc_has_per_ivp_ctx(rhs_kind))
-    return nnhip::fail_msg(NNHIP_EUNSUPPORTED, "rhs_kind %d reads a context block bound to ONE device's memory: bind and solve per device", rhs_kind);
+  std::shared_ptr<void> ctxShards;
+  rc = mg_ctx_shards(rhs_kind, n_gpus, counts, ndev, &ctxShards);
+  if (rc) return rc;
   int nTOut = 0;
   rc = nnhip_ode_time_grid(opt, tspan, n_t, t_out, &nTOut);  // (options, tspan) only: once, also when shards are empty
   if (rc) return rc;
   std::vector<int> rcs(n_gpus, NNHIP_OK);
   std::vector<std::string> errs(n_gpus);
   auto work = [&](int r) {
-    if (hipSetDevice(r) != hipSuccess) { rcs[r] = NNHIP_EHIP; errs[r] = "hipSetDevice failed"; return; }
+    if (hipSetDevice(r % ndev) != hipSuccess) { rcs[r] = NNHIP_EHIP; errs[r] = "hipSetDevice failed"; return; }
     if (counts[r] == 0) return;
+    if (ctxShards) (void)nnhip::rtc_ctx_shard_enter(rhs_kind, ctxShards, r);
     rcs[r] = nnhip_ode_solve_batch_f64_dev(opt, integrator, rhs_kind, rhs_params, n_params, y0[r], counts[r], dim, layout, tspan, n_t, nullptr, y_out[r],
                                            ny_out ? ny_out[r] : nullptr, nullptr, nullptr, max_steps, ws[r], ws_bytes, streams[r]);
     if (rcs[r]) errs[r] = nnhip::thread_error();
+    if (ctxShards) nnhip::rtc_ctx_shard_leave(rhs_kind);
     nnhip::release_thread_staging();
   };
   int prev = 0;

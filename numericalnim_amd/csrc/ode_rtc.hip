@@ -159,6 +159,49 @@ struct CodeObject {  // compiled once per (rhs, integrator); hipModuleLoadData b
   int ivpsPerBlockSolve = kBlock, ivpsPerBlockStep = kBlock, ivpsPerBlockAdvance = kBlock;
   std::map<int, std::shared_ptr<Program>> loaded;  // by device ordinal
 };
+// One bind call's result (nnhip_ode_rhs_bind_ctx_f64[_dev]).  Shared by the registry entry (the latest bind of any thread) and by the thread
+// that made it (thread-local: two host threads solving the same source with different contexts each read their own — bind and the calls that
+// follow it on the same thread cannot be torn apart by another thread's bind).  Library-owned device memory lives and dies with it.
+struct CtxShard { int device = -1; int64_t lo = 0, n = 0; void* d[3] = {nullptr, nullptr, nullptr}; };
+struct CtxBinding {
+  const double* shared = nullptr;  // device pointers (the caller's, or `owned`)
+  const double* ivp = nullptr;
+  double* aux = nullptr;
+  int64_t stride = 0;
+  int64_t sharedLen = 0, ivpRows = 0;
+  int nAux = 0;
+  // bound from HOST arrays (nnhip_ode_rhs_bind_ctx_f64): the device copies the library made, and the host copies they were made from — what the
+  // multi-GPU entries cut into column ranges, one per device
+  int ownedDevice = -1;
+  void* owned[3] = {nullptr, nullptr, nullptr};
+  bool haveHost = false;
+  std::vector<double> hShared, hIvp, hAux;
+  std::mutex mu;                 // shards / auxInShards
+  std::vector<CtxShard> shards;  // per-device column ranges [lo, lo + n) of the per-IVP rows and the mutable slots (stride n), the shared block whole
+  bool auxInShards = false;      // the mutable slots were last written by a sharded solve: gathered back before anything else reads them
+  void free_shards() {
+    int prev = 0;
+    const bool have = hipGetDevice(&prev) == hipSuccess;
+    for (CtxShard& sh : shards) {
+      if (sh.device < 0) continue;
+      (void)hipSetDevice(sh.device);
+      (void)hipDeviceSynchronize();  // launches reading the block may still be queued
+      for (void*& q : sh.d) { if (q) (void)hipFree(q); q = nullptr; }
+    }
+    shards.clear();
+    if (have) (void)hipSetDevice(prev);
+  }
+  ~CtxBinding() {
+    free_shards();
+    if (ownedDevice < 0) return;
+    int prev = 0;
+    const bool have = hipGetDevice(&prev) == hipSuccess;
+    (void)hipSetDevice(ownedDevice);
+    (void)hipDeviceSynchronize();
+    for (void*& q : owned) { if (q) (void)hipFree(q); q = nullptr; }
+    if (have) (void)hipSetDevice(prev);
+  }
+};
 struct CtxVec { std::string name; int64_t len = 0; bool perIvp = false; int64_t offset = 0; };  // offset: doubles into the shared block / row of the per-IVP block
 struct UserRhsEntry {
   std::string name, body;
@@ -171,14 +214,8 @@ struct UserRhsEntry {
   std::vector<CtxVec> vecs;
   int n_aux = 0;
   int64_t sharedLen = 0, ivpRows = 0;  // doubles of the shared block (scalars beyond kMaxParams included) / rows of the per-IVP block
-  // what is bound to the layout right now (nnhip_ode_rhs_bind_ctx_f64_dev): device pointers, the caller keeps them alive
-  const double* boundShared = nullptr;
-  const double* boundIvp = nullptr;
-  double* boundAux = nullptr;
-  int64_t boundStride = 0;
-  // device copies the library made itself for a host that has no device-memory management (nnhip_ode_rhs_bind_ctx_f64); freed at the next bind / release
-  int ownedDevice = -1;
-  void* owned[3] = {nullptr, nullptr, nullptr};
+  // what is bound to the layout right now: the most recent bind of any thread (a thread that bound one itself reads its own, see t_bound)
+  std::shared_ptr<CtxBinding> bound;
   std::map<int, CodeObject> programs;  // by integrator; key -1 = the rhs_batch kernel only, key -2 = the cumulative-quadrature kernels,
                                        // 1000 + integrator = the dense-output adaptive streaming kernel
 };
@@ -474,7 +511,6 @@ std::shared_ptr<Program> get_program(int rhs_kind, int integrator) {
 
 }  // namespace
 
-static void free_owned(UserRhsEntry& e);
 
 const char* rtc_last_error() { return g_rtc_err.c_str(); }
 const char* rtc_compiler_origin() {  // which libhiprtc builds the user's right-hand sides, and why not the other
@@ -522,8 +558,7 @@ int rtc_release(int rhs_kind) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (idx < 0 || idx >= (int)g_user.size() || !g_user[idx].alive) return -1;
   g_user[idx].programs.clear();  // drops the registry's references; a module is unloaded when its last launch in flight lets go (~Program)
-  free_owned(g_user[idx]);
-  g_user[idx].boundShared = nullptr; g_user[idx].boundIvp = nullptr; g_user[idx].boundAux = nullptr;
+  g_user[idx].bound.reset();  // (a thread that bound this kind keeps its own reference until it binds again or exits; `alive` below makes it unreachable)
   g_user[idx].alive = false;
   return 0;
 }
@@ -543,65 +578,106 @@ bool rtc_info(int rhs_kind, int* dim, int* n_params) {
   return true;
 }
 
-static void free_owned(UserRhsEntry& e) {  // caller holds g_mu
-  if (e.ownedDevice < 0) return;
-  int prev = 0;
-  const bool have = hipGetDevice(&prev) == hipSuccess;
-  (void)hipSetDevice(e.ownedDevice);
-  (void)hipDeviceSynchronize();  // launches reading the block may still be queued
-  for (void*& q : e.owned) { if (q) (void)hipFree(q); q = nullptr; }
-  if (have) (void)hipSetDevice(prev);
-  e.ownedDevice = -1;
+// ---- context bindings -------------------------------------------------------------------------------------------------------------
+namespace {
+thread_local std::map<int, std::shared_ptr<CtxBinding>> t_bound;  // this thread's own binding per rhs_kind
+struct ShardView { const double* shared; const double* ivp; double* aux; int64_t stride; };
+thread_local std::map<int, ShardView> t_shard;                     // a multi-GPU worker thread's column range (rtc_ctx_shard_enter)
+
+// the binding the calling thread's calls read: its own if it made one, else the latest of any thread.  Caller holds g_mu.
+std::shared_ptr<CtxBinding> binding_of(int idx) {
+  if (idx < 0 || idx >= (int)g_user.size() || !g_user[idx].alive) return nullptr;
+  auto it = t_bound.find(idx + NNHIP_RHS_USER_BASE);
+  if (it != t_bound.end() && it->second) return it->second;
+  return g_user[idx].bound;
 }
+bool check_layout(const UserRhsEntry& e, const void* shared, int64_t shared_len, const void* per_ivp, int64_t per_ivp_rows, const void* aux, int n_aux, int64_t stride) {
+  if (!e.hasCtx) { g_rtc_err = "this right-hand side was compiled without a context layout (nnhip_ode_rhs_compile_ctx)"; return false; }
+  if (shared_len != e.sharedLen || per_ivp_rows != e.ivpRows || n_aux != e.n_aux) {
+    g_rtc_err = "context block does not match the compiled layout: shared " + std::to_string(e.sharedLen) + " doubles, per-IVP " + std::to_string(e.ivpRows) +
+                " rows, " + std::to_string(e.n_aux) + " aux slots";
+    return false;
+  }
+  if ((e.sharedLen > 0 && !shared) || (e.ivpRows > 0 && !per_ivp) || (e.n_aux > 0 && !aux) || ((e.ivpRows > 0 || e.n_aux > 0) && stride < 1)) {
+    g_rtc_err = "context block: a declared part is NULL (or the stride is not positive)";
+    return false;
+  }
+  return true;
+}
+void install(int rhs_kind, const std::shared_ptr<CtxBinding>& b) {  // caller holds g_mu
+  g_user[rhs_kind - NNHIP_RHS_USER_BASE].bound = b;
+  t_bound[rhs_kind] = b;
+}
+// the mutable slots of a binding whose last writer was a sharded solve: device shards -> host copy -> the single-device block
+int collect_aux(CtxBinding& b) {
+  std::lock_guard<std::mutex> lk(b.mu);
+  if (!b.auxInShards) return 0;
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  bool ok = true;
+  if (b.nAux > 0) {
+    for (const CtxShard& sh : b.shards) {
+      if (sh.n == 0 || !sh.d[2]) continue;
+      ok = ok && hipSetDevice(sh.device) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+           hipMemcpy2D(b.hAux.data() + sh.lo, (size_t)b.stride * 8, sh.d[2], (size_t)sh.n * 8, (size_t)sh.n * 8, (size_t)b.nAux, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (ok && b.ownedDevice >= 0 && b.owned[2])
+      ok = hipSetDevice(b.ownedDevice) == hipSuccess && hipMemcpy(b.owned[2], b.hAux.data(), b.hAux.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+  }
+  (void)hipSetDevice(prev);
+  if (!ok) { g_rtc_err = "gathering the mutable slots of a sharded solve failed"; return -1; }
+  b.auxInShards = false;
+  return 0;
+}
+}  // namespace
 
 int rtc_bind_ctx_host(int rhs_kind, const double* shared, int64_t shared_len, const double* per_ivp, int64_t per_ivp_rows, const double* aux_init, int n_aux,
                       int64_t stride, int device) {
   const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (idx < 0 || idx >= (int)g_user.size() || !g_user[idx].alive) { g_rtc_err = "unknown user rhs_kind"; return -1; }
+    if (!check_layout(g_user[idx], shared, shared_len, per_ivp, per_ivp_rows, aux_init, n_aux, stride)) return -1;
+  }
   int prev = 0;
   if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device) != hipSuccess) { g_rtc_err = "bad device ordinal"; return -1; }
-  void* d[3] = {nullptr, nullptr, nullptr};
+  auto b = std::make_shared<CtxBinding>();
   const size_t bytes[3] = {(size_t)shared_len * 8, (size_t)per_ivp_rows * (size_t)stride * 8, (size_t)n_aux * (size_t)stride * 8};
   const void* src[3] = {shared, per_ivp, aux_init};
   bool ok = true;
+  b->ownedDevice = device;
   for (int k = 0; k < 3 && ok; ++k) {
     if (!bytes[k]) continue;
-    ok = src[k] != nullptr && hipMalloc(&d[k], bytes[k]) == hipSuccess && hipMemcpy(d[k], src[k], bytes[k], hipMemcpyHostToDevice) == hipSuccess;
-  }
-  int rc = -1;
-  if (ok) rc = rtc_bind_ctx(rhs_kind, (const double*)d[0], shared_len, (const double*)d[1], per_ivp_rows, (double*)d[2], n_aux, stride);
-  else g_rtc_err = "context block: a declared part is NULL or the device allocation failed";
-  if (rc == 0) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    UserRhsEntry& e = g_user[idx];
-    free_owned(e);
-    (void)hipSetDevice(device);
-    e.ownedDevice = device;
-    for (int k = 0; k < 3; ++k) e.owned[k] = d[k];
-  } else {
-    for (void* q : d) if (q) (void)hipFree(q);
+    ok = src[k] != nullptr && hipMalloc(&b->owned[k], bytes[k]) == hipSuccess && hipMemcpy(b->owned[k], src[k], bytes[k], hipMemcpyHostToDevice) == hipSuccess;
   }
   (void)hipSetDevice(prev);
-  return rc;
+  if (!ok) { g_rtc_err = "context block: a declared part is NULL or the device allocation failed"; return -1; }  // (~CtxBinding frees what was allocated)
+  b->shared = (const double*)b->owned[0]; b->ivp = (const double*)b->owned[1]; b->aux = (double*)b->owned[2]; b->stride = stride;
+  b->sharedLen = shared_len; b->ivpRows = per_ivp_rows; b->nAux = n_aux;
+  b->haveHost = true;
+  if (bytes[0]) b->hShared.assign(shared, shared + shared_len);
+  if (bytes[1]) b->hIvp.assign(per_ivp, per_ivp + (size_t)per_ivp_rows * (size_t)stride);
+  if (bytes[2]) b->hAux.assign(aux_init, aux_init + (size_t)n_aux * (size_t)stride);
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_user[idx].alive) { g_rtc_err = "unknown user rhs_kind"; return -1; }
+  install(rhs_kind, b);
+  return 0;
 }
 
 int rtc_read_aux(int rhs_kind, double* aux_out) {
   const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
-  const double* src = nullptr;
-  size_t bytes = 0;
-  int device = -1;
+  std::shared_ptr<CtxBinding> b;
   {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (idx < 0 || idx >= (int)g_user.size() || !g_user[idx].alive || !g_user[idx].hasCtx || g_user[idx].n_aux == 0 || !g_user[idx].boundAux) {
-      g_rtc_err = "no mutable slots bound to this rhs_kind";
-      return -1;
-    }
-    src = g_user[idx].boundAux; bytes = (size_t)g_user[idx].n_aux * (size_t)g_user[idx].boundStride * 8; device = g_user[idx].ownedDevice;
+    b = binding_of(idx);
+    if (!b || !g_user[idx].hasCtx || g_user[idx].n_aux == 0 || !b->aux) { g_rtc_err = "no mutable slots bound to this rhs_kind"; return -1; }
   }
   if (!aux_out) { g_rtc_err = "aux_out is NULL"; return -1; }
+  if (collect_aux(*b) != 0) return -1;
   int prev = 0;
   (void)hipGetDevice(&prev);
-  if (device >= 0) (void)hipSetDevice(device);
-  const bool ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(aux_out, src, bytes, hipMemcpyDeviceToHost) == hipSuccess;
+  if (b->ownedDevice >= 0) (void)hipSetDevice(b->ownedDevice);
+  const bool ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(aux_out, b->aux, (size_t)b->nAux * (size_t)b->stride * 8, hipMemcpyDeviceToHost) == hipSuccess;
   (void)hipSetDevice(prev);
   if (!ok) { g_rtc_err = "copying the mutable slots back failed"; return -1; }
   return 0;
@@ -611,18 +687,11 @@ int rtc_bind_ctx(int rhs_kind, const double* shared, int64_t shared_len, const d
   const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
   std::lock_guard<std::mutex> lk(g_mu);
   if (idx < 0 || idx >= (int)g_user.size() || !g_user[idx].alive) { g_rtc_err = "unknown user rhs_kind"; return -1; }
-  UserRhsEntry& e = g_user[idx];
-  if (!e.hasCtx) { g_rtc_err = "this right-hand side was compiled without a context layout (nnhip_ode_rhs_compile_ctx)"; return -1; }
-  if (shared_len != e.sharedLen || per_ivp_rows != e.ivpRows || n_aux != e.n_aux) {
-    g_rtc_err = "context block does not match the compiled layout: shared " + std::to_string(e.sharedLen) + " doubles, per-IVP " + std::to_string(e.ivpRows) +
-                " rows, " + std::to_string(e.n_aux) + " aux slots";
-    return -1;
-  }
-  if ((e.sharedLen > 0 && !shared) || (e.ivpRows > 0 && !per_ivp) || (e.n_aux > 0 && !aux) || ((e.ivpRows > 0 || e.n_aux > 0) && stride < 1)) {
-    g_rtc_err = "context block: a declared part is NULL (or the stride is not positive)";
-    return -1;
-  }
-  e.boundShared = shared; e.boundIvp = per_ivp; e.boundAux = aux; e.boundStride = stride;
+  if (!check_layout(g_user[idx], shared, shared_len, per_ivp, per_ivp_rows, aux, n_aux, stride)) return -1;
+  auto b = std::make_shared<CtxBinding>();  // the caller's own device memory: nothing owned, nothing to shard from
+  b->shared = shared; b->ivp = per_ivp; b->aux = aux; b->stride = stride;
+  b->sharedLen = shared_len; b->ivpRows = per_ivp_rows; b->nAux = n_aux;
+  install(rhs_kind, b);  // (a binding the library had uploaded itself is released with its last reference)
   return 0;
 }
 // Declares that the per-component body of `rhs_kind` reads components c - lo .. c + hi (cyclically) only.  Code objects compiled before are dropped.
@@ -638,11 +707,7 @@ int rtc_set_halo(int rhs_kind, int lo, int hi) {
   e.programs.clear();  // shared_ptr-owned modules: launches in flight keep theirs alive
   return 0;
 }
-void rtc_drop_owned_ctx(int rhs_kind) {  // a binding to the caller's own device memory replaces one the library had uploaded itself
-  const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (idx >= 0 && idx < (int)g_user.size()) free_owned(g_user[idx]);
-}
+void rtc_drop_owned_ctx(int) {}  // (owned device copies now live and die with their binding)
 
 // 0: no context layout (P untouched apart from zeroed pointers); 1: filled; -1: declared but not bound / N beyond the bound batch
 int rtc_ctx_fill(int rhs_kind, int64_t N, Params& P, int* n_scalars_in_block) {
@@ -650,15 +715,30 @@ int rtc_ctx_fill(int rhs_kind, int64_t N, Params& P, int* n_scalars_in_block) {
   if (n_scalars_in_block) *n_scalars_in_block = 0;
   const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
   if (idx < 0) return 0;
-  std::lock_guard<std::mutex> lk(g_mu);
-  if (idx >= (int)g_user.size() || !g_user[idx].alive) return 0;
-  const UserRhsEntry& e = g_user[idx];
-  if (!e.hasCtx) return 0;
-  const bool needsBlock = e.sharedLen > 0 || e.ivpRows > 0 || e.n_aux > 0;
-  if (needsBlock && !e.boundShared && !e.boundIvp && !e.boundAux) { g_rtc_err = "the right-hand side declares a context block but none is bound (nnhip_ode_rhs_bind_ctx_f64_dev)"; return -1; }
-  if ((e.ivpRows > 0 || e.n_aux > 0) && N > e.boundStride) { g_rtc_err = "N exceeds the batch the context block was bound for"; return -1; }
-  P.shared = e.boundShared; P.ivp = e.boundIvp; P.aux = e.boundAux; P.stride = e.boundStride;
-  if (n_scalars_in_block) *n_scalars_in_block = e.n_params > kMaxParams ? e.n_params : 0;
+  std::shared_ptr<CtxBinding> b;
+  int64_t ivpRows = 0;
+  int nAux = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (idx >= (int)g_user.size() || !g_user[idx].alive) return 0;
+    const UserRhsEntry& e = g_user[idx];
+    if (!e.hasCtx) return 0;
+    if (n_scalars_in_block) *n_scalars_in_block = e.n_params > kMaxParams ? e.n_params : 0;
+    ivpRows = e.ivpRows; nAux = e.n_aux;
+    auto sv = t_shard.find(rhs_kind);
+    if (sv != t_shard.end()) {  // a worker thread of a multi-GPU entry: its device's column range
+      if ((ivpRows > 0 || nAux > 0) && N > sv->second.stride) { g_rtc_err = "N exceeds the shard the context block was cut for"; return -1; }
+      P.shared = sv->second.shared; P.ivp = sv->second.ivp; P.aux = sv->second.aux; P.stride = sv->second.stride;
+      return 1;
+    }
+    const bool needsBlock = e.sharedLen > 0 || e.ivpRows > 0 || e.n_aux > 0;
+    b = binding_of(idx);
+    if (needsBlock && !b) { g_rtc_err = "the right-hand side declares a context block but none is bound (nnhip_ode_rhs_bind_ctx_f64_dev)"; return -1; }
+    if (!b) return 1;
+  }
+  if (collect_aux(*b) != 0) return -1;  // (outside g_mu: it talks to the devices)
+  if ((ivpRows > 0 || nAux > 0) && N > b->stride) { g_rtc_err = "N exceeds the batch the context block was bound for"; return -1; }
+  P.shared = b->shared; P.ivp = b->ivp; P.aux = b->aux; P.stride = b->stride;
   return 1;
 }
 bool rtc_has_aux(int rhs_kind) {
@@ -670,6 +750,76 @@ bool rtc_has_per_ivp_ctx(int rhs_kind) {
   const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
   std::lock_guard<std::mutex> lk(g_mu);
   return idx >= 0 && idx < (int)g_user.size() && g_user[idx].alive && g_user[idx].hasCtx && (g_user[idx].ivpRows > 0 || g_user[idx].n_aux > 0 || g_user[idx].sharedLen > 0);
+}
+
+// ---- a bound context block across several devices (the multi-GPU entries) -------------------------------------------------------------
+// The calling thread's binding of `rhs_kind`, cut into `n_shards` column ranges [lo[r], lo[r] + n[r]) of the per-IVP rows and the mutable slots,
+// shard r uploaded to devices[r] (the shared block whole).  Only a binding made from HOST arrays can be cut (the library has the values); one made
+// of the caller's device pointers belongs to that device.  -> 0, or -1 with the reason in rtc_last_error().  *handle keeps the binding alive.
+int rtc_ctx_shards_prepare(int rhs_kind, int n_shards, const int* devices, const int64_t* lo, const int64_t* n, std::shared_ptr<void>* handle) {
+  const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
+  std::shared_ptr<CtxBinding> b;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    b = binding_of(idx);
+  }
+  if (!b) { g_rtc_err = "the right-hand side declares a context block but none is bound"; return -1; }
+  if (!b->haveHost) {
+    g_rtc_err = "the context block was bound as device pointers of ONE device (nnhip_ode_rhs_bind_ctx_f64_dev): bind it from host arrays "
+                "(nnhip_ode_rhs_bind_ctx_f64) to have it sharded with the batch, or bind and solve per device";
+    return -1;
+  }
+  if (collect_aux(*b) != 0) return -1;
+  std::lock_guard<std::mutex> lk(b->mu);
+  for (int r = 0; r < n_shards; ++r)
+    if (lo[r] < 0 || n[r] < 0 || ((b->ivpRows > 0 || b->nAux > 0) && lo[r] + n[r] > b->stride)) { g_rtc_err = "the batch is larger than the bound context block"; return -1; }
+  bool same = (int)b->shards.size() == n_shards;
+  for (int r = 0; same && r < n_shards; ++r) same = b->shards[r].device == devices[r] && b->shards[r].lo == lo[r] && b->shards[r].n == n[r];
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  if (!same) {
+    b->free_shards();
+    b->shards.resize(n_shards);
+    for (int r = 0; r < n_shards; ++r) { b->shards[r].device = devices[r]; b->shards[r].lo = lo[r]; b->shards[r].n = n[r]; }
+  }
+  bool ok = true;
+  if (b->nAux > 0 && b->ownedDevice >= 0 && b->owned[2])  // a single-device solve may have written the slots since the bind: the device block is the truth
+    ok = hipSetDevice(b->ownedDevice) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+         hipMemcpy(b->hAux.data(), b->owned[2], b->hAux.size() * 8, hipMemcpyDeviceToHost) == hipSuccess;
+  for (int r = 0; r < n_shards && ok; ++r) {
+    CtxShard& sh = b->shards[r];
+    if (sh.n == 0) continue;
+    ok = hipSetDevice(sh.device) == hipSuccess;
+    const size_t bytes[3] = {(size_t)b->sharedLen * 8, (size_t)b->ivpRows * (size_t)sh.n * 8, (size_t)b->nAux * (size_t)sh.n * 8};
+    for (int k = 0; k < 3 && ok; ++k)
+      if (bytes[k] && !sh.d[k]) ok = hipMalloc(&sh.d[k], bytes[k]) == hipSuccess;
+    // the shared block whole (uploaded once per shard set); the column range of every per-IVP row; the CURRENT mutable slots
+    if (ok && bytes[0] && !same) ok = hipMemcpy(sh.d[0], b->hShared.data(), bytes[0], hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && bytes[1] && !same)
+      ok = hipMemcpy2D(sh.d[1], (size_t)sh.n * 8, b->hIvp.data() + sh.lo, (size_t)b->stride * 8, (size_t)sh.n * 8, (size_t)b->ivpRows, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && bytes[2])  // the CURRENT mutable slots, every time
+      ok = hipMemcpy2D(sh.d[2], (size_t)sh.n * 8, b->hAux.data() + sh.lo, (size_t)b->stride * 8, (size_t)sh.n * 8, (size_t)b->nAux, hipMemcpyHostToDevice) == hipSuccess;
+  }
+  (void)hipSetDevice(prev);
+  if (!ok) { b->free_shards(); g_rtc_err = "uploading a column range of the context block to its device failed"; return -1; }
+  b->auxInShards = b->nAux > 0;
+  if (handle) *handle = b;
+  return 0;
+}
+// on the worker thread of shard r: every call of this thread that takes `rhs_kind` reads the shard, until rtc_ctx_shard_leave
+int rtc_ctx_shard_enter(int rhs_kind, const std::shared_ptr<void>& handle, int r) {
+  CtxBinding* b = static_cast<CtxBinding*>(handle.get());
+  if (!b || r < 0 || r >= (int)b->shards.size()) { g_rtc_err = "no such shard"; return -1; }
+  const CtxShard& sh = b->shards[r];
+  t_shard[rhs_kind] = ShardView{(const double*)sh.d[0], (const double*)sh.d[1], (double*)sh.d[2], sh.n};
+  return 0;
+}
+void rtc_ctx_shard_leave(int rhs_kind) { t_shard.erase(rhs_kind); }
+// after a SYNCHRONOUS sharded solve: the mutable slots back into the host copy and the single-device block (asynchronous entries leave that
+// to the next reader: rtc_read_aux / the next single-device call / the next sharded one)
+int rtc_ctx_shards_collect(const std::shared_ptr<void>& handle) {
+  CtxBinding* b = static_cast<CtxBinding*>(handle.get());
+  return b ? collect_aux(*b) : 0;
 }
 
 static hipError_t launch(hipFunction_t f, int64_t n, int perBlock, void* arg, hipStream_t s) {

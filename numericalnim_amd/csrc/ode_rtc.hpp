@@ -1,5 +1,7 @@
 // ode_rtc.hpp — internal interface of the hiprtc user-RHS module (ode_rtc.hip).
 #pragma once
+#include <memory>
+
 #include "ode_kernels.hpp"
 #include "quad_kernels.hpp"
 
@@ -22,6 +24,11 @@ int rtc_bind_ctx_host(int rhs_kind, const double* shared, int64_t shared_len, co
 int rtc_read_aux(int rhs_kind, double* aux_out);
 void rtc_drop_owned_ctx(int rhs_kind);
 bool rtc_has_per_ivp_ctx(int rhs_kind);
+// a host-bound context block cut into column ranges, one per device (the multi-GPU entries); see ode_rtc.hip
+int rtc_ctx_shards_prepare(int rhs_kind, int n_shards, const int* devices, const int64_t* lo, const int64_t* n, std::shared_ptr<void>* handle);
+int rtc_ctx_shard_enter(int rhs_kind, const std::shared_ptr<void>& handle, int r);
+void rtc_ctx_shard_leave(int rhs_kind);
+int rtc_ctx_shards_collect(const std::shared_ptr<void>& handle);
 int rtc_set_halo(int rhs_kind, int lo, int hi);  // per-component body reads components c - lo .. c + hi only (banded form: DPP instead of the LDS stage vector); 0 / -1
 const char* rtc_compiler_origin();  // the libhiprtc in use (path, version), see rtc_api() in ode_rtc.hip
 bool rtc_has_aux(int rhs_kind);  // the right-hand side mutates per-IVP slots: the number and order of its evaluations are observable

@@ -213,8 +213,8 @@ class Rhs:
         """Binds `ctx` to this right-hand side's context layout (nnhip_ode_rhs_bind_ctx_f64_dev): the closure capturing its ctx.
         Called by solveODE & co. with the ctx they are given; arrays are uploaded — to `device`, the device of the batch being solved —
         and CUDA tensors are used in place (a tensor on another device than the batch is refused).
-        The binding belongs to the compiled right-hand side (process-wide, like the reference's closure object): concurrent solves of the SAME
-        source with DIFFERENT contexts must be serialised by the caller."""
+        The binding belongs to the calling THREAD (the library keeps one per thread and rhs_kind): concurrent solves of the SAME source with
+        DIFFERENT contexts from different host threads each read their own."""
         lay = getattr(self, "ctx_layout", None)
         if lay is None:
             return

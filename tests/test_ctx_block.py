@@ -193,3 +193,146 @@ def test_mutable_ctx_call_sequence_of_methods_without_fsal_with_dense_output(nn,
             t2, y2, ny, launches = nn.adaptiveStreamSolve(f, torch.from_numpy(y0).to(dev), ts, nn.newODEoptions(**kw), ctx=nn.newNumContext(tValues={"aux": aux2}),
                                                           integrator=integrator)
             assert np.array_equal(y2.cpu().numpy(), ref["y"], equal_nan=True) and np.array_equal(aux2.cpu().numpy(), ref["aux"]), (ts, aux2[2, :4].tolist(), ref["aux"][2, :4].tolist())
+
+
+def _host_bind(nn, f, shared, per, aux, stride, device=0):
+    import ctypes as C
+    dp = C.POINTER(C.c_double)
+    L = nn._lib.lib()
+    ptr = lambda a: None if a is None else a.ctypes.data_as(dp)  # noqa: E731
+    rc = L.nnhip_ode_rhs_bind_ctx_f64(f.kind, ptr(shared), 0 if shared is None else shared.size, ptr(per), 0 if per is None else per.shape[0],
+                                      ptr(aux), 0 if aux is None else aux.shape[0], stride, device)
+    assert rc == 0, nn._lib.last_error()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_shards", [2, 3, 8])
+def test_per_ivp_matrices_travel_with_their_shard(nn, oracle, dev, n_shards):
+    """the one-call multi-GPU entry on a batch whose members each carry their own 16 x 16 matrix (a per-IVP ctx.tValues entry,
+    commonTypes.nim:4-6) and share a forcing vector: the context block bound from host arrays is cut into the shards' column ranges — shard r's
+    device gets columns [lo_r, hi_r) — and the result equals the oracle's N closures and the single-device solve, bit for bit.  More shards than
+    devices on a one-GPU box (knob multi_gpu_oversubscribe); one shard per device where there are enough."""
+    import ctypes as C
+    import torch
+    O = oracle
+    L = nn._lib.lib()
+    dp = C.POINTER(C.c_double)
+    n, d = 1003, 16   # ragged shards
+    rng = np.random.default_rng(23)
+    A = (rng.standard_normal((n, d, d)) * 0.35 - 0.6 * np.eye(d)[None])
+    g = rng.standard_normal(d) * 0.2
+    s = 0.75
+    y0 = np.ascontiguousarray(0.5 + rng.random((d, n)))
+    per = np.ascontiguousarray(A.reshape(n, d * d).T)
+    f = _matvec(nn)
+    kw = dict(absTol=1e-7, relTol=1e-7, dtMin=1e-8, dtMax=0.25)
+    ts = np.array([0.0, 0.3, 1.0])
+    ref = O.solve_ode_batch_ctx(O.RHS_MATVEC, [s] + list(g), per, None, y0, n, d, ts, O.new_options(**kw), "tsit54", n_threads=min(32, os.cpu_count() or 1))
+    _host_bind(nn, f, np.ascontiguousarray(g), per, None, n)
+    opt = nn.newODEoptions(**kw)
+    p = np.array([s])
+    out = np.full((len(ts), d, n), -7.0)
+    t_out = np.empty(len(ts))
+    ny = np.empty(n, dtype=np.int32)
+    st = nn.ode.Stats()
+    try:
+        L.nnhip_tune_set(b"multi_gpu_oversubscribe", 1 if n_shards > torch.cuda.device_count() else 0)
+        rc = L.nnhip_ode_solve_batch_multi_gpu_f64(C.byref(opt), nn.ode.integrator_id("tsit54"), f.kind, p.ctypes.data_as(dp), 1, y0.ctypes.data, n, d, 0,
+                                                   ts.ctypes.data_as(dp), len(ts), t_out.ctypes.data_as(dp), out.ctypes.data, ny.ctypes.data, 0, C.byref(st), n_shards)
+        assert rc == 0, nn._lib.last_error()
+    finally:
+        L.nnhip_tune_set(b"multi_gpu_oversubscribe", 0)
+    assert np.array_equal(t_out, ref["t"]) and np.array_equal(out, ref["y"]) and np.array_equal(ny, ref["ny"])
+    assert st.steps_total == int(ref["steps"].sum())
+    # the same binding still serves a single-device call of the calling thread (host-pointer entry, whole batch)
+    out1 = np.full_like(out, -9.0)
+    rc = L.nnhip_ode_solve_batch_f64(C.byref(opt), nn.ode.integrator_id("tsit54"), f.kind, p.ctypes.data_as(dp), 1, y0.ctypes.data, n, d, 0, ts.ctypes.data_as(dp), len(ts),
+                                     t_out.ctypes.data_as(dp), out1.ctypes.data, None, None, None, 0, None, 0)
+    assert rc == 0 and np.array_equal(out1, out)
+    # a block bound as device pointers of one device cannot be cut: refused with the way out
+    ctx = nn.newNumContext(fValues={"s": s}, tValues={"g": g, "A": torch.from_numpy(per).to(dev)})
+    f.bind(ctx, dev)
+    try:
+        L.nnhip_tune_set(b"multi_gpu_oversubscribe", 1)
+        rc = L.nnhip_ode_solve_batch_multi_gpu_f64(C.byref(opt), nn.ode.integrator_id("tsit54"), f.kind, p.ctypes.data_as(dp), 1, y0.ctypes.data, n, d, 0,
+                                                   ts.ctypes.data_as(dp), len(ts), t_out.ctypes.data_as(dp), out.ctypes.data, ny.ctypes.data, 0, C.byref(st), 2)
+        assert rc == nn._lib.NNHIP_EUNSUPPORTED and "host arrays" in nn._lib.last_error()
+    finally:
+        L.nnhip_tune_set(b"multi_gpu_oversubscribe", 0)
+
+
+@pytest.mark.gpu
+def test_mutable_slots_come_back_from_their_shards(nn, oracle, dev):
+    """A closure that mutates its ctx (ode.nim:599), sharded: every shard's device updates its own columns of the mutable slots, and
+    nnhip_ode_rhs_read_aux_f64 returns them in the caller's order — the oracle's closures' final environments."""
+    import ctypes as C
+    O = oracle
+    L = nn._lib.lib()
+    dp = C.POINTER(C.c_double)
+    n = 501
+    f = nn.Rhs.custom(3, ZCROSS_SRC, keys=("sigma", "rho", "beta"), defaults=dict(sigma=10.0, rho=28.0, beta=8.0 / 3.0), n_aux=3, name="zcross_sharded")
+    y0 = np.ascontiguousarray(np.stack([1.0 + np.arange(n) * 1e-3, np.ones(n), np.ones(n) * 20.0]))
+    kw = dict(absTol=1e-6, relTol=1e-6, dtMin=1e-9, dtMax=0.1)
+    ts = np.array([0.0, 3.0])
+    aux0 = np.zeros((3, n))
+    ref = O.solve_ode_batch_ctx(O.RHS_LORENZ_ZCROSS, [10.0, 28.0, 8.0 / 3.0], None, aux0.copy(), y0, n, 3, ts, O.new_options(**kw), "dopri54", n_threads=8)
+    ref_aux = ref["aux"]
+    assert ref_aux[0].max() >= 1.0                        # crossings were counted
+    _host_bind(nn, f, None, None, aux0, n)
+    opt = nn.newODEoptions(**kw)
+    p = np.array([10.0, 28.0, 8.0 / 3.0])
+    out = np.empty((2, 3, n))
+    t_out = np.empty(2)
+    try:
+        L.nnhip_tune_set(b"multi_gpu_oversubscribe", 1)
+        rc = L.nnhip_ode_solve_batch_multi_gpu_f64(C.byref(opt), nn.ode.integrator_id("dopri54"), f.kind, p.ctypes.data_as(dp), 3, y0.ctypes.data, n, 3, 0,
+                                                   ts.ctypes.data_as(dp), 2, t_out.ctypes.data_as(dp), out.ctypes.data, None, 0, None, 3)
+        assert rc == 0, nn._lib.last_error()
+    finally:
+        L.nnhip_tune_set(b"multi_gpu_oversubscribe", 0)
+    got = np.empty((3, n))
+    assert L.nnhip_ode_rhs_read_aux_f64(f.kind, got.ctypes.data_as(dp)) == 0
+    assert np.array_equal(out, ref["y"]) and np.array_equal(got, ref_aux)
+
+
+@pytest.mark.gpu
+def test_two_threads_bind_different_contexts_to_one_source(nn, oracle, dev):
+    """a binding belongs to the thread that made it.  Two host threads solve the SAME compiled source with DIFFERENT
+    contexts at the same time, many times over: each must get its own context's result every time (was: process-wide per rhs_kind — a bind
+    of the other thread between this thread's bind and its launch changed what the launch read)."""
+    import threading
+    import torch
+    O = oracle
+    n, d = 300, 16
+    f = _matvec(nn)
+    kw = dict(absTol=1e-7, relTol=1e-7, dtMin=1e-8, dtMax=0.25)
+    rng = np.random.default_rng(5)
+    y0 = 0.5 + rng.random((d, n))
+    jobs = []
+    for k in range(2):
+        A = (rng.standard_normal((n, d, d)) * 0.35 - 0.6 * np.eye(d)[None])
+        g = rng.standard_normal(d) * 0.2
+        per = np.ascontiguousarray(A.reshape(n, d * d).T)
+        ref = O.solve_ode_batch_ctx(O.RHS_MATVEC, [0.75] + list(g), per, None, y0, n, d, [0.0, 1.0], O.new_options(**kw), "tsit54", n_threads=8)["y"][-1]
+        jobs.append((g, per, ref))
+    bad, errors = [0, 0], []
+
+    def worker(k):
+        try:
+            g, per, ref = jobs[k]
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                ctx = nn.newNumContext(fValues={"s": 0.75}, tValues={"g": g, "A": torch.from_numpy(per).to(dev)})
+                yt = torch.from_numpy(y0).to(dev)
+                for _ in range(40):
+                    t, y = nn.solveODE(f, yt, [0.0, 1.0], nn.newODEoptions(**kw), ctx=ctx, integrator="tsit54")
+                    if not np.array_equal(y[-1].cpu().numpy(), ref):
+                        bad[k] += 1
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errors, errors
+    assert bad == [0, 0], bad
