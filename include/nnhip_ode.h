@@ -306,6 +306,11 @@ int nnhip_ode_solve_batch_calls_f64(const nnhip_ode_options* opt, const nnhip_od
  * Reading the keys' range synchronises `stream` once.  per_ivp_params may be NULL (n_per_ivp = 0).
  * `ws`: device workspace of nnhip_ode_solve_sorted_workspace_bytes(N, n_t) bytes.  N < 2^31. */
 int64_t nnhip_ode_solve_sorted_workspace_bytes(int64_t N, int n_t);
+/* The order of integration the binned solve derives from a key: order_out[k] (device, uint32 [N]) = index of the k-th IVP integrated.  The keys are
+ * counted into 4096 slices of their range — by their order-preserving bit image (logarithmic across binades) when all finite keys have one sign and
+ * none is zero, LINEARLY IN VALUE when the range touches or straddles zero (a finished IVP's "0 steps left", a zero-length span, a centred
+ * parameter) — ascending from slice to slice, unordered inside one, non-finite keys last.  Asynchronous on `stream`. */
+int nnhip_ode_bin_order_f64_dev(const double* sort_key, int64_t N, uint32_t* order_out, void* stream);
 /* host-pointer form (all arrays in host memory, incl. sort_key; staged through `device` in one piece) */
 int nnhip_ode_solve_batch_sorted_f64(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params,
                                      const double* per_ivp_params, int n_per_ivp, const double* y0, int64_t N, int dim, int layout,

@@ -65,6 +65,7 @@ SIGNATURES = {
                                                    _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int]),
     "nnhip_ode_solve_batch_tend_f64_dev": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, _vp, C.c_int, _vp, C.c_int64, C.c_int, C.c_int,
                                                      _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
+    "nnhip_ode_bin_order_f64_dev": (C.c_int, [_vp, C.c_int64, _vp, _vp]),
     "nnhip_ode_solve_sorted_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int]),
     "nnhip_ode_solve_batch_sorted_f64": (C.c_int, [C.POINTER(Options), C.c_int, C.c_int, _dp, C.c_int, _vp, C.c_int, _vp, C.c_int64, C.c_int,
                                                    C.c_int, _dp, C.c_int, _dp, _vp, _vp, _vp, _vp, C.c_int64, _vp, C.c_int, C.c_int]),

@@ -166,6 +166,23 @@ int64_t nnhip_ode_solve_sorted_workspace_bytes(int64_t N, int n_t) {
          nnhip::argsort_workspace_bytes(N) + 256;
 }
 
+// The order of integration the binned solve derives from `sort_key`: order_out[k] = index of the k-th IVP to be integrated (a binning of the keys
+// into 4096 slices of their range, see ode_sort.hip — ascending from slice to slice, unordered inside one; non-finite keys last).  What the
+// sorted entry does internally, exposed so that a caller can look at it (tests: bin occupancy for keys containing 0 / of both signs) or reuse it.
+int nnhip_ode_bin_order_f64_dev(const double* sort_key, int64_t N, uint32_t* order_out, void* stream) {
+  if (N < 0 || N >= ((int64_t)1 << 31)) return fail(NNHIP_EVALUE, "N must be in [0, 2^31)");
+  if (N == 0) return NNHIP_OK;
+  if (!sort_key || !order_out) return fail(NNHIP_EVALUE, "sort_key / order_out is NULL");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t bytes = nnhip::argsort_workspace_bytes(N);
+  void* ws = nullptr;
+  HIP_TRY(hipMallocAsync(&ws, (size_t)bytes, s));
+  bool ok = nnhip::key_range_f64(sort_key, N, ws, nullptr, s) == hipSuccess;
+  ok = ok && nnhip::argsort_f64(sort_key, N, order_out, ws, bytes, s) == hipSuccess;
+  (void)hipFreeAsync(ws, s);
+  return ok ? NNHIP_OK : fail(NNHIP_EHIP, "binning the keys failed");
+}
+
 // solveODE over a batch whose members take very different step sequences (heterogeneous parameters / initial states): the
 // IVPs are integrated in ascending order of `sort_key` — neighbouring lanes of a wavefront then agree on accept / reject and
 // finish together — and every result is written at the IVP's own index (SolveArgs::perm), so the output is in the caller's

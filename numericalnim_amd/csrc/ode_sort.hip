@@ -18,10 +18,15 @@ __global__ void negate_kernel(const double* in, double* out, int64_t n) {
 // sequences, and IVPs whose keys agree to 1 part in 4096 of the key range are as similar as the key can tell.  So the keys are counted into kBins
 // bins and laid out bin after bin (a one-pass counting sort, three small launches, ~20 us at 1e6 keys) — rocPRIM's radix_sort_pairs, which round 3
 // called, picks a 10-pass merge sort for 1e6 32-bit keys (168 us; 61 us with 16-bit keys and its one-sweep passes: profiles/r04_bench_divergence.json).
-// The bin of a key: its order-preserving 64-bit image (monotone; logarithmic across binades, linear inside one) minus the image of the smallest
-// finite key, shifted so that the largest lands in bin kBins-2.  The bins are spent on the range the keys actually cover: a sweep over [100, 101]
-// and a probe whose progress spans six decades both use all of them.  Non-finite keys go last (-inf first).  Inside a bin the order is whatever
-// the atomics produce — it differs from run to run and changes nothing but which wavefront an IVP rides in (the results are per IVP).
+// The bin of a key, when all finite keys have one sign and none is zero: its order-preserving 64-bit image (monotone; logarithmic across binades,
+// linear inside one) minus the image of the smallest finite key, shifted so that the largest lands in bin kBins-2.  The bins are spent on the range
+// the keys actually cover: a sweep over [100, 101] and a probe whose progress spans six decades both use all of them.  The image is logarithmic
+// ALL THE WAY DOWN, though: one key equal to 0 (an IVP that finished inside the probe: steps still to take = 0; a zero-length span) or keys of both
+// signs (a centred parameter) stretch it over ~2000 binades, two bins per binade — a uniform sweep over [0, 10] then puts half its IVPs into four
+// bins and the speed-up is gone without a trace in the results (round-4 advice).  So when the range touches or straddles zero the bins are LINEAR
+// IN VALUE, (key - min) / (max - min): equal slices of the steps still to take / of the span / of the parameter.  Non-finite keys go last (-inf
+// first).  Inside a bin the order is whatever the atomics produce — it differs from run to run and changes nothing but which wavefront an IVP
+// rides in (the results are per IVP).
 constexpr int kBins = 4096, kBinThreads = 1024, kBinItems = 4;
 __device__ unsigned long long ordered_img(double v) {
   const unsigned long long b = (unsigned long long)__double_as_longlong(v);
@@ -33,6 +38,15 @@ __device__ int bin_shift(const unsigned long long* range) {  // smallest shift w
   shift = shift < 0 ? 0 : shift;
   return ((span >> shift) > (unsigned long long)(kBins - 2)) ? shift + 1 : shift;
 }
+__device__ double img_to_double(unsigned long long o) {
+  const unsigned long long b = (o >> 63) ? (o & 0x7fffffffffffffffULL) : ~o;
+  return __longlong_as_double((long long)b);
+}
+// all finite keys of one sign, none of them zero: the images of +0.0 / -0.0 are 0x8000... / 0x7fff...
+__device__ bool bins_by_image(const unsigned long long* range) {
+  const unsigned long long posZero = 0x8000000000000000ULL, negZero = 0x7fffffffffffffffULL;
+  return (range[0] > posZero && range[1] > posZero) || (range[0] < negZero && range[1] < negZero);
+}
 // pass 1: the bin of every key (kept as 16 bits for pass 2) and the global histogram; `hist` arrives zeroed
 __global__ __launch_bounds__(kBinThreads) void bin_count_kernel(const double* __restrict__ keys, const unsigned long long* __restrict__ range, uint16_t* __restrict__ bins,
                                                                  uint32_t* __restrict__ hist, int64_t n) {
@@ -41,6 +55,9 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_kernel(const double* __
   __syncthreads();
   const unsigned long long imgMin = range[0];
   const int shift = bin_shift(range);
+  const bool byImage = bins_by_image(range);
+  const double mnHalf = img_to_double(range[0]) * 0.5, halfSpan = img_to_double(range[1]) * 0.5 - mnHalf;  // (halved: max - min of finite doubles can overflow)
+  const double perUnit = halfSpan > 0.0 ? (double)(kBins - 2) / halfSpan : 0.0;
   const int64_t base = (int64_t)blockIdx.x * (kBinThreads * kBinItems);
   for (int k = 0; k < kBinItems; ++k) {
     const int64_t i = base + k * kBinThreads + threadIdx.x;
@@ -48,9 +65,14 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_kernel(const double* __
       const double v = keys[i];
       uint32_t q = kBins - 1;
       if (v == v && v != __longlong_as_double(0x7ff0000000000000LL)) {
-        const unsigned long long o = ordered_img(v);
-        const unsigned long long d = o > imgMin ? (o - imgMin) >> shift : 0ULL;
-        q = d > (unsigned long long)(kBins - 2) ? kBins - 2 : (uint32_t)d;
+        if (byImage) {
+          const unsigned long long o = ordered_img(v);
+          const unsigned long long d = o > imgMin ? (o - imgMin) >> shift : 0ULL;
+          q = d > (unsigned long long)(kBins - 2) ? kBins - 2 : (uint32_t)d;
+        } else {  // the range touches or straddles zero: linear in value
+          const double r = (v * 0.5 - mnHalf) * perUnit;
+          q = r >= (double)(kBins - 2) ? kBins - 2 : (r > 0.0 ? (uint32_t)r : 0u);  // (a NaN from 0 * inf on a denormal span lands in bin 0)
+        }
       }
       bins[i] = (uint16_t)q;
       atomicAdd(&lh[q], 1u);
@@ -61,10 +83,6 @@ __global__ __launch_bounds__(kBinThreads) void bin_count_kernel(const double* __
 }
 // pass 2: every block scans the histogram into bin starts (4096 counters: cheaper than a launch of its own), reserves its share of each bin with one
 // atomic per bin it holds keys of, and writes the indices of its keys there; `cursor` arrives zeroed
-__device__ double img_to_double(unsigned long long o) {
-  const unsigned long long b = (o >> 63) ? (o & 0x7fffffffffffffffULL) : ~o;
-  return __longlong_as_double((long long)b);
-}
 // `minSpread` > 0: keys within that fraction of their magnitude of each other (or no finite key at all) leave the batch in the caller's order — decided here, on
 // the device, for callers that must not wait for the range (the per-IVP-call entries); the sorted entry decides on the host and passes 0
 __global__ __launch_bounds__(kBinThreads) void bin_place_kernel(const uint16_t* __restrict__ bins, const uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor,

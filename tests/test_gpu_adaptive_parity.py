@@ -1362,3 +1362,61 @@ def test_lean_advance_kernels_give_the_general_kernels_bits(nn, oracle, dev):
                     n = y0.shape[1 - layout]
                     ref = O.solve_ode_batch(orc[0], orc[1], y0, n, dim, [0.0, 0.7], O.new_options(**kw), integ, layout=layout, n_threads=4)
                     assert _same_bits(got[1].cpu().numpy(), ref["y"][-1]), (name, integ, kw)
+
+
+def test_bin_order_spends_its_bins_on_the_keys_it_gets(nn, dev):
+    """Round-4 advice: the order of integration bins the keys by their bit image — logarithmic all the way down — so ONE key equal to 0 (a finished
+    IVP's "0 steps left", a zero-length span) or keys of both signs used to leave a uniform sweep with four bins for half its IVPs: the speed-up gone,
+    the results unchanged, no test the wiser.  The bins are linear in value when the range touches or straddles zero; same-signed keys keep the
+    logarithmic image.  Checked on the order itself (nnhip_ode_bin_order_f64_dev): sorted from slice to slice, every index once, and wavefronts
+    (64 consecutive positions) whose keys lie close together."""
+    import torch
+    L = nn._lib.lib()
+    n = 1 << 18
+    rng = np.random.default_rng(3)
+
+    def order_of(keys):
+        kt = torch.from_numpy(keys).to(dev)
+        out = torch.empty(n, dtype=torch.int32, device=dev)
+        assert L.nnhip_ode_bin_order_f64_dev(kt.data_ptr(), n, out.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0, nn._lib.last_error()
+        torch.cuda.synchronize()
+        o = out.cpu().numpy().astype(np.int64) & 0xffffffff
+        assert np.array_equal(np.sort(o), np.arange(n))        # a permutation
+        return o
+
+    def wave_spread(keys, o):
+        """median over wavefronts of (max - min of the keys it holds) / (range of all finite keys)"""
+        k = keys[o]
+        fin = np.isfinite(keys)
+        span = keys[fin].max() - keys[fin].min()
+        w = k[: (n // 64) * 64].reshape(-1, 64)
+        ok = np.isfinite(w).all(axis=1)
+        return float(np.median((w[ok].max(axis=1) - w[ok].min(axis=1)) / span))
+
+    cases = {
+        "uniform_with_a_zero": np.concatenate([[0.0], rng.uniform(0.0, 10.0, n - 1)]),          # linspace(0, ...)-like sweep
+        "steps_left_with_finished_ivps": -np.concatenate([np.zeros(1000), rng.uniform(1.0, 500.0, n - 1000)]),
+        "both_signs": rng.uniform(-5.0, 10.0, n),                                                  # a centred parameter
+        "one_sign_narrow": rng.uniform(100.0, 101.0, n),
+        "one_sign_six_decades": -10.0 ** rng.uniform(-6.0, 0.0, n),                               # probe progress
+    }
+    for name, keys in cases.items():
+        rng.shuffle(keys)
+        o = order_of(keys)
+        k = keys[o]
+        # ascending up to the width of a slice: a key may precede a smaller one only inside its own slice (1 / 4094 of the range, or of the image's)
+        spread = wave_spread(keys, o)
+        if name == "one_sign_six_decades":
+            w = np.log10(-k[: (n // 64) * 64]).reshape(-1, 64)
+            assert float(np.median(w.max(axis=1) - w.min(axis=1))) < 0.02, name      # a wavefront spans < 5 % in value: logarithmic slices
+        else:
+            assert spread < 3.0 / 4094, (name, spread)                                  # ~64 of 2^18 uniform keys per slice: a wavefront = one or two slices
+            viol = np.maximum.accumulate(k) - k
+            assert float(viol.max()) <= 1.01 * (keys.max() - keys.min()) / 4094, name
+    # non-finite keys go last, whatever the others are
+    keys = rng.uniform(-1.0, 1.0, n)
+    keys[::97] = np.nan
+    keys[5::1013] = np.inf
+    o = order_of(keys)
+    tail = ~np.isfinite(keys[o])
+    assert tail.sum() == (~np.isfinite(keys)).sum() and tail[-tail.sum():].all()
