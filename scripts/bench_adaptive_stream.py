@@ -69,16 +69,20 @@ for name, f, y0, layout, d, n in cases:
         # graph = polling groups replayed from a hipGraph (knob stream_graph 1); fsal_carried = knob adv_recompute_fsal 0
         # K > 1 (knob "adv_steps_per_launch"): K loop iterations per IVP and launch with the state kept in registers in between — ITS OWN
         # traffic model (1/K of the bytes per step), reported beside the one-iteration-per-launch figures, never mixed with them
-        for mode, knob, nt, K, refsal in (("default", 2, -1, 1, -1), ("nt0", 2, 0, 1, -1), ("nt1", 2, 1, 1, -1), ("graph", 1, -1, 1, -1),
-                                         ("fsal_carried", 2, -1, 1, 0), ("graph_fsal_carried", 1, -1, 1, 0), ("K2", 2, -1, 2, -1), ("K5", 2, -1, 5, -1),
-                                         ("K5_fsal_carried", 2, -1, 5, 0)):
+        # round 5: default = the lean kernels (the driver's own layout as the kernel's contract) + the automatic polling schedule (check_every 0);
+        # general_kernel = knob adv_lean 0; poll8 / general_kernel_poll8 = uniform polling groups of 8 (general_kernel_poll8 = round 4's default)
+        for mode, knob, nt, K, refsal, lean, ce in (("default", 2, -1, 1, -1, 1, 0), ("general_kernel", 2, -1, 1, -1, 0, 0), ("poll8", 2, -1, 1, -1, 1, 8),
+                                                    ("general_kernel_poll8", 2, -1, 1, -1, 0, 8), ("nt0", 2, 0, 1, -1, 1, 8), ("nt1", 2, 1, 1, -1, 1, 8),
+                                                    ("graph", 1, -1, 1, -1, 1, 8), ("fsal_carried", 2, -1, 1, 0, 1, 8), ("graph_fsal_carried", 1, -1, 1, 0, 1, 8),
+                                                    ("K2", 2, -1, 2, -1, 1, 8), ("K5", 2, -1, 5, -1, 1, 8), ("K5_fsal_carried", 2, -1, 5, 0, 1, 8)):
             if MODES and mode not in MODES:
                 continue
             L.nnhip_tune_set(b"stream_graph", knob)
             L.nnhip_tune_set(b"adv_nontemporal", nt)
             L.nnhip_tune_set(b"adv_steps_per_launch", K)
             L.nnhip_tune_set(b"adv_recompute_fsal", refsal)
-            dt, launches, ys = run(f, y0, integ, layout, 8)
+            L.nnhip_tune_set(b"adv_lean", lean)
+            dt, launches, ys = run(f, y0, integ, layout, ce)
             per_step = 8 * (4 * d + 4) if refsal == 0 else 8 * (2 * d + 4)
             nb = per_step * accepted / K
             res[f"{name}_{integ}_{mode}"] = dict(stream_ms=dt * 1e3, launches=launches, iterations=iters, us_per_iteration=dt * 1e6 / iters, steps_per_launch=K,
@@ -87,6 +91,7 @@ for name, f, y0, layout, d, n in cases:
                                                  frac_of_8TBps_round2_bytes=8 * (4 * d + 5) * accepted / K / dt / 8e12,
                                                  fused_ms=fused_ms, equal_to_fused=bool(torch.equal(ys, yf[-1])))
         L.nnhip_tune_set(b"adv_recompute_fsal", -1)
+        L.nnhip_tune_set(b"adv_lean", 1)
         L.nnhip_tune_set(b"stream_graph", 2)
         L.nnhip_tune_set(b"adv_nontemporal", -1)
         L.nnhip_tune_set(b"adv_steps_per_launch", 1)

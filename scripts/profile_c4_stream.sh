@@ -14,7 +14,7 @@ G=(
  "TCP_PENDING_STALL_CYCLES TCP_LFIFO_STALL_CYCLES TCP_RFIFO_STALL_CYCLES TCP_READ_TAGCONFLICT_STALL_CYCLES TA_BUSY TA_ADDR_STALLED_BY_TC_CYCLES TA_DATA_STALLED_BY_TC_CYCLES"
  )
 i=0
-for g in "${G[@]}"; do
+for g in "${G[@]:0:${PMC_GROUPS:-5}}"; do
   timeout 300 rocprofv3 --pmc $g --output-format csv -d gpurun_out/prof_${TAG}_$i -o c4 -- python scripts/bench_adaptive_stream.py > gpurun_out/prof_${TAG}_$i.log 2>&1 || tail -3 gpurun_out/prof_${TAG}_$i.log
   i=$((i+1))
 done

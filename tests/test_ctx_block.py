@@ -336,3 +336,80 @@ def test_two_threads_bind_different_contexts_to_one_source(nn, oracle, dev):
     for t in th: t.join()
     assert not errors, errors
     assert bad == [0, 0], bad
+
+
+@pytest.mark.gpu
+def test_device_resident_shards_read_their_columns_of_the_context(nn, oracle, dev):
+    """The two one-call entries whose shards live in device memory (nnhip_ode_solve_batch_multi_gpu_f64_dev, nnhip_ode_fixed_stream_multi_gpu_f64_dev),
+    on a batch with per-IVP matrices: shard r reads columns [lo_r, hi_r) of the host-bound context block.  Three ragged shards (one of them empty)
+    over-subscribing this box's devices, without the RCCL reassembly (RCCL wants one device per rank): every shard equals the oracle's closures."""
+    import ctypes as C
+    import torch
+    O = oracle
+    L = nn._lib.lib()
+    dp = C.POINTER(C.c_double)
+    counts = [257, 0, 300, 64]
+    G, n, d = len(counts), sum(counts), 16
+    ndev = torch.cuda.device_count()
+    rng = np.random.default_rng(29)
+    A = (rng.standard_normal((n, d, d)) * 0.35 - 0.6 * np.eye(d)[None])
+    g = rng.standard_normal(d) * 0.2
+    s = 0.75
+    y0 = np.ascontiguousarray(0.5 + rng.random((d, n)))
+    per = np.ascontiguousarray(A.reshape(n, d * d).T)
+    f = _matvec(nn)
+    _host_bind(nn, f, np.ascontiguousarray(g), per, None, n)
+    kw = dict(absTol=1e-7, relTol=1e-7, dtMin=1e-8, dtMax=0.25)
+    opt = nn.newODEoptions(**kw)
+    p = np.array([s])
+    lo = np.concatenate([[0], np.cumsum(counts)])
+    arr = lambda xs: (C.c_void_p * G)(*xs)  # noqa: E731
+    devs = [torch.device("cuda", r % ndev) for r in range(G)]
+    streams = [torch.cuda.Stream(device=devs[r]) for r in range(G)]
+    try:
+        L.nnhip_tune_set(b"multi_gpu_oversubscribe", 1)
+        # fused adaptive solve, dense tspan
+        ts = np.array([0.0, 0.4, 1.0])
+        ref = O.solve_ode_batch_ctx(O.RHS_MATVEC, [s] + list(g), per, None, y0, n, d, ts, O.new_options(**kw), "dopri54", n_threads=8)
+        y0s = [torch.from_numpy(np.ascontiguousarray(y0[:, lo[r]:lo[r + 1]])).to(devs[r]) for r in range(G)]
+        outs = [torch.full((len(ts), d, counts[r]), -3.0, dtype=torch.float64, device=devs[r]) for r in range(G)]
+        wsb = int(L.nnhip_ode_solve_workspace_bytes(len(ts)))
+        wss = [torch.empty(max(wsb, 8), dtype=torch.uint8, device=devs[r]) for r in range(G)]
+        t_out = np.empty(len(ts))
+        torch.cuda.synchronize()
+        rc = L.nnhip_ode_solve_batch_multi_gpu_f64_dev(C.byref(opt), nn.ode.integrator_id("dopri54"), f.kind, p.ctypes.data_as(dp), 1, G, (C.c_int64 * G)(*counts), d, 0,
+                                                       ts.ctypes.data_as(dp), len(ts), t_out.ctypes.data_as(dp), arr([y.data_ptr() for y in y0s]),
+                                                       arr([o.data_ptr() for o in outs]), None, 0, arr([w.data_ptr() for w in wss]), wsb, None,
+                                                       arr([q.cuda_stream for q in streams]), None)
+        assert rc == 0, nn._lib.last_error()
+        for q in streams: q.synchronize()
+        for r in range(G):
+            assert np.array_equal(outs[r].cpu().numpy(), ref["y"][:, :, lo[r]:lo[r + 1]]), r
+        # with a gather the over-subscription is refused (one device per RCCL rank)
+        fulls = [torch.empty((len(ts), d, n), dtype=torch.float64, device=devs[r]) for r in range(G)]
+        rc = L.nnhip_ode_solve_batch_multi_gpu_f64_dev(C.byref(opt), nn.ode.integrator_id("dopri54"), f.kind, p.ctypes.data_as(dp), 1, G, (C.c_int64 * G)(*counts), d, 0,
+                                                       ts.ctypes.data_as(dp), len(ts), t_out.ctypes.data_as(dp), arr([y.data_ptr() for y in y0s]),
+                                                       arr([o.data_ptr() for o in outs]), None, 0, arr([w.data_ptr() for w in wss]), wsb, arr([x.data_ptr() for x in fulls]),
+                                                       arr([q.cuda_stream for q in streams]), None)
+        if G > ndev:
+            assert rc == nn._lib.NNHIP_EVALUE
+        # the step-streaming loop (fixed step) over the same shards
+        optf = nn.newODEoptions(dt=2.0 ** -7)
+        reff = O.solve_ode_batch_ctx(O.RHS_MATVEC, [s] + list(g), per, None, y0, n, d, [0.0, 0.5], O.new_options(dt=2.0 ** -7), "rk4", n_threads=8)
+        ys = [torch.from_numpy(np.ascontiguousarray(y0[:, lo[r]:lo[r + 1]])).to(devs[r]) for r in range(G)]
+        scr = [torch.empty_like(y) for y in ys]
+        fin = (C.c_void_p * G)()
+        nst = C.c_int64(0)
+        torch.cuda.synchronize()
+        rc = L.nnhip_ode_fixed_stream_multi_gpu_f64_dev(C.byref(optf), nn.ode.integrator_id("rk4"), f.kind, p.ctypes.data_as(dp), 1, G, (C.c_int64 * G)(*counts), d, 0, 0.0, 0.5,
+                                                        arr([y.data_ptr() for y in ys]), arr([x.data_ptr() for x in scr]), None, arr([q.cuda_stream for q in streams]), None,
+                                                        C.byref(nst), fin)
+        assert rc == 0, nn._lib.last_error()
+        for q in streams: q.synchronize()
+        assert nst.value == 64
+        for r in range(G):
+            if counts[r] == 0: continue
+            got = ys[r] if fin[r] == ys[r].data_ptr() else scr[r]
+            assert np.array_equal(got.cpu().numpy(), reff["y"][-1][:, lo[r]:lo[r + 1]]), r
+    finally:
+        L.nnhip_tune_set(b"multi_gpu_oversubscribe", 0)
