@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "adv_poll_schedule.hpp"
 #include "ode_capi_internal.hpp"
 
 using namespace nnhip_capi;
@@ -682,60 +683,26 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
     }
     if (!execs[0] || !execs[1]) execs[0] = execs[1] = nullptr;
   }
-  // How many launches before the host asks "is anyone still integrating?".  A caller's check_every: that many, always.  Automatic (<= 0), eager
-  // launches: every step is at most dtMax long — the first is sqrt(dtMax * dtMin), the controller clamps the others (:538-541, :72-76), :525 only
-  // shortens — so no IVP can reach tEnd in fewer than n0 = ceil((tEnd - t0) / dtMax) iterations: the first group is n0 launches with nothing to
-  // poll in between, then groups of 2 (twice), 4, 8, 8 ... (n0 itself in slices of at most 4096 launches).  A homogeneous batch at loose tolerances needs n0 + 2 iterations (the two short
-  // first steps) and ends after n0 + 4 launches: C3 / C4 took 112 launches for their 102 iterations with uniform groups of 8 (~9 % of the
-  // loop spent confirming it was over), 104 now.
-  const bool uniformGroups = !autoPoll || (execs[0] != nullptr);
-  int64_t n0 = 0;
-  if (!uniformGroups) {
-    const double span = (tEnd - t0) / opt->dtMax * (1.0 - 1e-9);  // (the margin: t accumulates rounding errors of a few ulp per step)
-    n0 = span < 1e15 ? (int64_t)std::ceil(span) : (int64_t)1 << 50;
-    if (a.stepsPerLaunch > 1) n0 = (n0 + a.stepsPerLaunch - 1) / a.stepsPerLaunch;
-  }
-  int64_t issued = 0;
-  int tail = 0;  // polling groups issued beyond the n0 launches nobody can finish in
-  auto group_size = [&]() -> int {
-    if (uniformGroups) return check_every;
-    int64_t n;
-    if (n0 - issued >= 2) n = std::min<int64_t>(n0 - issued, 4096);  // (a bound on what is enqueued unseen: a batch that NaN-aborts retires early)
-    else { n = tail < 2 ? 2 : tail == 2 ? 4 : 8; ++tail; }
-    if (max_launches > 0 && issued + n > max_launches) n = std::max<int64_t>(1, max_launches - issued);
-    return (int)n;
-  };
-  auto issue = [&](int64_t g) -> int {
-    const int half = (int)(g & 1);
-    const int n = group_size();
+  // How many launches before the host asks "is anyone still integrating?": adv_poll_schedule.hpp (a caller's check_every and graph replay: uniform groups;
+  // check_every <= 0 with eager launches: the first ceil((tEnd - t0) / dtMax) launches unpolled, then 2, 2, 4, 8 ...)
+  nnhip::AdvPollSchedule sched = nnhip::AdvPollSchedule::make(!autoPoll || (execs[0] != nullptr), check_every, t0, tEnd, opt->dtMax, a.stepsPerLaunch, max_launches);
+  auto issue = [&](int n, int half) -> int {
     unsigned int* flags = poll.h + half * nnhip::kAggSlots;
     std::memset(flags, 0, nnhip::kAggSlots * sizeof(unsigned int));  // host memory; the group that last wrote this half has been waited for
     if (execs[half]) HIP_TRY(hipGraphLaunch(execs[half]->exec, s));
     else { const int r = adv_issue_group(fn, userKind, integrator, a, flags, n, split, s); if (r) return r; }
     HIP_TRY(hipEventRecord(poll.ev[half], s));
-    issued += n;
     return NNHIP_OK;
   };
-  int64_t launches = 0, g = 0;
-  rc = issue(0);
-  if (rc) return rc;
-  launches = issued;
-  for (;;) {
-    const bool more = !(max_launches > 0 && launches >= max_launches);
-    if (more) {  // keep the device busy while the host waits for group g's answer
-      rc = issue(g + 1);
-      if (rc) return rc;
-      launches = issued;
-    }
-    HIP_TRY(hipEventSynchronize(poll.ev[g & 1]));
+  auto wait = [&](int half) -> int {
+    HIP_TRY(hipEventSynchronize(poll.ev[half]));
     unsigned int any = 0;
-    for (int k = 0; k < nnhip::kAggSlots; ++k) any |= poll.h[(g & 1) * nnhip::kAggSlots + k];
-    if (!any || !more) {
-      if (more) HIP_TRY(hipEventSynchronize(poll.ev[(g + 1) & 1]));  // the speculative group (it found nothing left to do)
-      break;
-    }
-    ++g;
-  }
+    for (int k = 0; k < nnhip::kAggSlots; ++k) any |= poll.h[half * nnhip::kAggSlots + k];
+    return any ? 1 : 0;
+  };
+  int64_t launches = 0;
+  rc = nnhip::adv_poll_loop(sched, issue, wait, &launches);
+  if (rc) return rc;
   if (launches_out) *launches_out = launches;
   return NNHIP_OK;
 }

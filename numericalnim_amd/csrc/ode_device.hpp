@@ -13,7 +13,10 @@
 // glibc_pow.hpp, an operation-for-operation restatement of glibc's table-driven pow (bit-identical to the libm the
 // reference links against), so adaptive solves follow the reference's step sequence exactly.
 #pragma once
-#ifdef __HIPCC_RTC__
+#if defined(NNHIP_CPU_EMU)
+#include "hip_cpu_emu.hpp"  // tests/cpp: the device vocabulary on the host, lanes as threads (test infrastructure only)
+#include "../../include/nnhip_ode.h"
+#elif defined(__HIPCC_RTC__)
 // hiprtc pre-includes its built-in HIP runtime header; an explicit <hip/hip_runtime.h> is not found by a stand-alone
 // (non-PyTorch) process using /opt/rocm's hiprtc
 #include "nnhip_ode.h"  // virtual header handed to hiprtc

@@ -11,9 +11,9 @@
 //                      independent loads in flight per lane (the BASELINE.json headline kernel;
 //                      algorithmic traffic 16 B per trajectory-step)                 -> HBM bound
 #pragma once
-#ifdef __HIPCC_RTC__  // compiled at run time by hiprtc for a user-supplied RHS (ode_rtc.hip): device code only
-#define NNHIP_RTC 1
-#else
+#if defined(__HIPCC_RTC__) || defined(NNHIP_CPU_EMU)  // compiled at run time by hiprtc for a user-supplied RHS (ode_rtc.hip): device code only.
+#define NNHIP_RTC 1                                    // (NNHIP_CPU_EMU: tests/cpp/hip_cpu_emu.hpp — the kernel BODIES compiled for the host by the
+#else                                                  // test suite, lanes as threads; test infrastructure, never part of the library)
 #define NNHIP_RTC 0
 #include <tuple>
 #include <type_traits>
@@ -549,8 +549,15 @@ hipError_t launch_solve_lps(const SolveArgs& a, hipStream_t s) {
 // Kernel-argument prefetch: the argument struct is ~300 bytes and the compiler fetches it piecemeal, one s_load + s_waitcnt round
 // trip per basic block that first touches a field (five serialized scalar round trips before the first vector load of the advance
 // kernel).  Pinning the hot fields in SGPRs at the top of the kernel makes them ONE batch of s_loads behind one wait.
+#ifdef NNHIP_CPU_EMU  // (register classes of the target: nothing to pin on the host)
+#define NNHIP_PIN_SGPR64(x) ((void)(x))
+#define NNHIP_PIN_SGPR32(x) ((void)(x))
+#define NNHIP_KEEP_VGPR(x) ((void)(x))
+#else
 #define NNHIP_PIN_SGPR64(x) asm volatile("" ::"s"(__builtin_bit_cast(unsigned long long, (x))))
 #define NNHIP_PIN_SGPR32(x) asm volatile("" ::"s"(x))
+#define NNHIP_KEEP_VGPR(x) asm volatile("" : "+v"(x))  // the value is "modified" here: whatever produces it (a load) stays above this point
+#endif
 NNHIP_DEV void pin_step_args(const StepArgs& a) {
   NNHIP_PIN_SGPR64(a.N); NNHIP_PIN_SGPR64(a.ivpStride); NNHIP_PIN_SGPR64(a.compStride);
   NNHIP_PIN_SGPR64(a.y_in); NNHIP_PIN_SGPR64(a.fsal_in); NNHIP_PIN_SGPR64(a.y_out); NNHIP_PIN_SGPR64(a.fsal_out);
@@ -781,8 +788,8 @@ NNHIP_DEV void adv_fetch(const StepArgs& a, const Ops& ops, int64_t i, int64_t b
     adv_load_state<NT>(a, ops, base, s.y, s.fsal, withFsal);
     adv_ld_t_dt(a, i, s.t, s.dt);
 #pragma unroll
-    for (int c = 0; c < Ops::D; ++c) asm volatile("" : "+v"(s.y[c]), "+v"(s.fsal[c]));
-    asm volatile("" : "+v"(s.dt), "+v"(s.t));
+    for (int c = 0; c < Ops::D; ++c) { NNHIP_KEEP_VGPR(s.y[c]); NNHIP_KEEP_VGPR(s.fsal[c]); }
+    NNHIP_KEEP_VGPR(s.dt); NNHIP_KEEP_VGPR(s.t);
     s.live = s.t < a.tEnd;  // :511
   } else {
     if (a.dt_io) s.t = a.t_io[i];
@@ -1111,8 +1118,8 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_LEAN_ATTR void advance_lps_lean_k
   // every load of the system in ONE round trip, above the branch on `t` (left alone the compiler sinks the state loads below it: two serialized
   // memory latencies per wave, and the kernel's waves start together and stay in phase).  The general kernel's tile prefetch does the same.
 #pragma unroll
-  for (int j = 0; j < CPL; ++j) asm volatile("" : "+v"(y[j]));
-  asm volatile("" : "+v"(t), "+v"(dt));
+  for (int j = 0; j < CPL; ++j) NNHIP_KEEP_VGPR(y[j]);
+  NNHIP_KEEP_VGPR(t); NNHIP_KEEP_VGPR(dt);
   unsigned int stillActive = 0;
   if (in && t < a.tEnd) {                                                 // :511
     const LpsOps<RHS, false, CPL> ops{a.P, lds + sysInBlock * lps_stride<DIM>(), lds + lps_lds_doubles<DIM, CPL>() / 2 + sysInBlock * lps_stride<DIM>(), c};
@@ -1330,7 +1337,7 @@ NNHIP_DEV unsigned int advance_dense_body(const StepArgs& a, const OPS& ops, int
 #ifndef NNHIP_DENSE_NO_FENCE
   // everything the emission block derives from denseIndex / rowBase (row addresses, the index of the next requested time) is computed
   // AFTER the stages: left to the compiler it is hoisted to the top of the kernel and held in VGPRs across them
-  asm volatile("" : "+v"(denseIndex), "+v"(rowBase));
+  NNHIP_KEEP_VGPR(denseIndex); NNHIP_KEEP_VGPR(rowBase);
 #endif
   if (a.useDense && a.emitAfter && t < a.tEnd) {  // :511-524 of the next iteration
     double treq = sTreq, treqNext = sTreqNext;

@@ -1,0 +1,155 @@
+// hip_cpu_emu.hpp — TEST INFRASTRUCTURE ONLY.  The device vocabulary of numericalnim_amd/csrc/ode_device.hpp / ode_kernels.hpp on the host, so that
+// the kernel BODIES can be executed by the CPU test suite (tests/test_kernel_bodies_on_cpu.py): every lane of a workgroup is a host thread, workgroups run
+// one after the other.  Nothing here is linked into libnnhip_ode.so, nothing in the product includes it (the headers reach it only under
+// -DNNHIP_CPU_EMU, which no product build defines); the library still has no CPU path and fails without a HIP device.
+//
+// Why it exists: a round without GPU access (round 5) still had to show that new kernels compute the reference's bits.  What it shows: the indexing,
+// masking, control flow and arithmetic of a kernel body as written (compiled -ffp-contract=off: one IEEE rounding per operation, like the device build).
+// What it does not: anything about the gfx950 code the real compiler emits (scheduling, register allocation, memory model) — that is the GPU suite's.
+//
+// Cross-lane operations (DPP moves, ds_bpermute, shuffles): each lane publishes its operand in its own slot sequence and reads the source lane's slot of
+// the same sequence number — lanes that exchange data execute the same sequence of cross-lane operations (they belong to one system of the
+// lanes-per-system kernels), lanes that do not never wait for each other, so divergent systems inside a wavefront need no EXEC-mask model.
+// Not modelled: LDS visibility across lanes without a workgroup barrier (wave_lds_sync paths: the non-banded lanes-per-system right-hand sides).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#define __device__
+#define __host__
+#define __global__
+#define __forceinline__ inline
+#define __shared__ static  // function-scope arrays: one per kernel instantiation; workgroups run one after the other
+#define __launch_bounds__(...)
+#define amdgpu_waves_per_eu(...)  // __attribute__((amdgpu_waves_per_eu(f<A, B>()))) -> __attribute__(()): an occupancy hint of the target, and g++ cannot parse its argument
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+};
+struct alignas(16) double2 { double x, y; };
+inline double2 make_double2(double x, double y) { return double2{x, y}; }
+
+namespace hipemu {
+constexpr int kSlots = 1 << 14;  // cross-lane operations one lane may execute per launch
+struct Lane {
+  std::atomic<size_t> count{0};
+  std::unique_ptr<uint64_t[]> slot{new uint64_t[kSlots]};
+};
+struct Block {
+  unsigned nThreads = 0;
+  std::vector<Lane> lanes;
+  std::mutex mu;
+  std::condition_variable cv;
+  unsigned arrived = 0, generation = 0;
+  int orAcc = 0, orResult = 0;
+  explicit Block(unsigned n) : nThreads(n), lanes(n) {}
+  int barrier_or(int v) {  // every thread of the workgroup calls it
+    std::unique_lock<std::mutex> lk(mu);
+    orAcc |= v;
+    const unsigned gen = generation;
+    if (++arrived == nThreads) {
+      orResult = orAcc; orAcc = 0; arrived = 0; ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return generation != gen; });
+    }
+    return orResult;
+  }
+};
+struct Tl {
+  dim3 threadIdx_, blockIdx_, blockDim_, gridDim_;
+  Block* block = nullptr;
+};
+inline thread_local Tl tl;
+
+// publish `v`, return what lane `src` (index inside the workgroup) published at the same sequence number
+inline uint64_t exchange(uint64_t v, unsigned src) {
+  Block& b = *tl.block;
+  Lane& me = b.lanes[tl.threadIdx_.x];
+  const size_t k = me.count.load(std::memory_order_relaxed);
+  if (k >= (size_t)kSlots) { fprintf(stderr, "hip_cpu_emu: too many cross-lane operations in one launch\n"); abort(); }
+  me.slot[k] = v;
+  me.count.store(k + 1, std::memory_order_release);
+  Lane& s = b.lanes[src];
+  while (s.count.load(std::memory_order_acquire) <= k) std::this_thread::yield();
+  return s.slot[k];
+}
+inline unsigned lane_in_block(unsigned laneInWave) { return (tl.threadIdx_.x & ~63u) | (laneInWave & 63u); }
+inline int update_dpp(int /*old*/, int src, int ctrl, int /*row_mask*/, int /*bank_mask*/, bool /*bound_ctrl*/) {
+  const unsigned lane = tl.threadIdx_.x & 63u;
+  unsigned from;
+  if (ctrl >= 0 && ctrl <= 0xFF) from = (lane & ~3u) | ((unsigned)(ctrl >> (2 * (lane & 3u))) & 3u);     // quad_perm
+  else if (ctrl >= 0x121 && ctrl <= 0x12F) from = (lane & ~15u) | ((lane - (unsigned)(ctrl - 0x120)) & 15u);  // row_ror:n — lane i reads lane (i - n) mod 16
+  else { fprintf(stderr, "hip_cpu_emu: DPP control 0x%x is not modelled\n", ctrl); abort(); }
+  return (int)(uint32_t)exchange((uint32_t)src, lane_in_block(from));
+}
+inline int ds_bpermute(int addr, int v) { return (int)(uint32_t)exchange((uint32_t)v, lane_in_block((unsigned)(addr >> 2))); }
+template <class T>
+inline T shfl_from(T v, unsigned laneInWave) {
+  static_assert(sizeof(T) <= 8, "");
+  uint64_t u = 0;
+  memcpy(&u, &v, sizeof(T));
+  u = exchange(u, lane_in_block(laneInWave));
+  T r;
+  memcpy(&r, &u, sizeof(T));
+  return r;
+}
+inline std::mutex& atomics_mu() { static std::mutex m; return m; }
+
+// one launch: workgroups one after the other, every thread of a workgroup a host thread
+template <class Kernel, class... Args>
+void launch(Kernel kernel, dim3 grid, dim3 block, Args... args) {
+  for (unsigned b = 0; b < grid.x; ++b) {
+    Block ctx(block.x);
+    std::vector<std::thread> th;
+    th.reserve(block.x);
+    for (unsigned t = 0; t < block.x; ++t)
+      th.emplace_back([&, t]() {
+        tl.threadIdx_ = dim3(t); tl.blockIdx_ = dim3(b); tl.blockDim_ = block; tl.gridDim_ = grid; tl.block = &ctx;
+        kernel(args...);
+      });
+    for (auto& x : th) x.join();
+  }
+}
+}  // namespace hipemu
+
+#define threadIdx (hipemu::tl.threadIdx_)
+#define blockIdx (hipemu::tl.blockIdx_)
+#define blockDim (hipemu::tl.blockDim_)
+#define gridDim (hipemu::tl.gridDim_)
+
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) hipemu::update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
+#define __builtin_amdgcn_ds_bpermute(addr, v) hipemu::ds_bpermute((addr), (v))
+#define __builtin_amdgcn_readfirstlane(x) (x)  // uniform by construction wherever the kernels use it
+#define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_wave_barrier() ((void)0)
+#define __builtin_amdgcn_logf(x) log2f(x)
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
+#define __builtin_nontemporal_load(p) (*(p))
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
+inline int __all(int p) { return p; }  // (with readfirstlane(x) = x every lane is its own "uniform" wavefront: the per-lane path of the callers)
+inline int __syncthreads_or(int v) { return hipemu::tl.block->barrier_or(v); }
+inline void __syncthreads() { (void)hipemu::tl.block->barrier_or(0); }
+template <class T> inline T __shfl_down(T v, unsigned off, int = 64) { const unsigned l = threadIdx.x & 63u; return hipemu::shfl_from(v, l + off < 64 ? l + off : l); }
+template <class T> inline T __shfl_up(T v, unsigned off, int = 64) { const unsigned l = threadIdx.x & 63u; return hipemu::shfl_from(v, l >= off ? l - off : l); }
+template <class T> inline T __shfl_xor(T v, int mask, int = 64) { return hipemu::shfl_from(v, (threadIdx.x & 63u) ^ (unsigned)mask); }
+inline int __clzll(long long x) { return x == 0 ? 64 : __builtin_clzll((unsigned long long)x); }
+inline int __double2loint(double v) { uint64_t u; memcpy(&u, &v, 8); return (int)(uint32_t)u; }
+inline int __double2hiint(double v) { uint64_t u; memcpy(&u, &v, 8); return (int)(uint32_t)(u >> 32); }
+inline double __hiloint2double(int hi, int lo) { const uint64_t u = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; double v; memcpy(&v, &u, 8); return v; }
+inline double __longlong_as_double(long long x) { double v; memcpy(&v, &x, 8); return v; }
+inline long long __double_as_longlong(double v) { long long x; memcpy(&x, &v, 8); return x; }
+template <class T> inline T atomicAdd(T* p, T v) { std::lock_guard<std::mutex> lk(hipemu::atomics_mu()); const T o = *p; *p = o + v; return o; }
+template <class T> inline T atomicMax(T* p, T v) { std::lock_guard<std::mutex> lk(hipemu::atomics_mu()); const T o = *p; if (v > o) *p = v; return o; }
+template <class T> inline T atomicMin(T* p, T v) { std::lock_guard<std::mutex> lk(hipemu::atomics_mu()); const T o = *p; if (v < o) *p = v; return o; }

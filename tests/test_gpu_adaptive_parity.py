@@ -1410,9 +1410,10 @@ def test_bin_order_spends_its_bins_on_the_keys_it_gets(nn, dev):
             w = np.log10(-k[: (n // 64) * 64]).reshape(-1, 64)
             assert float(np.median(w.max(axis=1) - w.min(axis=1))) < 0.02, name      # a wavefront spans < 5 % in value: logarithmic slices
         else:
-            assert spread < 3.0 / 4094, (name, spread)                                  # ~64 of 2^18 uniform keys per slice: a wavefront = one or two slices
+            wide = 2.0 if name == "one_sign_narrow" else 1.0   # (the logarithmic image is cut by a power-of-two shift: slices up to twice the ideal width)
+            assert spread < wide * 3.0 / 4094, (name, spread)                           # ~64 of 2^18 uniform keys per slice: a wavefront = one or two slices
             viol = np.maximum.accumulate(k) - k
-            assert float(viol.max()) <= 1.01 * (keys.max() - keys.min()) / 4094, name
+            assert float(viol.max()) <= wide * 1.01 * (keys.max() - keys.min()) / 4094, name
     # non-finite keys go last, whatever the others are
     keys = rng.uniform(-1.0, 1.0, n)
     keys[::97] = np.nan
