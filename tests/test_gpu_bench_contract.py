@@ -9,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--steps", "2", "--warmup", "1", "--n-ivp", "200000", "--rk4-steps", "64", "--cpu-sample", "2000"]
+SMALL = ["--steps", "2", "--warmup", "1", "--n-ivp", "200000", "--rk4-steps", "64", "--cpu-sample", "2000", "--cpu-adaptive-sample", "500"]
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
         "config", "roofline"}
 
@@ -39,6 +39,15 @@ def test_single_process_line():
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
     assert out["parity_max_abs_err_vs_oracle"] == 0.0 and out["parity_checked_ivps"] == 2000
     assert out["fused_solve"]["bitwise_equal_to_stream"] is True
+    assert "informational_errors" not in out, out.get("informational_errors")
+    ac = out["adaptive_configs"]
+    for name in ("C3_dopri54_lorenz_1e6", "C4_tsit54_ring16_1e6"):
+        assert ac[name]["streamed_bitwise_equal_to_fused"] is True and ac[name]["streamed_launches"] == ac[name]["loop_iterations"] + 2 == 104
+        cb = ac[name]["cpu_baseline"]
+        assert cb["value"] > 0 and cb["all_cores"]["value"] > 0 and cb["max_abs_dev_gpu_vs_cpu"] <= 1e-6
+    fc = out["fused_solve_fp_contract"]
+    assert set(fc) == {"C2_rk4_neg_y", "C4_tsit54_ring16_1e6"} and all(v["bit_exact_ms"] > 0 and v["contracted_ms"] > 0 for v in fc.values())
+    assert fc["C2_rk4_neg_y"]["within_tolerance"] is True
     # value = trajectory-steps / wall time of the timed region
     assert abs(out["value"] - 200000 * 64 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-9
 
