@@ -369,7 +369,8 @@ int nnhip_ode_fixed_stream_dense_f64_dev(const nnhip_ode_options* opt, int integ
  * (int32 [N], required: rows the reference returns for IVP i; rows beyond are NaN) are device pointers, tspan / t_out host.
  * Every right-hand side kind (thread-per-IVP and lanes-per-system, compiled-in and run-time compiled).  `ws`:
  * nnhip_ode_adaptive_stream_dense_workspace_bytes(N, dim, n_t) bytes.  The host polls one group of `check_every` launches behind the
- * device (launches_out counts the group issued past the end as well).  max_launches > 0 bounds the loop of EACH direction exactly as
+ * device (launches_out counts the group issued past the end as well; check_every <= 0: the library's own schedule per direction, as
+ * nnhip_ode_adaptive_stream_f64_dev's).  max_launches > 0 bounds the loop of EACH direction exactly as
  * max_steps bounds the fused solve's (same rows, same ny_out); the call then returns NNHIP_TRUNCATED (> 0, all outputs written) if an
  * integration was cut short.
  * Bitwise equal to nnhip_ode_solve_batch_f64_dev. */

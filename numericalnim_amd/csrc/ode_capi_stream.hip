@@ -782,6 +782,7 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
   a.rows = y_out; a.rowStride = nState;
   // state of one launch beyond the Infinity Cache: non-temporal instantiation (thread-per-IVP kernels; knob "adv_nontemporal")
   a.nontemporal = g_adv_nt >= 0 ? g_adv_nt : ((dim <= 4 && (int64_t)sizeof(double) * ((fsalInHbm ? 2 : 1) * dim + 2) * N > (192LL << 20)) ? 1 : 0);
+  const bool autoPoll = check_every <= 0;  // the library's own polling schedule (adv_poll_schedule.hpp), per direction
   if (check_every <= 0) check_every = 8;
   const double dtInit = std::sqrt(opt->dtMax * opt->dtMin);  // :491-493
   const dim3 grid((unsigned)((N + nnhip::kBlock - 1) / nnhip::kBlock)), block(nnhip::kBlock);
@@ -856,14 +857,19 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
       }
       if (!execs[0] || !execs[1]) execs[0] = execs[1] = nullptr;
     }
+    // group sizes: a caller's check_every (and graph replay) uniform; check_every <= 0: nobody finishes within the first ceil((tEnd - tStartEff) / dtMax) launches
+    // of this direction, which go out unpolled, then 2, 2, 4, 8 ... (the cut of max_launches stays this loop's own: it must fall exactly where the fused solve's does)
+    nnhip::AdvPollSchedule sched = nnhip::AdvPollSchedule::make(!autoPoll || (execs[0] != nullptr), check_every, tStartEff, tEnd, opt->dtMax, 1, 0);
     auto issue = [&](int64_t grp) -> int {
       const int half = (int)(grp & 1);
       unsigned int* flags = poll.h + half * nnhip::kAggSlots;
       std::memset(flags, 0, nnhip::kAggSlots * sizeof(unsigned int));  // host memory; the group that last wrote this half has been waited for
-      const bool lastPermitted = max_launches > 0 && dirLaunches + check_every >= max_launches;
-      const int n = lastPermitted ? (int)(max_launches - dirLaunches) : check_every;
+      const int want = sched.next();
+      const bool lastPermitted = max_launches > 0 && dirLaunches + want >= max_launches;
+      const int n = lastPermitted ? (int)(max_launches - dirLaunches) : want;
       if (execs[half] && !lastPermitted) HIP_TRY(hipGraphLaunch(execs[half]->exec, s));
       else { const int ra = issue_group(flags, n, lastPermitted); if (ra) return ra; }
+      sched.issued_group(n);
       launches += n;
       dirLaunches += n;
       HIP_TRY(hipEventRecord(poll.ev[half], s));

@@ -763,7 +763,7 @@ def fixedStreamSolve(f, y0, tspan, options=None, ctx=None, integrator="rk4", lay
     return t_out[:ntout.value].copy(), y, ny.value, ns.value
 
 
-def adaptiveStreamSolve(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=LAYOUT_SOA, check_every=8, max_launches=0):
+def adaptiveStreamSolve(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=LAYOUT_SOA, check_every=0, max_launches=0):
     """solveODE (ode.nim:589-651) for an adaptive integrator THROUGH THE IntegratorProc SEAM: the whole ODESolver driver over the
     HBM-resident advance kernel, requested rows interpolated inside the launch that steps past them (nnhip_ode_adaptive_stream_dense_f64_dev).
     Returns (t, y, ny, launches); bitwise equal to solveODE.  max_launches > 0 bounds each direction's loop exactly as solveODE's

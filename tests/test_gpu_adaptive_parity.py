@@ -1325,6 +1325,13 @@ def test_automatic_polling_schedule_wastes_at_most_two_launches_beyond_the_specu
     need = int(cnt["steps"].max())
     assert torch.equal(ys, yf[-1]) and need <= launches <= need + 16, (need, launches)
     assert need > 17  # = ceil(0.5 / 0.03): the unpolled part was really shorter than the loop
+    # the dense driver polls on the same schedule, per direction: 11 requested times on both sides of tStart, rows and launches
+    ts = np.concatenate([np.linspace(-0.3, -0.05, 4), np.linspace(0.0, 1.0, 7)])
+    yl = torch.from_numpy(_lorenz_y0(3000)).to(dev)
+    tf, yf, cf = nn.solveODE(nn.Rhs.lorenz(), yl, ts, integrator="dopri54", return_counts=True)
+    t2, y2, ny2, launches = nn.adaptiveStreamSolve(nn.Rhs.lorenz(), yl, ts, integrator="dopri54")
+    assert np.array_equal(t2, tf) and torch.equal(y2, yf)
+    assert launches <= 102 + 4 + 32 + 4      # forward: 100 unpolled + 2 + 2; backward: ceil(0.3 / 0.01) = 30 unpolled + the two short first steps + 2 + 2 (uniform groups of 8: 112 + 40)
 
 
 def test_lean_advance_kernels_give_the_general_kernels_bits(nn, oracle, dev):
