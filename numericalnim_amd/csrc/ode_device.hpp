@@ -199,10 +199,15 @@ struct TpiOps {
 
 // Orders this wavefront's LDS traffic: DS operations of one wave execute in issue order, so all that is
 // needed between a lane's ds_write and another lane's ds_read is that the compiler keeps program order.
+template <int L = 64>  // L: the lanes that share the LDS region being synchronised (one system) — only the host-side test build needs to know
 NNHIP_DEV void wave_lds_sync() {
+#ifdef NNHIP_CPU_EMU
+  hipemu::group_sync(L);  // tests/cpp/hip_cpu_emu.hpp: lanes are threads there, a rendezvous of the system's lanes stands in for the wavefront's lock-step
+#else
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
 }
 
 // A right-hand side is "banded" when component c only reads components c-halo_lo .. c+halo_hi (cyclically; ring couplings,
@@ -314,13 +319,13 @@ struct LpsOps {
 #endif
 #pragma unroll
     for (int j = 0; j < CPL; ++j) ys[c0 + j] = y[j];
-    wave_lds_sync();
+    wave_lds_sync<DIM / CPL>();
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
       const double v = owns(j) ? RHS::comp(NEG ? -t : t, c0 + j, ys, P) : 0.0;
       dy[j] = NEG ? -v : v;
     }
-    wave_lds_sync();  // the next stage overwrites ys
+    wave_lds_sync<DIM / CPL>();  // the next stage overwrites ys
   }
   NNHIP_DEV double norm(const double (&yNew)[CPL], const double (&err_y)[CPL], const StepCtl& o) const {
     double e2[CPL];
@@ -364,11 +369,11 @@ struct LpsOps {
     } else {
 #pragma unroll
       for (int j = 0; j < CPL; ++j) es[c0 + j] = e2[j];
-      wave_lds_sync();
+      wave_lds_sync<DIM / CPL>();
       double sum = 0.0;
 #pragma unroll
       for (int j = 0; j < SIZE; ++j) sum = sum + es[j];  // same left-to-right order as utils.nim:233-235
-      wave_lds_sync();
+      wave_lds_sync<DIM / CPL>();
       return sqrt(1.0 / (double)SIZE * sum);
     }
   }

@@ -4,7 +4,7 @@
 // work left), compares the two states bit for bit after EVERY launch, and prints the final states as hex floats for the caller to compare with the oracle.
 // Built and run by tests/test_kernel_bodies_on_cpu.py:  g++ -std=c++20 -O1 -ffp-contract=off -DNNHIP_CPU_EMU -I tests/cpp -I numericalnim_amd/csrc ...
 //   emu_advance <case> <N> <method: 1 dopri54 | 2 tsit54> <absTol> <relTol> <dtMin> <dtMax> <tEnd>
-//   case: ring16 (16-component ring, AoS, 4 lanes per system x 4 components per lane) | ring8 (8 components, 4 lanes x 2) | lorenz (thread per IVP, SoA)
+//   case: ring16 (16-component ring, AoS, 4 lanes per system x 4 components per lane) | ring8 (8 components, 4 lanes x 2) | ring32 (8 lanes x 4) | linear16 (dy = a y, stage vector through LDS) | lorenz (thread per IVP, SoA)
 #include "ode_kernels.hpp"
 
 #include <cmath>
@@ -97,14 +97,21 @@ int main(int argc, char** argv) {
   Params P{};
   std::vector<double> y0, y;
   int launches = 0, rc = 64;
-  if (c == "ring16" || c == "ring8") {
-    const int d = c == "ring16" ? 16 : 8;
+  if (c == "ring16" || c == "ring8" || c == "ring32") {
+    const int d = c == "ring16" ? 16 : c == "ring32" ? 32 : 8;
     P.p[0] = 0.1;
     y0.resize((size_t)N * d);
     for (int64_t s = 0; s < N; ++s)
       for (int i = 0; i < d; ++i) y0[s * d + i] = (1.0 + (double)i / d + (double)(s % 1024) * 0x1p-20) * (double)(1 << (3 * (s % 5)));  // (magnitudes 1 ... 4096: under an absolute tolerance the systems take different step sequences)
     if (d == 16) rc = method == 1 ? run_lps<NNHIP_DOPRI54, RhsRing<16>, 4>(N, ctl, P, tEnd, y0, launches, y) : run_lps<NNHIP_TSIT54, RhsRing<16>, 4>(N, ctl, P, tEnd, y0, launches, y);
+    else if (d == 32) rc = method == 1 ? run_lps<NNHIP_DOPRI54, RhsRing<32>, 4>(N, ctl, P, tEnd, y0, launches, y) : run_lps<NNHIP_TSIT54, RhsRing<32>, 4>(N, ctl, P, tEnd, y0, launches, y);  // 8 lanes per system: neighbours by ds_bpermute, the ordered LDS-free chain is for <= 4 lanes
     else rc = method == 1 ? run_lps<NNHIP_DOPRI54, RhsRing<8>, 2>(N, ctl, P, tEnd, y0, launches, y) : run_lps<NNHIP_TSIT54, RhsRing<8>, 2>(N, ctl, P, tEnd, y0, launches, y);
+  } else if (c == "linear16") {  // dy = a y on 16 components: not banded — the stage vector goes through LDS (wave_lds_sync<4>), 4 lanes x 4 components
+    P.p[0] = -0.8;
+    y0.resize((size_t)N * 16);
+    for (int64_t s = 0; s < N; ++s)
+      for (int i = 0; i < 16; ++i) y0[s * 16 + i] = (1.0 + (double)i / 16 + (double)(s % 1024) * 0x1p-20) * (double)(1 << (3 * (s % 5)));
+    rc = method == 1 ? run_lps<NNHIP_DOPRI54, RhsLinear<16>, 4>(N, ctl, P, tEnd, y0, launches, y) : run_lps<NNHIP_TSIT54, RhsLinear<16>, 4>(N, ctl, P, tEnd, y0, launches, y);
   } else if (c == "lorenz") {
     P.p[0] = 10.0; P.p[1] = 28.0; P.p[2] = 8.0 / 3.0;
     y0.resize((size_t)N * 3);

@@ -10,7 +10,8 @@
 // Cross-lane operations (DPP moves, ds_bpermute, shuffles): each lane publishes its operand in its own slot sequence and reads the source lane's slot of
 // the same sequence number — lanes that exchange data execute the same sequence of cross-lane operations (they belong to one system of the
 // lanes-per-system kernels), lanes that do not never wait for each other, so divergent systems inside a wavefront need no EXEC-mask model.
-// Not modelled: LDS visibility across lanes without a workgroup barrier (wave_lds_sync paths: the non-banded lanes-per-system right-hand sides).
+// LDS shared by the lanes of one system (wave_lds_sync<L>: the stage vector of non-banded right-hand sides, the ordered LDS error sum of systems wider than
+// four lanes) is a function-scope static here, and the wavefront's lock-step a rendezvous of those L lanes (group_sync).
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -84,6 +85,18 @@ inline uint64_t exchange(uint64_t v, unsigned src) {
   Lane& s = b.lanes[src];
   while (s.count.load(std::memory_order_acquire) <= k) std::this_thread::yield();
   return s.slot[k];
+}
+// rendezvous of the L consecutive lanes (L a power of two) this lane belongs to: everything they wrote before is visible to all of them afterwards
+inline void group_sync(int L) {
+  Block& b = *tl.block;
+  const unsigned me = tl.threadIdx_.x, first = me & ~(unsigned)(L - 1);
+  Lane& mine = b.lanes[me];
+  const size_t k = mine.count.load(std::memory_order_relaxed);
+  if (k >= (size_t)kSlots) { fprintf(stderr, "hip_cpu_emu: too many cross-lane operations in one launch\n"); abort(); }
+  mine.slot[k] = 0;
+  mine.count.store(k + 1, std::memory_order_release);
+  for (unsigned l = first; l < first + (unsigned)L; ++l)
+    while (b.lanes[l].count.load(std::memory_order_acquire) <= k) std::this_thread::yield();
 }
 inline unsigned lane_in_block(unsigned laneInWave) { return (tl.threadIdx_.x & ~63u) | (laneInWave & 63u); }
 inline int update_dpp(int /*old*/, int src, int ctrl, int /*row_mask*/, int /*bank_mask*/, bool /*bound_ctrl*/) {

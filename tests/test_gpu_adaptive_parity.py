@@ -1330,7 +1330,7 @@ def test_automatic_polling_schedule_wastes_at_most_two_launches_beyond_the_specu
     yl = torch.from_numpy(_lorenz_y0(3000)).to(dev)
     tf, yf, cf = nn.solveODE(nn.Rhs.lorenz(), yl, ts, integrator="dopri54", return_counts=True)
     t2, y2, ny2, launches = nn.adaptiveStreamSolve(nn.Rhs.lorenz(), yl, ts, integrator="dopri54")
-    assert np.array_equal(t2, tf) and torch.equal(y2, yf)
+    assert np.array_equal(t2, tf) and np.array_equal(y2.cpu().numpy(), yf.cpu().numpy(), equal_nan=True)
     assert launches <= 102 + 4 + 32 + 4      # forward: 100 unpolled + 2 + 2; backward: ceil(0.3 / 0.01) = 30 unpolled + the two short first steps + 2 + 2 (uniform groups of 8: 112 + 40)
 
 

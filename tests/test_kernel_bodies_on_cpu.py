@@ -41,15 +41,17 @@ DEFAULT = dict(absTol=1e-4, relTol=1e-4, dtMin=1e-4, dtMax=1e-2)   # newODEoptio
 TIGHT = dict(absTol=1e-9, relTol=1e-13, dtMin=1e-8, dtMax=0.2)       # rejections, in-step shrinks through pow, systems that finish at different launches
 
 
-@pytest.mark.parametrize("case,n,dim", [("ring16", 70, 16), ("ring16", 1, 16), ("ring8", 131, 8)])
+@pytest.mark.parametrize("case,n,dim", [("ring16", 70, 16), ("ring16", 1, 16), ("ring8", 131, 8), ("ring32", 37, 32), ("linear16", 67, 16)])
 @pytest.mark.parametrize("method,name", [(1, "dopri54"), (2, "tsit54")])
 @pytest.mark.parametrize("opts,t_end", [(DEFAULT, 0.25), (TIGHT, 0.7)], ids=["default", "tight"])
 def test_lanes_per_system_lean_kernel_body(emu, oracle, case, n, dim, method, name, opts, t_end):
     """C4's streamed form: 4 lanes of a wavefront per system (16 components: 4 per lane; 8: 2 per lane), ring neighbours by DPP, ordered register-chain
-    norm; batches that do not fill their last workgroup (70 = 64 + 6 systems; 1 system; 131 = 2 x 64 + 3)."""
+    norm; batches that do not fill their last workgroup (70 = 64 + 6 systems; 1 system; 131 = 2 x 64 + 3).  ring32: 8 lanes per system (neighbours by
+    ds_bpermute, the ordered error sum through LDS); linear16: a right-hand side that is not banded (stage vector through LDS)."""
     O = oracle
     launches, y0, y = _run(emu, case, n, method, opts, t_end)
-    ref = O.solve_ode_batch(O.RHS_RING, [0.1], y0.reshape(n, dim), n, dim, [0.0, t_end], O.new_options(**opts), name, layout=O.LAYOUT_AOS)
+    kind, par = (O.RHS_LINEAR, [-0.8]) if case == "linear16" else (O.RHS_RING, [0.1])
+    ref = O.solve_ode_batch(kind, par, y0.reshape(n, dim), n, dim, [0.0, t_end], O.new_options(**opts), name, layout=O.LAYOUT_AOS)
     assert np.array_equal(y.reshape(n, dim), ref["y"][-1]), (case, name)
     assert launches == int(ref["steps"].max())
     if opts is TIGHT and n > 1:
