@@ -167,24 +167,9 @@ int check_common(const nnhip_ode_options* opt, int integrator, int rhs_kind, con
   return NNHIP_OK;
 }
 
-nnhip::StepCtl ctl_of(const nnhip_ode_options* o) { return nnhip::StepCtl{o->absTol, o->relTol, o->dtMax, o->dtMin}; }
 
 
 // ODESolver's bookkeeping before the loops (ode.nim:476-487, 510, 549, 585)
-void make_grid(const nnhip_ode_options* opt, const double* tspan, int n_t, TimeGrid& g) {
-  g.sorted.assign(tspan, tspan + n_t);
-  std::sort(g.sorted.begin(), g.sorted.end());  // tspan.sorted() (ode.nim:609)
-  const double t0 = opt->tStart;
-  for (double x : g.sorted) if (x > t0) g.tPos.push_back(x);  // :479
-  for (double x : g.sorted) if (x < t0) g.tNeg.push_back(x);  // :480
-  std::reverse(g.tNeg.begin(), g.tNeg.end());
-  g.nZero = std::find(g.sorted.begin(), g.sorted.end(), t0) != g.sorted.end() ? 1 : 0;  // `t0 in tspan` (:485)
-  if (!g.tPos.empty()) { g.tEndPos = g.tPos[0]; for (double x : g.tPos) g.tEndPos = nmax_h(g.tEndPos, x); }
-  if (!g.tNeg.empty()) { double mn = g.tNeg[0]; for (double x : g.tNeg) mn = nmin_h(mn, x); g.tEndNeg = -mn; }
-  for (auto it = g.tNeg.rbegin(); it != g.tNeg.rend(); ++it) g.tOut.push_back(*it);  // :585
-  if (g.nZero) g.tOut.push_back(t0);
-  for (double x : g.tPos) g.tOut.push_back(x);
-}
 
 // tuning knobs of the headline streaming kernel (nnhip_tune_set); defaults = the measured best
 nnhip::StreamTune g_tune;
@@ -543,76 +528,24 @@ int prepare_solve(const nnhip_ode_options* opt, int integrator, int rhs_kind, co
   if (!adaptive && !(opt->dt > 0.0)) return fail(NNHIP_EVALUE, "fixed-step integrators need options.dt > 0 (the reference would loop forever)");
   if (adaptive && !(opt->dtMin > 0.0) && max_steps <= 0) return fail(NNHIP_EVALUE, "adaptive integrators need options.dtMin > 0 or max_steps > 0");
 
-  TimeGrid g;
-  make_grid(opt, tspan, n_t, g);
-  if (t_out) std::copy(g.tOut.begin(), g.tOut.end(), t_out);
-  if (n_t_out) *n_t_out = (int)g.tOut.size();
-
   nnhip::SolveArgs& a = ps.a;
   a.y0 = y0; a.y_out = y_out; a.ny_out = ny_out; a.steps_out = steps_out; a.rejected_out = rejected_out; a.agg = agg;
   a.N = N;
   if (layout == NNHIP_LAYOUT_SOA) { a.ivpStride = 1; a.compStride = N; } else { a.ivpStride = dim; a.compStride = 1; }
   a.rowStride = (int64_t)dim * N;
-  a.n_t = n_t;
-  a.nPos = (int)g.tPos.size(); a.nNeg = (int)g.tNeg.size(); a.nZero = g.nZero;
-  a.t0 = opt->tStart; a.tEndPos = g.tEndPos; a.tEndNeg = g.tEndNeg;
-  a.dtInit = adaptive ? std::sqrt(opt->dtMax * opt->dtMin) : opt->dt;  // ode.nim:491-496
-  a.useDense = (n_t != 2) ? 1 : 0;                                      // ode.nim:499-502
-  a.maxSteps = max_steps;
-  a.ctl = ctl_of(opt);
   a.P = P;
   if (n_per_ivp < 0 || n_per_ivp > nnhip::kMaxParams || (n_per_ivp > 0 && !per_ivp_params && N > 0)) return fail(NNHIP_EVALUE, "bad per-IVP parameter table");
   a.perIvpParams = n_per_ivp > 0 ? per_ivp_params : nullptr;
   a.nPerIvp = n_per_ivp;
   a.perIvpStride = N;
-  a.uniformFull[0] = a.uniformFull[1] = -1;
-  a.nTail[0] = a.nTail[1] = 0;
-  a.emitW[0] = a.emitW[1] = nullptr; a.emitStep[0] = a.emitStep[1] = nullptr; a.nEmit[0] = a.nEmit[1] = 0;
+  // everything of the launch record that follows from (options, tspan, integrator) alone — time grid, first step size and, for fixed-step methods, the
+  // host-replayed step and emission schedule: solve_plan.hpp (plain C++; also what the CPU test suite feeds the kernel bodies with)
+  TimeGrid g;
   std::vector<double> emitW[2];
   std::vector<int64_t> emitStep[2];
-  if (!adaptive) {
-    // Replay ODESolver's fixed-step time loop on the host (same IEEE double operations, ode.nim:511-532): it does not depend on the
-    // state, so the device loop needs no `tEnd - t` / compare / select per step — and, with dense output, no `tReq <= t` test, no
-    // per-step lastIter copy and no per-lane Hermite weights either: the step at whose start each requested row is interpolated and the
-    // four weights of utils.nim:273-279 come out of the same replay (DriveIn::emitStep / emitW).
-    const double tS[2] = {opt->tStart, -opt->tStart}, tE[2] = {g.tEndPos, g.tEndNeg};
-    const bool have[2] = {a.nPos > 0, a.nNeg > 0};
-    for (int dir = 0; dir < 2; ++dir) {
-      if (!have[dir]) { a.uniformFull[dir] = 0; continue; }
-      if (!((tE[dir] - tS[dir]) / opt->dt < 5e7)) continue;  // keep the replay itself negligible; generic path otherwise
-      const std::vector<double>& req = dir == 0 ? g.tPos : g.tNeg;
-      const int high = (int)req.size() - 1;
-      double t = tS[dir], dt = opt->dt, lastT = tS[dir];
-      int64_t full = 0, total = 0;
-      int nTail = 0, denseIndex = 0;
-      bool ok = true;
-      while (t < tE[dir]) {  // :511
-        if (max_steps > 0 && total >= max_steps) break;
-        if (a.useDense) {      // :512-524
-          if (high < denseIndex) break;
-          while ((dir == 0 ? req[denseIndex] : -req[denseIndex]) <= t) {
-            if (total == 0) { ok = false; break; }  // (a requested time at or before the start of the first step: cannot happen, tPositive > t0)
-            const nnhip::HermiteW w = nnhip::hermite_weights(dir == 0 ? req[denseIndex] : -req[denseIndex], lastT, t);
-            emitW[dir].insert(emitW[dir].end(), {w.h00, w.h10w, w.h01, w.h11w});
-            emitStep[dir].push_back(total);
-            denseIndex += 1;
-            if (high < denseIndex) break;
-          }
-          if (!ok) break;
-        }
-        const double dtc = nmin_h(dt, tE[dir] - t);  // :525
-        lastT = t;                                   // :526-530
-        if (nTail == 0 && dtc == opt->dt) ++full;
-        else if (nTail < 4) a.tailDt[dir][nTail++] = dtc;
-        else { ok = false; break; }
-        dt = dtc;  // fixed-step steppers hand their input dt back (ode.nim:189): a clipped dt persists
-        t += dtc;  // :532
-        ++total;
-      }
-      if (ok) { a.uniformFull[dir] = full; a.nTail[dir] = nTail; a.nEmit[dir] = (int)emitStep[dir].size(); }
-      else { emitW[dir].clear(); emitStep[dir].clear(); }
-    }
-  }
+  plan_solve(opt, adaptive, tspan, n_t, max_steps, a, g, emitW, emitStep);
+  if (t_out) std::copy(g.tOut.begin(), g.tOut.end(), t_out);
+  if (n_t_out) *n_t_out = (int)g.tOut.size();
   a.tPos = nullptr; a.tNeg = nullptr;
   if (N > 0 && a.useDense && (a.nPos + a.nNeg) > 0) {
     const size_t n = (size_t)a.nPos + (size_t)a.nNeg;

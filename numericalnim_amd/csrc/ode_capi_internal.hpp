@@ -9,6 +9,7 @@
 
 #include "ode_kernels.hpp"
 #include "ode_rtc.hpp"
+#include "solve_plan.hpp"
 
 namespace nnhip_capi {
 
@@ -43,19 +44,10 @@ nnhip::DenseAdvLaunch find_advance_dense(int integrator, int rhs_kind, int dim);
 bool elementwise_rhs(int k);
 int check_common(const nnhip_ode_options* opt, int integrator, int rhs_kind, const double* rhs_params, int n_params, int64_t N, int dim, int layout,
                  nnhip::Params& P);
-nnhip::StepCtl ctl_of(const nnhip_ode_options* o);
 
 // Nim system.min/max (`if x <= y: x else: y`), host copy for the time loop
-inline double nmin_h(double x, double y) { return (x <= y) ? x : y; }
-inline double nmax_h(double x, double y) { return (y <= x) ? x : y; }
 
-struct TimeGrid {
-  std::vector<double> sorted, tPos, tNeg /*descending*/, tOut;
-  int nZero = 0;
-  double tEndPos = 0, tEndNeg = 0;
-};
-// ODESolver's bookkeeping before the loops (ode.nim:476-487, 510, 549, 585)
-void make_grid(const nnhip_ode_options* opt, const double* tspan, int n_t, TimeGrid& g);
+// TimeGrid, make_grid, plan_solve, ctl_of, nmin_h / nmax_h: solve_plan.hpp (plain C++, shared with the CPU test harness)
 
 // pinned staging for the (tiny) requested-time arrays of the device-pointer entries
 struct Staging {

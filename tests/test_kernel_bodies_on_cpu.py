@@ -67,3 +67,82 @@ def test_thread_per_ivp_lean_kernel_body(emu, oracle, method, name, opts, t_end,
     ref = O.solve_ode_batch(O.RHS_LORENZ, [10.0, 28.0, 8.0 / 3.0], y0.reshape(3, n), n, 3, [0.0, t_end], O.new_options(**opts), name)
     assert np.array_equal(y.reshape(3, n), ref["y"][-1]), name
     assert launches == int(ref["steps"].max())
+
+
+def test_step_kernel_body_equals_the_reference_text(nn, tmp_path):
+    """One IntegratorProc call per integrator through the BODY of step_tpi_kernel (what nnhip_ode_step_batch_f64_dev launches), on the host, against the 42
+    single steps the reference's own text produced (tests/golden/reference_text_vectors.json: accepted steps, in-step retries through pow, the dtMin double
+    hit): yNew, the FSAL slot, dtUsed and error, bit for bit — the GPU twin is tests/test_reference_text_pin.py::test_hip_single_step_matches_the_reference_text."""
+    import json
+    if shutil.which("g++") is None:
+        pytest.skip("needs g++")
+    exe = str(tmp_path / "emu_step")
+    subprocess.check_call(["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-DNNHIP_CPU_EMU", "-Wno-attributes", "-I", os.path.join(ROOT, "tests", "cpp"),
+                           "-I", os.path.join(ROOT, "numericalnim_amd", "csrc"), "-pthread", os.path.join(ROOT, "tests", "cpp", "emu_step.cpp"), "-o", exe])
+    steps = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_text_vectors.json")))["steps"]
+    assert len(steps) == 42 and len({s["integrator"] for s in steps}) == 14
+    lines = []
+    for s in steps:
+        o = nn.newODEoptions(**s["options"])    # abs() of everything, as newODEoptions does (ode.nim:101-102): host logic of the library, no device needed
+        lines.append(" ".join([str(nn.ode.integrator_id(s["integrator"])), s["t"], s["dt"]] + [float(v).hex() for v in (o.absTol, o.relTol, o.dtMax, o.dtMin)] + s["y"] + s["fsal"]))
+    r = subprocess.run([exe], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-300:]
+    out = r.stdout.strip().splitlines()
+    assert len(out) == 2 * len(steps)
+    hx = lambda v: float.fromhex(v).hex()  # noqa: E731  (one spelling of a hex float)
+    for k, s in enumerate(steps):
+        for row in (out[2 * k], out[2 * k + 1]):          # the first and the last of the five lanes that ran the same IVP
+            f = row.split()
+            assert [hx(v) for v in f[0:3]] == [hx(v) for v in s["yNew"]], (s["integrator"], s["input"])
+            assert [hx(v) for v in f[3:6]] == [hx(v) for v in s["fsalOut"]], (s["integrator"], s["input"], "FSAL slot")
+            assert hx(f[6]) == hx(s["dtUsed"]) and hx(f[7]) == hx(s["error"]), (s["integrator"], s["input"])
+
+
+@pytest.fixture(scope="module")
+def emu_solve(tmp_path_factory):
+    if shutil.which("g++") is None:
+        pytest.skip("needs g++")
+    exe = str(tmp_path_factory.mktemp("emu_solve") / "emu_solve")
+    subprocess.check_call(["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-DNNHIP_CPU_EMU", "-Wno-attributes", "-I", os.path.join(ROOT, "tests", "cpp"),
+                           "-I", os.path.join(ROOT, "numericalnim_amd", "csrc"), "-pthread", os.path.join(ROOT, "tests", "cpp", "emu_solve.cpp"), "-o", exe])
+    return exe
+
+
+def _golden_cases():
+    from golden_util import load_cases
+    return load_cases()
+
+
+@pytest.mark.parametrize("case", _golden_cases(), ids=lambda c: c["name"])
+def test_fused_solve_kernel_bodies_equal_the_reference_text(nn, emu_solve, case):
+    """All 101 fixtures of tests/golden/ode_golden.json (14 integrators; scalar, 2-, 3-, 4- and 16-component systems — the last on the lanes-per-system
+    kernel; 2-point and dense tspans on both sides of tStart; rejections, dtMin escapes, the dropped-rows quirk) through the BODIES of the fused solve kernels,
+    on the host, with the launch record the library's own planning code builds (solve_plan.hpp): the rows, the row counts and the output times equal what the
+    reference's own text returned (reference_text_vectors.json), bit for bit, in both layouts; accepted / rejected step counts equal the oracle's.  The GPU twin,
+    through the C ABI: tests/test_gpu_golden.py."""
+    import json
+    from golden_util import fh
+    reftext = {c["name"]: c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "reference_text_vectors.json")))["cases"]}[case["name"]]
+    dimv = max(case["dim"], 1)
+    n = len(case["y0"])
+    y0 = np.stack([fh(y) for y in case["y0"]])            # [n, dimv]
+    o = nn.newODEoptions(**case["options"])               # abs() of everything, as newODEoptions does: host logic of the library
+    hexes = lambda xs: " ".join(float(v).hex() for v in xs)  # noqa: E731
+    for layout in ((0,) if case["dim"] == 0 else (0, 1)):
+        flat = (y0.T if layout == 0 else y0).ravel()
+        text = "\n".join([
+            " ".join(str(v) for v in (nn.ode.integrator_id(case["integrator"]), case["rhs_kind"], case["dim"], layout, n, len(case["tspan"]), 0, len(case["params"]))),
+            hexes([o.dt, o.dtMax, o.dtMin, o.tStart, o.absTol, o.relTol, o.scaleMax, o.scaleMin]),
+            hexes(fh(case["params"])), hexes(fh(case["tspan"])), hexes(flat)]) + "\n"
+        r = subprocess.run([emu_solve], input=text, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (case["name"], r.returncode, r.stderr[-300:])
+        lines = r.stdout.strip().splitlines()
+        hx = lambda v: float.fromhex(v).hex()  # noqa: E731
+        tt = lines[0].split()
+        assert [hx(v) for v in tt[2:]] == reftext["t"] and int(tt[1]) == len(reftext["t"])
+        for i, exp in enumerate(case["ivps"]):
+            f = lines[1 + i].split()
+            ny, steps, rej = int(f[1]), int(f[2]), int(f[3])
+            assert ny == exp["n_y"] == reftext["ivps"][i]["n_y"], (case["name"], i)
+            assert [hx(v) for v in f[4:]] == reftext["ivps"][i]["y"], (case["name"], i, layout, "differs from the reference's text")
+            assert (steps, rej) == (exp["steps"], exp["rejected"]), (case["name"], i)
