@@ -150,7 +150,6 @@ int nnhip_host_free(void* p);
  *   probe, bins the batch again by the steps still to take, and finishes: for step sizes that change late in the span; default 0 = the probe's order throughout),
  *   "sort_resume" 0|1 (1: the automatic binned solve continues from its probe's state — forward 2-point tspans, DOPRI54 / Tsit54 / BS32 / RK21 —
  *   instead of integrating the probed steps twice; default 0: within 1 % either way, the resumed pass needs the per-call instantiation of the kernel),
- *   "adv_lean_ipt" 1|2 (IVPs per lane of the thread-per-IVP lean kernel; 2 is an unmeasured A/B candidate: the second IVP's loads under the first one's arithmetic; same bits),
  *   "adv_lean" 0|1 (0: the adaptive streaming loop keeps its general kernels where the lean ones — the driver's own layout as the kernel's contract — apply; same bits),
  *   "fixed_vec_ipl" 0|2 (0 = one IVP per lane instead of the vectorised fixed-step streaming kernel),
  *   "multi_gpu_oversubscribe" 0|1 (nnhip_ode_solve_batch_multi_gpu_f64 accepts more shards than devices: shard r on device r mod #devices),

@@ -73,7 +73,6 @@ int g_sort_resume = 0;     // tuning knob "sort_resume": the automatic binned so
                           // Built, bit-identical, measured and NOT the default (profiles/r04_bench_divergence.json): the resumed pass has to run on the per-call instantiation of
                           // the solve kernel (per-lane tStart / dt), which takes 1.61 ms for 122 steps where the lean one takes 1.46 ms for all 130: 1.70 vs 1.68 ms
 double g_sort_min_spread = 0.05;  // tuning knob "sort_min_spread_permille": the binned solve sorts only when the keys differ by more than this fraction of their magnitude
-int g_adv_lean_ipt = 1;   // tuning knob "adv_lean_ipt": IVPs per lane of the thread-per-IVP lean advance kernel (1; 2 = A/B candidate, see advance_tpi_lean2_kernel)
 int g_adv_lean = 1;       // tuning knob "adv_lean": 0 keeps the general advance kernels where the lean ones would apply (A/B, parity tests)
 int g_adv_split = 0;      // tuning knob "adv_split": index ranges the adaptive streaming loop interleaves on separate streams (0 = auto, 1, 2, 4)
 int g_dim16_variant = 0;  // tuning knob "dim16_variant": A/B mappings of the fused 16-component kernels (see ode_kernels.hpp)
@@ -344,7 +343,6 @@ int nnhip_tune_set(const char* key, int value) {
   if (k == "sort_rebin_steps") { if (value < 0 || value > 1000000) return fail(NNHIP_EVALUE, "sort_rebin_steps must be in 0..1000000"); g_sort_rebin_steps = value; return NNHIP_OK; }
   if (k == "sort_resume") { if (value != 0 && value != 1) return fail(NNHIP_EVALUE, "sort_resume must be 0 or 1"); g_sort_resume = value; return NNHIP_OK; }
   if (k == "sort_min_spread_permille") { if (value < 0 || value > 1000) return fail(NNHIP_EVALUE, "sort_min_spread_permille must be in 0..1000"); g_sort_min_spread = value / 1000.0; return NNHIP_OK; }
-  if (k == "adv_lean_ipt") { if (value != 1 && value != 2) return fail(NNHIP_EVALUE, "adv_lean_ipt must be 1 or 2"); g_adv_lean_ipt = value; release_adv_graphs(); return NNHIP_OK; }
   if (k == "adv_lean") { if (value != 0 && value != 1) return fail(NNHIP_EVALUE, "adv_lean must be 0 or 1"); g_adv_lean = value; release_adv_graphs(); return NNHIP_OK; }
   if (k == "adv_split") { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(NNHIP_EVALUE, "adv_split must be 0, 1, 2 or 4"); g_adv_split = value; return NNHIP_OK; }
   if (k == "dim16_variant") { if (value < 0 || value > 4) return fail(NNHIP_EVALUE, "dim16_variant must be 0..4"); g_dim16_variant = value; return NNHIP_OK; }

@@ -33,7 +33,7 @@ struct MethodInfo {
 extern const MethodInfo kMethods[NNHIP_N_INTEGRATORS];
 
 // tuning knobs (nnhip_tune_set; defined and documented in ode_capi.hip)
-extern int g_stream_graph, g_fixed_vec_ipl, g_adv_nt, g_adv_refsal, g_adv_block, g_adv_steps, g_adv_split, g_adv_lean, g_adv_lean_ipt;
+extern int g_stream_graph, g_fixed_vec_ipl, g_adv_nt, g_adv_refsal, g_adv_block, g_adv_steps, g_adv_split, g_adv_lean;
 extern nnhip::StreamTune g_tune;
 extern bool g_tune_auto;
 

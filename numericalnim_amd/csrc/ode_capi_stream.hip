@@ -646,7 +646,6 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
   a.stepsPerLaunch = g_adv_steps;
   a.recomputeFsal = recomputeFsal;
   a.noLean = g_adv_lean ? 0 : 1;
-  a.leanIpt = g_adv_lean_ipt;
   // thread-per-IVP kernels (the lanes-per-system ones are not memory-bound enough to gain: measured -3 %); the state of one launch = y, (t, dt) and FSAL if carried
   a.nontemporal = g_adv_nt >= 0 ? g_adv_nt : ((dim <= 4 && (int64_t)sizeof(double) * ((fsalInHbm ? 2 : 1) * dim + 2) * N > (192LL << 20)) ? 1 : 0);
   const bool autoPoll = check_every <= 0;  // the polling schedule is the library's (below); a caller's check_every is taken as given

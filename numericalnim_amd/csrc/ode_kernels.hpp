@@ -124,7 +124,6 @@ struct StepArgs {
   int nontemporal;  // advance mode: non-temporal hint on the streamed state arrays (working set beyond the Infinity Cache)
   int recomputeFsal;  // advance mode, DOPRI54 / Tsit54: FSAL is not carried through HBM but re-evaluated as f(t, y) at the start of the launch
                       // (see adv_fsal_in_hbm): 16*d bytes per step less for one more evaluation of f — the same bits
-  int leanIpt;        // advance mode, thread-per-IVP lean kernel: 2 = two IVPs per lane (A/B candidate, knob "adv_lean_ipt"); anything else = one
   int noLean;         // advance mode: 1 keeps the general kernels where the lean ones (advance_*_lean_kernel: the streaming driver's own layout as the
                       // kernel's contract) would apply — A/B and parity tests, tuning knob "adv_lean"
   // advance mode WITH dense output (adaptive streaming through the IntegratorProc seam, ode.nim:512-530): tReq == nullptr -> none.
@@ -554,9 +553,7 @@ hipError_t launch_solve_lps(const SolveArgs& a, hipStream_t s) {
 #define NNHIP_PIN_SGPR64(x) ((void)(x))
 #define NNHIP_PIN_SGPR32(x) ((void)(x))
 #define NNHIP_KEEP_VGPR(x) ((void)(x))
-#define NNHIP_LOADS_STAY_ABOVE() ((void)0)
 #else
-#define NNHIP_LOADS_STAY_ABOVE() asm volatile("" ::: "memory")  // memory operations are not moved across it; nothing waits here
 #define NNHIP_PIN_SGPR64(x) asm volatile("" ::"s"(__builtin_bit_cast(unsigned long long, (x))))
 #define NNHIP_PIN_SGPR32(x) asm volatile("" ::"s"(x))
 #define NNHIP_KEEP_VGPR(x) asm volatile("" : "+v"(x))  // the value is "modified" here: whatever produces it (a load) stays above this point
@@ -1166,58 +1163,6 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_TPI_ATTR void advance_tpi_lean_ke
     if (__syncthreads_or((int)stillActive) && tid == 0) a.active[blockIdx.x % kAggSlots] = 1u;
   }
 }
-// A/B candidate, off by default (knob "adv_lean_ipt" = 2): TWO IVPs per lane, the second one's state loads in flight under the first one's arithmetic.
-// Why: streamed C3 is neither VALU- nor bandwidth-bound but phase-locked: a SIMD's resident waves load together, compute together and
-// store together, so every round exposes its memory latency once.  Here a lane issues every load of both its IVPs at once and starts on the first as soon
-// as ITS state is there: the second IVP's latency runs under ~410 VALU instructions, and there is one exposed round trip per two IVPs instead of two per
-// IVP.  A finished IVP's state is read for nothing (never written).  Price: the second state in registers (3 waves per SIMD instead of 4 for 3-component systems).  Same inlined arithmetic per
-// IVP, hence the same bits (its body is executed by the CPU test suite next to the general kernel: tests/test_kernel_bodies_on_cpu.py); NOT measured yet.
-template <int METHOD, class RHS>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3))) void advance_tpi_lean2_kernel(const AdvLeanArgs a) {
-  constexpr int D = RHS::dim, IPT = 2;
-  controller_prologue();
-  pin_lean_args(a);
-  const unsigned int tid = threadIdx.x;
-  const int64_t i0 = (int64_t)blockIdx.x * ((int64_t)blockDim.x * IPT);    // uniform
-  const int64_t left = a.N - i0;
-  double* const yb = a.y + i0;
-  double2* const tb = a.td + i0;
-  unsigned int o[IPT];
-  bool live[IPT];
-  double t[IPT], dt[IPT], y[IPT][D];
-#pragma unroll
-  for (int j = 0; j < IPT; ++j) {                                          // IVP j of this lane: i0 + j * blockDim.x + tid (a wave reads 64 neighbours)
-    const unsigned int idx = tid + (unsigned int)j * blockDim.x;
-    live[j] = (int64_t)idx < left;
-    o[j] = live[j] ? idx : 0u;
-    const double2 td = tb[o[j]];
-    t[j] = td.x; dt[j] = td.y;
-  }
-  // every load of both IVPs in ONE round trip, unconditionally (a finished IVP's state is read for nothing, never written): loads behind a branch on `t`
-  // would each wait for everything issued before them (the wait counters are merged over the paths that reach the branch)
-#pragma unroll
-  for (int j = 0; j < IPT; ++j)
-#pragma unroll
-    for (int c = 0; c < D; ++c) y[j][c] = (yb + (int64_t)c * a.N)[o[j]];
-  NNHIP_LOADS_STAY_ABOVE();                                                // ... and none of them is sunk into the block that uses it
-#pragma unroll
-  for (int j = 0; j < IPT; ++j) live[j] = live[j] && t[j] < a.tEnd;       // :511
-  unsigned int stillActive = 0;
-  const TpiOps<RHS, false> ops{a.P};
-#pragma unroll
-  for (int j = 0; j < IPT; ++j) {
-    if (live[j]) {
-      double yNew[D];
-      stillActive |= adv_lean_iteration<METHOD>(ops, a.ctl, a.tEnd, t[j], dt[j], y[j], yNew) ? 1u : 0u;
-#pragma unroll
-      for (int c = 0; c < D; ++c) (yb + (int64_t)c * a.N)[o[j]] = yNew[c];
-      tb[o[j]] = make_double2(t[j], dt[j]);
-    }
-  }
-  if (a.active) {
-    if (__syncthreads_or((int)stillActive) && tid == 0) a.active[blockIdx.x % kAggSlots] = 1u;
-  }
-}
 #if !NNHIP_RTC
 // Does this launch have the layout the lean kernels are written for?  (Everything the streaming driver's default set-up produces.)
 #ifndef NNHIP_ADV_LEAN
@@ -1586,10 +1531,7 @@ hipError_t launch_advance_tpi(const StepArgs& a, int block, hipStream_t s) {
     const int64_t grid = (a.N + bs - 1) / bs;
     if (grid <= 0) return hipSuccess;
     if constexpr (METHOD == NNHIP_DOPRI54 || METHOD == NNHIP_TSIT54) {
-      if (adv_lean_applies<METHOD>(a, RHS::dim, false)) {
-        if (a.leanIpt == 2) return launch_kernel(advance_tpi_lean2_kernel<METHOD, RHS>, dim3((unsigned)((a.N + 2 * bs - 1) / (2 * bs))), dim3(bs), s, adv_lean_args(a));
-        return launch_kernel(advance_tpi_lean_kernel<METHOD, RHS>, dim3((unsigned)grid), dim3(bs), s, adv_lean_args(a));
-      }
+      if (adv_lean_applies<METHOD>(a, RHS::dim, false)) return launch_kernel(advance_tpi_lean_kernel<METHOD, RHS>, dim3((unsigned)grid), dim3(bs), s, adv_lean_args(a));
     }
     if (a.stepsPerLaunch > 1) return launch_kernel(advance_tpi_kernel<METHOD, RHS, false, true>, dim3((unsigned)grid), dim3(bs), s, a);
     if (a.nontemporal) return launch_kernel(advance_tpi_kernel<METHOD, RHS, true>, dim3((unsigned)grid), dim3(bs), s, a);

@@ -71,8 +71,7 @@ for name, f, y0, layout, d, n in cases:
         # traffic model (1/K of the bytes per step), reported beside the one-iteration-per-launch figures, never mixed with them
         # round 5: default = the lean kernels (the driver's own layout as the kernel's contract) + the automatic polling schedule (check_every 0);
         # general_kernel = knob adv_lean 0; poll8 / general_kernel_poll8 = uniform polling groups of 8 (general_kernel_poll8 = round 4's default)
-        # lean_ipt2: the thread-per-IVP lean kernel with two IVPs per lane (knob adv_lean_ipt 2, lean = 2 below): an unmeasured candidate
-        for mode, knob, nt, K, refsal, lean, ce in (("default", 2, -1, 1, -1, 1, 0), ("general_kernel", 2, -1, 1, -1, 0, 0), ("lean_ipt2", 2, -1, 1, -1, 2, 0), ("poll8", 2, -1, 1, -1, 1, 8),
+        for mode, knob, nt, K, refsal, lean, ce in (("default", 2, -1, 1, -1, 1, 0), ("general_kernel", 2, -1, 1, -1, 0, 0), ("poll8", 2, -1, 1, -1, 1, 8),
                                                     ("general_kernel_poll8", 2, -1, 1, -1, 0, 8), ("nt0", 2, 0, 1, -1, 1, 8), ("nt1", 2, 1, 1, -1, 1, 8),
                                                     ("graph", 1, -1, 1, -1, 1, 8), ("fsal_carried", 2, -1, 1, 0, 1, 8), ("graph_fsal_carried", 1, -1, 1, 0, 1, 8),
                                                     ("K2", 2, -1, 2, -1, 1, 8), ("K5", 2, -1, 5, -1, 1, 8), ("K5_fsal_carried", 2, -1, 5, 0, 1, 8)):
@@ -82,8 +81,7 @@ for name, f, y0, layout, d, n in cases:
             L.nnhip_tune_set(b"adv_nontemporal", nt)
             L.nnhip_tune_set(b"adv_steps_per_launch", K)
             L.nnhip_tune_set(b"adv_recompute_fsal", refsal)
-            L.nnhip_tune_set(b"adv_lean", 1 if lean else 0)
-            L.nnhip_tune_set(b"adv_lean_ipt", 2 if lean == 2 else 1)
+            L.nnhip_tune_set(b"adv_lean", lean)
             dt, launches, ys = run(f, y0, integ, layout, ce)
             per_step = 8 * (4 * d + 4) if refsal == 0 else 8 * (2 * d + 4)
             nb = per_step * accepted / K
@@ -94,7 +92,6 @@ for name, f, y0, layout, d, n in cases:
                                                  fused_ms=fused_ms, equal_to_fused=bool(torch.equal(ys, yf[-1])))
         L.nnhip_tune_set(b"adv_recompute_fsal", -1)
         L.nnhip_tune_set(b"adv_lean", 1)
-        L.nnhip_tune_set(b"adv_lean_ipt", 1)
         L.nnhip_tune_set(b"stream_graph", 2)
         L.nnhip_tune_set(b"adv_nontemporal", -1)
         L.nnhip_tune_set(b"adv_steps_per_launch", 1)

@@ -20,7 +20,7 @@ if [ "$STAGE" = bench ] || [ "$STAGE" = all ]; then
   tail -1 gpurun_out/r05_bench_default.json | cut -c1-900
 fi
 if [ "$STAGE" = adaptive ] || [ "$STAGE" = all ]; then
-  ADV_BENCH_MODES=default,general_kernel,lean_ipt2,poll8,general_kernel_poll8 timeout 900 python scripts/bench_adaptive_stream.py > gpurun_out/r05_bench_adaptive_stream.json 2> gpurun_out/bench_adaptive_stream.err
+  ADV_BENCH_MODES=default,general_kernel,poll8,general_kernel_poll8 timeout 900 python scripts/bench_adaptive_stream.py > gpurun_out/r05_bench_adaptive_stream.json 2> gpurun_out/bench_adaptive_stream.err
   # the same command twice more, interleaved order does not matter inside one process; a second run shows the box's own spread
   ADV_BENCH_MODES=default,general_kernel ADV_BENCH_INTEGRATORS=tsit54 ADV_BENCH_ONLY=C4 timeout 300 python scripts/bench_adaptive_stream.py > gpurun_out/r05_bench_adaptive_stream_c4_repeat.json 2>> gpurun_out/bench_adaptive_stream.err
   for cfg in C4:c4 C3_lorenz_N1e+06:c3; do

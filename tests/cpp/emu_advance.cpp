@@ -72,17 +72,14 @@ static int run_tpi(int64_t N, int block, const StepCtl& ctl, const Params& P, do
   Run g{N, DIM, false, y0, {}, std::vector<double>((size_t)N * DIM, 0.0)}, l = g;
   g.td.resize(2 * N); l.td.resize(2 * N);
   for (int64_t i = 0; i < N; ++i) { g.td[2 * i] = l.td[2 * i] = 0.0; g.td[2 * i + 1] = l.td[2 * i + 1] = std::sqrt(ctl.dtMax * ctl.dtMin); }
-  Run l2 = l;  // the two-IVPs-per-lane candidate (advance_tpi_lean2_kernel)
-  const unsigned grid = (unsigned)((N + block - 1) / block), grid2 = (unsigned)((N + 2 * block - 1) / (2 * block));
+  const unsigned grid = (unsigned)((N + block - 1) / block);
   for (launches = 0; launches < 100000;) {
     hipemu::launch(advance_tpi_kernel<METHOD, RHS, false, false>, dim3(grid), dim3(block), general_args(g, ctl, P, tEnd));
     hipemu::launch(advance_tpi_lean_kernel<METHOD, RHS>, dim3(grid), dim3(block), lean_args(l, ctl, P, tEnd));
-    hipemu::launch(advance_tpi_lean2_kernel<METHOD, RHS>, dim3(grid2), dim3(block), lean_args(l2, ctl, P, tEnd));
     ++launches;
     if (!same_bits(g.y, l.y) || !same_bits(g.td, l.td)) { std::fprintf(stderr, "lean and general kernels differ after launch %d\n", launches); return 2; }
-    if (!same_bits(g.y, l2.y) || !same_bits(g.td, l2.td)) { std::fprintf(stderr, "two-IVPs-per-lane and general kernels differ after launch %d\n", launches); return 4; }
-    const bool ga = any(g.active), la = any(l.active), l2a = any(l2.active);
-    if (ga != la || ga != l2a) { std::fprintf(stderr, "work-left flags differ after launch %d\n", launches); return 3; }
+    const bool ga = any(g.active), la = any(l.active);
+    if (ga != la) { std::fprintf(stderr, "work-left flags differ after launch %d\n", launches); return 3; }
     if (!la) break;
   }
   yOut = l.y;

@@ -221,11 +221,11 @@ def test_tune_set_validation(nn):
     L = nn._lib.lib()
     assert L.nnhip_tune_set(b"no_such_knob", 1) == -1
     for key, bad in ((b"rk4_stream_vec", 3), (b"rk4_stream_mode", 7), (b"rk4_stream_blocks_per_cu", 0), (b"dim16_variant", 9), (b"host_chunks", 100), (b"stream_graph", 3),
-                     (b"adv_recompute_fsal", 2), (b"adv_recompute_fsal", -2), (b"adv_lean", 2), (b"adv_lean_ipt", 3), (b"adv_steps_per_launch", 0), (b"adv_block", 32)):
+                     (b"adv_recompute_fsal", 2), (b"adv_recompute_fsal", -2), (b"adv_lean", 2), (b"adv_steps_per_launch", 0), (b"adv_block", 32)):
         assert L.nnhip_tune_set(key, bad) == -1, key
     for key, good, reset in ((b"rk4_stream_vec", 2, None), (b"rk4_stream_mode", 1, None), (b"rk4_stream_auto", 1, 1), (b"stream_graph", 1, 2),
                              (b"dim16_variant", 1, 0), (b"fp_contract", 1, 0), (b"host_chunks", 4, 0), (b"host_register", 1, 0),
-                             (b"adv_recompute_fsal", 0, -1), (b"adv_recompute_fsal", 1, -1), (b"adv_steps_per_launch", 5, 1), (b"adv_block", 128, 0), (b"adv_nontemporal", 1, -1), (b"adv_lean", 0, 1), (b"adv_lean_ipt", 2, 1)):
+                             (b"adv_recompute_fsal", 0, -1), (b"adv_recompute_fsal", 1, -1), (b"adv_steps_per_launch", 5, 1), (b"adv_block", 128, 0), (b"adv_nontemporal", 1, -1), (b"adv_lean", 0, 1)):
         assert L.nnhip_tune_set(key, good) == 0, key
         if reset is not None:
             assert L.nnhip_tune_set(key, reset) == 0

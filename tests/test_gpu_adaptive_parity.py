@@ -1363,13 +1363,6 @@ def test_lean_advance_kernels_give_the_general_kernels_bits(nn, oracle, dev):
                     finally:
                         assert L.nnhip_tune_set(b"adv_lean", 1) == 0
                 assert torch.equal(got[1], got[0]), (name, integ, kw)
-                if layout == 0:  # the two-IVPs-per-lane candidate of the thread-per-IVP lean kernel (knob "adv_lean_ipt" = 2; off by default)
-                    try:
-                        assert L.nnhip_tune_set(b"adv_lean_ipt", 2) == 0
-                        g2, _l2 = nn.adaptiveStream(f, yt.clone(), 0.0, 0.7, opt, integrator=integ, layout=layout)
-                    finally:
-                        assert L.nnhip_tune_set(b"adv_lean_ipt", 1) == 0
-                    assert torch.equal(g2, got[1]), (name, integ, kw, "adv_lean_ipt 2")
                 t, yf = nn.solveODE(f, yt, [0.0, 0.7], opt, integrator=integ, layout=layout)
                 assert torch.equal(got[1], yf[-1]), (name, integ, kw)
                 if orc is not None and y0.shape[1 - layout] <= 300:
