@@ -12,6 +12,30 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X / HIP device (run with -m gpu on the GPU box)")
 
 
+# GPU tests written in round 5, while gpurun was closed: they have never met a device.  The driver runs `pytest -x`: they go LAST, so that a
+# first-contact failure in one of them cannot hide the result of the tests that have a record on hardware.  Nothing is skipped or relaxed.
+# Remove a name from this list once it has passed on an MI355X (profiles/LAB_NOTES_r05.md section 0).
+_FIRST_CONTACT = (
+    "test_ctx_block.py::test_per_ivp_matrices_travel_with_their_shard",
+    "test_ctx_block.py::test_mutable_slots_come_back_from_their_shards",
+    "test_ctx_block.py::test_two_threads_bind_different_contexts_to_one_source",
+    "test_ctx_block.py::test_device_resident_shards_read_their_columns_of_the_context",
+    "test_gpu_adaptive_parity.py::test_automatic_polling_schedule_wastes_at_most_two_launches_beyond_the_speculative_pair",
+    "test_gpu_adaptive_parity.py::test_lean_advance_kernels_give_the_general_kernels_bits",
+    "test_gpu_adaptive_parity.py::test_bin_order_spends_its_bins_on_the_keys_it_gets",
+    "test_gpu_bench_contract.py::test_gpus_2_without_a_launcher_starts_its_own_ranks",
+    "test_gpu_bench_contract.py::test_a_launcher_of_another_size_is_refused",
+    "test_gpu_bench_contract.py::test_more_rccl_ranks_than_devices_is_refused",
+    "test_gpu_reference_text_quad.py::",
+)
+
+
+def pytest_collection_modifyitems(config, items):
+    def first_contact(item):
+        return any(("/" + k) in ("/" + item.nodeid) for k in _FIRST_CONTACT)
+    items.sort(key=first_contact)  # stable: everything else keeps its order
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as O
