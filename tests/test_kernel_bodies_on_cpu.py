@@ -14,6 +14,9 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# NNHIP_EMU_SANITIZE=1: the kernel bodies run under AddressSanitizer + UBSan (out-of-bounds lane accesses of partly filled workgroups, misaligned vector
+# accesses, signed overflow in index arithmetic abort the run) — several times slower, so opt-in; profiles/LAB_NOTES_r05.md records a full pass
+SANITIZE = ["-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all"] if os.environ.get("NNHIP_EMU_SANITIZE") else []
 
 
 @pytest.fixture(scope="module")
@@ -21,7 +24,7 @@ def emu(tmp_path_factory):
     if shutil.which("g++") is None:
         pytest.skip("needs g++")
     exe = str(tmp_path_factory.mktemp("emu") / "emu_advance")
-    subprocess.check_call(["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-DNNHIP_CPU_EMU", "-Wno-attributes", "-I", os.path.join(ROOT, "tests", "cpp"),
+    subprocess.check_call(["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-DNNHIP_CPU_EMU", *SANITIZE, "-Wno-attributes", "-I", os.path.join(ROOT, "tests", "cpp"),
                            "-I", os.path.join(ROOT, "numericalnim_amd", "csrc"), "-pthread", os.path.join(ROOT, "tests", "cpp", "emu_advance.cpp"), "-o", exe])
     return exe
 
@@ -77,7 +80,7 @@ def test_step_kernel_body_equals_the_reference_text(nn, tmp_path):
     if shutil.which("g++") is None:
         pytest.skip("needs g++")
     exe = str(tmp_path / "emu_step")
-    subprocess.check_call(["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-DNNHIP_CPU_EMU", "-Wno-attributes", "-I", os.path.join(ROOT, "tests", "cpp"),
+    subprocess.check_call(["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-DNNHIP_CPU_EMU", *SANITIZE, "-Wno-attributes", "-I", os.path.join(ROOT, "tests", "cpp"),
                            "-I", os.path.join(ROOT, "numericalnim_amd", "csrc"), "-pthread", os.path.join(ROOT, "tests", "cpp", "emu_step.cpp"), "-o", exe])
     steps = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_text_vectors.json")))["steps"]
     assert len(steps) == 42 and len({s["integrator"] for s in steps}) == 14
@@ -103,7 +106,7 @@ def emu_solve(tmp_path_factory):
     if shutil.which("g++") is None:
         pytest.skip("needs g++")
     exe = str(tmp_path_factory.mktemp("emu_solve") / "emu_solve")
-    subprocess.check_call(["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-DNNHIP_CPU_EMU", "-Wno-attributes", "-I", os.path.join(ROOT, "tests", "cpp"),
+    subprocess.check_call(["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-DNNHIP_CPU_EMU", *SANITIZE, "-Wno-attributes", "-I", os.path.join(ROOT, "tests", "cpp"),
                            "-I", os.path.join(ROOT, "numericalnim_amd", "csrc"), "-pthread", os.path.join(ROOT, "tests", "cpp", "emu_solve.cpp"), "-o", exe])
     return exe
 
@@ -146,3 +149,107 @@ def test_fused_solve_kernel_bodies_equal_the_reference_text(nn, emu_solve, case)
             assert ny == exp["n_y"] == reftext["ivps"][i]["n_y"], (case["name"], i)
             assert [hx(v) for v in f[4:]] == reftext["ivps"][i]["y"], (case["name"], i, layout, "differs from the reference's text")
             assert (steps, rej) == (exp["steps"], exp["rejected"]), (case["name"], i)
+
+
+# ---- the step-streaming kernels (tests/cpp/emu_stream.cpp) ------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def emu_stream(tmp_path_factory):
+    if shutil.which("g++") is None:
+        pytest.skip("needs g++")
+    exe = str(tmp_path_factory.mktemp("emu_stream") / "emu_stream")
+    subprocess.check_call(["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-DNNHIP_CPU_EMU", *SANITIZE, "-Wno-attributes", "-I", os.path.join(ROOT, "tests", "cpp"),
+                           "-I", os.path.join(ROOT, "numericalnim_amd", "csrc"), "-pthread", os.path.join(ROOT, "tests", "cpp", "emu_stream.cpp"), "-o", exe])
+    return exe
+
+
+def _rows(exe, *args):
+    r = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (args, r.returncode, r.stderr[-500:])
+    out = {}
+    for ln in r.stdout.strip().splitlines():
+        f = ln.split()
+        out[f[0]] = np.array([float.fromhex(x) for x in f[1:]])
+    return out
+
+
+@pytest.mark.parametrize("vec,mode,inplace,neg,n", [(1, 0, 0, 0, 1024 + 77), (2, 0, 1, 0, 2 * 1024 + 5), (4, 0, 0, 0, 2048 + 300), (2, 1, 0, 0, 1024 + 1), (4, 1, 1, 0, 4096),
+                                                    (2, 2, 0, 0, 5 * 1024 + 9), (4, 3, 1, 0, 7 * 2048 + 1), (1, 2, 1, 1, 3 * 512 + 17), (2, 0, 0, 1, 1024), (1, 0, 0, 0, 3)])
+def test_headline_kernel_body(emu_stream, oracle, vec, mode, inplace, neg, n):
+    """rk4_stream_vec_kernel — the kernel BASELINE's metric is measured on — as nnhip_ode_fixed_stream_f64_dev drives it (one launch per RK4_step, ode.nim:180-189,
+    t accumulated on the host): 16-byte lane accesses over full tiles, the scalar ragged tail tile, the persistent form with fewer workgroups than tiles, the
+    non-temporal forms, in place and ping-pong, and the backward branch's g(t, y) = -f(-t, y) (ode.nim:544-584).  40 steps of dt = 2^-10 == the oracle's solveODE."""
+    O = oracle
+    steps, dt = 40, 2.0 ** -10
+    d = _rows(emu_stream, "rk4", n, steps, vec, mode, inplace, neg)
+    y0 = d["y0"]
+    tspan = [-steps * dt, 0.0] if neg else [0.0, steps * dt]
+    ref = O.solve_ode_batch(O.RHS_NEG_Y, [], y0, n, 0, tspan, O.new_options(dt=dt), "rk4")
+    assert np.array_equal(d["y"], ref["y"][0 if neg else -1, 0]), (vec, mode, inplace, neg)
+    assert int(ref["steps"].max()) == steps == int(ref["steps"].min())
+
+
+_FIXED = ["heun2", "ralston2", "kutta3", "heun3", "ralston3", "ssprk3", "ralston4", "kutta4", "rk4"]
+
+
+@pytest.mark.parametrize("name", _FIXED)
+@pytest.mark.parametrize("aos,per_ivp,n", [(0, 0, 512 + 31), (1, 0, 512 + 1), (0, 1, 512), (1, 1, 7)])
+def test_fixed_step_streaming_kernel_body(nn, emu_stream, oracle, name, aos, per_ivp, n):
+    """fixed_stream_vec_kernel: any fixed-step IntegratorProc (ode.nim:107-189) over Lorenz, two IVPs per lane with 16-byte accesses (SoA: neighbouring IVPs of a
+    component plane; AoS: the six doubles of two neighbouring IVPs), the bounds-checked tail tile, uniform and per-IVP (t, dt); the FSAL slot is yNew (:189).
+    12 steps of dt = 2^-8 == the oracle's solveODE, bit for bit."""
+    O = oracle
+    steps, dt = 12, 2.0 ** -8
+    d = _rows(emu_stream, "fixed", nn.ode.integrator_id(name), n, steps, aos, per_ivp)
+    y0 = d["y0"].reshape(n, 3) if aos else d["y0"].reshape(3, n)
+    ref = O.solve_ode_batch(O.RHS_LORENZ, [10.0, 28.0, 8.0 / 3.0], y0, n, 3, [0.0, steps * dt], O.new_options(dt=dt), name, layout=O.LAYOUT_AOS if aos else O.LAYOUT_SOA)
+    got = d["y"].reshape(n, 3) if aos else d["y"].reshape(3, n)
+    assert np.array_equal(got, ref["y"][-1]), name
+    assert np.array_equal(d["fsal"], d["y"])
+
+
+@pytest.mark.parametrize("name", ["rk4", "kutta3", "rk21", "bs32", "dopri54", "tsit54", "vern65"])
+@pytest.mark.parametrize("n", [16 + 3, 1])
+def test_lanes_per_system_step_kernel_body(nn, emu_stream, oracle, name, n):
+    """step_lps_kernel: one IntegratorProc call (ode.nim:38) of a 16-component Vector[float] system spread over 16 lanes of a wavefront (ring neighbours by DPP
+    row rotation, the error norm as the ordered sum of utils.nim:233-235) — yNew, the FSAL slot, dtUsed and error of every system == the oracle's step."""
+    O = oracle
+    d = _rows(emu_stream, "steplps", nn.ode.integrator_id(name), n, 0)
+    y0, f0 = d["y0"].reshape(n, 16), d["f0"].reshape(n, 16)
+    opt = O.new_options(absTol=1e-9, relTol=1e-9, dtMax=1.0, dtMin=1e-6)
+    for i in range(n):
+        assert np.array_equal(f0[i], O.rhs(O.RHS_RING, [0.1], 0.25, y0[i]))
+        yn, fs, dtu, err = O.step(O.RHS_RING, [0.1], name, opt, 0.25, y0[i], f0[i], 2.0 ** -6)
+        assert np.array_equal(d["y"].reshape(n, 16)[i], yn), (name, i)
+        assert np.array_equal(d["fsal"].reshape(n, 16)[i], fs), (name, i, "FSAL slot")
+        assert d["dt"][i] == dtu and d["err"][i] == err, (name, i)
+
+
+@pytest.mark.parametrize("name", ["rk4", "kutta3"])
+def test_lanes_per_system_step_kernel_body_backward(nn, emu_stream, oracle, name):
+    """The same call for the backward branch g(t, y) = -f(-t, y) (ode.nim:544-584): one step of a solve towards t < tStart."""
+    O = oracle
+    n, dt = 5, 2.0 ** -6
+    d = _rows(emu_stream, "steplps", nn.ode.integrator_id(name), n, 1)
+    y0 = d["y0"].reshape(n, 16)
+    ref = O.solve_ode_batch(O.RHS_RING, [0.1], y0, n, 16, [-dt, 0.0], O.new_options(dt=dt), name, layout=O.LAYOUT_AOS)
+    assert np.array_equal(d["y"].reshape(n, 16), ref["y"][0]), name
+
+
+@pytest.mark.parametrize("neg", [0, 1])
+def test_dense_rows_kernel_body(emu_stream, oracle, neg):
+    """dense_rows_kernel: the rows due at the head of an iteration of ODESolver's loop (ode.nim:512-524) between two states — f at both ends (the backward
+    branch's g = -f(-t, .)) and hermiteSpline (utils.nim:273-279) per requested time == the oracle's rhs + hermite_spline, component by component."""
+    O = oracle
+    n = 256 + 9
+    d = _rows(emu_stream, "rows", n, neg)
+    ya, yb = d["ya"].reshape(3, n), d["yb"].reshape(3, n)
+    tA, tB, treq = 0.125, 0.15625, [0.125, 0.140625, 0.15]
+    par = [10.0, 28.0, 8.0 / 3.0]
+    for i in list(range(0, n, 37)) + [n - 1]:
+        da, db = O.rhs(O.RHS_LORENZ, par, -tA if neg else tA, ya[:, i]), O.rhs(O.RHS_LORENZ, par, -tB if neg else tB, yb[:, i])
+        if neg:
+            da, db = -da, -db
+        for k, tq in enumerate(treq):
+            row = d["r%d" % k].reshape(3, n)[:, i]
+            exp = [O.hermite_spline(tq, tA, tB, ya[c, i], yb[c, i], da[c], db[c]) for c in range(3)]
+            assert list(row) == exp, (i, k)
