@@ -12,6 +12,7 @@
 #include "ode_kernels.hpp"
 #include "ode_rtc.hpp"
 #include "quad_kernels.hpp"
+#include "consumer_kernels.hpp"  // (this translation unit only: the kernels in it are ordinary, non-inline __global__ functions)
 
 namespace nnhip {
 // ode_capi.hip
@@ -46,17 +47,6 @@ bool launch_dense_rows_kind(int rhs_kind, int dim, int64_t N, int64_t is, int64_
   return false;
 }
 
-// hermiteSpline (utils.nim:273-279) over a flat batch
-// negate_dy: the slopes are those of g(t, y) = -f(-t, y) (backward branch, ode.nim:545) while dy1 / dy2 hold f: use their negatives
-__global__ __launch_bounds__(kBlock) void hermite_kernel(double x, double x1, double x2, const double* __restrict__ y1,
-                                                         const double* __restrict__ y2, const double* __restrict__ dy1,
-                                                         const double* __restrict__ dy2, double* __restrict__ out, int64_t n, int negate_dy) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const HermiteW w = hermite_weights(x, x1, x2);
-  const double d1 = negate_dy ? -dy1[i] : dy1[i], d2 = negate_dy ? -dy2[i] : dy2[i];
-  out[i] = hermite_apply(w, y1[i], y2[i], d1, d2);
-}
 __global__ __launch_bounds__(kBlock) void fill_f64_kernel(double* __restrict__ p, int64_t n, double v) {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < n) p[i] = v;
@@ -110,121 +100,6 @@ int tableau_read(int device, double* out, int cap) {
   return n;
 }
 
-// newHermiteSpline(X, Y, dY).eval / .derivEval over M independent series (interpolate.nim:186-217, 299-390).
-// Everything that depends only on the query point (interval, basis weights, extrapolation branch) is computed on
-// the host in the reference's expression order and shipped as a descriptor; the kernel does the per-series part.
-struct HermSet {
-  int row;           // knots (row, row+1)
-  double w[4];       // h00, h10*xDiff, h01, h11*xDiff
-  double xDiff;
-};
-struct HermQuery {
-  int mode;          // 0 eval, 1 derivEval, 2 constant, 3 copy row A, 4 linear between rows A/B, 5 linear between derivEval sets A/B
-  HermSet a, b;
-  double k, value;
-};
-constexpr int kHermChunk = 24;
-struct HermChunk {
-  HermQuery q[kHermChunk];
-};
-
-NNHIP_DEV double herm_apply(const HermSet& s, const double* __restrict__ Y, const double* __restrict__ dY, int64_t M, int64_t m, bool deriv) {
-  const double p1 = Y[(int64_t)s.row * M + m], p2 = Y[(int64_t)(s.row + 1) * M + m];
-  const double m1 = dY[(int64_t)s.row * M + m], m2 = dY[(int64_t)(s.row + 1) * M + m];
-  const double v = s.w[0] * p1 + s.w[1] * m1 + s.w[2] * p2 + s.w[3] * m2;  // h00*p1 + h10*xDiff*m1 + h01*p2 + h11*xDiff*m2
-  return deriv ? v / s.xDiff : v;
-}
-
-__global__ __launch_bounds__(kBlock) void hermite_interp_kernel(const HermChunk c, int nq, const double* __restrict__ Y,
-                                                                const double* __restrict__ dY, int64_t M, double* __restrict__ out) {
-  const int64_t m = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const int qi = blockIdx.y;
-  if (m >= M || qi >= nq) return;
-  const HermQuery& q = c.q[qi];
-  double r;
-  switch (q.mode) {
-    case 0: r = herm_apply(q.a, Y, dY, M, m, false); break;
-    case 1: r = herm_apply(q.a, Y, dY, M, m, true); break;
-    case 2: r = q.value; break;
-    case 3: r = Y[(int64_t)q.a.row * M + m]; break;
-    case 4: { const double y0 = Y[(int64_t)q.a.row * M + m], y1 = Y[(int64_t)q.b.row * M + m]; r = y0 + q.k * (y1 - y0); break; }
-    default: { const double y0 = herm_apply(q.a, Y, dY, M, m, true), y1 = herm_apply(q.b, Y, dY, M, m, true); r = y0 + q.k * (y1 - y0); break; }
-  }
-  out[(int64_t)qi * M + m] = r;
-}
-
-// The slopes newHermiteSpline(X, Y) estimates when no derivatives are given (interpolate.nim:241-253): one-sided differences at
-// the ends, the mean of the two adjacent difference quotients inside.  Thread per (knot, series); invDx-free: the reference divides.
-__global__ __launch_bounds__(kBlock) void hermite_slopes_kernel(const double* __restrict__ X, int n, const double* __restrict__ Y,
-                                                                int64_t M, double* __restrict__ dY) {
-  const int64_t m = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const int i = blockIdx.y;
-  if (m >= M || i >= n) return;
-  const int64_t r = (int64_t)i * M + m;
-  if (i == 0) dY[r] = (Y[r + M] - Y[r]) / (X[1] - X[0]);
-  else if (i == n - 1) dY[r] = (Y[r] - Y[r - M]) / (X[n - 1] - X[n - 2]);
-  else dY[r] = 0.5 * ((Y[r + M] - Y[r]) / (X[i + 1] - X[i]) + (Y[r] - Y[r - M]) / (X[i] - X[i - 1]));
-}
-
-// cumtrapz(Y, X) over M series (integrate.nim:120-135): thread per series marches down the time axis;
-// the interval weights 0.5*(x_{i+1}-x_i) are computed on the host (same IEEE ops) and arrive as arguments.
-constexpr int kTrapzChunk = 384;
-struct TrapzWeights {
-  double w[kTrapzChunk];
-};
-__global__ __launch_bounds__(kBlock) void cumtrapz_kernel(const TrapzWeights W, int nw, int first, const double* __restrict__ Y,
-                                                          double* __restrict__ out, int64_t M) {
-  const int64_t m = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (m >= M) return;
-  // rows [first, first + nw] of Y / out; out[first] is already final unless first == 0
-  double yPrev = Y[(int64_t)first * M + m];
-  double integral;
-  if (first == 0) {
-    integral = yPrev - yPrev;  // "the right kind of zero" (:131-132): NaN/Inf states stay NaN
-    out[m] = integral;
-  } else {
-    integral = out[(int64_t)first * M + m];
-  }
-  for (int i = 0; i < nw; ++i) {
-    const double yNext = Y[(int64_t)(first + i + 1) * M + m];
-    integral += W.w[i] * (yNext + yPrev);  // 0.5 * (x[i+1] - x[i]) * (y[i+1] + y[i])  (:134)
-    out[(int64_t)(first + i + 1) * M + m] = integral;
-    yPrev = yNext;
-  }
-}
-
-// cumsimpson(Y, X) over M series (integrate.nim:329-375): composite Simpson on interval pairs + hermiteInterpolate
-// (utils.nim:282-312) with dy = Y.  Per-point weights depend only on X: computed on the host in reference order.
-__global__ __launch_bounds__(kBlock) void cumsimpson_kernel(const SimpsonPair* __restrict__ pairs, int nPairs, int evenN,
-                                                            const SimpsonPoint* __restrict__ pts, const double* __restrict__ Y,
-                                                            double* __restrict__ out, int64_t M, int n) {
-  const int64_t m = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (m >= M) return;
-  auto herm = [](const SimpsonPoint& p, double y1, double y2, double dy1, double dy2) {
-    return p.w[0] * y1 + p.w[1] * dy1 + p.w[2] * y2 + p.w[3] * dy2;  // h00*y1 + h10*(x2-x1)*dy1 + h01*y2 + h11*(x2-x1)*dy2
-  };
-  double y0 = Y[m];
-  double integral = y0 - y0;  // the right kind of zero (:350)
-  for (int i = 0; i < nPairs; ++i) {
-    const double y1 = Y[(int64_t)(2 * i + 1) * M + m], y2 = Y[(int64_t)(2 * i + 2) * M + m];
-    const SimpsonPair w = pairs[i];
-    const double next = integral + (w.alpha * y2 + w.beta * y1 + w.eta * y0);
-    out[(int64_t)(2 * i) * M + m] = herm(pts[2 * i], integral, next, y0, y2);
-    out[(int64_t)(2 * i + 1) * M + m] = herm(pts[2 * i + 1], integral, next, y0, y2);
-    integral = next;
-    y0 = y2;
-  }
-  if (evenN) {  // odd number of intervals: the last one is closed with the three-point rule of :363-373
-    const int l = n - 1;
-    const double ym2 = Y[(int64_t)(l - 2) * M + m], ym1 = y0, yl = Y[(int64_t)l * M + m];
-    const SimpsonPair w = pairs[nPairs];
-    const double next = integral + (w.eta * ym2 + w.beta * ym1 + w.alpha * yl);
-    out[(int64_t)(l - 1) * M + m] = herm(pts[l - 1], integral, next, ym1, yl);
-    integral = next;
-  }
-  out[(int64_t)(n - 1) * M + m] = integral;  // `if x[x.high] == t[t.high]: result.add(y[y.high])` (utils.nim:300-301)
-}
-
 // the controller's step-size factor (ode.nim:71,537) over an array of error norms
 template <int ORDER>
 __global__ __launch_bounds__(kBlock) void controller_factor_kernel(const double* __restrict__ error, double* __restrict__ out, int64_t n) {
@@ -245,28 +120,6 @@ int nnhip_hermite_spline_f64_dev(double x, double x1, double x2, const double* y
              ? NNHIP_OK : nnhip::fail_msg(NNHIP_EHIP, "hermite_spline: kernel launch failed");
 }
 
-static nnhip::HermSet herm_set(const double* X, int n, double x, bool deriv) {
-  // findInterval (interpolate.nim:114-115): clamp(lowerbound(X, x) - 1, 0, high - 1)
-  int k = (int)(std::lower_bound(X, X + n, x) - X) - 1;
-  if (k < 0) k = 0;
-  if (k > n - 2) k = n - 2;
-  nnhip::HermSet s;
-  s.row = k;
-  const double xDiff = X[k + 1] - X[k];
-  const double t = (x - X[k]) / xDiff;
-  const double t2 = t * t;
-  s.xDiff = xDiff;
-  if (!deriv) {  // interpolate.nim:190-195
-    const double t3 = t2 * t;
-    const double h00 = 2 * t3 - 3 * t2 + 1, h10 = t3 - 2 * t2 + t, h01 = -2 * t3 + 3 * t2, h11 = t3 - t2;
-    s.w[0] = h00; s.w[1] = h10 * xDiff; s.w[2] = h01; s.w[3] = h11 * xDiff;
-  } else {  // :207-211
-    const double h00 = 6 * t2 - 6 * t, h10 = 3 * t2 - 4 * t + 1, h01 = -6 * t2 + 6 * t, h11 = 3 * t2 - 2 * t;
-    s.w[0] = h00; s.w[1] = h10 * xDiff; s.w[2] = h01; s.w[3] = h11 * xDiff;
-  }
-  return s;
-}
-
 int nnhip_hermite_spline_eval_batch_f64_dev(const double* X, int n_knots, const double* Y, const double* dY, int64_t M,
                                             const double* xq, int n_q, int deriv, int extrap, double extrap_value, double* out,
                                             void* stream) {
@@ -277,27 +130,8 @@ int nnhip_hermite_spline_eval_batch_f64_dev(const double* X, int n_knots, const 
   if (extrap == 4) for (int q = 0; q < n_q; ++q) if (xq[q] < X[0] || xq[q] > X[n_knots - 1]) return nnhip::fail_msg(NNHIP_EVALUE, "x = %g is outside the interpolation range [%g, %g] (ExtrapolateKind.Error)", xq[q], X[0], X[n_knots - 1]);  // ValueError :340-341
   for (int q0 = 0; q0 < n_q; q0 += nnhip::kHermChunk) {
     nnhip::HermChunk c;
-    std::memset(&c, 0, sizeof(c));
     const int nq = std::min(nnhip::kHermChunk, n_q - q0);
-    for (int j = 0; j < nq; ++j) {
-      const double x = xq[q0 + j];
-      nnhip::HermQuery& hq = c.q[j];
-      const bool xLeft = x < X[0], xRight = x > X[n_knots - 1];
-      hq.mode = deriv ? 1 : 0;
-      hq.a = herm_set(X, n_knots, x, deriv != 0);
-      if (xLeft || xRight) {  // interpolate.nim:317-341 / 364-388
-        if (extrap == 0) { hq.mode = 2; hq.value = extrap_value; }
-        else if (extrap == 1) {
-          if (!deriv) { hq.mode = 3; hq.a.row = xLeft ? 0 : n_knots - 1; }
-          else hq.a = herm_set(X, n_knots, xLeft ? X[0] : X[n_knots - 1], true);
-        } else if (extrap == 2) {
-          const int r0 = xLeft ? 0 : n_knots - 2, r1 = r0 + 1;
-          hq.k = (x - X[r0]) / (X[r1] - X[r0]);
-          if (!deriv) { hq.mode = 4; hq.a.row = r0; hq.b.row = r1; }
-          else { hq.mode = 5; hq.a = herm_set(X, n_knots, X[r0], true); hq.b = herm_set(X, n_knots, X[r1], true); }
-        }
-      }
-    }
+    nnhip::herm_chunk_fill(X, n_knots, xq + q0, nq, deriv != 0, extrap, extrap_value, c);
     const dim3 grid((unsigned)((M + nnhip::kBlock - 1) / nnhip::kBlock), (unsigned)nq), block(nnhip::kBlock);
     if (nnhip::launch_kernel(nnhip::hermite_interp_kernel, grid, block, (hipStream_t)stream, c, nq, Y, dY, M, out + (int64_t)q0 * M) != hipSuccess)
       return nnhip::fail_msg(NNHIP_EHIP, "hermite spline eval: kernel launch failed");
@@ -332,8 +166,7 @@ int nnhip_cumtrapz_batch_f64_dev(const double* X, int n, const double* Y, int64_
   int first = 0;
   do {
     nnhip::TrapzWeights W;
-    const int nw = std::min(nnhip::kTrapzChunk, n - 1 - first);
-    for (int i = 0; i < nw; ++i) W.w[i] = 0.5 * (X[first + i + 1] - X[first + i]);
+    const int nw = nnhip::trapz_weights_fill(X, n, first, W);
     if (nnhip::launch_kernel(nnhip::cumtrapz_kernel, grid, block, (hipStream_t)stream, W, nw, first, Y, out, M) != hipSuccess) return nnhip::fail_msg(NNHIP_EHIP, "cumtrapz: kernel launch failed");
     first += nw;
   } while (first < n - 1);

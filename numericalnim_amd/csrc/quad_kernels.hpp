@@ -10,7 +10,7 @@
 // the host with the reference's own IEEE operations and shipped as tables; a wavefront reads them at uniform addresses.
 #pragma once
 #include "ode_kernels.hpp"
-#if !NNHIP_RTC
+#if !NNHIP_RTC || defined(NNHIP_CPU_EMU)  // (the host helpers below: the library, and the CPU test suite that runs the kernel bodies on the host)
 #include <vector>
 #endif
 
@@ -51,7 +51,7 @@ struct QuadArgs {
   int evenN;
 };
 
-#if !NNHIP_RTC
+#if !NNHIP_RTC || defined(NNHIP_CPU_EMU)
 // hermiteSpline's basis weights for x in [x1, x2] (utils.nim:273-279), in the reference's expression order
 inline void hermite_spline_weights(double x, double x1, double x2, double (&w)[4]) {
   const double t = (x - x1) / (x2 - x1);
@@ -89,7 +89,7 @@ inline void simpson_tables(const double* X, int64_t n, std::vector<SimpsonPair>&
     hermite_spline_weights(X[l - 1], X[l - 1], X[l], pts[l - 1].w);
   }
 }
-#endif  // !NNHIP_RTC
+#endif  // !NNHIP_RTC || NNHIP_CPU_EMU
 
 }  // namespace nnhip_abi
 

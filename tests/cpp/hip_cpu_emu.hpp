@@ -123,17 +123,18 @@ inline std::mutex& atomics_mu() { static std::mutex m; return m; }
 // one launch: workgroups one after the other, every thread of a workgroup a host thread
 template <class Kernel, class... Args>
 void launch(Kernel kernel, dim3 grid, dim3 block, Args... args) {
-  for (unsigned b = 0; b < grid.x; ++b) {
-    Block ctx(block.x);
-    std::vector<std::thread> th;
-    th.reserve(block.x);
-    for (unsigned t = 0; t < block.x; ++t)
-      th.emplace_back([&, t]() {
-        tl.threadIdx_ = dim3(t); tl.blockIdx_ = dim3(b); tl.blockDim_ = block; tl.gridDim_ = grid; tl.block = &ctx;
-        kernel(args...);
-      });
-    for (auto& x : th) x.join();
-  }
+  for (unsigned by = 0; by < grid.y; ++by)
+    for (unsigned b = 0; b < grid.x; ++b) {
+      Block ctx(block.x);
+      std::vector<std::thread> th;
+      th.reserve(block.x);
+      for (unsigned t = 0; t < block.x; ++t)
+        th.emplace_back([&, t]() {
+          tl.threadIdx_ = dim3(t); tl.blockIdx_ = dim3(b, by); tl.blockDim_ = block; tl.gridDim_ = grid; tl.block = &ctx;
+          kernel(args...);
+        });
+      for (auto& x : th) x.join();
+    }
 }
 }  // namespace hipemu
 

@@ -192,12 +192,14 @@ _FIXED = ["heun2", "ralston2", "kutta3", "heun3", "ralston3", "ssprk3", "ralston
 
 
 @pytest.mark.parametrize("name", _FIXED)
-@pytest.mark.parametrize("aos,per_ivp,n", [(0, 0, 512 + 31), (1, 0, 512 + 1), (0, 1, 512), (1, 1, 7)])
+@pytest.mark.parametrize("aos,per_ivp,n", [(0, 0, 512 + 30), (1, 0, 512 + 1), (0, 1, 512), (1, 1, 7)])
 def test_fixed_step_streaming_kernel_body(nn, emu_stream, oracle, name, aos, per_ivp, n):
     """fixed_stream_vec_kernel: any fixed-step IntegratorProc (ode.nim:107-189) over Lorenz, two IVPs per lane with 16-byte accesses (SoA: neighbouring IVPs of a
     component plane; AoS: the six doubles of two neighbouring IVPs), the bounds-checked tail tile, uniform and per-IVP (t, dt); the FSAL slot is yNew (:189).
-    12 steps of dt = 2^-8 == the oracle's solveODE, bit for bit."""
+    12 steps of dt = 2^-8 == the oracle's solveODE, bit for bit.  (SoA planes of an odd number of IVPs are not 16-byte aligned: nnhip_ode_step_batch_f64_dev
+    sends those to step_tpi_kernel — the same predicate here; under NNHIP_EMU_SANITIZE=1 UBSan enforces the alignment the kernel relies on.)"""
     O = oracle
+    assert aos or n % 2 == 0
     steps, dt = 12, 2.0 ** -8
     d = _rows(emu_stream, "fixed", nn.ode.integrator_id(name), n, steps, aos, per_ivp)
     y0 = d["y0"].reshape(n, 3) if aos else d["y0"].reshape(3, n)
@@ -253,3 +255,141 @@ def test_dense_rows_kernel_body(emu_stream, oracle, neg):
             row = d["r%d" % k].reshape(3, n)[:, i]
             exp = [O.hermite_spline(tq, tA, tB, ya[c, i], yb[c, i], da[c], db[c]) for c in range(3)]
             assert list(row) == exp, (i, k)
+
+
+# ---- the output consumers (tests/cpp/emu_consumers.cpp) against an execution of the reference's text ----------------------------------
+@pytest.fixture(scope="module")
+def emu_consumers(tmp_path_factory):
+    if shutil.which("g++") is None:
+        pytest.skip("needs g++")
+    exe = str(tmp_path_factory.mktemp("emu_consumers") / "emu_consumers")
+    subprocess.check_call(["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-DNNHIP_CPU_EMU", *SANITIZE, "-Wno-attributes", "-I", os.path.join(ROOT, "tests", "cpp"),
+                           "-I", os.path.join(ROOT, "numericalnim_amd", "csrc"), "-I", os.path.join(ROOT, "include"), "-pthread",
+                           os.path.join(ROOT, "tests", "cpp", "emu_consumers.cpp"), "-o", exe])
+    return exe
+
+
+def _quad_vectors():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "reference_text_quad_vectors.json")))
+
+
+def _hx(xs):
+    return " ".join(float(v).hex() for v in np.asarray(xs, dtype=np.float64).ravel())
+
+
+def _fh(xs):
+    return np.array([float.fromhex(x) for x in xs], dtype=np.float64)
+
+
+def _consume(exe, requests):
+    """-> one list of rows (each a float array) per request, plus the header line of `fn` requests"""
+    r = subprocess.run([exe], input="\n".join(requests) + "\n", capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, (r.returncode, r.stderr[-500:])
+    out, cur = [], []
+    for ln in r.stdout.splitlines():
+        if ln == "end":
+            out.append(cur)
+            cur = []
+        else:
+            cur.append(ln)
+    assert len(out) == len(requests)
+    return out
+
+
+def test_function_form_quadrature_kernel_bodies_equal_the_reference_text(emu_consumers):
+    """cumtrapz(f, X, ctx, dx) / cumsimpson(f, X, ctx, dx) (integrate.nim:138-175, 377-400): the library's host replay of everything X and dx decide
+    (quad_plan.hpp: grid size, the grid interval and Hermite weights of every result row, the non-uniform Simpson tables, where the march may stop) and the BODIES of
+    cumtrapz_fn_kernel / cumsimpson_fn_kernel on the host == all 144 function-form cases the reference's own text produced (scalar and 3-component integrands;
+    sorted, unsorted and duplicated X; queries on grid points and on the last one), bit for bit, in both layouts, for the first and the last item of a batch
+    that does not fill its workgroup.  GPU twin: tests/test_gpu_reference_text_quad.py::test_function_forms_equal_the_reference_text."""
+    cases = _quad_vectors()["cumquad_fn"]
+    assert len(cases) == 144
+    n = 3
+    reqs, meta = [], []
+    for c in cases:
+        d = max(c["dim"], 1)
+        p = _fh(c["params"])
+        for layout in ((0,) if d == 1 else (0, 1)):
+            reqs.append("fn %d %d %d %d %s %s %d %s" % (0 if c["rule"] == "trapz" else 1, d, layout, n, c["dx"], _hx(p[:3]), len(c["X"]), " ".join(c["X"])))
+            meta.append((c, d, layout))
+    outs = _consume(emu_consumers, reqs)
+    for (c, d, layout), o in zip(meta, outs):
+        head = o[0].split()
+        assert head[1] == "0" and int(head[3]) == c["rows"], c["name"]
+        got = np.array([[float.fromhex(v) for v in ln.split()] for ln in o[1:]]).reshape(c["rows"], *((d, n) if layout == 0 else (n, d)))
+        want = _fh(c["out"])
+        for i in (0, n - 1):
+            g = got[:, :, i] if layout == 0 else got[:, i, :]
+            assert np.array_equal(g.ravel(), want), (c["name"], layout, i)
+
+
+def test_discrete_quadrature_kernel_bodies_equal_the_reference_text(emu_consumers):
+    """cumtrapz(Y, X) / cumsimpson(Y, X) (integrate.nim:120-135, 329-375): cumtrapz_kernel (chunks of 384 interval weights) and cumsimpson_kernel with the
+    library's simpson_tables == the discrete cases of the reference's text on strictly ascending X (what the product accepts; the text's sorted-and-trimmed data for
+    the others is fed as it left sortAndTrimDataset).  GPU twin: ::test_discrete_forms_equal_the_reference_text."""
+    cases = _quad_vectors()["cumquad_discrete"]
+    reqs, meta = [], []
+    for c in cases:
+        X = _fh(c["X"] if c["strictly_ascending"] else c["X_sorted_trimmed"])
+        Ys = c["Y"] if c["strictly_ascending"] else c["Y_sorted_trimmed"]
+        Y = np.tile(np.stack([_fh(y) for y in Ys], axis=1), (1, 90))     # [n, 270]: more than one workgroup of series
+        for what in ("trapz", "simpson"):
+            if what == "simpson" and isinstance(c["cumsimpson"], dict):
+                continue                                                    # fewer than 3 points: ValueError (integrate.nim:345-346), refused by the C entry
+            reqs.append("%s %d %d %s %s" % (what, len(X), Y.shape[1], _hx(X), _hx(Y)))
+            meta.append((c, what))
+    outs = _consume(emu_consumers, reqs)
+    assert len(meta) >= 18
+    for (c, what), o in zip(meta, outs):
+        got = np.array([[float.fromhex(v) for v in ln.split()] for ln in o])
+        want = np.stack([_fh(v) for v in c["cumtrapz" if what == "trapz" else "cumsimpson"]], axis=1)
+        if what == "simpson" and not c["strictly_ascending"]:   # the text interpolates back to the caller's (unsorted / duplicated) abscissae: the sorted values, looked up
+            row = {x: k for k, x in enumerate(_fh(c["X_sorted_trimmed"]).tolist())}
+            got = got[[row[x] for x in _fh(c["X"]).tolist()]]
+        assert np.array_equal(got, np.tile(want, (1, 90))), (c["name"], what)
+
+
+def test_long_cumtrapz_crosses_weight_chunks(emu_consumers, oracle):
+    """1000 points: three launches of cumtrapz_kernel (384 weights each), every one resuming from the stored running integral == the oracle."""
+    rng = np.random.default_rng(5)
+    X = np.cumsum(rng.uniform(0.01, 0.2, 1000))
+    Y = rng.standard_normal((1000, 3))
+    o = _consume(emu_consumers, ["trapz 1000 3 %s %s" % (_hx(X), _hx(Y))])[0]
+    got = np.array([[float.fromhex(v) for v in ln.split()] for ln in o])
+    for m in range(3):
+        assert np.array_equal(got[:, m], oracle.cumtrapz(Y[:, m], X))
+
+
+def test_hermite_spline_kernel_bodies_equal_the_reference_text(emu_consumers):
+    """newHermiteSpline(X, Y[, dY]) + eval / derivEval with every ExtrapolateKind (interpolate.nim:186-253, 299-390): hermite_slopes_kernel, herm_chunk_fill (the
+    library's findInterval / basis weights / extrapolation branch per query) and hermite_interp_kernel == the reference's own text, bit for bit.  GPU twin:
+    ::test_hermite_spline_equals_the_reference_text."""
+    cases = _quad_vectors()["hermite"]
+    EX = {"Constant": 0, "Edge": 1, "Linear": 2, "Native": 3}
+    M = 70
+    reqs, meta = [], []
+    for c in cases:
+        X, Y, dY, xq = (_fh(c[k]) for k in ("X", "Y", "dY", "xq"))
+        Yb = np.tile(Y[:, None], (1, M))
+        reqs.append("slopes %d %d %s %s" % (len(X), M, _hx(X), _hx(Yb)))
+        meta.append((c, "slopes", None, None, None))
+        for key, slopes in (("with_dY", dY), ("estimated_slopes", _fh(c["slopes_from_text"]))):
+            dYb = np.tile(slopes[:, None], (1, M))
+            for ex, rec in c[key].items():
+                if ex not in EX:
+                    continue
+                for deriv in (0, 1):
+                    reqs.append("eval %d %d %d %d %d %s %s %s %s %s" % (len(X), M, len(xq), deriv, EX[ex], c["extrap_value"], _hx(X), _hx(Yb), _hx(dYb), _hx(xq)))
+                    meta.append((c, "eval", key, ex, deriv))
+    outs = _consume(emu_consumers, reqs)
+    n_eval = 0
+    for (c, what, key, ex, deriv), o in zip(meta, outs):
+        got = np.array([[float.fromhex(v) for v in ln.split()] for ln in o])
+        if what == "slopes":
+            assert np.array_equal(got, np.tile(_fh(c["slopes_from_text"])[:, None], (1, M))), c["name"]
+        else:
+            want = _fh(c[key][ex]["derivEval" if deriv else "eval"])
+            assert np.array_equal(got, np.tile(want[:, None], (1, M))), (c["name"], key, ex, deriv)
+            n_eval += 1
+    assert n_eval == 4 * 2 * 4 * 2
