@@ -393,3 +393,50 @@ def test_hermite_spline_kernel_bodies_equal_the_reference_text(emu_consumers):
             assert np.array_equal(got, np.tile(want[:, None], (1, M))), (c["name"], key, ex, deriv)
             n_eval += 1
     assert n_eval == 4 * 2 * 4 * 2
+
+
+# ---- the adaptive streaming driver with dense output (tests/cpp/emu_dense.cpp) ---------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def emu_dense(tmp_path_factory):
+    if shutil.which("g++") is None:
+        pytest.skip("needs g++")
+    exe = str(tmp_path_factory.mktemp("emu_dense") / "emu_dense")
+    subprocess.check_call(["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-DNNHIP_CPU_EMU", *SANITIZE, "-Wno-attributes", "-I", os.path.join(ROOT, "tests", "cpp"),
+                           "-I", os.path.join(ROOT, "numericalnim_amd", "csrc"), "-I", os.path.join(ROOT, "include"), "-pthread",
+                           os.path.join(ROOT, "tests", "cpp", "emu_dense.cpp"), "-o", exe])
+    return exe
+
+
+_ADAPTIVE = ("rk21", "bs32", "dopri54", "tsit54", "vern65")
+
+
+@pytest.mark.parametrize("case", [c for c in _golden_cases() if c["integrator"].lower() in _ADAPTIVE], ids=lambda c: c["name"])
+def test_dense_streaming_kernel_bodies_equal_the_reference_text(nn, emu_dense, case):
+    """Every adaptive fixture of tests/golden/ode_golden.json through the step-streaming form of the whole ODESolver (ode.nim:471-586) — state, (t, dt), denseIndex
+    and rows in memory, ONE loop iteration per launch (advance_dense_tpi_kernel / advance_dense_lps_kernel), the emission block of the next iteration's head
+    (:512-524) inside the launch that produced the step, forward direction first, then advance_dense_finalize_kernel's six modes (final rows, the t0 row, the
+    dropped-rows quirk, NaN fill) — on the host: output times, row counts and rows equal what the reference's own text returned, bit for bit, in both layouts.
+    The GPU twins go through nnhip_ode_adaptive_stream_dense_f64_dev (tests/test_gpu_golden.py, test_gpu_adaptive_parity.py)."""
+    import json
+    from golden_util import fh
+    reftext = {c["name"]: c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "reference_text_vectors.json")))["cases"]}[case["name"]]
+    n = len(case["y0"])
+    y0 = np.stack([fh(y) for y in case["y0"]])
+    o = nn.newODEoptions(**case["options"])
+    hexes = lambda xs: " ".join(float(v).hex() for v in xs)  # noqa: E731
+    for layout in ((0,) if case["dim"] == 0 else (0, 1)):
+        flat = (y0.T if layout == 0 else y0).ravel()
+        text = "\n".join([
+            " ".join(str(v) for v in (nn.ode.integrator_id(case["integrator"]), case["rhs_kind"], case["dim"], layout, n, len(case["tspan"]), 0, len(case["params"]))),
+            hexes([o.dt, o.dtMax, o.dtMin, o.tStart, o.absTol, o.relTol, o.scaleMax, o.scaleMin]),
+            hexes(fh(case["params"])), hexes(fh(case["tspan"])), hexes(flat)]) + "\n"
+        r = subprocess.run([emu_dense], input=text, capture_output=True, text=True, timeout=1800)
+        assert r.returncode == 0, (case["name"], r.returncode, r.stderr[-300:])
+        lines = r.stdout.strip().splitlines()
+        hx = lambda v: float.fromhex(v).hex()  # noqa: E731
+        tt = lines[0].split()
+        assert [hx(v) for v in tt[2:]] == reftext["t"] and int(tt[1]) == len(reftext["t"])
+        for i, exp in enumerate(case["ivps"]):
+            f = lines[1 + i].split()
+            assert int(f[1]) == exp["n_y"] == reftext["ivps"][i]["n_y"], (case["name"], i)
+            assert [hx(v) for v in f[4:]] == reftext["ivps"][i]["y"], (case["name"], i, layout, "differs from the reference's text")
