@@ -76,7 +76,7 @@ def test_streamed_c4_kernel_keeps_three_waves(stats):
 def test_fused_kernels_stay_inside_their_occupancy_choice(stats):
     """The fused solves (state in VGPRs for the whole solve): scalar RK4 at <= 64 VGPRs, DOPRI54 Lorenz and Tsit54 ring-16 inside the 3-wave budget the
     round-2 A/B chose (profiles/r02_c4_fused_ab.txt: C4 fused 8.07 -> 5.85 ms with the lean loop at 3 waves per SIMD).  Today's compiler spills 26 VGPRs (68 B of scratch
-    per lane) in the ring-16 kernel to get there: the ceiling below keeps that from growing unnoticed."""
+    per lane) in the ring-16 kernel to get there — around the two direction loops, none inside the step body: the ceiling below keeps that from growing unnoticed."""
     rk4 = _one(stats, "solve_tpi_kernel", "RhsNegY")
     _no_scratch(rk4)
     assert rk4["resources"]["vgpr_count"] <= 64
