@@ -602,6 +602,7 @@ int launch_solve_range(const PreparedSolve& ps, int64_t lo, int64_t n, hipStream
       return fail(NNHIP_EHIP, "user RHS launch failed: %s", nnhip::rtc_last_error());
     return NNHIP_OK;
   }
+  if (!ps.fn) return fail(NNHIP_EUNSUPPORTED, "launch_solve_range: the batch was not prepared (no fused-solve kernel selected)");
   HIP_TRY(ps.fn(a, stream));
   return NNHIP_OK;
 }
