@@ -70,3 +70,43 @@ def test_attribute_chains_on_the_package_exist():
                 bad.append((os.path.relpath(p, ROOT), node.lineno, "nn." + ".".join(reversed(chain))))
     assert not bad, sorted(set(bad))
     assert total > 500
+
+
+def test_calls_of_package_functions_bind_to_their_signatures():
+    """`nn.f(a, b, key=...)`: the positional count and every keyword must bind to f's signature (inspect) — a misspelt keyword in a GPU-only test is a TypeError
+    on the GPU box.  Calls with * / ** arguments are skipped."""
+    import inspect
+    import numericalnim_amd as nn
+    bad, total = [], 0
+    for p in _files():
+        src = open(p).read()
+        if "numericalnim_amd" not in src and "def test_" not in src:
+            continue
+        for node in ast.walk(ast.parse(src, p)):
+            if not (isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute)):
+                continue
+            chain, cur = [], node.func
+            while isinstance(cur, ast.Attribute):
+                chain.append(cur.attr)
+                cur = cur.value
+            if not (isinstance(cur, ast.Name) and cur.id == "nn"):
+                continue
+            obj = nn
+            try:
+                for a in reversed(chain):
+                    obj = getattr(obj, a)
+            except AttributeError:
+                continue  # reported by the test above
+            if any(isinstance(a, ast.Starred) for a in node.args) or any(k.arg is None for k in node.keywords):
+                continue
+            try:
+                sig = inspect.signature(obj)
+            except (TypeError, ValueError):
+                continue
+            total += 1
+            try:
+                sig.bind(*[None] * len(node.args), **{k.arg: None for k in node.keywords})
+            except TypeError as e:
+                bad.append((os.path.relpath(p, ROOT), node.lineno, "nn." + ".".join(reversed(chain)), str(e)))
+    assert not bad, bad
+    assert total > 300
