@@ -21,6 +21,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -120,20 +121,66 @@ inline T shfl_from(T v, unsigned laneInWave) {
 }
 inline std::mutex& atomics_mu() { static std::mutex m; return m; }
 
+// The host threads that play the lanes: started once per process and reused by every workgroup of every launch (a streaming loop makes thousands of launches;
+// creating and joining 256 threads for each of their workgroups was most of the test suite's time).
+class LanePool {
+ public:
+  static LanePool& get() { static LanePool p; return p; }
+  // run job(t) for t in [0, n) on n distinct threads, return when all are done.  Every worker sleeps on its own word (one futex wake per lane and workgroup,
+  // no shared lock to fight over), the launcher on the count of lanes still running.
+  template <class Job>
+  void run(unsigned n, Job&& job) {
+    while (workers_.size() < n) {
+      workers_.emplace_back(new Worker);
+      Worker* w = workers_.back().get();
+      const unsigned id = (unsigned)workers_.size() - 1;
+      w->th = std::thread([this, w, id]() { loop(w, id); });
+    }
+    job_ = [&job](unsigned t) { job(t); };
+    pending_.store(n, std::memory_order_release);
+    for (unsigned t = 0; t < n; ++t) {
+      workers_[t]->go.fetch_add(1, std::memory_order_release);
+      workers_[t]->go.notify_one();
+    }
+    for (unsigned left = pending_.load(std::memory_order_acquire); left != 0; left = pending_.load(std::memory_order_acquire)) pending_.wait(left, std::memory_order_acquire);
+  }
+  ~LanePool() {
+    stop_.store(true);
+    for (auto& w : workers_) { w->go.fetch_add(1); w->go.notify_one(); }
+    for (auto& w : workers_) w->th.join();
+  }
+
+ private:
+  struct Worker {
+    std::thread th;
+    std::atomic<uint32_t> go{0};
+  };
+  void loop(Worker* w, unsigned id) {
+    uint32_t seen = 0;
+    for (;;) {
+      w->go.wait(seen, std::memory_order_acquire);
+      seen = w->go.load(std::memory_order_acquire);
+      if (stop_.load()) return;
+      job_(id);
+      if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) pending_.notify_all();
+    }
+  }
+  std::vector<std::unique_ptr<Worker>> workers_;
+  std::function<void(unsigned)> job_;
+  std::atomic<unsigned> pending_{0};
+  std::atomic<bool> stop_{false};
+};
+
 // one launch: workgroups one after the other, every thread of a workgroup a host thread
 template <class Kernel, class... Args>
 void launch(Kernel kernel, dim3 grid, dim3 block, Args... args) {
   for (unsigned by = 0; by < grid.y; ++by)
     for (unsigned b = 0; b < grid.x; ++b) {
       Block ctx(block.x);
-      std::vector<std::thread> th;
-      th.reserve(block.x);
-      for (unsigned t = 0; t < block.x; ++t)
-        th.emplace_back([&, t]() {
-          tl.threadIdx_ = dim3(t); tl.blockIdx_ = dim3(b, by); tl.blockDim_ = block; tl.gridDim_ = grid; tl.block = &ctx;
-          kernel(args...);
-        });
-      for (auto& x : th) x.join();
+      LanePool::get().run(block.x, [&](unsigned t) {
+        tl.threadIdx_ = dim3(t); tl.blockIdx_ = dim3(b, by); tl.blockDim_ = block; tl.gridDim_ = grid; tl.block = &ctx;
+        kernel(args...);
+      });
     }
 }
 }  // namespace hipemu
