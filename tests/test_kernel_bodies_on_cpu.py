@@ -16,7 +16,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # NNHIP_EMU_SANITIZE=1: the kernel bodies run under AddressSanitizer + UBSan (out-of-bounds lane accesses of partly filled workgroups, misaligned vector
 # accesses, signed overflow in index arithmetic abort the run) — several times slower, so opt-in; profiles/LAB_NOTES_r05.md records a full pass
-SANITIZE = ["-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all"] if os.environ.get("NNHIP_EMU_SANITIZE") else []
+SANITIZE = ["-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-DNNHIP_EMU_THREADS"] if os.environ.get("NNHIP_EMU_SANITIZE") else []  # (lanes as OS threads there: ASan does not follow the default engine's swapcontext)
 
 
 @pytest.fixture(scope="module")
