@@ -72,6 +72,34 @@ def test_thread_per_ivp_lean_kernel_body(emu, oracle, method, name, opts, t_end,
     assert launches == int(ref["steps"].max())
 
 
+def _fuzz_cases(n_cases=30, seed=20250929):
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(n_cases):
+        case, dim = [("ring16", 16), ("ring8", 8), ("lorenz", 3), ("ring32", 32)][int(rng.integers(0, 4))]
+        out.append(dict(case=case, dim=dim, n=int(rng.integers(1, 160)), method=int(rng.integers(1, 3)),
+                        opts=dict(absTol=10.0 ** rng.uniform(-10, -3), relTol=10.0 ** rng.uniform(-12, -3), dtMin=10.0 ** rng.uniform(-9, -4), dtMax=10.0 ** rng.uniform(-2, -0.3)),
+                        t_end=float(rng.uniform(0.05, 0.9)), id="%02d_%s" % (k, case)))
+    return out
+
+
+@pytest.mark.parametrize("c", _fuzz_cases(), ids=lambda c: c["id"])
+def test_lean_kernel_bodies_fuzz(emu, oracle, c):
+    """30 seeded random configurations of the streaming loop (system, batch size 1..159, DOPRI54 / Tsit54, tolerances over seven decades, dtMin, dtMax, span):
+    the harness stops at the first launch after which the lean and the general kernel differ; the final states and the launch count equal the oracle's."""
+    O = oracle
+    name = {1: "dopri54", 2: "tsit54"}[c["method"]]
+    launches, y0, y = _run(emu, c["case"], c["n"], c["method"], c["opts"], c["t_end"])
+    n, d = c["n"], c["dim"]
+    if c["case"] == "lorenz":
+        ref = O.solve_ode_batch(O.RHS_LORENZ, [10.0, 28.0, 8.0 / 3.0], y0.reshape(3, n), n, 3, [0.0, c["t_end"]], O.new_options(**c["opts"]), name)
+        assert np.array_equal(y.reshape(3, n), ref["y"][-1]), c
+    else:
+        ref = O.solve_ode_batch(O.RHS_RING, [0.1], y0.reshape(n, d), n, d, [0.0, c["t_end"]], O.new_options(**c["opts"]), name, layout=O.LAYOUT_AOS)
+        assert np.array_equal(y.reshape(n, d), ref["y"][-1]), c
+    assert launches == int(ref["steps"].max())
+
+
 def test_step_kernel_body_equals_the_reference_text(nn, tmp_path):
     """One IntegratorProc call per integrator through the BODY of step_tpi_kernel (what nnhip_ode_step_batch_f64_dev launches), on the host, against the 42
     single steps the reference's own text produced (tests/golden/reference_text_vectors.json: accepted steps, in-step retries through pow, the dtMin double
