@@ -1,0 +1,275 @@
+"""The COMPILED gfx950 code of the hot kernels — the instructions hipcc put into the library's own object files (numericalnim_amd/csrc/*.o) — executed on the host
+by tools/gfx950_isa_interp.py (64 lanes as numpy vectors under EXEC, SGPRs / VCC / SCC, DPP moves, LDS, s_barrier, one IEEE operation per instruction) and compared
+bit for bit with the oracle.  tests/test_kernel_bodies_on_cpu.py runs the kernel SOURCE on the host and says nothing about what the device compiler made of it;
+this closes that gap as far as a host can (no timing, no memory model): register allocation, EXEC-mask handling of the nested accept / reject branches, DPP
+controls, the expansions of FP64 division and square root, 32-bit lane offsets against SGPR bases — all as emitted.
+
+It also yields DYNAMIC instruction counts per wavefront — what SQ_INSTS_VALU / SQ_WAVES measures on hardware.  Cross-check against the one such figure this
+repository holds from a GPU: round 4's PMC set of the general streamed C4 kernel, 587 VALU per wave (profiles/r04_c4_stream_pmc/): the interpreter counts 591 on
+the same kernel.  The lean kernels of round 5, which have never met a GPU: 527 (streamed C4, was 591), 362 (streamed C3, was 397).
+
+TEST INFRASTRUCTURE: nothing in the library or the package imports the interpreter; the product has no CPU path."""
+import json
+import math
+import os
+import shutil
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "numericalnim_amd", "csrc")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+DEFAULT = dict(absTol=1e-4, relTol=1e-4, dtMin=1e-4, dtMax=1e-2)     # newODEoptions(): BASELINE's C3 / C4 options
+TIGHT = dict(absTol=1e-9, relTol=1e-13, dtMin=1e-8, dtMax=0.2)         # rejections, in-step shrinks through pow, uneven finishing
+
+
+@pytest.fixture(scope="module")
+def G():
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump") or shutil.which("g++") is None:
+        pytest.skip("needs the ROCm LLVM tools and g++")
+    import gfx950_isa_interp
+    return gfx950_isa_interp
+
+
+@pytest.fixture(scope="module")
+def helpers(tmp_path_factory):
+    d = tmp_path_factory.mktemp("isa_helpers")
+    out = {}
+    for name in ("struct_layout", "kernarg_solve"):
+        exe = str(d / name)
+        subprocess.check_call(["g++", "-std=c++20", "-O1", "-DNNHIP_CPU_EMU", "-Wno-attributes", "-Wno-invalid-offsetof", "-I", os.path.join(ROOT, "tests", "cpp"), "-I", CSRC,
+                               "-I", os.path.join(ROOT, "include"), "-pthread", os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", exe])
+        out[name] = exe
+    out["layout"] = json.loads(subprocess.check_output([out["struct_layout"]]))
+    return out
+
+
+_CO = {}
+
+
+def _code_object(G, obj):
+    p = os.path.join(CSRC, obj)
+    if not os.path.exists(p):
+        pytest.skip(obj + " is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    if obj not in _CO:
+        _CO[obj] = G.CodeObject(p)
+    return _CO[obj]
+
+
+def _valu(c):
+    return c["valu_f64"] + c["valu_other"] + c["valu_dpp"] + c["valu_lane"]
+
+
+def _stream_loop(G, helpers, co, kernel_rx, lean, y, layout_aos, dim, par, opts, t_end, block, per_block):
+    """nnhip_ode_adaptive_stream_f64_dev's loop over the interpreted kernel: t = 0, dt = sqrt(dtMax dtMin), one launch per iteration until no workgroup reports
+    work left.  y is advanced in place.  -> (launches, per-wave counters of the second launch)"""
+    L = helpers["layout"]
+    n = y.shape[0] if layout_aos else y.shape[1]
+    mem = G.Memory(co)
+    td = np.zeros((n, 2))
+    td[:, 1] = math.sqrt(opts["dtMax"] * opts["dtMin"])
+    fsal = np.zeros_like(y)
+    active = np.zeros(L["kAggSlots"], dtype=np.uint32)
+    ay, atd, afs, aact = mem.alloc(y), mem.alloc(td), mem.alloc(fsal), mem.alloc(active)
+    k = co.kernel(kernel_rx)
+    if lean:
+        A = L["AdvLeanArgs"]
+        ka = bytearray(A["sizeof"])
+        struct.pack_into("<QQqd", ka, 0, ay, atd, n, t_end)
+        struct.pack_into("<Q", ka, A["active"], aact)
+    else:
+        A = L["StepArgs"]
+        ka = bytearray(A["sizeof"])
+        struct.pack_into("<qqq", ka, 0, n, dim if layout_aos else 1, 1 if layout_aos else n)
+        for f, v in (("y_in", ay), ("y_out", ay), ("fsal_in", afs), ("fsal_out", afs), ("t_io", atd), ("active", aact)):
+            struct.pack_into("<Q", ka, A[f], v)
+        struct.pack_into("<d", ka, A["tEnd"], t_end)
+        struct.pack_into("<i", ka, A["stepsPerLaunch"], 1)
+        struct.pack_into("<i", ka, A["recomputeFsal"], 1)
+        struct.pack_into("<q", ka, A["perIvpStride"], n)
+    struct.pack_into("<dddd", ka, A["ctl"], opts["absTol"], opts["relTol"], opts["dtMax"], opts["dtMin"])
+    struct.pack_into("<%dd" % len(par), ka, A["P"], *par)
+    M = G.Machine(co)
+    grid = (n + per_block - 1) // per_block
+    launches, second = 0, None
+    while True:
+        st = M.launch(k, (grid,), (block,), bytes(ka), mem)
+        launches += 1
+        if launches == 2:
+            second = st
+        if not active.any():
+            return launches, second
+        active[:] = 0
+        assert launches < 5000
+
+
+def _ring_y0(n, d):
+    return (1.0 + np.arange(d)[None, :] / 16 + ((np.arange(n) % 1024) * 2.0 ** -20)[:, None]).copy()
+
+
+def _lorenz_y0(n):
+    return np.stack([1.0 + (np.arange(n) % 1024) * 2.0 ** -20, np.ones(n), np.ones(n)]).copy()
+
+
+RESULTS = {}
+
+
+@pytest.mark.parametrize("opts,t_end,n", [(DEFAULT, 0.25, 70), (TIGHT, 0.4, 9)], ids=["default", "tight"])
+def test_streamed_c4_kernels_as_compiled(G, helpers, oracle, opts, t_end, n):
+    """advance_lps_lean_kernel<Tsit54, RhsRing<16>, 4> and the general advance_lps_kernel it stands in for, from the library's ode_tu_m_tsit54.o: 16-component ring,
+    four lanes per system (ring neighbours and the ordered norm chain by DPP quad_perm), a batch that leaves its last workgroup partly filled; default options
+    (first attempt accepted, clamp early-out) and tight ones (rejections, the pow path, systems finishing at different launches)."""
+    O = oracle
+    co = _code_object(G, "ode_tu_m_tsit54.o")
+    ref = None
+    got = {}
+    for lean, rx in ((True, r"advance_lps_lean_kernelILi2ENS_7RhsRingILi16EEELi4EE"), (False, r"advance_lps_kernelILi2ENS_7RhsRingILi16EEELi4ELb0EE")):
+        y = _ring_y0(n, 16)
+        y0 = y.copy()
+        launches, second = _stream_loop(G, helpers, co, rx, lean, y, True, 16, [0.1], opts, t_end, 256, 64)
+        if ref is None:
+            ref = O.solve_ode_batch(O.RHS_RING, [0.1], y0, n, 16, [0.0, t_end], O.new_options(**opts), "tsit54", layout=O.LAYOUT_AOS)
+        assert np.array_equal(y, ref["y"][-1]), ("lean" if lean else "general", "differs from the oracle")
+        assert launches == int(ref["steps"].max())
+        got[lean] = second[0]
+    if opts is TIGHT:
+        assert int(ref["steps"].max()) >= 10       # (the ring is too benign to reject a step; the controller's pow runs at every one of these steps — Lorenz below rejects)
+        return
+    lean_valu, gen_valu = _valu(got[True]), _valu(got[False])
+    RESULTS["streamed_c4"] = {"lean": dict(got[True]), "general": dict(got[False]), "valu_per_wave": {"lean": lean_valu, "general": gen_valu}}
+    assert got[True]["valu_f64"] == got[False]["valu_f64"]          # the same arithmetic ...
+    assert abs(gen_valu - 587) <= 0.03 * 587, gen_valu              # ... the interpreter's count of the general kernel = round 4's PMC figure (587 per wave) within 3 %
+    assert lean_valu <= gen_valu - 50, (lean_valu, gen_valu)        # ... and the lean kernel issues at least 50 fewer VALU instructions per wave (round 5: 527 vs 591)
+
+
+REJECTING = dict(absTol=1e-6, relTol=1e-6, dtMin=1e-9, dtMax=1.0)   # Lorenz from spread-out initial states: 170 rejected attempts, IVPs finish 28 .. 35 launches in
+
+
+@pytest.mark.parametrize("opts,t_end,n", [(DEFAULT, 0.25, 70), (REJECTING, 0.4, 70)], ids=["default", "rejecting"])
+def test_streamed_c3_kernels_as_compiled(G, helpers, oracle, opts, t_end, n):
+    """advance_tpi_lean_kernel<DOPRI54, RhsLorenz> and the general advance_tpi_kernel, from ode_tu_m_dopri54.o: SoA planes, one-wave workgroups (the driver's choice),
+    a partly filled second workgroup."""
+    O = oracle
+    co = _code_object(G, "ode_tu_m_dopri54.o")
+    par = [10.0, 28.0, 8.0 / 3.0]
+    ref, got = None, {}
+    for lean, rx in ((True, r"advance_tpi_lean_kernelILi1ENS_9RhsLorenzEEE"), (False, r"advance_tpi_kernelILi1ENS_9RhsLorenzELb0ELb0EE")):
+        y = _lorenz_y0(n)
+        if opts is REJECTING:
+            y[0] *= np.linspace(1.0, 30.0, n)
+        y0 = y.copy()
+        launches, second = _stream_loop(G, helpers, co, rx, lean, y, False, 3, par, opts, t_end, 64, 64)
+        if ref is None:
+            ref = O.solve_ode_batch(O.RHS_LORENZ, par, y0, n, 3, [0.0, t_end], O.new_options(**opts), "dopri54")
+        assert np.array_equal(y, ref["y"][-1]), ("lean" if lean else "general", "differs from the oracle")
+        assert launches == int(ref["steps"].max())
+        got[lean] = second[0]
+    if opts is REJECTING:
+        assert int(ref["rejected"].sum()) > 0 and int(ref["steps"].max()) > int(ref["steps"].min())   # the retry loop ran, IVPs finished at different launches
+    if opts is DEFAULT:
+        RESULTS["streamed_c3"] = {"lean": dict(got[True]), "general": dict(got[False]), "valu_per_wave": {"lean": _valu(got[True]), "general": _valu(got[False])}}
+        assert got[True]["valu_f64"] == got[False]["valu_f64"]
+        assert _valu(got[True]) <= _valu(got[False]) - 25, (got[True], got[False])
+
+
+@pytest.mark.parametrize("vec,mode", [(1, 0), (4, 1), (2, 2)])
+def test_headline_kernel_as_compiled(G, helpers, oracle, vec, mode):
+    """rk4_stream_vec_kernel<RhsNegY<1>, false, VEC, MODE> from ode_tu_rk4_stream.o — compiled with kernarg preloading: the scalar arguments arrive in SGPRs with the
+    wave (the kernel descriptor says how many; the interpreter fills them as the command processor does).  Full tiles + the ragged tail tile, 12 steps."""
+    O = oracle
+    co = _code_object(G, "ode_tu_rk4_stream.o")
+    k = co.kernel(r"rk4_stream_vec_kernelINS_7RhsNegYILi1EEELb0ELi%dELi%dEE" % (vec, mode))
+    tile = 256 * 2 * vec
+    n = 2 * tile + 77
+    steps, dt = 12, 2.0 ** -10
+    a = (1.0 + (np.arange(n) % 1024) * 2.0 ** -10).copy()
+    b = np.full(n, -7.0)
+    y0 = a.copy()
+    mem = G.Memory(co)
+    aa, ab = mem.alloc(a), mem.alloc(b)
+    M = G.Machine(co)
+    grid = (n + tile - 1) // tile
+    if mode & 2:
+        grid = min(grid, 2)
+    t, cur, nxt, st = 0.0, (aa, a), (ab, b), None
+    for _ in range(steps):
+        ka = struct.pack("<QQqdddd", cur[0], nxt[0], n, t, dt, 0.5 * dt, dt / 6.0) + bytes(helpers["layout"]["Params"]["sizeof"])
+        st = M.launch(k, (grid,), (256,), ka, mem)
+        t += dt
+        cur, nxt = nxt, cur
+    ref = O.solve_ode_batch(O.RHS_NEG_Y, [], y0, n, 0, [0.0, steps * dt], O.new_options(dt=dt), "rk4")
+    assert np.array_equal(cur[1], ref["y"][-1, 0])
+    c = st[0]
+    RESULTS["headline_vec%d_mode%d" % (vec, mode)] = dict(c)
+    assert c["vmem"] >= 2 * vec and c["lds"] == 0
+
+
+def _fused(G, helpers, co, kernel_rx, adaptive, y0, dim, layout, par, opt_fields, tspan, block, per_block):
+    n = y0.shape[0] if (layout == 1 and dim > 1) else (y0.shape[-1] if dim > 1 else y0.size)
+    mem = G.Memory(co)
+    yout = np.full((2,) + y0.shape, -7.0)
+    ny = np.full(n, -1, dtype=np.int32)
+    steps = np.full(n, -1, dtype=np.int64)
+    rej = np.full(n, -1, dtype=np.int64)
+    addrs = [mem.alloc(x) for x in (y0, yout, ny, steps, rej)]
+    cmd = [helpers["kernarg_solve"], str(int(adaptive)), str(n), str(dim), str(layout), "0", repr(tspan[0]), repr(tspan[1])] + [repr(float(v)) for v in opt_fields] + \
+          [str(len(par))] + [repr(float(p)) for p in par] + [str(a) for a in addrs]
+    size, hexbytes = subprocess.check_output(cmd, text=True).split()
+    ka = bytes.fromhex(hexbytes)
+    assert len(ka) == int(size)
+    k = co.kernel(kernel_rx)
+    st = G.Machine(co).launch(k, ((n + per_block - 1) // per_block,), (block,), ka, mem, max_instructions=60_000_000)
+    return yout, ny, steps, rej, st
+
+
+def test_fused_solves_as_compiled(G, helpers, oracle):
+    """The fused solve kernels (ODESolver per IVP, ode.nim:471-586, state in VGPRs for the whole solve) with the launch record the library's own planning code builds:
+    scalar RK4 (C1 / C2's fused form; host-replayed step schedule), DOPRI54 Lorenz (C3; 48 SGPRs spilled through lanes), Tsit54 on the 16-component ring, four lanes
+    per system (C4; 26 VGPRs in scratch around the direction loops) — rows, row counts and accepted / rejected counts equal the oracle's."""
+    O = oracle
+    # C1-shaped: dy = -y, 300 IVPs (a partly filled second workgroup), 200 steps of 2^-10
+    n, steps, dt = 300, 200, 2.0 ** -10
+    y0 = (1.0 + np.arange(n) * 2.0 ** -10).copy()
+    o = O.new_options(dt=dt)
+    yout, ny, st_, rej, st = _fused(G, helpers, _code_object(G, "ode_tu_m_rk4.o"), r"solve_tpi_kernelILi0ENS_7RhsNegYILi1EEELi0EE", False, y0, 1, 0, [],
+                                    [o.dt, o.dtMax, o.dtMin, o.tStart, o.absTol, o.relTol, o.scaleMax, o.scaleMin], [0.0, steps * dt], 256, 256)
+    ref = O.solve_ode_batch(O.RHS_NEG_Y, [], y0, n, 0, [0.0, steps * dt], o, "rk4")
+    assert np.array_equal(yout[1], ref["y"][-1, 0]) and np.array_equal(yout[0], y0) and (ny == 2).all() and (st_ == steps).all()
+    RESULTS["fused_rk4_200_steps"] = dict(st[0])
+    # C3-shaped: Lorenz, DOPRI54, default options
+    n = 70
+    y0 = _lorenz_y0(n)
+    o = O.new_options(**DEFAULT)
+    fields = [o.dt, o.dtMax, o.dtMin, o.tStart, o.absTol, o.relTol, o.scaleMax, o.scaleMin]
+    par = [10.0, 28.0, 8.0 / 3.0]
+    yout, ny, st_, rej, st = _fused(G, helpers, _code_object(G, "ode_tu_m_dopri54.o"), r"solve_tpi_kernelILi1ENS_9RhsLorenzELi0EE", True, y0, 3, 0, par, fields, [0.0, 0.25], 256, 256)
+    ref = O.solve_ode_batch(O.RHS_LORENZ, par, y0, n, 3, [0.0, 0.25], o, "dopri54")
+    assert np.array_equal(yout[1], ref["y"][-1]) and np.array_equal(st_, ref["steps"]) and np.array_equal(rej, ref["rejected"]) and (ny == 2).all()
+    # C4-shaped: 16-component ring, Tsit54, 4 lanes per system
+    n = 37
+    y0 = _ring_y0(n, 16)
+    yout, ny, st_, rej, st = _fused(G, helpers, _code_object(G, "ode_tu_m_tsit54.o"), r"solve_lps_kernelILi2ENS_7RhsRingILi16EEELi4ELb0ELi0EE", True, y0, 16, 1, [0.1], fields,
+                                    [0.0, 0.25], 256, 64)
+    ref = O.solve_ode_batch(O.RHS_RING, [0.1], y0, n, 16, [0.0, 0.25], o, "tsit54", layout=O.LAYOUT_AOS)
+    assert np.array_equal(yout[1], ref["y"][-1]) and np.array_equal(st_, ref["steps"]) and np.array_equal(rej, ref["rejected"]) and (ny == 2).all()
+
+
+def test_write_the_dynamic_counts(G):
+    """(runs last in this module) profiles/r05_isa_dynamic_counts.json is refreshed when NNHIP_WRITE_PROFILES=1; otherwise the committed file must agree."""
+    if "streamed_c4" not in RESULTS or "streamed_c3" not in RESULTS:
+        pytest.skip("the streamed cases did not run")
+    path = os.path.join(ROOT, "profiles", "r05_isa_dynamic_counts.json")
+    doc = {"what": "instructions one wavefront executes per launch, by class, counted by tools/gfx950_isa_interp.py on the library's own code objects "
+                   "(second launch of the default-option loop, wave 0 of workgroup 0: first attempt accepted, clamp early-out); VALU = valu_f64 + valu_other + valu_dpp + valu_lane",
+           "reference_point": "round 4 measured 587 VALU per wave on the general streamed C4 kernel (SQ_INSTS_VALU / SQ_WAVES, profiles/r04_c4_stream_pmc/)",
+           "kernels": RESULTS}
+    if os.environ.get("NNHIP_WRITE_PROFILES"):
+        json.dump(doc, open(path, "w"), indent=1, sort_keys=True)
+    committed = json.load(open(path))
+    for key in ("streamed_c4", "streamed_c3"):
+        assert committed["kernels"][key]["valu_per_wave"] == RESULTS[key]["valu_per_wave"], (key, "the committed counts are stale: rerun with NNHIP_WRITE_PROFILES=1")
