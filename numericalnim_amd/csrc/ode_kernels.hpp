@@ -1129,9 +1129,10 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_LEAN_ATTR void advance_lps_lean_k
     for (int j = 0; j < CPL; j += 2) *reinterpret_cast<double2*>(&yb[yo + j]) = make_double2(yNew[j], yNew[j + 1]);
     if (c == 0) tb[so] = make_double2(t, dt);
   }
-  if (a.active) {
-    if (__syncthreads_or((int)stillActive) && tid == 0) a.active[blockIdx.x % kAggSlots] = 1u;
-  }
+  // "anyone short of tEnd?": every lane that is stores the same 1 into its workgroup's slot — one store instruction per wavefront, merged by the memory pipeline.
+  // The general kernel's __syncthreads_or + single store costs a wavefront ~20 VALU instructions (DPP OR-reduction, mbcnt, readlane), two LDS operations and a
+  // barrier that keeps a workgroup's four waves from retiring on their own (dynamic count, tools/gfx950_isa_interp.py: 527 -> 507 VALU per wave on streamed C4).
+  if (a.active && stillActive) a.active[blockIdx.x % kAggSlots] = 1u;
 }
 // thread-per-IVP form: SoA planes y[c * N + i]; a block's part of plane c starts at y + c * N + blockIdx.x * blockDim.x (uniform)
 template <int METHOD, class RHS>
@@ -1159,9 +1160,7 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_TPI_ATTR void advance_tpi_lean_ke
     for (int c = 0; c < D; ++c) (yb + (int64_t)c * a.N)[o] = yNew[c];
     tb[o] = make_double2(t, dt);
   }
-  if (a.active) {
-    if (__syncthreads_or((int)stillActive) && tid == 0) a.active[blockIdx.x % kAggSlots] = 1u;
-  }
+  if (a.active && stillActive) a.active[blockIdx.x % kAggSlots] = 1u;  // (see advance_lps_lean_kernel)
 }
 #if !NNHIP_RTC
 // Does this launch have the layout the lean kernels are written for?  (Everything the streaming driver's default set-up produces.)

@@ -6,7 +6,7 @@ controls, the expansions of FP64 division and square root, 32-bit lane offsets a
 
 It also yields DYNAMIC instruction counts per wavefront — what SQ_INSTS_VALU / SQ_WAVES measures on hardware.  Cross-check against the one such figure this
 repository holds from a GPU: round 4's PMC set of the general streamed C4 kernel, 587 VALU per wave (profiles/r04_c4_stream_pmc/): the interpreter counts 591 on
-the same kernel.  The lean kernels of round 5, which have never met a GPU: 527 (streamed C4, was 591), 362 (streamed C3, was 397).
+the same kernel.  The lean kernels of round 5, which have never met a GPU: 501 (streamed C4, was 591), 348 (streamed C3, was 397).
 
 TEST INFRASTRUCTURE: nothing in the library or the package imports the interpreter; the product has no CPU path."""
 import json
@@ -144,7 +144,7 @@ def test_streamed_c4_kernels_as_compiled(G, helpers, oracle, opts, t_end, n):
     RESULTS["streamed_c4"] = {"lean": dict(got[True]), "general": dict(got[False]), "valu_per_wave": {"lean": lean_valu, "general": gen_valu}}
     assert got[True]["valu_f64"] == got[False]["valu_f64"]          # the same arithmetic ...
     assert abs(gen_valu - 587) <= 0.03 * 587, gen_valu              # ... the interpreter's count of the general kernel = round 4's PMC figure (587 per wave) within 3 %
-    assert lean_valu <= gen_valu - 50, (lean_valu, gen_valu)        # ... and the lean kernel issues at least 50 fewer VALU instructions per wave (round 5: 527 vs 591)
+    assert lean_valu <= gen_valu - 50, (lean_valu, gen_valu)        # ... and the lean kernel issues at least 50 fewer VALU instructions per wave (round 5: 501 vs 591)
 
 
 REJECTING = dict(absTol=1e-6, relTol=1e-6, dtMin=1e-9, dtMax=1.0)   # Lorenz from spread-out initial states: 170 rejected attempts, IVPs finish 28 .. 35 launches in
