@@ -259,6 +259,64 @@ def test_fused_solves_as_compiled(G, helpers, oracle):
     assert np.array_equal(yout[1], ref["y"][-1]) and np.array_equal(st_, ref["steps"]) and np.array_equal(rej, ref["rejected"]) and (ny == 2).all()
 
 
+def _ordered_img(v):
+    b = np.asarray(v, dtype=np.float64).view(np.uint64)
+    return np.where(b >> np.uint64(63), ~b, b | np.uint64(0x8000000000000000))
+
+
+@pytest.mark.parametrize("shape", ["uniform_with_a_zero", "both_signs", "one_sign_six_decades", "with_nan_and_inf"])
+def test_bin_order_kernels_as_compiled(G, shape):
+    """bin_count_kernel / bin_place_kernel from ode_sort.o (round 5: bins linear in value when the keys' range touches or straddles zero) — 1024 threads per
+    workgroup = 16 wavefronts meeting at s_barrier, LDS histograms with ds_add_u32 / ds_add_rtn_u32, the DPP / ds_bpermute scan, global atomics, 16-bit loads and
+    stores: the bins equal a numpy restatement of sort_kernels.hpp's arithmetic, the histogram the bin counts, and the order is a permutation sorted by bin."""
+    co = _code_object(G, "ode_sort.o")
+    rng = np.random.default_rng(11)
+    n = 4096 + 900                                       # two workgroups, the second partly filled
+    keys = {"uniform_with_a_zero": np.concatenate([[0.0], rng.uniform(0.0, 10.0, n - 1)]), "both_signs": rng.uniform(-5.0, 10.0, n),
+            "one_sign_six_decades": -10.0 ** rng.uniform(-6.0, 0.0, n), "with_nan_and_inf": rng.uniform(-1.0, 1.0, n)}[shape].copy()
+    if shape == "with_nan_and_inf":
+        keys[::97] = np.nan
+        keys[5::313] = np.inf
+    rng.shuffle(keys)
+    fin = np.isfinite(keys)
+    img = _ordered_img(keys)
+    rng_img = np.array([img[fin].min(), img[fin].max()], dtype=np.uint64)
+    bins = np.zeros(n, dtype=np.uint16)
+    hist = np.zeros(4096, dtype=np.uint32)
+    cursor = np.zeros(4096, dtype=np.uint32)
+    perm = np.full(n, 0xffffffff, dtype=np.uint32)
+    mem = G.Memory(co)
+    ak, ar, ab, ah, ac, ap = (mem.alloc(x) for x in (keys, rng_img, bins, hist, cursor, perm))
+    M = G.Machine(co)
+    blocks = (n + 4095) // 4096
+    M.launch(co.kernel(r"bin_count_kernel"), (blocks,), (1024,), struct.pack("<QQQQq", ak, ar, ab, ah, n), mem)
+    M.launch(co.kernel(r"bin_place_kernel"), (blocks,), (1024,), struct.pack("<QQQQqQd", ab, ah, ac, ap, n, ar, 0.0), mem)
+    # sort_kernels.hpp restated
+    mn, mx = float(keys[fin].min()), float(keys[fin].max())
+    by_image = (mn > 0 and mx > 0) or (mn < 0 and mx < 0)
+    want = np.full(n, 4095, dtype=np.int64)
+    nan_or_pinf = np.isnan(keys) | (keys == np.inf)
+    if by_image:
+        span = int(rng_img[1]) - int(rng_img[0])
+        shift = max(span.bit_length() - 12, 0)
+        if (span >> shift) > 4094:
+            shift += 1
+        d = np.array([(int(o) - int(rng_img[0])) >> shift if int(o) > int(rng_img[0]) else 0 for o in img], dtype=np.int64)
+        q = np.minimum(d, 4094)
+    else:
+        mn_half = mn * 0.5
+        half_span = mx * 0.5 - mn_half
+        per_unit = 4094.0 / half_span if half_span > 0 else 0.0
+        with np.errstate(invalid="ignore"):
+            r = (keys * 0.5 - mn_half) * per_unit
+            q = np.where(r >= 4094.0, 4094, np.where(r > 0.0, np.nan_to_num(r, nan=0.0, posinf=0.0, neginf=0.0).astype(np.int64), 0))
+    want[~nan_or_pinf] = q[~nan_or_pinf]
+    assert np.array_equal(bins.astype(np.int64), want), shape
+    assert np.array_equal(hist, np.bincount(want, minlength=4096).astype(np.uint32))
+    assert np.array_equal(np.sort(perm), np.arange(n, dtype=np.uint32))
+    assert (np.diff(want[perm].astype(np.int64)) >= 0).all()
+
+
 def test_write_the_dynamic_counts(G):
     """(runs last in this module) profiles/r05_isa_dynamic_counts.json is refreshed when NNHIP_WRITE_PROFILES=1; otherwise the committed file must agree."""
     if "streamed_c4" not in RESULTS or "streamed_c3" not in RESULTS:

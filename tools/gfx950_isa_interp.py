@@ -115,7 +115,7 @@ _MOD_RE = [
     ("quad_perm", re.compile(r"quad_perm:\[(\d),(\d),(\d),(\d)\]")), ("row_ror", re.compile(r"row_ror:(\d+)")), ("row_shr", re.compile(r"row_shr:(\d+)")),
     ("row_shl", re.compile(r"row_shl:(\d+)")), ("row_bcast", re.compile(r"row_bcast:(\d+)")), ("row_mask", re.compile(r"row_mask:(0x[0-9a-f]+)")),
     ("bank_mask", re.compile(r"bank_mask:(0x[0-9a-f]+)")), ("bound_ctrl", re.compile(r"bound_ctrl:(\d)")), ("offset", re.compile(r"offset:(-?\d+)")),
-    ("offset0", re.compile(r"offset0:(\d+)")), ("offset1", re.compile(r"offset1:(\d+)")), ("mul", re.compile(r"\bmul:(\d)")), ("div", re.compile(r"\bdiv:(\d)")),
+    ("bitop3", re.compile(r"bitop3:(0x[0-9a-f]+|\d+)")), ("offset0", re.compile(r"offset0:(\d+)")), ("offset1", re.compile(r"offset1:(\d+)")), ("mul", re.compile(r"\bmul:(\d)")), ("div", re.compile(r"\bdiv:(\d)")),
 ]
 _FLAGS = ("clamp", "nt", "sc0", "sc1", "glc", "slc", "row_mirror", "row_half_mirror", "wave_shr:1", "wave_shl:1", "wave_ror:1", "wave_rol:1", "gds")
 
@@ -176,6 +176,11 @@ class Kernel:
                 m = rx.search(rest)
                 if m:
                     i.mods[key] = tuple(int(x, 0) for x in m.groups()) if key == "quad_perm" else int(m.group(1), 0)
+                    rest = rest[:m.start()] + rest[m.end():]
+            for key in ("dst_sel", "dst_unused", "src0_sel", "src1_sel"):
+                m = re.search(key + r":(\w+)", rest)
+                if m:
+                    i.mods[key] = m.group(1)
                     rest = rest[:m.start()] + rest[m.end():]
             for fl in _FLAGS:
                 if re.search(r"(^|\s)" + re.escape(fl) + r"(\s|$)", rest):
@@ -747,8 +752,24 @@ def _v_mov_b64(w, i):
     w.wr_v64(i.ops[0], w.src64(i.ops[1], False))
 
 
+_SEL = {"BYTE_0": (0, 0xff), "BYTE_1": (8, 0xff), "BYTE_2": (16, 0xff), "BYTE_3": (24, 0xff), "WORD_0": (0, 0xffff), "WORD_1": (16, 0xffff), "DWORD": (0, 0xffffffff)}
+
+
+def _sdwa_src(val, sel):
+    sh, msk = _SEL[sel]
+    return (_vec(val) >> U32(sh)) & U32(msk)
+
+
 def _vop2_int(fn):
     def f(w, i):
+        if "src0_sel" in i.mods:  # SDWA: sub-dword source selects (zero-extended), whole-dword destination
+            if i.mods.get("dst_sel", "DWORD") != "DWORD":
+                raise NotImplementedError("SDWA destination select: " + i.text)
+            a = _sdwa_src(w.src32(i.ops[1]), i.mods["src0_sel"])
+            b = _sdwa_src(w.src32(i.ops[2]), i.mods.get("src1_sel", "DWORD"))
+            with np.errstate(over="ignore"):
+                w.wr_v32(i.ops[0], fn(a, b).astype(U32))
+            return
         a = w.src32(i.ops[1])
         m = None
         if any(k in i.mods for k in ("quad_perm", "row_ror", "row_shr", "row_shl", "row_mirror", "row_half_mirror")):
@@ -1194,6 +1215,101 @@ def _ds_bpermute_b32(w, i):
     w.wr_v32(i.ops[0], np.where(em[a], data[a], U32(0)))
 
 
+def _ds_write2(n, stride):
+    def f(w, i):
+        # ds_write2[st64]_bN vaddr, vdata0, vdata1 offset0:a offset1:b  (offsets in units of the element size, x64 for the st64 forms)
+        a = _vec(w.src32(i.ops[0])).astype(np.int64)
+        unit = 4 * n * stride
+        for tok, off in ((i.ops[1], i.mods.get("offset0", 0)), (i.ops[2], i.mods.get("offset1", 0))):
+            r = w._reg(tok)
+            for lane in np.nonzero(w.mask())[0]:
+                p = a[lane] + off * unit
+                w.lds[p:p + 4 * n] = np.ascontiguousarray(w.v[r[1]:r[1] + n, lane]).view(np.uint8)
+    return f
+
+
+def _ds_read2(n, stride):
+    def f(w, i):
+        a = _vec(w.src32(i.ops[1])).astype(np.int64)
+        unit = 4 * n * stride
+        r = w._reg(i.ops[0])
+        for k, off in enumerate((i.mods.get("offset0", 0), i.mods.get("offset1", 0))):
+            for lane in np.nonzero(w.mask())[0]:
+                p = a[lane] + off * unit
+                w.v[r[1] + k * n:r[1] + (k + 1) * n, lane] = w.lds[p:p + 4 * n].view(U32)
+    return f
+
+
+def _ds_add_u32(ret):
+    def f(w, i):
+        k = 1 if ret else 0
+        a = _ds_addr(w, i, i.ops[k])
+        r = w._reg(i.ops[k + 1])
+        rd = w._reg(i.ops[0]) if ret else None
+        for lane in np.nonzero(w.mask())[0]:  # lane order: one of the legal orders of the hardware's atomics
+            cur = w.lds[a[lane]:a[lane] + 4].view(U32)
+            old = int(cur[0])
+            cur[0] = (old + int(w.v[r[1], lane])) & 0xffffffff
+            if ret:
+                w.v[rd[1], lane] = old
+    return f
+
+
+def _global_load_small(nbytes, signed):
+    def f(w, i):
+        addr = _addr(w, i, i.ops[1], i.ops[2] if len(i.ops) > 2 else None)
+        r = w._reg(i.ops[0])
+        for lane in np.nonzero(w.mask())[0]:
+            v = int.from_bytes(bytes(w.mem.read(addr[lane], nbytes)), "little", signed=signed)
+            w.v[r[1], lane] = v & 0xffffffff
+    return f
+
+
+def _global_store_small(nbytes):
+    def f(w, i):
+        addr = _addr(w, i, i.ops[0], i.ops[2] if len(i.ops) > 2 else None)
+        r = w._reg(i.ops[1])
+        for lane in np.nonzero(w.mask())[0]:
+            w.mem.write(addr[lane], np.frombuffer(int(w.v[r[1], lane] & ((1 << (8 * nbytes)) - 1)).to_bytes(nbytes, "little"), dtype=np.uint8))
+    return f
+
+
+def _s_not(bits):
+    def f(w, i):
+        r = ~w.rd_s(i.ops[1], bits) & ((1 << bits) - 1)
+        w.wr_s(i.ops[0], r)
+        w.scc = int(r != 0)
+    return f
+
+
+def _s_flbit_i32_b64(w, i):
+    v = w.rd_s(i.ops[1], 64)
+    w.wr_s(i.ops[0], (64 - v.bit_length()) if v else 0xffffffff)
+
+
+def _s_minmax(fn, signed):
+    def f(w, i):
+        a, b = w.rd_s(i.ops[1]), w.rd_s(i.ops[2])
+        sa, sb = (w.sx(a, 32), w.sx(b, 32)) if signed else (a, b)
+        r = fn(sa, sb)
+        w.scc = int(r == sa)
+        w.wr_s(i.ops[0], r & 0xffffffff)
+    return f
+
+
+def _v_bitop3_b32(w, i):
+    a, b, c = (_vec(w.src32(t)) for t in i.ops[1:4])
+    tt = i.mods["bitop3"]
+    out = np.zeros(LANES, dtype=U32)
+    for idx in range(8):
+        if tt >> idx & 1:
+            ta = a if idx & 4 else ~a
+            tb = b if idx & 2 else ~b
+            tc = c if idx & 1 else ~c
+            out |= ta & tb & tc
+    w.wr_v32(i.ops[0], out)
+
+
 def _nop(w, i):
     return None
 
@@ -1263,4 +1379,13 @@ _OPS = {
     "global_atomic_or": _global_atomic(lambda a, b: a | b, 1), "global_atomic_or_x2": _global_atomic(lambda a, b: a | b, 2),
     "ds_write_b32": _ds_write(1), "ds_write_b64": _ds_write(2), "ds_read_b32": _ds_read(1), "ds_read_b64": _ds_read(2), "ds_or_b32": _ds_or_b32,
     "ds_bpermute_b32": _ds_bpermute_b32,
+    "ds_write_b128": _ds_write(4), "ds_read_b128": _ds_read(4), "ds_write_b96": _ds_write(3), "ds_read_b96": _ds_read(3),
+    "ds_write2_b32": _ds_write2(1, 1), "ds_write2_b64": _ds_write2(2, 1), "ds_write2st64_b32": _ds_write2(1, 64), "ds_write2st64_b64": _ds_write2(2, 64),
+    "ds_read2_b32": _ds_read2(1, 1), "ds_read2_b64": _ds_read2(2, 1), "ds_read2st64_b32": _ds_read2(1, 64), "ds_read2st64_b64": _ds_read2(2, 64),
+    "ds_add_u32": _ds_add_u32(False), "ds_add_rtn_u32": _ds_add_u32(True),
+    "global_load_ushort": _global_load_small(2, False), "global_load_sshort": _global_load_small(2, True), "global_load_ubyte": _global_load_small(1, False),
+    "global_load_sbyte": _global_load_small(1, True), "global_store_short": _global_store_small(2), "global_store_byte": _global_store_small(1),
+    "s_not_b32": _s_not(32), "s_not_b64": _s_not(64), "s_flbit_i32_b64": _s_flbit_i32_b64,
+    "s_min_u32": _s_minmax(min, False), "s_max_u32": _s_minmax(max, False), "s_min_i32": _s_minmax(min, True), "s_max_i32": _s_minmax(max, True),
+    "v_bitop3_b32": _v_bitop3_b32,
 }
