@@ -259,6 +259,42 @@ def test_fused_solves_as_compiled(G, helpers, oracle):
     assert np.array_equal(yout[1], ref["y"][-1]) and np.array_equal(st_, ref["steps"]) and np.array_equal(rej, ref["rejected"]) and (ny == 2).all()
 
 
+MIXED = dict(absTol=1e-7, relTol=1e-7, dtMin=1e-9, dtMax=0.25)
+
+
+@pytest.mark.parametrize("method,obj", [(1, "ode_tu_m_dopri54.o"), (2, "ode_tu_m_tsit54.o")], ids=["dopri54", "tsit54"])
+@pytest.mark.parametrize("case", ["ring32", "linear16", "affine_t16", "vanderpol", "ring4", "affine_t3", "neg_y1"])
+def test_other_lean_instantiations_as_compiled(G, helpers, oracle, method, obj, case):
+    """The lean kernels are instantiated for every compiled-in right-hand side: the 32-component ring (8 lanes per system: neighbours by ds_bpermute / row rotation, the
+    ordered error sum through LDS), 16-component systems without neighbours, a t-dependent right-hand side, Van der Pol, the 4-component ring on one lane, scalars —
+    each from the library's object file, tolerances at which the controller's pow runs at every step: bits and launch count == the oracle."""
+    O = oracle
+    co = _code_object(G, obj)
+    name = {1: "dopri54", 2: "tsit54"}[method]
+    n = 37
+    rng = np.random.default_rng(3)
+    lps = {"ring32": ("7RhsRingILi32EEE", 32, O.RHS_RING, [0.1]), "linear16": ("9RhsLinearILi16EEE", 16, O.RHS_LINEAR, [-0.7]),
+           "affine_t16": ("10RhsAffineTILi16EEE", 16, O.RHS_AFFINE_T, [-0.5, 0.3])}
+    tpi = {"vanderpol": ("12RhsVanDerPolE", 2, O.RHS_VANDERPOL, [3.0]), "ring4": ("7RhsRingILi4EEE", 4, O.RHS_RING, [0.1]),
+           "affine_t3": ("10RhsAffineTILi3EEE", 3, O.RHS_AFFINE_T, [-0.5, 0.3]), "neg_y1": ("7RhsNegYILi1EEE", 1, O.RHS_NEG_Y, [])}
+    t_end = 0.6
+    if case in lps:
+        tag, d, kind, par = lps[case]
+        y = (0.5 + rng.random((n, d))).copy()
+        y0 = y.copy()
+        launches, _ = _stream_loop(G, helpers, co, r"advance_lps_lean_kernelILi%dENS_%sLi4EEEv" % (method, tag), True, y, True, d, par, MIXED, t_end, 256, 256 // (d // 4))
+        ref = O.solve_ode_batch(kind, par, y0, n, d, [0.0, t_end], O.new_options(**MIXED), name, layout=O.LAYOUT_AOS)
+    else:
+        tag, d, kind, par = tpi[case]
+        y = (0.5 + rng.random((d, n))).copy()
+        y0 = y.copy()
+        launches, _ = _stream_loop(G, helpers, co, r"advance_tpi_lean_kernelILi%dENS_%sEEv" % (method, tag), True, y, False, d, par, MIXED, t_end, 64, 64)
+        ref = O.solve_ode_batch(kind, par, y0 if d > 1 else y0.reshape(-1), n, d if d > 1 else 0, [0.0, t_end], O.new_options(**MIXED), name)
+    want = ref["y"][-1] if d > 1 or case in lps else ref["y"][-1].reshape(1, n)
+    assert np.array_equal(y, want), (case, name)
+    assert launches == int(ref["steps"].max())
+
+
 def _ordered_img(v):
     b = np.asarray(v, dtype=np.float64).view(np.uint64)
     return np.where(b >> np.uint64(63), ~b, b | np.uint64(0x8000000000000000))
