@@ -436,6 +436,17 @@ def main():
                              "accepted_steps": int(cnt["steps"].sum()), "fused_ivps_per_s": n6 / (e0.elapsed_time(e1) / 3 * 1e-3),
                              "fused_accepted_steps_per_s": float(cnt["steps"].sum()) / (e0.elapsed_time(e1) / 3 * 1e-3)}
                 adaptive_inputs[name] = (fr, yy, layout, integ, d, yfu[-1])
+            try:  # static companion figures (not measured in this run): what a wavefront of the streamed kernel executes, counted on the library's code object
+                dyn = json.load(open(os.path.join(ROOT, "profiles", "r05_isa_dynamic_counts.json")))["kernels"]
+                for name, key, lanes_per_unit in (("C3_dopri54_lorenz_1e6", "streamed_c3", 1.0), ("C4_tsit54_ring16_1e6", "streamed_c4", 4.0)):
+                    valu = dyn[key]["valu_per_wave"]["lean"]
+                    waves_per_simd = n6 * lanes_per_unit / 64.0 / 1024.0          # 256 CUs x 4 SIMDs
+                    cfg[name]["streamed_kernel_static"] = {
+                        "valu_per_wave": valu, "valu_per_wave_general_kernel": dyn[key]["valu_per_wave"]["general"], "fp64_per_wave": dyn[key]["lean"]["valu_f64"],
+                        "valu_issue_floor_us_at_2.4GHz": valu * 4.0 * waves_per_simd / 2.4e3,   # 4 issue cycles per wave-wide FP64 / VALU instruction
+                        "source": "profiles/r05_isa_dynamic_counts.json (tools/gfx950_isa_interp.py on the library's code object; round 4's PMC on the general C4 kernel: 587)"}
+            except Exception:  # noqa: BLE001
+                pass
             out["adaptive_configs"] = cfg
         except Exception as exc:  # noqa: BLE001
             out.setdefault("informational_errors", {})['adaptive_configs'] = repr(exc)[:500]
