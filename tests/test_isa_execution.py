@@ -262,36 +262,59 @@ def test_fused_solves_as_compiled(G, helpers, oracle):
 MIXED = dict(absTol=1e-7, relTol=1e-7, dtMin=1e-9, dtMax=0.25)
 
 
-@pytest.mark.parametrize("method,obj", [(1, "ode_tu_m_dopri54.o"), (2, "ode_tu_m_tsit54.o")], ids=["dopri54", "tsit54"])
-@pytest.mark.parametrize("case", ["ring32", "linear16", "affine_t16", "vanderpol", "ring4", "affine_t3", "neg_y1"])
-def test_other_lean_instantiations_as_compiled(G, helpers, oracle, method, obj, case):
-    """The lean kernels are instantiated for every compiled-in right-hand side: the 32-component ring (8 lanes per system: neighbours by ds_bpermute / row rotation, the
-    ordered error sum through LDS), 16-component systems without neighbours, a t-dependent right-hand side, Van der Pol, the 4-component ring on one lane, scalars —
-    each from the library's object file, tolerances at which the controller's pow runs at every step: bits and launch count == the oracle."""
+_RHS_TAGS = {"7RhsNegY": ("RHS_NEG_Y", []), "9RhsLinear": ("RHS_LINEAR", [-0.7]), "10RhsAffineT": ("RHS_AFFINE_T", [-0.5, 0.3]), "7RhsRing": ("RHS_RING", [0.1]),
+             "12RhsVanDerPol": ("RHS_VANDERPOL", [3.0]), "9RhsLorenz": ("RHS_LORENZ", [10.0, 28.0, 8.0 / 3.0])}
+
+
+def _lean_symbols():
+    """every advance_*_lean_kernel instantiation of the two method objects that have them: (object, mangled name, lanes-per-system?, method, rhs tag, dim)"""
+    import re
+    out = []
+    llvm = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    for method, obj in ((1, "ode_tu_m_dopri54.o"), (2, "ode_tu_m_tsit54.o")):
+        p = os.path.join(CSRC, obj)
+        if not (os.path.exists(p) and os.path.exists(llvm)):
+            continue
+        try:
+            import gfx950_isa_interp as G
+            co = G.CodeObject(p)
+        except Exception:  # noqa: BLE001
+            continue
+        for name in sorted(co.symbols):
+            m = re.match(r"^_ZN5nnhip23advance_(lps|tpi)_lean_kernelILi(\d)ENS_(\d+Rhs[A-Za-z]+?)(?:ILi(\d+)EE)?E(?:Li(\d)E)?EEvNS_11AdvLeanArgsE$", name)
+            if m and not name.endswith(".kd"):
+                out.append((obj, name, m.group(1) == "lps", int(m.group(2)), m.group(3), int(m.group(4) or {"12RhsVanDerPol": 2, "9RhsLorenz": 3}[m.group(3)]), int(m.group(5) or 0)))
+        _CO[obj] = co
+    return out
+
+
+@pytest.mark.parametrize("sym", _lean_symbols(), ids=lambda t: "%s-%s%d-m%d" % ("lps" if t[2] else "tpi", t[4].lstrip("0123456789"), t[5], t[3]))
+def test_every_lean_instantiation_as_compiled(G, helpers, oracle, sym):
+    """EVERY instantiation of the lean kernels in the library (40: both methods x the compiled-in right-hand sides — scalars to the 32-component ring on 8 lanes per
+    system with the LDS error sum, t-dependent right-hand sides, Van der Pol, Lorenz), each from its object file, at tolerances where the controller's pow runs at
+    every step: bits and launch count == the oracle.  (A miscompiled instantiation would show here; round 5 had no other way to look.)"""
     O = oracle
+    obj, name, lps, method, tag, d, cpl = sym
     co = _code_object(G, obj)
-    name = {1: "dopri54", 2: "tsit54"}[method]
-    n = 37
+    kind, par = _RHS_TAGS[tag]
+    kind = getattr(O, kind)
+    integ = {1: "dopri54", 2: "tsit54"}[method]
+    n, t_end = 37, 0.6
     rng = np.random.default_rng(3)
-    lps = {"ring32": ("7RhsRingILi32EEE", 32, O.RHS_RING, [0.1]), "linear16": ("9RhsLinearILi16EEE", 16, O.RHS_LINEAR, [-0.7]),
-           "affine_t16": ("10RhsAffineTILi16EEE", 16, O.RHS_AFFINE_T, [-0.5, 0.3])}
-    tpi = {"vanderpol": ("12RhsVanDerPolE", 2, O.RHS_VANDERPOL, [3.0]), "ring4": ("7RhsRingILi4EEE", 4, O.RHS_RING, [0.1]),
-           "affine_t3": ("10RhsAffineTILi3EEE", 3, O.RHS_AFFINE_T, [-0.5, 0.3]), "neg_y1": ("7RhsNegYILi1EEE", 1, O.RHS_NEG_Y, [])}
-    t_end = 0.6
-    if case in lps:
-        tag, d, kind, par = lps[case]
+    rx = "^" + name.replace("$", "\\$") + "$"
+    if lps:
         y = (0.5 + rng.random((n, d))).copy()
         y0 = y.copy()
-        launches, _ = _stream_loop(G, helpers, co, r"advance_lps_lean_kernelILi%dENS_%sLi4EEEv" % (method, tag), True, y, True, d, par, MIXED, t_end, 256, 256 // (d // 4))
-        ref = O.solve_ode_batch(kind, par, y0, n, d, [0.0, t_end], O.new_options(**MIXED), name, layout=O.LAYOUT_AOS)
+        launches, _ = _stream_loop(G, helpers, co, rx, True, y, True, d, par, MIXED, t_end, 256, 256 // (d // cpl))
+        ref = O.solve_ode_batch(kind, par, y0, n, d, [0.0, t_end], O.new_options(**MIXED), integ, layout=O.LAYOUT_AOS)
+        want = ref["y"][-1]
     else:
-        tag, d, kind, par = tpi[case]
         y = (0.5 + rng.random((d, n))).copy()
         y0 = y.copy()
-        launches, _ = _stream_loop(G, helpers, co, r"advance_tpi_lean_kernelILi%dENS_%sEEv" % (method, tag), True, y, False, d, par, MIXED, t_end, 64, 64)
-        ref = O.solve_ode_batch(kind, par, y0 if d > 1 else y0.reshape(-1), n, d if d > 1 else 0, [0.0, t_end], O.new_options(**MIXED), name)
-    want = ref["y"][-1] if d > 1 or case in lps else ref["y"][-1].reshape(1, n)
-    assert np.array_equal(y, want), (case, name)
+        launches, _ = _stream_loop(G, helpers, co, rx, True, y, False, d, par, MIXED, t_end, 64, 64)
+        ref = O.solve_ode_batch(kind, par, y0 if d > 1 else y0.reshape(-1), n, d if d > 1 else 0, [0.0, t_end], O.new_options(**MIXED), integ)
+        want = ref["y"][-1] if d > 1 else ref["y"][-1].reshape(1, n)
+    assert np.array_equal(y, want), name
     assert launches == int(ref["steps"].max())
 
 
