@@ -318,6 +318,32 @@ def test_every_lean_instantiation_as_compiled(G, helpers, oracle, sym):
     assert launches == int(ref["steps"].max())
 
 
+_ALL = ["heun2", "ralston2", "kutta3", "heun3", "ralston3", "ssprk3", "ralston4", "kutta4", "rk4", "rk21", "bs32", "dopri54", "tsit54", "vern65"]
+
+
+@pytest.mark.parametrize("name", _ALL)
+def test_fused_lorenz_solve_of_every_integrator_as_compiled(nn, G, helpers, oracle, name):
+    """All 14 integrators (ode.nim:107-468): the fused thread-per-IVP Lorenz solve from each method's object file — the tableau, the stage sums and (for the five
+    adaptive ones) the controller as the device compiler emitted them — final states, row counts and accepted / rejected counters == the oracle."""
+    O = oracle
+    mid = nn.ode.integrator_id(name)
+    adaptive = name in ("rk21", "bs32", "dopri54", "tsit54", "vern65")
+    co = _code_object(G, "ode_tu_m_%s.o" % name)
+    n = 70
+    y0 = _lorenz_y0(n)
+    y0[0] *= np.linspace(1.0, 4.0, n)
+    o = O.new_options(**(dict(absTol=1e-6, relTol=1e-6, dtMin=1e-9, dtMax=1.0) if adaptive else dict(dt=2.0 ** -7)))
+    fields = [o.dt, o.dtMax, o.dtMin, o.tStart, o.absTol, o.relTol, o.scaleMax, o.scaleMin]
+    par = [10.0, 28.0, 8.0 / 3.0]
+    t_end = 0.3 if adaptive else 0.25
+    yout, ny, st_, rej, st = _fused(G, helpers, co, r"solve_tpi_kernelILi%dENS_9RhsLorenzELi0EE" % mid, adaptive, y0, 3, 0, par, fields, [0.0, t_end], 256, 256)
+    ref = O.solve_ode_batch(O.RHS_LORENZ, par, y0, n, 3, [0.0, t_end], o, name)
+    assert np.array_equal(yout[1], ref["y"][-1]) and np.array_equal(yout[0], y0) and (ny == 2).all(), name
+    assert np.array_equal(st_, ref["steps"]) and np.array_equal(rej, ref["rejected"])
+    if adaptive and name != "rk21":
+        assert int(ref["rejected"].sum()) > 0 or int(ref["steps"].max()) > int(ref["steps"].min())
+
+
 def _ordered_img(v):
     b = np.asarray(v, dtype=np.float64).view(np.uint64)
     return np.where(b >> np.uint64(63), ~b, b | np.uint64(0x8000000000000000))
