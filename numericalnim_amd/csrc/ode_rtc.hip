@@ -553,12 +553,22 @@ int rtc_register(const char* name, int dim, int n_params, const char* body, bool
   return NNHIP_RHS_USER_BASE + (int)g_user.size() - 1;
 }
 
+namespace {
+thread_local std::map<int, std::shared_ptr<CtxBinding>> t_bound;  // this thread's own binding per rhs_kind
+struct ShardView { const double* shared; const double* ivp; double* aux; int64_t stride; };
+thread_local std::map<int, ShardView> t_shard;                     // a multi-GPU worker thread's column range (rtc_ctx_shard_enter)
+}  // namespace
+
 int rtc_release(int rhs_kind) {
   const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
+  std::shared_ptr<CtxBinding> mine, latest;  // destroyed after g_mu is dropped: ~CtxBinding talks to the devices
   std::lock_guard<std::mutex> lk(g_mu);
   if (idx < 0 || idx >= (int)g_user.size() || !g_user[idx].alive) return -1;
   g_user[idx].programs.clear();  // drops the registry's references; a module is unloaded when its last launch in flight lets go (~Program)
-  g_user[idx].bound.reset();  // (a thread that bound this kind keeps its own reference until it binds again or exits; `alive` below makes it unreachable)
+  auto it = t_bound.find(rhs_kind);
+  if (it != t_bound.end()) { mine = std::move(it->second); t_bound.erase(it); }  // the releasing thread's own binding goes with the kind
+  latest = std::move(g_user[idx].bound);  // (another thread that bound this kind keeps its reference until it binds again or exits; `alive` below makes it unreachable)
+  g_user[idx].bound.reset();
   g_user[idx].alive = false;
   return 0;
 }
@@ -580,9 +590,6 @@ bool rtc_info(int rhs_kind, int* dim, int* n_params) {
 
 // ---- context bindings -------------------------------------------------------------------------------------------------------------
 namespace {
-thread_local std::map<int, std::shared_ptr<CtxBinding>> t_bound;  // this thread's own binding per rhs_kind
-struct ShardView { const double* shared; const double* ivp; double* aux; int64_t stride; };
-thread_local std::map<int, ShardView> t_shard;                     // a multi-GPU worker thread's column range (rtc_ctx_shard_enter)
 
 // the binding the calling thread's calls read: its own if it made one, else the latest of any thread.  Caller holds g_mu.
 std::shared_ptr<CtxBinding> binding_of(int idx) {
