@@ -233,10 +233,64 @@ def scenario_device_resident_shards():
     return "device-resident shards with a sharded context block, gathered on %d devices" % G
 
 
+def scenario_streaming_drivers():
+    """The host side of the step-streaming drivers: no kernel runs, so no IVP ever reports work left — the polling loops must end by themselves with exactly the
+    launches their schedule issues before a poll can stop them — the figures tests/cpp/test_poll_schedule.cpp replays from adv_poll_schedule.hpp for a batch
+    that needs 0 iterations (BASELINE's C3 / C4 options: 100 unpolled + the group of 2 enqueued ahead = 102, where a batch that needs 102 iterations takes 104; a caller's
+    check_every = 8: 8 + 8), max_launches cuts where it says, the fixed-step loop launches once per step; every table / state copy stays inside its allocation."""
+    n = 5000
+    lor = nn.Rhs.lorenz()
+    p = np.array([10.0, 28.0, 8.0 / 3.0])
+    opt = nn.newODEoptions()
+    integ = nn.ode.integrator_id("dopri54")
+    y = dev_alloc(0, 3 * n * 8)
+    wsb = int(L.nnhip_ode_adaptive_stream_workspace_bytes(n, 3))
+    ws = dev_alloc(0, wsb)
+    nl = C.c_int64(0)
+    s = C.c_void_p()
+    assert F.hipStreamCreateWithFlags(C.byref(s), 1) == 0
+    seen = []
+    for check_every, max_launches, want in ((0, 0, 102), (8, 0, 16), (0, 50, 50), (5, 12, 10)):
+        l0 = F.fake_hip_launches()
+        rc = L.nnhip_ode_adaptive_stream_f64_dev(C.byref(opt), integ, lor.kind, p.ctypes.data_as(dp), 3, n, 3, 0, 0.0, 1.0, y, ws, wsb, check_every, max_launches, C.byref(nl), s)
+        assert rc in (0, nn._lib.NNHIP_TRUNCATED), nn._lib.last_error()
+        assert nl.value == want, (check_every, max_launches, nl.value, want)
+        assert F.fake_hip_launches() - l0 == want + 1      # + the kernel that fills (t, dt)
+        seen.append(nl.value)
+    # the dense driver: requested times on both sides of tStart
+    ts = np.concatenate([np.linspace(-0.3, -0.05, 4), np.linspace(0.0, 1.0, 7)])
+    wsd = int(L.nnhip_ode_adaptive_stream_dense_workspace_bytes(n, 3, len(ts)))
+    wd = dev_alloc(0, wsd)
+    y0 = dev_alloc(0, 3 * n * 8)
+    yout = dev_alloc(0, len(ts) * 3 * n * 8)
+    ny = dev_alloc(0, n * 4)
+    t_out = np.empty(len(ts))
+    rc = L.nnhip_ode_adaptive_stream_dense_f64_dev(C.byref(opt), integ, lor.kind, p.ctypes.data_as(dp), 3, y0, n, 3, 0, ts.ctypes.data_as(dp), len(ts), t_out.ctypes.data_as(dp),
+                                                   yout, ny, wd, wsd, 0, 0, C.byref(nl), s)
+    assert rc == 0, nn._lib.last_error()
+    assert np.array_equal(t_out, np.sort(ts)) and nl.value == (100 + 2) + (30 + 2), nl.value   # forward [0, 1] and backward [0, 0.3] at dtMax = 0.01   # forward [0, 1] and backward [0, 0.3] at dtMax = 0.01
+    # the fixed-step loop: one launch per RK4 step
+    optf = nn.newODEoptions(dt=2.0 ** -10)
+    yf = dev_alloc(0, n * 8)
+    sc = dev_alloc(0, n * 8)
+    ns = C.c_int64(0)
+    fin = C.c_void_p()
+    l0 = F.fake_hip_launches()
+    rc = L.nnhip_ode_fixed_stream_f64_dev(C.byref(optf), nn.ode.integrator_id("rk4"), nn.Rhs.neg_y().kind, None, 0, n, 1, 0, 0.0, 1000 * 2.0 ** -10, yf, sc, C.byref(ns), C.byref(fin), s)
+    assert rc == 0 and ns.value == 1000 and F.fake_hip_launches() - l0 == 1000 and fin.value == yf, (rc, ns.value, nn._lib.last_error())
+    # the order of integration over a device key array
+    keys = dev_alloc(0, (1 << 16) * 8)
+    order = dev_alloc(0, (1 << 16) * 4)
+    assert L.nnhip_ode_bin_order_f64_dev(keys, 1 << 16, order, s) == 0, nn._lib.last_error()
+    for ptr in (y, ws, wd, y0, yout, ny, yf, sc, keys, order):
+        assert F.hipFree(C.c_void_p(ptr)) == 0
+    return "streaming drivers: launches %s, dense both directions 134, fixed-step 1000" % seen
+
+
 def main():
     only = sys.argv[1:]
     for sc in (scenario_sharded_context_host_entry, scenario_mutable_slots_round_trip, scenario_two_threads_bind_their_own_contexts, scenario_rccl_reassembly,
-               scenario_device_resident_shards):
+               scenario_device_resident_shards, scenario_streaming_drivers):
         if only and sc.__name__.replace("scenario_", "") not in only:
             continue
         print(sc.__name__, "->", sc(), flush=True)
