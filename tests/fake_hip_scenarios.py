@@ -287,10 +287,59 @@ def scenario_streaming_drivers():
     return "streaming drivers: launches %s, dense both directions 134, fixed-step 1000" % seen
 
 
+def scenario_consumers():
+    """The host side of the section-8-f4 consumers (this round's quad_plan.hpp / consumer_kernels.hpp re-factoring runs here through the C ABI): for every
+    function-form case of the reference's text the number of result rows the entry reports equals the text's, the table uploads stay in bounds; the discrete forms,
+    the spline evaluation with every ExtrapolateKind (ExtrapolateKind.Error is refused) and the slope estimate run through their host-pointer entries."""
+    import json
+    V = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_text_quad_vectors.json")))
+    fh = lambda xs: np.array([float.fromhex(x) for x in xs])  # noqa: E731
+    src = "for (int c = 0; c < {d}; ++c) dy[c] = ((p[0] * t + p[1]) * t) * (1.0 + (double)c) + p[2];"
+    fs = {d: nn.Rhs.custom(d, src.format(d=d), keys=("a", "b", "c"), name="poly%d_fake" % d) for d in (1, 3)}
+    n_items = 3
+    checked = 0
+    for c in V["cumquad_fn"]:
+        d = max(c["dim"], 1)
+        X = fh(c["X"])
+        p = np.ascontiguousarray(fh(c["params"])[:3])
+        out = np.empty((len(X), d, n_items))
+        rows = C.c_int(-1)
+        fn = L.nnhip_cumtrapz_fn_batch_f64 if c["rule"] == "trapz" else L.nnhip_cumsimpson_fn_batch_f64
+        rc = fn(fs[d].kind, p.ctypes.data_as(dp), 3, None, 0, n_items, d, 0, X.ctypes.data_as(dp), len(X), float.fromhex(c["dx"]), out.ctypes.data_as(dp), C.byref(rows), 0)
+        assert rc == 0, (c["name"], nn._lib.last_error())
+        assert rows.value == c["rows"], (c["name"], rows.value, c["rows"])
+        checked += 1
+    for c in V["cumquad_discrete"]:
+        if not c["strictly_ascending"]:
+            continue
+        X = fh(c["X"])
+        Y = np.ascontiguousarray(np.tile(np.stack([fh(y) for y in c["Y"]], axis=1), (1, 40)))
+        out = np.empty_like(Y)
+        assert L.nnhip_cumtrapz_batch_f64(X.ctypes.data_as(dp), len(X), Y.ctypes.data_as(dp), Y.shape[1], out.ctypes.data_as(dp), 0) == 0, nn._lib.last_error()
+        rc = L.nnhip_cumsimpson_batch_f64(X.ctypes.data_as(dp), len(X), Y.ctypes.data_as(dp), Y.shape[1], out.ctypes.data_as(dp), 0)
+        assert (rc != 0) == isinstance(c["cumsimpson"], dict), (c["name"], rc)      # fewer than 3 points: the reference's ValueError
+    for c in V["hermite"]:
+        X, Yv, dYv, xq = fh(c["X"]), fh(c["Y"]), fh(c["dY"]), fh(c["xq"])
+        Y = np.ascontiguousarray(np.tile(Yv[:, None], (1, 70)))
+        dY = np.ascontiguousarray(np.tile(dYv[:, None], (1, 70)))
+        out = np.empty((len(xq), 70))
+        for extrap in range(4):
+            for deriv in (0, 1):
+                rc = L.nnhip_hermite_spline_eval_batch_f64(X.ctypes.data_as(dp), len(X), Y.ctypes.data_as(dp), dY.ctypes.data_as(dp), 70, xq.ctypes.data_as(dp), len(xq), deriv, extrap,
+                                                           0.5, out.ctypes.data_as(dp), 0)
+                assert rc == 0, nn._lib.last_error()
+        outside = np.array([X[0] - 1.0])
+        assert L.nnhip_hermite_spline_eval_batch_f64(X.ctypes.data_as(dp), len(X), Y.ctypes.data_as(dp), dY.ctypes.data_as(dp), 70, outside.ctypes.data_as(dp), 1, 0, 4, 0.0,
+                                                     out.ctypes.data_as(dp), 0) != 0
+    for f in fs.values():
+        L.nnhip_ode_rhs_release(f.kind)
+    return "consumers: %d function-form cases with the reference text's row counts, discrete forms, spline evaluation" % checked
+
+
 def main():
     only = sys.argv[1:]
     for sc in (scenario_sharded_context_host_entry, scenario_mutable_slots_round_trip, scenario_two_threads_bind_their_own_contexts, scenario_rccl_reassembly,
-               scenario_device_resident_shards, scenario_streaming_drivers):
+               scenario_device_resident_shards, scenario_streaming_drivers, scenario_consumers):
         if only and sc.__name__.replace("scenario_", "") not in only:
             continue
         print(sc.__name__, "->", sc(), flush=True)
