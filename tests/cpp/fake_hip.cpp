@@ -142,17 +142,29 @@ hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {
 }
 
 // ---- streams, events, graphs ----
-hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned int) { *s = (hipStream_t) new int(t_device); return hipSuccess; }
-hipError_t hipStreamDestroy(hipStream_t s) { delete (int*)s; return hipSuccess; }
+struct FakeStream { int device; bool capturing; long captured; };
+struct FakeGraph { long launches; };
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned int) { *s = (hipStream_t) new FakeStream{t_device, false, 0}; return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t s) { delete (FakeStream*)s; return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned int) { return hipSuccess; }
-hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* st) { *st = hipStreamCaptureStatusNone; return hipSuccess; }
-hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorNotSupported; }
-hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t*) { return hipErrorNotSupported; }
-hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, hipGraphNode_t*, char*, size_t) { return hipErrorNotSupported; }
-hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
-hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
-hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+// graphs: work issued during a capture executes at once (copies move data, launches do nothing) AND is counted; replaying the graph only counts its launches
+hipError_t hipStreamIsCapturing(hipStream_t s, hipStreamCaptureStatus* st) { *st = (s && ((FakeStream*)s)->capturing) ? hipStreamCaptureStatusActive : hipStreamCaptureStatusNone; return hipSuccess; }
+hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode) {
+  if (!s || ((FakeStream*)s)->capturing) return hipErrorIllegalState;
+  ((FakeStream*)s)->capturing = true; ((FakeStream*)s)->captured = 0;
+  return hipSuccess;
+}
+hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g) {
+  if (!s || !((FakeStream*)s)->capturing) return hipErrorIllegalState;
+  ((FakeStream*)s)->capturing = false;
+  *g = (hipGraph_t) new FakeGraph{((FakeStream*)s)->captured};
+  return hipSuccess;
+}
+hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, hipGraphNode_t*, char*, size_t) { *e = (hipGraphExec_t) new FakeGraph{((FakeGraph*)g)->launches}; return hipSuccess; }
+hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) { g_launches += ((FakeGraph*)e)->launches; return hipSuccess; }
+hipError_t hipGraphDestroy(hipGraph_t g) { delete (FakeGraph*)g; return hipSuccess; }
+hipError_t hipGraphExecDestroy(hipGraphExec_t e) { delete (FakeGraph*)e; return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t) new int(0); return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned int) { return hipEventCreate(e); }
 hipError_t hipEventDestroy(hipEvent_t e) { delete (int*)e; return hipSuccess; }
@@ -161,11 +173,15 @@ hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.001f; return hipSuccess; }
 
 // ---- kernels: nothing runs ----
-hipError_t hipLaunchKernel(const void*, dim3, dim3, void**, size_t, hipStream_t) { g_launches++; return hipSuccess; }
+hipError_t hipLaunchKernel(const void*, dim3, dim3, void**, size_t, hipStream_t s) { g_launches++; if (s && ((FakeStream*)s)->capturing) ((FakeStream*)s)->captured++; return hipSuccess; }
 hipError_t hipModuleLoadData(hipModule_t* m, const void*) { *m = (hipModule_t) new int(0); return hipSuccess; }
 hipError_t hipModuleUnload(hipModule_t m) { delete (int*)m; return hipSuccess; }
 hipError_t hipModuleGetFunction(hipFunction_t* f, hipModule_t, const char*) { static int dummy; *f = (hipFunction_t)&dummy; return hipSuccess; }
-hipError_t hipModuleLaunchKernel(hipFunction_t, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, hipStream_t, void**, void**) { g_launches++; return hipSuccess; }
+hipError_t hipModuleLaunchKernel(hipFunction_t, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, hipStream_t s, void**, void**) {
+  g_launches++;
+  if (s && ((FakeStream*)s)->capturing) ((FakeStream*)s)->captured++;
+  return hipSuccess;
+}
 
 // ---- RCCL: one process, one communicator per fake device; collectives execute when every rank of the clique has issued its call (inside a group: at ncclGroupEnd) ----
 struct FakeComm { int rank, n; std::vector<FakeComm*>* clique; };

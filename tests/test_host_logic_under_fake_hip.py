@@ -48,3 +48,37 @@ def test_the_stand_in_catches_an_out_of_bounds_copy(fake):
             "buf = (C.c_char * 128)()\nassert F.hipMemcpy(p, buf, C.c_size_t(64), 1) == 0\nprint('in bounds ok', flush=True)\nF.hipMemcpy(p, buf, C.c_size_t(72), 1)\nprint('NOT REACHED')\n")
     r = subprocess.run([sys.executable, "-c", code], env=_env(fake, 1), capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "in bounds ok" in r.stdout and "NOT REACHED" not in r.stdout and "not inside one live device allocation" in r.stderr
+
+
+def _build_harness(tmp_path, src):
+    libdir = os.path.join(ROOT, "numericalnim_amd", "csrc")
+    exe = str(tmp_path / src.replace(".cpp", ""))
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", src), "-L", libdir, "-lnnhip_ode", "-L", "/opt/rocm/lib", "-lamdhip64", "-lpthread",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    return exe
+
+
+@pytest.mark.parametrize("gpus", [1, 2, 8])
+def test_c5_harness_on_a_fake_eight_gpu_node(fake, tmp_path, gpus):
+    """tests/cpp/bench_c5.cpp — config C5 through ONE C call from a process without PyTorch: shards resident per device, the graph-replayed step-streaming solve on
+    every device's own stream and worker thread, RCCL reassembly on a second stream — at 1, 2 and 8 of 8 fake devices: it runs to its JSON line (no --verify: nothing
+    is computed here).  On hardware this harness has only ever run with one GPU."""
+    import json
+    exe = _build_harness(tmp_path, "bench_c5.cpp")
+    r = subprocess.run([exe, "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--n-per-gpu", "100000", "--rk4-steps", "20"], env=_env(fake, 8),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == gpus and out["scaling"] == "weak" and out["value"] > 0
+
+
+def test_multithread_launch_harness_on_the_fake_node(fake, tmp_path):
+    """tests/cpp/bench_multithread_launch.cpp: 1, 2, 4, 8 host threads driving their own streams through the library at once, eager and graph-replayed — the
+    process-wide graph cache hit and released from several threads: no crash, no bad free, no copy out of bounds."""
+    import json
+    exe = _build_harness(tmp_path, "bench_multithread_launch.cpp")
+    r = subprocess.run([exe, "--rk4-steps", "50", "--reps", "2"], env=_env(fake, 1), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-1500:])
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["ok"] is True and out["c5_eager_G8"]["launches_per_s_aggregate"] > 0
