@@ -13,12 +13,15 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <dlfcn.h>
+
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 namespace {
@@ -91,10 +94,29 @@ hipError_t copy(void* dst, const void* src, size_t n, hipMemcpyKind kind) {
 }
 }  // namespace
 
+// ---- optional: a hook that EXECUTES launches (tests/isa_backed_node.py: the gfx950 interpreter) instead of dropping them ----
+typedef int (*fake_launch_hook_t)(const char* name, const void* image, unsigned gx, unsigned gy, unsigned gz, unsigned bx, unsigned by, unsigned bz, void** args);
+namespace {
+fake_launch_hook_t g_hook = nullptr;
+std::map<const void*, std::string> g_kernel_names;  // host stub -> mangled device name (recorded from __hipRegisterFunction)
+struct FakeModule { const void* image; };
+struct FakeFunction { FakeModule* module; std::string name; };
+}  // namespace
+
 extern "C" {
+void fake_hip_set_launch_hook(fake_launch_hook_t h) { g_hook = h; }
+// the compiler-generated registration of every kernel of a translation unit: remembered here, then handed on to the real runtime (which needs no device for it)
+void __hipRegisterFunction(void** modules, const void* hostFunction, char* deviceFunction, const char* deviceName, unsigned int threadLimit, void* tid, void* bid, void* blockDim,
+                           void* gridDim, int* wSize) {
+  { std::lock_guard<std::mutex> lk(g_mu); g_kernel_names[hostFunction] = deviceName; }
+  using Fn = void (*)(void**, const void*, char*, const char*, unsigned int, void*, void*, void*, void*, int*);
+  static Fn real = (Fn)dlsym(RTLD_NEXT, "__hipRegisterFunction");
+  if (real) real(modules, hostFunction, deviceFunction, deviceName, threadLimit, tid, bid, blockDim, gridDim, wSize);
+}
 // ---- counters for the tests ----
 long fake_hip_launches() { return g_launches.load(); }
 long fake_hip_copies() { return g_copies.load(); }
+int fake_hip_owns(const void* p, size_t n) { std::lock_guard<std::mutex> lk(g_mu); return find(p, n ? n : 1) != nullptr; }
 void fake_hip_dump_live() {
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto& kv : g_allocs) if (!kv.second.host) std::fprintf(stderr, "fake_hip: live device allocation %p, %zu bytes, device %d\n", (void*)kv.first, kv.second.size, kv.second.device);
@@ -151,6 +173,7 @@ hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned int) { return hi
 // graphs: work issued during a capture executes at once (copies move data, launches do nothing) AND is counted; replaying the graph only counts its launches
 hipError_t hipStreamIsCapturing(hipStream_t s, hipStreamCaptureStatus* st) { *st = (s && ((FakeStream*)s)->capturing) ? hipStreamCaptureStatusActive : hipStreamCaptureStatusNone; return hipSuccess; }
 hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode) {
+  if (g_hook) return hipErrorNotSupported;  // (executing launches: a replay would have to re-execute them; the callers use the eager paths)
   if (!s || ((FakeStream*)s)->capturing) return hipErrorIllegalState;
   ((FakeStream*)s)->capturing = true; ((FakeStream*)s)->captured = 0;
   return hipSuccess;
@@ -173,13 +196,27 @@ hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.001f; return hipSuccess; }
 
 // ---- kernels: nothing runs ----
-hipError_t hipLaunchKernel(const void*, dim3, dim3, void**, size_t, hipStream_t s) { g_launches++; if (s && ((FakeStream*)s)->capturing) ((FakeStream*)s)->captured++; return hipSuccess; }
-hipError_t hipModuleLoadData(hipModule_t* m, const void*) { *m = (hipModule_t) new int(0); return hipSuccess; }
-hipError_t hipModuleUnload(hipModule_t m) { delete (int*)m; return hipSuccess; }
-hipError_t hipModuleGetFunction(hipFunction_t* f, hipModule_t, const char*) { static int dummy; *f = (hipFunction_t)&dummy; return hipSuccess; }
-hipError_t hipModuleLaunchKernel(hipFunction_t, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, hipStream_t s, void**, void**) {
+hipError_t hipLaunchKernel(const void* fn, dim3 g, dim3 b, void** args, size_t, hipStream_t s) {
   g_launches++;
   if (s && ((FakeStream*)s)->capturing) ((FakeStream*)s)->captured++;
+  if (g_hook) {
+    std::string name;
+    { std::lock_guard<std::mutex> lk(g_mu); auto it = g_kernel_names.find(fn); if (it != g_kernel_names.end()) name = it->second; }
+    if (name.empty()) die("launch of a kernel that was never registered", fn, 0);
+    return g_hook(name.c_str(), nullptr, g.x, g.y, g.z, b.x, b.y, b.z, args) == 0 ? hipSuccess : hipErrorLaunchFailure;
+  }
+  return hipSuccess;
+}
+hipError_t hipModuleLoadData(hipModule_t* m, const void* image) { *m = (hipModule_t) new FakeModule{image}; return hipSuccess; }
+hipError_t hipModuleUnload(hipModule_t m) { delete (FakeModule*)m; return hipSuccess; }
+hipError_t hipModuleGetFunction(hipFunction_t* f, hipModule_t m, const char* name) { *f = (hipFunction_t) new FakeFunction{(FakeModule*)m, name}; return hipSuccess; }  // (leaked: a few per program)
+hipError_t hipModuleLaunchKernel(hipFunction_t f, unsigned gx, unsigned gy, unsigned gz, unsigned bx, unsigned by, unsigned bz, unsigned, hipStream_t s, void** params, void**) {
+  g_launches++;
+  if (s && ((FakeStream*)s)->capturing) ((FakeStream*)s)->captured++;
+  if (g_hook) {
+    FakeFunction* ff = (FakeFunction*)f;
+    return g_hook(ff->name.c_str(), ff->module->image, gx, gy, gz, bx, by, bz, params) == 0 ? hipSuccess : hipErrorLaunchFailure;
+  }
   return hipSuccess;
 }
 

@@ -64,16 +64,23 @@ except Exception:  # noqa: BLE001
 class CodeObject:
     """The gfx950 code object of a host object file / shared library built by hipcc: text (disassembled), loadable segments, kernel descriptors."""
 
-    def __init__(self, path):
+    def __init__(self, path=None, elf_bytes=None):
+        """path: a host object file / shared library of hipcc (its one device code object is extracted); elf_bytes: a gfx950 code object itself (hiprtc's output)"""
         self.tmp = tmp = tempfile.mkdtemp(prefix="isa_co_")
-        o = os.path.join(tmp, "t.o")
-        shutil.copy(path, o)
-        subprocess.check_call([os.path.join(LLVM, "llvm-objdump"), "--offloading", o], cwd=tmp, stdout=subprocess.DEVNULL)
-        os.remove(o)
-        co = [f for f in os.listdir(tmp) if "amdgcn" in f]
-        assert len(co) == 1, "expected one device code object in " + path
-        self.co_path = os.path.join(tmp, co[0])
+        if elf_bytes is not None:
+            self.co_path = os.path.join(tmp, "rtc.co")
+            with open(self.co_path, "wb") as f:
+                f.write(elf_bytes)
+        else:
+            o = os.path.join(tmp, "t.o")
+            shutil.copy(path, o)
+            subprocess.check_call([os.path.join(LLVM, "llvm-objdump"), "--offloading", o], cwd=tmp, stdout=subprocess.DEVNULL)
+            os.remove(o)
+            co = [f for f in os.listdir(tmp) if "amdgcn" in f]
+            assert len(co) == 1, "expected one device code object in " + path
+            self.co_path = os.path.join(tmp, co[0])
         self.raw = open(self.co_path, "rb").read()
+        self._meta = None
         syms = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "-s", "-W", self.co_path], text=True)
         self.symbols = {}
         for ln in syms.splitlines():
@@ -97,6 +104,17 @@ class CodeObject:
 
     def __del__(self):
         shutil.rmtree(getattr(self, "tmp", ""), ignore_errors=True)
+
+    def kernel_args(self, name):
+        """[(offset, size, value_kind)] of a kernel's arguments, from the code object's metadata note"""
+        if self._meta is None:
+            import yaml
+            txt = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", self.co_path], text=True)
+            a = txt.index("amdhsa.kernels:")
+            b = txt.index("\n...", a) if "\n..." in txt[a:] else len(txt)
+            doc = yaml.safe_load(txt[a:b])
+            self._meta = {k[".name"]: [(x[".offset"], x[".size"], x[".value_kind"]) for x in k.get(".args", [])] for k in doc["amdhsa.kernels"]}
+        return self._meta[name]
 
     def disassemble(self, name):
         """the instructions of one kernel (llvm-objdump restricted to the symbol: a library translation unit holds hundreds of kernels)"""
@@ -257,6 +275,7 @@ class Wave:
         self.k, self.mem, self.lds = kern, mem, lds
         self.s = np.zeros(128, dtype=U32)
         self.v = np.zeros((512, LANES), dtype=U32)
+        self.a = np.zeros((256, LANES), dtype=U32)  # accumulation VGPRs (used as spill space by register-heavy kernels)
         self.vcc, self.scc, self.m0 = 0, 0, 0
         self.exec = (1 << nlanes) - 1 if nlanes < 64 else ALL
         self.pc = 0
@@ -502,6 +521,13 @@ def _dpp_source(w, mods):
     elif "row_shl" in mods:
         src = lane + mods["row_shl"]
         valid = (src < row + 16)
+    elif "row_bcast" in mods:
+        if mods["row_bcast"] == 15:   # lane 15 of every row to all lanes of the NEXT row
+            src = row - 1
+            valid = lane >= 16
+        else:                          # row_bcast:31 — lane 31 to all lanes of rows 2 and 3
+            src = np.full(LANES, 31)
+            valid = lane >= 32
     elif "row_mirror" in mods:
         src = row | (15 - (lane & 15))
     elif "row_half_mirror" in mods:
@@ -534,10 +560,13 @@ class Machine:
         block = tuple(block) + (1,) * (3 - len(block))
         grid = tuple(grid) + (1,) * (3 - len(grid))
         kb = bytearray(kernarg) + bytearray(max(0, kern.kernarg_size - len(kernarg)) + 64)
-        hidden = kern.kernarg_size - 256  # code object v5: 256 bytes of implicit arguments behind the explicit ones
-        if hidden >= len(kernarg):
-            struct.pack_into("<IIIHHHHHH", kb, hidden, grid[0], grid[1], grid[2], block[0], block[1], block[2], 0, 0, 0)  # block counts, group sizes, remainders
-            struct.pack_into("<H", kb, hidden + 64, 1 + (grid[1] * block[1] > 1) + (grid[2] * block[2] > 1))       # grid dimensions
+        vals = {"hidden_block_count_x": grid[0], "hidden_block_count_y": grid[1], "hidden_block_count_z": grid[2], "hidden_group_size_x": block[0],
+                "hidden_group_size_y": block[1], "hidden_group_size_z": block[2], "hidden_remainder_x": 0, "hidden_remainder_y": 0, "hidden_remainder_z": 0,
+                "hidden_global_offset_x": 0, "hidden_global_offset_y": 0, "hidden_global_offset_z": 0,
+                "hidden_grid_dims": 1 + (grid[1] * block[1] > 1) + (grid[2] * block[2] > 1)}
+        for off, size, kind in kern.co.kernel_args(kern.name):  # the implicit arguments of code object v5, where the metadata puts them
+            if kind in vals:
+                kb[off:off + size] = int(vals[kind]).to_bytes(size, "little")
         ka = np.frombuffer(kb, dtype=np.uint8).copy()
         ka_addr = mem.alloc(ka)
         nthreads = block[0] * block[1] * block[2]
@@ -741,7 +770,7 @@ def _v_div_fixup_f64(w, i):
 
 def _v_mov_b32(w, i):
     val = w.src32(i.ops[1])
-    if any(k in i.mods for k in ("quad_perm", "row_ror", "row_shr", "row_shl", "row_mirror", "row_half_mirror")):
+    if any(k in i.mods for k in ("quad_perm", "row_ror", "row_shr", "row_shl", "row_bcast", "row_mirror", "row_half_mirror")):
         fetched, off = _dpp_fetch(w, val, i.mods)
         w.wr_v32(i.ops[0], fetched, w.mask() & ~off)
     else:
@@ -772,7 +801,7 @@ def _vop2_int(fn):
             return
         a = w.src32(i.ops[1])
         m = None
-        if any(k in i.mods for k in ("quad_perm", "row_ror", "row_shr", "row_shl", "row_mirror", "row_half_mirror")):
+        if any(k in i.mods for k in ("quad_perm", "row_ror", "row_shr", "row_shl", "row_bcast", "row_mirror", "row_half_mirror")):
             a, off = _dpp_fetch(w, a, i.mods)
             m = w.mask() & ~off
         b = _vec(w.src32(i.ops[2]))
@@ -962,6 +991,17 @@ def _global_atomic(fn, n, ret_possible=True):
                 rd = w._reg(ops[0])
                 w.v[rd[1]:rd[1] + n, lane] = np.array([old], dtype=dt).view(U32)
     return f
+
+
+def _v_accvgpr_write(w, i):
+    r = w._reg(i.ops[0])
+    m = w.mask()
+    w.a[r[1]][m] = _vec(w.src32(i.ops[1]))[m]
+
+
+def _v_accvgpr_read(w, i):
+    r = w._reg(i.ops[1])
+    w.wr_v32(i.ops[0], w.a[r[1]])
 
 
 # ---- scalar ------------------------------------------------------------------------------------------------------------------------------
@@ -1287,6 +1327,26 @@ def _s_flbit_i32_b64(w, i):
     w.wr_s(i.ops[0], (64 - v.bit_length()) if v else 0xffffffff)
 
 
+def _s_bcnt1(bits):
+    def f(w, i):
+        r = bin(w.rd_s(i.ops[1], bits) & ((1 << bits) - 1)).count("1")
+        w.wr_s(i.ops[0], r)
+        w.scc = int(r != 0)
+    return f
+
+
+def _s_ff1(bits):
+    def f(w, i):
+        v = w.rd_s(i.ops[1], bits) & ((1 << bits) - 1)
+        w.wr_s(i.ops[0], ((v & -v).bit_length() - 1) if v else 0xffffffff)
+    return f
+
+
+def _s_flbit_i32_b32(w, i):
+    v = w.rd_s(i.ops[1])
+    w.wr_s(i.ops[0], (32 - v.bit_length()) if v else 0xffffffff)
+
+
 def _s_minmax(fn, signed):
     def f(w, i):
         a, b = w.rd_s(i.ops[1]), w.rd_s(i.ops[2])
@@ -1326,6 +1386,8 @@ _OPS = {
     "s_or_b32": _s_bitop(lambda a, b: a | b, 32), "s_or_b64": _s_bitop(lambda a, b: a | b, 64),
     "s_xor_b32": _s_bitop(lambda a, b: a ^ b, 32), "s_xor_b64": _s_bitop(lambda a, b: a ^ b, 64),
     "s_andn2_b32": _s_bitop(lambda a, b: a & ~b, 32), "s_andn2_b64": _s_bitop(lambda a, b: a & ~b, 64),
+    "s_nor_b32": _s_bitop(lambda a, b: ~(a | b), 32), "s_nor_b64": _s_bitop(lambda a, b: ~(a | b), 64), "s_nand_b32": _s_bitop(lambda a, b: ~(a & b), 32),
+    "s_nand_b64": _s_bitop(lambda a, b: ~(a & b), 64), "s_xnor_b32": _s_bitop(lambda a, b: ~(a ^ b), 32), "s_xnor_b64": _s_bitop(lambda a, b: ~(a ^ b), 64),
     "s_orn2_b32": _s_bitop(lambda a, b: a | ~b, 32), "s_orn2_b64": _s_bitop(lambda a, b: a | ~b, 64),
     "s_and_saveexec_b64": _s_saveexec(lambda s, e: s & e), "s_or_saveexec_b64": _s_saveexec(lambda s, e: s | e),
     "s_xor_saveexec_b64": _s_saveexec(lambda s, e: s ^ e), "s_andn2_saveexec_b64": _s_saveexec(lambda s, e: s & ~e),
@@ -1363,6 +1425,7 @@ _OPS = {
     "v_min_u32": _vop2_int(np.minimum), "v_max_u32": _vop2_int(np.maximum),
     "v_min_i32": _vop2_int(lambda a, b: np.minimum(a.view(I32), b.view(I32)).view(U32)), "v_max_i32": _vop2_int(lambda a, b: np.maximum(a.view(I32), b.view(I32)).view(U32)),
     "v_bfrev_b32": _v_bfrev_b32, "v_ffbh_u32": _v_ffbh_u32,
+    "v_accvgpr_write_b32": _v_accvgpr_write, "v_accvgpr_read_b32": _v_accvgpr_read,
     "v_not_b32": _v_not_b32, "v_cvt_u32_f64": _v_cvt_u32_f64, "v_cvt_i32_f64": _v_cvt_i32_f64, "v_frexp_mant_f64": _v_frexp_mant_f64, "v_frexp_exp_i32_f64": _v_frexp_exp_i32_f64,
     "v_trunc_f64": _v_rounding_f64(np.trunc), "v_floor_f64": _v_rounding_f64(np.floor), "v_ceil_f64": _v_rounding_f64(np.ceil), "v_rndne_f64": _v_rounding_f64(np.rint),
     "v_lshlrev_b64": _v_shift64("l"), "v_lshrrev_b64": _v_shift64("r"), "v_ashrrev_i64": _v_shift64("a"),
@@ -1385,6 +1448,7 @@ _OPS = {
     "ds_add_u32": _ds_add_u32(False), "ds_add_rtn_u32": _ds_add_u32(True),
     "global_load_ushort": _global_load_small(2, False), "global_load_sshort": _global_load_small(2, True), "global_load_ubyte": _global_load_small(1, False),
     "global_load_sbyte": _global_load_small(1, True), "global_store_short": _global_store_small(2), "global_store_byte": _global_store_small(1),
+    "s_bcnt1_i32_b32": _s_bcnt1(32), "s_bcnt1_i32_b64": _s_bcnt1(64), "s_ff1_i32_b32": _s_ff1(32), "s_ff1_i32_b64": _s_ff1(64), "s_flbit_i32_b32": _s_flbit_i32_b32,
     "s_not_b32": _s_not(32), "s_not_b64": _s_not(64), "s_flbit_i32_b64": _s_flbit_i32_b64,
     "s_min_u32": _s_minmax(min, False), "s_max_u32": _s_minmax(max, False), "s_min_i32": _s_minmax(min, True), "s_max_i32": _s_minmax(max, True),
     "v_bitop3_b32": _v_bitop3_b32,
