@@ -1081,6 +1081,10 @@ def _s_mul_i32(w, i):
     w.wr_s(i.ops[0], (w.rd_s(i.ops[1]) * w.rd_s(i.ops[2])) & 0xffffffff)
 
 
+def _s_mul_hi_i32(w, i):
+    w.wr_s(i.ops[0], ((w.sx(w.rd_s(i.ops[1]), 32) * w.sx(w.rd_s(i.ops[2]), 32)) >> 32) & 0xffffffff)
+
+
 def _s_mul_hi_u32(w, i):
     w.wr_s(i.ops[0], ((w.rd_s(i.ops[1]) * w.rd_s(i.ops[2])) >> 32) & 0xffffffff)
 
@@ -1393,7 +1397,7 @@ _OPS = {
     "s_xor_saveexec_b64": _s_saveexec(lambda s, e: s ^ e), "s_andn2_saveexec_b64": _s_saveexec(lambda s, e: s & ~e),
     "s_orn2_saveexec_b64": _s_saveexec(lambda s, e: s | ~e), "s_andn1_saveexec_b64": _s_saveexec(lambda s, e: ~s & e),
     "s_add_u32": _s_add_u32, "s_addc_u32": _s_addc_u32, "s_sub_u32": _s_sub_u32, "s_subb_u32": _s_subb_u32, "s_add_i32": _s_add_i32, "s_sub_i32": _s_sub_i32,
-    "s_mul_i32": _s_mul_i32, "s_mul_hi_u32": _s_mul_hi_u32,
+    "s_mul_i32": _s_mul_i32, "s_mul_hi_u32": _s_mul_hi_u32, "s_mul_hi_i32": _s_mul_hi_i32,
     "s_lshl_b32": _s_shift(True, 32), "s_lshl_b64": _s_shift(True, 64), "s_lshr_b32": _s_shift(False, 32), "s_lshr_b64": _s_shift(False, 64),
     "s_ashr_i32": _s_shift(False, 32, True), "s_ashr_i64": _s_shift(False, 64, True),
     "s_bfe_i32": _s_bfe_i32, "s_bfe_u32": _s_bfe_u32, "s_brev_b32": _s_brev_b32, "s_cselect_b32": _s_cselect, "s_cselect_b64": _s_cselect,
