@@ -233,6 +233,16 @@ def scenario_streaming_results():
         assert np.array_equal(dev_view(yd, y0.shape), ref["y"][-1]), name
         assert int(ref["steps"].max()) == 102 and nl.value == 104, (name, nl.value)
         lines.append("%s %d launches" % (name, nl.value))
+        # the general kernels through the same driver (knob adv_lean = 0): the same bits, the same launches
+        dev_view(yd, y0.shape)[...] = y0
+        L.nnhip_tune_set(b"adv_lean", 0)
+        try:
+            rc = L.nnhip_ode_adaptive_stream_f64_dev(C.byref(opt), nn.ode.integrator_id(integ), f.kind, p.ctypes.data_as(dp), len(par), n, d, layout, 0.0, 1.0, yd, ws, wsb, 0, 0,
+                                                     C.byref(nl), s)
+        finally:
+            L.nnhip_tune_set(b"adv_lean", 1)
+        check_node()
+        assert rc == 0 and nl.value == 104 and np.array_equal(dev_view(yd, y0.shape), ref["y"][-1]), (name, "general kernel")
         F.hipFree(C.c_void_p(yd))
         F.hipFree(C.c_void_p(ws))
     # dense driver, both directions
@@ -352,11 +362,46 @@ def scenario_consumers_results():
     return "consumers with results: %d function-form cases, the discrete forms, the spline with every ExtrapolateKind == the reference's text" % done
 
 
+def scenario_bin_order_results():
+    """nnhip_ode_bin_order_f64_dev with its kernels running (key range, bin count, bin place): a permutation, ascending from slice to slice — for keys whose range
+    touches zero (linear bins, this round), same-signed keys over six decades (logarithmic image) and keys with NaN / inf (last)."""
+    n = 3 * 4096 + 77
+    rng = np.random.default_rng(3)
+    s = C.c_void_p()
+    assert F.hipStreamCreateWithFlags(C.byref(s), 1) == 0
+    kd = dev_alloc(0, n * 8)
+    od = dev_alloc(0, n * 4)
+    shapes = {"uniform_with_a_zero": np.concatenate([[0.0], rng.uniform(0.0, 10.0, n - 1)]), "both_signs": rng.uniform(-5.0, 10.0, n),
+              "one_sign_six_decades": -10.0 ** rng.uniform(-6.0, 0.0, n), "with_nan_and_inf": rng.uniform(-1.0, 1.0, n)}
+    shapes["with_nan_and_inf"][::97] = np.nan
+    shapes["with_nan_and_inf"][5::313] = np.inf
+    for name, keys in shapes.items():
+        rng.shuffle(keys)
+        dev_view(kd, (n,))[...] = keys
+        assert L.nnhip_ode_bin_order_f64_dev(kd, n, od, s) == 0, nn._lib.last_error()
+        check_node()
+        o = dev_view(od, (n,), np.uint32).astype(np.int64)
+        assert np.array_equal(np.sort(o), np.arange(n)), name
+        k = keys[o]
+        fin = np.isfinite(k)
+        assert fin[:fin.sum()].all(), name                                   # non-finite keys last
+        kf = k[:fin.sum()]
+        if name == "one_sign_six_decades":
+            viol = np.maximum.accumulate(np.log10(-kf[::-1]))[::-1]          # ascending keys = descending magnitudes
+            assert float((np.log10(-kf) - viol).max()) <= 6.0 / 4094 * 2.02, name
+        else:
+            viol = np.maximum.accumulate(kf) - kf
+            assert float(viol.max()) <= 1.01 * (kf.max() - kf.min()) / 4094, (name, float(viol.max()))
+    F.hipFree(C.c_void_p(kd))
+    F.hipFree(C.c_void_p(od))
+    return "order of integration: 4 key shapes, permutations ascending from slice to slice"
+
+
 def main():
     only = sys.argv[1:]
     t00 = time.time()
     for sc in (scenario_golden_fixtures, scenario_sharded_context_results, scenario_mutable_slots_results, scenario_two_threads_results, scenario_streaming_results,
-               scenario_c5_shape_with_results, scenario_consumers_results):
+               scenario_c5_shape_with_results, scenario_consumers_results, scenario_bin_order_results):
         if only and sc.__name__.replace("scenario_", "") not in only:
             continue
         t0 = time.time()

@@ -6,7 +6,8 @@ scenarios; each runs in a subprocess (LD_PRELOAD):
     NNHIP_ISA_NODE_FULL=1: all 160, recorded in profiles/r05_isa_node_full.txt);
   * what needs several GPUs or had never run: context blocks cut along 3 and 8 shards == the oracle's closures; mutable slots back from their shards; two threads with
     their own contexts; the adaptive streaming loop over the lean kernels with the automatic polling (102 iterations, 104 launches, the fused solve's bits) and the dense
-    driver; config C5's shape on 3 devices with the RCCL reassembly; the consumers' entries == the reference's text.
+    driver; config C5's shape on 3 devices with the RCCL reassembly; the consumers' entries == the reference's text; the order of integration over
+    four key shapes; the general advance kernels through the same driver (knob adv_lean = 0): the lean kernels' bits and launches.
 TEST INFRASTRUCTURE, five to six orders of magnitude slower than a GPU; the product has no CPU path and this is not one (nothing in the package or the library refers to
 it; it needs LD_PRELOAD, the ROCm LLVM tools and the build tree's object files)."""
 import os
@@ -57,6 +58,7 @@ def test_golden_fixtures_end_to_end(fake):
     ("c5_shape_with_results", 3, "every device holds the oracle's"),
     ("c5_shape_with_results", 8, "C5 shape on 8 devices"),
     ("consumers_results", 1, "== the reference's text"),
+    ("bin_order_results", 1, "permutations ascending from slice to slice"),
 ])
 def test_first_executions_with_results(fake, scenario, devices, needle):
     out = _run(fake, devices, scenario)
