@@ -307,6 +307,69 @@ def scenario_c5_shape_with_results():
     return "C5 shape on %d devices: every device holds the oracle's %d final states" % (G, n)
 
 
+def scenario_device_resident_shards_results():
+    """The two one-call entries whose shards live on the devices, on a batch with per-IVP matrices: shard r reads columns [lo_r, hi_r) of the host-bound context
+    block, the fused results are reassembled on every device (RCCL), then the fixed-step streaming loop over the same shards — == the oracle's closures."""
+    if NDEV < 3:
+        return "device-resident shards: skipped (needs 3 devices)"
+    counts = [21, 0, 17] + [3] * (NDEV - 3)
+    G, n, d = NDEV, sum(counts), 4
+    lo = np.concatenate([[0], np.cumsum(counts)])
+    rng = np.random.default_rng(29)
+    A = rng.standard_normal((n, d, d)) * 0.35 - 0.6 * np.eye(d)[None]
+    g = rng.standard_normal(d) * 0.2
+    s = 0.75
+    y0 = np.ascontiguousarray(0.5 + rng.random((d, n)))
+    per = np.ascontiguousarray(A.reshape(n, d * d).T)
+    f = nn.Rhs.custom(4, MATVEC_SRC, keys=("s",), tvalues={"g": 4, "A": 16}, per_ivp=("A",), name="matvec4_dev_isa")
+    host_bind(f, np.ascontiguousarray(g), per, None, n)
+    kw = dict(absTol=1e-7, relTol=1e-7, dtMin=1e-8, dtMax=0.25)
+    opt = nn.newODEoptions(**kw)
+    p = np.array([s])
+    ts = np.array([0.0, 0.4, 1.0])
+    ref = O.solve_ode_batch_ctx(O.RHS_MATVEC, [s] + list(g), per, None, y0, n, d, ts, O.new_options(**kw), "dopri54")
+    wsb = int(L.nnhip_ode_solve_workspace_bytes(3))
+    y0s, outs, wss, fulls = [], [], [], []
+    for r in range(G):
+        y0s.append(dev_alloc(r, d * counts[r] * 8))
+        dev_view(y0s[r], (d, counts[r]))[...] = y0[:, lo[r]:lo[r + 1]]
+        outs.append(dev_alloc(r, 3 * d * counts[r] * 8))
+        wss.append(dev_alloc(r, wsb))
+        fulls.append(dev_alloc(r, 3 * d * n * 8))
+    t_out = np.empty(3)
+    rc = L.nnhip_ode_solve_batch_multi_gpu_f64_dev(C.byref(opt), nn.ode.integrator_id("dopri54"), f.kind, p.ctypes.data_as(dp), 1, G, (C.c_int64 * G)(*counts), d, 0,
+                                                   ts.ctypes.data_as(dp), 3, t_out.ctypes.data_as(dp), arr(y0s), arr(outs), None, 0, arr(wss), wsb, arr(fulls), arr([None] * G), None)
+    check_node()
+    assert rc == 0, (nn._lib.last_error(), L.nnhip_multigpu_last_error())
+    for r in range(G):
+        assert np.array_equal(dev_view(outs[r], (3, d, counts[r])), ref["y"][:, :, lo[r]:lo[r + 1]]), r
+        assert np.array_equal(dev_view(fulls[r], (3, d, n)), ref["y"]), ("gathered", r)
+    optf = nn.newODEoptions(dt=2.0 ** -5)
+    reff = O.solve_ode_batch_ctx(O.RHS_MATVEC, [s] + list(g), per, None, y0, n, d, [0.0, 0.5], O.new_options(dt=2.0 ** -5), "rk4")
+    ys = [dev_alloc(r, d * counts[r] * 8) for r in range(G)]
+    scr = [dev_alloc(r, d * counts[r] * 8) for r in range(G)]
+    for r in range(G):
+        dev_view(ys[r], (d, counts[r]))[...] = y0[:, lo[r]:lo[r + 1]]
+    fin = (C.c_void_p * G)()
+    nst = C.c_int64(0)
+    L.nnhip_tune_set(b"stream_graph", 0)
+    try:
+        rc = L.nnhip_ode_fixed_stream_multi_gpu_f64_dev(C.byref(optf), nn.ode.integrator_id("rk4"), f.kind, p.ctypes.data_as(dp), 1, G, (C.c_int64 * G)(*counts), d, 0, 0.0, 0.5,
+                                                        arr(ys), arr(scr), None, arr([None] * G), None, C.byref(nst), fin)
+    finally:
+        L.nnhip_tune_set(b"stream_graph", -1)
+    check_node()
+    assert rc == 0 and nst.value == 16, (rc, nst.value, nn._lib.last_error())
+    for r in range(G):
+        if counts[r]:
+            got = ys[r] if fin[r] == ys[r] else scr[r]
+            assert np.array_equal(dev_view(got, (d, counts[r])), reff["y"][-1][:, lo[r]:lo[r + 1]]), r
+    for ptr in y0s + outs + wss + fulls + ys + scr:
+        F.hipFree(C.c_void_p(ptr))
+    L.nnhip_ode_rhs_release(f.kind)
+    return "device-resident shards read their columns of the context: fused + gathered + streamed == the oracle's closures on %d devices" % G
+
+
 def scenario_consumers_results():
     """The section-8-f4 consumers through their host entries, results against the reference's text: function-form cumtrapz / cumsimpson (run-time compiled integrand),
     the discrete forms, newHermiteSpline's slopes and eval / derivEval with every ExtrapolateKind."""
@@ -401,7 +464,7 @@ def main():
     only = sys.argv[1:]
     t00 = time.time()
     for sc in (scenario_golden_fixtures, scenario_sharded_context_results, scenario_mutable_slots_results, scenario_two_threads_results, scenario_streaming_results,
-               scenario_c5_shape_with_results, scenario_consumers_results, scenario_bin_order_results):
+               scenario_c5_shape_with_results, scenario_device_resident_shards_results, scenario_consumers_results, scenario_bin_order_results):
         if only and sc.__name__.replace("scenario_", "") not in only:
             continue
         t0 = time.time()

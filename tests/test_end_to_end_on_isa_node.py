@@ -57,6 +57,7 @@ def test_golden_fixtures_end_to_end(fake):
     ("streaming_results", 1, "C3 104 launches, C4 104 launches"),
     ("c5_shape_with_results", 3, "every device holds the oracle's"),
     ("c5_shape_with_results", 8, "C5 shape on 8 devices"),
+    ("device_resident_shards_results", 4, "fused + gathered + streamed == the oracle's closures on 4 devices"),
     ("consumers_results", 1, "== the reference's text"),
     ("bin_order_results", 1, "permutations ascending from slice to slice"),
 ])
