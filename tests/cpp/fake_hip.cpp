@@ -98,7 +98,9 @@ hipError_t copy(void* dst, const void* src, size_t n, hipMemcpyKind kind) {
 typedef int (*fake_launch_hook_t)(const char* name, const void* image, unsigned gx, unsigned gy, unsigned gz, unsigned bx, unsigned by, unsigned bz, void** args);
 namespace {
 fake_launch_hook_t g_hook = nullptr;
-std::map<const void*, std::string> g_kernel_names;  // host stub -> mangled device name (recorded from __hipRegisterFunction)
+// host stub -> mangled device name (recorded from __hipRegisterFunction).  Constructed on first use and never destroyed: a program LINKED against the library runs the
+// library's registration constructors before this preloaded object's own static constructors (the loader initialises a preloaded object last).
+std::map<const void*, std::string>& kernel_names() { static auto* m = new std::map<const void*, std::string>(); return *m; }
 struct FakeModule { const void* image; };
 struct FakeFunction { FakeModule* module; std::string name; };
 }  // namespace
@@ -108,7 +110,7 @@ void fake_hip_set_launch_hook(fake_launch_hook_t h) { g_hook = h; }
 // the compiler-generated registration of every kernel of a translation unit: remembered here, then handed on to the real runtime (which needs no device for it)
 void __hipRegisterFunction(void** modules, const void* hostFunction, char* deviceFunction, const char* deviceName, unsigned int threadLimit, void* tid, void* bid, void* blockDim,
                            void* gridDim, int* wSize) {
-  { std::lock_guard<std::mutex> lk(g_mu); g_kernel_names[hostFunction] = deviceName; }
+  { std::lock_guard<std::mutex> lk(g_mu); kernel_names()[hostFunction] = deviceName; }
   using Fn = void (*)(void**, const void*, char*, const char*, unsigned int, void*, void*, void*, void*, int*);
   static Fn real = (Fn)dlsym(RTLD_NEXT, "__hipRegisterFunction");
   if (real) real(modules, hostFunction, deviceFunction, deviceName, threadLimit, tid, bid, blockDim, gridDim, wSize);
@@ -201,7 +203,7 @@ hipError_t hipLaunchKernel(const void* fn, dim3 g, dim3 b, void** args, size_t, 
   if (s && ((FakeStream*)s)->capturing) ((FakeStream*)s)->captured++;
   if (g_hook) {
     std::string name;
-    { std::lock_guard<std::mutex> lk(g_mu); auto it = g_kernel_names.find(fn); if (it != g_kernel_names.end()) name = it->second; }
+    { std::lock_guard<std::mutex> lk(g_mu); auto it = kernel_names().find(fn); if (it != kernel_names().end()) name = it->second; }
     if (name.empty()) die("launch of a kernel that was never registered", fn, 0);
     return g_hook(name.c_str(), nullptr, g.x, g.y, g.z, b.x, b.y, b.z, args) == 0 ? hipSuccess : hipErrorLaunchFailure;
   }
