@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--verify-gathers", action="store_true",
                     help="debug: after every overlapped all-gather completes, compare this rank's slice of the gathered tensor with the "
                          "solve result it was issued for (checks the buffer rotation; adds a device comparison per solve)")
+    ap.add_argument("--adaptive-n", type=float, default=1e6, help="IVPs / systems of the informational C3 / C4 / heterogeneous-batch legs (BASELINE.json: 1e6; smaller only to exercise the legs)")
+    ap.add_argument("--beyond-cache-n", type=float, default=6.4e7, help="IVPs of the informational leg whose working set cannot live in the Infinity Cache (1 GB at 6.4e7)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity comparison inside the cpu_baseline leg and the all-gather placement check")
     return ap.parse_args()
 
@@ -377,7 +379,7 @@ def main():
         out["roofline"]["achieved_hbm_only"], out["roofline"]["frac_hbm_only"] = achieved, achieved / 8000.0
     if not args.no_fused and world == 1 and n <= 20_000_000:
         try:  # an informational leg must not cost the run its line: a failure is reported under informational_errors
-            nb = 64_000_000
+            nb = int(args.beyond_cache_n)
             yb = nd.c2_y0_torch(0, nb, dev)
             sb = torch.empty_like(yb)
             tb_end = 100 * dt
@@ -403,11 +405,11 @@ def main():
     if not args.no_fused and world == 1:
         try:  # an informational leg must not cost the run its line: a failure is reported under informational_errors
             cfg = {}
-            n6 = 1_000_000
+            n6 = int(args.adaptive_n)
             y3 = torch.from_numpy(np.stack([1.0 + (np.arange(n6) % 1024) * 2.0 ** -20, np.ones(n6), np.ones(n6)])).to(dev)
             y16 = torch.from_numpy(1.0 + np.arange(16)[None, :] / 16 + ((np.arange(n6) % 1024) * 2.0 ** -20)[:, None]).to(dev)
             side = torch.cuda.Stream()
-            for name, fr, yy, layout, integ, d in (("C3_dopri54_lorenz_1e6", nn.Rhs.lorenz(), y3, 0, "dopri54", 3), ("C4_tsit54_ring16_1e6", nn.Rhs.ring(0.1), y16, 1, "tsit54", 16)):
+            for name, fr, yy, layout, integ, d in (("C3_dopri54_lorenz_1e6", nn.Rhs.lorenz(), y3, 0, "dopri54", 3), ("C4_tsit54_ring16_1e6", nn.Rhs.ring(0.1), y16, 1, "tsit54", 16)):  # (names: BASELINE's sizes; "ivps" holds --adaptive-n)
                 _, yfu, cnt = nn.solveODE(fr, yy, [0.0, 1.0], nn.newODEoptions(), integrator=integ, layout=layout, return_counts=True)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -430,7 +432,7 @@ def main():
                         best = dtw if best is None or dtw < best else best
                 per_step = 8 * (2 * d + 4)  # y in / out and (t, dt) in / out; FSAL is re-evaluated per launch
                 cfg[name] = {"fused_ms": e0.elapsed_time(e1) / 3, "streamed_ms": best * 1e3, "loop_iterations": iters, "streamed_us_per_iteration": best * 1e6 / iters,
-                             "streamed_launches": int(_l),
+                             "streamed_launches": int(_l), "ivps": n6,
                              "streamed_bytes_per_step": per_step, "streamed_GBps": per_step * float(cnt["steps"].sum()) / best / 1e9,
                              "streamed_bitwise_equal_to_fused": bool(torch.equal(ys, yfu[-1])),
                              "accepted_steps": int(cnt["steps"].sum()), "fused_ivps_per_s": n6 / (e0.elapsed_time(e1) / 3 * 1e-3),
@@ -491,7 +493,7 @@ def main():
     # 1e6 separate calls with their own tEnd: in the caller's order / longest span first.  All must equal the plain solves bit for bit.
     if not args.no_fused and world == 1:
         try:  # an informational leg must not cost the run its line: a failure is reported under informational_errors
-            n6 = 1_000_000
+            n6 = int(args.adaptive_n)
             rng = np.random.default_rng(0)
             mu = torch.from_numpy(rng.uniform(0.1, 20.0, n6)[None, :].copy()).to(dev)
             yv = torch.from_numpy(np.stack([np.full(n6, 2.0), np.zeros(n6)])).to(dev)

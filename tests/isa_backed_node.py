@@ -103,6 +103,7 @@ class Node:
         except BaseException as e:  # noqa: BLE001  (an exception must not unwind through the C caller)
             import traceback
             self.errors.append("%s: %s\n%s" % (name, e, traceback.format_exc()))
+            print("isa_backed_node: launch of %s failed: %r" % (name, e), file=sys.stderr, flush=True)
             return 1
 
 

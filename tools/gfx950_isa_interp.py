@@ -867,6 +867,38 @@ def _v_cvt_f64_i32(w, i):
     w.wr_v64(i.ops[0], _vec(w.src32(i.ops[1])).view(I32).astype(F64))
 
 
+# f32 operations: the opt-in contracted build's controller estimates err^0.2 in f32 (v_log_f32 / v_exp_f32: the hardware's are ~1 ulp approximations of log2 / exp2 —
+# numpy's float32 log2 / exp2 stand in, so kernels that use them are compared within a tolerance, never bit for bit) and refines it in f64.
+F32 = np.float32
+
+
+def _f32(w, tok):
+    return _vec(w.src32(tok)).view(F32)
+
+
+def _v_cvt_f32_f64(w, i):
+    with np.errstate(all="ignore"):
+        w.wr_v32(i.ops[0], w.f64(i.ops[1]).astype(F32).view(U32))
+
+
+def _v_cvt_f64_f32(w, i):
+    w.wr_v64(i.ops[0], _f32(w, i.ops[1]).astype(F64))
+
+
+def _f32_unary(fn):
+    def f(w, i):
+        with np.errstate(all="ignore"):
+            w.wr_v32(i.ops[0], fn(_f32(w, i.ops[1])).astype(F32).view(U32))
+    return f
+
+
+def _f32_binary(fn):
+    def f(w, i):
+        with np.errstate(all="ignore"):
+            w.wr_v32(i.ops[0], fn(_f32(w, i.ops[1]), _f32(w, i.ops[2])).astype(F32).view(U32))
+    return f
+
+
 def _v_mbcnt(hi):
     def f(w, i):
         msk = w.src32(i.ops[1])
@@ -1435,6 +1467,8 @@ _OPS = {
     "v_lshlrev_b64": _v_shift64("l"), "v_lshrrev_b64": _v_shift64("r"), "v_ashrrev_i64": _v_shift64("a"),
     "v_lshl_add_u64": _v_lshl_add_u64, "v_bfe_u32": _v_bfe_u32, "v_mad_u64_u32": _v_mad_u64_u32, "v_mad_u32_u24": _v_mad_u32_u24,
     "v_cndmask_b32": _v_cndmask_b32, "v_cvt_f64_u32": _v_cvt_f64_u32, "v_cvt_f64_i32": _v_cvt_f64_i32,
+    "v_cvt_f32_f64": _v_cvt_f32_f64, "v_cvt_f64_f32": _v_cvt_f64_f32, "v_log_f32": _f32_unary(np.log2), "v_exp_f32": _f32_unary(np.exp2),
+    "v_mul_f32": _f32_binary(np.multiply), "v_add_f32": _f32_binary(np.add), "v_sub_f32": _f32_binary(np.subtract),
     "v_mbcnt_lo_u32_b32": _v_mbcnt(False), "v_mbcnt_hi_u32_b32": _v_mbcnt(True),
     "v_readlane_b32": _v_readlane, "v_readfirstlane_b32": _v_readfirstlane, "v_writelane_b32": _v_writelane,
     "global_load_dword": _global_load(1), "global_load_dwordx2": _global_load(2), "global_load_dwordx3": _global_load(3), "global_load_dwordx4": _global_load(4),
