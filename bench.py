@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--verify-gathers", action="store_true",
                     help="debug: after every overlapped all-gather completes, compare this rank's slice of the gathered tensor with the "
                          "solve result it was issued for (checks the buffer rotation; adds a device comparison per solve)")
-    ap.add_argument("--adaptive-n", type=float, default=1e6, help="IVPs / systems of the informational C3 / C4 / heterogeneous-batch legs (BASELINE.json: 1e6; smaller only to exercise the legs)")
+    ap.add_argument("--adaptive-n", type=float, default=1e6, help="IVPs / systems of the informational C3 / C4 / heterogeneous-batch legs (BASELINE.json: 1e6; smaller only to exercise the legs, 0 skips them)")
     ap.add_argument("--beyond-cache-n", type=float, default=6.4e7, help="IVPs of the informational leg whose working set cannot live in the Infinity Cache (1 GB at 6.4e7)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity comparison inside the cpu_baseline leg and the all-gather placement check")
     return ap.parse_args()
@@ -402,7 +402,7 @@ def main():
 
     # ---- informational: BASELINE.json's adaptive configs C3 / C4 (1e6 IVPs / systems), fused and through the HBM-resident loop ----
     adaptive_inputs = {}
-    if not args.no_fused and world == 1:
+    if not args.no_fused and world == 1 and args.adaptive_n >= 1:
         try:  # an informational leg must not cost the run its line: a failure is reported under informational_errors
             cfg = {}
             n6 = int(args.adaptive_n)
@@ -491,7 +491,7 @@ def main():
     # ---- informational: batches whose members take different step sequences (every reference call is its own, ode.nim:589-591) ----
     # 1e6 Van der Pol IVPs with their own stiffness in random order: as handed over / binned below the boundary (automatic probe; the caller's key), and
     # 1e6 separate calls with their own tEnd: in the caller's order / longest span first.  All must equal the plain solves bit for bit.
-    if not args.no_fused and world == 1:
+    if not args.no_fused and world == 1 and args.adaptive_n >= 1:
         try:  # an informational leg must not cost the run its line: a failure is reported under informational_errors
             n6 = int(args.adaptive_n)
             rng = np.random.default_rng(0)

@@ -1,0 +1,71 @@
+"""The Python that only ever runs on a GPU box — __graft_entry__.smoke(), bench.py, the package's device-tensor paths — executed here, without a GPU, on the
+ISA-backed fake node (tests/isa_backed_node.py) through tests/fake_torch: a stand-in for the handful of PyTorch names that Python uses, whose "cuda" tensors live in
+the fake node's tracked device memory.  The kernels that run are the library's own gfx950 code objects (tools/gfx950_isa_interp.py), the host logic is the library's,
+the Python is the file the driver will run.  Test infrastructure: what it shows is that these files execute and produce checked results; it says nothing about
+PyTorch, timing or a real device.  The wider run (the -m gpu test files themselves under the same stand-ins) is scripts/run_gpu_suite_on_isa_node.sh; its record for
+this round is profiles/r05_gpu_suite_on_isa_node.txt."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def node_env(tmp_path_factory, nn):
+    if shutil.which("g++") is None or not os.path.exists("/opt/rocm/include/rccl/rccl.h") or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("needs g++, the ROCm headers and the ROCm LLVM tools")
+    d = tmp_path_factory.mktemp("fake_node")
+    lib = str(d / "libfakehip.so")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-shared", "-fPIC", "-Wno-unused-result", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "cpp", "fake_hip.cpp"), "-o", lib])
+    os.symlink(lib, str(d / "librccl.so.1"))
+    env = dict(os.environ, LD_PRELOAD=lib, FAKE_HIP_LIB=lib, FAKE_HIP_DEVICES="1", LD_LIBRARY_PATH=str(d) + ":" + os.environ.get("LD_LIBRARY_PATH", ""),
+               PYTHONPATH=os.path.join(ROOT, "tests", "fake_torch") + ":" + ROOT)
+    env.pop("WORLD_SIZE", None)
+    return env
+
+
+def test_smoke_runs_on_the_isa_node(node_env):
+    """__graft_entry__.smoke() as the driver calls it: fused + streamed RK4, DOPRI54 on Lorenz, the dense Tsit54 streaming solve in both directions — bit-exact vs the oracle."""
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT, env=node_env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-2500:])
+    assert "smoke ok" in r.stdout and "bit-exact vs the oracle" in r.stdout, r.stdout[-500:]
+
+
+def test_bench_line_on_the_isa_node(node_env):
+    """bench.py's required path + the fused leg + the CPU baseline at a size the interpreter finishes in seconds: one JSON line, the contract's keys, the timed
+    kernel's result equal to the oracle's, the launch count of the step-streaming solve exact."""
+    r = subprocess.run([sys.executable, "bench.py", "--n-ivp", "4096", "--rk4-steps", "8", "--steps", "2", "--warmup", "1", "--adaptive-n", "0", "--beyond-cache-n", "4096",
+                        "--cpu-sample", "1000", "--cpu-ivps-per-thread", "100"], cwd=ROOT, env=node_env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-2500:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["parity_max_abs_err_vs_oracle"] == 0.0 and d["parity_checked_ivps"] == 1000
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"]) and d["roofline"]["bound"] == "hbm"
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["all_cores"]["cores"] >= 1
+    assert d["fused_solve"]["bitwise_equal_to_stream"] is True
+    assert d["beyond_infinity_cache"]["launches"] == 100
+    assert "informational_errors" not in d, d["informational_errors"]     # (--adaptive-n 0 skips the 1e6-sized legs; the others ran)
+
+
+@pytest.mark.skipif(not os.environ.get("NNHIP_ISA_NODE_FULL"), reason="~7 min: every informational leg of bench.py at 192 IVPs / systems (NNHIP_ISA_NODE_FULL=1)")
+def test_every_leg_of_bench_on_the_isa_node(node_env):
+    r = subprocess.run([sys.executable, "bench.py", "--n-ivp", "4096", "--rk4-steps", "8", "--steps", "2", "--warmup", "1", "--adaptive-n", "192", "--beyond-cache-n", "8192",
+                        "--cpu-sample", "1000", "--cpu-ivps-per-thread", "100", "--cpu-adaptive-sample", "64"], cwd=ROOT, env=node_env, capture_output=True, text=True, timeout=3000)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-2500:])
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "informational_errors" not in d, d["informational_errors"]
+    for name in ("C3_dopri54_lorenz_1e6", "C4_tsit54_ring16_1e6"):
+        c = d["adaptive_configs"][name]
+        assert c["streamed_bitwise_equal_to_fused"] and c["streamed_launches"] == c["loop_iterations"] + 2 and c["cpu_baseline"]["max_abs_dev_gpu_vs_cpu"] == 0.0
+    assert all(v["within_tolerance"] for v in d["fused_solve_fp_contract"].values())
+    assert d["heterogeneous_batches"]["sweep_bitwise_equal"] and d["heterogeneous_batches"]["calls_bitwise_equal"]
