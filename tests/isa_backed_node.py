@@ -104,6 +104,8 @@ class Node:
             import traceback
             self.errors.append("%s: %s\n%s" % (name, e, traceback.format_exc()))
             print("isa_backed_node: launch of %s failed: %r" % (name, e), file=sys.stderr, flush=True)
+            if os.environ.get("NNHIP_ISA_NODE_VERBOSE"):
+                print(self.errors[-1], file=sys.stderr, flush=True)
             return 1
 
 

@@ -277,6 +277,7 @@ class Wave:
         self.v = np.zeros((512, LANES), dtype=U32)
         self.a = np.zeros((256, LANES), dtype=U32)  # accumulation VGPRs (used as spill space by register-heavy kernels)
         self.vcc, self.scc, self.m0 = 0, 0, 0
+        self.gpr_idx = None   # VGPR indexing mode (s_set_gpr_idx_on): (index, set of SRC0 / SRC1 / SRC2 / DST) or None
         self.exec = (1 << nlanes) - 1 if nlanes < 64 else ALL
         self.pc = 0
         self.counts = collections.Counter()
@@ -589,6 +590,13 @@ class Machine:
         return stats
 
     def run_to_barrier(self, w, budget):
+        try:
+            return self._run_to_barrier(w, budget)
+        except (MemoryError, NotImplementedError, AssertionError, IndexError, ValueError, KeyError) as e:   # say where: the instruction and its address
+            i = w.k.ins[max(w.pc - 1, 0)]
+            raise type(e)("%s  [at 0x%x: %s]" % (e, i.addr, i.text)) from e
+
+    def _run_to_barrier(self, w, budget):
         k = w.k
         ins = k.ins
         while True:
@@ -601,6 +609,8 @@ class Machine:
             if fn is None:
                 fn = i.fn = _resolve(i)
             w.pc += 1
+            if w.gpr_idx is not None and i.cls.startswith("valu") and fn is not _v_mov_b32:
+                raise NotImplementedError("VGPR indexing mode is modelled for v_mov_b32 only: " + i.text)
             r = fn(w, i)
             if r == "end":
                 w.done = True
@@ -628,6 +638,13 @@ def _jump(w, i):
 
 def _s_branch(w, i):
     _jump(w, i)
+
+
+def _s_setpc(w, i):   # a computed jump inside the kernel (s_getpc + offset: switch tables, outlined blocks)
+    target = w.rd_s(i.ops[0])
+    if target not in w.k.index:
+        raise NotImplementedError("s_setpc_b64 to 0x%x, which is not an instruction of this kernel" % target)
+    w.pc = w.k.index[target]
 
 
 def _s_cbranch(cond):
@@ -769,6 +786,15 @@ def _v_div_fixup_f64(w, i):
 
 
 def _v_mov_b32(w, i):
+    if w.gpr_idx is not None:     # s_set_gpr_idx_on: M0[7:0] is added to the VGPR number of the operands the mode names
+        idx, modes = w.gpr_idx
+        src, dst = i.ops[1], i.ops[0]
+        if "SRC0" in modes and re.match(r"^v\d+$", src):
+            src = "v%d" % (int(src[1:]) + idx)
+        if "DST" in modes:
+            dst = "v%d" % (int(dst[1:]) + idx)
+        w.wr_v32(dst, w.src32(src))
+        return
     val = w.src32(i.ops[1])
     if any(k in i.mods for k in ("quad_perm", "row_ror", "row_shr", "row_shl", "row_bcast", "row_mirror", "row_half_mirror")):
         fetched, off = _dpp_fetch(w, val, i.mods)
@@ -1208,7 +1234,7 @@ def _global_load(n):
         addr = _addr(w, i, i.ops[1], i.ops[2] if len(i.ops) > 2 else None)
         r = w._reg(i.ops[0])
         for lane in np.nonzero(w.mask())[0]:
-            w.v[r[1]:r[1] + n, lane] = w.mem.read(addr[lane], 4 * n).view(U32)
+            (w.a if r[0] == "a" else w.v)[r[1]:r[1] + n, lane] = w.mem.read(addr[lane], 4 * n).view(U32)
     return f
 
 
@@ -1217,7 +1243,7 @@ def _global_store(n):
         addr = _addr(w, i, i.ops[0], i.ops[2] if len(i.ops) > 2 else None)
         r = w._reg(i.ops[1])
         for lane in np.nonzero(w.mask())[0]:
-            w.mem.write(addr[lane], np.ascontiguousarray(w.v[r[1]:r[1] + n, lane]).view(np.uint8))
+            w.mem.write(addr[lane], np.ascontiguousarray((w.a if r[0] == "a" else w.v)[r[1]:r[1] + n, lane]).view(np.uint8))
     return f
 
 
@@ -1238,7 +1264,7 @@ def _scratch_store(n):
         if w.scratch is None:
             w.scratch = np.zeros((LANES, max(w.k.scratch_bytes, 4) + 64), dtype=np.uint8)
         for lane in np.nonzero(w.mask())[0]:
-            w.scratch[lane, a[lane]:a[lane] + 4 * n] = np.ascontiguousarray(w.v[r[1]:r[1] + n, lane]).view(np.uint8)
+            w.scratch[lane, a[lane]:a[lane] + 4 * n] = np.ascontiguousarray((w.a if r[0] == "a" else w.v)[r[1]:r[1] + n, lane]).view(np.uint8)
     return f
 
 
@@ -1249,7 +1275,7 @@ def _scratch_load(n):
         if w.scratch is None:
             w.scratch = np.zeros((LANES, max(w.k.scratch_bytes, 4) + 64), dtype=np.uint8)
         for lane in np.nonzero(w.mask())[0]:
-            w.v[r[1]:r[1] + n, lane] = w.scratch[lane, a[lane]:a[lane] + 4 * n].view(U32)
+            (w.a if r[0] == "a" else w.v)[r[1]:r[1] + n, lane] = w.scratch[lane, a[lane]:a[lane] + 4 * n].view(U32)
     return f
 
 
@@ -1262,7 +1288,7 @@ def _ds_write(n):
         a = _ds_addr(w, i, i.ops[0])
         r = w._reg(i.ops[1])
         for lane in np.nonzero(w.mask())[0]:
-            w.lds[a[lane]:a[lane] + 4 * n] = np.ascontiguousarray(w.v[r[1]:r[1] + n, lane]).view(np.uint8)
+            w.lds[a[lane]:a[lane] + 4 * n] = np.ascontiguousarray((w.a if r[0] == "a" else w.v)[r[1]:r[1] + n, lane]).view(np.uint8)
     return f
 
 
@@ -1271,7 +1297,7 @@ def _ds_read(n):
         a = _ds_addr(w, i, i.ops[1])
         r = w._reg(i.ops[0])
         for lane in np.nonzero(w.mask())[0]:
-            w.v[r[1]:r[1] + n, lane] = w.lds[a[lane]:a[lane] + 4 * n].view(U32)
+            (w.a if r[0] == "a" else w.v)[r[1]:r[1] + n, lane] = w.lds[a[lane]:a[lane] + 4 * n].view(U32)
     return f
 
 
@@ -1280,7 +1306,7 @@ def _ds_or_b32(w, i):
     r = w._reg(i.ops[1])
     for lane in np.nonzero(w.mask())[0]:
         cur = w.lds[a[lane]:a[lane] + 4].view(U32)
-        cur[0] |= w.v[r[1], lane]
+        cur[0] |= (w.a if r[0] == "a" else w.v)[r[1], lane]
 
 
 def _ds_bpermute_b32(w, i):
@@ -1300,7 +1326,7 @@ def _ds_write2(n, stride):
             r = w._reg(tok)
             for lane in np.nonzero(w.mask())[0]:
                 p = a[lane] + off * unit
-                w.lds[p:p + 4 * n] = np.ascontiguousarray(w.v[r[1]:r[1] + n, lane]).view(np.uint8)
+                w.lds[p:p + 4 * n] = np.ascontiguousarray((w.a if r[0] == "a" else w.v)[r[1]:r[1] + n, lane]).view(np.uint8)
     return f
 
 
@@ -1312,7 +1338,7 @@ def _ds_read2(n, stride):
         for k, off in enumerate((i.mods.get("offset0", 0), i.mods.get("offset1", 0))):
             for lane in np.nonzero(w.mask())[0]:
                 p = a[lane] + off * unit
-                w.v[r[1] + k * n:r[1] + (k + 1) * n, lane] = w.lds[p:p + 4 * n].view(U32)
+                (w.a if r[0] == "a" else w.v)[r[1] + k * n:r[1] + (k + 1) * n, lane] = w.lds[p:p + 4 * n].view(U32)
     return f
 
 
@@ -1325,7 +1351,7 @@ def _ds_add_u32(ret):
         for lane in np.nonzero(w.mask())[0]:  # lane order: one of the legal orders of the hardware's atomics
             cur = w.lds[a[lane]:a[lane] + 4].view(U32)
             old = int(cur[0])
-            cur[0] = (old + int(w.v[r[1], lane])) & 0xffffffff
+            cur[0] = (old + int((w.a if r[0] == "a" else w.v)[r[1], lane])) & 0xffffffff
             if ret:
                 w.v[rd[1], lane] = old
     return f
@@ -1337,7 +1363,7 @@ def _global_load_small(nbytes, signed):
         r = w._reg(i.ops[0])
         for lane in np.nonzero(w.mask())[0]:
             v = int.from_bytes(bytes(w.mem.read(addr[lane], nbytes)), "little", signed=signed)
-            w.v[r[1], lane] = v & 0xffffffff
+            (w.a if r[0] == "a" else w.v)[r[1], lane] = v & 0xffffffff
     return f
 
 
@@ -1346,7 +1372,7 @@ def _global_store_small(nbytes):
         addr = _addr(w, i, i.ops[0], i.ops[2] if len(i.ops) > 2 else None)
         r = w._reg(i.ops[1])
         for lane in np.nonzero(w.mask())[0]:
-            w.mem.write(addr[lane], np.frombuffer(int(w.v[r[1], lane] & ((1 << (8 * nbytes)) - 1)).to_bytes(nbytes, "little"), dtype=np.uint8))
+            w.mem.write(addr[lane], np.frombuffer(int((w.a if r[0] == "a" else w.v)[r[1], lane] & ((1 << (8 * nbytes)) - 1)).to_bytes(nbytes, "little"), dtype=np.uint8))
     return f
 
 
@@ -1410,10 +1436,29 @@ def _nop(w, i):
     return None
 
 
+def _v_accvgpr_mov(w, i):
+    d, r = w._reg(i.ops[0]), w._reg(i.ops[1])
+    m = w.mask()
+    w.a[d[1]][m] = w.a[r[1]][m]
+
+
+def _s_set_gpr_idx_on(w, i):
+    m = re.match(r"^gpr_idx\((.*)\)$", i.ops[1])
+    modes = set(m.group(1).split(",")) if m else {n for b, n in enumerate(("SRC0", "SRC1", "SRC2", "DST")) if int(i.ops[1], 0) >> b & 1}
+    idx = w.rd_s(i.ops[0]) & 0xff
+    w.m0 = (w.m0 & ~0xf0ff) | idx | (sum(1 << b for b, n in enumerate(("SRC0", "SRC1", "SRC2", "DST")) if n in modes) << 12)
+    w.gpr_idx = (idx, modes)
+
+
+def _s_set_gpr_idx_off(w, i):
+    w.gpr_idx = None
+
+
 _OPS = {
+    "v_accvgpr_mov_b32": _v_accvgpr_mov, "s_set_gpr_idx_on": _s_set_gpr_idx_on, "s_set_gpr_idx_off": _s_set_gpr_idx_off,
     "s_nop": _nop, "s_waitcnt": _nop, "s_sleep": _nop, "s_setprio": _nop, "s_waitcnt_vscnt": _nop, "s_setreg_imm32_b32": _nop,
     "s_endpgm": lambda w, i: "end", "s_barrier": lambda w, i: "barrier",
-    "s_branch": _s_branch,
+    "s_branch": _s_branch, "s_setpc_b64": _s_setpc,
     "s_cbranch_scc0": _s_cbranch(lambda w: not w.scc), "s_cbranch_scc1": _s_cbranch(lambda w: w.scc),
     "s_cbranch_vccz": _s_cbranch(lambda w: w.vcc == 0), "s_cbranch_vccnz": _s_cbranch(lambda w: w.vcc != 0),
     "s_cbranch_execz": _s_cbranch(lambda w: w.exec == 0), "s_cbranch_execnz": _s_cbranch(lambda w: w.exec != 0),
