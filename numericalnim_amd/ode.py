@@ -15,6 +15,7 @@ torch CUDA tensors stay on the device (device-pointer entry points, torch's curr
 numpy arrays go through the host-pointer entry point.  Nothing here computes on the CPU.
 """
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -267,7 +268,13 @@ class Rhs:
         _check(_lib.lib().nnhip_ode_rhs_bind_ctx_f64_dev(self.kind, shared.data_ptr() if shared is not None else None, int(shared.numel()) if shared is not None else 0,
                                                          ivp.data_ptr() if ivp is not None else None, int(ivp.shape[0]) if ivp is not None else 0,
                                                          aux.data_ptr() if aux is not None else None, lay["n_aux"], stride))
-        self._bound = (shared, ivp, aux)  # keeps the device memory alive while calls are in flight
+        # Keeps the device memory alive while calls are in flight — per THREAD, like the library's binding: one Rhs object is shared by the threads
+        # that solve its source, and a slot on the object itself let thread A's bind free the tensors thread B's binding still pointed at (found on
+        # the fake node, whose allocation registry refused the kernel's read of the freed block: tests/test_ctx_block.py, two-thread test).
+        tls = self.__dict__.get("_bound_tls")
+        if tls is None:
+            tls = self.__dict__.setdefault("_bound_tls", threading.local())
+        tls.bound = (shared, ivp, aux)
 
     def params_all(self, ctx):
         out = []

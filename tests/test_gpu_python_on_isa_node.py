@@ -69,3 +69,37 @@ def test_every_leg_of_bench_on_the_isa_node(node_env):
         assert c["streamed_bitwise_equal_to_fused"] and c["streamed_launches"] == c["loop_iterations"] + 2 and c["cpu_baseline"]["max_abs_dev_gpu_vs_cpu"] == 0.0
     assert all(v["within_tolerance"] for v in d["fused_solve_fp_contract"].values())
     assert d["heterogeneous_batches"]["sweep_bitwise_equal"] and d["heterogeneous_batches"]["calls_bitwise_equal"]
+
+
+_TWO_THREAD_BIND = r'''
+import ctypes as C, os, threading
+import numpy as np, torch
+import numericalnim_amd as nn
+F = C.CDLL(os.environ["FAKE_HIP_LIB"]); F.fake_hip_owns.restype = C.c_int
+dev = torch.device("cuda:0")
+f = nn.Rhs.custom(2, "dy[0] = g[0] * y[1]; dy[1] = -g[1] * y[0];", tvalues={"g": 2}, name="osc")     # one Rhs object, shared by the threads
+step = threading.Barrier(2)
+ok = [None, None]
+def worker(k):
+    ctx = nn.newNumContext(tValues={"g": np.array([1.0 + k, 2.0 + k])})
+    if k == 1:
+        step.wait()                      # thread 0 has bound
+    f.bind(ctx, dev)
+    ptr = f._bound_tls.bound[0].data_ptr()     # (the address only: holding the tensor would itself keep the block alive)
+    if k == 0:
+        step.wait()
+    step.wait()                          # both have bound: thread 1's bind must not have freed what thread 0's binding points at
+    ok[k] = bool(F.fake_hip_owns(C.c_void_p(ptr), C.c_size_t(16))) and list((C.c_double * 2).from_address(ptr)) == [1.0 + k, 2.0 + k]
+th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+[t.start() for t in th]; [t.join() for t in th]
+assert ok == [True, True], ok
+print("BOTH BINDINGS ALIVE")
+'''
+
+
+def test_a_bind_of_one_thread_does_not_free_what_another_threads_binding_points_at(node_env):
+    """Found by tests/test_ctx_block.py's two-thread test on the fake node (the allocation registry refused a kernel's read of a freed block): the device tensors
+    a bind uploads were kept alive in ONE slot of the Rhs object, so thread A's bind freed the block thread B's (thread-local) library binding still pointed at —
+    on a GPU the caching allocator would have handed that block to A's next upload and B would have integrated with A's context.  The slot is per thread now."""
+    r = subprocess.run([sys.executable, "-c", _TWO_THREAD_BIND], cwd=ROOT, env=node_env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "BOTH BINDINGS ALIVE" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])

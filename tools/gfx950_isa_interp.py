@@ -1518,6 +1518,10 @@ _OPS = {
     "v_readlane_b32": _v_readlane, "v_readfirstlane_b32": _v_readfirstlane, "v_writelane_b32": _v_writelane,
     "global_load_dword": _global_load(1), "global_load_dwordx2": _global_load(2), "global_load_dwordx3": _global_load(3), "global_load_dwordx4": _global_load(4),
     "global_store_dword": _global_store(1), "global_store_dwordx2": _global_store(2), "global_store_dwordx3": _global_store(3), "global_store_dwordx4": _global_store(4),
+    # flat_*: the address decides the memory; the kernels of this library only ever hand them global addresses (an LDS / scratch aperture address would fail the
+    # memory lookup, loudly)
+    "flat_load_dword": _global_load(1), "flat_load_dwordx2": _global_load(2), "flat_load_dwordx3": _global_load(3), "flat_load_dwordx4": _global_load(4),
+    "flat_store_dword": _global_store(1), "flat_store_dwordx2": _global_store(2), "flat_store_dwordx3": _global_store(3), "flat_store_dwordx4": _global_store(4),
     "scratch_store_dword": _scratch_store(1), "scratch_store_dwordx2": _scratch_store(2), "scratch_store_dwordx4": _scratch_store(4),
     "scratch_load_dword": _scratch_load(1), "scratch_load_dwordx2": _scratch_load(2), "scratch_load_dwordx4": _scratch_load(4),
     "global_atomic_add": _global_atomic(lambda a, b: a + b, 1), "global_atomic_add_x2": _global_atomic(lambda a, b: a + b, 2),
