@@ -5,7 +5,10 @@ which no GPU could be reached.  It is only ever importable in a subprocess that 
 scripts/run_gpu_suite_on_isa_node.sh); the package, the library and bench.py know nothing of it.  "cuda" tensors live in the fake node's tracked device
 allocations (hipMalloc of the preloaded runtime), so every pointer the Python mirror hands to the C ABI is vetted like a device pointer.
 
-What it cannot show: anything about PyTorch itself (its allocator, stream semantics, dtype promotion beyond numpy's), timing, RCCL process groups."""
+torch.distributed here (distributed/__init__.py, distributed/run.py) is a launcher that starts N local ranks and a process group that exchanges .npy files: enough for
+bench.py's multi-rank path to execute with its checks on.
+
+What it cannot show: anything about PyTorch itself (its allocator, stream semantics, dtype promotion beyond numpy's), timing, RCCL / gloo."""
 import ctypes as _ct
 import os as _os
 import sys as _sys

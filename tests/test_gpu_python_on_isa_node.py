@@ -103,3 +103,43 @@ def test_a_bind_of_one_thread_does_not_free_what_another_threads_binding_points_
     on a GPU the caching allocator would have handed that block to A's next upload and B would have integrated with A's context.  The slot is per thread now."""
     r = subprocess.run([sys.executable, "-c", _TWO_THREAD_BIND], cwd=ROOT, env=node_env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "BOTH BINDINGS ALIVE" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
+
+
+def _line(r):
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-2500:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]          # only rank 0 prints
+    return json.loads(lines[0])
+
+
+def test_gpus_2_without_a_launcher_on_the_isa_node(node_env):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (the shape of the driver's N = 1 line with another N): bench.py starts its own two ranks through
+    `python -m torch.distributed.run` — here the stand-in launcher and a file-exchange process group (tests/fake_torch/torch/distributed) — each rank integrates its
+    contiguous shard on the node, every overlapped all-gather is compared with the solve it belongs to, rank 0 prints the one line.  The multi-rank path of bench.py
+    (buffer rotation, max-over-ranks timing through an all-reduce, placement check) had never executed since it was changed in round 5."""
+    env = {k: v for k, v in node_env.items() if k not in ("RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--verify-gathers", "--steps", "3", "--warmup", "1", "--n-ivp", "4096", "--rk4-steps", "8"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    d = _line(r)
+    assert d["n_gpus"] == 2 and d["world_size_reported_by_backend"] == 2 and d["config"]["backend"] == "gloo" and d["scaling"] == "weak"
+    assert d["gathers_verified"] == 4 and d["allgather_ms_per_solve"] > 0 and "cpu_baseline" not in d
+    pr = d["ms_per_step_per_rank"]
+    assert 0 < pr["min"] <= pr["max"] == d["ms_per_step"]
+    assert abs(d["value"] - 2 * 4096 * 8 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-9     # whole-job aggregate
+
+
+def test_the_drivers_eight_rank_line_on_an_eight_device_fake_node(node_env):
+    """The SCALE run's launch line as the task states it — `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus 8 --steps K --warmup W`, backend "nccl", one rank per device — on an 8-device fake node: config C5's shape end to end through bench.py."""
+    env = dict(node_env, FAKE_HIP_DEVICES="8")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29611",
+                        "bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1", "--verify-gathers", "--n-ivp", "1000", "--rk4-steps", "6"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    d = _line(r)
+    assert d["n_gpus"] == 8 and d["world_size_reported_by_backend"] == 8 and "backend" not in d["config"]        # (nccl is the default and is not spelled out)
+    assert d["gathers_verified"] == 4 and d["config"]["final_state_allgather"] and d["config"]["allgather_overlapped_with_next_solve"]
+    assert abs(d["value"] - 8 * 1000 * 6 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-9
+    # more ranks than devices over the backend that wants one device per rank: refused with a message, not a hang (2 devices, 8 ranks)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29612",
+                        "bench.py", "--gpus", "8", "--n-ivp", "1000", "--rk4-steps", "6"], cwd=ROOT, env=dict(node_env, FAKE_HIP_DEVICES="2"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "need 8 devices" in r.stderr
