@@ -47,10 +47,12 @@ cases = []
 ONLY = os.environ.get("ADV_BENCH_ONLY", "")   # e.g. "C3_lorenz_N1e+07" to profile one config
 MODES = [m for m in os.environ.get("ADV_BENCH_MODES", "").split(",") if m]     # e.g. "default,fsal_carried"
 INTEGS = [m for m in os.environ.get("ADV_BENCH_INTEGRATORS", "").split(",") if m] or ["dopri54", "tsit54"]
+NOVR = int(os.environ.get("ADV_BENCH_N", "0"))   # dry runs of this script (e.g. on the ISA-backed fake node): every batch this size; the names keep BASELINE's sizes
 for n in (1_000_000, 10_000_000):
+    label, n = f"C3_lorenz_N{n:.0e}", NOVR or n
     y0 = torch.from_numpy(np.stack([1.0 + (np.arange(n) % 1024) * 2.0 ** -20, np.ones(n), np.ones(n)])).to(dev)
-    cases.append((f"C3_lorenz_N{n:.0e}", nn.Rhs.lorenz(), y0, 0, 3, n))
-n = 1_000_000
+    cases.append((label, nn.Rhs.lorenz(), y0, 0, 3, n))
+n = NOVR or 1_000_000
 y16 = torch.from_numpy(1.0 + np.arange(16)[None, :] / 16 + ((np.arange(n) % 1024) * 2.0 ** -20)[:, None]).to(dev)
 cases.append(("C4_ring16_N1e+06", nn.Rhs.ring(0.1), y16, 1, 16, n))
 for name, f, y0, layout, d, n in cases:
