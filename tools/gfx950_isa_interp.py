@@ -958,6 +958,10 @@ def _v_writelane(w, i):
     w.v[r[1]][lane] = w.rd_s(i.ops[1]) & 0xffffffff
 
 
+def _sx24(x):   # the low 24 bits of a 32-bit lane value, sign-extended
+    return ((x.astype(I64) & 0xffffff) ^ 0x800000) - 0x800000
+
+
 def _vop3_int(fn):
     def f(w, i):
         a, b, c = (_vec(w.src32(t)) for t in i.ops[1:4])
@@ -1499,6 +1503,7 @@ _OPS = {
     "v_addc_co_u32": _v_add_co(carry_in=True), "v_subb_co_u32": _v_add_co(sub=True, carry_in=True), "v_subbrev_co_u32": _v_add_co(sub=True, rev=True, carry_in=True),
     "v_add3_u32": _vop3_int(lambda a, b, c: a + b + c), "v_lshl_add_u32": _vop3_int(lambda a, b, c: (a << (b & U32(31))) + c),
     "v_add_lshl_u32": _vop3_int(lambda a, b, c: (a + b) << (c & U32(31))), "v_lshl_or_b32": _vop3_int(lambda a, b, c: (a << (b & U32(31))) | c),
+    "v_mad_i32_i24": _vop3_int(lambda a, b, c: (_sx24(a) * _sx24(b) + c.view(I32).astype(I64)).astype(I64).astype(U64).astype(U32)),
     "v_med3_i32": _vop3_int(lambda a, b, c: np.sort(np.stack([a.view(I32), b.view(I32), c.view(I32)]), axis=0)[1].view(U32)),
     "v_med3_u32": _vop3_int(lambda a, b, c: np.sort(np.stack([a, b, c]), axis=0)[1]),
     "v_min3_i32": _vop3_int(lambda a, b, c: np.minimum(np.minimum(a.view(I32), b.view(I32)), c.view(I32)).view(U32)),
@@ -1506,6 +1511,7 @@ _OPS = {
     "v_min3_u32": _vop3_int(lambda a, b, c: np.minimum(np.minimum(a, b), c)), "v_max3_u32": _vop3_int(lambda a, b, c: np.maximum(np.maximum(a, b), c)),
     "v_and_or_b32": _vop3_int(lambda a, b, c: (a & b) | c), "v_or3_b32": _vop3_int(lambda a, b, c: a | b | c), "v_xad_u32": _vop3_int(lambda a, b, c: (a ^ b) + c),
     "v_bfi_b32": _vop3_int(lambda a, b, c: (a & b) | (~a & c)), "v_alignbit_b32": _vop3_int(lambda a, b, c: ((a.astype(U64) << U64(32) | b.astype(U64)) >> (c & U32(31)).astype(U64)).astype(U32)),
+    "v_mul_i32_i24": _vop2_int(lambda a, b: (_sx24(a) * _sx24(b)).astype(U64).astype(U32)),
     "v_mul_u32_u24": _vop2_int(lambda a, b: ((a & U32(0xffffff)).astype(U64) * (b & U32(0xffffff)).astype(U64)).astype(U32)),
     "v_mul_hi_u32": _vop2_int(lambda a, b: ((a.astype(U64) * b.astype(U64)) >> U64(32)).astype(U32)),
     "v_min_u32": _vop2_int(np.minimum), "v_max_u32": _vop2_int(np.maximum),
