@@ -1082,6 +1082,18 @@ def _s_movk_i32(w, i):
     w.wr_s(i.ops[0], w.sx(int(i.ops[1], 0) & 0xffff, 16) & 0xffffffff)
 
 
+def _s_mulk_i32(w, i):   # D = D * sext(imm16), low 32 bits; SCC untouched
+    k = w.sx(int(i.ops[1], 0) & 0xffff, 16)
+    w.wr_s(i.ops[0], (w.sx(w.rd_s(i.ops[0]), 32) * k) & 0xffffffff)
+
+
+def _s_addk_i32(w, i):   # D = D + sext(imm16); SCC = signed overflow
+    k = w.sx(int(i.ops[1], 0) & 0xffff, 16)
+    r = w.sx(w.rd_s(i.ops[0]), 32) + k
+    w.scc = int(not -(1 << 31) <= r < (1 << 31))
+    w.wr_s(i.ops[0], r & 0xffffffff)
+
+
 def _s_bitop(fn, bits):
     mask = (1 << bits) - 1
 
@@ -1466,7 +1478,7 @@ _OPS = {
     "s_cbranch_scc0": _s_cbranch(lambda w: not w.scc), "s_cbranch_scc1": _s_cbranch(lambda w: w.scc),
     "s_cbranch_vccz": _s_cbranch(lambda w: w.vcc == 0), "s_cbranch_vccnz": _s_cbranch(lambda w: w.vcc != 0),
     "s_cbranch_execz": _s_cbranch(lambda w: w.exec == 0), "s_cbranch_execnz": _s_cbranch(lambda w: w.exec != 0),
-    "s_mov_b32": _s_mov, "s_mov_b64": _s_mov, "s_movk_i32": _s_movk_i32,
+    "s_mov_b32": _s_mov, "s_mov_b64": _s_mov, "s_movk_i32": _s_movk_i32, "s_mulk_i32": _s_mulk_i32, "s_addk_i32": _s_addk_i32,
     "s_and_b32": _s_bitop(lambda a, b: a & b, 32), "s_and_b64": _s_bitop(lambda a, b: a & b, 64),
     "s_or_b32": _s_bitop(lambda a, b: a | b, 32), "s_or_b64": _s_bitop(lambda a, b: a | b, 64),
     "s_xor_b32": _s_bitop(lambda a, b: a ^ b, 32), "s_xor_b64": _s_bitop(lambda a, b: a ^ b, 64),
