@@ -1536,6 +1536,12 @@ _OPS = {
     "v_lshl_add_u64": _v_lshl_add_u64, "v_bfe_u32": _v_bfe_u32, "v_mad_u64_u32": _v_mad_u64_u32, "v_mad_u32_u24": _v_mad_u32_u24,
     "v_cndmask_b32": _v_cndmask_b32, "v_cvt_f64_u32": _v_cvt_f64_u32, "v_cvt_f64_i32": _v_cvt_f64_i32,
     "v_cvt_f32_f64": _v_cvt_f32_f64, "v_cvt_f64_f32": _v_cvt_f64_f32, "v_log_f32": _f32_unary(np.log2), "v_exp_f32": _f32_unary(np.exp2),
+    # the compiler's 32-bit integer division: an f32 reciprocal estimate, then integer correction steps that absorb the estimate's last-bit error
+    "v_cvt_f32_u32": lambda w, i: w.wr_v32(i.ops[0], _vec(w.src32(i.ops[1])).astype(F32).view(U32)),
+    "v_cvt_f32_i32": lambda w, i: w.wr_v32(i.ops[0], _vec(w.src32(i.ops[1])).view(I32).astype(F32).view(U32)),
+    "v_cvt_u32_f32": lambda w, i: w.wr_v32(i.ops[0], np.clip(np.nan_to_num(np.trunc(_f32(w, i.ops[1]).astype(F64)), nan=0.0), 0.0, 4294967295.0).astype(U64).astype(U32)),
+    "v_cvt_i32_f32": lambda w, i: w.wr_v32(i.ops[0], np.clip(np.nan_to_num(np.trunc(_f32(w, i.ops[1]).astype(F64)), nan=0.0), -2147483648.0, 2147483647.0).astype(I64).astype(I32).view(U32)),
+    "v_rcp_iflag_f32": _f32_unary(lambda x: F32(1.0) / x), "v_rcp_f32": _f32_unary(lambda x: F32(1.0) / x),
     "v_mul_f32": _f32_binary(np.multiply), "v_add_f32": _f32_binary(np.add), "v_sub_f32": _f32_binary(np.subtract),
     "v_mbcnt_lo_u32_b32": _v_mbcnt(False), "v_mbcnt_hi_u32_b32": _v_mbcnt(True),
     "v_readlane_b32": _v_readlane, "v_readfirstlane_b32": _v_readfirstlane, "v_writelane_b32": _v_writelane,
