@@ -1516,6 +1516,8 @@ _OPS = {
     "v_add3_u32": _vop3_int(lambda a, b, c: a + b + c), "v_lshl_add_u32": _vop3_int(lambda a, b, c: (a << (b & U32(31))) + c),
     "v_add_lshl_u32": _vop3_int(lambda a, b, c: (a + b) << (c & U32(31))), "v_lshl_or_b32": _vop3_int(lambda a, b, c: (a << (b & U32(31))) | c),
     "v_mad_i32_i24": _vop3_int(lambda a, b, c: (_sx24(a) * _sx24(b) + c.view(I32).astype(I64)).astype(I64).astype(U64).astype(U32)),
+    "v_mad_legacy_u16": _vop3_int(lambda a, b, c: ((a & U32(0xffff)) * (b & U32(0xffff)) + (c & U32(0xffff))) & U32(0xffff)),
+    "v_mad_u16": _vop3_int(lambda a, b, c: ((a & U32(0xffff)) * (b & U32(0xffff)) + (c & U32(0xffff))) & U32(0xffff)),
     "v_med3_i32": _vop3_int(lambda a, b, c: np.sort(np.stack([a.view(I32), b.view(I32), c.view(I32)]), axis=0)[1].view(U32)),
     "v_med3_u32": _vop3_int(lambda a, b, c: np.sort(np.stack([a, b, c]), axis=0)[1]),
     "v_min3_i32": _vop3_int(lambda a, b, c: np.minimum(np.minimum(a.view(I32), b.view(I32)), c.view(I32)).view(U32)),
@@ -1523,6 +1525,11 @@ _OPS = {
     "v_min3_u32": _vop3_int(lambda a, b, c: np.minimum(np.minimum(a, b), c)), "v_max3_u32": _vop3_int(lambda a, b, c: np.maximum(np.maximum(a, b), c)),
     "v_and_or_b32": _vop3_int(lambda a, b, c: (a & b) | c), "v_or3_b32": _vop3_int(lambda a, b, c: a | b | c), "v_xad_u32": _vop3_int(lambda a, b, c: (a ^ b) + c),
     "v_bfi_b32": _vop3_int(lambda a, b, c: (a & b) | (~a & c)), "v_alignbit_b32": _vop3_int(lambda a, b, c: ((a.astype(U64) << U64(32) | b.astype(U64)) >> (c & U32(31)).astype(U64)).astype(U32)),
+    # 16-bit integer VALU (GFX9: the result's low half, the destination's high half zeroed)
+    "v_add_u16": _vop2_int(lambda a, b: (a + b) & U32(0xffff)), "v_sub_u16": _vop2_int(lambda a, b: (a - b) & U32(0xffff)),
+    "v_subrev_u16": _vop2_int(lambda a, b: (b - a) & U32(0xffff)), "v_mul_lo_u16": _vop2_int(lambda a, b: ((a & U32(0xffff)) * (b & U32(0xffff))) & U32(0xffff)),
+    "v_lshlrev_b16": _vop2_int(lambda a, b: ((b & U32(0xffff)) << (a & U32(15))) & U32(0xffff)), "v_lshrrev_b16": _vop2_int(lambda a, b: (b & U32(0xffff)) >> (a & U32(15))),
+    "v_max_u16": _vop2_int(lambda a, b: np.maximum(a & U32(0xffff), b & U32(0xffff))), "v_min_u16": _vop2_int(lambda a, b: np.minimum(a & U32(0xffff), b & U32(0xffff))),
     "v_mul_i32_i24": _vop2_int(lambda a, b: (_sx24(a) * _sx24(b)).astype(U64).astype(U32)),
     "v_mul_u32_u24": _vop2_int(lambda a, b: ((a & U32(0xffffff)).astype(U64) * (b & U32(0xffffff)).astype(U64)).astype(U32)),
     "v_mul_hi_u32": _vop2_int(lambda a, b: ((a.astype(U64) * b.astype(U64)) >> U64(32)).astype(U32)),
