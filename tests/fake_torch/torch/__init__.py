@@ -1,8 +1,8 @@
 """TEST INFRASTRUCTURE — NOT PyTorch.  A stand-in for the few PyTorch names this repository's Python uses (device memory, streams, events, a Tensor with
 numpy semantics), for ONE purpose: to run bench.py, __graft_entry__.smoke() and the -m gpu tests' Python on the ISA-backed fake node
 (tests/isa_backed_node.py: tests/cpp/fake_hip.cpp under LD_PRELOAD + tools/gfx950_isa_interp.py executing the library's compiled gfx950 code), in a round in
-which no GPU could be reached.  It is only ever importable in a subprocess that puts tests/fake_torch first on PYTHONPATH (tests/test_gpu_suite_on_isa_node.py,
-scripts/run_gpu_suite_on_isa_node.sh); the package, the library and bench.py know nothing of it.  "cuda" tensors live in the fake node's tracked device
+which no GPU could be reached.  It is only ever importable in a subprocess that puts tests/fake_torch first on PYTHONPATH (tests/test_gpu_python_on_isa_node.py,
+scripts/run_gpu_suite_on_isa_node.py); the package, the library and bench.py know nothing of it.  "cuda" tensors live in the fake node's tracked device
 allocations (hipMalloc of the preloaded runtime), so every pointer the Python mirror hands to the C ABI is vetted like a device pointer.
 
 torch.distributed here (distributed/__init__.py, distributed/run.py) is a launcher that starts N local ranks and a process group that exchanges .npy files: enough for
@@ -17,7 +17,7 @@ import time as _time
 import numpy as _np
 
 if "FAKE_HIP_LIB" not in _os.environ:
-    raise ImportError("tests/fake_torch is a test stand-in for the ISA-backed fake node; it needs FAKE_HIP_LIB (see tests/test_gpu_suite_on_isa_node.py)")
+    raise ImportError("tests/fake_torch is a test stand-in for the ISA-backed fake node; it needs FAKE_HIP_LIB (see tests/test_gpu_python_on_isa_node.py)")
 _F = _ct.CDLL(_os.environ["FAKE_HIP_LIB"])
 __version__ = "0.0-fake-node"
 

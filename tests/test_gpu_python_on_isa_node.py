@@ -2,7 +2,7 @@
 ISA-backed fake node (tests/isa_backed_node.py) through tests/fake_torch: a stand-in for the handful of PyTorch names that Python uses, whose "cuda" tensors live in
 the fake node's tracked device memory.  The kernels that run are the library's own gfx950 code objects (tools/gfx950_isa_interp.py), the host logic is the library's,
 the Python is the file the driver will run.  Test infrastructure: what it shows is that these files execute and produce checked results; it says nothing about
-PyTorch, timing or a real device.  The wider run (the -m gpu test files themselves under the same stand-ins) is scripts/run_gpu_suite_on_isa_node.sh; its record for
+PyTorch, timing or a real device.  The wider run (the -m gpu test files themselves under the same stand-ins) is scripts/run_gpu_suite_on_isa_node.py; its record for
 this round is profiles/r05_gpu_suite_on_isa_node.txt."""
 import json
 import os
