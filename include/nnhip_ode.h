@@ -150,11 +150,15 @@ int nnhip_host_free(void* p);
  *   probe, bins the batch again by the steps still to take, and finishes: for step sizes that change late in the span; default 0 = the probe's order throughout),
  *   "sort_resume" 0|1 (1: the automatic binned solve continues from its probe's state — forward 2-point tspans, DOPRI54 / Tsit54 / BS32 / RK21 —
  *   instead of integrating the probed steps twice; default 0: within 1 % either way, the resumed pass needs the per-call instantiation of the kernel),
- *   "adv_lean" 0|1 (0: the adaptive streaming loop keeps its general kernels where the lean ones — the driver's own layout as the kernel's contract — apply; same bits),
+ *   "adv_lean" 0|1 (1: the adaptive streaming loop runs its lean kernels — the driver's own layout as the kernel's contract — where they apply; same bits.
+ *   Default 0: opt-in until an MI355X has timed them, the hardware record of round 4 is of the general kernels),
+ *   "adv_auto_poll" 0|1 (1: check_every <= 0 selects the library's own polling schedule, see nnhip_ode_adaptive_stream_f64_dev; default 0: check_every <= 0
+ *   means uniform groups of 8 launches, the behaviour with a hardware record),
  *   "fixed_vec_ipl" 0|2 (0 = one IVP per lane instead of the vectorised fixed-step streaming kernel),
  *   "multi_gpu_oversubscribe" 0|1 (nnhip_ode_solve_batch_multi_gpu_f64 accepts more shards than devices: shard r on device r mod #devices),
- *   "dim16_variant" 0..4 (A/B mappings of the fused 16-component kernels), "fp_contract" 0|1 (opt-in FMA-contracted fused
- *   kernels: NOT bit-exact, within 1e-10 / 1e-6), "host_chunks" 0..64 (0 = automatic: 8 when the caller's buffers are page-locked, else 1) and
+ *   "dim16_variant" 0..4 (A/B mappings of the fused 16-component kernels), "fp_contract" 0|1 (opt-in FMA-contracted kernels — the fused solves
+ *   of RK4 / DOPRI54 / Tsit54 / Vern65 and the lean kernels of the adaptive streaming loop, DOPRI54 / Tsit54, wherever a launch has their layout
+ *   (whatever "adv_lean" says): NOT bit-exact, within 1e-10 / 1e-6), "host_chunks" 0..64 (0 = automatic: 8 when the caller's buffers are page-locked, else 1) and
  *   "host_register" 0|1 (pipelining of the host-pointer solve) */
 /* Changing a knob drops the calling thread's hipGraph caches so that the new setting takes effect on its next call. */
 int nnhip_tune_set(const char* key, int value);
@@ -369,8 +373,8 @@ int nnhip_ode_fixed_stream_dense_f64_dev(const nnhip_ode_options* opt, int integ
  * (int32 [N], required: rows the reference returns for IVP i; rows beyond are NaN) are device pointers, tspan / t_out host.
  * Every right-hand side kind (thread-per-IVP and lanes-per-system, compiled-in and run-time compiled).  `ws`:
  * nnhip_ode_adaptive_stream_dense_workspace_bytes(N, dim, n_t) bytes.  The host polls one group of `check_every` launches behind the
- * device (launches_out counts the group issued past the end as well; check_every <= 0: the library's own schedule per direction, as
- * nnhip_ode_adaptive_stream_f64_dev's).  max_launches > 0 bounds the loop of EACH direction exactly as
+ * device (launches_out counts the group issued past the end as well; check_every <= 0: as
+ * nnhip_ode_adaptive_stream_f64_dev's, per direction).  max_launches > 0 bounds the loop of EACH direction exactly as
  * max_steps bounds the fused solve's (same rows, same ny_out); the call then returns NNHIP_TRUNCATED (> 0, all outputs written) if an
  * integration was cut short.
  * Bitwise equal to nnhip_ode_solve_batch_f64_dev. */
@@ -391,7 +395,7 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
  * every allocator's blocks are, it holds (t, dt) of an IVP side by side — one 16-byte access each way per launch; otherwise two columns).  The host
  * learns whether anyone is still integrating every `check_every` launches and always has the next group enqueued
  * before it waits (groups can be replayed from a hipGraph on a non-default stream: knob "stream_graph" = 1), so up to 2*check_every trailing launches
- * find nothing to do (they read t only).  check_every <= 0: the library's own schedule — no step is longer than dtMax, so nobody finishes within
+ * find nothing to do (they read t only).  check_every <= 0: uniform groups of 8; with knob "adv_auto_poll" = 1 the library's own schedule — no step is longer than dtMax, so nobody finishes within
  * the first ceil((tEnd - t0) / dtMax) launches, which go out unpolled; then groups of 2, 2, 4, 8, 8 ... (graph replay: uniform groups of 8).  Results are bitwise those of the fused solve.  Thread-per-IVP kernels for small
  * systems, lanes-per-system kernels for Vector[float] states of 8 / 16 / 32 ... components (ahead of time or run-time compiled). */
 /* [core] */

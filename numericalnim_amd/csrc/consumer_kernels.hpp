@@ -140,6 +140,27 @@ __global__ __launch_bounds__(kBlock) void cumsimpson_kernel(const SimpsonPair* _
   out[(int64_t)(n - 1) * M + m] = integral;  // `if x[x.high] == t[t.high]: result.add(y[y.high])` (utils.nim:300-301)
 }
 
+// sortAndTrimDataset on the device side (utils.nim:360-407; the host decides the permutation from X: dataset_plan.hpp).
+// Rows of the sorted, duplicate-free dataset gathered from the caller's (sortDataset :399-402 + the deletions of removeDuplicates :377-381); also the
+// inverse step of cumsimpson(Y, X), whose result is read back at the caller's abscissae (hermiteInterpolate, integrate.nim:375).  src[k] < 0: a NaN row
+// (rows the reference's result does not have).  Thread per (row, series).
+__global__ __launch_bounds__(kBlock) void gather_rows_kernel(const int32_t* __restrict__ src, int nRows, const double* __restrict__ Y, double* __restrict__ out, int64_t M) {
+  const int64_t m = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int k = blockIdx.y;
+  if (m >= M || k >= nRows) return;
+  const int32_t j = src[k];
+  out[(int64_t)k * M + m] = j >= 0 ? Y[(int64_t)j * M + m] : __longlong_as_double(0x7ff8000000000000LL);
+}
+// removeDuplicates' check (:367-372): rows with the same abscissa must hold the same values (`y[iy][i] != ys[iy]` raises; NaN != NaN, so a NaN
+// duplicate is impure there and here).  *flag becomes 1 if any pair differs anywhere in the batch.
+__global__ __launch_bounds__(kBlock) void dup_rows_differ_kernel(const int32_t* __restrict__ keep, const int32_t* __restrict__ drop, int nPairs, const double* __restrict__ Y,
+                                                                 int64_t M, unsigned int* __restrict__ flag) {
+  const int64_t m = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int p = blockIdx.y;
+  if (m >= M || p >= nPairs) return;
+  if (Y[(int64_t)keep[p] * M + m] != Y[(int64_t)drop[p] * M + m]) *flag = 1u;
+}
+
 inline HermSet herm_set(const double* X, int n, double x, bool deriv) {
   // findInterval (interpolate.nim:114-115): clamp(lowerbound(X, x) - 1, 0, high - 1)
   int k = (int)(std::lower_bound(X, X + n, x) - X) - 1;

@@ -23,6 +23,8 @@ nnhip_abi::SolveLaunchFn find_solve_rk4(int rhs_kind, int dim, int dim16_variant
 nnhip_abi::SolveLaunchFn find_solve_dopri54(int rhs_kind, int dim, int dim16_variant);
 nnhip_abi::SolveLaunchFn find_solve_tsit54(int rhs_kind, int dim, int dim16_variant);
 nnhip_abi::SolveLaunchFn find_solve_vern65(int rhs_kind, int dim, int dim16_variant);
+nnhip_abi::StepLaunchFn find_advance_lean_dopri54(int rhs_kind, int dim);  // ode_tu_lean_fast.hip
+nnhip_abi::StepLaunchFn find_advance_lean_tsit54(int rhs_kind, int dim);
 }  // namespace nnhip_fast
 
 namespace nnhip_capi {
@@ -73,7 +75,10 @@ int g_sort_resume = 0;     // tuning knob "sort_resume": the automatic binned so
                           // Built, bit-identical, measured and NOT the default (profiles/r04_bench_divergence.json): the resumed pass has to run on the per-call instantiation of
                           // the solve kernel (per-lane tStart / dt), which takes 1.61 ms for 122 steps where the lean one takes 1.46 ms for all 130: 1.70 vs 1.68 ms
 double g_sort_min_spread = 0.05;  // tuning knob "sort_min_spread_permille": the binned solve sorts only when the keys differ by more than this fraction of their magnitude
-int g_adv_lean = 1;       // tuning knob "adv_lean": 0 keeps the general advance kernels where the lean ones would apply (A/B, parity tests)
+int g_adv_lean = 0;       // tuning knob "adv_lean": 1 = the adaptive streaming loop runs its lean kernels (the driver's own layout as the kernel's contract) where they apply.
+                          // Same bits as the general kernels.  Opt-in until an MI355X has timed them: round 4's hardware record is of the general kernels.
+int g_adv_auto_poll = 0;  // tuning knob "adv_auto_poll": 1 = check_every <= 0 means the library's own polling schedule (adv_poll_schedule.hpp); 0 = uniform groups
+                          // of 8 launches, the behaviour with a hardware record (round 4).  Opt-in for the same reason.
 int g_adv_split = 0;      // tuning knob "adv_split": index ranges the adaptive streaming loop interleaves on separate streams (0 = auto, 1, 2, 4)
 int g_dim16_variant = 0;  // tuning knob "dim16_variant": A/B mappings of the fused 16-component kernels (see ode_kernels.hpp)
 
@@ -101,6 +106,14 @@ nnhip::StepLaunchFn find_step(int integrator, int rhs_kind, int dim) {
     NNHIP_FOR_EACH_METHOD(X)
 #undef X
   }
+  return nullptr;
+}
+
+// the FMA-contracted lean kernel of (integrator, right-hand side), or nullptr (knob "fp_contract" off, another integrator, no such instantiation)
+nnhip::StepLaunchFn find_advance_lean_contracted(int integrator, int rhs_kind, int dim) {
+  if (!g_fast_math) return nullptr;
+  if (integrator == NNHIP_DOPRI54) return nnhip_fast::find_advance_lean_dopri54(rhs_kind, dim);
+  if (integrator == NNHIP_TSIT54) return nnhip_fast::find_advance_lean_tsit54(rhs_kind, dim);
   return nullptr;
 }
 
@@ -329,7 +342,7 @@ int nnhip_tune_set(const char* key, int value) {
   release_adv_graphs();
   if (k == "host_chunks") { if (value < 0 || value > 64) return fail(NNHIP_EVALUE, "host_chunks must be 0..64"); g_host_chunks = value; return NNHIP_OK; }
   if (k == "host_register") { g_host_register = value != 0; return NNHIP_OK; }
-  if (k == "fp_contract") { g_fast_math = value != 0; return NNHIP_OK; }
+  if (k == "fp_contract") { g_fast_math = value != 0; release_adv_graphs(); return NNHIP_OK; }
   if (k == "stream_graph") { if (value < 0 || value > 2) return fail(NNHIP_EVALUE, "stream_graph must be 0, 1 or 2"); g_stream_graph = value; return NNHIP_OK; }
   if (k == "fixed_vec_ipl") { if (value != 0 && value != 2) return fail(NNHIP_EVALUE, "fixed_vec_ipl must be 0 (off) or 2"); g_fixed_vec_ipl = value; return NNHIP_OK; }
   if (k == "multi_gpu_oversubscribe") { g_mg_oversubscribe = value != 0; return NNHIP_OK; }
@@ -343,6 +356,7 @@ int nnhip_tune_set(const char* key, int value) {
   if (k == "sort_rebin_steps") { if (value < 0 || value > 1000000) return fail(NNHIP_EVALUE, "sort_rebin_steps must be in 0..1000000"); g_sort_rebin_steps = value; return NNHIP_OK; }
   if (k == "sort_resume") { if (value != 0 && value != 1) return fail(NNHIP_EVALUE, "sort_resume must be 0 or 1"); g_sort_resume = value; return NNHIP_OK; }
   if (k == "sort_min_spread_permille") { if (value < 0 || value > 1000) return fail(NNHIP_EVALUE, "sort_min_spread_permille must be in 0..1000"); g_sort_min_spread = value / 1000.0; return NNHIP_OK; }
+  if (k == "adv_auto_poll") { if (value != 0 && value != 1) return fail(NNHIP_EVALUE, "adv_auto_poll must be 0 or 1"); g_adv_auto_poll = value; return NNHIP_OK; }
   if (k == "adv_lean") { if (value != 0 && value != 1) return fail(NNHIP_EVALUE, "adv_lean must be 0 or 1"); g_adv_lean = value; release_adv_graphs(); return NNHIP_OK; }
   if (k == "adv_split") { if (value != 0 && value != 1 && value != 2 && value != 4) return fail(NNHIP_EVALUE, "adv_split must be 0, 1, 2 or 4"); g_adv_split = value; return NNHIP_OK; }
   if (k == "dim16_variant") { if (value < 0 || value > 4) return fail(NNHIP_EVALUE, "dim16_variant must be 0..4"); g_dim16_variant = value; return NNHIP_OK; }

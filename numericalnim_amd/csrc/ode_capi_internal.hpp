@@ -33,12 +33,13 @@ struct MethodInfo {
 extern const MethodInfo kMethods[NNHIP_N_INTEGRATORS];
 
 // tuning knobs (nnhip_tune_set; defined and documented in ode_capi.hip)
-extern int g_stream_graph, g_fixed_vec_ipl, g_adv_nt, g_adv_refsal, g_adv_block, g_adv_steps, g_adv_split, g_adv_lean;
+extern int g_stream_graph, g_fixed_vec_ipl, g_adv_nt, g_adv_refsal, g_adv_block, g_adv_steps, g_adv_split, g_adv_lean, g_adv_auto_poll;
 extern nnhip::StreamTune g_tune;
 extern bool g_tune_auto;
 
 nnhip::StepLaunchFn find_step(int integrator, int rhs_kind, int dim);
 nnhip::StepLaunchFn find_advance(int integrator, int rhs_kind, int dim);
+nnhip::StepLaunchFn find_advance_lean_contracted(int integrator, int rhs_kind, int dim);
 nnhip::FixedVecLaunchFn find_fixed_vec(int integrator, int rhs_kind, int dim);
 nnhip::DenseAdvLaunch find_advance_dense(int integrator, int rhs_kind, int dim);
 bool elementwise_rhs(int k);

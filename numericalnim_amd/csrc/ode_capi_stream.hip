@@ -648,7 +648,7 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
   a.noLean = g_adv_lean ? 0 : 1;
   // thread-per-IVP kernels (the lanes-per-system ones are not memory-bound enough to gain: measured -3 %); the state of one launch = y, (t, dt) and FSAL if carried
   a.nontemporal = g_adv_nt >= 0 ? g_adv_nt : ((dim <= 4 && (int64_t)sizeof(double) * ((fsalInHbm ? 2 : 1) * dim + 2) * N > (192LL << 20)) ? 1 : 0);
-  const bool autoPoll = check_every <= 0;  // the polling schedule is the library's (below); a caller's check_every is taken as given
+  const bool autoPoll = check_every <= 0 && g_adv_auto_poll;  // the polling schedule is the library's (below, knob "adv_auto_poll"); a caller's check_every is taken as given
   if (check_every <= 0) check_every = 8;
   rc = adv_poll_reserve();
   if (rc) return rc;
@@ -658,6 +658,10 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
   if (split == 0) split = 1;  // measured and rejected as a default: 1e6 Lorenz IVPs 29 us per iteration unsplit, 35 us in 2 ranges, 44 us in 4
                               // (profiles/r02_pow_tables_ab.txt) — the launches were never gap-bound: the kernel itself takes 27 us
   if ((int64_t)split > N) split = 1;
+  // knob "fp_contract": where the launch has the lean kernels' layout, the FMA-contracted lean kernel advances it (within north_star's 1e-6, not the reference's bits)
+  if (fn && split == 1 && nnhip::adv_lean_layout_ok(a, dim, layout == NNHIP_LAYOUT_AOS)) {
+    if (nnhip::StepLaunchFn contracted = find_advance_lean_contracted(integrator, rhs_kind, dim)) fn = contracted;
+  }
 
   // ---- the polling group as a graph (cached per thread; key = everything the launches depend on), one per half of the flag block ----
   std::shared_ptr<GraphExec> execs[2];  // held for the whole call: another thread's eviction / nnhip_release() cannot destroy them under it
@@ -782,7 +786,7 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
   a.rows = y_out; a.rowStride = nState;
   // state of one launch beyond the Infinity Cache: non-temporal instantiation (thread-per-IVP kernels; knob "adv_nontemporal")
   a.nontemporal = g_adv_nt >= 0 ? g_adv_nt : ((dim <= 4 && (int64_t)sizeof(double) * ((fsalInHbm ? 2 : 1) * dim + 2) * N > (192LL << 20)) ? 1 : 0);
-  const bool autoPoll = check_every <= 0;  // the library's own polling schedule (adv_poll_schedule.hpp), per direction
+  const bool autoPoll = check_every <= 0 && g_adv_auto_poll;  // the library's own polling schedule (adv_poll_schedule.hpp, knob "adv_auto_poll"), per direction
   if (check_every <= 0) check_every = 8;
   const double dtInit = std::sqrt(opt->dtMax * opt->dtMin);  // :491-493
   const dim3 grid((unsigned)((N + nnhip::kBlock - 1) / nnhip::kBlock)), block(nnhip::kBlock);

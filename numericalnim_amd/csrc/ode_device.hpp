@@ -690,11 +690,11 @@ template <> struct ClampThresholds<6> { static constexpr double hi = 1.296165915
 
 template <int ORDER>
 NNHIP_DEV double shrink_factor(double error) {
+  if (error < ClampThresholds<ORDER>::hi) return 4.0;   // (both builds: the root is within 1 ulp as well, the same margin decides the clamp)
+  if (error > ClampThresholds<ORDER>::lo) return 0.125;
 #if defined(NNHIP_FAST_ROOT)
   return nmin(4.0, nmax(0.125, 0.9 * nth_root<ORDER>(1.0 / error)));
 #else
-  if (error < ClampThresholds<ORDER>::hi) return 4.0;
-  if (error > ClampThresholds<ORDER>::lo) return 0.125;
 #if defined(NNHIP_GPOW_LDS)
   return nmin(4.0, nmax(0.125, 0.9 * nnhip_gpow::pow_pos_t<nnhip_gpow::TabLds>(1.0 / error, 1.0 / (double)ORDER)));
 #else

@@ -1082,6 +1082,21 @@ NNHIP_DEV bool adv_lean_iteration(const Ops& ops, const StepCtl& ctl, double tEn
   if (error != error) t = tEnd;  // NaN abort (same deviation as the fused driver): retire the IVP
   return t < tEnd;
 }
+// "anyone short of tEnd?" — asked only by the launch that closes a polling group (a.active != nullptr, uniform): that launch answers like the general kernels,
+// ONE store per workgroup after an OR over its waves, into its slot of the host-mapped flag block.  The launches in between (100 of BASELINE's 104) skip the
+// reduction's ~20 VALU instructions, its two LDS operations and the barrier that keeps a workgroup's waves from retiring on their own.
+#ifndef NNHIP_ADV_LEAN_REPORT  // A/B hook: 0 = every lane still integrating stores the 1 itself (one merged store per wavefront, no barrier; round 5's form)
+#define NNHIP_ADV_LEAN_REPORT 1
+#endif
+NNHIP_DEV void adv_lean_report(const AdvLeanArgs& a, unsigned int stillActive) {
+#if NNHIP_ADV_LEAN_REPORT
+  if (a.active) {
+    if (__syncthreads_or((int)stillActive) && threadIdx.x == 0) a.active[blockIdx.x % kAggSlots] = 1u;
+  }
+#else
+  if (a.active && stillActive) a.active[blockIdx.x % kAggSlots] = 1u;
+#endif
+}
 #ifdef NNHIP_ADV_LEAN_WPE
 #define NNHIP_ADV_LEAN_ATTR __attribute__((amdgpu_waves_per_eu(NNHIP_ADV_LEAN_WPE)))
 #else
@@ -1129,10 +1144,7 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_LEAN_ATTR void advance_lps_lean_k
     for (int j = 0; j < CPL; j += 2) *reinterpret_cast<double2*>(&yb[yo + j]) = make_double2(yNew[j], yNew[j + 1]);
     if (c == 0) tb[so] = make_double2(t, dt);
   }
-  // "anyone short of tEnd?": every lane that is stores the same 1 into its workgroup's slot — one store instruction per wavefront, merged by the memory pipeline.
-  // The general kernel's __syncthreads_or + single store costs a wavefront ~20 VALU instructions (DPP OR-reduction, mbcnt, readlane), two LDS operations and a
-  // barrier that keeps a workgroup's four waves from retiring on their own (dynamic count, tools/gfx950_isa_interp.py: 527 -> 507 VALU per wave on streamed C4).
-  if (a.active && stillActive) a.active[blockIdx.x % kAggSlots] = 1u;
+  adv_lean_report(a, stillActive);
 }
 // thread-per-IVP form: SoA planes y[c * N + i]; a block's part of plane c starts at y + c * N + blockIdx.x * blockDim.x (uniform)
 template <int METHOD, class RHS>
@@ -1148,35 +1160,43 @@ __global__ __launch_bounds__(kBlock) NNHIP_ADV_TPI_ATTR void advance_tpi_lean_ke
   double* const yb = a.y + i0;
   double2* const tb = a.td + i0;
   const double2 td = tb[o];
-  double t = td.x, dt = td.y;
-  unsigned int stillActive = 0;
-  if (in && t < a.tEnd) {                                                 // :511 (finished IVPs touch no other memory)
-    double y[D], yNew[D];
+  double y[D];
 #pragma unroll
-    for (int c = 0; c < D; ++c) y[c] = (yb + (int64_t)c * a.N)[o];
+  for (int c = 0; c < D; ++c) y[c] = (yb + (int64_t)c * a.N)[o];
+  double t = td.x, dt = td.y;
+  // (t, dt) AND the state in one round trip, above the branch on `t`, as in the lanes-per-system kernel: behind the branch the state loads wait for t to
+  // arrive — two dependent memory latencies per wave in a kernel whose waves start together and stay in phase (streamed C3).
+  // Finished IVPs then read (never write) their state: in a BASELINE loop that happens in the launches after the last step only.
+#pragma unroll
+  for (int c = 0; c < D; ++c) NNHIP_KEEP_VGPR(y[c]);
+  NNHIP_KEEP_VGPR(t); NNHIP_KEEP_VGPR(dt);
+  unsigned int stillActive = 0;
+  if (in && t < a.tEnd) {                                                 // :511
+    double yNew[D];
     const TpiOps<RHS, false> ops{a.P};
     stillActive = adv_lean_iteration<METHOD>(ops, a.ctl, a.tEnd, t, dt, y, yNew) ? 1u : 0u;
 #pragma unroll
     for (int c = 0; c < D; ++c) (yb + (int64_t)c * a.N)[o] = yNew[c];
     tb[o] = make_double2(t, dt);
   }
-  if (a.active && stillActive) a.active[blockIdx.x % kAggSlots] = 1u;  // (see advance_lps_lean_kernel)
+  adv_lean_report(a, stillActive);
 }
 #if !NNHIP_RTC
 // Does this launch have the layout the lean kernels are written for?  (Everything the streaming driver's default set-up produces.)
 #ifndef NNHIP_ADV_LEAN
 #define NNHIP_ADV_LEAN 1
 #endif
+inline bool adv_lean_layout_ok(const StepArgs& a, int dim, bool aos) {  // the launch record describes exactly the state the lean kernels are written for
+  if (!a.recomputeFsal || a.stepsPerLaunch > 1 || a.nontemporal) return false;
+  if (a.y_in != a.y_out || a.dt_io || !a.t_io || a.error || a.steps_io || a.perIvpParams || a.P.ivp || a.P.aux || a.tReq) return false;
+  if ((((uintptr_t)a.y_in | (uintptr_t)a.t_io) & 15) != 0) return false;
+  if (aos) return a.compStride == 1 && a.ivpStride == dim;
+  return a.ivpStride == 1 && a.compStride == a.N;
+}
 template <int METHOD>
 inline bool adv_lean_applies(const StepArgs& a, int dim, bool aos) {
   if constexpr (!(METHOD == NNHIP_DOPRI54 || METHOD == NNHIP_TSIT54)) return false;
-  else {
-    if (!NNHIP_ADV_LEAN || a.noLean || !a.recomputeFsal || a.stepsPerLaunch > 1 || a.nontemporal) return false;
-    if (a.y_in != a.y_out || a.dt_io || !a.t_io || a.error || a.steps_io || a.perIvpParams || a.P.ivp || a.P.aux || a.tReq) return false;
-    if ((((uintptr_t)a.y_in | (uintptr_t)a.t_io) & 15) != 0) return false;
-    if (aos) return a.compStride == 1 && a.ivpStride == dim;
-    return a.ivpStride == 1 && a.compStride == a.N;
-  }
+  else return NNHIP_ADV_LEAN && !a.noLean && adv_lean_layout_ok(a, dim, aos);
 }
 inline AdvLeanArgs adv_lean_args(const StepArgs& a) {
   AdvLeanArgs l{};
@@ -1568,6 +1588,28 @@ hipError_t launch_advance_lps(const StepArgs& a, int block, hipStream_t s) {
   } else {
     return hipErrorInvalidValue;
   }
+}
+#endif
+
+#if !NNHIP_RTC
+// The lean kernels on their own — what the opt-in FMA-contracted build (namespace nnhip_fast, tuning knob "fp_contract") instantiates of the streaming path:
+// the two kernels BASELINE's streamed C3 / C4 run on, over the compiled-in right-hand sides.  The caller has checked adv_lean_layout_ok; a launch record of
+// any other shape is refused, not reinterpreted.
+template <int METHOD, class RHS>
+hipError_t launch_advance_tpi_lean_only(const StepArgs& a, int block, hipStream_t s) {
+  if (!adv_lean_layout_ok(a, RHS::dim, false)) return hipErrorInvalidValue;
+  const int bs = (block == 64 || block == 128) ? block : kBlock;
+  const int64_t grid = (a.N + bs - 1) / bs;
+  if (grid <= 0) return hipSuccess;
+  return launch_kernel(advance_tpi_lean_kernel<METHOD, RHS>, dim3((unsigned)grid), dim3(bs), s, adv_lean_args(a));
+}
+template <int METHOD, class RHS, int CPL>
+hipError_t launch_advance_lps_lean_only(const StepArgs& a, int, hipStream_t s) {
+  if (!adv_lean_layout_ok(a, RHS::dim, true)) return hipErrorInvalidValue;
+  constexpr int perBlock = kBlock / (RHS::dim / CPL);
+  const int64_t grid = (a.N + perBlock - 1) / perBlock;
+  if (grid <= 0) return hipSuccess;
+  return launch_kernel(advance_lps_lean_kernel<METHOD, RHS, CPL>, dim3((unsigned)grid), dim3(kBlock), s, adv_lean_args(a));
 }
 #endif
 
@@ -2014,6 +2056,25 @@ StepLaunchFn find_advance_tpi(int rhs_kind, int dim) {
 #undef X
 #define X(kind, d, T, CA, CF) \
   if (rhs_kind == kind && dim == d) return &launch_advance_lps<METHOD, T, NNHIP_ADV_CPL(CA), ((CA) < 4 ? (CA) : 4)>;
+  NNHIP_FOR_EACH_LPS_RHS(X)
+#undef X
+  return nullptr;
+}
+
+// (rhs_kind, dim) -> the lean advance kernel alone (nullptr: the right-hand side has none); thread-per-IVP planes or lanes-per-system rows as find_advance_tpi picks them
+template <int METHOD>
+StepLaunchFn find_advance_lean(int rhs_kind, int dim) {
+  static_assert(METHOD == NNHIP_DOPRI54 || METHOD == NNHIP_TSIT54, "the lean kernels re-evaluate FSAL");
+#define X(kind, d, T) \
+  if (rhs_kind == kind && dim == d) return &launch_advance_tpi_lean_only<METHOD, T>;
+  NNHIP_FOR_EACH_TPI_RHS(X)
+#undef X
+#define X(kind, d, T, CA, CF)                                                                       \
+  if (rhs_kind == kind && dim == d) {                                                               \
+    constexpr int CPL = (CA) < 4 ? (CA) : 4; /* = launch_advance_lps's CPLR: FSAL re-evaluated */   \
+    if constexpr (CPL % 2 == 0 && adv_lps_spg(CPL) == 1 && RhsSize<T>::value == T::dim) return &launch_advance_lps_lean_only<METHOD, T, CPL>; \
+    else return nullptr;                                                                            \
+  }
   NNHIP_FOR_EACH_LPS_RHS(X)
 #undef X
   return nullptr;

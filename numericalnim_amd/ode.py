@@ -774,7 +774,8 @@ def adaptiveStreamSolve(f, y0, tspan, options=None, ctx=None, integrator="dopri5
     """solveODE (ode.nim:589-651) for an adaptive integrator THROUGH THE IntegratorProc SEAM: the whole ODESolver driver over the
     HBM-resident advance kernel, requested rows interpolated inside the launch that steps past them (nnhip_ode_adaptive_stream_dense_f64_dev).
     Returns (t, y, ny, launches); bitwise equal to solveODE.  max_launches > 0 bounds each direction's loop exactly as solveODE's
-    max_steps does (a warning is issued when it cut an integration short)."""
+    max_steps does (a warning is issued when it cut an integration short).  check_every <= 0: polling groups of 8 launches, or the
+    library's own schedule under tuning(adv_auto_poll=1)."""
     import torch
     L = _lib.lib()
     options = options if options is not None else _default_options()
@@ -810,7 +811,9 @@ def adaptiveStream(f, y, t0, tEnd, options=None, ctx=None, integrator="dopri54",
     """ODESolver's adaptive loop (ode.nim:506-542) over the HBM-resident `advance` kernel; y (CUDA tensor) is advanced
     in place from t0 to tEnd.  Returns (y, number of launches).  Bitwise equal to solveODE(f, y0, [t0, tEnd])[1][-1].
     steps_per_launch (None = leave the process-wide knob "adv_steps_per_launch" as it is, default 1): loop iterations per IVP and
-    launch; K > 1 keeps the state in registers for K iterations (same bits, 1/K of the launches, 1/K of the HBM traffic per step)."""
+    launch; K > 1 keeps the state in registers for K iterations (same bits, 1/K of the launches, 1/K of the HBM traffic per step).
+    check_every <= 0: polling groups of 8 launches, or the library's own schedule under tuning(adv_auto_poll=1); tuning(adv_lean=1)
+    selects the lean kernels (same bits), tuning(fp_contract=1) their FMA-contracted build (within 1e-6, not bit-equal)."""
     import torch
     L = _lib.lib()
     options = options if options is not None else _default_options()
@@ -829,6 +832,35 @@ def adaptiveStream(f, y, t0, tEnd, options=None, ctx=None, integrator="dopri54",
                                                    y.data_ptr(), ws.data_ptr(), wsb, int(check_every), 0, C.byref(nl),
                                                    torch.cuda.current_stream().cuda_stream))
     return y, nl.value
+
+
+# library defaults of the tuning knobs this module's callers flip (include/nnhip_ode.h, nnhip_tune_set); `tuning` restores these
+_KNOB_DEFAULTS = {"adv_lean": 0, "adv_auto_poll": 0, "fp_contract": 0, "stream_graph": 0, "adv_steps_per_launch": 1, "calls_bin": 1,
+                  "adv_recompute_fsal": -1, "adv_nontemporal": -1, "adv_block": 0, "adv_split": 0}
+
+
+class tuning:
+    """with tuning(adv_lean=1, adv_auto_poll=1): ... — process-wide tuning knobs (nnhip_tune_set) for the duration of a block, then back to the
+    library's defaults.  Opt-in settings of the adaptive streaming loop: adv_lean (its lean kernels, same bits), adv_auto_poll (its own polling
+    schedule when check_every <= 0), fp_contract (FMA-contracted kernels: within 1e-10 / 1e-6, not the reference's bits)."""
+
+    def __init__(self, **knobs):
+        unknown = [k for k in knobs if k not in _KNOB_DEFAULTS]
+        if unknown:
+            raise ValueError("tuning(): no default on record for " + ", ".join(unknown))
+        self.knobs = knobs
+
+    def __enter__(self):
+        L = _lib.lib()
+        for k, v in self.knobs.items():
+            _check(L.nnhip_tune_set(k.encode(), int(v)))
+        return self
+
+    def __exit__(self, *exc):
+        L = _lib.lib()
+        for k in self.knobs:
+            L.nnhip_tune_set(k.encode(), _KNOB_DEFAULTS[k])
+        return False
 
 
 def hostLibmMatchesDevicePow(n=20000, seed=1234):

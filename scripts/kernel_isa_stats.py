@@ -102,7 +102,10 @@ def main():
         ins = [i for i in ins if i and not i.endswith(":") and not i.startswith("s_code_end")]
         cnt = collections.Counter(classify(i) for i in ins)
         valu = sum(v for k, v in cnt.items() if k.startswith(("valu", "lane")))
-        res[name] = {"resources": META.get(name, {}), "instructions": len(ins), "valu_total": valu, "valu_f64": cnt["valu_f64"] + cnt["valu_f64_dpp"], "classes": dict(cnt.most_common())}
+        first_branch = next((k for k, i in enumerate(ins) if i.startswith(("s_cbranch", "s_branch"))), len(ins))
+        hoisted = sum(1 for i in ins[:first_branch] if i.startswith(("global_load", "flat_load", "buffer_load")))  # vector loads issued before any branch: one memory round trip
+        res[name] = {"resources": META.get(name, {}), "instructions": len(ins), "valu_total": valu, "valu_f64": cnt["valu_f64"] + cnt["valu_f64_dpp"], "classes": dict(cnt.most_common()),
+                     "loads_before_first_branch": hoisted}
         if dump:
             with open(dump, "w") as f:
                 f.write(name + "\n" + "\n".join(body) + "\n")

@@ -24,6 +24,7 @@ _FIRST_CONTACT = (
     "test_ctx_block.py::test_device_resident_shards_read_their_columns_of_the_context",
     "test_gpu_adaptive_parity.py::test_automatic_polling_schedule_wastes_at_most_two_launches_beyond_the_speculative_pair",
     "test_gpu_adaptive_parity.py::test_lean_advance_kernels_give_the_general_kernels_bits",
+    "test_gpu_adaptive_parity.py::test_streamed_fp_contract_opt_in_stays_within_north_star_tolerance",
     "test_gpu_adaptive_parity.py::test_bin_order_spends_its_bins_on_the_keys_it_gets",
     "test_gpu_bench_contract.py::test_gpus_2_without_a_launcher_starts_its_own_ranks",
     "test_gpu_bench_contract.py::test_a_launcher_of_another_size_is_refused",

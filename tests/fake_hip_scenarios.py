@@ -250,8 +250,9 @@ def scenario_streaming_drivers():
     s = C.c_void_p()
     assert F.hipStreamCreateWithFlags(C.byref(s), 1) == 0
     seen = []
-    for check_every, max_launches, want in ((0, 0, 102), (8, 0, 16), (0, 50, 50), (5, 12, 10)):
+    for check_every, max_launches, want in ((0, 0, 102), (8, 0, 16), (0, 50, 50), (5, 12, 10), (-1, 0, 16)):
         l0 = F.fake_hip_launches()
+        L.nnhip_tune_set(b"adv_auto_poll", 0 if check_every < 0 else 1)   # (-1: check_every <= 0 WITHOUT the opt-in knob = uniform groups of 8, the default)
         rc = L.nnhip_ode_adaptive_stream_f64_dev(C.byref(opt), integ, lor.kind, p.ctypes.data_as(dp), 3, n, 3, 0, 0.0, 1.0, y, ws, wsb, check_every, max_launches, C.byref(nl), s)
         assert rc in (0, nn._lib.NNHIP_TRUNCATED), nn._lib.last_error()
         assert nl.value == want, (check_every, max_launches, nl.value, want)
@@ -265,10 +266,12 @@ def scenario_streaming_drivers():
     yout = dev_alloc(0, len(ts) * 3 * n * 8)
     ny = dev_alloc(0, n * 4)
     t_out = np.empty(len(ts))
+    L.nnhip_tune_set(b"adv_auto_poll", 1)
     rc = L.nnhip_ode_adaptive_stream_dense_f64_dev(C.byref(opt), integ, lor.kind, p.ctypes.data_as(dp), 3, y0, n, 3, 0, ts.ctypes.data_as(dp), len(ts), t_out.ctypes.data_as(dp),
                                                    yout, ny, wd, wsd, 0, 0, C.byref(nl), s)
     assert rc == 0, nn._lib.last_error()
-    assert np.array_equal(t_out, np.sort(ts)) and nl.value == (100 + 2) + (30 + 2), nl.value   # forward [0, 1] and backward [0, 0.3] at dtMax = 0.01   # forward [0, 1] and backward [0, 0.3] at dtMax = 0.01
+    L.nnhip_tune_set(b"adv_auto_poll", 0)
+    assert np.array_equal(t_out, np.sort(ts)) and nl.value == (100 + 2) + (30 + 2), nl.value   # forward [0, 1] and backward [0, 0.3] at dtMax = 0.01
     # the fixed-step loop: one launch per RK4 step
     optf = nn.newODEoptions(dt=2.0 ** -10)
     yf = dev_alloc(0, n * 8)

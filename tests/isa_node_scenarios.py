@@ -225,6 +225,8 @@ def scenario_streaming_results():
         ws = dev_alloc(0, wsb)
         nl = C.c_int64(0)
         p = np.array(par)
+        L.nnhip_tune_set(b"adv_lean", 1)        # the opt-in pair of round 5: the lean kernels, the library's own polling schedule
+        L.nnhip_tune_set(b"adv_auto_poll", 1)
         rc = L.nnhip_ode_adaptive_stream_f64_dev(C.byref(opt), nn.ode.integrator_id(integ), f.kind, p.ctypes.data_as(dp), len(par), n, d, layout, 0.0, 1.0, yd, ws, wsb, 0, 0,
                                                  C.byref(nl), s)
         check_node()
@@ -240,7 +242,7 @@ def scenario_streaming_results():
             rc = L.nnhip_ode_adaptive_stream_f64_dev(C.byref(opt), nn.ode.integrator_id(integ), f.kind, p.ctypes.data_as(dp), len(par), n, d, layout, 0.0, 1.0, yd, ws, wsb, 0, 0,
                                                      C.byref(nl), s)
         finally:
-            L.nnhip_tune_set(b"adv_lean", 1)
+            L.nnhip_tune_set(b"adv_auto_poll", 0)
         check_node()
         assert rc == 0 and nl.value == 104 and np.array_equal(dev_view(yd, y0.shape), ref["y"][-1]), (name, "general kernel")
         F.hipFree(C.c_void_p(yd))

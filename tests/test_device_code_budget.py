@@ -48,20 +48,24 @@ def test_headline_kernel_is_tiny_and_spill_free(stats):
 
 
 def test_streamed_c3_kernel_keeps_four_waves(stats):
-    """advance_tpi_lean_kernel<DOPRI54, Lorenz>: 128 VGPRs = 4 waves per SIMD, no scratch, no EXEC masks spilled through lanes (the general kernel: 17 SGPR spills)."""
+    """advance_tpi_lean_kernel<DOPRI54, Lorenz>: 128 VGPRs = 4 waves per SIMD, no scratch, at most 4 scalars spilled through lanes (the general kernel: 17) —
+    round 6: the per-workgroup answer of a polled launch (adv_lean_report) keeps one more EXEC mask alive across the step: 2 v_writelane on the step path.
+    Its four loads — (t, dt) and the three planes of the state — are issued together, before the first branch (one memory round trip per wave, not two)."""
     lean, gen = _one(stats, "advance_tpi_lean_kernel"), _one(stats, "advance_tpi_kernel")
     _no_scratch(lean)
     _no_scratch(gen)
     assert lean["resources"]["vgpr_count"] <= 128 and gen["resources"]["vgpr_count"] <= 128
-    assert lean["resources"]["sgpr_spill_count"] == 0
-    assert lean["classes"].get("lane(read/writelane)", 0) <= 4 < gen["classes"].get("lane(read/writelane)", 0)
+    assert lean["resources"]["sgpr_spill_count"] <= 4
+    assert lean["classes"].get("lane(read/writelane)", 0) <= 12 < gen["classes"].get("lane(read/writelane)", 0)
     assert lean["valu_f64"] == gen["valu_f64"]                      # the same arithmetic, instruction for instruction ...
-    assert lean["valu_total"] <= gen["valu_total"] - 60            # ... and at least 60 fewer other VALU instructions around it (round 5: 919 vs 988)
+    assert lean["valu_total"] <= gen["valu_total"] - 60            # ... and at least 60 fewer other VALU instructions around it (round 6: 926 vs 988, of which ~40 in adv_lean_report)
+    assert lean["loads_before_first_branch"] >= 4
 
 
 def test_streamed_c4_kernel_keeps_three_waves(stats):
     """advance_lps_lean_kernel<Tsit54, Ring<16>, 4 components per lane>: <= 168 VGPRs = 3 waves per SIMD, no scratch, no SGPR spills; the FP64 work of the general
-    kernel with at least 90 fewer other VALU instructions (round 5: 1192 vs 1294 static; 64-bit address arithmetic 31 -> 6)."""
+    kernel with at least 90 fewer other VALU instructions (round 6: 1192 vs 1294 static, ~30 of the 1192 in adv_lean_report, which only a polled launch executes;
+    64-bit address arithmetic 31 -> 6)."""
     lean, gen = _one(stats, "advance_lps_lean_kernel"), _one(stats, "advance_lps_kernel")
     _no_scratch(lean)
     _no_scratch(gen)

@@ -1316,10 +1316,16 @@ def test_per_call_tspans_binned_by_span_are_the_same_calls(nn, dev, integrator):
 
 
 def test_automatic_polling_schedule_wastes_at_most_two_launches_beyond_the_speculative_pair(nn, dev):
-    """check_every <= 0 (the Python default): no step is longer than dtMax, so the first ceil((tEnd - t0) / dtMax) launches go out unpolled,
-    then the host polls every 2 launches (2, 2, 4, 8 ...).  BASELINE's C3 / C4 options (defaults, tspan [0, 1], dtMax 1e-2): 102 loop
-    iterations, 104 launches (uniform groups of 8 took 112) — and the bits of the fused solve, lanes-per-system form included."""
+    """check_every <= 0 under knob "adv_auto_poll" = 1 (opt-in: never run on an MI355X before this test does): no step is longer than dtMax, so the
+    first ceil((tEnd - t0) / dtMax) launches go out unpolled, then the host polls every 2 launches (2, 2, 4, 8 ...).  BASELINE's C3 / C4 options
+    (defaults, tspan [0, 1], dtMax 1e-2): 102 loop iterations, 104 launches (the default, uniform groups of 8: 112) — and the bits of the fused solve,
+    lanes-per-system form included."""
     import torch
+    with nn.tuning(adv_auto_poll=1):
+        _automatic_polling_schedule(nn, dev, torch)
+
+
+def _automatic_polling_schedule(nn, dev, torch):
     n = _sz(5000, 130)
     for f, y0, layout, integ in ((nn.Rhs.lorenz(), _lorenz_y0(n), 0, "dopri54"), (nn.Rhs.ring(0.1), _ring_y0(n, 16), 1, "tsit54")):
         yt = torch.from_numpy(y0).to(dev)
@@ -1327,6 +1333,9 @@ def test_automatic_polling_schedule_wastes_at_most_two_launches_beyond_the_specu
         ys, launches = nn.adaptiveStream(f, yt.clone(), 0.0, 1.0, integrator=integ, layout=layout)
         need = int(cnt["steps"].max())
         assert torch.equal(ys, yf[-1]) and need == 102 and launches == 104, (integ, need, launches)
+        with nn.tuning(adv_auto_poll=0):   # the default: groups of 8, the last one speculative
+            ys, launches = nn.adaptiveStream(f, yt.clone(), 0.0, 1.0, integrator=integ, layout=layout)
+        assert torch.equal(ys, yf[-1]) and launches == 112, (integ, launches)
     # a span that is not a multiple of dtMax, a batch that finishes at different launches, a bound on the launches
     opt = nn.newODEoptions(absTol=1e-7, relTol=1e-7, dtMin=1e-9, dtMax=0.03)
     yh = _lorenz_y0(_sz(4000, 130))
@@ -1374,7 +1383,7 @@ def test_lean_advance_kernels_give_the_general_kernels_bits(nn, oracle, dev):
                         assert L.nnhip_tune_set(b"adv_lean", lean) == 0
                         got[lean], launches = nn.adaptiveStream(f, yt.clone(), 0.0, 0.7, opt, integrator=integ, layout=layout)
                     finally:
-                        assert L.nnhip_tune_set(b"adv_lean", 1) == 0
+                        assert L.nnhip_tune_set(b"adv_lean", 0) == 0
                 assert torch.equal(got[1], got[0]), (name, integ, kw)
                 t, yf = nn.solveODE(f, yt, [0.0, 0.7], opt, integrator=integ, layout=layout)
                 assert torch.equal(got[1], yf[-1]), (name, integ, kw)
@@ -1382,6 +1391,35 @@ def test_lean_advance_kernels_give_the_general_kernels_bits(nn, oracle, dev):
                     n = y0.shape[1 - layout]
                     ref = O.solve_ode_batch(orc[0], orc[1], y0, n, dim, [0.0, 0.7], O.new_options(**kw), integ, layout=layout, n_threads=4)
                     assert _same_bits(got[1].cpu().numpy(), ref["y"][-1]), (name, integ, kw)
+
+
+def test_streamed_fp_contract_opt_in_stays_within_north_star_tolerance(nn, oracle, dev):
+    """Knob "fp_contract" = 1 on the adaptive streaming loop (round 6): where a launch has the lean kernels' layout — the driver's default set-up — the
+    FMA-contracted lean kernel of DOPRI54 / Tsit54 advances it (ode_tu_lean_fast.hip): BASELINE's C3 / C4 shapes, default and tight options, against the
+    oracle at north_star's tolerance for adaptive methods (1e-6 absolute per component).  Step counts can differ from the bit-exact loop on knife-edge
+    steps: the launch counts are reported in the assertion message, not asserted equal.  A launch WITHOUT that layout (FSAL carried: knob
+    adv_recompute_fsal = 0) keeps the bit-exact general kernel under the same knob, and knob off is bit-exact again."""
+    import torch
+    O = oracle
+    n = _sz(3001, 70)
+    cases = (("lorenz", nn.Rhs.lorenz(), _lorenz_y0(n), 0, 3, (O.RHS_LORENZ, LOR), "dopri54"), ("ring16", nn.Rhs.ring(0.1), _ring_y0(n, 16), 1, 16, (O.RHS_RING, [0.1]), "tsit54"),
+             ("lorenz", nn.Rhs.lorenz(), _lorenz_y0(n), 0, 3, (O.RHS_LORENZ, LOR), "tsit54"), ("ring16", nn.Rhs.ring(0.1), _ring_y0(n, 16), 1, 16, (O.RHS_RING, [0.1]), "dopri54"))
+    for name, f, y0, layout, dim, orc, integ in cases:
+        for kw in ({}, dict(absTol=1e-10, relTol=1e-10, dtMin=1e-6, dtMax=1e-1)):
+            y0 = np.ascontiguousarray(y0)
+            yt = torch.from_numpy(y0).to(dev)
+            opt = nn.newODEoptions(**kw)
+            exact, l_exact = nn.adaptiveStream(f, yt.clone(), 0.0, 1.0, opt, integrator=integ, layout=layout)
+            with nn.tuning(fp_contract=1):
+                fast, l_fast = nn.adaptiveStream(f, yt.clone(), 0.0, 1.0, opt, integrator=integ, layout=layout)
+                with nn.tuning(adv_recompute_fsal=0):   # FSAL carried through HBM: not the lean layout -> the general kernel, the reference's bits
+                    carried, _ = nn.adaptiveStream(f, yt.clone(), 0.0, 1.0, opt, integrator=integ, layout=layout)
+            again, _ = nn.adaptiveStream(f, yt.clone(), 0.0, 1.0, opt, integrator=integ, layout=layout)
+            assert torch.equal(carried, exact) and torch.equal(again, exact), (name, integ, kw)
+            ref = O.solve_ode_batch(orc[0], orc[1], y0, n, dim, [0.0, 1.0], O.new_options(**kw), integ, layout=layout, n_threads=8)
+            dev_abs = float(np.abs(fast.cpu().numpy() - ref["y"][-1]).max())
+            assert _same_bits(exact.cpu().numpy(), ref["y"][-1]), (name, integ, kw)
+            assert 0.0 < dev_abs <= TOL_ADAPTIVE, (name, integ, kw, dev_abs, "launches exact / contracted", l_exact, l_fast)
 
 
 def test_bin_order_spends_its_bins_on_the_keys_it_gets(nn, dev):

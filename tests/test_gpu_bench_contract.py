@@ -39,10 +39,16 @@ def test_single_process_line():
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
     assert out["parity_max_abs_err_vs_oracle"] == 0.0 and out["parity_checked_ivps"] == 2000
     assert out["fused_solve"]["bitwise_equal_to_stream"] is True
-    assert "informational_errors" not in out, out.get("informational_errors")
+    # informational legs never cost the line; the ones that go through settings without a hardware record (the opt-in lean kernels / polling schedule /
+    # contracted build) may report an error here without failing the contract — everything with a record must be clean
+    assert all(k.startswith("streamed_opt_in:") for k in out.get("informational_errors", {})), out.get("informational_errors")
     ac = out["adaptive_configs"]
     for name in ("C3_dopri54_lorenz_1e6", "C4_tsit54_ring16_1e6"):
-        assert ac[name]["streamed_bitwise_equal_to_fused"] is True and ac[name]["streamed_launches"] == ac[name]["loop_iterations"] + 2 == 104
+        its = ac[name]["loop_iterations"]
+        assert ac[name]["streamed_bitwise_equal_to_fused"] is True and its == 102 and its <= ac[name]["streamed_launches"] <= its + 16   # groups of 8: the last one speculative
+        for tag, o in ac[name]["streamed_opt_in"].items():   # whatever ran must be right: bits for the bit-exact settings, tolerance for the contracted one
+            assert its <= o["streamed_launches"] <= its + 16 and o["within_north_star_tolerance"] is True, (name, tag, o)
+            assert o["bitwise_equal_to_fused"] is (not tag.endswith("fp_contract")) or o["max_abs_deviation_from_fused"] == 0.0, (name, tag, o)
         cb = ac[name]["cpu_baseline"]
         assert cb["value"] > 0 and cb["all_cores"]["value"] > 0 and cb["max_abs_dev_gpu_vs_cpu"] <= 1e-6
     fc = out["fused_solve_fp_contract"]
