@@ -531,7 +531,9 @@ int nnhip_hermite_spline_f64_dev(double x, double x1, double x2, const double* y
 /* Output consumer: newHermiteSpline(X, Y, dY) + eval / derivEval (src/numericalnim/interpolate.nim:114-115,
  * 186-240, 299-390) over M independent series — e.g. M = dim*N for a trajectory tensor returned by the solver, with
  * dY = f(t_j, y_j) from nnhip_ode_rhs_batch_f64_dev (the README's (t, y, dy) recipe).
- *   X [n_knots] host, strictly ascending (what sortAndTrimDataset yields; else NNHIP_EVALUE)
+ *   X [n_knots] host, in any order: the constructor's sortAndTrimDataset(@X, @[@Y, @dY]) (interpolate.nim:231) runs here when X is not strictly
+ *   ascending — per call: a spline that is evaluated often is sorted once with nnhip_sort_and_trim_dataset_f64_dev (then nothing moves here);
+ *   NaN in X, impure duplicates (the same x with different y anywhere in the batch; ValueError utils.nim:372) and fewer than 2 distinct knots: NNHIP_EVALUE
  *   Y, dY [n_knots][M] device;  xq [n_q] host;  out [n_q][M] device
  *   deriv 0 = eval, 1 = derivEval;  extrap: 0 Constant(extrap_value) 1 Edge 2 Linear 3 Native 4 Error (ExtrapolateKind :89-90;
  *   Error out of range -> NNHIP_EVALUE, as the reference raises ValueError) */
@@ -540,16 +542,31 @@ int nnhip_hermite_spline_eval_batch_f64_dev(const double* X, int n_knots, const 
                                             void* stream);
 /* newHermiteSpline(X, Y) WITHOUT derivatives (interpolate.nim:241-253): the three-point difference slopes the reference
  * estimates — (Y1-Y0)/(X1-X0) at the ends, 0.5*((Y[i+1]-Y[i])/(X[i+1]-X[i]) + (Y[i]-Y[i-1])/(X[i]-X[i-1])) inside — over M series.
- * X [n_knots] host, strictly ascending, 2 <= n_knots <= 65535; Y, dY [n_knots][M] device.  Feed dY to the eval entry above.
- * Synchronises `stream`. */
+ * X [n_knots] host, 2 <= n_knots <= 65535; Y, dY [n_knots][M] device.  X in any order: the slopes are those of the sorted, trimmed data
+ * (interpolate.nim:244), dY row k belongs to sortAndTrimDataset's row k (rows beyond its count: NaN) — use nnhip_sort_and_trim_dataset_f64_dev for the
+ * matching X / Y.  Feed dY to the eval entry above.  Synchronises `stream`. */
 int nnhip_hermite_spline_slopes_f64_dev(const double* X, int n_knots, const double* Y, int64_t M, double* dY, void* stream);
+/* sortAndTrimDataset(x, @[y_0, ...]) (src/numericalnim/utils.nim:384-413: sorted ascending by x — equal x by original position —, of every run of equal x
+ * the first row kept, the others required to be pure duplicates of it), the front end of every discrete consumer below, as an entry of its own:
+ *   X [n] host;  Y: host array of n_y (<= 8) device pointers, each [n][M];  X_out [n] host;  Y_out: n_y device pointers [n][M], not aliasing Y;
+ *   *n_out = rows of the result; rows beyond it are NaN.  NaN in X (no defined order in the reference's comparison sort) and impure duplicates anywhere
+ *   in the batch (ValueError :372; NaN values count as different, as `!=` does there): NNHIP_EVALUE.  Strictly ascending X: a copy. */
+int nnhip_sort_and_trim_dataset_f64_dev(const double* X, int n, const double* const* Y, int n_y, int64_t M, double* X_out, double* const* Y_out, int* n_out,
+                                        void* stream);
+/* Host only: how many rows the discrete consumers return for this X — *n_sorted_trimmed (nullable) = distinct abscissae = rows of cumtrapz(Y, X) and of a
+ * spline's knots; *n_cumsimpson_rows (nullable) = rows of cumsimpson(Y, X): len(X) for unsorted X, and for sorted X the rows below the maximum plus ONE for
+ * the maximum however often it is repeated (hermiteInterpolate, utils.nim:290-301). */
+int nnhip_dataset_rows_f64(const double* X, int n, int* n_sorted_trimmed, int* n_cumsimpson_rows);
 /* Output consumer: cumtrapz(Y, X) for discrete points (src/numericalnim/integrate.nim:120-135) over M series (a trajectory
- * tensor's columns).  X [n] host, strictly ascending; Y, out [n][M] device; out[0] = Y[0]-Y[0].  trapz(Y, X) (:104-117) is the
+ * tensor's columns).  X [n] host, in any order (sortAndTrimDataset first, :131; strictly ascending X moves nothing); Y, out [n][M] device; the result has
+ * nnhip_dataset_rows_f64's n_sorted_trimmed rows, in ascending x (rows beyond: NaN); out[0] = Y[0]-Y[0].  trapz(Y, X) (:104-117) is the
  * last row for finite data. */
 int nnhip_cumtrapz_batch_f64_dev(const double* X, int n, const double* Y, int64_t M, double* out, void* stream);
 /* cumsimpson(Y, X) for discrete points (integrate.nim:329-375: composite Simpson with non-uniform weights on interval pairs,
  * three-point closure for an odd number of intervals, then hermiteInterpolate (utils.nim:282-312) with dy = Y); same layout as
- * cumtrapz; n >= 3 (else NNHIP_EVALUE, as the reference raises ValueError).  Synchronises `stream` before returning. */
+ * cumtrapz; at least 3 distinct abscissae (else NNHIP_EVALUE, as the reference raises ValueError).  X in any order: the rule runs on the sorted,
+ * trimmed data (:340) and the result is returned AT THE CALLER's abscissae, in the caller's order (:375) — nnhip_dataset_rows_f64's n_cumsimpson_rows rows,
+ * rows beyond NaN.  Synchronises `stream` before returning. */
 int nnhip_cumsimpson_batch_f64_dev(const double* X, int n, const double* Y, int64_t M, double* out, void* stream);
 /* The function-argument forms: cumtrapz(f, X, ctx, dx) (src/numericalnim/integrate.nim:138-175) and cumsimpson(f, X, ctx, dx)
  * (:377-400) — sample f on a grid of spacing dx over [min X, max X (+1)], accumulate the rule left to right, resample the running

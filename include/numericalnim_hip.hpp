@@ -321,14 +321,18 @@ inline std::vector<OdeBatch> cumtrapz(const std::vector<OdeBatch>& Y, const std:
   const std::vector<double> in = detail::flatten(Y);
   std::vector<double> out(in.size());
   throwOn(nnhip_cumtrapz_batch_f64(X.data(), (int)X.size(), in.data(), (int64_t)Y.at(0).data.size(), out.data(), device));
-  return detail::rows(out, X.size(), Y[0]);
+  int nRows = 0;  // X in any order: sorted and trimmed below the boundary (integrate.nim:131) — one row per distinct abscissa
+  throwOn(nnhip_dataset_rows_f64(X.data(), (int)X.size(), &nRows, nullptr));
+  return detail::rows(out, (size_t)nRows, Y[0]);
 }
 inline std::vector<OdeBatch> cumsimpson(const std::vector<OdeBatch>& Y, const std::vector<double>& X, int device = 0) {
   if (Y.size() != X.size()) throw std::invalid_argument("X and Y must have the same length");
   const std::vector<double> in = detail::flatten(Y);
   std::vector<double> out(in.size());
   throwOn(nnhip_cumsimpson_batch_f64(X.data(), (int)X.size(), in.data(), (int64_t)Y.at(0).data.size(), out.data(), device));
-  return detail::rows(out, X.size(), Y[0]);
+  int nRows = 0;  // the rows hermiteInterpolate yields at the caller's abscissae (integrate.nim:375)
+  throwOn(nnhip_dataset_rows_f64(X.data(), (int)X.size(), nullptr, &nRows));
+  return detail::rows(out, (size_t)nRows, Y[0]);
 }
 
 // cumtrapz(f, X, ctx, dx) / cumsimpson(f, X, ctx, dx) (integrate.nim:138-175, 377-400) for N parameter sets at once:

@@ -279,7 +279,9 @@ proc cumtrapz*(Y: openArray[OdeBatch], X: openArray[float]): seq[OdeBatch] =
   var outBuf = newSeq[cdouble](yin.len)
   let m = Y[0].data.len
   check nnhip_cumtrapz_batch_f64(addr xs[0], xs.len.cint, addr yin[0], m.int64, addr outBuf[0], 0)
-  for j in 0 ..< xs.len:
+  var rows: cint      # X in any order: the backend sorts and trims (integrate.nim:131); one row per distinct abscissa
+  check nnhip_dataset_rows_f64(addr xs[0], xs.len.cint, addr rows, nil)
+  for j in 0 ..< rows.int:
     result.add OdeBatch(n: Y[0].n, dim: Y[0].dim, layout: Y[0].layout, data: outBuf[j*m ..< (j+1)*m])
 
 proc cumsimpson*(Y: openArray[OdeBatch], X: openArray[float]): seq[OdeBatch] =
@@ -289,7 +291,9 @@ proc cumsimpson*(Y: openArray[OdeBatch], X: openArray[float]): seq[OdeBatch] =
   var outBuf = newSeq[cdouble](yin.len)
   let m = Y[0].data.len
   check nnhip_cumsimpson_batch_f64(addr xs[0], xs.len.cint, addr yin[0], m.int64, addr outBuf[0], 0)
-  for j in 0 ..< xs.len:
+  var rows: cint      # the rows hermiteInterpolate yields at the caller's abscissae (integrate.nim:375)
+  check nnhip_dataset_rows_f64(addr xs[0], xs.len.cint, nil, addr rows)
+  for j in 0 ..< rows.int:
     result.add OdeBatch(n: Y[0].n, dim: Y[0].dim, layout: Y[0].layout, data: outBuf[j*m ..< (j+1)*m])
 
 type BatchHermiteSpline* = object            ## newHermiteSpline(X, Y[, dY]) for a whole batch (interpolate.nim:216-257)

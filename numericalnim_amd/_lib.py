@@ -108,6 +108,8 @@ SIGNATURES = {
     "nnhip_ode_rhs_release": (C.c_int, [C.c_int]),
     "nnhip_hermite_spline_eval_batch_f64_dev": (C.c_int, [_dp, C.c_int, _vp, _vp, C.c_int64, _dp, C.c_int, C.c_int, C.c_int, C.c_double, _vp, _vp]),
     "nnhip_hermite_spline_slopes_f64_dev": (C.c_int, [_dp, C.c_int, _vp, C.c_int64, _vp, _vp]),
+    "nnhip_sort_and_trim_dataset_f64_dev": (C.c_int, [_dp, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int64, _dp, C.POINTER(C.c_void_p), C.POINTER(C.c_int), _vp]),
+    "nnhip_dataset_rows_f64": (C.c_int, [_dp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nnhip_cumtrapz_batch_f64_dev": (C.c_int, [_dp, C.c_int, _vp, C.c_int64, _vp, _vp]),
     "nnhip_cumsimpson_batch_f64_dev": (C.c_int, [_dp, C.c_int, _vp, C.c_int64, _vp, _vp]),
     "nnhip_cumtrapz_fn_batch_f64_dev": (C.c_int, [C.c_int, _dp, C.c_int, _vp, C.c_int, C.c_int64, C.c_int, C.c_int, _dp, C.c_int, C.c_double, _vp,

@@ -146,19 +146,20 @@ __global__ __launch_bounds__(kBlock) void cumsimpson_kernel(const SimpsonPair* _
 // (rows the reference's result does not have).  Thread per (row, series).
 __global__ __launch_bounds__(kBlock) void gather_rows_kernel(const int32_t* __restrict__ src, int nRows, const double* __restrict__ Y, double* __restrict__ out, int64_t M) {
   const int64_t m = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const int k = blockIdx.y;
-  if (m >= M || k >= nRows) return;
-  const int32_t j = src[k];
-  out[(int64_t)k * M + m] = j >= 0 ? Y[(int64_t)j * M + m] : __longlong_as_double(0x7ff8000000000000LL);
+  if (m >= M) return;
+  for (int k = blockIdx.y; k < nRows; k += gridDim.y) {  // (gridDim.y <= 65535: long series take several rows per block row)
+    const int32_t j = src[k];
+    out[(int64_t)k * M + m] = j >= 0 ? Y[(int64_t)j * M + m] : __longlong_as_double(0x7ff8000000000000LL);
+  }
 }
 // removeDuplicates' check (:367-372): rows with the same abscissa must hold the same values (`y[iy][i] != ys[iy]` raises; NaN != NaN, so a NaN
 // duplicate is impure there and here).  *flag becomes 1 if any pair differs anywhere in the batch.
 __global__ __launch_bounds__(kBlock) void dup_rows_differ_kernel(const int32_t* __restrict__ keep, const int32_t* __restrict__ drop, int nPairs, const double* __restrict__ Y,
                                                                  int64_t M, unsigned int* __restrict__ flag) {
   const int64_t m = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const int p = blockIdx.y;
-  if (m >= M || p >= nPairs) return;
-  if (Y[(int64_t)keep[p] * M + m] != Y[(int64_t)drop[p] * M + m]) *flag = 1u;
+  if (m >= M) return;
+  for (int p = blockIdx.y; p < nPairs; p += gridDim.y)
+    if (Y[(int64_t)keep[p] * M + m] != Y[(int64_t)drop[p] * M + m]) *flag = 1u;
 }
 
 inline HermSet herm_set(const double* X, int n, double x, bool deriv) {

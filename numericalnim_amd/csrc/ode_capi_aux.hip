@@ -13,6 +13,7 @@
 #include "ode_rtc.hpp"
 #include "quad_kernels.hpp"
 #include "consumer_kernels.hpp"  // (this translation unit only: the kernels in it are ordinary, non-inline __global__ functions)
+#include "dataset_plan.hpp"
 
 namespace nnhip {
 // ode_capi.hip
@@ -108,6 +109,67 @@ __global__ __launch_bounds__(kBlock) void controller_factor_kernel(const double*
   if (i < n) out[i] = shrink_factor<ORDER>(error[i]);
 }
 
+// sortAndTrimDataset (utils.nim:404-407) in front of a discrete consumer.  The permutation, the trimmed abscissae and the pairs of rows that must be pure
+// duplicates come from the host (dataset_plan.hpp); the caller's series are gathered into sorted order on the device, after the purity check (an impure
+// duplicate anywhere in the batch: NNHIP_EVALUE, the reference's ValueError :372).  Strictly ascending X — the solver's own output grid — moves nothing.
+struct SortedDataset {
+  DatasetPlan pl;
+  std::vector<double*> owned;  // gathered series [n'][M] (device)
+  int32_t* dIdx = nullptr;     // src | keep | drop
+  unsigned int* dFlag = nullptr;
+  bool touchedStream = false;
+  ~SortedDataset() {
+    for (double* p : owned) (void)hipFree(p);
+    if (dIdx) (void)hipFree(dIdx);
+    if (dFlag) (void)hipFree(dFlag);
+  }
+  int n() const { return (int)pl.x.size(); }
+  const double* X() const { return pl.x.data(); }
+};
+int sorted_dataset(const char* who, const double* X, int n, const double* const* Y, int nY, int64_t M, hipStream_t s, SortedDataset& sd, const double** sorted) {
+  std::string why;
+  if (dataset_plan(X, n, sd.pl, why) != 0) return fail_msg(NNHIP_EVALUE, "%s: %s", who, why.c_str());
+  for (int k = 0; k < nY; ++k) sorted[k] = Y[k];
+  if (sd.pl.identity || M == 0) return NNHIP_OK;
+  for (int k = 0; k < nY; ++k) if (!Y[k]) return fail_msg(NNHIP_EVALUE, "%s: a series pointer is NULL", who);
+  const DatasetPlan& pl = sd.pl;
+  const size_t nS = pl.src.size(), nD = pl.dupKeep.size();
+  std::vector<int32_t> idx(pl.src);
+  idx.insert(idx.end(), pl.dupKeep.begin(), pl.dupKeep.end());
+  idx.insert(idx.end(), pl.dupDrop.begin(), pl.dupDrop.end());
+  if (hipMalloc((void**)&sd.dIdx, idx.size() * sizeof(int32_t)) != hipSuccess) return fail_msg(NNHIP_ENOMEM, "%s: hipMalloc failed", who);
+  sd.touchedStream = true;
+  if (hipMemcpyAsync(sd.dIdx, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)  // (idx is a local)
+    return fail_msg(NNHIP_EHIP, "%s: upload of the sort permutation failed", who);
+  const unsigned gx = (unsigned)((M + kBlock - 1) / kBlock);
+  if (nD > 0) {  // removeDuplicates :367-372
+    unsigned int flag = 0;
+    if (hipMalloc((void**)&sd.dFlag, sizeof(unsigned int)) != hipSuccess) return fail_msg(NNHIP_ENOMEM, "%s: hipMalloc failed", who);
+    if (hipMemsetAsync(sd.dFlag, 0, sizeof(unsigned int), s) != hipSuccess) return fail_msg(NNHIP_EHIP, "%s: memset failed", who);
+    for (int k = 0; k < nY; ++k)
+      if (launch_kernel(dup_rows_differ_kernel, dim3(gx, (unsigned)std::min<size_t>(nD, 65535)), dim3(kBlock), s, (const int32_t*)(sd.dIdx + nS), (const int32_t*)(sd.dIdx + nS + nD), (int)nD, Y[k], M,
+                        sd.dFlag) != hipSuccess)
+        return fail_msg(NNHIP_EHIP, "%s: kernel launch failed", who);
+    if (hipMemcpyAsync(&flag, sd.dFlag, sizeof(flag), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+      return fail_msg(NNHIP_EHIP, "%s: reading the duplicate check back failed", who);
+    if (flag) return fail_msg(NNHIP_EVALUE, "%s: impure y-duplicates were found (the same x with different y; ValueError, utils.nim:372)", who);
+  }
+  for (int k = 0; k < nY; ++k) {
+    double* g = nullptr;
+    if (hipMalloc((void**)&g, nS * (size_t)M * sizeof(double)) != hipSuccess) return fail_msg(NNHIP_ENOMEM, "%s: hipMalloc failed", who);
+    sd.owned.push_back(g);
+    if (launch_kernel(gather_rows_kernel, dim3(gx, (unsigned)std::min<size_t>(nS, 65535)), dim3(kBlock), s, (const int32_t*)sd.dIdx, (int)nS, Y[k], g, M) != hipSuccess)
+      return fail_msg(NNHIP_EHIP, "%s: kernel launch failed", who);
+    sorted[k] = g;
+  }
+  return NNHIP_OK;
+}
+// rows [first, n) of out [n][M] := NaN — rows the reference's result does not have
+int nan_rows(double* out, int first, int n, int64_t M, hipStream_t s) {
+  if (first >= n || M <= 0) return NNHIP_OK;
+  return launch_fill_f64(out + (int64_t)first * M, (int64_t)(n - first) * M, __builtin_nan(""), s) == hipSuccess ? NNHIP_OK : fail_msg(NNHIP_EHIP, "fill failed");
+}
+
 }  // namespace nnhip
 
 extern "C" {
@@ -124,9 +186,17 @@ int nnhip_hermite_spline_eval_batch_f64_dev(const double* X, int n_knots, const 
                                             const double* xq, int n_q, int deriv, int extrap, double extrap_value, double* out,
                                             void* stream) {
   if (n_knots < 2 || M < 0 || n_q < 0 || !X || (n_q > 0 && !xq) || extrap < 0 || extrap > 4) return nnhip::fail_msg(NNHIP_EVALUE, "hermite spline eval: need >= 2 knots, M >= 0, n_q >= 0, non-NULL X / xq and an ExtrapolateKind in 0..4");
-  for (int i = 1; i < n_knots; ++i) if (!(X[i - 1] < X[i])) return nnhip::fail_msg(NNHIP_EVALUE, "hermite spline eval: X must be strictly ascending (X[%d] = %g, X[%d] = %g)", i - 1, X[i - 1], i, X[i]);  // sortAndTrimDataset's postcondition (:231)
+  if (M > 0 && n_q > 0 && (!Y || !dY || !out)) return nnhip::fail_msg(NNHIP_EVALUE, "hermite spline eval: Y / dY / out is NULL");
+  // newHermiteSpline(X, Y, dY) sorts and trims its data (interpolate.nim:231): knots in any order are the constructor's business, done here per call
+  // (a caller that evaluates one spline often sorts once: nnhip_sort_and_trim_dataset_f64_dev)
+  nnhip::SortedDataset sd;
+  const double* ser[2] = {Y, dY};
+  const double* srt[2];
+  if (int rcs = nnhip::sorted_dataset("newHermiteSpline(X, Y, dY)", X, n_knots, ser, 2, (n_q > 0 ? M : 0), (hipStream_t)stream, sd, srt)) return rcs;
+  if (sd.n() < 2) return nnhip::fail_msg(NNHIP_EVALUE, "hermite spline eval: fewer than 2 distinct knots");
+  struct SyncAtExit { hipStream_t s; bool on; ~SyncAtExit() { if (on) (void)hipStreamSynchronize(s); } } syncAtExit{(hipStream_t)stream, !sd.pl.identity};  // the gathered series are freed on return
+  X = sd.X(); n_knots = sd.n(); Y = srt[0]; dY = srt[1];
   if (M == 0 || n_q == 0) return NNHIP_OK;
-  if (!Y || !dY || !out) return nnhip::fail_msg(NNHIP_EVALUE, "hermite spline eval: Y / dY / out is NULL");
   if (extrap == 4) for (int q = 0; q < n_q; ++q) if (xq[q] < X[0] || xq[q] > X[n_knots - 1]) return nnhip::fail_msg(NNHIP_EVALUE, "x = %g is outside the interpolation range [%g, %g] (ExtrapolateKind.Error)", xq[q], X[0], X[n_knots - 1]);  // ValueError :340-341
   for (int q0 = 0; q0 < n_q; q0 += nnhip::kHermChunk) {
     nnhip::HermChunk c;
@@ -142,10 +212,16 @@ int nnhip_hermite_spline_eval_batch_f64_dev(const double* X, int n_knots, const 
 int nnhip_hermite_spline_slopes_f64_dev(const double* X, int n_knots, const double* Y, int64_t M, double* dY, void* stream) {
   if (n_knots < 2 || M < 0 || !X) return nnhip::fail_msg(NNHIP_EVALUE, "hermite slopes: need >= 2 knots, M >= 0 and a non-NULL X");
   if (n_knots > 65535) return nnhip::fail_msg(NNHIP_EUNSUPPORTED, "hermite slopes: at most 65535 knots (got %d)", n_knots);
-  for (int i = 1; i < n_knots; ++i) if (!(X[i - 1] < X[i])) return nnhip::fail_msg(NNHIP_EVALUE, "hermite slopes: X must be strictly ascending (X[%d] = %g, X[%d] = %g)", i - 1, X[i - 1], i, X[i]);  // sortAndTrimDataset's postcondition (:244)
-  if (M == 0) return NNHIP_OK;
-  if (!Y || !dY) return nnhip::fail_msg(NNHIP_EVALUE, "hermite slopes: Y / dY is NULL");
+  if (M > 0 && (!Y || !dY)) return nnhip::fail_msg(NNHIP_EVALUE, "hermite slopes: Y / dY is NULL");
   hipStream_t s = (hipStream_t)stream;
+  // newHermiteSpline(X, Y) estimates its slopes on the sorted, trimmed data (interpolate.nim:244-251): dY row k belongs to sortAndTrimDataset's row k
+  nnhip::SortedDataset sd;
+  const double* srt[1];
+  if (int rcs = nnhip::sorted_dataset("newHermiteSpline(X, Y)", X, n_knots, &Y, 1, M, s, sd, srt)) return rcs;
+  if (sd.n() < 2) return nnhip::fail_msg(NNHIP_EVALUE, "hermite slopes: fewer than 2 distinct knots");
+  if (int rcn = nnhip::nan_rows(dY, sd.n(), n_knots, M, s)) return rcn;
+  X = sd.X(); n_knots = sd.n(); Y = srt[0];
+  if (M == 0) return NNHIP_OK;
   double* dX = nullptr;
   if (hipMalloc((void**)&dX, (size_t)n_knots * sizeof(double)) != hipSuccess) return nnhip::fail_msg(NNHIP_ENOMEM, "hermite slopes: hipMalloc failed");
   int rc = NNHIP_OK;
@@ -159,33 +235,56 @@ int nnhip_hermite_spline_slopes_f64_dev(const double* X, int n_knots, const doub
 
 int nnhip_cumtrapz_batch_f64_dev(const double* X, int n, const double* Y, int64_t M, double* out, void* stream) {
   if (n < 1 || M < 0 || !X) return nnhip::fail_msg(NNHIP_EVALUE, "cumtrapz: need n >= 1, M >= 0 and a non-NULL X");
-  for (int i = 1; i < n; ++i) if (!(X[i - 1] < X[i])) return nnhip::fail_msg(NNHIP_EVALUE, "cumtrapz: X must be strictly ascending (X[%d] = %g, X[%d] = %g)", i - 1, X[i - 1], i, X[i]);  // sortAndTrimDataset's postcondition (:130)
+  if (M > 0 && (!Y || !out)) return nnhip::fail_msg(NNHIP_EVALUE, "cumulative quadrature: Y / out is NULL");
+  nnhip::SortedDataset sd;   // `let (xSorted, ySorted) = sortAndTrimDataset(@X, @Y)` (integrate.nim:131)
+  const double* srt[1];
+  if (int rcs = nnhip::sorted_dataset("cumtrapz(Y, X)", X, n, &Y, 1, M, (hipStream_t)stream, sd, srt)) return rcs;
   if (M == 0) return NNHIP_OK;
-  if (!Y || !out) return nnhip::fail_msg(NNHIP_EVALUE, "cumulative quadrature: Y / out is NULL");
+  if (int rcn = nnhip::nan_rows(out, sd.n(), n, M, (hipStream_t)stream)) return rcn;
+  const int ns = sd.n();
   const dim3 grid((unsigned)((M + nnhip::kBlock - 1) / nnhip::kBlock)), block(nnhip::kBlock);
   int first = 0;
   do {
     nnhip::TrapzWeights W;
-    const int nw = nnhip::trapz_weights_fill(X, n, first, W);
-    if (nnhip::launch_kernel(nnhip::cumtrapz_kernel, grid, block, (hipStream_t)stream, W, nw, first, Y, out, M) != hipSuccess) return nnhip::fail_msg(NNHIP_EHIP, "cumtrapz: kernel launch failed");
+    const int nw = nnhip::trapz_weights_fill(sd.X(), ns, first, W);
+    if (nnhip::launch_kernel(nnhip::cumtrapz_kernel, grid, block, (hipStream_t)stream, W, nw, first, srt[0], out, M) != hipSuccess) return nnhip::fail_msg(NNHIP_EHIP, "cumtrapz: kernel launch failed");
     first += nw;
-  } while (first < n - 1);
+  } while (first < ns - 1);
+  if (!sd.pl.identity && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return nnhip::fail_msg(NNHIP_EHIP, "cumtrapz: stream failed");  // the gathered series are freed on return
   return NNHIP_OK;
 }
 
 int nnhip_cumsimpson_batch_f64_dev(const double* X, int n, const double* Y, int64_t M, double* out, void* stream) {
   if (M < 0 || !X) return nnhip::fail_msg(NNHIP_EVALUE, "cumsimpson: need M >= 0 and a non-NULL X");
-  if (n < 3) return nnhip::fail_msg(NNHIP_EVALUE, "cumsimpson: X and Y must have at least 3 elements (got %d)", n);  // ValueError (integrate.nim:345-346)
-  for (int i = 1; i < n; ++i) if (!(X[i - 1] < X[i])) return nnhip::fail_msg(NNHIP_EVALUE, "cumsimpson: X must be strictly ascending (X[%d] = %g, X[%d] = %g)", i - 1, X[i - 1], i, X[i]);
+  if (n < 1) return nnhip::fail_msg(NNHIP_EVALUE, "cumsimpson: n must be >= 1");
+  if (M > 0 && (!Y || !out)) return nnhip::fail_msg(NNHIP_EVALUE, "cumulative quadrature: Y / out is NULL");
+  hipStream_t s = (hipStream_t)stream;
+  nnhip::SortedDataset sd;   // `var (xSorted, ySorted) = sortAndTrimDataset(@X, @Y)` (integrate.nim:340)
+  const double* srt[1];
+  if (int rcs = nnhip::sorted_dataset("cumsimpson(Y, X)", X, n, &Y, 1, M, s, sd, srt)) return rcs;
+  if (sd.n() < 3) return nnhip::fail_msg(NNHIP_EVALUE, "cumsimpson: X and Y must have at least 3 elements (got %d distinct abscissae)", sd.n());  // ValueError (integrate.nim:345-346)
   if (M == 0) return NNHIP_OK;
-  if (!Y || !out) return nnhip::fail_msg(NNHIP_EVALUE, "cumulative quadrature: Y / out is NULL");
+  // the rule runs on the sorted data; the result is read back at the CALLER's abscissae (hermiteInterpolate(X, xs, y, dy), :375): value at x = row rank(x)
+  std::vector<int32_t> resultRows;
+  nnhip::simpson_result_rows(sd.pl, X, n, resultRows);
+  const bool direct = sd.pl.identity;  // then row j of the result is sorted row j
+  const int nCaller = n;
+  double* outCaller = out;
+  double* sortedOut = nullptr;
+  int32_t* dRows = nullptr;
+  struct Scratch { double*& a; int32_t*& b; ~Scratch() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); } } scratch{sortedOut, dRows};
+  if (!direct) {
+    if (hipMalloc((void**)&sortedOut, (size_t)sd.n() * (size_t)M * sizeof(double)) != hipSuccess || hipMalloc((void**)&dRows, (size_t)nCaller * sizeof(int32_t)) != hipSuccess)
+      return nnhip::fail_msg(NNHIP_ENOMEM, "cumsimpson: hipMalloc failed");
+    out = sortedOut;
+  }
+  X = sd.X(); n = sd.n(); Y = srt[0];
   std::vector<nnhip::SimpsonPair> pairs;
   std::vector<nnhip::SimpsonPoint> pts;
   int64_t nPairs64 = 0;
   bool evenN = false;
   nnhip::simpson_tables(X, n, pairs, pts, nPairs64, evenN);
   const int nPairs = (int)nPairs64;
-  hipStream_t s = (hipStream_t)stream;
   nnhip::SimpsonPair* dPairs = nullptr;
   nnhip::SimpsonPoint* dPts = nullptr;
   if (hipMalloc((void**)&dPairs, pairs.size() * sizeof(pairs[0])) != hipSuccess) return nnhip::fail_msg(NNHIP_ENOMEM, "cumsimpson: hipMalloc failed");
@@ -198,10 +297,51 @@ int nnhip_cumsimpson_batch_f64_dev(const double* X, int n, const double* Y, int6
   if (!rc && nnhip::launch_kernel(nnhip::cumsimpson_kernel, grid, block, s, (const nnhip::SimpsonPair*)dPairs, nPairs, evenN ? 1 : 0,
                                   (const nnhip::SimpsonPoint*)dPts, Y, out, M, n) != hipSuccess)
     rc = NNHIP_EHIP;
+  if (!rc && !direct) {
+    resultRows.resize((size_t)nCaller, -1);  // rows the reference's result does not have (a repeated maximum of a sorted X): NaN
+    if (hipMemcpyAsync(dRows, resultRows.data(), (size_t)nCaller * sizeof(int32_t), hipMemcpyHostToDevice, s) != hipSuccess ||
+        nnhip::launch_kernel(nnhip::gather_rows_kernel, dim3(grid.x, (unsigned)std::min(nCaller, 65535)), block, s, (const int32_t*)dRows, nCaller, (const double*)sortedOut, outCaller, M) != hipSuccess)
+      rc = NNHIP_EHIP;
+  }
   (void)hipStreamSynchronize(s);  // the weight tables are freed below
   (void)hipFree(dPairs);
   (void)hipFree(dPts);
   return rc;
+}
+
+int nnhip_sort_and_trim_dataset_f64_dev(const double* X, int n, const double* const* Y, int n_y, int64_t M, double* X_out, double* const* Y_out, int* n_out,
+                                        void* stream) {
+  if (n < 1 || n_y < 0 || M < 0 || !X || !X_out || !n_out || (n_y > 0 && (!Y || !Y_out))) return nnhip::fail_msg(NNHIP_EVALUE, "sortAndTrimDataset: need n >= 1, n_y >= 0, M >= 0 and non-NULL X / X_out / n_out / Y / Y_out");
+  if (n_y > 8) return nnhip::fail_msg(NNHIP_EUNSUPPORTED, "sortAndTrimDataset: at most 8 series arrays (got %d)", n_y);
+  for (int k = 0; k < n_y; ++k) if (M > 0 && (!Y[k] || !Y_out[k] || Y[k] == Y_out[k])) return nnhip::fail_msg(NNHIP_EVALUE, "sortAndTrimDataset: series %d is NULL or Y_out aliases Y", k);
+  hipStream_t s = (hipStream_t)stream;
+  nnhip::SortedDataset sd;
+  const double* srt[8];
+  if (int rcs = nnhip::sorted_dataset("sortAndTrimDataset", X, n, Y, n_y, M, s, sd, srt)) return rcs;
+  const int ns = sd.n();
+  for (int k = 0; k < n_y && M > 0; ++k) {
+    if (hipMemcpyAsync(Y_out[k], srt[k], (size_t)ns * (size_t)M * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess) return nnhip::fail_msg(NNHIP_EHIP, "sortAndTrimDataset: copy failed");
+    if (int rcn = nnhip::nan_rows(Y_out[k], ns, n, M, s)) return rcn;
+  }
+  if (!sd.pl.identity && hipStreamSynchronize(s) != hipSuccess) return nnhip::fail_msg(NNHIP_EHIP, "sortAndTrimDataset: stream failed");  // the gathered series are freed on return
+  std::copy(sd.pl.x.begin(), sd.pl.x.end(), X_out);
+  for (int i = ns; i < n; ++i) X_out[i] = __builtin_nan("");
+  *n_out = ns;
+  return NNHIP_OK;
+}
+
+int nnhip_dataset_rows_f64(const double* X, int n, int* n_sorted_trimmed, int* n_cumsimpson_rows) {
+  if (n < 1 || !X) return nnhip::fail_msg(NNHIP_EVALUE, "dataset rows: need n >= 1 and a non-NULL X");
+  nnhip::DatasetPlan pl;
+  std::string why;
+  if (nnhip::dataset_plan(X, n, pl, why) != 0) return nnhip::fail_msg(NNHIP_EVALUE, "sortAndTrimDataset: %s", why.c_str());
+  if (n_sorted_trimmed) *n_sorted_trimmed = (int)pl.x.size();
+  if (n_cumsimpson_rows) {
+    std::vector<int32_t> rows;
+    nnhip::simpson_result_rows(pl, X, n, rows);
+    *n_cumsimpson_rows = (int)rows.size();
+  }
+  return NNHIP_OK;
 }
 
 int nnhip_ode_controller_factor_f64_dev(int order, const double* error, double* out, int64_t n, void* stream) {
@@ -307,21 +447,26 @@ int nnhip_ode_solve_batch_multi_gpu_sweep_f64(const nnhip_ode_options* opt, int 
   // Contiguous index ranges [r*N/G, (r+1)*N/G): nothing couples trajectories (ode.nim:589: one solveODE call per IVP).  Every
   // device works on its range of the caller's own arrays (nnhip::solve_host_range: strided copies straight between the caller's
   // buffers and the device, chunked and overlapped with the kernel when the buffers are page-locked) — no intermediate copies.
-  for (int r = 0; r < n_gpus; ++r) {
-    th.emplace_back([&, r]() {
-      const int64_t lo = N * r / n_gpus, hi = N * (r + 1) / n_gpus, n = hi - lo;
-      std::memset(&sts[r], 0, sizeof(nnhip_ode_stats));
-      sts[r].ny_min = 0x7fffffff;
-      if (n == 0) return;
-      if (ctxShards) (void)nnhip::rtc_ctx_shard_enter(rhs_kind, ctxShards, r);  // this thread's calls read shard r of the context block
-      rcs[r] = nnhip::solve_host_range(opt, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y0, N, lo, n, dim, layout, tspan, n_t,
-                                       nullptr, y_out, ny_out, steps_out, rejected_out, max_steps, &sts[r], r % ndev);
-      if (rcs[r]) errs[r] = nnhip::thread_error();  // the message lives in THIS thread's buffer: hand it to the caller
-      if (ctxShards) nnhip::rtc_ctx_shard_leave(rhs_kind);
-      nnhip::release_thread_staging();              // pinned staging + event of this (short-lived) thread
-    });
+  auto shard = [&](int r, bool worker) {
+    const int64_t lo = N * r / n_gpus, hi = N * (r + 1) / n_gpus, n = hi - lo;
+    std::memset(&sts[r], 0, sizeof(nnhip_ode_stats));
+    sts[r].ny_min = 0x7fffffff;
+    if (n == 0) return;
+    if (ctxShards) (void)nnhip::rtc_ctx_shard_enter(rhs_kind, ctxShards, r);  // this thread's calls read shard r of the context block
+    rcs[r] = nnhip::solve_host_range(opt, integrator, rhs_kind, rhs_params, n_params, per_ivp_params, n_per_ivp, y0, N, lo, n, dim, layout, tspan, n_t,
+                                     nullptr, y_out, ny_out, steps_out, rejected_out, max_steps, &sts[r], r % ndev);
+    if (rcs[r]) errs[r] = nnhip::thread_error();  // the message lives in THIS thread's buffer: hand it to the caller
+    if (ctxShards) nnhip::rtc_ctx_shard_leave(rhs_kind);
+    if (worker) nnhip::release_thread_staging();  // pinned staging + event of a (short-lived) worker thread
+  };
+  // One device: the whole batch on the CALLING thread — a context block is then read through this thread's own binding (the per-thread contract of
+  // nnhip_ode_rhs_bind_ctx_f64: a fresh worker thread has no binding of its own and would read the latest bind of ANY thread).  Several devices: one worker
+  // thread each, reading the column range cut above from the calling thread's binding.
+  if (n_gpus == 1) shard(0, false);
+  else {
+    for (int r = 0; r < n_gpus; ++r) th.emplace_back(shard, r, true);
+    for (auto& t : th) t.join();
   }
-  for (auto& t : th) t.join();
   if (ctxShards && nnhip::rtc_ctx_shards_collect(ctxShards) != 0)  // the mutable slots back where nnhip_ode_rhs_read_aux_f64 and single-device calls read them
     return nnhip::fail_msg(NNHIP_EHIP, "rhs_kind %d: %s", rhs_kind, nnhip::rtc_last_error());
   for (int r = 0; r < n_gpus; ++r)

@@ -204,7 +204,7 @@ int nnhip_cumtrapz_batch_f64(const double* X, int n, const double* Y, int64_t M,
   const size_t bytes = (size_t)n * (size_t)M * sizeof(double);
   if ((rc = st.upload(Y, bytes, &dY)) || (rc = st.upload(nullptr, bytes, &dOut))) return rc;
   rc = nnhip_cumtrapz_batch_f64_dev(X, n, (const double*)dY, M, (double*)dOut, st.s);
-  if (rc) return nnhip::fail_msg(rc, "cumtrapz(Y, X): bad arguments (X must be strictly ascending) or launch failure");
+  if (rc) return rc;  // (the device entry's message stands: NaN in X, impure duplicates, ...)
   return st.download(out, dOut, bytes);
 }
 
@@ -217,7 +217,7 @@ int nnhip_cumsimpson_batch_f64(const double* X, int n, const double* Y, int64_t 
   const size_t bytes = (size_t)n * (size_t)M * sizeof(double);
   if ((rc = st.upload(Y, bytes, &dY)) || (rc = st.upload(nullptr, bytes, &dOut))) return rc;
   rc = nnhip_cumsimpson_batch_f64_dev(X, n, (const double*)dY, M, (double*)dOut, st.s);
-  if (rc) return nnhip::fail_msg(rc, "cumsimpson(Y, X): needs >= 3 strictly ascending points (ValueError, integrate.nim:345-346) or launch failure");
+  if (rc) return rc;  // (the device entry's message stands: fewer than 3 distinct abscissae, NaN in X, impure duplicates, ...)
   return st.download(out, dOut, bytes);
 }
 
@@ -230,12 +230,21 @@ int nnhip_hermite_spline_eval_batch_f64(const double* X, int n_knots, const doub
   void *dYd = nullptr, *ddY = nullptr, *dOut = nullptr;
   const size_t bytes = (size_t)n_knots * (size_t)M * sizeof(double);
   if ((rc = st.upload(Y, bytes, &dYd)) || (rc = st.upload(dY, bytes, &ddY)) || (rc = st.upload(nullptr, (size_t)n_q * (size_t)M * sizeof(double), &dOut))) return rc;
-  if (!dY && M > 0) {  // newHermiteSpline(X, Y): estimate the slopes (interpolate.nim:241-253)
-    rc = nnhip_hermite_spline_slopes_f64_dev(X, n_knots, (const double*)dYd, M, (double*)ddY, st.s);
-    if (rc) return nnhip::fail_msg(rc, "newHermiteSpline(X, Y): X must be strictly ascending");
+  std::vector<double> xs;
+  if (!dY && M > 0) {  // newHermiteSpline(X, Y): sort and trim (interpolate.nim:244), then estimate the slopes on the sorted data (:245-251)
+    void* dYs = nullptr;
+    if ((rc = st.upload(nullptr, bytes, &dYs))) return rc;
+    xs.resize((size_t)n_knots);
+    const double* in1[1] = {(const double*)dYd};
+    double* out1[1] = {(double*)dYs};
+    int ns = 0;
+    if ((rc = nnhip_sort_and_trim_dataset_f64_dev(X, n_knots, in1, 1, M, xs.data(), out1, &ns, st.s))) return rc;
+    if (ns < 2) return nnhip::fail_msg(NNHIP_EVALUE, "newHermiteSpline(X, Y): fewer than 2 distinct knots");
+    X = xs.data(); n_knots = ns; dYd = dYs;
+    if ((rc = nnhip_hermite_spline_slopes_f64_dev(X, n_knots, (const double*)dYd, M, (double*)ddY, st.s))) return rc;
   }
   rc = nnhip_hermite_spline_eval_batch_f64_dev(X, n_knots, (const double*)dYd, (const double*)ddY, M, xq, n_q, deriv, extrap, extrap_value, (double*)dOut, st.s);
-  if (rc) return nnhip::fail_msg(rc, "HermiteSpline eval: bad arguments (X strictly ascending, extrap in 0..4; Error extrapolation raises outside the knots)");
+  if (rc) return rc;  // (the device entry's message stands: extrap outside 0..4, Error extrapolation outside the knots, impure duplicates, ...)
   return st.download(out, dOut, (size_t)n_q * (size_t)M * sizeof(double));
 }
 

@@ -611,9 +611,21 @@ bool check_layout(const UserRhsEntry& e, const void* shared, int64_t shared_len,
   }
   return true;
 }
-void install(int rhs_kind, const std::shared_ptr<CtxBinding>& b) {  // caller holds g_mu
-  g_user[rhs_kind - NNHIP_RHS_USER_BASE].bound = b;
-  t_bound[rhs_kind] = b;
+// Caller holds g_mu and destroys `dropped` AFTER releasing it: the last reference to a binding the library uploaded itself runs ~CtxBinding — hipSetDevice,
+// hipDeviceSynchronize, hipFree per shard and owned block — which must not happen with every other thread's rtc_ctx_fill / get_program / launch waiting on g_mu.
+void install(int rhs_kind, const std::shared_ptr<CtxBinding>& b, std::vector<std::shared_ptr<CtxBinding>>& dropped) {
+  std::shared_ptr<CtxBinding>& slot = g_user[rhs_kind - NNHIP_RHS_USER_BASE].bound;
+  dropped.push_back(std::move(slot));
+  slot = b;
+  std::shared_ptr<CtxBinding>& mine = t_bound[rhs_kind];
+  dropped.push_back(std::move(mine));
+  mine = b;
+  // this thread's bindings of kinds that have been released since (rtc_release by another thread cannot reach them): let go of their device copies now
+  for (auto it = t_bound.begin(); it != t_bound.end();) {
+    const int idx = it->first - NNHIP_RHS_USER_BASE;
+    if (idx < 0 || idx >= (int)g_user.size() || !g_user[idx].alive) { dropped.push_back(std::move(it->second)); it = t_bound.erase(it); }
+    else ++it;
+  }
 }
 // the mutable slots of a binding whose last writer was a sharded solve: device shards -> host copy -> the single-device block
 int collect_aux(CtxBinding& b) {
@@ -665,9 +677,10 @@ int rtc_bind_ctx_host(int rhs_kind, const double* shared, int64_t shared_len, co
   if (bytes[0]) b->hShared.assign(shared, shared + shared_len);
   if (bytes[1]) b->hIvp.assign(per_ivp, per_ivp + (size_t)per_ivp_rows * (size_t)stride);
   if (bytes[2]) b->hAux.assign(aux_init, aux_init + (size_t)n_aux * (size_t)stride);
+  std::vector<std::shared_ptr<CtxBinding>> dropped;  // destroyed after g_mu is released (declared before the guard)
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g_user[idx].alive) { g_rtc_err = "unknown user rhs_kind"; return -1; }
-  install(rhs_kind, b);
+  install(rhs_kind, b, dropped);
   return 0;
 }
 
@@ -692,13 +705,14 @@ int rtc_read_aux(int rhs_kind, double* aux_out) {
 
 int rtc_bind_ctx(int rhs_kind, const double* shared, int64_t shared_len, const double* per_ivp, int64_t per_ivp_rows, double* aux, int n_aux, int64_t stride) {
   const int idx = rhs_kind - NNHIP_RHS_USER_BASE;
+  std::vector<std::shared_ptr<CtxBinding>> dropped;  // a binding the library had uploaded itself is released with its last reference — after g_mu (declared before the guard)
   std::lock_guard<std::mutex> lk(g_mu);
   if (idx < 0 || idx >= (int)g_user.size() || !g_user[idx].alive) { g_rtc_err = "unknown user rhs_kind"; return -1; }
   if (!check_layout(g_user[idx], shared, shared_len, per_ivp, per_ivp_rows, aux, n_aux, stride)) return -1;
   auto b = std::make_shared<CtxBinding>();  // the caller's own device memory: nothing owned, nothing to shard from
   b->shared = shared; b->ivp = per_ivp; b->aux = aux; b->stride = stride;
   b->sharedLen = shared_len; b->ivpRows = per_ivp_rows; b->nAux = n_aux;
-  install(rhs_kind, b);  // (a binding the library had uploaded itself is released with its last reference)
+  install(rhs_kind, b, dropped);
   return 0;
 }
 // Declares that the per-component body of `rhs_kind` reads components c - lo .. c + hi (cyclically) only.  Code objects compiled before are dropped.

@@ -26,13 +26,43 @@ def rhsBatch(f, t, y, ctx=None, layout=LAYOUT_SOA):
     return out
 
 
+def _dataset_rows(Xa):
+    """(rows of sortAndTrimDataset's result, rows of cumsimpson(Y, X)'s) for the caller's X — decided on the host (nnhip_dataset_rows_f64)."""
+    ns, nr = C.c_int(0), C.c_int(0)
+    _check(_lib.lib().nnhip_dataset_rows_f64(Xa.ctypes.data_as(C.POINTER(C.c_double)), len(Xa), C.byref(ns), C.byref(nr)))
+    return ns.value, nr.value
+
+
+def sortAndTrimDataset(X, *Ys):
+    """sortAndTrimDataset(x, @[y_0, ...]) (utils.nim:404-413) over batched series: X host, every Y an [n, ...] CUDA tensor (each trailing element its
+    own series).  Returns (X_sorted_trimmed, [Y_sorted_trimmed ...]); impure duplicates raise ValueError as in the reference."""
+    import torch
+    Xa = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
+    Ys = [y.contiguous() for y in Ys]
+    if any(len(Xa) != y.shape[0] for y in Ys):
+        raise ValueError("X and Y must have the same length")
+    M = int(Ys[0][0].numel()) if Ys else 0
+    outs = [torch.empty_like(y) for y in Ys]
+    Xo = np.empty_like(Xa)
+    no = C.c_int(0)
+    arr = (C.c_void_p * max(len(Ys), 1))
+    dev = Ys[0].device if Ys else None
+    import contextlib
+    with (torch.cuda.device(dev) if dev is not None else contextlib.nullcontext()):
+        _check(_lib.lib().nnhip_sort_and_trim_dataset_f64_dev(Xa.ctypes.data_as(C.POINTER(C.c_double)), len(Xa), arr(*[y.data_ptr() for y in Ys]), len(Ys), M,
+                                                              Xo.ctypes.data_as(C.POINTER(C.c_double)), arr(*[o.data_ptr() for o in outs]), C.byref(no),
+                                                              torch.cuda.current_stream().cuda_stream if dev is not None else None))
+    return Xo[:no.value].copy(), [o[:no.value] for o in outs]
+
+
 class HermiteSpline:
     """newHermiteSpline(X, Y, dY) for a whole batch: Y, dY are [n_knots, ...] CUDA tensors (every trailing element its
-    own series).  X must be strictly ascending (the solver's output grid is, unless tStart is duplicated)."""
+    own series).  X in any order: the constructor sorts and trims the data as the reference's does (interpolate.nim:231, 244); the solver's output
+    grid is strictly ascending already, and then nothing moves."""
 
     def __init__(self, X, Y, dY=None):
         self.X = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
-        self.host = isinstance(Y, np.ndarray)  # numpy series: host-pointer entry (staged through the device per call)
+        self.host = isinstance(Y, np.ndarray)  # numpy series: host-pointer entry (staged through the device per call, which sorts and trims there)
         if len(self.X) != Y.shape[0] or (dY is not None and len(self.X) != dY.shape[0]):
             raise ValueError("X and Y and dY must have the same length.")  # interpolate.nim:229-230
         if self.host:
@@ -41,6 +71,10 @@ class HermiteSpline:
             self.M = int(self.Y[0].size)
             return
         import torch
+        if len(self.X) > 1 and not bool(np.all(self.X[1:] > self.X[:-1])):   # sortAndTrimDataset(@X, @[@Y, @dY]) / (@X, @Y), once, here
+            self.X, sorted_ = sortAndTrimDataset(self.X, *([Y] if dY is None else [Y, dY]))
+            Y = sorted_[0]
+            dY = None if dY is None else sorted_[1]
         self.Y = Y.contiguous()
         self.M = int(self.Y[0].numel())
         if dY is None:  # newHermiteSpline(X, Y): three-point difference slopes (interpolate.nim:241-253)
@@ -130,7 +164,8 @@ def _cumquad_fn(rule, f, X, ctx, dx, sweep, n, dim, device, layout):
 
 def cumtrapz(Y, X, ctx=None, dx=1e-5, sweep=None, n=1, dim=1, device=None, layout=LAYOUT_SOA):
     """cumtrapz(Y, X) for discrete points (integrate.nim:120-135), batched: Y is an [n, ...] CUDA tensor, every trailing
-    element its own series; X strictly ascending.  Returns the cumulative integrals, same shape as Y.
+    element its own series; X in any order (sorted and trimmed first, as the reference does: the result has one row per distinct abscissa, ascending).
+    Returns the cumulative integrals.
     With an Rhs as first argument: cumtrapz(f, X, ctx, dx) (integrate.nim:138-175), see _cumquad_fn."""
     import torch
     from .ode import Rhs
@@ -144,17 +179,18 @@ def cumtrapz(Y, X, ctx=None, dx=1e-5, sweep=None, n=1, dim=1, device=None, layou
         outh = np.empty_like(Yh)
         dp = C.POINTER(C.c_double)
         _check(_lib.lib().nnhip_cumtrapz_batch_f64(Xa.ctypes.data_as(dp), len(Xa), Yh.ctypes.data_as(dp), int(Yh[0].size), outh.ctypes.data_as(dp), 0))
-        return outh
+        return outh[:_dataset_rows(Xa)[0]]
     Yc = Y.contiguous()
     out = torch.empty_like(Yc)
     with torch.cuda.device(Yc.device):
         _check(_lib.lib().nnhip_cumtrapz_batch_f64_dev(Xa.ctypes.data_as(C.POINTER(C.c_double)), len(Xa), Yc.data_ptr(), int(Yc[0].numel()),
                                                        out.data_ptr(), torch.cuda.current_stream().cuda_stream))
-    return out
+    return out[:_dataset_rows(Xa)[0]]
 
 
 def cumsimpson(Y, X, ctx=None, dx=1e-5, sweep=None, n=1, dim=1, device=None, layout=LAYOUT_SOA):
-    """cumsimpson(Y, X) for discrete points (integrate.nim:329-375), batched like cumtrapz; needs len(X) >= 3.
+    """cumsimpson(Y, X) for discrete points (integrate.nim:329-375), batched like cumtrapz; needs 3 distinct abscissae.  X in any order: the result
+    is returned at the caller's abscissae, in the caller's order (hermiteInterpolate, :375).
     With an Rhs as first argument: cumsimpson(f, X, ctx, dx) (integrate.nim:377-400), see _cumquad_fn."""
     import torch
     from .ode import Rhs
@@ -170,13 +206,13 @@ def cumsimpson(Y, X, ctx=None, dx=1e-5, sweep=None, n=1, dim=1, device=None, lay
         outh = np.empty_like(Yh)
         dp = C.POINTER(C.c_double)
         _check(_lib.lib().nnhip_cumsimpson_batch_f64(Xa.ctypes.data_as(dp), len(Xa), Yh.ctypes.data_as(dp), int(Yh[0].size), outh.ctypes.data_as(dp), 0))
-        return outh
+        return outh[:_dataset_rows(Xa)[1]]
     Yc = Y.contiguous()
     out = torch.empty_like(Yc)
     with torch.cuda.device(Yc.device):
         _check(_lib.lib().nnhip_cumsimpson_batch_f64_dev(Xa.ctypes.data_as(C.POINTER(C.c_double)), len(Xa), Yc.data_ptr(), int(Yc[0].numel()),
                                                          out.data_ptr(), torch.cuda.current_stream().cuda_stream))
-    return out
+    return out[:_dataset_rows(Xa)[1]]
 
 
 def trapz(Y, X):

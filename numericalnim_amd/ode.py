@@ -835,31 +835,39 @@ def adaptiveStream(f, y, t0, tEnd, options=None, ctx=None, integrator="dopri54",
 
 
 # library defaults of the tuning knobs this module's callers flip (include/nnhip_ode.h, nnhip_tune_set); `tuning` restores these
-_KNOB_DEFAULTS = {"adv_lean": 0, "adv_auto_poll": 0, "fp_contract": 0, "stream_graph": 0, "adv_steps_per_launch": 1, "calls_bin": 1,
+_KNOB_DEFAULTS = {"adv_lean": 0, "adv_auto_poll": 0, "fp_contract": 0, "stream_graph": 2, "adv_steps_per_launch": 1, "calls_bin": 1,
                   "adv_recompute_fsal": -1, "adv_nontemporal": -1, "adv_block": 0, "adv_split": 0}
 
 
+_KNOB_STATE = dict(_KNOB_DEFAULTS)  # what `tuning` blocks have set (the library has no getter; direct nnhip_tune_set calls are not seen here)
+
+
 class tuning:
-    """with tuning(adv_lean=1, adv_auto_poll=1): ... — process-wide tuning knobs (nnhip_tune_set) for the duration of a block, then back to the
-    library's defaults.  Opt-in settings of the adaptive streaming loop: adv_lean (its lean kernels, same bits), adv_auto_poll (its own polling
-    schedule when check_every <= 0), fp_contract (FMA-contracted kernels: within 1e-10 / 1e-6, not the reference's bits)."""
+    """with tuning(adv_lean=1, adv_auto_poll=1): ... — process-wide tuning knobs (nnhip_tune_set) for the duration of a block, then back to what they
+    were before it (blocks nest; outside any block: the library's defaults).  Opt-in settings of the adaptive streaming loop: adv_lean (its lean
+    kernels, same bits), adv_auto_poll (its own polling schedule when check_every <= 0), fp_contract (FMA-contracted kernels: within 1e-10 / 1e-6,
+    not the reference's bits)."""
 
     def __init__(self, **knobs):
         unknown = [k for k in knobs if k not in _KNOB_DEFAULTS]
         if unknown:
             raise ValueError("tuning(): no default on record for " + ", ".join(unknown))
         self.knobs = knobs
+        self.before = {}
 
     def __enter__(self):
         L = _lib.lib()
         for k, v in self.knobs.items():
+            self.before[k] = _KNOB_STATE[k]
             _check(L.nnhip_tune_set(k.encode(), int(v)))
+            _KNOB_STATE[k] = int(v)
         return self
 
     def __exit__(self, *exc):
         L = _lib.lib()
-        for k in self.knobs:
-            L.nnhip_tune_set(k.encode(), _KNOB_DEFAULTS[k])
+        for k, v in self.before.items():
+            L.nnhip_tune_set(k.encode(), v)
+            _KNOB_STATE[k] = v
         return False
 
 

@@ -681,8 +681,58 @@ static std::vector<T> hermiteInterpolate(const std::vector<double>& x, const std
   return result;
 }
 
+// sortAndTrimDataset (utils.nim:404-407) = sortDataset (:384-402) followed by removeDuplicates (:360-381), for scalar series y[k] over one x.
+struct SortedTrimmed {
+  std::vector<double> x;
+  std::vector<std::vector<double>> y;
+};
+static SortedTrimmed sortAndTrimDataset(const std::vector<double>& x, const std::vector<std::vector<double>>& y) {
+  const size_t n = x.size();
+  for (double v : x)
+    if (v != v) throw std::domain_error("NaN in x: the comparison sort of sortDataset has no defined order for it");  // (not a reference error: no defined result to restate)
+  // sortDataset: var zipped_x = zip(x, toSeq(0 .. xLen-1)); zipped_x.sort(sortOrder) (:392-393) — tuples compare field by field: by x (cmp: <, ==), then by index
+  std::vector<std::pair<double, long>> zipped(n);
+  for (size_t i = 0; i < n; ++i) zipped[i] = {x[i], (long)i};
+  std::sort(zipped.begin(), zipped.end(), [](const std::pair<double, long>& a, const std::pair<double, long>& b) {
+    if (a.first < b.first) return true;
+    if (a.first == b.first) return a.second < b.second;
+    return false;
+  });
+  SortedTrimmed s;
+  s.x.resize(n);
+  s.y.assign(y.size(), std::vector<double>(n));
+  for (size_t i = 0; i < n; ++i) {  // result.y[resultIdx][i] = y[resultIdx][idxNew] (:399-402)
+    s.x[i] = zipped[i].first;
+    for (size_t k = 0; k < y.size(); ++k) s.y[k][i] = y[k][(size_t)zipped[i].second];
+  }
+  // removeDuplicates: findDuplicates(x) = the index lists of getIndexTable(x) longer than 1 (:347-357): a Table keyed by float — equal keys (-0.0 == 0.0,
+  // and hash(x) hashes x + 0.0) share an entry.  x is sorted here, so the members of an entry are adjacent: dups = runs of equal values, ascending indices.
+  std::vector<size_t> idxDelete;
+  for (size_t i = 0; i < n;) {
+    size_t j = i + 1;
+    while (j < n && s.x[j] == s.x[i]) ++j;
+    for (size_t d = i; d < j && j - i > 1; ++d)        // `for i in dups` — dups[0] included, which compares equal to itself unless it is NaN (:369-372)
+      for (size_t k = 0; k < y.size(); ++k)
+        if (s.y[k][d] != s.y[k][i]) throw std::invalid_argument("impure y-duplicates was found");  // ValueError :372
+    for (size_t d = i + 1; d < j; ++d) idxDelete.push_back(d);  // idxDelete.add dups[1 .. ^1] (:376)
+    i = j;
+  }
+  for (size_t q = idxDelete.size(); q-- > 0;) {  // delete (:338-344): indices in descending order
+    s.x.erase(s.x.begin() + (long)idxDelete[q]);
+    for (auto& yk : s.y) yk.erase(yk.begin() + (long)idxDelete[q]);
+  }
+  return s;
+}
+
+template <class T>
+static std::vector<T> cumsimpsonSorted(const std::vector<T>& Y, const std::vector<double>& X, const std::vector<double>& callerX);
 template <class T>
 static std::vector<T> cumsimpsonDiscrete(const std::vector<T>& Y, const std::vector<double>& X) {  // X sorted, duplicate-free
+  return cumsimpsonSorted<T>(Y, X, X);
+}
+// the body of cumsimpson(Y, X) after its first line (:341-375): X, Y = (xSorted, ySorted); callerX = the argument X, which the last line interpolates back to
+template <class T>
+static std::vector<T> cumsimpsonSorted(const std::vector<T>& Y, const std::vector<double>& X, const std::vector<double>& callerX) {
   int N = (int)X.size();
   const int n = N;
   bool evenN = false;
@@ -711,7 +761,7 @@ static std::vector<T> cumsimpsonDiscrete(const std::vector<T>& Y, const std::vec
     integral = integral + (eta * Y[last - 2] + beta * Y[last - 1] + alpha * Y[last]);
     y.push_back(integral); dy.push_back(Y[last]); xs.push_back(X[last]);
   }
-  return hermiteInterpolate<T>(X, xs, y, dy);  // :375
+  return hermiteInterpolate<T>(callerX, xs, y, dy);  // :375
 }
 
 template <class T, class F>
@@ -1054,60 +1104,53 @@ int oracle_hermite_slopes(const double* X, int n, const double* Y, double* dY) {
 
 // cumtrapz(Y, X) for discrete points (src/numericalnim/integrate.nim:120-135) on one scalar series; X sorted and
 // duplicate-free (sortAndTrimDataset's postcondition).  trapz(Y, X) (:104-117) equals the last entry for finite data.
-int oracle_cumtrapz(const double* X, int n, const double* Y, double* out) {
+// X in any order: `let (xSorted, ySorted) = sortAndTrimDataset(@X, @Y)` (:130) first.  Returns the number of rows (distinct abscissae), -1 for the
+// reference's ValueError (impure duplicates), -2 for NaN in X (no defined order in the reference's sort: nothing to restate).
+int oracle_cumtrapz(const double* Xc, int nc, const double* Yc, double* out) {
+  oracle::SortedTrimmed st;
+  try { st = oracle::sortAndTrimDataset(std::vector<double>(Xc, Xc + nc), {std::vector<double>(Yc, Yc + nc)}); }
+  catch (const std::invalid_argument&) { return -1; }
+  catch (const std::domain_error&) { return -2; }
+  const std::vector<double>&X = st.x, &Y = st.y[0];
+  const int n = (int)X.size();
   out[0] = Y[0] - Y[0];            // "get the right kind of zero" (:131)
   double integral = Y[0] - Y[0];   // :132
   for (int i = 0; i <= n - 2; ++i) {
     integral += 0.5 * (X[i + 1] - X[i]) * (Y[i + 1] + Y[i]);  // :134
     out[i + 1] = integral;
   }
-  return 0;
+  return n;
+}
+
+// sortAndTrimDataset(x, @[y_0 .. y_{nY-1}]) (utils.nim:404-407) on scalar series.  Returns the rows of the result, -1 for ValueError (impure duplicates),
+// -2 for NaN in X.
+int oracle_sort_and_trim(const double* X, int n, const double* const* Y, int nY, double* Xout, double* const* Yout) {
+  std::vector<std::vector<double>> ys;
+  for (int k = 0; k < nY; ++k) ys.emplace_back(Y[k], Y[k] + n);
+  oracle::SortedTrimmed st;
+  try { st = oracle::sortAndTrimDataset(std::vector<double>(X, X + n), ys); }
+  catch (const std::invalid_argument&) { return -1; }
+  catch (const std::domain_error&) { return -2; }
+  std::copy(st.x.begin(), st.x.end(), Xout);
+  for (int k = 0; k < nY; ++k) std::copy(st.y[(size_t)k].begin(), st.y[(size_t)k].end(), Yout[k]);
+  return (int)st.x.size();
 }
 
 // cumsimpson(Y, X) for discrete points (src/numericalnim/integrate.nim:329-375) on one scalar series: composite Simpson on
 // pairs of intervals (non-uniform weights :354-359, odd-tail correction :364-373) gives the integral at every second
 // point; hermiteInterpolate (utils.nim:282-312, sorted branch) with dy = Y fills in all points of X.
-// X sorted and duplicate-free; n >= 3 (else ValueError -> -1).
 int oracle_cumsimpson(const double* X, int n, const double* Y, double* out) {
-  if (n < 3) return -1;  // :345-346
-  int N = n;
-  bool evenN = false;
-  if (N % 2 == 0) { evenN = true; N -= 1; }  // :347-349
-  std::vector<double> xs, y, dy;
-  double integral = Y[0] - Y[0];  // :350
-  y.push_back(integral); dy.push_back(Y[0]); xs.push_back(X[0]);
-  for (int i = 0; i < (N - 1) / 2; ++i) {  // :354
-    const double h1 = X[2 * i + 1] - X[2 * i];
-    const double h2 = X[2 * i + 2] - X[2 * i + 1];
-    const double alpha = (2.0 * oracle::cube(h2) - oracle::cube(h1) + 3.0 * h1 * oracle::sq(h2)) / (6.0 * h2 * (h2 + h1));
-    const double beta = (oracle::cube(h2) + oracle::cube(h1) + 3.0 * h1 * h2 * (h2 + h1)) / (6.0 * h2 * h1);
-    const double eta = (2.0 * oracle::cube(h1) - oracle::cube(h2) + 3.0 * h2 * oracle::sq(h1)) / (6.0 * h1 * (h2 + h1));
-    integral += alpha * Y[2 * i + 2] + beta * Y[2 * i + 1] + eta * Y[2 * i];  // :359
-    y.push_back(integral); dy.push_back(Y[2 * i + 2]); xs.push_back(X[2 * i + 2]);
-  }
-  if (evenN) {  // :363-373
-    const int last = n - 1;
-    const double h1 = X[last - 1] - X[last - 2];
-    const double h2 = X[last] - X[last - 1];
-    const double alpha = (2.0 * oracle::sq(h2) + 3.0 * h1 * h2) / (6.0 * (h1 + h2));
-    const double beta = (oracle::sq(h2) + 3.0 * h1 * h2) / (6.0 * h1);
-    const double eta = -(oracle::cube(h2)) / (6.0 * h1 * (h1 + h2));
-    integral += eta * Y[last - 2] + beta * Y[last - 1] + alpha * Y[last];
-    y.push_back(integral); dy.push_back(Y[last]); xs.push_back(X[last]);
-  }
-  // hermiteInterpolate(X, xs, y, dy), X sorted (utils.nim:290-301)
-  int k = 0, xIndex = 0;
-  const int th = (int)xs.size() - 1;
-  bool done = false;
-  for (int i = 0; i <= th - 1 && !done; ++i) {
-    while (xs[i] <= X[xIndex] && X[xIndex] < xs[i + 1]) {
-      out[k++] = oracle::hermiteSpline<double>(X[xIndex], xs[i], xs[i + 1], y[i], y[i + 1], dy[i], dy[i + 1]);
-      xIndex += 1;
-      if (n - 1 < xIndex) { done = true; break; }
-    }
-  }
-  if (X[n - 1] == xs[th]) out[k++] = y[th];
-  return k;
+  // X in any order: `var (xSorted, ySorted) = sortAndTrimDataset(@X, @Y)` (:340); the rule on the sorted data (:341-373, cumsimpsonSorted above, the restatement
+  // shared with the function form); the result at the CALLER's abscissae: hermiteInterpolate(X, xs, y, dy) (:375), sorted or unsorted branch as X is.
+  // Returns the number of rows, -1 for the reference's ValueError (impure duplicates, fewer than 3 distinct abscissae), -2 for NaN in X.
+  const std::vector<double> callerX(X, X + n);
+  try {
+    const oracle::SortedTrimmed st = oracle::sortAndTrimDataset(callerX, {std::vector<double>(Y, Y + n)});
+    const std::vector<double> r = oracle::cumsimpsonSorted<double>(st.y[0], st.x, callerX);
+    std::copy(r.begin(), r.end(), out);
+    return (int)r.size();
+  } catch (const std::invalid_argument&) { return -1; }
+  catch (const std::domain_error&) { return -2; }
 }
 
 // cumtrapz(f, X, ctx, dx) (rule 0) / cumsimpson(f, X, ctx, dx) (rule 1) with f(x) := rhs(x, y = 0, params) — the integrand is a

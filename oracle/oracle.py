@@ -61,6 +61,7 @@ def lib():
         _lib.oracle_linspace.argtypes = [C.c_double, C.c_double, C.c_int, dp]
         _lib.oracle_hermite_interp.argtypes = [dp, C.c_int, dp, dp, dp, C.c_int, C.c_int, C.c_int, C.c_double, dp]
         _lib.oracle_cumtrapz.argtypes = [dp, C.c_int, dp, dp]
+        _lib.oracle_sort_and_trim.argtypes = [dp, C.c_int, C.POINTER(dp), C.c_int, dp, C.POINTER(dp)]
         _lib.oracle_cumsimpson.argtypes = [dp, C.c_int, dp, dp]
         _lib.oracle_vector_op.argtypes = [C.c_int, dp, C.c_int, dp, C.c_int, C.c_double, dp]
     return _lib
@@ -217,6 +218,8 @@ EXTRAP = {"Constant": 0, "Edge": 1, "Linear": 2, "Native": 3, "Error": 4}  # int
 def hermite_interp(X, Y, dY, xq, deriv=False, extrap="Native", extrap_value=0.0):
     """newHermiteSpline(X, Y, dY).eval / .derivEval (interpolate.nim:186-240, 299-390) for one scalar series."""
     X, Y, dY, xq = (np.ascontiguousarray(np.asarray(a, dtype=np.float64)) for a in (X, Y, dY, xq))
+    if len(X) > 1 and not np.all(X[1:] > X[:-1]):   # `let sortedDataset = sortAndTrimDataset(@X, @[@Y, @dY])` (interpolate.nim:231)
+        X, (Y, dY) = sort_and_trim(X, Y, dY)
     out = np.empty(len(xq), dtype=np.float64)
     rc = lib().oracle_hermite_interp(_dp(X), len(X), _dp(Y), _dp(dY), _dp(xq), len(xq), int(deriv), EXTRAP[extrap], extrap_value, _dp(out))
     if rc:
@@ -227,27 +230,48 @@ def hermite_interp(X, Y, dY, xq, deriv=False, extrap="Native", extrap_value=0.0)
 def hermite_slopes(X, Y):
     """The derivative estimates of newHermiteSpline(X, Y) (interpolate.nim:241-253) for one scalar series."""
     X, Y = (np.ascontiguousarray(np.asarray(a, dtype=np.float64)) for a in (X, Y))
+    if len(X) > 1 and not np.all(X[1:] > X[:-1]):   # `let (xSorted, ySorted) = sortAndTrimDataset(@X, @Y)` (interpolate.nim:244): slopes of the sorted, trimmed data
+        X, (Y,) = sort_and_trim(X, Y)
     out = np.empty(len(X), dtype=np.float64)
     if lib().oracle_hermite_slopes(_dp(X), len(X), _dp(Y), _dp(out)):
         raise ValueError("need at least 2 points")
     return out
 
 
+def _raise_dataset(k):
+    if k == -2:
+        raise ArithmeticError("NaN in X: sortAndTrimDataset has no defined order for it (nothing to restate)")
+    if k < 0:
+        raise ValueError("ValueError in the reference (impure y-duplicates / too few distinct abscissae)")
+
+
+def sort_and_trim(X, *Ys):
+    """sortAndTrimDataset(x, @[y_0, ...]) (utils.nim:404-407) on scalar series -> (x, [y_0, ...]); ValueError for impure duplicates."""
+    X = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
+    Ys = [np.ascontiguousarray(np.asarray(y, dtype=np.float64)) for y in Ys]
+    xo = np.empty_like(X)
+    outs = [np.empty_like(X) for _ in Ys]
+    pp = C.POINTER(C.c_double) * max(len(Ys), 1)
+    k = lib().oracle_sort_and_trim(_dp(X), len(X), pp(*[_dp(y) for y in Ys]), len(Ys), _dp(xo), pp(*[_dp(o) for o in outs]))
+    _raise_dataset(k)
+    return xo[:k].copy(), [o[:k].copy() for o in outs]
+
+
 def cumtrapz(Y, X):
-    """cumtrapz(Y, X) (integrate.nim:120-135) for one scalar series with sorted, unique X."""
+    """cumtrapz(Y, X) (integrate.nim:120-135) for one scalar series; X in any order (sorted and trimmed first, :130)."""
     X, Y = (np.ascontiguousarray(np.asarray(a, dtype=np.float64)) for a in (X, Y))
     out = np.empty(len(X), dtype=np.float64)
-    lib().oracle_cumtrapz(_dp(X), len(X), _dp(Y), _dp(out))
-    return out
+    k = lib().oracle_cumtrapz(_dp(X), len(X), _dp(Y), _dp(out))
+    _raise_dataset(k)
+    return out[:k].copy()
 
 
 def cumsimpson(Y, X):
-    """cumsimpson(Y, X) (integrate.nim:329-375) for one scalar series with sorted, unique X (len >= 3)."""
+    """cumsimpson(Y, X) (integrate.nim:329-375) for one scalar series; X in any order (3 distinct abscissae or more); the result at the caller's abscissae."""
     X, Y = (np.ascontiguousarray(np.asarray(a, dtype=np.float64)) for a in (X, Y))
     out = np.empty(len(X), dtype=np.float64)
     k = lib().oracle_cumsimpson(_dp(X), len(X), _dp(Y), _dp(out))
-    if k < 0:
-        raise ValueError("X and Y must have at least 3 elements to perform Simpson, use cumtrapz instead")
+    _raise_dataset(k)
     return out[:k].copy()
 
 

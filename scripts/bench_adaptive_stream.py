@@ -71,12 +71,15 @@ for name, f, y0, layout, d, n in cases:
         # graph = polling groups replayed from a hipGraph (knob stream_graph 1); fsal_carried = knob adv_recompute_fsal 0
         # K > 1 (knob "adv_steps_per_launch"): K loop iterations per IVP and launch with the state kept in registers in between — ITS OWN
         # traffic model (1/K of the bytes per step), reported beside the one-iteration-per-launch figures, never mixed with them
-        # round 5: default = the lean kernels (the driver's own layout as the kernel's contract) + the automatic polling schedule (check_every 0);
-        # general_kernel = knob adv_lean 0; poll8 / general_kernel_poll8 = uniform polling groups of 8 (general_kernel_poll8 = round 4's default)
-        for mode, knob, nt, K, refsal, lean, ce in (("default", 2, -1, 1, -1, 1, 0), ("general_kernel", 2, -1, 1, -1, 0, 0), ("poll8", 2, -1, 1, -1, 1, 8),
-                                                    ("general_kernel_poll8", 2, -1, 1, -1, 0, 8), ("nt0", 2, 0, 1, -1, 1, 8), ("nt1", 2, 1, 1, -1, 1, 8),
-                                                    ("graph", 1, -1, 1, -1, 1, 8), ("fsal_carried", 2, -1, 1, 0, 1, 8), ("graph_fsal_carried", 1, -1, 1, 0, 1, 8),
-                                                    ("K2", 2, -1, 2, -1, 1, 8), ("K5", 2, -1, 5, -1, 1, 8), ("K5_fsal_carried", 2, -1, 5, 0, 1, 8)):
+        # round 6: default = the library's defaults = the configuration with a hardware record (general kernels, polling groups of 8: round 4's);
+        # lean = knob adv_lean 1 (same bits); lean_auto_poll = + the library's own polling schedule (knob adv_auto_poll 1, check_every 0): round 5's pair;
+        # general_auto_poll = the schedule alone; lean_auto_poll_fp_contract = + the FMA-contracted lean kernels (within 1e-6, not bit-equal)
+        #       mode                          graph nt  K refsal lean ce auto contract
+        for mode, knob, nt, K, refsal, lean, ce, auto, contract in (
+                ("default", 2, -1, 1, -1, 0, 0, 0, 0), ("lean", 2, -1, 1, -1, 1, 0, 0, 0), ("lean_auto_poll", 2, -1, 1, -1, 1, 0, 1, 0), ("general_auto_poll", 2, -1, 1, -1, 0, 0, 1, 0),
+                ("lean_auto_poll_fp_contract", 2, -1, 1, -1, 1, 0, 1, 1), ("nt0", 2, 0, 1, -1, 0, 8, 0, 0), ("nt1", 2, 1, 1, -1, 0, 8, 0, 0),
+                ("graph", 1, -1, 1, -1, 0, 8, 0, 0), ("fsal_carried", 2, -1, 1, 0, 0, 8, 0, 0), ("graph_fsal_carried", 1, -1, 1, 0, 0, 8, 0, 0),
+                ("K2", 2, -1, 2, -1, 0, 8, 0, 0), ("K5", 2, -1, 5, -1, 0, 8, 0, 0), ("K5_fsal_carried", 2, -1, 5, 0, 0, 8, 0, 0)):
             if MODES and mode not in MODES:
                 continue
             L.nnhip_tune_set(b"stream_graph", knob)
@@ -84,6 +87,8 @@ for name, f, y0, layout, d, n in cases:
             L.nnhip_tune_set(b"adv_steps_per_launch", K)
             L.nnhip_tune_set(b"adv_recompute_fsal", refsal)
             L.nnhip_tune_set(b"adv_lean", lean)
+            L.nnhip_tune_set(b"adv_auto_poll", auto)
+            L.nnhip_tune_set(b"fp_contract", contract)
             dt, launches, ys = run(f, y0, integ, layout, ce)
             per_step = 8 * (4 * d + 4) if refsal == 0 else 8 * (2 * d + 4)
             nb = per_step * accepted / K
@@ -91,9 +96,11 @@ for name, f, y0, layout, d, n in cases:
                                                  fsal="carried through HBM" if refsal == 0 else "re-evaluated per launch", bytes_per_step=per_step / K,
                                                  GBps=nb / dt / 1e9, frac_of_8TBps=nb / dt / 8e12,
                                                  frac_of_8TBps_round2_bytes=8 * (4 * d + 5) * accepted / K / dt / 8e12,
-                                                 fused_ms=fused_ms, equal_to_fused=bool(torch.equal(ys, yf[-1])))
+                                                 fused_ms=fused_ms, equal_to_fused=bool(torch.equal(ys, yf[-1])), max_abs_deviation_from_fused=float((ys - yf[-1]).abs().max()))
         L.nnhip_tune_set(b"adv_recompute_fsal", -1)
-        L.nnhip_tune_set(b"adv_lean", 1)
+        L.nnhip_tune_set(b"adv_lean", 0)
+        L.nnhip_tune_set(b"adv_auto_poll", 0)
+        L.nnhip_tune_set(b"fp_contract", 0)
         L.nnhip_tune_set(b"stream_graph", 2)
         L.nnhip_tune_set(b"adv_nontemporal", -1)
         L.nnhip_tune_set(b"adv_steps_per_launch", 1)

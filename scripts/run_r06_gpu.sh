@@ -2,7 +2,7 @@
 # Round 6: the measurements DESIGN.md section 6 quotes.  Stages, each one gpurun call (box time is budgeted):
 #   gpurun --timeout 3000 -- 'bash scripts/run_r06_gpu.sh tests'      the whole -m gpu suite
 #   gpurun --timeout 1500 -- 'bash scripts/run_r06_gpu.sh bench'      default bench line + rocprofv3 stats / PMC of the headline kernel (both cache regimes)
-#   gpurun --timeout 2400 -- 'bash scripts/run_r06_gpu.sh adaptive'   streamed C3 / C4: lean vs general kernels, automatic vs uniform polling (same box, same process),
+#   gpurun --timeout 2400 -- 'bash scripts/run_r06_gpu.sh adaptive'   streamed C3 / C4: general vs lean vs FMA-contracted lean kernels, uniform vs automatic polling (same box, same process),
 #                                                                     kernel-trace stats and PMC sets of both C4 kernels and of C3 at 1e6
 #   gpurun --timeout 1500 -- 'bash scripts/run_r06_gpu.sh rest'       fused configs, extras, divergence binning, torch-free C5 harness
 set -u
@@ -22,19 +22,21 @@ if [ "$STAGE" = bench ] || [ "$STAGE" = all ]; then
   tail -1 gpurun_out/r06_bench_default.json | cut -c1-900
 fi
 if [ "$STAGE" = adaptive ] || [ "$STAGE" = all ]; then
-  ADV_BENCH_MODES=default,general_kernel,poll8,general_kernel_poll8 timeout 900 python scripts/bench_adaptive_stream.py > gpurun_out/r06_bench_adaptive_stream.json 2> gpurun_out/bench_adaptive_stream.err
-  # the same command twice more, interleaved order does not matter inside one process; a second run shows the box's own spread
-  ADV_BENCH_MODES=default,general_kernel ADV_BENCH_INTEGRATORS=tsit54 ADV_BENCH_ONLY=C4 timeout 300 python scripts/bench_adaptive_stream.py > gpurun_out/r06_bench_adaptive_stream_c4_repeat.json 2>> gpurun_out/bench_adaptive_stream.err
+  # default = the recorded configuration (general kernels, groups of 8); the opt-in settings one by one, same process, same box
+  ADV_BENCH_MODES=default,lean,lean_auto_poll,general_auto_poll,lean_auto_poll_fp_contract timeout 900 python scripts/bench_adaptive_stream.py > gpurun_out/r06_bench_adaptive_stream.json 2> gpurun_out/bench_adaptive_stream.err
+  # the same command once more for C4: a second run shows the box's own spread
+  ADV_BENCH_MODES=default,lean,lean_auto_poll_fp_contract ADV_BENCH_INTEGRATORS=tsit54 ADV_BENCH_ONLY=C4 timeout 300 python scripts/bench_adaptive_stream.py > gpurun_out/r06_bench_adaptive_stream_c4_repeat.json 2>> gpurun_out/bench_adaptive_stream.err
   for cfg in C4:c4 C3_lorenz_N1e+06:c3; do
     only=${cfg%%:*}; tag=${cfg##*:}
-    ADV_BENCH_ONLY=$only ADV_BENCH_MODES=default,general_kernel timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_adv_stats_$tag -o adv -- \
+    ADV_BENCH_ONLY=$only ADV_BENCH_MODES=default,lean,lean_auto_poll_fp_contract timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_adv_stats_$tag -o adv -- \
       python scripts/bench_adaptive_stream.py > gpurun_out/prof_adv_stats_$tag.log 2>&1
   done
-  # PMC: the lean and the general kernel of streamed C4 (Tsit54), and streamed C3 at 1e6 (DOPRI54), counters only, one group per pass
-  ADV_BENCH_INTEGRATORS=tsit54 ADV_BENCH_MODES=default ADV_BENCH_ONLY=C4 KFILTER="advance_lps_lean_kernel<2," TAG=c4lean PMC_GROUPS=3 bash scripts/profile_c4_stream.sh > gpurun_out/prof_c4lean.log 2>&1
-  ADV_BENCH_INTEGRATORS=tsit54 ADV_BENCH_MODES=general_kernel ADV_BENCH_ONLY=C4 KFILTER="advance_lps_kernel<2," TAG=c4general PMC_GROUPS=3 bash scripts/profile_c4_stream.sh > gpurun_out/prof_c4general.log 2>&1
-  ADV_BENCH_INTEGRATORS=dopri54 ADV_BENCH_MODES=default ADV_BENCH_ONLY=C3_lorenz_N1e+06 KFILTER="advance_tpi_lean_kernel<1," TAG=c3lean PMC_GROUPS=5 bash scripts/profile_c4_stream.sh > gpurun_out/prof_c3lean.log 2>&1
-  ADV_BENCH_INTEGRATORS=dopri54 ADV_BENCH_MODES=general_kernel ADV_BENCH_ONLY=C3_lorenz_N1e+06 KFILTER="advance_tpi_kernel<1," TAG=c3general PMC_GROUPS=2 bash scripts/profile_c4_stream.sh > gpurun_out/prof_c3general.log 2>&1
+  # PMC: the general, the lean and the contracted lean kernel of streamed C4 (Tsit54), and streamed C3 at 1e6 (DOPRI54), counters only, one group per pass
+  ADV_BENCH_INTEGRATORS=tsit54 ADV_BENCH_MODES=lean ADV_BENCH_ONLY=C4 KFILTER="nnhip::advance_lps_lean_kernel<2," TAG=c4lean PMC_GROUPS=3 bash scripts/profile_c4_stream.sh > gpurun_out/prof_c4lean.log 2>&1
+  ADV_BENCH_INTEGRATORS=tsit54 ADV_BENCH_MODES=default ADV_BENCH_ONLY=C4 KFILTER="advance_lps_kernel<2," TAG=c4general PMC_GROUPS=3 bash scripts/profile_c4_stream.sh > gpurun_out/prof_c4general.log 2>&1
+  ADV_BENCH_INTEGRATORS=tsit54 ADV_BENCH_MODES=lean_auto_poll_fp_contract ADV_BENCH_ONLY=C4 KFILTER="nnhip_fast::advance_lps_lean_kernel<2," TAG=c4contracted PMC_GROUPS=3 bash scripts/profile_c4_stream.sh > gpurun_out/prof_c4contracted.log 2>&1
+  ADV_BENCH_INTEGRATORS=dopri54 ADV_BENCH_MODES=lean ADV_BENCH_ONLY=C3_lorenz_N1e+06 KFILTER="nnhip::advance_tpi_lean_kernel<1," TAG=c3lean PMC_GROUPS=5 bash scripts/profile_c4_stream.sh > gpurun_out/prof_c3lean.log 2>&1
+  ADV_BENCH_INTEGRATORS=dopri54 ADV_BENCH_MODES=default ADV_BENCH_ONLY=C3_lorenz_N1e+06 KFILTER="advance_tpi_kernel<1," TAG=c3general PMC_GROUPS=2 bash scripts/profile_c4_stream.sh > gpurun_out/prof_c3general.log 2>&1
   python - <<'PY'
 import json
 d = json.load(open("gpurun_out/r06_bench_adaptive_stream.json"))

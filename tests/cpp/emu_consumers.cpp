@@ -4,12 +4,14 @@
 // nnhip_hermite_spline_slopes_f64_dev do, minus the uploads.  tests/test_kernel_bodies_on_cpu.py compares the output with the vectors an execution of the
 // reference's text produced (tests/golden/reference_text_quad_vectors.json), bit for bit.  One request per line on stdin (hex floats):
 //   fn <rule 0 trapz | 1 simpson> <dim 1|3> <layout 0 SoA | 1 AoS> <N> <dx> <p0> <p1> <p2> <n_x> X...      -> "rc <code> rows <r>" + one line per row: N*dim values
-//   trapz <n> <M> X... Y[n][M]...                                                                            -> n lines of M values
-//   simpson <n> <M> X... Y[n][M]...                                                                          -> n lines of M values
-//   slopes <n> <M> X... Y[n][M]...                                                                           -> n lines of M values
+//   trapz <n> <M> X... Y[n][M]...        X in the CALLER's order (sortAndTrimDataset runs here as in the entries)     -> one line of M values per result row
+//   simpson <n> <M> X... Y[n][M]...                                                                          -> one line per result row (the caller's abscissae, the caller's order)
+//   slopes <n> <M> X... Y[n][M]...                                                                           -> one line per sorted, trimmed knot
+//   (a refusal — NaN in X, impure duplicates, too few distinct abscissae — prints one line "error <why>")
 //   eval <n> <M> <n_q> <deriv> <extrap> <extrap_value> X... Y[n][M]... dY[n][M]... xq...                     -> n_q lines of M values
 // The integrand of `fn` is the one the GPU test compiles at run time: f_c(x) = ((p0 x + p1) x) (1 + c) + p2.
 #include "consumer_kernels.hpp"
+#include "dataset_plan.hpp"
 #include "quad_plan.hpp"
 
 #include <cstdio>
@@ -78,6 +80,29 @@ static int do_fn(std::istringstream& in) {
   return 0;
 }
 
+// sorted_dataset of ode_capi_aux.hip minus the uploads: the host's plan, the purity check and the gather, kernel bodies on the host.  -> false: refused
+static bool sort_and_trim(std::vector<double>& X, std::vector<std::vector<double>*> Ys, int& n, int64_t M, DatasetPlan& pl, const std::vector<double>& callerX) {
+  std::string why;
+  if (dataset_plan(callerX.data(), n, pl, why) != 0) { std::printf("error %s\n", why.c_str()); return false; }
+  if (pl.identity) return true;
+  const unsigned gx = (unsigned)((M + kBlock - 1) / kBlock);
+  if (!pl.dupKeep.empty()) {
+    unsigned int flag = 0;
+    for (auto* Y : Ys)
+      hipemu::launch(dup_rows_differ_kernel, dim3(gx, (unsigned)pl.dupKeep.size()), dim3(kBlock), (const int32_t*)pl.dupKeep.data(), (const int32_t*)pl.dupDrop.data(),
+                     (int)pl.dupKeep.size(), (const double*)Y->data(), M, &flag);
+    if (flag) { std::printf("error impure y-duplicates\n"); return false; }
+  }
+  for (auto* Y : Ys) {
+    std::vector<double> g(pl.src.size() * (size_t)M, -7.0);
+    hipemu::launch(gather_rows_kernel, dim3(gx, (unsigned)pl.src.size()), dim3(kBlock), (const int32_t*)pl.src.data(), (int)pl.src.size(), (const double*)Y->data(), g.data(), M);
+    Y->swap(g);
+  }
+  X = pl.x;
+  n = (int)pl.x.size();
+  return true;
+}
+
 static int do_discrete(const std::string& what, std::istringstream& in) {
   int n;
   int64_t M;
@@ -85,6 +110,11 @@ static int do_discrete(const std::string& what, std::istringstream& in) {
   std::vector<double> X, Y;
   rdv(in, X, (size_t)n);
   rdv(in, Y, (size_t)n * (size_t)M);
+  const std::vector<double> callerX = X;   // X in the CALLER's order: sortAndTrimDataset runs here, as in the entries
+  const int nCaller = n;
+  DatasetPlan pl;
+  if (!sort_and_trim(X, {&Y}, n, M, pl, callerX)) return 0;
+  if ((what == "simpson" && n < 3) || (what == "slopes" && n < 2)) { std::printf("error too few distinct abscissae\n"); return 0; }
   std::vector<double> out((size_t)n * (size_t)M, -7.0);
   const dim3 grid((unsigned)((M + kBlock - 1) / kBlock)), block(kBlock);
   if (what == "trapz") {  // nnhip_cumtrapz_batch_f64_dev
@@ -103,6 +133,14 @@ static int do_discrete(const std::string& what, std::istringstream& in) {
     simpson_tables(X.data(), n, pairs, pts, nPairs, evenN);
     hipemu::launch(cumsimpson_kernel, grid, block, (const SimpsonPair*)pairs.data(), (int)nPairs, evenN ? 1 : 0, (const SimpsonPoint*)pts.data(), (const double*)Y.data(),
                    out.data(), M, n);
+    if (!pl.identity) {  // back to the caller's abscissae (hermiteInterpolate, integrate.nim:375)
+      std::vector<int32_t> rows;
+      simpson_result_rows(pl, callerX.data(), nCaller, rows);
+      std::vector<double> back(rows.size() * (size_t)M, -7.0);
+      hipemu::launch(gather_rows_kernel, dim3(grid.x, (unsigned)rows.size()), block, (const int32_t*)rows.data(), (int)rows.size(), (const double*)out.data(), back.data(), M);
+      out.swap(back);
+      n = (int)rows.size();
+    }
   } else {  // nnhip_hermite_spline_slopes_f64_dev
     hipemu::launch(hermite_slopes_kernel, dim3(grid.x, (unsigned)n), block, (const double*)X.data(), n, (const double*)Y.data(), M, out.data());
   }
@@ -117,6 +155,10 @@ static int do_eval(std::istringstream& in) {
   const double val = rd(in);
   std::vector<double> X, Y, dY, xq;
   rdv(in, X, (size_t)n); rdv(in, Y, (size_t)n * (size_t)M); rdv(in, dY, (size_t)n * (size_t)M); rdv(in, xq, (size_t)n_q);
+  const std::vector<double> callerX = X;   // knots in the CALLER's order: the constructor's sortAndTrimDataset(@X, @[@Y, @dY]) (interpolate.nim:231) runs here, as in the entry
+  DatasetPlan pl;
+  if (!sort_and_trim(X, {&Y, &dY}, n, M, pl, callerX)) return 0;
+  if (n < 2) { std::printf("error too few distinct abscissae\n"); return 0; }
   std::vector<double> out((size_t)n_q * (size_t)M, -7.0);
   for (int q0 = 0; q0 < n_q; q0 += kHermChunk) {  // nnhip_hermite_spline_eval_batch_f64_dev
     HermChunk c;

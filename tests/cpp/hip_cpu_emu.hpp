@@ -2,6 +2,8 @@
 // the kernel BODIES can be executed by the CPU test suite (tests/test_kernel_bodies_on_cpu.py): every lane of a workgroup is a coroutine (or, in the sanitizer
 // builds, a host thread) that runs concurrently with the others, workgroups run one after the other.  Nothing here is linked into libnnhip_ode.so, nothing in the product includes it (the headers reach it only under
 // -DNNHIP_CPU_EMU, which no product build defines); the library still has no CPU path and fails without a HIP device.
+// NNHIP_CPU_EMU is a COMPILE-TIME TEST HOOK: no library build defines it, no entry of the C ABI dispatches on it, it must never become a selectable path — and
+// tests/test_abi_and_host_logic.py::test_no_emulation_symbol_in_the_product_library checks that libnnhip_ode.so's symbol tables hold no `hipemu` symbol and that neither the library's Makefile nor anything the package imports names the macro.
 //
 // Why it exists: a round without GPU access (round 5) still had to show that new kernels compute the reference's bits.  What it shows: the indexing,
 // masking, control flow and arithmetic of a kernel body as written (compiled -ffp-contract=off: one IEEE rounding per operation, like the device build).

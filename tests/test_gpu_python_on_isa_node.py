@@ -12,6 +12,8 @@ import sys
 
 import pytest
 
+pytestmark = pytest.mark.slow  # the whole file runs on the ISA-backed fake node (minutes)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 

@@ -269,6 +269,7 @@ def _fused(G, helpers, co, kernel_rx, adaptive, y0, dim, layout, par, opt_fields
     return yout, ny, steps, rej, st
 
 
+@pytest.mark.slow
 def test_fused_solves_as_compiled(G, helpers, oracle):
     """The fused solve kernels (ODESolver per IVP, ode.nim:471-586, state in VGPRs for the whole solve) with the launch record the library's own planning code builds:
     scalar RK4 (C1 / C2's fused form; host-replayed step schedule), DOPRI54 Lorenz (C3; 48 SGPRs spilled through lanes), Tsit54 on the 16-component ring, four lanes
@@ -330,6 +331,7 @@ def _lean_symbols():
     return out
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize("sym", _lean_symbols(), ids=lambda t: "%s-%s%d-m%d" % ("lps" if t[2] else "tpi", t[4].lstrip("0123456789"), t[5], t[3]))
 def test_every_lean_instantiation_as_compiled(G, helpers, oracle, sym):
     """EVERY instantiation of the lean kernels in the library (40: both methods x the compiled-in right-hand sides — scalars to the 32-component ring on 8 lanes per
@@ -363,6 +365,7 @@ def test_every_lean_instantiation_as_compiled(G, helpers, oracle, sym):
 _ALL = ["heun2", "ralston2", "kutta3", "heun3", "ralston3", "ssprk3", "ralston4", "kutta4", "rk4", "rk21", "bs32", "dopri54", "tsit54", "vern65"]
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize("name", _ALL)
 def test_fused_lorenz_solve_of_every_integrator_as_compiled(nn, G, helpers, oracle, name):
     """All 14 integrators (ode.nim:107-468): the fused thread-per-IVP Lorenz solve from each method's object file — the tableau, the stage sums and (for the five

@@ -353,29 +353,41 @@ def test_function_form_quadrature_kernel_bodies_equal_the_reference_text(emu_con
 
 
 def test_discrete_quadrature_kernel_bodies_equal_the_reference_text(emu_consumers):
-    """cumtrapz(Y, X) / cumsimpson(Y, X) (integrate.nim:120-135, 329-375): cumtrapz_kernel (chunks of 384 interval weights) and cumsimpson_kernel with the
-    library's simpson_tables == the discrete cases of the reference's text on strictly ascending X (what the product accepts; the text's sorted-and-trimmed data for
-    the others is fed as it left sortAndTrimDataset).  GPU twin: ::test_discrete_forms_equal_the_reference_text."""
+    """cumtrapz(Y, X) / cumsimpson(Y, X) (integrate.nim:120-135, 329-375): the library's sortAndTrimDataset (dataset_plan.hpp + gather_rows_kernel /
+    dup_rows_differ_kernel), cumtrapz_kernel (chunks of 384 interval weights) and cumsimpson_kernel with the library's simpson_tables == the discrete cases of the
+    reference's text, fed with the CALLER's X and Y — unsorted, with pure duplicates — exactly as the text was.  GPU twin: ::test_discrete_forms_equal_the_reference_text."""
     cases = _quad_vectors()["cumquad_discrete"]
     reqs, meta = [], []
     for c in cases:
-        X = _fh(c["X"] if c["strictly_ascending"] else c["X_sorted_trimmed"])
-        Ys = c["Y"] if c["strictly_ascending"] else c["Y_sorted_trimmed"]
-        Y = np.tile(np.stack([_fh(y) for y in Ys], axis=1), (1, 90))     # [n, 270]: more than one workgroup of series
+        X = _fh(c["X"])
+        Y = np.tile(np.stack([_fh(y) for y in c["Y"]], axis=1), (1, 90))     # [n, 270]: more than one workgroup of series
         for what in ("trapz", "simpson"):
-            if what == "simpson" and isinstance(c["cumsimpson"], dict):
-                continue                                                    # fewer than 3 points: ValueError (integrate.nim:345-346), refused by the C entry
             reqs.append("%s %d %d %s %s" % (what, len(X), Y.shape[1], _hx(X), _hx(Y)))
             meta.append((c, what))
     outs = _consume(emu_consumers, reqs)
-    assert len(meta) >= 18
+    assert len(meta) >= 30
     for (c, what), o in zip(meta, outs):
+        if what == "simpson" and isinstance(c["cumsimpson"], dict):        # fewer than 3 distinct abscissae: ValueError (integrate.nim:345-346), refused
+            assert len(o) == 1 and o[0].startswith("error too few"), (c["name"], o[:1])
+            continue
         got = np.array([[float.fromhex(v) for v in ln.split()] for ln in o])
         want = np.stack([_fh(v) for v in c["cumtrapz" if what == "trapz" else "cumsimpson"]], axis=1)
-        if what == "simpson" and not c["strictly_ascending"]:   # the text interpolates back to the caller's (unsorted / duplicated) abscissae: the sorted values, looked up
-            row = {x: k for k, x in enumerate(_fh(c["X_sorted_trimmed"]).tolist())}
-            got = got[[row[x] for x in _fh(c["X"]).tolist()]]
-        assert np.array_equal(got, np.tile(want, (1, 90))), (c["name"], what)
+        assert got.shape == (want.shape[0], 270) and np.array_equal(got, np.tile(want, (1, 90))), (c["name"], what)
+    assert {c["name"] for c in cases if not c["strictly_ascending"]} >= {"unsorted", "unsorted_pure_duplicates", "sorted_repeated_maximum", "sorted_repeated_inside", "descending",
+                                                                        "negative_zero_pair", "all_but_two_equal"}
+    # what the reference refuses (utils.nim:372): the same x with different y — in ANY series of the batch; NaN duplicates are impure too (NaN != NaN); NaN in X
+    reqs = []
+    for c in _quad_vectors()["impure"]:
+        X, y = _fh(c["X"]), _fh(c["Y"])
+        clean = np.cos(X)
+        Y = np.stack([clean] * 69 + [y] + [clean] * 5, axis=1)            # one impure series among 75, in the second wave of the workgroup
+        for what in ("trapz", "simpson", "slopes"):
+            assert c[{"trapz": "cumtrapz", "simpson": "cumsimpson", "slopes": "newHermiteSpline"}[what]] == {"raises": "ValueError"}
+            reqs.append("%s %d %d %s %s" % (what, len(X), Y.shape[1], _hx(X), _hx(Y)))
+    reqs.append("trapz 3 2 %s %s" % (_hx([0.0, float("nan"), 1.0]), _hx(np.ones((3, 2)))))
+    outs = _consume(emu_consumers, reqs)
+    assert all(len(o) == 1 and o[0].startswith("error impure") for o in outs[:-1]), outs
+    assert outs[-1][0].startswith("error X[1] is NaN")
 
 
 def test_long_cumtrapz_crosses_weight_chunks(emu_consumers, oracle):
@@ -398,17 +410,19 @@ def test_hermite_spline_kernel_bodies_equal_the_reference_text(emu_consumers):
     M = 70
     reqs, meta = [], []
     for c in cases:
-        X, Y, dY, xq = (_fh(c[k]) for k in ("X", "Y", "dY", "xq"))
+        X, Y, dY, xq = (_fh(c[k]) for k in ("X", "Y", "dY", "xq"))     # knots in the CALLER's order (two cases unsorted, one of them with pure duplicates)
         Yb = np.tile(Y[:, None], (1, M))
         reqs.append("slopes %d %d %s %s" % (len(X), M, _hx(X), _hx(Yb)))
         meta.append((c, "slopes", None, None, None))
-        for key, slopes in (("with_dY", dY), ("estimated_slopes", _fh(c["slopes_from_text"]))):
-            dYb = np.tile(slopes[:, None], (1, M))
+        Xs = _fh(c["X_sorted_trimmed"])                                # newHermiteSpline(X, Y): the slopes belong to the sorted, trimmed knots (interpolate.nim:244-251)
+        Ys = Y[[list(X).index(x) for x in Xs]]
+        for key, (Xk, Yk, slopes) in (("with_dY", (X, Y, dY)), ("estimated_slopes", (Xs, Ys, _fh(c["slopes_from_text"])))):
+            Ykb, dYb = np.tile(Yk[:, None], (1, M)), np.tile(slopes[:, None], (1, M))
             for ex, rec in c[key].items():
                 if ex not in EX:
                     continue
                 for deriv in (0, 1):
-                    reqs.append("eval %d %d %d %d %d %s %s %s %s %s" % (len(X), M, len(xq), deriv, EX[ex], c["extrap_value"], _hx(X), _hx(Yb), _hx(dYb), _hx(xq)))
+                    reqs.append("eval %d %d %d %d %d %s %s %s %s %s" % (len(Xk), M, len(xq), deriv, EX[ex], c["extrap_value"], _hx(Xk), _hx(Ykb), _hx(dYb), _hx(xq)))
                     meta.append((c, "eval", key, ex, deriv))
     outs = _consume(emu_consumers, reqs)
     n_eval = 0
@@ -420,7 +434,7 @@ def test_hermite_spline_kernel_bodies_equal_the_reference_text(emu_consumers):
             want = _fh(c[key][ex]["derivEval" if deriv else "eval"])
             assert np.array_equal(got, np.tile(want[:, None], (1, M))), (c["name"], key, ex, deriv)
             n_eval += 1
-    assert n_eval == 4 * 2 * 4 * 2
+    assert n_eval == len(cases) * 2 * 4 * 2 and len(cases) == 6
 
 
 # ---- the adaptive streaming driver with dense output (tests/cpp/emu_dense.cpp) ---------------------------------------------------------------------------------
