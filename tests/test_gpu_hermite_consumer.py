@@ -29,10 +29,6 @@ def test_hermite_spline_on_trajectories(nn, oracle, dev):
     assert torch.equal(spl.eval(t), y)
     with pytest.raises(ValueError):
         spl.eval([1.5], extrap="Error")
-    # knots handed over in descending order: the constructor sorts (interpolate.nim:231; round 6) — the rows of y, dy then belong to the reversed abscissae
-    rev = nn.newHermiteSpline(t[::-1].copy(), y, dy).eval([0.5]).cpu().numpy().reshape(1, -1)
-    for m in range(0, Yh.shape[1], 37):
-        assert np.array_equal(rev[:, m], O.hermite_interp(t[::-1].copy(), Yh[:, m], dYh[:, m], [0.5]))
     # interpolation error of the cubic Hermite spline against a fine-grid solve is small
     tf, yf = nn.solveODE(f, torch.from_numpy(y0).to(dev), [0.0, 0.525], nn.newODEoptions(dt=1e-3), integrator="rk4")
     assert float((spl.eval(0.525) - yf[-1]).abs().max()) < 2e-2  # h^4 error of a cubic Hermite with knot spacing 0.05 on Lorenz
@@ -56,9 +52,6 @@ def test_cumtrapz_on_trajectories(nn, oracle, dev):
     assert np.array_equal(nn.trapz(y, t).cpu().numpy(), c[-1])
     exact = y0 * (1 - np.exp(-0.8 * t[-1])) / 0.8
     assert np.abs(c[-1] - exact).max() < 1e-4
-    cr = nn.cumtrapz(y, t[::-1].copy()).cpu().numpy()   # descending X: sorted first (integrate.nim:131; round 6)
-    for m in range(0, n, 13):
-        assert np.array_equal(cr[:, m], O.cumtrapz(yh[:, m], t[::-1].copy()))
 
 
 @pytest.mark.parametrize("n_t", [3, 4, 5, 10, 11, 200, 201])
@@ -106,11 +99,10 @@ def test_hermite_spline_without_dy(nn, oracle, dev):
         nn.newHermiteSpline(X[:1], Y[:1])
 
 
-def test_host_pointer_forms_equal_the_device_forms(nn, oracle, dev):
+def test_host_pointer_forms_equal_the_device_forms(nn, dev):
     """The consumers called with host arrays (what the Nim shim would do) stage through the device and return the same bits:
     HermiteSpline with and without dY, cumtrapz, cumsimpson, and the function forms with a host parameter sweep."""
     import torch
-    O = oracle
     rng = np.random.default_rng(12)
     X = np.cumsum(0.05 + rng.random(41))
     Yh = np.stack([np.cos(X) * (1 + k) for k in range(6)], axis=1)
@@ -135,4 +127,28 @@ def test_host_pointer_forms_equal_the_device_forms(nn, oracle, dev):
                               fn(f, Xq, dx=1e-2, n=3, ctx=nn.newNumContext({"a": 0.5, "b": 2.0})).cpu().numpy())
     with pytest.raises(ValueError):
         nn.cumsimpson(Yh[:2], X[:2])
-    assert np.array_equal(nn.cumtrapz(Yh, X[::-1].copy())[:, 0], O.cumtrapz(Yh[:, 0], X[::-1].copy()))   # descending X: sorted first (round 6)
+
+
+def test_descending_abscissae_are_sorted_like_the_reference(nn, oracle, dev):
+    """Until round 5 these calls were refused (the product required strictly ascending X); the reference sorts and trims first (integrate.nim:131, 340;
+    interpolate.nim:231, 244), and since round 6 so does the backend: a trajectory handed over with its time axis reversed — device entries and host-pointer
+    entries — against the oracle, which is fed the same reversed arrays.  (A first-contact test: tests/conftest.py runs it after the recorded ones.)"""
+    import torch
+    O = oracle
+    rng = np.random.default_rng(21)
+    X = np.cumsum(0.05 + rng.random(41))
+    Yh = np.stack([np.cos(X) * (1 + k) for k in range(6)], axis=1)
+    dYh = np.stack([-np.sin(X) * (1 + k) for k in range(6)], axis=1)
+    Xr = X[::-1].copy()
+    Y, dY = torch.from_numpy(Yh).to(dev), torch.from_numpy(dYh).to(dev)
+    xq = X[0] + (X[-1] - X[0]) * rng.random(30)
+    ct, cs = nn.cumtrapz(Y, Xr).cpu().numpy(), nn.cumsimpson(Y, Xr).cpu().numpy()
+    ev = nn.newHermiteSpline(Xr, Y, dY).eval(xq).cpu().numpy()
+    es = nn.newHermiteSpline(Xr, Y).derivEval(xq).cpu().numpy()
+    for m in range(6):
+        assert np.array_equal(ct[:, m], O.cumtrapz(Yh[:, m], Xr)) and np.array_equal(cs[:, m], O.cumsimpson(Yh[:, m], Xr))
+        assert np.array_equal(ev[:, m], O.hermite_interp(Xr, Yh[:, m], dYh[:, m], xq))
+        xs, (ys,) = O.sort_and_trim(Xr, Yh[:, m])
+        assert np.array_equal(es[:, m], O.hermite_interp(xs, ys, O.hermite_slopes(Xr, Yh[:, m]), xq, deriv=True))
+    assert np.array_equal(nn.cumtrapz(Yh, Xr), ct) and np.array_equal(nn.cumsimpson(Yh, Xr), cs)      # the host-pointer entries
+    assert np.array_equal(nn.newHermiteSpline(Xr, Yh, dYh).eval(xq), ev) and np.array_equal(nn.newHermiteSpline(Xr, Yh).derivEval(xq), es)
