@@ -37,6 +37,10 @@ if [ "$STAGE" = adaptive ] || [ "$STAGE" = all ]; then
   ADV_BENCH_INTEGRATORS=tsit54 ADV_BENCH_MODES=lean_auto_poll_fp_contract ADV_BENCH_ONLY=C4 KFILTER="nnhip_fast::advance_lps_lean_kernel<2," TAG=c4contracted PMC_GROUPS=3 bash scripts/profile_c4_stream.sh > gpurun_out/prof_c4contracted.log 2>&1
   ADV_BENCH_INTEGRATORS=dopri54 ADV_BENCH_MODES=lean ADV_BENCH_ONLY=C3_lorenz_N1e+06 KFILTER="nnhip::advance_tpi_lean_kernel<1," TAG=c3lean PMC_GROUPS=5 bash scripts/profile_c4_stream.sh > gpurun_out/prof_c3lean.log 2>&1
   ADV_BENCH_INTEGRATORS=dopri54 ADV_BENCH_MODES=default ADV_BENCH_ONLY=C3_lorenz_N1e+06 KFILTER="advance_tpi_kernel<1," TAG=c3general PMC_GROUPS=2 bash scripts/profile_c4_stream.sh > gpurun_out/prof_c3general.log 2>&1
+  # the kernels alone, torch-free (tools/microbench/mb_adv.hip): general vs lean, bit-exact and FMA-contracted builds, 60 timed iterations each, interleaved and repeated
+  make -C tools/microbench mb_adv mb_adv_contract > gpurun_out/mb_build.log 2>&1
+  timeout 300 tools/microbench/mb_adv lean > gpurun_out/r06_mb_adv_lean.txt 2>&1
+  timeout 300 tools/microbench/mb_adv_contract lean > gpurun_out/r06_mb_adv_lean_contracted.txt 2>&1
   python - <<'PY'
 import json
 d = json.load(open("gpurun_out/r06_bench_adaptive_stream.json"))

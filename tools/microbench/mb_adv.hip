@@ -136,6 +136,15 @@ template <int METHOD, class RHS, int CPL>
 static Launch lps_base(int K = 1) {
   return [K](const StepArgs& a0, hipStream_t st) { StepArgs a = a0; a.stepsPerLaunch = K; return launch_advance_lps<METHOD, RHS, CPL>(a, 0, st); };
 }
+// the general kernel where the lean one would apply (StepArgs::noLean: what tuning knob "adv_lean" 0 sets in the library)
+template <int METHOD, class RHS, int CPL>
+static Launch lps_general() {
+  return [](const StepArgs& a0, hipStream_t st) { StepArgs a = a0; a.noLean = 1; return launch_advance_lps<METHOD, RHS, CPL>(a, 0, st); };
+}
+template <int METHOD, class RHS>
+static Launch tpi_general(int block) {
+  return [block](const StepArgs& a0, hipStream_t st) { StepArgs a = a0; a.noLean = 1; return launch_advance_tpi<METHOD, RHS>(a, block, st); };
+}
 template <int METHOD, class RHS, int CPL, bool PP = false, int PROBE = 0>
 static Launch lps_persist(int blocksPerCU) {
   return [blocksPerCU](const StepArgs& a, hipStream_t st) {
@@ -182,6 +191,43 @@ int main(int argc, char** argv) {
   const char* only = argc > 1 ? argv[1] : "";
   int dev = 0; CK(hipSetDevice(dev));
   const double dtMax = 1e-2, dtMin = 1e-4;
+  if (strstr(only, "lean")) {  // round 6: the general kernels against the lean ones (mode 3 = the streaming driver's own layout, where lps_base / tpi_base dispatch to the
+                               // lean kernels), BASELINE's streamed C4 and C3 at 1e6, interleaved and repeated.  Other builds of this file, same argument:
+                               //   make mb_adv_contract   both columns FMA-contracted (the lean column = the library's "fp_contract" kernels; bits differ from the exact build's)
+                               //   make mb_adv_report0    round 5's flag store (every active lane, no barrier) — only matters in polled launches, which this harness never issues
+                               //   make mb_adv EXTRA=-DNNHIP_ADV_LEAN_WPE=4   contracted C4 at 128 VGPRs (9 spilled) = 4 waves per SIMD
+    {
+      Problem p; p.N = 1000000; p.dim = 16; p.layout = 1; p.y0.resize((size_t)p.N * 16);
+      for (int64_t i = 0; i < p.N; ++i) for (int c = 0; c < 16; ++c) p.y0[i * 16 + c] = 1.0 + c / 16.0 + (double)(i % 1024) * 0x1p-20;
+      std::memset(&p.P, 0, sizeof(p.P)); p.P.p[0] = 0.1;
+      p.ctl = StepCtl{1e-4, 1e-4, dtMax, dtMin}; p.t0 = 0; p.tEnd = 1.0; p.dt0 = std::sqrt(dtMax * dtMin);
+      using R = RhsRing<16>;
+      std::vector<Candidate> c;
+      for (int rep = 0; rep < 2; ++rep) {
+        c.push_back({"tsit54 general CPL=4", lps_general<NNHIP_TSIT54, R, 4>(), 1, 3});
+        c.push_back({"tsit54 LEAN CPL=4", lps_base<NNHIP_TSIT54, R, 4>(), 1, 3});
+        c.push_back({"dopri54 general CPL=4", lps_general<NNHIP_DOPRI54, R, 4>(), 1, 3});
+        c.push_back({"dopri54 LEAN CPL=4", lps_base<NNHIP_DOPRI54, R, 4>(), 1, 3});
+      }
+      run_all<R>("C4 streamed, general vs lean (288 B per system-step)", p, c, 10, 60, 5, 8.0 * (2 * 16 + 4));
+    }
+    {
+      Problem p; p.N = 1000000; p.dim = 3; p.layout = 0; p.y0.resize((size_t)p.N * 3);
+      for (int64_t i = 0; i < p.N; ++i) { p.y0[i] = 1.0 + (double)(i % 1024) * 0x1p-20; p.y0[p.N + i] = 1.0; p.y0[2 * p.N + i] = 1.0; }
+      std::memset(&p.P, 0, sizeof(p.P)); p.P.p[0] = 10.0; p.P.p[1] = 28.0; p.P.p[2] = 8.0 / 3.0;
+      p.ctl = StepCtl{1e-4, 1e-4, dtMax, dtMin}; p.t0 = 0; p.tEnd = 1.0; p.dt0 = std::sqrt(dtMax * dtMin);
+      using R = RhsLorenz;
+      std::vector<Candidate> c;
+      for (int rep = 0; rep < 2; ++rep) {
+        c.push_back({"dopri54 general b64", tpi_general<NNHIP_DOPRI54, R>(64), 1, 3});
+        c.push_back({"dopri54 LEAN b64", tpi_base<NNHIP_DOPRI54, R>(64, 0), 1, 3});
+        c.push_back({"tsit54 general b64", tpi_general<NNHIP_TSIT54, R>(64), 1, 3});
+        c.push_back({"tsit54 LEAN b64", tpi_base<NNHIP_TSIT54, R>(64, 0), 1, 3});
+      }
+      run_all<R>("C3 streamed at 1e6, general vs lean (80 B per IVP-step)", p, c, 10, 60, 5, 8.0 * (2 * 3 + 4));
+    }
+    return 0;
+  }
   if (!*only || strstr(only, "c4")) {  // C4: 1e6 x 16 ring, AoS, default options
     Problem p; p.N = 1000000; p.dim = 16; p.layout = 1; p.y0.resize((size_t)p.N * 16);
     for (int64_t i = 0; i < p.N; ++i) for (int c = 0; c < 16; ++c) p.y0[i * 16 + c] = 1.0 + c / 16.0 + (double)(i % 1024) * 0x1p-20;
