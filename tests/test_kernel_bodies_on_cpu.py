@@ -390,6 +390,47 @@ def test_discrete_quadrature_kernel_bodies_equal_the_reference_text(emu_consumer
     assert outs[-1][0].startswith("error X[1] is NaN")
 
 
+def test_sort_and_trim_plan_agrees_with_the_oracle_on_random_datasets(emu_consumers, oracle):
+    """The product's sortAndTrimDataset (dataset_plan.hpp on the host, gather_rows_kernel / dup_rows_differ_kernel bodies) against the oracle's restatement of
+    utils.nim:360-413 on 60 random datasets: shuffled abscissae, runs of pure duplicates, -0.0 / 0.0 pairs, sorted inputs with repeated maxima, lengths 3 ... 40 —
+    cumtrapz rows (one per distinct abscissa), cumsimpson rows (at the caller's abscissae, hermiteInterpolate's two branches) and the slopes of the sorted knots."""
+    rng = np.random.default_rng(2026)
+    reqs, meta = [], []
+    for case in range(60):
+        n = int(rng.integers(3, 41))
+        X = np.round(rng.uniform(-2.0, 3.0, n), 1 if case % 3 else 3)          # one decimal: many duplicates
+        if case % 5 == 0:
+            X = np.sort(X)                                                      # the sorted branch, with whatever repeats the rounding produced
+            X[-1] = X[-2] if case % 10 == 0 else X[-1]
+        if case % 7 == 0:
+            X[rng.integers(0, n)] = 0.0
+            X[rng.integers(0, n)] = -0.0
+        Y = np.stack([np.cos(X) * 2.0, (0.75 * X - 1.25) * X + 0.5, np.exp(-X) - 0.3 * X], axis=1)     # functions of x: every duplicate is pure
+        for what in ("trapz", "simpson", "slopes"):
+            reqs.append("%s %d %d %s %s" % (what, n, 3, _hx(X), _hx(Y)))
+            meta.append((what, X, Y))
+    outs = _consume(emu_consumers, reqs)
+    seen = {"refused": 0, "trimmed": 0, "fewer_simpson_rows": 0}
+    for (what, X, Y), o in zip(meta, outs):
+        xs, _ = oracle.sort_and_trim(X, Y[:, 0])
+        seen["trimmed"] += len(xs) < len(X)
+        if o and o[0].startswith("error"):
+            assert (what == "simpson" and len(xs) < 3) or (what == "slopes" and len(xs) < 2), (what, X, o)
+            seen["refused"] += 1
+            continue
+        got = np.array([[float.fromhex(v) for v in ln.split()] for ln in o])
+        for m in range(3):
+            if what == "trapz":
+                want = oracle.cumtrapz(Y[:, m], X)
+            elif what == "simpson":
+                want = oracle.cumsimpson(Y[:, m], X)
+                seen["fewer_simpson_rows"] += len(want) < len(X)
+            else:
+                want = oracle.hermite_slopes(X, Y[:, m])
+            assert got.shape[0] == len(want) and np.array_equal(got[:, m], want), (what, m, X)
+    assert seen["trimmed"] > 60 and seen["fewer_simpson_rows"] > 0, seen
+
+
 def test_long_cumtrapz_crosses_weight_chunks(emu_consumers, oracle):
     """1000 points: three launches of cumtrapz_kernel (384 weights each), every one resuming from the stored running integral == the oracle."""
     rng = np.random.default_rng(5)
