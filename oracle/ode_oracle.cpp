@@ -11,8 +11,9 @@
 // check / time the HIP product path against it.  NOTHING in the product path (numericalnim_amd/,
 // include/) may include, link or call anything in oracle/.
 //
-// Parity pin status: the reference is Nim and no Nim compiler exists in the build image, so the
-// reference itself cannot be run here, and it stores no bit-level golden vectors.  The oracle is
+// Parity pin status — by the letter of the rule, PARITY UNPINNED at the bit level: the reference is Nim and no
+// Nim compiler exists in the build image, so the reference itself cannot be run here, and it stores no bit-level
+// golden vectors.  What exists instead: the oracle is
 // pinned against every known-answer test the reference holds for this path
 // (tests/test_ode.nim:24-257: all 14 integrators vs exp(-0.1 t) on linspace(-10,10,100) incl.
 // `t == tspan`, at the reference's own tolerances; tests/test_vector.nim operator semantics;
@@ -21,10 +22,14 @@
 // survey's independent scratch known-answer values, and — bit for bit — against a second
 // restatement written independently from ode.nim / utils.nim in plain Python floats (oracle/py_restatement.py;
 // tests/test_oracle_two_restatements.py: 14 integrators, scalar and Vector states, both directions, dense rows).
+// Since round 4 it is also compared, bit for bit, with an EXECUTION OF THE REFERENCE'S OWN TEXT by a Nim-subset interpreter written
+// here (oracle/nim_subset.py, nim_subset_quad.py; vectors under tests/golden/reference_text_*.json): every ODE row, and since rounds
+// 5 / 6 the f4 consumers incl. sortAndTrimDataset.  An interpreter of our own is a stand-in for the compiler the image lacks: the
+// strongest pin obtainable here, formally not a run of the reference.
 // Bit-level identity with a Nim build is by construction (same IEEE-754 double operations in the same order,
 // compiled -ffp-contract=off, no fast-math, the same libm pow), not by execution.
 //
-// Build: see oracle/Makefile  (g++ -O2 -ffp-contract=off -fno-fast-math)
+// Build: see oracle/Makefile  (g++ -O3 -ffp-contract=off -fno-fast-math; same bits as -O2)
 // =============================================================================
 #include <algorithm>
 #include <cctype>
