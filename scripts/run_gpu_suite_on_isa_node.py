@@ -64,21 +64,28 @@ def main():
         return tid, status, time.time() - t0, why
 
     res = []
+    out_path = (os.path.join(ROOT, a.o) if not os.path.isabs(a.o) else a.o) if a.o else None
+    if out_path:  # results are appended as they arrive: a run that is cut short (session end, timeout of the caller) keeps what it has
+        with open(out_path, "a") as f:
+            f.write("# %s  -j %d --timeout %d --devices %d %s  (%d ids; lines follow as tests finish)\n" % (time.strftime("%Y-%m-%d %H:%M"), a.j, a.timeout, a.devices, " ".join(a.sel), len(ids)))
     with cf.ThreadPoolExecutor(a.j) as ex:
-        for k, r in enumerate(ex.map(run, ids)):
+        futs = [ex.submit(run, t) for t in ids]
+        for k, fu in enumerate(cf.as_completed(futs)):
+            r = fu.result()
             res.append(r)
             print("%4d/%d  %-34s %6.0f s  %s  %s" % (k + 1, len(ids), r[1], r[2], r[0], r[3]), flush=True)
+            if out_path:
+                with open(out_path, "a") as f:
+                    f.write("%-34s %6.0f s  %s%s\n" % (r[1], r[2], r[0], ("   " + r[3]) if r[3] else ""))
     tally = {}
     for _t, s, _d, _w in res:
         s = "too large for the interpreter" if s.startswith("too large") else s
         tally[s] = tally.get(s, 0) + 1
     summary = "  ".join("%s: %d" % kv for kv in sorted(tally.items()))
     print("SUMMARY  " + summary)
-    if a.o:
-        with open(os.path.join(ROOT, a.o) if not os.path.isabs(a.o) else a.o, "a") as f:
-            f.write("# %s  -j %d --timeout %d --devices %d %s\n# %s\n" % (time.strftime("%Y-%m-%d %H:%M"), a.j, a.timeout, a.devices, " ".join(a.sel), summary))
-            for t, s, dur, w in res:
-                f.write("%-34s %6.0f s  %s%s\n" % (s, dur, t, ("   " + w) if w else ""))
+    if out_path:
+        with open(out_path, "a") as f:
+            f.write("# %s\n" % summary)
     return 0 if all(s in ("passed", "skipped", "deselected") or s.startswith("too large") for _t, s, _d, _w in res) else 1
 
 
