@@ -160,7 +160,8 @@ int nnhip_host_free(void* p);
  *   of RK4 / DOPRI54 / Tsit54 / Vern65 and the lean kernels of the adaptive streaming loop, DOPRI54 / Tsit54, wherever a launch has their layout
  *   (whatever "adv_lean" says): NOT bit-exact, within 1e-10 / 1e-6), "host_chunks" 0..64 (0 = automatic: 8 when the caller's buffers are page-locked, else 1) and
  *   "host_register" 0|1 (pipelining of the host-pointer solve) */
-/* Changing a knob drops the calling thread's hipGraph caches so that the new setting takes effect on its next call. */
+/* Changing a knob drops the calling thread's hipGraph caches so that the new setting takes effect on its next call.  Knobs are process-wide atomics:
+ * setting one while other host threads are inside the library is defined (no torn value; a call already running may finish under the old setting). */
 int nnhip_tune_set(const char* key, int value);
 /* Which instantiation of the headline kernel (rk4_stream_vec_kernel<RHS, NEG, VEC, MODE>) the scalar RK4 step entry launches for
  * `n_states` flat float64 states (in_place: y_out == y_in, else two buffers): the knobs above, or the automatic choice by working set.

@@ -49,38 +49,38 @@ extern const MethodInfo kMethods[NNHIP_N_INTEGRATORS] = {
     {"ralston4", 0, 4.0, 0, 1}, {"kutta4", 0, 4.0, 0, 1},
 };
 
-int g_host_chunks = 0;    // tuning knob "host_chunks": 0 = auto (8 when the caller's buffers are page-locked, else 1; see nnhip_ode_solve_batch_f64)
-int g_host_register = 0;  // tuning knob "host_register": page-lock the caller's buffers for the duration of a host-pointer solve
-int g_fast_math = 0;     // tuning knob "fp_contract": 1 = FMA-contracted instantiations of the fused kernels (not bit-exact)
-int g_stream_graph = 2;  // tuning knob "stream_graph": 0 eager launches; 1 hipGraph capture + replay of the streaming loop;
+std::atomic<int> g_host_chunks{0};    // tuning knob "host_chunks": 0 = auto (8 when the caller's buffers are page-locked, else 1; see nnhip_ode_solve_batch_f64)
+std::atomic<int> g_host_register{0};  // tuning knob "host_register": page-lock the caller's buffers for the duration of a host-pointer solve
+std::atomic<int> g_fast_math{0};     // tuning knob "fp_contract": 1 = FMA-contracted instantiations of the fused kernels (not bit-exact)
+std::atomic<int> g_stream_graph{2};  // tuning knob "stream_graph": 0 eager launches; 1 hipGraph capture + replay of the streaming loop;
                          // 2 (default) = replay only launch-bound batches, from the second identical call on
-int g_fixed_vec_ipl = 2;  // tuning knob "fixed_vec_ipl": IVPs per lane of the vectorised fixed-step streaming kernel (0 = off, 2)
-int g_mg_oversubscribe = 0;  // tuning knob "multi_gpu_oversubscribe": the multi-GPU host entry accepts more shards than devices (shard r on device
+std::atomic<int> g_fixed_vec_ipl{2};  // tuning knob "fixed_vec_ipl": IVPs per lane of the vectorised fixed-step streaming kernel (0 = off, 2)
+std::atomic<int> g_mg_oversubscribe{0};  // tuning knob "multi_gpu_oversubscribe": the multi-GPU host entry accepts more shards than devices (shard r on device
                              // r mod #devices) — lets a one-GPU box exercise the sharded code path (index ranges, strided copies, empty shards)
-int g_adv_nt = -1;        // tuning knob "adv_nontemporal": -1 = automatic (thread-per-IVP state beyond 192 MiB), 0 / 1 = force
-int g_adv_refsal = -1;    // tuning knob "adv_recompute_fsal": DOPRI54 / Tsit54 streaming loops re-evaluate FSAL = f(t, y) per launch instead of carrying it through
+std::atomic<int> g_adv_nt{-1};        // tuning knob "adv_nontemporal": -1 = automatic (thread-per-IVP state beyond 192 MiB), 0 / 1 = force
+std::atomic<int> g_adv_refsal{-1};    // tuning knob "adv_recompute_fsal": DOPRI54 / Tsit54 streaming loops re-evaluate FSAL = f(t, y) per launch instead of carrying it through
                           // HBM (16*d bytes per step less, the same bits).  -1 = automatic (on, unless the right-hand side has mutable slots: the extra
                           // evaluation would be observable), 0 = carry (the IntegratorProc signature as the reference passes it), 1 = force
-int g_adv_block = 0;      // tuning knob "adv_block": workgroup size of the thread-per-IVP advance kernel (0 = auto: 64)
-int g_sort_copy = 0;      // tuning knob "sort_copy": the binned solve reorders the batch physically (gather, solve, scatter) instead of following perm[] inside the
+std::atomic<int> g_adv_block{0};      // tuning knob "adv_block": workgroup size of the thread-per-IVP advance kernel (0 = auto: 64)
+std::atomic<int> g_sort_copy{0};      // tuning knob "sort_copy": the binned solve reorders the batch physically (gather, solve, scatter) instead of following perm[] inside the
                           // kernel.  Measured and NOT the default (profiles/r03_bench_divergence.json, 1e6 Van der Pol IVPs): 1.77 ms against 1.65 ms with the
                           // order array followed in the kernel (pre-sorted by the caller: 1.52) — the five extra kernels and the stream-ordered allocation cost
                           // more than the scattered first load and last stores they remove
-int g_adv_steps = 1;      // tuning knob "adv_steps_per_launch": loop iterations per IVP and launch of nnhip_ode_adaptive_stream_f64_dev (1 = the IntegratorProc
+std::atomic<int> g_adv_steps{1};      // tuning knob "adv_steps_per_launch": loop iterations per IVP and launch of nnhip_ode_adaptive_stream_f64_dev (1 = the IntegratorProc
                           // seam proper; K > 1 keeps the state in registers for K iterations: 8*(4d+5)/K bytes per attempted step, a different traffic model)
-int g_sort_auto_key = 1;   // tuning knob "sort_auto_key": what the automatic binned solve ranks by — 0 the probe's progress, 1 the steps still to take (tEnd - t) / dt (forward spans)
-int g_calls_bin = 1;       // tuning knob "calls_bin": the per-IVP-call solves (every IVP its own tEnd / tspan) of kCallsBinMinN calls or more integrate the longest spans first, binned by span
-int g_sort_rebin_steps = 0;  // tuning knob "sort_rebin_steps": > 0 = the resumed automatic binned solve stops after that many further accepted steps per IVP, re-bins by the steps still to take, and finishes
-int g_sort_resume = 0;     // tuning knob "sort_resume": the automatic binned solve continues from its probe's state instead of restarting (where the loop's state is (t, dt, y)).
+std::atomic<int> g_sort_auto_key{1};   // tuning knob "sort_auto_key": what the automatic binned solve ranks by — 0 the probe's progress, 1 the steps still to take (tEnd - t) / dt (forward spans)
+std::atomic<int> g_calls_bin{1};       // tuning knob "calls_bin": the per-IVP-call solves (every IVP its own tEnd / tspan) of kCallsBinMinN calls or more integrate the longest spans first, binned by span
+std::atomic<int> g_sort_rebin_steps{0};  // tuning knob "sort_rebin_steps": > 0 = the resumed automatic binned solve stops after that many further accepted steps per IVP, re-bins by the steps still to take, and finishes
+std::atomic<int> g_sort_resume{0};     // tuning knob "sort_resume": the automatic binned solve continues from its probe's state instead of restarting (where the loop's state is (t, dt, y)).
                           // Built, bit-identical, measured and NOT the default (profiles/r04_bench_divergence.json): the resumed pass has to run on the per-call instantiation of
                           // the solve kernel (per-lane tStart / dt), which takes 1.61 ms for 122 steps where the lean one takes 1.46 ms for all 130: 1.70 vs 1.68 ms
-double g_sort_min_spread = 0.05;  // tuning knob "sort_min_spread_permille": the binned solve sorts only when the keys differ by more than this fraction of their magnitude
-int g_adv_lean = 0;       // tuning knob "adv_lean": 1 = the adaptive streaming loop runs its lean kernels (the driver's own layout as the kernel's contract) where they apply.
+std::atomic<double> g_sort_min_spread{0.05};  // tuning knob "sort_min_spread_permille": the binned solve sorts only when the keys differ by more than this fraction of their magnitude
+std::atomic<int> g_adv_lean{0};       // tuning knob "adv_lean": 1 = the adaptive streaming loop runs its lean kernels (the driver's own layout as the kernel's contract) where they apply.
                           // Same bits as the general kernels.  Opt-in until an MI355X has timed them: round 4's hardware record is of the general kernels.
-int g_adv_auto_poll = 0;  // tuning knob "adv_auto_poll": 1 = check_every <= 0 means the library's own polling schedule (adv_poll_schedule.hpp); 0 = uniform groups
+std::atomic<int> g_adv_auto_poll{0};  // tuning knob "adv_auto_poll": 1 = check_every <= 0 means the library's own polling schedule (adv_poll_schedule.hpp); 0 = uniform groups
                           // of 8 launches, the behaviour with a hardware record (round 4).  Opt-in for the same reason.
-int g_adv_split = 0;      // tuning knob "adv_split": index ranges the adaptive streaming loop interleaves on separate streams (0 = auto, 1, 2, 4)
-int g_dim16_variant = 0;  // tuning knob "dim16_variant": A/B mappings of the fused 16-component kernels (see ode_kernels.hpp)
+std::atomic<int> g_adv_split{0};      // tuning knob "adv_split": index ranges the adaptive streaming loop interleaves on separate streams (0 = auto, 1, 2, 4)
+std::atomic<int> g_dim16_variant{0};  // tuning knob "dim16_variant": A/B mappings of the fused 16-component kernels (see ode_kernels.hpp)
 
 nnhip::SolveLaunchFn find_solve(int integrator, int rhs_kind, int dim) {
   if (g_fast_math) {  // opt-in FMA-contracted build of the compute-bound fused kernels
@@ -185,8 +185,9 @@ int check_common(const nnhip_ode_options* opt, int integrator, int rhs_kind, con
 // ODESolver's bookkeeping before the loops (ode.nim:476-487, 510, 549, 585)
 
 // tuning knobs of the headline streaming kernel (nnhip_tune_set); defaults = the measured best
-nnhip::StreamTune g_tune;
-bool g_tune_auto = true;  // pick (vec, mode) from the working-set size; any explicit nnhip_tune_set pins them
+// the headline kernel's (vec, mode, blocksPerCU): three independent knobs, read as a snapshot (tune_snapshot)
+std::atomic<int> g_tune_vec{nnhip::StreamTune{}.vec}, g_tune_mode{nnhip::StreamTune{}.mode}, g_tune_blocks_per_cu{nnhip::StreamTune{}.blocksPerCU};
+std::atomic<bool> g_tune_auto{true};  // pick (vec, mode) from the working-set size; any explicit nnhip_tune_set pins them
 
 // pinned staging for the (tiny) requested-time arrays of the device-pointer solve
 thread_local Staging g_stage;
@@ -362,9 +363,9 @@ int nnhip_tune_set(const char* key, int value) {
   if (k == "dim16_variant") { if (value < 0 || value > 4) return fail(NNHIP_EVALUE, "dim16_variant must be 0..4"); g_dim16_variant = value; return NNHIP_OK; }
   if (k == "rk4_stream_auto") { g_tune_auto = value != 0; return NNHIP_OK; }
   if (k == "rk4_stream_vec" || k == "rk4_stream_mode") g_tune_auto = false;
-  if (k == "rk4_stream_vec") { if (value != 1 && value != 2 && value != 4 && value != 8) return fail(NNHIP_EVALUE, "rk4_stream_vec must be 1, 2, 4 or 8"); g_tune.vec = value; return NNHIP_OK; }
-  if (k == "rk4_stream_mode") { if (value < 0 || value > 3) return fail(NNHIP_EVALUE, "rk4_stream_mode must be 0..3"); g_tune.mode = value; return NNHIP_OK; }
-  if (k == "rk4_stream_blocks_per_cu") { if (value < 1 || value > 64) return fail(NNHIP_EVALUE, "rk4_stream_blocks_per_cu must be 1..64"); g_tune.blocksPerCU = value; return NNHIP_OK; }
+  if (k == "rk4_stream_vec") { if (value != 1 && value != 2 && value != 4 && value != 8) return fail(NNHIP_EVALUE, "rk4_stream_vec must be 1, 2, 4 or 8"); g_tune_vec = value; return NNHIP_OK; }
+  if (k == "rk4_stream_mode") { if (value < 0 || value > 3) return fail(NNHIP_EVALUE, "rk4_stream_mode must be 0..3"); g_tune_mode = value; return NNHIP_OK; }
+  if (k == "rk4_stream_blocks_per_cu") { if (value < 1 || value > 64) return fail(NNHIP_EVALUE, "rk4_stream_blocks_per_cu must be 1..64"); g_tune_blocks_per_cu = value; return NNHIP_OK; }
   return fail(NNHIP_EVALUE, "unknown tuning key %s", key);
 }
 
@@ -731,8 +732,9 @@ int solve_host_range(const nnhip_ode_options* opt, int integrator, int rhs_kind,
   // duration of the call costs more than it gains ("host_register", off).  Hence: automatic = 8 chunks when both buffers are
   // already page-locked (hipHostMalloc / hipHostRegister by the caller), else 1.  A wrapper that allocates a fresh result array
   // per call pays ~8-13 ms of first-touch page faults inside the copy on top of this.
-  int nChunks = g_host_chunks > 0 ? g_host_chunks : 1;
-  if (g_host_chunks == 0 && (nState + nOut) * sizeof(double) >= ((size_t)32 << 20) && is_page_locked(y0) && is_page_locked(y_out)) nChunks = 8;
+  const int hostChunks = g_host_chunks;
+  int nChunks = hostChunks > 0 ? hostChunks : 1;
+  if (hostChunks == 0 && (nState + nOut) * sizeof(double) >= ((size_t)32 << 20) && is_page_locked(y0) && is_page_locked(y_out)) nChunks = 8;
   if ((int64_t)nChunks > N) nChunks = (int)std::max<int64_t>(1, N);
   rc = host_ctx_acquire(device, nChunks * 2, &hc);
   if (rc) { host_ctx_release(hc); return rc; }

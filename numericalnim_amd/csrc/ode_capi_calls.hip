@@ -68,7 +68,7 @@ int nnhip_ode_solve_batch_calls_f64_dev(const nnhip_ode_options* opt, int integr
       void* sortWs = d + colKey + colPerm;
       bool ok = nnhip::span_key_f64(t_end, t_start, opt->tStart, key, N, s) == hipSuccess;
       ok = ok && nnhip::key_range_f64(key, N, sortWs, nullptr, s) == hipSuccess;
-      ok = ok && nnhip::argsort_f64(key, N, perm, sortWs, sortBytes, s, g_sort_min_spread > 0.0 ? g_sort_min_spread : 1e-300) == hipSuccess;
+      ok = ok && nnhip::argsort_f64(key, N, perm, sortWs, sortBytes, s, std::max(g_sort_min_spread.load(), 1e-300)) == hipSuccess;
       if (ok) ps.a.perm = perm;
       rc = launch_solve_range(ps, 0, N, s);
       (void)hipFreeAsync(d, s);
@@ -150,7 +150,7 @@ int nnhip_ode_solve_batch_tspans_f64_dev(const nnhip_ode_options* opt, int integ
     uint32_t* perm = (uint32_t*)(d + colKey);
     void* sortWs = d + colKey + colPerm;
     bool ok = nnhip::key_range_f64(spanKey, N, sortWs, nullptr, s) == hipSuccess;
-    ok = ok && nnhip::argsort_f64(spanKey, N, perm, sortWs, sortBytes, s, g_sort_min_spread > 0.0 ? g_sort_min_spread : 1e-300) == hipSuccess;
+    ok = ok && nnhip::argsort_f64(spanKey, N, perm, sortWs, sortBytes, s, std::max(g_sort_min_spread.load(), 1e-300)) == hipSuccess;
     if (ok) ps.a.perm = perm;
   }
   return done(launch_solve_range(ps, 0, N, s));

@@ -1,6 +1,7 @@
 // ode_capi_internal.hpp — what the translation units of the C ABI share (ode_capi.hip: library, options, dispatch, fused solve;
 // ode_capi_calls.hip: per-IVP calls and the binned solves; ode_capi_stream.hip: the step-streaming entries).  Not part of the product's interface: include/nnhip_ode.h is.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
@@ -33,9 +34,13 @@ struct MethodInfo {
 extern const MethodInfo kMethods[NNHIP_N_INTEGRATORS];
 
 // tuning knobs (nnhip_tune_set; defined and documented in ode_capi.hip)
-extern int g_stream_graph, g_fixed_vec_ipl, g_adv_nt, g_adv_refsal, g_adv_block, g_adv_steps, g_adv_split, g_adv_lean, g_adv_auto_poll;
-extern nnhip::StreamTune g_tune;
-extern bool g_tune_auto;
+// Tuning knobs (nnhip_tune_set) are process-wide and may be set by one host thread while others are inside the library: atomics, each read once per call.
+extern std::atomic<int> g_stream_graph, g_fixed_vec_ipl, g_adv_nt, g_adv_refsal, g_adv_block, g_adv_steps, g_adv_split, g_adv_lean, g_adv_auto_poll;
+extern std::atomic<int> g_tune_vec, g_tune_mode, g_tune_blocks_per_cu;
+extern std::atomic<bool> g_tune_auto;
+// ONE read of a knob whose values below `lowest` mean "automatic"
+inline int knob_or(const std::atomic<int>& k, int lowest, int automatic) { const int v = k.load(std::memory_order_relaxed); return v >= lowest ? v : automatic; }
+inline nnhip::StreamTune tune_snapshot() { nnhip::StreamTune t; t.vec = g_tune_vec; t.mode = g_tune_mode; t.blocksPerCU = g_tune_blocks_per_cu; return t; }
 
 nnhip::StepLaunchFn find_step(int integrator, int rhs_kind, int dim);
 nnhip::StepLaunchFn find_advance(int integrator, int rhs_kind, int dim);
@@ -83,8 +88,8 @@ int prepare_solve(const nnhip_ode_options* opt, int integrator, int rhs_kind, co
                   int64_t* rejected_out, int64_t max_steps, void* ws, int64_t ws_bytes, unsigned long long* agg, int* n_t_out, hipStream_t stream, PreparedSolve& ps);
 int launch_solve_range(const PreparedSolve& ps, int64_t lo, int64_t n, hipStream_t stream);
 // knobs of the binned solves (defined and documented in ode_capi.hip)
-extern int g_sort_copy, g_sort_auto_key, g_calls_bin, g_sort_rebin_steps, g_sort_resume;
-extern double g_sort_min_spread;
+extern std::atomic<int> g_sort_copy, g_sort_auto_key, g_calls_bin, g_sort_rebin_steps, g_sort_resume;
+extern std::atomic<double> g_sort_min_spread;
 // hipGraph caches and polling blocks of the streaming loops (ode_capi_stream.hip), released by nnhip_release() / knob changes
 void release_stream_graphs();
 void release_adv_graphs();

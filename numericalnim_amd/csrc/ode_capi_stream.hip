@@ -23,7 +23,7 @@ using namespace nnhip_capi;
 // Infinity Cache plain accesses with one 16-B load per lane win (6.9 TB/s); beyond it, non-temporal
 // accesses with 4 loads in flight per lane do (6.4 TB/s vs 5.9).
 static nnhip::StreamTune rk4_stream_tune_for(int64_t workingSet) {
-  nnhip::StreamTune tune = g_tune;
+  nnhip::StreamTune tune = tune_snapshot();
   if (g_tune_auto) {
     if (workingSet <= (192LL << 20)) { tune.vec = 1; tune.mode = 0; } else { tune.vec = 4; tune.mode = 1; }
   }
@@ -71,7 +71,7 @@ int nnhip_ode_step_batch_f64_dev(const nnhip_ode_options* opt, int integrator, i
       va.t = t_uniform; va.dt = dt_uniform; va.P = P;
       // arrays beyond the Infinity Cache: non-temporal hint (knob "adv_nontemporal"; 5.06 -> see profiles/r02_bench_extra.json)
       const int64_t bytes = (int64_t)sizeof(double) * N * ((y_in == y_out ? 1 : 2) * dim + (fsal_out ? dim : 0) + (t_dev ? 1 : 0) + (dt_dev ? 1 : 0));
-      const int ntv = g_adv_nt >= 0 ? g_adv_nt : (bytes > (192LL << 20) ? 1 : 0);
+      const int ntv = knob_or(g_adv_nt, 0, (bytes > (192LL << 20) ? 1 : 0));
       HIP_TRY(vf(va, negate_time, ntv, (hipStream_t)stream));
       return NNHIP_OK;
     }
@@ -90,7 +90,7 @@ int nnhip_ode_step_batch_f64_dev(const nnhip_ode_options* opt, int integrator, i
   a.y_in = y_in; a.fsal_in = fsal_in; a.y_out = y_out; a.fsal_out = fsal_out; a.dt_used = dt_used; a.error = error;
   a.ctl = ctl_of(opt); a.P = P;
   // state beyond the Infinity Cache: non-temporal hint (adaptive thread-per-IVP kernels; knob "adv_nontemporal")
-  a.nontemporal = g_adv_nt >= 0 ? g_adv_nt : ((dim <= 4 && (int64_t)sizeof(double) * (4 * dim + 5) * N > (192LL << 20)) ? 1 : 0);
+  a.nontemporal = knob_or(g_adv_nt, 0, ((dim <= 4 && (int64_t)sizeof(double) * (4 * dim + 5) * N > (192LL << 20)) ? 1 : 0));
   if (user) {
     if (nnhip::rtc_launch_step(rhs_kind, integrator, a, negate_time, (hipStream_t)stream) != hipSuccess)
       return fail(NNHIP_EHIP, "user RHS launch failed: %s", nnhip::rtc_last_error());
@@ -542,7 +542,7 @@ int adv_issue_group(nnhip::StepLaunchFn fn, int userKind, int integrator, const 
       nnhip::StepArgs a = split > 1 ? adv_range(full, lo, hi - lo) : full;
       a.active = k == checkEvery - 1 ? active : nullptr;
       hipStream_t st = r == 0 ? s : p.side[r - 1];
-      if (fn) HIP_TRY(fn(a, g_adv_block ? g_adv_block : 64, st));  // one-wave workgroups retire and refill sooner: 1e7 Lorenz IVPs 208 -> 203 us, 1e6 24.0 -> 23.0 us (mb_adv c3a)
+      if (fn) HIP_TRY(fn(a, knob_or(g_adv_block, 1, 64), st));  // one-wave workgroups retire and refill sooner: 1e7 Lorenz IVPs 208 -> 203 us, 1e6 24.0 -> 23.0 us (mb_adv c3a)
       else if (nnhip::rtc_launch_advance(userKind, integrator, a, st) != hipSuccess) return fail(NNHIP_EHIP, "user RHS launch failed: %s", nnhip::rtc_last_error());
     }
   }
@@ -620,7 +620,7 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
   double* fsal = tArr + 2 * N;
   // DOPRI54 / Tsit54: FSAL re-evaluated by each launch instead of carried through HBM (knob "adv_recompute_fsal"; see adv_fsal_in_hbm in ode_kernels.hpp)
   const bool fsalRecomputable = integrator == NNHIP_DOPRI54 || integrator == NNHIP_TSIT54;
-  const int recomputeFsal = !fsalRecomputable ? 0 : (g_adv_refsal >= 0 ? g_adv_refsal : (nnhip::rtc_has_aux(rhs_kind) ? 0 : 1));
+  const int recomputeFsal = !fsalRecomputable ? 0 : knob_or(g_adv_refsal, 0, nnhip::rtc_has_aux(rhs_kind) ? 0 : 1);
   const bool fsalInHbm = !(recomputeFsal || integrator == NNHIP_BS32 || integrator == NNHIP_RK21);  // BS32 / RK21 never read the slot
   // FSAL = f(t0, y) (:506); t = t0; dt = sqrt(dtMax*dtMin) (:491-493)
   if (nnhip::rtc_has_aux(rhs_kind)) {  // lastIter.dy = f(t0, y, ctx) (:498): the first of the reference's two evaluations at t0, observable through aux
@@ -647,7 +647,7 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
   a.recomputeFsal = recomputeFsal;
   a.noLean = g_adv_lean ? 0 : 1;
   // thread-per-IVP kernels (the lanes-per-system ones are not memory-bound enough to gain: measured -3 %); the state of one launch = y, (t, dt) and FSAL if carried
-  a.nontemporal = g_adv_nt >= 0 ? g_adv_nt : ((dim <= 4 && (int64_t)sizeof(double) * ((fsalInHbm ? 2 : 1) * dim + 2) * N > (192LL << 20)) ? 1 : 0);
+  a.nontemporal = knob_or(g_adv_nt, 0, ((dim <= 4 && (int64_t)sizeof(double) * ((fsalInHbm ? 2 : 1) * dim + 2) * N > (192LL << 20)) ? 1 : 0));
   const bool autoPoll = check_every <= 0 && g_adv_auto_poll;  // the polling schedule is the library's (below, knob "adv_auto_poll"); a caller's check_every is taken as given
   if (check_every <= 0) check_every = 8;
   rc = adv_poll_reserve();
@@ -780,12 +780,12 @@ int nnhip_ode_adaptive_stream_dense_f64_dev(const nnhip_ode_options* opt, int in
   a.denseIdx_io = denseIdx; a.emitAfter = 1;
   {
     const bool fsalRecomputable = integrator == NNHIP_DOPRI54 || integrator == NNHIP_TSIT54;
-    a.recomputeFsal = !fsalRecomputable ? 0 : (g_adv_refsal >= 0 ? g_adv_refsal : (nnhip::rtc_has_aux(rhs_kind) ? 0 : 1));
+    a.recomputeFsal = !fsalRecomputable ? 0 : knob_or(g_adv_refsal, 0, nnhip::rtc_has_aux(rhs_kind) ? 0 : 1);
   }
   const bool fsalInHbm = !(a.recomputeFsal || integrator == NNHIP_RK21);
   a.rows = y_out; a.rowStride = nState;
   // state of one launch beyond the Infinity Cache: non-temporal instantiation (thread-per-IVP kernels; knob "adv_nontemporal")
-  a.nontemporal = g_adv_nt >= 0 ? g_adv_nt : ((dim <= 4 && (int64_t)sizeof(double) * ((fsalInHbm ? 2 : 1) * dim + 2) * N > (192LL << 20)) ? 1 : 0);
+  a.nontemporal = knob_or(g_adv_nt, 0, ((dim <= 4 && (int64_t)sizeof(double) * ((fsalInHbm ? 2 : 1) * dim + 2) * N > (192LL << 20)) ? 1 : 0));
   const bool autoPoll = check_every <= 0 && g_adv_auto_poll;  // the library's own polling schedule (adv_poll_schedule.hpp, knob "adv_auto_poll"), per direction
   if (check_every <= 0) check_every = 8;
   const double dtInit = std::sqrt(opt->dtMax * opt->dtMin);  // :491-493

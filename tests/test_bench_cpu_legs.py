@@ -44,3 +44,43 @@ def test_adaptive_legs(oracle):
         r = b.cpu_baseline_adaptive(O, name, yh, layout, integ, d, gpu, n1, 8)
         assert r["max_abs_dev_gpu_vs_cpu"] == 0.0 and r["value"] > 0 and r["unit"] == "IVPs/s" and r["cores"] == 1
         assert r["all_cores"]["cores"] == 8 and "first 64 IVPs" in r["all_cores"]["sample"] and r["accepted_steps_per_s"] > 100 * r["value"] * 0.99
+
+
+def test_opt_in_child_never_costs_the_parent_its_line(monkeypatch):
+    """bench.py runs the settings without a hardware record in a child process: whatever happens to the child — a crash (device fault -> abort), a hang (timeout), garbage
+    on stdout — the parent gets an `informational_errors` entry under the `streamed_opt_in:` prefix the contract test tolerates, and carries on."""
+    import json
+    import subprocess
+    b = _bench()
+
+    class R:
+        def __init__(self, rc, out, err=""):
+            self.returncode, self.stdout, self.stderr = rc, out, err
+
+    calls = []
+
+    def fake_run(outcome):
+        def run(cmd, **kw):
+            calls.append((cmd, kw))
+            if isinstance(outcome, Exception):
+                raise outcome
+            return outcome
+        return run
+
+    # a device fault aborts the child: no JSON, rc -6
+    monkeypatch.setattr(subprocess, "run", fake_run(R(-6, "amdgpu banner\n", "Memory access fault by GPU node-1")))
+    res, err = b.streamed_opt_in_parent(1000, 5)
+    assert res == {} and list(err) == ["streamed_opt_in:child"] and "rc -6" in err["streamed_opt_in:child"] and "Memory access fault" in err["streamed_opt_in:child"]
+    cmd, kw = calls[-1]
+    assert cmd[1].endswith("bench.py") and cmd[2:] == ["--child-leg", "streamed_opt_in", "--adaptive-n", "1000"] and kw["timeout"] == 5
+    assert not {"RANK", "LOCAL_RANK", "WORLD_SIZE"} & set(kw["env"])
+    # a hang: subprocess.run kills the child and raises
+    monkeypatch.setattr(subprocess, "run", fake_run(subprocess.TimeoutExpired("bench.py", 5)))
+    res, err = b.streamed_opt_in_parent(1000, 5)
+    assert res == {} and "TimeoutExpired" in err["streamed_opt_in:child"]
+    # the child's own per-setting errors travel with its results
+    payload = {"streamed_opt_in": {"C3_dopri54_lorenz_1e6": {"lean": {"streamed_launches": 104}}, "C4_tsit54_ring16_1e6": {}},
+               "errors": {"streamed_opt_in:C4_tsit54_ring16_1e6:lean": "RuntimeError('x')"}}
+    monkeypatch.setattr(subprocess, "run", fake_run(R(0, "banner\n" + json.dumps(payload) + "\n")))
+    res, err = b.streamed_opt_in_parent(1000, 5)
+    assert res == payload["streamed_opt_in"] and err == payload["errors"] and all(k.startswith("streamed_opt_in:") for k in err)

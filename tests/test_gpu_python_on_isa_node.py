@@ -62,13 +62,17 @@ def test_bench_line_on_the_isa_node(node_env):
 @pytest.mark.skipif(not os.environ.get("NNHIP_ISA_NODE_FULL"), reason="~7 min: every informational leg of bench.py at 192 IVPs / systems (NNHIP_ISA_NODE_FULL=1)")
 def test_every_leg_of_bench_on_the_isa_node(node_env):
     r = subprocess.run([sys.executable, "bench.py", "--n-ivp", "4096", "--rk4-steps", "8", "--steps", "2", "--warmup", "1", "--adaptive-n", "192", "--beyond-cache-n", "8192",
-                        "--cpu-sample", "1000", "--cpu-ivps-per-thread", "100", "--cpu-adaptive-sample", "64"], cwd=ROOT, env=node_env, capture_output=True, text=True, timeout=3000)
+                        "--cpu-sample", "1000", "--cpu-ivps-per-thread", "100", "--cpu-adaptive-sample", "64"], cwd=ROOT, env=dict(node_env, NNHIP_BENCH_CHILD_TIMEOUT="2400"),
+                       capture_output=True, text=True, timeout=3000)
     assert r.returncode == 0, (r.stdout[-800:], r.stderr[-2500:])
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert "informational_errors" not in d, d["informational_errors"]
     for name in ("C3_dopri54_lorenz_1e6", "C4_tsit54_ring16_1e6"):
         c = d["adaptive_configs"][name]
         assert c["streamed_bitwise_equal_to_fused"] and c["loop_iterations"] <= c["streamed_launches"] <= c["loop_iterations"] + 16 and c["cpu_baseline"]["max_abs_dev_gpu_vs_cpu"] == 0.0
+        # the opt-in settings come back from bench.py's child process (bench.streamed_opt_in_parent)
+        assert set(c["streamed_opt_in"]) == {"lean", "lean_auto_poll", "lean_auto_poll_fp_contract"} and all(o["within_north_star_tolerance"] for o in c["streamed_opt_in"].values())
+        assert c["streamed_opt_in"]["lean"]["bitwise_equal_to_fused"] and c["streamed_opt_in"]["lean_auto_poll"]["bitwise_equal_to_fused"]
     assert all(v["within_tolerance"] for v in d["fused_solve_fp_contract"].values())
     assert d["heterogeneous_batches"]["sweep_bitwise_equal"] and d["heterogeneous_batches"]["calls_bitwise_equal"]
 
