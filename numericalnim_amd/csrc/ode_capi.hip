@@ -687,6 +687,7 @@ int solve_host_range(const nnhip_ode_options* opt, int integrator, int rhs_kind,
   if (N < 0 || NFull < N || lo0 < 0 || lo0 + N > NFull || dim < 1 || n_t < 0) return fail(NNHIP_EVALUE, "bad sizes");
   if (n_per_ivp < 0 || n_per_ivp > nnhip::kMaxParams || (n_per_ivp > 0 && !per_ivp_params && N > 0)) return fail(NNHIP_EVALUE, "bad per-IVP parameter table");
   if (!opt || (n_t > 0 && !tspan)) return fail(NNHIP_EVALUE, "options / tspan is NULL");
+  if (N > 0 && (!y0 || (n_t > 0 && !y_out))) return fail(NNHIP_EVALUE, "y0 / y_out is NULL");
   for (int j = 0; j < n_t; ++j) if (!std::isfinite(tspan[j])) return fail(NNHIP_EVALUE, "tspan[%d] is not finite", j);
   if (!std::isfinite(opt->tStart)) return fail(NNHIP_EVALUE, "options.tStart is not finite");
   int ndev = nnhip_device_count();

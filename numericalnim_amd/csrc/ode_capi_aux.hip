@@ -372,7 +372,10 @@ int nnhip_ode_tableau_f64(int integrator, int device, double* out, int cap) {
 int nnhip_ode_rhs_batch_f64_dev(int rhs_kind, const double* rhs_params, int n_params, int64_t N, int dim, int layout, double t,
                                 const double* y, double* dy, void* stream) {
   if (N < 0 || dim < 1 || n_params < 0 || n_params > nnhip::kMaxParams) return nnhip::fail_msg(NNHIP_EVALUE, "rhs_batch: bad N / dim / n_params");
+  if (n_params > 0 && !rhs_params) return nnhip::fail_msg(NNHIP_EVALUE, "rhs_batch: rhs_params is NULL");
+  if (layout != NNHIP_LAYOUT_SOA && layout != NNHIP_LAYOUT_AOS) return nnhip::fail_msg(NNHIP_EVALUE, "rhs_batch: layout must be NNHIP_LAYOUT_SOA or NNHIP_LAYOUT_AOS");
   if (N == 0) return NNHIP_OK;
+  if (!y || !dy) return nnhip::fail_msg(NNHIP_EVALUE, "rhs_batch: y / dy is NULL");
   nnhip::Params P;
   for (int k = 0; k < nnhip::kMaxParams; ++k) P.p[k] = k < n_params ? rhs_params[k] : 0.0;
   if (nnhip::rtc_ctx_fill(rhs_kind, N, P, nullptr) < 0) return nnhip::fail_msg(NNHIP_EVALUE, "rhs_batch: rhs_kind %d: %s", rhs_kind, nnhip::rtc_last_error());

@@ -92,7 +92,7 @@ int nnhip_ode_solve_batch_tend_f64_dev(const nnhip_ode_options* opt, int integra
 // duplicates, tStart_i inside or not (ode.nim:589-591, 476-487, 609).  A device pre-pass sorts and splits every row
 // (nnhip::prepare_tspans); the fused kernels then read their own requested times.  Workspace: the prepared rows + the counts.
 int64_t nnhip_ode_solve_tspans_workspace_bytes(int64_t N, int n_t) {
-  if (N < 0 || n_t < 0) return 0;
+  if (!batch_size_sane(N, (int64_t)n_t + 2)) return 0;
   return (((int64_t)N * n_t * 8 + 255) & ~(int64_t)255) + (((int64_t)N * 3 * 4 + 255) & ~(int64_t)255) + 256;
 }
 
@@ -160,7 +160,7 @@ int nnhip_ode_solve_batch_tspans_f64_dev(const nnhip_ode_options* opt, int integ
 // Workspace of nnhip_ode_solve_batch_sorted_f64_dev: requested times + order of integration (4N) + probe progress / key (8N)
 // + the device sort's scratch.
 int64_t nnhip_ode_solve_sorted_workspace_bytes(int64_t N, int n_t) {
-  if (N < 0) return 0;
+  if (!batch_size_sane(N, 8)) return 0;
   // [requested times / schedule][perm: 4N][key: 8N][resume state t, dt, tEnd: 3 x 8N][argsort workspace]
   return ((nnhip_ode_solve_workspace_bytes(n_t) + 255) & ~(int64_t)255) + (((int64_t)N * 4 + 255) & ~(int64_t)255) + 4 * (((int64_t)N * 8 + 255) & ~(int64_t)255) +
          nnhip::argsort_workspace_bytes(N) + 256;
@@ -200,14 +200,16 @@ int nnhip_ode_solve_batch_sorted_f64_dev(const nnhip_ode_options* opt, int integ
   hipStream_t s = (hipStream_t)stream;
   char* base = (char*)ws;
   const int64_t wsTimes = (nnhip_ode_solve_workspace_bytes(n_t) + 255) & ~(int64_t)255;
-  uint32_t* perm = (uint32_t*)(base + wsTimes);
+  auto at = [base](int64_t off) -> char* { return base ? base + off : nullptr; };  // (N == 0 comes without a workspace: nothing below is touched then)
+  uint32_t* perm = (uint32_t*)at(wsTimes);
   const int64_t colBytes = ((int64_t)N * 8 + 255) & ~(int64_t)255;
-  double* key = (double*)(base + wsTimes + (((int64_t)N * 4 + 255) & ~(int64_t)255));
-  double* resT = (double*)((char*)key + colBytes);    // resume state of the automatic mode: t, dt where the probe stopped, and tEnd as a column
-  double* resDt = (double*)((char*)resT + colBytes);
-  double* resEnd = (double*)((char*)resDt + colBytes);
-  void* sortWs = (char*)resEnd + colBytes;
-  const int64_t sortWsBytes = ws_bytes - (int64_t)((char*)sortWs - base);
+  const int64_t keyOff = wsTimes + (((int64_t)N * 4 + 255) & ~(int64_t)255);
+  double* key = (double*)at(keyOff);
+  double* resT = (double*)at(keyOff + colBytes);    // resume state of the automatic mode: t, dt where the probe stopped, and tEnd as a column
+  double* resDt = (double*)at(keyOff + 2 * colBytes);
+  double* resEnd = (double*)at(keyOff + 3 * colBytes);
+  void* sortWs = at(keyOff + 4 * colBytes);
+  const int64_t sortWsBytes = ws_bytes - (keyOff + 4 * colBytes);
   const bool adaptive = kMethods[integrator].adaptive != 0;
   PreparedSolve ps;
   bool sorted = adaptive && N > 1;  // integrate in the order of `perm`
@@ -349,6 +351,8 @@ int nnhip_ode_solve_batch_sorted_f64(const nnhip_ode_options* opt, int integrato
                                      const double* tspan, int n_t, double* t_out, double* y_out, int32_t* ny_out, int64_t* steps_out,
                                      int64_t* rejected_out, int64_t max_steps, const double* sort_key, int probe_steps, int device) {
   if (N < 0 || dim < 1 || n_t < 0) return fail(NNHIP_EVALUE, "bad sizes");
+  if (N >= ((int64_t)1 << 31) || !batch_size_sane(N, (int64_t)dim * ((int64_t)n_t + 1) + (n_per_ivp > 0 ? n_per_ivp : 0))) return fail(NNHIP_EVALUE, "N must be in [0, 2^31) and the batch addressable");
+  if (N > 0 && (!y0 || (n_t > 0 && !y_out))) return fail(NNHIP_EVALUE, "y0 / y_out is NULL");  // before anything is allocated for them
   int ndev = nnhip_device_count();
   if (ndev < 0) return ndev;
   if (ndev == 0) return fail(NNHIP_EHIP, "no HIP device available (this library has no CPU fallback)");

@@ -38,6 +38,9 @@ extern const MethodInfo kMethods[NNHIP_N_INTEGRATORS];
 extern std::atomic<int> g_stream_graph, g_fixed_vec_ipl, g_adv_nt, g_adv_refsal, g_adv_block, g_adv_steps, g_adv_split, g_adv_lean, g_adv_auto_poll;
 extern std::atomic<int> g_tune_vec, g_tune_mode, g_tune_blocks_per_cu;
 extern std::atomic<bool> g_tune_auto;
+// Workspace-size queries: N IVPs x `per` doubles each beyond 2^44 doubles (128 TiB) is no batch — the size functions answer 0 ("invalid", as for N < 0) instead of
+// overflowing their arithmetic; the compute entries then refuse the call (workspace missing / too small).
+inline bool batch_size_sane(int64_t N, int64_t per) { return N >= 0 && per >= 0 && (per == 0 || N <= ((int64_t)1 << 44) / per); }
 // ONE read of a knob whose values below `lowest` mean "automatic"
 inline int knob_or(const std::atomic<int>& k, int lowest, int automatic) { const int v = k.load(std::memory_order_relaxed); return v >= lowest ? v : automatic; }
 inline nnhip::StreamTune tune_snapshot() { nnhip::StreamTune t; t.vec = g_tune_vec; t.mode = g_tune_mode; t.blocksPerCU = g_tune_blocks_per_cu; return t; }

@@ -163,9 +163,14 @@ struct HostStage {
   }
 };
 
+// N items x `per` doubles each beyond 2^44 doubles is no batch: refused before the byte counts below can overflow
+inline bool sizes_addressable(int64_t N, int64_t per) { return N >= 0 && per >= 0 && (per == 0 || N <= ((int64_t)1 << 44) / per); }
+
 int cumquad_fn_host(int rule, int rhs_kind, const double* rhs_params, int n_params, const double* per_item_params, int n_per_item, int64_t N, int dim,
                     int layout, const double* X, int n_x, double dx, double* out, int* n_rows_out, int device) {
   if (N < 0 || dim < 1 || n_x < 1 || n_per_item < 0) return nnhip::fail_msg(NNHIP_EVALUE, "bad sizes");
+  if (!sizes_addressable(N, (int64_t)dim * n_x + n_per_item)) return nnhip::fail_msg(NNHIP_EVALUE, "N x dim x n_x is beyond any device");
+  if (!X || (N > 0 && n_per_item > 0 && !per_item_params) || (n_params > 0 && !rhs_params)) return nnhip::fail_msg(NNHIP_EVALUE, "X / per_item_params / rhs_params is NULL");  // before anything is allocated
   HostStage st;
   int rc = st.begin(device);
   if (rc) return rc;
@@ -196,7 +201,8 @@ int nnhip_cumsimpson_fn_batch_f64(int rhs_kind, const double* rhs_params, int n_
 }
 
 int nnhip_cumtrapz_batch_f64(const double* X, int n, const double* Y, int64_t M, double* out, int device) {
-  if (n < 1 || M < 0) return nnhip::fail_msg(NNHIP_EVALUE, "bad sizes");
+  if (n < 1 || M < 0 || !sizes_addressable(M, n)) return nnhip::fail_msg(NNHIP_EVALUE, "bad sizes");
+  if (!X || (M > 0 && (!Y || !out))) return nnhip::fail_msg(NNHIP_EVALUE, "cumtrapz: X / Y / out is NULL");  // before anything is allocated for them
   HostStage st;
   int rc = st.begin(device);
   if (rc) return rc;
@@ -209,7 +215,8 @@ int nnhip_cumtrapz_batch_f64(const double* X, int n, const double* Y, int64_t M,
 }
 
 int nnhip_cumsimpson_batch_f64(const double* X, int n, const double* Y, int64_t M, double* out, int device) {
-  if (n < 1 || M < 0) return nnhip::fail_msg(NNHIP_EVALUE, "bad sizes");
+  if (n < 1 || M < 0 || !sizes_addressable(M, n)) return nnhip::fail_msg(NNHIP_EVALUE, "bad sizes");
+  if (!X || (M > 0 && (!Y || !out))) return nnhip::fail_msg(NNHIP_EVALUE, "cumsimpson: X / Y / out is NULL");  // before anything is allocated for them
   HostStage st;
   int rc = st.begin(device);
   if (rc) return rc;
@@ -223,7 +230,8 @@ int nnhip_cumsimpson_batch_f64(const double* X, int n, const double* Y, int64_t 
 
 int nnhip_hermite_spline_eval_batch_f64(const double* X, int n_knots, const double* Y, const double* dY, int64_t M, const double* xq, int n_q,
                                         int deriv, int extrap, double extrap_value, double* out, int device) {
-  if (n_knots < 2 || M < 0 || n_q < 0) return nnhip::fail_msg(NNHIP_EVALUE, "bad sizes");
+  if (n_knots < 2 || M < 0 || n_q < 0 || !sizes_addressable(M, (int64_t)n_knots + n_q)) return nnhip::fail_msg(NNHIP_EVALUE, "bad sizes");
+  if (!X || (n_q > 0 && !xq) || (M > 0 && (!Y || (n_q > 0 && !out)))) return nnhip::fail_msg(NNHIP_EVALUE, "hermite spline eval: X / xq / Y / out is NULL");  // before anything is allocated for them
   HostStage st;
   int rc = st.begin(device);
   if (rc) return rc;

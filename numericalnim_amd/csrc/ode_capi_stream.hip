@@ -269,7 +269,7 @@ int nnhip_ode_fixed_stream_f64_dev(const nnhip_ode_options* opt, int integrator,
 // f(t, y) and one Hermite kernel per requested time.  The two state buffers of the ping-pong ARE (lastIter.y, y).  Bitwise equal
 // to the fused solve, rows, NaN fill and the reference's dropped-rows quirk included (they are uniform over the batch here).
 int64_t nnhip_ode_fixed_stream_dense_workspace_bytes(int64_t N, int dim) {
-  if (N < 0 || dim < 1) return 0;
+  if (dim < 1 || !batch_size_sane(N, 4 * (int64_t)dim)) return 0;
   return 4 * N * dim * (int64_t)sizeof(double);  // ping, pong, f(lastT, lastY), f(t, y)
 }
 
@@ -424,7 +424,7 @@ int nnhip_ode_fixed_stream_dense_f64_dev(const nnhip_ode_options* opt, int integ
 }
 
 int64_t nnhip_ode_adaptive_stream_workspace_bytes(int64_t N, int dim) {
-  if (N < 0 || dim < 1) return 0;
+  if (dim < 1 || !batch_size_sane(N, (int64_t)dim + 4)) return 0;
   return (int64_t)sizeof(double) * (N * dim /*FSAL*/ + 3 * N /*(t, dt) + one spare column*/) + (int64_t)sizeof(unsigned int) * nnhip::kAggSlots;
 }
 
@@ -713,7 +713,7 @@ int nnhip_ode_adaptive_stream_f64_dev(const nnhip_ode_options* opt, int integrat
 
 // ---- ODESolver through the IntegratorProc seam, adaptive methods, WITH dense output --------------------------------------------
 int64_t nnhip_ode_adaptive_stream_dense_workspace_bytes(int64_t N, int dim, int n_t) {
-  if (N < 0 || dim < 1) return 0;
+  if (dim < 1 || !batch_size_sane(N, 2 * (int64_t)dim + 4)) return 0;
   const int64_t nt = n_t < 0 ? 0 : n_t;
   // y, FSAL [dim*N]; (t, dt) [N][2]; denseIndex [N] and the forward direction's row count [N] (int32); requested times (lastIter = (t, y, dy)
   // lives in the kernel's registers)

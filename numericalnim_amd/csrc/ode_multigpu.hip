@@ -65,7 +65,12 @@ extern "C" const char* nnhip_multigpu_last_error(void) { return g_mg_err; }
 // is the stream on device r whose prior work produced shard[r]; the collective is enqueued on it.
 extern "C" int nnhip_allgather_states_f64_dev(int n_gpus, const double* const* shard, const int64_t* counts, int dim, int layout,
                                               double* const* full, void* const* streams) {
-  if (n_gpus < 1 || !shard || !counts || !full || dim < 1 || (layout != NNHIP_LAYOUT_SOA && layout != NNHIP_LAYOUT_AOS)) return NNHIP_EVALUE;
+  if (n_gpus < 1 || !shard || !counts || !full || dim < 1 || (layout != NNHIP_LAYOUT_SOA && layout != NNHIP_LAYOUT_AOS)) {
+    snprintf(g_mg_err, sizeof(g_mg_err), "allgather_states: need n_gpus >= 1, dim >= 1, a layout of NNHIP_LAYOUT_SOA / _AOS and non-NULL shard / counts / full");
+    return NNHIP_EVALUE;
+  }
+  for (int r = 0; r < n_gpus; ++r)
+    if (counts[r] < 0 || !full[r] || (counts[r] > 0 && !shard[r])) { snprintf(g_mg_err, sizeof(g_mg_err), "allgather_states: counts[%d] < 0, or shard[%d] / full[%d] is NULL", r, r, r); return NNHIP_EVALUE; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < n_gpus) { snprintf(g_mg_err, sizeof(g_mg_err), "need %d HIP devices, have %d", n_gpus, ndev); return NNHIP_EHIP; }
   std::lock_guard<std::mutex> lk(g_mu);
@@ -82,7 +87,7 @@ extern "C" int nnhip_allgather_states_f64_dev(int n_gpus, const double* const* s
   int64_t N = 0;
   bool equal = true;
   std::vector<int64_t> lo((size_t)n_gpus);
-  for (int r = 0; r < n_gpus; ++r) { if (counts[r] < 0) return NNHIP_EVALUE; lo[r] = N; N += counts[r]; equal = equal && counts[r] == counts[0]; }
+  for (int r = 0; r < n_gpus; ++r) { lo[r] = N; N += counts[r]; equal = equal && counts[r] == counts[0]; }
   int prev = 0;
   (void)hipGetDevice(&prev);
   // AoS: every shard is one contiguous block of the full tensor -> one all-gather (equal shards) or one broadcast per

@@ -26,7 +26,7 @@ $CL -O1 -g -std=c++17 $FS -shared-libsan -D__HIP_PLATFORM_AMD__ -I /opt/rocm/inc
 run() {  # tag, devices, command...
   local tag=$1 dev=$2; shift 2
   NNHIP_LIB="$OUT/libnnhip_ode.so" LD_PRELOAD="$RT/$RTL $OUT/libfakehip.so" FAKE_HIP_LIB="$OUT/libfakehip.so" FAKE_HIP_DEVICES=$dev LD_LIBRARY_PATH="$OUT:$RT" \
-    ASAN_OPTIONS="detect_leaks=0 halt_on_error=0 exitcode=0" UBSAN_OPTIONS="print_stacktrace=1" TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 history_size=4 exitcode=0 second_deadlock_stack=1" timeout 1800 "$@" > "$OUT/$tag.out" 2> "$OUT/$tag.err"
+    ASAN_OPTIONS="detect_leaks=0 halt_on_error=0 exitcode=0 allocator_may_return_null=1" UBSAN_OPTIONS="print_stacktrace=1" TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 history_size=4 exitcode=0 second_deadlock_stack=1" timeout 1800 "$@" > "$OUT/$tag.out" 2> "$OUT/$tag.err"
   echo "$tag: rc=$? last line: $(tail -1 "$OUT/$tag.out" | cut -c1-80) | sanitizer ($SAN) reports: $(grep -c "$PAT" "$OUT/$tag.err")"
   grep SUMMARY "$OUT/$tag.err" | sort | uniq -c | sort -rn | head -12
 }
@@ -38,3 +38,17 @@ STRESS_KNOBS="stream_graph=0" run stress_eager 1 python tests/fake_hip_thread_st
 STRESS_KNOBS="stream_graph=1" run stress_graph 1 python tests/fake_hip_thread_stress.py
 STRESS_KNOBS="stream_graph=1" STRESS_TOGGLE_KNOBS=1 run stress_graph_knobs_toggled 1 python tests/fake_hip_thread_stress.py
 STRESS_KNOBS="stream_graph=0,adv_lean=1,adv_auto_poll=1,fp_contract=1" run stress_opt_in 1 python tests/fake_hip_thread_stress.py
+if [ "$SAN" != thread ]; then
+  # the boundary's error behaviour: every entry of include/nnhip_ode.h with hostile arguments (tests/fake_hip_abi_arg_fuzz.py), one process per entry
+  mkdir -p "$OUT/fuzz"; bad=0
+  for n in $(python -c "from numericalnim_amd import _lib; print(' '.join(_lib.SIGNATURES))"); do
+    NNHIP_LIB="$OUT/libnnhip_ode.so" LD_PRELOAD="$RT/$RTL $OUT/libfakehip.so" FAKE_HIP_LIB="$OUT/libfakehip.so" FAKE_HIP_DEVICES=2 LD_LIBRARY_PATH="$OUT:$RT" \
+      ASAN_OPTIONS="detect_leaks=0 exitcode=77 allocator_may_return_null=1" UBSAN_OPTIONS="print_stacktrace=1" timeout 120 python tests/fake_hip_abi_arg_fuzz.py $n ${FUZZ_TRIALS:-200} > "$OUT/fuzz/$n.out" 2> "$OUT/fuzz/$n.err"
+    rc=$?
+    if [ $rc -ne 0 ] || ! grep -q "^DONE" "$OUT/fuzz/$n.out"; then
+      bad=$((bad + 1)); echo "arg fuzz $n: rc=$rc last call: $(grep -v '^DONE' "$OUT/fuzz/$n.out" | tail -1 | cut -c1-260)"
+      grep -m3 "ERROR: AddressSanitizer\|runtime error\|SUMMARY\|fake_hip\|AssertionError" "$OUT/fuzz/$n.err" | cut -c1-240
+    fi
+  done
+  echo "arg fuzz: $(ls "$OUT/fuzz"/*.out | wc -l) entries x ${FUZZ_TRIALS:-200} hostile calls, $bad entries with a finding"
+fi

@@ -307,3 +307,41 @@ def test_tuning_blocks_nest_and_restore_what_was_set_before():
     assert ode._KNOB_STATE == ode._KNOB_DEFAULTS
     with pytest.raises(ValueError):
         nn.tuning(no_such_knob=1)
+
+
+def test_hostile_arguments_get_an_error_code_before_anything_is_touched(nn):
+    """Findings of the argument fuzz under AddressSanitizer (scripts/tsan_host_audit.sh SAN=address, tests/fake_hip_abi_arg_fuzz.py): a NULL where data is
+    needed, or sizes no device could hold, are refused with NNHIP_EVALUE and a message BEFORE a byte is allocated, copied or dereferenced — these return
+    without a HIP call, so they are checkable here."""
+    _lib = nn._lib
+    L = _lib.lib()
+    ev = _lib.NNHIP_EVALUE
+    dp = C.POINTER(C.c_double)
+    opt = nn.newODEoptions()
+    ts = np.array([0.0, 1.0])
+    one = np.ones(8)
+    p = lambda a: a.ctypes.data_as(dp)  # noqa: E731
+    # the right-hand side alone: rhs_params NULL with n_params > 0 was dereferenced; y / dy NULL went to the launch; the layout was not checked
+    assert L.nnhip_ode_rhs_batch_f64_dev(nn.Rhs.LORENZ, None, 3, 4, 3, 0, 0.0, C.c_void_p(16), C.c_void_p(16), None) == ev and b"rhs_params" in L.nnhip_last_error()
+    assert L.nnhip_ode_rhs_batch_f64_dev(nn.Rhs.NEG_Y, None, 0, 4, 1, 0, 0.0, None, C.c_void_p(16), None) == ev
+    assert L.nnhip_ode_rhs_batch_f64_dev(nn.Rhs.NEG_Y, None, 0, 4, 1, 7, 0.0, C.c_void_p(16), C.c_void_p(16), None) == ev and b"layout" in L.nnhip_last_error()
+    # host solves: y0 / y_out NULL with N > 0 (the copies would have started from address 0)
+    assert L.nnhip_ode_solve_batch_f64(C.byref(opt), 0, nn.Rhs.NEG_Y, None, 0, None, 4, 1, 0, p(ts), 2, p(one), one.ctypes.data, None, None, None, 0, None, 0) == ev
+    assert b"y0" in L.nnhip_last_error()
+    assert L.nnhip_ode_solve_batch_f64(C.byref(opt), 0, nn.Rhs.NEG_Y, None, 0, one.ctypes.data, 4, 1, 0, p(ts), 2, p(one), None, None, None, None, 0, None, 0) == ev
+    assert L.nnhip_ode_solve_batch_sorted_f64(C.byref(opt), 1, nn.Rhs.LORENZ, None, 0, None, 0, None, 1 << 40, 2 ** 31 - 1, 0, p(ts), 2, p(one), None, None, None, None, 0,
+                                              None, 8, 0) == ev
+    assert L.nnhip_ode_solve_batch_sorted_f64(C.byref(opt), 1, nn.Rhs.LORENZ, None, 0, None, 0, None, 5, 3, 0, p(ts), 2, p(one), one.ctypes.data, None, None, None, 0,
+                                              None, 8, 0) == ev
+    # the discrete consumers' host forms: X / Y / out NULL used to be noticed after 2 x n x M x 8 bytes had been allocated on the device
+    assert L.nnhip_cumtrapz_batch_f64(None, 2 ** 31 - 1, None, 1, None, 0) == ev and L.nnhip_cumsimpson_batch_f64(p(one), 8, None, 5, p(one), 0) == ev
+    assert L.nnhip_hermite_spline_eval_batch_f64(p(one), 8, None, None, 3, p(one), 2, 0, 0, 0.0, p(one), 0) == ev
+    rows = C.c_int(-1)
+    assert L.nnhip_cumtrapz_fn_batch_f64(nn.Rhs.AFFINE_T, None, 2, None, 0, 4, 1, 0, p(one), 3, 0.01, p(one), C.byref(rows), 0) == ev
+    assert L.nnhip_cumsimpson_fn_batch_f64(nn.Rhs.AFFINE_T, p(one), 2, None, 0, 1 << 40, 2 ** 31 - 1, 0, p(one), 100000, 0.01, None, C.byref(rows), 0) == ev
+    # workspace sizes of batches no device could hold: 0 ("invalid", like N < 0), not an overflowed product
+    assert L.nnhip_ode_adaptive_stream_workspace_bytes(1 << 40, 2 ** 31 - 1) == 0 and L.nnhip_ode_adaptive_stream_dense_workspace_bytes(1 << 40, 2 ** 31 - 1, 1) == 0
+    assert L.nnhip_ode_fixed_stream_dense_workspace_bytes(1 << 40, 2 ** 31 - 1) == 0 and L.nnhip_ode_solve_tspans_workspace_bytes(1 << 40, 2 ** 31 - 1) == 0
+    assert L.nnhip_ode_adaptive_stream_workspace_bytes(10 ** 6, 16) == 8 * (16 * 10 ** 6 + 3 * 10 ** 6) + 4 * 64 or L.nnhip_ode_adaptive_stream_workspace_bytes(10 ** 6, 16) > 8 * 19 * 10 ** 6
+    # the RCCL reassembly: its refusals carry a message on the multi-GPU entries' own channel
+    assert L.nnhip_allgather_states_f64_dev(2, None, None, 3, 0, None, None) == ev and b"allgather_states" in L.nnhip_multigpu_last_error()
