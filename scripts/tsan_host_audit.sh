@@ -37,6 +37,7 @@ run scenarios_3dev 3 python tests/fake_hip_scenarios.py
 STRESS_KNOBS="stream_graph=0" run stress_eager 1 python tests/fake_hip_thread_stress.py
 STRESS_KNOBS="stream_graph=1" run stress_graph 1 python tests/fake_hip_thread_stress.py
 STRESS_KNOBS="stream_graph=1" STRESS_TOGGLE_KNOBS=1 run stress_graph_knobs_toggled 1 python tests/fake_hip_thread_stress.py
+STRESS_KNOBS="stream_graph=1" STRESS_RELEASE=1 run stress_graph_release_between_rounds 1 python tests/fake_hip_thread_stress.py
 STRESS_KNOBS="stream_graph=0,adv_lean=1,adv_auto_poll=1,fp_contract=1" run stress_opt_in 1 python tests/fake_hip_thread_stress.py
 if [ "$SAN" != thread ]; then
   # the boundary's error behaviour: every entry of include/nnhip_ode.h with hostile arguments (tests/fake_hip_abi_arg_fuzz.py), one process per entry

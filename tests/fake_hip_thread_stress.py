@@ -77,6 +77,8 @@ def worker(k):
                 else:
                     raise AssertionError("an unknown integrator was accepted")
             s.synchronize()
+            if os.environ.get("STRESS_RELEASE"):   # a thread may drop its caches (and the process-wide idle contexts) whenever it likes, others in mid-call or not
+                assert nn._lib.lib().nnhip_release() == 0
     except BaseException as exc:  # noqa: BLE001
         import traceback
         errors.append((k, traceback.format_exc()))
