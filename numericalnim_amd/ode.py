@@ -327,6 +327,16 @@ def _shape_info(y0, layout):
     return shp[0], shp[1], False
 
 
+def _require_state(name, x, like=None):
+    """A device batch handed to a per-step seam: a float64 tensor on a HIP device (the kernels read 8 bytes per value from the pointer they are given — a float32
+    or CPU tensor would be misread, not converted), and — for a companion of `like` (FSAL, scratch) — of the same shape on the same device."""
+    import torch
+    if not _is_torch(x) or not x.is_cuda or x.dtype != torch.float64:
+        raise ValueError(f"{name} must be a float64 tensor on a CUDA/HIP device")
+    if like is not None and (tuple(x.shape) != tuple(like.shape) or x.device != like.device):
+        raise ValueError(f"{name} must have y's shape {tuple(like.shape)} and live on y's device")
+
+
 def _params_array(f, ctx, like=None):
     """like: the state batch of the call (its device is where a context block has to live)"""
     if getattr(f, "ctx_layout", None) is not None:
@@ -482,7 +492,7 @@ def solveODE(f, y0, tspan, options=None, ctx=None, integrator="dopri54", layout=
                 raise ValueError('sort_by must be an array of shape [N] or "auto"')
             _check(L.nnhip_ode_solve_batch_sorted_f64(C.byref(options), integ, f.kind, pp, int(p.size), swh, kh, y0c.ctypes.data, N, dim, layout, tsp, n_t, tp,
                                                       y.ctypes.data, ny.ctypes.data if return_counts else None, st.ctypes.data if return_counts else None,
-                                                      rj.ctypes.data if return_counts else None, int(max_steps), keyh, 0, 0))
+                                                      rj.ctypes.data if return_counts else None, int(max_steps), keyh, int(probe_steps), 0))
             t = t_out[:ntout.value].copy()
             return (t, y, dict(ny=ny, steps=st, rejected=rj)) if return_counts else (t, y)
         _check(L.nnhip_ode_solve_batch_sweep_f64(C.byref(options), integ, f.kind, pp, int(p.size), swh, kh, y0c.ctypes.data, N, dim, layout, tsp,
@@ -506,6 +516,9 @@ def integratorStep(f, t, y, FSAL, dt, options=None, ctx=None, integrator="dopri5
     L = _lib.lib()
     options = options if options is not None else _default_options()
     integ, use_fsal, adaptive = _integ_info(integrator)
+    _require_state("y", y)
+    if FSAL is not None:
+        _require_state("FSAL", FSAL, y)
     p, pp = _params_array(f, ctx, y)
     N, dim, scalar = _shape_info(y, layout)
     yc = y if y.is_contiguous() else y.contiguous()
@@ -522,6 +535,9 @@ def integratorStep(f, t, y, FSAL, dt, options=None, ctx=None, integrator="dopri5
         fs_new = (o[1] if o[1] is not None else torch.empty_like(yc)) if (use_fsal or FSAL is not None) else None
         t_dev = t.contiguous() if (_is_torch(t) and t.is_cuda) else None
         dt_dev = dt.contiguous() if (_is_torch(dt) and dt.is_cuda) else None
+        for nm, v in (("t", t_dev), ("dt", dt_dev)):
+            if v is not None and (v.dtype != torch.float64 or v.dim() != 1 or v.shape[0] != N or v.device != yc.device):
+                raise ValueError(f"{nm} must be a Python float or a float64 tensor [N] on y's device")
         # host scalars that are not Python floats (np.float32, np.int64, 0-d arrays, 0-d CPU tensors): ctypes refuses them
         if t_dev is None and type(t) is not float:
             t = float(t)
@@ -554,10 +570,15 @@ def fixedStream(f, y, t0, tEnd, options=None, ctx=None, integrator="rk4", layout
     L = _lib.lib()
     options = options if options is not None else _default_options()
     integ = integrator_id(integrator)
+    _require_state("y", y)
     p, pp = _params_array(f, ctx, y)
     N, dim, scalar = _shape_info(y, layout)
     if not y.is_contiguous():
         raise ValueError("y must be contiguous (it is updated in place)")
+    if scratch is not None:
+        _require_state("scratch", scratch, y)
+        if not scratch.is_contiguous() or scratch.data_ptr() == y.data_ptr():
+            raise ValueError("scratch must be a contiguous tensor of its own (the ping-pong partner of y)")
     nsteps = C.c_int64(0)
     yfin = C.c_void_p(0)
     with torch.cuda.device(y.device):
@@ -580,6 +601,7 @@ def solveODEPerIvpEnd(f, y0, t_end, options=None, ctx=None, integrator="dopri54"
     L = _lib.lib()
     options = options if options is not None else _default_options()
     integ = integrator_id(integrator)
+    _require_state("y0", y0)
     p, pp = _params_array(f, ctx, y0)
     N, dim, scalar = _shape_info(y0, layout)
     y0c = y0.contiguous()
@@ -620,6 +642,7 @@ def solveODEPerIvpTspan(f, y0, tspans, options=None, ctx=None, integrator="dopri
     L = _lib.lib()
     options = options if options is not None else _default_options()
     integ = integrator_id(integrator)
+    _require_state("y0", y0)
     p, pp = _params_array(f, ctx, y0)
     N, dim, scalar = _shape_info(y0, layout)
     y0c = y0.contiguous()
@@ -744,6 +767,7 @@ def fixedStreamSolve(f, y0, tspan, options=None, ctx=None, integrator="rk4", lay
     L = _lib.lib()
     options = options if options is not None else _default_options()
     integ = integrator_id(integrator)
+    _require_state("y0", y0)
     p, pp = _params_array(f, ctx, y0)
     N, dim, scalar = _shape_info(y0, layout)
     tspan = np.ascontiguousarray(np.asarray(tspan, dtype=np.float64))
@@ -780,6 +804,7 @@ def adaptiveStreamSolve(f, y0, tspan, options=None, ctx=None, integrator="dopri5
     L = _lib.lib()
     options = options if options is not None else _default_options()
     integ = integrator_id(integrator)
+    _require_state("y0", y0)
     p, pp = _params_array(f, ctx, y0)
     N, dim, scalar = _shape_info(y0, layout)
     tspan = np.ascontiguousarray(np.asarray(tspan, dtype=np.float64))
@@ -818,6 +843,7 @@ def adaptiveStream(f, y, t0, tEnd, options=None, ctx=None, integrator="dopri54",
     L = _lib.lib()
     options = options if options is not None else _default_options()
     integ = integrator_id(integrator)
+    _require_state("y", y)
     p, pp = _params_array(f, ctx, y)
     N, dim, scalar = _shape_info(y, layout)
     if not y.is_contiguous():

@@ -41,6 +41,7 @@ _FIRST_CONTACT = (
     "test_gpu_bench_contract.py::test_more_rccl_ranks_than_devices_is_refused",
     "test_gpu_reference_text_quad.py::",
     "test_gpu_hermite_consumer.py::test_descending_abscissae_are_sorted_like_the_reference",
+    "test_gpu_rk4_parity.py::test_per_step_seams_refuse_companions_they_would_misread",
 )
 
 

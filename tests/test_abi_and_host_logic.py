@@ -345,3 +345,16 @@ def test_hostile_arguments_get_an_error_code_before_anything_is_touched(nn):
     assert L.nnhip_ode_adaptive_stream_workspace_bytes(10 ** 6, 16) == 8 * (16 * 10 ** 6 + 3 * 10 ** 6) + 4 * 64 or L.nnhip_ode_adaptive_stream_workspace_bytes(10 ** 6, 16) > 8 * 19 * 10 ** 6
     # the RCCL reassembly: its refusals carry a message on the multi-GPU entries' own channel
     assert L.nnhip_allgather_states_f64_dev(2, None, None, 3, 0, None, None) == ev and b"allgather_states" in L.nnhip_multigpu_last_error()
+
+
+def test_per_step_seams_refuse_tensors_they_would_misread(nn):
+    """The per-step seams take device pointers: a CPU tensor, a float32 tensor or a numpy array handed to them would be MISREAD by the kernels (8 bytes per value
+    from whatever address), not converted.  The Python mirror refuses them before the library is called (checkable without a GPU: the refusal comes first)."""
+    import torch
+    f = nn.Rhs.neg_y()
+    for bad in (torch.ones(8, dtype=torch.float64), torch.ones(8, dtype=torch.float32), np.ones(8)):
+        for call in (lambda y: nn.fixedStream(f, y, 0.0, 1.0), lambda y: nn.adaptiveStream(f, y, 0.0, 1.0), lambda y: nn.integratorStep(f, 0.0, y, None, 0.1),
+                     lambda y: nn.fixedStreamSolve(f, y, [0.0, 1.0]), lambda y: nn.adaptiveStreamSolve(f, y, [0.0, 1.0]),
+                     lambda y: nn.solveODEPerIvpEnd(f, y, y), lambda y: nn.solveODEPerIvpTspan(f, y, y)):
+            with pytest.raises(ValueError, match="float64 tensor on a CUDA/HIP device"):
+                call(bad)

@@ -311,3 +311,36 @@ def test_fixed_stream_dense_reports_truncation(nn, dev):
         warnings.simplefilter("always")
         t, y, ny, ns = nn.fixedStreamSolve(nn.Rhs.linear(-0.1), y0, ts, opt, integrator="rk4", max_steps=64)
     assert ns == 64 and not w
+
+
+def test_per_step_seams_refuse_companions_they_would_misread(nn, dev):
+    """On the device: a float32 state, an FSAL / scratch buffer of another shape, dtype or device, a 0-d or wrong-length (t, dt) tensor — each would make a kernel read or
+    write outside what it was given; the Python mirror refuses them (ValueError) and the well-formed call next to each still works."""
+    import torch
+    f = nn.Rhs.lorenz()
+    y = torch.ones((3, 64), dtype=torch.float64, device=dev)
+    opt = nn.newODEoptions(dt=2.0 ** -6)
+    for bad in (y.float(), y.cpu()):
+        with pytest.raises(ValueError, match="float64 tensor on a CUDA/HIP device"):
+            nn.integratorStep(f, 0.0, bad, None, 0.01, opt, integrator="rk4")
+        with pytest.raises(ValueError, match="float64 tensor on a CUDA/HIP device"):
+            nn.adaptiveStream(f, bad, 0.0, 0.1)
+    with pytest.raises(ValueError, match="FSAL must"):
+        nn.integratorStep(f, 0.0, y, y[:, :32].contiguous(), 0.01, opt, integrator="dopri54")
+    with pytest.raises(ValueError, match="FSAL must"):
+        nn.integratorStep(f, 0.0, y, y.float(), 0.01, opt, integrator="dopri54")
+    for bad_t in (torch.zeros((), dtype=torch.float64, device=dev), torch.zeros(63, dtype=torch.float64, device=dev), torch.zeros(64, dtype=torch.float32, device=dev)):
+        with pytest.raises(ValueError, match="Python float or a float64 tensor"):
+            nn.integratorStep(f, bad_t, y, None, 0.01, opt, integrator="rk4")
+        with pytest.raises(ValueError, match="Python float or a float64 tensor"):
+            nn.integratorStep(f, 0.0, y, None, bad_t, opt, integrator="rk4")
+    yy = torch.ones(1000, dtype=torch.float64, device=dev)
+    with pytest.raises(ValueError, match="scratch must"):
+        nn.fixedStream(nn.Rhs.neg_y(), yy, 0.0, 0.25, opt, scratch=torch.empty(999, dtype=torch.float64, device=dev))
+    with pytest.raises(ValueError, match="scratch must"):
+        nn.fixedStream(nn.Rhs.neg_y(), yy, 0.0, 0.25, opt, scratch=yy)
+    # the well-formed neighbours
+    r = nn.integratorStep(f, torch.zeros(64, dtype=torch.float64, device=dev), y, y.clone(), torch.full((64,), 0.01, dtype=torch.float64, device=dev), opt, integrator="dopri54")
+    assert r[0].shape == y.shape and bool(torch.isfinite(r[0]).all())
+    yf, ns = nn.fixedStream(nn.Rhs.neg_y(), yy, 0.0, 0.25, opt, scratch=torch.empty_like(yy))
+    assert ns == 16 and bool(torch.isfinite(yf).all())
