@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .ode import _check, _params_array, _shape_info, LAYOUT_SOA
+from .ode import _check, _params_array, _require_state, _shape_info, LAYOUT_SOA
 
 ExtrapolateKind = {"Constant": 0, "Edge": 1, "Linear": 2, "Native": 3, "Error": 4}  # interpolate.nim:89-90
 
@@ -14,6 +14,7 @@ ExtrapolateKind = {"Constant": 0, "Edge": 1, "Linear": 2, "Native": 3, "Error": 
 def rhsBatch(f, t, y, ctx=None, layout=LAYOUT_SOA):
     """dy = f(t, y) over a device batch (one RHS evaluation per IVP)."""
     import torch
+    _require_state("y", y)
     p, pp = _params_array(f, ctx)
     N, dim, _ = _shape_info(y, layout)
     yc = y.contiguous()
@@ -38,6 +39,8 @@ def sortAndTrimDataset(X, *Ys):
     own series).  Returns (X_sorted_trimmed, [Y_sorted_trimmed ...]); impure duplicates raise ValueError as in the reference."""
     import torch
     Xa = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
+    for k, y in enumerate(Ys):
+        _require_state("series %d" % k, y, Ys[0] if k else None)
     Ys = [y.contiguous() for y in Ys]
     if any(len(Xa) != y.shape[0] for y in Ys):
         raise ValueError("X and Y must have the same length")
@@ -71,6 +74,9 @@ class HermiteSpline:
             self.M = int(self.Y[0].size)
             return
         import torch
+        _require_state("Y", Y)
+        if dY is not None:
+            _require_state("dY", dY, Y)
         if len(self.X) > 1 and not bool(np.all(self.X[1:] > self.X[:-1])):   # sortAndTrimDataset(@X, @[@Y, @dY]) / (@X, @Y), once, here
             self.X, sorted_ = sortAndTrimDataset(self.X, *([Y] if dY is None else [Y, dY]))
             Y = sorted_[0]
@@ -180,6 +186,7 @@ def cumtrapz(Y, X, ctx=None, dx=1e-5, sweep=None, n=1, dim=1, device=None, layou
         dp = C.POINTER(C.c_double)
         _check(_lib.lib().nnhip_cumtrapz_batch_f64(Xa.ctypes.data_as(dp), len(Xa), Yh.ctypes.data_as(dp), int(Yh[0].size), outh.ctypes.data_as(dp), 0))
         return outh[:_dataset_rows(Xa)[0]]
+    _require_state("Y", Y)
     Yc = Y.contiguous()
     out = torch.empty_like(Yc)
     with torch.cuda.device(Yc.device):
@@ -207,6 +214,7 @@ def cumsimpson(Y, X, ctx=None, dx=1e-5, sweep=None, n=1, dim=1, device=None, lay
         dp = C.POINTER(C.c_double)
         _check(_lib.lib().nnhip_cumsimpson_batch_f64(Xa.ctypes.data_as(dp), len(Xa), Yh.ctypes.data_as(dp), int(Yh[0].size), outh.ctypes.data_as(dp), 0))
         return outh[:_dataset_rows(Xa)[1]]
+    _require_state("Y", Y)
     Yc = Y.contiguous()
     out = torch.empty_like(Yc)
     with torch.cuda.device(Yc.device):

@@ -358,3 +358,16 @@ def test_per_step_seams_refuse_tensors_they_would_misread(nn):
                      lambda y: nn.solveODEPerIvpEnd(f, y, y), lambda y: nn.solveODEPerIvpTspan(f, y, y)):
             with pytest.raises(ValueError, match="float64 tensor on a CUDA/HIP device"):
                 call(bad)
+
+
+def test_consumers_refuse_device_series_they_would_misread(nn):
+    """The same for the consumers of the path (cumtrapz / cumsimpson / newHermiteSpline / sortAndTrimDataset over device series): a float32 or CPU tensor is refused,
+    numpy series keep going to the host-pointer entries (which fail loudly without a GPU: no CPU fallback)."""
+    import torch
+    from numericalnim_amd import interpolate as ni
+    X = np.linspace(0.0, 1.0, 5)
+    for bad in (torch.ones((5, 4), dtype=torch.float64), torch.ones((5, 4), dtype=torch.float32)):
+        for call in (lambda Y: ni.cumtrapz(Y, X), lambda Y: ni.cumsimpson(Y, X), lambda Y: ni.HermiteSpline(X, Y), lambda Y: ni.sortAndTrimDataset(X[::-1].copy(), Y),
+                     lambda Y: ni.rhsBatch(nn.Rhs.neg_y(), 0.0, Y[0])):
+            with pytest.raises(ValueError, match="float64 tensor on a CUDA/HIP device"):
+                call(bad)
