@@ -163,6 +163,8 @@ int nnhip_host_free(void* p);
 /* Changing a knob drops the calling thread's hipGraph caches so that the new setting takes effect on its next call.  Knobs are process-wide atomics:
  * setting one while other host threads are inside the library is defined (no torn value; a call already running may finish under the old setting). */
 int nnhip_tune_set(const char* key, int value);
+/* The current value of a knob (the same keys; booleans as 0 / 1): what a scoped setter saves and restores. */
+int nnhip_tune_get(const char* key, int* value);
 /* Which instantiation of the headline kernel (rk4_stream_vec_kernel<RHS, NEG, VEC, MODE>) the scalar RK4 step entry launches for
  * `n_states` flat float64 states (in_place: y_out == y_in, else two buffers): the knobs above, or the automatic choice by working set.
  * Lets a profile be matched to the variant it was taken on (bench.py checks profiles/pmc_traffic.json's kernel name with it). */

@@ -8,7 +8,7 @@ call raises.
 """
 from .ode import (  # noqa: F401
     ODEoptions, newODEoptions, NumContext, newNumContext, Rhs, solveODE, integratorStep, fixedStream, fixedStreamSolve, adaptiveStream, adaptiveStreamSolve, solveODEPerIvpEnd, solveODEPerIvpTspan, solveODECalls, solveODECallsTspan,
-    fixedODE, adaptiveODE, allODE, implementedODE, LAYOUT_SOA, LAYOUT_AOS, NnhipError, hostLibmMatchesDevicePow, tuning,
+    fixedODE, adaptiveODE, allODE, implementedODE, LAYOUT_SOA, LAYOUT_AOS, NnhipError, hostLibmMatchesDevicePow, tuning, tuneGet,
 )
 from .interpolate import newHermiteSpline, HermiteSpline, rhsBatch, cumtrapz, cumsimpson, trapz, sortAndTrimDataset  # noqa: F401
 from . import _lib  # noqa: F401

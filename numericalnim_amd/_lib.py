@@ -36,6 +36,7 @@ SIGNATURES = {
     "nnhip_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_int64]),
     "nnhip_host_free": (C.c_int, [C.c_void_p]),
     "nnhip_tune_set": (C.c_int, [C.c_char_p, C.c_int]),
+    "nnhip_tune_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "nnhip_ode_rk4_stream_variant": (C.c_int, [C.c_int64, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nnhip_ode_new_options": (C.c_int, [C.POINTER(Options)] + [C.c_double] * 8),
     "nnhip_ode_default_options": (C.c_int, [C.POINTER(Options)]),

@@ -369,6 +369,22 @@ int nnhip_tune_set(const char* key, int value) {
   return fail(NNHIP_EVALUE, "unknown tuning key %s", key);
 }
 
+int nnhip_tune_get(const char* key, int* value) {
+  if (!key || !value) return fail(NNHIP_EVALUE, "key / value is NULL");
+  const std::string k(key);
+  static const struct { const char* name; const std::atomic<int>* knob; } kInt[] = {
+      {"host_chunks", &g_host_chunks}, {"host_register", &g_host_register}, {"fp_contract", &g_fast_math}, {"stream_graph", &g_stream_graph},
+      {"fixed_vec_ipl", &g_fixed_vec_ipl}, {"multi_gpu_oversubscribe", &g_mg_oversubscribe}, {"adv_recompute_fsal", &g_adv_refsal},
+      {"adv_nontemporal", &g_adv_nt}, {"adv_block", &g_adv_block}, {"sort_copy", &g_sort_copy}, {"adv_steps_per_launch", &g_adv_steps},
+      {"sort_auto_key", &g_sort_auto_key}, {"calls_bin", &g_calls_bin}, {"sort_rebin_steps", &g_sort_rebin_steps}, {"sort_resume", &g_sort_resume},
+      {"adv_auto_poll", &g_adv_auto_poll}, {"adv_lean", &g_adv_lean}, {"adv_split", &g_adv_split}, {"dim16_variant", &g_dim16_variant},
+      {"rk4_stream_vec", &g_tune_vec}, {"rk4_stream_mode", &g_tune_mode}, {"rk4_stream_blocks_per_cu", &g_tune_blocks_per_cu}};
+  for (const auto& e : kInt) if (k == e.name) { *value = e.knob->load(); return NNHIP_OK; }
+  if (k == "sort_min_spread_permille") { *value = (int)std::lround(g_sort_min_spread.load() * 1000.0); return NNHIP_OK; }
+  if (k == "rk4_stream_auto") { *value = g_tune_auto.load() ? 1 : 0; return NNHIP_OK; }
+  return fail(NNHIP_EVALUE, "unknown tuning key %s", key);
+}
+
 int nnhip_ode_new_options(nnhip_ode_options* out, double dt, double absTol, double relTol, double dtMax, double dtMin,
                           double scaleMax, double scaleMin, double tStart) {
   if (!out) return fail(NNHIP_EVALUE, "out is NULL");

@@ -860,41 +860,45 @@ def adaptiveStream(f, y, t0, tEnd, options=None, ctx=None, integrator="dopri54",
     return y, nl.value
 
 
-# library defaults of the tuning knobs this module's callers flip (include/nnhip_ode.h, nnhip_tune_set); `tuning` restores these
-_KNOB_DEFAULTS = {"adv_lean": 0, "adv_auto_poll": 0, "fp_contract": 0, "stream_graph": 2, "adv_steps_per_launch": 1, "calls_bin": 1,
-                  "adv_recompute_fsal": -1, "adv_nontemporal": -1, "adv_block": 0, "adv_split": 0}
-
-
-_KNOB_STATE = dict(_KNOB_DEFAULTS)  # what `tuning` blocks have set (the library has no getter; direct nnhip_tune_set calls are not seen here)
-
-
 class tuning:
-    """with tuning(adv_lean=1, adv_auto_poll=1): ... — process-wide tuning knobs (nnhip_tune_set) for the duration of a block, then back to what they
-    were before it (blocks nest; outside any block: the library's defaults).  Opt-in settings of the adaptive streaming loop: adv_lean (its lean
-    kernels, same bits), adv_auto_poll (its own polling schedule when check_every <= 0), fp_contract (FMA-contracted kernels: within 1e-10 / 1e-6,
-    not the reference's bits)."""
+    """with tuning(adv_lean=1, adv_auto_poll=1): ... — process-wide tuning knobs (nnhip_tune_set) for the duration of a block, then back to what the LIBRARY says they
+    were before it (nnhip_tune_get: a knob set by a direct nnhip_tune_set call, or by another block, is restored to that value, not to a default).  Blocks nest.  Any key
+    of nnhip_tune_set is accepted.  Opt-in settings of the adaptive streaming loop: adv_lean (its lean kernels, same bits), adv_auto_poll (its own polling schedule when
+    check_every <= 0), fp_contract (FMA-contracted kernels: within 1e-10 / 1e-6, not the reference's bits)."""
 
     def __init__(self, **knobs):
-        unknown = [k for k in knobs if k not in _KNOB_DEFAULTS]
-        if unknown:
-            raise ValueError("tuning(): no default on record for " + ", ".join(unknown))
         self.knobs = knobs
-        self.before = {}
+        self.before = []
 
     def __enter__(self):
         L = _lib.lib()
-        for k, v in self.knobs.items():
-            self.before[k] = _KNOB_STATE[k]
-            _check(L.nnhip_tune_set(k.encode(), int(v)))
-            _KNOB_STATE[k] = int(v)
+        try:
+            for k, v in self.knobs.items():
+                old = C.c_int(0)
+                rc = L.nnhip_tune_get(k.encode(), C.byref(old))
+                if rc:
+                    raise ValueError("tuning(): " + _lib.last_error())
+                _check(L.nnhip_tune_set(k.encode(), int(v)))
+                self.before.append((k, old.value))
+        except Exception:
+            self.__exit__()
+            raise
         return self
 
     def __exit__(self, *exc):
         L = _lib.lib()
-        for k, v in self.before.items():
+        while self.before:  # in reverse: rk4_stream_vec / _mode switch the automatic choice off, rk4_stream_auto set earlier in the block must come back last
+            k, v = self.before.pop()
             L.nnhip_tune_set(k.encode(), v)
-            _KNOB_STATE[k] = v
         return False
+
+
+def tuneGet(key):
+    """The current value of a process-wide tuning knob (nnhip_tune_get)."""
+    v = C.c_int(0)
+    if _lib.lib().nnhip_tune_get(str(key).encode(), C.byref(v)):
+        raise ValueError(_lib.last_error())
+    return v.value
 
 
 def hostLibmMatchesDevicePow(n=20000, seed=1234):

@@ -225,11 +225,15 @@ def test_tune_set_validation(nn):
         assert L.nnhip_tune_set(key, bad) == -1, key
     for key, good, reset in ((b"rk4_stream_vec", 2, None), (b"rk4_stream_mode", 1, None), (b"rk4_stream_auto", 1, 1), (b"stream_graph", 1, 2),
                              (b"dim16_variant", 1, 0), (b"fp_contract", 1, 0), (b"host_chunks", 4, 0), (b"host_register", 1, 0),
-                             (b"adv_recompute_fsal", 0, -1), (b"adv_recompute_fsal", 1, -1), (b"adv_steps_per_launch", 5, 1), (b"adv_block", 128, 0), (b"adv_nontemporal", 1, -1), (b"adv_lean", 0, 1)):
+                             (b"adv_recompute_fsal", 0, -1), (b"adv_recompute_fsal", 1, -1), (b"adv_steps_per_launch", 5, 1), (b"adv_block", 128, 0), (b"adv_nontemporal", 1, -1), (b"adv_lean", 1, 0)):
         assert L.nnhip_tune_set(key, good) == 0, key
         if reset is not None:
             assert L.nnhip_tune_set(key, reset) == 0
     assert L.nnhip_tune_set(b"rk4_stream_auto", 1) == 0  # back to automatic variant selection
+    # what the library itself reports afterwards: the recorded configuration (this test once "reset" adv_lean to 1 — round 5's default — for the rest of the process)
+    for key, default in (("stream_graph", 2), ("dim16_variant", 0), ("fp_contract", 0), ("host_chunks", 0), ("host_register", 0), ("adv_recompute_fsal", -1),
+                         ("adv_steps_per_launch", 1), ("adv_block", 0), ("adv_nontemporal", -1), ("adv_lean", 0), ("adv_auto_poll", 0), ("rk4_stream_auto", 1)):
+        assert nn.tuneGet(key) == default, key
 
 
 def test_rtc_compiler_choice(nn):
@@ -296,17 +300,37 @@ def test_no_emulation_symbol_in_the_product_library():
 
 
 def test_tuning_blocks_nest_and_restore_what_was_set_before():
-    """nn.tuning(...) (the Python side of nnhip_tune_set): an inner block hands the knob back as the OUTER block set it, not at the library's default."""
+    """nn.tuning(...) (the Python side of nnhip_tune_set / nnhip_tune_get): an inner block hands the knob back as the OUTER block set it, a block hands back what a
+    direct nnhip_tune_set call had set — what the LIBRARY reports, not a default table; a refused value undoes the block's earlier knobs."""
     import numericalnim_amd as nn
-    from numericalnim_amd import ode
+    L = nn._lib.lib()
+    g = nn.tuneGet
+    assert (g("adv_auto_poll"), g("adv_lean"), g("fp_contract"), g("stream_graph"), g("adv_steps_per_launch")) == (0, 0, 0, 2, 1)   # the recorded configuration
     with nn.tuning(adv_auto_poll=1, adv_lean=1):
-        assert ode._KNOB_STATE["adv_auto_poll"] == 1
+        assert g("adv_auto_poll") == 1 and g("adv_lean") == 1
         with nn.tuning(adv_auto_poll=0):
-            assert ode._KNOB_STATE["adv_auto_poll"] == 0 and ode._KNOB_STATE["adv_lean"] == 1
-        assert ode._KNOB_STATE["adv_auto_poll"] == 1
-    assert ode._KNOB_STATE == ode._KNOB_DEFAULTS
-    with pytest.raises(ValueError):
-        nn.tuning(no_such_knob=1)
+            assert g("adv_auto_poll") == 0 and g("adv_lean") == 1
+        assert g("adv_auto_poll") == 1
+    assert g("adv_auto_poll") == 0 and g("adv_lean") == 0
+    assert L.nnhip_tune_set(b"calls_bin", 0) == 0            # set behind the context manager's back ...
+    with nn.tuning(calls_bin=1, sort_min_spread_permille=125):
+        assert g("calls_bin") == 1 and g("sort_min_spread_permille") == 125
+    assert g("calls_bin") == 0 and g("sort_min_spread_permille") == 50   # ... and handed back as it was
+    assert L.nnhip_tune_set(b"calls_bin", 1) == 0
+    with pytest.raises(ValueError, match="unknown tuning key"):
+        with nn.tuning(adv_lean=1, no_such_knob=1):
+            pass
+    assert g("adv_lean") == 0                                # the knob set before the refused one came back
+    with pytest.raises(ValueError, match="adv_block must be"):
+        with nn.tuning(adv_lean=1, adv_block=96):
+            pass
+    assert g("adv_lean") == 0 and g("adv_block") == 0
+    # the headline kernel's variant: pinning (vec, mode) switches the automatic choice off; the block restores all three
+    with nn.tuning(rk4_stream_auto=0, rk4_stream_vec=8, rk4_stream_mode=1):
+        assert (g("rk4_stream_auto"), g("rk4_stream_vec"), g("rk4_stream_mode")) == (0, 8, 1)
+    assert g("rk4_stream_auto") == 1
+    v = C.c_int(7)
+    assert L.nnhip_tune_get(None, C.byref(v)) == -1 and L.nnhip_tune_get(b"adv_lean", None) == -1 and L.nnhip_tune_get(b"nope", C.byref(v)) == -1 and v.value == 7
 
 
 def test_hostile_arguments_get_an_error_code_before_anything_is_touched(nn):
