@@ -55,4 +55,9 @@ if [ "$STAGE" = rest ] || [ "$STAGE" = all ]; then
   g++ -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -I /opt/rocm/include -I include tests/cpp/bench_c5.cpp -L numericalnim_amd/csrc -lnnhip_ode -L /opt/rocm/lib -lamdhip64 \
       -Wl,-rpath,$PWD/numericalnim_amd/csrc -Wl,-rpath,/opt/rocm/lib -o /tmp/bench_c5 && /tmp/bench_c5 --gpus 1 --steps 10 --warmup 2 --verify 2>/dev/null | grep "^{" > gpurun_out/r06_bench_c5_cpp.json
   tail -c 400 gpurun_out/r06_bench_divergence.json
+  # does this box's HIP runtime load zstd-compressed offload bundles (format version 2) of this library?  `make COMPRESS=1`: 44 MB -> 14 MB, opt-in until this says yes
+  rm -rf /tmp/nnc && mkdir -p /tmp/nnc/numericalnim_amd && cp -r numericalnim_amd/csrc /tmp/nnc/numericalnim_amd/csrc && cp -r include /tmp/nnc/include
+  (cd /tmp/nnc/numericalnim_amd/csrc && rm -f *.o libnnhip_ode.so && make COMPRESS=1 -j"$(nproc)" > /tmp/nnc/build.log 2>&1; ls -la libnnhip_ode.so) > gpurun_out/r06_compressed_build.txt 2>&1
+  NNHIP_LIB=/tmp/nnc/numericalnim_amd/csrc/libnnhip_ode.so timeout 300 python -c "import __graft_entry__ as g; g.smoke()" >> gpurun_out/r06_compressed_build.txt 2>&1; echo "smoke on the compressed build rc=$?" >> gpurun_out/r06_compressed_build.txt
+  tail -3 gpurun_out/r06_compressed_build.txt
 fi
