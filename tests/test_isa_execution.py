@@ -463,3 +463,29 @@ def test_write_the_dynamic_counts(G):
     committed = json.load(open(path))
     for key in ("streamed_c4", "streamed_c3"):
         assert committed["kernels"][key]["valu_per_wave"] == RESULTS[key]["valu_per_wave"], (key, "the committed counts are stale: rerun with NNHIP_WRITE_PROFILES=1")
+
+
+def test_workgroup_or_reduction_sees_every_row_of_the_wave(G, tmp_path):
+    """__syncthreads_or — the "anyone still integrating?" of every polled launch — as hipcc compiles it for gfx950: row_shl scans, then ONE `v_mov_b32_dpp ... wave_shl:1`
+    carries each row's result into its left neighbour, then row_mirror.  The interpreter once ran that wave-wide control as a plain move: a wave whose only active lane
+    sat in row 1 or 3 (lanes 16-31, 48-63) answered "nobody", and a heterogeneous batch on the ISA-backed node ended its polling loop while its slowest IVP was still
+    integrating (found through test_adaptive_dense_output_through_the_step_streaming_seam; the device code was right, round 4 passed it on hardware).  Every lane alone, one-wave
+    and four-wave workgroups, must be seen."""
+    if shutil.which("hipcc") is None:
+        pytest.skip("needs hipcc")
+    src = tmp_path / "wgor.hip"
+    src.write_text('#include <hip/hip_runtime.h>\nextern "C" __global__ void wg_or(unsigned int* out, int k) { const int any = __syncthreads_or(k >= 0 && (int)threadIdx.x == k);\n'
+                   '  if (threadIdx.x == 0) out[blockIdx.x] = any ? 1u : 0u; }\n')
+    obj = str(tmp_path / "wgor.o")
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-c", str(src), "-o", obj])
+    co = G.CodeObject(obj)
+    assert any("wave_shl:1" in i.mods for i in co.kernel("wg_or").ins), "the compiler no longer uses the wave-wide shift: this test no longer covers it"
+    k = co.kernel("wg_or")
+    M = G.Machine(co)
+    for block in (64, 256):
+        for lane in list(range(0, block, 5)) + [15, 16, 31, 32, 47, 48, 63, block - 1, -1]:
+            mem = G.Memory(co)
+            out = np.full(1, 7, dtype=np.uint32)
+            a = mem.alloc(out)
+            M.launch(k, (1,), (block,), struct.pack("<Qi", a, lane), mem)
+            assert out[0] == (1 if lane >= 0 else 0), (block, lane, int(out[0]))

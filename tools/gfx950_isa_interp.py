@@ -135,6 +135,9 @@ _MOD_RE = [
     ("bank_mask", re.compile(r"bank_mask:(0x[0-9a-f]+)")), ("bound_ctrl", re.compile(r"bound_ctrl:(\d)")), ("offset", re.compile(r"offset:(-?\d+)")),
     ("bitop3", re.compile(r"bitop3:(0x[0-9a-f]+|\d+)")), ("offset0", re.compile(r"offset0:(\d+)")), ("offset1", re.compile(r"offset1:(\d+)")), ("mul", re.compile(r"\bmul:(\d)")), ("div", re.compile(r"\bdiv:(\d)")),
 ]
+# every DPP control the decoder knows: an instruction carrying one of them goes through _dpp_fetch (round 6, second session: the four wave-wide controls were parsed as
+# flags but missing here, so `v_mov_b32_dpp ... wave_shl:1` — the cross-row step of __syncthreads_or's wave reduction — ran as a plain move and the reduction lost rows 1 and 3)
+_DPP_CTRL = ("quad_perm", "row_ror", "row_shr", "row_shl", "row_bcast", "row_mirror", "row_half_mirror", "wave_shr:1", "wave_shl:1", "wave_ror:1", "wave_rol:1")
 _FLAGS = ("clamp", "nt", "sc0", "sc1", "glc", "slc", "row_mirror", "row_half_mirror", "wave_shr:1", "wave_shl:1", "wave_ror:1", "wave_rol:1", "gds")
 
 
@@ -212,7 +215,7 @@ class Kernel:
 
 
 def classify(op, mods):
-    dpp = any(k in mods for k in ("quad_perm", "row_ror", "row_shr", "row_shl", "row_bcast", "row_mirror", "row_half_mirror"))
+    dpp = any(k in mods for k in _DPP_CTRL)
     if op.startswith(("v_readlane", "v_writelane", "v_readfirstlane")):
         return "valu_lane"
     if op.startswith("v_"):
@@ -533,6 +536,16 @@ def _dpp_source(w, mods):
         src = row | (15 - (lane & 15))
     elif "row_half_mirror" in mods:
         src = (lane & ~7) | (7 - (lane & 7))
+    elif "wave_shl:1" in mods:   # DPP_WF_SL1: lane i reads lane i + 1 of the WAVE (lane 63 has no source)
+        src = lane + 1
+        valid = src < LANES
+    elif "wave_shr:1" in mods:   # DPP_WF_SR1: lane i reads lane i - 1 (lane 0 has no source)
+        src = lane - 1
+        valid = src >= 0
+    elif "wave_rol:1" in mods:   # DPP_WF_RL1: rotate, lane i reads lane (i + 1) mod 64
+        src = (lane + 1) % LANES
+    elif "wave_ror:1" in mods:   # DPP_WF_RR1
+        src = (lane - 1) % LANES
     else:
         raise NotImplementedError("DPP control " + str(mods))
     return np.where(valid, src, lane), valid
@@ -796,7 +809,7 @@ def _v_mov_b32(w, i):
         w.wr_v32(dst, w.src32(src))
         return
     val = w.src32(i.ops[1])
-    if any(k in i.mods for k in ("quad_perm", "row_ror", "row_shr", "row_shl", "row_bcast", "row_mirror", "row_half_mirror")):
+    if any(k in i.mods for k in _DPP_CTRL):
         fetched, off = _dpp_fetch(w, val, i.mods)
         w.wr_v32(i.ops[0], fetched, w.mask() & ~off)
     else:
@@ -827,7 +840,7 @@ def _vop2_int(fn):
             return
         a = w.src32(i.ops[1])
         m = None
-        if any(k in i.mods for k in ("quad_perm", "row_ror", "row_shr", "row_shl", "row_bcast", "row_mirror", "row_half_mirror")):
+        if any(k in i.mods for k in _DPP_CTRL):
             a, off = _dpp_fetch(w, a, i.mods)
             m = w.mask() & ~off
         b = _vec(w.src32(i.ops[2]))
