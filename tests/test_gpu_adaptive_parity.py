@@ -1479,3 +1479,45 @@ def test_bin_order_spends_its_bins_on_the_keys_it_gets(nn, dev):
     o = order_of(keys)
     tail = ~np.isfinite(keys[o])
     assert tail.sum() == (~np.isfinite(keys)).sum() and tail[-tail.sum():].all()
+
+
+@pytest.mark.parametrize("family", ["tpi_scalar", "tpi_lorenz", "lps_ring16"])
+def test_polled_launches_see_a_lone_straggler_in_every_row_of_a_wave(nn, dev, family):
+    """The polling loop's "anyone still integrating?" is a workgroup OR over `stillActive` (__syncthreads_or: row scans, one wave-wide shift, a row mirror, LDS across waves).
+    A batch in which ONE member needs at least twice the steps of all the others leaves, for most of the loop, a single active lane — here placed in every row of its wave
+    (lanes 0-15 / 16-31 / 32-47 / 48-63), in the first and in a later workgroup.  If the reduction lost a row the loop would end while the straggler is still integrating: every
+    driver (general and lean advance kernels, the dense driver; polling after every launch and in groups of 3) must return the fused solve's bits.  (Written after the ISA
+    interpreter of the CPU suite turned out to drop rows 1 and 3 — tools/gfx950_isa_interp.py, wave_shl:1 — which this repository's homogeneous BASELINE batches never exercised.)"""
+    import torch
+    opt = nn.newODEoptions(absTol=1e-9, relTol=1e-9, dtMin=1e-9, dtMax=0.5)
+    if family == "tpi_scalar":
+        f, layout, n = nn.Rhs.linear(-3.0), 0, 150
+        base = np.full(n, 1e-13)                      # far below absTol / relTol: the controller lets these run at dtMax
+        big = lambda a, k: a.__setitem__(k, 1.0)     # noqa: E731
+        positions = (0, 17, 38, 63, 64 + 20, 128 + 21)
+    elif family == "tpi_lorenz":
+        f, layout, n = nn.Rhs.lorenz(), 0, 90
+        base = np.full((3, n), 1e-13)
+        big = lambda a, k: a.__setitem__((slice(None), k), [1.0, 1.0, 25.0])   # noqa: E731
+        positions = (5, 16, 47, 60, 64 + 18)
+    else:   # 4 lanes per system: a 256-lane workgroup holds 64 systems, a wave 16 of them; system k sits in row (k % 16) // 4 of wave (k % 64) // 16
+        f, layout, n = nn.Rhs.ring(0.9), 1, 80
+        base = np.full((n, 16), 1e-13)
+        big = lambda a, k: a.__setitem__(k, 1.0 + np.arange(16) / 4.0)         # noqa: E731
+        positions = (1, 6, 10, 15, 16 + 5, 48 + 14, 64 + 7)
+    for k in positions:
+        y0h = base.copy()
+        big(y0h, k)
+        y0 = torch.from_numpy(y0h).to(dev)
+        tf, yf, cnt = nn.solveODE(f, y0, [0.0, 2.0], opt, integrator="tsit54", layout=layout, return_counts=True)
+        steps = cnt["steps"].cpu().numpy()
+        assert steps[k] >= 2 * np.delete(steps, k).max(), (family, k, int(steps[k]), int(np.delete(steps, k).max()))   # the batch has the shape this test is about: the straggler integrates alone for half the loop or more
+        for ce in (1, 3):
+            ys, launches = nn.adaptiveStream(f, y0.clone(), 0.0, 2.0, opt, integrator="tsit54", layout=layout, check_every=ce)
+            assert torch.equal(ys, yf[-1]) and launches >= int(steps[k]), (family, k, ce, "general", launches, int(steps[k]))
+            with nn.tuning(adv_lean=1):
+                yl, ll = nn.adaptiveStream(f, y0.clone(), 0.0, 2.0, opt, integrator="tsit54", layout=layout, check_every=ce)
+            assert torch.equal(yl, yf[-1]) and ll >= int(steps[k]), (family, k, ce, "lean", ll, int(steps[k]))
+            ts = [0.0, 0.7, 2.0]
+            t2, yd, ny, ld = nn.adaptiveStreamSolve(f, y0, ts, opt, integrator="tsit54", layout=layout, check_every=ce)
+            assert torch.equal(yd, nn.solveODE(f, y0, ts, opt, integrator="tsit54", layout=layout)[1]), (family, k, ce, "dense")
