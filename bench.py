@@ -13,7 +13,8 @@ Usage: python bench.py --gpus N --steps K --warmup W
   N>1 either way: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (the launcher's RANK /
   LOCAL_RANK / WORLD_SIZE are used), or plain `python bench.py --gpus N ...` — with WORLD_SIZE unset bench.py starts its own N ranks
   through torch.distributed.run on 127.0.0.1 (a free port) and rank 0's line is the output.  --gpus != WORLD_SIZE is an error.
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  (Informational legs that go through settings without a hardware record — the opt-in lean / auto-poll / FMA-contracted
+streamed kernels — are measured in a child process, `bench.py --child-leg streamed_opt_in`, under a timeout: see streamed_opt_in_parent.)
 """
 import argparse
 import json
